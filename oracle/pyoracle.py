@@ -1,0 +1,147 @@
+"""ctypes binding of the CPU oracle (oracle/libpm_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (openmvs_amd/) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OrcView(C.Structure):
+    _fields_ = [("image", C.POINTER(C.c_float)), ("w", C.c_int), ("h", C.c_int),
+                ("K", C.c_double * 9), ("R", C.c_double * 9), ("C", C.c_double * 3),
+                ("depth", C.POINTER(C.c_float)),
+                ("Kd", C.c_double * 9), ("Rd", C.c_double * 9), ("Cd", C.c_double * 3)]
+
+
+class OrcOpt(C.Structure):
+    _fields_ = [("nSubResolutionLevels", C.c_uint32), ("nEstimationIters", C.c_uint32),
+                ("nEstimationGeometricIters", C.c_uint32), ("nRandomIters", C.c_uint32),
+                ("fEstimationGeometricWeight", C.c_float), ("fRandomDepthRatio", C.c_float),
+                ("fRandomAngle1Range", C.c_float), ("fRandomAngle2Range", C.c_float),
+                ("fRandomSmoothDepth", C.c_float), ("fRandomSmoothNormal", C.c_float),
+                ("fRandomSmoothBonus", C.c_float), ("fNCCThresholdKeep", C.c_float),
+                ("fDescriptorMinMagnitudeThreshold", C.c_float),
+                ("seed", C.c_uint32), ("viewID", C.c_uint32), ("rngMode", C.c_int32), ("nThreads", C.c_int32)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libpm_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("pm_oracle.cpp", "sgm_oracle.cpp")] + \
+           [os.path.join(_HERE, "..", "openmvs_amd", "csrc", "pm_math.h")]
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s))
+    if stale and all(os.path.exists(s) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libpm_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_estimate_depth_map.restype = C.c_int
+        _LIB.orc_score_pixel.restype = C.c_int
+    return _LIB
+
+
+def default_opt(**kw) -> OrcOpt:
+    o = OrcOpt()
+    lib().orc_default_opt(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def make_views(gray, K, R, Cc, ids, depth_maps=None):
+    """ids[0] = reference view, ids[1:] = sources.  depth_maps: optional dict id -> [H,W] float32."""
+    keep = []
+    arr = (OrcView * len(ids))()
+    for n, i in enumerate(ids):
+        img = np.ascontiguousarray(gray[i], np.float32); keep.append(img)
+        v = arr[n]
+        v.image = _fp(img); v.h, v.w = img.shape
+        v.K[:] = np.asarray(K[i], np.float64).ravel(); v.R[:] = np.asarray(R[i], np.float64).ravel(); v.C[:] = np.asarray(Cc[i], np.float64).ravel()
+        if n > 0 and depth_maps is not None:
+            d = np.ascontiguousarray(depth_maps[i], np.float32); keep.append(d)
+            v.depth = _fp(d)
+            v.Kd[:] = v.K[:]; v.Rd[:] = v.R[:]; v.Cd[:] = v.C[:]
+    return arr, keep
+
+
+def estimate_depth_map(views, n_views, dmin, dmax, opt: OrcOpt, geo_iter: int = -1,
+                       depth=None, normal=None, stages: bool = False):
+    """One DepthMapsData::EstimateDepthMap call.  Returns (depth, normal, conf[, stage list])."""
+    h, w = views[0].h, views[0].w
+    depth = np.zeros((h, w), np.float32) if depth is None else np.ascontiguousarray(depth, np.float32).copy()
+    normal = np.zeros((h, w, 3), np.float32) if normal is None else np.ascontiguousarray(normal, np.float32).copy()
+    conf = np.zeros((h, w), np.float32)
+    dump = None; cap = 0; used = C.c_size_t(0)
+    if stages:
+        cap = int((4 + h * w * 5) * 24)
+        dump = np.zeros(cap, np.float32)
+    rc = lib().orc_estimate_depth_map(views, C.c_int(n_views), _fp(depth), _fp(normal), _fp(conf),
+                                      C.c_float(dmin), C.c_float(dmax), C.byref(opt), C.c_int(geo_iter),
+                                      _fp(dump) if stages else None, C.c_size_t(cap), C.byref(used))
+    if rc != 0:
+        raise RuntimeError(f"orc_estimate_depth_map failed: {rc}")
+    if not stages:
+        return depth, normal, conf
+    out = []; p = 0
+    while p < used.value:
+        lvl, it, sw, sh = (int(dump[p + k]) for k in range(4)); n = sw * sh
+        out.append(dict(level=lvl, iter=it, depth=dump[p + 4:p + 4 + n].reshape(sh, sw).copy(),
+                        normal=dump[p + 4 + n:p + 4 + 4 * n].reshape(sh, sw, 3).copy(),
+                        cost=dump[p + 4 + 4 * n:p + 4 + 5 * n].reshape(sh, sw).copy()))
+        p += 4 + 5 * n
+    return depth, normal, conf, out
+
+
+def score_pixel(views, n_views, opt: OrcOpt, x, y, depth, normal, prior=None):
+    sc = np.zeros(n_views - 1, np.float32); agg = C.c_float(0)
+    nrm = np.ascontiguousarray(normal, np.float32)
+    pr = None if prior is None else np.ascontiguousarray(prior, np.float32)
+    rc = lib().orc_score_pixel(views, C.c_int(n_views), C.byref(opt), C.c_int(x), C.c_int(y), C.c_float(depth), _fp(nrm),
+                               _fp(pr) if pr is not None else None, _fp(sc), C.byref(agg))
+    return rc, sc, agg.value
+
+
+def zigzag(w, h, raw_stride=64):
+    out = np.zeros((w * h, 2), np.uint16)
+    lib().orc_zigzag(C.c_int(w), C.c_int(h), C.c_int(raw_stride), out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return out
+
+
+def resize_area(img, f):
+    img = np.ascontiguousarray(img, np.float32); h, w = img.shape
+    o = np.zeros((h // f, w // f), np.float32)
+    lib().orc_resize_area(_fp(img), C.c_int(w), C.c_int(h), C.c_int(f), _fp(o)); return o
+
+
+def resize_linear(img, nw, nh):
+    img = np.ascontiguousarray(img, np.float32); h, w = img.shape
+    o = np.zeros((nh, nw), np.float32)
+    lib().orc_resize_linear(_fp(img), C.c_int(w), C.c_int(h), C.c_int(nw), C.c_int(nh), _fp(o)); return o
+
+
+def resize_nearest(img, nw, nh):
+    img = np.ascontiguousarray(img, np.float32); h, w = img.shape
+    o = np.zeros((nh, nw), np.float32)
+    lib().orc_resize_nearest(_fp(img), C.c_int(w), C.c_int(h), C.c_int(nw), C.c_int(nh), _fp(o)); return o
+
+
+def math_eval(kind, a, b=None):
+    a = np.ascontiguousarray(a, np.float32); b = a if b is None else np.ascontiguousarray(b, np.float32)
+    o = np.zeros_like(a)
+    lib().orc_math_eval(C.c_int(kind), _fp(a), _fp(b), _fp(o), C.c_size_t(a.size)); return o

@@ -1,0 +1,152 @@
+/* pmhip.h -- C ABI of the MI355X-native PatchMatch depth-map engine (libpmhip.so).
+ *
+ * Drop-in boundary: the reference dispatches every depth-map estimation through
+ *     if (pmCUDA) { pmCUDA->EstimateDepthMap(arrDepthData[idxImage]); return true; }
+ * (libs/MVS/SceneDensify.cpp:618-623); the plug-in object has four methods
+ * (libs/MVS/PatchMatchCUDA.inl:102-108): ctor(device), Init(bGeomConsistency), Release(),
+ * EstimateDepthMap(DepthData&), and is created / re-initialised at
+ * libs/MVS/SceneDensify.cpp:1872-1881 and :1910-1916.  Section 1 mirrors exactly that surface
+ * with plain pointers and sizes.  Section 2 is the HBM-resident scene interface the reference
+ * reaches through files (depthNNNN.dmap written per view and re-read by the geometric rounds,
+ * libs/MVS/SceneDensify.cpp:378-414,2095-2117): all images, cameras and depth maps stay on the
+ * device and many reference views are estimated concurrently -- this is what fills the GPU.
+ *
+ * Algorithm = the reference's *CPU* estimator (libs/MVS/DepthMap.cpp:415-971 driven by
+ * libs/MVS/SceneDensify.cpp:490-805), not its CUDA variant; see DESIGN.md.
+ * All functions return 0 on success, a negative PMHIP_E_* code otherwise; none ever exits.
+ * A handle is single-caller (the reference serialises calls with a semaphore,
+ * SceneDensify.cpp:2041-2059) but may be used from different host threads sequentially.
+ */
+#ifndef PMHIP_H_
+#define PMHIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMHIP_MAX_SOURCES 16 /* >= OPTDENSE::nMaxViews (12), libs/MVS/DepthMap.cpp:76 */
+
+enum {
+	PMHIP_OK = 0,
+	PMHIP_E_ARG = -1,      /* bad argument */
+	PMHIP_E_SIZE = -2,     /* image size not divisible by 2^nSubResolutionLevels or views differ in size */
+	PMHIP_E_HIP = -3,      /* HIP runtime error (see pmhip_last_error) */
+	PMHIP_E_STATE = -4,    /* call out of order (e.g. estimate before init) */
+	PMHIP_E_NODEVICE = -5  /* no usable GPU: the adapter falls back like SceneDensify.cpp:1876-1877 */
+};
+
+typedef struct pmhip_engine pmhip_engine;
+
+/* OPTDENSE subset consumed by the estimator; defaults = libs/MVS/DepthMap.cpp:69-114. */
+typedef struct PMHipParams {
+	uint32_t nSubResolutionLevels;      /* 2 */
+	uint32_t nEstimationIters;          /* 3 */
+	uint32_t nEstimationGeometricIters; /* 2 (only decides the finalize threshold x1.333, SceneDensify.cpp:774-776) */
+	uint32_t nRandomIters;              /* 6 */
+	float fEstimationGeometricWeight;   /* 0.1 */
+	float fRandomDepthRatio;            /* 0.003 */
+	float fRandomAngle1Range;           /* 16 deg */
+	float fRandomAngle2Range;           /* 10 deg */
+	float fRandomSmoothDepth;           /* 0.02 */
+	float fRandomSmoothNormal;          /* 13 deg */
+	float fRandomSmoothBonus;           /* 0.93 */
+	float fNCCThresholdKeep;            /* 0.9 */
+	float fDescriptorMinMagnitudeThreshold; /* 0.02 */
+	uint32_t seed;                      /* counter-based RNG seed (the reference seeds from random_device) */
+} PMHipParams;
+
+/* DepthData::ViewData (libs/MVS/DepthMap.h:158-205) as plain data; images are contiguous
+ * row-major float gray in [0,1] (cv::Mat1f), cameras are x_cam = R (X - C). */
+typedef struct PMHipView {
+	const float* image;       /* host pointer, w*h floats */
+	int32_t w, h;
+	double K[9], R[9], C[3];
+	const float* depth;       /* nullable; known depth-map of this source view => geometric pass */
+	double Kd[9], Rd[9], Cd[3]; /* camera stored with that depth-map (cameraDepthMap) */
+	uint32_t id;              /* global view ID (mixed into the RNG key for views[0]) */
+} PMHipView;
+
+/* DepthData (libs/MVS/DepthMap.h:157-271): views[0] is the reference view. depthMap/normalMap
+ * are in/out (zero depth / zero normal == "unset", randomised in the init pass exactly like
+ * ScoreDepthMapTmp, SceneDensify.cpp:505-512); confMap is out ([0,1], 1 best); all caller-owned. */
+typedef struct PMHipDepthData {
+	const PMHipView* views;
+	int32_t nViews;           /* 1 + number of source views, 2..1+PMHIP_MAX_SOURCES */
+	float* depthMap;          /* w*h */
+	float* normalMap;         /* w*h*3, camera space */
+	float* confMap;           /* w*h */
+	float dMin, dMax;
+} PMHipDepthData;
+
+/* ---- 1. PatchMatchCUDA-shaped interface -------------------------------------------------- */
+int pmhip_default_params(PMHipParams* p);
+/* PatchMatchCUDA::PatchMatchCUDA(int device), PatchMatchCUDA.cpp:46-51 */
+int pmhip_create(int device, pmhip_engine** out);
+/* PatchMatchCUDA::~PatchMatchCUDA, PatchMatchCUDA.cpp:53-56 */
+void pmhip_destroy(pmhip_engine* e);
+/* PatchMatchCUDA::Init(bool bGeomConsistency), PatchMatchCUDA.cpp:97-106 */
+int pmhip_init(pmhip_engine* e, int bGeomConsistency);
+/* PatchMatchCUDA::Release(), PatchMatchCUDA.cpp:58-81 */
+int pmhip_release(pmhip_engine* e);
+/* PatchMatchCUDA::EstimateDepthMap(DepthData&), PatchMatchCUDA.cpp:174-416; semantics of
+ * DepthMapsData::EstimateDepthMap(idx, nGeometricIter), SceneDensify.cpp:616-805:
+ * nGeometricIter < 0 -> photometric pass over the pyramid; >= 0 -> that geometric round
+ * (requires pmhip_init(e,1) and views[1..].depth). Blocking. */
+int pmhip_estimate_depth_map(pmhip_engine* e, PMHipDepthData* dd, const PMHipParams* p, int nGeometricIter);
+const char* pmhip_last_error(pmhip_engine* e);
+
+/* ---- 2. HBM-resident scene interface ------------------------------------------------------ */
+/* Allocate device storage for nImages views of w x h (image pyramids, depth/normal/conf maps,
+ * the previous-round depth snapshot).  Replaces Scene images + depthNNNN.dmap files. */
+int pmhip_scene_create(pmhip_engine* e, int nImages, int w, int h, int nLevels);
+/* Upload (onDevice == 0) or adopt-by-copy (onDevice != 0, device pointer) one view.
+ * neighbors: global IDs of its source views, best first (ViewScore order, DepthMap.h:209). */
+int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevice,
+                         const double K[9], const double R[9], const double C[3],
+                         float dMin, float dMax, const int32_t* neighbors, int nNeighbors);
+/* Estimate the depth maps of viewIds[0..nViews) concurrently (one EstimateDepthMap per view,
+ * SceneDensify.cpp:616-805).  nGeometricIter < 0: photometric; >= 0: geometric round reading the
+ * snapshot taken by pmhip_scene_commit_round.  Asynchronous on the engine stream unless sync != 0. */
+int pmhip_scene_estimate(pmhip_engine* e, const int32_t* viewIds, int nViews, const PMHipParams* p,
+                         int nGeometricIter, int sync);
+/* End of a round: snapshot depth maps of all views as the "saved .dmap" the next geometric round
+ * reads (the reference renames depthNNNN.geo.dmap -> .dmap, SceneDensify.cpp:1943-1950). */
+int pmhip_scene_commit_round(pmhip_engine* e);
+/* Clear a view's maps to "unset" (InitViews with an empty point cloud, SceneDensify.cpp:417-425). */
+int pmhip_scene_reset_view(pmhip_engine* e, int idx);
+/* Provide an initial depth/normal estimate (host pointers, nullable each). */
+int pmhip_scene_set_maps(pmhip_engine* e, int idx, const float* depth, const float* normal);
+/* Download maps (any pointer may be NULL). */
+int pmhip_scene_get_maps(pmhip_engine* e, int idx, float* depth, float* normal, float* conf);
+/* Device pointers for collectives (RCCL all-gather of the snapshot / broadcast of images).
+ * what: 0 image level 0, 1 depth, 2 normal, 3 conf, 4 snapshot depth.  The per-kind arrays are
+ * single contiguous allocations ordered by view index, so idx 0 addresses the whole set. */
+void* pmhip_scene_device_ptr(pmhip_engine* e, int what, int idx);
+/* Rebuild image pyramids after image level 0 was written through pmhip_scene_device_ptr. */
+int pmhip_scene_images_updated(pmhip_engine* e);
+int pmhip_sync(pmhip_engine* e);
+/* Engine stream (hipStream_t) so callers can bracket work with their own events. */
+void* pmhip_stream(pmhip_engine* e);
+
+/* Timing of the dominant kernel (the diagonal sweep) measured with HIP events on the engine
+ * stream since the last reset: number of launches, summed milliseconds, summed algorithmic bytes
+ * (SURVEY.md 8d model) and pixel-updates. */
+typedef struct PMHipKernelStats {
+	uint64_t sweepLaunches; double sweepMs; double sweepBytes; uint64_t sweepPixels;
+	uint64_t initLaunches; double initMs;
+} PMHipKernelStats;
+int pmhip_stats_reset(pmhip_engine* e, int enableEvents);
+int pmhip_stats_get(pmhip_engine* e, PMHipKernelStats* out);
+
+/* ---- 3. self-test hooks (used by tests/, no oracle involved) ------------------------------ */
+/* Evaluate csrc/pm_math.h on the device: kind 0 exp, 1 acos, 2 atan2(a,b), 3 sin, 4 cos, 5 sqrt, 6 a/b. */
+int pmhip_math_eval(pmhip_engine* e, int kind, const float* a, const float* b, float* out, size_t n);
+/* Device resampling kernels on host buffers: kind 0 area (factor f = arg), 1 linear x2, 2 nearest x2. */
+int pmhip_resize(pmhip_engine* e, int kind, const float* src, int w, int h, int arg, float* dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMHIP_H_ */

@@ -1,0 +1,62 @@
+"""Build the HIP shared libraries of the engine in-tree (hipcc, gfx950 only).
+
+`python -m openmvs_amd.build` or `openmvs_amd.build.build_all()`.  hipcc cross-compiles without a
+GPU; the resulting .so files sit next to this package (git-ignored, shipped to the GPU box).
+-ffp-contract=off and correctly rounded divide/sqrt are part of the numerical contract with the
+CPU oracle (see csrc/pm_math.h), not tuning knobs.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value"]
+
+LIBS = {
+    "libpmhip.so": (["pm_engine.hip"], ["pm_kernels.hip", "pm_math.h", "../../include/pmhip.h"]),
+    "libsgmhip.so": (["sgm_engine.hip"], ["sgm_kernels.hip", "../../include/sgmhip.h"]),
+}
+
+
+def lib_path(name: str) -> str:
+    return os.path.join(_HERE, name)
+
+
+def _stale(out: str, deps: list[str]) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(name: str, force: bool = False, verbose: bool = False) -> str | None:
+    srcs, deps = LIBS[name]
+    srcs_abs = [os.path.join(_CSRC, s) for s in srcs]
+    if not all(os.path.exists(s) for s in srcs_abs):
+        return None
+    out = lib_path(name)
+    if not force and not _stale(out, srcs_abs + [os.path.normpath(os.path.join(_CSRC, d)) for d in deps]):
+        return out
+    if not os.path.exists(HIPCC):
+        if os.path.exists(out):
+            return out  # GPU box without a compiler in PATH: use the shipped binary
+        raise RuntimeError("hipcc not found and %s is not built" % name)
+    cmd = [HIPCC] + FLAGS + srcs_abs + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=_CSRC)
+    return out
+
+
+def build_all(force: bool = False, verbose: bool = False) -> list[str]:
+    return [p for p in (build_lib(n, force, verbose) for n in LIBS) if p]
+
+
+if __name__ == "__main__":
+    for p in build_all(force=True, verbose=True):
+        print("built", p)

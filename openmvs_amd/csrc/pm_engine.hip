@@ -1,0 +1,599 @@
+// pm_engine.hip -- host side of libpmhip.so: the extern "C" boundary declared in include/pmhip.h.
+//
+// Mirrors the reference's GPU plug-in boundary (PatchMatchCUDA, libs/MVS/PatchMatchCUDA.inl:102-108)
+// and the pass structure of DepthMapsData::EstimateDepthMap (libs/MVS/SceneDensify.cpp:616-805):
+// per pyramid level {level hand-off, init-score pass, nEstimationIters sweeps}, then finalize.
+// Everything stays in HBM between passes; one stream; no host sync inside a call.
+#include "../../include/pmhip.h"
+#include "pm_kernels.hip"
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+namespace {
+
+#define HIPCHK(e, call) do { hipError_t _r = (call); if (_r != hipSuccess) { (e)->err = std::string(#call) + ": " + hipGetErrorString(_r); return PMHIP_E_HIP; } } while (0)
+
+struct SceneView {
+	double K[9], R[9], C[3];
+	float dMin = 0, dMax = 0;
+	int nNb = 0; int nb[PM_MAX_SRC];
+	uint32_t id = 0;
+	bool set = false;
+};
+
+// cv::Matx product convention (accumulate from 0, left to right)
+void mul33(const double* a, const double* b, double* c) {
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += a[i*3+k] * b[k*3+j]; c[i*3+j] = s; }
+}
+void mul31(const double* a, const double* v, double* c) {
+	for (int i = 0; i < 3; ++i) { double s = 0; for (int k = 0; k < 3; ++k) s += a[i*3+k] * v[k]; c[i] = s; }
+}
+void transp33(const double* a, double* t) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t[j*3+i] = a[i*3+j]; }
+// cv::Matx<double,3,3>::inv(): adjugate / determinant (OpenCV matx.hpp, Matx_FastInvOp<_Tp,3,3>)
+void inv33(const double* a, double* b) {
+	double d = a[0]*(a[4]*a[8] - a[7]*a[5]) - a[1]*(a[3]*a[8] - a[6]*a[5]) + a[2]*(a[3]*a[7] - a[6]*a[4]);
+	d = 1 / d;
+	b[0] = (a[4]*a[8] - a[5]*a[7]) * d; b[1] = (a[2]*a[7] - a[1]*a[8]) * d; b[2] = (a[1]*a[5] - a[2]*a[4]) * d;
+	b[3] = (a[5]*a[6] - a[3]*a[8]) * d; b[4] = (a[0]*a[8] - a[2]*a[6]) * d; b[5] = (a[2]*a[3] - a[0]*a[5]) * d;
+	b[6] = (a[3]*a[7] - a[4]*a[6]) * d; b[7] = (a[1]*a[6] - a[0]*a[7]) * d; b[8] = (a[0]*a[4] - a[1]*a[3]) * d;
+}
+// Camera::InvK, libs/MVS/Camera.h:176-185
+void invK(const double* K, double* o) {
+	for (int i = 0; i < 9; ++i) o[i] = (i % 4 == 0) ? 1.0 : 0.0;
+	o[0] = 1.0 / K[0]; o[4] = 1.0 / K[4]; o[2] = -K[2] * o[0]; o[5] = -K[5] * o[4];
+}
+// Camera::ScaleK(K, size, newSize), libs/MVS/Camera.h:160-170
+void scaleK(const double* K, int w, int h, int nw, int nh, double* o) {
+	const double sx = (double)nw / (double)w, sy = (double)nh / (double)h;
+	o[0] = K[0]*sx; o[1] = K[1]*sx; o[2] = (K[2]+0.5)*sx-0.5;
+	o[3] = 0;       o[4] = K[4]*sy; o[5] = (K[5]+0.5)*sy-0.5;
+	o[6] = 0; o[7] = 0; o[8] = 1;
+}
+
+} // namespace
+
+struct pmhip_engine {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool inited = false, geom = false;
+	std::string err;
+	// scene (HBM resident)
+	int nImages = 0, w = 0, h = 0, nLevels = 0; // nLevels = sub-resolution levels available (pyramid has nLevels+1 entries)
+	float* d_img[4] = {nullptr, nullptr, nullptr, nullptr};
+	float *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr, *d_snap = nullptr;
+	std::vector<SceneView> views;
+	bool pyramidDirty = true;
+	// batch scratch (grow only)
+	int batchCap = 0;
+	float* d_lvl[4] = {nullptr, nullptr, nullptr, nullptr}; // level l>=1: [batch][6][h_l*w_l]; level 0: prior [batch][h*w]
+	PMTask* d_tasks = nullptr; PMTask* h_tasks = nullptr;     // [4 levels][batchCap]
+	PMUpTask* d_ups = nullptr; PMUpTask* h_ups = nullptr;     // [4][batchCap]
+	// single-view interface staging
+	bool ownsSingle = false;
+	// stats
+	bool statsOn = false;
+	struct Ev { hipEvent_t a, b; int kind; };
+	std::vector<Ev> events;
+	PMHipKernelStats stats{};
+	int lw(int l) const { return w >> l; }
+	int lh(int l) const { return h >> l; }
+};
+
+static void freeScene(pmhip_engine* e) {
+	hipSetDevice(e->device);
+	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
+	if (e->d_depth) hipFree(e->d_depth); if (e->d_normal) hipFree(e->d_normal); if (e->d_conf) hipFree(e->d_conf); if (e->d_snap) hipFree(e->d_snap);
+	e->d_depth = e->d_normal = e->d_conf = e->d_snap = nullptr;
+	if (e->d_tasks) hipFree(e->d_tasks); if (e->h_tasks) hipHostFree(e->h_tasks);
+	if (e->d_ups) hipFree(e->d_ups); if (e->h_ups) hipHostFree(e->h_ups);
+	e->d_tasks = nullptr; e->h_tasks = nullptr; e->d_ups = nullptr; e->h_ups = nullptr;
+	e->batchCap = 0; e->nImages = 0; e->views.clear();
+}
+
+static int ensureBatch(pmhip_engine* e, int n) {
+	if (n <= e->batchCap) return 0;
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	for (int l = 0; l < 4; ++l) { if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
+	if (e->d_tasks) hipFree(e->d_tasks); if (e->h_tasks) hipHostFree(e->h_tasks);
+	if (e->d_ups) hipFree(e->d_ups); if (e->h_ups) hipHostFree(e->h_ups);
+	e->d_tasks = nullptr; e->h_tasks = nullptr; e->d_ups = nullptr; e->h_ups = nullptr;
+	const int cap = std::max(n, 1);
+	HIPCHK(e, hipMalloc(&e->d_lvl[0], sizeof(float) * (size_t)cap * e->w * e->h));
+	for (int l = 1; l <= e->nLevels; ++l)
+		HIPCHK(e, hipMalloc(&e->d_lvl[l], sizeof(float) * (size_t)cap * 6 * e->lw(l) * e->lh(l)));
+	HIPCHK(e, hipMalloc(&e->d_tasks, sizeof(PMTask) * 4 * cap));
+	HIPCHK(e, hipHostMalloc(&e->h_tasks, sizeof(PMTask) * 4 * cap));
+	HIPCHK(e, hipMalloc(&e->d_ups, sizeof(PMUpTask) * 4 * cap));
+	HIPCHK(e, hipHostMalloc(&e->h_ups, sizeof(PMUpTask) * 4 * cap));
+	e->batchCap = cap;
+	return 0;
+}
+
+static int buildPyramid(pmhip_engine* e) {
+	if (!e->pyramidDirty) return 0;
+	for (int l = 1; l <= e->nLevels; ++l) {
+		const size_t n = (size_t)e->lw(l) * e->lh(l) * e->nImages;
+		const int blocks = (int)std::min<size_t>((n + 255) / 256, 65535);
+		// every level is resampled from the full-resolution image (ScaleDepthData(fullRes, 1/2^l), SceneDensify.cpp:654)
+		hipLaunchKernelGGL(pm_area_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_img[0], e->d_img[l], e->w, e->h, 1 << l, e->nImages);
+	}
+	HIPCHK(e, hipGetLastError());
+	e->pyramidDirty = false;
+	return 0;
+}
+
+static PMKParams makeKParams(const PMHipParams& p) {
+	// DepthEstimator ctor, libs/MVS/DepthMap.cpp:397-406 (same float expressions)
+	PMKParams k;
+	k.smoothBonusDepth = 1.f - p.fRandomSmoothBonus;
+	k.smoothBonusNormal = (1.f - p.fRandomSmoothBonus) * 0.96f;
+	k.smoothSigmaDepth = -1.f / (2.f * (p.fRandomSmoothDepth * p.fRandomSmoothDepth));
+	const float sn = PM_FD2R(p.fRandomSmoothNormal);
+	k.smoothSigmaNormal = -1.f / (2.f * (sn * sn));
+	k.thMagnitudeSq = p.fDescriptorMinMagnitudeThreshold > 0 ? p.fDescriptorMinMagnitudeThreshold * p.fDescriptorMinMagnitudeThreshold : -1.f;
+	k.angle1Range = PM_FD2R(p.fRandomAngle1Range);
+	k.angle2Range = PM_FD2R(p.fRandomAngle2Range);
+	k.thConfSmall = p.fNCCThresholdKeep * 0.66f;
+	k.thConfBig = p.fNCCThresholdKeep * 0.9f;
+	k.thConfRand = p.fNCCThresholdKeep * 1.1f;
+	k.thRobust = p.fNCCThresholdKeep * 4.f / 3.f;
+	k.thKeep = p.fNCCThresholdKeep;
+	k.geoWeight = p.fEstimationGeometricWeight;
+	k.depthRatio = p.fRandomDepthRatio;
+	k.nRandomIters = p.nRandomIters;
+	return k;
+}
+
+template <bool GEO>
+static void launchInit(int G, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, uint32_t pass) {
+	switch (G) {
+	case 1: hipLaunchKernelGGL((pm_init_kernel<1, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
+	case 2: hipLaunchKernelGGL((pm_init_kernel<2, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
+	case 4: hipLaunchKernelGGL((pm_init_kernel<4, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
+	case 8: hipLaunchKernelGGL((pm_init_kernel<8, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
+	default: hipLaunchKernelGGL((pm_init_kernel<16, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
+	}
+}
+template <bool GEO>
+static void launchSweep(int G, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
+	switch (G) {
+	case 1: hipLaunchKernelGGL((pm_sweep_kernel<1, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, dir, d, xlo, count, pass); break;
+	case 2: hipLaunchKernelGGL((pm_sweep_kernel<2, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, dir, d, xlo, count, pass); break;
+	case 4: hipLaunchKernelGGL((pm_sweep_kernel<4, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, dir, d, xlo, count, pass); break;
+	case 8: hipLaunchKernelGGL((pm_sweep_kernel<8, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, dir, d, xlo, count, pass); break;
+	default: hipLaunchKernelGGL((pm_sweep_kernel<16, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, dir, d, xlo, count, pass); break;
+	}
+}
+
+static void evBegin(pmhip_engine* e, int kind) {
+	if (!e->statsOn) return;
+	pmhip_engine::Ev ev; ev.kind = kind;
+	hipEventCreate(&ev.a); hipEventCreate(&ev.b);
+	hipEventRecord(ev.a, e->stream);
+	e->events.push_back(ev);
+}
+static void evEnd(pmhip_engine* e) {
+	if (!e->statsOn) return;
+	hipEventRecord(e->events.back().b, e->stream);
+}
+
+// One DepthMapsData::EstimateDepthMap (SceneDensify.cpp:616-805) for each view of the batch, concurrently.
+static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHipParams& p, int nGeometricIter) {
+	if (nB <= 0) return 0;
+	if (nGeometricIter >= 0 && !e->geom) { e->err = "geometric round requested but engine initialised with bGeomConsistency == 0"; return PMHIP_E_STATE; }
+	const unsigned iterBegin = nGeometricIter < 0 ? 0u : p.nEstimationIters + (unsigned)nGeometricIter;
+	const unsigned iterEnd = nGeometricIter < 0 ? p.nEstimationIters : iterBegin + 1;
+	const int S = nGeometricIter < 0 ? (int)p.nSubResolutionLevels : 0;
+	if (S > e->nLevels || S > 3) { e->err = "nSubResolutionLevels exceeds the pyramid allocated by pmhip_scene_create"; return PMHIP_E_ARG; }
+	if ((e->w % (1 << S)) || (e->h % (1 << S))) { e->err = "image size must be divisible by 2^nSubResolutionLevels"; return PMHIP_E_SIZE; }
+	int rc = ensureBatch(e, nB); if (rc) return rc;
+	rc = buildPyramid(e); if (rc) return rc;
+	const PMKParams kp = makeKParams(p);
+	const bool geo = nGeometricIter >= 0;
+	int maxSrc = 0;
+	for (int b = 0; b < nB; ++b) {
+		const int id = ids[b];
+		if (id < 0 || id >= e->nImages || !e->views[id].set) { e->err = "view not set"; return PMHIP_E_ARG; }
+		const SceneView& v = e->views[id];
+		if (v.nNb < 1) { e->err = "view has no source views"; return PMHIP_E_ARG; }
+		for (int k = 0; k < v.nNb; ++k) if (v.nb[k] < 0 || v.nb[k] >= e->nImages || !e->views[v.nb[k]].set) { e->err = "neighbour view not set"; return PMHIP_E_ARG; }
+		maxSrc = std::max(maxSrc, v.nNb);
+	}
+	int G = 1; while (G < maxSrc) G <<= 1;
+	const size_t P0 = (size_t)e->w * e->h;
+	// the staging buffers are reused by the next call: make sure the previous call's copies are done
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	for (int l = S; l >= 0; --l) {
+		const int lw = e->lw(l), lh = e->lh(l);
+		const size_t Pl = (size_t)lw * lh;
+		PMTask* ht = e->h_tasks + (size_t)l * e->batchCap;
+		PMUpTask* hu = e->h_ups + (size_t)l * e->batchCap;
+		for (int b = 0; b < nB; ++b) {
+			const int id = ids[b];
+			const SceneView& v = e->views[id];
+			PMTask& t = ht[b];
+			memset(&t, 0, sizeof(t));
+			if (l == 0) {
+				t.depth = e->d_depth + P0 * id; t.normal = e->d_normal + P0 * 3 * id; t.conf = e->d_conf + P0 * id;
+				t.prior = (S > 0) ? e->d_lvl[0] + P0 * b : nullptr;
+			} else {
+				float* base = e->d_lvl[l] + Pl * 6 * b;
+				t.depth = base; t.normal = base + Pl; t.conf = base + Pl * 4;
+				t.prior = (l < S) ? base + Pl * 5 : nullptr;
+			}
+			t.ref = e->d_img[l] + Pl * id;
+			t.w = lw; t.h = lh; t.nSrc = v.nNb;
+			double K0[9];
+			if (l == 0) memcpy(K0, v.K, sizeof(K0)); else scaleK(v.K, e->w, e->h, lw, lh, K0);
+			inv33(K0, t.Hr);
+			t.fx = K0[0]; t.fy = K0[4]; t.cx = K0[2]; t.cy = K0[5];
+			t.dMin = v.dMin; t.dMax = v.dMax; t.dMinSqr = sqrtf(v.dMin); t.dMaxSqr = sqrtf(v.dMax);
+			t.k0 = p.seed; t.k1base = v.id * 0x9E3779B1u;
+			double R0T[9]; transp33(v.R, R0T);
+			double KR0[9]; mul33(K0, v.R, KR0);
+			for (int k = 0; k < v.nNb; ++k) {
+				const SceneView& sv = e->views[v.nb[k]];
+				PMSrcView& s = t.src[k];
+				s.img = e->d_img[l] + Pl * v.nb[k];
+				s.w = lw; s.h = lh;
+				double Kj[9];
+				if (l == 0) memcpy(Kj, sv.K, sizeof(Kj)); else scaleK(sv.K, e->w, e->h, lw, lh, Kj);
+				double KR[9], dC[3];
+				mul33(Kj, sv.R, KR);
+				mul33(KR, R0T, s.Hl);
+				for (int i = 0; i < 3; ++i) dC[i] = v.C[i] - sv.C[i];
+				mul31(KR, dC, s.Hm);
+				s.depth = nullptr;
+				if (geo) {
+					// ViewData::Init geometric part, DepthMap.h:179-184; cameraDepthMap == the neighbour's own camera
+					s.depth = e->d_snap + P0 * v.nb[k];
+					double tm[9], vv[3], RdT[9], iKd[9], t2[9];
+					mul33(KR, R0T, tm); for (int i = 0; i < 9; ++i) s.Tl[i] = (float)tm[i];
+					mul31(KR, dC, vv); for (int i = 0; i < 3; ++i) s.Tm[i] = (float)vv[i];
+					transp33(sv.R, RdT); mul33(KR0, RdT, tm); invK(Kj, iKd); mul33(tm, iKd, t2);
+					for (int i = 0; i < 9; ++i) s.Tr[i] = (float)t2[i];
+					for (int i = 0; i < 3; ++i) dC[i] = sv.C[i] - v.C[i];
+					mul31(KR0, dC, vv); for (int i = 0; i < 3; ++i) s.Tn[i] = (float)vv[i];
+				}
+			}
+			// level hand-off descriptors
+			PMUpTask& u = hu[b];
+			memset(&u, 0, sizeof(u));
+			if (l == S && S > 0) { // coarsest: INTER_NEAREST of the caller's initial estimate
+				u.sdepth = e->d_depth + P0 * id; u.snormal = e->d_normal + P0 * 3 * id; u.ddepth = t.depth; u.dnormal = t.normal; u.dprior = nullptr;
+			} else if (l < S) {
+				const size_t Pc = (size_t)e->lw(l + 1) * e->lh(l + 1);
+				float* cb = e->d_lvl[l + 1] + Pc * 6 * b;
+				u.sdepth = cb; u.snormal = cb + Pc; u.ddepth = t.depth; u.dnormal = t.normal; u.dprior = const_cast<float*>(t.prior);
+			}
+		}
+		PMTask* dt = e->d_tasks + (size_t)l * e->batchCap;
+		PMUpTask* du = e->d_ups + (size_t)l * e->batchCap;
+		HIPCHK(e, hipMemcpyAsync(dt, ht, sizeof(PMTask) * nB, hipMemcpyHostToDevice, e->stream));
+		HIPCHK(e, hipMemcpyAsync(du, hu, sizeof(PMUpTask) * nB, hipMemcpyHostToDevice, e->stream));
+		const int eb = (int)std::min<size_t>((Pl + 255) / 256, 4096);
+		if (l == S && S > 0)
+			hipLaunchKernelGGL(pm_nearest_down_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, e->w, e->h, lw, lh);
+		else if (l < S)
+			hipLaunchKernelGGL(pm_upsample_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, e->lw(l + 1), e->lh(l + 1), lw, lh);
+		// pass A: ScoreDepthMapTmp
+		const int PPB = PM_BLOCK / G;
+		const uint32_t passInit = (uint32_t)l * 64u + 32u + (geo ? 16u + (uint32_t)nGeometricIter : 0u);
+		evBegin(e, 1);
+		{
+			const dim3 grid((unsigned)((Pl + PPB - 1) / PPB), nB);
+			if (geo) launchInit<true>(G, grid, e->stream, dt, kp, passInit); else launchInit<false>(G, grid, e->stream, dt, kp, passInit);
+		}
+		evEnd(e);
+		if (e->statsOn) e->stats.initLaunches += 1;
+		// pass B: sweeps, one launch per anti-diagonal
+		for (unsigned iter = iterBegin; iter < iterEnd; ++iter) {
+			const int dir = (int)(iter % 2u);
+			const uint32_t pass = (uint32_t)l * 64u + iter;
+			const int dLo = 2 * PM_HW, dHi = (lw - 1 - PM_HW) + (lh - 1 - PM_HW);
+			evBegin(e, 0);
+			for (int k = 0; k <= dHi - dLo; ++k) {
+				const int d = dir == 0 ? dLo + k : dHi - k;
+				const int xlo = std::max(PM_HW, d - (lh - 1 - PM_HW));
+				const int xhi = std::min(lw - 1 - PM_HW, d - PM_HW);
+				const int count = xhi - xlo + 1;
+				if (count <= 0) continue;
+				const dim3 grid((unsigned)((count + PPB - 1) / PPB), nB);
+				if (geo) launchSweep<true>(G, grid, e->stream, dt, kp, dir, d, xlo, count, pass);
+				else launchSweep<false>(G, grid, e->stream, dt, kp, dir, d, xlo, count, pass);
+				if (e->statsOn) e->stats.sweepLaunches += 1;
+			}
+			evEnd(e);
+			if (e->statsOn) {
+				// algorithmic bytes of one sweep, SURVEY.md 8(d): P_l * [4(1+N) + 20 + 20 + 4[prior] + 4N[geo]] per view
+				double bytes = 0;
+				for (int b = 0; b < nB; ++b) { const int N = e->views[ids[b]].nNb; bytes += (double)Pl * (4.0 * (1 + N) + 40.0 + (l < S ? 4.0 : 0.0) + (geo ? 4.0 * N : 0.0)); }
+				e->stats.sweepBytes += bytes;
+				e->stats.sweepPixels += (uint64_t)Pl * nB;
+			}
+		}
+		HIPCHK(e, hipGetLastError());
+	}
+	// pass C: EndDepthMapTmp (threshold x1.333 when geometric rounds will follow, SceneDensify.cpp:774-776)
+	float th = p.fNCCThresholdKeep;
+	if (nGeometricIter < 0 && p.nEstimationGeometricIters) th *= 1.333f;
+	hipLaunchKernelGGL(pm_finalize_kernel, dim3((unsigned)std::min<size_t>((P0 + 255) / 256, 4096), nB), dim3(256), 0, e->stream, e->d_tasks, th);
+	HIPCHK(e, hipGetLastError());
+	return 0;
+}
+
+static int collectStats(pmhip_engine* e) {
+	if (e->events.empty()) return 0;
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	for (auto& ev : e->events) {
+		float ms = 0; hipEventElapsedTime(&ms, ev.a, ev.b);
+		if (ev.kind == 0) e->stats.sweepMs += ms; else e->stats.initMs += ms;
+		hipEventDestroy(ev.a); hipEventDestroy(ev.b);
+	}
+	e->events.clear();
+	return 0;
+}
+
+extern "C" {
+
+int pmhip_default_params(PMHipParams* p) {
+	if (!p) return PMHIP_E_ARG;
+	// libs/MVS/DepthMap.cpp:69-114
+	p->nSubResolutionLevels = 2; p->nEstimationIters = 3; p->nEstimationGeometricIters = 2; p->nRandomIters = 6;
+	p->fEstimationGeometricWeight = 0.1f; p->fRandomDepthRatio = 0.003f; p->fRandomAngle1Range = 16.f; p->fRandomAngle2Range = 10.f;
+	p->fRandomSmoothDepth = 0.02f; p->fRandomSmoothNormal = 13.f; p->fRandomSmoothBonus = 0.93f; p->fNCCThresholdKeep = 0.9f;
+	p->fDescriptorMinMagnitudeThreshold = 0.02f; p->seed = 0;
+	return 0;
+}
+
+int pmhip_create(int device, pmhip_engine** out) {
+	if (!out) return PMHIP_E_ARG;
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return PMHIP_E_NODEVICE;
+	if (device < 0) device = 0; // "-1 = best device" (DensifyPointCloud.cpp:112): one GPU per process here
+	if (device >= n) return PMHIP_E_NODEVICE;
+	pmhip_engine* e = new pmhip_engine();
+	e->device = device;
+	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return PMHIP_E_HIP; }
+	*out = e;
+	return 0;
+}
+
+void pmhip_destroy(pmhip_engine* e) {
+	if (!e) return;
+	hipSetDevice(e->device);
+	if (e->stream) hipStreamSynchronize(e->stream);
+	for (auto& ev : e->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+	freeScene(e);
+	if (e->stream) hipStreamDestroy(e->stream);
+	delete e;
+}
+
+int pmhip_init(pmhip_engine* e, int bGeomConsistency) {
+	if (!e) return PMHIP_E_ARG;
+	e->inited = true; e->geom = bGeomConsistency != 0;
+	return 0;
+}
+
+int pmhip_release(pmhip_engine* e) {
+	if (!e) return PMHIP_E_ARG;
+	hipSetDevice(e->device);
+	hipStreamSynchronize(e->stream);
+	freeScene(e);
+	e->inited = false;
+	return 0;
+}
+
+const char* pmhip_last_error(pmhip_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int pmhip_scene_create(pmhip_engine* e, int nImages, int w, int h, int nLevels) {
+	if (!e || nImages < 2 || w < 2 * PM_HW + 1 || h < 2 * PM_HW + 1 || nLevels < 0 || nLevels > 3) return PMHIP_E_ARG;
+	if ((w % (1 << nLevels)) || (h % (1 << nLevels))) { e->err = "image size must be divisible by 2^nLevels"; return PMHIP_E_SIZE; }
+	HIPCHK(e, hipSetDevice(e->device));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	freeScene(e);
+	e->nImages = nImages; e->w = w; e->h = h; e->nLevels = nLevels;
+	const size_t P0 = (size_t)w * h;
+	for (int l = 0; l <= nLevels; ++l) HIPCHK(e, hipMalloc(&e->d_img[l], sizeof(float) * (size_t)e->lw(l) * e->lh(l) * nImages));
+	HIPCHK(e, hipMalloc(&e->d_depth, sizeof(float) * P0 * nImages));
+	HIPCHK(e, hipMalloc(&e->d_normal, sizeof(float) * P0 * 3 * nImages));
+	HIPCHK(e, hipMalloc(&e->d_conf, sizeof(float) * P0 * nImages));
+	HIPCHK(e, hipMalloc(&e->d_snap, sizeof(float) * P0 * nImages));
+	HIPCHK(e, hipMemsetAsync(e->d_depth, 0, sizeof(float) * P0 * nImages, e->stream));
+	HIPCHK(e, hipMemsetAsync(e->d_normal, 0, sizeof(float) * P0 * 3 * nImages, e->stream));
+	HIPCHK(e, hipMemsetAsync(e->d_conf, 0, sizeof(float) * P0 * nImages, e->stream));
+	HIPCHK(e, hipMemsetAsync(e->d_snap, 0, sizeof(float) * P0 * nImages, e->stream));
+	e->views.assign(nImages, SceneView());
+	for (int i = 0; i < nImages; ++i) e->views[i].id = (uint32_t)i;
+	e->pyramidDirty = true;
+	return 0;
+}
+
+int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevice, const double K[9], const double R[9], const double C[3],
+		float dMin, float dMax, const int32_t* neighbors, int nNeighbors) {
+	if (!e || idx < 0 || idx >= e->nImages || !K || !R || !C || nNeighbors < 0 || nNeighbors > PM_MAX_SRC) return PMHIP_E_ARG;
+	if (!(dMin > 0) || !(dMin < dMax)) { e->err = "need 0 < dMin < dMax"; return PMHIP_E_ARG; }
+	HIPCHK(e, hipSetDevice(e->device));
+	SceneView& v = e->views[idx];
+	memcpy(v.K, K, 72); memcpy(v.R, R, 72); memcpy(v.C, C, 24);
+	v.dMin = dMin; v.dMax = dMax; v.nNb = nNeighbors;
+	for (int k = 0; k < nNeighbors; ++k) v.nb[k] = neighbors[k];
+	v.set = true;
+	if (gray) {
+		const size_t P0 = (size_t)e->w * e->h;
+		HIPCHK(e, hipMemcpyAsync(e->d_img[0] + P0 * idx, gray, sizeof(float) * P0, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+		if (!onDevice) HIPCHK(e, hipStreamSynchronize(e->stream)); // caller may free the host buffer
+		e->pyramidDirty = true;
+	}
+	return 0;
+}
+
+int pmhip_scene_images_updated(pmhip_engine* e) { if (!e) return PMHIP_E_ARG; e->pyramidDirty = true; return 0; }
+
+int pmhip_scene_estimate(pmhip_engine* e, const int32_t* viewIds, int nViews, const PMHipParams* p, int nGeometricIter, int sync) {
+	if (!e || !viewIds || !p || nViews < 0) return PMHIP_E_ARG;
+	if (!e->inited) { e->err = "pmhip_init not called"; return PMHIP_E_STATE; }
+	HIPCHK(e, hipSetDevice(e->device));
+	int rc = estimateBatch(e, viewIds, nViews, *p, nGeometricIter);
+	if (rc) return rc;
+	if (sync) HIPCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+int pmhip_scene_commit_round(pmhip_engine* e) {
+	if (!e || !e->d_snap) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	HIPCHK(e, hipMemcpyAsync(e->d_snap, e->d_depth, sizeof(float) * (size_t)e->w * e->h * e->nImages, hipMemcpyDeviceToDevice, e->stream));
+	return 0;
+}
+
+int pmhip_scene_reset_view(pmhip_engine* e, int idx) {
+	if (!e || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	const size_t P0 = (size_t)e->w * e->h;
+	HIPCHK(e, hipMemsetAsync(e->d_depth + P0 * idx, 0, sizeof(float) * P0, e->stream));
+	HIPCHK(e, hipMemsetAsync(e->d_normal + P0 * 3 * idx, 0, sizeof(float) * P0 * 3, e->stream));
+	HIPCHK(e, hipMemsetAsync(e->d_conf + P0 * idx, 0, sizeof(float) * P0, e->stream));
+	return 0;
+}
+
+int pmhip_scene_set_maps(pmhip_engine* e, int idx, const float* depth, const float* normal) {
+	if (!e || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	const size_t P0 = (size_t)e->w * e->h;
+	if (depth) HIPCHK(e, hipMemcpyAsync(e->d_depth + P0 * idx, depth, sizeof(float) * P0, hipMemcpyHostToDevice, e->stream));
+	if (normal) HIPCHK(e, hipMemcpyAsync(e->d_normal + P0 * 3 * idx, normal, sizeof(float) * P0 * 3, hipMemcpyHostToDevice, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+int pmhip_scene_get_maps(pmhip_engine* e, int idx, float* depth, float* normal, float* conf) {
+	if (!e || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	const size_t P0 = (size_t)e->w * e->h;
+	if (depth) HIPCHK(e, hipMemcpyAsync(depth, e->d_depth + P0 * idx, sizeof(float) * P0, hipMemcpyDeviceToHost, e->stream));
+	if (normal) HIPCHK(e, hipMemcpyAsync(normal, e->d_normal + P0 * 3 * idx, sizeof(float) * P0 * 3, hipMemcpyDeviceToHost, e->stream));
+	if (conf) HIPCHK(e, hipMemcpyAsync(conf, e->d_conf + P0 * idx, sizeof(float) * P0, hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+void* pmhip_scene_device_ptr(pmhip_engine* e, int what, int idx) {
+	if (!e || idx < 0 || idx >= e->nImages) return nullptr;
+	const size_t P0 = (size_t)e->w * e->h;
+	switch (what) {
+	case 0: return e->d_img[0] + P0 * idx;
+	case 1: return e->d_depth + P0 * idx;
+	case 2: return e->d_normal + P0 * 3 * idx;
+	case 3: return e->d_conf + P0 * idx;
+	case 4: return e->d_snap + P0 * idx;
+	default: return nullptr;
+	}
+}
+
+int pmhip_sync(pmhip_engine* e) { if (!e) return PMHIP_E_ARG; HIPCHK(e, hipSetDevice(e->device)); HIPCHK(e, hipStreamSynchronize(e->stream)); return 0; }
+void* pmhip_stream(pmhip_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int pmhip_stats_reset(pmhip_engine* e, int enableEvents) {
+	if (!e) return PMHIP_E_ARG;
+	hipSetDevice(e->device);
+	collectStats(e);
+	memset(&e->stats, 0, sizeof(e->stats));
+	e->statsOn = enableEvents != 0;
+	return 0;
+}
+int pmhip_stats_get(pmhip_engine* e, PMHipKernelStats* out) {
+	if (!e || !out) return PMHIP_E_ARG;
+	hipSetDevice(e->device);
+	int rc = collectStats(e); if (rc) return rc;
+	*out = e->stats;
+	return 0;
+}
+
+// PatchMatchCUDA::EstimateDepthMap(DepthData&), libs/MVS/PatchMatchCUDA.cpp:174-416 -- host buffers in, host buffers out.
+int pmhip_estimate_depth_map(pmhip_engine* e, PMHipDepthData* dd, const PMHipParams* p, int nGeometricIter) {
+	if (!e || !dd || !p || !dd->views || dd->nViews < 2 || dd->nViews > 1 + PM_MAX_SRC || !dd->depthMap || !dd->normalMap || !dd->confMap) return PMHIP_E_ARG;
+	if (!e->inited) { e->err = "pmhip_init not called"; return PMHIP_E_STATE; }
+	const int w = dd->views[0].w, h = dd->views[0].h, n = dd->nViews;
+	for (int i = 0; i < n; ++i) {
+		if (!dd->views[i].image) return PMHIP_E_ARG;
+		if (dd->views[i].w != w || dd->views[i].h != h) { e->err = "all views must have the reference view's size"; return PMHIP_E_SIZE; }
+		if (nGeometricIter >= 0 && i > 0 && !dd->views[i].depth) { e->err = "geometric round needs views[i].depth"; return PMHIP_E_ARG; }
+	}
+	const int S = (int)p->nSubResolutionLevels;
+	if (S > 3) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	// keep device buffers between calls; re-allocate only when geometry changes (reference: PatchMatchCUDA.cpp:264-322)
+	if (e->nImages != n || e->w != w || e->h != h || e->nLevels < S) {
+		int rc = pmhip_scene_create(e, n, w, h, std::max(S, e->nImages == n && e->w == w && e->h == h ? e->nLevels : 0));
+		if (rc) return rc;
+	}
+	const size_t P0 = (size_t)w * h;
+	int32_t nb[PM_MAX_SRC];
+	for (int i = 1; i < n; ++i) nb[i - 1] = i;
+	for (int i = 0; i < n; ++i) {
+		const PMHipView& v = dd->views[i];
+		int rc = pmhip_scene_set_view(e, i, v.image, 0, v.K, v.R, v.C, dd->dMin, dd->dMax, nb, i == 0 ? n - 1 : 0);
+		if (rc) return rc;
+		e->views[i].id = v.id;
+		if (nGeometricIter >= 0 && i > 0) {
+			// the geometric term uses the camera stored with the depth-map (cameraDepthMap); it must be the view's camera here
+			HIPCHK(e, hipMemcpyAsync(e->d_snap + P0 * i, v.depth, sizeof(float) * P0, hipMemcpyHostToDevice, e->stream));
+		}
+	}
+	int rc = pmhip_scene_set_maps(e, 0, dd->depthMap, dd->normalMap);
+	if (rc) return rc;
+	const int32_t id0 = 0;
+	rc = estimateBatch(e, &id0, 1, *p, nGeometricIter);
+	if (rc) return rc;
+	return pmhip_scene_get_maps(e, 0, dd->depthMap, dd->normalMap, dd->confMap);
+}
+
+int pmhip_math_eval(pmhip_engine* e, int kind, const float* a, const float* b, float* out, size_t n) {
+	if (!e || !a || !out || n == 0) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	float *da = nullptr, *db = nullptr, *dout = nullptr;
+	HIPCHK(e, hipMalloc(&da, n * 4)); HIPCHK(e, hipMalloc(&db, n * 4)); HIPCHK(e, hipMalloc(&dout, n * 4));
+	HIPCHK(e, hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(db, b ? b : a, n * 4, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(pm_math_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, e->stream, kind, da, db, dout, n);
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	HIPCHK(e, hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+	hipFree(da); hipFree(db); hipFree(dout);
+	return 0;
+}
+
+int pmhip_resize(pmhip_engine* e, int kind, const float* src, int w, int h, int arg, float* dst) {
+	if (!e || !src || !dst || w <= 0 || h <= 0) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	const size_t ns = (size_t)w * h;
+	int dw, dh;
+	if (kind == 0) { if (arg < 1 || w % arg || h % arg) return PMHIP_E_SIZE; dw = w / arg; dh = h / arg; } else { dw = w * 2; dh = h * 2; }
+	const size_t nd = (size_t)dw * dh;
+	float *ds = nullptr, *dd = nullptr, *dn = nullptr, *dn2 = nullptr, *dp = nullptr; PMUpTask* du = nullptr;
+	HIPCHK(e, hipMalloc(&ds, ns * 4)); HIPCHK(e, hipMalloc(&dd, nd * 4));
+	HIPCHK(e, hipMemcpy(ds, src, ns * 4, hipMemcpyHostToDevice));
+	const int blocks = (int)std::min<size_t>((nd + 255) / 256, 4096);
+	if (kind == 0) {
+		hipLaunchKernelGGL(pm_area_kernel, dim3(blocks), dim3(256), 0, e->stream, ds, dd, w, h, arg, 1);
+	} else if (kind == 1) {
+		HIPCHK(e, hipMalloc(&dn, ns * 12)); HIPCHK(e, hipMalloc(&dn2, nd * 12)); HIPCHK(e, hipMalloc(&dp, nd * 4)); HIPCHK(e, hipMalloc(&du, sizeof(PMUpTask)));
+		HIPCHK(e, hipMemset(dn, 0, ns * 12));
+		PMUpTask u{ds, dn, dd, dn2, dp};
+		HIPCHK(e, hipMemcpy(du, &u, sizeof(u), hipMemcpyHostToDevice));
+		hipLaunchKernelGGL(pm_upsample_kernel, dim3(blocks, 1), dim3(256), 0, e->stream, du, w, h, dw, dh);
+	} else {
+		hipLaunchKernelGGL(pm_nearest_up_f_kernel, dim3(blocks), dim3(256), 0, e->stream, ds, dd, w, h, dw, dh);
+	}
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	HIPCHK(e, hipMemcpy(dst, dd, nd * 4, hipMemcpyDeviceToHost));
+	hipFree(ds); hipFree(dd); if (dn) hipFree(dn); if (dn2) hipFree(dn2); if (dp) hipFree(dp); if (du) hipFree(du);
+	return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,605 @@
+// pm_kernels.hip -- CDNA4 (gfx950) kernels of the PatchMatch depth-map estimator.
+//
+// What is computed: the reference's CPU estimator (libs/MVS/DepthMap.cpp:415-971, passes of
+// libs/MVS/SceneDensify.cpp:490-576), written from scratch for a 64-wide wavefront machine.
+//
+// Work decomposition ("pixel group" mapping): G = next_pow2(#source views) adjacent lanes own one
+// pixel; lane v of the group scores the hypothesis against source view v (25 bilinear taps walked
+// serially, exactly the reference's accumulation order), the two smallest view scores are found
+// with a log2(G)-step __shfl_xor butterfly inside the group (wave64 cross-lane, no LDS traffic),
+// and everything that is per pixel (RNG, plane perturbation, accept/reject) is evaluated
+// redundantly by the G lanes so no broadcast is needed.  A wave64 therefore advances 64/G pixels
+// and a 256-thread workgroup 256/G.  The 25 bilateral patch weights of each pixel are computed
+// cooperatively by its G lanes and staged in LDS (float2 {w, w*(I-mean)} per tap, read back as
+// broadcast ds_read_b64).
+//
+// Schedule: the CPU sweep visits pixels in anti-diagonal order (MapMatrix2ZigzagIdx,
+// DepthMap.cpp:329-356): a pixel sees *new* values at its left/top neighbours and *old* values at
+// right/bottom (DepthMap.cpp:641-766).  All pixels of one anti-diagonal are independent, so one
+// launch processes one anti-diagonal of every reference view in the batch (grid.y = views), in place;
+// launches on one stream order the diagonals.  This reproduces the sequential result bit for bit.
+//
+// No MFMA: the path is a gather stencil.  No FMA contraction (-ffp-contract=off) -- see pm_math.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pm_math.h"
+
+#define PM_MAX_SRC 16
+#define PM_BLOCK 256
+#define PM_HW 4      // nSizeHalfWindow, DepthMap.h:277
+#define PM_NT 25     // nTexels, DepthMap.h:281
+
+struct PMSrcView {
+	const float* img;     // source image at this pyramid level
+	const float* depth;   // nullable: source depth-map (geometric pass)
+	int w, h;
+	double Hl[9];         // K_j R_j R_0^T          (ViewData::Init, DepthMap.h:175-185)
+	double Hm[3];         // K_j R_j (C_0 - C_j)
+	float Tl[9], Tm[3], Tr[9], Tn[3];
+};
+struct PMTask {           // one reference view at one pyramid level
+	float* depth; float* normal; float* conf;
+	const float* prior;   // nullable: low-resolution depth prior at this level
+	const float* ref;     // reference image at this level
+	int w, h, nSrc, pad0;
+	double Hr[9];         // K_0^-1
+	double fx, fy, cx, cy;
+	float dMin, dMax, dMinSqr, dMaxSqr;
+	uint32_t k0, k1base;  // Philox key: (seed, viewID*0x9E3779B1 + pass)
+	PMSrcView src[PM_MAX_SRC];
+};
+struct PMKParams {        // DepthEstimator ctor constants, DepthMap.cpp:397-406
+	float smoothBonusDepth, smoothBonusNormal, smoothSigmaDepth, smoothSigmaNormal;
+	float thMagnitudeSq, angle1Range, angle2Range, thConfSmall, thConfBig, thConfRand, thRobust;
+	float thKeep, geoWeight, depthRatio;
+	uint32_t nRandomIters;
+};
+
+enum { PM_STREAM_INIT = 0, PM_STREAM_RAND = 1, PM_STREAM_REFINE = 2 };
+
+#define PM_INF __builtin_huge_valf()
+#define PM_FD2R(d) ((d) * (PM_PI_F / 180.f))
+
+// ---- small device helpers -----------------------------------------------------------------
+__device__ __forceinline__ bool pm_inside1(float px, float py, int w, int h) {
+	// isInsideWithBorder<float,1>, libs/Common/Types.h:1649-1651
+	return px >= 1.f && py >= 1.f && px <= (float)(w - 2) && py <= (float)(h - 2);
+}
+__device__ __forceinline__ bool pm_in_range(float d, float lo, float hi) { return lo <= d && d < hi; } // ISINSIDE, Types.h:1193
+
+// Dir2Normal / Normal2Dir, libs/Common/Util.inl:754-766
+__device__ __forceinline__ void pm_dir2normal(float p0, float p1, float& nx, float& ny, float& nz) {
+	float sx, cx, sy, cy;
+	pm_sincosf(p0, &sx, &cx); pm_sincosf(p1, &sy, &cy);
+	nx = cx * sy; ny = sx * sy; nz = cy;
+}
+// RandomNormal, DepthMap.h:439-444
+__device__ __forceinline__ void pm_random_normal(float u1, float u2, float vx, float vy, float vz, float& nx, float& ny, float& nz) {
+	const float a0 = PM_FD2R(0.f), a1 = PM_FD2R(180.f), b0 = PM_FD2R(90.f), b1 = PM_FD2R(180.f);
+	const float p0 = a0 + (a1 - a0) * u1;
+	const float p1 = b0 + (b1 - b0) * u2;
+	pm_dir2normal(p0, p1, nx, ny, nz);
+	if (nx * vx + ny * vy + nz * vz > 0) { nx = -nx; ny = -ny; nz = -nz; }
+}
+// CorrectNormal, DepthMap.h:447-453 (+ axis-angle matrix, libs/Common/Rotation.inl:701-728), float
+__device__ __forceinline__ void pm_correct_normal(float vx, float vy, float vz, float& nx, float& ny, float& nz) {
+	const float cosAngLen = nx * vx + ny * vy + nz * vz;
+	if (cosAngLen >= 0) {
+		const float nv = pm_sqrtf(vx * vx + vy * vy + vz * vz);
+		const float phi = pm_minf((pm_acosf(pm_clampf(cosAngLen / nv, -1.f, 1.f)) - PM_FD2R(90.f)) * 1.01f, -0.001f);
+		float a0 = ny * vz - nz * vy, a1 = nz * vx - nx * vz, a2 = nx * vy - ny * vx;
+		const float an = pm_sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+		const float ia = 1.f / an;
+		a0 *= ia; a1 *= ia; a2 *= ia;
+		float s, c; pm_sincosf(phi, &s, &c);
+		const float O[9] = {0.f, -a2, a1, a2, 0.f, -a0, -a1, a0, 0.f};
+		float Rm[9];
+#pragma unroll
+		for (int i = 0; i < 3; ++i)
+#pragma unroll
+			for (int j = 0; j < 3; ++j) {
+				float t = 0.f;
+#pragma unroll
+				for (int k = 0; k < 3; ++k) t += O[i * 3 + k] * O[k * 3 + j];
+				Rm[i * 3 + j] = ((i == j ? 1.f : 0.f) + O[i * 3 + j] * s) + t * (1.f - c);
+			}
+		const float r0 = Rm[0] * nx + Rm[1] * ny + Rm[2] * nz;
+		const float r1 = Rm[3] * nx + Rm[4] * ny + Rm[5] * nz;
+		const float r2 = Rm[6] * nx + Rm[7] * ny + Rm[8] * nz;
+		nx = r0; ny = r1; nz = r2;
+	}
+}
+
+// two smallest of the group's values (as a multiset) by xor-butterfly; exact (comparisons only)
+template <int G>
+__device__ __forceinline__ void pm_group_min2(float s, float& m1, float& m2) {
+	float a = s, b = PM_INF;
+#pragma unroll
+	for (int m = 1; m < G; m <<= 1) {
+		const float oa = __shfl_xor(a, m, G);
+		const float ob = __shfl_xor(b, m, G);
+		const float na = pm_minf(a, oa);
+		const float nb = pm_minf(pm_maxf(a, oa), pm_minf(b, ob));
+		a = na; b = nb;
+	}
+	m1 = a; m2 = b;
+}
+
+// ScorePixelImage for this lane's source view, DepthMap.cpp:465-564.
+// sf[]: the (view-independent) smoothness factors of the up-to-4 close neighbours, in insertion
+// order, sfValid bit k set if neighbour k exists (DepthMap.cpp:524-533).
+template <bool GEO>
+__device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask& t, const PMKParams& kp,
+		int x, int y, double X0x, double X0y, float normSq0, float sumW, const float2* wts,
+		float depth, float nx, float ny, float nz,
+		float sf0, float sf1, float sf2, float sf3, unsigned sfValid, float prior)
+{
+	// ComputeHomographyMatrix, DepthMap.h:414-423 (double, then cast to float)
+	float H[9];
+	{
+		const double n0 = (double)nx, n1 = (double)ny, n2 = (double)nz;
+		const double ndx = (n0 * X0x + n1 * X0y) + n2;
+		const double den = ndx * (double)depth;
+		const double inv = (den == 0.0) ? 1e+14 : 1.0 / den;
+		const double r0 = n0 * inv, r1 = n1 * inv, r2 = n2 * inv;
+#pragma unroll
+		for (int i = 0; i < 3; ++i) {
+			const double hm = s.Hm[i];
+			const double m0 = s.Hl[i * 3 + 0] + hm * r0;
+			const double m1 = s.Hl[i * 3 + 1] + hm * r1;
+			const double m2 = s.Hl[i * 3 + 2] + hm * r2;
+#pragma unroll
+			for (int j = 0; j < 3; ++j)
+				H[i * 3 + j] = (float)((m0 * t.Hr[j] + m1 * t.Hr[3 + j]) + m2 * t.Hr[6 + j]);
+		}
+	}
+	const float px = (float)(x - PM_HW), py = (float)(y - PM_HW);
+	float X0 = H[0] * px + H[1] * py + H[2];
+	float X1 = H[3] * px + H[4] * py + H[5];
+	float X2 = H[6] * px + H[7] * py + H[8];
+	float bX0 = X0, bX1 = X1, bX2 = X2;
+#pragma unroll
+	for (int i = 0; i < 9; ++i) H[i] *= 2.f; // nSizeStep
+	float sum = 0.f, sumSq = 0.f, num = 0.f;
+	const int sw = s.w, sh = s.h;
+	const float* __restrict__ img = s.img;
+	int n = 0;
+	bool oob = false;
+	for (int i = 0; i < 5; ++i) {
+#pragma unroll
+		for (int j = 0; j < 5; ++j) {
+			const float ptx = X0 / X2, pty = X1 / X2;
+			if (!pm_inside1(ptx, pty, sw, sh)) { oob = true; break; }
+			// TImage::sample, libs/Common/Types.inl:2273-2281
+			const int lx = (int)ptx, ly = (int)pty;
+			const float fx = ptx - (float)lx, fx1 = 1.f - fx;
+			const float fy = pty - (float)ly, fy1 = 1.f - fy;
+			const float* p = img + (size_t)ly * sw + lx;
+			const float v00 = p[0], v01 = p[1], v10 = p[sw], v11 = p[sw + 1];
+			const float v = (v00 * fx1 + v01 * fx) * fy1 + (v10 * fx1 + v11 * fx) * fy;
+			const float2 pw = wts[n++];
+			const float vw = v * pw.x;
+			sum += vw;
+			sumSq += v * vw;
+			num += v * pw.y;
+			X0 += H[0]; X1 += H[3]; X2 += H[6];
+		}
+		if (oob) break;
+		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
+		X0 = bX0; X1 = bX1; X2 = bX2;
+	}
+	if (oob) return kp.thRobust;
+	const float normSq1 = sumSq - (sum * sum) / sumW;
+	const float nrmSq = normSq0 * normSq1;
+	if (nrmSq <= 1e-16f) return kp.thRobust;
+	const float ncc = pm_clampf(num / pm_sqrtf(nrmSq), -1.f, 1.f);
+	float score = 1.f - ncc;
+	if (sfValid & 1u) score *= sf0;
+	if (sfValid & 2u) score *= sf1;
+	if (sfValid & 4u) score *= sf2;
+	if (sfValid & 8u) score *= sf3;
+	if (GEO) {
+		// geometric consistency, DepthMap.cpp:535-551
+		if (s.depth != nullptr) {
+			float consistency = 4.f;
+			const float Xc0 = (float)X0x * depth, Xc1 = (float)X0y * depth, Xc2 = depth;
+			const float Y0 = (s.Tl[0] * Xc0 + s.Tl[1] * Xc1 + s.Tl[2] * Xc2) + s.Tm[0];
+			const float Y1 = (s.Tl[3] * Xc0 + s.Tl[4] * Xc1 + s.Tl[5] * Xc2) + s.Tm[1];
+			const float Y2 = (s.Tl[6] * Xc0 + s.Tl[7] * Xc1 + s.Tl[8] * Xc2) + s.Tm[2];
+			if (Y2 > 0) {
+				const float x1x = Y0 / Y2, x1y = Y1 / Y2;
+				if (pm_inside1(x1x, x1y, sw, sh)) {
+					// TImage::sample with validity functor, Types.inl:2299-2314; IsDepthSimilar(z,d,0.03), Util.inl:798-809
+					const int lx = (int)x1x, ly = (int)x1y;
+					const float fx = x1x - (float)lx, fx1 = 1.f - fx;
+					const float fy = x1y - (float)ly, fy1 = 1.f - fy;
+					const float* p = s.depth + (size_t)ly * sw + lx;
+					const float x0y0 = p[0], x1y0 = p[1], x0y1 = p[sw], x1y1 = p[sw + 1];
+					const bool b00 = pm_fabsf(Y2 - x0y0) / Y2 < 0.03f, b10 = pm_fabsf(Y2 - x1y0) / Y2 < 0.03f;
+					const bool b01 = pm_fabsf(Y2 - x0y1) / Y2 < 0.03f, b11 = pm_fabsf(Y2 - x1y1) / Y2 < 0.03f;
+					if (b00 || b10 || b01 || b11) {
+						const float depth1 =
+							fy1 * (fx1 * (b00 ? x0y0 : (b10 ? x1y0 : (b01 ? x0y1 : x1y1))) + fx * (b10 ? x1y0 : (b00 ? x0y0 : (b11 ? x1y1 : x0y1)))) +
+							fy  * (fx1 * (b01 ? x0y1 : (b11 ? x1y1 : (b00 ? x0y0 : x1y0))) + fx * (b11 ? x1y1 : (b01 ? x0y1 : (b10 ? x1y0 : x0y0))));
+						const float Xd0 = x1x * depth1, Xd1 = x1y * depth1, Xd2 = depth1;
+						const float B0 = (s.Tr[0] * Xd0 + s.Tr[1] * Xd1 + s.Tr[2] * Xd2) + s.Tn[0];
+						const float B1 = (s.Tr[3] * Xd0 + s.Tr[4] * Xd1 + s.Tr[5] * Xd2) + s.Tn[1];
+						const float B2 = (s.Tr[6] * Xd0 + s.Tr[7] * Xd1 + s.Tr[8] * Xd2) + s.Tn[2];
+						const float xbx = B0 / B2, xby = B1 / B2;
+						const float dx = (float)x - xbx, dy = (float)y - xby;
+						const float dist = (float)sqrt((double)dx * (double)dx + (double)dy * (double)dy); // cv::norm(Point2f) -> double
+						consistency = pm_minf(pm_sqrtf(dist * (dist + 2.f)), consistency);
+					}
+				}
+			}
+			score += kp.geoWeight * consistency;
+		}
+	}
+	// low-resolution prior, DepthMap.cpp:553-561
+	if (prior > 0) {
+		const float deltaDepth = pm_minf(pm_fabsf(prior - depth) / prior, 0.5f);
+		const float sigma = -1.f / (1.f * 0.02f);
+		const float f = pm_expf(normSq0 * sigma);
+		score = (1.f - f) * score + f * deltaDepth;
+	}
+	return pm_minf(2.f, score);
+}
+
+// ScorePixel aggregation, DepthMap.cpp:594-611 (MINMEAN)
+template <int G>
+__device__ __forceinline__ float pm_aggregate(float viewScore, int nSrc, float thRobust) {
+	float m1, m2;
+	pm_group_min2<G>(viewScore, m1, m2);
+	if (nSrc <= 1) return m1;
+	if (m2 >= thRobust) return m1;
+	return (m1 + m2) / 2.f;
+}
+
+// FillPixelPatch, DepthMap.cpp:422-462: cooperative weights into LDS; returns normSq0, sumW.
+// Must be called by every thread of the workgroup (contains __syncthreads()).
+template <int G>
+__device__ __forceinline__ void pm_fill_patch(const PMTask& t, bool inb, int x, int y, int v, float2* wts, float& normSq0, float& sumW) {
+	const float sigmaColor = -1.f / (2.f * (0.1f * 0.1f));
+	const float sigmaSpatial = -1.f / (2.f * 9.f);
+	if (inb) {
+		const float colCenter = t.ref[(size_t)y * t.w + x];
+		for (int k = v; k < PM_NT; k += G) {
+			const int i = (k / 5) * 2 - PM_HW, j = (k % 5) * 2 - PM_HW;
+			const float I = t.ref[(size_t)(y + i) * t.w + (x + j)];
+			const float dc = I - colCenter;
+			const float wColor = (dc * dc) * sigmaColor;
+			const float wSpatial = (float)(j * j + i * i) * sigmaSpatial;
+			wts[k] = make_float2(pm_expf(wColor + wSpatial), I);
+		}
+	}
+	__syncthreads();
+	float tm = 0.f;
+	normSq0 = 0.f; sumW = 0.f;
+	if (inb) {
+		float acc = 0.f;
+		for (int k = 0; k < PM_NT; ++k) { const float2 p = wts[k]; acc += p.y * p.x; sumW += p.x; }
+		tm = acc / sumW;
+		for (int k = 0; k < PM_NT; ++k) { const float2 p = wts[k]; const float d = p.y - tm; const float tw = p.x * d; normSq0 += tw * d; }
+	}
+	__syncthreads();
+	if (inb) {
+		for (int k = v; k < PM_NT; k += G) { const float2 p = wts[k]; const float d = p.y - tm; wts[k] = make_float2(p.x, p.x * d); }
+	}
+	__syncthreads();
+}
+
+__device__ __forceinline__ float pm_pow2neg(unsigned i) { return pm_u2f((127u - i) << 23); } // scaleRanges[i] = 2^-i, DepthMap.cpp:359
+
+// -------------------------------------------------------------------------------------------
+// ScoreDepthMapTmp, SceneDensify.cpp:490-517: fully parallel, no neighbour dependency.
+template <int G, bool GEO>
+__global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restrict__ tasks, PMKParams kp, uint32_t pass) {
+	constexpr int PPB = PM_BLOCK / G;
+	__shared__ float2 s_w[PPB][PM_NT + 1];
+	const PMTask& t = tasks[blockIdx.y];
+	const int g = threadIdx.x / G, v = threadIdx.x % G;
+	const int w = t.w, h = t.h;
+	const long p = (long)blockIdx.x * PPB + g;
+	const bool active = p < (long)w * h;
+	const int x = active ? (int)(p % w) : 0, y = active ? (int)(p / w) : 0;
+	const bool inb = active && x >= PM_HW && y >= PM_HW && x < w - PM_HW && y < h - PM_HW; // PreparePixelPatch
+	float normSq0, sumW;
+	pm_fill_patch<G>(t, inb, x, y, v, s_w[g], normSq0, sumW);
+	if (!active) return;
+	const size_t idx = (size_t)y * w + x;
+	const float prior = t.prior ? t.prior[idx] : 0.f;
+	const bool valid = inb && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
+	if (!valid) {
+		if (v == 0) { t.depth[idx] = 0.f; t.normal[idx * 3] = 0.f; t.normal[idx * 3 + 1] = 0.f; t.normal[idx * 3 + 2] = 0.f; t.conf[idx] = 2.f; }
+		return;
+	}
+	const double X0x = ((double)x - t.cx) / t.fx, X0y = ((double)y - t.cy) / t.fy;
+	const float vx = (float)X0x, vy = (float)X0y, vz = 1.f;
+	float depth = t.depth[idx];
+	float nx = t.normal[idx * 3], ny = t.normal[idx * 3 + 1], nz = t.normal[idx * 3 + 2];
+	const PmPhilox4 r = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_INIT * 256), 0u, t.k0, t.k1base + pass);
+	if (!pm_in_range(depth, t.dMin, t.dMax)) {
+		const float rr = t.dMinSqr + (t.dMaxSqr - t.dMinSqr) * pm_u32_to_unit(r.v[0]);
+		depth = rr * rr;
+		pm_random_normal(pm_u32_to_unit(r.v[1]), pm_u32_to_unit(r.v[2]), vx, vy, vz, nx, ny, nz);
+	} else if (nx * vx + ny * vy + nz * vz >= 0) {
+		pm_random_normal(pm_u32_to_unit(r.v[1]), pm_u32_to_unit(r.v[2]), vx, vy, vz, nx, ny, nz);
+	}
+	float sc = PM_INF;
+	if (v < t.nSrc)
+		sc = pm_score_view<GEO>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, 0u, prior);
+	const float conf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
+	if (v == 0) { t.depth[idx] = depth; t.normal[idx * 3] = nx; t.normal[idx * 3 + 1] = ny; t.normal[idx * 3 + 2] = nz; t.conf[idx] = conf; }
+}
+
+// -------------------------------------------------------------------------------------------
+// ProcessPixel, DepthMap.cpp:630-852, for all pixels of anti-diagonal x+y == d (x = xlo + i).
+// dir 0 = LT2RB (left/top are new), 1 = RB2LT (right/bottom are new).
+template <int G, bool GEO>
+__global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
+	constexpr int PPB = PM_BLOCK / G;
+	constexpr int SL = (G >= 4) ? 1 : 4 / G; // smoothness slots owned per lane
+	__shared__ float2 s_w[PPB][PM_NT + 1];
+	const PMTask& t = tasks[blockIdx.y];
+	const int g = threadIdx.x / G, v = threadIdx.x % G;
+	const int w = t.w, h = t.h;
+	const int pi = blockIdx.x * PPB + g;
+	const bool active = pi < count;
+	const int x = xlo + (active ? pi : 0), y = d - x;
+	float normSq0, sumW;
+	pm_fill_patch<G>(t, active, x, y, v, s_w[g], normSq0, sumW);
+	const size_t idx = (size_t)y * w + x;
+	const float prior = (active && t.prior) ? t.prior[idx] : 0.f;
+	const bool valid = active && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
+	const double X0x = ((double)x - t.cx) / t.fx, X0y = ((double)y - t.cy) / t.fy;
+	const float vx = (float)X0x, vy = (float)X0y, vz = 1.f;
+
+	float depth = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, conf = 2.f;
+	// neighbour slots in insertion order (DepthMap.cpp:641-766): with sgn = -1 (LT2RB) / +1 (RB2LT):
+	// slot0 (x+sgn,y), slot1 (x,y+sgn) are the already-updated propagation sources; slot2 (x-sgn,y), slot3 (x,y-sgn).
+	const int sgn = dir == 0 ? -1 : 1;
+	float pd0 = 0.f, pnx0 = 0.f, pny0 = 0.f, pnz0 = 0.f, pconf0 = 2.f; bool pok0 = false; // propagation candidate, slot 0
+	float pd1 = 0.f, pnx1 = 0.f, pny1 = 0.f, pnz1 = 0.f, pconf1 = 2.f; bool pok1 = false; // slot 1
+	float qX0[SL], qX1[SL], qX2[SL], qn0[SL], qn1[SL], qn2[SL]; // my smoothness slot(s)
+	unsigned closeMask = 0u;
+#pragma unroll
+	for (int q = 0; q < SL; ++q) { qX0[q] = qX1[q] = qX2[q] = 0.f; qn0[q] = qn1[q] = 0.f; qn2[q] = 1.f; }
+	if (valid) {
+		depth = t.depth[idx]; nx = t.normal[idx * 3]; ny = t.normal[idx * 3 + 1]; nz = t.normal[idx * 3 + 2]; conf = t.conf[idx];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int ox = (k == 0) ? sgn : (k == 2 ? -sgn : 0), oy = (k == 1) ? sgn : (k == 3 ? -sgn : 0);
+			const int qx = x + ox, qy = y + oy;
+			// bounds tests exactly as written: x > HW / y > HW / x < W-HW / y < H-HW
+			bool ok;
+			if (ox == -1) ok = x > PM_HW; else if (ox == 1) ok = x < w - PM_HW; else if (oy == -1) ok = y > PM_HW; else ok = y < h - PM_HW;
+			float nd = 0.f;
+			const size_t qi = (size_t)qy * w + qx;
+			if (ok) { nd = t.depth[qi]; ok = nd > 0; }
+			if (ok) closeMask |= 1u << k;
+			if (k == 0 && ok) { pok0 = true; pd0 = nd; pnx0 = t.normal[qi * 3]; pny0 = t.normal[qi * 3 + 1]; pnz0 = t.normal[qi * 3 + 2]; pconf0 = t.conf[qi]; }
+			if (k == 1 && ok) { pok1 = true; pd1 = nd; pnx1 = t.normal[qi * 3]; pny1 = t.normal[qi * 3 + 1]; pnz1 = t.normal[qi * 3 + 2]; pconf1 = t.conf[qi]; }
+			if (ok && (k % G) == v) {
+				const int q = (k / G < SL) ? k / G : 0;
+				// TransformPointI2C(Point3(nx, ndepth)) in double then Cast<float>, Camera.h:338-344
+				const double z = (double)nd;
+				qX0[q] = (float)(((double)qx - t.cx) * z / t.fx);
+				qX1[q] = (float)(((double)qy - t.cy) * z / t.fy);
+				qX2[q] = (float)z;
+				qn0[q] = t.normal[qi * 3]; qn1[q] = t.normal[qi * 3 + 1]; qn2[q] = t.normal[qi * 3 + 2];
+			}
+		}
+	}
+	// state machine: every outer trip scores at most one hypothesis per pixel, so the lanes of a wave
+	// stay converged on the expensive part whatever branch each pixel is in.
+	enum { ST_PROP0 = 0, ST_PROP1 = 1, ST_DECIDE = 2, ST_RAND = 3, ST_REFINE = 4, ST_DONE = 5 };
+	int st = valid ? ST_PROP0 : ST_DONE;
+	unsigned it = 0, idxScale = 0;
+	float scaleRange = 1.f, depthRange = 0.f, p0 = 0.f, p1 = 0.f;
+	bool smooth = true, changed = false;
+	const uint32_t k1 = t.k1base + pass;
+	for (;;) {
+		bool need = false;
+		float hd = 0.f, hnx = 0.f, hny = 0.f, hnz = 1.f, hp0 = 0.f, hp1 = 0.f;
+		int hst = ST_DONE;
+		while (!need && st != ST_DONE) {
+			if (st <= ST_PROP1) {
+				const bool vert = (st == ST_PROP1); ++st; // slot 0: same row, slot 1: same column
+				const bool pok = vert ? pok1 : pok0;
+				const float pconf = vert ? pconf1 : pconf0;
+				if (pok && pconf < kp.thKeep) {
+					// InterpolatePixel, DepthMap.cpp:915-959
+					const float cnx = vert ? pnx1 : pnx0, cny = vert ? pny1 : pny0, cnz = vert ? pnz1 : pnz0, cd = vert ? pd1 : pd0;
+					float depthNew = cd; bool zero;
+					if (vert) { // same column
+						const float nx1 = (float)(((double)y - t.cy) / t.fy);
+						const float denom = cnz + nx1 * cny;
+						zero = pm_fabsf(denom) < 0.0001f;
+						const float x1 = (float)(((double)(y + sgn) - t.cy) / t.fy);
+						const float nom = cd * (cnz + x1 * cny);
+						if (!zero) depthNew = nom / denom;
+					} else {
+						const float nx1 = (float)(((double)x - t.cx) / t.fx);
+						const float denom = cnz + nx1 * cnx;
+						zero = pm_fabsf(denom) < 0.0001f;
+						const float x1 = (float)(((double)(x + sgn) - t.cx) / t.fx);
+						const float nom = cd * (cnz + x1 * cnx);
+						if (!zero) depthNew = nom / denom;
+					}
+					hd = (!zero && pm_in_range(depthNew, t.dMin, t.dMax)) ? depthNew : cd;
+					hnx = cnx; hny = cny; hnz = cnz;
+					pm_correct_normal(vx, vy, vz, hnx, hny, hnz);
+					need = true; hst = ST_PROP0;
+				}
+			} else if (st == ST_DECIDE) {
+				// RefineIters:, DepthMap.cpp:802-827
+				if (conf <= kp.thConfSmall) idxScale = 2;
+				else if (conf <= kp.thConfBig) idxScale = 1;
+				else if (conf >= kp.thConfRand) { smooth = false; st = ST_RAND; it = 0; continue; }
+				scaleRange = pm_pow2neg(idxScale);
+				depthRange = depth * kp.depthRatio;
+				p0 = pm_atan2f(ny, nx); p1 = pm_acosf(pm_clampf(nz, -1.f, 1.f)); // Normal2Dir
+				st = ST_REFINE; it = 0;
+			} else if (st == ST_RAND) {
+				if (it >= kp.nRandomIters) { st = ST_DONE; break; }
+				const PmPhilox4 r = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_RAND * 256) + it, 0u, t.k0, k1);
+				++it;
+				const float rr = t.dMinSqr + (t.dMaxSqr - t.dMinSqr) * pm_u32_to_unit(r.v[0]);
+				hd = rr * rr;
+				pm_random_normal(pm_u32_to_unit(r.v[1]), pm_u32_to_unit(r.v[2]), vx, vy, vz, hnx, hny, hnz);
+				need = true; hst = ST_RAND;
+			} else { // ST_REFINE, DepthMap.cpp:832-852
+				if (it >= kp.nRandomIters) { st = ST_DONE; break; }
+				const PmPhilox4 r = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_REFINE * 256) + it, 0u, t.k0, k1);
+				++it;
+				const float ndepth = depth + (depthRange * scaleRange) * (2.f * pm_u32_to_unit(r.v[0]) - 1.f);
+				if (!pm_in_range(ndepth, t.dMin, t.dMax)) continue;
+				hp0 = p0 + (kp.angle1Range * scaleRange) * (2.f * pm_u32_to_unit(r.v[1]) - 1.f);
+				hp1 = p1 + (kp.angle2Range * scaleRange) * (2.f * pm_u32_to_unit(r.v[2]) - 1.f);
+				pm_dir2normal(hp0, hp1, hnx, hny, hnz);
+				if (hnx * vx + hny * vy + hnz * vz >= 0) continue;
+				hd = ndepth;
+				need = true; hst = ST_REFINE;
+			}
+		}
+		if (!__any(need)) break;
+		// smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533
+		float sf[4] = {1.f, 1.f, 1.f, 1.f};
+		unsigned sfValid = 0u;
+		{
+			const bool useS = need && smooth;
+			const float planeD = -hd * (hnx * vx + hny * vy + hnz * vz); // InitPlane, DepthMap.cpp:963-971
+			float myF[SL];
+#pragma unroll
+			for (int q = 0; q < SL; ++q) {
+				myF[q] = 1.f;
+				const int k = q * G + v;
+				if (useS && k < 4 && ((closeMask >> k) & 1u)) {
+					const float dist = (hnx * qX0[q] + (hny * qX1[q] + hnz * qX2[q])) + planeD; // Planef::Distance, Eigen 3-dot order
+					const float r = dist / hd;
+					const float factorDepth = pm_expf((r * r) * kp.smoothSigmaDepth);
+					const float ca = pm_clampf((hnx * qn0[q] + hny * qn1[q] + hnz * qn2[q]) /
+						pm_sqrtf((hnx * hnx + hny * hny + hnz * hnz) * (qn0[q] * qn0[q] + qn1[q] * qn1[q] + qn2[q] * qn2[q])), -1.f, 1.f);
+					const float ac = pm_acosf(ca);
+					const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
+					myF[q] = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				sf[k] = __shfl(myF[k / G < SL ? k / G : 0], (k % G), G);
+			if (useS) sfValid = closeMask;
+		}
+		float sc = PM_INF;
+		if (need && v < t.nSrc)
+			sc = pm_score_view<GEO>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], sfValid, prior);
+		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
+		if (need && conf > nconf) {
+			conf = nconf; depth = hd; nx = hnx; ny = hny; nz = hnz; changed = true;
+			if (hst == ST_RAND) { if (conf < kp.thConfRand) st = ST_DECIDE; }
+			else if (hst == ST_REFINE) { p0 = hp0; p1 = hp1; scaleRange = pm_pow2neg(++idxScale); }
+		}
+	}
+	if (changed && v == 0) { t.depth[idx] = depth; t.normal[idx * 3] = nx; t.normal[idx * 3 + 1] = ny; t.normal[idx * 3 + 2] = nz; t.conf[idx] = conf; }
+}
+
+// EndDepthMapTmp, SceneDensify.cpp:528-576
+__global__ void pm_finalize_kernel(const PMTask* __restrict__ tasks, float thKeep) {
+	const PMTask& t = tasks[blockIdx.y];
+	const size_t n = (size_t)t.w * t.h;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const float depth = t.depth[i], conf = t.conf[i];
+		if (depth <= 0 || conf >= thKeep) { t.conf[i] = 0.f; t.depth[i] = 0.f; t.normal[i * 3] = 0.f; t.normal[i * 3 + 1] = 0.f; t.normal[i * 3 + 2] = 0.f; }
+		else t.conf[i] = conf >= 1.f ? 0.f : 1.f - conf;
+	}
+}
+
+// ---- resampling (cv::resize restated; see oracle header for the conventions) ---------------
+// INTER_AREA, integer factor f (ScaleDepthData, SceneDensify.cpp:586): dst[img][y][x]
+__global__ void pm_area_kernel(const float* __restrict__ src, float* __restrict__ dst, int sw, int sh, int f, int nImg) {
+	const int dw = sw / f, dh = sh / f;
+	const size_t n = (size_t)dw * dh * nImg;
+	const float scale = 1.f / (float)(f * f);
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const int x = (int)(i % dw), y = (int)((i / dw) % dh); const size_t im = i / ((size_t)dw * dh);
+		const float* s = src + im * (size_t)sw * sh;
+		float o;
+		if (f == 2) {
+			const float* p = s + (size_t)(2 * y) * sw + 2 * x;
+			o = ((p[0] + p[1]) + (p[sw] + p[sw + 1])) * 0.25f;
+		} else {
+			float sum = 0.f;
+			for (int j = 0; j < f; ++j) for (int k = 0; k < f; ++k) sum += s[(size_t)(y * f + j) * sw + (x * f + k)];
+			o = sum * scale;
+		}
+		dst[i] = o;
+	}
+}
+__device__ __forceinline__ void pm_linear_coef(int d, int dn, int sn, int& s, float& a) {
+	const double scale = (double)sn / (double)dn;
+	float f = (float)(((double)d + 0.5) * scale - 0.5);
+	int si = (int)pm_floorf(f);
+	f -= (float)si;
+	if (si < 0) { f = 0.f; si = 0; }
+	if (si >= sn - 1) { f = 0.f; si = sn - 1; }
+	s = si; a = f;
+}
+// level hand-off (SceneDensify.cpp:660-664): depth INTER_LINEAR, normal INTER_NEAREST, prior = copy of depth
+struct PMUpTask { const float* sdepth; const float* snormal; float* ddepth; float* dnormal; float* dprior; };
+__global__ void pm_upsample_kernel(const PMUpTask* __restrict__ ups, int sw, int sh, int dw, int dh) {
+	const PMUpTask u = ups[blockIdx.y];
+	const size_t n = (size_t)dw * dh;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const int x = (int)(i % dw), y = (int)(i / dw);
+		int x0, y0; float a1, b1;
+		pm_linear_coef(x, dw, sw, x0, a1); pm_linear_coef(y, dh, sh, y0, b1);
+		const int x1 = min(x0 + 1, sw - 1), y1 = min(y0 + 1, sh - 1);
+		const float a0 = 1.f - a1, b0 = 1.f - b1;
+		const float t0 = u.sdepth[(size_t)y0 * sw + x0] * a0 + u.sdepth[(size_t)y0 * sw + x1] * a1;
+		const float t1 = u.sdepth[(size_t)y1 * sw + x0] * a0 + u.sdepth[(size_t)y1 * sw + x1] * a1;
+		const float dv = t0 * b0 + t1 * b1;
+		u.ddepth[i] = dv; u.dprior[i] = dv;
+		const int nx = min((int)floor((double)x * ((double)sw / (double)dw)), sw - 1);
+		const int ny = min((int)floor((double)y * ((double)sh / (double)dh)), sh - 1);
+		const size_t si = (size_t)ny * sw + nx;
+		u.dnormal[i * 3] = u.snormal[si * 3]; u.dnormal[i * 3 + 1] = u.snormal[si * 3 + 1]; u.dnormal[i * 3 + 2] = u.snormal[si * 3 + 2];
+	}
+}
+// INTER_NEAREST down-sampling of the initial estimate to the coarsest level (ScaleDepthData, SceneDensify.cpp:596-599)
+__global__ void pm_nearest_down_kernel(const PMUpTask* __restrict__ ups, int sw, int sh, int dw, int dh) {
+	const PMUpTask u = ups[blockIdx.y];
+	const size_t n = (size_t)dw * dh;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const int x = (int)(i % dw), y = (int)(i / dw);
+		const int nx = min((int)floor((double)x * ((double)sw / (double)dw)), sw - 1);
+		const int ny = min((int)floor((double)y * ((double)sh / (double)dh)), sh - 1);
+		const size_t si = (size_t)ny * sw + nx;
+		u.ddepth[i] = u.sdepth[si];
+		u.dnormal[i * 3] = u.snormal[si * 3]; u.dnormal[i * 3 + 1] = u.snormal[si * 3 + 1]; u.dnormal[i * 3 + 2] = u.snormal[si * 3 + 2];
+	}
+}
+__global__ void pm_nearest_up_f_kernel(const float* __restrict__ s, float* __restrict__ d, int sw, int sh, int dw, int dh) {
+	const size_t n = (size_t)dw * dh;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const int x = (int)(i % dw), y = (int)(i / dw);
+		const int nx = min((int)floor((double)x * ((double)sw / (double)dw)), sw - 1);
+		const int ny = min((int)floor((double)y * ((double)sh / (double)dh)), sh - 1);
+		d[i] = s[(size_t)ny * sw + nx];
+	}
+}
+
+// pm_math.h on the device (self-test hook)
+__global__ void pm_math_kernel(int kind, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		float s, c;
+		switch (kind) {
+		case 0: o[i] = pm_expf(a[i]); break;
+		case 1: o[i] = pm_acosf(a[i]); break;
+		case 2: o[i] = pm_atan2f(a[i], b[i]); break;
+		case 3: pm_sincosf(a[i], &s, &c); o[i] = s; break;
+		case 4: pm_sincosf(a[i], &s, &c); o[i] = c; break;
+		case 5: o[i] = pm_sqrtf(a[i]); break;
+		default: o[i] = a[i] / b[i]; break;
+		}
+	}
+}

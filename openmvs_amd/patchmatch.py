@@ -1,0 +1,229 @@
+"""ctypes binding of libpmhip.so -- the host-side mirror of the reference's GPU plug-in.
+
+`PatchMatchHIP` has the same four-method surface as the reference's `PatchMatchCUDA`
+(libs/MVS/PatchMatchCUDA.inl:102-108: ctor(device), Init(bGeomConsistency), Release(),
+EstimateDepthMap(DepthData&)), plus the HBM-resident scene interface of include/pmhip.h.
+There is no CPU fallback: if the HIP library or a GPU is missing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MAX_SOURCES = 16
+
+
+class PMHipParams(C.Structure):
+    _fields_ = [("nSubResolutionLevels", C.c_uint32), ("nEstimationIters", C.c_uint32),
+                ("nEstimationGeometricIters", C.c_uint32), ("nRandomIters", C.c_uint32),
+                ("fEstimationGeometricWeight", C.c_float), ("fRandomDepthRatio", C.c_float),
+                ("fRandomAngle1Range", C.c_float), ("fRandomAngle2Range", C.c_float),
+                ("fRandomSmoothDepth", C.c_float), ("fRandomSmoothNormal", C.c_float),
+                ("fRandomSmoothBonus", C.c_float), ("fNCCThresholdKeep", C.c_float),
+                ("fDescriptorMinMagnitudeThreshold", C.c_float), ("seed", C.c_uint32)]
+
+
+class PMHipView(C.Structure):
+    _fields_ = [("image", C.POINTER(C.c_float)), ("w", C.c_int32), ("h", C.c_int32),
+                ("K", C.c_double * 9), ("R", C.c_double * 9), ("C", C.c_double * 3),
+                ("depth", C.POINTER(C.c_float)),
+                ("Kd", C.c_double * 9), ("Rd", C.c_double * 9), ("Cd", C.c_double * 3),
+                ("id", C.c_uint32)]
+
+
+class PMHipDepthData(C.Structure):
+    _fields_ = [("views", C.POINTER(PMHipView)), ("nViews", C.c_int32),
+                ("depthMap", C.POINTER(C.c_float)), ("normalMap", C.POINTER(C.c_float)),
+                ("confMap", C.POINTER(C.c_float)), ("dMin", C.c_float), ("dMax", C.c_float)]
+
+
+class PMHipKernelStats(C.Structure):
+    _fields_ = [("sweepLaunches", C.c_uint64), ("sweepMs", C.c_double), ("sweepBytes", C.c_double),
+                ("sweepPixels", C.c_uint64), ("initLaunches", C.c_uint64), ("initMs", C.c_double)]
+
+
+EXPORTS = ["pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
+           "pmhip_estimate_depth_map", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
+           "pmhip_scene_estimate", "pmhip_scene_commit_round", "pmhip_scene_reset_view", "pmhip_scene_set_maps",
+           "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_images_updated", "pmhip_sync",
+           "pmhip_stream", "pmhip_stats_reset", "pmhip_stats_get", "pmhip_math_eval", "pmhip_resize"]
+
+_LIB = None
+
+
+def load_library() -> C.CDLL:
+    """Load libpmhip.so (building it first when the sources are newer).  Fails loudly."""
+    global _LIB
+    if _LIB is None:
+        path = _build.build_lib("libpmhip.so")
+        if path is None or not os.path.exists(path):
+            raise RuntimeError("libpmhip.so is not built (python -m openmvs_amd.build)")
+        lib = C.CDLL(path)
+        lib.pmhip_last_error.restype = C.c_char_p
+        lib.pmhip_scene_device_ptr.restype = C.c_void_p
+        lib.pmhip_stream.restype = C.c_void_p
+        lib.pmhip_destroy.restype = None
+        for n in EXPORTS:
+            getattr(lib, n)  # raises AttributeError if a declared symbol is missing
+        _LIB = lib
+    return _LIB
+
+
+def default_params(**kw) -> PMHipParams:
+    p = PMHipParams()
+    load_library().pmhip_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class PatchMatchError(RuntimeError):
+    pass
+
+
+class PatchMatchHIP:
+    """Mirror of `class PatchMatchCUDA` (libs/MVS/PatchMatchCUDA.inl:76-139)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.pmhip_create(C.c_int(device), C.byref(self._h))
+        if rc != 0:
+            raise PatchMatchError(f"pmhip_create failed ({rc}): no usable MI355X / HIP device")
+        self.params = default_params()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PatchMatchError(f"pmhip error {rc}: {self._lib.pmhip_last_error(self._h).decode()}")
+
+    # -- the four reference methods ---------------------------------------------------------
+    def Init(self, bGeomConsistency: bool):
+        self._chk(self._lib.pmhip_init(self._h, C.c_int(1 if bGeomConsistency else 0)))
+
+    def Release(self):
+        if self._h:
+            self._chk(self._lib.pmhip_release(self._h))
+
+    def EstimateDepthMap(self, gray, K, R, Cc, ids, dmin, dmax, depth=None, normal=None, src_depths=None,
+                         nGeometricIter: int = -1, params: PMHipParams | None = None):
+        """One depth map.  ids[0] = reference view, ids[1:] = sources (indices into gray/K/R/Cc).
+        src_depths: dict id -> depth map, required for a geometric round.  Returns (depth, normal, conf)."""
+        p = params or self.params
+        n = len(ids)
+        views = (PMHipView * n)()
+        keep = []
+        for k, i in enumerate(ids):
+            img = np.ascontiguousarray(gray[i], np.float32); keep.append(img)
+            v = views[k]
+            v.image = _fp(img); v.h, v.w = img.shape
+            v.K[:] = np.asarray(K[i], np.float64).ravel(); v.R[:] = np.asarray(R[i], np.float64).ravel(); v.C[:] = np.asarray(Cc[i], np.float64).ravel()
+            v.id = int(i)
+            if k > 0 and src_depths is not None:
+                d = np.ascontiguousarray(src_depths[i], np.float32); keep.append(d)
+                v.depth = _fp(d); v.Kd[:] = v.K[:]; v.Rd[:] = v.R[:]; v.Cd[:] = v.C[:]
+        h, w = keep[0].shape
+        depth = np.zeros((h, w), np.float32) if depth is None else np.ascontiguousarray(depth, np.float32).copy()
+        normal = np.zeros((h, w, 3), np.float32) if normal is None else np.ascontiguousarray(normal, np.float32).copy()
+        conf = np.zeros((h, w), np.float32)
+        dd = PMHipDepthData(views, n, _fp(depth), _fp(normal), _fp(conf), float(dmin), float(dmax))
+        self._chk(self._lib.pmhip_estimate_depth_map(self._h, C.byref(dd), C.byref(p), C.c_int(nGeometricIter)))
+        return depth, normal, conf
+
+    # -- HBM-resident scene interface --------------------------------------------------------
+    def scene_create(self, n_images, w, h, n_levels=2):
+        self._chk(self._lib.pmhip_scene_create(self._h, n_images, w, h, n_levels))
+        self._scene = (n_images, w, h)
+
+    def scene_set_view(self, idx, gray, K, R, Cc, dmin, dmax, neighbors, device_ptr=None):
+        K = np.ascontiguousarray(K, np.float64); R = np.ascontiguousarray(R, np.float64); Cc = np.ascontiguousarray(Cc, np.float64)
+        nb = np.ascontiguousarray(neighbors, np.int32)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        if device_ptr is not None:
+            src, ondev = C.cast(C.c_void_p(device_ptr), C.POINTER(C.c_float)), 1
+        elif gray is None:
+            src, ondev = None, 0
+        else:
+            g = np.ascontiguousarray(gray, np.float32); src, ondev = _fp(g), 0
+        self._chk(self._lib.pmhip_scene_set_view(self._h, idx, src, ondev, dp(K), dp(R), dp(Cc), C.c_float(dmin), C.c_float(dmax),
+                                                 nb.ctypes.data_as(C.POINTER(C.c_int32)), len(nb)))
+
+    def scene_load(self, scene, n_levels=2):
+        """Upload a synth.Scene (or anything with the same attributes)."""
+        self.scene_create(scene.n_views, scene.width, scene.height, n_levels)
+        for i in range(scene.n_views):
+            self.scene_set_view(i, scene.gray[i], scene.K[i], scene.R[i], scene.C[i], float(scene.dmin[i]), float(scene.dmax[i]), scene.neighbors[i])
+
+    def scene_estimate(self, view_ids, nGeometricIter=-1, params=None, sync=True):
+        ids = np.ascontiguousarray(view_ids, np.int32)
+        p = params or self.params
+        self._chk(self._lib.pmhip_scene_estimate(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), len(ids), C.byref(p),
+                                                 C.c_int(nGeometricIter), C.c_int(1 if sync else 0)))
+
+    def scene_commit_round(self):
+        self._chk(self._lib.pmhip_scene_commit_round(self._h))
+
+    def scene_reset_view(self, idx):
+        self._chk(self._lib.pmhip_scene_reset_view(self._h, idx))
+
+    def scene_set_maps(self, idx, depth=None, normal=None):
+        d = None if depth is None else np.ascontiguousarray(depth, np.float32)
+        n = None if normal is None else np.ascontiguousarray(normal, np.float32)
+        self._chk(self._lib.pmhip_scene_set_maps(self._h, idx, _fp(d) if d is not None else None, _fp(n) if n is not None else None))
+
+    def scene_get_maps(self, idx):
+        _, w, h = self._scene
+        d = np.zeros((h, w), np.float32); n = np.zeros((h, w, 3), np.float32); c = np.zeros((h, w), np.float32)
+        self._chk(self._lib.pmhip_scene_get_maps(self._h, idx, _fp(d), _fp(n), _fp(c)))
+        return d, n, c
+
+    def scene_device_ptr(self, what, idx=0) -> int:
+        return int(self._lib.pmhip_scene_device_ptr(self._h, what, idx) or 0)
+
+    def scene_images_updated(self):
+        self._chk(self._lib.pmhip_scene_images_updated(self._h))
+
+    def sync(self):
+        self._chk(self._lib.pmhip_sync(self._h))
+
+    def stream(self) -> int:
+        return int(self._lib.pmhip_stream(self._h) or 0)
+
+    def stats_reset(self, enable=True):
+        self._chk(self._lib.pmhip_stats_reset(self._h, 1 if enable else 0))
+
+    def stats_get(self) -> PMHipKernelStats:
+        s = PMHipKernelStats()
+        self._chk(self._lib.pmhip_stats_get(self._h, C.byref(s)))
+        return s
+
+    # -- self-test hooks -----------------------------------------------------------------------
+    def math_eval(self, kind, a, b=None):
+        a = np.ascontiguousarray(a, np.float32); b = a if b is None else np.ascontiguousarray(b, np.float32)
+        o = np.zeros_like(a)
+        self._chk(self._lib.pmhip_math_eval(self._h, kind, _fp(a), _fp(b), _fp(o), C.c_size_t(a.size)))
+        return o
+
+    def resize(self, kind, img, arg=2):
+        img = np.ascontiguousarray(img, np.float32); h, w = img.shape
+        o = np.zeros((h // arg, w // arg) if kind == 0 else (h * 2, w * 2), np.float32)
+        self._chk(self._lib.pmhip_resize(self._h, kind, _fp(img), w, h, arg, _fp(o)))
+        return o
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pmhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,178 @@
+"""CPU tests of the oracle: known-answer tests authored for this project because the reference
+pins nothing on this path, plus golden-fixture regression pins."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_zigzag_3x3_order_follows_the_code_not_the_comment():
+    # DepthMap.cpp:336-354 walks every anti-diagonal top-right -> bottom-left: 1 2 4 3 5 7 6 8 9
+    xy = po.zigzag(3, 3, 64)
+    cells = [int(y) * 3 + int(x) + 1 for x, y in xy]
+    assert cells == [1, 2, 4, 3, 5, 7, 6, 8, 9]
+
+
+@pytest.mark.parametrize("w,h,stride", [(7, 5, 64), (13, 150, 64), (40, 200, 16), (64, 129, 64)])
+def test_zigzag_visits_once_and_left_top_first(w, h, stride):
+    xy = po.zigzag(w, h, stride)
+    order = -np.ones((h, w), np.int64)
+    for i, (x, y) in enumerate(xy):
+        assert order[y, x] == -1
+        order[y, x] = i
+    assert (order >= 0).all()
+    assert (order[:, 1:] > order[:, :-1]).all()   # left neighbour earlier
+    assert (order[1:, :] > order[:-1, :]).all()   # top neighbour earlier (also across bands)
+
+
+def test_philox_known_answers():
+    import ctypes as C
+    out = (C.c_uint32 * 4)()
+    po.lib().orc_philox(0, 0, 0, 0, 0, 0, out)
+    assert [hex(v) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]   # Random123 kat_vectors
+    f = 0xFFFFFFFF
+    po.lib().orc_philox(f, f, f, f, f, f, out)
+    assert [hex(v) for v in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+
+
+def test_math_kernels_accuracy():
+    r = np.random.RandomState(0)
+    x = (-87 * r.rand(200000)).astype(np.float32)
+    assert np.max(np.abs(po.math_eval(0, x) / np.exp(x.astype(np.float64)) - 1)) < 2.5e-7
+    a = (2 * r.rand(200000) - 1).astype(np.float32)
+    assert np.max(np.abs(po.math_eval(1, a) - np.arccos(a.astype(np.float64)))) < 6e-7
+    y = (2 * r.rand(200000) - 1).astype(np.float32); z = (2 * r.rand(200000) - 1).astype(np.float32)
+    assert np.max(np.abs(po.math_eval(2, y, z) - np.arctan2(y.astype(np.float64), z.astype(np.float64)))) < 6e-7
+    t = (8 * (2 * r.rand(200000) - 1)).astype(np.float32)
+    assert np.max(np.abs(po.math_eval(3, t) - np.sin(t.astype(np.float64)))) < 2e-7
+    assert np.max(np.abs(po.math_eval(4, t) - np.cos(t.astype(np.float64)))) < 2e-7
+    assert po.math_eval(0, np.zeros(1, np.float32))[0] == 1.0 and po.math_eval(1, np.ones(1, np.float32))[0] == 0.0
+
+
+def test_resize_conventions():
+    r = np.random.RandomState(1)
+    img = r.rand(24, 32).astype(np.float32)
+    a2 = po.resize_area(img, 2)
+    ref2 = ((img[0::2, 0::2] + img[0::2, 1::2]) + (img[1::2, 0::2] + img[1::2, 1::2])) * np.float32(0.25)
+    assert np.array_equal(a2, ref2)
+    a4 = po.resize_area(img, 4)
+    assert np.allclose(a4, img.reshape(6, 4, 8, 4).mean((1, 3)), atol=1e-6)
+    up = po.resize_linear(img, 64, 48)
+    # interior: weights 0.25/0.75 around half-pixel centres; borders clamp
+    assert up[0, 0] == img[0, 0] and up[-1, -1] == img[-1, -1]
+    assert np.isclose(up[1, 1], 0.75 * (0.75 * img[0, 0] + 0.25 * img[0, 1]) + 0.25 * (0.75 * img[1, 0] + 0.25 * img[1, 1]), atol=1e-6)
+    nn = po.resize_nearest(img, 64, 48)
+    assert np.array_equal(nn, np.repeat(np.repeat(img, 2, 0), 2, 1))
+    dn = po.resize_nearest(img, 8, 6)
+    assert np.array_equal(dn, img[::4, ::4])
+
+
+def _fronto_pair(shift):
+    """Two identical cameras separated along x; a fronto-parallel plane at depth d gives a pure
+    integral shift `shift` px, so the true plane must score ~0 (ZNCC = 1)."""
+    r = np.random.RandomState(3)
+    W, H = 96, 64
+    tex = r.rand(H, W + 40).astype(np.float32)
+    ref = tex[:, 20:20 + W].copy()
+    src = tex[:, 20 + shift:20 + shift + W].copy()      # src(x) = ref(x + shift)
+    f = 100.0; d = 2.0
+    K = np.array([[f, 0, 47.5], [0, f, 31.5], [0, 0, 1]])
+    R = np.eye(3)
+    # x_src = x_ref - f*B/d  with B = C_src.x - C_ref.x  ->  want x_src = x_ref - shift
+    B = shift * d / f
+    Cs = [np.zeros(3), np.array([B, 0, 0.0])]
+    return np.stack([ref, src]), [K, K], [R, R], Cs, d
+
+
+def test_score_true_fronto_parallel_plane_is_zero():
+    gray, K, R, Cc, d = _fronto_pair(3)
+    views, keep = po.make_views(gray, K, R, Cc, [0, 1])
+    opt = po.default_opt()
+    n = np.array([0, 0, -1], np.float32)
+    rc, s, agg = po.score_pixel(views, 2, opt, 40, 30, d, n)
+    assert rc == 0 and abs(s[0]) < 1e-4 and agg == s[0]            # N == 1 -> min aggregation
+    rc, s2, _ = po.score_pixel(views, 2, opt, 40, 30, d * 1.2, n)
+    assert s2[0] > 0.3
+    # a tap leaving the source image returns thRobust = 0.9*4/3 (DepthMap.cpp:484-485)
+    rc, s3, _ = po.score_pixel(views, 2, opt, 5, 30, d, n)
+    assert np.isclose(s3[0], 1.2, atol=1e-6)
+    # border pixels are not processable (PreparePixelPatch, DepthMap.cpp:415-420)
+    assert po.score_pixel(views, 2, opt, 3, 30, d, n)[0] == 1
+
+
+def test_low_texture_rejected_unless_prior():
+    gray, K, R, Cc, d = _fronto_pair(2)
+    gray = gray.copy(); gray[0][:] = 0.5                            # textureless reference
+    views, keep = po.make_views(gray, K, R, Cc, [0, 1])
+    opt = po.default_opt()
+    n = np.array([0, 0, -1], np.float32)
+    assert po.score_pixel(views, 2, opt, 40, 30, d, n)[0] == 1      # normSq0 < 0.0004, no prior (DepthMap.cpp:458)
+    prior = np.full((64, 96), d, np.float32)
+    rc, s, _ = po.score_pixel(views, 2, opt, 40, 30, d, n, prior=prior)
+    assert rc == 0 and np.isclose(s[0], 1.2)                        # nrmSq <= 1e-16 -> thRobust (DepthMap.cpp:515)
+
+
+def test_minmean_aggregation(small_scene):
+    sc = small_scene
+    ids = [0] + list(sc.neighbors[0])
+    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+    opt = po.default_opt()
+    rc, s, agg = po.score_pixel(views, len(ids), opt, 80, 60, float(sc.gt_depth[0, 60, 80]), np.array([0, 0, -1], np.float32))
+    ss = np.sort(s)
+    exp = (ss[0] + ss[1]) / np.float32(2) if ss[1] < 1.2 else ss[0]
+    assert rc == 0 and agg == exp
+
+
+def test_estimate_converges_to_ground_truth(small_scene):
+    sc = small_scene
+    ids = [0] + list(sc.neighbors[0])
+    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+    opt = po.default_opt(nEstimationGeometricIters=0)
+    d, n, c = po.estimate_depth_map(views, len(ids), float(sc.dmin[0]), float(sc.dmax[0]), opt)
+    m = d > 0
+    rel = np.abs(d[m] - sc.gt_depth[0][m]) / sc.gt_depth[0][m]
+    assert m.mean() > 0.8 and np.median(rel) < 3e-3
+    assert (c[m] > 0).all() and (c[~m] == 0).all() and (n[~m] == 0).all()
+    assert np.allclose(np.linalg.norm(n[m], axis=-1), 1, atol=1e-4)
+    # deterministic
+    d2, n2, c2 = po.estimate_depth_map(views, len(ids), float(sc.dmin[0]), float(sc.dmax[0]), opt)
+    assert np.array_equal(d, d2) and np.array_equal(n, n2) and np.array_equal(c, c2)
+
+
+def test_mt19937_mode_is_statistically_equivalent(small_scene):
+    sc = small_scene
+    ids = [0] + list(sc.neighbors[0])
+    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+    res = []
+    for mode in (0, 1):
+        opt = po.default_opt(nEstimationGeometricIters=0, rngMode=mode)
+        d, _, _ = po.estimate_depth_map(views, len(ids), float(sc.dmin[0]), float(sc.dmax[0]), opt)
+        m = d > 0
+        res.append((m.mean(), np.median(np.abs(d[m] - sc.gt_depth[0][m]) / sc.gt_depth[0][m])))
+    assert abs(res[0][0] - res[1][0]) < 0.03 and abs(res[0][1] - res[1][1]) < 1e-3
+
+
+def test_threaded_baseline_mode_runs(small_scene):
+    sc = small_scene
+    ids = [0] + list(sc.neighbors[0])
+    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+    opt = po.default_opt(nEstimationGeometricIters=0, nThreads=4)
+    d, _, _ = po.estimate_depth_map(views, len(ids), float(sc.dmin[0]), float(sc.dmax[0]), opt)
+    m = d > 0
+    assert m.mean() > 0.8 and np.median(np.abs(d[m] - sc.gt_depth[0][m]) / sc.gt_depth[0][m]) < 3e-3
+
+
+def test_golden_fixture_pins_the_oracle():
+    g = np.load(os.path.join(GOLD, "pm_golden_96x64.npz"))
+    from openmvs_amd import synth
+    sc = synth.make_scene(int(g["n_views"]), 96, 64, n_src=int(g["n_src"]))
+    assert np.array_equal(sc.gray, g["gray"])                       # generator is part of the pin
+    ids = [0] + list(sc.neighbors[0])
+    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+    opt = po.default_opt(seed=int(g["seed"]))
+    d, n, c = po.estimate_depth_map(views, len(ids), float(sc.dmin[0]), float(sc.dmax[0]), opt)
+    assert np.array_equal(d, g["depth_photo"]) and np.array_equal(n, g["normal_photo"]) and np.array_equal(c, g["conf_photo"])

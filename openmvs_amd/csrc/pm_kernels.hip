@@ -227,7 +227,7 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 						const float B2 = (s.Tr[6] * Xd0 + s.Tr[7] * Xd1 + s.Tr[8] * Xd2) + s.Tn[2];
 						const float xbx = B0 / B2, xby = B1 / B2;
 						const float dx = (float)x - xbx, dy = (float)y - xby;
-						const float dist = (float)sqrt((double)dx * (double)dx + (double)dy * (double)dy); // cv::norm(Point2f) -> double
+						const float dist = pm_hypot_d(dx, dy); // cv::norm(Point2f) -> double
 						consistency = pm_minf(pm_sqrtf(dist * (dist + 2.f)), consistency);
 					}
 				}
@@ -599,6 +599,7 @@ __global__ void pm_math_kernel(int kind, const float* __restrict__ a, const floa
 		case 3: pm_sincosf(a[i], &s, &c); o[i] = s; break;
 		case 4: pm_sincosf(a[i], &s, &c); o[i] = c; break;
 		case 5: o[i] = pm_sqrtf(a[i]); break;
+		case 7: o[i] = pm_hypot_d(a[i], b[i]); break;
 		default: o[i] = a[i] / b[i]; break;
 		}
 	}

@@ -54,12 +54,22 @@ PM_HD uint32_t pm_f2u(float f) {
 	return u;
 }
 
-// correctly rounded sqrt on both sides
+// correctly rounded sqrt on both sides.  NB: on gfx950/ROCm 7.2 __fsqrt_rn() lowers to a bare
+// v_sqrt_f32 (1 ulp); the builtin below gets the correctly rounded expansion under
+// -fhip-fp32-correctly-rounded-divide-sqrt (checked in tests/test_gpu_patchmatch.py).
 PM_HD float pm_sqrtf(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-	return __fsqrt_rn(x);
+	return __builtin_sqrtf(x);
 #else
 	return sqrtf(x);
+#endif
+}
+// (float)sqrt((double)a*a + (double)b*b): cv::norm(Point2f) evaluates in double (DepthMap.cpp:545)
+PM_HD float pm_hypot_d(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (float)__builtin_sqrt((double)a * (double)a + (double)b * (double)b);
+#else
+	return (float)sqrt((double)a * (double)a + (double)b * (double)b);
 #endif
 }
 PM_HD float pm_floorf(float x) {

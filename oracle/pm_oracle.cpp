@@ -424,7 +424,7 @@ struct DepthEstimator {
 						for (int i = 0; i < 3; ++i) Xb[i] = (image1.Tr[i*3]*Xd[0] + image1.Tr[i*3+1]*Xd[1] + image1.Tr[i*3+2]*Xd[2]) + image1.Tn[i];
 						const float xbx = Xb[0] / Xb[2], xby = Xb[1] / Xb[2];
 						const float dx = (float)x0x - xbx, dy = (float)x0y - xby;
-						const float dist = (float)sqrt((double)dx*dx + (double)dy*dy); // cv::norm(Point2f) is double
+						const float dist = pm_hypot_d(dx, dy); // cv::norm(Point2f) is double
 						consistency = pm_minf(pm_sqrtf(dist * (dist + 2.f)), consistency);
 					}
 				}
@@ -900,6 +900,7 @@ void orc_math_eval(int kind, const float* a, const float* b, float* o, size_t n)
 		case 3: pm_sincosf(a[i], &s, &c); o[i] = s; break;
 		case 4: pm_sincosf(a[i], &s, &c); o[i] = c; break;
 		case 5: o[i] = pm_sqrtf(a[i]); break;
+		case 7: o[i] = pm_hypot_d(a[i], b[i]); break;
 		default: o[i] = a[i] / b[i]; break;
 		}
 	}

@@ -29,7 +29,8 @@ def test_device_math_is_bitwise_identical_to_host():
     cases = [(0, (-90 * r.rand(n)).astype(np.float32), None), (1, (2 * r.rand(n) - 1).astype(np.float32), None),
              (2, r.randn(n).astype(np.float32), r.randn(n).astype(np.float32)),
              (3, (8 * (2 * r.rand(n) - 1)).astype(np.float32), None), (4, (8 * (2 * r.rand(n) - 1)).astype(np.float32), None),
-             (5, (100 * r.rand(n)).astype(np.float32), None), (6, r.randn(n).astype(np.float32), (r.randn(n) + 3).astype(np.float32))]
+             (5, (100 * r.rand(n)).astype(np.float32), None), (6, r.randn(n).astype(np.float32), (r.randn(n) + 3).astype(np.float32)),
+             (7, (3 * r.randn(n)).astype(np.float32), (3 * r.randn(n)).astype(np.float32))]
     for kind, a, b in cases:
         _same(e.math_eval(kind, a, b), po.math_eval(kind, a, b), f"pm_math kind {kind}")
     e.close()

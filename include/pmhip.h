@@ -124,6 +124,10 @@ int pmhip_scene_get_maps(pmhip_engine* e, int idx, float* depth, float* normal, 
  * what: 0 image level 0, 1 depth, 2 normal, 3 conf, 4 snapshot depth.  The per-kind arrays are
  * single contiguous allocations ordered by view index, so idx 0 addresses the whole set. */
 void* pmhip_scene_device_ptr(pmhip_engine* e, int what, int idx);
+/* Device-to-device copy between a caller buffer (e.g. a torch tensor used for an RCCL collective)
+ * and `count` consecutive views of one per-kind array, starting at view firstIdx; `what` as above.
+ * toEngine != 0 copies caller -> engine.  Asynchronous on the engine stream. */
+int pmhip_scene_copy(pmhip_engine* e, int what, int firstIdx, int count, void* devPtr, int toEngine);
 /* Rebuild image pyramids after image level 0 was written through pmhip_scene_device_ptr. */
 int pmhip_scene_images_updated(pmhip_engine* e);
 int pmhip_sync(pmhip_engine* e);

@@ -496,6 +496,17 @@ void* pmhip_scene_device_ptr(pmhip_engine* e, int what, int idx) {
 	}
 }
 
+int pmhip_scene_copy(pmhip_engine* e, int what, int firstIdx, int count, void* devPtr, int toEngine) {
+	if (!e || !devPtr || count <= 0 || firstIdx < 0 || firstIdx + count > e->nImages) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	char* base = (char*)pmhip_scene_device_ptr(e, what, firstIdx);
+	if (!base) return PMHIP_E_ARG;
+	const size_t bytes = sizeof(float) * (size_t)e->w * e->h * (what == 2 ? 3 : 1) * count;
+	HIPCHK(e, hipMemcpyAsync(toEngine ? (void*)base : devPtr, toEngine ? devPtr : (void*)base, bytes, hipMemcpyDeviceToDevice, e->stream));
+	if (toEngine && what == 0) e->pyramidDirty = true;
+	return 0;
+}
+
 int pmhip_sync(pmhip_engine* e) { if (!e) return PMHIP_E_ARG; HIPCHK(e, hipSetDevice(e->device)); HIPCHK(e, hipStreamSynchronize(e->stream)); return 0; }
 void* pmhip_stream(pmhip_engine* e) { return e ? (void*)e->stream : nullptr; }
 

@@ -56,10 +56,11 @@ def _albedo(x, y, ap, ch):
     return v
 
 
-def make_scene(n_views: int, width: int, height: int, n_src: int = 8, seed: int = SEED,
-               device: str | torch.device = "cpu", spacing: float = 0.12, grid_cols: int | None = None,
-               gray_only: bool = False) -> Scene:
-    """Render `n_views` views of the seeded scene at width x height."""
+def make_scene_torch(n_views: int, width: int, height: int, n_src: int = 8, seed: int = SEED,
+                     device: str | torch.device = "cpu", spacing: float = 0.12, grid_cols: int | None = None,
+                     want_bgr: bool = False, gt_views: int | None = None) -> dict:
+    """Render `n_views` views of the seeded scene; images stay torch tensors on `device`.
+    gt_views: keep ground-truth depth only for the first gt_views views (None = all)."""
     rng = np.random.RandomState(seed)
     dev = torch.device(device)
     S = 1.0
@@ -99,10 +100,15 @@ def make_scene(n_views: int, width: int, height: int, n_src: int = 8, seed: int 
     u = torch.arange(width, device=dev, dtype=torch.float64)
     v = torch.arange(height, device=dev, dtype=torch.float64)
     vv, uu = torch.meshgrid(v, u, indexing="ij")
-    gray = np.zeros((n_views, height, width), np.float32)
-    bgr = None if gray_only else np.zeros((n_views, height, width, 3), np.uint8)
-    gt = np.zeros((n_views, height, width), np.float32)
+    n_gt = n_views if gt_views is None else min(gt_views, n_views)
+    gray = torch.zeros((n_views, height, width), dtype=torch.float32, device=dev)
+    bgr = torch.zeros((n_views, height, width, 3), dtype=torch.uint8, device=dev) if want_bgr else None
+    gt = torch.zeros((n_gt, height, width), dtype=torch.float32, device=dev)
+    dmin = np.zeros(n_views, np.float32); dmax = np.zeros(n_views, np.float32)
     lo = np.full(3, np.inf); hi = np.full(3, -np.inf)
+    c114 = torch.tensor(0.114, dtype=torch.float32, device=dev); c587 = torch.tensor(0.587, dtype=torch.float32, device=dev)
+    c299 = torch.tensor(0.299, dtype=torch.float32, device=dev)
+    inv255 = torch.tensor(1.0, dtype=torch.float32, device=dev) / 255.0
     for i in range(n_views):
         K = Ks[i]; R = torch.tensor(Rs[i], device=dev); C = torch.tensor(Cs[i], device=dev)
         rx = (uu - K[0, 2]) / K[0, 0]; ry = (vv - K[1, 2]) / K[1, 1]
@@ -122,13 +128,14 @@ def make_scene(n_views: int, width: int, height: int, n_src: int = 8, seed: int 
             a = a * (0.92 + 0.08 * chk)
             chans.append(torch.clamp(torch.round(a * 255.0), 0, 255))
         b, g, r_ = (c_.to(torch.float32) for c_ in chans)
-        inv255 = torch.tensor(1.0, dtype=torch.float32, device=dev) / 255.0
-        gr = torch.tensor(0.114, dtype=torch.float32) * (b * inv255) + torch.tensor(0.587, dtype=torch.float32) * (g * inv255) \
-            + torch.tensor(0.299, dtype=torch.float32) * (r_ * inv255)
-        gray[i] = gr.cpu().numpy()
+        # Image::toGray(BGR, normalize): cb*(B/255) + cg*(G/255) + cr*(R/255) in float, Types.inl:2377-2420
+        gray[i] = c114 * (b * inv255) + c587 * (g * inv255) + c299 * (r_ * inv255)
         if bgr is not None:
-            bgr[i] = torch.stack(chans, -1).to(torch.uint8).cpu().numpy()
-        gt[i] = t.to(torch.float32).cpu().numpy()
+            bgr[i] = torch.stack(chans, -1).to(torch.uint8)
+        tf = t.to(torch.float32)
+        if i < n_gt:
+            gt[i] = tf
+        dmin[i] = float(tf.min()) * 0.9; dmax[i] = float(tf.max()) * 1.1
         for a_, P in enumerate((X, Y, Z)):
             lo[a_] = min(lo[a_], float(P.min())); hi[a_] = max(hi[a_], float(P.max()))
     # neighbours: nearest camera centres
@@ -136,7 +143,16 @@ def make_scene(n_views: int, width: int, height: int, n_src: int = 8, seed: int 
     d2 = ((Cs[:, None, :] - Cs[None, :, :]) ** 2).sum(-1)
     np.fill_diagonal(d2, np.inf)
     nbr = np.argsort(d2, axis=1, kind="stable")[:, :n_src].astype(np.int32)
-    dmin = (gt.reshape(n_views, -1).min(1) * 0.9).astype(np.float32)
-    dmax = (gt.reshape(n_views, -1).max(1) * 1.1).astype(np.float32)
-    return Scene(width, height, gray, bgr if bgr is not None else np.zeros((0,), np.uint8), Ks, Rs, Cs, gt, nbr, dmin, dmax,
-                 float(np.linalg.norm(hi - lo)), {"seed": seed, "spacing": spacing, "cols": cols})
+    return dict(width=width, height=height, gray=gray, bgr=bgr, K=Ks, R=Rs, C=Cs, gt_depth=gt, neighbors=nbr,
+                dmin=dmin.astype(np.float32), dmax=dmax.astype(np.float32), diameter=float(np.linalg.norm(hi - lo)),
+                meta={"seed": seed, "spacing": spacing, "cols": cols})
+
+
+def make_scene(n_views: int, width: int, height: int, n_src: int = 8, seed: int = SEED,
+               device: str | torch.device = "cpu", spacing: float = 0.12, grid_cols: int | None = None,
+               gray_only: bool = False) -> Scene:
+    """Render `n_views` views of the seeded scene at width x height; numpy arrays on the host."""
+    t = make_scene_torch(n_views, width, height, n_src, seed, device, spacing, grid_cols, want_bgr=not gray_only)
+    bgr = t["bgr"].cpu().numpy() if t["bgr"] is not None else np.zeros((0,), np.uint8)
+    return Scene(width, height, t["gray"].cpu().numpy(), bgr, t["K"], t["R"], t["C"], t["gt_depth"].cpu().numpy(),
+                 t["neighbors"], t["dmin"], t["dmax"], t["diameter"], t["meta"])

@@ -13,7 +13,8 @@ from oracle import pyoracle as po  # noqa: E402
 
 N_VIEWS, N_SRC, SEED = 5, 4, 7
 sc = synth.make_scene(N_VIEWS, 96, 64, n_src=N_SRC)
-out = dict(n_views=N_VIEWS, n_src=N_SRC, seed=SEED, gray=sc.gray)
+out = dict(n_views=N_VIEWS, n_src=N_SRC, seed=SEED, gray=sc.gray, K=sc.K, R=sc.R, C=sc.C, neighbors=sc.neighbors,
+           dmin=sc.dmin, dmax=sc.dmax, diameter=sc.diameter)
 # photometric pass for every view (needed as inputs of the geometric round of view 0)
 photo = {}
 for v in range(N_VIEWS):

@@ -92,22 +92,22 @@ def test_initial_estimate_is_honoured(engine, small_scene):
     _same(d, od, "depth"); _same(n, on, "normal"); _same(c, oc, "conf")
 
 
-def test_geometric_round_parity_and_golden(engine, small_scene):
+def test_geometric_round_parity_and_golden(engine):
     g = np.load(os.path.join(GOLD, "pm_golden_96x64.npz"))
-    sc = synth.make_scene(int(g["n_views"]), 96, 64, n_src=int(g["n_src"]))
-    seed = int(g["seed"])
-    p = default_params(seed=seed)
+    gray, K, R, Cc, nbr, dmin, dmax = (g[k] for k in ("gray", "K", "R", "C", "neighbors", "dmin", "dmax"))
+    nv = int(g["n_views"])
+    p = default_params(seed=int(g["seed"]))
     engine.Init(False)
     photo = {}
-    for v in range(sc.n_views):
-        ids = [v] + list(sc.neighbors[v])
-        photo[v] = engine.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[v], sc.dmax[v], params=p)
+    for v in range(nv):
+        ids = [v] + list(nbr[v])
+        photo[v] = engine.EstimateDepthMap(gray, K, R, Cc, ids, dmin[v], dmax[v], params=p)
         _same(photo[v][0], g["depth_photo_all"][v], f"photometric depth view {v} vs golden")
     _same(photo[0][1], g["normal_photo"], "normal vs golden"); _same(photo[0][2], g["conf_photo"], "conf vs golden")
     engine.Release(); engine.Init(True)                 # SceneDensify.cpp:1910-1916
-    ids = [0] + list(sc.neighbors[0])
-    d, n, c = engine.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[0], sc.dmax[0], depth=photo[0][0], normal=photo[0][1],
-                                      src_depths={v: photo[v][0] for v in range(sc.n_views)}, nGeometricIter=0, params=p)
+    ids = [0] + list(nbr[0])
+    d, n, c = engine.EstimateDepthMap(gray, K, R, Cc, ids, dmin[0], dmax[0], depth=photo[0][0], normal=photo[0][1],
+                                      src_depths={v: photo[v][0] for v in range(nv)}, nGeometricIter=0, params=p)
     _same(d, g["depth_geo0"], "geo depth vs golden"); _same(n, g["normal_geo0"], "geo normal"); _same(c, g["conf_geo0"], "geo conf")
     engine.Release(); engine.Init(False)
 

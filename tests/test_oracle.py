@@ -167,12 +167,24 @@ def test_threaded_baseline_mode_runs(small_scene):
 
 
 def test_golden_fixture_pins_the_oracle():
+    # self-contained fixture: inputs (images, cameras, neighbours, ranges) and oracle outputs
+    g = np.load(os.path.join(GOLD, "pm_golden_96x64.npz"))
+    ids = [0] + list(g["neighbors"][0])
+    views, keep = po.make_views(g["gray"], g["K"], g["R"], g["C"], ids)
+    opt = po.default_opt(seed=int(g["seed"]))
+    d, n, c = po.estimate_depth_map(views, len(ids), float(g["dmin"][0]), float(g["dmax"][0]), opt)
+    assert np.array_equal(d, g["depth_photo"]) and np.array_equal(n, g["normal_photo"]) and np.array_equal(c, g["conf_photo"])
+    views, keep = po.make_views(g["gray"], g["K"], g["R"], g["C"], ids, depth_maps={v: g["depth_photo_all"][v] for v in range(int(g["n_views"]))})
+    d, n, c = po.estimate_depth_map(views, len(ids), float(g["dmin"][0]), float(g["dmax"][0]), opt, geo_iter=0,
+                                    depth=g["depth_photo"], normal=g["normal_photo"])
+    assert np.array_equal(d, g["depth_geo0"]) and np.array_equal(n, g["normal_geo0"]) and np.array_equal(c, g["conf_geo0"])
+
+
+def test_generator_reproduces_the_fixture_inputs_closely():
+    # the generator runs through torch's libm, which may differ in the last ulp between hosts; the
+    # fixture stores its own inputs, so this is only a drift alarm (<= 1 grey level on a few pixels)
     g = np.load(os.path.join(GOLD, "pm_golden_96x64.npz"))
     from openmvs_amd import synth
     sc = synth.make_scene(int(g["n_views"]), 96, 64, n_src=int(g["n_src"]))
-    assert np.array_equal(sc.gray, g["gray"])                       # generator is part of the pin
-    ids = [0] + list(sc.neighbors[0])
-    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
-    opt = po.default_opt(seed=int(g["seed"]))
-    d, n, c = po.estimate_depth_map(views, len(ids), float(sc.dmin[0]), float(sc.dmax[0]), opt)
-    assert np.array_equal(d, g["depth_photo"]) and np.array_equal(n, g["normal_photo"]) and np.array_equal(c, g["conf_photo"])
+    assert np.abs(sc.gray - g["gray"]).max() <= 1.01 / 255 and (sc.gray != g["gray"]).mean() < 1e-3
+    assert np.array_equal(sc.neighbors, g["neighbors"]) and np.allclose(sc.K, g["K"]) and np.allclose(sc.C, g["C"])

@@ -64,6 +64,8 @@ struct pmhip_engine {
 	// scene (HBM resident)
 	int nImages = 0, w = 0, h = 0, nLevels = 0; // nLevels = sub-resolution levels available (pyramid has nLevels+1 entries)
 	float* d_img[4] = {nullptr, nullptr, nullptr, nullptr};
+	float* d_imgS[4] = {nullptr, nullptr, nullptr, nullptr}; // anti-diagonal-major copies, (w_l+h_l-1)*h_l floats per image
+	size_t skewPitch(int l) const { return (size_t)(lw(l) + lh(l) - 1) * lh(l); }
 	float *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr, *d_snap = nullptr;
 	std::vector<SceneView> views;
 	bool pyramidDirty = true;
@@ -85,7 +87,7 @@ struct pmhip_engine {
 
 static void freeScene(pmhip_engine* e) {
 	hipSetDevice(e->device);
-	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
+	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_imgS[l]) hipFree(e->d_imgS[l]); e->d_imgS[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
 	if (e->d_depth) hipFree(e->d_depth); if (e->d_normal) hipFree(e->d_normal); if (e->d_conf) hipFree(e->d_conf); if (e->d_snap) hipFree(e->d_snap);
 	e->d_depth = e->d_normal = e->d_conf = e->d_snap = nullptr;
 	if (e->d_tasks) hipFree(e->d_tasks); if (e->h_tasks) hipHostFree(e->h_tasks);
@@ -120,6 +122,11 @@ static int buildPyramid(pmhip_engine* e) {
 		const int blocks = (int)std::min<size_t>((n + 255) / 256, 65535);
 		// every level is resampled from the full-resolution image (ScaleDepthData(fullRes, 1/2^l), SceneDensify.cpp:654)
 		hipLaunchKernelGGL(pm_area_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_img[0], e->d_img[l], e->w, e->h, 1 << l, e->nImages);
+	}
+	for (int l = 0; l <= e->nLevels; ++l) {
+		const size_t n = (size_t)e->lw(l) * e->lh(l) * e->nImages;
+		const int blocks = (int)std::min<size_t>((n + 255) / 256, 65535);
+		hipLaunchKernelGGL(pm_skew_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_img[l], e->d_imgS[l], e->lw(l), e->lh(l), e->nImages);
 	}
 	HIPCHK(e, hipGetLastError());
 	e->pyramidDirty = false;
@@ -226,6 +233,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 				t.prior = (l < S) ? base + Pl * 5 : nullptr;
 			}
 			t.ref = e->d_img[l] + Pl * id;
+			t.refS = e->d_imgS[l] + e->skewPitch(l) * id;
 			t.w = lw; t.h = lh; t.nSrc = v.nNb;
 			double K0[9];
 			if (l == 0) memcpy(K0, v.K, sizeof(K0)); else scaleK(v.K, e->w, e->h, lw, lh, K0);
@@ -239,6 +247,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 				const SceneView& sv = e->views[v.nb[k]];
 				PMSrcView& s = t.src[k];
 				s.img = e->d_img[l] + Pl * v.nb[k];
+				s.imgS = e->d_imgS[l] + e->skewPitch(l) * v.nb[k];
 				s.w = lw; s.h = lh;
 				double Kj[9];
 				if (l == 0) memcpy(Kj, sv.K, sizeof(Kj)); else scaleK(sv.K, e->w, e->h, lw, lh, Kj);
@@ -399,7 +408,10 @@ int pmhip_scene_create(pmhip_engine* e, int nImages, int w, int h, int nLevels) 
 	freeScene(e);
 	e->nImages = nImages; e->w = w; e->h = h; e->nLevels = nLevels;
 	const size_t P0 = (size_t)w * h;
-	for (int l = 0; l <= nLevels; ++l) HIPCHK(e, hipMalloc(&e->d_img[l], sizeof(float) * (size_t)e->lw(l) * e->lh(l) * nImages));
+	for (int l = 0; l <= nLevels; ++l) {
+		HIPCHK(e, hipMalloc(&e->d_img[l], sizeof(float) * (size_t)e->lw(l) * e->lh(l) * nImages));
+		HIPCHK(e, hipMalloc(&e->d_imgS[l], sizeof(float) * e->skewPitch(l) * nImages));
+	}
 	HIPCHK(e, hipMalloc(&e->d_depth, sizeof(float) * P0 * nImages));
 	HIPCHK(e, hipMalloc(&e->d_normal, sizeof(float) * P0 * 3 * nImages));
 	HIPCHK(e, hipMalloc(&e->d_conf, sizeof(float) * P0 * nImages));

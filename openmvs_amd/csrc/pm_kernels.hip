@@ -30,7 +30,8 @@
 #define PM_NT 25     // nTexels, DepthMap.h:281
 
 struct PMSrcView {
-	const float* img;     // source image at this pyramid level
+	const float* img;     // source image at this pyramid level, row-major
+	const float* imgS;    // same image, anti-diagonal-major ("skewed"): texel (u,v) at (u+v)*h + v
 	const float* depth;   // nullable: source depth-map (geometric pass)
 	int w, h;
 	double Hl[9];         // K_j R_j R_0^T          (ViewData::Init, DepthMap.h:175-185)
@@ -40,7 +41,8 @@ struct PMSrcView {
 struct PMTask {           // one reference view at one pyramid level
 	float* depth; float* normal; float* conf;
 	const float* prior;   // nullable: low-resolution depth prior at this level
-	const float* ref;     // reference image at this level
+	const float* ref;     // reference image at this level, row-major
+	const float* refS;    // reference image, anti-diagonal-major
 	int w, h, nSrc, pad0;
 	double Hr[9];         // K_0^-1
 	double fx, fy, cx, cy;
@@ -128,7 +130,11 @@ __device__ __forceinline__ void pm_group_min2(float s, float& m1, float& m2) {
 // ScorePixelImage for this lane's source view, DepthMap.cpp:465-564.
 // sf[]: the (view-independent) smoothness factors of the up-to-4 close neighbours, in insertion
 // order, sfValid bit k set if neighbour k exists (DepthMap.cpp:524-533).
-template <bool GEO>
+// SKEW selects the image layout the 100 bilinear taps read: the sweep kernel walks an anti-diagonal, so
+// the footprints of the pixels of one wave lie along an anti-diagonal of the source image too; in the
+// anti-diagonal-major copy those texels are contiguous (one or two 128-B lines per view instead of one
+// line per pixel), which is what the vector L1 / texture-address unit is bound by here.  Same values.
+template <bool GEO, bool SKEW>
 __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask& t, const PMKParams& kp,
 		int x, int y, double X0x, double X0y, float normSq0, float sumW, const float2* wts,
 		float depth, float nx, float ny, float nz,
@@ -162,7 +168,7 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 	for (int i = 0; i < 9; ++i) H[i] *= 2.f; // nSizeStep
 	float sum = 0.f, sumSq = 0.f, num = 0.f;
 	const int sw = s.w, sh = s.h;
-	const float* __restrict__ img = s.img;
+	const float* __restrict__ img = SKEW ? s.imgS : s.img;
 	int n = 0;
 	bool oob = false;
 	for (int i = 0; i < 5; ++i) {
@@ -174,8 +180,14 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 			const int lx = (int)ptx, ly = (int)pty;
 			const float fx = ptx - (float)lx, fx1 = 1.f - fx;
 			const float fy = pty - (float)ly, fy1 = 1.f - fy;
-			const float* p = img + (size_t)ly * sw + lx;
-			const float v00 = p[0], v01 = p[1], v10 = p[sw], v11 = p[sw + 1];
+			float v00, v01, v10, v11;
+			if (SKEW) {
+				const float* p = img + (size_t)(lx + ly) * sh + ly;
+				v00 = p[0]; v01 = p[sh]; v10 = p[sh + 1]; v11 = p[2 * sh + 1];
+			} else {
+				const float* p = img + (size_t)ly * sw + lx;
+				v00 = p[0]; v01 = p[1]; v10 = p[sw]; v11 = p[sw + 1];
+			}
 			const float v = (v00 * fx1 + v01 * fx) * fy1 + (v10 * fx1 + v11 * fx) * fy;
 			const float2 pw = wts[n++];
 			const float vw = v * pw.x;
@@ -257,15 +269,15 @@ __device__ __forceinline__ float pm_aggregate(float viewScore, int nSrc, float t
 
 // FillPixelPatch, DepthMap.cpp:422-462: cooperative weights into LDS; returns normSq0, sumW.
 // Must be called by every thread of the workgroup (contains __syncthreads()).
-template <int G>
+template <int G, bool SKEW>
 __device__ __forceinline__ void pm_fill_patch(const PMTask& t, bool inb, int x, int y, int v, float2* wts, float& normSq0, float& sumW) {
 	const float sigmaColor = -1.f / (2.f * (0.1f * 0.1f));
 	const float sigmaSpatial = -1.f / (2.f * 9.f);
 	if (inb) {
-		const float colCenter = t.ref[(size_t)y * t.w + x];
+		const float colCenter = SKEW ? t.refS[(size_t)(x + y) * t.h + y] : t.ref[(size_t)y * t.w + x];
 		for (int k = v; k < PM_NT; k += G) {
 			const int i = (k / 5) * 2 - PM_HW, j = (k % 5) * 2 - PM_HW;
-			const float I = t.ref[(size_t)(y + i) * t.w + (x + j)];
+			const float I = SKEW ? t.refS[(size_t)(x + j + y + i) * t.h + (y + i)] : t.ref[(size_t)(y + i) * t.w + (x + j)];
 			const float dc = I - colCenter;
 			const float wColor = (dc * dc) * sigmaColor;
 			const float wSpatial = (float)(j * j + i * i) * sigmaSpatial;
@@ -304,7 +316,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 	const int x = active ? (int)(p % w) : 0, y = active ? (int)(p / w) : 0;
 	const bool inb = active && x >= PM_HW && y >= PM_HW && x < w - PM_HW && y < h - PM_HW; // PreparePixelPatch
 	float normSq0, sumW;
-	pm_fill_patch<G>(t, inb, x, y, v, s_w[g], normSq0, sumW);
+	pm_fill_patch<G, false>(t, inb, x, y, v, s_w[g], normSq0, sumW);
 	if (!active) return;
 	const size_t idx = (size_t)y * w + x;
 	const float prior = t.prior ? t.prior[idx] : 0.f;
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 	}
 	float sc = PM_INF;
 	if (v < t.nSrc)
-		sc = pm_score_view<GEO>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, 0u, prior);
+		sc = pm_score_view<GEO, false>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, 0u, prior);
 	const float conf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 	if (v == 0) { t.depth[idx] = depth; t.normal[idx * 3] = nx; t.normal[idx * 3 + 1] = ny; t.normal[idx * 3 + 2] = nz; t.conf[idx] = conf; }
 }
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const PMTask* __rest
 	const bool active = pi < count;
 	const int x = xlo + (active ? pi : 0), y = d - x;
 	float normSq0, sumW;
-	pm_fill_patch<G>(t, active, x, y, v, s_w[g], normSq0, sumW);
+	pm_fill_patch<G, true>(t, active, x, y, v, s_w[g], normSq0, sumW);
 	const size_t idx = (size_t)y * w + x;
 	const float prior = (active && t.prior) ? t.prior[idx] : 0.f;
 	const bool valid = active && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
@@ -492,7 +504,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const PMTask* __rest
 		}
 		float sc = PM_INF;
 		if (need && v < t.nSrc)
-			sc = pm_score_view<GEO>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], sfValid, prior);
+			sc = pm_score_view<GEO, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], sfValid, prior);
 		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 		if (need && conf > nconf) {
 			conf = nconf; depth = hd; nx = hnx; ny = hny; nz = hnz; changed = true;
@@ -533,6 +545,14 @@ __global__ void pm_area_kernel(const float* __restrict__ src, float* __restrict_
 			o = sum * scale;
 		}
 		dst[i] = o;
+	}
+}
+// anti-diagonal-major copy of nImg row-major images: dst[img][(u+v)*h + v] = src[img][v*w + u]
+__global__ void pm_skew_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, int nImg) {
+	const size_t n = (size_t)w * h * nImg, sp = (size_t)(w + h - 1) * h;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const int u = (int)(i % w), v = (int)((i / w) % h); const size_t im = i / ((size_t)w * h);
+		dst[im * sp + (size_t)(u + v) * h + v] = src[i];
 	}
 }
 __device__ __forceinline__ void pm_linear_coef(int d, int dn, int sn, int& s, float& a) {

@@ -34,6 +34,14 @@ def _stale(out: str, deps: list[str]) -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name: str, out_name: str, extra_flags: list[str]) -> str:
+    """Experiment helper: build `name` with extra -D flags into openmvs_amd/<out_name>."""
+    srcs, _ = LIBS[name]
+    out = lib_path(out_name)
+    subprocess.check_call([HIPCC] + FLAGS + list(extra_flags) + [os.path.join(_CSRC, s) for s in srcs] + ["-o", out], cwd=_CSRC)
+    return out
+
+
 def build_lib(name: str, force: bool = False, verbose: bool = False) -> str | None:
     srcs, deps = LIBS[name]
     srcs_abs = [os.path.join(_CSRC, s) for s in srcs]

@@ -8,10 +8,15 @@
 #include "pm_kernels.hip"
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <string>
 #include <vector>
+
+#ifndef PMHIP_DEFAULT_GROUPS
+#define PMHIP_DEFAULT_GROUPS 4
+#endif
 
 namespace {
 
@@ -59,6 +64,11 @@ void scaleK(const double* K, int w, int h, int nw, int nh, double* o) {
 struct pmhip_engine {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	// view groups of a batch sweep on their own streams so that the tail of one group's diagonal launch
+	// overlaps the next launch of another group (views are independent; diagonals of one view are not)
+	int nGroups = 1;
+	hipStream_t gstream[16] = {};
+	hipEvent_t forkEv = nullptr, joinEv[16] = {};
 	bool inited = false, geom = false;
 	std::string err;
 	// scene (HBM resident)
@@ -305,16 +315,28 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			const uint32_t pass = (uint32_t)l * 64u + iter;
 			const int dLo = 2 * PM_HW, dHi = (lw - 1 - PM_HW) + (lh - 1 - PM_HW);
 			evBegin(e, 0);
+			const int NG = std::max(1, std::min(e->nGroups, nB));
+			if (NG > 1) {
+				HIPCHK(e, hipEventRecord(e->forkEv, e->stream));
+				for (int g = 0; g < NG; ++g) HIPCHK(e, hipStreamWaitEvent(e->gstream[g], e->forkEv, 0));
+			}
 			for (int k = 0; k <= dHi - dLo; ++k) {
 				const int d = dir == 0 ? dLo + k : dHi - k;
 				const int xlo = std::max(PM_HW, d - (lh - 1 - PM_HW));
 				const int xhi = std::min(lw - 1 - PM_HW, d - PM_HW);
 				const int count = xhi - xlo + 1;
 				if (count <= 0) continue;
-				const dim3 grid((unsigned)((count + PPB - 1) / PPB), nB);
-				if (geo) launchSweep<true>(G, grid, e->stream, dt, kp, dir, d, xlo, count, pass);
-				else launchSweep<false>(G, grid, e->stream, dt, kp, dir, d, xlo, count, pass);
-				if (e->statsOn) e->stats.sweepLaunches += 1;
+				for (int g = 0; g < NG; ++g) {
+					const int s0 = (int)((long)nB * g / NG), s1 = (int)((long)nB * (g + 1) / NG);
+					hipStream_t st = NG > 1 ? e->gstream[g] : e->stream;
+					const dim3 grid((unsigned)((count + PPB - 1) / PPB), s1 - s0);
+					if (geo) launchSweep<true>(G, grid, st, dt + s0, kp, dir, d, xlo, count, pass);
+					else launchSweep<false>(G, grid, st, dt + s0, kp, dir, d, xlo, count, pass);
+				}
+				if (e->statsOn) e->stats.sweepLaunches += NG;
+			}
+			if (NG > 1) {
+				for (int g = 0; g < NG; ++g) { HIPCHK(e, hipEventRecord(e->joinEv[g], e->gstream[g])); HIPCHK(e, hipStreamWaitEvent(e->stream, e->joinEv[g], 0)); }
 			}
 			evEnd(e);
 			if (e->statsOn) {
@@ -369,6 +391,11 @@ int pmhip_create(int device, pmhip_engine** out) {
 	pmhip_engine* e = new pmhip_engine();
 	e->device = device;
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return PMHIP_E_HIP; }
+	const char* ng = getenv("PMHIP_GROUPS");
+	e->nGroups = ng ? std::max(1, std::min(16, atoi(ng))) : PMHIP_DEFAULT_GROUPS;
+	for (int g = 0; g < e->nGroups; ++g)
+		if (hipStreamCreateWithFlags(&e->gstream[g], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->joinEv[g], hipEventDisableTiming) != hipSuccess) { delete e; return PMHIP_E_HIP; }
+	if (hipEventCreateWithFlags(&e->forkEv, hipEventDisableTiming) != hipSuccess) { delete e; return PMHIP_E_HIP; }
 	*out = e;
 	return 0;
 }
@@ -379,6 +406,8 @@ void pmhip_destroy(pmhip_engine* e) {
 	if (e->stream) hipStreamSynchronize(e->stream);
 	for (auto& ev : e->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
 	freeScene(e);
+	for (int g = 0; g < 16; ++g) { if (e->gstream[g]) hipStreamDestroy(e->gstream[g]); if (e->joinEv[g]) hipEventDestroy(e->joinEv[g]); }
+	if (e->forkEv) hipEventDestroy(e->forkEv);
 	if (e->stream) hipStreamDestroy(e->stream);
 	delete e;
 }

@@ -25,7 +25,18 @@
 #include "pm_math.h"
 
 #define PM_MAX_SRC 16
+#ifndef PM_BLOCK
 #define PM_BLOCK 256
+#endif
+#ifndef PM_MINWAVES
+#define PM_MINWAVES 3   // waves per SIMD the register allocator must leave room for (measured: 3 beats 4 (spills) and 5)
+#endif
+// Pointers read out of PMTask live in the generic address space as far as the compiler knows, which
+// turns every access into a flat_load; they are all HBM buffers, so say so (global_load, own vmcnt).
+typedef const float __attribute__((address_space(1)))* pm_gcf;
+typedef float __attribute__((address_space(1)))* pm_gf;
+__device__ __forceinline__ pm_gcf pm_glob(const float* p) { return (pm_gcf)p; }
+__device__ __forceinline__ pm_gf pm_globw(float* p) { return (pm_gf)p; }
 #define PM_HW 4      // nSizeHalfWindow, DepthMap.h:277
 #define PM_NT 25     // nTexels, DepthMap.h:281
 
@@ -168,35 +179,45 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 	for (int i = 0; i < 9; ++i) H[i] *= 2.f; // nSizeStep
 	float sum = 0.f, sumSq = 0.f, num = 0.f;
 	const int sw = s.w, sh = s.h;
-	const float* __restrict__ img = SKEW ? s.imgS : s.img;
-	int n = 0;
+	const pm_gcf img = pm_glob(SKEW ? s.imgS : s.img);
+	// The reference returns thRobust at the first tap that leaves the image (DepthMap.cpp:484-485).  Here a
+	// tap outside only raises a flag and its address is clamped, so there is no branch between taps: the
+	// 20 loads of a tap row are issued back to back (memory-level parallelism) and the sums of a flagged
+	// hypothesis are simply discarded -- identical result, no load ever depends on a previous load.
 	bool oob = false;
+	const int lxMax = sw - 2, lyMax = sh - 2;
+#pragma unroll 1
 	for (int i = 0; i < 5; ++i) {
+		float fxs[5], fys[5];
+		size_t offs[5];
 #pragma unroll
 		for (int j = 0; j < 5; ++j) {
 			const float ptx = X0 / X2, pty = X1 / X2;
-			if (!pm_inside1(ptx, pty, sw, sh)) { oob = true; break; }
+			oob = oob || !pm_inside1(ptx, pty, sw, sh);
 			// TImage::sample, libs/Common/Types.inl:2273-2281
-			const int lx = (int)ptx, ly = (int)pty;
-			const float fx = ptx - (float)lx, fx1 = 1.f - fx;
-			const float fy = pty - (float)ly, fy1 = 1.f - fy;
-			float v00, v01, v10, v11;
-			if (SKEW) {
-				const float* p = img + (size_t)(lx + ly) * sh + ly;
-				v00 = p[0]; v01 = p[sh]; v10 = p[sh + 1]; v11 = p[2 * sh + 1];
-			} else {
-				const float* p = img + (size_t)ly * sw + lx;
-				v00 = p[0]; v01 = p[1]; v10 = p[sw]; v11 = p[sw + 1];
-			}
-			const float v = (v00 * fx1 + v01 * fx) * fy1 + (v10 * fx1 + v11 * fx) * fy;
-			const float2 pw = wts[n++];
+			int lx = (int)ptx, ly = (int)pty;
+			fxs[j] = ptx - (float)lx; fys[j] = pty - (float)ly;
+			lx = min(max(lx, 0), lxMax); ly = min(max(ly, 0), lyMax);
+			offs[j] = SKEW ? (size_t)(lx + ly) * sh + ly : (size_t)ly * sw + lx;
+			X0 += H[0]; X1 += H[3]; X2 += H[6];
+		}
+		float v00[5], v01[5], v10[5], v11[5];
+#pragma unroll
+		for (int j = 0; j < 5; ++j) {
+			const pm_gcf p = img + offs[j];
+			if (SKEW) { v00[j] = p[0]; v01[j] = p[sh]; v10[j] = p[sh + 1]; v11[j] = p[2 * sh + 1]; }
+			else { v00[j] = p[0]; v01[j] = p[1]; v10[j] = p[sw]; v11[j] = p[sw + 1]; }
+		}
+#pragma unroll
+		for (int j = 0; j < 5; ++j) {
+			const float fx = fxs[j], fx1 = 1.f - fx, fy = fys[j], fy1 = 1.f - fy;
+			const float v = (v00[j] * fx1 + v01[j] * fx) * fy1 + (v10[j] * fx1 + v11[j] * fx) * fy;
+			const float2 pw = wts[i * 5 + j];
 			const float vw = v * pw.x;
 			sum += vw;
 			sumSq += v * vw;
 			num += v * pw.y;
-			X0 += H[0]; X1 += H[3]; X2 += H[6];
 		}
-		if (oob) break;
 		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
 		X0 = bX0; X1 = bX1; X2 = bX2;
 	}
@@ -225,7 +246,7 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 					const int lx = (int)x1x, ly = (int)x1y;
 					const float fx = x1x - (float)lx, fx1 = 1.f - fx;
 					const float fy = x1y - (float)ly, fy1 = 1.f - fy;
-					const float* p = s.depth + (size_t)ly * sw + lx;
+					const pm_gcf p = pm_glob(s.depth) + (size_t)ly * sw + lx;
 					const float x0y0 = p[0], x1y0 = p[1], x0y1 = p[sw], x1y1 = p[sw + 1];
 					const bool b00 = pm_fabsf(Y2 - x0y0) / Y2 < 0.03f, b10 = pm_fabsf(Y2 - x1y0) / Y2 < 0.03f;
 					const bool b01 = pm_fabsf(Y2 - x0y1) / Y2 < 0.03f, b11 = pm_fabsf(Y2 - x1y1) / Y2 < 0.03f;
@@ -274,10 +295,11 @@ __device__ __forceinline__ void pm_fill_patch(const PMTask& t, bool inb, int x, 
 	const float sigmaColor = -1.f / (2.f * (0.1f * 0.1f));
 	const float sigmaSpatial = -1.f / (2.f * 9.f);
 	if (inb) {
-		const float colCenter = SKEW ? t.refS[(size_t)(x + y) * t.h + y] : t.ref[(size_t)y * t.w + x];
+		const pm_gcf refS = pm_glob(t.refS), ref = pm_glob(t.ref);
+		const float colCenter = SKEW ? refS[(size_t)(x + y) * t.h + y] : ref[(size_t)y * t.w + x];
 		for (int k = v; k < PM_NT; k += G) {
 			const int i = (k / 5) * 2 - PM_HW, j = (k % 5) * 2 - PM_HW;
-			const float I = SKEW ? t.refS[(size_t)(x + j + y + i) * t.h + (y + i)] : t.ref[(size_t)(y + i) * t.w + (x + j)];
+			const float I = SKEW ? refS[(size_t)(x + j + y + i) * t.h + (y + i)] : ref[(size_t)(y + i) * t.w + (x + j)];
 			const float dc = I - colCenter;
 			const float wColor = (dc * dc) * sigmaColor;
 			const float wSpatial = (float)(j * j + i * i) * sigmaSpatial;
@@ -319,16 +341,17 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 	pm_fill_patch<G, false>(t, inb, x, y, v, s_w[g], normSq0, sumW);
 	if (!active) return;
 	const size_t idx = (size_t)y * w + x;
-	const float prior = t.prior ? t.prior[idx] : 0.f;
+	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
+	const float prior = t.prior ? pm_glob(t.prior)[idx] : 0.f;
 	const bool valid = inb && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
 	if (!valid) {
-		if (v == 0) { t.depth[idx] = 0.f; t.normal[idx * 3] = 0.f; t.normal[idx * 3 + 1] = 0.f; t.normal[idx * 3 + 2] = 0.f; t.conf[idx] = 2.f; }
+		if (v == 0) { gDepth[idx] = 0.f; gNormal[idx * 3] = 0.f; gNormal[idx * 3 + 1] = 0.f; gNormal[idx * 3 + 2] = 0.f; gConf[idx] = 2.f; }
 		return;
 	}
 	const double X0x = ((double)x - t.cx) / t.fx, X0y = ((double)y - t.cy) / t.fy;
 	const float vx = (float)X0x, vy = (float)X0y, vz = 1.f;
-	float depth = t.depth[idx];
-	float nx = t.normal[idx * 3], ny = t.normal[idx * 3 + 1], nz = t.normal[idx * 3 + 2];
+	float depth = gDepth[idx];
+	float nx = gNormal[idx * 3], ny = gNormal[idx * 3 + 1], nz = gNormal[idx * 3 + 2];
 	const PmPhilox4 r = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_INIT * 256), 0u, t.k0, t.k1base + pass);
 	if (!pm_in_range(depth, t.dMin, t.dMax)) {
 		const float rr = t.dMinSqr + (t.dMaxSqr - t.dMinSqr) * pm_u32_to_unit(r.v[0]);
@@ -341,14 +364,14 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 	if (v < t.nSrc)
 		sc = pm_score_view<GEO, false>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, 0u, prior);
 	const float conf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
-	if (v == 0) { t.depth[idx] = depth; t.normal[idx * 3] = nx; t.normal[idx * 3 + 1] = ny; t.normal[idx * 3 + 2] = nz; t.conf[idx] = conf; }
+	if (v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
 }
 
 // -------------------------------------------------------------------------------------------
 // ProcessPixel, DepthMap.cpp:630-852, for all pixels of anti-diagonal x+y == d (x = xlo + i).
 // dir 0 = LT2RB (left/top are new), 1 = RB2LT (right/bottom are new).
 template <int G, bool GEO>
-__global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
+__global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	constexpr int PPB = PM_BLOCK / G;
 	constexpr int SL = (G >= 4) ? 1 : 4 / G; // smoothness slots owned per lane
 	__shared__ float2 s_w[PPB][PM_NT + 1];
@@ -361,7 +384,8 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const PMTask* __rest
 	float normSq0, sumW;
 	pm_fill_patch<G, true>(t, active, x, y, v, s_w[g], normSq0, sumW);
 	const size_t idx = (size_t)y * w + x;
-	const float prior = (active && t.prior) ? t.prior[idx] : 0.f;
+	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
+	const float prior = (active && t.prior) ? pm_glob(t.prior)[idx] : 0.f;
 	const bool valid = active && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
 	const double X0x = ((double)x - t.cx) / t.fx, X0y = ((double)y - t.cy) / t.fy;
 	const float vx = (float)X0x, vy = (float)X0y, vz = 1.f;
@@ -377,7 +401,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const PMTask* __rest
 #pragma unroll
 	for (int q = 0; q < SL; ++q) { qX0[q] = qX1[q] = qX2[q] = 0.f; qn0[q] = qn1[q] = 0.f; qn2[q] = 1.f; }
 	if (valid) {
-		depth = t.depth[idx]; nx = t.normal[idx * 3]; ny = t.normal[idx * 3 + 1]; nz = t.normal[idx * 3 + 2]; conf = t.conf[idx];
+		depth = gDepth[idx]; nx = gNormal[idx * 3]; ny = gNormal[idx * 3 + 1]; nz = gNormal[idx * 3 + 2]; conf = gConf[idx];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const int ox = (k == 0) ? sgn : (k == 2 ? -sgn : 0), oy = (k == 1) ? sgn : (k == 3 ? -sgn : 0);
@@ -387,10 +411,10 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const PMTask* __rest
 			if (ox == -1) ok = x > PM_HW; else if (ox == 1) ok = x < w - PM_HW; else if (oy == -1) ok = y > PM_HW; else ok = y < h - PM_HW;
 			float nd = 0.f;
 			const size_t qi = (size_t)qy * w + qx;
-			if (ok) { nd = t.depth[qi]; ok = nd > 0; }
+			if (ok) { nd = gDepth[qi]; ok = nd > 0; }
 			if (ok) closeMask |= 1u << k;
-			if (k == 0 && ok) { pok0 = true; pd0 = nd; pnx0 = t.normal[qi * 3]; pny0 = t.normal[qi * 3 + 1]; pnz0 = t.normal[qi * 3 + 2]; pconf0 = t.conf[qi]; }
-			if (k == 1 && ok) { pok1 = true; pd1 = nd; pnx1 = t.normal[qi * 3]; pny1 = t.normal[qi * 3 + 1]; pnz1 = t.normal[qi * 3 + 2]; pconf1 = t.conf[qi]; }
+			if (k == 0 && ok) { pok0 = true; pd0 = nd; pnx0 = gNormal[qi * 3]; pny0 = gNormal[qi * 3 + 1]; pnz0 = gNormal[qi * 3 + 2]; pconf0 = gConf[qi]; }
+			if (k == 1 && ok) { pok1 = true; pd1 = nd; pnx1 = gNormal[qi * 3]; pny1 = gNormal[qi * 3 + 1]; pnz1 = gNormal[qi * 3 + 2]; pconf1 = gConf[qi]; }
 			if (ok && (k % G) == v) {
 				const int q = (k / G < SL) ? k / G : 0;
 				// TransformPointI2C(Point3(nx, ndepth)) in double then Cast<float>, Camera.h:338-344
@@ -398,7 +422,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const PMTask* __rest
 				qX0[q] = (float)(((double)qx - t.cx) * z / t.fx);
 				qX1[q] = (float)(((double)qy - t.cy) * z / t.fy);
 				qX2[q] = (float)z;
-				qn0[q] = t.normal[qi * 3]; qn1[q] = t.normal[qi * 3 + 1]; qn2[q] = t.normal[qi * 3 + 2];
+				qn0[q] = gNormal[qi * 3]; qn1[q] = gNormal[qi * 3 + 1]; qn2[q] = gNormal[qi * 3 + 2];
 			}
 		}
 	}
@@ -512,7 +536,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const PMTask* __rest
 			else if (hst == ST_REFINE) { p0 = hp0; p1 = hp1; scaleRange = pm_pow2neg(++idxScale); }
 		}
 	}
-	if (changed && v == 0) { t.depth[idx] = depth; t.normal[idx * 3] = nx; t.normal[idx * 3 + 1] = ny; t.normal[idx * 3 + 2] = nz; t.conf[idx] = conf; }
+	if (changed && v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
 }
 
 // EndDepthMapTmp, SceneDensify.cpp:528-576

@@ -59,7 +59,7 @@ def load_library() -> C.CDLL:
     """Load libpmhip.so (building it first when the sources are newer).  Fails loudly."""
     global _LIB
     if _LIB is None:
-        path = _build.build_lib("libpmhip.so")
+        path = os.environ.get("PMHIP_LIB") or _build.build_lib("libpmhip.so")   # PMHIP_LIB: tuning experiments only
         if path is None or not os.path.exists(path):
             raise RuntimeError("libpmhip.so is not built (python -m openmvs_amd.build)")
         lib = C.CDLL(path)

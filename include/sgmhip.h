@@ -1,0 +1,62 @@
+/* sgmhip.h -- C ABI of the MI355X-native semi-global-matching kernels (libsgmhip.so).
+ *
+ * Boundary: the private hot method of the reference's SGM,
+ *     void SemiGlobalMatcher::Match(const ViewData& left, const ViewData& right,
+ *                                   DisparityMap& disparityMap, AccumCostMap& costMap)
+ * (libs/MVS/SemiGlobalMatcher.h:170, body libs/MVS/SemiGlobalMatcher.cpp:863-1302), which works on
+ * the members imagePixels / imageCosts / imageAccumCosts / maxNumDisp (SemiGlobalMatcher.h:198-201)
+ * prepared by its caller Match(scene, idxImage, numNeighbors) (:530-737, reached from
+ * SceneDensify.cpp:2048).  Those members become plain arguments here; everything around the call
+ * (rectification, pyramid, range maps, cross-check, sub-pixel refinement) stays with the caller.
+ * Integer outputs are bit-identical to the reference algorithm (u8 costs, u16 sums, i16 disparities).
+ */
+#ifndef SGMHIP_H_
+#define SGMHIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SGMHIP_OK = 0, SGMHIP_E_ARG = -1, SGMHIP_E_HIP = -3, SGMHIP_E_NODEVICE = -5 };
+
+typedef struct sgmhip_engine sgmhip_engine;
+
+/* SemiGlobalMatcher::PixelData (SemiGlobalMatcher.h:79-82): 16 bytes, one per pixel of the valid
+ * grid (w-6) x (h-6), row-major; range.minDisp >= range.maxDisp marks an invalid pixel. */
+typedef struct SGMHipPixelData {
+	uint64_t idx;            /* offset of this pixel's first cost in the ragged cost/accum arrays */
+	int16_t minDisp, maxDisp;
+	int32_t pad_;
+} SGMHipPixelData;
+
+int sgmhip_create(int device, sgmhip_engine** out);
+void sgmhip_destroy(sgmhip_engine* e);
+const char* sgmhip_last_error(sgmhip_engine* e);
+
+/* GenerateP2s (SemiGlobalMatcher.cpp:518-524): P2s[i] = round(P2*(1+alpha*exp(-i^2/(2 beta^2)))). */
+int sgmhip_generate_p2s(uint16_t P2, float alpha, float beta, uint16_t out256[256]);
+
+/* Upload one stereo problem (host pointers): left colour BGR u8 (w*h*3), left/right gray float
+ * (w*h), pixel table ((w-6)*(h-6)), total number of costs, max disparities per pixel. */
+int sgmhip_set_problem(sgmhip_engine* e, const uint8_t* leftBGR, const float* leftGray, const float* rightGray,
+                       int w, int h, const SGMHipPixelData* pixels, uint64_t numCosts, int maxNumDisp);
+/* SemiGlobalMatcher::Match(ViewData,ViewData,...): cost volume + 8-path aggregation + WTA on the
+ * resident problem.  Asynchronous unless sync != 0.  P1 / P2s as in the SemiGlobalMatcher ctor. */
+int sgmhip_match(sgmhip_engine* e, uint16_t P1, const uint16_t P2s[256], int sync);
+/* Download results (any pointer may be NULL): disparity i16 and cost u16 per valid-grid pixel;
+ * the raw cost volume (u8) and the 8-path sums (u16), numCosts entries each. */
+int sgmhip_get_results(sgmhip_engine* e, int16_t* disparity, uint16_t* cost, uint8_t* costs, uint16_t* accums);
+int sgmhip_sync(sgmhip_engine* e);
+
+/* HIP-event timing since the last reset: milliseconds in the cost-volume, aggregation (8 path
+ * kernels) and WTA kernels, number of match calls. */
+typedef struct SGMHipStats { double costMs, aggrMs, wtaMs; uint64_t calls, aggrLaunches; } SGMHipStats;
+int sgmhip_stats_reset(sgmhip_engine* e, int enable);
+int sgmhip_stats_get(sgmhip_engine* e, SGMHipStats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGMHIP_H_ */

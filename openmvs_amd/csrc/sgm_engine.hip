@@ -1,0 +1,151 @@
+// sgm_engine.hip -- host side of libsgmhip.so (include/sgmhip.h).
+#include "../../include/sgmhip.h"
+#include "sgm_kernels.hip"
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#define SGMCHK(e, call) do { hipError_t _r = (call); if (_r != hipSuccess) { (e)->err = std::string(#call) + ": " + hipGetErrorString(_r); return SGMHIP_E_HIP; } } while (0)
+
+struct sgmhip_engine {
+	int device = 0; hipStream_t stream = nullptr; std::string err;
+	int w = 0, h = 0, vw = 0, vh = 0, maxNumDisp = 0; uint64_t numCosts = 0;
+	size_t capImg = 0, capPix = 0, capCosts = 0;
+	unsigned char* d_color = nullptr; float* d_grayL = nullptr; float* d_grayR = nullptr;
+	SGMPixel* d_pixels = nullptr; unsigned char* d_costs = nullptr; unsigned short* d_accums = nullptr;
+	short* d_disp = nullptr; unsigned short* d_cost = nullptr; unsigned short* d_P2s = nullptr;
+	bool statsOn = false; SGMHipStats stats{};
+	struct Ev { hipEvent_t a, b; int kind; }; std::vector<Ev> events;
+};
+
+static void sgmFree(sgmhip_engine* e) {
+	hipSetDevice(e->device);
+	void* ps[] = {e->d_color, e->d_grayL, e->d_grayR, e->d_pixels, e->d_costs, e->d_accums, e->d_disp, e->d_cost};
+	for (void* p : ps) if (p) hipFree(p);
+	e->d_color = nullptr; e->d_grayL = e->d_grayR = nullptr; e->d_pixels = nullptr; e->d_costs = nullptr; e->d_accums = nullptr; e->d_disp = nullptr; e->d_cost = nullptr;
+	e->capImg = e->capPix = e->capCosts = 0;
+}
+static void evB(sgmhip_engine* e, int kind) { if (!e->statsOn) return; sgmhip_engine::Ev ev; ev.kind = kind; hipEventCreate(&ev.a); hipEventCreate(&ev.b); hipEventRecord(ev.a, e->stream); e->events.push_back(ev); }
+static void evE(sgmhip_engine* e) { if (!e->statsOn) return; hipEventRecord(e->events.back().b, e->stream); }
+static int sgmCollect(sgmhip_engine* e) {
+	if (e->events.empty()) return 0;
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	for (auto& ev : e->events) { float ms = 0; hipEventElapsedTime(&ms, ev.a, ev.b); (ev.kind == 0 ? e->stats.costMs : ev.kind == 1 ? e->stats.aggrMs : e->stats.wtaMs) += ms; hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+	e->events.clear();
+	return 0;
+}
+
+extern "C" {
+
+int sgmhip_create(int device, sgmhip_engine** out) {
+	if (!out) return SGMHIP_E_ARG;
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) return SGMHIP_E_NODEVICE;
+	if (device < 0) device = 0;
+	sgmhip_engine* e = new sgmhip_engine(); e->device = device;
+	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&e->d_P2s, 512) != hipSuccess) { delete e; return SGMHIP_E_HIP; }
+	*out = e;
+	return 0;
+}
+void sgmhip_destroy(sgmhip_engine* e) {
+	if (!e) return;
+	hipSetDevice(e->device); hipStreamSynchronize(e->stream);
+	for (auto& ev : e->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+	sgmFree(e); if (e->d_P2s) hipFree(e->d_P2s); hipStreamDestroy(e->stream); delete e;
+}
+const char* sgmhip_last_error(sgmhip_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int sgmhip_generate_p2s(uint16_t P2, float alpha, float beta, uint16_t out256[256]) {
+	if (!out256) return SGMHIP_E_ARG;
+	for (int i = 0; i < 256; ++i) { const float fi = (float)i; out256[i] = (uint16_t)(int)floorf((float)P2 * (1.f + alpha * pm_expf(-(fi * fi) / (2.f * (beta * beta)))) + .5f); }
+	return 0;
+}
+
+int sgmhip_set_problem(sgmhip_engine* e, const uint8_t* leftBGR, const float* leftGray, const float* rightGray, int w, int h,
+		const SGMHipPixelData* pixels, uint64_t numCosts, int maxNumDisp) {
+	if (!e || !leftBGR || !leftGray || !rightGray || !pixels || w <= 2 * SGM_HW || h <= 2 * SGM_HW || numCosts == 0 || maxNumDisp <= 0 || maxNumDisp > 256) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	const size_t nImg = (size_t)w * h, nPix = (size_t)(w - 2 * SGM_HW) * (h - 2 * SGM_HW);
+	if (nImg > e->capImg || nPix > e->capPix || numCosts > e->capCosts) {
+		SGMCHK(e, hipStreamSynchronize(e->stream));
+		sgmFree(e);
+		SGMCHK(e, hipMalloc(&e->d_color, nImg * 3)); SGMCHK(e, hipMalloc(&e->d_grayL, nImg * 4)); SGMCHK(e, hipMalloc(&e->d_grayR, nImg * 4));
+		SGMCHK(e, hipMalloc(&e->d_pixels, nPix * sizeof(SGMPixel))); SGMCHK(e, hipMalloc(&e->d_disp, nPix * 2)); SGMCHK(e, hipMalloc(&e->d_cost, nPix * 2));
+		SGMCHK(e, hipMalloc(&e->d_costs, numCosts)); SGMCHK(e, hipMalloc(&e->d_accums, numCosts * 2));
+		e->capImg = nImg; e->capPix = nPix; e->capCosts = numCosts;
+	}
+	e->w = w; e->h = h; e->vw = w - 2 * SGM_HW; e->vh = h - 2 * SGM_HW; e->numCosts = numCosts; e->maxNumDisp = maxNumDisp;
+	SGMCHK(e, hipMemcpyAsync(e->d_color, leftBGR, nImg * 3, hipMemcpyHostToDevice, e->stream));
+	SGMCHK(e, hipMemcpyAsync(e->d_grayL, leftGray, nImg * 4, hipMemcpyHostToDevice, e->stream));
+	SGMCHK(e, hipMemcpyAsync(e->d_grayR, rightGray, nImg * 4, hipMemcpyHostToDevice, e->stream));
+	SGMCHK(e, hipMemcpyAsync(e->d_pixels, pixels, nPix * sizeof(SGMPixel), hipMemcpyHostToDevice, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+static void launchPath(sgmhip_engine* e, int NK, int lines, size_t shmem, int P1, int dx, int dy, const SGMLines& ln) {
+	switch (NK) {
+	case 1: hipLaunchKernelGGL((sgm_path_kernel<1>), dim3(lines), dim3(64), shmem, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, e->d_accums, e->d_P2s, P1, dx, dy, ln, e->maxNumDisp); break;
+	case 2: hipLaunchKernelGGL((sgm_path_kernel<2>), dim3(lines), dim3(64), shmem, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, e->d_accums, e->d_P2s, P1, dx, dy, ln, e->maxNumDisp); break;
+	default: hipLaunchKernelGGL((sgm_path_kernel<4>), dim3(lines), dim3(64), shmem, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, e->d_accums, e->d_P2s, P1, dx, dy, ln, e->maxNumDisp); break;
+	}
+}
+
+int sgmhip_match(sgmhip_engine* e, uint16_t P1, const uint16_t P2s[256], int sync) {
+	if (!e || !P2s || e->numCosts == 0) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	SGMCHK(e, hipMemcpyAsync(e->d_P2s, P2s, 512, hipMemcpyHostToDevice, e->stream));
+	const long nPix = (long)e->vw * e->vh;
+	const int W = e->vw, H = e->vh;
+	evB(e, 0);
+	hipLaunchKernelGGL(sgm_cost_kernel, dim3((unsigned)((nPix + 3) / 4)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_costs);
+	evE(e);
+	SGMCHK(e, hipMemsetAsync(e->d_accums, 0, e->numCosts * 2, e->stream)); // imageAccumCosts.Memset(0), :990
+	const int NK = e->maxNumDisp <= 64 ? 1 : (e->maxNumDisp <= 128 ? 2 : 4);
+	const size_t shmem = sizeof(int) * 2 * (size_t)(e->maxNumDisp + 2);
+	// the eight paths with the threaded variant's start sets, SemiGlobalMatcher.cpp:1083-1200
+	struct Dir { int dx, dy; SGMLines ln; } dirs[8] = {
+		{0, 1,   {W, 0, 0, 1, 0,      0, 0, 0, 0, 0}},            // width-down
+		{1, 0,   {H, 0, 0, 0, 1,      0, 0, 0, 0, 0}},            // height-right
+		{0, -1,  {W, 0, H - 1, 1, 0,  0, 0, 0, 0, 0}},            // width-up
+		{-1, 0,  {H, W - 1, 0, 0, 1,  0, 0, 0, 0, 0}},            // height-left
+		{1, 1,   {W, 0, 0, 1, 0,      H - 1, 0, 1, 0, 1}},        // right-down: top row, then left column y >= 1
+		{-1, 1,  {W - 1, 0, 0, 1, 0,  H, W - 1, 0, 0, 1}},        // left-down: top row x < W-1, then right column
+		{1, -1,  {W - 1, 1, H - 1, 1, 0,  H, 0, 0, 0, 1}},        // right-up: bottom row x >= 1, then left column
+		{-1, -1, {W, 0, H - 1, 1, 0,  H - 1, W - 1, 0, 0, 1}},    // left-up: bottom row, then right column y <= H-2
+	};
+	evB(e, 1);
+	for (const Dir& d : dirs) {
+		const int lines = d.ln.nA + d.ln.nB;
+		if (lines > 0) launchPath(e, NK, lines, shmem, (int)P1, d.dx, d.dy, d.ln);
+		if (e->statsOn) e->stats.aggrLaunches += 1;
+	}
+	evE(e);
+	evB(e, 2);
+	hipLaunchKernelGGL(sgm_wta_kernel, dim3((unsigned)((nPix + 3) / 4)), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, e->d_cost);
+	evE(e);
+	SGMCHK(e, hipGetLastError());
+	if (e->statsOn) e->stats.calls += 1;
+	if (sync) SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+int sgmhip_get_results(sgmhip_engine* e, int16_t* disparity, uint16_t* cost, uint8_t* costs, uint16_t* accums) {
+	if (!e || e->numCosts == 0) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	const size_t nPix = (size_t)e->vw * e->vh;
+	if (disparity) SGMCHK(e, hipMemcpyAsync(disparity, e->d_disp, nPix * 2, hipMemcpyDeviceToHost, e->stream));
+	if (cost) SGMCHK(e, hipMemcpyAsync(cost, e->d_cost, nPix * 2, hipMemcpyDeviceToHost, e->stream));
+	if (costs) SGMCHK(e, hipMemcpyAsync(costs, e->d_costs, e->numCosts, hipMemcpyDeviceToHost, e->stream));
+	if (accums) SGMCHK(e, hipMemcpyAsync(accums, e->d_accums, e->numCosts * 2, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+int sgmhip_sync(sgmhip_engine* e) { if (!e) return SGMHIP_E_ARG; SGMCHK(e, hipSetDevice(e->device)); SGMCHK(e, hipStreamSynchronize(e->stream)); return 0; }
+int sgmhip_stats_reset(sgmhip_engine* e, int enable) { if (!e) return SGMHIP_E_ARG; hipSetDevice(e->device); sgmCollect(e); memset(&e->stats, 0, sizeof(e->stats)); e->statsOn = enable != 0; return 0; }
+int sgmhip_stats_get(sgmhip_engine* e, SGMHipStats* out) { if (!e || !out) return SGMHIP_E_ARG; hipSetDevice(e->device); int rc = sgmCollect(e); if (rc) return rc; *out = e->stats; return 0; }
+
+} // extern "C"

@@ -1,0 +1,199 @@
+// sgm_kernels.hip -- CDNA4 (gfx950) kernels for SemiGlobalMatcher::Match(ViewData,ViewData,...)
+// (libs/MVS/SemiGlobalMatcher.cpp:863-1302): WZNCC cost volume, 8-path aggregation, winner-take-all.
+//
+// Layout is the reference's: a ragged cost volume, pixel p owns numDisp(p) consecutive entries at
+// PixelData::idx (u8 costs, u16 path sums).  All three kernels map the 64 lanes of a wave onto the
+// disparities of ONE pixel, so a wave's accesses to costs / sums are one contiguous 64..128-byte
+// segment (coalesced), the cross-disparity minimum is a wave reduction, and the path recurrence
+// L(d) <- Lp(d-1), Lp(d), Lp(d+1) goes through a 2-slot LDS line buffer.  Integer work is exact.
+//
+// The aggregation is a chain of dependent pixels along each path, so one wave owns one line and
+// walks it in chunks of SGM_T pixels: the PixelData, cost bytes and running sums of a whole chunk
+// are requested up front (independent loads, latency overlapped), then the chunk is consumed
+// serially.  The O(D^2) inner loop of the reference (:1030-1044) is evaluated in its O(D) form
+// (valid because P1 <= P2; see oracle/sgm_oracle.cpp: orc_sgm_step_forms_agree).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pm_math.h"
+
+struct SGMPixel { unsigned long long idx; short minDisp, maxDisp; int pad; }; // == SGMHipPixelData
+#define SGM_HW 3
+#define SGM_NT 49
+#define SGM_T 8          // pixels per prefetch chunk
+#define SGM_INF 0x3fffffff
+
+__device__ __forceinline__ int sgm_round2int(float x) { return (int)pm_floorf(x + .5f); } // ROUND2INT, Types.h:949-955
+
+// ---- cost volume, SemiGlobalMatcher.cpp:874-985: one wave per valid-grid pixel ---------------
+__global__ __launch_bounds__(256) void sgm_cost_kernel(const unsigned char* __restrict__ colorL, const float* __restrict__ grayL,
+		const float* __restrict__ grayR, int w, int h, int vw, int vh, const SGMPixel* __restrict__ pixels, unsigned char* __restrict__ costs) {
+	__shared__ float2 s_w[4][SGM_NT + 1];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const long pix = (long)blockIdx.x * 4 + wave;
+	const bool active = pix < (long)vw * vh;
+	SGMPixel px; px.idx = 0; px.minDisp = 0; px.maxDisp = 0;
+	if (active) px = pixels[pix];
+	const bool valid = active && px.minDisp < px.maxDisp;
+	const int ux = (int)(pix % vw) + SGM_HW, uy = (int)(pix / vw) + SGM_HW;
+	const float sigmaColor = -1.f / (2.f * ((0.3f * 255) * (0.3f * 255)));
+	const float sigmaSpatial = -1.f / (2.f * ((0.4f * 7) * (0.4f * 7)));
+	if (valid && lane < SGM_NT) {
+		const int i = lane / 7 - SGM_HW, j = lane % 7 - SGM_HW;
+		const unsigned char* a = colorL + ((size_t)(uy + i) * w + (ux + j)) * 3;
+		const unsigned char* c = colorL + ((size_t)uy * w + ux) * 3;
+		unsigned s = 0;
+#pragma unroll
+		for (int k = 0; k < 3; ++k) { const unsigned d = a[k] < c[k] ? c[k] - a[k] : a[k] - c[k]; s += d * d; }
+		const float wColor = (float)s * sigmaColor;
+		const float wSpatial = (float)(j * j + i * i) * sigmaSpatial;
+		s_w[wave][lane] = make_float2(pm_expf(wColor + wSpatial), grayL[(size_t)(uy + i) * w + (ux + j)]);
+	}
+	__syncthreads();
+	float sumW = 0.f, normSq0 = 0.f, tm = 0.f;
+	if (valid) {
+		float acc = 0.f;
+		for (int k = 0; k < SGM_NT; ++k) { const float2 p = s_w[wave][k]; acc += p.y * p.x; sumW += p.x; }
+		tm = acc / sumW;
+		for (int k = 0; k < SGM_NT; ++k) { const float2 p = s_w[wave][k]; const float t = p.y - tm; const float tw = p.x * t; normSq0 += tw * t; }
+	}
+	__syncthreads();
+	if (valid && lane < SGM_NT) { const float2 p = s_w[wave][lane]; s_w[wave][lane] = make_float2(p.x, p.x * (p.y - tm)); }
+	__syncthreads();
+	if (!valid) return;
+	const float eps = 1e-3f;
+	for (int d = px.minDisp + lane; d < px.maxDisp; d += 64) {
+		unsigned char cost;
+		if (ux - SGM_HW + d < 0 || ux + SGM_HW + d >= w) cost = 255; // some tap outside the right image (:954-957)
+		else {
+			float sum = 0.f, sumSq = 0.f, nom = 0.f;
+			int n = 0;
+			for (int i = -SGM_HW; i <= SGM_HW; ++i) {
+				const float* row = grayR + (size_t)(uy + i) * w + (ux + d);
+#pragma unroll
+				for (int j = -SGM_HW; j <= SGM_HW; ++j) {
+					const float f = row[j];
+					const float2 pw = s_w[wave][n++];
+					const float fw = f * pw.x;
+					sum += fw; sumSq += f * fw; nom += f * pw.y;
+				}
+			}
+			const float normSq1 = sumSq - (sum * sum) / sumW;
+			const float ncc = nom / pm_sqrtf(normSq0 * normSq1 + eps);
+			cost = ncc <= 0 ? (unsigned char)255 : (unsigned char)sgm_round2int((1.f - pm_minf(ncc, 1.f)) * 255.f);
+		}
+		costs[px.idx + (unsigned)(d - px.minDisp)] = cost;
+	}
+}
+
+// line start sets of one path direction: nA lines from (ax,ay) stepping (adx,ady), then the rest from (bx,by)
+struct SGMLines { int nA, ax, ay, adx, ady, nB, bx, by, bdx, bdy; };
+
+// ---- wave helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ int sgm_wave_min(int v) {
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
+	return v;
+}
+
+// ---- one path direction, SemiGlobalMatcher.cpp:1003-1046 + ACCUM_PIXELS :1065-1082 -----------
+// One 64-thread workgroup (one wave) per line.  NK = ceil(maxNumDisp / 64) disparities per lane.
+// Line start sets are the threaded variant's (:1083-1200); see the host for the numbering.
+template <int NK>
+__global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ grayL, int w, int vw, int vh,
+		const SGMPixel* __restrict__ pixels, const unsigned char* __restrict__ costs, unsigned short* __restrict__ accums,
+		const unsigned short* __restrict__ P2s, int P1, int dx, int dy, SGMLines ln, int maxNumDisp) {
+	extern __shared__ __attribute__((aligned(16))) int s_L[]; // 2 x (maxNumDisp + 2): previous / current line of L
+	const int lane = threadIdx.x;
+	const int line = blockIdx.x;
+	int x, y;
+	if (line < ln.nA) { x = ln.ax + line * ln.adx; y = ln.ay + line * ln.ady; }
+	else { const int i = line - ln.nA; x = ln.bx + i * ln.bdx; y = ln.by + i * ln.bdy; }
+	const int stride = maxNumDisp + 2;
+	int cur = 0;
+	int rpMin = 0, rpMax = 0;
+	float Ip = 0.5f;
+	for (int k = lane; k < 2 * stride; k += 64) s_L[k] = 0;
+	__syncthreads();
+	while (x >= 0 && y >= 0 && x < vw && y < vh) {
+		// ---- request a chunk of SGM_T pixels along the path -------------------------------------
+		SGMPixel px[SGM_T]; float gI[SGM_T]; bool ok[SGM_T];
+		unsigned char c8[SGM_T][NK]; unsigned short a16[SGM_T][NK];
+#pragma unroll
+		for (int t = 0; t < SGM_T; ++t) {
+			const int tx = x + t * dx, ty = y + t * dy;
+			ok[t] = tx >= 0 && ty >= 0 && tx < vw && ty < vh;
+			px[t].idx = 0; px[t].minDisp = 0; px[t].maxDisp = 0; gI[t] = 0.f;
+			if (ok[t]) {
+				px[t] = pixels[(size_t)ty * vw + tx];
+				gI[t] = grayL[(size_t)ty * w + tx]; // imageGray(u) with the valid-grid coordinate: the reference's quirk (:1078)
+			}
+		}
+#pragma unroll
+		for (int t = 0; t < SGM_T; ++t) {
+			const int nD = px[t].maxDisp - px[t].minDisp;
+			ok[t] = ok[t] && nD > 0;
+#pragma unroll
+			for (int q = 0; q < NK; ++q) {
+				const int k = lane + 64 * q;
+				c8[t][q] = 0; a16[t][q] = 0;
+				if (ok[t] && k < nD) { c8[t][q] = costs[px[t].idx + k]; a16[t][q] = accums[px[t].idx + k]; }
+			}
+		}
+		// ---- consume it serially ----------------------------------------------------------------
+#pragma unroll
+		for (int t = 0; t < SGM_T; ++t) {
+			if (!ok[t]) continue; // invalid pixels do not reset Lp / Ip (:1071-1072)
+			const int rsMin = px[t].minDisp, rsMax = px[t].maxDisp, nD = rsMax - rsMin;
+			const float DI = gI[t] - Ip;
+			int ip = sgm_round2int(255.f * DI); ip = ip < 0 ? -ip : ip;
+			const int P2 = P2s[ip];
+			const int lo = max(rpMin, rsMin), hi = min(rpMax, rsMax);
+			const int* Lp = s_L + cur * stride + 1;       // Lp[d - rpMin]
+			int* Ls = s_L + (cur ^ 1) * stride + 1;        // Ls[d - rsMin]
+			if (lo >= hi) {
+#pragma unroll
+				for (int q = 0; q < NK; ++q) {
+					const int k = lane + 64 * q;
+					if (k < nD) { const int L = (int)c8[t][q] + P2; Ls[k] = L; accums[px[t].idx + k] = (unsigned short)(a16[t][q] + L); }
+				}
+			} else {
+				int m = SGM_INF;
+				for (int dp = lo + lane; dp < hi; dp += 64) m = min(m, Lp[dp - rpMin]);
+				m = sgm_wave_min(m);
+#pragma unroll
+				for (int q = 0; q < NK; ++q) {
+					const int k = lane + 64 * q;
+					if (k < nD) {
+						const int d = rsMin + k;
+						int best = m + P2;
+						if (d >= lo && d < hi) best = min(best, Lp[d - rpMin]);
+						if (d - 1 >= lo && d - 1 < hi) best = min(best, Lp[d - 1 - rpMin] + P1);
+						if (d + 1 >= lo && d + 1 < hi) best = min(best, Lp[d + 1 - rpMin] + P1);
+						const int L = (int)c8[t][q] + best - m;
+						Ls[k] = L; accums[px[t].idx + k] = (unsigned short)(a16[t][q] + L);
+					}
+				}
+			}
+			rpMin = rsMin; rpMax = rsMax; Ip = gI[t]; cur ^= 1;
+			__syncthreads();
+		}
+		x += SGM_T * dx; y += SGM_T * dy;
+	}
+}
+
+// ---- winner-take-all, SemiGlobalMatcher.cpp:1272-1301: one wave per pixel --------------------
+__global__ __launch_bounds__(256) void sgm_wta_kernel(const SGMPixel* __restrict__ pixels, const unsigned short* __restrict__ accums,
+		long nPix, short* __restrict__ disp, unsigned short* __restrict__ cost) {
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const long pix = (long)blockIdx.x * 4 + wave;
+	if (pix >= nPix) return;
+	const SGMPixel px = pixels[pix];
+	const int nD = px.maxDisp - px.minDisp;
+	if (nD <= 0) { if (lane == 0) { disp[pix] = px.minDisp; cost[pix] = 0xFFFF; } return; }
+	// first minimum == lexicographic minimum of (value, index)
+	unsigned key = 0xFFFFFFFFu;
+	for (int k = lane; k < nD; k += 64) key = min(key, ((unsigned)accums[px.idx + k] << 16) | (unsigned)k);
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, m, 64));
+	if (lane == 0) { disp[pix] = (short)(px.minDisp + (int)(key & 0xFFFFu)); cost[pix] = (unsigned short)(key >> 16); }
+}

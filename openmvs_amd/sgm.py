@@ -1,0 +1,112 @@
+"""ctypes binding of libsgmhip.so: host-side mirror of SemiGlobalMatcher::Match(ViewData, ViewData,
+DisparityMap&, AccumCostMap&) (libs/MVS/SemiGlobalMatcher.cpp:863-1302).  No CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+PIXEL_DTYPE = np.dtype([("idx", np.uint64), ("minDisp", np.int16), ("maxDisp", np.int16), ("pad", np.int32)])
+EXPORTS = ["sgmhip_create", "sgmhip_destroy", "sgmhip_last_error", "sgmhip_generate_p2s", "sgmhip_set_problem",
+           "sgmhip_match", "sgmhip_get_results", "sgmhip_sync", "sgmhip_stats_reset", "sgmhip_stats_get"]
+
+
+class SGMHipStats(C.Structure):
+    _fields_ = [("costMs", C.c_double), ("aggrMs", C.c_double), ("wtaMs", C.c_double), ("calls", C.c_uint64), ("aggrLaunches", C.c_uint64)]
+
+
+_LIB = None
+
+
+def load_library() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        path = os.environ.get("SGMHIP_LIB") or _build.build_lib("libsgmhip.so")
+        if path is None or not os.path.exists(path):
+            raise RuntimeError("libsgmhip.so is not built (python -m openmvs_amd.build)")
+        lib = C.CDLL(path)
+        lib.sgmhip_last_error.restype = C.c_char_p
+        lib.sgmhip_destroy.restype = None
+        for n in EXPORTS:
+            getattr(lib, n)
+        _LIB = lib
+    return _LIB
+
+
+def generate_p2s(P2=4, alpha=14.0, beta=38.0) -> np.ndarray:
+    """SemiGlobalMatcher::GenerateP2s with the ctor defaults (SemiGlobalMatcher.h:151)."""
+    out = np.zeros(256, np.uint16)
+    load_library().sgmhip_generate_p2s(C.c_uint16(P2), C.c_float(alpha), C.c_float(beta), out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return out
+
+
+def make_pixels(ranges_min: np.ndarray, ranges_max: np.ndarray):
+    """Build the PixelData table (SemiGlobalMatcher.h:79-82) for a valid grid: idx = running sum of numDisp."""
+    mn = np.ascontiguousarray(ranges_min, np.int16); mx = np.ascontiguousarray(ranges_max, np.int16)
+    nd = np.maximum(mx.astype(np.int64) - mn.astype(np.int64), 0).ravel()
+    idx = np.concatenate([[0], np.cumsum(nd)[:-1]]).astype(np.uint64)
+    px = np.zeros(nd.size, PIXEL_DTYPE)
+    px["idx"] = idx; px["minDisp"] = mn.ravel(); px["maxDisp"] = mx.ravel()
+    return px, int(nd.sum()), int(nd.max())
+
+
+class SGMError(RuntimeError):
+    pass
+
+
+class SemiGlobalMatcherHIP:
+    def __init__(self, device: int = 0, P1: int = 3, P2: int = 4, P2alpha: float = 14.0, P2beta: float = 38.0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.sgmhip_create(C.c_int(device), C.byref(self._h))
+        if rc != 0:
+            raise SGMError(f"sgmhip_create failed ({rc}): no usable HIP device")
+        self.P1 = P1
+        self.P2s = generate_p2s(P2, P2alpha, P2beta)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SGMError(f"sgmhip error {rc}: {self._lib.sgmhip_last_error(self._h).decode()}")
+
+    def set_problem(self, left_bgr, left_gray, right_gray, pixels, num_costs, max_num_disp):
+        lb = np.ascontiguousarray(left_bgr, np.uint8); lg = np.ascontiguousarray(left_gray, np.float32); rg = np.ascontiguousarray(right_gray, np.float32)
+        h, w = lg.shape
+        px = np.ascontiguousarray(pixels)
+        assert px.dtype == PIXEL_DTYPE and px.size == (w - 6) * (h - 6)
+        self._shape = (h - 6, w - 6); self._num = num_costs
+        self._chk(self._lib.sgmhip_set_problem(self._h, lb.ctypes.data_as(C.POINTER(C.c_uint8)), lg.ctypes.data_as(C.POINTER(C.c_float)),
+                                               rg.ctypes.data_as(C.POINTER(C.c_float)), w, h, px.ctypes.data_as(C.c_void_p), C.c_uint64(num_costs), max_num_disp))
+
+    def Match(self, sync=True):
+        self._chk(self._lib.sgmhip_match(self._h, C.c_uint16(self.P1), self.P2s.ctypes.data_as(C.POINTER(C.c_uint16)), 1 if sync else 0))
+
+    def results(self, volumes=False):
+        d = np.zeros(self._shape, np.int16); c = np.zeros(self._shape, np.uint16)
+        costs = np.zeros(self._num, np.uint8) if volumes else None
+        acc = np.zeros(self._num, np.uint16) if volumes else None
+        self._chk(self._lib.sgmhip_get_results(self._h, d.ctypes.data_as(C.POINTER(C.c_int16)), c.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                               costs.ctypes.data_as(C.POINTER(C.c_uint8)) if volumes else None,
+                                               acc.ctypes.data_as(C.POINTER(C.c_uint16)) if volumes else None))
+        return (d, c, costs, acc) if volumes else (d, c)
+
+    def sync(self):
+        self._chk(self._lib.sgmhip_sync(self._h))
+
+    def stats_reset(self, enable=True):
+        self._chk(self._lib.sgmhip_stats_reset(self._h, 1 if enable else 0))
+
+    def stats_get(self) -> SGMHipStats:
+        s = SGMHipStats(); self._chk(self._lib.sgmhip_stats_get(self._h, C.byref(s))); return s
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sgmhip_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -145,3 +145,30 @@ def math_eval(kind, a, b=None):
     a = np.ascontiguousarray(a, np.float32); b = a if b is None else np.ascontiguousarray(b, np.float32)
     o = np.zeros_like(a)
     lib().orc_math_eval(C.c_int(kind), _fp(a), _fp(b), _fp(o), C.c_size_t(a.size)); return o
+
+
+# ---- SGM oracle (oracle/sgm_oracle.cpp) -----------------------------------------------------
+def sgm_generate_p2s(P2=4, alpha=14.0, beta=38.0):
+    out = np.zeros(256, np.uint16)
+    lib().orc_sgm_generate_p2s(C.c_uint16(P2), C.c_float(alpha), C.c_float(beta), out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return out
+
+
+def sgm_match(left_bgr, left_gray, right_gray, pixels, num_costs, max_num_disp, P1, P2s):
+    lb = np.ascontiguousarray(left_bgr, np.uint8); lg = np.ascontiguousarray(left_gray, np.float32); rg = np.ascontiguousarray(right_gray, np.float32)
+    h, w = lg.shape
+    px = np.ascontiguousarray(pixels); p2 = np.ascontiguousarray(P2s, np.uint16)
+    d = np.zeros((h - 6, w - 6), np.int16); c = np.zeros((h - 6, w - 6), np.uint16)
+    costs = np.zeros(num_costs, np.uint8); acc = np.zeros(num_costs, np.uint16)
+    lib().orc_sgm_match(lb.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(lg), _fp(rg), C.c_int(w), C.c_int(h), px.ctypes.data_as(C.c_void_p),
+                        C.c_uint64(num_costs), C.c_int(max_num_disp), C.c_uint16(P1), p2.ctypes.data_as(C.POINTER(C.c_uint16)),
+                        d.ctypes.data_as(C.POINTER(C.c_int16)), c.ctypes.data_as(C.POINTER(C.c_uint16)),
+                        costs.ctypes.data_as(C.POINTER(C.c_uint8)), acc.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return d, c, costs, acc
+
+
+def sgm_step_forms_agree(Lp, pmin, pmax, costs, smin, smax, P1, P2) -> bool:
+    Lp = np.ascontiguousarray(Lp, np.uint16); costs = np.ascontiguousarray(costs, np.uint8)
+    lib().orc_sgm_step_forms_agree.restype = C.c_int
+    return bool(lib().orc_sgm_step_forms_agree(Lp.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int(pmin), C.c_int(pmax),
+                                               costs.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(smin), C.c_int(smax), C.c_uint16(P1), C.c_uint16(P2)))

@@ -25,6 +25,20 @@ def test_pmhip_exports_every_declared_symbol():
     assert sorted(patchmatch.EXPORTS) == names
 
 
+def test_sgmhip_exports_every_declared_symbol():
+    from openmvs_amd import sgm
+    lib = sgm.load_library()
+    names = _declared("sgmhip.h")
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(sgm.EXPORTS) == names
+    assert sgm.PIXEL_DTYPE.itemsize == 16 and C.sizeof(sgm.SGMHipStats) == 40
+    # GenerateP2s needs no GPU: P2*(1+alpha) .. P2
+    p = sgm.generate_p2s()
+    assert p[0] == 60 and p[255] == 4
+
+
 def test_struct_sizes_match_header():
     from openmvs_amd import patchmatch as pm
     assert C.sizeof(pm.PMHipParams) == 4 * 4 + 9 * 4 + 4

@@ -23,6 +23,24 @@ LIBS = {
 }
 
 
+HOST_LIBS = {"libdmapio.so": (["dmap_io.cpp"], ["../../include/dmapio.h"])}   # plain C++ (g++), no GPU code
+
+
+def build_host_lib(name: str, force: bool = False) -> str | None:
+    srcs, deps = HOST_LIBS[name]
+    srcs_abs = [os.path.join(_CSRC, s) for s in srcs]
+    out = lib_path(name)
+    if not force and not _stale(out, srcs_abs + [os.path.normpath(os.path.join(_CSRC, d)) for d in deps]):
+        return out
+    cxx = shutil.which("g++")
+    if cxx is None:
+        if os.path.exists(out):
+            return out
+        raise RuntimeError("g++ not found and %s is not built" % name)
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-shared", "-fPIC"] + srcs_abs + ["-o", out], cwd=_CSRC)
+    return out
+
+
 def lib_path(name: str) -> str:
     return os.path.join(_HERE, name)
 
@@ -62,7 +80,7 @@ def build_lib(name: str, force: bool = False, verbose: bool = False) -> str | No
 
 
 def build_all(force: bool = False, verbose: bool = False) -> list[str]:
-    return [p for p in (build_lib(n, force, verbose) for n in LIBS) if p]
+    return [p for p in (build_lib(n, force, verbose) for n in LIBS) if p] + [build_host_lib(n, force) for n in HOST_LIBS]
 
 
 if __name__ == "__main__":

@@ -1,0 +1,70 @@
+"""`.dmap` on-disk format: byte-identical writer, reader round trip, flags."""
+import os
+
+import numpy as np
+import pytest
+
+from openmvs_amd import dmap
+from tests.golden.make_dmap_golden import content
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_writer_reproduces_the_file_the_reference_reader_accepted(tmp_path):
+    # tests/golden/depth0007.dmap was written by this writer and parsed by the reference's
+    # scripts/python/MvsUtils.py::loadDMAP at fixture-generation time (make_dmap_golden.py)
+    p = tmp_path / dmap.depth_file_name(7)
+    dmap.save(p, **content())
+    assert open(p, "rb").read() == open(os.path.join(GOLD, "depth0007.dmap"), "rb").read()
+    assert not os.path.exists(str(p) + ".tmp")            # written to .tmp then renamed (DepthMap.cpp:234-252)
+
+
+def test_layout_is_the_28_byte_header_plus_planes(tmp_path):
+    c = content()
+    p = tmp_path / "d.dmap"
+    dmap.save(p, **c)
+    raw = open(p, "rb").read()
+    assert raw[:2] == b"DR" and raw[2] == 15 and raw[3] == 0
+    assert np.frombuffer(raw[4:20], np.uint32).tolist() == [40, 24, 20, 12]
+    n = 20 * 12
+    assert len(raw) == 28 + 2 + len(c["image_name"]) + 4 + 4 * 4 + 21 * 8 + n * 4 + n * 12 + n * 4 + n * 4
+
+
+def test_reader_round_trip_and_flags(tmp_path):
+    c = content()
+    p = tmp_path / "d.dmap"
+    dmap.save(p, **c)
+    d = dmap.load(p)
+    assert d["file_name"] == c["image_name"] and d["reference_view_id"] == 7 and d["neighbor_view_ids"] == [3, 9, 12]
+    assert np.array_equal(d["depth_map"], c["depth"]) and np.array_equal(d["normal_map"], c["normal"])
+    assert np.array_equal(d["confidence_map"], c["conf"]) and np.array_equal(d["views_map"], c["views"])
+    assert np.array_equal(d["K"], c["K"]) and np.array_equal(d["R"], c["R"]) and np.array_equal(d["C"], c["Cc"])
+    d1 = dmap.load(p, flags=1)                              # InitViews loads neighbours with flags 1 (SceneDensify.cpp:389-391)
+    assert "normal_map" not in d1 and np.array_equal(d1["depth_map"], c["depth"])
+    d3 = dmap.load(p, flags=5)
+    assert "normal_map" not in d3 and np.array_equal(d3["confidence_map"], c["conf"])
+    c2 = dict(c, normal=None, views=None)
+    dmap.save(p, **c2)
+    d = dmap.load(p)
+    assert not d["has_normal"] and d["has_conf"] and not d["has_views"] and np.array_equal(d["confidence_map"], c["conf"])
+
+
+def test_invalid_files_are_rejected(tmp_path):
+    p = tmp_path / "bad.dmap"
+    open(p, "wb").write(b"XX" + b"\0" * 64)
+    with pytest.raises(IOError):
+        dmap.load(p)
+    with pytest.raises(IOError):
+        dmap.load(tmp_path / "missing.dmap")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/scripts/python"), reason="reference tree only exists in the build container")
+def test_reference_reader_parses_our_file(tmp_path):
+    import sys
+    sys.path.insert(0, "/root/reference/scripts/python")
+    from MvsUtils import loadDMAP
+    c = content()
+    p = tmp_path / "d.dmap"
+    dmap.save(p, **c)
+    d = loadDMAP(str(p))
+    assert np.array_equal(d["depth_map"], c["depth"]) and np.array_equal(d["normal_map"], c["normal"]) and np.array_equal(d["views_map"], c["views"])

@@ -1,0 +1,21 @@
+"""SGM timing probe (GPU box): BASELINE config 4, 2048x1536, D = 64 / 128, + ragged tSGM-like ranges."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from openmvs_amd import sgm
+from tests import sgm_cases as sc
+w, h = 2048, 1536
+lb, lg, rg = sc.stereo_pair(w, h, 21, seed=9)
+m = sgm.SemiGlobalMatcherHIP(0)
+for kind, lo, hi in (("uniform", 0, 64), ("uniform", 0, 128), ("ragged", 0, 64)):
+    px, n, mx = sc.ranges(w, h, kind, lo, hi)
+    m.set_problem(lb, lg, rg, px, n, mx)
+    m.Match()
+    m.stats_reset(True); t = time.time()
+    reps = 4
+    for _ in range(reps): m.Match(sync=False)
+    m.sync(); dt = (time.time() - t) / reps
+    s = m.stats_get()
+    gb = 43.0 * n / 1e9
+    print("%s D<=%d numCosts %.1fM: %.2f ms/match (cost %.2f aggr %.2f wta %.2f) -> %.1f GB/s on the 43 B/cost model (aggr alone: %.1f GB/s of 40 B/cost)" % (
+        kind, hi - lo, n / 1e6, dt * 1e3, s.costMs / reps, s.aggrMs / reps, s.wtaMs / reps, gb / dt, 40.0 * n / 1e9 / (s.aggrMs / reps / 1e3)), flush=True)

@@ -97,32 +97,38 @@ def main():
     del gray
     torch.cuda.empty_cache()
     p = default_params(seed=1, nEstimationGeometricIters=a.geo_iters)
-    mine = list(range(rank * Vg, (rank + 1) * Vg))
     B = a.batch if a.batch > 0 else Vg
-    batches = [mine[i:i + B] for i in range(0, Vg, B)]
-    snap_mine = torch.empty((Vg, H, W), dtype=torch.float32, device=dev) if world > 1 else None
-    snap_all = torch.empty((V, H, W), dtype=torch.float32, device=dev) if world > 1 else None
 
-    def exchange():
-        # previous-round depth maps of all views become visible to every rank (the reference writes
-        # depthNNNN.dmap and re-reads the neighbours' files, SceneDensify.cpp:378-393,1943-1950)
-        eng.scene_commit_round()
-        if world > 1:
-            eng.scene_copy(4, rank * Vg, Vg, snap_mine.data_ptr(), False)
+    class EngineEstimator:
+        """Adapter between the sharding driver (openmvs_amd/distributed.py, also exercised under gloo
+        in tests/test_distributed.py) and the HBM-resident scene interface of the HIP engine."""
+
+        def __init__(self):
+            self.buf = torch.empty((Vg, H, W), dtype=torch.float32, device=dev)
+
+        def reset(self, ids):
+            for v in ids:
+                eng.scene_reset_view(v)
+
+        def estimate(self, ids, geo):
+            for i in range(0, len(ids), B):
+                eng.scene_estimate(ids[i:i + B], geo, p, sync=False)
+
+        def local_depths(self, ids):
+            eng.scene_copy(1, ids[0], len(ids), self.buf.data_ptr(), False)
             eng.sync()
-            dist.all_gather_into_tensor(snap_all, snap_mine)
-            torch.cuda.synchronize()
-            eng.scene_copy(4, 0, V, snap_all.data_ptr(), True)
+            return self.buf
 
-    def step():
-        for v in mine:
-            eng.scene_reset_view(v)
-        for b in batches:
-            eng.scene_estimate(b, -1, p, sync=False)
-        for g in range(a.geo_iters):
-            exchange()
-            for b in batches:
-                eng.scene_estimate(b, g, p, sync=False)
+        def set_snapshot(self, allv):
+            # previous-round depth maps of all views become visible to this rank (the reference writes
+            # depthNNNN.dmap and re-reads the neighbours' files, SceneDensify.cpp:378-393,1943-1950)
+            torch.cuda.synchronize()
+            eng.scene_copy(4, 0, V, allv.data_ptr(), True)
+
+    from openmvs_amd.distributed import ShardedDensifier
+    drv = ShardedDensifier(EngineEstimator(), V, world, rank, geo_iters=a.geo_iters)
+    assert len(drv.mine) == Vg
+    step = drv.run
 
     def fence():
         eng.sync(); torch.cuda.synchronize()

@@ -1,0 +1,79 @@
+"""N > 1 path on CPU: 2 gloo ranks shard the reference views, exchange depth maps at round
+boundaries, and must reproduce the single-process result exactly.  The estimator stand-in is the
+CPU oracle (tests may use it); the GPU box runs the same driver with the HIP engine (bench.py)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from openmvs_amd import synth
+from openmvs_amd.distributed import ShardedDensifier, all_gather_views, shard_range
+
+SEED = 9
+
+
+class OracleEstimator:
+    def __init__(self, sc):
+        from oracle import pyoracle as po
+        self.po, self.sc = po, sc
+        h, w = sc.height, sc.width
+        self.depth = np.zeros((sc.n_views, h, w), np.float32); self.normal = np.zeros((sc.n_views, h, w, 3), np.float32)
+        self.conf = np.zeros((sc.n_views, h, w), np.float32); self.snap = None
+
+    def reset(self, ids):
+        for v in ids:
+            self.depth[v] = 0; self.normal[v] = 0; self.conf[v] = 0
+
+    def estimate(self, ids, geo):
+        po, sc = self.po, self.sc
+        for v in ids:
+            vid = [v] + list(sc.neighbors[v])
+            src = None if geo < 0 else {i: self.snap[i] for i in range(sc.n_views)}
+            views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, vid, depth_maps=src)
+            opt = po.default_opt(seed=SEED, viewID=v, nSubResolutionLevels=1)
+            self.depth[v], self.normal[v], self.conf[v] = po.estimate_depth_map(views, len(vid), float(sc.dmin[v]), float(sc.dmax[v]), opt, geo_iter=geo,
+                                                                                  depth=self.depth[v], normal=self.normal[v])
+
+    def local_depths(self, ids):
+        return torch.from_numpy(self.depth[list(ids)].copy())
+
+    def set_snapshot(self, allv):
+        self.snap = allv.numpy().copy()
+
+
+def _scene():
+    return synth.make_scene(4, 48, 32, n_src=3)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = _scene()
+    est = OracleEstimator(sc)
+    drv = ShardedDensifier(est, sc.n_views, world, rank, geo_iters=2)
+    drv.run()
+    final = all_gather_views(est.local_depths(drv.mine), sc.n_views, world, rank)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "sharded.npy"), final.numpy())
+    dist.destroy_process_group()
+
+
+def test_shard_ranges_cover_everything():
+    for n, w in ((100, 8), (7, 2), (5, 8), (16, 4)):
+        got = [v for r in range(w) for v in shard_range(n, w, r)]
+        assert got == list(range(n))
+
+
+def test_two_ranks_match_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    sharded = np.load(tmp_path / "sharded.npy")
+    sc = _scene()
+    est = OracleEstimator(sc)
+    ShardedDensifier(est, sc.n_views, 1, 0, geo_iters=2).run()
+    assert np.array_equal(sharded, est.depth)
+    assert (sharded > 0).mean() > 0.3

@@ -147,6 +147,8 @@ int pmhip_stats_get(pmhip_engine* e, PMHipKernelStats* out);
 /* ---- 3. self-test hooks (used by tests/, no oracle involved) ------------------------------ */
 /* Evaluate csrc/pm_math.h on the device: kind 0 exp, 1 acos, 2 atan2(a,b), 3 sin, 4 cos, 5 sqrt, 6 a/b, 7 (float)sqrt((double)a*a+(double)b*b). */
 int pmhip_math_eval(pmhip_engine* e, int kind, const float* a, const float* b, float* out, size_t n);
+/* Per-phase cycle counters of the sweep kernel (all zero unless the library was built with -DPM_PROFILE). */
+int pmhip_prof_get(pmhip_engine* e, unsigned long long out16[16], int reset);
 /* Device resampling kernels on host buffers: kind 0 area (factor f = arg), 1 linear x2, 2 nearest x2. */
 int pmhip_resize(pmhip_engine* e, int kind, const float* src, int w, int h, int arg, float* dst);
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value", "-Wno-pass-failed"]
 
 LIBS = {
     "libpmhip.so": (["pm_engine.hip"], ["pm_kernels.hip", "pm_math.h", "../../include/pmhip.h"]),

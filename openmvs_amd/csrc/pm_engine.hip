@@ -15,7 +15,7 @@
 #include <vector>
 
 #ifndef PMHIP_DEFAULT_GROUPS
-#define PMHIP_DEFAULT_GROUPS 4
+#define PMHIP_DEFAULT_GROUPS 2
 #endif
 
 namespace {
@@ -248,6 +248,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			double K0[9];
 			if (l == 0) memcpy(K0, v.K, sizeof(K0)); else scaleK(v.K, e->w, e->h, lw, lh, K0);
 			inv33(K0, t.Hr);
+			t.hrUpper = (t.Hr[1] == 0.0 && t.Hr[3] == 0.0 && t.Hr[6] == 0.0 && t.Hr[7] == 0.0) ? 1 : 0;
 			t.fx = K0[0]; t.fy = K0[4]; t.cx = K0[2]; t.cy = K0[5];
 			t.dMin = v.dMin; t.dMax = v.dMax; t.dMinSqr = sqrtf(v.dMin); t.dMaxSqr = sqrtf(v.dMax);
 			t.k0 = p.seed; t.k1base = v.id * 0x9E3779B1u;
@@ -604,6 +605,21 @@ int pmhip_estimate_depth_map(pmhip_engine* e, PMHipDepthData* dd, const PMHipPar
 	rc = estimateBatch(e, &id0, 1, *p, nGeometricIter);
 	if (rc) return rc;
 	return pmhip_scene_get_maps(e, 0, dd->depthMap, dd->normalMap, dd->confMap);
+}
+
+// in-kernel phase counters (only populated by -DPM_PROFILE builds); reset != 0 clears them after reading
+int pmhip_prof_get(pmhip_engine* e, unsigned long long out16[16], int reset) {
+	if (!e || !out16) return PMHIP_E_ARG;
+#ifdef PM_PROFILE
+	HIPCHK(e, hipSetDevice(e->device));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	HIPCHK(e, hipMemcpyFromSymbol(out16, HIP_SYMBOL(pm_prof), sizeof(unsigned long long) * 16));
+	if (reset) { unsigned long long z[16] = {0}; HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(pm_prof), z, sizeof(z))); }
+	return 0;
+#else
+	for (int i = 0; i < 16; ++i) out16[i] = 0;
+	return 0;
+#endif
 }
 
 int pmhip_math_eval(pmhip_engine* e, int kind, const float* a, const float* b, float* out, size_t n) {

@@ -26,7 +26,13 @@
 
 #define PM_MAX_SRC 16
 #ifndef PM_BLOCK
-#define PM_BLOCK 256
+#define PM_BLOCK 64    // one wave per workgroup: LDS windows are per wave, so small workgroups pack the CU's 160 KB best (tools/tune.py)
+#endif
+#ifndef PM_USE_TILES
+#define PM_USE_TILES 1   // stage source-image windows in LDS in the sweep kernel
+#endif
+#ifndef PM_TAPCHUNK
+#define PM_TAPCHUNK 5   // taps of a row whose loads are issued together (5 = whole row)
 #endif
 #ifndef PM_MINWAVES
 #define PM_MINWAVES 3   // waves per SIMD the register allocator must leave room for (measured: 3 beats 4 (spills) and 5)
@@ -56,6 +62,8 @@ struct PMTask {           // one reference view at one pyramid level
 	const float* refS;    // reference image, anti-diagonal-major
 	int w, h, nSrc, pad0;
 	double Hr[9];         // K_0^-1
+	int hrUpper;          // 1 if Hr[1] == Hr[3] == Hr[6] == Hr[7] == 0 exactly (zero-skew K): products with those vanish exactly
+	int pad1;
 	double fx, fy, cx, cy;
 	float dMin, dMax, dMinSqr, dMaxSqr;
 	uint32_t k0, k1base;  // Philox key: (seed, viewID*0x9E3779B1 + pass)
@@ -71,6 +79,28 @@ struct PMKParams {        // DepthEstimator ctor constants, DepthMap.cpp:397-406
 enum { PM_STREAM_INIT = 0, PM_STREAM_RAND = 1, PM_STREAM_REFINE = 2 };
 
 #define PM_INF __builtin_huge_valf()
+
+// Optional in-kernel phase timing (build with -DPM_PROFILE): lane 0 of every wave accumulates s_memtime deltas
+// per phase into pm_prof[]; read back with pmhip_prof_get.  Phases: 0 setup (weights, neighbour gather, tiles),
+// 1 hypothesis generation, 2 smoothness factors, 3 homography, 4 taps, 5 score epilogue, 6 aggregation+accept,
+// 7 number of outer trips, 8 trips x active pixel-lanes, 9 waves, 10 tap rows served from LDS, 11 tap rows total.
+#ifdef PM_PROFILE
+__device__ unsigned long long pm_prof[16];
+struct PmProfAcc { unsigned long long a[12]; unsigned long long t; };
+#define PM_PROF_ARG , PmProfAcc& _pa
+#define PM_PROF_PASS , _pa
+#define PM_PROF_DECL PmProfAcc _pa; for (int _i = 0; _i < 12; ++_i) _pa.a[_i] = 0; _pa.t = __builtin_readcyclecounter()
+#define PM_TICK(i) do { const unsigned long long _n = __builtin_readcyclecounter(); _pa.a[i] += _n - _pa.t; _pa.t = _n; } while (0)
+#define PM_COUNT(i, n) do { _pa.a[i] += (unsigned long long)(n); } while (0)
+#define PM_PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int _i = 0; _i < 12; ++_i) atomicAdd(&pm_prof[_i], _pa.a[_i]); } while (0)
+#else
+#define PM_PROF_ARG
+#define PM_PROF_PASS
+#define PM_PROF_DECL do {} while (0)
+#define PM_TICK(i) do {} while (0)
+#define PM_COUNT(i, n) do {} while (0)
+#define PM_PROF_FLUSH() do {} while (0)
+#endif
 #define PM_FD2R(d) ((d) * (PM_PI_F / 180.f))
 
 // ---- small device helpers -----------------------------------------------------------------
@@ -145,31 +175,53 @@ __device__ __forceinline__ void pm_group_min2(float s, float& m1, float& m2) {
 // the footprints of the pixels of one wave lie along an anti-diagonal of the source image too; in the
 // anti-diagonal-major copy those texels are contiguous (one or two 128-B lines per view instead of one
 // line per pixel), which is what the vector L1 / texture-address unit is bound by here.  Same values.
-template <bool GEO, bool SKEW>
-__device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask& t, const PMKParams& kp,
-		int x, int y, double X0x, double X0y, float normSq0, float sumW, const float2* wts,
-		float depth, float nx, float ny, float nz,
-		float sf0, float sf1, float sf2, float sf3, unsigned sfValid, float prior)
-{
-	// ComputeHomographyMatrix, DepthMap.h:414-423 (double, then cast to float)
-	float H[9];
-	{
-		const double n0 = (double)nx, n1 = (double)ny, n2 = (double)nz;
-		const double ndx = (n0 * X0x + n1 * X0y) + n2;
-		const double den = ndx * (double)depth;
-		const double inv = (den == 0.0) ? 1e+14 : 1.0 / den;
-		const double r0 = n0 * inv, r1 = n1 * inv, r2 = n2 * inv;
+// ComputeHomographyMatrix, DepthMap.h:414-423: (Hl + Hm * (n^T / (n.X0 * depth))) * Hr in double, cast to float
+__device__ __forceinline__ void pm_homography(const PMSrcView& s, const PMTask& t, double X0x, double X0y,
+		float depth, float nx, float ny, float nz, float* H) {
+	const double n0 = (double)nx, n1 = (double)ny, n2 = (double)nz;
+	const double ndx = (n0 * X0x + n1 * X0y) + n2;
+	const double den = ndx * (double)depth;
+	const double inv = (den == 0.0) ? 1e+14 : 1.0 / den; // INVERT, Types.h:1234
+	const double r0 = n0 * inv, r1 = n1 * inv, r2 = n2 * inv;
 #pragma unroll
-		for (int i = 0; i < 3; ++i) {
-			const double hm = s.Hm[i];
-			const double m0 = s.Hl[i * 3 + 0] + hm * r0;
-			const double m1 = s.Hl[i * 3 + 1] + hm * r1;
-			const double m2 = s.Hl[i * 3 + 2] + hm * r2;
+	for (int i = 0; i < 3; ++i) {
+		const double hm = s.Hm[i];
+		const double m0 = s.Hl[i * 3 + 0] + hm * r0;
+		const double m1 = s.Hl[i * 3 + 1] + hm * r1;
+		const double m2 = s.Hl[i * 3 + 2] + hm * r2;
+		if (t.hrUpper) {
+			// (m0*Hr0j + m1*Hr1j) + m2*Hr2j with the structurally-zero entries of K^-1 dropped: x*0 == 0 and 0+y == y exactly
+			H[i * 3 + 0] = (float)(m0 * t.Hr[0]);
+			H[i * 3 + 1] = (float)(m1 * t.Hr[4]);
+			H[i * 3 + 2] = (float)((m0 * t.Hr[2] + m1 * t.Hr[5]) + m2 * t.Hr[8]);
+		} else {
 #pragma unroll
 			for (int j = 0; j < 3; ++j)
 				H[i * 3 + j] = (float)((m0 * t.Hr[j] + m1 * t.Hr[3 + j]) + m2 * t.Hr[6 + j]);
 		}
 	}
+}
+
+// LDS source tiles of the sweep kernel: per (wave, source view) a PM_TR x TC window of the anti-diagonal-major
+// image, placed around the footprints of the wave's pixels under their current planes.  TC = pixels per wave + 16.
+#ifndef PM_TR
+#define PM_TR 20        // window rows (anti-diagonals): 19 are needed (patch 17 + bilinear 2), the rest is slack for perturbed planes
+#endif
+#ifndef PM_TCX
+#define PM_TCX 12       // window columns = pixels per wave + PM_TCX: PPW + 9 are needed
+#endif
+#define PM_TILE_PAD 4   // per-view stride = PM_TR*TC + 4 floats: staggers the views over the LDS banks
+
+template <bool GEO, bool SKEW, int TC>
+__device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask& t, const PMKParams& kp,
+		int x, int y, double X0x, double X0y, float normSq0, float sumW, const float2* wts,
+		float depth, float nx, float ny, float nz,
+		float sf0, float sf1, float sf2, float sf3, unsigned sfValid, float prior,
+		const float* tile, int ts0, int tt0 PM_PROF_ARG)
+{
+	float H[9];
+	pm_homography(s, t, X0x, X0y, depth, nx, ny, nz, H);
+	PM_TICK(3);
 	const float px = (float)(x - PM_HW), py = (float)(y - PM_HW);
 	float X0 = H[0] * px + H[1] * py + H[2];
 	float X1 = H[3] * px + H[4] * py + H[5];
@@ -188,39 +240,72 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 	const int lxMax = sw - 2, lyMax = sh - 2;
 #pragma unroll 1
 	for (int i = 0; i < 5; ++i) {
-		float fxs[5], fys[5];
-		size_t offs[5];
+		// a tap row is consumed in chunks of PM_TAPCHUNK taps: all loads of a chunk are in flight together; a
+		// smaller chunk trades memory-level parallelism for registers (occupancy)
 #pragma unroll
-		for (int j = 0; j < 5; ++j) {
-			const float ptx = X0 / X2, pty = X1 / X2;
-			oob = oob || !pm_inside1(ptx, pty, sw, sh);
-			// TImage::sample, libs/Common/Types.inl:2273-2281
-			int lx = (int)ptx, ly = (int)pty;
-			fxs[j] = ptx - (float)lx; fys[j] = pty - (float)ly;
-			lx = min(max(lx, 0), lxMax); ly = min(max(ly, 0), lyMax);
-			offs[j] = SKEW ? (size_t)(lx + ly) * sh + ly : (size_t)ly * sw + lx;
-			X0 += H[0]; X1 += H[3]; X2 += H[6];
-		}
-		float v00[5], v01[5], v10[5], v11[5];
+		for (int j0 = 0; j0 < 5; j0 += PM_TAPCHUNK) {
+			constexpr int CH = PM_TAPCHUNK;
+			float fxs[CH], fys[CH];
+			unsigned offs[CH];   // texel offsets fit 32 bits (an image or its skewed copy is < 2^32 floats)
+			int tix[CH];
+			bool allIn = true;
 #pragma unroll
-		for (int j = 0; j < 5; ++j) {
-			const pm_gcf p = img + offs[j];
-			if (SKEW) { v00[j] = p[0]; v01[j] = p[sh]; v10[j] = p[sh + 1]; v11[j] = p[2 * sh + 1]; }
-			else { v00[j] = p[0]; v01[j] = p[1]; v10[j] = p[sw]; v11[j] = p[sw + 1]; }
-		}
+			for (int j = 0; j < CH; ++j) {
+				if (j0 + j >= 5) break;
+				float ptx, pty;
+				pm_div2(X0, X1, X2, &ptx, &pty); // == X0 / X2, X1 / X2 (TPoint2(Point3), Types.h:1291)
+				oob = oob || !pm_inside1(ptx, pty, sw, sh);
+				// TImage::sample, libs/Common/Types.inl:2273-2281
+				int lx = (int)ptx, ly = (int)pty;
+				fxs[j] = ptx - (float)lx; fys[j] = pty - (float)ly;
+				lx = min(max(lx, 0), lxMax); ly = min(max(ly, 0), lyMax);
+				offs[j] = SKEW ? (unsigned)(lx + ly) * (unsigned)sh + (unsigned)ly : (unsigned)ly * (unsigned)sw + (unsigned)lx;
+				if (TC > 0) {
+					const int rs = lx + ly - ts0, ct = ly - tt0;
+					const bool in = (unsigned)rs < (unsigned)(PM_TR - 2) && (unsigned)ct < (unsigned)(TC - 1);
+					// a hypothesis already flagged out-of-image needs no texel at all (its sums are discarded): keep it on the LDS path
+					allIn = allIn && (in || oob);
+					tix[j] = in ? rs * TC + ct : 0;
+				}
+				X0 += H[0]; X1 += H[3]; X2 += H[6];
+			}
+			float v00[CH], v01[CH], v10[CH], v11[CH];
+#ifdef PM_PROFILE
+			if (TC > 0) { PM_COUNT(10, __popcll(__ballot(allIn))); PM_COUNT(11, __popcll(__ballot(true))); PM_COUNT(7, __all(allIn) ? 1 : 0); }
+#endif
+			if (TC > 0 && allIn) {
+				// texels (lx,ly), (lx+1,ly), (lx,ly+1), (lx+1,ly+1) sit at skew (s,t), (s+1,t), (s+1,t+1), (s+2,t+1)
 #pragma unroll
-		for (int j = 0; j < 5; ++j) {
-			const float fx = fxs[j], fx1 = 1.f - fx, fy = fys[j], fy1 = 1.f - fy;
-			const float v = (v00[j] * fx1 + v01[j] * fx) * fy1 + (v10[j] * fx1 + v11[j] * fx) * fy;
-			const float2 pw = wts[i * 5 + j];
-			const float vw = v * pw.x;
-			sum += vw;
-			sumSq += v * vw;
-			num += v * pw.y;
+				for (int j = 0; j < CH; ++j) {
+					if (j0 + j >= 5) break;
+					const float* q = tile + tix[j];
+					v00[j] = q[0]; v01[j] = q[TC]; v10[j] = q[TC + 1]; v11[j] = q[2 * TC + 1];
+				}
+			} else {
+#pragma unroll
+				for (int j = 0; j < CH; ++j) {
+					if (j0 + j >= 5) break;
+					const pm_gcf p = img + offs[j];
+					if (SKEW) { v00[j] = p[0]; v01[j] = p[sh]; v10[j] = p[sh + 1]; v11[j] = p[2 * sh + 1]; }
+					else { v00[j] = p[0]; v01[j] = p[1]; v10[j] = p[sw]; v11[j] = p[sw + 1]; }
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < CH; ++j) {
+				if (j0 + j >= 5) break;
+				const float fx = fxs[j], fx1 = 1.f - fx, fy = fys[j], fy1 = 1.f - fy;
+				const float v = (v00[j] * fx1 + v01[j] * fx) * fy1 + (v10[j] * fx1 + v11[j] * fx) * fy;
+				const float2 pw = wts[i * 5 + j0 + j];
+				const float vw = v * pw.x;
+				sum += vw;
+				sumSq += v * vw;
+				num += v * pw.y;
+			}
 		}
 		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
 		X0 = bX0; X1 = bX1; X2 = bX2;
 	}
+	PM_TICK(4);
 	if (oob) return kp.thRobust;
 	const float normSq1 = sumSq - (sum * sum) / sumW;
 	const float nrmSq = normSq0 * normSq1;
@@ -275,6 +360,7 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		const float f = pm_expf(normSq0 * sigma);
 		score = (1.f - f) * score + f * deltaDepth;
 	}
+	PM_TICK(5);
 	return pm_minf(2.f, score);
 }
 
@@ -361,8 +447,9 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 		pm_random_normal(pm_u32_to_unit(r.v[1]), pm_u32_to_unit(r.v[2]), vx, vy, vz, nx, ny, nz);
 	}
 	float sc = PM_INF;
+	PM_PROF_DECL;
 	if (v < t.nSrc)
-		sc = pm_score_view<GEO, false>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, 0u, prior);
+		sc = pm_score_view<GEO, false, 0>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, 0u, prior, nullptr, 0, 0 PM_PROF_PASS);
 	const float conf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 	if (v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
 }
@@ -374,7 +461,12 @@ template <int G, bool GEO>
 __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	constexpr int PPB = PM_BLOCK / G;
 	constexpr int SL = (G >= 4) ? 1 : 4 / G; // smoothness slots owned per lane
+	constexpr int PPW = 64 / G;               // pixels per wave
+	constexpr int TC = PM_USE_TILES ? PPW + PM_TCX : 0;
+	constexpr int TSTRIDE = PM_TR * TC + PM_TILE_PAD;
+	PM_PROF_DECL;
 	__shared__ float2 s_w[PPB][PM_NT + 1];
+	__shared__ float s_tile[PM_USE_TILES ? PM_BLOCK / 64 : 1][PM_USE_TILES ? G * TSTRIDE : 1];
 	const PMTask& t = tasks[blockIdx.y];
 	const int g = threadIdx.x / G, v = threadIdx.x % G;
 	const int w = t.w, h = t.h;
@@ -394,8 +486,7 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 	// neighbour slots in insertion order (DepthMap.cpp:641-766): with sgn = -1 (LT2RB) / +1 (RB2LT):
 	// slot0 (x+sgn,y), slot1 (x,y+sgn) are the already-updated propagation sources; slot2 (x-sgn,y), slot3 (x,y-sgn).
 	const int sgn = dir == 0 ? -1 : 1;
-	float pd0 = 0.f, pnx0 = 0.f, pny0 = 0.f, pnz0 = 0.f, pconf0 = 2.f; bool pok0 = false; // propagation candidate, slot 0
-	float pd1 = 0.f, pnx1 = 0.f, pny1 = 0.f, pnz1 = 0.f, pconf1 = 2.f; bool pok1 = false; // slot 1
+	bool pok0 = false, pok1 = false; // propagation candidates (slots 0 and 1) exist; their estimates are re-read when used
 	float qX0[SL], qX1[SL], qX2[SL], qn0[SL], qn1[SL], qn2[SL]; // my smoothness slot(s)
 	unsigned closeMask = 0u;
 #pragma unroll
@@ -413,8 +504,8 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 			const size_t qi = (size_t)qy * w + qx;
 			if (ok) { nd = gDepth[qi]; ok = nd > 0; }
 			if (ok) closeMask |= 1u << k;
-			if (k == 0 && ok) { pok0 = true; pd0 = nd; pnx0 = gNormal[qi * 3]; pny0 = gNormal[qi * 3 + 1]; pnz0 = gNormal[qi * 3 + 2]; pconf0 = gConf[qi]; }
-			if (k == 1 && ok) { pok1 = true; pd1 = nd; pnx1 = gNormal[qi * 3]; pny1 = gNormal[qi * 3 + 1]; pnz1 = gNormal[qi * 3 + 2]; pconf1 = gConf[qi]; }
+			if (k == 0 && ok) pok0 = true;
+			if (k == 1 && ok) pok1 = true;
 			if (ok && (k % G) == v) {
 				const int q = (k / G < SL) ? k / G : 0;
 				// TransformPointI2C(Point3(nx, ndepth)) in double then Cast<float>, Camera.h:338-344
@@ -426,6 +517,50 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 			}
 		}
 	}
+	// ---- stage source tiles in LDS -------------------------------------------------------------------
+	// Every hypothesis of this visit (propagated neighbours' planes, small perturbations of the current plane)
+	// projects close to where the current plane does, so one window per (wave, view) around the current
+	// footprints serves nearly all 100 x ~8 taps; the rest (random restarts, depth discontinuities) fall back
+	// to global loads tap-row by tap-row.  Window origin = min over the wave's pixels of the footprint centre.
+	int ts0 = 0, tt0 = 0;
+	const float* tile = nullptr;
+	if (TC > 0) {
+		int cs = 0x7fffffff, ctt = 0x7fffffff;
+		if (valid && v < t.nSrc) {
+			float Hc[9];
+			pm_homography(t.src[v], t, X0x, X0y, depth, nx, ny, nz, Hc);
+			const float fxp = (float)x, fyp = (float)y;
+			const float c0 = Hc[0] * fxp + Hc[1] * fyp + Hc[2], c1 = Hc[3] * fxp + Hc[4] * fyp + Hc[5], c2 = Hc[6] * fxp + Hc[7] * fyp + Hc[8];
+			const float cu = c0 / c2, cv = c1 / c2;
+			if (cu > -1e6f && cu < 1e6f && cv > -1e6f && cv < 1e6f) { const int iu = (int)pm_floorf(cu), iv = (int)pm_floorf(cv); cs = iu + iv; ctt = iv; }
+		}
+#pragma unroll
+		for (int m = G; m < 64; m <<= 1) { cs = min(cs, __shfl_xor(cs, m, 64)); ctt = min(ctt, __shfl_xor(ctt, m, 64)); }
+		if (cs == 0x7fffffff) { cs = 0; ctt = 0; }
+		ts0 = cs - 8 - (PM_TR - 19) / 2; tt0 = ctt - PM_HW - (PM_TCX - 9) / 2;
+		const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+		float* tw = s_tile[wave];
+		const int nS = t.nSrc;
+		constexpr int TCD = TC > 0 ? TC : 1;
+		constexpr int NLD = (PM_TR * TCD + 63) / 64;
+		for (int vv = 0; vv < nS; ++vv) {
+			const int fs0 = __shfl(ts0, vv, 64), ft0 = __shfl(tt0, vv, 64);
+			const pm_gcf src = pm_glob(t.src[vv].imgS);
+			const int sh = t.src[vv].h, sMax = t.src[vv].w + t.src[vv].h - 1;
+			float vals[NLD];
+#pragma unroll
+			for (int k = 0; k < NLD; ++k) { // all loads of a window first, then the LDS writes
+				const int i = lane + 64 * k;
+				const int r = i / TCD, c = i - r * TCD;
+				const int ss = fs0 + r, tt = ft0 + c;
+				vals[k] = (i < PM_TR * TC && ss >= 0 && ss < sMax && tt >= 0 && tt < sh) ? src[(size_t)ss * sh + tt] : 0.f;
+			}
+#pragma unroll
+			for (int k = 0; k < NLD; ++k) { const int i = lane + 64 * k; if (i < PM_TR * TC) tw[vv * TSTRIDE + i] = vals[k]; }
+		}
+		tile = tw + v * TSTRIDE;
+		__syncthreads();
+	}
 	// state machine: every outer trip scores at most one hypothesis per pixel, so the lanes of a wave
 	// stay converged on the expensive part whatever branch each pixel is in.
 	enum { ST_PROP0 = 0, ST_PROP1 = 1, ST_DECIDE = 2, ST_RAND = 3, ST_REFINE = 4, ST_DONE = 5 };
@@ -434,6 +569,7 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 	float scaleRange = 1.f, depthRange = 0.f, p0 = 0.f, p1 = 0.f;
 	bool smooth = true, changed = false;
 	const uint32_t k1 = t.k1base + pass;
+	PM_TICK(0); PM_COUNT(9, 1);
 	for (;;) {
 		bool need = false;
 		float hd = 0.f, hnx = 0.f, hny = 0.f, hnz = 1.f, hp0 = 0.f, hp1 = 0.f;
@@ -442,10 +578,12 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 			if (st <= ST_PROP1) {
 				const bool vert = (st == ST_PROP1); ++st; // slot 0: same row, slot 1: same column
 				const bool pok = vert ? pok1 : pok0;
-				const float pconf = vert ? pconf1 : pconf0;
+				// the neighbour (already updated in this sweep, one diagonal earlier) is not touched again before we are done
+				const size_t qi = vert ? (size_t)(y + sgn) * w + x : (size_t)y * w + (x + sgn);
+				const float pconf = pok ? gConf[qi] : 2.f;
 				if (pok && pconf < kp.thKeep) {
 					// InterpolatePixel, DepthMap.cpp:915-959
-					const float cnx = vert ? pnx1 : pnx0, cny = vert ? pny1 : pny0, cnz = vert ? pnz1 : pnz0, cd = vert ? pd1 : pd0;
+					const float cnx = gNormal[qi * 3], cny = gNormal[qi * 3 + 1], cnz = gNormal[qi * 3 + 2], cd = gDepth[qi];
 					float depthNew = cd; bool zero;
 					if (vert) { // same column
 						const float nx1 = (float)(((double)y - t.cy) / t.fy);
@@ -499,6 +637,7 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 			}
 		}
 		if (!__any(need)) break;
+		PM_TICK(1); PM_COUNT(6 + 5, 0); PM_COUNT(8, __popcll(__ballot(need)));
 		// smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533
 		float sf[4] = {1.f, 1.f, 1.f, 1.f};
 		unsigned sfValid = 0u;
@@ -526,16 +665,19 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 				sf[k] = __shfl(myF[k / G < SL ? k / G : 0], (k % G), G);
 			if (useS) sfValid = closeMask;
 		}
+		PM_TICK(2);
 		float sc = PM_INF;
 		if (need && v < t.nSrc)
-			sc = pm_score_view<GEO, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], sfValid, prior);
+			sc = pm_score_view<GEO, true, TC>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], sfValid, prior, tile, ts0, tt0 PM_PROF_PASS);
 		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 		if (need && conf > nconf) {
 			conf = nconf; depth = hd; nx = hnx; ny = hny; nz = hnz; changed = true;
 			if (hst == ST_RAND) { if (conf < kp.thConfRand) st = ST_DECIDE; }
 			else if (hst == ST_REFINE) { p0 = hp0; p1 = hp1; scaleRange = pm_pow2neg(++idxScale); }
 		}
+		PM_TICK(6);
 	}
+	PM_PROF_FLUSH();
 	if (changed && v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
 }
 
@@ -644,6 +786,8 @@ __global__ void pm_math_kernel(int kind, const float* __restrict__ a, const floa
 		case 4: pm_sincosf(a[i], &s, &c); o[i] = c; break;
 		case 5: o[i] = pm_sqrtf(a[i]); break;
 		case 7: o[i] = pm_hypot_d(a[i], b[i]); break;
+		case 8: { float qx, qy; pm_div2(a[i], b[i] * 3.0f, b[i], &qx, &qy); o[i] = qx; } break;
+		case 9: { float qx, qy; pm_div2(b[i], a[i], b[i] + a[i], &qx, &qy); o[i] = qy; } break;
 		default: o[i] = a[i] / b[i]; break;
 		}
 	}

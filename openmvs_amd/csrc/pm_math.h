@@ -72,6 +72,31 @@ PM_HD float pm_hypot_d(float a, float b) {
 	return (float)sqrt((double)a * (double)a + (double)b * (double)b);
 #endif
 }
+// x/z and y/z, each correctly rounded (== the IEEE quotient the oracle computes with '/'), sharing one
+// reciprocal.  On the device this is the compiler's own division expansion (v_rcp, two reciprocal-refining
+// FMAs, quotient, two residual-correcting FMA steps) minus v_div_scale / v_div_fixup, which only matter when
+// an operand or the quotient sits near the ends of the exponent range; outside the guarded range we fall back
+// to '/'.  13 instructions for the pair instead of 22.  Checked bit-for-bit against '/' in the gpu tests.
+PM_HD void pm_div2(float x, float y, float z, float* qx, float* qy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	const float az = __builtin_fabsf(z);
+	if (az > 9.094947e-13f && az < 1.0995116e12f && __builtin_fabsf(x) < 1.0e18f && __builtin_fabsf(y) < 1.0e18f) { // 2^-40 < |z| < 2^40
+		float r = __builtin_amdgcn_rcpf(z);
+		const float e = __builtin_fmaf(-z, r, 1.0f);
+		r = __builtin_fmaf(e, r, r);
+		float q = x * r;
+		float t = __builtin_fmaf(-z, q, x); q = __builtin_fmaf(t, r, q);
+		t = __builtin_fmaf(-z, q, x); q = __builtin_fmaf(t, r, q);
+		*qx = q;
+		q = y * r;
+		t = __builtin_fmaf(-z, q, y); q = __builtin_fmaf(t, r, q);
+		t = __builtin_fmaf(-z, q, y); q = __builtin_fmaf(t, r, q);
+		*qy = q;
+	} else { *qx = x / z; *qy = y / z; }
+#else
+	*qx = x / z; *qy = y / z;
+#endif
+}
 PM_HD float pm_floorf(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
 	return __builtin_floorf(x);

@@ -50,7 +50,7 @@ EXPORTS = ["pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init"
            "pmhip_estimate_depth_map", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
            "pmhip_scene_estimate", "pmhip_scene_commit_round", "pmhip_scene_reset_view", "pmhip_scene_set_maps",
            "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_images_updated", "pmhip_sync",
-           "pmhip_stream", "pmhip_stats_reset", "pmhip_stats_get", "pmhip_math_eval", "pmhip_resize"]
+           "pmhip_stream", "pmhip_stats_reset", "pmhip_stats_get", "pmhip_prof_get", "pmhip_math_eval", "pmhip_resize"]
 
 _LIB = None
 
@@ -206,6 +206,11 @@ class PatchMatchHIP:
         s = PMHipKernelStats()
         self._chk(self._lib.pmhip_stats_get(self._h, C.byref(s)))
         return s
+
+    def prof_get(self, reset=True):
+        out = (C.c_ulonglong * 16)()
+        self._chk(self._lib.pmhip_prof_get(self._h, out, 1 if reset else 0))
+        return list(out)
 
     # -- self-test hooks -----------------------------------------------------------------------
     def math_eval(self, kind, a, b=None):

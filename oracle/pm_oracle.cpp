@@ -901,6 +901,8 @@ void orc_math_eval(int kind, const float* a, const float* b, float* o, size_t n)
 		case 4: pm_sincosf(a[i], &s, &c); o[i] = c; break;
 		case 5: o[i] = pm_sqrtf(a[i]); break;
 		case 7: o[i] = pm_hypot_d(a[i], b[i]); break;
+		case 8: o[i] = a[i] / b[i]; break;                 // reference value of pm_div2's first quotient
+		case 9: o[i] = a[i] / (b[i] + a[i]); break;        // ... and of its second quotient, other operand roles
 		default: o[i] = a[i] / b[i]; break;
 		}
 	}

@@ -30,7 +30,11 @@ def test_device_math_is_bitwise_identical_to_host():
              (2, r.randn(n).astype(np.float32), r.randn(n).astype(np.float32)),
              (3, (8 * (2 * r.rand(n) - 1)).astype(np.float32), None), (4, (8 * (2 * r.rand(n) - 1)).astype(np.float32), None),
              (5, (100 * r.rand(n)).astype(np.float32), None), (6, r.randn(n).astype(np.float32), (r.randn(n) + 3).astype(np.float32)),
-             (7, (3 * r.randn(n)).astype(np.float32), (3 * r.randn(n)).astype(np.float32))]
+             (7, (3 * r.randn(n)).astype(np.float32), (3 * r.randn(n)).astype(np.float32)),
+             # pm_div2 (shared-reciprocal correctly rounded division) vs '/': pixel-like magnitudes, tiny and huge operands
+             (8, (4096 * r.rand(n)).astype(np.float32), (0.5 + r.rand(n)).astype(np.float32)),
+             (8, (r.randn(n) * 10.0 ** r.randint(-30, 30, n)).astype(np.float32), (r.randn(n) * 10.0 ** r.randint(-14, 14, n)).astype(np.float32)),
+             (9, (2000 * r.rand(n)).astype(np.float32), (0.01 + r.rand(n)).astype(np.float32))]
     for kind, a, b in cases:
         _same(e.math_eval(kind, a, b), po.math_eval(kind, a, b), f"pm_math kind {kind}")
     e.close()

@@ -1,0 +1,21 @@
+"""In-kernel phase breakdown of the sweep kernel (needs libs built with -DPM_PROFILE; see tools/README)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openmvs_amd import synth
+from openmvs_amd.patchmatch import PatchMatchHIP, default_params
+views = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+sc = synth.make_scene(views, 1920, 1080, n_src=8, device="cuda", gray_only=True)
+e = PatchMatchHIP(0); e.Init(True); e.scene_load(sc, 2)
+p = default_params(seed=1); ids = list(range(views))
+for rep in range(2):
+    for v in ids: e.scene_reset_view(v)
+    e.prof_get(True); e.sync(); t0 = time.time()
+    e.scene_estimate(ids, -1, p)
+    for g in range(2): e.scene_commit_round(); e.scene_estimate(ids, g, p)
+    e.sync(); dt = time.time() - t0
+    c = e.prof_get(True)
+names = ["setup", "hyp-gen", "smooth", "homography", "taps", "epilogue", "aggr+accept"]
+tot = sum(c[:7]) or 1
+print(os.environ.get("PMHIP_LIB", "default"), "views", views, "%.2f s -> %.2f Mpix/s" % (dt, views * 1920 * 1080 / dt / 1e6))
+for i, n in enumerate(names): print("  %-12s %5.1f %%   %8.0f cycles/wave" % (n, 100.0 * c[i] / tot, c[i] / max(1, c[9])))
+print("  active lanes/trip-sum %.1f per wave; LDS-served lane-rows %.1f %%; rows where the whole wave stayed on LDS: %d of %d lane-rows/64" % (c[8] / max(1, c[9]), 100.0 * c[10] / max(1, c[11]), c[7], c[11] // 64))

@@ -157,8 +157,10 @@ def main():
         d0, n0, c0 = eng.scene_get_maps(0)
         m = d0 > 0
         rel = np.abs(d0[m] - gt0[m]) / gt0[m]
-        sweep_s = st.sweepMs / 1e3
+        sweep_s = st.sweepMs / 1e3          # summed over the streams the launches ran on (== sum of kernel durations)
+        wall_s = st.sweepWallMs / 1e3       # wall time of the sweep phases (view groups overlap)
         achieved = st.sweepBytes / 1e9 / max(sweep_s, 1e-12)
+        device = st.sweepBytes / 1e9 / max(wall_s, 1e-12)
         out = {
             "metric": "Mpix/s depth-map output at 1920x1080 N-view", "value": round(mpix, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2),
@@ -170,8 +172,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "launches": int(st.sweepLaunches), "avg_launch_us": round(1e3 * st.sweepMs / max(1, st.sweepLaunches), 2),
                          "algorithmic_bytes_per_launch": round(st.sweepBytes / max(1, st.sweepLaunches), 1),
-                         "sweep_share_of_step": round(sweep_s / dt, 4),
-                         "note": "algorithmic bytes = SURVEY 8(d) B_sweep summed over the timed sweeps / summed HIP-event time of the sweep launches (rank 0)"},
+                         "concurrent_streams": round(sweep_s / max(wall_s, 1e-12), 2), "device_achieved": round(device, 2),
+                         "device_frac": round(device / HBM_PEAK_GBS, 6), "sweep_share_of_step": round(wall_s / dt, 4),
+                         "note": "achieved = algorithmic bytes per launch (SURVEY 8(d) B_sweep / launches) / average launch duration from HIP events on the "
+                                 "launching streams (rank 0); two view groups run on two streams, so the device moves device_achieved"},
             "accuracy": {"valid_frac_view0": round(float(m.mean()), 4), "median_rel_err_vs_ground_truth": float(np.median(rel))},
         }
     # ---- CPU baseline + parity check (rank 0, 1 GPU only; outside the timed region) ----------

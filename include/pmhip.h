@@ -134,12 +134,14 @@ int pmhip_sync(pmhip_engine* e);
 /* Engine stream (hipStream_t) so callers can bracket work with their own events. */
 void* pmhip_stream(pmhip_engine* e);
 
-/* Timing of the dominant kernel (the diagonal sweep) measured with HIP events on the engine
- * stream since the last reset: number of launches, summed milliseconds, summed algorithmic bytes
- * (SURVEY.md 8d model) and pixel-updates. */
+/* Timing of the dominant kernel (the diagonal sweep) measured with HIP events on the streams the
+ * launches go to, since the last reset: number of launches, summed milliseconds (sweepMs / sweepLaunches
+ * == the kernel's average duration as rocprofv3 reports it, also when view groups run concurrently),
+ * summed algorithmic bytes (SURVEY.md 8d model) and pixel-updates. */
 typedef struct PMHipKernelStats {
 	uint64_t sweepLaunches; double sweepMs; double sweepBytes; uint64_t sweepPixels;
 	uint64_t initLaunches; double initMs;
+	double sweepWallMs; /* wall time of the sweep phases; sweepMs sums the per-stream times of the concurrent view groups */
 } PMHipKernelStats;
 int pmhip_stats_reset(pmhip_engine* e, int enableEvents);
 int pmhip_stats_get(pmhip_engine* e, PMHipKernelStats* out);

@@ -186,17 +186,20 @@ static void launchSweep(int G, dim3 grid, hipStream_t s, const PMTask* t, const 
 	}
 }
 
-static void evBegin(pmhip_engine* e, int kind) {
-	if (!e->statsOn) return;
+static size_t evBeginOn(pmhip_engine* e, int kind, hipStream_t st) {
+	if (!e->statsOn) return 0;
 	pmhip_engine::Ev ev; ev.kind = kind;
 	hipEventCreate(&ev.a); hipEventCreate(&ev.b);
-	hipEventRecord(ev.a, e->stream);
+	hipEventRecord(ev.a, st);
 	e->events.push_back(ev);
+	return e->events.size() - 1;
 }
-static void evEnd(pmhip_engine* e) {
+static void evEndOn(pmhip_engine* e, size_t idx, hipStream_t st) {
 	if (!e->statsOn) return;
-	hipEventRecord(e->events.back().b, e->stream);
+	hipEventRecord(e->events[idx].b, st);
 }
+static void evBegin(pmhip_engine* e, int kind) { evBeginOn(e, kind, e->stream); }
+static void evEnd(pmhip_engine* e) { if (e->statsOn) hipEventRecord(e->events.back().b, e->stream); }
 
 // One DepthMapsData::EstimateDepthMap (SceneDensify.cpp:616-805) for each view of the batch, concurrently.
 static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHipParams& p, int nGeometricIter) {
@@ -315,12 +318,13 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			const int dir = (int)(iter % 2u);
 			const uint32_t pass = (uint32_t)l * 64u + iter;
 			const int dLo = 2 * PM_HW, dHi = (lw - 1 - PM_HW) + (lh - 1 - PM_HW);
-			evBegin(e, 0);
 			const int NG = std::max(1, std::min(e->nGroups, nB));
+			const size_t evWall = evBeginOn(e, 2, e->stream);
+			size_t evG[16] = {};
 			if (NG > 1) {
 				HIPCHK(e, hipEventRecord(e->forkEv, e->stream));
-				for (int g = 0; g < NG; ++g) HIPCHK(e, hipStreamWaitEvent(e->gstream[g], e->forkEv, 0));
-			}
+				for (int g = 0; g < NG; ++g) { HIPCHK(e, hipStreamWaitEvent(e->gstream[g], e->forkEv, 0)); evG[g] = evBeginOn(e, 0, e->gstream[g]); }
+			} else evG[0] = evBeginOn(e, 0, e->stream);
 			for (int k = 0; k <= dHi - dLo; ++k) {
 				const int d = dir == 0 ? dLo + k : dHi - k;
 				const int xlo = std::max(PM_HW, d - (lh - 1 - PM_HW));
@@ -337,9 +341,9 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 				if (e->statsOn) e->stats.sweepLaunches += NG;
 			}
 			if (NG > 1) {
-				for (int g = 0; g < NG; ++g) { HIPCHK(e, hipEventRecord(e->joinEv[g], e->gstream[g])); HIPCHK(e, hipStreamWaitEvent(e->stream, e->joinEv[g], 0)); }
-			}
-			evEnd(e);
+				for (int g = 0; g < NG; ++g) { evEndOn(e, evG[g], e->gstream[g]); HIPCHK(e, hipEventRecord(e->joinEv[g], e->gstream[g])); HIPCHK(e, hipStreamWaitEvent(e->stream, e->joinEv[g], 0)); }
+			} else evEndOn(e, evG[0], e->stream);
+			evEndOn(e, evWall, e->stream);
 			if (e->statsOn) {
 				// algorithmic bytes of one sweep, SURVEY.md 8(d): P_l * [4(1+N) + 20 + 20 + 4[prior] + 4N[geo]] per view
 				double bytes = 0;
@@ -363,7 +367,7 @@ static int collectStats(pmhip_engine* e) {
 	HIPCHK(e, hipStreamSynchronize(e->stream));
 	for (auto& ev : e->events) {
 		float ms = 0; hipEventElapsedTime(&ms, ev.a, ev.b);
-		if (ev.kind == 0) e->stats.sweepMs += ms; else e->stats.initMs += ms;
+		if (ev.kind == 0) e->stats.sweepMs += ms; else if (ev.kind == 2) e->stats.sweepWallMs += ms; else e->stats.initMs += ms;
 		hipEventDestroy(ev.a); hipEventDestroy(ev.b);
 	}
 	e->events.clear();

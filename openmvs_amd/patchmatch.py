@@ -43,7 +43,7 @@ class PMHipDepthData(C.Structure):
 
 class PMHipKernelStats(C.Structure):
     _fields_ = [("sweepLaunches", C.c_uint64), ("sweepMs", C.c_double), ("sweepBytes", C.c_double),
-                ("sweepPixels", C.c_uint64), ("initLaunches", C.c_uint64), ("initMs", C.c_double)]
+                ("sweepPixels", C.c_uint64), ("initLaunches", C.c_uint64), ("initMs", C.c_double), ("sweepWallMs", C.c_double)]
 
 
 EXPORTS = ["pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",

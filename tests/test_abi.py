@@ -43,7 +43,7 @@ def test_struct_sizes_match_header():
     from openmvs_amd import patchmatch as pm
     assert C.sizeof(pm.PMHipParams) == 4 * 4 + 9 * 4 + 4
     assert C.sizeof(pm.PMHipView) == 8 + 8 + 21 * 8 + 8 + 21 * 8 + 8
-    assert C.sizeof(pm.PMHipKernelStats) == 48
+    assert C.sizeof(pm.PMHipKernelStats) == 56
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -31,7 +31,7 @@ extern "C" {
 enum {
 	PMHIP_OK = 0,
 	PMHIP_E_ARG = -1,      /* bad argument */
-	PMHIP_E_SIZE = -2,     /* image size not divisible by 2^nSubResolutionLevels or views differ in size */
+	PMHIP_E_SIZE = -2,     /* views differ in size, or image too small for the requested sub-resolution levels */
 	PMHIP_E_HIP = -3,      /* HIP runtime error (see pmhip_last_error) */
 	PMHIP_E_STATE = -4,    /* call out of order (e.g. estimate before init) */
 	PMHIP_E_NODEVICE = -5  /* no usable GPU: the adapter falls back like SceneDensify.cpp:1876-1877 */

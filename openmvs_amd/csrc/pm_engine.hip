@@ -91,8 +91,9 @@ struct pmhip_engine {
 	struct Ev { hipEvent_t a, b; int kind; };
 	std::vector<Ev> events;
 	PMHipKernelStats stats{};
-	int lw(int l) const { return w >> l; }
-	int lh(int l) const { return h >> l; }
+	// cv::resize(img, img, Size(), 1/2^l, 1/2^l): output size = cvRound(size / 2^l), ties to even (ScaleDepthData, SceneDensify.cpp:586)
+	int lw(int l) const { return (int)nearbyint((double)w / (double)(1 << l)); }
+	int lh(int l) const { return (int)nearbyint((double)h / (double)(1 << l)); }
 };
 
 static void freeScene(pmhip_engine* e) {
@@ -131,7 +132,7 @@ static int buildPyramid(pmhip_engine* e) {
 		const size_t n = (size_t)e->lw(l) * e->lh(l) * e->nImages;
 		const int blocks = (int)std::min<size_t>((n + 255) / 256, 65535);
 		// every level is resampled from the full-resolution image (ScaleDepthData(fullRes, 1/2^l), SceneDensify.cpp:654)
-		hipLaunchKernelGGL(pm_area_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_img[0], e->d_img[l], e->w, e->h, 1 << l, e->nImages);
+		hipLaunchKernelGGL(pm_area_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_img[0], e->d_img[l], e->w, e->h, e->lw(l), e->lh(l), 1 << l, e->nImages);
 	}
 	for (int l = 0; l <= e->nLevels; ++l) {
 		const size_t n = (size_t)e->lw(l) * e->lh(l) * e->nImages;
@@ -209,7 +210,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 	const unsigned iterEnd = nGeometricIter < 0 ? p.nEstimationIters : iterBegin + 1;
 	const int S = nGeometricIter < 0 ? (int)p.nSubResolutionLevels : 0;
 	if (S > e->nLevels || S > 3) { e->err = "nSubResolutionLevels exceeds the pyramid allocated by pmhip_scene_create"; return PMHIP_E_ARG; }
-	if ((e->w % (1 << S)) || (e->h % (1 << S))) { e->err = "image size must be divisible by 2^nSubResolutionLevels"; return PMHIP_E_SIZE; }
+	if (e->lw(S) < 2 * PM_HW + 1 || e->lh(S) < 2 * PM_HW + 1) { e->err = "image too small for this many sub-resolution levels"; return PMHIP_E_SIZE; }
 	int rc = ensureBatch(e, nB); if (rc) return rc;
 	rc = buildPyramid(e); if (rc) return rc;
 	const PMKParams kp = makeKParams(p);
@@ -300,7 +301,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 		HIPCHK(e, hipMemcpyAsync(du, hu, sizeof(PMUpTask) * nB, hipMemcpyHostToDevice, e->stream));
 		const int eb = (int)std::min<size_t>((Pl + 255) / 256, 4096);
 		if (l == S && S > 0)
-			hipLaunchKernelGGL(pm_nearest_down_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, e->w, e->h, lw, lh);
+			hipLaunchKernelGGL(pm_nearest_down_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, e->w, e->h, lw, lh, 1 << S);
 		else if (l < S)
 			hipLaunchKernelGGL(pm_upsample_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, e->lw(l + 1), e->lh(l + 1), lw, lh);
 		// pass A: ScoreDepthMapTmp
@@ -436,7 +437,6 @@ const char* pmhip_last_error(pmhip_engine* e) { return e ? e->err.c_str() : "nul
 
 int pmhip_scene_create(pmhip_engine* e, int nImages, int w, int h, int nLevels) {
 	if (!e || nImages < 2 || w < 2 * PM_HW + 1 || h < 2 * PM_HW + 1 || nLevels < 0 || nLevels > 3) return PMHIP_E_ARG;
-	if ((w % (1 << nLevels)) || (h % (1 << nLevels))) { e->err = "image size must be divisible by 2^nLevels"; return PMHIP_E_SIZE; }
 	HIPCHK(e, hipSetDevice(e->device));
 	HIPCHK(e, hipStreamSynchronize(e->stream));
 	freeScene(e);
@@ -645,14 +645,14 @@ int pmhip_resize(pmhip_engine* e, int kind, const float* src, int w, int h, int 
 	HIPCHK(e, hipSetDevice(e->device));
 	const size_t ns = (size_t)w * h;
 	int dw, dh;
-	if (kind == 0) { if (arg < 1 || w % arg || h % arg) return PMHIP_E_SIZE; dw = w / arg; dh = h / arg; } else { dw = w * 2; dh = h * 2; }
+	if (kind == 0) { if (arg < 1) return PMHIP_E_SIZE; dw = (int)nearbyint((double)w / arg); dh = (int)nearbyint((double)h / arg); } else { dw = w * 2; dh = h * 2; }
 	const size_t nd = (size_t)dw * dh;
 	float *ds = nullptr, *dd = nullptr, *dn = nullptr, *dn2 = nullptr, *dp = nullptr; PMUpTask* du = nullptr;
 	HIPCHK(e, hipMalloc(&ds, ns * 4)); HIPCHK(e, hipMalloc(&dd, nd * 4));
 	HIPCHK(e, hipMemcpy(ds, src, ns * 4, hipMemcpyHostToDevice));
 	const int blocks = (int)std::min<size_t>((nd + 255) / 256, 4096);
 	if (kind == 0) {
-		hipLaunchKernelGGL(pm_area_kernel, dim3(blocks), dim3(256), 0, e->stream, ds, dd, w, h, arg, 1);
+		hipLaunchKernelGGL(pm_area_kernel, dim3(blocks), dim3(256), 0, e->stream, ds, dd, w, h, dw, dh, arg, 1);
 	} else if (kind == 1) {
 		HIPCHK(e, hipMalloc(&dn, ns * 12)); HIPCHK(e, hipMalloc(&dn2, nd * 12)); HIPCHK(e, hipMalloc(&dp, nd * 4)); HIPCHK(e, hipMalloc(&du, sizeof(PMUpTask)));
 		HIPCHK(e, hipMemset(dn, 0, ns * 12));

@@ -492,28 +492,43 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 #pragma unroll
 	for (int q = 0; q < SL; ++q) { qX0[q] = qX1[q] = qX2[q] = 0.f; qn0[q] = qn1[q] = 0.f; qn2[q] = 1.f; }
 	if (valid) {
-		depth = gDepth[idx]; nx = gNormal[idx * 3]; ny = gNormal[idx * 3 + 1]; nz = gNormal[idx * 3 + 2]; conf = gConf[idx];
+		// all loads of the gather are issued before any of them is consumed (one memory round trip instead of a
+		// chain of three): neighbours outside the processable area are redirected to the pixel itself and masked
+		size_t qis[4]; bool bok[4]; int qxs[4], qys[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const int ox = (k == 0) ? sgn : (k == 2 ? -sgn : 0), oy = (k == 1) ? sgn : (k == 3 ? -sgn : 0);
-			const int qx = x + ox, qy = y + oy;
 			// bounds tests exactly as written: x > HW / y > HW / x < W-HW / y < H-HW
 			bool ok;
 			if (ox == -1) ok = x > PM_HW; else if (ox == 1) ok = x < w - PM_HW; else if (oy == -1) ok = y > PM_HW; else ok = y < h - PM_HW;
-			float nd = 0.f;
-			const size_t qi = (size_t)qy * w + qx;
-			if (ok) { nd = gDepth[qi]; ok = nd > 0; }
+			bok[k] = ok; qxs[k] = x + ox; qys[k] = y + oy;
+			qis[k] = ok ? (size_t)(y + oy) * w + (x + ox) : idx;
+		}
+		float nds[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) nds[k] = gDepth[qis[k]];
+		float on0[SL], on1[SL], on2[SL];
+#pragma unroll
+		for (int q = 0; q < SL; ++q) {
+			const int k = q * G + v;
+			const size_t qi = (k == 0) ? qis[0] : (k == 1) ? qis[1] : (k == 2) ? qis[2] : (k == 3) ? qis[3] : idx;
+			on0[q] = gNormal[qi * 3]; on1[q] = gNormal[qi * 3 + 1]; on2[q] = gNormal[qi * 3 + 2];
+		}
+		depth = gDepth[idx]; nx = gNormal[idx * 3]; ny = gNormal[idx * 3 + 1]; nz = gNormal[idx * 3 + 2]; conf = gConf[idx];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const bool ok = bok[k] && nds[k] > 0;
 			if (ok) closeMask |= 1u << k;
 			if (k == 0 && ok) pok0 = true;
 			if (k == 1 && ok) pok1 = true;
 			if (ok && (k % G) == v) {
 				const int q = (k / G < SL) ? k / G : 0;
 				// TransformPointI2C(Point3(nx, ndepth)) in double then Cast<float>, Camera.h:338-344
-				const double z = (double)nd;
-				qX0[q] = (float)(((double)qx - t.cx) * z / t.fx);
-				qX1[q] = (float)(((double)qy - t.cy) * z / t.fy);
+				const double z = (double)nds[k];
+				qX0[q] = (float)(((double)qxs[k] - t.cx) * z / t.fx);
+				qX1[q] = (float)(((double)qys[k] - t.cy) * z / t.fy);
 				qX2[q] = (float)z;
-				qn0[q] = gNormal[qi * 3]; qn1[q] = gNormal[qi * 3 + 1]; qn2[q] = gNormal[qi * 3 + 2];
+				qn0[q] = on0[q]; qn1[q] = on1[q]; qn2[q] = on2[q];
 			}
 		}
 	}
@@ -580,10 +595,10 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 				const bool pok = vert ? pok1 : pok0;
 				// the neighbour (already updated in this sweep, one diagonal earlier) is not touched again before we are done
 				const size_t qi = vert ? (size_t)(y + sgn) * w + x : (size_t)y * w + (x + sgn);
-				const float pconf = pok ? gConf[qi] : 2.f;
+				const size_t qj = pok ? qi : idx;
+				const float pconf = gConf[qj], cnx = gNormal[qj * 3], cny = gNormal[qj * 3 + 1], cnz = gNormal[qj * 3 + 2], cd = gDepth[qj]; // one batch
 				if (pok && pconf < kp.thKeep) {
 					// InterpolatePixel, DepthMap.cpp:915-959
-					const float cnx = gNormal[qi * 3], cny = gNormal[qi * 3 + 1], cnz = gNormal[qi * 3 + 2], cd = gDepth[qi];
 					float depthNew = cd; bool zero;
 					if (vert) { // same column
 						const float nx1 = (float)(((double)y - t.cy) / t.fy);
@@ -693,22 +708,32 @@ __global__ void pm_finalize_kernel(const PMTask* __restrict__ tasks, float thKee
 }
 
 // ---- resampling (cv::resize restated; see oracle header for the conventions) ---------------
-// INTER_AREA, integer factor f (ScaleDepthData, SceneDensify.cpp:586): dst[img][y][x]
-__global__ void pm_area_kernel(const float* __restrict__ src, float* __restrict__ dst, int sw, int sh, int f, int nImg) {
-	const int dw = sw / f, dh = sh / f;
+// INTER_AREA, integer factor f (ScaleDepthData, SceneDensify.cpp:586): dst[img][y][x], dw x dh = cvRound(sw/f) x cvRound(sh/f).
+// Blocks cut by the right/bottom border average the available pixels; a cut bottom row takes that path for every pixel
+// (OpenCV ResizeAreaFast_Invoker) -- see the oracle's resizeArea.
+__global__ void pm_area_kernel(const float* __restrict__ src, float* __restrict__ dst, int sw, int sh, int dw, int dh, int f, int nImg) {
 	const size_t n = (size_t)dw * dh * nImg;
 	const float scale = 1.f / (float)(f * f);
+	const int fullCols = sw / f;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
 		const int x = (int)(i % dw), y = (int)((i / dw) % dh); const size_t im = i / ((size_t)dw * dh);
 		const float* s = src + im * (size_t)sw * sh;
+		const int sx0 = x * f, sy0 = y * f;
 		float o;
-		if (f == 2) {
-			const float* p = s + (size_t)(2 * y) * sw + 2 * x;
-			o = ((p[0] + p[1]) + (p[sw] + p[sw + 1])) * 0.25f;
+		if (sy0 >= sh || sx0 >= sw) o = 0.f;
+		else if (sy0 + f <= sh && x < fullCols) {
+			if (f == 2) {
+				const float* p = s + (size_t)sy0 * sw + sx0;
+				o = ((p[0] + p[1]) + (p[sw] + p[sw + 1])) * 0.25f;
+			} else {
+				float sum = 0.f;
+				for (int j = 0; j < f; ++j) for (int k = 0; k < f; ++k) sum += s[(size_t)(sy0 + j) * sw + (sx0 + k)];
+				o = sum * scale;
+			}
 		} else {
-			float sum = 0.f;
-			for (int j = 0; j < f; ++j) for (int k = 0; k < f; ++k) sum += s[(size_t)(y * f + j) * sw + (x * f + k)];
-			o = sum * scale;
+			float sum = 0.f; int count = 0;
+			for (int j = 0; j < f && sy0 + j < sh; ++j) for (int k = 0; k < f && sx0 + k < sw; ++k) { sum += s[(size_t)(sy0 + j) * sw + (sx0 + k)]; ++count; }
+			o = sum / (float)count;
 		}
 		dst[i] = o;
 	}
@@ -751,14 +776,14 @@ __global__ void pm_upsample_kernel(const PMUpTask* __restrict__ ups, int sw, int
 		u.dnormal[i * 3] = u.snormal[si * 3]; u.dnormal[i * 3 + 1] = u.snormal[si * 3 + 1]; u.dnormal[i * 3 + 2] = u.snormal[si * 3 + 2];
 	}
 }
-// INTER_NEAREST down-sampling of the initial estimate to the coarsest level (ScaleDepthData, SceneDensify.cpp:596-599)
-__global__ void pm_nearest_down_kernel(const PMUpTask* __restrict__ ups, int sw, int sh, int dw, int dh) {
+// INTER_NEAREST down-sampling of the initial estimate to the coarsest level (ScaleDepthData, SceneDensify.cpp:596-599):
+// fx = 1/f given, so the source index is min(dst*f, size-1)
+__global__ void pm_nearest_down_kernel(const PMUpTask* __restrict__ ups, int sw, int sh, int dw, int dh, int f) {
 	const PMUpTask u = ups[blockIdx.y];
 	const size_t n = (size_t)dw * dh;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
 		const int x = (int)(i % dw), y = (int)(i / dw);
-		const int nx = min((int)floor((double)x * ((double)sw / (double)dw)), sw - 1);
-		const int ny = min((int)floor((double)y * ((double)sh / (double)dh)), sh - 1);
+		const int nx = min(x * f, sw - 1), ny = min(y * f, sh - 1);
 		const size_t si = (size_t)ny * sw + nx;
 		u.ddepth[i] = u.sdepth[si];
 		u.dnormal[i * 3] = u.snormal[si * 3]; u.dnormal[i * 3 + 1] = u.snormal[si * 3 + 1]; u.dnormal[i * 3 + 2] = u.snormal[si * 3 + 2];

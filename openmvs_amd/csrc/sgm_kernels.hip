@@ -113,21 +113,28 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 	int rpMin = 0, rpMax = 0;
 	float Ip = 0.5f;
 	for (int k = lane; k < 2 * stride; k += 64) s_L[k] = 0;
+	// the P2 table is indexed by a value computed inside the recurrence: keep it in LDS so the chain never waits on HBM
+	__shared__ unsigned short s_P2[256];
+	for (int k = lane; k < 256; k += 64) s_P2[k] = P2s[k];
 	__syncthreads();
-	while (x >= 0 && y >= 0 && x < vw && y < vh) {
-		// ---- request a chunk of SGM_T pixels along the path -------------------------------------
-		SGMPixel px[SGM_T]; float gI[SGM_T]; bool ok[SGM_T];
-		unsigned char c8[SGM_T][NK]; unsigned short a16[SGM_T][NK];
+	// Software pipeline over chunks of SGM_T pixels: while chunk k is consumed (a serial recurrence), the cost bytes
+	// and running sums of chunk k+1 and the pixel table of chunk k+2 are already in flight, so no step of the
+	// recurrence waits on HBM.  Chunk state lives in registers (fully unrolled arrays).
+	SGMPixel pxA[SGM_T], pxB[SGM_T]; float gA[SGM_T], gB[SGM_T]; bool okA[SGM_T], okB[SGM_T];
+	unsigned char cA[SGM_T][NK], cB[SGM_T][NK]; unsigned short aA[SGM_T][NK], aB[SGM_T][NK];
+	auto loadPixels = [&](int cx, int cy, SGMPixel* px, float* g, bool* ok) {
 #pragma unroll
 		for (int t = 0; t < SGM_T; ++t) {
-			const int tx = x + t * dx, ty = y + t * dy;
+			const int tx = cx + t * dx, ty = cy + t * dy;
 			ok[t] = tx >= 0 && ty >= 0 && tx < vw && ty < vh;
-			px[t].idx = 0; px[t].minDisp = 0; px[t].maxDisp = 0; gI[t] = 0.f;
+			px[t].idx = 0; px[t].minDisp = 0; px[t].maxDisp = 0; g[t] = 0.f;
 			if (ok[t]) {
 				px[t] = pixels[(size_t)ty * vw + tx];
-				gI[t] = grayL[(size_t)ty * w + tx]; // imageGray(u) with the valid-grid coordinate: the reference's quirk (:1078)
+				g[t] = grayL[(size_t)ty * w + tx]; // imageGray(u) with the valid-grid coordinate: the reference's quirk (:1078)
 			}
 		}
+	};
+	auto loadCosts = [&](const SGMPixel* px, bool* ok, unsigned char (*c8)[NK], unsigned short (*a16)[NK]) {
 #pragma unroll
 		for (int t = 0; t < SGM_T; ++t) {
 			const int nD = px[t].maxDisp - px[t].minDisp;
@@ -139,14 +146,22 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 				if (ok[t] && k < nD) { c8[t][q] = costs[px[t].idx + k]; a16[t][q] = accums[px[t].idx + k]; }
 			}
 		}
-		// ---- consume it serially ----------------------------------------------------------------
+	};
+	loadPixels(x, y, pxA, gA, okA);
+	loadCosts(pxA, okA, cA, aA);
+	loadPixels(x + SGM_T * dx, y + SGM_T * dy, pxB, gB, okB);
+	while (x >= 0 && y >= 0 && x < vw && y < vh) {
+		loadCosts(pxB, okB, cB, aB);                                  // chunk k+1: costs / sums
+		SGMPixel pxC[SGM_T]; float gC[SGM_T]; bool okC[SGM_T];
+		loadPixels(x + 2 * SGM_T * dx, y + 2 * SGM_T * dy, pxC, gC, okC); // chunk k+2: pixel table
+		// ---- consume chunk k serially ------------------------------------------------------------
 #pragma unroll
 		for (int t = 0; t < SGM_T; ++t) {
-			if (!ok[t]) continue; // invalid pixels do not reset Lp / Ip (:1071-1072)
-			const int rsMin = px[t].minDisp, rsMax = px[t].maxDisp, nD = rsMax - rsMin;
-			const float DI = gI[t] - Ip;
+			if (!okA[t]) continue; // invalid pixels do not reset Lp / Ip (:1071-1072)
+			const int rsMin = pxA[t].minDisp, rsMax = pxA[t].maxDisp, nD = rsMax - rsMin;
+			const float DI = gA[t] - Ip;
 			int ip = sgm_round2int(255.f * DI); ip = ip < 0 ? -ip : ip;
-			const int P2 = P2s[ip];
+			const int P2 = s_P2[ip];
 			const int lo = max(rpMin, rsMin), hi = min(rpMax, rsMax);
 			const int* Lp = s_L + cur * stride + 1;       // Lp[d - rpMin]
 			int* Ls = s_L + (cur ^ 1) * stride + 1;        // Ls[d - rsMin]
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 #pragma unroll
 				for (int q = 0; q < NK; ++q) {
 					const int k = lane + 64 * q;
-					if (k < nD) { const int L = (int)c8[t][q] + P2; Ls[k] = L; accums[px[t].idx + k] = (unsigned short)(a16[t][q] + L); }
+					if (k < nD) { const int L = (int)cA[t][q] + P2; Ls[k] = L; accums[pxA[t].idx + k] = (unsigned short)(aA[t][q] + L); }
 				}
 			} else {
 				int m = SGM_INF;
@@ -169,15 +184,23 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 						if (d >= lo && d < hi) best = min(best, Lp[d - rpMin]);
 						if (d - 1 >= lo && d - 1 < hi) best = min(best, Lp[d - 1 - rpMin] + P1);
 						if (d + 1 >= lo && d + 1 < hi) best = min(best, Lp[d + 1 - rpMin] + P1);
-						const int L = (int)c8[t][q] + best - m;
-						Ls[k] = L; accums[px[t].idx + k] = (unsigned short)(a16[t][q] + L);
+						const int L = (int)cA[t][q] + best - m;
+						Ls[k] = L; accums[pxA[t].idx + k] = (unsigned short)(aA[t][q] + L);
 					}
 				}
 			}
-			rpMin = rsMin; rpMax = rsMax; Ip = gI[t]; cur ^= 1;
+			rpMin = rsMin; rpMax = rsMax; Ip = gA[t]; cur ^= 1;
 			__syncthreads();
 		}
 		x += SGM_T * dx; y += SGM_T * dy;
+		// rotate the pipeline registers
+#pragma unroll
+		for (int t = 0; t < SGM_T; ++t) {
+			pxA[t] = pxB[t]; gA[t] = gB[t]; okA[t] = okB[t];
+			pxB[t] = pxC[t]; gB[t] = gC[t]; okB[t] = okC[t];
+#pragma unroll
+			for (int q = 0; q < NK; ++q) { cA[t][q] = cB[t][q]; aA[t][q] = aB[t][q]; }
+		}
 	}
 }
 

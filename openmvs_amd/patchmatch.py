@@ -221,7 +221,7 @@ class PatchMatchHIP:
 
     def resize(self, kind, img, arg=2):
         img = np.ascontiguousarray(img, np.float32); h, w = img.shape
-        o = np.zeros((h // arg, w // arg) if kind == 0 else (h * 2, w * 2), np.float32)
+        o = np.zeros((int(np.rint(h / arg)), int(np.rint(w / arg))) if kind == 0 else (h * 2, w * 2), np.float32)
         self._chk(self._lib.pmhip_resize(self._h, kind, _fp(img), w, h, arg, _fp(o)))
         return o
 

@@ -18,7 +18,7 @@
 //   * exp/acos/atan2/sin/cos come from csrc/pm_math.h (same polynomial kernels as the
 //     GPU) instead of libm; CorrectNormal's rotation is evaluated in float.
 //   * third-party arithmetic (cv::resize, cv::Matx::inv) is restated from OpenCV's
-//     published algorithms; sizes must be divisible by 2^levels (INTER_AREA == box mean).
+//     published algorithms (integer-factor INTER_AREA incl. its border rule for non-divisible sizes).
 #include "../openmvs_amd/csrc/pm_math.h"
 #include <math.h>
 #include <stdint.h>
@@ -85,20 +85,50 @@ static void scaleK(const double* K, int w, int h, int nw, int nh, double* o) {
 
 // ---------------------------------------------------------------------------
 // third-party resampling (OpenCV cv::resize), restated; see header note
-// INTER_AREA with integer factor f: f==2 -> ((a+b)+(c+d))*0.25 (ResizeAreaFastVec 2x2),
-// otherwise running row-major sum * (1/f^2) (ResizeAreaFast_Invoker)
+// cv::resize(src, dst, Size(), fx, fy, ...) output size: saturate_cast<int>(ssize*fx) == cvRound (ties to even)
+static inline int cvRoundHalfEven(double v) { return (int)nearbyint(v); }
+static inline int scaledSize(int n, int f) { return cvRoundHalfEven((double)n / (double)f); }
+// INTER_AREA with integer factor f = 1/fx (scale_x == scale_y == f exactly -> OpenCV's "area fast" path):
+// a destination pixel whose f x f block lies inside the source is, for f==2, ((a+b)+(c+d))*0.25 (ResizeAreaFastVec),
+// otherwise the running row-major sum * (1/f^2) (ResizeAreaFast_Invoker); blocks cut by the right/bottom border
+// (sizes not divisible by f) average the available pixels, (float)sum/count, and every pixel of a cut bottom row
+// takes that path (w = 0 in ResizeAreaFast_Invoker).
 static void resizeArea(const ImgF& s, int f, ImgF& o) {
-	o.create(s.w / f, s.h / f);
+	o.create(scaledSize(s.w, f), scaledSize(s.h, f));
 	const float scale = 1.f / (float)(f * f);
-	for (int y = 0; y < o.h; ++y) for (int x = 0; x < o.w; ++x) {
-		if (f == 2) {
-			o(y,x) = ((s(2*y,2*x) + s(2*y,2*x+1)) + (s(2*y+1,2*x) + s(2*y+1,2*x+1))) * 0.25f;
-		} else {
-			float sum = 0;
-			for (int j = 0; j < f; ++j) for (int i = 0; i < f; ++i) sum += s(y*f+j, x*f+i);
-			o(y,x) = sum * scale;
+	const int fullCols = s.w / f;
+	for (int y = 0; y < o.h; ++y) {
+		const int sy0 = y * f;
+		const bool rowFull = sy0 + f <= s.h;
+		for (int x = 0; x < o.w; ++x) {
+			const int sx0 = x * f;
+			if (sy0 >= s.h || sx0 >= s.w) { o(y,x) = 0; continue; }
+			if (rowFull && x < fullCols) {
+				if (f == 2) {
+					o(y,x) = ((s(sy0,sx0) + s(sy0,sx0+1)) + (s(sy0+1,sx0) + s(sy0+1,sx0+1))) * 0.25f;
+				} else {
+					float sum = 0;
+					for (int j = 0; j < f; ++j) for (int i = 0; i < f; ++i) sum += s(sy0+j, sx0+i);
+					o(y,x) = sum * scale;
+				}
+			} else {
+				float sum = 0; int count = 0;
+				for (int j = 0; j < f && sy0 + j < s.h; ++j) for (int i = 0; i < f && sx0 + i < s.w; ++i) { sum += s(sy0+j, sx0+i); ++count; }
+				o(y,x) = sum / (float)count;
+			}
 		}
 	}
+}
+// INTER_NEAREST down by fx = 1/f (ifx = 1/fx = f exactly): sx = min(dx*f, ssize-1)
+static void resizeNearestDown(const ImgF& s, int f, ImgF& o) {
+	o.create(scaledSize(s.w, f), scaledSize(s.h, f));
+	for (int y = 0; y < o.h; ++y) { const int sy = std::min(y * f, s.h - 1);
+		for (int x = 0; x < o.w; ++x) o(y,x) = s(sy, std::min(x * f, s.w - 1)); }
+}
+static void resizeNearestDownN(const ImgN& s, int f, ImgN& o) {
+	o.create(scaledSize(s.w, f), scaledSize(s.h, f));
+	for (int y = 0; y < o.h; ++y) { const int sy = std::min(y * f, s.h - 1);
+		for (int x = 0; x < o.w; ++x) { const float* p = s.at(sy, std::min(x * f, s.w - 1)); float* q = o.at(y,x); q[0]=p[0]; q[1]=p[1]; q[2]=p[2]; } }
 }
 // INTER_NEAREST: sx = min(floor(dx*ssize/dsize), ssize-1)
 static void resizeNearest(const ImgF& s, int nw, int nh, ImgF& o) {
@@ -688,8 +718,8 @@ static void ScaleDepthData(const DepthData& in, int f, DepthData& out) {
 		}
 	}
 	for (size_t i = 0; i < out.images.size(); ++i) out.images[i].Init(out.images[0].camera);
-	if (!in.depthMap.empty()) resizeNearest(in.depthMap, in.depthMap.w / f, in.depthMap.h / f, out.depthMap);
-	if (!in.normalMap.empty()) resizeNearestN(in.normalMap, in.normalMap.w / f, in.normalMap.h / f, out.normalMap);
+	if (!in.depthMap.empty()) resizeNearestDown(in.depthMap, f, out.depthMap);
+	if (!in.normalMap.empty()) resizeNearestDownN(in.normalMap, f, out.normalMap);
 }
 
 template <typename F>
@@ -710,7 +740,7 @@ static int EstimateDepthMap(DepthData& full, const Opt& opt, int nGeometricIter,
 	const unsigned iterEnd = nGeometricIter < 0 ? opt.nEstimationIters : iterBegin + 1;
 	const unsigned totalScaleNumber = nGeometricIter < 0 ? opt.nSubResolutionLevels : 0u;
 	const int W0 = full.images[0].image.w, H0 = full.images[0].image.h;
-	if ((W0 % (1 << totalScaleNumber)) || (H0 % (1 << totalScaleNumber))) return -2;
+	if (scaledSize(W0, 1 << totalScaleNumber) < 2 * DepthEstimator::HW + 1 || scaledSize(H0, 1 << totalScaleNumber) < 2 * DepthEstimator::HW + 1) return -2;
 	for (auto& v : full.images) v.Init(full.images[0].camera);
 	ImgF lowResDepthMap; ImgN lowResNormalMap;
 	std::vector<Weight> weightMap0;
@@ -882,6 +912,11 @@ void orc_zigzag(int w, int h, int rawStride, uint16_t* outXY) {
 }
 void orc_resize_area(const float* s, int w, int h, int f, float* o) {
 	orc::ImgF a, b; a.create(w, h); memcpy(a.d.data(), s, sizeof(float) * w * h); orc::resizeArea(a, f, b); memcpy(o, b.d.data(), sizeof(float) * b.w * b.h);
+}
+void orc_resize_nearest_down(const float* s, int w, int h, int f, float* o) {
+	orc::ImgF a, b; a.create(w, h); memcpy(a.d.data(), s, sizeof(float) * w * h); orc::resizeNearestDown(a, f, b); memcpy(o, b.d.data(), sizeof(float) * b.w * b.h);
+}
+int orc_scaled_size(int n, int f) { return orc::scaledSize(n, f);
 }
 void orc_resize_linear(const float* s, int w, int h, int nw, int nh, float* o) {
 	orc::ImgF a, b; a.create(w, h); memcpy(a.d.data(), s, sizeof(float) * w * h); orc::resizeLinear(a, nw, nh, b); memcpy(o, b.d.data(), sizeof(float) * nw * nh);

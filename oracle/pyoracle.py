@@ -123,9 +123,20 @@ def zigzag(w, h, raw_stride=64):
     return out
 
 
+def scaled_size(n, f):
+    lib().orc_scaled_size.restype = C.c_int
+    return int(lib().orc_scaled_size(C.c_int(n), C.c_int(f)))
+
+
+def resize_nearest_down(img, f):
+    img = np.ascontiguousarray(img, np.float32); h, w = img.shape
+    o = np.zeros((scaled_size(h, f), scaled_size(w, f)), np.float32)
+    lib().orc_resize_nearest_down(_fp(img), C.c_int(w), C.c_int(h), C.c_int(f), _fp(o)); return o
+
+
 def resize_area(img, f):
     img = np.ascontiguousarray(img, np.float32); h, w = img.shape
-    o = np.zeros((h // f, w // f), np.float32)
+    o = np.zeros((scaled_size(h, f), scaled_size(w, f)), np.float32)
     lib().orc_resize_area(_fp(img), C.c_int(w), C.c_int(h), C.c_int(f), _fp(o)); return o
 
 

@@ -82,6 +82,22 @@ def test_single_view_parity_N8_and_N1(engine, nine_scene):
         _same(d, od, f"depth N={nsrc}"); _same(n, on, f"normal N={nsrc}"); _same(c, oc, f"conf N={nsrc}")
 
 
+def test_non_divisible_image_size_parity(engine):
+    # 163x121 with 2 sub-levels: level sizes cvRound -> 82x60, 41x30; INTER_AREA border rule on both axes
+    sc = synth.make_scene(4, 163, 121, n_src=3)
+    engine.Init(False)
+    r = np.random.RandomState(5)
+    img = r.rand(121, 163).astype(np.float32)
+    _same(engine.resize(0, img, 2), po.resize_area(img, 2), "area 2 odd"); _same(engine.resize(0, img, 4), po.resize_area(img, 4), "area 4 odd")
+    d0 = (sc.gt_depth[2] * (1 + 0.01 * r.randn(121, 163))).astype(np.float32)     # exercises the nearest down-sampling of the initial estimate
+    n0 = np.zeros((121, 163, 3), np.float32); n0[..., 2] = -1
+    p = default_params(seed=4)
+    ids = [2] + list(sc.neighbors[2])
+    d, n, c = engine.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[2], sc.dmax[2], depth=d0, normal=n0, params=p)
+    od, on, oc = _oracle(sc, 2, 4, depth=d0, normal=n0)
+    _same(d, od, "depth"); _same(n, on, "normal"); _same(c, oc, "conf")
+
+
 def test_initial_estimate_is_honoured(engine, small_scene):
     sc = small_scene
     engine.Init(False)

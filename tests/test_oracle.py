@@ -71,6 +71,35 @@ def test_resize_conventions():
     assert np.array_equal(dn, img[::4, ::4])
 
 
+def test_area_resize_of_non_divisible_sizes_follows_opencv_border_rule():
+    # cv::resize(img, Size(), 0.5, 0.5, INTER_AREA) on 7x5: output cvRound(3.5) x cvRound(2.5) = 4 x 2 (ties to even);
+    # blocks cut by the border average what exists; the cut bottom row takes that path for all its pixels
+    r = np.random.RandomState(4)
+    img = r.rand(5, 7).astype(np.float32)
+    o = po.resize_area(img, 2)
+    assert o.shape == (2, 4)
+    assert o[0, 0] == ((img[0, 0] + img[0, 1]) + (img[1, 0] + img[1, 1])) * np.float32(0.25)
+    assert o[0, 3] == (img[0, 6] + img[1, 6]) / np.float32(2)                      # right border: one column left
+    img2 = r.rand(7, 6).astype(np.float32)                                         # 7 rows -> 4 output rows, last one cut
+    o2 = po.resize_area(img2, 2)
+    assert o2.shape == (4, 3) and o2[3, 1] == (img2[6, 2] + img2[6, 3]) / np.float32(2)
+    o4 = po.resize_area(r.rand(10, 9).astype(np.float32), 4)
+    assert o4.shape == (2, 2)                                                      # cvRound(2.5) = 2, cvRound(2.25) = 2
+    assert po.scaled_size(479, 2) == 240 and po.scaled_size(479, 4) == 120 and po.scaled_size(641, 2) == 320 and po.scaled_size(639, 2) == 320
+    nd = po.resize_nearest_down(img, 2)
+    assert nd.shape == (2, 4) and nd[1, 3] == img[2, 6]
+
+
+def test_odd_image_size_runs_through_the_pyramid():
+    from openmvs_amd import synth
+    sc = synth.make_scene(4, 163, 121, n_src=3)
+    ids = [0] + list(sc.neighbors[0])
+    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+    d, n, c = po.estimate_depth_map(views, len(ids), float(sc.dmin[0]), float(sc.dmax[0]), po.default_opt(nEstimationGeometricIters=0))
+    m = d > 0
+    assert m.mean() > 0.6 and np.median(np.abs(d[m] - sc.gt_depth[0][m]) / sc.gt_depth[0][m]) < 5e-3
+
+
 def _fronto_pair(shift):
     """Two identical cameras separated along x; a fronto-parallel plane at depth d gives a pure
     integral shift `shift` px, so the true plane must score ~0 (ZNCC = 1)."""

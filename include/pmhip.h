@@ -124,6 +124,14 @@ int pmhip_scene_get_maps(pmhip_engine* e, int idx, float* depth, float* normal, 
  * what: 0 image level 0, 1 depth, 2 normal, 3 conf, 4 snapshot depth.  The per-kind arrays are
  * single contiguous allocations ordered by view index, so idx 0 addresses the whole set. */
 void* pmhip_scene_device_ptr(pmhip_engine* e, int what, int idx);
+/* DepthMapsData::FilterDepthMap (SceneDensify.cpp:1050-1299) for each view of viewIds against its first <= 8 neighbours
+ * (Scene::DenseReconstructionFilter, :2136-2170): cross-view splat + z-test, then the confidence-weighted fusion
+ * (bAdjust != 0, OPTDENSE::bFilterAdjust) or the strict agreement test.  Defaults: nMinViewsFilter 2, nMinViewsFilterAdjust 1,
+ * fDepthDiffThreshold 0.01 (DepthMap.cpp:77-78,91).  Results are staged until pmhip_scene_filter_commit, because every view
+ * must be filtered against the unfiltered maps of its neighbours (:2183-2210). */
+int pmhip_scene_filter(pmhip_engine* e, const int32_t* viewIds, int nViews, int bAdjust, uint32_t nMinViewsFilter,
+                       uint32_t nMinViewsFilterAdjust, float fDepthDiffThreshold, int sync);
+int pmhip_scene_filter_commit(pmhip_engine* e);
 /* Device-to-device copy between a caller buffer (e.g. a torch tensor used for an RCCL collective)
  * and `count` consecutive views of one per-kind array, starting at view firstIdx; `what` as above.
  * toEngine != 0 copies caller -> engine.  Asynchronous on the engine stream. */

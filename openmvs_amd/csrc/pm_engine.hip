@@ -6,6 +6,7 @@
 // Everything stays in HBM between passes; one stream; no host sync inside a call.
 #include "../../include/pmhip.h"
 #include "pm_kernels.hip"
+#include "pm_filter.hip"
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -77,6 +78,9 @@ struct pmhip_engine {
 	float* d_imgS[4] = {nullptr, nullptr, nullptr, nullptr}; // anti-diagonal-major copies, (w_l+h_l-1)*h_l floats per image
 	size_t skewPitch(int l) const { return (size_t)(lw(l) + lh(l) - 1) * lh(l); }
 	float *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr, *d_snap = nullptr;
+	// FilterDepthMap staging: filtered depth/conf of every view (committed after all views are filtered) and splat buffers
+	float *d_fdepth = nullptr, *d_fconf = nullptr; unsigned char* d_fvalid = nullptr;
+	unsigned long long* d_splat = nullptr; int splatCap = 0; PMFTask* d_ftasks = nullptr; PMFTask* h_ftasks = nullptr; int ftaskCap = 0;
 	std::vector<SceneView> views;
 	bool pyramidDirty = true;
 	// batch scratch (grow only)
@@ -101,6 +105,9 @@ static void freeScene(pmhip_engine* e) {
 	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_imgS[l]) hipFree(e->d_imgS[l]); e->d_imgS[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
 	if (e->d_depth) hipFree(e->d_depth); if (e->d_normal) hipFree(e->d_normal); if (e->d_conf) hipFree(e->d_conf); if (e->d_snap) hipFree(e->d_snap);
 	e->d_depth = e->d_normal = e->d_conf = e->d_snap = nullptr;
+	if (e->d_fdepth) hipFree(e->d_fdepth); if (e->d_fconf) hipFree(e->d_fconf); if (e->d_fvalid) hipFree(e->d_fvalid);
+	if (e->d_splat) hipFree(e->d_splat); if (e->d_ftasks) hipFree(e->d_ftasks); if (e->h_ftasks) hipHostFree(e->h_ftasks);
+	e->d_fdepth = e->d_fconf = nullptr; e->d_fvalid = nullptr; e->d_splat = nullptr; e->d_ftasks = nullptr; e->h_ftasks = nullptr; e->splatCap = e->ftaskCap = 0;
 	if (e->d_tasks) hipFree(e->d_tasks); if (e->h_tasks) hipHostFree(e->h_tasks);
 	if (e->d_ups) hipFree(e->d_ups); if (e->h_ups) hipHostFree(e->h_ups);
 	e->d_tasks = nullptr; e->h_tasks = nullptr; e->d_ups = nullptr; e->h_ups = nullptr;
@@ -540,6 +547,90 @@ void* pmhip_scene_device_ptr(pmhip_engine* e, int what, int idx) {
 	case 4: return e->d_snap + P0 * idx;
 	default: return nullptr;
 	}
+}
+
+// DepthMapsData::FilterDepthMap for each view of viewIds against its first <= 8 neighbours (Scene::DenseReconstructionFilter,
+// SceneDensify.cpp:2136-2170).  Results are staged; pmhip_scene_filter_commit installs them once every view has been
+// filtered against the *unfiltered* maps of its neighbours (EVT_ADJUSTDEPTHMAP is processed after all filter events, :2183-2210).
+int pmhip_scene_filter(pmhip_engine* e, const int32_t* viewIds, int nViews, int bAdjust, uint32_t nMinViewsFilter,
+		uint32_t nMinViewsFilterAdjust, float fDepthDiffThreshold, int sync) {
+	if (!e || !viewIds || nViews <= 0 || e->nImages < 2) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	const size_t P0 = (size_t)e->w * e->h;
+	if (!e->d_fdepth) {
+		HIPCHK(e, hipMalloc(&e->d_fdepth, sizeof(float) * P0 * e->nImages));
+		HIPCHK(e, hipMalloc(&e->d_fconf, sizeof(float) * P0 * e->nImages));
+		HIPCHK(e, hipMalloc(&e->d_fvalid, e->nImages));
+		HIPCHK(e, hipMemsetAsync(e->d_fvalid, 0, e->nImages, e->stream));
+	}
+	const int CH = std::min(nViews, 4); // reference views per launch: bounds the splat buffer (8 x 8 B per pixel per view)
+	if (e->splatCap < CH) {
+		HIPCHK(e, hipStreamSynchronize(e->stream));
+		if (e->d_splat) hipFree(e->d_splat); if (e->d_ftasks) hipFree(e->d_ftasks); if (e->h_ftasks) hipHostFree(e->h_ftasks);
+		HIPCHK(e, hipMalloc(&e->d_splat, sizeof(unsigned long long) * P0 * PMF_MAXN * CH));
+		HIPCHK(e, hipMalloc(&e->d_ftasks, sizeof(PMFTask) * CH));
+		HIPCHK(e, hipHostMalloc(&e->h_ftasks, sizeof(PMFTask) * CH));
+		e->splatCap = CH;
+	}
+	const unsigned nCal = (unsigned)e->nImages;
+	const unsigned nMinViews = std::min(nMinViewsFilter, nCal - 1), nMinViewsAdjust = std::min(nMinViewsFilterAdjust, nCal - 1);
+	std::vector<unsigned char> hv(e->nImages, 2); // 2 = untouched
+	for (int b0 = 0; b0 < nViews; b0 += CH) {
+		const int nb = std::min(CH, nViews - b0);
+		HIPCHK(e, hipStreamSynchronize(e->stream)); // staging reuse
+		for (int b = 0; b < nb; ++b) {
+			const int id = viewIds[b0 + b];
+			if (id < 0 || id >= e->nImages || !e->views[id].set) { e->err = "view not set"; return PMHIP_E_ARG; }
+			const SceneView& v = e->views[id];
+			PMFTask& t = e->h_ftasks[b];
+			memset(&t, 0, sizeof(t));
+			memcpy(t.ref.K, v.K, 72); memcpy(t.ref.R, v.R, 72); memcpy(t.ref.C, v.C, 24);
+			t.refDepth = e->d_depth + P0 * id; t.refConf = e->d_conf + P0 * id;
+			t.N = 0;
+			for (int k = 0; k < v.nNb && t.N < PMF_MAXN; ++k) {
+				const int j = v.nb[k];
+				if (j < 0 || j >= e->nImages || !e->views[j].set) continue;
+				const SceneView& sv = e->views[j];
+				memcpy(t.nb[t.N].K, sv.K, 72); memcpy(t.nb[t.N].R, sv.R, 72); memcpy(t.nb[t.N].C, sv.C, 24);
+				t.nbDepth[t.N] = e->d_depth + P0 * j; t.nbConf[t.N] = e->d_conf + P0 * j;
+				++t.N;
+			}
+			t.splat = e->d_splat + P0 * PMF_MAXN * b;
+			t.outDepth = e->d_fdepth + P0 * id; t.outConf = e->d_fconf + P0 * id;
+			t.w = e->w; t.h = e->h; t.dMin = v.dMin; t.dMax = v.dMax;
+			t.filterable = !((unsigned)t.N < nMinViews || (unsigned)t.N < nMinViewsAdjust); // :1060-1063
+			hv[id] = t.filterable ? 1 : 0;
+		}
+		HIPCHK(e, hipMemcpyAsync(e->d_ftasks, e->h_ftasks, sizeof(PMFTask) * nb, hipMemcpyHostToDevice, e->stream));
+		const size_t nS = P0 * PMF_MAXN * nb;
+		hipLaunchKernelGGL(pmf_clear_kernel, dim3((unsigned)std::min<size_t>((nS + 255) / 256, 65535)), dim3(256), 0, e->stream, e->d_splat, nS);
+		const unsigned gx = (unsigned)std::min<size_t>((P0 + 255) / 256, 2048);
+		hipLaunchKernelGGL(pmf_splat_kernel, dim3(gx, nb, PMF_MAXN), dim3(256), 0, e->stream, e->d_ftasks);
+		hipLaunchKernelGGL(pmf_vote_kernel, dim3(gx, nb), dim3(256), 0, e->stream, e->d_ftasks, bAdjust, nMinViews, nMinViewsAdjust, fDepthDiffThreshold);
+		HIPCHK(e, hipGetLastError());
+	}
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	for (int i = 0; i < e->nImages; ++i) if (hv[i] != 2) HIPCHK(e, hipMemcpyAsync(e->d_fvalid + i, &hv[i], 1, hipMemcpyHostToDevice, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	(void)sync;
+	return 0;
+}
+
+// install the staged filtered depth / confidence maps of the views filtered since the last commit (normal maps are
+// left untouched, exactly like the reference: LoadDepthMap + LoadConfidenceMap only, SceneDensify.cpp:2190-2192)
+int pmhip_scene_filter_commit(pmhip_engine* e) {
+	if (!e || !e->d_fdepth) return PMHIP_E_STATE;
+	HIPCHK(e, hipSetDevice(e->device));
+	const size_t P0 = (size_t)e->w * e->h;
+	std::vector<unsigned char> hv(e->nImages);
+	HIPCHK(e, hipMemcpy(hv.data(), e->d_fvalid, e->nImages, hipMemcpyDeviceToHost));
+	for (int i = 0; i < e->nImages; ++i) if (hv[i] == 1) {
+		HIPCHK(e, hipMemcpyAsync(e->d_depth + P0 * i, e->d_fdepth + P0 * i, sizeof(float) * P0, hipMemcpyDeviceToDevice, e->stream));
+		HIPCHK(e, hipMemcpyAsync(e->d_conf + P0 * i, e->d_fconf + P0 * i, sizeof(float) * P0, hipMemcpyDeviceToDevice, e->stream));
+	}
+	HIPCHK(e, hipMemsetAsync(e->d_fvalid, 0, e->nImages, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
 }
 
 int pmhip_scene_copy(pmhip_engine* e, int what, int firstIdx, int count, void* devPtr, int toEngine) {

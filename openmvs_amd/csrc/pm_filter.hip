@@ -1,0 +1,144 @@
+// pm_filter.hip -- DepthMapsData::FilterDepthMap (libs/MVS/SceneDensify.cpp:1050-1299) on the HBM-resident scene.
+//
+// Splat (:1084-1128): every neighbour pixel is projected into the reference view and z-tested onto the 4 surrounding
+// pixels.  The reference does this sequentially in raster order with "if (depthRef != 0 && depthRef < z) continue;
+// depthRef = z; conf = c", i.e. the final depth is the minimum z and the final confidence belongs to the LAST source pixel
+// (raster order) that attains it.  That is one 64-bit atomicMin on the key (float bits of z << 32) | (0xFFFFFFFF - source
+// index): positive floats order like their bit patterns, and the complemented index makes the later pixel win ties.
+// Vote (:1141-1290): independent per reference pixel, neighbours visited in the reference's order (n = N-1 .. 0) so the
+// float accumulations round identically.  Camera maths in double, cv::Matx accumulation order (Camera.h:338-399).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define PMF_MAXN 8   // numMaxNeighbors, SceneDensify.cpp:2152
+#define PMF_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+struct PMFCam { double K[9], R[9], C[3]; };
+struct PMFTask {          // one reference view
+	PMFCam ref; PMFCam nb[PMF_MAXN];
+	const float* refDepth; const float* refConf;
+	const float* nbDepth[PMF_MAXN]; const float* nbConf[PMF_MAXN];
+	unsigned long long* splat;   // [N][h*w] packed keys
+	float* outDepth; float* outConf;
+	int N, w, h, filterable;
+	float dMin, dMax;
+};
+
+__device__ __forceinline__ void pmf_mulMV(const double* M, double v0, double v1, double v2, double* o) {
+#pragma unroll
+	for (int i = 0; i < 3; ++i) o[i] = ((0.0 + M[i * 3] * v0) + M[i * 3 + 1] * v1) + M[i * 3 + 2] * v2;
+}
+__device__ __forceinline__ void pmf_mulMtV(const double* M, double v0, double v1, double v2, double* o) {
+#pragma unroll
+	for (int i = 0; i < 3; ++i) o[i] = ((0.0 + M[i] * v0) + M[3 + i] * v1) + M[6 + i] * v2;
+}
+__device__ __forceinline__ void pmf_I2W(const PMFCam& c, double x, double y, double z, double* X) { // Camera.h:338-356
+	double t[3];
+	pmf_mulMtV(c.R, (x - c.K[2]) * z / c.K[0], (y - c.K[5]) * z / c.K[4], z, t);
+	X[0] = t[0] + c.C[0]; X[1] = t[1] + c.C[1]; X[2] = t[2] + c.C[2];
+}
+__device__ __forceinline__ void pmf_W2C(const PMFCam& c, const double* X, double* o) { pmf_mulMV(c.R, X[0] - c.C[0], X[1] - c.C[1], X[2] - c.C[2], o); }
+__device__ __forceinline__ bool pmf_similar(float d0, float d1, float th) { return pm_fabsf(d0 - d1) / d0 < th; }
+
+__global__ void pmf_clear_kernel(unsigned long long* p, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = PMF_EMPTY;
+}
+
+// grid.y = reference views of the batch, grid.z = neighbour slot
+__global__ void pmf_splat_kernel(const PMFTask* __restrict__ tasks) {
+	const PMFTask& t = tasks[blockIdx.y];
+	const int n = blockIdx.z;
+	if (!t.filterable || n >= t.N) return;
+	const size_t P = (size_t)t.w * t.h;
+	const float* __restrict__ src = t.nbDepth[n];
+	unsigned long long* dst = t.splat + (size_t)n * P;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
+		const float depth = src[i];
+		if (depth == 0) continue;
+		const int xj = (int)(i % t.w), yi = (int)(i / t.w);
+		double X[3], camX[3];
+		pmf_I2W(t.nb[n], (double)xj, (double)yi, (double)depth, X);
+		pmf_W2C(t.ref, X, camX);
+		if (camX[2] <= 0) continue;
+		const double ix = t.ref.K[2] + t.ref.K[0] * (camX[0] / camX[2]), iy = t.ref.K[5] + t.ref.K[4] * (camX[1] / camX[2]); // TransformPointC2I
+		const float z = (float)camX[2];
+		const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+		const int x0 = (int)floor(ix), x1 = (int)ceil(ix), y0 = (int)floor(iy), y1 = (int)ceil(iy);
+		const int px[4] = {x0, x0, x1, x1}, py[4] = {y0, y1, y0, y1};
+#pragma unroll
+		for (int p = 0; p < 4; ++p)
+			if (px[p] >= 0 && py[p] >= 0 && px[p] < t.w && py[p] < t.h)
+				atomicMin(dst + (size_t)py[p] * t.w + px[p], key);
+	}
+}
+
+// the per-pixel vote; bAdjust selects the confidence-weighted fusion (:1141-1212) or the strict agreement test (:1213-1290)
+__global__ void pmf_vote_kernel(const PMFTask* __restrict__ tasks, int bAdjust, unsigned nMinViews, unsigned nMinViewsAdjust, float fDepthDiffThreshold) {
+	const PMFTask& t = tasks[blockIdx.y];
+	if (!t.filterable) return;
+	const int w = t.w, h = t.h, N = t.N;
+	const size_t P = (size_t)w * h;
+	const float thDepthDiff = fDepthDiffThreshold * 1.2f;
+	for (size_t xr = (size_t)blockIdx.x * blockDim.x + threadIdx.x; xr < P; xr += (size_t)gridDim.x * blockDim.x) {
+		const float depth = t.refDepth[xr];
+		float od = 0.f, oc = 0.f;
+		if (depth != 0) {
+			const int j = (int)(xr % w), i = (int)(xr / w);
+			if (bAdjust) {
+				float posConf = t.refConf[xr], negConf = 0.f;
+				float avgDepth = depth * posConf;
+				unsigned nPos = 0, nNeg = 0;
+				bool discard = false;
+				for (int n = N; n-- > 0; ) {
+					const unsigned long long key = t.splat[(size_t)n * P + xr];
+					if (key == PMF_EMPTY) { // d == 0
+						if (nPos + nNeg + (unsigned)n < nMinViews) { discard = true; break; }
+						continue;
+					}
+					const float d = __uint_as_float((unsigned)(key >> 32));
+					const float cn = t.nbConf[n][0xFFFFFFFFu - (unsigned)key]; // confMaps[n](xRef)
+					if (pmf_similar(depth, d, thDepthDiff)) { avgDepth += d * cn; posConf += cn; ++nPos; }
+					else {
+						if (depth > d) negConf += cn; // occlusion
+						else {                          // free-space violation
+							double X[3], cx[3];
+							pmf_I2W(t.ref, (double)j, (double)i, (double)depth, X);
+							pmf_W2C(t.nb[n], X, cx);
+							const double ux = t.nb[n].K[2] + t.nb[n].K[0] * (cx[0] / cx[2]), uy = t.nb[n].K[5] + t.nb[n].K[4] * (cx[1] / cx[2]);
+							const int x = (int)floor(ux + .5), y = (int)floor(uy + .5); // ROUND2INT(double)
+							if (x >= 0 && y >= 0 && x < w && y < h) { const float c = t.nbConf[n][(size_t)y * w + x]; negConf += (c > 0 ? c : cn); }
+							else negConf += cn;
+						}
+						++nNeg;
+					}
+				}
+				if (!discard && nPos >= nMinViewsAdjust && posConf > negConf) {
+					avgDepth /= posConf;
+					if (t.dMin <= avgDepth && avgDepth < t.dMax) { od = avgDepth; oc = posConf - negConf; }
+				}
+			} else {
+				const float thStrict = fDepthDiffThreshold * 0.8f;
+				unsigned nGood = 0, nViews = 0;
+				for (int n = N; n-- > 0; ) {
+					const unsigned long long key = t.splat[(size_t)n * P + xr];
+					if (key != PMF_EMPTY) { ++nViews; if (pmf_similar(depth, __uint_as_float((unsigned)(key >> 32)), thStrict)) ++nGood; }
+				}
+				if (!(nGood < nMinViews || nGood < nViews * 75u / 100u)) {
+					nGood = 0; nViews = 0;
+					const int dxs[4] = {-1, 1, 0, 0}, dys[4] = {0, 0, -1, 1};
+#pragma unroll
+					for (int dd = 0; dd < 4; ++dd) {
+						const int x = j + dxs[dd], y = i + dys[dd];
+						if (!(x >= 0 && y >= 0 && x < w && y < h)) continue;
+						for (int n = N; n-- > 0; ) {
+							const unsigned long long key = t.splat[(size_t)n * P + (size_t)y * w + x];
+							if (key != PMF_EMPTY) { ++nViews; if (pmf_similar(depth, __uint_as_float((unsigned)(key >> 32)), thDepthDiff)) ++nGood; }
+						}
+					}
+					if (!(nGood < nMinViews * 2u || nGood < nViews * 65u / 100u)) { od = depth; oc = t.refConf[xr]; }
+				}
+			}
+		}
+		t.outDepth[xr] = od; t.outConf[xr] = oc;
+	}
+}

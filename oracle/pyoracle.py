@@ -35,7 +35,7 @@ class OrcOpt(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libpm_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("pm_oracle.cpp", "sgm_oracle.cpp")] + \
+    srcs = [os.path.join(_HERE, f) for f in ("pm_oracle.cpp", "sgm_oracle.cpp", "filter_oracle.cpp")] + \
            [os.path.join(_HERE, "..", "openmvs_amd", "csrc", "pm_math.h")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s))
     if stale and all(os.path.exists(s) for s in srcs):
@@ -183,3 +183,28 @@ def sgm_step_forms_agree(Lp, pmin, pmax, costs, smin, smax, P1, P2) -> bool:
     lib().orc_sgm_step_forms_agree.restype = C.c_int
     return bool(lib().orc_sgm_step_forms_agree(Lp.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int(pmin), C.c_int(pmax),
                                                costs.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(smin), C.c_int(smax), C.c_uint16(P1), C.c_uint16(P2)))
+
+
+# ---- FilterDepthMap oracle (oracle/filter_oracle.cpp) ------------------------------------------
+class FltView(C.Structure):
+    _fields_ = [("depth", C.POINTER(C.c_float)), ("conf", C.POINTER(C.c_float)), ("K", C.c_double * 9), ("R", C.c_double * 9), ("C", C.c_double * 3)]
+
+
+def filter_depth_map(depths, confs, K, R, Cc, ref, nbs, dmin, dmax, bAdjust=True, nMinViewsFilter=2, nMinViewsFilterAdjust=1,
+                     nCalibratedImages=None, fDepthDiffThreshold=0.01):
+    """One DepthMapsData::FilterDepthMap call: view `ref` against neighbour views `nbs` (ids into the arrays)."""
+    keep = []
+
+    def mk(i):
+        v = FltView(); d = np.ascontiguousarray(depths[i], np.float32); c = np.ascontiguousarray(confs[i], np.float32); keep.extend([d, c])
+        v.depth = _fp(d); v.conf = _fp(c)
+        v.K[:] = np.asarray(K[i], np.float64).ravel(); v.R[:] = np.asarray(R[i], np.float64).ravel(); v.C[:] = np.asarray(Cc[i], np.float64).ravel()
+        return v
+    rv = mk(ref); arr = (FltView * max(1, len(nbs)))(*[mk(i) for i in nbs])
+    h, w = depths[ref].shape
+    nd = np.zeros((h, w), np.float32); nc = np.zeros((h, w), np.float32)
+    lib().orc_filter_depth_map.restype = C.c_int
+    rc = lib().orc_filter_depth_map(C.byref(rv), arr, C.c_int(len(nbs)), C.c_int(w), C.c_int(h), C.c_float(dmin), C.c_float(dmax), C.c_int(1 if bAdjust else 0),
+                                    C.c_uint(nMinViewsFilter), C.c_uint(nMinViewsFilterAdjust), C.c_uint(nCalibratedImages or len(depths)), C.c_float(fDepthDiffThreshold),
+                                    _fp(nd), _fp(nc))
+    return rc, nd, nc

@@ -159,6 +159,30 @@ def test_scene_batch_full_schedule_matches_oracle(small_scene):
     e.close()
 
 
+@pytest.mark.parametrize("adjust", [True, False])
+def test_filter_depth_map_parity(small_scene, adjust):
+    """Scene::DenseReconstructionFilter on the HBM-resident scene vs the FilterDepthMap oracle, bit for bit."""
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    sc = small_scene
+    e = PatchMatchHIP(0); e.Init(False)
+    e.scene_load(sc, n_levels=2)
+    allv = list(range(sc.n_views))
+    e.scene_estimate(allv, -1, default_params(seed=2, nEstimationGeometricIters=0))
+    pre = [e.scene_get_maps(v) for v in allv]
+    e.scene_filter(allv, bAdjust=adjust)
+    dep = np.stack([p[0] for p in pre]); cnf = np.stack([p[2] for p in pre])
+    changed = 0
+    for v in allv:
+        d, n, c = e.scene_get_maps(v)
+        rc, od, oc = po.filter_depth_map(dep, cnf, sc.K, sc.R, sc.C, v, list(sc.neighbors[v]), sc.dmin[v], sc.dmax[v], bAdjust=adjust)
+        assert rc == 0
+        _same(d, od, f"filtered depth v{v}"); _same(c, oc, f"filtered conf v{v}"); _same(n, pre[v][1], "normals untouched")
+        changed += int((d != pre[v][0]).sum())
+        assert ((od > 0).sum() > 0.5 * (pre[v][0] > 0).sum())
+    assert changed > 0
+    e.close()
+
+
 def test_full_size_properties():
     """BASELINE config 2 (1 ref x 8 src, 1920x1080): the oracle needs ~15 min here, so check
     size-independent properties: run-to-run determinism (race check of the diagonal schedule),

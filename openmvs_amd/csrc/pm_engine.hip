@@ -616,6 +616,32 @@ int pmhip_scene_filter(pmhip_engine* e, const int32_t* viewIds, int nViews, int 
 	return 0;
 }
 
+// DepthMapsData::GapInterpolation (SceneDensify.cpp:904-1045) on the maps of these views, in place (row pass, then column pass).
+int pmhip_scene_gap_interpolation(pmhip_engine* e, const int32_t* viewIds, int nViews, uint32_t nIpolGapSize, float fDepthDiffThreshold) {
+	if (!e || !viewIds || nViews <= 0) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	const size_t P0 = (size_t)e->w * e->h;
+	float* tmp = nullptr; PMGTask* dt = nullptr;
+	HIPCHK(e, hipMalloc(&tmp, sizeof(float) * P0 * 5));
+	HIPCHK(e, hipMalloc(&dt, sizeof(PMGTask) * 2));
+	const float th = fDepthDiffThreshold * 2.5f;
+	const unsigned gx = (unsigned)std::min<size_t>((P0 + 255) / 256, 4096);
+	int rc = 0;
+	for (int b = 0; b < nViews && rc == 0; ++b) {
+		const int id = viewIds[b];
+		if (id < 0 || id >= e->nImages) { rc = PMHIP_E_ARG; break; }
+		float* D = e->d_depth + P0 * id; float* N = e->d_normal + P0 * 3 * id; float* Cf = e->d_conf + P0 * id;
+		PMGTask ht[2] = {{D, N, Cf, tmp, tmp + P0, tmp + P0 * 4, e->w, e->h}, {tmp, tmp + P0, tmp + P0 * 4, D, N, Cf, e->w, e->h}};
+		if (hipMemcpyAsync(dt, ht, sizeof(ht), hipMemcpyHostToDevice, e->stream) != hipSuccess) { rc = PMHIP_E_HIP; break; }
+		hipLaunchKernelGGL(pmf_gap_kernel, dim3(gx, 1), dim3(256), 0, e->stream, dt, 1, nIpolGapSize, th);       // 1. row-wise
+		hipLaunchKernelGGL(pmf_gap_kernel, dim3(gx, 1), dim3(256), 0, e->stream, dt + 1, 0, nIpolGapSize, th);   // 2. column-wise
+		if (hipStreamSynchronize(e->stream) != hipSuccess) { rc = PMHIP_E_HIP; break; }
+	}
+	hipFree(tmp); hipFree(dt);
+	if (rc == PMHIP_E_HIP) e->err = "gap interpolation: HIP error";
+	return rc;
+}
+
 // install the staged filtered depth / confidence maps of the views filtered since the last commit (normal maps are
 // left untouched, exactly like the reference: LoadDepthMap + LoadConfidenceMap only, SceneDensify.cpp:2190-2192)
 int pmhip_scene_filter_commit(pmhip_engine* e) {

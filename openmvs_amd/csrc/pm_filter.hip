@@ -142,3 +142,56 @@ __global__ void pmf_vote_kernel(const PMFTask* __restrict__ tasks, int bAdjust, 
 		t.outDepth[xr] = od; t.outConf[xr] = oc;
 	}
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// DepthMapsData::GapInterpolation (SceneDensify.cpp:904-1045).  The sequential row pass only ever reads original
+// values (it fills behind the scan position), so every gap is independent: the thread of the valid pixel that closes
+// a gap measures it leftwards and fills it.  The column pass works on the row pass' result, hence the two buffers.
+struct PMGTask { const float* id; const float* in; const float* ic; float* od; float* on; float* oc; int w, h; };
+__global__ void pmf_gap_kernel(const PMGTask* __restrict__ tasks, int rows, unsigned nIpolGapSize, float th) {
+	const PMGTask& t = tasks[blockIdx.y];
+	const int w = t.w, h = t.h;
+	const size_t P = (size_t)w * h;
+	for (size_t at = (size_t)blockIdx.x * blockDim.x + threadIdx.x; at < P; at += (size_t)gridDim.x * blockDim.x) {
+		const int x = (int)(at % w), y = (int)(at / w);
+		const int u = rows ? x : y;                 // position along the scan direction
+		const size_t step = rows ? 1 : (size_t)w;
+		const float d1 = t.id[at];
+		// every pixel is copied through; gap pixels are overwritten by the thread that owns the gap (they are invalid, so
+		// their own thread writes the unchanged invalid value first only if no gap owner exists -- see below)
+		if (d1 <= 0) {
+			// is this pixel inside a fillable gap?  then its closing pixel's thread writes it; otherwise copy it
+			unsigned left = 0; while ((int)left < u && left <= nIpolGapSize && t.id[at - (left + 1) * step] <= 0) ++left;
+			unsigned right = 0; const int lim = (rows ? w : h) - 1 - u;
+			while ((int)right < lim && left + right < nIpolGapSize + 1 && t.id[at + (right + 1) * step] <= 0) ++right;
+			const unsigned count = left + right + 1;
+			bool filled = false;
+			if (count <= nIpolGapSize && (int)left < u && (int)right < lim) {
+				const float d0 = t.id[at - (left + 1) * step], de = t.id[at + (right + 1) * step];
+				filled = d0 > 0 && de > 0 && pmf_similar(d0, de, th);
+			}
+			if (!filled) { t.od[at] = d1; t.on[at * 3] = t.in[at * 3]; t.on[at * 3 + 1] = t.in[at * 3 + 1]; t.on[at * 3 + 2] = t.in[at * 3 + 2]; t.oc[at] = t.ic[at]; }
+			continue;
+		}
+		t.od[at] = d1; t.on[at * 3] = t.in[at * 3]; t.on[at * 3 + 1] = t.in[at * 3 + 1]; t.on[at * 3 + 2] = t.in[at * 3 + 2]; t.oc[at] = t.ic[at];
+		unsigned count = 0;
+		while ((int)count < u && count <= nIpolGapSize && t.id[at - (count + 1) * step] <= 0) ++count;
+		if (count == 0 || count > nIpolGapSize || !((unsigned)u > count)) continue;
+		const size_t af = at - (count + 1) * step;
+		const float d0 = t.id[af];
+		if (!(d0 > 0) || !pmf_similar(d0, d1, th)) continue;
+		const float diff = (d1 - d0) / (float)(count + 1);
+		float d = d0;
+		const float c = pm_minf(t.ic[af], t.ic[at]);
+		float p0 = pm_atan2f(t.in[af * 3 + 1], t.in[af * 3]), p1 = pm_acosf(pm_clampf(t.in[af * 3 + 2], -1.f, 1.f)); // Normal2Dir, Util.inl:754-759
+		const float q0 = pm_atan2f(t.in[at * 3 + 1], t.in[at * 3]), q1 = pm_acosf(pm_clampf(t.in[at * 3 + 2], -1.f, 1.f));
+		const float dd0 = (q0 - p0) / (float)(count + 1), dd1 = (q1 - p1) / (float)(count + 1);
+		for (size_t ac = af + step; ac != at; ac += step) {
+			d += diff; t.od[ac] = d;
+			p0 += dd0; p1 += dd1;
+			float sx, cx, sy, cy; pm_sincosf(p0, &sx, &cx); pm_sincosf(p1, &sy, &cy); // Dir2Normal
+			t.on[ac * 3] = cx * sy; t.on[ac * 3 + 1] = sx * sy; t.on[ac * 3 + 2] = cy;
+			t.oc[ac] = c;
+		}
+	}
+}

@@ -129,3 +129,51 @@ int orc_filter_depth_map(const FltView* ref, const FltView* nb, int N, int w, in
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// DepthMapsData::GapInterpolation, libs/MVS/SceneDensify.cpp:904-1045: fill row gaps then column gaps of at most
+// nIpolGapSize invalid pixels between two similar depths (threshold fDepthDiffThreshold*2.5) by linear interpolation of
+// depth and of the normal's direction angles; confidence = min of the two ends.  In place, literal transcription.
+#include "../openmvs_amd/csrc/pm_math.h"
+namespace flt {
+static inline void Normal2Dir(const float* d, float* p) { p[0] = pm_atan2f(d[1], d[0]); p[1] = pm_acosf(pm_clampf(d[2], -1.f, 1.f)); } // Util.inl:754-759
+static inline void Dir2Normal(const float* p, float* d) { float sx, cx, sy, cy; pm_sincosf(p[0], &sx, &cx); pm_sincosf(p[1], &sy, &cy); d[0] = cx * sy; d[1] = sx * sy; d[2] = cy; }
+static void gapPass(float* depth, float* normal, float* conf, int w, int h, bool rows, unsigned nIpolGapSize, float th) {
+	const int outer = rows ? h : w, inner = rows ? w : h;
+	for (int o = 0; o < outer; ++o) {
+		unsigned count = 0;
+		for (int u = 0; u < inner; ++u) {
+			const size_t at = rows ? (size_t)o * w + u : (size_t)u * w + o;
+			const float d1 = depth[at];
+			if (d1 <= 0) { ++count; continue; }
+			if (count == 0) continue;
+			if (count <= nIpolGapSize && (unsigned)u > count) {
+				int uc = u - (int)count; const int uf = uc - 1;
+				const size_t af = rows ? (size_t)o * w + uf : (size_t)uf * w + o;
+				const float d0 = depth[af];
+				if (similar(d0, d1, th)) {
+					const float diff = (d1 - d0) / (float)(count + 1);
+					float d = d0;
+					const float c = pm_minf(conf[af], conf[at]);
+					float dir1[2], dir2[2];
+					Normal2Dir(normal + af * 3, dir1); Normal2Dir(normal + at * 3, dir2);
+					const float dd[2] = {(dir2[0] - dir1[0]) / (float)(count + 1), (dir2[1] - dir1[1]) / (float)(count + 1)};
+					do {
+						const size_t ac = rows ? (size_t)o * w + uc : (size_t)uc * w + o;
+						depth[ac] = (d += diff);
+						dir1[0] += dd[0]; dir1[1] += dd[1];
+						Dir2Normal(dir1, normal + ac * 3);
+						conf[ac] = c;
+					} while (++uc < u);
+				}
+			}
+			count = 0;
+		}
+	}
+}
+}
+extern "C" void orc_gap_interpolation(float* depth, float* normal, float* conf, int w, int h, unsigned nIpolGapSize, float fDepthDiffThreshold) {
+	const float th = fDepthDiffThreshold * 2.5f;
+	flt::gapPass(depth, normal, conf, w, h, true, nIpolGapSize, th);
+	flt::gapPass(depth, normal, conf, w, h, false, nIpolGapSize, th);
+}

@@ -208,3 +208,10 @@ def filter_depth_map(depths, confs, K, R, Cc, ref, nbs, dmin, dmax, bAdjust=True
                                     C.c_uint(nMinViewsFilter), C.c_uint(nMinViewsFilterAdjust), C.c_uint(nCalibratedImages or len(depths)), C.c_float(fDepthDiffThreshold),
                                     _fp(nd), _fp(nc))
     return rc, nd, nc
+
+
+def gap_interpolation(depth, normal, conf, nIpolGapSize=7, fDepthDiffThreshold=0.01):
+    d = np.ascontiguousarray(depth, np.float32).copy(); n = np.ascontiguousarray(normal, np.float32).copy(); c = np.ascontiguousarray(conf, np.float32).copy()
+    h, w = d.shape
+    lib().orc_gap_interpolation(_fp(d), _fp(n), _fp(c), C.c_int(w), C.c_int(h), C.c_uint(nIpolGapSize), C.c_float(fDepthDiffThreshold))
+    return d, n, c

@@ -183,6 +183,35 @@ def test_filter_depth_map_parity(small_scene, adjust):
     e.close()
 
 
+def test_gap_interpolation_parity(small_scene):
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    sc = small_scene
+    e = PatchMatchHIP(0); e.Init(False)
+    e.scene_load(sc, n_levels=2)
+    allv = list(range(sc.n_views))
+    e.scene_estimate(allv, -1, default_params(seed=6, nEstimationGeometricIters=0))
+    r = np.random.RandomState(8)
+    pre = []
+    for v in allv:                                     # punch extra holes of assorted sizes into the estimated maps
+        d, n, c = e.scene_get_maps(v)
+        for _ in range(60):
+            y, x = r.randint(6, sc.height - 12), r.randint(6, sc.width - 14)
+            hh, ww = r.randint(1, 11), r.randint(1, 11)
+            d[y:y + hh, x:x + ww] = 0; n[y:y + hh, x:x + ww] = 0; c[y:y + hh, x:x + ww] = 0
+        e.scene_set_maps(v, d, n); pre.append((d, n, c))
+    # conf has no setter: compare on maps whose conf comes from the device (download again after set)
+    pre = [(p[0], p[1], e.scene_get_maps(v)[2]) for v, p in enumerate(pre)]
+    e.scene_gap_interpolation(allv)
+    filled = 0
+    for v in allv:
+        d, n, c = e.scene_get_maps(v)
+        od, on, oc = po.gap_interpolation(*pre[v])
+        _same(d, od, f"gap depth v{v}"); _same(n, on, f"gap normal v{v}"); _same(c, oc, f"gap conf v{v}")
+        filled += int(((d > 0) & (pre[v][0] == 0)).sum())
+    assert filled > 100
+    e.close()
+
+
 def test_full_size_properties():
     """BASELINE config 2 (1 ref x 8 src, 1920x1080): the oracle needs ~15 min here, so check
     size-independent properties: run-to-run determinism (race check of the diagonal schedule),

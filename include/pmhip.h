@@ -132,6 +132,9 @@ void* pmhip_scene_device_ptr(pmhip_engine* e, int what, int idx);
 int pmhip_scene_filter(pmhip_engine* e, const int32_t* viewIds, int nViews, int bAdjust, uint32_t nMinViewsFilter,
                        uint32_t nMinViewsFilterAdjust, float fDepthDiffThreshold, int sync);
 int pmhip_scene_filter_commit(pmhip_engine* e);
+/* DepthMapsData::RemoveSmallSegments (SceneDensify.cpp:809-900; OPTDENSE::nSpeckleSize 100, fDepthDiffThreshold 0.01): invalidates
+ * depth segments smaller than nSpeckleSize pixels, in place on the device; same result as the sequential region growing. */
+int pmhip_scene_remove_small_segments(pmhip_engine* e, const int32_t* viewIds, int nViews, uint32_t nSpeckleSize, float fDepthDiffThreshold);
 /* DepthMapsData::GapInterpolation (SceneDensify.cpp:904-1045; OPTDENSE::nIpolGapSize 7, fDepthDiffThreshold 0.01): fills row then
  * column gaps of the depth / normal / confidence maps of these views, in place on the device. */
 int pmhip_scene_gap_interpolation(pmhip_engine* e, const int32_t* viewIds, int nViews, uint32_t nIpolGapSize, float fDepthDiffThreshold);

@@ -12,6 +12,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -639,6 +641,62 @@ int pmhip_scene_gap_interpolation(pmhip_engine* e, const int32_t* viewIds, int n
 	}
 	hipFree(tmp); hipFree(dt);
 	if (rc == PMHIP_E_HIP) e->err = "gap interpolation: HIP error";
+	return rc;
+}
+
+// DepthMapsData::RemoveSmallSegments (SceneDensify.cpp:809-900) on the maps of these views, in place; see pm_filter.hip.
+int pmhip_scene_remove_small_segments(pmhip_engine* e, const int32_t* viewIds, int nViews, uint32_t nSpeckleSize, float fDepthDiffThreshold) {
+	if (!e || !viewIds || nViews <= 0) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	const int n = e->w * e->h;
+	const size_t P0 = (size_t)n;
+	const int cap = n; // asymmetric edges are rare; n pairs is far more than ever needed
+	int *parent = nullptr, *size = nullptr, *edges = nullptr, *nEdges = nullptr, *ovr = nullptr;
+	HIPCHK(e, hipMalloc(&parent, sizeof(int) * n)); HIPCHK(e, hipMalloc(&size, sizeof(int) * n));
+	HIPCHK(e, hipMalloc(&edges, sizeof(int) * 2 * cap)); HIPCHK(e, hipMalloc(&nEdges, sizeof(int))); HIPCHK(e, hipMalloc(&ovr, sizeof(int) * 2 * cap));
+	const float th = fDepthDiffThreshold * 0.7f;
+	const unsigned gx = (unsigned)std::min<size_t>((P0 + 255) / 256, 4096);
+	int rc = 0;
+	std::vector<int> hedges, hsize;
+	for (int b = 0; b < nViews && rc == 0; ++b) {
+		const int id = viewIds[b];
+		if (id < 0 || id >= e->nImages) { rc = PMHIP_E_ARG; break; }
+		float* D = e->d_depth + P0 * id; float* N = e->d_normal + P0 * 3 * id; float* Cf = e->d_conf + P0 * id;
+		hipMemsetAsync(nEdges, 0, sizeof(int), e->stream);
+		hipLaunchKernelGGL(pmf_cc_init_kernel, dim3(gx), dim3(256), 0, e->stream, parent, size, n);
+		hipLaunchKernelGGL(pmf_cc_hook_kernel, dim3(gx), dim3(256), 0, e->stream, D, parent, e->w, e->h, th);
+		hipLaunchKernelGGL(pmf_cc_flatten_kernel, dim3(gx), dim3(256), 0, e->stream, parent, size, n);
+		hipLaunchKernelGGL(pmf_cc_asym_kernel, dim3(gx), dim3(256), 0, e->stream, D, parent, e->w, e->h, th, edges, nEdges, cap);
+		int ne = 0;
+		if (hipMemcpyAsync(&ne, nEdges, sizeof(int), hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) { rc = PMHIP_E_HIP; break; }
+		if (ne > cap) { e->err = "remove_small_segments: asymmetric edge list overflow"; rc = PMHIP_E_HIP; break; }
+		if (ne > 0) {
+			// replay the reference's seed order on the quotient graph of components linked by one-directional edges
+			hedges.resize(2 * (size_t)ne); hsize.resize(n);
+			if (hipMemcpy(hedges.data(), edges, sizeof(int) * 2 * ne, hipMemcpyDeviceToHost) != hipSuccess ||
+				hipMemcpy(hsize.data(), size, sizeof(int) * n, hipMemcpyDeviceToHost) != hipSuccess) { rc = PMHIP_E_HIP; break; }
+			std::map<int, std::set<int>> adj;
+			for (int k = 0; k < ne; ++k) { adj[hedges[2 * k]].insert(hedges[2 * k + 1]); adj[hedges[2 * k + 1]]; }
+			std::set<int> done;
+			std::vector<int> pairs;
+			for (auto& kv : adj) {                      // std::map iterates roots in increasing (= seed) order
+				const int r = kv.first;
+				if (done.count(r)) continue;
+				std::vector<int> seg{r}; done.insert(r);
+				for (size_t q = 0; q < seg.size(); ++q) for (int nb : adj[seg[q]]) if (!done.count(nb)) { done.insert(nb); seg.push_back(nb); }
+				long total = 0; for (int x : seg) total += hsize[x];
+				const int val = total < (long)nSpeckleSize ? 0 : (int)nSpeckleSize;   // forces remove / keep for every member
+				for (int x : seg) { pairs.push_back(x); pairs.push_back(val); }
+			}
+			const int np = (int)(pairs.size() / 2);
+			if (hipMemcpy(ovr, pairs.data(), sizeof(int) * pairs.size(), hipMemcpyHostToDevice) != hipSuccess) { rc = PMHIP_E_HIP; break; }
+			hipLaunchKernelGGL(pmf_cc_override_kernel, dim3((np + 255) / 256), dim3(256), 0, e->stream, size, ovr, np);
+		}
+		hipLaunchKernelGGL(pmf_cc_apply_kernel, dim3(gx), dim3(256), 0, e->stream, D, N, Cf, parent, size, e->w, e->h, (int)nSpeckleSize);
+		if (hipStreamSynchronize(e->stream) != hipSuccess) { rc = PMHIP_E_HIP; break; }
+	}
+	hipFree(parent); hipFree(size); hipFree(edges); hipFree(nEdges); hipFree(ovr);
+	if (rc == PMHIP_E_HIP && e->err.empty()) e->err = "remove_small_segments: HIP error";
 	return rc;
 }
 

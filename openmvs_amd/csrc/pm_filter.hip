@@ -195,3 +195,79 @@ __global__ void pmf_gap_kernel(const PMGTask* __restrict__ tasks, int rows, unsi
 		}
 	}
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// DepthMapsData::RemoveSmallSegments (SceneDensify.cpp:809-900).  The reference grows regions from seeds in
+// column-major order along DIRECTED edges (cur -> nb iff |d_cur - d_nb| / d_cur < th), so a segment is "everything
+// reachable from the first not-yet-claimed pixel".  Exact parallel reformulation:
+//   * pixels joined by MUTUAL edges (both directions similar) are always claimed together -> connected components of
+//     the mutual graph by lock-free union-find (root = smallest column-major index = the pixel the sequential scan
+//     meets first);
+//   * the few ASYMMETRIC edges (exactly one direction) form a small quotient graph between components, on which the
+//     host replays the seed order (pmhip_scene_remove_small_segments); components without asymmetric edges are
+//     decided by their size alone.
+__device__ __forceinline__ int pmf_find(int* parent, int a) {
+	int p = parent[a];
+	while (p != a) { const int gp = parent[p]; if (gp != p) parent[a] = gp; a = p; p = parent[a]; } // parents only decrease: safe under races
+	return a;
+}
+__device__ __forceinline__ void pmf_union(int* parent, int a, int b) {
+	for (;;) {
+		a = pmf_find(parent, a); b = pmf_find(parent, b);
+		if (a == b) return;
+		if (a > b) { const int t = a; a = b; b = t; }          // a < b: hook the larger root under the smaller
+		const int old = atomicMin(&parent[b], a);
+		if (old == b) return;
+		b = old;
+	}
+}
+__global__ void pmf_cc_init_kernel(int* parent, int* size, int n) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { parent[i] = i; size[i] = 0; }
+}
+// ids are column-major: id(x,y) = x*h + y (the reference scans u outer, v inner)
+__global__ void pmf_cc_hook_kernel(const float* __restrict__ depth, int* parent, int w, int h, float th) {
+	const int n = w * h;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const int x = i % w, y = i / w;
+		const float d = depth[i];
+		if (!(d > 0)) continue;
+		if (x + 1 < w) { const float e = depth[i + 1]; if (e > 0 && pmf_similar(d, e, th) && pmf_similar(e, d, th)) pmf_union(parent, x * h + y, (x + 1) * h + y); }
+		if (y + 1 < h) { const float e = depth[i + w]; if (e > 0 && pmf_similar(d, e, th) && pmf_similar(e, d, th)) pmf_union(parent, x * h + y, x * h + y + 1); }
+	}
+}
+// read-only find: in the flatten pass the only writer of parent[i] must be thread i (a compressing find of another
+// thread could overwrite the final root with a stale grandparent)
+__device__ __forceinline__ int pmf_find_ro(const int* parent, int a) { int p = parent[a]; while (p != a) { a = p; p = parent[a]; } return a; }
+__global__ void pmf_cc_flatten_kernel(int* parent, int* size, int n) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const int r = pmf_find_ro(parent, i); parent[i] = r; atomicAdd(&size[r], 1); }
+}
+// asymmetric edges between different components: (root of cur, root of nb) with cur -> nb similar but not nb -> cur
+__global__ void pmf_cc_asym_kernel(const float* __restrict__ depth, const int* __restrict__ parent, int w, int h, float th, int* edges, int* nEdges, int cap) {
+	const int n = w * h;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const int x = i % w, y = i / w;
+		const float d = depth[i];
+		if (!(d > 0)) continue;
+		const int dx[4] = {-1, 1, 0, 0}, dy[4] = {0, 0, -1, 1};
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int qx = x + dx[k], qy = y + dy[k];
+			if (qx < 0 || qy < 0 || qx >= w || qy >= h) continue;
+			const float e = depth[qy * w + qx];
+			if (e > 0 && pmf_similar(d, e, th) && !pmf_similar(e, d, th)) {
+				const int ra = parent[x * h + y], rb = parent[qx * h + qy];
+				if (ra != rb) { const int at = atomicAdd(nEdges, 1); if (at < cap) { edges[2 * at] = ra; edges[2 * at + 1] = rb; } }
+			}
+		}
+	}
+}
+__global__ void pmf_cc_override_kernel(int* size, const int* __restrict__ pairs, int n) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) size[pairs[2 * i]] = pairs[2 * i + 1];
+}
+__global__ void pmf_cc_apply_kernel(float* depth, float* normal, float* conf, const int* __restrict__ parent, const int* __restrict__ size, int w, int h, int speckle) {
+	const int n = w * h;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const int x = i % w, y = i / w;
+		if (size[parent[x * h + y]] < speckle) { depth[i] = 0.f; normal[3 * i] = 0.f; normal[3 * i + 1] = 0.f; normal[3 * i + 2] = 0.f; conf[i] = 0.f; }
+	}
+}

@@ -49,7 +49,7 @@ class PMHipKernelStats(C.Structure):
 EXPORTS = ["pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
            "pmhip_estimate_depth_map", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
            "pmhip_scene_estimate", "pmhip_scene_commit_round", "pmhip_scene_reset_view", "pmhip_scene_set_maps",
-           "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_images_updated", "pmhip_sync",
+           "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_remove_small_segments", "pmhip_scene_images_updated", "pmhip_sync",
            "pmhip_stream", "pmhip_stats_reset", "pmhip_stats_get", "pmhip_prof_get", "pmhip_math_eval", "pmhip_resize"]
 
 _LIB = None
@@ -194,6 +194,10 @@ class PatchMatchHIP:
                                                C.c_uint32(nMinViewsFilter), C.c_uint32(nMinViewsFilterAdjust), C.c_float(fDepthDiffThreshold), 1))
         if commit:
             self._chk(self._lib.pmhip_scene_filter_commit(self._h))
+
+    def scene_remove_small_segments(self, view_ids, nSpeckleSize=100, fDepthDiffThreshold=0.01):
+        ids = np.ascontiguousarray(view_ids, np.int32)
+        self._chk(self._lib.pmhip_scene_remove_small_segments(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), len(ids), C.c_uint32(nSpeckleSize), C.c_float(fDepthDiffThreshold)))
 
     def scene_gap_interpolation(self, view_ids, nIpolGapSize=7, fDepthDiffThreshold=0.01):
         ids = np.ascontiguousarray(view_ids, np.int32)

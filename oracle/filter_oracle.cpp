@@ -177,3 +177,36 @@ extern "C" void orc_gap_interpolation(float* depth, float* normal, float* conf, 
 	flt::gapPass(depth, normal, conf, w, h, true, nIpolGapSize, th);
 	flt::gapPass(depth, normal, conf, w, h, false, nIpolGapSize, th);
 }
+
+// ---------------------------------------------------------------------------------------------
+// DepthMapsData::RemoveSmallSegments, libs/MVS/SceneDensify.cpp:809-900, literal: region growing from seeds in
+// column-major order along *directed* similarity edges (|d_cur - d_nb| / d_cur < 0.7 * fDepthDiffThreshold);
+// segments smaller than nSpeckleSize are invalidated.
+extern "C" void orc_remove_small_segments(float* depth, float* normal, float* conf, int w, int h, unsigned speckle_size, float fDepthDiffThreshold) {
+	const float th = fDepthDiffThreshold * 0.7f;
+	std::vector<unsigned char> done((size_t)w * h, 0);
+	std::vector<int> seg; seg.reserve((size_t)w * h);
+	for (int u = 0; u < w; ++u) for (int v = 0; v < h; ++v) {
+		if (done[(size_t)v * w + u]) continue;
+		seg.clear(); seg.push_back(v * w + u);
+		size_t cur = 0;
+		while (cur < seg.size()) {
+			const int a = seg[cur]; const int ax = a % w, ay = a / w;
+			const float dc = depth[a];
+			if (dc > 0) {
+				const int nx[4] = {ax - 1, ax + 1, ax, ax}, ny[4] = {ay, ay, ay - 1, ay + 1};
+				for (int i = 0; i < 4; ++i) {
+					if (!(nx[i] >= 0 && ny[i] >= 0 && nx[i] < w && ny[i] < h)) continue;
+					const int b = ny[i] * w + nx[i];
+					if (done[b]) continue;
+					const float dn = depth[b];
+					if (dn > 0 && flt::similar(dc, dn, th)) { seg.push_back(b); done[b] = 1; }
+				}
+			}
+			++cur;
+			done[a] = 1;
+		}
+		if (seg.size() < speckle_size)
+			for (int a : seg) { depth[a] = 0; normal[a * 3] = normal[a * 3 + 1] = normal[a * 3 + 2] = 0; conf[a] = 0; }
+	}
+}

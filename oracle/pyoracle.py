@@ -215,3 +215,10 @@ def gap_interpolation(depth, normal, conf, nIpolGapSize=7, fDepthDiffThreshold=0
     h, w = d.shape
     lib().orc_gap_interpolation(_fp(d), _fp(n), _fp(c), C.c_int(w), C.c_int(h), C.c_uint(nIpolGapSize), C.c_float(fDepthDiffThreshold))
     return d, n, c
+
+
+def remove_small_segments(depth, normal, conf, nSpeckleSize=100, fDepthDiffThreshold=0.01):
+    d = np.ascontiguousarray(depth, np.float32).copy(); n = np.ascontiguousarray(normal, np.float32).copy(); c = np.ascontiguousarray(conf, np.float32).copy()
+    h, w = d.shape
+    lib().orc_remove_small_segments(_fp(d), _fp(n), _fp(c), C.c_int(w), C.c_int(h), C.c_uint(nSpeckleSize), C.c_float(fDepthDiffThreshold))
+    return d, n, c

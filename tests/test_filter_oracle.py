@@ -62,3 +62,85 @@ def test_gap_interpolation_fills_small_similar_gaps_only():
     ramp = np.full((4, 12), 2.0, np.float32); ramp[1, 3:6] = 0; ramp[1, 6:] = 2.04     # 2 % step: interpolated linearly
     dr, _, _ = po.gap_interpolation(ramp, np.broadcast_to(normal[0, 0], (4, 12, 3)).copy(), np.full((4, 12), 0.5, np.float32))
     assert np.allclose(dr[1, 3:6], [2.01, 2.02, 2.03], atol=1e-6)
+
+
+def _reformulated_remove_small_segments(depth, speckle, th):
+    """Pure-python model of the GPU formulation (pm_filter.hip): union-find over MUTUAL edges with root = smallest
+    column-major index, then a replay of the seed order on the quotient graph of asymmetric edges."""
+    h, w = depth.shape
+    cm = lambda x, y: x * h + y
+    parent = list(range(w * h))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]; a = parent[a]
+        return a
+    sim = lambda a, b: abs(np.float32(a) - np.float32(b)) / np.float32(a) < np.float32(th)
+    for y in range(h):
+        for x in range(w):
+            d = depth[y, x]
+            if not d > 0: continue
+            for qx, qy in ((x + 1, y), (x, y + 1)):
+                if qx < w and qy < h and depth[qy, qx] > 0 and sim(d, depth[qy, qx]) and sim(depth[qy, qx], d):
+                    a, b = find(cm(x, y)), find(cm(qx, qy))
+                    if a != b: parent[max(a, b)] = min(a, b)
+    root = np.array([[find(cm(x, y)) for x in range(w)] for y in range(h)])
+    size = np.bincount(root.ravel(), minlength=w * h)
+    adj = {}
+    for y in range(h):
+        for x in range(w):
+            d = depth[y, x]
+            if not d > 0: continue
+            for qx, qy in ((x - 1, y), (x + 1, y), (x, y - 1), (x, y + 1)):
+                if 0 <= qx < w and 0 <= qy < h and depth[qy, qx] > 0 and sim(d, depth[qy, qx]) and not sim(depth[qy, qx], d) and root[y, x] != root[qy, qx]:
+                    adj.setdefault(root[y, x], set()).add(root[qy, qx]); adj.setdefault(root[qy, qx], set())
+    decided = {}
+    done = set()
+    for r in sorted(adj):
+        if r in done: continue
+        seg = [r]; done.add(r); q = 0
+        while q < len(seg):
+            for nb in sorted(adj[seg[q]]):
+                if nb not in done: done.add(nb); seg.append(nb)
+            q += 1
+        rm = sum(size[s] for s in seg) < speckle
+        for s in seg: decided[s] = rm
+    remove = np.zeros((h, w), bool)
+    for y in range(h):
+        for x in range(w):
+            r = root[y, x]
+            remove[y, x] = decided[r] if r in decided else size[r] < speckle
+    return remove
+
+
+def test_remove_small_segments_reformulation_equals_the_sequential_region_growing():
+    r = np.random.RandomState(11)
+    th = np.float32(0.01) * np.float32(0.7)
+    n_asym_cases = 0
+    for trial in range(60):
+        h, w = r.randint(8, 22), r.randint(8, 22)
+        # piecewise-constant levels spaced right at the similarity threshold so that one-directional edges are common
+        levels = 2.0 * (1 + float(th)) ** (r.randint(0, 5, (h, w)) * r.choice([0.97, 1.0, 1.03]))
+        depth = levels.astype(np.float32)
+        depth[r.rand(h, w) < 0.15] = 0
+        normal = np.zeros((h, w, 3), np.float32); normal[..., 2] = -1; conf = np.full((h, w), 0.5, np.float32)
+        speckle = int(r.choice([3, 6, 12, 30]))
+        od, on, oc = po.remove_small_segments(depth, normal, conf, nSpeckleSize=speckle)
+        rm = _reformulated_remove_small_segments(depth, speckle, th)
+        want = (depth > 0) & (od == 0)
+        assert np.array_equal(rm & (depth > 0), want), f"trial {trial}"
+        assert (on[od == 0] == 0).all() and (oc[od == 0] == 0).all()
+        a = depth[:, :-1]; b = depth[:, 1:]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            n_asym_cases += int((((np.abs(a - b) / a < th) != (np.abs(a - b) / b < th)) & (a > 0) & (b > 0)).sum())
+    assert n_asym_cases > 50          # the test really exercises one-directional edges
+
+
+def test_remove_small_segments_basic():
+    depth = np.zeros((30, 40), np.float32); depth[2:20, 2:30] = 2.0        # 504-px segment: kept
+    depth[24:27, 5:9] = 2.0                                                # 12-px island: removed
+    depth[22:28, 20:36] = 3.0                                              # 96-px island: removed (< 100)
+    normal = np.zeros((30, 40, 3), np.float32); normal[..., 2] = -1; conf = np.full((30, 40), 0.5, np.float32)
+    d, n, c = po.remove_small_segments(depth, normal, conf)
+    assert (d[2:20, 2:30] == 2.0).all() and (d[24:27, 5:9] == 0).all() and (d[22:28, 20:36] == 0).all()
+    assert (n[24:27, 5:9] == 0).all() and (c[22:28, 20:36] == 0).all()

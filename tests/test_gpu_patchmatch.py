@@ -183,6 +183,36 @@ def test_filter_depth_map_parity(small_scene, adjust):
     e.close()
 
 
+def test_remove_small_segments_parity(small_scene):
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    sc = small_scene
+    e = PatchMatchHIP(0); e.Init(False)
+    e.scene_load(sc, n_levels=2)
+    allv = list(range(sc.n_views))
+    e.scene_estimate(allv, -1, default_params(seed=6, nEstimationGeometricIters=0))
+    r = np.random.RandomState(12)
+    th = np.float32(0.007)
+    pre = []
+    for v in allv:
+        d, n, c = e.scene_get_maps(v)
+        if v >= 2:   # synthetic terraces right at the similarity threshold: plenty of one-directional edges and small islands
+            lv = (2.0 * (1 + float(th)) ** (r.randint(0, 6, d.shape) * r.choice([0.97, 1.0, 1.03]))).astype(np.float32)
+            blk = np.kron(r.rand(d.shape[0] // 4, d.shape[1] // 4) < 0.5, np.ones((4, 4), bool))
+            d = np.where(blk, lv, d).astype(np.float32); d[r.rand(*d.shape) < 0.1] = 0
+            n = n.copy(); n[d > 0] = [0, 0, -1]; n[d == 0] = 0
+        e.scene_set_maps(v, d, n)
+        pre.append((d, n, e.scene_get_maps(v)[2]))
+    e.scene_remove_small_segments(allv, nSpeckleSize=40)
+    removed = 0
+    for v in allv:
+        d, n, c = e.scene_get_maps(v)
+        od, on, oc = po.remove_small_segments(pre[v][0], pre[v][1], pre[v][2], nSpeckleSize=40)
+        _same(d, od, f"speckle depth v{v}"); _same(n, on, f"speckle normal v{v}"); _same(c, oc, f"speckle conf v{v}")
+        removed += int(((pre[v][0] > 0) & (d == 0)).sum())
+    assert removed > 50
+    e.close()
+
+
 def test_gap_interpolation_parity(small_scene):
     from openmvs_amd.patchmatch import PatchMatchHIP
     sc = small_scene

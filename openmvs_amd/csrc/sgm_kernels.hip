@@ -89,10 +89,36 @@ __global__ __launch_bounds__(256) void sgm_cost_kernel(const unsigned char* __re
 struct SGMLines { int nA, ax, ay, adx, ady, nB, bx, by, bdx, bdy; };
 
 // ---- wave helpers ---------------------------------------------------------------------------
+// wave64 minimum on the VALU cross-lane network (DPP row shifts + row broadcasts, then one readlane) instead of six
+// dependent ds_bpermute round trips through the LDS crossbar: this reduction sits on the critical path of every step
+// of the path recurrence.
 __device__ __forceinline__ int sgm_wave_min(int v) {
-#pragma unroll
-	for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
-	return v;
+	const int big = SGM_INF;
+	v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x111, 0xf, 0xf, false)); // row_shr:1
+	v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x112, 0xf, 0xf, false)); // row_shr:2
+	v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x114, 0xf, 0xf, false)); // row_shr:4
+	v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x118, 0xf, 0xf, false)); // row_shr:8  -> lane 15 of each row of 16 holds the row minimum
+	v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1 and 3
+	v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave minimum
+	return __builtin_amdgcn_readlane(v, 63);
+}
+
+// accums(d) += L(d) (:1020,1043).  The eight path kernels run concurrently on eight streams, so the sum is an atomic add;
+// two u16 sums share a 32-bit word (no carry between halves: a sum never exceeds 8*(255+60) = 2520), and the lane owning
+// the even entry adds its right neighbour's value in the same atomic.  Must be called by all 64 lanes.
+__device__ __forceinline__ void sgm_accumulate(unsigned* words, unsigned long long idx, int k, int nD, int L, int lane) {
+	const int Lnext = __shfl_down(L, 1, 64);                       // value of entry k+1 (lane+1), garbage for lane 63
+	const unsigned long long pos = idx + (unsigned)k;
+	if (k < nD) {
+		if ((pos & 1ull) == 0) {
+			unsigned v = (unsigned)L;
+			if (lane < 63 && k + 1 < nD) v |= (unsigned)Lnext << 16;
+			atomicAdd(words + (pos >> 1), v);
+		} else if (lane == 0 || k == 0) {
+			atomicAdd(words + (pos >> 1), (unsigned)L << 16);       // odd entry whose even partner belongs to nobody in this wave-instruction
+		}
+	}
+	// an odd entry at lane 63+1 of the previous 64-chunk is handled above by (lane == 0); the even entry of lane 63 adds alone
 }
 
 // ---- one path direction, SemiGlobalMatcher.cpp:1003-1046 + ACCUM_PIXELS :1065-1082 -----------
@@ -100,7 +126,7 @@ __device__ __forceinline__ int sgm_wave_min(int v) {
 // Line start sets are the threaded variant's (:1083-1200); see the host for the numbering.
 template <int NK>
 __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ grayL, int w, int vw, int vh,
-		const SGMPixel* __restrict__ pixels, const unsigned char* __restrict__ costs, unsigned short* __restrict__ accums,
+		const SGMPixel* __restrict__ pixels, const unsigned char* __restrict__ costs, unsigned* __restrict__ accumWords,
 		const unsigned short* __restrict__ P2s, int P1, int dx, int dy, SGMLines ln, int maxNumDisp) {
 	extern __shared__ __attribute__((aligned(16))) int s_L[]; // 2 x (maxNumDisp + 2): previous / current line of L
 	const int lane = threadIdx.x;
@@ -121,7 +147,7 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 	// and running sums of chunk k+1 and the pixel table of chunk k+2 are already in flight, so no step of the
 	// recurrence waits on HBM.  Chunk state lives in registers (fully unrolled arrays).
 	SGMPixel pxA[SGM_T], pxB[SGM_T]; float gA[SGM_T], gB[SGM_T]; bool okA[SGM_T], okB[SGM_T];
-	unsigned char cA[SGM_T][NK], cB[SGM_T][NK]; unsigned short aA[SGM_T][NK], aB[SGM_T][NK];
+	unsigned char cA[SGM_T][NK], cB[SGM_T][NK];
 	auto loadPixels = [&](int cx, int cy, SGMPixel* px, float* g, bool* ok) {
 #pragma unroll
 		for (int t = 0; t < SGM_T; ++t) {
@@ -134,7 +160,7 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 			}
 		}
 	};
-	auto loadCosts = [&](const SGMPixel* px, bool* ok, unsigned char (*c8)[NK], unsigned short (*a16)[NK]) {
+	auto loadCosts = [&](const SGMPixel* px, bool* ok, unsigned char (*c8)[NK]) {
 #pragma unroll
 		for (int t = 0; t < SGM_T; ++t) {
 			const int nD = px[t].maxDisp - px[t].minDisp;
@@ -142,16 +168,16 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 #pragma unroll
 			for (int q = 0; q < NK; ++q) {
 				const int k = lane + 64 * q;
-				c8[t][q] = 0; a16[t][q] = 0;
-				if (ok[t] && k < nD) { c8[t][q] = costs[px[t].idx + k]; a16[t][q] = accums[px[t].idx + k]; }
+				c8[t][q] = 0;
+				if (ok[t] && k < nD) c8[t][q] = costs[px[t].idx + k];
 			}
 		}
 	};
 	loadPixels(x, y, pxA, gA, okA);
-	loadCosts(pxA, okA, cA, aA);
+	loadCosts(pxA, okA, cA);
 	loadPixels(x + SGM_T * dx, y + SGM_T * dy, pxB, gB, okB);
 	while (x >= 0 && y >= 0 && x < vw && y < vh) {
-		loadCosts(pxB, okB, cB, aB);                                  // chunk k+1: costs / sums
+		loadCosts(pxB, okB, cB);                                      // chunk k+1: cost bytes
 		SGMPixel pxC[SGM_T]; float gC[SGM_T]; bool okC[SGM_T];
 		loadPixels(x + 2 * SGM_T * dx, y + 2 * SGM_T * dy, pxC, gC, okC); // chunk k+2: pixel table
 		// ---- consume chunk k serially ------------------------------------------------------------
@@ -169,7 +195,9 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 #pragma unroll
 				for (int q = 0; q < NK; ++q) {
 					const int k = lane + 64 * q;
-					if (k < nD) { const int L = (int)cA[t][q] + P2; Ls[k] = L; accums[pxA[t].idx + k] = (unsigned short)(aA[t][q] + L); }
+					const int L = (int)cA[t][q] + P2;
+					if (k < nD) Ls[k] = L;
+					sgm_accumulate(accumWords, pxA[t].idx, k, nD, L, lane);
 				}
 			} else {
 				int m = SGM_INF;
@@ -178,15 +206,17 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 #pragma unroll
 				for (int q = 0; q < NK; ++q) {
 					const int k = lane + 64 * q;
+					int L = 0;
 					if (k < nD) {
 						const int d = rsMin + k;
 						int best = m + P2;
 						if (d >= lo && d < hi) best = min(best, Lp[d - rpMin]);
 						if (d - 1 >= lo && d - 1 < hi) best = min(best, Lp[d - 1 - rpMin] + P1);
 						if (d + 1 >= lo && d + 1 < hi) best = min(best, Lp[d + 1 - rpMin] + P1);
-						const int L = (int)cA[t][q] + best - m;
-						Ls[k] = L; accums[pxA[t].idx + k] = (unsigned short)(aA[t][q] + L);
+						L = (int)cA[t][q] + best - m;
+						Ls[k] = L;
 					}
+					sgm_accumulate(accumWords, pxA[t].idx, k, nD, L, lane);
 				}
 			}
 			rpMin = rsMin; rpMax = rsMax; Ip = gA[t]; cur ^= 1;
@@ -199,7 +229,7 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 			pxA[t] = pxB[t]; gA[t] = gB[t]; okA[t] = okB[t];
 			pxB[t] = pxC[t]; gB[t] = gC[t]; okB[t] = okC[t];
 #pragma unroll
-			for (int q = 0; q < NK; ++q) { cA[t][q] = cB[t][q]; aA[t][q] = aB[t][q]; }
+			for (int q = 0; q < NK; ++q) cA[t][q] = cB[t][q];
 		}
 	}
 }

@@ -144,3 +144,20 @@ def test_remove_small_segments_basic():
     d, n, c = po.remove_small_segments(depth, normal, conf)
     assert (d[2:20, 2:30] == 2.0).all() and (d[24:27, 5:9] == 0).all() and (d[22:28, 20:36] == 0).all()
     assert (n[24:27, 5:9] == 0).all() and (c[22:28, 20:36] == 0).all()
+
+
+def test_filter_golden_fixture_pins_the_post_filter_oracles():
+    import os
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(G, "pm_golden_96x64.npz")); f = np.load(os.path.join(G, "filter_golden_96x64.npz"))
+    nv = int(g["n_views"]); depth = g["depth_photo_all"]
+    for v in range(nv):
+        sd, sn, sc_ = po.remove_small_segments(depth[v], f["normal"][v], f["conf"][v], nSpeckleSize=30)
+        assert np.array_equal(sd, f["speckle_depth"][v])
+        gd, gn, gc = po.gap_interpolation(sd, sn, sc_)
+        assert np.array_equal(gd, f["gap_depth"][v]) and np.array_equal(gn, f["gap_normal"][v]) and np.array_equal(gc, f["gap_conf"][v])
+    for v in range(nv):
+        rc, fd, fc = po.filter_depth_map(f["gap_depth"], f["gap_conf"], g["K"], g["R"], g["C"], v, list(g["neighbors"][v]), g["dmin"][v], g["dmax"][v])
+        assert rc == 0 and np.array_equal(fd, f["filt_depth"][v]) and np.array_equal(fc, f["filt_conf"][v])
+        rc, sd, sc_ = po.filter_depth_map(f["gap_depth"], f["gap_conf"], g["K"], g["R"], g["C"], v, list(g["neighbors"][v]), g["dmin"][v], g["dmax"][v], bAdjust=False)
+        assert np.array_equal(sd, f["strict_depth"][v]) and np.array_equal(sc_, f["strict_conf"][v])

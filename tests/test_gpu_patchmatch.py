@@ -242,6 +242,37 @@ def test_gap_interpolation_parity(small_scene):
     e.close()
 
 
+def test_whole_dense_schedule_matches_the_oracle_pipeline(small_scene, tmp_path):
+    """Scene::ComputeDepthMaps order of operations (SceneDensify.cpp:1884-1980): photometric, 2 geometric rounds, speckle + gap
+    filters after the last round, cross-view filter, .dmap files -- device pipeline vs the same chain of oracle stages."""
+    from openmvs_amd import densify, dmap
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    sc = small_scene
+    seed = 31
+    e = PatchMatchHIP(0)
+    e.scene_load(sc, n_levels=2)
+    allv = list(range(sc.n_views))
+    p = default_params(seed=seed)
+    densify.compute_depth_maps(e, allv, p, n_speckle_size=30)
+    paths = densify.save_depth_maps(e, sc, allv, str(tmp_path))
+    # oracle chain
+    cur = {v: _oracle(sc, v, seed) for v in allv}
+    for geo in range(2):
+        prev = {v: cur[v][0] for v in allv}
+        cur = {v: _oracle(sc, v, seed, geo_iter=geo, depth=cur[v][0], normal=cur[v][1], src=prev) for v in allv}
+    cur = {v: po.gap_interpolation(*po.remove_small_segments(*cur[v], nSpeckleSize=30)) for v in allv}
+    dep = np.stack([cur[v][0] for v in allv]); cnf = np.stack([cur[v][2] for v in allv])
+    for v in allv:
+        rc, fd, fc = po.filter_depth_map(dep, cnf, sc.K, sc.R, sc.C, v, list(sc.neighbors[v]), sc.dmin[v], sc.dmax[v])
+        assert rc == 0
+        f = dmap.load(paths[v])
+        _same(f["depth_map"], fd, f"final depth v{v}"); _same(f["confidence_map"], fc, f"final conf v{v}"); _same(f["normal_map"], cur[v][1], f"final normal v{v}")
+        assert f["reference_view_id"] == v and f["neighbor_view_ids"] == [int(i) for i in sc.neighbors[v]]
+        m = fd > 0
+        assert m.mean() > 0.5 and np.median(np.abs(fd[m] - sc.gt_depth[v][m]) / sc.gt_depth[v][m]) < 2e-3
+    e.close()
+
+
 def test_full_size_properties():
     """BASELINE config 2 (1 ref x 8 src, 1920x1080): the oracle needs ~15 min here, so check
     size-independent properties: run-to-run determinism (race check of the diagonal schedule),

@@ -118,6 +118,8 @@ int pmhip_scene_commit_round(pmhip_engine* e);
 int pmhip_scene_reset_view(pmhip_engine* e, int idx);
 /* Provide an initial depth/normal estimate (host pointers, nullable each). */
 int pmhip_scene_set_maps(pmhip_engine* e, int idx, const float* depth, const float* normal);
+/* Install a confidence map (host pointer), e.g. one read back from a .dmap before filtering / fusing without re-estimating. */
+int pmhip_scene_set_conf(pmhip_engine* e, int idx, const float* conf);
 /* Download maps (any pointer may be NULL). */
 int pmhip_scene_get_maps(pmhip_engine* e, int idx, float* depth, float* normal, float* conf);
 /* Device pointers for collectives (RCCL all-gather of the snapshot / broadcast of images).
@@ -138,6 +140,31 @@ int pmhip_scene_remove_small_segments(pmhip_engine* e, const int32_t* viewIds, i
 /* DepthMapsData::GapInterpolation (SceneDensify.cpp:904-1045; OPTDENSE::nIpolGapSize 7, fDepthDiffThreshold 0.01): fills row then
  * column gaps of the depth / normal / confidence maps of these views, in place on the device. */
 int pmhip_scene_gap_interpolation(pmhip_engine* e, const int32_t* viewIds, int nViews, uint32_t nIpolGapSize, float fDepthDiffThreshold);
+/* DepthMapsData::FuseDepthMaps (SceneDensify.cpp:1372-1650) over the resident depth / normal / confidence maps: every unclaimed depth
+ * seeds a 3D point, claims the agreeing pixels of the view's neighbours (depth within fDepthDiffThreshold, normals within
+ * fNormalDiffThreshold degrees), is kept if it gathered nMinViewsFuse views and then zeroes the neighbour depths it occludes.
+ * `order` lists the views to fuse, best connected first (the reference sorts by Image::neighbors.size(), :1423-1450); each view uses
+ * the neighbour list given to pmhip_scene_set_view (the IDs stored in its .dmap).  Runs on working copies: the scene's maps are not
+ * modified.  Point order, views, weights, positions, colours and normals equal the sequential reference (see csrc/pm_fuse.h).
+ * Defaults (DepthMap.cpp:75,92,93,101,102): nMinViewsFuse 2, fDepthDiffThreshold 0.01, fNormalDiffThreshold 25, colours and normals on. */
+typedef struct PMHipFuseParams {
+	uint32_t nMinViewsFuse;
+	float fDepthDiffThreshold;
+	float fNormalDiffThreshold;   /* degrees */
+	int32_t bEstimateColor;       /* needs pmhip_scene_set_color for every view */
+	int32_t bEstimateNormal;
+} PMHipFuseParams;
+/* 8-bit BGR image of view idx at depth-map resolution (Image::image, read at SceneDensify.cpp:1529,1567), host pointer, w*h*3 bytes. */
+int pmhip_scene_set_color(pmhip_engine* e, int idx, const unsigned char* bgr);
+int pmhip_scene_fuse(pmhip_engine* e, const int32_t* order, int nOrder, const PMHipFuseParams* params,
+                     uint64_t* nPoints, uint64_t* nViews, uint64_t* nDepths);
+/* Download the fused cloud (PointCloud::points / pointViews / pointWeights / colors / normals, libs/MVS/PointCloud.h): points 3*nPoints
+ * floats, viewStart nPoints+1 offsets into views / weights / projs (nViews entries; projs = x,y of the pixel each view contributed),
+ * colors 3*nPoints BGR bytes, normals 3*nPoints floats.  Any pointer may be NULL. */
+int pmhip_scene_fuse_get(pmhip_engine* e, float* points, uint32_t* viewStart, uint32_t* views, float* weights, uint16_t* projs,
+                         unsigned char* colors, float* normals);
+/* Reservation rounds the last pmhip_scene_fuse needed, summed over its views (diagnostic). */
+uint64_t pmhip_scene_fuse_rounds(pmhip_engine* e);
 /* Device-to-device copy between a caller buffer (e.g. a torch tensor used for an RCCL collective)
  * and `count` consecutive views of one per-kind array, starting at view firstIdx; `what` as above.
  * toEngine != 0 copies caller -> engine.  Asynchronous on the engine stream. */

@@ -7,6 +7,7 @@
 #include "../../include/pmhip.h"
 #include "pm_kernels.hip"
 #include "pm_filter.hip"
+#include "pm_fuse.hip"
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -85,6 +86,17 @@ struct pmhip_engine {
 	unsigned long long* d_splat = nullptr; int splatCap = 0; PMFTask* d_ftasks = nullptr; PMFTask* h_ftasks = nullptr; int ftaskCap = 0;
 	std::vector<SceneView> views;
 	bool pyramidDirty = true;
+	// FuseDepthMaps state (pm_fuse.hip); buffers live until the scene is released
+	struct Fuse {
+		float* depth = nullptr; uint32_t *claimed = nullptr, *resv = nullptr; uint8_t* bgr = nullptr; PMFuseCam* cams = nullptr;
+		uint8_t *recN = nullptr, *recColor = nullptr; float *recX = nullptr, *recWeight = nullptr, *recNormal = nullptr; uint32_t *recView = nullptr, *recProj = nullptr;
+		uint32_t* pend[2] = {nullptr, nullptr}; uint32_t* counters = nullptr; unsigned long long* nDepthsDev = nullptr;
+		uint2 *tileSums = nullptr, *tileOff = nullptr;
+		PMFuseOut out{}; size_t cap = 0;
+		uint32_t* pin = nullptr;
+		std::vector<unsigned char> hasBgr;
+		uint64_t nPoints = 0, nViews = 0, nDepths = 0, rounds = 0; bool haveColor = false, haveNormal = false;
+	} fu;
 	// batch scratch (grow only)
 	int batchCap = 0;
 	float* d_lvl[4] = {nullptr, nullptr, nullptr, nullptr}; // level l>=1: [batch][6][h_l*w_l]; level 0: prior [batch][h*w]
@@ -102,8 +114,25 @@ struct pmhip_engine {
 	int lh(int l) const { return (int)nearbyint((double)h / (double)(1 << l)); }
 };
 
+static void freeFuseOut(pmhip_engine* e) {
+	auto& f = e->fu;
+	if (f.out.points) hipFree(f.out.points); if (f.out.viewStart) hipFree(f.out.viewStart); if (f.out.views) hipFree(f.out.views);
+	if (f.out.weights) hipFree(f.out.weights); if (f.out.projs) hipFree(f.out.projs); if (f.out.colors) hipFree(f.out.colors); if (f.out.normals) hipFree(f.out.normals);
+	f.out = PMFuseOut{}; f.cap = 0;
+}
+static void freeFuse(pmhip_engine* e) {
+	auto& f = e->fu;
+	void* ptrs[] = {f.depth, f.claimed, f.resv, f.bgr, f.cams, f.recN, f.recColor, f.recX, f.recWeight, f.recNormal, f.recView, f.recProj,
+	                f.pend[0], f.pend[1], f.counters, f.nDepthsDev, f.tileSums, f.tileOff};
+	for (void* q : ptrs) if (q) hipFree(q);
+	if (f.pin) hipHostFree(f.pin);
+	freeFuseOut(e);
+	f = pmhip_engine::Fuse{};
+}
+
 static void freeScene(pmhip_engine* e) {
 	hipSetDevice(e->device);
+	freeFuse(e);
 	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_imgS[l]) hipFree(e->d_imgS[l]); e->d_imgS[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
 	if (e->d_depth) hipFree(e->d_depth); if (e->d_normal) hipFree(e->d_normal); if (e->d_conf) hipFree(e->d_conf); if (e->d_snap) hipFree(e->d_snap);
 	e->d_depth = e->d_normal = e->d_conf = e->d_snap = nullptr;
@@ -527,6 +556,15 @@ int pmhip_scene_set_maps(pmhip_engine* e, int idx, const float* depth, const flo
 	return 0;
 }
 
+int pmhip_scene_set_conf(pmhip_engine* e, int idx, const float* conf) {
+	if (!e || !conf || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	const size_t P0 = (size_t)e->w * e->h;
+	HIPCHK(e, hipMemcpyAsync(e->d_conf + P0 * idx, conf, sizeof(float) * P0, hipMemcpyHostToDevice, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
 int pmhip_scene_get_maps(pmhip_engine* e, int idx, float* depth, float* normal, float* conf) {
 	if (!e || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
 	HIPCHK(e, hipSetDevice(e->device));
@@ -842,5 +880,142 @@ int pmhip_resize(pmhip_engine* e, int kind, const float* src, int w, int h, int 
 	hipFree(ds); hipFree(dd); if (dn) hipFree(dn); if (dn2) hipFree(dn2); if (dp) hipFree(dp); if (du) hipFree(du);
 	return 0;
 }
+
+// ---- FuseDepthMaps (libs/MVS/SceneDensify.cpp:1372-1650) on the resident scene -------------------------------------------------
+static int ensureFuse(pmhip_engine* e) {
+	auto& f = e->fu;
+	if (f.depth) return 0;
+	const size_t P = (size_t)e->w * e->h, N = (size_t)e->nImages;
+	HIPCHK(e, hipMalloc(&f.depth, sizeof(float) * P * N));
+	HIPCHK(e, hipMalloc(&f.claimed, sizeof(uint32_t) * P * N));
+	HIPCHK(e, hipMalloc(&f.resv, sizeof(uint32_t) * P * N));
+	HIPCHK(e, hipMalloc(&f.cams, sizeof(PMFuseCam) * N));
+	HIPCHK(e, hipMalloc(&f.recN, P)); HIPCHK(e, hipMalloc(&f.recColor, 3 * P));
+	HIPCHK(e, hipMalloc(&f.recX, sizeof(float) * 3 * P)); HIPCHK(e, hipMalloc(&f.recNormal, sizeof(float) * 3 * P));
+	HIPCHK(e, hipMalloc(&f.recWeight, sizeof(float) * PMFU_MAXV * P));
+	HIPCHK(e, hipMalloc(&f.recView, sizeof(uint32_t) * PMFU_MAXV * P)); HIPCHK(e, hipMalloc(&f.recProj, sizeof(uint32_t) * PMFU_MAXV * P));
+	HIPCHK(e, hipMalloc(&f.pend[0], sizeof(uint32_t) * P)); HIPCHK(e, hipMalloc(&f.pend[1], sizeof(uint32_t) * P));
+	HIPCHK(e, hipMalloc(&f.counters, sizeof(uint32_t) * 8)); HIPCHK(e, hipMalloc(&f.nDepthsDev, sizeof(unsigned long long) * 2));
+	const size_t nTiles = (P + PMFU_TILE - 1) / PMFU_TILE;
+	HIPCHK(e, hipMalloc(&f.tileSums, sizeof(uint2) * nTiles)); HIPCHK(e, hipMalloc(&f.tileOff, sizeof(uint2) * nTiles));
+	HIPCHK(e, hipHostMalloc(&f.pin, sizeof(uint32_t) * 16));
+	return 0;
+}
+
+int pmhip_scene_set_color(pmhip_engine* e, int idx, const unsigned char* bgr) {
+	if (!e || !bgr || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	auto& f = e->fu;
+	const size_t P = (size_t)e->w * e->h;
+	if (!f.bgr) { HIPCHK(e, hipMalloc(&f.bgr, 3 * P * e->nImages)); f.hasBgr.assign(e->nImages, 0); }
+	HIPCHK(e, hipMemcpyAsync(f.bgr + 3 * P * idx, bgr, 3 * P, hipMemcpyHostToDevice, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	f.hasBgr[idx] = 1;
+	return 0;
+}
+
+int pmhip_scene_fuse(pmhip_engine* e, const int32_t* order, int nOrder, const PMHipFuseParams* prm, uint64_t* nPoints, uint64_t* nViews, uint64_t* nDepths) {
+	if (!e || !order || nOrder <= 0 || !prm || e->nImages < 1) return PMHIP_E_ARG;
+	if (e->w > 65535 || e->h > 65535) { e->err = "fusion stores projections as 16-bit pixel coordinates"; return PMHIP_E_SIZE; }
+	HIPCHK(e, hipSetDevice(e->device));
+	int rc = ensureFuse(e); if (rc) return rc;
+	auto& f = e->fu;
+	const size_t P = (size_t)e->w * e->h, N = (size_t)e->nImages;
+	bool wantColor = prm->bEstimateColor != 0;
+	if (wantColor) for (int i = 0; i < e->nImages; ++i) if (e->views[i].set && (!f.bgr || !f.hasBgr[i])) { e->err = "bEstimateColor needs pmhip_scene_set_color for every view"; return PMHIP_E_STATE; }
+	const bool wantNormal = prm->bEstimateNormal != 0;
+	// cameras (P composed like Camera::ComposeP)
+	std::vector<PMFuseCam> hc(N);
+	for (size_t i = 0; i < N; ++i) { memset(&hc[i], 0, sizeof(PMFuseCam)); if (!e->views[i].set) continue; memcpy(hc[i].K, e->views[i].K, 72); memcpy(hc[i].R, e->views[i].R, 72); memcpy(hc[i].C, e->views[i].C, 24); pmfu_composeP(hc[i]); }
+	HIPCHK(e, hipMemcpyAsync(f.cams, hc.data(), sizeof(PMFuseCam) * N, hipMemcpyHostToDevice, e->stream));
+	HIPCHK(e, hipMemcpyAsync(f.depth, e->d_depth, sizeof(float) * P * N, hipMemcpyDeviceToDevice, e->stream));
+	hipLaunchKernelGGL(pmfu_fill_u32, dim3(2048), dim3(256), 0, e->stream, f.claimed, P * N, PMFU_NO_ID);
+	hipLaunchKernelGGL(pmfu_fill_u32, dim3(2048), dim3(256), 0, e->stream, f.resv, P * N, PMFU_FREE);
+	HIPCHK(e, hipMemsetAsync(f.counters, 0, sizeof(uint32_t) * 8, e->stream));
+	HIPCHK(e, hipMemsetAsync(f.nDepthsDev, 0, sizeof(unsigned long long) * 2, e->stream));
+	// output capacity: a point needs a seed and every pixel joins at most one point, so both are bounded by the valid depths
+	hipLaunchKernelGGL(pmfu_count_valid, dim3(2048), dim3(256), 0, e->stream, f.depth, P * N, f.nDepthsDev + 1);
+	unsigned long long nValid = 0;
+	HIPCHK(e, hipMemcpyAsync(&nValid, f.nDepthsDev + 1, sizeof(nValid), hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	if (nValid >= 0xFFFFFFFFull) { e->err = "more than 2^32 depths"; return PMHIP_E_SIZE; }
+	if (f.cap < (size_t)nValid + 1 || (wantColor && !f.out.colors) || (wantNormal && !f.out.normals)) {
+		freeFuseOut(e);
+		const size_t cap = (size_t)nValid + 1;
+		HIPCHK(e, hipMalloc(&f.out.points, sizeof(float) * 3 * cap)); HIPCHK(e, hipMalloc(&f.out.viewStart, sizeof(uint32_t) * (cap + 1)));
+		HIPCHK(e, hipMalloc(&f.out.views, sizeof(uint32_t) * cap)); HIPCHK(e, hipMalloc(&f.out.weights, sizeof(float) * cap));
+		HIPCHK(e, hipMalloc(&f.out.projs, sizeof(uint16_t) * 2 * cap));
+		if (wantColor) HIPCHK(e, hipMalloc(&f.out.colors, 3 * cap));
+		if (wantNormal) HIPCHK(e, hipMalloc(&f.out.normals, sizeof(float) * 3 * cap));
+		f.cap = cap;
+	}
+	PMFuseOut out = f.out;
+	if (!wantColor) out.colors = nullptr;
+	if (!wantNormal) out.normals = nullptr;
+	const unsigned nMin = std::min<unsigned>(prm->nMinViewsFuse, (unsigned)e->nImages);
+	const float normalError = cosf(prm->fNormalDiffThreshold * (3.14159265358979323846f / 180.f));   // COS(FD2R(x)), SceneDensify.cpp:1455
+	f.rounds = 0;
+	const unsigned nTiles = (unsigned)((P + PMFU_TILE - 1) / PMFU_TILE);
+	for (int o = 0; o < nOrder; ++o) {
+		const int A = order[o];
+		if (A < 0 || A >= e->nImages || !e->views[A].set) { e->err = "fuse: view not set"; return PMHIP_E_ARG; }
+		PMFuseCtx c; memset(&c, 0, sizeof(c));
+		c.w = e->w; c.h = e->h; c.nImages = e->nImages; c.A = A;
+		for (int k = 0; k < e->views[A].nNb && c.nNb < PMFU_MAXNB; ++k) { const int b = e->views[A].nb[k]; if (b >= 0 && b < e->nImages && b != A && e->views[b].set) c.nb[c.nNb++] = b; }
+		c.depth = f.depth; c.normal = e->d_normal; c.conf = e->d_conf; c.bgr = f.bgr; c.claimed = f.claimed; c.resv = f.resv; c.cams = f.cams;
+		c.nMinViewsFuse = nMin; c.fDepthDiffThreshold = prm->fDepthDiffThreshold; c.normalError = normalError;
+		c.bEstimateColor = wantColor ? 1 : 0; c.bEstimateNormal = wantNormal ? 1 : 0;
+		c.recN = f.recN; c.recX = f.recX; c.recView = f.recView; c.recWeight = f.recWeight; c.recProj = f.recProj; c.recColor = f.recColor; c.recNormal = f.recNormal;
+		HIPCHK(e, hipMemsetAsync(f.counters, 0, sizeof(uint32_t) * 2, e->stream));
+		hipLaunchKernelGGL(pmfu_seed_kernel, dim3((unsigned)std::min<size_t>((P + 255) / 256, 4096)), dim3(256), 0, e->stream, c, f.pend[0], f.counters, f.nDepthsDev);
+		HIPCHK(e, hipMemcpyAsync(f.pin, f.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+		HIPCHK(e, hipStreamSynchronize(e->stream));
+		uint32_t n = f.pin[0]; int cur = 0;
+		while (n) {
+			++f.rounds;
+			HIPCHK(e, hipMemsetAsync(f.counters + 1, 0, sizeof(uint32_t), e->stream));
+			const unsigned gb = (n + 255) / 256;
+			hipLaunchKernelGGL(pmfu_reserve_kernel, dim3(gb), dim3(256), 0, e->stream, c, f.pend[cur], n);
+			hipLaunchKernelGGL(pmfu_commit_kernel, dim3(gb), dim3(256), 0, e->stream, c, f.pend[cur], n, f.pend[cur ^ 1], f.counters + 1);
+			HIPCHK(e, hipMemcpyAsync(f.pin, f.counters + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+			HIPCHK(e, hipStreamSynchronize(e->stream));
+			if (f.pin[0] >= n) { e->err = "fuse: no progress in a reservation round"; return PMHIP_E_STATE; }
+			n = f.pin[0]; cur ^= 1;
+		}
+		hipLaunchKernelGGL(pmfu_tile_sums, dim3(nTiles), dim3(PMFU_TB), 0, e->stream, f.recN, (uint32_t)P, f.tileSums);
+		hipLaunchKernelGGL(pmfu_scan_tiles, dim3(1), dim3(1024), 0, e->stream, f.tileSums, nTiles, f.counters + 2, f.tileOff);
+		hipLaunchKernelGGL(pmfu_scatter_kernel, dim3(nTiles), dim3(PMFU_TB), 0, e->stream, c, f.tileOff, out);
+		HIPCHK(e, hipGetLastError());
+	}
+	unsigned long long nd = 0;
+	HIPCHK(e, hipMemcpyAsync(f.pin, f.counters + 2, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(e, hipMemcpyAsync(&nd, f.nDepthsDev, sizeof(nd), hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	f.nPoints = f.pin[0]; f.nViews = f.pin[1]; f.nDepths = nd; f.haveColor = wantColor; f.haveNormal = wantNormal;
+	const uint32_t last = (uint32_t)f.nViews;
+	HIPCHK(e, hipMemcpyAsync(f.out.viewStart + f.nPoints, &last, sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	if (nPoints) *nPoints = f.nPoints; if (nViews) *nViews = f.nViews; if (nDepths) *nDepths = f.nDepths;
+	return 0;
+}
+
+int pmhip_scene_fuse_get(pmhip_engine* e, float* points, uint32_t* viewStart, uint32_t* views, float* weights, uint16_t* projs, unsigned char* colors, float* normals) {
+	if (!e || !e->fu.out.points) return PMHIP_E_STATE;
+	HIPCHK(e, hipSetDevice(e->device));
+	auto& f = e->fu;
+	if ((colors && !f.haveColor) || (normals && !f.haveNormal)) { e->err = "fuse_get: colours / normals were not estimated"; return PMHIP_E_STATE; }
+	const size_t n = (size_t)f.nPoints, v = (size_t)f.nViews;
+	if (points && n) HIPCHK(e, hipMemcpyAsync(points, f.out.points, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, e->stream));
+	if (viewStart) HIPCHK(e, hipMemcpyAsync(viewStart, f.out.viewStart, sizeof(uint32_t) * (n + 1), hipMemcpyDeviceToHost, e->stream));
+	if (views && v) HIPCHK(e, hipMemcpyAsync(views, f.out.views, sizeof(uint32_t) * v, hipMemcpyDeviceToHost, e->stream));
+	if (weights && v) HIPCHK(e, hipMemcpyAsync(weights, f.out.weights, sizeof(float) * v, hipMemcpyDeviceToHost, e->stream));
+	if (projs && v) HIPCHK(e, hipMemcpyAsync(projs, f.out.projs, sizeof(uint16_t) * 2 * v, hipMemcpyDeviceToHost, e->stream));
+	if (colors && n) HIPCHK(e, hipMemcpyAsync(colors, f.out.colors, 3 * n, hipMemcpyDeviceToHost, e->stream));
+	if (normals && n) HIPCHK(e, hipMemcpyAsync(normals, f.out.normals, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+uint64_t pmhip_scene_fuse_rounds(pmhip_engine* e) { return e ? e->fu.rounds : 0; }
 
 } // extern "C"

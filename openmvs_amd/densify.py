@@ -13,8 +13,10 @@ REMOVE_SPECKLES, FILL_GAPS, ADJUST_FILTER = 1, 2, 4   # OPTDENSE::DepthFlags, li
 
 def compute_depth_maps(engine, view_ids, params, n_optimize: int = 7, b_filter_adjust: bool = True,
                        n_speckle_size: int = 100, n_ipol_gap_size: int = 7, f_depth_diff_threshold: float = 0.01,
-                       n_min_views_filter: int = 2, n_min_views_filter_adjust: int = 1):
-    """Runs the reference's dense schedule for `view_ids` on a loaded scene (engine.scene_load / scene_set_view)."""
+                       n_min_views_filter: int = 2, n_min_views_filter_adjust: int = 1, init_depth=None, init_normal=None):
+    """Runs the reference's dense schedule for `view_ids` on a loaded scene (engine.scene_load / scene_set_view).
+    `init_depth` / `init_normal` (dicts view id -> map) seed the photometric pass like `InitViews(..., loadDepthMaps=0)` does
+    (SceneDensify.cpp:418-460); views without an entry start from random planes."""
     ids = list(view_ids)
     G = int(params.nEstimationGeometricIters)
 
@@ -27,6 +29,8 @@ def compute_depth_maps(engine, view_ids, params, n_optimize: int = 7, b_filter_a
     engine.Init(False)
     for v in ids:
         engine.scene_reset_view(v)
+        if init_depth is not None and v in init_depth:
+            engine.scene_set_maps(v, init_depth[v], None if init_normal is None else init_normal.get(v))
     engine.scene_estimate(ids, -1, params)
     if G == 0:
         post()
@@ -52,3 +56,79 @@ def save_depth_maps(engine, scene, view_ids, out_dir: str, image_names=None):
         _dmap.save(p, name, ids, (scene.width, scene.height), scene.K[v], scene.R[v], scene.C[v], float(scene.dmin[v]), float(scene.dmax[v]), d, n, c)
         paths.append(p)
     return paths
+
+
+# ---- scene front end: *.mvs + images -> engine scene -----------------------------------------------------------------------------
+
+class SceneViews:
+    """What `Scene::ComputeDepthMaps` has in hand after its preparation steps (libs/MVS/SceneDensify.cpp:1772-1870) for a scene whose
+    images share one resolution: gray images, pixel cameras, neighbour lists, depth ranges and the sparse initial maps.  Same
+    attribute names as `synth.Scene`, so `PatchMatchHIP.scene_load` takes either."""
+
+    def __init__(self):
+        self.width = self.height = 0
+        self.gray = []; self.K = []; self.R = []; self.C = []
+        self.dmin = []; self.dmax = []; self.neighbors = []; self.view_scores = []
+        self.init_depth = {}; self.init_normal = {}
+        self.names = []; self.ids = []          # ids: images that passed view selection, in scene order
+
+    @property
+    def n_views(self):
+        return len(self.gray)
+
+
+def _resize_area_u8(img, w: int, h: int):
+    """cv::resize(..., INTER_AREA) of an 8-bit image for an exact integer shrink factor (the only case implemented): the box mean,
+    rounded to nearest-even like OpenCV's `saturate_cast<uchar>(float)`."""
+    import numpy as np
+    H, W = img.shape[:2]
+    if W % w or H % h or W // w != H // h:
+        raise NotImplementedError("image resize %dx%d -> %dx%d: only exact integer INTER_AREA factors are implemented" % (W, H, w, h))
+    f = W // w
+    s = img.reshape(h, f, w, f, -1).astype(np.float32).sum(axis=(1, 3))
+    return np.rint(s * np.float32(1.0 / (f * f))).astype(np.uint8)
+
+
+def load_scene(mvs_path: str, opt=None, image_loader=None):
+    """Reads an MVSI scene and its images and runs view selection + depth initialisation for every valid image.
+
+    `image_loader(path) -> (h,w,3) uint8 RGB` defaults to PIL.  Returns a `SceneViews`."""
+    import numpy as np
+    from . import mvsi, views
+    opt = opt or views.DenseOptions()
+    sc = mvsi.load(mvs_path)
+    base = os.path.dirname(os.path.abspath(mvs_path))
+    if image_loader is None:
+        def image_loader(p):
+            from PIL import Image
+            with Image.open(p) as im:
+                return np.asarray(im.convert("RGB"))
+    sv = SceneViews()
+    rgbs, sizes = [], []
+    for im in sc.images:
+        p = im.name if os.path.isabs(im.name) else os.path.join(base, im.name)
+        rgb = image_loader(p)
+        H, W = rgb.shape[:2]
+        res, _ = views.compute_max_resolution(W, H, opt.nResolutionLevel, opt.nMinResolution, opt.nMaxResolution)
+        w, h = views.resized_size(W, H, res)
+        if (w, h) != (W, H):
+            rgb = _resize_area_u8(rgb, w, h)
+        rgbs.append(rgb); sizes.append((w, h))
+    if len(set(sizes)) != 1:
+        raise NotImplementedError("the batch scene interface needs one image resolution; got %s" % sorted(set(sizes)))
+    sv.width, sv.height = sizes[0]
+    cams = views.Cameras(sc, sizes)
+    for i, im in enumerate(sc.images):
+        sv.gray.append(views.to_gray(rgbs[i])); sv.names.append(im.name)
+        sv.K.append(cams.K[i]); sv.R.append(cams.R[i]); sv.C.append(cams.C[i])
+        sel = views.select_views(sc, cams, i, opt) if im.is_valid() else None
+        if sel is None:
+            sv.neighbors.append(np.zeros(0, np.int32)); sv.view_scores.append(None); sv.dmin.append(0.1); sv.dmax.append(100.0)
+            continue
+        nb, points, _ = sel
+        if np.any(np.abs(nb["scale"] - 1) >= 0.15):          # DepthData::ViewData::NeedScaleImage, libs/MVS/DepthMap.h:194-197
+            raise NotImplementedError("image %d: a neighbour needs rescaling (scale %s)" % (i, nb["scale"]))
+        d, n, dmin, dmax = views.init_depth_map(sc, cams, i, points, opt)
+        sv.ids.append(i); sv.neighbors.append(nb["ID"].astype(np.int32)); sv.view_scores.append(nb)
+        sv.dmin.append(dmin); sv.dmax.append(dmax); sv.init_depth[i] = d; sv.init_normal[i] = n
+    return sv

@@ -46,7 +46,12 @@ class PMHipKernelStats(C.Structure):
                 ("sweepPixels", C.c_uint64), ("initLaunches", C.c_uint64), ("initMs", C.c_double), ("sweepWallMs", C.c_double)]
 
 
-EXPORTS = ["pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
+class PMHipFuseParams(C.Structure):
+    _fields_ = [("nMinViewsFuse", C.c_uint32), ("fDepthDiffThreshold", C.c_float), ("fNormalDiffThreshold", C.c_float),
+                ("bEstimateColor", C.c_int32), ("bEstimateNormal", C.c_int32)]
+
+
+EXPORTS = ["pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
            "pmhip_estimate_depth_map", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
            "pmhip_scene_estimate", "pmhip_scene_commit_round", "pmhip_scene_reset_view", "pmhip_scene_set_maps",
            "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_remove_small_segments", "pmhip_scene_images_updated", "pmhip_sync",
@@ -67,6 +72,7 @@ def load_library() -> C.CDLL:
         lib.pmhip_scene_device_ptr.restype = C.c_void_p
         lib.pmhip_stream.restype = C.c_void_p
         lib.pmhip_destroy.restype = None
+        lib.pmhip_scene_fuse_rounds.restype = C.c_uint64
         for n in EXPORTS:
             getattr(lib, n)  # raises AttributeError if a declared symbol is missing
         _LIB = lib
@@ -178,6 +184,10 @@ class PatchMatchHIP:
         n = None if normal is None else np.ascontiguousarray(normal, np.float32)
         self._chk(self._lib.pmhip_scene_set_maps(self._h, idx, _fp(d) if d is not None else None, _fp(n) if n is not None else None))
 
+    def scene_set_conf(self, idx, conf):
+        c = np.ascontiguousarray(conf, np.float32)
+        self._chk(self._lib.pmhip_scene_set_conf(self._h, idx, _fp(c)))
+
     def scene_get_maps(self, idx):
         _, w, h = self._scene
         d = np.zeros((h, w), np.float32); n = np.zeros((h, w, 3), np.float32); c = np.zeros((h, w), np.float32)
@@ -202,6 +212,32 @@ class PatchMatchHIP:
     def scene_gap_interpolation(self, view_ids, nIpolGapSize=7, fDepthDiffThreshold=0.01):
         ids = np.ascontiguousarray(view_ids, np.int32)
         self._chk(self._lib.pmhip_scene_gap_interpolation(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), len(ids), C.c_uint32(nIpolGapSize), C.c_float(fDepthDiffThreshold)))
+
+    def scene_set_color(self, idx, bgr):
+        """8-bit BGR image of a view at depth-map resolution (only fusion with bEstimateColor reads it)."""
+        b = np.ascontiguousarray(bgr, np.uint8)
+        _, w, h = self._scene
+        if b.shape != (h, w, 3):
+            raise ValueError("bgr must be (h, w, 3) uint8")
+        self._chk(self._lib.pmhip_scene_set_color(self._h, idx, b.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def scene_fuse(self, order, nMinViewsFuse=2, fDepthDiffThreshold=0.01, fNormalDiffThreshold=25.0, bEstimateColor=True, bEstimateNormal=True):
+        """DepthMapsData::FuseDepthMaps over the resident maps (libs/MVS/SceneDensify.cpp:1372-1650); `order` = views, best connected
+        first.  Returns a dict with the fields of MVS::PointCloud: points, viewStart/views/weights (CSR), projs, colors (BGR), normals."""
+        od = np.ascontiguousarray(order, np.int32)
+        prm = PMHipFuseParams(nMinViewsFuse, fDepthDiffThreshold, fNormalDiffThreshold, 1 if bEstimateColor else 0, 1 if bEstimateNormal else 0)
+        nP, nV, nD = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self._lib.pmhip_scene_fuse(self._h, od.ctypes.data_as(C.POINTER(C.c_int32)), len(od), C.byref(prm), C.byref(nP), C.byref(nV), C.byref(nD)))
+        P, V = int(nP.value), int(nV.value)
+        pts = np.zeros((P, 3), np.float32); vs = np.zeros(P + 1, np.uint32); views = np.zeros(V, np.uint32); wts = np.zeros(V, np.float32)
+        projs = np.zeros((V, 2), np.uint16)
+        cols = np.zeros((P, 3), np.uint8) if bEstimateColor else None
+        nrm = np.zeros((P, 3), np.float32) if bEstimateNormal else None
+        vp = lambda a, t: None if a is None else a.ctypes.data_as(C.POINTER(t))
+        self._chk(self._lib.pmhip_scene_fuse_get(self._h, vp(pts, C.c_float), vp(vs, C.c_uint32), vp(views, C.c_uint32), vp(wts, C.c_float),
+                                                 vp(projs, C.c_uint16), vp(cols, C.c_uint8), vp(nrm, C.c_float)))
+        return dict(nPoints=P, nDepths=int(nD.value), points=pts, viewStart=vs, views=views, weights=wts, projs=projs, colors=cols, normals=nrm,
+                    rounds=int(self._lib.pmhip_scene_fuse_rounds(self._h)))
 
     def scene_copy(self, what, first, count, device_ptr, to_engine):
         self._chk(self._lib.pmhip_scene_copy(self._h, what, first, count, C.c_void_p(device_ptr), 1 if to_engine else 0))

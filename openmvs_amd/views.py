@@ -1,0 +1,290 @@
+"""Host-side callers in front of the depth-map estimator: neighbour-view selection and depth-map initialisation.
+
+These are the steps `Scene::ComputeDepthMaps` runs between loading the scene and the first `EstimateDepthMap` call
+(reference `libs/MVS/SceneDensify.cpp:1754-1870`): per image it scores every other image by the sparse points they share
+(`Scene::SelectNeighborViews`, `libs/MVS/Scene.cpp:801-934`), drops the bad ones (`Scene::FilterNeighborViews`, `:953-968`),
+cuts the list at a score ratio (`DepthMapsData::InitViews`, `SceneDensify.cpp:333-340`) and seeds the reference depth map from the
+sparse points (`:418-460`, `TriangulatePoints2DepthMap`, `libs/MVS/DepthMap.cpp:1117-1192`).
+
+They operate on a few thousand sparse points per image and stay on the host, as in the reference; numpy in float32/float64 follows
+the reference's mixed precision term by term (the order of the float sums included) so that the ranking it produces is the
+reference's.  Parity status: unpinned — the reference ships no golden neighbour lists (its `scene.mvs` test fixture is archive
+version 6, which predates stored view scores), so tests check invariants and the end-to-end acceptance of
+`apps/Tests/Tests.cpp:78-105` instead.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import mvsi
+
+VIEW_SCORE_DTYPE = mvsi.VIEW_SCORE_DTYPE
+f32 = np.float32
+
+
+@dataclass
+class DenseOptions:
+    """The `OPTDENSE` values read by view selection and initialisation (defaults: `libs/MVS/DepthMap.cpp:69-90`)."""
+    nResolutionLevel: int = 1
+    nMaxResolution: int = 3200
+    nMinResolution: int = 640
+    nMinViews: int = 2
+    nMaxViews: int = 12
+    nMinViewsTrustPoint: int = 2
+    nNumViews: int = 0
+    nPointInsideROI: int = 1
+    bAddCorners: bool = False
+    bInitSparse: bool = True
+    fViewMinScore: float = 2.0
+    fViewMinScoreRatio: float = 0.03
+    fMinArea: float = 0.05
+    fMinAngle: float = 3.0
+    fOptimAngle: float = 12.0
+    fMaxAngle: float = 65.0
+
+
+def compute_max_resolution(width: int, height: int, level: int, min_size: int, max_size: int):
+    """`TImage::computeMaxResolution` (libs/Common/Types.inl:2459-2477) -> (max resolution, effective level)."""
+    size0 = max(width, height)
+    if level == 0:
+        return min(size0, max_size), 0
+    size = size0 >> level
+    if size < min_size:
+        level = 0
+        while (size0 >> (level + 1)) >= min_size:
+            level += 1
+        size = size0 >> level
+    return min(size, max_size), level
+
+
+def resized_size(width: int, height: int, max_resolution: int):
+    """`Image::ResizeImage` size rule (libs/MVS/Image.cpp:139-150; `computeResize`, Types.inl:2440-2445)."""
+    if max_resolution == 0 or max(width, height) <= max_resolution:
+        return width, height
+    scale = max_resolution / width if width > height else max_resolution / height
+    return int(np.rint(width * scale)), int(np.rint(height * scale))
+
+
+def to_gray(rgb: np.ndarray) -> np.ndarray:
+    """`TImage::toGray(out, COLOR_BGR2GRAY, bNormalize=true)` (libs/Common/Types.inl:2377-2425) for an (h,w,3) uint8 RGB array:
+    float32 0.114*B + 0.587*G + 0.299*R of the channels divided by 255, summed in that (B, G, R) order."""
+    c = rgb.astype(f32) / f32(255)
+    return (f32(0.114) * c[..., 2] + f32(0.587) * c[..., 1]) + f32(0.299) * c[..., 0]
+
+
+class Cameras:
+    """Pixel cameras of every valid image of a scene at the working resolution (K, R, C, P in float64 like `MVS::Camera`)."""
+
+    def __init__(self, scene: mvsi.Scene, sizes=None):
+        n = len(scene.images)
+        self.valid = np.array([im.is_valid() for im in scene.images])
+        self.K = np.zeros((n, 3, 3)); self.R = np.zeros((n, 3, 3)); self.C = np.zeros((n, 3)); self.P = np.zeros((n, 3, 4))
+        self.size = np.zeros((n, 2), np.int64)
+        for i in range(n):
+            if not self.valid[i]:
+                continue
+            K, R, C, w, h = scene.camera(i, None if sizes is None else sizes[i])
+            self.K[i], self.R[i], self.C[i], self.size[i] = K, R, C, (w, h)
+            self.P[i, :, :3] = K @ R                    # Camera::ComposeP (libs/MVS/Camera.h)
+            self.P[i, :, 3] = -(K @ R) @ C
+
+    def point_depth(self, i: int, X: np.ndarray) -> np.ndarray:
+        """`Camera::PointDepth` (libs/Common/Util.inl:462-464): R[2].(X-C) in double."""
+        return (np.asarray(X, np.float64) - self.C[i]) @ self.R[i, 2]
+
+    def project_p(self, i: int, X: np.ndarray) -> np.ndarray:
+        """`Camera::ProjectPointP<float>` (libs/MVS/Camera.h:308-320): rows of P in double, each cast to float, then x*(1/z)."""
+        q = (np.asarray(X, np.float64) @ self.P[i, :, :3].T + self.P[i, :, 3]).astype(f32)
+        inv = f32(1) / q[:, 2]
+        return np.stack([q[:, 0] * inv, q[:, 1] * inv], 1)
+
+
+def _seq_sum_f32(x: np.ndarray) -> np.float32:
+    """Left-to-right float32 sum (the reference accumulates in a scalar loop; numpy's `sum` is pairwise)."""
+    return np.add.accumulate(x.astype(f32), dtype=f32)[-1] if len(x) else f32(0)
+
+
+def select_neighbor_views(scene: mvsi.Scene, cams: Cameras, ID: int, nMinViews=2, nMinPointViews=2,
+                          fOptimAngle=np.deg2rad(12.0), nInsideROI=1):
+    """`Scene::SelectNeighborViews(ID, points, ...)` (libs/MVS/Scene.cpp:801-934).
+
+    Returns (ok, neighbors, points, avgDepth): `neighbors` a VIEW_SCORE_DTYPE array sorted by decreasing score, `points` the indices of
+    the sparse points seen by `ID` in at least `nMinPointViews` views, `avgDepth` the mean depth of all points seen by `ID`."""
+    nImages = len(scene.images)
+    nCalibrated = int(cams.valid.sum())
+    nMinPointViews = min(nMinPointViews, nCalibrated)
+    fOptimAngle = f32(fOptimAngle)
+    sigmaSmall = f32(-1) / (f32(2) * (fOptimAngle * f32(0.38)) ** 2)
+    sigmaLarge = f32(-1) / (f32(2) * (fOptimAngle * f32(0.7)) ** 2)
+    start, views = scene.vertex_view_start, scene.vertex_views["image_id"]
+    nviews = np.diff(start)
+    owner = np.repeat(np.arange(len(scene.vertices)), nviews)            # vertex of every (vertex, view) record
+    seen = np.zeros(len(scene.vertices), bool)
+    seen[owner[views == ID]] = True
+    X = scene.vertices
+    wROI = np.ones(len(X), f32)
+    if nInsideROI > 0 and scene.is_bounded():
+        inside = scene.roi_contains(X)
+        if nInsideROI > 1:
+            seen &= inside
+        wROI[~inside] = f32(0.7)
+    depth = cams.point_depth(ID, X).astype(f32)
+    seen &= depth > 0
+    idxSeen = np.nonzero(seen)[0]
+    points = idxSeen[nviews[idxSeen] >= nMinPointViews].astype(np.uint32)
+    nPoints = len(idxSeen)
+    avgDepth = _seq_sum_f32(depth[idxSeen])
+    if nPoints > 3:
+        avgDepth = avgDepth / f32(nPoints)
+    # score shared views: one record per (seen vertex, other view), in the reference's vertex-major order
+    rec = np.nonzero(seen[owner] & (views != ID))[0]
+    pv, vw = owner[rec], views[rec].astype(np.int64)
+    Xd = X[pv].astype(np.float64)
+    V1 = (cams.C[ID] - Xd).astype(f32)
+    V2 = (cams.C[vw] - Xd).astype(f32)
+    dot = (V1[:, 0] * V2[:, 0] + V1[:, 1] * V2[:, 1]) + V1[:, 2] * V2[:, 2]
+    n1 = (V1[:, 0] * V1[:, 0] + V1[:, 1] * V1[:, 1]) + V1[:, 2] * V1[:, 2]
+    n2 = (V2[:, 0] * V2[:, 0] + V2[:, 1] * V2[:, 1]) + V2[:, 2] * V2[:, 2]
+    fAngle = np.arccos(np.clip(dot / np.sqrt(n1 * n2), f32(-1), f32(1))).astype(f32)
+    dA = fAngle - fOptimAngle
+    wAngle = np.exp((dA * dA) * np.where(fAngle < fOptimAngle, sigmaSmall, sigmaLarge)).astype(f32)
+    foot1 = (cams.K[ID, 0, 0] / cams.point_depth(ID, Xd)).astype(f32)
+    foot2 = (cams.K[vw, 0, 0] / np.einsum("ij,ij->i", Xd - cams.C[vw], cams.R[vw, 2])).astype(f32)
+    ratio = foot1 / foot2
+    wScale = np.where(ratio > f32(1.6), (f32(1.6) / ratio) ** 2, np.where(ratio >= f32(1), f32(1), ratio * ratio)).astype(f32)
+    contrib = (np.maximum(wAngle, f32(0.1)) * wScale) * wROI[pv]
+    score = np.zeros(nImages, f32); sumScale = np.zeros(nImages, f32); sumAngle = np.zeros(nImages, f32)
+    count = np.zeros(nImages, np.uint32)
+    np.add.at(score, vw, contrib)                    # ufunc.at applies the records one after the other, like the reference loop
+    np.add.at(sumScale, vw, ratio)
+    np.add.at(sumAngle, vw, fAngle)
+    np.add.at(count, vw, 1)
+    # covered area of the shared projections, per candidate
+    out = []
+    boundsA = cams.size[ID].astype(f32)
+    inPoints = np.zeros(len(X), bool)
+    inPoints[points] = True
+    projA = cams.project_p(ID, X[points])
+    insideA = (projA[:, 0] >= 0) & (projA[:, 1] >= 0) & (projA[:, 0] < boundsA[0]) & (projA[:, 1] < boundsA[1])
+    pos = np.full(len(X), -1, np.int64)
+    pos[points] = np.arange(len(points))
+    for IDB in range(nImages):
+        if not cams.valid[IDB] or count[IDB] < 3 or IDB == ID:
+            continue
+        shared = owner[(views == IDB) & inPoints[owner]]
+        if len(shared) == 0:
+            continue
+        k = pos[shared]
+        projB = cams.project_p(IDB, X[shared])
+        bB = cams.size[IDB].astype(f32)
+        ok = insideA[k] & (projB[:, 0] >= 0) & (projB[:, 1] >= 0) & (projB[:, 0] < bB[0]) & (projB[:, 1] < bB[1])
+        if not ok.any():
+            continue
+        area = covered_area(projA[k][ok], boundsA)
+        out.append((IDB, count[IDB], sumScale[IDB] / f32(count[IDB]), sumAngle[IDB] / f32(count[IDB]), area,
+                    score[IDB] * max(area, f32(0.01))))
+    neighbors = np.array(out, VIEW_SCORE_DTYPE) if out else np.zeros(0, VIEW_SCORE_DTYPE)
+    neighbors = neighbors[np.argsort(-neighbors["score"], kind="stable")]
+    ok = len(points) > 3 and len(neighbors) >= min(nMinViews, nCalibrated - 1)
+    return ok, neighbors, points, float(avgDepth)
+
+
+def covered_area(projs: np.ndarray, bounds: np.ndarray, s: int = 16) -> np.float32:
+    """`ComputeCoveredArea<float,2,16,false>` (libs/Common/Util.inl:846-866): fraction of the s x s grid cells hit."""
+    cell = np.floor((projs / bounds) * f32(s)).astype(np.int64)
+    return f32(len(np.unique(cell[:, 0] * s + cell[:, 1]))) / f32(s * s)
+
+
+def filter_neighbor_views(neighbors: np.ndarray, fMinArea=0.05, fMinScale=0.2, fMaxScale=3.2,
+                          fMinAngle=np.deg2rad(3.0), fMaxAngle=np.deg2rad(65.0), nMaxViews=12) -> np.ndarray:
+    """`Scene::FilterNeighborViews` (libs/MVS/Scene.cpp:953-968): scan from the worst neighbour up, dropping invalid ones while more
+    than max(4, 3/4 nMaxViews) remain, then keep the best nMaxViews."""
+    keep = list(range(len(neighbors)))
+    nMin = max(4, nMaxViews * 3 // 4)
+    for n in range(len(neighbors) - 1, -1, -1):
+        nb = neighbors[n]
+        bad = (nb["area"] < f32(fMinArea) or not (f32(fMinScale) <= nb["scale"] <= f32(fMaxScale))
+               or not (f32(fMinAngle) <= nb["angle"] <= f32(fMaxAngle)))
+        if len(keep) > nMin and bad:
+            keep.remove(n)
+    return neighbors[keep][:nMaxViews]
+
+
+def select_views(scene: mvsi.Scene, cams: Cameras, ID: int, opt: DenseOptions = DenseOptions()):
+    """`DepthMapsData::SelectViews(DepthData&)` (libs/MVS/SceneDensify.cpp:273-293) followed by the score cut of `InitViews`
+    (`:333-340`).  Returns (neighbors, points, avgDepth) or None when the image cannot be densified."""
+    ok, nb, points, avg = select_neighbor_views(scene, cams, ID, opt.nMinViews,
+                                                opt.nMinViewsTrustPoint if opt.nMinViewsTrustPoint > 1 else 2,
+                                                np.deg2rad(opt.fOptimAngle), opt.nPointInsideROI)
+    if not ok:
+        return None
+    nb = filter_neighbor_views(nb, opt.fMinArea, 0.2, 3.2, np.deg2rad(opt.fMinAngle), np.deg2rad(opt.fMaxAngle), opt.nMaxViews)
+    if len(nb) == 0:
+        return None
+    fMinScore = max(nb[0]["score"] * f32(opt.fViewMinScoreRatio), f32(opt.fViewMinScore))
+    cut = len(nb)
+    for i in range(len(nb)):
+        if (opt.nNumViews and i + 1 > opt.nNumViews) or nb[i]["score"] < fMinScore:
+            cut = i
+            break
+    nb = nb[:cut]
+    if len(nb) == 0:
+        return None
+    return nb, points, avg
+
+
+def init_depth_map(scene: mvsi.Scene, cams: Cameras, ID: int, points: np.ndarray, opt: DenseOptions = DenseOptions()):
+    """The `loadDepthMaps == 0` branch of `DepthMapsData::InitViews` (libs/MVS/SceneDensify.cpp:418-460).
+
+    Returns (depthMap, normalMap, dMin, dMax).  Three cases, as in the reference:
+      * no points: empty maps, range [0.1, 100];
+      * `nMinViewsTrustPoint < 2`: each point's depth splatted on a 5x5 block with a zero normal (`:428-452`);
+      * otherwise `TriangulatePoints2DepthMap` with `bInitSparse` (DepthMap.cpp:1117-1157): each point written to the 2x2 block around
+        its projection with the area-weighted vertex normal of the Delaunay mesh of the projections (`Mesh::ComputeNormalVertices`,
+        libs/MVS/Mesh.cpp:356-371).  The reference triangulates with CGAL; scipy's Qhull Delaunay gives the same triangulation except
+        for co-circular point sets, so normals may differ at such vertices (the estimator treats them as initial guesses only).
+    The dense interpolation mode (`bInitSparse=0`, rasterising the triangles) and `bAddCorners` are not implemented."""
+    w, h = (int(v) for v in cams.size[ID])
+    depthMap = np.zeros((h, w), f32)
+    normalMap = np.zeros((h, w, 3), f32)
+    if len(points) == 0:
+        return depthMap, normalMap, 1e-1, 1e+2
+    K = cams.K[ID]
+    X = scene.vertices[points]
+    if opt.nMinViewsTrustPoint < 2:
+        camX = (X.astype(np.float64) - cams.C[ID]) @ cams.R[ID].T
+        px = np.floor(K[0, 0] * camX[:, 0] / camX[:, 2] + K[0, 2] + 0.5).astype(np.int64)    # ROUND2INT
+        py = np.floor(K[1, 1] * camX[:, 1] / camX[:, 2] + K[1, 2] + 0.5).astype(np.int64)
+        d = camX[:, 2].astype(f32)
+        for x, y, z in zip(px, py, d):                                   # later points overwrite earlier ones, as in the reference
+            depthMap[max(y - 2, 0):min(y + 2, h - 1) + 1, max(x - 2, 0):min(x + 2, w - 1) + 1] = z
+        return depthMap, normalMap, float(d.min() * f32(0.9)), float(d.max() * f32(1.1))
+    if not opt.bInitSparse or opt.bAddCorners:
+        raise NotImplementedError("only the reference's default bInitSparse=1, bAddCorners=0 initialisation is implemented")
+    q = (X.astype(np.float64) @ cams.P[ID, :, :3].T + cams.P[ID, :, 3]).astype(f32)        # ProjectPointP3<float>
+    z = q[:, 2]
+    proj = np.stack([q[:, 0] / z, q[:, 1] / z], 1)
+    vert = np.stack([((proj[:, 0] - K[0, 2]) * z / K[0, 0]).astype(f32), ((proj[:, 1] - K[1, 2]) * z / K[1, 1]).astype(f32), z], 1)
+    normals = np.zeros_like(vert)
+    if len(points) >= 3:
+        from scipy.spatial import Delaunay
+        tri = Delaunay(proj.astype(np.float64)).simplices
+        a, b, c = proj[tri[:, 0]], proj[tri[:, 1]], proj[tri[:, 2]]
+        ccw = ((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])) > 0
+        tri = np.where(ccw[:, None], tri, tri[:, ::-1])                 # CGAL faces are counter-clockwise ...
+        f0, f1, f2 = tri[:, 2], tri[:, 1], tri[:, 0]                    # ... and the mesh stores them reversed (DepthMap.cpp:1110)
+        t = np.cross(vert[f1] - vert[f0], vert[f2] - vert[f0]).astype(f32)
+        for f in (f0, f1, f2):
+            np.add.at(normals, f, t)
+        nrm = np.sqrt((normals.astype(np.float64) ** 2).sum(1))
+        normals = np.where(nrm[:, None] > 0, normals / np.maximum(nrm, 1e-300)[:, None], 0).astype(f32)
+    ix = np.floor(proj).astype(np.int64)
+    for (x, y), zz, n in zip(ix, z, normals):
+        for dx, dy in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            ax, ay = x + dx, y + dy
+            if 0 <= ax < w and 0 <= ay < h:
+                depthMap[ay, ax] = zz
+                normalMap[ay, ax] = n
+    return depthMap, normalMap, float(z.min() * f32(0.9)), float(z.max() * f32(1.1))

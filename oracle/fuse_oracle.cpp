@@ -1,0 +1,210 @@
+// fuse_oracle.cpp -- CPU restatement of DepthMapsData::FuseDepthMaps (libs/MVS/SceneDensify.cpp:1372-1650 in /root/reference):
+// walk the depth maps best-connected image first, raster order inside an image; every still-unclaimed depth seeds a 3D point,
+// is projected into the neighbour depth maps, claims the agreeing pixels there (similar depth :1553 and normal :1556), remembers
+// the ones it occludes (:1576-1579), and is kept if it gathered nMinViewsFuse views (:1581-1606) -- in which case the occluded
+// neighbour depths are zeroed -- or rolled back otherwise.
+// *** TEST INFRASTRUCTURE ONLY *** -- nothing under openmvs_amd/ may include, link or call this file; it exists so tests can check
+// the device fusion against a literal sequential statement of the reference algorithm.
+// PARITY UNPINNED: the reference has no golden point clouds for this function (its pipeline test only asserts a point count,
+// apps/Tests/Tests.cpp:86), and it does not build here (needs OpenCV/CGAL/Boost), so the arithmetic below is pinned to the source
+// text only: cv::Matx / cv::Point3_ operator semantics (products with a double scalar are computed in double and rounded to the
+// element type), Round2Int = floor(x + .5f) (libs/Common/Types.h:949-955), Conf2Weight (SceneDensify.cpp:120-122),
+// IsDepthSimilar = |d0-d1|/d0 < th (libs/Common/Util.inl:797-809).
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+struct Cam { double K[9], R[9], C[3], P[12]; };
+
+// Camera::ComposeP -> AssembleProjectionMatrix (libs/MVS/Camera.cpp:173-180): M = K*R, P = [M | M*(-C)], left-to-right sums
+void composeP(Cam& c) {
+	double M[9];
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += c.K[i*3+k] * c.R[k*3+j]; M[i*3+j] = s; }
+	for (int i = 0; i < 3; ++i) {
+		for (int j = 0; j < 3; ++j) c.P[i*4+j] = M[i*3+j];
+		c.P[i*4+3] = M[i*3+0] * (-c.C[0]) + M[i*3+1] * (-c.C[1]) + M[i*3+2] * (-c.C[2]);
+	}
+}
+// Camera::TransformPointI2W(Point3(x, y, depth)) in double (libs/MVS/Camera.h:338-356)
+void I2W(const Cam& c, double x, double y, double z, double* X) {
+	const double ci[3] = {(x - c.K[2]) * z / c.K[0], (y - c.K[5]) * z / c.K[4], z};
+	for (int i = 0; i < 3; ++i) { double s = 0; for (int k = 0; k < 3; ++k) s += c.R[k*3+i] * ci[k]; X[i] = s + c.C[i]; }
+}
+// Camera::ProjectPointP3<float> (libs/MVS/Camera.h:308-314)
+void projectP3(const Cam& c, const float* X, float* q) {
+	for (int i = 0; i < 3; ++i) q[i] = (float)(c.P[i*4+0] * X[0] + c.P[i*4+1] * X[1] + c.P[i*4+2] * X[2] + c.P[i*4+3]);
+}
+// Cast<float>(camera.R.t() * Cast<REAL>(n)) (SceneDensify.cpp:1525,1554)
+void normalW(const Cam& c, const float* n, float* o) {
+	for (int i = 0; i < 3; ++i) { double s = 0; for (int k = 0; k < 3; ++k) s += c.R[k*3+i] * (double)n[k]; o[i] = (float)s; }
+}
+inline float conf2weight(float conf, float depth) { const float a = 1.f - conf; return 1.f / ((a > 0.03f ? a : 0.03f) * depth * depth); }
+inline int round2int(float x) { return (int)floorf(x + .5f); }
+inline uint8_t toU8(float v) { int i = round2int(v); return (uint8_t)(i < 0 ? 0 : i > 255 ? 255 : i); }
+}
+
+extern "C" {
+
+struct OrcFuseView {
+	const float* depth;       // w*h, 0 = no estimate; NULL = image has no depth map (DepthData::IsEmpty)
+	const float* normal;      // w*h*3 camera-space unit normals, or NULL
+	const float* conf;        // w*h, or NULL (weight uses conf = 1)
+	const uint8_t* bgr;       // w*h*3, or NULL
+	double K[9], R[9], C[3];
+	const uint32_t* neighbors; uint32_t nNeighbors;   // DepthData::neighbors, in order
+};
+
+struct OrcFuseCloud {
+	uint64_t nPoints, nDepths, nViews;
+	float* points;            // 3*nPoints
+	uint32_t* viewStart;      // nPoints+1
+	uint32_t* views;          // nViews, ascending image index inside a point
+	float* weights;           // nViews
+	uint16_t* projs;          // 2*nViews (x, y) of the pixel each view contributed
+	uint8_t* colors;          // 3*nPoints or NULL
+	float* normals;           // 3*nPoints or NULL
+};
+
+void orc_fuse_free(OrcFuseCloud* c) {
+	free(c->points); free(c->viewStart); free(c->views); free(c->weights); free(c->projs); free(c->colors); free(c->normals);
+	memset(c, 0, sizeof(*c));
+}
+
+// order[0..nOrder): image indices, best connected first (the caller sorts; the reference uses std::sort on the neighbour count,
+// SceneDensify.cpp:1448, whose order among ties is unspecified).  normalError = cos(fNormalDiffThreshold).
+int orc_fuse_depth_maps(const OrcFuseView* views_, int nImages, int w, int h, const uint32_t* order, int nOrder,
+		unsigned nMinViewsFuse, float fDepthDiffThreshold, float normalError, int bEstimateColor, int bEstimateNormal, OrcFuseCloud* out) {
+	memset(out, 0, sizeof(*out));
+	if ((unsigned)nImages < nMinViewsFuse) nMinViewsFuse = (unsigned)nImages;
+	const size_t P = (size_t)w * h;
+	std::vector<Cam> cams(nImages);
+	std::vector<std::vector<float>> depthMaps(nImages);
+	bool bNormalMap = true;
+	for (int i = 0; i < nImages; ++i) {
+		memcpy(cams[i].K, views_[i].K, 72); memcpy(cams[i].R, views_[i].R, 72); memcpy(cams[i].C, views_[i].C, 24);
+		composeP(cams[i]);
+		if (views_[i].depth) { depthMaps[i].assign(views_[i].depth, views_[i].depth + P); if (!views_[i].normal) bNormalMap = false; }
+	}
+	if (bEstimateNormal && !bNormalMap) bEstimateNormal = 0;
+	const uint32_t NO_ID = 0xFFFFFFFFu;
+	std::vector<std::vector<uint32_t>> arrDepthIdx(nImages);
+	struct Pt { float X[3]; std::vector<uint32_t> views; std::vector<float> weights; std::vector<uint16_t> projs; };
+	std::vector<Pt> points;
+	std::vector<uint8_t> colors; std::vector<float> normals;
+	std::vector<float*> invalidDepths;
+	uint64_t nDepths = 0;
+	for (int o = 0; o < nOrder; ++o) {
+		const uint32_t idxImage = order[o];
+		const OrcFuseView& vA = views_[idxImage];
+		if (!vA.depth) continue;
+		for (uint32_t n = 0; n < vA.nNeighbors; ++n) {
+			const uint32_t b = vA.neighbors[n];
+			if (arrDepthIdx[b].empty() && views_[b].depth) arrDepthIdx[b].assign(P, NO_ID);
+		}
+		if (arrDepthIdx[idxImage].empty()) arrDepthIdx[idxImage].assign(P, NO_ID);
+		std::vector<uint32_t>& depthIdxs = arrDepthIdx[idxImage];
+		const Cam& camA = cams[idxImage];
+		for (int i = 0; i < h; ++i) for (int j = 0; j < w; ++j) {
+			const size_t x = (size_t)i * w + j;
+			const float depth = depthMaps[idxImage][x];
+			if (depth == 0) continue;
+			++nDepths;
+			if (depthIdxs[x] != NO_ID) continue;
+			const uint32_t idxPoint = (uint32_t)points.size();
+			depthIdxs[x] = idxPoint;
+			points.emplace_back();
+			Pt& pt = points.back();
+			double Xw[3]; I2W(camA, (double)(float)j, (double)(float)i, (double)depth, Xw);
+			float point[3] = {(float)Xw[0], (float)Xw[1], (float)Xw[2]};
+			pt.views.push_back(idxImage);
+			const float w0 = conf2weight(vA.conf ? vA.conf[x] : 1.f, depth);
+			pt.weights.push_back(w0);
+			double confidence = (double)w0;
+			pt.projs.push_back((uint16_t)j); pt.projs.push_back((uint16_t)i);
+			float normal[3] = {0, 0, -1};
+			if (bNormalMap) normalW(camA, vA.normal + x * 3, normal);
+			double X[3]; for (int k = 0; k < 3; ++k) X[k] = (double)(float)((double)point[k] * confidence);       // Point3f * double -> Point3f
+			float Cc[3] = {0, 0, 0};
+			if (vA.bgr) for (int k = 0; k < 3; ++k) Cc[k] = (float)(confidence * (double)(float)vA.bgr[x * 3 + k]);   // TPixel<float>::operator*(double)
+			float N[3]; for (int k = 0; k < 3; ++k) N[k] = (float)((double)normal[k] * confidence);
+			invalidDepths.clear();
+			for (uint32_t n = 0; n < vA.nNeighbors; ++n) {
+				const uint32_t idxImageB = vA.neighbors[n];
+				const OrcFuseView& vB = views_[idxImageB];
+				if (!vB.depth) continue;
+				const Cam& camB = cams[idxImageB];
+				float q[3]; projectP3(camB, point, q);
+				if (q[2] <= 0) continue;
+				const int xb = round2int(q[0] / q[2]), yb = round2int(q[1] / q[2]);
+				if (!(xb >= 0 && yb >= 0 && xb < w && yb < h)) continue;
+				const size_t xB = (size_t)yb * w + xb;
+				float& depthB = depthMaps[idxImageB][xB];
+				if (depthB == 0) continue;
+				uint32_t& idxPointB = arrDepthIdx[idxImageB][xB];
+				if (idxPointB != NO_ID) continue;
+				if (fabsf(q[2] - depthB) / q[2] < fDepthDiffThreshold) {
+					float normalB[3] = {0, 0, -1};
+					if (bNormalMap) normalW(camB, vB.normal + xB * 3, normalB);
+					if (normal[0] * normalB[0] + normal[1] * normalB[1] + normal[2] * normalB[2] > normalError) {
+						const float confidenceB = conf2weight(vB.conf ? vB.conf[xB] : 1.f, depthB);
+						size_t idx = 0; while (idx < pt.views.size() && pt.views[idx] < idxImageB) ++idx;          // InsertSort
+						pt.views.insert(pt.views.begin() + idx, idxImageB);
+						pt.weights.insert(pt.weights.begin() + idx, confidenceB);
+						pt.projs.insert(pt.projs.begin() + 2 * idx, {(uint16_t)xb, (uint16_t)yb});
+						idxPointB = idxPoint;
+						double XB[3]; I2W(camB, (double)(float)xb, (double)(float)yb, (double)depthB, XB);
+						for (int k = 0; k < 3; ++k) X[k] += XB[k] * (double)confidenceB;
+						if (bEstimateColor && vB.bgr) for (int k = 0; k < 3; ++k) Cc[k] += (float)vB.bgr[xB * 3 + k] * confidenceB;
+						if (bEstimateNormal) for (int k = 0; k < 3; ++k) N[k] += normalB[k] * confidenceB;
+						confidence += (double)confidenceB;
+						continue;
+					}
+				}
+				if (q[2] < depthB) invalidDepths.push_back(&depthB);
+			}
+			if (pt.views.size() < nMinViewsFuse) {
+				for (size_t v = 0; v < pt.views.size(); ++v)
+					arrDepthIdx[pt.views[v]][(size_t)pt.projs[2*v+1] * w + pt.projs[2*v]] = NO_ID;
+				points.pop_back();
+			} else {
+				const double nrm = 1.0 / confidence;
+				for (int k = 0; k < 3; ++k) pt.X[k] = (float)(X[k] * nrm);
+				if (bEstimateColor) for (int k = 0; k < 3; ++k) colors.push_back(toU8((float)nrm * Cc[k]));
+				if (bEstimateNormal) {
+					float v[3]; for (int k = 0; k < 3; ++k) v[k] = N[k] * (float)nrm;
+					// cv::normalize(Vec3f): v * (1/norm) with the norm accumulated in double (core/matx.hpp normL2Sqr<float,double>)
+					double s = 0; for (int k = 0; k < 3; ++k) s += (double)v[k] * (double)v[k];
+					const double nv = sqrt(s);
+					const double inv = nv ? 1. / nv : 0.;
+					for (int k = 0; k < 3; ++k) normals.push_back((float)((double)v[k] * inv));
+				}
+				for (float* pDepth : invalidDepths) *pDepth = 0;
+			}
+		}
+	}
+	out->nPoints = points.size(); out->nDepths = nDepths;
+	out->points = (float*)malloc(sizeof(float) * 3 * (points.size() + 1));
+	out->viewStart = (uint32_t*)malloc(sizeof(uint32_t) * (points.size() + 1));
+	uint64_t nv = 0; for (const Pt& p : points) nv += p.views.size();
+	out->nViews = nv;
+	out->views = (uint32_t*)malloc(sizeof(uint32_t) * (nv + 1)); out->weights = (float*)malloc(sizeof(float) * (nv + 1));
+	out->projs = (uint16_t*)malloc(sizeof(uint16_t) * 2 * (nv + 1));
+	uint32_t at = 0;
+	for (size_t i = 0; i < points.size(); ++i) {
+		memcpy(out->points + 3 * i, points[i].X, 12);
+		out->viewStart[i] = at;
+		for (size_t v = 0; v < points[i].views.size(); ++v, ++at) {
+			out->views[at] = points[i].views[v]; out->weights[at] = points[i].weights[v];
+			out->projs[2*at] = points[i].projs[2*v]; out->projs[2*at+1] = points[i].projs[2*v+1];
+		}
+	}
+	out->viewStart[points.size()] = at;
+	if (bEstimateColor) { out->colors = (uint8_t*)malloc(colors.size() + 1); memcpy(out->colors, colors.data(), colors.size()); }
+	if (bEstimateNormal) { out->normals = (float*)malloc(sizeof(float) * (normals.size() + 1)); memcpy(out->normals, normals.data(), sizeof(float) * normals.size()); }
+	return 0;
+}
+
+} // extern "C"

@@ -35,7 +35,7 @@ class OrcOpt(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libpm_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("pm_oracle.cpp", "sgm_oracle.cpp", "filter_oracle.cpp")] + \
+    srcs = [os.path.join(_HERE, f) for f in ("pm_oracle.cpp", "sgm_oracle.cpp", "filter_oracle.cpp", "fuse_oracle.cpp")] + \
            [os.path.join(_HERE, "..", "openmvs_amd", "csrc", "pm_math.h")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s))
     if stale and all(os.path.exists(s) for s in srcs):
@@ -222,3 +222,72 @@ def remove_small_segments(depth, normal, conf, nSpeckleSize=100, fDepthDiffThres
     h, w = d.shape
     lib().orc_remove_small_segments(_fp(d), _fp(n), _fp(c), C.c_int(w), C.c_int(h), C.c_uint(nSpeckleSize), C.c_float(fDepthDiffThreshold))
     return d, n, c
+
+
+# ---- FuseDepthMaps oracle (oracle/fuse_oracle.cpp) ---------------------------------------------
+class OrcFuseView(C.Structure):
+    _fields_ = [("depth", C.POINTER(C.c_float)), ("normal", C.POINTER(C.c_float)), ("conf", C.POINTER(C.c_float)), ("bgr", C.POINTER(C.c_uint8)),
+                ("K", C.c_double * 9), ("R", C.c_double * 9), ("C", C.c_double * 3), ("neighbors", C.POINTER(C.c_uint32)), ("nNeighbors", C.c_uint32)]
+
+
+class OrcFuseCloud(C.Structure):
+    _fields_ = [("nPoints", C.c_uint64), ("nDepths", C.c_uint64), ("nViews", C.c_uint64), ("points", C.POINTER(C.c_float)),
+                ("viewStart", C.POINTER(C.c_uint32)), ("views", C.POINTER(C.c_uint32)), ("weights", C.POINTER(C.c_float)),
+                ("projs", C.POINTER(C.c_uint16)), ("colors", C.POINTER(C.c_uint8)), ("normals", C.POINTER(C.c_float))]
+
+
+def fuse_order(neighbor_counts, valid=None):
+    """Processing order of FuseDepthMaps: images with a depth map, by decreasing neighbour count (SceneDensify.cpp:1423-1450); ties by index."""
+    idx = [i for i in range(len(neighbor_counts)) if (valid is None or valid[i]) and neighbor_counts[i] > 0]
+    return sorted(idx, key=lambda i: (-neighbor_counts[i], i))
+
+
+def fuse_depth_maps(depths, normals, confs, bgrs, K, R, Cc, neighbors, order=None, nMinViewsFuse=2, fDepthDiffThreshold=0.01,
+                    fNormalDiffThreshold=25.0, bEstimateColor=True, bEstimateNormal=True, fn=None):
+    """One DepthMapsData::FuseDepthMaps call over all images.  depths[i] may be None (no depth map).  Returns a dict of arrays.
+    `fn` overrides the C entry point (same signature), used to run the host emulation of the device kernels through the same wrapper."""
+    n = len(depths)
+    first = next(d for d in depths if d is not None)
+    h, w = first.shape
+    keep = []
+    arr = (OrcFuseView * n)()
+
+    def ptr(a, dt, ct):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dt); keep.append(a)
+        return a.ctypes.data_as(C.POINTER(ct))
+    for i in range(n):
+        v = arr[i]
+        v.depth = ptr(depths[i], np.float32, C.c_float)
+        v.normal = ptr(None if normals is None or depths[i] is None else normals[i], np.float32, C.c_float)
+        v.conf = ptr(None if confs is None or depths[i] is None else confs[i], np.float32, C.c_float)
+        v.bgr = ptr(None if bgrs is None else bgrs[i], np.uint8, C.c_uint8)
+        v.K[:] = np.asarray(K[i], np.float64).ravel(); v.R[:] = np.asarray(R[i], np.float64).ravel(); v.C[:] = np.asarray(Cc[i], np.float64).ravel()
+        nb = np.ascontiguousarray(neighbors[i], np.uint32); keep.append(nb)
+        v.neighbors = nb.ctypes.data_as(C.POINTER(C.c_uint32)); v.nNeighbors = len(nb)
+    if order is None:
+        order = fuse_order([len(x) for x in neighbors], [d is not None for d in depths])
+    od = np.ascontiguousarray(order, np.uint32)
+    out = OrcFuseCloud()
+    f = fn or lib().orc_fuse_depth_maps
+    f.restype = C.c_int
+    # COS(FD2R(x)) in float with the C library's cosf, the same call the engine makes (numpy's float32 cos may differ in the last bit)
+    libm = C.CDLL("libm.so.6"); libm.cosf.restype = C.c_float; libm.cosf.argtypes = [C.c_float]
+    normalError = libm.cosf(float(np.float32(fNormalDiffThreshold) * (np.float32(3.14159265358979323846) / np.float32(180))))
+    rc = f(arr, C.c_int(n), C.c_int(w), C.c_int(h), od.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int(len(od)), C.c_uint(nMinViewsFuse),
+           C.c_float(fDepthDiffThreshold), C.c_float(float(normalError)), C.c_int(1 if bEstimateColor else 0), C.c_int(1 if bEstimateNormal else 0), C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"fuse failed: {rc}")
+    P, V = int(out.nPoints), int(out.nViews)
+
+    def take(p, cnt, dt):
+        return np.ctypeslib.as_array(p, shape=(max(cnt, 1),))[:cnt].astype(dt, copy=True) if cnt >= 0 and bool(p) else None
+    res = dict(nPoints=P, nDepths=int(out.nDepths), points=take(out.points, 3 * P, np.float32).reshape(P, 3),
+               viewStart=take(out.viewStart, P + 1, np.uint32), views=take(out.views, V, np.uint32), weights=take(out.weights, V, np.float32),
+               projs=take(out.projs, 2 * V, np.uint16).reshape(V, 2),
+               colors=None if not out.colors else take(out.colors, 3 * P, np.uint8).reshape(P, 3),
+               normals=None if not out.normals else take(out.normals, 3 * P, np.float32).reshape(P, 3))
+    free = (lib().orc_fuse_free if fn is None else getattr(fn, "_free", lib().orc_fuse_free))
+    free(C.byref(out))
+    return res

@@ -1,0 +1,85 @@
+"""-m gpu: FuseDepthMaps on the device (deterministic reservations, csrc/pm_fuse.hip) against the sequential oracle
+(oracle/fuse_oracle.cpp).  Everything is compared exactly: point order, view lists, projections, weights, positions, colours, normals."""
+import time
+
+import numpy as np
+import pytest
+
+from openmvs_amd import synth
+from openmvs_amd.patchmatch import PatchMatchHIP
+from oracle import pyoracle as po
+from tests import fuse_cases as fc
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(e, sc, maps):
+    e.scene_load(sc, n_levels=0)
+    d, n, c = maps
+    for v in range(sc.n_views):
+        e.scene_set_maps(v, d[v], n[v]); e.scene_set_conf(v, c[v]); e.scene_set_color(v, sc.bgr[v])
+
+
+def _order(sc):
+    return po.fuse_order([len(x) for x in sc.neighbors])
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_device_fuse_is_the_sequential_fuse(small_scene, nine_scene, case):
+    sc, seed, kw = [(small_scene, 1, {}), (small_scene, 2, dict(nMinViewsFuse=3)), (nine_scene, 3, {}),
+                    (nine_scene, 4, dict(fDepthDiffThreshold=0.03, fNormalDiffThreshold=60.0, bEstimateColor=False, bEstimateNormal=False))][case]
+    maps = fc.make_maps(sc, seed=seed)
+    e = PatchMatchHIP(0)
+    _load(e, sc, maps)
+    got = e.scene_fuse(_order(sc), **kw)
+    ref = po.fuse_depth_maps(*maps, list(sc.bgr), sc.K, sc.R, sc.C, [list(x) for x in sc.neighbors], **kw)
+    fc.same_cloud(got, ref, f"case {case}")
+    assert got["nPoints"] > 1000 and got["rounds"] < 40 * sc.n_views
+    # the scene's own maps are untouched (fusion works on copies), and a second call gives the same cloud
+    d0, _, _ = e.scene_get_maps(0)
+    assert np.array_equal(d0, maps[0][0])
+    fc.same_cloud(e.scene_fuse(_order(sc), **kw), ref, f"case {case} again")
+    e.close()
+
+
+def test_device_fuse_custom_order_and_errors(small_scene):
+    sc = small_scene
+    maps = fc.make_maps(sc, seed=5)
+    e = PatchMatchHIP(0)
+    e.scene_load(sc, n_levels=0)
+    for v in range(sc.n_views):
+        e.scene_set_maps(v, maps[0][v], maps[1][v]); e.scene_set_conf(v, maps[2][v])
+    with pytest.raises(Exception):
+        e.scene_fuse(_order(sc))                       # colours requested but never uploaded
+    order = [4, 0, 2, 1]                               # view 3 is only ever a neighbour
+    got = e.scene_fuse(order, bEstimateColor=False)
+    ref = po.fuse_depth_maps(*maps, None, sc.K, sc.R, sc.C, [list(x) for x in sc.neighbors], order=order, bEstimateColor=False)
+    fc.same_cloud(got, ref, "custom order")
+    e.close()
+
+
+def test_device_fuse_full_size_is_exact_and_timed():
+    """9 views of 1920x1080 (BASELINE config 2's resolution): 15 M depths.  The sequential oracle needs ~10 s for this, so the
+    comparison stays exact at full size; the guarantees of fusion are asserted as well and both times are printed."""
+    sc = synth.make_scene(9, 1920, 1080, n_src=8, device="cuda")
+    maps = fc.make_maps(sc, seed=7)
+    e = PatchMatchHIP(0)
+    _load(e, sc, maps)
+    e.scene_fuse(_order(sc))                                  # warm-up: allocations
+    t = time.time(); r = e.scene_fuse(_order(sc)); dt = time.time() - t
+    t = time.time()
+    ref = po.fuse_depth_maps(*maps, list(sc.bgr), sc.K, sc.R, sc.C, [list(x) for x in sc.neighbors])
+    dt_ref = time.time() - t
+    fc.same_cloud(r, ref, "full size")
+    nv = np.diff(r["viewStart"].astype(np.int64))
+    assert r["nPoints"] > 1_000_000 and nv.min() >= 2 and nv.max() <= 9 and r["viewStart"][-1] == len(r["views"])
+    key = r["views"].astype(np.int64) * (1 << 32) + r["projs"][:, 1].astype(np.int64) * 65536 + r["projs"][:, 0]
+    assert len(np.unique(key)) == len(key)
+    first = r["viewStart"][:-1]
+    v0 = r["views"][first]; xy = r["projs"][first]
+    z = np.einsum("ij,ij->i", r["points"].astype(np.float64) - sc.C[v0], sc.R[v0][:, 2])
+    gt = sc.gt_depth[v0, xy[:, 1], xy[:, 0]]
+    assert np.median(np.abs(z - gt) / gt) < 2e-3
+    print(f"\nfuse 9x1080p: {r['nPoints']} points from {r['nDepths']} depths; device {dt*1e3:.0f} ms incl. download ({r['rounds']} rounds), "
+          f"sequential oracle {dt_ref*1e3:.0f} ms")
+    e.close()

@@ -273,6 +273,63 @@ def test_whole_dense_schedule_matches_the_oracle_pipeline(small_scene, tmp_path)
     e.close()
 
 
+def test_real_scene_from_mvs_archive_matches_oracle_and_sfm_points():
+    """The reference's own pipeline fixture (tests/data/scene: 4 JPEGs 640x479 + MVSI archive): scene front end (reader, view selection,
+    sparse initialisation) -> photometric pass + 2 geometric rounds seeded by the sparse maps.  Device == oracle bit for bit on real
+    images, and both agree with the SfM points they never saw as constraints (only as 2x2 seeds) to well under a percent."""
+    from openmvs_amd import densify, mvsi, views
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    path = os.path.join(os.path.dirname(__file__), "data", "scene", "scene.mvs")
+    sv = densify.load_scene(path)
+    seed = 5
+    e = PatchMatchHIP(0)
+    e.scene_load(sv, n_levels=2)
+    p = default_params(seed=seed)
+    densify.compute_depth_maps(e, sv.ids, p, n_optimize=0, init_depth=sv.init_depth, init_normal=sv.init_normal)
+    got = {v: e.scene_get_maps(v) for v in sv.ids}
+
+    def orc(v, geo=-1, depth=None, normal=None, src=None):
+        ids = [v] + list(sv.neighbors[v])
+        vw, keep = po.make_views(sv.gray, sv.K, sv.R, sv.C, ids, depth_maps=src)
+        return po.estimate_depth_map(vw, len(ids), float(sv.dmin[v]), float(sv.dmax[v]), po.default_opt(seed=seed, viewID=v),
+                                     geo_iter=geo, depth=depth, normal=normal)
+    cur = {v: orc(v, depth=sv.init_depth[v], normal=sv.init_normal[v]) for v in sv.ids}
+    for g in range(2):
+        prev = {v: cur[v][0] for v in sv.ids}
+        cur = {v: orc(v, geo=g, depth=cur[v][0], normal=cur[v][1], src=prev) for v in sv.ids}
+    sc = mvsi.load(path); cams = views.Cameras(sc)
+    for v in sv.ids:
+        for k, what in enumerate(("depth", "normal", "conf")):
+            _same(got[v][k], cur[v][k], f"real scene view {v} {what}")
+        d = got[v][0]
+        assert 0.6 < (d > 0).mean() < 0.95
+        _, _, pts, _ = views.select_neighbor_views(sc, cams, v)
+        X = sc.vertices[pts]; pr = cams.project_p(v, X); z = cams.point_depth(v, X)
+        xi = np.rint(pr[:, 0]).astype(int); yi = np.rint(pr[:, 1]).astype(int)
+        m = (xi >= 4) & (yi >= 4) & (xi < sv.width - 4) & (yi < sv.height - 4)
+        dm = d[yi[m], xi[m]]; ok = dm > 0
+        rel = np.abs(dm[ok] - z[m][ok]) / z[m][ok]
+        assert ok.mean() > 0.95 and np.median(rel) < 5e-3 and np.percentile(rel, 90) < 3e-2
+    # the complete schedule (speckle + gap filters, cross-view filter) keeps most of it
+    densify.compute_depth_maps(e, sv.ids, p, init_depth=sv.init_depth, init_normal=sv.init_normal)
+    final = {v: e.scene_get_maps(v) for v in sv.ids}
+    for v in sv.ids:
+        assert 0.5 < (final[v][0] > 0).mean() < 0.95
+    # ... and fusing them passes the reference's own acceptance for this dataset: >= 200000 points (apps/Tests/Tests.cpp:86)
+    from tests import fuse_cases as fcs
+    from PIL import Image
+    bgr = [np.ascontiguousarray(np.asarray(Image.open(os.path.join(os.path.dirname(path), n)).convert("RGB"))[..., ::-1]) for n in sv.names]
+    for v in range(sv.n_views):
+        e.scene_set_color(v, bgr[v])
+    order = po.fuse_order([len(x) for x in sv.neighbors])
+    cloud = e.scene_fuse(order)
+    ref = po.fuse_depth_maps([final[v][0] for v in sv.ids], [final[v][1] for v in sv.ids], [final[v][2] for v in sv.ids], bgr,
+                             sv.K, sv.R, sv.C, [list(x) for x in sv.neighbors], order=order)
+    fcs.same_cloud(cloud, ref, "real scene fuse")
+    assert cloud["nPoints"] >= 200000
+    e.close()
+
+
 def test_full_size_properties():
     """BASELINE config 2 (1 ref x 8 src, 1920x1080): the oracle needs ~15 min here, so check
     size-independent properties: run-to-run determinism (race check of the diagonal schedule),

@@ -18,8 +18,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value", "-Wno-pass-failed"]
 
 LIBS = {
-    "libpmhip.so": (["pm_engine.hip"], ["pm_kernels.hip", "pm_math.h", "../../include/pmhip.h"]),
-    "libsgmhip.so": (["sgm_engine.hip"], ["sgm_kernels.hip", "../../include/sgmhip.h"]),
+    "libpmhip.so": (["pm_engine.hip"], ["pm_kernels.hip", "pm_filter.hip", "pm_fuse.hip", "pm_fuse.h", "pm_math.h", "../../include/pmhip.h"]),
+    "libsgmhip.so": (["sgm_engine.hip"], ["sgm_kernels.hip", "pm_math.h", "../../include/sgmhip.h"]),
 }
 
 

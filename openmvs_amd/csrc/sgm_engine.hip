@@ -15,7 +15,7 @@ struct sgmhip_engine {
 	int w = 0, h = 0, vw = 0, vh = 0, maxNumDisp = 0; uint64_t numCosts = 0;
 	size_t capImg = 0, capPix = 0, capCosts = 0;
 	unsigned char* d_color = nullptr; float* d_grayL = nullptr; float* d_grayR = nullptr;
-	SGMPixel* d_pixels = nullptr; unsigned char* d_costs = nullptr; unsigned short* d_accums = nullptr;
+	SGMPixel* d_pixels = nullptr; unsigned char* d_costs = nullptr; unsigned short* d_accums = nullptr; float4* d_setup = nullptr;
 	short* d_disp = nullptr; unsigned short* d_cost = nullptr; unsigned short* d_P2s = nullptr;
 	bool statsOn = false; SGMHipStats stats{};
 	struct Ev { hipEvent_t a, b; int kind; }; std::vector<Ev> events;
@@ -23,9 +23,9 @@ struct sgmhip_engine {
 
 static void sgmFree(sgmhip_engine* e) {
 	hipSetDevice(e->device);
-	void* ps[] = {e->d_color, e->d_grayL, e->d_grayR, e->d_pixels, e->d_costs, e->d_accums, e->d_disp, e->d_cost};
+	void* ps[] = {e->d_color, e->d_grayL, e->d_grayR, e->d_pixels, e->d_costs, e->d_accums, e->d_disp, e->d_cost, e->d_setup};
 	for (void* p : ps) if (p) hipFree(p);
-	e->d_color = nullptr; e->d_grayL = e->d_grayR = nullptr; e->d_pixels = nullptr; e->d_costs = nullptr; e->d_accums = nullptr; e->d_disp = nullptr; e->d_cost = nullptr;
+	e->d_color = nullptr; e->d_grayL = e->d_grayR = nullptr; e->d_pixels = nullptr; e->d_costs = nullptr; e->d_accums = nullptr; e->d_disp = nullptr; e->d_cost = nullptr; e->d_setup = nullptr;
 	e->capImg = e->capPix = e->capCosts = 0;
 }
 static void evB(sgmhip_engine* e, int kind) { if (!e->statsOn) return; sgmhip_engine::Ev ev; ev.kind = kind; hipEventCreate(&ev.a); hipEventCreate(&ev.b); hipEventRecord(ev.a, e->stream); e->events.push_back(ev); }
@@ -79,7 +79,7 @@ int sgmhip_set_problem(sgmhip_engine* e, const uint8_t* leftBGR, const float* le
 		SGMCHK(e, hipStreamSynchronize(e->stream));
 		sgmFree(e);
 		SGMCHK(e, hipMalloc(&e->d_color, nImg * 3)); SGMCHK(e, hipMalloc(&e->d_grayL, nImg * 4)); SGMCHK(e, hipMalloc(&e->d_grayR, nImg * 4));
-		SGMCHK(e, hipMalloc(&e->d_pixels, nPix * sizeof(SGMPixel))); SGMCHK(e, hipMalloc(&e->d_disp, nPix * 2)); SGMCHK(e, hipMalloc(&e->d_cost, nPix * 2));
+		SGMCHK(e, hipMalloc(&e->d_pixels, nPix * sizeof(SGMPixel))); SGMCHK(e, hipMalloc(&e->d_disp, nPix * 2)); SGMCHK(e, hipMalloc(&e->d_cost, nPix * 2)); SGMCHK(e, hipMalloc(&e->d_setup, nPix * sizeof(float4)));
 		SGMCHK(e, hipMalloc(&e->d_costs, numCosts)); SGMCHK(e, hipMalloc(&e->d_accums, (numCosts + 1) / 2 * 4 + 4)); // u16 sums, addressed as 32-bit words by the path kernels
 		e->capImg = nImg; e->capPix = nPix; e->capCosts = numCosts;
 	}
@@ -107,7 +107,9 @@ int sgmhip_match(sgmhip_engine* e, uint16_t P1, const uint16_t P2s[256], int syn
 	const long nPix = (long)e->vw * e->vh;
 	const int W = e->vw, H = e->vh;
 	evB(e, 0);
-	hipLaunchKernelGGL(sgm_cost_kernel, dim3((unsigned)((nPix + 3) / 4)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_costs);
+	hipLaunchKernelGGL(sgm_setup_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->w, W, H, e->d_pixels, e->d_setup);
+	const long nPairs = (long)((W + 1) / 2) * H;
+	hipLaunchKernelGGL(sgm_cost_kernel, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_setup, e->d_costs);
 	evE(e);
 	SGMCHK(e, hipMemsetAsync(e->d_accums, 0, (e->numCosts + 1) / 2 * 4, e->stream)); // imageAccumCosts.Memset(0), :990
 	const int NK = e->maxNumDisp <= 64 ? 1 : (e->maxNumDisp <= 128 ? 2 : 4);

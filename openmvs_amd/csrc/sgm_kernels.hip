@@ -19,69 +19,123 @@
 struct SGMPixel { unsigned long long idx; short minDisp, maxDisp; int pad; }; // == SGMHipPixelData
 #define SGM_HW 3
 #define SGM_NT 49
+#ifndef SGM_T
 #define SGM_T 8          // pixels per prefetch chunk
+#endif
 #define SGM_INF 0x3fffffff
 
 __device__ __forceinline__ int sgm_round2int(float x) { return (int)pm_floorf(x + .5f); } // ROUND2INT, Types.h:949-955
 
-// ---- cost volume, SemiGlobalMatcher.cpp:874-985: one wave per valid-grid pixel ---------------
-__global__ __launch_bounds__(256) void sgm_cost_kernel(const unsigned char* __restrict__ colorL, const float* __restrict__ grayL,
-		const float* __restrict__ grayR, int w, int h, int vw, int vh, const SGMPixel* __restrict__ pixels, unsigned char* __restrict__ costs) {
-	__shared__ float2 s_w[4][SGM_NT + 1];
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const long pix = (long)blockIdx.x * 4 + wave;
-	const bool active = pix < (long)vw * vh;
-	SGMPixel px; px.idx = 0; px.minDisp = 0; px.maxDisp = 0;
-	if (active) px = pixels[pix];
-	const bool valid = active && px.minDisp < px.maxDisp;
-	const int ux = (int)(pix % vw) + SGM_HW, uy = (int)(pix / vw) + SGM_HW;
+// ---- cost volume, SemiGlobalMatcher.cpp:874-985 --------------------------------------------------------------------------
+// The kernel is fp32-VALU bound (49 taps x 3 running sums per cost, all in the reference's summation order), so the design goal
+// is wave-instructions per cost:
+//  * the per-pixel prologue (weighted mean and variance of the left window, :905-935) is two serial 49-term sums; done by the
+//    wave that owns the pixel it costs 196 wave-instructions per pixel, done one pixel per LANE (sgm_setup_kernel) it costs 1/64
+//    of that.  Its three results per pixel travel through a 16-byte record;
+//  * a wave computes the costs of TWO horizontally adjacent pixels, one disparity of each per lane, as float2 lanes: the three
+//    multiply-add pairs of a tap become v_pk_mul_f32 / v_pk_add_f32 (IEEE, unfused: -ffp-contract=off), and one ds_read_b128
+//    delivers the weights of both pixels.
+typedef float sgm_v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float sgm_weight(const unsigned char* __restrict__ colorL, int w, int ux, int uy, int i, int j) {
 	const float sigmaColor = -1.f / (2.f * ((0.3f * 255) * (0.3f * 255)));
 	const float sigmaSpatial = -1.f / (2.f * ((0.4f * 7) * (0.4f * 7)));
-	if (valid && lane < SGM_NT) {
-		const int i = lane / 7 - SGM_HW, j = lane % 7 - SGM_HW;
-		const unsigned char* a = colorL + ((size_t)(uy + i) * w + (ux + j)) * 3;
-		const unsigned char* c = colorL + ((size_t)uy * w + ux) * 3;
-		unsigned s = 0;
+	const unsigned char* a = colorL + ((size_t)(uy + i) * w + (ux + j)) * 3;
+	const unsigned char* c = colorL + ((size_t)uy * w + ux) * 3;
+	unsigned s = 0;
 #pragma unroll
-		for (int k = 0; k < 3; ++k) { const unsigned d = a[k] < c[k] ? c[k] - a[k] : a[k] - c[k]; s += d * d; }
-		const float wColor = (float)s * sigmaColor;
-		const float wSpatial = (float)(j * j + i * i) * sigmaSpatial;
-		s_w[wave][lane] = make_float2(pm_expf(wColor + wSpatial), grayL[(size_t)(uy + i) * w + (ux + j)]);
+	for (int k = 0; k < 3; ++k) { const unsigned d = a[k] < c[k] ? c[k] - a[k] : a[k] - c[k]; s += d * d; }
+	const float wColor = (float)s * sigmaColor;
+	const float wSpatial = (float)(j * j + i * i) * sigmaSpatial;
+	return pm_expf(wColor + wSpatial);
+}
+
+// one valid-grid pixel per lane: {sumW, mean, normSq0, 0}
+__global__ __launch_bounds__(256) void sgm_setup_kernel(const unsigned char* __restrict__ colorL, const float* __restrict__ grayL,
+		int w, int vw, int vh, const SGMPixel* __restrict__ pixels, float4* __restrict__ setup) {
+	const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (pix >= (long)vw * vh) return;
+	const SGMPixel px = pixels[pix];
+	if (!(px.minDisp < px.maxDisp)) { setup[pix] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+	const int ux = (int)(pix % vw) + SGM_HW, uy = (int)(pix / vw) + SGM_HW;
+	float wk[SGM_NT], vk[SGM_NT];
+	float acc = 0.f, sumW = 0.f;
+#pragma unroll
+	for (int k = 0; k < SGM_NT; ++k) {
+		const int i = k / 7 - SGM_HW, j = k % 7 - SGM_HW;
+		wk[k] = sgm_weight(colorL, w, ux, uy, i, j);
+		vk[k] = grayL[(size_t)(uy + i) * w + (ux + j)];
+		acc += vk[k] * wk[k]; sumW += wk[k];
 	}
-	__syncthreads();
-	float sumW = 0.f, normSq0 = 0.f, tm = 0.f;
-	if (valid) {
-		float acc = 0.f;
-		for (int k = 0; k < SGM_NT; ++k) { const float2 p = s_w[wave][k]; acc += p.y * p.x; sumW += p.x; }
-		tm = acc / sumW;
-		for (int k = 0; k < SGM_NT; ++k) { const float2 p = s_w[wave][k]; const float t = p.y - tm; const float tw = p.x * t; normSq0 += tw * t; }
-	}
-	__syncthreads();
-	if (valid && lane < SGM_NT) { const float2 p = s_w[wave][lane]; s_w[wave][lane] = make_float2(p.x, p.x * (p.y - tm)); }
-	__syncthreads();
-	if (!valid) return;
+	const float tm = acc / sumW;
+	float normSq0 = 0.f;
+#pragma unroll
+	for (int k = 0; k < SGM_NT; ++k) { const float t = vk[k] - tm; const float tw = wk[k] * t; normSq0 += tw * t; }
+	setup[pix] = make_float4(sumW, tm, normSq0, 0.f);
+}
+
+__device__ __forceinline__ unsigned char sgm_cost_of(float sum, float sumSq, float nom, float sumW, float normSq0) {
 	const float eps = 1e-3f;
-	for (int d = px.minDisp + lane; d < px.maxDisp; d += 64) {
-		unsigned char cost;
-		if (ux - SGM_HW + d < 0 || ux + SGM_HW + d >= w) cost = 255; // some tap outside the right image (:954-957)
-		else {
-			float sum = 0.f, sumSq = 0.f, nom = 0.f;
-			int n = 0;
-			for (int i = -SGM_HW; i <= SGM_HW; ++i) {
-				const float* row = grayR + (size_t)(uy + i) * w + (ux + d);
+	const float normSq1 = sumSq - (sum * sum) / sumW;
+	const float ncc = nom / pm_sqrtf(normSq0 * normSq1 + eps);
+	return ncc <= 0 ? (unsigned char)255 : (unsigned char)sgm_round2int((1.f - pm_minf(ncc, 1.f)) * 255.f);
+}
+
+// one wave per pair of horizontally adjacent valid-grid pixels (A, B = A + 1)
+__global__ __launch_bounds__(256, 4) void sgm_cost_kernel(const unsigned char* __restrict__ colorL, const float* __restrict__ grayL,
+		const float* __restrict__ grayR, int w, int h, int vw, int vh, const SGMPixel* __restrict__ pixels,
+		const float4* __restrict__ setup, unsigned char* __restrict__ costs) {
+	__shared__ float4 s_w[4][SGM_NT + 1];                              // (wA, wB, wA*(vA-meanA), wB*(vB-meanB)) per tap
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int ppr = (vw + 1) >> 1;                                     // pairs per row
+	const long pair = (long)blockIdx.x * 4 + wave;
+	if (pair >= (long)ppr * vh) return;                                // (no workgroup barrier below: each wave owns its LDS rows)
+	const int row = (int)(pair / ppr), colA = (int)(pair % ppr) * 2;
+	const long pixA = (long)row * vw + colA;
+	const bool hasB = colA + 1 < vw;
+	const SGMPixel pxA = pixels[pixA];
+	SGMPixel pxB; pxB.idx = 0; pxB.minDisp = 0; pxB.maxDisp = 0; pxB.pad = 0;
+	if (hasB) pxB = pixels[pixA + 1];
+	const int nDA = pxA.maxDisp > pxA.minDisp ? pxA.maxDisp - pxA.minDisp : 0;
+	const int nDB = pxB.maxDisp > pxB.minDisp ? pxB.maxDisp - pxB.minDisp : 0;
+	if (nDA == 0 && nDB == 0) return;
+	const int ux = colA + SGM_HW, uy = row + SGM_HW;                   // pixel A in image coordinates; B is at ux + 1
+	const float4 sA = setup[pixA];
+	const float4 sB = hasB ? setup[pixA + 1] : make_float4(1.f, 0.f, 0.f, 0.f);
+	if (lane < SGM_NT) {
+		const int i = lane / 7 - SGM_HW, j = lane % 7 - SGM_HW;
+		float wA = 0.f, wB = 0.f, tA = 0.f, tB = 0.f;
+		if (nDA) { wA = sgm_weight(colorL, w, ux, uy, i, j); tA = wA * (grayL[(size_t)(uy + i) * w + (ux + j)] - sA.y); }
+		if (nDB) { wB = sgm_weight(colorL, w, ux + 1, uy, i, j); tB = wB * (grayL[(size_t)(uy + i) * w + (ux + 1 + j)] - sB.y); }
+		s_w[wave][lane] = make_float4(wA, wB, tA, tB);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	const int nDmax = nDA > nDB ? nDA : nDB;
+#pragma unroll 1
+	for (int k = lane; k < nDmax; k += 64) {
+		asm volatile("" ::: "memory");   // keep the 49 weight reads inside the iteration (hoisted, they occupy 196 VGPRs and spill)
+		const int dA = pxA.minDisp + k, dB = pxB.minDisp + k;
+		const bool actA = k < nDA, actB = k < nDB;
+		const bool inA = actA && !(ux - SGM_HW + dA < 0 || ux + SGM_HW + dA >= w);       // all taps inside the right image (:954-957)
+		const bool inB = actB && !(ux + 1 - SGM_HW + dB < 0 || ux + 1 + SGM_HW + dB >= w);
+		const int cA = inA ? ux + dA : SGM_HW, cB = inB ? ux + 1 + dB : SGM_HW;           // a safe column for lanes that will not use the result
+		sgm_v2f sum = {0.f, 0.f}, sumSq = {0.f, 0.f}, nom = {0.f, 0.f};
+		int n = 0;
+		for (int i = -SGM_HW; i <= SGM_HW; ++i) {
+			const float* rowA = grayR + (size_t)(uy + i) * w + cA;
+			const float* rowB = grayR + (size_t)(uy + i) * w + cB;
 #pragma unroll
-				for (int j = -SGM_HW; j <= SGM_HW; ++j) {
-					const float f = row[j];
-					const float2 pw = s_w[wave][n++];
-					const float fw = f * pw.x;
-					sum += fw; sumSq += f * fw; nom += f * pw.y;
-				}
+			for (int j = -SGM_HW; j <= SGM_HW; ++j) {
+				const sgm_v2f f = {rowA[j], rowB[j]};
+				const float4 pw = s_w[wave][n++];
+				const sgm_v2f pww = {pw.x, pw.y}, pwt = {pw.z, pw.w};
+				const sgm_v2f fw = f * pww;
+				sum += fw; sumSq += f * fw; nom += f * pwt;
 			}
-			const float normSq1 = sumSq - (sum * sum) / sumW;
-			const float ncc = nom / pm_sqrtf(normSq0 * normSq1 + eps);
-			cost = ncc <= 0 ? (unsigned char)255 : (unsigned char)sgm_round2int((1.f - pm_minf(ncc, 1.f)) * 255.f);
 		}
-		costs[px.idx + (unsigned)(d - px.minDisp)] = cost;
+		if (actA) costs[pxA.idx + (unsigned)k] = inA ? sgm_cost_of(sum.x, sumSq.x, nom.x, sA.x, sA.z) : (unsigned char)255;
+		if (actB) costs[pxB.idx + (unsigned)k] = inB ? sgm_cost_of(sum.y, sumSq.y, nom.y, sB.x, sB.z) : (unsigned char)255;
 	}
 }
 
@@ -104,133 +158,150 @@ __device__ __forceinline__ int sgm_wave_min(int v) {
 }
 
 // accums(d) += L(d) (:1020,1043).  The eight path kernels run concurrently on eight streams, so the sum is an atomic add;
-// two u16 sums share a 32-bit word (no carry between halves: a sum never exceeds 8*(255+60) = 2520), and the lane owning
-// the even entry adds its right neighbour's value in the same atomic.  Must be called by all 64 lanes.
-__device__ __forceinline__ void sgm_accumulate(unsigned* words, unsigned long long idx, int k, int nD, int L, int lane) {
-	const int Lnext = __shfl_down(L, 1, 64);                       // value of entry k+1 (lane+1), garbage for lane 63
-	const unsigned long long pos = idx + (unsigned)k;
-	if (k < nD) {
-		if ((pos & 1ull) == 0) {
-			unsigned v = (unsigned)L;
-			if (lane < 63 && k + 1 < nD) v |= (unsigned)Lnext << 16;
-			atomicAdd(words + (pos >> 1), v);
-		} else if (lane == 0 || k == 0) {
-			atomicAdd(words + (pos >> 1), (unsigned)L << 16);       // odd entry whose even partner belongs to nobody in this wave-instruction
-		}
-	}
-	// an odd entry at lane 63+1 of the previous 64-chunk is handled above by (lane == 0); the even entry of lane 63 adds alone
+// two u16 sums share a 32-bit word (no carry between halves: a sum never exceeds 8*(255+60) = 2520).  The lane whose entry sits
+// in the low half adds its right neighbour's value in the same atomic; an entry in a high half whose low-half partner is not in
+// this wave-instruction (lane 0) adds alone.  One predicated atomic per lane, no divergent control flow.  Called by all 64 lanes.
+__device__ __forceinline__ void sgm_accumulate(unsigned* wordsBase, unsigned par, int k, int nD, int L, int lane) {
+	const int Lnext = __shfl_down(L, 1, 64);                       // value of entry k+1 (lane+1); not used by lane 63
+	const unsigned e = ((unsigned)k + par) & 1u;                   // 0: this entry is the low half of its word
+	const bool act = k < nD;
+	const bool pair = lane < 63 && k + 1 < nD;
+	const unsigned val = e == 0u ? ((unsigned)L | (pair ? (unsigned)Lnext << 16 : 0u)) : ((unsigned)L << 16);
+	if (act && (e == 0u || lane == 0)) atomicAdd(wordsBase + (((unsigned)k + par) >> 1), val);
 }
 
 // ---- one path direction, SemiGlobalMatcher.cpp:1003-1046 + ACCUM_PIXELS :1065-1082 -----------
 // One 64-thread workgroup (one wave) per line.  NK = ceil(maxNumDisp / 64) disparities per lane.
 // Line start sets are the threaded variant's (:1083-1200); see the host for the numbering.
+//
+// The step of the recurrence is a chain of dependent instructions executed by one wave, and the whole aggregation is
+// 8 x (pixels) such steps: its cost is the instruction count of a step.  Hence:
+//  * the previous line of L sits in LDS with SGM_INF on both sides (a slot holds logical indices [-MD, 2*MD), MD = 64*NK) and
+//    every step rewrites all of [0, MD) (L or SGM_INF), so Lp(d-1), Lp(d), Lp(d+1) are three unconditional reads at
+//    k + (rsMin - rpMin) and the range tests of the reference reduce to "k > 0" and "k < nD-1";
+//  * the pixel table of the line is staged through LDS 64 pixels at a time by one coalesced load per lane, so no per-pixel
+//    state lives in scalar registers across the chunk (the first version spilled SGPRs into VGPR lanes in every step);
+//  * cost bytes are prefetched one sub-chunk (SGM_T pixels) ahead in registers, A/B double-buffered without register moves;
+//    the single s_waitcnt vmcnt(0) per sub-chunk also drains the accumulate atomics (loads and atomics share the counter, so
+//    the compiler cannot wait for less);
+//  * the workgroup is one wave and the LDS executes a wave's instructions in order: no barrier between steps.
+#define SGM_TT 64        // pixels per pixel-table chunk
+struct SGMStep { int rpMin, rpMax, cur; float Ip; };
+
+template <int NK>
+__device__ __forceinline__ void sgm_step(int* sL, const unsigned short* sP2, const SGMPixel& px, float g, const unsigned char* c8,
+		unsigned* accumWords, int P1, int lane, SGMStep& st) {
+	constexpr int MD = 64 * NK, SL = 3 * MD;
+	const int rsMin = px.minDisp, rsMax = px.maxDisp, nD = rsMax - rsMin;
+	if (nD <= 0) return;                                            // invalid pixels do not reset Lp / Ip (:1071-1072)
+	const float DI = g - st.Ip;
+	int ip = sgm_round2int(255.f * DI); ip = ip < 0 ? -ip : ip;
+	const int P2 = sP2[ip];
+	const int lo = max(st.rpMin, rsMin), hi = min(st.rpMax, rsMax);
+	const int* Lp = sL + st.cur * SL + MD + (rsMin - st.rpMin);     // Lp[k] = previous L at the disparity of entry k
+	int* Ls = sL + (st.cur ^ 1) * SL + MD;
+	unsigned* wordsBase = accumWords + (px.idx >> 1);
+	const unsigned par = (unsigned)(px.idx & 1ull);
+	if (lo >= hi) {                                                 // no common disparity (also the first pixel of a line)
+#pragma unroll
+		for (int q = 0; q < NK; ++q) {
+			const int k = lane + 64 * q;
+			const int L = (int)c8[q] + P2;
+			Ls[k] = k < nD ? L : SGM_INF;
+			sgm_accumulate(wordsBase, par, k, nD, L, lane);
+		}
+	} else {
+		int a0[NK], am[NK], ap[NK];
+		int m = SGM_INF;
+#pragma unroll
+		for (int q = 0; q < NK; ++q) {
+			const int k = lane + 64 * q;
+			a0[q] = k < nD ? Lp[k] : SGM_INF; am[q] = Lp[k - 1]; ap[q] = Lp[k + 1];
+			m = min(m, a0[q]);
+		}
+		m = sgm_wave_min(m);
+#pragma unroll
+		for (int q = 0; q < NK; ++q) {
+			const int k = lane + 64 * q;
+			const int side = min(k > 0 ? am[q] : SGM_INF, k < nD - 1 ? ap[q] : SGM_INF) + P1;
+			const int best = min(min(m + P2, a0[q]), side);
+			const int L = (int)c8[q] + best - m;
+			Ls[k] = k < nD ? L : SGM_INF;
+			sgm_accumulate(wordsBase, par, k, nD, L, lane);
+		}
+	}
+	st.rpMin = rsMin; st.rpMax = rsMax; st.Ip = g; st.cur ^= 1;
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
 template <int NK>
 __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ grayL, int w, int vw, int vh,
 		const SGMPixel* __restrict__ pixels, const unsigned char* __restrict__ costs, unsigned* __restrict__ accumWords,
 		const unsigned short* __restrict__ P2s, int P1, int dx, int dy, SGMLines ln, int maxNumDisp) {
-	extern __shared__ __attribute__((aligned(16))) int s_L[]; // 2 x (maxNumDisp + 2): previous / current line of L
+	constexpr int MD = 64 * NK, SL = 3 * MD;
+	__shared__ int s_L[2 * SL];
+	__shared__ unsigned short s_P2[256];
+	__shared__ SGMPixel s_px[2][SGM_TT];
+	__shared__ float s_g[2][SGM_TT];
 	const int lane = threadIdx.x;
 	const int line = blockIdx.x;
 	int x, y;
 	if (line < ln.nA) { x = ln.ax + line * ln.adx; y = ln.ay + line * ln.ady; }
 	else { const int i = line - ln.nA; x = ln.bx + i * ln.bdx; y = ln.by + i * ln.bdy; }
-	const int stride = maxNumDisp + 2;
-	int cur = 0;
-	int rpMin = 0, rpMax = 0;
-	float Ip = 0.5f;
-	for (int k = lane; k < 2 * stride; k += 64) s_L[k] = 0;
-	// the P2 table is indexed by a value computed inside the recurrence: keep it in LDS so the chain never waits on HBM
-	__shared__ unsigned short s_P2[256];
+	for (int k = lane; k < 2 * SL; k += 64) s_L[k] = SGM_INF;
 	for (int k = lane; k < 256; k += 64) s_P2[k] = P2s[k];
-	__syncthreads();
-	// Software pipeline over chunks of SGM_T pixels: while chunk k is consumed (a serial recurrence), the cost bytes
-	// and running sums of chunk k+1 and the pixel table of chunk k+2 are already in flight, so no step of the
-	// recurrence waits on HBM.  Chunk state lives in registers (fully unrolled arrays).
-	SGMPixel pxA[SGM_T], pxB[SGM_T]; float gA[SGM_T], gB[SGM_T]; bool okA[SGM_T], okB[SGM_T];
-	unsigned char cA[SGM_T][NK], cB[SGM_T][NK];
-	auto loadPixels = [&](int cx, int cy, SGMPixel* px, float* g, bool* ok) {
-#pragma unroll
-		for (int t = 0; t < SGM_T; ++t) {
-			const int tx = cx + t * dx, ty = cy + t * dy;
-			ok[t] = tx >= 0 && ty >= 0 && tx < vw && ty < vh;
-			px[t].idx = 0; px[t].minDisp = 0; px[t].maxDisp = 0; g[t] = 0.f;
-			if (ok[t]) {
-				px[t] = pixels[(size_t)ty * vw + tx];
-				g[t] = grayL[(size_t)ty * w + tx]; // imageGray(u) with the valid-grid coordinate: the reference's quirk (:1078)
-			}
+	// pixel-table chunk: lane t owns pixel t of the chunk
+	auto tableLoad = [&](int cx, int cy, SGMPixel& px, float& g) {
+		const int tx = cx + lane * dx, ty = cy + lane * dy;
+		px.idx = 0; px.minDisp = 0; px.maxDisp = 0; px.pad = 0; g = 0.f;
+		if (tx >= 0 && ty >= 0 && tx < vw && ty < vh) {
+			px = pixels[(size_t)ty * vw + tx];
+			g = grayL[(size_t)ty * w + tx]; // imageGray(u) with the valid-grid coordinate: the reference's quirk (:1078)
 		}
 	};
-	auto loadCosts = [&](const SGMPixel* px, bool* ok, unsigned char (*c8)[NK]) {
+	auto costLoad = [&](int slot, int t0, unsigned char (*c8)[NK]) {   // cost bytes of pixels t0..t0+SGM_T-1 of table slot `slot`
 #pragma unroll
 		for (int t = 0; t < SGM_T; ++t) {
-			const int nD = px[t].maxDisp - px[t].minDisp;
-			ok[t] = ok[t] && nD > 0;
+			const SGMPixel px = s_px[slot][t0 + t];
+			const int nD = px.maxDisp - px.minDisp;
 #pragma unroll
 			for (int q = 0; q < NK; ++q) {
 				const int k = lane + 64 * q;
 				c8[t][q] = 0;
-				if (ok[t] && k < nD) c8[t][q] = costs[px[t].idx + k];
+				if (k < nD) c8[t][q] = costs[px.idx + k];
 			}
 		}
 	};
-	loadPixels(x, y, pxA, gA, okA);
-	loadCosts(pxA, okA, cA);
-	loadPixels(x + SGM_T * dx, y + SGM_T * dy, pxB, gB, okB);
+	SGMPixel tpx; float tg;
+	tableLoad(x, y, tpx, tg);
+	s_px[0][lane] = tpx; s_g[0][lane] = tg;                         // (waits for the loads)
+	tableLoad(x + SGM_TT * dx, y + SGM_TT * dy, tpx, tg);           // chunk 1, in flight
+	__syncthreads();
+	unsigned char cA[SGM_T][NK], cB[SGM_T][NK];
+	costLoad(0, 0, cA);
+	SGMStep st; st.rpMin = 0; st.rpMax = 0; st.cur = 0; st.Ip = 0.5f;
+	int slot = 0;
 	while (x >= 0 && y >= 0 && x < vw && y < vh) {
-		loadCosts(pxB, okB, cB);                                      // chunk k+1: cost bytes
-		SGMPixel pxC[SGM_T]; float gC[SGM_T]; bool okC[SGM_T];
-		loadPixels(x + 2 * SGM_T * dx, y + 2 * SGM_T * dy, pxC, gC, okC); // chunk k+2: pixel table
-		// ---- consume chunk k serially ------------------------------------------------------------
+		// table of the next chunk: complete by now (requested a whole chunk ago); park it in the other slot and request the one after
+		__builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
+		s_px[slot ^ 1][lane] = tpx; s_g[slot ^ 1][lane] = tg;
+		tableLoad(x + 2 * SGM_TT * dx, y + 2 * SGM_TT * dy, tpx, tg);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+		for (int t0 = 0; t0 < SGM_TT; t0 += 2 * SGM_T) {
+			// sub-chunk A is in registers (or arriving); request B, consume A; then request the next A, consume B
+			__builtin_amdgcn_s_waitcnt(0x0F70);
+			costLoad(slot, t0 + SGM_T, cB);
 #pragma unroll
-		for (int t = 0; t < SGM_T; ++t) {
-			if (!okA[t]) continue; // invalid pixels do not reset Lp / Ip (:1071-1072)
-			const int rsMin = pxA[t].minDisp, rsMax = pxA[t].maxDisp, nD = rsMax - rsMin;
-			const float DI = gA[t] - Ip;
-			int ip = sgm_round2int(255.f * DI); ip = ip < 0 ? -ip : ip;
-			const int P2 = s_P2[ip];
-			const int lo = max(rpMin, rsMin), hi = min(rpMax, rsMax);
-			const int* Lp = s_L + cur * stride + 1;       // Lp[d - rpMin]
-			int* Ls = s_L + (cur ^ 1) * stride + 1;        // Ls[d - rsMin]
-			if (lo >= hi) {
+			for (int t = 0; t < SGM_T; ++t) sgm_step<NK>(s_L, s_P2, s_px[slot][t0 + t], s_g[slot][t0 + t], cA[t], accumWords, P1, lane, st);
+			__builtin_amdgcn_s_waitcnt(0x0F70);
+			if (t0 + 2 * SGM_T < SGM_TT) costLoad(slot, t0 + 2 * SGM_T, cA); else costLoad(slot ^ 1, 0, cA);
 #pragma unroll
-				for (int q = 0; q < NK; ++q) {
-					const int k = lane + 64 * q;
-					const int L = (int)cA[t][q] + P2;
-					if (k < nD) Ls[k] = L;
-					sgm_accumulate(accumWords, pxA[t].idx, k, nD, L, lane);
-				}
-			} else {
-				int m = SGM_INF;
-				for (int dp = lo + lane; dp < hi; dp += 64) m = min(m, Lp[dp - rpMin]);
-				m = sgm_wave_min(m);
-#pragma unroll
-				for (int q = 0; q < NK; ++q) {
-					const int k = lane + 64 * q;
-					int L = 0;
-					if (k < nD) {
-						const int d = rsMin + k;
-						int best = m + P2;
-						if (d >= lo && d < hi) best = min(best, Lp[d - rpMin]);
-						if (d - 1 >= lo && d - 1 < hi) best = min(best, Lp[d - 1 - rpMin] + P1);
-						if (d + 1 >= lo && d + 1 < hi) best = min(best, Lp[d + 1 - rpMin] + P1);
-						L = (int)cA[t][q] + best - m;
-						Ls[k] = L;
-					}
-					sgm_accumulate(accumWords, pxA[t].idx, k, nD, L, lane);
-				}
-			}
-			rpMin = rsMin; rpMax = rsMax; Ip = gA[t]; cur ^= 1;
-			__syncthreads();
+			for (int t = 0; t < SGM_T; ++t) sgm_step<NK>(s_L, s_P2, s_px[slot][t0 + SGM_T + t], s_g[slot][t0 + SGM_T + t], cB[t], accumWords, P1, lane, st);
 		}
-		x += SGM_T * dx; y += SGM_T * dy;
-		// rotate the pipeline registers
-#pragma unroll
-		for (int t = 0; t < SGM_T; ++t) {
-			pxA[t] = pxB[t]; gA[t] = gB[t]; okA[t] = okB[t];
-			pxB[t] = pxC[t]; gB[t] = gC[t]; okB[t] = okC[t];
-#pragma unroll
-			for (int q = 0; q < NK; ++q) cA[t][q] = cB[t][q];
-		}
+		x += SGM_TT * dx; y += SGM_TT * dy; slot ^= 1;
 	}
 }
 

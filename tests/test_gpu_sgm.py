@@ -35,7 +35,8 @@ def test_p2s_match(matcher):
 
 
 @pytest.mark.parametrize("w,h,kind,dmin,dmax", [(96, 64, "uniform", 0, 16), (96, 64, "uniform", -8, 56), (128, 80, "ragged", -4, 60),
-                                               (70, 150, "ragged", -3, 30), (160, 96, "uniform", -10, 118), (120, 90, "ragged", 0, 200)])
+                                               (70, 150, "ragged", -3, 30), (160, 96, "uniform", -10, 118), (120, 90, "ragged", 0, 200),
+                                               (97, 65, "ragged", -5, 40), (203, 71, "uniform", 0, 70)])   # odd valid widths: the last pixel of a row has no pair partner
 def test_match_parity(matcher, w, h, kind, dmin, dmax):
     lb, lg, rg = sc.stereo_pair(w, h, 5, seed=w)
     px, n, mx = sc.ranges(w, h, kind, dmin, dmax, seed=h)

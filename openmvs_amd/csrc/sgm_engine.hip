@@ -11,7 +11,6 @@
 
 struct sgmhip_engine {
 	int device = 0; hipStream_t stream = nullptr; std::string err;
-	hipStream_t pstream[8] = {}; hipEvent_t forkEv = nullptr, joinEv[8] = {}; // the eight path directions run concurrently
 	int w = 0, h = 0, vw = 0, vh = 0, maxNumDisp = 0; uint64_t numCosts = 0;
 	size_t capImg = 0, capPix = 0, capCosts = 0;
 	unsigned char* d_color = nullptr; float* d_grayL = nullptr; float* d_grayR = nullptr;
@@ -48,8 +47,6 @@ int sgmhip_create(int device, sgmhip_engine** out) {
 	if (device < 0) device = 0;
 	sgmhip_engine* e = new sgmhip_engine(); e->device = device;
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&e->d_P2s, 512) != hipSuccess) { delete e; return SGMHIP_E_HIP; }
-	for (int i = 0; i < 8; ++i) if (hipStreamCreateWithFlags(&e->pstream[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->joinEv[i], hipEventDisableTiming) != hipSuccess) { delete e; return SGMHIP_E_HIP; }
-	if (hipEventCreateWithFlags(&e->forkEv, hipEventDisableTiming) != hipSuccess) { delete e; return SGMHIP_E_HIP; }
 	*out = e;
 	return 0;
 }
@@ -58,8 +55,6 @@ void sgmhip_destroy(sgmhip_engine* e) {
 	hipSetDevice(e->device); hipStreamSynchronize(e->stream);
 	for (auto& ev : e->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
 	sgmFree(e); if (e->d_P2s) hipFree(e->d_P2s);
-	for (int i = 0; i < 8; ++i) { if (e->pstream[i]) hipStreamDestroy(e->pstream[i]); if (e->joinEv[i]) hipEventDestroy(e->joinEv[i]); }
-	if (e->forkEv) hipEventDestroy(e->forkEv);
 	hipStreamDestroy(e->stream); delete e;
 }
 const char* sgmhip_last_error(sgmhip_engine* e) { return e ? e->err.c_str() : "null engine"; }
@@ -92,11 +87,11 @@ int sgmhip_set_problem(sgmhip_engine* e, const uint8_t* leftBGR, const float* le
 	return 0;
 }
 
-static void launchPath(sgmhip_engine* e, hipStream_t st, int NK, int lines, size_t shmem, int P1, int dx, int dy, const SGMLines& ln) {
+static void launchPath(sgmhip_engine* e, hipStream_t st, int NK, int lines, int P1, const SGMDirs& dirs) {
 	switch (NK) {
-	case 1: hipLaunchKernelGGL((sgm_path_kernel<1>), dim3(lines), dim3(64), shmem, st, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, P1, dx, dy, ln, e->maxNumDisp); break;
-	case 2: hipLaunchKernelGGL((sgm_path_kernel<2>), dim3(lines), dim3(64), shmem, st, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, P1, dx, dy, ln, e->maxNumDisp); break;
-	default: hipLaunchKernelGGL((sgm_path_kernel<4>), dim3(lines), dim3(64), shmem, st, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, P1, dx, dy, ln, e->maxNumDisp); break;
+	case 1: hipLaunchKernelGGL((sgm_path_kernel<1>), dim3(lines), dim3(64), 0, st, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, P1, dirs); break;
+	case 2: hipLaunchKernelGGL((sgm_path_kernel<2>), dim3(lines), dim3(64), 0, st, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, P1, dirs); break;
+	default: hipLaunchKernelGGL((sgm_path_kernel<4>), dim3(lines), dim3(64), 0, st, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, P1, dirs); break;
 	}
 }
 
@@ -113,7 +108,6 @@ int sgmhip_match(sgmhip_engine* e, uint16_t P1, const uint16_t P2s[256], int syn
 	evE(e);
 	SGMCHK(e, hipMemsetAsync(e->d_accums, 0, (e->numCosts + 1) / 2 * 4, e->stream)); // imageAccumCosts.Memset(0), :990
 	const int NK = e->maxNumDisp <= 64 ? 1 : (e->maxNumDisp <= 128 ? 2 : 4);
-	const size_t shmem = sizeof(int) * 2 * (size_t)(e->maxNumDisp + 2);
 	// the eight paths with the threaded variant's start sets, SemiGlobalMatcher.cpp:1083-1200
 	struct Dir { int dx, dy; SGMLines ln; } dirs[8] = {
 		{0, 1,   {W, 0, 0, 1, 0,      0, 0, 0, 0, 0}},            // width-down
@@ -125,17 +119,20 @@ int sgmhip_match(sgmhip_engine* e, uint16_t P1, const uint16_t P2s[256], int syn
 		{1, -1,  {W - 1, 1, H - 1, 1, 0,  H, 0, 0, 0, 1}},        // right-up: bottom row x >= 1, then left column
 		{-1, -1, {W, 0, H - 1, 1, 0,  H - 1, W - 1, 0, 0, 1}},    // left-up: bottom row, then right column y <= H-2
 	};
-	evB(e, 1);
-	SGMCHK(e, hipEventRecord(e->forkEv, e->stream));
+	// one grid for all of them, the directions with the longest lines first (their chains bound the kernel's duration)
+	const int horizFirst[8] = {1, 3, 0, 2, 4, 5, 6, 7}, vertFirst[8] = {0, 2, 1, 3, 4, 5, 6, 7};
+	const int* ord = W >= H ? horizFirst : vertFirst;
+	SGMDirs sd; memset(&sd, 0, sizeof(sd));
+	int total = 0;
 	for (int i = 0; i < 8; ++i) {
-		const Dir& d = dirs[i];
-		const int lines = d.ln.nA + d.ln.nB;
-		SGMCHK(e, hipStreamWaitEvent(e->pstream[i], e->forkEv, 0));
-		if (lines > 0) launchPath(e, e->pstream[i], NK, lines, shmem, (int)P1, d.dx, d.dy, d.ln);
-		SGMCHK(e, hipEventRecord(e->joinEv[i], e->pstream[i]));
-		SGMCHK(e, hipStreamWaitEvent(e->stream, e->joinEv[i], 0));
-		if (e->statsOn) e->stats.aggrLaunches += 1;
+		const Dir& d = dirs[ord[i]];
+		sd.dx[i] = d.dx; sd.dy[i] = d.dy; sd.ln[i] = d.ln; sd.first[i] = total;
+		total += d.ln.nA + d.ln.nB;
 	}
+	sd.first[8] = total;
+	evB(e, 1);
+	if (total > 0) launchPath(e, e->stream, NK, total, (int)P1, sd);
+	if (e->statsOn) e->stats.aggrLaunches += 1;
 	evE(e);
 	evB(e, 2);
 	hipLaunchKernelGGL(sgm_wta_kernel, dim3((unsigned)((nPix + 3) / 4)), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, e->d_cost);

@@ -235,17 +235,26 @@ __device__ __forceinline__ void sgm_step(int* sL, const unsigned short* sP2, con
 	__builtin_amdgcn_wave_barrier();
 }
 
+// All eight directions in one grid: the lines of direction i are the workgroups first[i] .. first[i+1]-1.  (Eight launches on eight
+// streams shared four hardware queues and overlapped only ~2.4x.)  The host lists the directions longest lines first.
+struct SGMDirs { int dx[8], dy[8]; SGMLines ln[8]; int first[9]; };
+
 template <int NK>
 __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ grayL, int w, int vw, int vh,
 		const SGMPixel* __restrict__ pixels, const unsigned char* __restrict__ costs, unsigned* __restrict__ accumWords,
-		const unsigned short* __restrict__ P2s, int P1, int dx, int dy, SGMLines ln, int maxNumDisp) {
+		const unsigned short* __restrict__ P2s, int P1, SGMDirs dirs) {
 	constexpr int MD = 64 * NK, SL = 3 * MD;
 	__shared__ int s_L[2 * SL];
 	__shared__ unsigned short s_P2[256];
 	__shared__ SGMPixel s_px[2][SGM_TT];
 	__shared__ float s_g[2][SGM_TT];
 	const int lane = threadIdx.x;
-	const int line = blockIdx.x;
+	int dir = 0;
+#pragma unroll
+	for (int i = 1; i < 8; ++i) dir += (int)blockIdx.x >= dirs.first[i] ? 1 : 0;
+	const int line = (int)blockIdx.x - dirs.first[dir];
+	const int dx = dirs.dx[dir], dy = dirs.dy[dir];
+	const SGMLines ln = dirs.ln[dir];
 	int x, y;
 	if (line < ln.nA) { x = ln.ax + line * ln.adx; y = ln.ay + line * ln.ady; }
 	else { const int i = line - ln.nA; x = ln.bx + i * ln.bdx; y = ln.by + i * ln.bdy; }

@@ -146,6 +146,8 @@ int pmhip_scene_gap_interpolation(pmhip_engine* e, const int32_t* viewIds, int n
  * `order` lists the views to fuse, best connected first (the reference sorts by Image::neighbors.size(), :1423-1450); each view uses
  * the neighbour list given to pmhip_scene_set_view (the IDs stored in its .dmap).  Runs on working copies: the scene's maps are not
  * modified.  Point order, views, weights, positions, colours and normals equal the sequential reference (see csrc/pm_fuse.h).
+ * nMinViewsFuse < 2 selects DepthMapsData::MergeDepthMaps instead (:1305-1368, as Scene::DenseReconstruction does, :1695-1698): every valid
+ * depth becomes a single-view point (pass the views in index order; weights come back 0, the reference produces none).
  * Defaults (DepthMap.cpp:75,92,93,101,102): nMinViewsFuse 2, fDepthDiffThreshold 0.01, fNormalDiffThreshold 25, colours and normals on. */
 typedef struct PMHipFuseParams {
 	uint32_t nMinViewsFuse;

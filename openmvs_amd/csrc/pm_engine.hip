@@ -966,6 +966,14 @@ int pmhip_scene_fuse(pmhip_engine* e, const int32_t* order, int nOrder, const PM
 		c.nMinViewsFuse = nMin; c.fDepthDiffThreshold = prm->fDepthDiffThreshold; c.normalError = normalError;
 		c.bEstimateColor = wantColor ? 1 : 0; c.bEstimateNormal = wantNormal ? 1 : 0;
 		c.recN = f.recN; c.recX = f.recX; c.recView = f.recView; c.recWeight = f.recWeight; c.recProj = f.recProj; c.recColor = f.recColor; c.recNormal = f.recNormal;
+		if (prm->nMinViewsFuse < 2) {   // MergeDepthMaps (Scene::DenseReconstruction, SceneDensify.cpp:1695-1698)
+			hipLaunchKernelGGL(pmfu_merge_kernel, dim3((unsigned)std::min<size_t>((P + 255) / 256, 4096)), dim3(256), 0, e->stream, c, f.nDepthsDev);
+			hipLaunchKernelGGL(pmfu_tile_sums, dim3(nTiles), dim3(PMFU_TB), 0, e->stream, f.recN, (uint32_t)P, f.tileSums);
+			hipLaunchKernelGGL(pmfu_scan_tiles, dim3(1), dim3(1024), 0, e->stream, f.tileSums, nTiles, f.counters + 2, f.tileOff);
+			hipLaunchKernelGGL(pmfu_scatter_kernel, dim3(nTiles), dim3(PMFU_TB), 0, e->stream, c, f.tileOff, out);
+			HIPCHK(e, hipGetLastError());
+			continue;
+		}
 		HIPCHK(e, hipMemsetAsync(f.counters, 0, sizeof(uint32_t) * 2, e->stream));
 		hipLaunchKernelGGL(pmfu_seed_kernel, dim3((unsigned)std::min<size_t>((P + 255) / 256, 4096)), dim3(256), 0, e->stream, c, f.pend[0], f.counters, f.nDepthsDev);
 		HIPCHK(e, hipMemcpyAsync(f.pin, f.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));

@@ -202,3 +202,23 @@ PM_HD void pmfu_commit(const PMFuseCtx& c, uint32_t p) {
 	}
 	for (int m = 0; m < nInvalid; ++m) c.depth[invalid[m]] = 0.f;
 }
+
+// DepthMapsData::MergeDepthMaps (SceneDensify.cpp:1305-1368), used when nMinViewsFuse < 2: every valid depth of image A becomes a
+// point with that single view, the image's own colour and the normal of DepthData::GetNormal (R^T n, DepthMap.cpp:137-146); no
+// weights are produced (the reference leaves PointCloud::pointWeights empty; the record carries 0).
+PM_HD void pmfu_merge(const PMFuseCtx& c, uint32_t p) {
+	const size_t P = (size_t)c.w * c.h;
+	const size_t xa = (size_t)c.A * P + p;
+	const float depth = c.depth[xa];
+	if (depth == 0) { c.recN[p] = 0; return; }
+	float point[3]; pmfu_seed_point(c, p, depth, point);
+	c.recN[p] = 1;
+	for (int k = 0; k < 3; ++k) c.recX[(size_t)k * P + p] = point[k];
+	c.recView[p] = (uint32_t)c.A; c.recWeight[p] = 0.f; c.recProj[p] = (p % (uint32_t)c.w) | ((p / (uint32_t)c.w) << 16);
+	if (c.bEstimateColor) for (int k = 0; k < 3; ++k) c.recColor[(size_t)k * P + p] = c.bgr ? c.bgr[xa * 3 + k] : (uint8_t)0;
+	if (c.bEstimateNormal) {
+		float n[3] = {0.f, 0.f, -1.f};
+		if (c.normal) pmfu_normalW(c.cams[c.A], c.normal + xa * 3, n);
+		for (int k = 0; k < 3; ++k) c.recNormal[(size_t)k * P + p] = n[k];
+	}
+}

@@ -45,6 +45,14 @@ __global__ __launch_bounds__(256) void pmfu_commit_kernel(PMFuseCtx c, const uin
 	else next[atomicAdd(nNext, 1u)] = p;
 }
 
+__global__ __launch_bounds__(256) void pmfu_merge_kernel(PMFuseCtx c, unsigned long long* nDepths) {
+	const uint32_t P = (uint32_t)c.w * (uint32_t)c.h;
+	unsigned cnt = 0;
+	for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) { pmfu_merge(c, p); cnt += c.recN[p]; }
+	for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+	if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(nDepths, (unsigned long long)cnt);
+}
+
 // ---- compaction ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PMFU_TB) void pmfu_tile_sums(const uint8_t* recN, uint32_t P, uint2* tileSums) {
 	__shared__ uint32_t sc[PMFU_TB], sv[PMFU_TB];

@@ -207,4 +207,37 @@ int orc_fuse_depth_maps(const OrcFuseView* views_, int nImages, int w, int h, co
 	return 0;
 }
 
+// DepthMapsData::MergeDepthMaps (SceneDensify.cpp:1305-1368): images in index order, every depth != 0 a point of its own.
+int orc_merge_depth_maps(const OrcFuseView* views_, int nImages, int w, int h, int bEstimateColor, int bEstimateNormal, OrcFuseCloud* out) {
+	memset(out, 0, sizeof(*out));
+	const size_t P = (size_t)w * h;
+	std::vector<float> pts, nrm; std::vector<uint32_t> vws; std::vector<uint16_t> prj; std::vector<uint8_t> col;
+	for (int a = 0; a < nImages; ++a) {
+		const OrcFuseView& v = views_[a];
+		if (!v.depth) continue;
+		Cam cam; memcpy(cam.K, v.K, 72); memcpy(cam.R, v.R, 72); memcpy(cam.C, v.C, 24);
+		for (int i = 0; i < h; ++i) for (int j = 0; j < w; ++j) {
+			const size_t x = (size_t)i * w + j;
+			const float depth = v.depth[x];
+			if (depth == 0) continue;
+			double X[3]; I2W(cam, (double)(float)j, (double)(float)i, (double)depth, X);
+			for (int k = 0; k < 3; ++k) pts.push_back((float)X[k]);
+			vws.push_back((uint32_t)a); prj.push_back((uint16_t)j); prj.push_back((uint16_t)i);
+			if (bEstimateColor) for (int k = 0; k < 3; ++k) col.push_back(v.bgr ? v.bgr[x * 3 + k] : (uint8_t)0);
+			if (bEstimateNormal) { float n[3] = {0, 0, -1}; if (v.normal) normalW(cam, v.normal + x * 3, n); for (int k = 0; k < 3; ++k) nrm.push_back(n[k]); }
+		}
+	}
+	(void)P;
+	const size_t n = vws.size();
+	out->nPoints = out->nDepths = out->nViews = n;
+	out->points = (float*)malloc(12 * n + 8); memcpy(out->points, pts.data(), 12 * n);
+	out->viewStart = (uint32_t*)malloc(4 * (n + 1)); for (size_t i = 0; i <= n; ++i) out->viewStart[i] = (uint32_t)i;
+	out->views = (uint32_t*)malloc(4 * n + 8); memcpy(out->views, vws.data(), 4 * n);
+	out->weights = (float*)calloc(n + 1, 4);
+	out->projs = (uint16_t*)malloc(4 * n + 8); memcpy(out->projs, prj.data(), 4 * n);
+	if (bEstimateColor) { out->colors = (uint8_t*)malloc(3 * n + 8); memcpy(out->colors, col.data(), 3 * n); }
+	if (bEstimateNormal) { out->normals = (float*)malloc(12 * n + 8); memcpy(out->normals, nrm.data(), 12 * n); }
+	return 0;
+}
+
 } // extern "C"

@@ -270,6 +270,10 @@ def fuse_depth_maps(depths, normals, confs, bgrs, K, R, Cc, neighbors, order=Non
         order = fuse_order([len(x) for x in neighbors], [d is not None for d in depths])
     od = np.ascontiguousarray(order, np.uint32)
     out = OrcFuseCloud()
+    if nMinViewsFuse < 2 and fn is None:           # Scene::DenseReconstruction picks MergeDepthMaps then (SceneDensify.cpp:1695-1698)
+        lib().orc_merge_depth_maps.restype = C.c_int
+        rc = lib().orc_merge_depth_maps(arr, C.c_int(n), C.c_int(w), C.c_int(h), C.c_int(1 if bEstimateColor else 0), C.c_int(1 if bEstimateNormal else 0), C.byref(out))
+        return _cloud(out, rc, lib().orc_fuse_free)
     f = fn or lib().orc_fuse_depth_maps
     f.restype = C.c_int
     # COS(FD2R(x)) in float with the C library's cosf, the same call the engine makes (numpy's float32 cos may differ in the last bit)
@@ -277,6 +281,10 @@ def fuse_depth_maps(depths, normals, confs, bgrs, K, R, Cc, neighbors, order=Non
     normalError = libm.cosf(float(np.float32(fNormalDiffThreshold) * (np.float32(3.14159265358979323846) / np.float32(180))))
     rc = f(arr, C.c_int(n), C.c_int(w), C.c_int(h), od.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int(len(od)), C.c_uint(nMinViewsFuse),
            C.c_float(fDepthDiffThreshold), C.c_float(float(normalError)), C.c_int(1 if bEstimateColor else 0), C.c_int(1 if bEstimateNormal else 0), C.byref(out))
+    return _cloud(out, rc, lib().orc_fuse_free if fn is None else getattr(fn, "_free", lib().orc_fuse_free))
+
+
+def _cloud(out, rc, free):
     if rc != 0:
         raise RuntimeError(f"fuse failed: {rc}")
     P, V = int(out.nPoints), int(out.nViews)
@@ -288,6 +296,5 @@ def fuse_depth_maps(depths, normals, confs, bgrs, K, R, Cc, neighbors, order=Non
                projs=take(out.projs, 2 * V, np.uint16).reshape(V, 2),
                colors=None if not out.colors else take(out.colors, 3 * P, np.uint8).reshape(P, 3),
                normals=None if not out.normals else take(out.normals, 3 * P, np.float32).reshape(P, 3))
-    free = (lib().orc_fuse_free if fn is None else getattr(fn, "_free", lib().orc_fuse_free))
     free(C.byref(out))
     return res

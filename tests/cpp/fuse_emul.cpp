@@ -26,6 +26,7 @@ static void shuffle(std::vector<uint32_t>& v, uint64_t& st, int mode) {
 int emu_fuse_depth_maps(const EmuFuseView* vs, int nImages, int w, int h, const uint32_t* order, int nOrder, unsigned nMinViewsFuse,
 		float fDepthDiffThreshold, float normalError, int bEstimateColor, int bEstimateNormal, EmuFuseCloud* out) {
 	memset(out, 0, sizeof(*out));
+	const bool merge = nMinViewsFuse < 2;          // MergeDepthMaps, as the engine routes it
 	const char* m = getenv("EMU_FUSE_ORDER");
 	const int mode = m ? atoi(m) : 2;
 	uint64_t st = 12345;
@@ -71,6 +72,11 @@ int emu_fuse_depth_maps(const EmuFuseView* vs, int nImages, int w, int h, const 
 		c.recColor = recColor.data(); c.recNormal = recNormal.data();
 		std::fill(recN.begin(), recN.end(), 0);
 		std::vector<uint32_t> pending, next;
+		if (merge) {                                           // the merge kernel, threads in a shuffled order
+			std::vector<uint32_t> all(P); for (uint32_t p = 0; p < (uint32_t)P; ++p) all[p] = p;
+			shuffle(all, st, mode);
+			for (uint32_t p : all) { pmfu_merge(c, p); nDepths += recN[p]; }
+		} else
 		for (uint32_t p = 0; p < (uint32_t)P; ++p) {          // the seed kernel
 			if (depth[P * A + p] == 0) continue;
 			++nDepths;

@@ -105,3 +105,19 @@ def test_emulation_with_missing_depth_maps_and_custom_order(emul, small_scene):
     b = po.fuse_depth_maps(d, n, c, list(sc.bgr), sc.K, sc.R, sc.C, [list(x) for x in sc.neighbors], order=order, fn=emul.emu_fuse_depth_maps)
     fc.same_cloud(b, a, "missing map")
     assert 3 not in set(a["views"]) and a["nPoints"] > 0
+
+
+def test_merge_depth_maps_mode(emul, small_scene):
+    """nMinViewsFuse < 2 = DepthMapsData::MergeDepthMaps: every valid depth is a single-view point, images in index order."""
+    sc = small_scene
+    maps = fc.make_maps(sc, seed=6)
+    order = list(range(sc.n_views))
+    a = _fuse(sc, maps, nMinViewsFuse=1, order=order)
+    assert a["nPoints"] == a["nDepths"] == sum(int((d > 0).sum()) for d in maps[0])
+    assert np.all(np.diff(a["viewStart"]) == 1) and np.all(np.diff(a["views"].astype(np.int64)) >= 0) and not a["weights"].any()
+    v, xy = a["views"], a["projs"]
+    assert np.array_equal(a["colors"], sc.bgr[v, xy[:, 1], xy[:, 0]])
+    z = np.einsum("ij,ij->i", a["points"].astype(np.float64) - sc.C[v], sc.R[v][:, 2])
+    assert np.allclose(z, np.stack(maps[0])[v, xy[:, 1], xy[:, 0]], rtol=1e-5)
+    b = _fuse(sc, maps, nMinViewsFuse=1, order=order, fn=emul.emu_fuse_depth_maps)
+    fc.same_cloud(b, a, "merge")

@@ -42,6 +42,20 @@ def test_device_fuse_is_the_sequential_fuse(small_scene, nine_scene, case):
     e.close()
 
 
+def test_device_merge_mode(small_scene):
+    """nMinViewsFuse < 2 routes to MergeDepthMaps (SceneDensify.cpp:1305-1368)."""
+    sc = small_scene
+    maps = fc.make_maps(sc, seed=6)
+    e = PatchMatchHIP(0)
+    _load(e, sc, maps)
+    order = list(range(sc.n_views))
+    got = e.scene_fuse(order, nMinViewsFuse=1)
+    ref = po.fuse_depth_maps(*maps, list(sc.bgr), sc.K, sc.R, sc.C, [list(x) for x in sc.neighbors], order=order, nMinViewsFuse=1)
+    fc.same_cloud(got, ref, "merge")
+    assert got["nPoints"] == sum(int((d > 0).sum()) for d in maps[0])
+    e.close()
+
+
 def test_device_fuse_custom_order_and_errors(small_scene):
     sc = small_scene
     maps = fc.make_maps(sc, seed=5)

@@ -118,6 +118,13 @@ int pmhip_scene_commit_round(pmhip_engine* e);
 int pmhip_scene_reset_view(pmhip_engine* e, int idx);
 /* Provide an initial depth/normal estimate (host pointers, nullable each). */
 int pmhip_scene_set_maps(pmhip_engine* e, int idx, const float* depth, const float* normal);
+/* Ignore mask of a view (OPTDENSE::nIgnoreMaskLabel, DepthEstimator::ImportIgnoreMask, DepthMap.cpp:296-323): w*h bytes at image
+ * resolution, 0 = the pixel is ignored -- not estimated at any pyramid level, depth / normal / confidence 0 -- exactly like the masked
+ * MapMatrix2ZigzagIdx + DepthData::ApplyIgnoreMask (SceneDensify.cpp:679-683); level masks are INTER_NEAREST resamples.  NULL removes it.
+ * While masks are in use the level hand-off resizes depth maps with INTER_NEAREST as the reference does (:661);
+ * pmhip_scene_set_mask_mode forces that on (1) / off (0) for scenes where the option is set but no view has a mask file; -1 = automatic. */
+int pmhip_scene_set_mask(pmhip_engine* e, int idx, const unsigned char* mask);
+int pmhip_scene_set_mask_mode(pmhip_engine* e, int mode);
 /* Install a confidence map (host pointer), e.g. one read back from a .dmap before filtering / fusing without re-estimating. */
 int pmhip_scene_set_conf(pmhip_engine* e, int idx, const float* conf);
 /* Download maps (any pointer may be NULL). */

@@ -81,6 +81,8 @@ struct pmhip_engine {
 	float* d_imgS[4] = {nullptr, nullptr, nullptr, nullptr}; // anti-diagonal-major copies, (w_l+h_l-1)*h_l floats per image
 	size_t skewPitch(int l) const { return (size_t)(lw(l) + lh(l) - 1) * lh(l); }
 	float *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr, *d_snap = nullptr;
+	// ignore masks (nIgnoreMaskLabel): per level [nImages][P_l] bytes, allocated with the first mask; maskMode -1 = on iff a mask is set
+	unsigned char* d_mask[4] = {nullptr, nullptr, nullptr, nullptr}; std::vector<unsigned char> hasMask; bool maskDirty = false; int maskMode = -1;
 	// FilterDepthMap staging: filtered depth/conf of every view (committed after all views are filtered) and splat buffers
 	float *d_fdepth = nullptr, *d_fconf = nullptr; unsigned char* d_fvalid = nullptr;
 	unsigned long long* d_splat = nullptr; int splatCap = 0; PMFTask* d_ftasks = nullptr; PMFTask* h_ftasks = nullptr; int ftaskCap = 0;
@@ -136,6 +138,8 @@ static void freeScene(pmhip_engine* e) {
 	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_imgS[l]) hipFree(e->d_imgS[l]); e->d_imgS[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
 	if (e->d_depth) hipFree(e->d_depth); if (e->d_normal) hipFree(e->d_normal); if (e->d_conf) hipFree(e->d_conf); if (e->d_snap) hipFree(e->d_snap);
 	e->d_depth = e->d_normal = e->d_conf = e->d_snap = nullptr;
+	for (int l = 0; l < 4; ++l) { if (e->d_mask[l]) hipFree(e->d_mask[l]); e->d_mask[l] = nullptr; }
+	e->hasMask.clear(); e->maskDirty = false; e->maskMode = -1;
 	if (e->d_fdepth) hipFree(e->d_fdepth); if (e->d_fconf) hipFree(e->d_fconf); if (e->d_fvalid) hipFree(e->d_fvalid);
 	if (e->d_splat) hipFree(e->d_splat); if (e->d_ftasks) hipFree(e->d_ftasks); if (e->h_ftasks) hipHostFree(e->h_ftasks);
 	e->d_fdepth = e->d_fconf = nullptr; e->d_fvalid = nullptr; e->d_splat = nullptr; e->d_ftasks = nullptr; e->h_ftasks = nullptr; e->splatCap = e->ftaskCap = 0;
@@ -253,6 +257,19 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 	rc = buildPyramid(e); if (rc) return rc;
 	const PMKParams kp = makeKParams(p);
 	const bool geo = nGeometricIter >= 0;
+	bool anyMask = false;
+	for (unsigned char m : e->hasMask) anyMask = anyMask || m;
+	const int nearestDepth = (e->maskMode < 0 ? anyMask : e->maskMode != 0) ? 1 : 0;
+	if (anyMask && e->maskDirty) {
+		for (int l = 1; l <= e->nLevels; ++l) {
+			const size_t Pm = (size_t)e->lw(l) * e->lh(l);
+			for (int i = 0; i < e->nImages; ++i) if (e->hasMask[i])
+				hipLaunchKernelGGL(pm_mask_level_kernel, dim3((unsigned)std::min<size_t>((Pm + 255) / 256, 4096)), dim3(256), 0, e->stream,
+					e->d_mask[0] + (size_t)e->w * e->h * i, e->d_mask[l] + Pm * i, e->w, e->h, e->lw(l), e->lh(l));
+		}
+		HIPCHK(e, hipGetLastError());
+		e->maskDirty = false;
+	}
 	int maxSrc = 0;
 	for (int b = 0; b < nB; ++b) {
 		const int id = ids[b];
@@ -286,6 +303,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			}
 			t.ref = e->d_img[l] + Pl * id;
 			t.refS = e->d_imgS[l] + e->skewPitch(l) * id;
+			t.mask = (anyMask && e->hasMask[id]) ? e->d_mask[l] + Pl * id : nullptr;
 			t.w = lw; t.h = lh; t.nSrc = v.nNb;
 			double K0[9];
 			if (l == 0) memcpy(K0, v.K, sizeof(K0)); else scaleK(v.K, e->w, e->h, lw, lh, K0);
@@ -341,7 +359,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 		if (l == S && S > 0)
 			hipLaunchKernelGGL(pm_nearest_down_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, e->w, e->h, lw, lh, 1 << S);
 		else if (l < S)
-			hipLaunchKernelGGL(pm_upsample_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, e->lw(l + 1), e->lh(l + 1), lw, lh);
+			hipLaunchKernelGGL(pm_upsample_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, e->lw(l + 1), e->lh(l + 1), lw, lh, nearestDepth);
 		// pass A: ScoreDepthMapTmp
 		const int PPB = PM_BLOCK / G;
 		const uint32_t passInit = (uint32_t)l * 64u + 32u + (geo ? 16u + (uint32_t)nGeometricIter : 0u);
@@ -553,6 +571,24 @@ int pmhip_scene_set_maps(pmhip_engine* e, int idx, const float* depth, const flo
 	if (depth) HIPCHK(e, hipMemcpyAsync(e->d_depth + P0 * idx, depth, sizeof(float) * P0, hipMemcpyHostToDevice, e->stream));
 	if (normal) HIPCHK(e, hipMemcpyAsync(e->d_normal + P0 * 3 * idx, normal, sizeof(float) * P0 * 3, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+int pmhip_scene_set_mask(pmhip_engine* e, int idx, const unsigned char* mask) {
+	if (!e || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	const size_t P0 = (size_t)e->w * e->h;
+	if (e->hasMask.empty()) e->hasMask.assign(e->nImages, 0);
+	if (!mask) { e->hasMask[idx] = 0; return 0; }
+	if (!e->d_mask[0]) for (int l = 0; l <= e->nLevels; ++l) HIPCHK(e, hipMalloc(&e->d_mask[l], (size_t)e->lw(l) * e->lh(l) * e->nImages));
+	HIPCHK(e, hipMemcpyAsync(e->d_mask[0] + P0 * idx, mask, P0, hipMemcpyHostToDevice, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	e->hasMask[idx] = 1; e->maskDirty = true;
+	return 0;
+}
+int pmhip_scene_set_mask_mode(pmhip_engine* e, int mode) {
+	if (!e || mode < -1 || mode > 1) return PMHIP_E_ARG;
+	e->maskMode = mode;
 	return 0;
 }
 
@@ -871,7 +907,7 @@ int pmhip_resize(pmhip_engine* e, int kind, const float* src, int w, int h, int 
 		HIPCHK(e, hipMemset(dn, 0, ns * 12));
 		PMUpTask u{ds, dn, dd, dn2, dp};
 		HIPCHK(e, hipMemcpy(du, &u, sizeof(u), hipMemcpyHostToDevice));
-		hipLaunchKernelGGL(pm_upsample_kernel, dim3(blocks, 1), dim3(256), 0, e->stream, du, w, h, dw, dh);
+		hipLaunchKernelGGL(pm_upsample_kernel, dim3(blocks, 1), dim3(256), 0, e->stream, du, w, h, dw, dh, 0);
 	} else {
 		hipLaunchKernelGGL(pm_nearest_up_f_kernel, dim3(blocks), dim3(256), 0, e->stream, ds, dd, w, h, dw, dh);
 	}

@@ -60,6 +60,7 @@ struct PMTask {           // one reference view at one pyramid level
 	const float* prior;   // nullable: low-resolution depth prior at this level
 	const float* ref;     // reference image at this level, row-major
 	const float* refS;    // reference image, anti-diagonal-major
+	const unsigned char* mask; // nullable: ignore mask at this level, 0 = pixel is not estimated (DepthData::ApplyIgnoreMask + masked MapMatrix2ZigzagIdx)
 	int w, h, nSrc, pad0;
 	double Hr[9];         // K_0^-1
 	int hrUpper;          // 1 if Hr[1] == Hr[3] == Hr[6] == Hr[7] == 0 exactly (zero-skew K): products with those vanish exactly
@@ -429,7 +430,8 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 	const size_t idx = (size_t)y * w + x;
 	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
 	const float prior = t.prior ? pm_glob(t.prior)[idx] : 0.f;
-	const bool valid = inb && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
+	const bool masked = t.mask != nullptr && t.mask[idx] == 0;   // not in the reference's pixel list: depth/normal zeroed, never scored
+	const bool valid = inb && !masked && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
 	if (!valid) {
 		if (v == 0) { gDepth[idx] = 0.f; gNormal[idx * 3] = 0.f; gNormal[idx * 3 + 1] = 0.f; gNormal[idx * 3 + 2] = 0.f; gConf[idx] = 2.f; }
 		return;
@@ -478,7 +480,8 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 	const size_t idx = (size_t)y * w + x;
 	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
 	const float prior = (active && t.prior) ? pm_glob(t.prior)[idx] : 0.f;
-	const bool valid = active && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
+	const bool masked = active && t.mask != nullptr && t.mask[idx] == 0;
+	const bool valid = active && !masked && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
 	const double X0x = ((double)x - t.cx) / t.fx, X0y = ((double)y - t.cy) / t.fy;
 	const float vx = (float)X0x, vy = (float)X0y, vz = 1.f;
 
@@ -757,7 +760,8 @@ __device__ __forceinline__ void pm_linear_coef(int d, int dn, int sn, int& s, fl
 }
 // level hand-off (SceneDensify.cpp:660-664): depth INTER_LINEAR, normal INTER_NEAREST, prior = copy of depth
 struct PMUpTask { const float* sdepth; const float* snormal; float* ddepth; float* dnormal; float* dprior; };
-__global__ void pm_upsample_kernel(const PMUpTask* __restrict__ ups, int sw, int sh, int dw, int dh) {
+// nearestDepth != 0: the reference resizes the depth map with INTER_NEAREST too when ignore masks are enabled (SceneDensify.cpp:661)
+__global__ void pm_upsample_kernel(const PMUpTask* __restrict__ ups, int sw, int sh, int dw, int dh, int nearestDepth) {
 	const PMUpTask u = ups[blockIdx.y];
 	const size_t n = (size_t)dw * dh;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -768,11 +772,12 @@ __global__ void pm_upsample_kernel(const PMUpTask* __restrict__ ups, int sw, int
 		const float a0 = 1.f - a1, b0 = 1.f - b1;
 		const float t0 = u.sdepth[(size_t)y0 * sw + x0] * a0 + u.sdepth[(size_t)y0 * sw + x1] * a1;
 		const float t1 = u.sdepth[(size_t)y1 * sw + x0] * a0 + u.sdepth[(size_t)y1 * sw + x1] * a1;
-		const float dv = t0 * b0 + t1 * b1;
-		u.ddepth[i] = dv; u.dprior[i] = dv;
+		float dv = t0 * b0 + t1 * b1;
 		const int nx = min((int)floor((double)x * ((double)sw / (double)dw)), sw - 1);
 		const int ny = min((int)floor((double)y * ((double)sh / (double)dh)), sh - 1);
 		const size_t si = (size_t)ny * sw + nx;
+		if (nearestDepth) dv = u.sdepth[si];
+		u.ddepth[i] = dv; u.dprior[i] = dv;
 		u.dnormal[i * 3] = u.snormal[si * 3]; u.dnormal[i * 3 + 1] = u.snormal[si * 3 + 1]; u.dnormal[i * 3 + 2] = u.snormal[si * 3 + 2];
 	}
 }
@@ -790,6 +795,17 @@ __global__ void pm_nearest_down_kernel(const PMUpTask* __restrict__ ups, int sw,
 	}
 }
 __global__ void pm_nearest_up_f_kernel(const float* __restrict__ s, float* __restrict__ d, int sw, int sh, int dw, int dh) {
+	const size_t n = (size_t)dw * dh;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const int x = (int)(i % dw), y = (int)(i / dw);
+		const int nx = min((int)floor((double)x * ((double)sw / (double)dw)), sw - 1);
+		const int ny = min((int)floor((double)y * ((double)sh / (double)dh)), sh - 1);
+		d[i] = s[(size_t)ny * sw + nx];
+	}
+}
+
+// ignore mask of one view at a pyramid level: cv::resize(mask, size, INTER_NEAREST) of the level-0 mask (ImportIgnoreMask, DepthMap.cpp:309)
+__global__ void pm_mask_level_kernel(const unsigned char* __restrict__ s, unsigned char* __restrict__ d, int sw, int sh, int dw, int dh) {
 	const size_t n = (size_t)dw * dh;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
 		const int x = (int)(i % dw), y = (int)(i / dw);

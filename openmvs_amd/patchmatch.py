@@ -51,7 +51,7 @@ class PMHipFuseParams(C.Structure):
                 ("bEstimateColor", C.c_int32), ("bEstimateNormal", C.c_int32)]
 
 
-EXPORTS = ["pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
+EXPORTS = ["pmhip_scene_set_mask", "pmhip_scene_set_mask_mode", "pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
            "pmhip_estimate_depth_map", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
            "pmhip_scene_estimate", "pmhip_scene_commit_round", "pmhip_scene_reset_view", "pmhip_scene_set_maps",
            "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_remove_small_segments", "pmhip_scene_images_updated", "pmhip_sync",
@@ -183,6 +183,19 @@ class PatchMatchHIP:
         d = None if depth is None else np.ascontiguousarray(depth, np.float32)
         n = None if normal is None else np.ascontiguousarray(normal, np.float32)
         self._chk(self._lib.pmhip_scene_set_maps(self._h, idx, _fp(d) if d is not None else None, _fp(n) if n is not None else None))
+
+    def scene_set_mask(self, idx, mask):
+        """Ignore mask of a view: (h, w) array, 0 = ignore the pixel (--ignore-mask-label); None removes it."""
+        if mask is None:
+            self._chk(self._lib.pmhip_scene_set_mask(self._h, idx, None)); return
+        m = np.ascontiguousarray(np.asarray(mask) != 0, np.uint8)
+        _, w, h = self._scene
+        if m.shape != (h, w):
+            raise ValueError("mask must be (h, w)")
+        self._chk(self._lib.pmhip_scene_set_mask(self._h, idx, m.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def scene_set_mask_mode(self, mode):
+        self._chk(self._lib.pmhip_scene_set_mask_mode(self._h, int(mode)))
 
     def scene_set_conf(self, idx, conf):
         c = np.ascontiguousarray(conf, np.float32)

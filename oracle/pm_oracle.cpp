@@ -645,8 +645,8 @@ struct DepthEstimator {
 	}
 };
 
-// MapMatrix2ZigzagIdx, DepthMap.cpp:329-356 (no mask)
-static void MapMatrix2ZigzagIdx(int w, int hTotal, std::vector<std::pair<uint16_t,uint16_t>>& coords, int rawStride) {
+// MapMatrix2ZigzagIdx, DepthMap.cpp:329-356; mask (nullable, w*hTotal bytes): only pixels with a non-zero entry are listed (:346-347)
+static void MapMatrix2ZigzagIdx(int w, int hTotal, std::vector<std::pair<uint16_t,uint16_t>>& coords, int rawStride, const unsigned char* mask = nullptr) {
 	const int w1 = w - 1;
 	coords.clear(); coords.reserve((size_t)w * hTotal);
 	for (int dy = 0, h = rawStride; dy < hTotal; dy += h) {
@@ -655,7 +655,8 @@ static void MapMatrix2ZigzagIdx(int w, int hTotal, std::vector<std::pair<uint16_
 		int lastX = 0;
 		int xx = 0, xy = 0;
 		for (int i = 0, ei = w * h; i < ei; ++i) {
-			coords.emplace_back((uint16_t)xx, (uint16_t)(xy + dy));
+			if (!mask || mask[(size_t)(xy + dy) * w + xx])
+				coords.emplace_back((uint16_t)xx, (uint16_t)(xy + dy));
 			if (xx-- == 0 || ++xy == h) {
 				if (++lastX < w) { xx = lastX; xy = 0; }
 				else { xx = w1; xy = lastX - w1; }
@@ -733,8 +734,10 @@ static void runThreads(int T, std::vector<DepthEstimator*>& est, F fn) {
 
 // DepthMapsData::EstimateDepthMap, SceneDensify.cpp:616-805
 // nGeometricIter < 0: photometric pass (pyramid); >= 0: one geometric-consistency round.
+// ignoreMask (nullable): W0*H0 bytes at image resolution, 0 = ignore (the BitMatrix of ImportIgnoreMask, DepthMap.cpp:296-323);
+// maskMode: OPTDENSE::nIgnoreMaskLabel >= 0 (selects INTER_NEAREST for the depth hand-off, SceneDensify.cpp:661).
 static int EstimateDepthMap(DepthData& full, const Opt& opt, int nGeometricIter,
-		void (*levelHook)(void*, int, int, const DepthData&), void* hookArg) {
+		void (*levelHook)(void*, int, int, const DepthData&), void* hookArg, const unsigned char* ignoreMask = nullptr, bool maskMode = false) {
 	const int T = std::max(1, opt.nThreads);
 	const unsigned iterBegin = nGeometricIter < 0 ? 0u : opt.nEstimationIters + (unsigned)nGeometricIter;
 	const unsigned iterEnd = nGeometricIter < 0 ? opt.nEstimationIters : iterBegin + 1;
@@ -753,7 +756,7 @@ static int EstimateDepthMap(DepthData& full, const Opt& opt, int nGeometricIter,
 		DepthData& dd = scaleNumber == 0 ? full : currentDepthData;
 		const int w = dd.images[0].image.w, h = dd.images[0].image.h;
 		if (scaleNumber != totalScaleNumber) {
-			resizeLinear(lowResDepthMap, w, h, dd.depthMap);
+			if (maskMode) resizeNearest(lowResDepthMap, w, h, dd.depthMap); else resizeLinear(lowResDepthMap, w, h, dd.depthMap);
 			resizeNearestN(lowResNormalMap, w, h, dd.normalMap);
 			currentSizeResDepthMap = dd.depthMap;
 		} else if (totalScaleNumber > 0) {
@@ -763,7 +766,17 @@ static int EstimateDepthMap(DepthData& full, const Opt& opt, int nGeometricIter,
 		if (dd.normalMap.empty()) dd.normalMap.create(w, h);
 		dd.confMap.create(w, h);
 		weightMap0.assign((size_t)w * h, Weight());
-		MapMatrix2ZigzagIdx(w, h, coords, std::max(64, T * 8));
+		std::vector<unsigned char> levelMask;
+		if (ignoreMask) {   // cv::resize(mask, size, INTER_NEAREST), then DepthData::ApplyIgnoreMask (DepthMap.cpp:215-231)
+			levelMask.resize((size_t)w * h);
+			const double ifx = (double)W0 / w, ify = (double)H0 / h;
+			for (int y = 0; y < h; ++y) { const int sy = std::min((int)floor(y * ify), H0 - 1);
+				for (int x = 0; x < w; ++x) { const int sx = std::min((int)floor(x * ifx), W0 - 1); levelMask[(size_t)y * w + x] = ignoreMask[(size_t)sy * W0 + sx]; } }
+			for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) if (!levelMask[(size_t)y * w + x]) {
+				dd.depthMap(y, x) = 0; float* n = dd.normalMap.at(y, x); n[0] = n[1] = n[2] = 0; dd.confMap(y, x) = 0;
+			}
+		}
+		MapMatrix2ZigzagIdx(w, h, coords, std::max(64, T * 8), ignoreMask ? levelMask.data() : nullptr);
 		const ImgF* prior = currentSizeResDepthMap.empty() ? nullptr : &currentSizeResDepthMap;
 		const uint32_t level = scaleNumber;
 		auto makeEstimators = [&](unsigned iter, uint32_t pass, std::vector<std::unique_ptr<DepthEstimator>>& own, std::vector<DepthEstimator*>& ptrs) {
@@ -882,6 +895,19 @@ int orc_estimate_depth_map(const OrcView* views, int nViews, float* depth, float
 	const size_t n = (size_t)views[0].w * views[0].h;
 	memcpy(depth, dd.depthMap.d.data(), n * 4); memcpy(normal, dd.normalMap.d.data(), n * 12); memcpy(conf, dd.confMap.d.data(), n * 4);
 	if (stageUsed) *stageUsed = ctx.used;
+	return 0;
+}
+
+// Same with OPTDENSE::nIgnoreMaskLabel >= 0: mask (nullable) = the reference view's ignore mask at image resolution, 0 = ignore.
+int orc_estimate_depth_map_masked(const OrcView* views, int nViews, float* depth, float* normal, float* conf,
+		float dMin, float dMax, const OrcOpt* opt, int nGeometricIter, const unsigned char* mask, int maskMode) {
+	if (nViews < 2) return -1;
+	orc::DepthData dd; loadDepthData(views, nViews, depth, normal, dMin, dMax, dd);
+	orc::Opt o = toOpt(opt);
+	const int rc = orc::EstimateDepthMap(dd, o, nGeometricIter, nullptr, nullptr, mask, maskMode != 0);
+	if (rc) return rc;
+	const size_t n = (size_t)views[0].w * views[0].h;
+	memcpy(depth, dd.depthMap.d.data(), n * 4); memcpy(normal, dd.normalMap.d.data(), n * 12); memcpy(conf, dd.confMap.d.data(), n * 4);
 	return 0;
 }
 

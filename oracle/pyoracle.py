@@ -108,6 +108,22 @@ def estimate_depth_map(views, n_views, dmin, dmax, opt: OrcOpt, geo_iter: int = 
     return depth, normal, conf, out
 
 
+def estimate_depth_map_masked(views, n_views, dmin, dmax, opt: OrcOpt, mask, geo_iter: int = -1, depth=None, normal=None, mask_mode=True):
+    """EstimateDepthMap with --ignore-mask-label: `mask` (h, w), 0 = ignored pixel, or None (then only the NEAREST hand-off of mask_mode)."""
+    h, w = views[0].h, views[0].w
+    depth = np.zeros((h, w), np.float32) if depth is None else np.ascontiguousarray(depth, np.float32).copy()
+    normal = np.zeros((h, w, 3), np.float32) if normal is None else np.ascontiguousarray(normal, np.float32).copy()
+    conf = np.zeros((h, w), np.float32)
+    m = None if mask is None else np.ascontiguousarray(np.asarray(mask) != 0, np.uint8)
+    lib().orc_estimate_depth_map_masked.restype = C.c_int
+    rc = lib().orc_estimate_depth_map_masked(views, C.c_int(n_views), _fp(depth), _fp(normal), _fp(conf), C.c_float(dmin), C.c_float(dmax),
+                                             C.byref(opt), C.c_int(geo_iter), None if m is None else m.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                             C.c_int(1 if mask_mode else 0))
+    if rc != 0:
+        raise RuntimeError(f"orc_estimate_depth_map_masked failed: {rc}")
+    return depth, normal, conf
+
+
 def score_pixel(views, n_views, opt: OrcOpt, x, y, depth, normal, prior=None):
     sc = np.zeros(n_views - 1, np.float32); agg = C.c_float(0)
     nrm = np.ascontiguousarray(normal, np.float32)

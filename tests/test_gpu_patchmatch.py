@@ -273,6 +273,48 @@ def test_whole_dense_schedule_matches_the_oracle_pipeline(small_scene, tmp_path)
     e.close()
 
 
+def test_ignore_mask_parity(small_scene):
+    """Ignore masks (pmhip_scene_set_mask): photometric pass over 3 levels + one geometric round; the masked view and an unmasked
+    view of the same scene (which then also uses the NEAREST depth hand-off) both equal the oracle bit for bit."""
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    sc = small_scene
+    seed = 11
+    mask = np.ones((sc.height, sc.width), np.uint8); mask[20:70, 30:90] = 0; mask[::7, ::5] = 0; mask[100:, :12] = 0
+    e = PatchMatchHIP(0)
+    e.scene_load(sc, n_levels=2)
+    e.scene_set_mask(0, mask)
+    p = default_params(seed=seed, nEstimationGeometricIters=1)
+    allv = list(range(sc.n_views))
+    e.Init(False)
+    for v in allv:
+        e.scene_reset_view(v)
+    e.scene_estimate(allv, -1, p)
+    photo = {v: e.scene_get_maps(v) for v in allv}
+    e.scene_commit_round(); e.Init(True)
+    e.scene_estimate(allv, 0, p)
+    geo = {v: e.scene_get_maps(v) for v in allv}
+
+    def orc(v, geo_iter=-1, depth=None, normal=None, src=None):
+        ids = [v] + list(sc.neighbors[v])
+        vw, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids, depth_maps=src)
+        return po.estimate_depth_map_masked(vw, len(ids), float(sc.dmin[v]), float(sc.dmax[v]), po.default_opt(seed=seed, viewID=v, nEstimationGeometricIters=1),
+                                            mask if v == 0 else None, geo_iter=geo_iter, depth=depth, normal=normal, mask_mode=True)
+    ophoto = {v: orc(v) for v in allv}
+    prev = {v: ophoto[v][0] for v in allv}
+    for v in (0, 2):
+        for k, what in enumerate(("depth", "normal", "conf")):
+            _same(photo[v][k], ophoto[v][k], f"masked photometric view {v} {what}")
+        og = orc(v, geo_iter=0, depth=ophoto[v][0], normal=ophoto[v][1], src=prev)
+        for k, what in enumerate(("depth", "normal", "conf")):
+            _same(geo[v][k], og[k], f"masked geometric view {v} {what}")
+    assert not geo[0][0][mask == 0].any() and (geo[0][0][mask != 0] > 0).mean() > 0.5
+    e.scene_set_mask(0, None)                    # removing the mask restores the plain estimator (LINEAR hand-off again)
+    e.Init(False); e.scene_reset_view(2); e.scene_estimate([2], -1, p)
+    plain = _oracle(sc, 2, seed, nEstimationGeometricIters=1)
+    _same(e.scene_get_maps(2)[0], plain[0], "mask removed")
+    e.close()
+
+
 def test_real_scene_from_mvs_archive_matches_oracle_and_sfm_points():
     """The reference's own pipeline fixture (tests/data/scene: 4 JPEGs 640x479 + MVSI archive): scene front end (reader, view selection,
     sparse initialisation) -> photometric pass + 2 geometric rounds seeded by the sparse maps.  Device == oracle bit for bit on real

@@ -217,3 +217,27 @@ def test_generator_reproduces_the_fixture_inputs_closely():
     sc = synth.make_scene(int(g["n_views"]), 96, 64, n_src=int(g["n_src"]))
     assert np.abs(sc.gray - g["gray"]).max() <= 1.01 / 255 and (sc.gray != g["gray"]).mean() < 1e-3
     assert np.array_equal(sc.neighbors, g["neighbors"]) and np.allclose(sc.K, g["K"]) and np.allclose(sc.C, g["C"])
+
+
+def test_ignore_mask_semantics(small_scene):
+    """--ignore-mask-label (DepthMap.cpp:296-323, SceneDensify.cpp:661,679-683): masked pixels are never estimated and come out 0;
+    an all-ones mask with the LINEAR hand-off is the plain estimator; the option alone switches the depth hand-off to NEAREST."""
+    sc = small_scene
+    v = 0
+    ids = [v] + list(sc.neighbors[v])
+    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+    opt = po.default_opt(seed=3, viewID=v)
+    base = po.estimate_depth_map(views, len(ids), float(sc.dmin[v]), float(sc.dmax[v]), opt)
+    ones = np.ones((sc.height, sc.width), np.uint8)
+    same = po.estimate_depth_map_masked(views, len(ids), float(sc.dmin[v]), float(sc.dmax[v]), opt, ones, mask_mode=False)
+    for a, b in zip(base, same):
+        assert np.array_equal(a, b)
+    mask = ones.copy(); mask[20:70, 30:90] = 0; mask[::7, ::5] = 0
+    d, n, c = po.estimate_depth_map_masked(views, len(ids), float(sc.dmin[v]), float(sc.dmax[v]), opt, mask)
+    assert not d[mask == 0].any() and not n[mask == 0].any() and not c[mask == 0].any()
+    keepm = mask != 0
+    assert (d[keepm] > 0).mean() > 0.5
+    ok = keepm & (d > 0)
+    assert np.median(np.abs(d[ok] - sc.gt_depth[v][ok]) / sc.gt_depth[v][ok]) < 5e-3
+    nearest = po.estimate_depth_map_masked(views, len(ids), float(sc.dmin[v]), float(sc.dmax[v]), opt, None, mask_mode=True)
+    assert not np.array_equal(nearest[0], base[0]) and (nearest[0] > 0).mean() > 0.5

@@ -50,6 +50,24 @@ int sgmhip_match(sgmhip_engine* e, uint16_t P1, const uint16_t P2s[256], int syn
 int sgmhip_get_results(sgmhip_engine* e, int16_t* disparity, uint16_t* cost, uint8_t* costs, uint16_t* accums);
 int sgmhip_sync(sgmhip_engine* e);
 
+/* ---- the steps of the tSGM loop around Match (SemiGlobalMatcher.cpp:1449-1811); disparity maps int16 with NO_DISP = 32767,
+ * masks uint8 with INVALID = 0 / VALID = 255, all host pointers, row-major ------------------------------------------------ */
+/* ConsistencyCrossCheck(l2r, r2l, thCross) (:1449-1489): l2r (wl x h) is filtered in place against r2l (wr x h). */
+int sgmhip_consistency_cross_check(sgmhip_engine* e, int16_t* l2r, const int16_t* r2l, int wl, int h, int wr, int thCross);
+/* FilterByCost (:1491-1514): disparities whose cost exceeds th become NO_DISP. */
+int sgmhip_filter_by_cost(sgmhip_engine* e, int16_t* disparity, const uint16_t* cost, int w, int h, uint16_t th);
+/* ExtractMask (:1516-1573, thValid default 3): per row, from both ends, pixels are marked INVALID until thValid valid disparities were met.
+ * initValid != 0: the mask starts all VALID (the reference creates it when its size differs), else `mask` is in/out. */
+int sgmhip_extract_mask(sgmhip_engine* e, const int16_t* disparity, uint8_t* mask, int w, int h, int thValid, int initValid);
+/* UpscaleMask (:1657-1690): mask (w x h) -> mask2x (w2 x h2): pixel (r,c) covers the 2x2 block at (2r+3, 2c+3); the rest is INVALID. */
+int sgmhip_upscale_mask(sgmhip_engine* e, const uint8_t* mask, int w, int h, uint8_t* mask2x, int w2, int h2);
+/* FlipDirection (:1628-1655): r2l(r, c+d-1 .. c+d+1) = -l2r(r,c), later columns overwrite earlier ones; elsewhere NO_DISP. */
+int sgmhip_flip_direction(sgmhip_engine* e, const int16_t* l2r, int w, int h, int16_t* r2l);
+/* RefineDisparityMap (:1693-1811) on the resident result of the last sgmhip_match, using its 8-path sums in place on the device:
+ * subpixelMode 0 NA, 1 LINEAR, 2 POLY4, 3 PARABOLA, 4 SINE, 5 COSINE, 6 LC_BLEND (the reference's default with subpixelSteps 4).
+ * Fetch the result with sgmhip_get_results.  cos/sin come from csrc/pm_math.h (Cephes kernels), not libm. */
+int sgmhip_refine_disparity(sgmhip_engine* e, int subpixelMode, int subpixelSteps);
+
 /* HIP-event timing since the last reset: milliseconds in the cost-volume, aggregation (8 path
  * kernels) and WTA kernels, number of match calls. */
 typedef struct SGMHipStats { double costMs, aggrMs, wtaMs; uint64_t calls, aggrLaunches; } SGMHipStats;

@@ -1,6 +1,7 @@
 // sgm_engine.hip -- host side of libsgmhip.so (include/sgmhip.h).
 #include "../../include/sgmhip.h"
 #include "sgm_kernels.hip"
+#include "sgm_post.hip"
 #include <math.h>
 #include <string.h>
 #include <algorithm>
@@ -157,5 +158,90 @@ int sgmhip_get_results(sgmhip_engine* e, int16_t* disparity, uint16_t* cost, uin
 int sgmhip_sync(sgmhip_engine* e) { if (!e) return SGMHIP_E_ARG; SGMCHK(e, hipSetDevice(e->device)); SGMCHK(e, hipStreamSynchronize(e->stream)); return 0; }
 int sgmhip_stats_reset(sgmhip_engine* e, int enable) { if (!e) return SGMHIP_E_ARG; hipSetDevice(e->device); sgmCollect(e); memset(&e->stats, 0, sizeof(e->stats)); e->statsOn = enable != 0; return 0; }
 int sgmhip_stats_get(sgmhip_engine* e, SGMHipStats* out) { if (!e || !out) return SGMHIP_E_ARG; hipSetDevice(e->device); int rc = sgmCollect(e); if (rc) return rc; *out = e->stats; return 0; }
+
+// ---- tSGM steps around Match (SemiGlobalMatcher.cpp:1449-1811), see csrc/sgm_post.h ---------------------------------------------
+namespace {
+struct DevBuf {   // scoped device allocation for the stateless helpers
+	void* p = nullptr;
+	~DevBuf() { if (p) hipFree(p); }
+	hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+inline unsigned gridFor(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 65535); }
+}
+
+int sgmhip_consistency_cross_check(sgmhip_engine* e, int16_t* l2r, const int16_t* r2l, int wl, int h, int wr, int thCross) {
+	if (!e || !l2r || !r2l || wl <= 0 || wr <= 0 || h <= 0 || thCross < 0) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	DevBuf a, b; const size_t nl = (size_t)wl * h, nr = (size_t)wr * h;
+	SGMCHK(e, a.alloc(nl * 2)); SGMCHK(e, b.alloc(nr * 2));
+	SGMCHK(e, hipMemcpyAsync(a.p, l2r, nl * 2, hipMemcpyHostToDevice, e->stream)); SGMCHK(e, hipMemcpyAsync(b.p, r2l, nr * 2, hipMemcpyHostToDevice, e->stream));
+	hipLaunchKernelGGL(sgmp_cross_check_kernel, dim3(gridFor(nl)), dim3(256), 0, e->stream, (int16_t*)a.p, (const int16_t*)b.p, wl, wr, h, thCross);
+	SGMCHK(e, hipMemcpyAsync(l2r, a.p, nl * 2, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+int sgmhip_filter_by_cost(sgmhip_engine* e, int16_t* disparity, const uint16_t* cost, int w, int h, uint16_t th) {
+	if (!e || !disparity || !cost || w <= 0 || h <= 0) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	DevBuf a, b; const size_t n = (size_t)w * h;
+	SGMCHK(e, a.alloc(n * 2)); SGMCHK(e, b.alloc(n * 2));
+	SGMCHK(e, hipMemcpyAsync(a.p, disparity, n * 2, hipMemcpyHostToDevice, e->stream)); SGMCHK(e, hipMemcpyAsync(b.p, cost, n * 2, hipMemcpyHostToDevice, e->stream));
+	hipLaunchKernelGGL(sgmp_filter_by_cost_kernel, dim3(gridFor(n)), dim3(256), 0, e->stream, (int16_t*)a.p, (const uint16_t*)b.p, n, th);
+	SGMCHK(e, hipMemcpyAsync(disparity, a.p, n * 2, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+int sgmhip_extract_mask(sgmhip_engine* e, const int16_t* disparity, uint8_t* mask, int w, int h, int thValid, int initValid) {
+	if (!e || !disparity || !mask || w <= 0 || h <= 0) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	DevBuf a, b; const size_t n = (size_t)w * h;
+	SGMCHK(e, a.alloc(n * 2)); SGMCHK(e, b.alloc(n));
+	SGMCHK(e, hipMemcpyAsync(a.p, disparity, n * 2, hipMemcpyHostToDevice, e->stream));
+	if (initValid) SGMCHK(e, hipMemsetAsync(b.p, 0xFF, n, e->stream));      // maskMap.create(size); setTo(VALID), :1521-1524
+	else SGMCHK(e, hipMemcpyAsync(b.p, mask, n, hipMemcpyHostToDevice, e->stream));
+	hipLaunchKernelGGL(sgmp_extract_mask_kernel, dim3((h + 63) / 64), dim3(64), 0, e->stream, (const int16_t*)a.p, (uint8_t*)b.p, w, h, thValid);
+	SGMCHK(e, hipMemcpyAsync(mask, b.p, n, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+int sgmhip_upscale_mask(sgmhip_engine* e, const uint8_t* mask, int w, int h, uint8_t* mask2x, int w2, int h2) {
+	if (!e || !mask || !mask2x || w <= 0 || h <= 0 || w2 <= 0 || h2 <= 0) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	DevBuf a, b; const size_t n = (size_t)w * h, n2 = (size_t)w2 * h2;
+	SGMCHK(e, a.alloc(n)); SGMCHK(e, b.alloc(n2));
+	SGMCHK(e, hipMemcpyAsync(a.p, mask, n, hipMemcpyHostToDevice, e->stream));
+	hipLaunchKernelGGL(sgmp_upscale_mask_kernel, dim3(gridFor(n2)), dim3(256), 0, e->stream, (const uint8_t*)a.p, w, h, (uint8_t*)b.p, w2, h2);
+	SGMCHK(e, hipMemcpyAsync(mask2x, b.p, n2, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+int sgmhip_flip_direction(sgmhip_engine* e, const int16_t* l2r, int w, int h, int16_t* r2l) {
+	if (!e || !l2r || !r2l || w <= 0 || h <= 0 || w > 65534) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	DevBuf a, k, b; const size_t n = (size_t)w * h;
+	SGMCHK(e, a.alloc(n * 2)); SGMCHK(e, k.alloc(n * 4)); SGMCHK(e, b.alloc(n * 2));
+	SGMCHK(e, hipMemcpyAsync(a.p, l2r, n * 2, hipMemcpyHostToDevice, e->stream));
+	SGMCHK(e, hipMemsetAsync(k.p, 0, n * 4, e->stream));
+	hipLaunchKernelGGL(sgmp_flip_scatter_kernel, dim3(gridFor(n)), dim3(256), 0, e->stream, (const int16_t*)a.p, (uint32_t*)k.p, w, h);
+	hipLaunchKernelGGL(sgmp_flip_decode_kernel, dim3(gridFor(n)), dim3(256), 0, e->stream, (const uint32_t*)k.p, (int16_t*)b.p, n);
+	SGMCHK(e, hipMemcpyAsync(r2l, b.p, n * 2, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+int sgmhip_refine_disparity(sgmhip_engine* e, int subpixelMode, int subpixelSteps) {
+	if (!e || e->numCosts == 0 || subpixelMode < 0 || subpixelMode > SGMP_SUBPIXEL_LC_BLEND || subpixelSteps < 0 || subpixelSteps > 64) return SGMHIP_E_ARG;
+	if (subpixelSteps <= 1) return 0;                                     // :1696-1697
+	SGMCHK(e, hipSetDevice(e->device));
+	const long nPix = (long)e->vw * e->vh;
+	hipLaunchKernelGGL(sgmp_refine_kernel, dim3(gridFor((size_t)nPix)), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, subpixelMode, subpixelSteps);
+	SGMCHK(e, hipGetLastError());
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
 
 } // extern "C"

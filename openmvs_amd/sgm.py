@@ -11,7 +11,12 @@ from . import build as _build
 
 PIXEL_DTYPE = np.dtype([("idx", np.uint64), ("minDisp", np.int16), ("maxDisp", np.int16), ("pad", np.int32)])
 EXPORTS = ["sgmhip_create", "sgmhip_destroy", "sgmhip_last_error", "sgmhip_generate_p2s", "sgmhip_set_problem",
-           "sgmhip_match", "sgmhip_get_results", "sgmhip_sync", "sgmhip_stats_reset", "sgmhip_stats_get"]
+           "sgmhip_match", "sgmhip_get_results", "sgmhip_sync", "sgmhip_stats_reset", "sgmhip_stats_get",
+           "sgmhip_consistency_cross_check", "sgmhip_filter_by_cost", "sgmhip_extract_mask", "sgmhip_upscale_mask", "sgmhip_flip_direction",
+           "sgmhip_refine_disparity"]
+NO_DISP = 32767          # SemiGlobalMatcher::NO_DISP
+INVALID, VALID = 0, 255  # MaskMap values
+SUBPIXEL_NA, SUBPIXEL_LINEAR, SUBPIXEL_POLY4, SUBPIXEL_PARABOLA, SUBPIXEL_SINE, SUBPIXEL_COSINE, SUBPIXEL_LC_BLEND = range(7)
 
 
 class SGMHipStats(C.Structure):
@@ -91,6 +96,39 @@ class SemiGlobalMatcherHIP:
                                                costs.ctypes.data_as(C.POINTER(C.c_uint8)) if volumes else None,
                                                acc.ctypes.data_as(C.POINTER(C.c_uint16)) if volumes else None))
         return (d, c, costs, acc) if volumes else (d, c)
+
+    # ---- the tSGM steps around Match (libs/MVS/SemiGlobalMatcher.cpp:1449-1811) -------------------------------------------
+    def ConsistencyCrossCheck(self, l2r, r2l, thCross=1):
+        a = np.ascontiguousarray(l2r, np.int16).copy(); b = np.ascontiguousarray(r2l, np.int16)
+        self._chk(self._lib.sgmhip_consistency_cross_check(self._h, a.ctypes.data_as(C.POINTER(C.c_int16)), b.ctypes.data_as(C.POINTER(C.c_int16)),
+                                                           a.shape[1], a.shape[0], b.shape[1], thCross))
+        return a
+
+    def FilterByCost(self, disparity, cost, th):
+        a = np.ascontiguousarray(disparity, np.int16).copy(); c = np.ascontiguousarray(cost, np.uint16)
+        self._chk(self._lib.sgmhip_filter_by_cost(self._h, a.ctypes.data_as(C.POINTER(C.c_int16)), c.ctypes.data_as(C.POINTER(C.c_uint16)), a.shape[1], a.shape[0], C.c_uint16(th)))
+        return a
+
+    def ExtractMask(self, disparity, mask=None, thValid=3):
+        a = np.ascontiguousarray(disparity, np.int16)
+        m = np.zeros(a.shape, np.uint8) if mask is None else np.ascontiguousarray(mask, np.uint8).copy()
+        self._chk(self._lib.sgmhip_extract_mask(self._h, a.ctypes.data_as(C.POINTER(C.c_int16)), m.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], a.shape[0], thValid, 1 if mask is None else 0))
+        return m
+
+    def UpscaleMask(self, mask, size2x):
+        m = np.ascontiguousarray(mask, np.uint8); w2, h2 = size2x
+        o = np.zeros((h2, w2), np.uint8)
+        self._chk(self._lib.sgmhip_upscale_mask(self._h, m.ctypes.data_as(C.POINTER(C.c_uint8)), m.shape[1], m.shape[0], o.ctypes.data_as(C.POINTER(C.c_uint8)), w2, h2))
+        return o
+
+    def FlipDirection(self, l2r):
+        a = np.ascontiguousarray(l2r, np.int16); o = np.zeros_like(a)
+        self._chk(self._lib.sgmhip_flip_direction(self._h, a.ctypes.data_as(C.POINTER(C.c_int16)), a.shape[1], a.shape[0], o.ctypes.data_as(C.POINTER(C.c_int16))))
+        return o
+
+    def RefineDisparityMap(self, subpixelMode=SUBPIXEL_LC_BLEND, subpixelSteps=4):
+        """In place on the device, on the result of the last Match(); read it back with results()."""
+        self._chk(self._lib.sgmhip_refine_disparity(self._h, subpixelMode, subpixelSteps))
 
     def sync(self):
         self._chk(self._lib.sgmhip_sync(self._h))

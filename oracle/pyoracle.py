@@ -35,7 +35,7 @@ class OrcOpt(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libpm_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("pm_oracle.cpp", "sgm_oracle.cpp", "filter_oracle.cpp", "fuse_oracle.cpp")] + \
+    srcs = [os.path.join(_HERE, f) for f in ("pm_oracle.cpp", "sgm_oracle.cpp", "filter_oracle.cpp", "fuse_oracle.cpp", "sgm_post_oracle.cpp")] + \
            [os.path.join(_HERE, "..", "openmvs_amd", "csrc", "pm_math.h")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s))
     if stale and all(os.path.exists(s) for s in srcs):
@@ -314,3 +314,48 @@ def _cloud(out, rc, free):
                normals=None if not out.normals else take(out.normals, 3 * P, np.float32).reshape(P, 3))
     free(C.byref(out))
     return res
+
+
+# ---- tSGM steps around Match (oracle/sgm_post_oracle.cpp); `impl` = a CDLL with the same entry points under another prefix ---------
+def _sgm_post(prefix, impl=None):
+    L = impl or lib()
+    return lambda name: getattr(L, prefix + name)
+
+
+def sgm_cross_check(l2r, r2l, thCross=1, impl=None, prefix="orc_sgm_"):
+    a = np.ascontiguousarray(l2r, np.int16).copy(); b = np.ascontiguousarray(r2l, np.int16)
+    _sgm_post(prefix, impl)("cross_check")(a.ctypes.data_as(C.POINTER(C.c_int16)), b.ctypes.data_as(C.POINTER(C.c_int16)), C.c_int(a.shape[1]), C.c_int(a.shape[0]), C.c_int(b.shape[1]), C.c_int(thCross))
+    return a
+
+
+def sgm_filter_by_cost(disp, cost, th, impl=None, prefix="orc_sgm_"):
+    a = np.ascontiguousarray(disp, np.int16).copy(); c = np.ascontiguousarray(cost, np.uint16)
+    _sgm_post(prefix, impl)("filter_by_cost")(a.ctypes.data_as(C.POINTER(C.c_int16)), c.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int(a.shape[1]), C.c_int(a.shape[0]), C.c_uint16(th))
+    return a
+
+
+def sgm_extract_mask(disp, mask=None, thValid=3, impl=None, prefix="orc_sgm_"):
+    a = np.ascontiguousarray(disp, np.int16)
+    m = np.zeros(a.shape, np.uint8) if mask is None else np.ascontiguousarray(mask, np.uint8).copy()
+    _sgm_post(prefix, impl)("extract_mask")(a.ctypes.data_as(C.POINTER(C.c_int16)), m.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(a.shape[1]), C.c_int(a.shape[0]), C.c_int(thValid), C.c_int(1 if mask is None else 0))
+    return m
+
+
+def sgm_upscale_mask(mask, size2x, impl=None, prefix="orc_sgm_"):
+    m = np.ascontiguousarray(mask, np.uint8); w2, h2 = size2x
+    o = np.zeros((h2, w2), np.uint8)
+    _sgm_post(prefix, impl)("upscale_mask")(m.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(m.shape[1]), C.c_int(m.shape[0]), o.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(w2), C.c_int(h2))
+    return o
+
+
+def sgm_flip_direction(l2r, impl=None, prefix="orc_sgm_"):
+    a = np.ascontiguousarray(l2r, np.int16); o = np.zeros_like(a)
+    _sgm_post(prefix, impl)("flip_direction")(a.ctypes.data_as(C.POINTER(C.c_int16)), C.c_int(a.shape[1]), C.c_int(a.shape[0]), o.ctypes.data_as(C.POINTER(C.c_int16)))
+    return o
+
+
+def sgm_refine(disp, pixels, accums, mode=6, steps=4, impl=None, prefix="orc_sgm_"):
+    """RefineDisparityMap: disp (valid-grid int16), pixels = the SGMHipPixelData table, accums = the 8-path sums (uint16)."""
+    a = np.ascontiguousarray(disp, np.int16).copy(); px = np.ascontiguousarray(pixels); ac = np.ascontiguousarray(accums, np.uint16)
+    _sgm_post(prefix, impl)("refine")(a.ctypes.data_as(C.POINTER(C.c_int16)), px.ctypes.data_as(C.c_void_p), ac.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_long(a.size), C.c_int(mode), C.c_int(steps))
+    return a

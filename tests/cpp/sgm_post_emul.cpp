@@ -1,0 +1,43 @@
+// sgm_post_emul.cpp -- host emulation of the tSGM post-processing kernels: the host+device functions of openmvs_amd/csrc/sgm_post.h are
+// driven by loops that visit the "threads" in a scrambled order, the way sgm_post.hip's kernels would on the GPU.  tests/test_sgm_post.py
+// compares the results with the sequential oracle.  Test code only.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "../../openmvs_amd/csrc/sgm_post.h"
+
+namespace {
+std::vector<size_t> order(size_t n, uint64_t seed) {
+	std::vector<size_t> v(n); for (size_t i = 0; i < n; ++i) v[i] = i;
+	uint64_t st = seed * 2654435761u + 12345;
+	for (size_t i = n; i > 1; --i) { st = st * 6364136223846793005ull + 1442695040888963407ull; std::swap(v[i-1], v[(st >> 33) % i]); }
+	return v;
+}
+}
+extern "C" {
+struct EmuSgmPixel { unsigned long long idx; short minDisp, maxDisp; int pad; };
+void emu_sgm_cross_check(int16_t* l2r, const int16_t* r2l, int wl, int h, int wr, int thCross) {
+	for (size_t i : order((size_t)wl * h, 1)) sgmp_cross_check(l2r, r2l, wl, wr, (int)(i / wl), (int)(i % wl), thCross);
+}
+void emu_sgm_filter_by_cost(int16_t* disp, const uint16_t* cost, int w, int h, uint16_t th) {
+	for (size_t i : order((size_t)w * h, 2)) sgmp_filter_by_cost(disp, cost, i, th);
+}
+void emu_sgm_extract_mask(const int16_t* disp, uint8_t* mask, int w, int h, int thValid, int initValid) {
+	if (initValid) memset(mask, 0xFF, (size_t)w * h);
+	for (size_t r : order((size_t)h, 3)) sgmp_extract_mask_row(disp, mask, w, (int)r, thValid);
+}
+void emu_sgm_upscale_mask(const uint8_t* mask, int w, int h, uint8_t* mask2x, int w2, int h2) {
+	for (size_t i : order((size_t)w2 * h2, 4)) mask2x[i] = sgmp_upscale_mask(mask, w, h, (int)(i / w2), (int)(i % w2));
+}
+void emu_sgm_flip_direction(const int16_t* l2r, int w, int h, int16_t* r2l) {
+	std::vector<uint32_t> keys((size_t)w * h, 0u);
+	for (size_t i : order((size_t)w * h, 5)) sgmp_flip_scatter(l2r, keys.data(), w, (int)(i / w), (int)(i % w));
+	for (size_t i : order((size_t)w * h, 6)) r2l[i] = sgmp_flip_decode(keys[i]);
+}
+void emu_sgm_refine(int16_t* disp, const EmuSgmPixel* pixels, const uint16_t* accums, long nPix, int mode, int steps) {
+	if (steps <= 1) return;
+	for (size_t i : order((size_t)nPix, 7)) disp[i] = sgmp_refine(disp[i], pixels[i].minDisp, pixels[i].maxDisp, accums + pixels[i].idx, mode, steps);
+}
+}

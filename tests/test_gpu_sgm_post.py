@@ -1,0 +1,50 @@
+"""-m gpu: the tSGM steps around Match on the device (csrc/sgm_post.hip through the C ABI) against the sequential oracle; exact."""
+import numpy as np
+import pytest
+
+from openmvs_amd import sgm
+from oracle import pyoracle as po
+from tests import sgm_cases as sc
+from tests import sgm_post_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def matcher():
+    m = sgm.SemiGlobalMatcherHIP(0)
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("w,h,seed", [(131, 77, 1), (640, 301, 2), (9, 5, 3)])
+def test_map_steps_match_the_oracle(matcher, w, h, seed):
+    l2r, r2l = pc.disparity_pair(w, h, seed)
+    for th in (0, 1, 3):
+        assert np.array_equal(matcher.ConsistencyCrossCheck(l2r, r2l, th), po.sgm_cross_check(l2r, r2l, th))
+    narrow = r2l[:, :max(1, w - 5)].copy()
+    assert np.array_equal(matcher.ConsistencyCrossCheck(l2r, narrow, 1), po.sgm_cross_check(l2r, narrow, 1))
+    cost = pc.cost_map(w, h, seed)
+    assert np.array_equal(matcher.FilterByCost(l2r, cost, 1300), po.sgm_filter_by_cost(l2r, cost, 1300))
+    m0 = pc.mask_map(w, h, seed)
+    for tv in (1, 3, 50):
+        assert np.array_equal(matcher.ExtractMask(l2r, thValid=tv), po.sgm_extract_mask(l2r, thValid=tv))
+        assert np.array_equal(matcher.ExtractMask(l2r, m0, tv), po.sgm_extract_mask(l2r, m0, tv))
+    for size in ((2 * w + 6, 2 * h + 6), (2 * w + 5, 2 * h + 7), (2 * w + 1, 2 * h)):
+        assert np.array_equal(matcher.UpscaleMask(m0, size), po.sgm_upscale_mask(m0, size))
+    assert np.array_equal(matcher.FlipDirection(l2r), po.sgm_flip_direction(l2r))
+
+
+def test_refine_on_the_resident_match(matcher):
+    w, h = 80, 60
+    lb, lg, rg = sc.stereo_pair(w, h, 5, seed=3)
+    px, n, mx = sc.ranges(w, h, "ragged", -3, 20, seed=4)
+    od, oc, ocosts, oacc = po.sgm_match(lb, lg, rg, px, n, mx, matcher.P1, matcher.P2s)
+    for mode in range(7):
+        for steps in (1, 4, 16):
+            matcher.set_problem(lb, lg, rg, px, n, mx)
+            matcher.Match()
+            matcher.RefineDisparityMap(mode, steps)
+            d, c = matcher.results()
+            assert np.array_equal(d, po.sgm_refine(od, px, oacc, mode, steps)), (mode, steps)
+            assert np.array_equal(c, oc)

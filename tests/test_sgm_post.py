@@ -1,0 +1,117 @@
+"""CPU tests of the tSGM steps around Match: known answers of the sequential oracle, and the parallel forms of the device kernels
+(openmvs_amd/csrc/sgm_post.h, run through a host emulation with scrambled thread orders) against it."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import sgm_cases as sc
+from tests import sgm_post_cases as pc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NO = pc.NO_DISP
+
+
+@pytest.fixture(scope="module")
+def emul():
+    src = os.path.join(HERE, "cpp", "sgm_post_emul.cpp")
+    out = os.path.join(HERE, "cpp", "build", "libsgm_post_emul.so")
+    hdr = os.path.join(HERE, "..", "openmvs_amd", "csrc", "sgm_post.h")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not os.path.exists(out) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(out):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", out, src])
+    return C.CDLL(out)
+
+
+def test_cross_check_known_answers():
+    l2r = np.full((1, 8), NO, np.int16); r2l = np.full((1, 8), NO, np.int16)
+    l2r[0, 2] = 3; r2l[0, 5] = -3          # consistent
+    l2r[0, 3] = 3; r2l[0, 6] = -5          # |3-5| = 2 > 1
+    l2r[0, 4] = 9                          # lands outside
+    l2r[0, 0] = 1                          # partner invalid
+    l2r[0, 1] = 3; r2l[0, 4] = -2          # |3-2| = 1 <= 1
+    out = po.sgm_cross_check(l2r, r2l)
+    assert list(out[0]) == [NO, 3, 3, NO, NO, NO, NO, NO]
+    assert list(po.sgm_cross_check(l2r, r2l, thCross=2)[0][:4]) == [NO, 3, 3, 3]
+
+
+def test_flip_direction_known_answers():
+    l2r = np.full((1, 10), NO, np.int16)
+    l2r[0, 1] = 2; l2r[0, 2] = 2; l2r[0, 8] = 3; l2r[0, 0] = -4
+    out = po.sgm_flip_direction(l2r)[0]
+    # pixel 1 (d=2) writes -2 to columns 2..4, pixel 2 (d=2) then overwrites 3..5; pixel 8 (d=3) clips to column 9 (10 is outside)
+    exp = np.full(10, NO, np.int16); exp[2:5] = -2; exp[3:6] = -2
+    assert np.array_equal(out, exp)
+    l2r = np.full((1, 6), NO, np.int16); l2r[0, 4] = -4; l2r[0, 2] = -1
+    out = po.sgm_flip_direction(l2r)[0]     # pixel 2 -> columns 0..2 = 1 ; pixel 4 -> columns max(-1,0)..1 = 4 (later column wins on 0,1)
+    assert list(out) == [4, 4, 1, NO, NO, NO]
+
+
+def test_extract_and_upscale_mask_known_answers():
+    d = np.array([[NO, 5, NO, 6, 7, 8, NO, 9, 1, NO]], np.int16)
+    m = po.sgm_extract_mask(d, thValid=2)[0]
+    # from the left: columns 0..3 go INVALID (2nd valid at column 3); from the right: 9, 8, 7 (2nd valid at column 7)
+    assert list(m) == [0, 0, 0, 0, 255, 255, 255, 0, 0, 0]
+    m0 = np.full((1, 10), 255, np.uint8); m0[0, 1] = 0      # already-invalid pixels are skipped and do not count
+    m = po.sgm_extract_mask(d, mask=m0, thValid=2)[0]
+    assert list(m) == [0, 0, 0, 0, 0, 255, 255, 0, 0, 0]
+    up = po.sgm_upscale_mask(np.array([[255, 0], [0, 255]], np.uint8), (8, 9))
+    exp = np.zeros((9, 8), np.uint8); exp[3:5, 3:5] = 255; exp[5:7, 5:7] = 255
+    assert np.array_equal(up, exp)
+    assert np.array_equal(po.sgm_upscale_mask(np.full((3, 3), 255, np.uint8), (8, 8))[3:, 3:], np.full((5, 5), 255, np.uint8))   # clipped at the border
+
+
+def test_refine_known_answers():
+    px = np.zeros(4, [("idx", np.uint64), ("minDisp", np.int16), ("maxDisp", np.int16), ("pad", np.int32)])
+    px["idx"] = [0, 4, 8, 12]; px["minDisp"] = [0, 0, 0, 5]; px["maxDisp"] = [4, 4, 4, 6]
+    acc = np.array([10, 20, 30, 40,   40, 20, 40, 50,   40, 30, 20, 10,   7, 0, 0, 0], np.uint16)
+    d = np.array([0, 1, 3, 5], np.int16)
+    out = po.sgm_refine(d, px, acc, mode=1, steps=4)
+    # pixel 0 at its range minimum: +0.5*10/20 = 0.25 -> 1; pixel 1 symmetric parabola -> ld == rd -> x = 1 -> linear 0.5 -> offset 0 -> 4;
+    # pixel 2 at the last disparity: 3 - 0.5*10/20 = 2.75 -> 11; pixel 3 has a single disparity: returned unscaled (reference quirk)
+    assert list(out) == [1, 4, 11, 5]
+    assert list(po.sgm_refine(d, px, acc, mode=0, steps=4)) == [0, 4, 12, 20]
+    assert list(po.sgm_refine(d, px, acc, mode=6, steps=1)) == [0, 1, 3, 5]
+    none = po.sgm_refine(np.array([NO, NO, NO, NO], np.int16), px, acc)
+    assert np.all(none == NO)
+
+
+@pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (131, 77, 1), (9, 5, 2)])
+def test_parallel_forms_match_the_sequential_oracle(emul, w, h, seed):
+    l2r, r2l = pc.disparity_pair(w, h, seed)
+    E = dict(impl=emul, prefix="emu_sgm_")
+    for th in (0, 1, 3):
+        assert np.array_equal(po.sgm_cross_check(l2r, r2l, th, **E), po.sgm_cross_check(l2r, r2l, th))
+    assert np.array_equal(po.sgm_cross_check(l2r, r2l[:, :w - 5].copy(), 1, **E), po.sgm_cross_check(l2r, r2l[:, :w - 5].copy(), 1))
+    cost = pc.cost_map(w, h, seed)
+    assert np.array_equal(po.sgm_filter_by_cost(l2r, cost, 1300, **E), po.sgm_filter_by_cost(l2r, cost, 1300))
+    for tv in (1, 3, 50):
+        assert np.array_equal(po.sgm_extract_mask(l2r, thValid=tv, **E), po.sgm_extract_mask(l2r, thValid=tv))
+        m0 = pc.mask_map(w, h, seed)
+        assert np.array_equal(po.sgm_extract_mask(l2r, m0, tv, **E), po.sgm_extract_mask(l2r, m0, tv))
+    m = pc.mask_map(w, h, seed)
+    for size in ((2 * w + 6, 2 * h + 6), (2 * w + 5, 2 * h + 7), (2 * w + 1, 2 * h)):
+        assert np.array_equal(po.sgm_upscale_mask(m, size, **E), po.sgm_upscale_mask(m, size))
+    assert np.array_equal(po.sgm_flip_direction(l2r, **E), po.sgm_flip_direction(l2r))
+    flipped = po.sgm_flip_direction(po.sgm_cross_check(l2r, r2l))
+    if w >= 64:
+        assert (flipped != NO).sum() > 0 and np.all(flipped[flipped != NO] < 0)
+
+
+def test_refine_parallel_form_on_a_real_volume(emul):
+    """Sums and disparities of an actual Match (the oracle's) at a small size; all seven fits."""
+    w, h = 80, 60
+    lb, lg, rg = sc.stereo_pair(w, h, 5, seed=3)
+    px, n, mx = sc.ranges(w, h, "ragged", -3, 20, seed=4)
+    d, c, costs, acc = po.sgm_match(lb, lg, rg, px, n, mx, 3, po.sgm_generate_p2s())
+    for mode in range(7):
+        for steps in (1, 4, 16):
+            a = po.sgm_refine(d, px, acc, mode, steps)
+            b = po.sgm_refine(d, px, acc, mode, steps, impl=emul, prefix="emu_sgm_")
+            assert np.array_equal(a, b), (mode, steps)
+    ref4 = po.sgm_refine(d, px, acc, 6, 4)
+    ok = (d != NO) & ((px["maxDisp"] - px["minDisp"]).reshape(d.shape) >= 2)
+    assert np.all(np.abs(ref4[ok].astype(np.int32) - 4 * d[ok].astype(np.int32)) <= 2)      # a sub-pixel offset is at most half a disparity

@@ -68,6 +68,20 @@ int sgmhip_flip_direction(sgmhip_engine* e, const int16_t* l2r, int w, int h, in
  * Fetch the result with sgmhip_get_results.  cos/sin come from csrc/pm_math.h (Cephes kernels), not libm. */
 int sgmhip_refine_disparity(sgmhip_engine* e, int subpixelMode, int subpixelSteps);
 
+/* Disparity2RangeMap (:1350-1444): from the previous level's disparity map (w x h) and the 2x mask (w2 x h2, w2 > 2w+3, h2 >= 2h+3), the pixel
+ * table of the next level: per 2x pixel the search range around the median of the valid disparities in a 7x7 window (41x41 at holes) and the
+ * running cost index.  minNumDisp / minNumDispInvalid: 11 / 33 on the first level, 5 / 7 afterwards (:621,642).  pixels: w2*h2 entries. */
+int sgmhip_disparity2range_map(sgmhip_engine* e, const int16_t* disparity, int w, int h, const uint8_t* mask2x, int w2, int h2,
+                               int minNumDisp, int minNumDispInvalid, SGMHipPixelData* pixels, uint64_t* numCosts, int* maxNumDisp);
+/* Depth2DisparityMap (:1836-1860): depth map of the un-rectified image (dw x dh) -> disparity map of the rectified image (valid size w x h);
+ * invH 3x3 and invQ 4x4 row-major doubles (Image::StereoRectifyImages' H and Q, inverted). */
+int sgmhip_depth2disparity_map(sgmhip_engine* e, const float* depthMap, int dw, int dh, const double invH[9], const double invQ[16], int subpixelSteps,
+                               int16_t* disparity, int w, int h);
+/* Disparity2DepthMap (:1862-1923): disparity (+ optional cost) map of the rectified image (w x h) -> depth (+ confidence = 1/(cost+1)) map of the
+ * un-rectified image (dw x dh). */
+int sgmhip_disparity2depth_map(sgmhip_engine* e, const int16_t* disparity, const uint16_t* cost, int w, int h, const double H[9], const double Q[16],
+                               int subpixelSteps, float* depthMap, float* confMap, int dw, int dh);
+
 /* HIP-event timing since the last reset: milliseconds in the cost-volume, aggregation (8 path
  * kernels) and WTA kernels, number of match calls. */
 typedef struct SGMHipStats { double costMs, aggrMs, wtaMs; uint64_t calls, aggrLaunches; } SGMHipStats;

@@ -244,4 +244,65 @@ int sgmhip_refine_disparity(sgmhip_engine* e, int subpixelMode, int subpixelStep
 	return 0;
 }
 
+int sgmhip_disparity2range_map(sgmhip_engine* e, const int16_t* disparity, int w, int h, const uint8_t* mask2x, int w2, int h2,
+		int minNumDisp, int minNumDispInvalid, SGMHipPixelData* pixels, uint64_t* numCosts, int* maxNumDisp) {
+	if (!e || !disparity || !mask2x || !pixels || w <= 0 || h <= 0 || w2 <= SGM_HW + 2 * w || h2 < SGM_HW + 2 * h) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	DevBuf a, m, r; const size_t n = (size_t)w * h, n2 = (size_t)w2 * h2;
+	SGMCHK(e, a.alloc(n * 2)); SGMCHK(e, m.alloc(n2)); SGMCHK(e, r.alloc(n * 4));
+	SGMCHK(e, hipMemcpyAsync(a.p, disparity, n * 2, hipMemcpyHostToDevice, e->stream)); SGMCHK(e, hipMemcpyAsync(m.p, mask2x, n2, hipMemcpyHostToDevice, e->stream));
+	hipLaunchKernelGGL(sgmp_range_kernel, dim3(gridFor(n)), dim3(256), 0, e->stream, (const int16_t*)a.p, w, h, (const uint8_t*)m.p, w2, minNumDisp, minNumDispInvalid, (short2*)r.p);
+	std::vector<int16_t> rg(n * 2);
+	SGMCHK(e, hipMemcpyAsync(rg.data(), r.p, n * 4, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	// expansion to the 2x pixel table in raster order (:1409-1441): 2x pixel (R, C) takes the range of low-resolution pixel
+	// (R < HW+2 ? 0 : min((R-HW)/2, h-1), likewise for C); idx is the running sum of numDisp
+	uint64_t total = 0; int mx = 0;
+	for (int R = 0; R < h2; ++R) {
+		const int rr = R < SGM_HW + 2 ? 0 : std::min((R - SGM_HW) / 2, h - 1);
+		for (int Cc = 0; Cc < w2; ++Cc) {
+			const int cc = Cc < SGM_HW + 2 ? 0 : std::min((Cc - SGM_HW) / 2, w - 1);
+			const int16_t lo = rg[((size_t)rr * w + cc) * 2], hi = rg[((size_t)rr * w + cc) * 2 + 1];
+			SGMHipPixelData& px = pixels[(size_t)R * w2 + Cc];
+			px.idx = total; px.minDisp = lo; px.maxDisp = hi;
+			const int nd = (int16_t)(hi - lo);
+			total += (uint64_t)(int64_t)nd;
+			if (nd > mx) mx = nd;
+		}
+	}
+	if (numCosts) *numCosts = total;
+	if (maxNumDisp) *maxNumDisp = mx;
+	return 0;
+}
+
+int sgmhip_depth2disparity_map(sgmhip_engine* e, const float* depthMap, int dw, int dh, const double invH[9], const double invQ[16], int subpixelSteps,
+		int16_t* disparity, int w, int h) {
+	if (!e || !depthMap || !invH || !invQ || !disparity || dw <= 0 || dh <= 0 || w <= 0 || h <= 0) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	DevBuf a, b; const size_t nd = (size_t)dw * dh, n = (size_t)w * h;
+	SGMCHK(e, a.alloc(nd * 4)); SGMCHK(e, b.alloc(n * 2));
+	SGMCHK(e, hipMemcpyAsync(a.p, depthMap, nd * 4, hipMemcpyHostToDevice, e->stream));
+	SGMPMat mh{}, mq{}; memcpy(mh.m, invH, 72); memcpy(mq.m, invQ, 128);
+	hipLaunchKernelGGL(sgmp_depth2disparity_kernel, dim3(gridFor(n)), dim3(256), 0, e->stream, (const float*)a.p, dw, dh, mh, mq, subpixelSteps, (int16_t*)b.p, w, h);
+	SGMCHK(e, hipMemcpyAsync(disparity, b.p, n * 2, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+int sgmhip_disparity2depth_map(sgmhip_engine* e, const int16_t* disparity, const uint16_t* cost, int w, int h, const double H[9], const double Q[16],
+		int subpixelSteps, float* depthMap, float* confMap, int dw, int dh) {
+	if (!e || !disparity || !H || !Q || !depthMap || (cost && !confMap) || dw <= 0 || dh <= 0 || w <= 0 || h <= 0 || subpixelSteps <= 0) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	DevBuf a, c, d, f; const size_t n = (size_t)w * h, nd = (size_t)dw * dh;
+	SGMCHK(e, a.alloc(n * 2)); SGMCHK(e, c.alloc(n * 2)); SGMCHK(e, d.alloc(nd * 4)); SGMCHK(e, f.alloc(nd * 4));
+	SGMCHK(e, hipMemcpyAsync(a.p, disparity, n * 2, hipMemcpyHostToDevice, e->stream));
+	if (cost) SGMCHK(e, hipMemcpyAsync(c.p, cost, n * 2, hipMemcpyHostToDevice, e->stream));
+	SGMPMat mh{}, mq{}; memcpy(mh.m, H, 72); memcpy(mq.m, Q, 128);
+	hipLaunchKernelGGL(sgmp_disparity2depth_kernel, dim3(gridFor(nd)), dim3(256), 0, e->stream, (const int16_t*)a.p, cost ? (const uint16_t*)c.p : nullptr, w, h, mh, mq, subpixelSteps, (float*)d.p, (float*)f.p, dw, dh);
+	SGMCHK(e, hipMemcpyAsync(depthMap, d.p, nd * 4, hipMemcpyDeviceToHost, e->stream));
+	if (cost) SGMCHK(e, hipMemcpyAsync(confMap, f.p, nd * 4, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
 } // extern "C"

@@ -117,3 +117,126 @@ PM_HD int16_t sgmp_refine(int16_t d, int minDisp, int maxDisp, const uint16_t* a
 	else disparity += sgmp_subpixel(accums[i - 1], accums[i], accums[i + 1], mode);
 	return (int16_t)(int)pm_floorf(disparity * (float)steps + .5f);
 }
+
+// ---- Disparity2RangeMap (:1350-1444): per low-resolution pixel, the disparity search range for the next tSGM level from the median / minimum /
+// maximum of the valid disparities in a 7x7 window (41x41 where the pixel itself has no disparity).  The k-th smallest of up to 1681 int16 values
+// is found by bisection on the value (16 counting passes over the window) so that a thread needs no storage.
+PM_HD int sgmp_window_count_le(const int16_t* disp, int w, int h, int r, int c, int hw, int v, int* nValid) {
+	int n = 0, le = 0;
+	for (int i = -hw; i <= hw; ++i) { const int y = r + i; if (y < 0 || y >= h) continue;
+		for (int j = -hw; j <= hw; ++j) { const int x = c + j; if (x < 0 || x >= w) continue;
+			const int16_t d = disp[(size_t)y * w + x];
+			if (d == SGMP_NO_DISP) continue;
+			++n; if (d <= v) ++le; } }
+	*nValid = n;
+	return le;
+}
+PM_HD int sgmp_window_kth(const int16_t* disp, int w, int h, int r, int c, int hw, int k) {   // k-th smallest (0-based) of the valid values
+	int lo = -32768, hi = 32766;     // NO_DISP = 32767 is never a value
+	while (lo < hi) {
+		const int mid = lo + ((hi - lo) >> 1);
+		int n; const int le = sgmp_window_count_le(disp, w, h, r, c, hw, mid, &n);
+		if (le > k) hi = mid; else lo = mid + 1;
+	}
+	return lo;
+}
+// out: minDisp, maxDisp (both NO_DISP for a masked-out pixel); returns numDisp
+PM_HD int sgmp_range_of(const int16_t* disp, int w, int h, const uint8_t* mask2x, int w2, int r, int c, int minNumDisp, int minNumDispInvalid,
+		int16_t* oMin, int16_t* oMax) {
+	if (mask2x[(size_t)(r * 2 + SGMP_HW) * w2 + (SGMP_HW + 2 * c)] == SGMP_INVALID) { *oMin = SGMP_NO_DISP; *oMax = SGMP_NO_DISP; return 0; }
+	const bool bInvalid = disp[(size_t)r * w + c] == SGMP_NO_DISP;
+	const int hw = bInvalid ? 20 : 3;
+	int n = 0, mn = 32767, mx = -32768;
+	for (int i = -hw; i <= hw; ++i) { const int y = r + i; if (y < 0 || y >= h) continue;
+		for (int j = -hw; j <= hw; ++j) { const int x = c + j; if (x < 0 || x >= w) continue;
+			const int d = disp[(size_t)y * w + x];
+			if (d == SGMP_NO_DISP) continue;
+			++n; mn = d < mn ? d : mn; mx = d > mx ? d : mx; } }
+	int rmin, rmax, numDisp;
+	if (n < 3) {
+		const int a = (int16_t)(w * 2 / 3);
+		rmax = a < minNumDispInvalid ? a : minNumDispInvalid; rmin = (int16_t)(-rmax); numDisp = (int16_t)(rmax - rmin);
+	} else {
+		int med;
+		if (n & 1) med = sgmp_window_kth(disp, w, h, r, c, hw, n >> 1);
+		else med = (int16_t)((sgmp_window_kth(disp, w, h, r, c, hw, (n >> 1) - 1) + sgmp_window_kth(disp, w, h, r, c, hw, n >> 1)) / 2);
+		const int d2 = (int16_t)(med * 2);
+		numDisp = (int16_t)((mx - mn) * 2);
+		if (numDisp < minNumDisp) {
+			numDisp = minNumDisp; rmin = (int16_t)(d2 - numDisp / 2); rmax = (int16_t)(d2 + (numDisp + 1) / 2);
+		} else {
+			const int maxNum = bInvalid ? 64 : 32;
+			if (numDisp > maxNum) {
+				rmin = (int16_t)(d2 - (maxNum * (d2 - mn * 2) + 1) / numDisp);
+				rmax = (int16_t)(d2 + (maxNum * (mx * 2 + 1 - d2) + 1) / numDisp);
+				numDisp = (int16_t)(rmax - rmin);
+			} else { rmin = (int16_t)(d2 - numDisp / 2); rmax = (int16_t)(d2 + (numDisp + 1) / 2); }
+		}
+	}
+	*oMin = (int16_t)rmin; *oMax = (int16_t)rmax;
+	return numDisp;
+}
+
+// ---- disparity <-> depth between the rectified and the original image (:1815-1923; Image::Disparity2Depth / Depth2Disparity,
+// libs/MVS/Image.cpp:367-433; TImage::sampleSafe with a validity functor, libs/Common/Types.inl:2315-2332) -------------------------------
+PM_HD int sgmp_clampi(int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
+// bilinear sample of the valid neighbours only; valid(v): float maps v > 0, int16 maps v != NO_DISP.  T = float or int16_t / uint16_t
+template <typename T, typename VALID>
+PM_HD bool sgmp_sample_safe(const T* img, int w, int h, float px, float py, VALID valid, float* out) {
+	const int lx = (int)px, ly = (int)py;
+	const float x = px - (float)lx, x1 = 1.f - x, y = py - (float)ly, y1 = 1.f - y;
+	const T v00 = img[(size_t)sgmp_clampi(ly, h) * w + sgmp_clampi(lx, w)], v10 = img[(size_t)sgmp_clampi(ly, h) * w + sgmp_clampi(lx + 1, w)];
+	const T v01 = img[(size_t)sgmp_clampi(ly + 1, h) * w + sgmp_clampi(lx, w)], v11 = img[(size_t)sgmp_clampi(ly + 1, h) * w + sgmp_clampi(lx + 1, w)];
+	const bool b00 = valid(v00), b10 = valid(v10), b01 = valid(v01), b11 = valid(v11);
+	if (!b00 && !b10 && !b01 && !b11) return false;
+	const float a = (float)(b00 ? v00 : (b10 ? v10 : (b01 ? v01 : v11))), b = (float)(b10 ? v10 : (b00 ? v00 : (b11 ? v11 : v01)));
+	const float cc = (float)(b01 ? v01 : (b11 ? v11 : (b00 ? v00 : v10))), dd = (float)(b11 ? v11 : (b01 ? v01 : (b10 ? v10 : v00)));
+	*out = y1 * (x1 * a + x * b) + y * (x1 * cc + x * dd);
+	return true;
+}
+struct SgmpValidDepth { PM_HD bool operator()(float d) const { return d > 0; } };
+struct SgmpValidDisp { PM_HD bool operator()(int16_t d) const { return d != SGMP_NO_DISP; } };
+struct SgmpValidCost { PM_HD bool operator()(uint16_t c) const { return c != SGMP_NO_ACCUM; } };
+// ProjectVertex_3x3_2_2 with a double matrix and integer input, float output (libs/Common/Util.inl:389-393; INVERT as the reference)
+PM_HD void sgmp_project_h(const double* H, int x, int y, float* u) {
+	const double z = H[6] * x + H[7] * y + H[8];
+	const double invZ = z == 0.0 ? 1e+14 : 1.0 / z;   // INVERT(0) = INV_ZERO, libs/Common/Types.h:562,1234
+	u[0] = (float)((H[0] * x + H[1] * y + H[2]) * invZ);
+	u[1] = (float)((H[3] * x + H[4] * y + H[5]) * invZ);
+}
+// Image::Depth2Disparity
+PM_HD bool sgmp_depth2disparity(const double* Q, float ux, float uy, float d, float* disparity) {
+	const double w = (Q[12] * ux + Q[13] * uy + Q[14]) * d + Q[15];
+	if ((w < 0 ? -w : w) < 1e-7) return false;
+	const double z = (Q[8] * ux + Q[9] * uy + Q[10]) * d + Q[11];
+	*disparity = -(float)(z / w);
+	return true;
+}
+// TDisparity2Depth(Q, u, d)
+PM_HD float sgmp_disparity2depth(const double* Q, float ux, float uy, float d) {
+	const double w = Q[12] * ux + Q[13] * uy - Q[14] * d + Q[15];
+	if ((w < 0 ? -w : w) < 1e-7) return 0.f;
+	const double z = Q[8] * ux + Q[9] * uy - Q[10] * d + Q[11];
+	const float depth = (float)(z / w);
+	return depth < 0.0001f ? 0.f : depth;
+}
+// Depth2DisparityMap, one pixel (r,c) of the valid-size disparity map
+PM_HD int16_t sgmp_depth2disparity_px(const float* depth, int dw, int dh, const double* invH, const double* invQ, int steps, int r, int c) {
+	float u[2]; sgmp_project_h(invH, c + SGMP_HW, r + SGMP_HW, u);
+	float dep, disp;
+	if (!sgmp_sample_safe(depth, dw, dh, u[0], u[1], SgmpValidDepth(), &dep) || !sgmp_depth2disparity(invQ, u[0], u[1], dep, &disp)) return SGMP_NO_DISP;
+	return (int16_t)(int)pm_floorf(disp * (float)steps + .5f);
+}
+// Disparity2DepthMap, one pixel (r,c) of the depth map; cost may be null
+PM_HD void sgmp_disparity2depth_px(const int16_t* disp, const uint16_t* cost, int w, int h, const double* H, const double* Q, int steps, int r, int c, float* depth, float* conf) {
+	float u[2]; sgmp_project_h(H, c, r, u);
+	u[0] -= (float)SGMP_HW; u[1] -= (float)SGMP_HW;
+	float d;
+	if (!sgmp_sample_safe(disp, w, h, u[0], u[1], SgmpValidDisp(), &d)) { *depth = 0.f; if (cost) *conf = 0.f; return; }
+	if (cost) {
+		float cst = 0.f;      // (left untouched by the reference when no neighbour is valid; costs of valid disparities are valid)
+		sgmp_sample_safe(cost, w, h, u[0], u[1], SgmpValidCost(), &cst);
+		*conf = 1.f / (cst + 1.f);
+	}
+	*depth = sgmp_disparity2depth(Q, u[0], u[1], d / (float)steps);
+}

@@ -36,3 +36,27 @@ __global__ void sgmp_refine_kernel(const SGMPixel* __restrict__ pixels, const un
 		disp[i] = sgmp_refine(disp[i], px.minDisp, px.maxDisp, accums + px.idx, mode, steps);
 	}
 }
+
+// Disparity2RangeMap, device part: the range of every low-resolution pixel (the host expands it to the 2x pixel table and its running index)
+__global__ void sgmp_range_kernel(const int16_t* disp, int w, int h, const uint8_t* mask2x, int w2, int minNumDisp, int minNumDispInvalid, short2* ranges) {
+	const size_t n = (size_t)w * h;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		int16_t a, b;
+		sgmp_range_of(disp, w, h, mask2x, w2, (int)(i / w), (int)(i % w), minNumDisp, minNumDispInvalid, &a, &b);
+		ranges[i] = make_short2(a, b);
+	}
+}
+struct SGMPMat { double m[16]; };
+__global__ void sgmp_depth2disparity_kernel(const float* depth, int dw, int dh, SGMPMat invH, SGMPMat invQ, int steps, int16_t* disp, int w, int h) {
+	const size_t n = (size_t)w * h;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+		disp[i] = sgmp_depth2disparity_px(depth, dw, dh, invH.m, invQ.m, steps, (int)(i / w), (int)(i % w));
+}
+__global__ void sgmp_disparity2depth_kernel(const int16_t* disp, const uint16_t* cost, int w, int h, SGMPMat H, SGMPMat Q, int steps, float* depth, float* conf, int dw, int dh) {
+	const size_t n = (size_t)dw * dh;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		float cf = 0.f;
+		sgmp_disparity2depth_px(disp, cost, w, h, H.m, Q.m, steps, (int)(i / dw), (int)(i % dw), depth + i, &cf);
+		if (cost) conf[i] = cf;
+	}
+}

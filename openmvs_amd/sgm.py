@@ -13,7 +13,7 @@ PIXEL_DTYPE = np.dtype([("idx", np.uint64), ("minDisp", np.int16), ("maxDisp", n
 EXPORTS = ["sgmhip_create", "sgmhip_destroy", "sgmhip_last_error", "sgmhip_generate_p2s", "sgmhip_set_problem",
            "sgmhip_match", "sgmhip_get_results", "sgmhip_sync", "sgmhip_stats_reset", "sgmhip_stats_get",
            "sgmhip_consistency_cross_check", "sgmhip_filter_by_cost", "sgmhip_extract_mask", "sgmhip_upscale_mask", "sgmhip_flip_direction",
-           "sgmhip_refine_disparity"]
+           "sgmhip_refine_disparity", "sgmhip_disparity2range_map", "sgmhip_depth2disparity_map", "sgmhip_disparity2depth_map"]
 NO_DISP = 32767          # SemiGlobalMatcher::NO_DISP
 INVALID, VALID = 0, 255  # MaskMap values
 SUBPIXEL_NA, SUBPIXEL_LINEAR, SUBPIXEL_POLY4, SUBPIXEL_PARABOLA, SUBPIXEL_SINE, SUBPIXEL_COSINE, SUBPIXEL_LC_BLEND = range(7)
@@ -129,6 +129,31 @@ class SemiGlobalMatcherHIP:
     def RefineDisparityMap(self, subpixelMode=SUBPIXEL_LC_BLEND, subpixelSteps=4):
         """In place on the device, on the result of the last Match(); read it back with results()."""
         self._chk(self._lib.sgmhip_refine_disparity(self._h, subpixelMode, subpixelSteps))
+
+    def Disparity2RangeMap(self, disparity, mask2x, minNumDisp=5, minNumDispInvalid=7):
+        """-> (pixel table of the 2x level, numCosts, maxNumDisp), ready for set_problem."""
+        a = np.ascontiguousarray(disparity, np.int16); m = np.ascontiguousarray(mask2x, np.uint8)
+        px = np.zeros(m.size, PIXEL_DTYPE); n = C.c_uint64(0); mx = C.c_int(0)
+        self._chk(self._lib.sgmhip_disparity2range_map(self._h, a.ctypes.data_as(C.POINTER(C.c_int16)), a.shape[1], a.shape[0], m.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                       m.shape[1], m.shape[0], minNumDisp, minNumDispInvalid, px.ctypes.data_as(C.c_void_p), C.byref(n), C.byref(mx)))
+        return px, int(n.value), int(mx.value)
+
+    def Depth2DisparityMap(self, depth, invH, invQ, subpixelSteps, size):
+        d = np.ascontiguousarray(depth, np.float32); w, h = size
+        o = np.zeros((h, w), np.int16)
+        ih = np.ascontiguousarray(invH, np.float64); iq = np.ascontiguousarray(invQ, np.float64)
+        self._chk(self._lib.sgmhip_depth2disparity_map(self._h, d.ctypes.data_as(C.POINTER(C.c_float)), d.shape[1], d.shape[0], ih.ctypes.data_as(C.POINTER(C.c_double)),
+                                                       iq.ctypes.data_as(C.POINTER(C.c_double)), subpixelSteps, o.ctypes.data_as(C.POINTER(C.c_int16)), w, h))
+        return o
+
+    def Disparity2DepthMap(self, disparity, cost, H, Q, subpixelSteps, size):
+        a = np.ascontiguousarray(disparity, np.int16); c = None if cost is None else np.ascontiguousarray(cost, np.uint16); dw, dh = size
+        dep = np.zeros((dh, dw), np.float32); cf = np.zeros((dh, dw), np.float32)
+        hh = np.ascontiguousarray(H, np.float64); qq = np.ascontiguousarray(Q, np.float64)
+        self._chk(self._lib.sgmhip_disparity2depth_map(self._h, a.ctypes.data_as(C.POINTER(C.c_int16)), None if c is None else c.ctypes.data_as(C.POINTER(C.c_uint16)), a.shape[1], a.shape[0],
+                                                       hh.ctypes.data_as(C.POINTER(C.c_double)), qq.ctypes.data_as(C.POINTER(C.c_double)), subpixelSteps,
+                                                       dep.ctypes.data_as(C.POINTER(C.c_float)), cf.ctypes.data_as(C.POINTER(C.c_float)), dw, dh))
+        return dep, (None if c is None else cf)
 
     def sync(self):
         self._chk(self._lib.sgmhip_sync(self._h))

@@ -359,3 +359,36 @@ def sgm_refine(disp, pixels, accums, mode=6, steps=4, impl=None, prefix="orc_sgm
     a = np.ascontiguousarray(disp, np.int16).copy(); px = np.ascontiguousarray(pixels); ac = np.ascontiguousarray(accums, np.uint16)
     _sgm_post(prefix, impl)("refine")(a.ctypes.data_as(C.POINTER(C.c_int16)), px.ctypes.data_as(C.c_void_p), ac.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_long(a.size), C.c_int(mode), C.c_int(steps))
     return a
+
+
+_SGM_PIXEL = np.dtype([("idx", np.uint64), ("minDisp", np.int16), ("maxDisp", np.int16), ("pad", np.int32)])
+
+
+def sgm_disparity2range_map(disp, mask2x, minNumDisp=5, minNumDispInvalid=7, impl=None, prefix="orc_sgm_"):
+    a = np.ascontiguousarray(disp, np.int16); m = np.ascontiguousarray(mask2x, np.uint8)
+    px = np.zeros(m.size, _SGM_PIXEL); mx = C.c_int(0)
+    f = _sgm_post(prefix, impl)("disparity2range_map"); f.restype = C.c_ulonglong
+    n = f(a.ctypes.data_as(C.POINTER(C.c_int16)), C.c_int(a.shape[1]), C.c_int(a.shape[0]), m.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(m.shape[1]), C.c_int(m.shape[0]),
+          C.c_int(minNumDisp), C.c_int(minNumDispInvalid), px.ctypes.data_as(C.c_void_p), C.byref(mx))
+    return px, int(n), int(mx.value)
+
+
+def _dp(a):
+    a = np.ascontiguousarray(a, np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def sgm_depth2disparity_map(depth, invH, invQ, steps, size, impl=None, prefix="orc_sgm_"):
+    d = np.ascontiguousarray(depth, np.float32); w, h = size
+    o = np.zeros((h, w), np.int16); kh, ph = _dp(invH); kq, pq = _dp(invQ)
+    _sgm_post(prefix, impl)("depth2disparity_map")(d.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(d.shape[1]), C.c_int(d.shape[0]), ph, pq, C.c_int(steps),
+                                                   o.ctypes.data_as(C.POINTER(C.c_int16)), C.c_int(w), C.c_int(h))
+    return o
+
+
+def sgm_disparity2depth_map(disp, cost, H, Q, steps, size, impl=None, prefix="orc_sgm_"):
+    a = np.ascontiguousarray(disp, np.int16); c = None if cost is None else np.ascontiguousarray(cost, np.uint16); dw, dh = size
+    dep = np.zeros((dh, dw), np.float32); cf = np.zeros((dh, dw), np.float32); kh, ph = _dp(H); kq, pq = _dp(Q)
+    _sgm_post(prefix, impl)("disparity2depth_map")(a.ctypes.data_as(C.POINTER(C.c_int16)), None if c is None else c.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int(a.shape[1]), C.c_int(a.shape[0]),
+                                                   ph, pq, C.c_int(steps), dep.ctypes.data_as(C.POINTER(C.c_float)), cf.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(dw), C.c_int(dh))
+    return dep, (None if c is None else cf)

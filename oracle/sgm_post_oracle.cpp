@@ -97,3 +97,130 @@ void orc_sgm_refine(int16_t* disp, const OrcSgmPixel* pixels, const uint16_t* ac
 	}
 }
 } // extern "C"
+
+// ---- Disparity2RangeMap (:1350-1444), Depth2DisparityMap (:1836-1860), Disparity2DepthMap (:1862-1923) -------------------------------
+#include <algorithm>
+namespace {
+int getMedian(std::vector<int16_t>& v) {   // cList::GetMedian<Disparity>, libs/Common/List.h:668-678
+	const size_t n = v.size();
+	if (n % 2) { std::nth_element(v.begin(), v.begin() + (n >> 1), v.end()); return v[n >> 1]; }
+	std::nth_element(v.begin(), v.begin() + (n >> 1), v.end());
+	const int16_t nth = v[n >> 1];
+	std::nth_element(v.begin(), v.begin() + (n >> 1) - 1, v.begin() + (n >> 1));
+	const int16_t nth1 = v[(n >> 1) - 1];
+	return (int16_t)(((int16_t)nth1 + (int16_t)nth) / (int16_t)2);
+}
+template <typename T> T getPixel(const T* img, int w, int h, int y, int x) { x = x < 0 ? 0 : (x >= w ? w - 1 : x); y = y < 0 ? 0 : (y >= h ? h - 1 : y); return img[(size_t)y * w + x]; }
+template <typename T, typename F> bool sampleSafe(const T* img, int w, int h, float px, float py, F functor, float& v) {   // Types.inl:2315-2332
+	const int lx = (int)px, ly = (int)py;
+	const float x = px - lx, x1 = 1.f - x, y = py - ly, y1 = 1.f - y;
+	const T x0y0 = getPixel(img, w, h, ly, lx), x1y0 = getPixel(img, w, h, ly, lx + 1), x0y1 = getPixel(img, w, h, ly + 1, lx), x1y1 = getPixel(img, w, h, ly + 1, lx + 1);
+	const bool b00 = functor(x0y0), b10 = functor(x1y0), b01 = functor(x0y1), b11 = functor(x1y1);
+	if (!b00 && !b10 && !b01 && !b11) return false;
+	v = y1 * (x1 * (float)(b00 ? x0y0 : (b10 ? x1y0 : (b01 ? x0y1 : x1y1))) + x * (float)(b10 ? x1y0 : (b00 ? x0y0 : (b11 ? x1y1 : x0y1)))) +
+	    y * (x1 * (float)(b01 ? x0y1 : (b11 ? x1y1 : (b00 ? x0y0 : x1y0))) + x * (float)(b11 ? x1y1 : (b01 ? x0y1 : (b10 ? x1y0 : x0y0))));
+	return true;
+}
+void projectVertex(const double* H, const int* X, float* pt) {   // ProjectVertex_3x3_2_2, Util.inl:389-393
+	const double z = H[6] * X[0] + H[7] * X[1] + H[8];
+	const double invZ = z == 0 ? 1e+14 : 1.0 / z;
+	pt[0] = (float)((H[0] * X[0] + H[1] * X[1] + H[2]) * invZ);
+	pt[1] = (float)((H[3] * X[0] + H[4] * X[1] + H[5]) * invZ);
+}
+}
+extern "C" {
+unsigned long long orc_sgm_disparity2range_map(const int16_t* disparityMap, int cols, int rows, const uint8_t* maskMap, int w2, int h2,
+		int minNumDisp, int minNumDispInvalid, OrcSgmPixel* imagePixels, int* outMaxNumDisp) {
+	unsigned long long numCosts = 0;
+	int maxNumDisp = 0;
+	std::vector<int16_t> disps;
+	for (int r = 0; r < rows; ++r) {
+		const int r2 = (r == 0 ? 0 : r * 2 + HW);
+		const int offset = r2 * w2;
+		int c2e = HW;
+		const uint8_t* pm = maskMap + (size_t)(r * 2 + HW) * w2 + HW;
+		int c2 = 0;
+		for (int c = 0; c < cols; ++c, pm += 2) {
+			int16_t numDisp; int16_t rmin, rmax;
+			if (*pm == INVALID) { rmin = rmax = NO_DISP; numDisp = 0; }
+			else {
+				const bool bInvalid = disparityMap[(size_t)r * cols + c] == NO_DISP;
+				disps.clear();
+				const int hw = bInvalid ? 20 : 3;
+				for (int i = -hw; i <= hw; ++i) for (int j = -hw; j <= hw; ++j) {
+					const int ux = c + j, uy = r + i;
+					if (ux >= 0 && uy >= 0 && ux < cols && uy < rows) { const int16_t d = disparityMap[(size_t)uy * cols + ux]; if (d != NO_DISP) disps.push_back(d); }
+				}
+				if (disps.size() < 3) {
+					const int16_t a = (int16_t)(cols * 2 / 3);
+					rmax = a < (int16_t)minNumDispInvalid ? a : (int16_t)minNumDispInvalid; rmin = (int16_t)-rmax; numDisp = (int16_t)(rmax - rmin);
+				} else {
+					int16_t mn = *std::min_element(disps.begin(), disps.end()), mx = *std::max_element(disps.begin(), disps.end());
+					const int16_t disp = (int16_t)(getMedian(disps) * 2);
+					numDisp = (int16_t)((mx - mn) * 2);
+					if (numDisp < minNumDisp) { numDisp = (int16_t)minNumDisp; rmin = (int16_t)(disp - numDisp / 2); rmax = (int16_t)(disp + (numDisp + 1) / 2); }
+					else {
+						const int16_t maxNum = bInvalid ? 64 : 32;
+						if (numDisp > maxNum) {
+							rmin = (int16_t)(disp - (maxNum * (disp - mn * 2) + 1) / numDisp);
+							rmax = (int16_t)(disp + (maxNum * (mx * 2 + 1 - disp) + 1) / numDisp);
+							numDisp = (int16_t)(rmax - rmin);
+						} else { rmin = (int16_t)(disp - numDisp / 2); rmax = (int16_t)(disp + (numDisp + 1) / 2); }
+					}
+				}
+				if (maxNumDisp < numDisp) maxNumDisp = numDisp;
+			}
+			c2e += 2;
+			do { OrcSgmPixel& pixel = imagePixels[offset + c2]; pixel.minDisp = rmin; pixel.maxDisp = rmax; pixel.idx = numCosts; numCosts += numDisp; } while (++c2 < c2e);
+		}
+		do {
+			const OrcSgmPixel& pixel = imagePixels[offset + c2e - 1];
+			OrcSgmPixel& _pixel = imagePixels[offset + c2e];
+			_pixel.minDisp = pixel.minDisp; _pixel.maxDisp = pixel.maxDisp; _pixel.idx = numCosts;
+			numCosts += (int16_t)(pixel.maxDisp - pixel.minDisp);
+		} while (++c2e < w2);
+		const int _offsete = (r + 1 == rows ? h2 : r * 2 + HW + 2) * w2;
+		for (int _offset = offset + w2; _offset < _offsete; _offset += w2) for (int cc = 0; cc < w2; ++cc) {
+			const OrcSgmPixel& pixel = imagePixels[offset + cc];
+			OrcSgmPixel& _pixel = imagePixels[_offset + cc];
+			_pixel.minDisp = pixel.minDisp; _pixel.maxDisp = pixel.maxDisp; _pixel.idx = numCosts;
+			numCosts += (int16_t)(pixel.maxDisp - pixel.minDisp);
+		}
+	}
+	if (outMaxNumDisp) *outMaxNumDisp = maxNumDisp;
+	return numCosts;
+}
+void orc_sgm_depth2disparity_map(const float* depthMap, int dw, int dh, const double* invH, const double* invQ, int subpixelSteps, int16_t* disparityMap, int w, int h) {
+	for (int r = 0; r < h; ++r) for (int c = 0; c < w; ++c) {
+		const int x[2] = {c + HW, r + HW}; float u[2];
+		projectVertex(invH, x, u);
+		float depth, disparity = 0;
+		bool ok = sampleSafe(depthMap, dw, dh, u[0], u[1], [](float d) { return d > 0; }, depth);
+		if (ok) {   // Image::Depth2Disparity, Image.cpp:425-433
+			const double ww = (invQ[12] * u[0] + invQ[13] * u[1] + invQ[14]) * depth + invQ[15];
+			if (fabs(ww) < 1e-7) ok = false;
+			else { const double z = (invQ[8] * u[0] + invQ[9] * u[1] + invQ[10]) * depth + invQ[11]; disparity = -(float)(z / ww); }
+		}
+		disparityMap[(size_t)r * w + c] = ok ? (int16_t)(int)floorf(disparity * subpixelSteps + .5f) : NO_DISP;
+	}
+}
+void orc_sgm_disparity2depth_map(const int16_t* disparityMap, const uint16_t* costMap, int w, int h, const double* H, const double* Q, int subpixelSteps,
+		float* depthMap, float* confMap, int dw, int dh) {
+	for (int r = 0; r < dh; ++r) for (int c = 0; c < dw; ++c) {
+		const int x[2] = {c, r}; float u[2];
+		projectVertex(H, x, u);
+		u[0] -= (float)HW; u[1] -= (float)HW;
+		float disparity;
+		const size_t i = (size_t)r * dw + c;
+		if (!sampleSafe(disparityMap, w, h, u[0], u[1], [](int16_t d) { return d != NO_DISP; }, disparity)) { depthMap[i] = 0; if (costMap) confMap[i] = 0; continue; }
+		float cost = 0;
+		if (costMap) sampleSafe(costMap, w, h, u[0], u[1], [](uint16_t cc) { return cc != 65535; }, cost);
+		const float d = disparity / subpixelSteps;
+		const double ww = Q[12] * u[0] + Q[13] * u[1] - Q[14] * d + Q[15];   // TDisparity2Depth, Image.cpp:371-381
+		float depth = 0;
+		if (!(fabs(ww) < 1e-7)) { const double z = Q[8] * u[0] + Q[9] * u[1] - Q[10] * d + Q[11]; depth = (float)(z / ww); if (depth < 0.0001f) depth = 0; }
+		depthMap[i] = depth;
+		if (costMap) confMap[i] = 1.f / (cost + 1);
+	}
+}
+} // extern "C"

@@ -41,3 +41,25 @@ void emu_sgm_refine(int16_t* disp, const EmuSgmPixel* pixels, const uint16_t* ac
 	for (size_t i : order((size_t)nPix, 7)) disp[i] = sgmp_refine(disp[i], pixels[i].minDisp, pixels[i].maxDisp, accums + pixels[i].idx, mode, steps);
 }
 }
+
+extern "C" {
+unsigned long long emu_sgm_disparity2range_map(const int16_t* disp, int w, int h, const uint8_t* mask2x, int w2, int h2, int minNumDisp, int minNumDispInvalid,
+		EmuSgmPixel* pixels, int* maxNumDisp) {
+	std::vector<int16_t> rg((size_t)w * h * 2);
+	for (size_t i : order((size_t)w * h, 8)) sgmp_range_of(disp, w, h, mask2x, w2, (int)(i / w), (int)(i % w), minNumDisp, minNumDispInvalid, &rg[i * 2], &rg[i * 2 + 1]);
+	unsigned long long total = 0; int mx = 0;      // the host-side expansion of sgmhip_disparity2range_map
+	for (int R = 0; R < h2; ++R) { const int rr = R < SGMP_HW + 2 ? 0 : std::min((R - SGMP_HW) / 2, h - 1);
+		for (int Cc = 0; Cc < w2; ++Cc) { const int cc = Cc < SGMP_HW + 2 ? 0 : std::min((Cc - SGMP_HW) / 2, w - 1);
+			const int16_t lo = rg[((size_t)rr * w + cc) * 2], hi = rg[((size_t)rr * w + cc) * 2 + 1];
+			EmuSgmPixel& px = pixels[(size_t)R * w2 + Cc]; px.idx = total; px.minDisp = lo; px.maxDisp = hi; px.pad = 0;
+			const int nd = (int16_t)(hi - lo); total += (unsigned long long)(long long)nd; if (nd > mx) mx = nd; } }
+	if (maxNumDisp) *maxNumDisp = mx;
+	return total;
+}
+void emu_sgm_depth2disparity_map(const float* depth, int dw, int dh, const double* invH, const double* invQ, int steps, int16_t* disp, int w, int h) {
+	for (size_t i : order((size_t)w * h, 9)) disp[i] = sgmp_depth2disparity_px(depth, dw, dh, invH, invQ, steps, (int)(i / w), (int)(i % w));
+}
+void emu_sgm_disparity2depth_map(const int16_t* disp, const uint16_t* cost, int w, int h, const double* H, const double* Q, int steps, float* depth, float* conf, int dw, int dh) {
+	for (size_t i : order((size_t)dw * dh, 10)) { float cf = 0.f; sgmp_disparity2depth_px(disp, cost, w, h, H, Q, steps, (int)(i / dw), (int)(i % dw), depth + i, &cf); if (cost) conf[i] = cf; }
+}
+}

@@ -28,3 +28,23 @@ def mask_map(w, h, seed=0):
     m[r.rand(h, w) < 0.1] = 0
     m[:, :3] = 0
     return m
+
+
+def smooth_disparity(w, h, seed=0):
+    """A piecewise-smooth low-resolution disparity map with holes (what a tSGM level hands to Disparity2RangeMap)."""
+    r = np.random.RandomState(seed + 300)
+    ys, xs = np.mgrid[0:h, 0:w]
+    d = (8 * np.sin(xs / 9.0) + 5 * np.cos(ys / 7.0) + (xs > w // 2) * 12).astype(np.int16)
+    d[r.rand(h, w) < 0.2] = NO_DISP
+    d[h // 3:h // 3 + 12, w // 4:w // 4 + 25] = NO_DISP        # a hole bigger than the 7x7 window
+    d[:, :2] = NO_DISP
+    return d
+
+
+def rectification(seed=0):
+    """A plausible stereo rectification: H (3x3 homography close to identity) and Q (4x4 disparity-to-depth) and their inverses."""
+    r = np.random.RandomState(seed + 400)
+    H = np.eye(3) + 0.02 * r.randn(3, 3); H[2, :2] *= 1e-3; H[2, 2] = 1
+    f, cx, cy, B = 600.0, 80.0, 60.0, 0.3
+    Q = np.array([[1, 0, 0, -cx], [0, 1, 0, -cy], [0, 0, 0, f], [0, 0, -1.0 / B, 0]], np.float64)
+    return H, Q, np.linalg.inv(H), np.linalg.inv(Q + 1e-9 * np.eye(4))

@@ -48,3 +48,38 @@ def test_refine_on_the_resident_match(matcher):
             d, c = matcher.results()
             assert np.array_equal(d, po.sgm_refine(od, px, oacc, mode, steps)), (mode, steps)
             assert np.array_equal(c, oc)
+
+
+# The three functions below were written after the round's GPU budget was used up: their logic is verified on the CPU through the host emulation
+# (tests/test_sgm_post.py) but this is their first run on a device, hence the non-strict xfail (an XPASS is the expected outcome).
+_first_run = pytest.mark.xfail(strict=False, reason="first device run of these kernels (CPU emulation verified)")
+
+
+@_first_run
+@pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (97, 53, 1)])
+def test_range_map_matches_the_oracle(matcher, w, h, seed):
+    d = pc.smooth_disparity(w, h, seed)
+    mask = pc.mask_map(2 * w + 7, 2 * h + 6, seed)
+    for a, b in ((11, 33), (5, 7)):
+        px0, n0, m0 = po.sgm_disparity2range_map(d, mask, a, b)
+        px1, n1, m1 = matcher.Disparity2RangeMap(d, mask, a, b)
+        assert n0 == n1 and m0 == m1
+        for k in ("idx", "minDisp", "maxDisp"):
+            assert np.array_equal(px0[k], px1[k]), k
+
+
+@_first_run
+@pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (97, 53, 1)])
+def test_disparity_depth_conversions_match_the_oracle(matcher, w, h, seed):
+    H, Q, iH, iQ = pc.rectification(seed)
+    depth = (3.0 + 0.5 * np.sin(np.arange(h * w).reshape(h, w) / 50.0)).astype(np.float32)
+    depth[np.random.RandomState(seed).rand(h, w) < 0.2] = 0
+    cost = pc.cost_map(w - 6, h - 6, seed)
+    for steps in (1, 4):
+        a = po.sgm_depth2disparity_map(depth, iH, iQ, steps, (w - 6, h - 6))
+        assert np.array_equal(matcher.Depth2DisparityMap(depth, iH, iQ, steps, (w - 6, h - 6)), a)
+        for cst in (None, cost):
+            da, ca = po.sgm_disparity2depth_map(a, cst, H, Q, steps, (w, h))
+            db, cb = matcher.Disparity2DepthMap(a, cst, H, Q, steps, (w, h))
+            assert np.array_equal(da.view(np.uint32), db.view(np.uint32))
+            assert cst is None or np.array_equal(ca.view(np.uint32), cb.view(np.uint32))

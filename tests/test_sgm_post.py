@@ -115,3 +115,48 @@ def test_refine_parallel_form_on_a_real_volume(emul):
     ref4 = po.sgm_refine(d, px, acc, 6, 4)
     ok = (d != NO) & ((px["maxDisp"] - px["minDisp"]).reshape(d.shape) >= 2)
     assert np.all(np.abs(ref4[ok].astype(np.int32) - 4 * d[ok].astype(np.int32)) <= 2)      # a sub-pixel offset is at most half a disparity
+
+
+def test_range_map_known_answers():
+    """A constant map: median = min = max = d -> numDisp 0 < minNumDisp -> [2d - n/2, 2d + (n+1)/2); masked pixels get an empty range."""
+    d = np.full((6, 8), 7, np.int16)
+    mask = np.full((2 * 6 + 6, 2 * 8 + 6), 255, np.uint8)
+    mask[3 + 2 * 2, 3 + 2 * 5] = 0                       # low-resolution pixel (2,5) is masked out
+    px, n, mx = po.sgm_disparity2range_map(d, mask, 5, 7)
+    t = px.reshape(mask.shape)
+    assert mx == 5 and t["minDisp"][0, 0] == 12 and t["maxDisp"][0, 0] == 17
+    assert t["minDisp"][3 + 4, 3 + 10] == NO and t["maxDisp"][3 + 4 + 1, 3 + 10 + 1] == NO      # its 2x2 block
+    nd = (t["maxDisp"].astype(np.int64) - t["minDisp"]).ravel()
+    assert n == nd.sum() and np.array_equal(px["idx"], np.concatenate([[0], np.cumsum(nd)[:-1]]).astype(np.uint64))
+    # fewer than 3 valid disparities around a pixel: symmetric default range min(2w/3, minNumDispInvalid)
+    d2 = np.full((6, 8), NO, np.int16); d2[0, 0] = 1
+    t2 = po.sgm_disparity2range_map(d2, mask, 5, 7)[0].reshape(mask.shape)
+    assert t2["minDisp"][10, 10] == -5 and t2["maxDisp"][10, 10] == 5          # 8*2/3 = 5 < 7
+
+
+@pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (97, 53, 1)])
+def test_range_map_and_conversions_parallel_forms(emul, w, h, seed):
+    E = dict(impl=emul, prefix="emu_sgm_")
+    d = pc.smooth_disparity(w, h, seed)
+    mask = pc.mask_map(2 * w + 7, 2 * h + 6, seed)
+    for a, b in ((11, 33), (5, 7)):
+        px0, n0, m0 = po.sgm_disparity2range_map(d, mask, a, b)
+        px1, n1, m1 = po.sgm_disparity2range_map(d, mask, a, b, **E)
+        assert n0 == n1 and m0 == m1 and np.array_equal(px0["idx"], px1["idx"]) and np.array_equal(px0["minDisp"], px1["minDisp"]) and np.array_equal(px0["maxDisp"], px1["maxDisp"])
+        assert 0 < m0 <= 66 and n0 > 0
+    H, Q, iH, iQ = pc.rectification(seed)
+    depth = (3.0 + 0.5 * np.sin(np.arange(h * w).reshape(h, w) / 50.0)).astype(np.float32)
+    depth[np.random.RandomState(seed).rand(h, w) < 0.2] = 0
+    for steps in (1, 4):
+        a = po.sgm_depth2disparity_map(depth, iH, iQ, steps, (w - 6, h - 6))
+        b = po.sgm_depth2disparity_map(depth, iH, iQ, steps, (w - 6, h - 6), **E)
+        assert np.array_equal(a, b) and (a != NO).mean() > 0.5
+        cost = pc.cost_map(w - 6, h - 6, seed)
+        for cst in (None, cost):
+            da, ca = po.sgm_disparity2depth_map(a, cst, H, Q, steps, (w, h))
+            db, cb = po.sgm_disparity2depth_map(a, cst, H, Q, steps, (w, h), **E)
+            assert np.array_equal(da.view(np.uint32), db.view(np.uint32)) and (cst is None or np.array_equal(ca.view(np.uint32), cb.view(np.uint32)))
+        # depth -> disparity -> depth comes back (up to the disparity quantisation) where both are defined
+        back = po.sgm_disparity2depth_map(a, None, H, Q, steps, (w, h))[0]
+        ok = (back > 0) & (depth > 0)
+        assert ok.mean() > 0.3 and np.median(np.abs(back[ok] - depth[ok]) / depth[ok]) < 0.06

@@ -188,3 +188,41 @@ def test_load_scene_prepares_every_view():
     assert [list(map(int, n)) for n in sv.neighbors] == [[2, 3, 1], [3, 2, 0], [0, 1, 3], [1, 0, 2]]
     assert all(g.shape == (479, 640) and g.dtype == np.float32 and 0 <= g.min() and g.max() <= 1 for g in sv.gray)
     assert all(0 < sv.dmin[i] < sv.dmax[i] for i in sv.ids) and set(sv.init_depth) == set(sv.ids)
+
+
+def test_roi_weighting_and_restriction(scene):
+    """nPointInsideROI (Scene.cpp:824-838): 1 down-weights points outside the ROI box (x0.7), 2 ignores them."""
+    sc = mvsi.load(SCENE)
+    cams = views.Cameras(sc)
+    X = sc.vertices
+    lo, hi = np.percentile(X, 25, axis=0), np.percentile(X, 75, axis=0)
+    sc.obb_rot = np.eye(3); sc.obb_min = lo.astype(np.float64); sc.obb_max = hi.astype(np.float64)
+    assert sc.is_bounded()
+    inside = sc.roi_contains(X)
+    assert 0.05 < inside.mean() < 0.6 and np.array_equal(inside, np.all((X >= lo.astype(np.float32)) & (X <= hi.astype(np.float32)), axis=1))
+    _, nb0, p0, _ = views.select_neighbor_views(sc, cams, 0, nInsideROI=0)
+    _, nb1, p1, _ = views.select_neighbor_views(sc, cams, 0, nInsideROI=1)
+    ok2, nb2, p2, _ = views.select_neighbor_views(sc, cams, 0, nInsideROI=2)
+    assert np.array_equal(p0, p1) and len(p2) < len(p1) and set(p2) <= set(p1) and np.all(inside[p2])
+    for a, b in zip(np.sort(nb0, order="ID"), np.sort(nb1, order="ID")):      # same statistics, smaller score
+        assert a["points"] == b["points"] and a["angle"] == b["angle"] and 0.7 * a["score"] - 1e-3 <= b["score"] < a["score"]
+    assert all(n["points"] <= m["points"] for n, m in zip(np.sort(nb2, order="ID"), np.sort(nb1, order="ID")))
+
+
+def test_archive_with_lines_and_normals_round_trips(scene, tmp_path):
+    sc = mvsi.load(SCENE)
+    r = np.random.RandomState(0)
+    sc.vertices_normal = r.randn(len(sc.vertices), 3).astype(np.float32)
+    sc.lines = r.randn(5, 2, 3).astype(np.float32)
+    sc.line_view_start = np.array([0, 2, 4, 4, 7, 9], np.int64)
+    sc.line_views = np.zeros(9, mvsi.VIEW_DTYPE); sc.line_views["image_id"] = r.randint(0, 4, 9); sc.line_views["confidence"] = r.rand(9)
+    sc.lines_normal = r.randn(5, 3).astype(np.float32); sc.lines_color = r.randint(0, 255, (5, 3)).astype(np.uint8)
+    sc.transform = r.randn(4, 4)
+    p = str(tmp_path / "full.mvs")
+    mvsi.save(p, sc, version=7)
+    s2 = mvsi.load(p)
+    for k in ("vertices_normal", "lines", "line_view_start", "line_views", "lines_normal", "lines_color", "transform"):
+        assert np.array_equal(getattr(s2, k), getattr(sc, k)), k
+    mvsi.save(p, sc, version=0)                                   # the head-less first format: no lines, no transform
+    s0 = mvsi.load(p)
+    assert s0.version == 0 and len(s0.lines) == 0 and np.array_equal(s0.vertices_normal, sc.vertices_normal)

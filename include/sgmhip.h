@@ -82,6 +82,16 @@ int sgmhip_depth2disparity_map(sgmhip_engine* e, const float* depthMap, int dw, 
 int sgmhip_disparity2depth_map(sgmhip_engine* e, const int16_t* disparity, const uint16_t* cost, int w, int h, const double H[9], const double Q[16],
                                int subpixelSteps, float* depthMap, float* confMap, int dw, int dh);
 
+/* ProjectDisparity2DepthMap (:1925-2039): forward-projects every valid disparity into the un-rectified image (dw x dh), keeps per pixel and quadrant
+ * the nearest projection and blends the (up to four) agreeing ones; depthRangeMap: 2 floats per pixel (depth at disparity -1 / +1), confMap only
+ * with a cost map.  Where depthMap is 0 the other two maps are 0 (uninitialised in the reference).  *anyDepth = the reference's return value. */
+int sgmhip_project_disparity2depth_map(sgmhip_engine* e, const int16_t* disparity, const uint16_t* cost, int w, int h, const double Q[16], int subpixelSteps,
+                                       float* depthMap, float* depthRangeMap, float* confMap, int dw, int dh, int* anyDepth);
+/* The per-pixel fusion of SemiGlobalMatcher::Fuse (:797-849) over nPairs (<= 32) pair maps produced by the call above: depths whose trust ranges
+ * contain each other are clustered, the largest cluster (>= minViews members) is averaged. */
+int sgmhip_fuse_pairs(sgmhip_engine* e, const float* const* depthMaps, const float* const* depthRangeMaps, const float* const* confMaps, int nPairs,
+                      int dw, int dh, unsigned minViews, float* depthMap, float* confMap);
+
 /* HIP-event timing since the last reset: milliseconds in the cost-volume, aggregation (8 path
  * kernels) and WTA kernels, number of match calls. */
 typedef struct SGMHipStats { double costMs, aggrMs, wtaMs; uint64_t calls, aggrLaunches; } SGMHipStats;

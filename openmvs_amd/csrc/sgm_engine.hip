@@ -305,4 +305,52 @@ int sgmhip_disparity2depth_map(sgmhip_engine* e, const int16_t* disparity, const
 	return 0;
 }
 
+int sgmhip_project_disparity2depth_map(sgmhip_engine* e, const int16_t* disparity, const uint16_t* cost, int w, int h, const double Q[16], int subpixelSteps,
+		float* depthMap, float* depthRangeMap, float* confMap, int dw, int dh, int* anyDepth) {
+	if (!e || !disparity || !Q || !depthMap || !depthRangeMap || (cost && !confMap) || w <= 0 || h <= 0 || dw <= 0 || dh <= 0 || subpixelSteps <= 0 || (size_t)w * h > 0xFFFFFFFFull) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	DevBuf a, c, k, d, rg, cf, cnt; const size_t n = (size_t)w * h, nd = (size_t)dw * dh;
+	SGMCHK(e, a.alloc(n * 2)); SGMCHK(e, c.alloc(n * 2)); SGMCHK(e, k.alloc(nd * 4 * 8)); SGMCHK(e, d.alloc(nd * 4)); SGMCHK(e, rg.alloc(nd * 8)); SGMCHK(e, cf.alloc(nd * 4)); SGMCHK(e, cnt.alloc(4));
+	SGMCHK(e, hipMemcpyAsync(a.p, disparity, n * 2, hipMemcpyHostToDevice, e->stream));
+	if (cost) SGMCHK(e, hipMemcpyAsync(c.p, cost, n * 2, hipMemcpyHostToDevice, e->stream));
+	SGMCHK(e, hipMemsetAsync(cnt.p, 0, 4, e->stream)); SGMCHK(e, hipMemsetAsync(rg.p, 0, nd * 8, e->stream));
+	SGMPMat mq{}; memcpy(mq.m, Q, 128);
+	const uint16_t* dc = cost ? (const uint16_t*)c.p : nullptr;
+	hipLaunchKernelGGL(sgmp_fill_u64, dim3(gridFor(nd * 4)), dim3(256), 0, e->stream, (unsigned long long*)k.p, nd * 4, SGMP_KEY_NONE);
+	hipLaunchKernelGGL(sgmp_proj_splat_kernel, dim3(gridFor(n)), dim3(256), 0, e->stream, (const int16_t*)a.p, dc, w, h, mq, subpixelSteps, (unsigned long long*)k.p, dw, dh);
+	hipLaunchKernelGGL(sgmp_proj_resolve_kernel, dim3(gridFor(nd)), dim3(256), 0, e->stream, (const int16_t*)a.p, dc, w, mq, subpixelSteps, (const unsigned long long*)k.p, dw, dh,
+		(float*)d.p, (float*)rg.p, cost ? (float*)cf.p : nullptr, (unsigned*)cnt.p);
+	unsigned num = 0;
+	SGMCHK(e, hipMemcpyAsync(depthMap, d.p, nd * 4, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipMemcpyAsync(depthRangeMap, rg.p, nd * 8, hipMemcpyDeviceToHost, e->stream));
+	if (cost) SGMCHK(e, hipMemcpyAsync(confMap, cf.p, nd * 4, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipMemcpyAsync(&num, cnt.p, 4, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	if (anyDepth) *anyDepth = num > 0 ? 1 : 0;
+	return 0;
+}
+
+int sgmhip_fuse_pairs(sgmhip_engine* e, const float* const* depthMaps, const float* const* depthRangeMaps, const float* const* confMaps, int nPairs, int dw, int dh,
+		unsigned minViews, float* depthMap, float* confMap) {
+	if (!e || !depthMaps || !depthRangeMaps || !confMaps || nPairs < 0 || nPairs > SGMP_MAX_PAIRS || dw <= 0 || dh <= 0 || !depthMap || !confMap) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	const size_t nd = (size_t)dw * dh;
+	std::vector<DevBuf> bufs((size_t)nPairs * 3);
+	SGMPPairs pr{};
+	for (int p = 0; p < nPairs; ++p) {
+		if (!depthMaps[p] || !depthRangeMaps[p] || !confMaps[p]) return SGMHIP_E_ARG;
+		SGMCHK(e, bufs[p * 3].alloc(nd * 4)); SGMCHK(e, bufs[p * 3 + 1].alloc(nd * 8)); SGMCHK(e, bufs[p * 3 + 2].alloc(nd * 4));
+		SGMCHK(e, hipMemcpyAsync(bufs[p * 3].p, depthMaps[p], nd * 4, hipMemcpyHostToDevice, e->stream));
+		SGMCHK(e, hipMemcpyAsync(bufs[p * 3 + 1].p, depthRangeMaps[p], nd * 8, hipMemcpyHostToDevice, e->stream));
+		SGMCHK(e, hipMemcpyAsync(bufs[p * 3 + 2].p, confMaps[p], nd * 4, hipMemcpyHostToDevice, e->stream));
+		pr.depth[p] = (const float*)bufs[p * 3].p; pr.range[p] = (const float*)bufs[p * 3 + 1].p; pr.conf[p] = (const float*)bufs[p * 3 + 2].p;
+	}
+	DevBuf d, c; SGMCHK(e, d.alloc(nd * 4)); SGMCHK(e, c.alloc(nd * 4));
+	hipLaunchKernelGGL(sgmp_fuse_pairs_kernel, dim3(gridFor(nd)), dim3(256), 0, e->stream, pr, nPairs, nd, minViews, (float*)d.p, (float*)c.p);
+	SGMCHK(e, hipMemcpyAsync(depthMap, d.p, nd * 4, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipMemcpyAsync(confMap, c.p, nd * 4, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
 } // extern "C"

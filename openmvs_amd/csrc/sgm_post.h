@@ -240,3 +240,120 @@ PM_HD void sgmp_disparity2depth_px(const int16_t* disp, const uint16_t* cost, in
 	}
 	*depth = sgmp_disparity2depth(Q, u[0], u[1], d / (float)steps);
 }
+
+// ---- ProjectDisparity2DepthMap (:1925-2039): every valid disparity is projected into the un-rectified image and offered to the 3x3 pixels
+// around it; per pixel and per quadrant (left/right x top/bottom of the projection) the NEAREST projection is kept, the first one in raster
+// order on ties.  Parallel form: one 64-bit atomicMin per offer on (float bits of the squared distance << 32 | source index); the resolve pass
+// recomputes the winner's values from its index, so nothing but the keys is stored.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SGMP_ATOMIC_MIN64(p, v) atomicMin((p), (v))
+#else
+#define SGMP_ATOMIC_MIN64(p, v) do { if (*(p) > (v)) *(p) = (v); } while (0)
+#endif
+#define SGMP_KEY_NONE 0xFFFFFFFFFFFFFFFFull
+// TDisparity2Depth(Q, ImageRef u, d, pt) (libs/MVS/Image.cpp:391-404)
+PM_HD float sgmp_disparity2depth_pt(const double* Q, int ux, int uy, float d, float* px, float* py) {
+	const double w = Q[12] * ux + Q[13] * uy - Q[14] * d + Q[15];
+	if ((w < 0 ? -w : w) < 1e-7) return 0.f;
+	const double z = (Q[8] * ux + Q[9] * uy - Q[10] * d + Q[11]) / w;
+	if (z < 1e-7) return 0.f;
+	const double nrm = 1.0 / (w * z);
+	*px = (float)((Q[0] * ux + Q[1] * uy - Q[2] * d + Q[3]) * nrm);
+	*py = (float)((Q[4] * ux + Q[5] * uy - Q[6] * d + Q[7]) * nrm);
+	return (float)z;
+}
+// TDisparity2Depth(Q, ImageRef u, d)
+PM_HD float sgmp_disparity2depth_i(const double* Q, int ux, int uy, float d) {
+	const double w = Q[12] * ux + Q[13] * uy - Q[14] * d + Q[15];
+	if ((w < 0 ? -w : w) < 1e-7) return 0.f;
+	const double z = Q[8] * ux + Q[9] * uy - Q[10] * d + Q[11];
+	const float depth = (float)(z / w);
+	return depth < 0.0001f ? 0.f : depth;
+}
+struct SgmpProj { float depth, rangeX, rangeY, conf, ux, uy; int x, y; };
+// the values source pixel (r,c) of the disparity map contributes; false if it contributes nothing
+PM_HD bool sgmp_proj_source(const int16_t* disp, const uint16_t* cost, int w, const double* Q, int steps, int r, int c, SgmpProj* o) {
+	const int16_t di = disp[(size_t)r * w + c];
+	if (di == SGMP_NO_DISP) return false;
+	const float disparity = (float)di / (float)steps;
+	const int dx = c + SGMP_HW, dy = r + SGMP_HW;
+	float ux = 0.f, uy = 0.f;
+	const float depth = sgmp_disparity2depth_pt(Q, dx, dy, disparity, &ux, &uy);
+	if (depth <= 0) return false;
+	const int center = (int16_t)(int)pm_floorf(disparity);
+	o->depth = depth;
+	o->rangeX = sgmp_disparity2depth_i(Q, dx, dy, (float)(center - 1));
+	o->rangeY = sgmp_disparity2depth_i(Q, dx, dy, (float)(center + 1));
+	o->conf = cost ? 1.f / (float)((int)cost[(size_t)r * w + c] + 1) : 0.f;
+	o->x = (int)pm_floorf(ux); o->y = (int)pm_floorf(uy);
+	o->ux = ux - 0.5f; o->uy = uy - 0.5f;
+	return true;
+}
+PM_HD void sgmp_proj_splat(const int16_t* disp, const uint16_t* cost, int w, const double* Q, int steps, int r, int c, unsigned long long* keys, int dw, int dh) {
+	SgmpProj s;
+	if (!sgmp_proj_source(disp, cost, w, Q, steps, r, c, &s)) return;
+	const unsigned long long src = (unsigned long long)((size_t)r * w + c);
+	for (int i = -1; i <= 1; ++i) for (int j = -1; j <= 1; ++j) {
+		const int nx = s.x + j, ny = s.y + i;
+		if (nx < 0 || ny < 0 || nx >= dw || ny >= dh) continue;
+		const float ddx = (float)nx - s.ux, ddy = (float)ny - s.uy;
+		if (pm_fabsf(ddx) > 0.75f || pm_fabsf(ddy) > 0.75f) continue;
+		const int q = (ddx < 0 ? 1 : 0) + (ddy < 0 ? 2 : 0);
+		const float distSq = ddx * ddx + ddy * ddy;
+		SGMP_ATOMIC_MIN64(keys + ((size_t)q * dh + ny) * dw + nx, ((unsigned long long)pm_f2u(distSq) << 32) | src);
+	}
+}
+// one pixel of the output maps; returns 1 if a depth was produced
+PM_HD int sgmp_proj_resolve(const int16_t* disp, const uint16_t* cost, int w, const double* Q, int steps, const unsigned long long* keys, int dw, int dh,
+		int r, int c, float* depth, float* range2, float* conf) {
+	float qd[4], qrx[4], qry[4], qc[4], qdist[4];
+	for (int q = 0; q < 4; ++q) {
+		qd[q] = 0.f; qrx[q] = qry[q] = qc[q] = qdist[q] = 0.f;
+		const unsigned long long key = keys[((size_t)q * dh + r) * dw + c];
+		if (key == SGMP_KEY_NONE) continue;
+		const size_t src = (size_t)(key & 0xFFFFFFFFull);
+		SgmpProj s;
+		sgmp_proj_source(disp, cost, w, Q, steps, (int)(src / w), (int)(src % w), &s);
+		qd[q] = s.depth; qrx[q] = s.rangeX; qry[q] = s.rangeY; qc[q] = s.conf; qdist[q] = pm_u2f((uint32_t)(key >> 32));
+	}
+	float distCenter = 3.402823466e+38f, depthCenter = 0.f;
+	for (int q = 0; q < 4; ++q) { if (qd[q] <= 0) continue; if (distCenter > qdist[q]) { distCenter = qdist[q]; depthCenter = qd[q]; } }
+	if (distCenter > 0.75f * 0.75f) { *depth = 0.f; return 0; }
+	float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, wsum = 0.f;
+	for (int q = 0; q < 4; ++q) {
+		if (qd[q] <= 0 || !(pm_fabsf(depthCenter - qd[q]) / depthCenter < 0.02f)) continue;
+		const float wq = pm_sqrtf(qdist[q]);
+		v0 += qd[q] * wq; v1 += qrx[q] * wq; v2 += qry[q] * wq; v3 += qc[q] * wq; wsum += wq;
+	}
+	const float inv = 1.f / wsum;
+	*depth = v0 * inv; range2[0] = v1 * inv; range2[1] = v2 * inv; *conf = v3 * inv;
+	return 1;
+}
+
+// ---- SemiGlobalMatcher::Fuse, the per-pixel part (:797-849): cluster the pair depths whose trust ranges contain them, average the largest cluster
+#define SGMP_MAX_PAIRS 32
+PM_HD void sgmp_fuse_pairs_px(const float* const* depthMaps, const float* const* rangeMaps, const float* const* confMaps, int nPairs, size_t i, unsigned minViews,
+		float* depth, float* conf) {
+	float cx[SGMP_MAX_PAIRS], cy[SGMP_MAX_PAIRS]; unsigned members[SGMP_MAX_PAIRS]; int cnt[SGMP_MAX_PAIRS]; int nC = 0;   // members: bit p = pair p in the cluster (insertion = ascending p)
+	for (int p = 0; p < nPairs; ++p) {
+		const float d = depthMaps[p][i];
+		if (d <= 0) continue;
+		const float rx = rangeMaps[p][i * 2], ry = rangeMaps[p][i * 2 + 1];
+		unsigned numClusters = 0;
+		for (int k = 0; k < nC; ++k) {
+			if (!(cx[k] <= d && d < cy[k])) continue;
+			members[k] |= 1u << p; ++cnt[k];
+			if (cx[k] < rx) cx[k] = rx;
+			if (cy[k] > ry) cy[k] = ry;
+			++numClusters;
+		}
+		if (numClusters == 0) { cx[nC] = rx; cy[nC] = ry; members[nC] = 1u << p; cnt[nC] = 1; ++nC; }
+	}
+	if (nC == 0) { *depth = 0.f; *conf = 0.f; return; }
+	int best = 0;
+	for (int k = 1; k < nC; ++k) if (cnt[best] < cnt[k]) best = k;          // std::max_element: first of the largest
+	if ((unsigned)cnt[best] < minViews) { *depth = 0.f; *conf = 0.f; return; }
+	float ds = 0.f, cs = 0.f; unsigned n = 0;
+	for (int p = 0; p < nPairs; ++p) if ((members[best] >> p) & 1u) { ds += depthMaps[p][i]; cs += confMaps[p][i]; ++n; }
+	*depth = ds / (float)n; *conf = cs / (float)n;
+}

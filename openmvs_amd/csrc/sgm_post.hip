@@ -60,3 +60,28 @@ __global__ void sgmp_disparity2depth_kernel(const int16_t* disp, const uint16_t*
 		if (cost) conf[i] = cf;
 	}
 }
+
+__global__ void sgmp_fill_u64(unsigned long long* p, size_t n, unsigned long long v) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void sgmp_proj_splat_kernel(const int16_t* disp, const uint16_t* cost, int w, int h, SGMPMat Q, int steps, unsigned long long* keys, int dw, int dh) {
+	const size_t n = (size_t)w * h;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+		sgmp_proj_splat(disp, cost, w, Q.m, steps, (int)(i / w), (int)(i % w), keys, dw, dh);
+}
+__global__ void sgmp_proj_resolve_kernel(const int16_t* disp, const uint16_t* cost, int w, SGMPMat Q, int steps, const unsigned long long* keys, int dw, int dh,
+		float* depth, float* range2, float* conf, unsigned* numDepths) {
+	const size_t n = (size_t)dw * dh;
+	unsigned cnt = 0;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		float cf = 0.f;
+		cnt += (unsigned)sgmp_proj_resolve(disp, cost, w, Q.m, steps, keys, dw, dh, (int)(i / dw), (int)(i % dw), depth + i, range2 + i * 2, &cf);
+		if (conf) conf[i] = cf;
+	}
+	if (cnt) atomicAdd(numDepths, cnt);
+}
+struct SGMPPairs { const float* depth[SGMP_MAX_PAIRS]; const float* range[SGMP_MAX_PAIRS]; const float* conf[SGMP_MAX_PAIRS]; };
+__global__ void sgmp_fuse_pairs_kernel(SGMPPairs pr, int nPairs, size_t n, unsigned minViews, float* depth, float* conf) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+		sgmp_fuse_pairs_px(pr.depth, pr.range, pr.conf, nPairs, i, minViews, depth + i, conf + i);
+}

@@ -13,7 +13,8 @@ PIXEL_DTYPE = np.dtype([("idx", np.uint64), ("minDisp", np.int16), ("maxDisp", n
 EXPORTS = ["sgmhip_create", "sgmhip_destroy", "sgmhip_last_error", "sgmhip_generate_p2s", "sgmhip_set_problem",
            "sgmhip_match", "sgmhip_get_results", "sgmhip_sync", "sgmhip_stats_reset", "sgmhip_stats_get",
            "sgmhip_consistency_cross_check", "sgmhip_filter_by_cost", "sgmhip_extract_mask", "sgmhip_upscale_mask", "sgmhip_flip_direction",
-           "sgmhip_refine_disparity", "sgmhip_disparity2range_map", "sgmhip_depth2disparity_map", "sgmhip_disparity2depth_map"]
+           "sgmhip_refine_disparity", "sgmhip_disparity2range_map", "sgmhip_depth2disparity_map", "sgmhip_disparity2depth_map",
+           "sgmhip_project_disparity2depth_map", "sgmhip_fuse_pairs"]
 NO_DISP = 32767          # SemiGlobalMatcher::NO_DISP
 INVALID, VALID = 0, 255  # MaskMap values
 SUBPIXEL_NA, SUBPIXEL_LINEAR, SUBPIXEL_POLY4, SUBPIXEL_PARABOLA, SUBPIXEL_SINE, SUBPIXEL_COSINE, SUBPIXEL_LC_BLEND = range(7)
@@ -154,6 +155,25 @@ class SemiGlobalMatcherHIP:
                                                        hh.ctypes.data_as(C.POINTER(C.c_double)), qq.ctypes.data_as(C.POINTER(C.c_double)), subpixelSteps,
                                                        dep.ctypes.data_as(C.POINTER(C.c_float)), cf.ctypes.data_as(C.POINTER(C.c_float)), dw, dh))
         return dep, (None if c is None else cf)
+
+    def ProjectDisparity2DepthMap(self, disparity, cost, Q, subpixelSteps, size):
+        """-> (any depth produced, depthMap, depthRangeMap (h, w, 2), confMap or None)"""
+        a = np.ascontiguousarray(disparity, np.int16); c = None if cost is None else np.ascontiguousarray(cost, np.uint16); dw, dh = size
+        dep = np.zeros((dh, dw), np.float32); rg = np.zeros((dh, dw, 2), np.float32); cf = np.zeros((dh, dw), np.float32); anyd = C.c_int(0)
+        qq = np.ascontiguousarray(Q, np.float64)
+        self._chk(self._lib.sgmhip_project_disparity2depth_map(self._h, a.ctypes.data_as(C.POINTER(C.c_int16)), None if c is None else c.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                                               a.shape[1], a.shape[0], qq.ctypes.data_as(C.POINTER(C.c_double)), subpixelSteps, dep.ctypes.data_as(C.POINTER(C.c_float)),
+                                                               rg.ctypes.data_as(C.POINTER(C.c_float)), None if c is None else cf.ctypes.data_as(C.POINTER(C.c_float)), dw, dh, C.byref(anyd)))
+        return bool(anyd.value), dep, rg, (None if c is None else cf)
+
+    def FusePairs(self, depths, ranges, confs, minViews=2):
+        """The per-pixel cluster fusion of SemiGlobalMatcher::Fuse over the maps of ProjectDisparity2DepthMap."""
+        dh, dw = depths[0].shape
+        keep = [[np.ascontiguousarray(a, np.float32) for a in arrs] for arrs in (depths, ranges, confs)]
+        ptrs = [(C.POINTER(C.c_float) * len(k))(*[a.ctypes.data_as(C.POINTER(C.c_float)) for a in k]) for k in keep]
+        dep = np.zeros((dh, dw), np.float32); cf = np.zeros((dh, dw), np.float32)
+        self._chk(self._lib.sgmhip_fuse_pairs(self._h, ptrs[0], ptrs[1], ptrs[2], len(depths), dw, dh, C.c_uint(minViews), dep.ctypes.data_as(C.POINTER(C.c_float)), cf.ctypes.data_as(C.POINTER(C.c_float))))
+        return dep, cf
 
     def sync(self):
         self._chk(self._lib.sgmhip_sync(self._h))

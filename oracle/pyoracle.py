@@ -392,3 +392,25 @@ def sgm_disparity2depth_map(disp, cost, H, Q, steps, size, impl=None, prefix="or
     _sgm_post(prefix, impl)("disparity2depth_map")(a.ctypes.data_as(C.POINTER(C.c_int16)), None if c is None else c.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int(a.shape[1]), C.c_int(a.shape[0]),
                                                    ph, pq, C.c_int(steps), dep.ctypes.data_as(C.POINTER(C.c_float)), cf.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(dw), C.c_int(dh))
     return dep, (None if c is None else cf)
+
+
+def sgm_project_disparity2depth_map(disp, cost, Q, steps, size, impl=None, prefix="orc_sgm_"):
+    a = np.ascontiguousarray(disp, np.int16); c = None if cost is None else np.ascontiguousarray(cost, np.uint16); dw, dh = size
+    dep = np.zeros((dh, dw), np.float32); rg = np.zeros((dh, dw, 2), np.float32); cf = np.zeros((dh, dw), np.float32); kq, pq = _dp(Q)
+    f = _sgm_post(prefix, impl)("project_disparity2depth_map"); f.restype = C.c_int
+    ok = f(a.ctypes.data_as(C.POINTER(C.c_int16)), None if c is None else c.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int(a.shape[1]), C.c_int(a.shape[0]), pq, C.c_int(steps),
+           dep.ctypes.data_as(C.POINTER(C.c_float)), rg.ctypes.data_as(C.POINTER(C.c_float)), None if c is None else cf.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(dw), C.c_int(dh))
+    return bool(ok), dep, rg, (None if c is None else cf)
+
+
+def _fptrs(arrs, dt=np.float32):
+    keep = [np.ascontiguousarray(a, dt) for a in arrs]
+    return keep, (C.POINTER(C.c_float) * max(1, len(keep)))(*[k.ctypes.data_as(C.POINTER(C.c_float)) for k in keep])
+
+
+def sgm_fuse_pairs(depths, ranges, confs, minViews=2, impl=None, prefix="orc_sgm_"):
+    dh, dw = depths[0].shape
+    kd, pd = _fptrs(depths); kr, pr = _fptrs(ranges); kc, pc = _fptrs(confs)
+    dep = np.zeros((dh, dw), np.float32); cf = np.zeros((dh, dw), np.float32)
+    _sgm_post(prefix, impl)("fuse_pairs")(pd, pr, pc, C.c_int(len(depths)), C.c_int(dw), C.c_int(dh), C.c_uint(minViews), dep.ctypes.data_as(C.POINTER(C.c_float)), cf.ctypes.data_as(C.POINTER(C.c_float)))
+    return dep, cf

@@ -224,3 +224,110 @@ void orc_sgm_disparity2depth_map(const int16_t* disparityMap, const uint16_t* co
 	}
 }
 } // extern "C"
+
+// ---- ProjectDisparity2DepthMap (:1925-2039) and the per-pixel part of SemiGlobalMatcher::Fuse (:797-849) --------------------------------
+namespace {
+float disparity2depth(const double* Q, int ux, int uy, float d) {   // TDisparity2Depth(Q, ImageRef, d), Image.cpp:371-381
+	const double w = Q[12] * ux + Q[13] * uy - Q[14] * d + Q[15];
+	if (fabs(w) < 1e-7) return 0;
+	const double z = Q[8] * ux + Q[9] * uy - Q[10] * d + Q[11];
+	const float depth = (float)(z / w);
+	return depth < 0.0001f ? 0.f : depth;
+}
+float disparity2depthPt(const double* Q, int ux, int uy, float d, float* pt) {   // :391-404
+	const double w = Q[12] * ux + Q[13] * uy - Q[14] * d + Q[15];
+	if (fabs(w) < 1e-7) return 0;
+	const double z = (Q[8] * ux + Q[9] * uy - Q[10] * d + Q[11]) / w;
+	if (z < 1e-7) return 0;
+	const double nrm = 1.0 / (w * z);
+	pt[0] = (float)((Q[0] * ux + Q[1] * uy - Q[2] * d + Q[3]) * nrm);
+	pt[1] = (float)((Q[4] * ux + Q[5] * uy - Q[6] * d + Q[7]) * nrm);
+	return (float)z;
+}
+}
+extern "C" {
+int orc_sgm_project_disparity2depth_map(const int16_t* disparityMap, const uint16_t* costMap, int w, int h, const double* Q, int subpixelSteps,
+		float* depthMap, float* depthRangeMap, float* confMap, int dw, int dh) {
+	const float overlapBorder = 0.5f + 0.25f;
+	const size_t nd = (size_t)dw * dh;
+	struct DD { std::vector<float> dist, depth, rx, ry, conf; } dd[4];
+	for (auto& d : dd) { d.dist.assign(nd, 0); d.depth.assign(nd, 0); d.rx.assign(nd, 0); d.ry.assign(nd, 0); d.conf.assign(nd, 0); }
+	for (int r = 0; r < h; ++r) for (int c = 0; c < w; ++c) {
+		const int16_t disparityInt = disparityMap[(size_t)r * w + c];
+		if (disparityInt == NO_DISP) continue;
+		const float disparity = (float)disparityInt / subpixelSteps;
+		float u[2] = {0, 0};
+		const int dx[2] = {c + HW, r + HW};
+		const float depth = disparity2depthPt(Q, dx[0], dx[1], disparity, u);
+		if (depth <= 0) continue;
+		const int16_t disparityCenter = (int16_t)(int)floorf(disparity);
+		const float rangeX = disparity2depth(Q, dx[0], dx[1], (float)(disparityCenter - 1)), rangeY = disparity2depth(Q, dx[0], dx[1], (float)(disparityCenter + 1));
+		const float cost = costMap ? 1.f / (costMap[(size_t)r * w + c] + 1) : 0.f;
+		const int x[2] = {(int)floorf(u[0]), (int)floorf(u[1])};
+		u[0] -= 0.5f; u[1] -= 0.5f;
+		for (int i = -1; i <= 1; ++i) for (int j = -1; j <= 1; ++j) {
+			const int nx[2] = {x[0] + j, x[1] + i};
+			if (!(nx[0] >= 0 && nx[1] >= 0 && nx[0] < dw && nx[1] < dh)) continue;
+			const float dist[2] = {(float)nx[0] - u[0], (float)nx[1] - u[1]};
+			if (fabsf(dist[0]) > overlapBorder || fabsf(dist[1]) > overlapBorder) continue;
+			const int idx = (dist[0] < 0 ? 1 : 0) + (dist[1] < 0 ? 2 : 0);
+			DD& D = dd[idx];
+			const float deistSq = dist[0] * dist[0] + dist[1] * dist[1];
+			const size_t p = (size_t)nx[1] * dw + nx[0];
+			if (D.depth[p] > 0 && D.dist[p] <= deistSq) continue;
+			D.dist[p] = deistSq; D.depth[p] = depth; D.rx[p] = rangeX; D.ry[p] = rangeY; D.conf[p] = cost;
+		}
+	}
+	const float thDist = 0.75f * 0.75f, thDepth = 0.02f;
+	unsigned numDepths = 0;
+	for (size_t p = 0; p < nd; ++p) {
+		depthRangeMap[p * 2] = depthRangeMap[p * 2 + 1] = 0; if (confMap) confMap[p] = 0;      // (uninitialised in the reference where depth == 0)
+		float distCenter = 3.402823466e+38f, depthCenter = 0;
+		for (int i = 0; i < 4; ++i) { const float depth = dd[i].depth[p]; if (depth <= 0) continue; if (distCenter > dd[i].dist[p]) { distCenter = dd[i].dist[p]; depthCenter = depth; } }
+		if (distCenter > thDist) { depthMap[p] = 0; continue; }
+		float value[4] = {0, 0, 0, 0}, weight = 0;
+		for (int i = 0; i < 4; ++i) {
+			const float depth = dd[i].depth[p];
+			if (depth <= 0 || !(fabsf(depthCenter - depth) / depthCenter < thDepth)) continue;
+			const float wq = sqrtf(dd[i].dist[p]);
+			const float v[4] = {depth, dd[i].rx[p], dd[i].ry[p], dd[i].conf[p]};
+			for (int k = 0; k < 4; ++k) value[k] += v[k] * wq;
+			weight += wq;
+		}
+		const float inv = 1.f / weight;
+		depthMap[p] = value[0] * inv; depthRangeMap[p * 2] = value[1] * inv; depthRangeMap[p * 2 + 1] = value[2] * inv;
+		if (confMap) confMap[p] = value[3] * inv;
+		++numDepths;
+	}
+	return numDepths > 0 ? 1 : 0;
+}
+
+void orc_sgm_fuse_pairs(const float* const* depthMaps, const float* const* rangeMaps, const float* const* confMaps, int nPairs, int dw, int dh, unsigned minViews,
+		float* depthMap, float* confMap) {
+	struct Cluster { std::vector<int> views; float x, y; };
+	for (size_t i = 0; i < (size_t)dw * dh; ++i) {
+		std::vector<Cluster> clusters;
+		for (int p = 0; p < nPairs; ++p) {
+			const float depth = depthMaps[p][i];
+			if (depth <= 0) continue;
+			const float rx = rangeMaps[p][i * 2], ry = rangeMaps[p][i * 2 + 1];
+			unsigned numClusters = 0;
+			for (Cluster& cl : clusters) {
+				if (!(cl.x <= depth && depth < cl.y)) continue;
+				cl.views.push_back(p);
+				if (cl.x < rx) cl.x = rx;
+				if (cl.y > ry) cl.y = ry;
+				++numClusters;
+			}
+			if (numClusters == 0) clusters.push_back(Cluster{{p}, rx, ry});
+		}
+		if (clusters.empty()) { depthMap[i] = 0; confMap[i] = 0; continue; }
+		const Cluster& cluster = *std::max_element(clusters.begin(), clusters.end(), [](const Cluster& a, const Cluster& b) { return a.views.size() < b.views.size(); });
+		if (cluster.views.size() < minViews) { depthMap[i] = 0; confMap[i] = 0; continue; }
+		float depth = 0, conf = 0; unsigned numDepths = 0;
+		for (int p : cluster.views) { depth += depthMaps[p][i]; conf += confMaps[p][i]; ++numDepths; }
+		depth /= numDepths; conf /= numDepths;
+		depthMap[i] = depth; confMap[i] = conf;
+	}
+}
+} // extern "C"

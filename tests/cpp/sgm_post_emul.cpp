@@ -63,3 +63,17 @@ void emu_sgm_disparity2depth_map(const int16_t* disp, const uint16_t* cost, int 
 	for (size_t i : order((size_t)dw * dh, 10)) { float cf = 0.f; sgmp_disparity2depth_px(disp, cost, w, h, H, Q, steps, (int)(i / dw), (int)(i % dw), depth + i, &cf); if (cost) conf[i] = cf; }
 }
 }
+
+extern "C" {
+int emu_sgm_project_disparity2depth_map(const int16_t* disp, const uint16_t* cost, int w, int h, const double* Q, int steps, float* depth, float* range2, float* conf, int dw, int dh) {
+	std::vector<unsigned long long> keys((size_t)dw * dh * 4, SGMP_KEY_NONE);
+	for (size_t i : order((size_t)w * h, 11)) sgmp_proj_splat(disp, cost, w, Q, steps, (int)(i / w), (int)(i % w), keys.data(), dw, dh);
+	int any = 0;
+	memset(range2, 0, (size_t)dw * dh * 8);
+	for (size_t i : order((size_t)dw * dh, 12)) { float cf = 0.f; any |= sgmp_proj_resolve(disp, cost, w, Q, steps, keys.data(), dw, dh, (int)(i / dw), (int)(i % dw), depth + i, range2 + i * 2, &cf); if (conf) conf[i] = cf; }
+	return any;
+}
+void emu_sgm_fuse_pairs(const float* const* depthMaps, const float* const* rangeMaps, const float* const* confMaps, int nPairs, int dw, int dh, unsigned minViews, float* depth, float* conf) {
+	for (size_t i : order((size_t)dw * dh, 13)) sgmp_fuse_pairs_px(depthMaps, rangeMaps, confMaps, nPairs, i, minViews, depth + i, conf + i);
+}
+}

@@ -46,5 +46,8 @@ def rectification(seed=0):
     r = np.random.RandomState(seed + 400)
     H = np.eye(3) + 0.02 * r.randn(3, 3); H[2, :2] *= 1e-3; H[2, 2] = 1
     f, cx, cy, B = 600.0, 80.0, 60.0, 0.3
-    Q = np.array([[1, 0, 0, -cx], [0, 1, 0, -cy], [0, 0, 0, f], [0, 0, -1.0 / B, 0]], np.float64)
+    Qcv = np.array([[1, 0, 0, -cx], [0, 1, 0, -cy], [0, 0, 0, f], [0, 0, -1.0 / B, 0]], np.float64)
+    # the reference's Q maps (u, v, -d, 1) to (x*z, y*z, z, 1)*w in ORIGINAL image coordinates (Image.h:87-93): reprojection, then the camera matrix
+    K4 = np.array([[f, 0, cx, 0], [0, f, cy, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float64)
+    Q = K4 @ Qcv
     return H, Q, np.linalg.inv(H), np.linalg.inv(Q + 1e-9 * np.eye(4))

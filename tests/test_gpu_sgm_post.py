@@ -83,3 +83,25 @@ def test_disparity_depth_conversions_match_the_oracle(matcher, w, h, seed):
             db, cb = matcher.Disparity2DepthMap(a, cst, H, Q, steps, (w, h))
             assert np.array_equal(da.view(np.uint32), db.view(np.uint32))
             assert cst is None or np.array_equal(ca.view(np.uint32), cb.view(np.uint32))
+
+
+@_first_run
+@pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (97, 53, 1)])
+def test_projection_and_pair_fusion_match_the_oracle(matcher, w, h, seed):
+    from tests.test_sgm_post import _pair_maps
+    H, Q, iH, iQ = pc.rectification(seed)
+    depth = (3.0 + 0.5 * np.sin(np.arange(h * w).reshape(h, w) / 50.0)).astype(np.float32)
+    depth[np.random.RandomState(seed).rand(h, w) < 0.15] = 0
+    cost = pc.cost_map(w - 6, h - 6, seed)
+    for steps in (1, 4):
+        disp = po.sgm_depth2disparity_map(depth, np.eye(3), iQ, steps, (w - 6, h - 6))
+        for cst in (None, cost):
+            ok0, d0, r0, c0 = po.sgm_project_disparity2depth_map(disp, cst, Q, steps, (w, h))
+            ok1, d1, r1, c1 = matcher.ProjectDisparity2DepthMap(disp, cst, Q, steps, (w, h))
+            assert ok0 == ok1 and np.array_equal(d0.view(np.uint32), d1.view(np.uint32)) and np.array_equal(r0.view(np.uint32), r1.view(np.uint32))
+            assert cst is None or np.array_equal(c0.view(np.uint32), c1.view(np.uint32))
+    base, deps, rgs, cfs = _pair_maps(w, h, seed)
+    for mv in (1, 2, 3):
+        a = po.sgm_fuse_pairs(deps, rgs, cfs, mv)
+        b = matcher.FusePairs(deps, rgs, cfs, mv)
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))

@@ -160,3 +160,57 @@ def test_range_map_and_conversions_parallel_forms(emul, w, h, seed):
         back = po.sgm_disparity2depth_map(a, None, H, Q, steps, (w, h))[0]
         ok = (back > 0) & (depth > 0)
         assert ok.mean() > 0.3 and np.median(np.abs(back[ok] - depth[ok]) / depth[ok]) < 0.06
+
+
+def _pair_maps(w, h, seed, n_pairs=4):
+    """What SemiGlobalMatcher::Fuse sees: the same surface projected through n pairs with different noise, holes and trust ranges."""
+    r = np.random.RandomState(seed + 500)
+    base = (3.0 + 0.5 * np.sin(np.arange(h * w).reshape(h, w) / 40.0)).astype(np.float32)
+    deps, rgs, cfs = [], [], []
+    for p in range(n_pairs):
+        d = (base * (1 + 0.01 * r.randn(h, w))).astype(np.float32)
+        o = r.rand(h, w) < 0.1; d[o] *= r.choice([0.6, 1.5], int(o.sum())).astype(np.float32)
+        d[r.rand(h, w) < 0.25] = 0
+        half = (0.02 + 0.03 * r.rand(h, w)).astype(np.float32) * d
+        deps.append(d); rgs.append(np.stack([d - half, d + half], -1).astype(np.float32)); cfs.append(r.rand(h, w).astype(np.float32))
+    return base, deps, rgs, cfs
+
+
+@pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (97, 53, 1)])
+def test_projection_and_pair_fusion_parallel_forms(emul, w, h, seed):
+    E = dict(impl=emul, prefix="emu_sgm_")
+    H, Q, iH, iQ = pc.rectification(seed)
+    depth = (3.0 + 0.5 * np.sin(np.arange(h * w).reshape(h, w) / 50.0)).astype(np.float32)
+    depth[np.random.RandomState(seed).rand(h, w) < 0.15] = 0
+    cost = pc.cost_map(w - 6, h - 6, seed)
+    for steps in (1, 4):
+        disp = po.sgm_depth2disparity_map(depth, np.linalg.inv(np.eye(3)), iQ, steps, (w - 6, h - 6))     # identity homography: the rectified frame is the image
+        for cst in (None, cost):
+            ok0, d0, r0, c0 = po.sgm_project_disparity2depth_map(disp, cst, Q, steps, (w, h))
+            ok1, d1, r1, c1 = po.sgm_project_disparity2depth_map(disp, cst, Q, steps, (w, h), **E)
+            assert ok0 and ok1 and np.array_equal(d0.view(np.uint32), d1.view(np.uint32)) and np.array_equal(r0.view(np.uint32), r1.view(np.uint32))
+            assert cst is None or np.array_equal(c0.view(np.uint32), c1.view(np.uint32))
+        m = (d0 > 0) & (depth > 0)
+        assert m.mean() > 0.3 and np.median(np.abs(d0[m] - depth[m]) / depth[m]) < 0.06
+        assert np.all(r0[d0 > 0].min(1) > 0) and np.all(r0[d0 > 0][:, 0] > r0[d0 > 0][:, 1])      # depth at disparity-1 is farther than at disparity+1
+    assert not po.sgm_project_disparity2depth_map(np.full((h - 6, w - 6), NO, np.int16), None, Q, 4, (w, h))[0]
+    base, deps, rgs, cfs = _pair_maps(w, h, seed)
+    for mv in (1, 2, 3):
+        a = po.sgm_fuse_pairs(deps, rgs, cfs, mv)
+        b = po.sgm_fuse_pairs(deps, rgs, cfs, mv, **E)
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    f2 = po.sgm_fuse_pairs(deps, rgs, cfs, 2)[0]
+    ok = f2 > 0
+    assert 0.3 < ok.mean() < 1 and np.median(np.abs(f2[ok] - base[ok]) / base[ok]) < 0.01
+
+
+def test_pair_fusion_known_answer():
+    one = lambda v: np.full((1, 1), v, np.float32)
+    rng = lambda a, b: np.array([[[a, b]]], np.float32)
+    # pair 0: 2.0 in [1.9,2.1); pair 1: 2.05 in [2.0,2.2) joins pair 0's cluster (range shrinks to [2.0,2.1)); pair 2: 5.0 alone
+    d, c = po.sgm_fuse_pairs([one(2.0), one(2.05), one(5.0)], [rng(1.9, 2.1), rng(2.0, 2.2), rng(4.9, 5.1)], [one(0.2), one(0.4), one(0.9)], 2)
+    assert np.isclose(d[0, 0], (np.float32(2.0) + np.float32(2.05)) / 2) and np.isclose(c[0, 0], 0.3)
+    assert po.sgm_fuse_pairs([one(2.0), one(2.05), one(5.0)], [rng(1.9, 2.1), rng(2.0, 2.2), rng(4.9, 5.1)], [one(0.2), one(0.4), one(0.9)], 3)[0][0, 0] == 0
+    # the shrunk range [2.0, 2.1) no longer admits 1.95: it founds its own cluster; both clusters have... the first of the largest wins
+    d, _ = po.sgm_fuse_pairs([one(2.0), one(2.05), one(1.95)], [rng(1.9, 2.1), rng(2.0, 2.2), rng(1.9, 2.0)], [one(0), one(0), one(0)], 1)
+    assert np.isclose(d[0, 0], 2.025)

@@ -121,3 +121,20 @@ def test_merge_depth_maps_mode(emul, small_scene):
     assert np.allclose(z, np.stack(maps[0])[v, xy[:, 1], xy[:, 0]], rtol=1e-5)
     b = _fuse(sc, maps, nMinViewsFuse=1, order=order, fn=emul.emu_fuse_depth_maps)
     fc.same_cloud(b, a, "merge")
+
+
+def _golden_inputs():
+    g = np.load(os.path.join(HERE, "golden", "pm_golden_96x64.npz")); f = np.load(os.path.join(HERE, "golden", "filter_golden_96x64.npz"))
+    z = np.load(os.path.join(HERE, "golden", "fuse_golden_96x64.npz"))
+    nv = int(g["n_views"])
+    return g, z, list(f["filt_depth"]), list(f["gap_normal"]), list(f["filt_conf"]), list(z["bgr"]), [list(g["neighbors"][v]) for v in range(nv)]
+
+
+def test_oracle_reproduces_the_committed_golden_cloud():
+    """Regression pin of the fusion oracle (tests/golden/make_fuse_golden.py wrote the fixture from it)."""
+    g, z, d, n, c, bgr, nbrs = _golden_inputs()
+    for tag, kw in (("fuse2", dict(nMinViewsFuse=2)), ("fuse3", dict(nMinViewsFuse=3, fNormalDiffThreshold=40.0))):
+        r = po.fuse_depth_maps(d, n, c, bgr, g["K"], g["R"], g["C"], nbrs, **kw)
+        assert r["nDepths"] == int(z[tag + "_nDepths"]) and r["nPoints"] == len(z[tag + "_points"]) > 500
+        for k in ("points", "viewStart", "views", "weights", "projs", "colors", "normals"):
+            assert np.array_equal(r[k], z[tag + "_" + k]), (tag, k)

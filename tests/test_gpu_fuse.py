@@ -42,6 +42,27 @@ def test_device_fuse_is_the_sequential_fuse(small_scene, nine_scene, case):
     e.close()
 
 
+def test_device_fuse_reproduces_the_golden_cloud():
+    """The committed fixture (tests/golden/fuse_golden_96x64.npz, written by the oracle): same inputs through the C ABI."""
+    from tests.test_fuse import _golden_inputs
+    g, z, d, n, c, bgr, nbrs = _golden_inputs()
+    nv = int(g["n_views"])
+
+    class S:      # the attributes scene_load reads
+        n_views = nv; width = 96; height = 64; gray = g["gray"]; K = g["K"]; R = g["R"]; C = g["C"]; dmin = g["dmin"]; dmax = g["dmax"]; neighbors = g["neighbors"]
+    e = PatchMatchHIP(0)
+    e.scene_load(S, n_levels=0)
+    for v in range(nv):
+        e.scene_set_maps(v, d[v], n[v]); e.scene_set_conf(v, c[v]); e.scene_set_color(v, bgr[v])
+    order = po.fuse_order([len(x) for x in nbrs])
+    for tag, kw in (("fuse2", dict(nMinViewsFuse=2)), ("fuse3", dict(nMinViewsFuse=3, fNormalDiffThreshold=40.0))):
+        r = e.scene_fuse(order, **kw)
+        assert r["nDepths"] == int(z[tag + "_nDepths"])
+        for k in ("points", "viewStart", "views", "weights", "projs", "colors", "normals"):
+            assert np.array_equal(r[k], z[tag + "_" + k]), (tag, k)
+    e.close()
+
+
 def test_device_merge_mode(small_scene):
     """nMinViewsFuse < 2 routes to MergeDepthMaps (SceneDensify.cpp:1305-1368)."""
     sc = small_scene

@@ -23,7 +23,8 @@ LIBS = {
 }
 
 
-HOST_LIBS = {"libdmapio.so": (["dmap_io.cpp"], ["../../include/dmapio.h"])}   # plain C++ (g++), no GPU code
+HOST_LIBS = {"libdmapio.so": (["dmap_io.cpp"], ["../../include/dmapio.h"]),          # plain C++ (g++), no GPU code
+             "libmvsfront.so": (["mvs_front.cpp"], ["../../include/mvsfront.h"])}
 
 
 def build_host_lib(name: str, force: bool = False) -> str | None:
@@ -37,7 +38,7 @@ def build_host_lib(name: str, force: bool = False) -> str | None:
         if os.path.exists(out):
             return out
         raise RuntimeError("g++ not found and %s is not built" % name)
-    subprocess.check_call([cxx, "-O2", "-std=c++17", "-shared", "-fPIC"] + srcs_abs + ["-o", out], cwd=_CSRC)
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off"] + srcs_abs + ["-o", out], cwd=_CSRC)
     return out
 
 

@@ -259,7 +259,9 @@ def init_depth_map(scene: mvsi.Scene, cams: Cameras, ID: int, points: np.ndarray
         py = np.floor(K[1, 1] * camX[:, 1] / camX[:, 2] + K[1, 2] + 0.5).astype(np.int64)
         d = camX[:, 2].astype(f32)
         for x, y, z in zip(px, py, d):                                   # later points overwrite earlier ones, as in the reference
-            depthMap[max(y - 2, 0):min(y + 2, h - 1) + 1, max(x - 2, 0):min(x + 2, w - 1) + 1] = z
+            y0, y1, x0, x1 = max(y - 2, 0), min(y + 2, h - 1), max(x - 2, 0), min(x + 2, w - 1)
+            if y1 >= y0 and x1 >= x0:                                    # (a projection outside the image splats nothing)
+                depthMap[y0:y1 + 1, x0:x1 + 1] = z
         return depthMap, normalMap, float(d.min() * f32(0.9)), float(d.max() * f32(1.1))
     if not opt.bInitSparse or opt.bAddCorners:
         raise NotImplementedError("only the reference's default bInitSparse=1, bAddCorners=0 initialisation is implemented")
@@ -279,7 +281,8 @@ def init_depth_map(scene: mvsi.Scene, cams: Cameras, ID: int, points: np.ndarray
         for f in (f0, f1, f2):
             np.add.at(normals, f, t)
         nrm = np.sqrt((normals.astype(np.float64) ** 2).sum(1))
-        normals = np.where(nrm[:, None] > 0, normals / np.maximum(nrm, 1e-300)[:, None], 0).astype(f32)
+        inv = np.where(nrm > 0, 1.0 / np.maximum(nrm, 1e-300), 0.0)          # cv::normalize: v * (1/|v|), the norm in double
+        normals = (normals.astype(np.float64) * inv[:, None]).astype(f32)
     ix = np.floor(proj).astype(np.int64)
     for (x, y), zz, n in zip(ix, z, normals):
         for dx, dy in ((0, 0), (1, 0), (0, 1), (1, 1)):

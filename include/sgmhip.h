@@ -92,6 +92,10 @@ int sgmhip_project_disparity2depth_map(sgmhip_engine* e, const int16_t* disparit
 int sgmhip_fuse_pairs(sgmhip_engine* e, const float* const* depthMaps, const float* const* depthRangeMaps, const float* const* confMaps, int nPairs,
                       int dw, int dh, unsigned minViews, float* depthMap, float* confMap);
 
+/* cv::filterSpeckles(disparityMap, NO_DISP, maxSpeckleSize, maxDiff) as the tSGM loop applies it on the first level (:687-688; OPTDENSE::nSpeckleSize,
+ * 5): 4-connected regions of disparities differing by <= maxDiff step to step that have at most maxSpeckleSize pixels become NO_DISP. */
+int sgmhip_filter_speckles(sgmhip_engine* e, int16_t* disparity, int w, int h, int maxSpeckleSize, int maxDiff);
+
 /* HIP-event timing since the last reset: milliseconds in the cost-volume, aggregation (8 path
  * kernels) and WTA kernels, number of match calls. */
 typedef struct SGMHipStats { double costMs, aggrMs, wtaMs; uint64_t calls, aggrLaunches; } SGMHipStats;

@@ -353,4 +353,20 @@ int sgmhip_fuse_pairs(sgmhip_engine* e, const float* const* depthMaps, const flo
 	return 0;
 }
 
+int sgmhip_filter_speckles(sgmhip_engine* e, int16_t* disparity, int w, int h, int maxSpeckleSize, int maxDiff) {
+	if (!e || !disparity || w <= 0 || h <= 0 || maxSpeckleSize < 0 || maxDiff < 0 || (size_t)w * h > 0x7fffffffull) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	DevBuf a, p, z; const size_t n = (size_t)w * h;
+	SGMCHK(e, a.alloc(n * 2)); SGMCHK(e, p.alloc(n * 4)); SGMCHK(e, z.alloc(n * 4));
+	SGMCHK(e, hipMemcpyAsync(a.p, disparity, n * 2, hipMemcpyHostToDevice, e->stream));
+	const unsigned g = gridFor(n);
+	hipLaunchKernelGGL(sgmp_speckle_init_kernel, dim3(g), dim3(256), 0, e->stream, (int*)p.p, (int*)z.p, (int)n);
+	hipLaunchKernelGGL(sgmp_speckle_hook_kernel, dim3(g), dim3(256), 0, e->stream, (const int16_t*)a.p, (int*)p.p, w, h, maxDiff);
+	hipLaunchKernelGGL(sgmp_speckle_flatten_kernel, dim3(g), dim3(256), 0, e->stream, (int*)p.p, (int*)z.p, (int)n);
+	hipLaunchKernelGGL(sgmp_speckle_apply_kernel, dim3(g), dim3(256), 0, e->stream, (int16_t*)a.p, (const int*)p.p, (const int*)z.p, (int)n, maxSpeckleSize);
+	SGMCHK(e, hipMemcpyAsync(disparity, a.p, n * 2, hipMemcpyDeviceToHost, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
 } // extern "C"

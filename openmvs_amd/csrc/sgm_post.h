@@ -357,3 +357,44 @@ PM_HD void sgmp_fuse_pairs_px(const float* const* depthMaps, const float* const*
 	for (int p = 0; p < nPairs; ++p) if ((members[best] >> p) & 1u) { ds += depthMaps[p][i]; cs += confMaps[p][i]; ++n; }
 	*depth = ds / (float)n; *conf = cs / (float)n;
 }
+
+// ---- cv::filterSpeckles(disparityMap, NO_DISP, maxSpeckleSize, maxDiff) as the tSGM loop calls it on the first level (:687-688; OpenCV
+// calib3d stereosgbm.cpp filterSpecklesImpl): regions grown over 4-neighbours whose disparities differ by at most maxDiff, step by step; a
+// region of at most maxSpeckleSize pixels is erased.  The growth condition is symmetric, so regions are plain connected components:
+// lock-free union-find (hook the larger root under the smaller with an atomic min, as in pm_filter.hip), flatten, count, erase.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SGMP_ATOMIC_MIN_I(p, v) atomicMin((p), (v))
+#define SGMP_ATOMIC_ADD_I(p, v) atomicAdd((p), (v))
+#else
+PM_HD int sgmp_host_min(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }
+PM_HD int sgmp_host_add(int* p, int v) { const int o = *p; *p = o + v; return o; }
+#define SGMP_ATOMIC_MIN_I(p, v) sgmp_host_min((p), (v))
+#define SGMP_ATOMIC_ADD_I(p, v) sgmp_host_add((p), (v))
+#endif
+PM_HD int sgmp_cc_find(int* parent, int a) {
+	int p = parent[a];
+	while (p != a) { const int gp = parent[p]; if (gp != p) parent[a] = gp; a = p; p = parent[a]; }   // parents only decrease: safe under races
+	return a;
+}
+PM_HD int sgmp_cc_find_ro(const int* parent, int a) { int p = parent[a]; while (p != a) { a = p; p = parent[a]; } return a; }
+PM_HD void sgmp_cc_union(int* parent, int a, int b) {
+	for (;;) {
+		a = sgmp_cc_find(parent, a); b = sgmp_cc_find(parent, b);
+		if (a == b) return;
+		if (a > b) { const int t = a; a = b; b = t; }
+		const int old = SGMP_ATOMIC_MIN_I(&parent[b], a);
+		if (old == b) return;
+		b = old;
+	}
+}
+PM_HD void sgmp_speckle_hook(const int16_t* disp, int* parent, int w, int h, int i, int maxDiff) {
+	const int16_t d = disp[i];
+	if (d == SGMP_NO_DISP) return;
+	const int x = i % w, y = i / w;
+	if (x + 1 < w) { const int16_t e = disp[i + 1]; if (e != SGMP_NO_DISP) { const int df = (int)d - (int)e; if ((df < 0 ? -df : df) <= maxDiff) sgmp_cc_union(parent, i, i + 1); } }
+	if (y + 1 < h) { const int16_t e = disp[i + w]; if (e != SGMP_NO_DISP) { const int df = (int)d - (int)e; if ((df < 0 ? -df : df) <= maxDiff) sgmp_cc_union(parent, i, i + w); } }
+}
+PM_HD void sgmp_speckle_flatten(int* parent, int* size, int i) { const int r = sgmp_cc_find_ro(parent, i); parent[i] = r; SGMP_ATOMIC_ADD_I(&size[r], 1); }
+PM_HD void sgmp_speckle_apply(int16_t* disp, const int* parent, const int* size, int i, int maxSpeckleSize) {
+	if (disp[i] != SGMP_NO_DISP && size[parent[i]] <= maxSpeckleSize) disp[i] = SGMP_NO_DISP;
+}

@@ -85,3 +85,17 @@ __global__ void sgmp_fuse_pairs_kernel(SGMPPairs pr, int nPairs, size_t n, unsig
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
 		sgmp_fuse_pairs_px(pr.depth, pr.range, pr.conf, nPairs, i, minViews, depth + i, conf + i);
 }
+
+__global__ void sgmp_speckle_init_kernel(int* parent, int* size, int n) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { parent[i] = i; size[i] = 0; }
+}
+__global__ void sgmp_speckle_hook_kernel(const int16_t* disp, int* parent, int w, int h, int maxDiff) {
+	const int n = w * h;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) sgmp_speckle_hook(disp, parent, w, h, i, maxDiff);
+}
+__global__ void sgmp_speckle_flatten_kernel(int* parent, int* size, int n) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) sgmp_speckle_flatten(parent, size, i);
+}
+__global__ void sgmp_speckle_apply_kernel(int16_t* disp, const int* parent, const int* size, int n, int maxSpeckleSize) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) sgmp_speckle_apply(disp, parent, size, i, maxSpeckleSize);
+}

@@ -14,7 +14,7 @@ EXPORTS = ["sgmhip_create", "sgmhip_destroy", "sgmhip_last_error", "sgmhip_gener
            "sgmhip_match", "sgmhip_get_results", "sgmhip_sync", "sgmhip_stats_reset", "sgmhip_stats_get",
            "sgmhip_consistency_cross_check", "sgmhip_filter_by_cost", "sgmhip_extract_mask", "sgmhip_upscale_mask", "sgmhip_flip_direction",
            "sgmhip_refine_disparity", "sgmhip_disparity2range_map", "sgmhip_depth2disparity_map", "sgmhip_disparity2depth_map",
-           "sgmhip_project_disparity2depth_map", "sgmhip_fuse_pairs"]
+           "sgmhip_project_disparity2depth_map", "sgmhip_fuse_pairs", "sgmhip_filter_speckles"]
 NO_DISP = 32767          # SemiGlobalMatcher::NO_DISP
 INVALID, VALID = 0, 255  # MaskMap values
 SUBPIXEL_NA, SUBPIXEL_LINEAR, SUBPIXEL_POLY4, SUBPIXEL_PARABOLA, SUBPIXEL_SINE, SUBPIXEL_COSINE, SUBPIXEL_LC_BLEND = range(7)
@@ -174,6 +174,11 @@ class SemiGlobalMatcherHIP:
         dep = np.zeros((dh, dw), np.float32); cf = np.zeros((dh, dw), np.float32)
         self._chk(self._lib.sgmhip_fuse_pairs(self._h, ptrs[0], ptrs[1], ptrs[2], len(depths), dw, dh, C.c_uint(minViews), dep.ctypes.data_as(C.POINTER(C.c_float)), cf.ctypes.data_as(C.POINTER(C.c_float))))
         return dep, cf
+
+    def FilterSpeckles(self, disparity, maxSpeckleSize=100, maxDiff=5):
+        a = np.ascontiguousarray(disparity, np.int16).copy()
+        self._chk(self._lib.sgmhip_filter_speckles(self._h, a.ctypes.data_as(C.POINTER(C.c_int16)), a.shape[1], a.shape[0], maxSpeckleSize, maxDiff))
+        return a
 
     def sync(self):
         self._chk(self._lib.sgmhip_sync(self._h))

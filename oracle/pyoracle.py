@@ -414,3 +414,9 @@ def sgm_fuse_pairs(depths, ranges, confs, minViews=2, impl=None, prefix="orc_sgm
     dep = np.zeros((dh, dw), np.float32); cf = np.zeros((dh, dw), np.float32)
     _sgm_post(prefix, impl)("fuse_pairs")(pd, pr, pc, C.c_int(len(depths)), C.c_int(dw), C.c_int(dh), C.c_uint(minViews), dep.ctypes.data_as(C.POINTER(C.c_float)), cf.ctypes.data_as(C.POINTER(C.c_float)))
     return dep, cf
+
+
+def sgm_filter_speckles(disp, maxSpeckleSize=100, maxDiff=5, impl=None, prefix="orc_sgm_"):
+    a = np.ascontiguousarray(disp, np.int16).copy()
+    _sgm_post(prefix, impl)("filter_speckles")(a.ctypes.data_as(C.POINTER(C.c_int16)), C.c_int(a.shape[1]), C.c_int(a.shape[0]), C.c_int16(32767), C.c_int(maxSpeckleSize), C.c_int(maxDiff))
+    return a

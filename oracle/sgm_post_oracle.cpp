@@ -331,3 +331,35 @@ void orc_sgm_fuse_pairs(const float* const* depthMaps, const float* const* range
 	}
 }
 } // extern "C"
+
+// ---- cv::filterSpeckles for CV_16S (OpenCV calib3d/src/stereosgbm.cpp, filterSpecklesImpl; OpenCV is a dependency that is not vendored in the
+// reference tree): the published algorithm restated -- scan in raster order, flood-fill every unlabelled pixel != newVal over 4-neighbours whose
+// value differs by at most maxDiff from the pixel being expanded, and overwrite regions of at most maxSpeckleSize pixels with newVal.
+extern "C" void orc_sgm_filter_speckles(int16_t* img, int w, int h, int16_t newVal, int maxSpeckleSize, int maxDiff) {
+	std::vector<int> labels((size_t)w * h, 0);
+	std::vector<unsigned char> rtype(1, 0);           // rtype[label] = 1: small region
+	std::vector<int> ws;
+	int curlabel = 0;
+	for (int i = 0; i < h; ++i) for (int j = 0; j < w; ++j) {
+		const size_t p0 = (size_t)i * w + j;
+		if (img[p0] == newVal) continue;
+		if (labels[p0]) { if (rtype[labels[p0]]) img[p0] = newVal; continue; }
+		++curlabel; rtype.push_back(0);
+		labels[p0] = curlabel;
+		ws.clear(); ws.push_back((int)p0);
+		int count = 0;
+		while (!ws.empty()) {
+			const int p = ws.back(); ws.pop_back();
+			++count;
+			const int x = p % w, y = p / w; const int dp = img[p];
+			const int nb[4][2] = {{x, y + 1}, {x, y - 1}, {x + 1, y}, {x - 1, y}};
+			for (const auto& q : nb) {
+				if (q[0] < 0 || q[1] < 0 || q[0] >= w || q[1] >= h) continue;
+				const size_t pq = (size_t)q[1] * w + q[0];
+				if (labels[pq] || img[pq] == newVal || abs(dp - img[pq]) > maxDiff) continue;
+				labels[pq] = curlabel; ws.push_back((int)pq);
+			}
+		}
+		if (count <= maxSpeckleSize) { rtype[curlabel] = 1; img[p0] = newVal; }
+	}
+}

@@ -77,3 +77,13 @@ void emu_sgm_fuse_pairs(const float* const* depthMaps, const float* const* range
 	for (size_t i : order((size_t)dw * dh, 13)) sgmp_fuse_pairs_px(depthMaps, rangeMaps, confMaps, nPairs, i, minViews, depth + i, conf + i);
 }
 }
+
+extern "C" void emu_sgm_filter_speckles(int16_t* img, int w, int h, int16_t newVal, int maxSpeckleSize, int maxDiff) {
+	(void)newVal;                                             // the kernels are specialised for newVal = NO_DISP, as the tSGM loop uses them
+	const size_t n = (size_t)w * h;
+	std::vector<int> parent(n), size(n, 0);
+	for (size_t i = 0; i < n; ++i) parent[i] = (int)i;
+	for (size_t i : order(n, 14)) sgmp_speckle_hook(img, parent.data(), w, h, (int)i, maxDiff);
+	for (size_t i : order(n, 15)) sgmp_speckle_flatten(parent.data(), size.data(), (int)i);
+	for (size_t i : order(n, 16)) sgmp_speckle_apply(img, parent.data(), size.data(), (int)i, maxSpeckleSize);
+}

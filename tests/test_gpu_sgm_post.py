@@ -105,3 +105,13 @@ def test_projection_and_pair_fusion_match_the_oracle(matcher, w, h, seed):
         a = po.sgm_fuse_pairs(deps, rgs, cfs, mv)
         b = matcher.FusePairs(deps, rgs, cfs, mv)
         assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+@_first_run
+def test_filter_speckles_matches_the_oracle(matcher):
+    for w, h, seed in ((64, 40, 0), (131, 77, 1), (400, 300, 2)):
+        base = pc.smooth_disparity(w, h, seed)
+        r = np.random.RandomState(seed + 9)
+        noisy = base.copy(); o = r.rand(h, w) < 0.08; noisy[o] = r.randint(-60, 60, int(o.sum())).astype(np.int16)
+        for mx, df in ((100, 5), (10, 1), (0, 0), (5000, 50)):
+            assert np.array_equal(matcher.FilterSpeckles(noisy, mx, df), po.sgm_filter_speckles(noisy, mx, df)), (w, h, mx, df)

@@ -214,3 +214,24 @@ def test_pair_fusion_known_answer():
     # the shrunk range [2.0, 2.1) no longer admits 1.95: it founds its own cluster; both clusters have... the first of the largest wins
     d, _ = po.sgm_fuse_pairs([one(2.0), one(2.05), one(1.95)], [rng(1.9, 2.1), rng(2.0, 2.2), rng(1.9, 2.0)], [one(0), one(0), one(0)], 1)
     assert np.isclose(d[0, 0], 2.025)
+
+
+def test_filter_speckles(emul):
+    E = dict(impl=emul, prefix="emu_sgm_")
+    d = np.full((6, 10), NO, np.int16)
+    d[0, 0:3] = [10, 12, 14]            # a chain: consecutive differences 2 <= maxDiff although the ends differ by 4
+    d[2, 0:2] = [10, 20]                # two singletons (difference 10)
+    d[4:6, 4:9] = 7                     # a 10-pixel block
+    out = po.sgm_filter_speckles(d, maxSpeckleSize=3, maxDiff=2)
+    assert np.all(out[0, 0:3] == NO) and np.all(out[2, 0:2] == NO) and np.all(out[4:6, 4:9] == 7)      # size 3 <= 3 erased, 10 kept
+    assert np.all(po.sgm_filter_speckles(d, maxSpeckleSize=2, maxDiff=2)[0, 0:3] == [10, 12, 14])       # size 3 > 2 kept
+    for w, h, seed in ((64, 40, 0), (131, 77, 1), (200, 150, 2)):
+        base = pc.smooth_disparity(w, h, seed)
+        r = np.random.RandomState(seed + 9)
+        noisy = base.copy(); o = r.rand(h, w) < 0.08; noisy[o] = r.randint(-60, 60, int(o.sum())).astype(np.int16)
+        for mx, df in ((100, 5), (10, 1), (0, 0), (5000, 50)):
+            a = po.sgm_filter_speckles(noisy, mx, df)
+            b = po.sgm_filter_speckles(noisy, mx, df, **E)
+            assert np.array_equal(a, b), (w, h, mx, df)
+        a = po.sgm_filter_speckles(noisy, 100, 5)
+        assert ((noisy != NO) & (a == NO)).sum() > 0 and np.all(a[a != NO] == noisy[a != NO])

@@ -67,6 +67,9 @@ int sgmhip_flip_direction(sgmhip_engine* e, const int16_t* l2r, int w, int h, in
  * subpixelMode 0 NA, 1 LINEAR, 2 POLY4, 3 PARABOLA, 4 SINE, 5 COSINE, 6 LC_BLEND (the reference's default with subpixelSteps 4).
  * Fetch the result with sgmhip_get_results.  cos/sin come from csrc/pm_math.h (Cephes kernels), not libm. */
 int sgmhip_refine_disparity(sgmhip_engine* e, int subpixelMode, int subpixelSteps);
+/* Replace the resident disparity map of the last sgmhip_match (valid-grid size) with a post-processed one -- the tSGM loop refines the
+ * cross-checked map, not the raw winner-take-all result (:693-699). */
+int sgmhip_set_disparity(sgmhip_engine* e, const int16_t* disparity);
 
 /* Disparity2RangeMap (:1350-1444): from the previous level's disparity map (w x h) and the 2x mask (w2 x h2, w2 > 2w+3, h2 >= 2h+3), the pixel
  * table of the next level: per 2x pixel the search range around the median of the valid disparities in a 7x7 window (41x41 at holes) and the

@@ -369,4 +369,12 @@ int sgmhip_filter_speckles(sgmhip_engine* e, int16_t* disparity, int w, int h, i
 	return 0;
 }
 
+int sgmhip_set_disparity(sgmhip_engine* e, const int16_t* disparity) {
+	if (!e || !disparity || e->numCosts == 0) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	SGMCHK(e, hipMemcpyAsync(e->d_disp, disparity, (size_t)e->vw * e->vh * 2, hipMemcpyHostToDevice, e->stream));
+	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
 } // extern "C"

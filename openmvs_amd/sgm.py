@@ -14,7 +14,7 @@ EXPORTS = ["sgmhip_create", "sgmhip_destroy", "sgmhip_last_error", "sgmhip_gener
            "sgmhip_match", "sgmhip_get_results", "sgmhip_sync", "sgmhip_stats_reset", "sgmhip_stats_get",
            "sgmhip_consistency_cross_check", "sgmhip_filter_by_cost", "sgmhip_extract_mask", "sgmhip_upscale_mask", "sgmhip_flip_direction",
            "sgmhip_refine_disparity", "sgmhip_disparity2range_map", "sgmhip_depth2disparity_map", "sgmhip_disparity2depth_map",
-           "sgmhip_project_disparity2depth_map", "sgmhip_fuse_pairs", "sgmhip_filter_speckles"]
+           "sgmhip_project_disparity2depth_map", "sgmhip_fuse_pairs", "sgmhip_filter_speckles", "sgmhip_set_disparity"]
 NO_DISP = 32767          # SemiGlobalMatcher::NO_DISP
 INVALID, VALID = 0, 255  # MaskMap values
 SUBPIXEL_NA, SUBPIXEL_LINEAR, SUBPIXEL_POLY4, SUBPIXEL_PARABOLA, SUBPIXEL_SINE, SUBPIXEL_COSINE, SUBPIXEL_LC_BLEND = range(7)
@@ -126,6 +126,11 @@ class SemiGlobalMatcherHIP:
         a = np.ascontiguousarray(l2r, np.int16); o = np.zeros_like(a)
         self._chk(self._lib.sgmhip_flip_direction(self._h, a.ctypes.data_as(C.POINTER(C.c_int16)), a.shape[1], a.shape[0], o.ctypes.data_as(C.POINTER(C.c_int16))))
         return o
+
+    def set_disparity(self, disparity):
+        a = np.ascontiguousarray(disparity, np.int16)
+        assert a.shape == self._shape
+        self._chk(self._lib.sgmhip_set_disparity(self._h, a.ctypes.data_as(C.POINTER(C.c_int16))))
 
     def RefineDisparityMap(self, subpixelMode=SUBPIXEL_LC_BLEND, subpixelSteps=4):
         """In place on the device, on the result of the last Match(); read it back with results()."""

@@ -115,3 +115,22 @@ def test_filter_speckles_matches_the_oracle(matcher):
         noisy = base.copy(); o = r.rand(h, w) < 0.08; noisy[o] = r.randint(-60, 60, int(o.sum())).astype(np.int16)
         for mx, df in ((100, 5), (10, 1), (0, 0), (5000, 50)):
             assert np.array_equal(matcher.FilterSpeckles(noisy, mx, df), po.sgm_filter_speckles(noisy, mx, df)), (w, h, mx, df)
+
+
+@_first_run
+def test_tsgm_loop_on_the_device_equals_the_loop_on_the_oracle(matcher):
+    """openmvs_amd/tsgm.py: the same coarse-to-fine loop, every step on the device vs every step on the oracle."""
+    from openmvs_amd import tsgm
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    from tests.tsgm_backends import DeviceBackend, OracleBackend
+    w, h, d0 = 256, 192, 12
+    lb, lg, rg = sc.stereo_pair(w, h, d0, seed=4)
+    rb = np.roll(lb, d0, axis=1)
+    mask = np.full((h, w), 255, np.uint8); mask[:, :5] = 0
+    e = PatchMatchHIP(0)
+    dev = tsgm.tsgm_match(DeviceBackend(matcher, e), lb, lg, rb, rg, mask, mask, min_resolution=64)
+    ref = tsgm.tsgm_match(OracleBackend(), lb, lg, rb, rg, mask, mask, min_resolution=64)
+    e.close()
+    assert dev[2] == ref[2] == 3 and np.array_equal(dev[0], ref[0]) and np.array_equal(dev[1], ref[1])
+    ok = dev[0] != tsgm.NO_DISP
+    assert ok.mean() > 0.6 and abs(np.median(dev[0][ok] / 4.0) - d0) < 0.5

@@ -42,6 +42,7 @@ def test_device_fuse_is_the_sequential_fuse(small_scene, nine_scene, case):
     e.close()
 
 
+@pytest.mark.xfail(strict=False, reason="added after the round's GPU budget was spent: verified kernels, but this fixture path has not run on a device yet")
 def test_device_fuse_reproduces_the_golden_cloud():
     """The committed fixture (tests/golden/fuse_golden_96x64.npz, written by the oracle): same inputs through the C ABI."""
     from tests.test_fuse import _golden_inputs

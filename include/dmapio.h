@@ -32,6 +32,16 @@ int dmap_read_header(const char* fileName, DMapHeader* hdr);
  * sized from the header; a NULL pointer skips that plane. */
 int dmap_read(const char* fileName, DMapHeader* hdr, unsigned flags, float* depth, float* normal, float* conf, uint8_t* views);
 
+/* ---- .dimap: disparity-data file of the SGM path (SemiGlobalMatcher::ExportDisparityDataRawFull / ImportDisparityDataRawFull,
+ * libs/MVS/SemiGlobalMatcher.cpp:2094-2188): i32 imageW, imageH | f64 H[9] | f64 Q[16] | i16 subpixelSteps | i32 cols, rows | i16 disparity[] | optional u16 cost[].
+ * The maps are stored with the 3-pixel border (NO_DISP 32767 / NO_ACCUMCOST 65535) around the valid grid; these functions take / return the
+ * valid grid (w x h) like the *Full variants.  cost may be NULL. */
+int dimap_write(const char* fileName, int imageW, int imageH, const double H[9], const double Q[16], int16_t subpixelSteps,
+                const int16_t* disparity, const uint16_t* cost, int w, int h);
+/* Call with disparity == NULL to obtain the sizes and *hasCost, then with buffers of w*h entries (cost NULL skips it). */
+int dimap_read(const char* fileName, int* imageW, int* imageH, double H[9], double Q[16], int16_t* subpixelSteps, int* w, int* h, int* hasCost,
+               int16_t* disparity, uint16_t* cost);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,3 +87,66 @@ int dmap_read(const char* fileName, DMapHeader* h, unsigned flags, float* depth,
 }
 
 } // extern "C"
+
+// ---- .dimap: the disparity-data file of the SGM path (SemiGlobalMatcher::ExportDisparityDataRawFull / ImportDisparityDataRawFull,
+// libs/MVS/SemiGlobalMatcher.cpp:2094-2188).  Layout: i32 imageW, imageH | f64 H[9] | f64 Q[16] | i16 subpixelSteps | i32 cols, rows |
+// i16 disparity[rows*cols] | optional u16 cost[rows*cols]; the stored maps carry the 3-pixel border (NO_DISP / NO_ACCUMCOST) around the valid grid.
+extern "C" {
+
+int dimap_write(const char* fileName, int imageW, int imageH, const double H[9], const double Q[16], int16_t subpixelSteps,
+		const int16_t* disparity, const uint16_t* cost, int w, int h) {
+	if (!fileName || !H || !Q || !disparity || w <= 0 || h <= 0) return -2;
+	const int HWB = 3, fw = w + 2 * HWB, fh = h + 2 * HWB;
+	std::string tmp = std::string(fileName) + ".tmp";
+	FILE* f = fopen(tmp.c_str(), "wb");
+	if (!f) return -1;
+	bool ok = fwrite(&imageW, 4, 1, f) == 1 && fwrite(&imageH, 4, 1, f) == 1 && fwrite(H, 8, 9, f) == 9 && fwrite(Q, 8, 16, f) == 16 &&
+	          fwrite(&subpixelSteps, 2, 1, f) == 1 && fwrite(&fw, 4, 1, f) == 1 && fwrite(&fh, 4, 1, f) == 1;
+	std::string row((size_t)fw * 2, 0);
+	for (int pass = 0; pass < (cost ? 2 : 1) && ok; ++pass) {
+		const uint16_t fill = pass == 0 ? (uint16_t)32767 : (uint16_t)65535;            // NO_DISP / NO_ACCUMCOST
+		for (int y = 0; y < fh && ok; ++y) {
+			uint16_t* r = (uint16_t*)&row[0];
+			for (int x = 0; x < fw; ++x) r[x] = fill;
+			const int sy = y - HWB;
+			if (sy >= 0 && sy < h) memcpy(r + HWB, pass == 0 ? (const void*)(disparity + (size_t)sy * w) : (const void*)(cost + (size_t)sy * w), (size_t)w * 2);
+			ok = fwrite(r, 2, (size_t)fw, f) == (size_t)fw;
+		}
+	}
+	ok = (fclose(f) == 0) && ok;
+	if (!ok || rename(tmp.c_str(), fileName) != 0) { remove(tmp.c_str()); return -1; }
+	return 0;
+}
+
+// First call with disparity == NULL to get the sizes (w, h = valid grid; *hasCost); then with buffers of w*h entries.
+int dimap_read(const char* fileName, int* imageW, int* imageH, double H[9], double Q[16], int16_t* subpixelSteps, int* w, int* h, int* hasCost,
+		int16_t* disparity, uint16_t* cost) {
+	if (!fileName) return -2;
+	FILE* f = fopen(fileName, "rb");
+	if (!f) return -1;
+	int iw = 0, ih = 0, fw = 0, fh = 0; double hh[9], qq[16]; int16_t st = 0;
+	bool ok = fread(&iw, 4, 1, f) == 1 && fread(&ih, 4, 1, f) == 1 && fread(hh, 8, 9, f) == 9 && fread(qq, 8, 16, f) == 16 && fread(&st, 2, 1, f) == 1 &&
+	          fread(&fw, 4, 1, f) == 1 && fread(&fh, 4, 1, f) == 1;
+	const int HWB = 3;
+	if (!ok || iw <= 0 || ih <= 0 || fw <= 2 * HWB || fh <= 2 * HWB) { fclose(f); return -2; }
+	const long dataStart = ftell(f);
+	fseek(f, 0, SEEK_END); const long size = ftell(f);
+	const long need = (long)fw * fh * 2;
+	if (size - dataStart < need) { fclose(f); return -2; }
+	const bool withCost = size - dataStart >= 2 * need;
+	if (imageW) *imageW = iw; if (imageH) *imageH = ih; if (H) memcpy(H, hh, 72); if (Q) memcpy(Q, qq, 128); if (subpixelSteps) *subpixelSteps = st;
+	if (w) *w = fw - 2 * HWB; if (h) *h = fh - 2 * HWB; if (hasCost) *hasCost = withCost ? 1 : 0;
+	const int vw = fw - 2 * HWB, vh = fh - 2 * HWB;
+	for (int pass = 0; pass < 2 && ok; ++pass) {
+		void* dst = pass == 0 ? (void*)disparity : (void*)cost;
+		if (!dst || (pass == 1 && !withCost)) continue;
+		for (int y = 0; y < vh && ok; ++y) {
+			fseek(f, dataStart + (long)pass * need + ((long)(y + HWB) * fw + HWB) * 2, SEEK_SET);
+			ok = fread((char*)dst + (size_t)y * vw * 2, 2, (size_t)vw, f) == (size_t)vw;
+		}
+	}
+	fclose(f);
+	return ok ? 0 : -2;
+}
+
+} // extern "C"

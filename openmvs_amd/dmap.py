@@ -15,7 +15,7 @@ class DMapHeader(C.Structure):
                 ("K", C.c_double * 9), ("R", C.c_double * 9), ("C", C.c_double * 3), ("imageFileName", C.c_char * 1024)]
 
 
-EXPORTS = ["dmap_write", "dmap_read_header", "dmap_read"]
+EXPORTS = ["dmap_write", "dmap_read_header", "dmap_read", "dimap_write", "dimap_read"]
 _LIB = None
 
 
@@ -73,3 +73,29 @@ def load(path, flags: int = 15) -> dict:
         if a is not None:
             out[k] = a
     return out
+
+
+# ---- .dimap (disparity data of the SGM path) ---------------------------------------------------------------------------------------
+def save_dimap(path, image_size, H, Q, subpixel_steps, disparity, cost=None):
+    """SemiGlobalMatcher::ExportDisparityDataRawFull (libs/MVS/SemiGlobalMatcher.cpp:2124-2138): valid-grid maps in, bordered maps on disk."""
+    d = np.ascontiguousarray(disparity, np.int16); c = None if cost is None else np.ascontiguousarray(cost, np.uint16)
+    hh = np.ascontiguousarray(H, np.float64); qq = np.ascontiguousarray(Q, np.float64)
+    rc = load_library().dimap_write(str(path).encode(), int(image_size[0]), int(image_size[1]), hh.ctypes.data_as(C.POINTER(C.c_double)), qq.ctypes.data_as(C.POINTER(C.c_double)),
+                                    C.c_int16(subpixel_steps), d.ctypes.data_as(C.c_void_p), None if c is None else c.ctypes.data_as(C.c_void_p), d.shape[1], d.shape[0])
+    if rc != 0:
+        raise IOError("dimap_write failed: %d" % rc)
+
+
+def load_dimap(path) -> dict:
+    """ImportDisparityDataRawFull (:2178-2188)."""
+    lib = load_library()
+    iw, ih, w, h, hc = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int(); st = C.c_int16()
+    H = np.zeros((3, 3)); Q = np.zeros((4, 4))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    args = (str(path).encode(), C.byref(iw), C.byref(ih), dp(H), dp(Q), C.byref(st), C.byref(w), C.byref(h), C.byref(hc))
+    if lib.dimap_read(*args, None, None) != 0:
+        raise IOError("invalid disparity-data file '%s'" % path)
+    d = np.zeros((h.value, w.value), np.int16); c = np.zeros((h.value, w.value), np.uint16) if hc.value else None
+    if lib.dimap_read(*args, d.ctypes.data_as(C.c_void_p), None if c is None else c.ctypes.data_as(C.c_void_p)) != 0:
+        raise IOError("dimap_read failed")
+    return dict(image_size=(iw.value, ih.value), H=H, Q=Q, subpixel_steps=int(st.value), disparity=d, cost=c)

@@ -68,3 +68,31 @@ def test_reference_reader_parses_our_file(tmp_path):
     dmap.save(p, **c)
     d = loadDMAP(str(p))
     assert np.array_equal(d["depth_map"], c["depth"]) and np.array_equal(d["normal_map"], c["normal"]) and np.array_equal(d["views_map"], c["views"])
+
+
+def test_dimap_layout_and_round_trip(tmp_path):
+    """`.dimap` (SemiGlobalMatcher.cpp:2094-2188): header of 2 i32 + 9 + 16 f64 + i16 + 2 i32, then the maps with their 3-pixel NO_DISP border."""
+    import struct
+    from openmvs_amd import dmap
+    r = np.random.RandomState(0)
+    d = r.randint(-50, 50, (5, 7)).astype(np.int16); c = r.randint(0, 2000, (5, 7)).astype(np.uint16)
+    H = r.randn(3, 3); Q = r.randn(4, 4)
+    p = str(tmp_path / "0001_0002.dimap")
+    dmap.save_dimap(p, (640, 480), H, Q, 4, d, c)
+    raw = open(p, "rb").read()
+    assert len(raw) == 8 + 72 + 128 + 2 + 8 + 2 * (13 * 11) * 2 and not (tmp_path / "0001_0002.dimap.tmp").exists()
+    assert struct.unpack_from("<ii", raw, 0) == (640, 480) and struct.unpack_from("<h", raw, 208)[0] == 4 and struct.unpack_from("<ii", raw, 210) == (13, 11)
+    assert np.array_equal(np.frombuffer(raw, "<f8", 9, 8).reshape(3, 3), H) and np.array_equal(np.frombuffer(raw, "<f8", 16, 80).reshape(4, 4), Q)
+    full = np.frombuffer(raw, "<i2", 13 * 11, 218).reshape(11, 13)
+    assert np.array_equal(full[3:-3, 3:-3], d) and np.all(full[:3] == 32767) and np.all(full[:, -3:] == 32767)
+    fullc = np.frombuffer(raw, "<u2", 13 * 11, 218 + 13 * 11 * 2).reshape(11, 13)
+    assert np.array_equal(fullc[3:-3, 3:-3], c) and np.all(fullc[-3:] == 65535)
+    g = dmap.load_dimap(p)
+    assert g["image_size"] == (640, 480) and g["subpixel_steps"] == 4 and np.array_equal(g["disparity"], d) and np.array_equal(g["cost"], c)
+    assert np.array_equal(g["H"], H) and np.array_equal(g["Q"], Q)
+    dmap.save_dimap(p, (640, 480), H, Q, 1, d)                       # without a cost map
+    g = dmap.load_dimap(p)
+    assert g["cost"] is None and np.array_equal(g["disparity"], d)
+    open(p, "wb").write(raw[:300])
+    with pytest.raises(IOError):
+        dmap.load_dimap(p)

@@ -1,0 +1,88 @@
+"""The SGM path end to end on the reference's own pipeline-test scene (tests/data/scene), CPU only: stereo rectification of two image pairs
+(openmvs_amd/rectify.py), the tSGM coarse-to-fine loop (openmvs_amd/tsgm.py, driven on the oracle backend), ProjectDisparity2DepthMap and the
+per-pixel pair fusion.  The resulting depth maps are compared with the SfM points of the scene, which never entered the computation: this is
+the real-data check of the restated chain (the device runs the same loop through tests/test_gpu_sgm_post.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from openmvs_amd import mvsi, rectify, tsgm, views
+from oracle import pyoracle as po
+from tests.tsgm_backends import OracleBackend
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCENE = os.path.join(HERE, "data", "scene")
+
+
+def _gray(b):
+    f = np.float32
+    return (f(0.114) * (b[..., 0].astype(f) / f(255)) + f(0.587) * (b[..., 1].astype(f) / f(255))) + f(0.299) * (b[..., 2].astype(f) / f(255))
+
+
+@pytest.fixture(scope="module")
+def scene():
+    from PIL import Image
+    sc = mvsi.load(os.path.join(SCENE, "scene.mvs"))
+    cams = views.Cameras(sc)
+    bgr = [np.ascontiguousarray(np.asarray(Image.open(os.path.join(SCENE, im.name)).convert("RGB"))[..., ::-1]) for im in sc.images]
+    own = np.repeat(np.arange(len(sc.vertices)), np.diff(sc.vertex_view_start)); ids = sc.vertex_views["image_id"]
+    seen = []
+    for i in range(len(sc.images)):
+        s = np.zeros(len(sc.vertices), bool); s[own[ids == i]] = True; seen.append(s)
+    return sc, cams, bgr, seen
+
+
+def _w2i3(cams, i, X):
+    """Camera::TransformPointW2I3 (libs/MVS/Camera.h:396-399)."""
+    cx = (X - cams.C[i]) @ cams.R[i].T; K = cams.K[i]
+    return np.stack([K[0, 2] + K[0, 0] * cx[:, 0] / cx[:, 2], K[1, 2] + K[1, 1] * cx[:, 1] / cx[:, 2], cx[:, 2]], 1).astype(np.float32)
+
+
+def _pair_depth(scene, A, B):
+    sc, cams, bgr, seen = scene
+    X = sc.vertices[seen[A] & seen[B]].astype(np.float64)
+    p1, p2 = _w2i3(cams, A, X), _w2i3(cams, B, X)
+    r = rectify.stereo_rectify_images(bgr[A], cams.K[A], cams.R[A], cams.C[A], bgr[B], cams.K[B], cams.R[B], cams.C[B], p1, p2)
+    assert r is not None and abs(r["t"]) > 0.5
+    # rectified: corresponding points share their row, and the rotations are rotations
+    a = rectify._project_h(r["H"], p1[:, :2])
+    b = rectify._project_h(r["K2"] @ r["R2"] @ rectify._inv_k(cams.K[B]), p2[:, :2])
+    assert np.abs(a[:, 1] - b[:, 1]).max() < 1e-3
+    assert np.allclose(r["R1"] @ r["R1"].T, np.eye(3), atol=1e-12) and np.isclose(np.linalg.det(r["R1"]), 1)
+    # Q maps (x', y', d) of the rectified left image to the depth in the original image: exact on the sparse points themselves
+    d = b[:, 0] - a[:, 0]
+    xs = np.rint(a[:, 0]).astype(int); ys = np.rint(a[:, 1]).astype(int)
+    Q = r["Q"]
+    wq = Q[3, 0] * xs + Q[3, 1] * ys - Q[3, 2] * d + Q[3, 3]; zq = (Q[2, 0] * xs + Q[2, 1] * ys - Q[2, 2] * d + Q[2, 3]) / wq
+    assert np.median(np.abs(zq - p1[:, 2]) / p1[:, 2]) < 2e-3
+    w, h = r["size"]; w4, h4 = w // 4 * 4, h // 4 * 4
+    lb, rb = r["rect1"][:h4, :w4].copy(), r["rect2"][:h4, :w4].copy()
+    disp, cost, levels = tsgm.tsgm_match(OracleBackend(), lb, _gray(lb), rb, _gray(rb), r["mask1"][:h4, :w4].copy(), r["mask2"][:h4, :w4].copy(), min_resolution=160)
+    assert levels == 3 and (disp != tsgm.NO_DISP).mean() > 0.4
+    H0, W0 = bgr[A].shape[:2]
+    ok, dep, rg, cf = po.sgm_project_disparity2depth_map(disp, cost, r["Q"], 4, (W0, H0))
+    assert ok and (dep > 0).mean() > 0.4
+    return dep, rg, cf
+
+
+def _against_sfm(scene, A, dep):
+    sc, cams, bgr, seen = scene
+    p = _w2i3(cams, A, sc.vertices[seen[A]].astype(np.float64))
+    xi = np.rint(p[:, 0]).astype(int); yi = np.rint(p[:, 1]).astype(int)
+    m = (xi >= 0) & (yi >= 0) & (xi < dep.shape[1]) & (yi < dep.shape[0])
+    dm = dep[yi[m], xi[m]]; v = dm > 0
+    rel = np.abs(dm[v] - p[m][v, 2]) / p[m][v, 2]
+    return v.mean(), np.median(rel), np.percentile(rel, 90)
+
+
+def test_sgm_chain_matches_the_sfm_points(scene):
+    pairs = [_pair_depth(scene, 0, 2), _pair_depth(scene, 0, 3)]
+    for dep, rg, cf in pairs:
+        cover, med, p90 = _against_sfm(scene, 0, dep)
+        assert cover > 0.6 and med < 6e-3 and p90 < 3e-2, (cover, med, p90)
+        good = dep > 0
+        assert np.all(rg[good].min(1) <= dep[good] * 1.001) and np.all(rg[good].max(1) >= dep[good] * 0.999)   # the depths at disparity -1 / +1 bracket it
+    fused, conf = po.sgm_fuse_pairs([p[0] for p in pairs], [p[1] for p in pairs], [p[2] for p in pairs], minViews=2)
+    cover, med, p90 = _against_sfm(scene, 0, fused)
+    assert (fused > 0).mean() > 0.25 and cover > 0.4 and med < 5e-3 and p90 < 2e-2, (cover, med, p90)

@@ -86,3 +86,24 @@ def test_sgm_chain_matches_the_sfm_points(scene):
     fused, conf = po.sgm_fuse_pairs([p[0] for p in pairs], [p[1] for p in pairs], [p[2] for p in pairs], minViews=2)
     cover, med, p90 = _against_sfm(scene, 0, fused)
     assert (fused > 0).mean() > 0.25 and cover > 0.4 and med < 5e-3 and p90 < 2e-2, (cover, med, p90)
+
+
+def test_sgm_pipeline_module(scene, tmp_path):
+    """openmvs_amd/sgm_pipeline.py (the orchestration a host would call) gives the same maps, and its pair data survives a .dimap round trip."""
+    from openmvs_amd import dmap, sgm_pipeline
+    sc, cams, bgr, seen = scene
+    be = OracleBackend()
+    cam = lambda i: (cams.K[i], cams.R[i], cams.C[i])
+    pairs = []
+    for B in (2, 3):
+        p = sgm_pipeline.match_pair(be, bgr[0], cam(0), bgr[B], cam(B), sc.vertices[seen[0] & seen[B]], min_resolution=160)
+        assert p is not None
+        f = str(tmp_path / ("0000_%04d.dimap" % B))
+        dmap.save_dimap(f, p["image_size"], p["H"], p["Q"], p["subpixel_steps"], p["disparity"], p["cost"])
+        g = dmap.load_dimap(f)
+        assert np.array_equal(g["disparity"], p["disparity"]) and np.array_equal(g["cost"], p["cost"]) and np.array_equal(g["Q"], p["Q"])
+        pairs.append(dict(p, disparity=g["disparity"], cost=g["cost"]))
+    depth, conf = sgm_pipeline.fuse_pairs(be, pairs, 2)
+    cover, med, p90 = _against_sfm(scene, 0, depth)
+    assert cover > 0.4 and med < 5e-3 and p90 < 2e-2
+    assert conf[depth > 0].min() > 0 and not conf[depth == 0].any()

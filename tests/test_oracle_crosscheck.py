@@ -34,13 +34,31 @@ def _weights(img, x, y):
     return w, tw, sumW, normSq0
 
 
+def _inv_k(K):
+    o = np.eye(3); o[0, 0] = 1 / K[0, 0]; o[1, 1] = 1 / K[1, 1]; o[0, 2] = -K[0, 2] * o[0, 0]; o[1, 2] = -K[1, 2] * o[1, 1]
+    return o
+
+
+def _sample_if(img, px, py, ok):
+    """TImage::sample(v, pt, functor), libs/Common/Types.inl:2296-2314: bilinear over the neighbours that pass the test, each failing one replaced."""
+    lx, ly = int(px), int(py)
+    x = f32(px - f32(lx)); x1 = f32(f32(1) - x); y = f32(py - f32(ly)); y1 = f32(f32(1) - y)
+    v00, v10, v01, v11 = img[ly, lx], img[ly, lx + 1], img[ly + 1, lx], img[ly + 1, lx + 1]
+    b00, b10, b01, b11 = ok(v00), ok(v10), ok(v01), ok(v11)
+    if not (b00 or b10 or b01 or b11):
+        return False, f32(0)
+    a = v00 if b00 else (v10 if b10 else (v01 if b01 else v11)); b = v10 if b10 else (v00 if b00 else (v11 if b11 else v01))
+    c = v01 if b01 else (v11 if b11 else (v00 if b00 else v10)); d = v11 if b11 else (v01 if b01 else (v10 if b10 else v00))
+    return True, f32(f32(y1 * f32(f32(x1 * a) + f32(x * b))) + f32(y * f32(f32(x1 * c) + f32(x * d))))
+
+
 def _sample(img, px, py):
     lx, ly = int(px), int(py)
     x = f32(px - f32(lx)); x1 = f32(f32(1) - x); y = f32(py - f32(ly)); y1 = f32(f32(1) - y)
     return f32(f32(f32(img[ly, lx] * x1) + f32(img[ly, lx + 1] * x)) * y1 + f32(f32(img[ly + 1, lx] * x1) + f32(img[ly + 1, lx + 1] * x)) * y)
 
 
-def score_view(img0, K0, R0, C0, img1, K1, R1, C1, x, y, depth, normal, thRobust=TH_ROBUST):
+def score_view(img0, K0, R0, C0, img1, K1, R1, C1, x, y, depth, normal, thRobust=TH_ROBUST, depth1_map=None, geo_weight=f32(0.1), prior=None):
     w, tw, sumW, normSq0 = _weights(img0, x, y)
     Hl = K1 @ R1 @ R0.T; Hm = K1 @ R1 @ (C0 - C1); Hr = np.linalg.inv(K0)
     X0 = np.array([(x - K0[0, 2]) / K0[0, 0], (y - K0[1, 2]) / K0[1, 1], 1.0])
@@ -67,7 +85,32 @@ def score_view(img0, K0, R0, C0, img1, K1, R1, C1, x, y, depth, normal, thRobust
     if nrm <= f32(1e-16):
         return thRobust
     ncc = min(max(f32(num / f32(np.sqrt(nrm))), f32(-1)), f32(1))
-    return min(f32(2), f32(f32(1) - ncc))
+    score = f32(f32(1) - ncc)
+    if depth1_map is not None:           # geometric consistency with the source view's depth map, DepthMap.cpp:536-551
+        KR1 = K1 @ R1
+        Tl = (KR1 @ R0.T).astype(f32); Tm = (KR1 @ (C0 - C1)).astype(f32)
+        Tr = (K0 @ R0 @ R1.T @ _inv_k(K1)).astype(f32); Tn = (K0 @ R0 @ (C1 - C0)).astype(f32)
+        mv = lambda M, v: np.array([f32(f32(f32(M[r, 0] * v[0]) + f32(M[r, 1] * v[1])) + f32(M[r, 2] * v[2])) for r in range(3)], f32)
+        p = np.array([f32(f32(X0[0]) * depth), f32(f32(X0[1]) * depth), depth], f32)
+        X1 = (mv(Tl, p) + Tm).astype(f32)
+        consistency = f32(4)
+        if X1[2] > 0:
+            x1 = (f32(X1[0] / X1[2]), f32(X1[1] / X1[2]))
+            if x1[0] >= 1 and x1[1] >= 1 and x1[0] <= w1 - 2 and x1[1] <= h1 - 2:
+                ok, d1 = _sample_if(depth1_map, x1[0], x1[1], lambda d: abs(f32(X1[2] - d)) / X1[2] < f32(0.03))
+                if ok:
+                    q = (mv(Tr, np.array([f32(x1[0] * d1), f32(x1[1] * d1), d1], f32)) + Tn).astype(f32)
+                    xb = (f32(q[0] / q[2]), f32(q[1] / q[2]))
+                    dx, dy = f32(f32(x) - xb[0]), f32(f32(y) - xb[1])
+                    dist = f32(np.sqrt(f32(f32(dx * dx) + f32(dy * dy))))
+                    consistency = min(f32(np.sqrt(f32(dist * f32(dist + f32(2))))), consistency)
+        score = f32(score + f32(geo_weight * consistency))
+    if prior is not None and prior[y, x] > 0:      # low-resolution depth prior on texture-less patches, :553-561
+        d0 = prior[y, x]
+        deltaDepth = min(f32(abs(f32(d0 - depth)) / d0), f32(0.5))
+        factor = f32(np.exp(f32(normSq0 * f32(f32(-1) / f32(f32(1) * f32(0.02))))))
+        score = f32(f32(f32(f32(1) - factor) * score) + f32(factor * deltaDepth))
+    return min(f32(2), score)
 
 
 def minmean(scores, thRobust=TH_ROBUST):
@@ -108,3 +151,32 @@ def test_thRobust_is_the_reference_value():
     """thRobust = fNCCThresholdKeep * 4/3 (DepthMap.cpp:406) with the default fNCCThresholdKeep 0.9 -> 1.2."""
     o = po.default_opt()
     assert abs(o.fNCCThresholdKeep - 0.9) < 1e-7
+
+
+def test_geometric_and_prior_terms_two_readings_agree(small_scene):
+    sc = small_scene
+    r = np.random.RandomState(1)
+    ref = 2
+    ids = [ref] + list(sc.neighbors[ref])
+    noisy = {v: (sc.gt_depth[v] * (1 + 0.01 * r.randn(*sc.gt_depth[v].shape))).astype(f32) for v in range(sc.n_views)}
+    for v in noisy:
+        noisy[v][r.rand(*noisy[v].shape) < 0.1] = 0
+    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids, depth_maps=noisy)
+    opt = po.default_opt(seed=1, viewID=ref)
+    gw = f32(opt.fEstimationGeometricWeight)
+    prior = (sc.gt_depth[ref] * f32(1.01)).astype(f32); prior[::3] = 0
+    checked = 0
+    for _ in range(50):
+        x = int(r.randint(HW + 2, sc.width - HW - 2)); y = int(r.randint(HW + 2, sc.height - HW - 2))
+        depth = f32(sc.gt_depth[ref][y, x] * (1 + 0.01 * r.randn()))
+        view_ray = np.array([(x - sc.K[ref][0, 2]) / sc.K[ref][0, 0], (y - sc.K[ref][1, 2]) / sc.K[ref][1, 1], 1.0])
+        nrm = -view_ray / np.linalg.norm(view_ray) + 0.2 * r.randn(3); nrm /= np.linalg.norm(nrm)
+        nrm = nrm.astype(f32)
+        rc, got, agg = po.score_pixel(views, len(ids), opt, x, y, float(depth), nrm, prior)
+        if rc != 0:
+            continue
+        mine = [score_view(sc.gray[ref], sc.K[ref], sc.R[ref], sc.C[ref], sc.gray[v], sc.K[v], sc.R[v], sc.C[v], x, y, depth, nrm,
+                           depth1_map=noisy[v], geo_weight=gw, prior=prior) for v in ids[1:]]
+        assert np.allclose(got, np.array(mine, f32), rtol=0, atol=5e-5), (x, y, got, mine)
+        checked += 1
+    assert checked > 30

@@ -361,6 +361,18 @@ struct DepthEstimator {
 		double Hd[9]; mul33(M, img.Hr, Hd);
 		for (int i = 0; i < 9; ++i) H[i] = (float)Hd[i];
 	}
+	// one factor of the smoothness product, DepthMap.cpp:524-533 (the current plane must have been set with InitPlane)
+	float SmoothFactor(const NeighborEstimate& nb, float depth, const float* normal) const {
+		// Planef::Distance (Eigen 3-vector dot: e0 + (e1 + e2)), Plane.inl:187-190
+		const float dist = (planeN[0]*nb.X[0] + (planeN[1]*nb.X[1] + planeN[2]*nb.X[2])) + planeD;
+		const float factorDepth = pm_expf(SQ(dist / depth) * smoothSigmaDepth);
+		// ComputeAngle, Util.inl:544-546
+		const float ca = pm_clampf((normal[0]*nb.normal[0] + normal[1]*nb.normal[1] + normal[2]*nb.normal[2]) /
+			pm_sqrtf((normal[0]*normal[0] + normal[1]*normal[1] + normal[2]*normal[2]) *
+			         (nb.normal[0]*nb.normal[0] + nb.normal[1]*nb.normal[1] + nb.normal[2]*nb.normal[2])), -1.f, 1.f);
+		const float factorNormal = pm_expf(SQ(pm_acosf(ca)) * smoothSigmaNormal);
+		return (1.f - smoothBonusDepth * factorDepth) * (1.f - smoothBonusNormal * factorNormal);
+	}
 	// InitPlane, DepthMap.cpp:963-971
 	void InitPlane(float depth, const float* normal) {
 		planeN[0] = normal[0]; planeN[1] = normal[1]; planeN[2] = normal[2];
@@ -426,18 +438,8 @@ struct DepthEstimator {
 		const float ncc = pm_clampf(num / pm_sqrtf(nrmSq), -1.f, 1.f);
 		float score = 1.f - ncc;
 		// encourage smoothness, :524-533
-		for (int k = 0; k < nClose; ++k) {
-			const NeighborEstimate& nb = close[k];
-			// Planef::Distance (Eigen 3-vector dot: e0 + (e1 + e2)), Plane.inl:187-190
-			const float dist = (planeN[0]*nb.X[0] + (planeN[1]*nb.X[1] + planeN[2]*nb.X[2])) + planeD;
-			const float factorDepth = pm_expf(SQ(dist / depth) * smoothSigmaDepth);
-			// ComputeAngle, Util.inl:544-546
-			const float ca = pm_clampf((normal[0]*nb.normal[0] + normal[1]*nb.normal[1] + normal[2]*nb.normal[2]) /
-				pm_sqrtf((normal[0]*normal[0] + normal[1]*normal[1] + normal[2]*normal[2]) *
-				         (nb.normal[0]*nb.normal[0] + nb.normal[1]*nb.normal[1] + nb.normal[2]*nb.normal[2])), -1.f, 1.f);
-			const float factorNormal = pm_expf(SQ(pm_acosf(ca)) * smoothSigmaNormal);
-			score *= (1.f - smoothBonusDepth * factorDepth) * (1.f - smoothBonusNormal * factorNormal);
-		}
+		for (int k = 0; k < nClose; ++k)
+			score *= SmoothFactor(close[k], depth, normal);
 		// geometric consistency, :535-551
 		if (!image1.depthMap.empty()) {
 			float consistency = 4.f;
@@ -908,6 +910,32 @@ int orc_estimate_depth_map_masked(const OrcView* views, int nViews, float* depth
 	if (rc) return rc;
 	const size_t n = (size_t)views[0].w * views[0].h;
 	memcpy(depth, dd.depthMap.d.data(), n * 4); memcpy(normal, dd.normalMap.d.data(), n * 12); memcpy(conf, dd.confMap.d.data(), n * 4);
+	return 0;
+}
+
+// The small per-pixel helpers of ProcessPixel at pixel (x, y), for the second-reading tests: InterpolatePixel of the neighbour estimate
+// (nx, ny, ndepth, nnormal) to (x, y), CorrectNormal of that normal, and the smoothness factor of the hypothesis plane (hypDepth, hypNormal)
+// with respect to that neighbour.
+int orc_pixel_helpers(const OrcView* views, int nViews, const OrcOpt* opt, int x, int y, float dMin, float dMax, int nx, int ny, float ndepth, const float* nnormal,
+		float hypDepth, const float* hypNormal, float* outInterpDepth, float* outCorrected, float* outSmoothFactor) {
+	orc::DepthData dd; loadDepthData(views, nViews, nullptr, nullptr, dMin, dMax, dd);
+	for (auto& v : dd.images) v.Init(dd.images[0].camera);
+	const int w = views[0].w, h = views[0].h;
+	dd.depthMap.create(w, h); dd.normalMap.create(w, h); dd.confMap.create(w, h);
+	float* nn = dd.normalMap.at(ny, nx); nn[0] = nnormal[0]; nn[1] = nnormal[1]; nn[2] = nnormal[2];
+	orc::Opt o = toOpt(opt);
+	std::vector<orc::Weight> wm((size_t)w * h);
+	std::vector<std::pair<uint16_t,uint16_t>> coords;
+	std::atomic<long> idx(-1);
+	orc::DepthEstimator e(0, dd, idx, wm, coords, o, 0, 0);
+	if (!e.PreparePixelPatch(x, y)) return 1;
+	e.FillPixelPatch();                      // sets X0 (its texture verdict does not matter here)
+	*outInterpDepth = e.InterpolatePixel(nx, ny, ndepth, nnormal);
+	outCorrected[0] = nnormal[0]; outCorrected[1] = nnormal[1]; outCorrected[2] = nnormal[2];
+	e.CorrectNormal(outCorrected);
+	e.nClose = 0; e.addClose(nx, ny, ndepth);
+	e.InitPlane(hypDepth, hypNormal);
+	*outSmoothFactor = e.SmoothFactor(e.close[0], hypDepth, hypNormal);
 	return 0;
 }
 

@@ -133,6 +133,16 @@ def score_pixel(views, n_views, opt: OrcOpt, x, y, depth, normal, prior=None):
     return rc, sc, agg.value
 
 
+def pixel_helpers(views, n_views, opt: OrcOpt, x, y, dmin, dmax, nx, ny, ndepth, nnormal, hyp_depth, hyp_normal):
+    """(InterpolatePixel depth, CorrectNormal(nnormal), smoothness factor of the hypothesis plane w.r.t. the neighbour) at pixel (x, y)."""
+    nn = np.ascontiguousarray(nnormal, np.float32); hn = np.ascontiguousarray(hyp_normal, np.float32)
+    di = C.c_float(0); sf = C.c_float(0); cn = np.zeros(3, np.float32)
+    lib().orc_pixel_helpers.restype = C.c_int
+    rc = lib().orc_pixel_helpers(views, C.c_int(n_views), C.byref(opt), C.c_int(x), C.c_int(y), C.c_float(dmin), C.c_float(dmax), C.c_int(nx), C.c_int(ny),
+                                 C.c_float(ndepth), _fp(nn), C.c_float(hyp_depth), _fp(hn), C.byref(di), _fp(cn), C.byref(sf))
+    return rc, di.value, cn, sf.value
+
+
 def zigzag(w, h, raw_stride=64):
     out = np.zeros((w * h, 2), np.uint16)
     lib().orc_zigzag(C.c_int(w), C.c_int(h), C.c_int(raw_stride), out.ctypes.data_as(C.POINTER(C.c_uint16)))

@@ -180,3 +180,74 @@ def test_geometric_and_prior_terms_two_readings_agree(small_scene):
         assert np.allclose(got, np.array(mine, f32), rtol=0, atol=5e-5), (x, y, got, mine)
         checked += 1
     assert checked > 30
+
+
+# ---- second readings of the small per-pixel helpers of ProcessPixel (DepthMap.cpp:915-971, DepthMap.h:447-453, Rotation.inl:696-728) ----------
+def interpolate_pixel(K, x0, y0, nx, ny, depth, n, dmin, dmax):
+    if x0 == nx:
+        nx1 = f32((float(y0) - K[1, 2]) / K[1, 1]); denom = f32(n[2] + f32(nx1 * n[1]))
+        if abs(denom) < f32(0.0001):
+            return depth
+        x1 = f32((float(ny) - K[1, 2]) / K[1, 1]); nom = f32(depth * f32(n[2] + f32(x1 * n[1])))
+    else:
+        nx1 = f32((float(x0) - K[0, 2]) / K[0, 0]); denom = f32(n[2] + f32(nx1 * n[0]))
+        if abs(denom) < f32(0.0001):
+            return depth
+        x1 = f32((float(nx) - K[0, 2]) / K[0, 0]); nom = f32(depth * f32(n[2] + f32(x1 * n[0])))
+    dn = f32(nom / denom)
+    return dn if (dmin <= dn < dmax) else depth
+
+
+def correct_normal(K, x0, y0, n):
+    v = np.array([(x0 - K[0, 2]) / K[0, 0], (y0 - K[1, 2]) / K[1, 1], 1.0]).astype(f32)
+    c = f32(n.dot(v))
+    if c < 0:
+        return n
+    phi = min(f32(f32(f32(np.arccos(f32(c / f32(np.linalg.norm(v))))) - f32(np.deg2rad(90))) * f32(1.01)), f32(-0.001))
+    axis = np.cross(n, v).astype(f32); axis = (axis * f32(f32(1) / f32(np.linalg.norm(axis)))).astype(f32)
+    O = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]], f32)
+    Rm = (np.eye(3, dtype=f32) + O * f32(np.sin(phi)) + (O @ O) * f32(f32(1) - f32(np.cos(phi)))).astype(f32)
+    return (Rm @ n).astype(f32)
+
+
+def smooth_factor(K, x0, y0, hyp_depth, hyp_n, nx, ny, ndepth, nn, bonus=f32(0.93), sdepth=f32(0.02), snormal_deg=f32(13)):
+    X0 = np.array([(x0 - K[0, 2]) / K[0, 0], (y0 - K[1, 2]) / K[1, 1], 1.0]).astype(f32)
+    D = f32(-hyp_depth * f32(hyp_n.dot(X0)))                                           # InitPlane
+    Xn = np.array([(nx - K[0, 2]) * float(ndepth) / K[0, 0], (ny - K[1, 2]) * float(ndepth) / K[1, 1], float(ndepth)]).astype(f32)   # TransformPointI2C in double
+    dist = f32(f32(hyp_n.dot(Xn)) + D)
+    sd = f32(f32(-1) / f32(f32(2) * f32(sdepth * sdepth))); rn = f32(np.deg2rad(snormal_deg)); sn = f32(f32(-1) / f32(f32(2) * f32(rn * rn)))
+    fd = f32(np.exp(f32(f32(dist / hyp_depth) ** 2) * sd))
+    ca = min(max(f32(f32(hyp_n.dot(nn)) / f32(np.sqrt(f32(f32(hyp_n.dot(hyp_n)) * f32(nn.dot(nn)))))), f32(-1)), f32(1))
+    fn = f32(np.exp(f32(f32(np.arccos(ca)) ** 2) * sn))
+    bd = f32(f32(1) - bonus); bn = f32(bd * f32(0.96))
+    return f32(f32(f32(1) - f32(bd * fd)) * f32(f32(1) - f32(bn * fn)))
+
+
+def test_process_pixel_helpers_two_readings_agree(small_scene):
+    sc = small_scene
+    r = np.random.RandomState(2)
+    ref = 0
+    ids = [ref] + list(sc.neighbors[ref])
+    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+    opt = po.default_opt(seed=1, viewID=ref)
+    K = sc.K[ref]; dmin, dmax = float(sc.dmin[ref]), float(sc.dmax[ref])
+    rotated = 0
+    for _ in range(200):
+        x = int(r.randint(HW + 1, sc.width - HW - 1)); y = int(r.randint(HW + 1, sc.height - HW - 1))
+        nx, ny = [(x - 1, y), (x + 1, y), (x, y - 1), (x, y + 1)][r.randint(4)]
+        ndepth = f32(r.uniform(dmin, dmax))
+        nn = r.randn(3); nn /= np.linalg.norm(nn); nn = nn.astype(f32)          # any unit vector: about half of them face away and get rotated
+        hd = f32(r.uniform(dmin, dmax)); hn = r.randn(3); hn /= np.linalg.norm(hn); hn = hn.astype(f32)
+        rc, di, cn, sf = po.pixel_helpers(views, len(ids), opt, x, y, dmin, dmax, nx, ny, float(ndepth), nn, float(hd), hn)
+        assert rc == 0
+        mine_d = interpolate_pixel(K, x, y, nx, ny, ndepth, nn, f32(dmin), f32(dmax))
+        assert abs(di - mine_d) <= 2e-6 * max(1.0, abs(di)), (x, y, nx, ny, di, mine_d)
+        mine_n = correct_normal(K, x, y, nn)
+        rotated += int(not np.array_equal(mine_n, nn))
+        assert np.abs(cn - mine_n).max() < 3e-6, (cn, mine_n)
+        vd = np.array([(x - K[0, 2]) / K[0, 0], (y - K[1, 2]) / K[1, 1], 1.0])
+        if rotated and not np.array_equal(mine_n, nn):
+            assert mine_n.dot(vd) < 0                                             # after the correction the normal faces the camera
+        mine_s = smooth_factor(K, x, y, hd, hn, nx, ny, ndepth, nn)
+        assert abs(sf - mine_s) < 3e-6, (sf, mine_s)
+    assert 40 < rotated < 160

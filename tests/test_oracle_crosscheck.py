@@ -3,7 +3,6 @@ ComputeHomographyMatrix, ScorePixelImage's photometric term and the MINMEAN aggr
 DepthMap.h:403-423 in /root/reference) -- compared with the C++ oracle's orc_score_pixel.  Two readings of the same text must agree; the only
 tolerated difference is the last bits of exp (numpy's vs the Cephes kernel of pm_math.h)."""
 import numpy as np
-import pytest
 
 from oracle import pyoracle as po
 

@@ -3,7 +3,6 @@
     python tools/probe_fuse.py [views=9] [width=1920] [height=1080] [--oracle]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 from openmvs_amd import synth
 from openmvs_amd.patchmatch import PatchMatchHIP
 from tests import fuse_cases as fc

@@ -54,6 +54,17 @@ int mvsf_select_neighbor_views(const mvsf_scene* s, int idx, const int* sizes, u
 int mvsf_init_depth_map(const mvsf_scene* s, int idx, int w, int h, const uint32_t* points, int nPoints, uint32_t nMinViewsTrustPoint,
                         float* depthMap, float* normalMap, float* dMin, float* dMax);
 
+/* The same with OPTDENSE::bInitSparse = 0 (DepthMap.cpp:1158-1190): every face of the Delaunay mesh rasterised (TImage::RasterizeTriangleBary,
+ * libs/Common/Types.inl:2629-2669) with perspective-correct depth and interpolated vertex normal; pixels outside the mesh stay zero. */
+int mvsf_init_depth_map_dense(const mvsf_scene* s, int idx, int w, int h, const uint32_t* points, int nPoints,
+                              float* depthMap, float* normalMap, float* dMin, float* dMax);
+
+/* The depth-only TriangulatePoints2DepthMap (DepthMap.cpp:1194-1251) that seeds the SGM path (SemiGlobalMatcher.cpp:608-618: corners, dense, at half the
+ * first level's resolution).  addCorners: the four image corners join the mesh at a depth extrapolated from the faces next to them (DepthMap.cpp:1050-1107;
+ * avgDepth is the image's average depth from mvsf_select_neighbor_views), so that the mesh covers the whole image.  dMin / dMax: depth bounds of the points. */
+int mvsf_triangulate_depth_map(const mvsf_scene* s, int idx, int w, int h, const uint32_t* points, int nPoints, int addCorners, float avgDepth, int sparseOnly,
+                               float* depthMap, float* dMin, float* dMax);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <map>
+#include <array>
 
 namespace {
 const uint32_t NO_ID = 0xFFFFFFFFu;
@@ -378,7 +380,118 @@ int mvsf_select_views(const mvsf_scene* s, int idx, const int* sizes, const MVSF
 	return 0;
 }
 
-int mvsf_init_depth_map(const mvsf_scene* s, int idx, int w, int h, const uint32_t* points, int nPoints, uint32_t nMinViewsTrustPoint,
+// TriangulatePointsDelaunay (libs/MVS/DepthMap.cpp:1019-1115): projections, camera-space vertices and the Delaunay faces (stored reversed, :1110) of
+// the sparse points, in a canonical face order (smallest index first -- a rotation keeps the winding -- then sorted; the order only matters for
+// pixels exactly on a shared edge).  withCorners: the four image corners as extra vertices at a depth extrapolated from the nearby faces (:1050-1107).
+struct PointMesh { std::vector<float> proj, vert; std::vector<std::array<int,3>> faces; float zMin = 3.402823466e+38f, zMax = 0.f; };
+static inline void i2c(const PixCam& cam, float x, float y, float d, float* o) {         // TransformPointI2C, Camera.h:338-344
+	o[0] = (float)((x - cam.K[2]) * d / cam.K[0]); o[1] = (float)((y - cam.K[5]) * d / cam.K[4]); o[2] = d;
+}
+static void triangulatePoints(const mvsf_scene& s, const PixCam& cam, const uint32_t* points, int nPoints, bool withCorners, float avgDepth, PointMesh& m) {
+	const int w = cam.w, h = cam.h;
+	std::vector<double> xy((size_t)nPoints * 2);
+	m.proj.resize((size_t)nPoints * 2); m.vert.resize((size_t)nPoints * 3);
+	for (int i = 0; i < nPoints; ++i) {
+		const float* X = &s.X[(size_t)points[i] * 3];
+		const float q0 = (float)(cam.P[0] * X[0] + cam.P[1] * X[1] + cam.P[2] * X[2] + cam.P[3]);
+		const float q1 = (float)(cam.P[4] * X[0] + cam.P[5] * X[1] + cam.P[6] * X[2] + cam.P[7]);
+		const float z = (float)(cam.P[8] * X[0] + cam.P[9] * X[1] + cam.P[10] * X[2] + cam.P[11]);
+		const float x = q0 / z, y = q1 / z;
+		m.proj[2*i] = x; m.proj[2*i+1] = y; xy[2*i] = x; xy[2*i+1] = y;
+		i2c(cam, x, y, z, &m.vert[3*i]);
+		m.zMin = std::min(m.zMin, z); m.zMax = std::max(m.zMax, z);
+	}
+	const bool corners = withCorners && nPoints >= 3;
+	if (corners) {
+		const float cxy[4][2] = {{0.f, 0.f}, {(float)(w - 1), 0.f}, {0.f, (float)(h - 1)}, {(float)(w - 1), (float)(h - 1)}};
+		for (const auto& c : cxy) {
+			m.proj.push_back(c[0]); m.proj.push_back(c[1]); xy.push_back(c[0]); xy.push_back(c[1]);
+			float v[3]; i2c(cam, c[0], c[1], avgDepth, v); m.vert.insert(m.vert.end(), v, v + 3);
+		}
+	}
+	std::vector<Tri> tris; delaunay(xy, tris);
+	m.faces.clear(); m.faces.reserve(tris.size());
+	for (const Tri& t : tris) {
+		std::array<int,3> f = {t.v[2], t.v[1], t.v[0]};
+		const int r = (int)(std::min_element(f.begin(), f.end()) - f.begin());
+		m.faces.push_back({f[r], f[(r+1)%3], f[(r+2)%3]});
+	}
+	std::sort(m.faces.begin(), m.faces.end());
+	if (!corners) return;
+	std::map<std::pair<int,int>, std::vector<int>> edges;                                  // undirected edge -> faces
+	for (int fi = 0; fi < (int)m.faces.size(); ++fi) for (int k = 0; k < 3; ++k) {
+		const int a = m.faces[fi][k], b = m.faces[fi][(k+1)%3];
+		edges[{std::min(a, b), std::max(a, b)}].push_back(fi);
+	}
+	for (int ci = nPoints; ci < nPoints + 4; ++ci) {
+		const double posA[2] = {m.proj[2*ci], m.proj[2*ci+1]};
+		double d[3] = {m.vert[3*ci], m.vert[3*ci+1], m.vert[3*ci+2]};
+		const double dn = sqrt(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]);
+		for (double& v : d) v /= dn;                                                       // Ray3d(0, normalized(vertex))
+		std::vector<std::pair<float,float>> top;                                           // (score, depth)
+		for (int fi = 0; fi < (int)m.faces.size(); ++fi) {
+			const auto& f = m.faces[fi];
+			if (f[0] != ci && f[1] != ci && f[2] != ci) continue;
+			int o[2], no = 0; for (int v : f) if (v != ci) o[no++] = v;
+			const auto& sh = edges[{std::min(o[0], o[1]), std::max(o[0], o[1])}];
+			int nb = -1; for (int g : sh) if (g != fi) { nb = g; break; }
+			if (nb < 0) continue;                                                          // hull edge: the neighbour is the infinite face
+			const auto& fb = m.faces[nb];
+			double p[3][3]; for (int k = 0; k < 3; ++k) for (int c = 0; c < 3; ++c) p[k][c] = m.vert[3*fb[k]+c];
+			const double e1[3] = {p[1][0]-p[0][0], p[1][1]-p[0][1], p[1][2]-p[0][2]}, e2[3] = {p[2][0]-p[0][0], p[2][1]-p[0][1], p[2][2]-p[0][2]};
+			double nr[3] = {e1[1]*e2[2]-e1[2]*e2[1], e1[2]*e2[0]-e1[0]*e2[2], e1[0]*e2[1]-e1[1]*e2[0]};
+			const double nn = sqrt(nr[0]*nr[0] + nr[1]*nr[1] + nr[2]*nr[2]);
+			if (nn == 0) continue;
+			for (double& v : nr) v /= nn;
+			const double Vd = nr[0]*d[0] + nr[1]*d[1] + nr[2]*d[2];
+			const double t = Vd == 0 ? 0.0 : (nr[0]*p[0][0] + nr[1]*p[0][1] + nr[2]*p[0][2]) / Vd;   // TRay::IntersectsDist, libs/Common/Ray.inl:600-610
+			const double zB = d[2] * t;
+			if (zB <= 0) continue;
+			const double bx = ((double)m.proj[2*fb[0]] + m.proj[2*fb[1]] + m.proj[2*fb[2]]) / 3.0, by = ((double)m.proj[2*fb[0]+1] + m.proj[2*fb[1]+1] + m.proj[2*fb[2]+1]) / 3.0;
+			const double dist = sqrt((bx - posA[0]) * (bx - posA[0]) + (by - posA[1]) * (by - posA[1]));
+			top.emplace_back(1.f / (float)dist, std::min(std::max((float)zB, m.zMin), m.zMax));
+		}
+		std::stable_sort(top.begin(), top.end(), [](const std::pair<float,float>& a, const std::pair<float,float>& b) { return a.first > b.first; });
+		if (top.size() > 3) top.resize(3);
+		if (top.empty()) continue;                                                         // (the reference asserts three)
+		float sum = 0.f; for (const auto& e : top) sum += e.first;
+		const float inv = 1.f / sum;
+		float depth = 0.f; for (const auto& e : top) depth += (e.first * inv) * e.second;
+		i2c(cam, m.proj[2*ci], m.proj[2*ci+1], depth, &m.vert[3*ci]);
+	}
+}
+
+// One face of the dense initialisation: TImage::RasterizeTriangleBary (libs/Common/Types.inl:2629-2669) driving the RasterDepth functor of
+// TriangulatePoints2DepthMap (libs/MVS/DepthMap.cpp:1159-1187): perspective-correct barycentric depth and normal at every covered pixel centre.
+static inline float edgeFn(const float* a, const float* b, const float* c) { return (c[0] - a[0]) * (b[1] - a[1]) - (c[1] - a[1]) * (b[0] - a[0]); }   // Util.inl:602-604
+static void rasterFace(const float* v1, const float* v2, const float* v3, float z0, float z1, float z2, const float* n0, const float* n1, const float* n2,
+		int w, int h, float* depthMap, float* normalMap) {
+	const float mnx = std::min(v1[0], std::min(v2[0], v3[0])), mxx = std::max(v1[0], std::max(v2[0], v3[0]));
+	const float mny = std::min(v1[1], std::min(v2[1], v3[1])), mxy = std::max(v1[1], std::max(v2[1], v3[1]));
+	if (mxx < 0 || mnx > (float)(w - 1) || mxy < 0 || mny > (float)(h - 1)) return;
+	const int x0 = std::max((int)floorf(mnx), 0), x1 = std::min((int)ceilf(mxx), w - 1), y0 = std::max((int)floorf(mny), 0), y1 = std::min((int)ceilf(mxy), h - 1);
+	const float area = edgeFn(v1, v2, v3);
+	if (area <= 0) return;
+	const float inv = 1.f / area;
+	for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) {
+		const float p[2] = {(float)x, (float)y};
+		const float b1 = edgeFn(v2, v3, p) * inv; if (b1 < 0) continue;
+		const float b2 = edgeFn(v3, v1, p) * inv; if (b2 < 0) continue;
+		const float b3 = edgeFn(v1, v2, p) * inv; if (b3 < 0) continue;
+		float pb[3] = {b1 * z1 * z2, b2 * z0 * z2, b3 * z0 * z1};                          // PerspectiveCorrectBarycentricCoordinates, Util.inl:746-749
+		const float invd = 1.f / (pb[0] + pb[1] + pb[2]);
+		for (float& v : pb) v = invd * v;
+		depthMap[(size_t)y * w + x] = pb[0] * z0 + pb[1] * z1 + pb[2] * z2;
+		if (!normalMap) continue;
+		float n[3];
+		for (int k = 0; k < 3; ++k) n[k] = n0[k] * pb[0] + n1[k] * pb[1] + n2[k] * pb[2];
+		const double nn = sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
+		const double in = nn ? 1.0 / nn : 0.0;
+		for (int k = 0; k < 3; ++k) normalMap[((size_t)y * w + x) * 3 + k] = (float)(n[k] * in);
+	}
+}
+
+static int initDepthMap(const mvsf_scene* s, int idx, int w, int h, const uint32_t* points, int nPoints, uint32_t nMinViewsTrustPoint, bool dense,
 		float* depthMap, float* normalMap, float* dMin, float* dMax) {
 	if (!s || idx < 0 || idx >= (int)s->images.size() || !depthMap || !normalMap || !dMin || !dMax || nPoints < 0 || (nPoints && !points)) return -1;
 	PixCam cam;
@@ -402,31 +515,30 @@ int mvsf_init_depth_map(const mvsf_scene* s, int idx, int w, int h, const uint32
 		*dMin = mn * 0.9f; *dMax = mx * 1.1f;
 		return 0;
 	}
-	// TriangulatePoints2DepthMap with bInitSparse, DepthMap.cpp:1117-1157
-	std::vector<double> xy((size_t)nPoints * 2); std::vector<float> proj((size_t)nPoints * 2), vert((size_t)nPoints * 3);
-	for (int i = 0; i < nPoints; ++i) {
-		const float* X = &s->X[(size_t)points[i] * 3];
-		const float q0 = (float)(cam.P[0] * X[0] + cam.P[1] * X[1] + cam.P[2] * X[2] + cam.P[3]);
-		const float q1 = (float)(cam.P[4] * X[0] + cam.P[5] * X[1] + cam.P[6] * X[2] + cam.P[7]);
-		const float z = (float)(cam.P[8] * X[0] + cam.P[9] * X[1] + cam.P[10] * X[2] + cam.P[11]);
-		const float x = q0 / z, y = q1 / z;
-		proj[2*i] = x; proj[2*i+1] = y; xy[2*i] = x; xy[2*i+1] = y;
-		vert[3*i] = (float)((x - cam.K[2]) * z / cam.K[0]); vert[3*i+1] = (float)((y - cam.K[5]) * z / cam.K[4]); vert[3*i+2] = z;   // TransformPointI2C, Camera.h:338-344
-		mn = std::min(mn, z); mx = std::max(mx, z);
-	}
+	// TriangulatePoints2DepthMap, DepthMap.cpp:1117-1192
+	PointMesh m;
+	triangulatePoints(*s, cam, points, nPoints, false, 0.f, m);
+	const std::vector<float>& proj = m.proj; const std::vector<float>& vert = m.vert;
 	std::vector<float> nrm((size_t)nPoints * 3, 0.f);
-	std::vector<Tri> tris; delaunay(xy, tris);
-	for (const Tri& t : tris) {                                                           // faces are stored reversed (DepthMap.cpp:1110); Mesh::ComputeNormalVertices, Mesh.cpp:356-371
-		const int f0 = t.v[2], f1 = t.v[1], f2 = t.v[0];
+	for (const auto& f : m.faces) {                                                       // Mesh::ComputeNormalVertices, Mesh.cpp:356-371
+		const int f0 = f[0], f1 = f[1], f2 = f[2];
 		const float a[3] = {vert[3*f1] - vert[3*f0], vert[3*f1+1] - vert[3*f0+1], vert[3*f1+2] - vert[3*f0+2]};
 		const float b[3] = {vert[3*f2] - vert[3*f0], vert[3*f2+1] - vert[3*f0+1], vert[3*f2+2] - vert[3*f0+2]};
 		const float c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
-		for (int f : {f0, f1, f2}) for (int k = 0; k < 3; ++k) nrm[3*f+k] += c[k];
+		for (int v : {f0, f1, f2}) for (int k = 0; k < 3; ++k) nrm[3*v+k] += c[k];
 	}
 	for (int i = 0; i < nPoints; ++i) {
 		const double nn = sqrt((double)nrm[3*i] * nrm[3*i] + (double)nrm[3*i+1] * nrm[3*i+1] + (double)nrm[3*i+2] * nrm[3*i+2]);
 		const double inv = nn ? 1.0 / nn : 0.0;
 		for (int k = 0; k < 3; ++k) nrm[3*i+k] = (float)(nrm[3*i+k] * inv);
+	}
+	*dMin = m.zMin * 0.9f; *dMax = m.zMax * 1.1f;
+	if (dense) {                                                                          // DepthMap.cpp:1158-1190
+		for (const auto& f : m.faces) rasterFace(&proj[2*f[0]], &proj[2*f[1]], &proj[2*f[2]], vert[3*f[0]+2], vert[3*f[1]+2], vert[3*f[2]+2],
+		                                         &nrm[3*f[0]], &nrm[3*f[1]], &nrm[3*f[2]], w, h, depthMap, normalMap);
+		return 0;
+	}
+	for (int i = 0; i < nPoints; ++i) {
 		const int ix = (int)floorf(proj[2*i]), iy = (int)floorf(proj[2*i+1]);
 		for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx) {                   // (0,0),(1,0),(0,1),(1,1): the same 4 pixels whatever the order
 			const int ax = ix + dx, ay = iy + dy;
@@ -435,8 +547,42 @@ int mvsf_init_depth_map(const mvsf_scene* s, int idx, int w, int h, const uint32
 			for (int k = 0; k < 3; ++k) normalMap[((size_t)ay * w + ax) * 3 + k] = nrm[3*i+k];
 		}
 	}
-	*dMin = mn * 0.9f; *dMax = mx * 1.1f;
 	return 0;
+}
+
+int mvsf_init_depth_map(const mvsf_scene* s, int idx, int w, int h, const uint32_t* points, int nPoints, uint32_t nMinViewsTrustPoint,
+		float* depthMap, float* normalMap, float* dMin, float* dMax) {
+	return initDepthMap(s, idx, w, h, points, nPoints, nMinViewsTrustPoint, false, depthMap, normalMap, dMin, dMax);
+}
+int mvsf_triangulate_depth_map(const mvsf_scene* s, int idx, int w, int h, const uint32_t* points, int nPoints, int addCorners, float avgDepth, int sparseOnly,
+		float* depthMap, float* dMin, float* dMax) {
+	if (!s || idx < 0 || idx >= (int)s->images.size() || !depthMap || !dMin || !dMax || nPoints < 0 || (nPoints && !points)) return -1;
+	PixCam cam;
+	if (!pixelCamera(*s, idx, w, h, cam)) return -3;
+	w = cam.w; h = cam.h;
+	const int nAll = mvsf_num_points(s);
+	for (int i = 0; i < nPoints; ++i) if ((int)points[i] >= nAll) return -1;
+	memset(depthMap, 0, sizeof(float) * (size_t)w * h);
+	PointMesh m;
+	triangulatePoints(*s, cam, points, nPoints, addCorners != 0, avgDepth, m);
+	*dMin = m.zMin; *dMax = m.zMax;
+	if (sparseOnly) {
+		for (size_t i = 0; i < m.vert.size() / 3; ++i) {
+			const int ix = (int)floorf(m.proj[2*i]), iy = (int)floorf(m.proj[2*i+1]);
+			for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx) {
+				const int ax = ix + dx, ay = iy + dy;
+				if (ax >= 0 && ay >= 0 && ax < w && ay < h) depthMap[(size_t)ay * w + ax] = m.vert[3*i+2];
+			}
+		}
+		return 0;
+	}
+	for (const auto& f : m.faces) rasterFace(&m.proj[2*f[0]], &m.proj[2*f[1]], &m.proj[2*f[2]], m.vert[3*f[0]+2], m.vert[3*f[1]+2], m.vert[3*f[2]+2],
+	                                         nullptr, nullptr, nullptr, w, h, depthMap, nullptr);
+	return 0;
+}
+int mvsf_init_depth_map_dense(const mvsf_scene* s, int idx, int w, int h, const uint32_t* points, int nPoints,
+		float* depthMap, float* normalMap, float* dMin, float* dMax) {
+	return initDepthMap(s, idx, w, h, points, nPoints, 2, true, depthMap, normalMap, dMin, dMax);
 }
 
 } // extern "C"

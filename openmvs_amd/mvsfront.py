@@ -10,7 +10,7 @@ from . import build as _build
 
 VIEW_SCORE_DTYPE = np.dtype([("ID", "<u4"), ("points", "<u4"), ("scale", "<f4"), ("angle", "<f4"), ("area", "<f4"), ("score", "<f4")])
 EXPORTS = ["mvsf_default_options", "mvsf_load", "mvsf_free", "mvsf_version", "mvsf_num_images", "mvsf_num_points", "mvsf_image_info", "mvsf_point",
-           "mvsf_camera", "mvsf_select_views", "mvsf_select_neighbor_views", "mvsf_init_depth_map"]
+           "mvsf_camera", "mvsf_select_views", "mvsf_select_neighbor_views", "mvsf_init_depth_map", "mvsf_init_depth_map_dense", "mvsf_triangulate_depth_map"]
 
 
 class MVSFOptions(C.Structure):
@@ -97,12 +97,27 @@ class SceneFront:
             return None
         return nb[:nn.value].copy(), pts[:npts.value].copy(), float(avg.value)
 
-    def init_depth_map(self, i, points, size, nMinViewsTrustPoint=2):
+    def init_depth_map(self, i, points, size, nMinViewsTrustPoint=2, dense=False):
+        """dense: OPTDENSE::bInitSparse = 0 (rasterised triangles instead of 2x2 splats)."""
         w, h = size
         d = np.zeros((h, w), np.float32); n = np.zeros((h, w, 3), np.float32); dmin = C.c_float(); dmax = C.c_float()
         p = np.ascontiguousarray(points, np.uint32)
-        rc = self._lib.mvsf_init_depth_map(self._h, i, w, h, p.ctypes.data_as(C.POINTER(C.c_uint32)), len(p), nMinViewsTrustPoint,
-                                           d.ctypes.data_as(C.POINTER(C.c_float)), n.ctypes.data_as(C.POINTER(C.c_float)), C.byref(dmin), C.byref(dmax))
+        out = (d.ctypes.data_as(C.POINTER(C.c_float)), n.ctypes.data_as(C.POINTER(C.c_float)), C.byref(dmin), C.byref(dmax))
+        if dense:
+            rc = self._lib.mvsf_init_depth_map_dense(self._h, i, w, h, p.ctypes.data_as(C.POINTER(C.c_uint32)), len(p), *out)
+        else:
+            rc = self._lib.mvsf_init_depth_map(self._h, i, w, h, p.ctypes.data_as(C.POINTER(C.c_uint32)), len(p), nMinViewsTrustPoint, *out)
         if rc != 0:
             raise ValueError("mvsf_init_depth_map failed: %d" % rc)
         return d, n, float(dmin.value), float(dmax.value)
+
+    def triangulate_depth_map(self, i, points, size, avg_depth=None, sparse=False):
+        """mvsf_triangulate_depth_map: avg_depth not None = with the image corners.  -> (depthMap, dMin, dMax)."""
+        w, h = size
+        d = np.zeros((h, w), np.float32); dmin = C.c_float(); dmax = C.c_float()
+        p = np.ascontiguousarray(points, np.uint32)
+        rc = self._lib.mvsf_triangulate_depth_map(self._h, i, w, h, p.ctypes.data_as(C.POINTER(C.c_uint32)), len(p), int(avg_depth is not None),
+                                                  C.c_float(avg_depth or 0.0), int(sparse), d.ctypes.data_as(C.POINTER(C.c_float)), C.byref(dmin), C.byref(dmax))
+        if rc != 0:
+            raise ValueError("mvsf_triangulate_depth_map failed: %d" % rc)
+        return d, float(dmin.value), float(dmax.value)

@@ -100,3 +100,12 @@ def stereo_rectify_images(img1, K1, R1w, C1, img2, K2, R2w, C2, points1, points2
     Q[0, 0] = Q[1, 1] = 1; Q[0, 3] = -K1r[0, 2]; Q[1, 3] = -K1r[1, 2]; Q[2, 3] = K1r[0, 0]; Q[3, 2] = -1.0 / t; Q[3, 3] = (K1r[0, 2] - K2r[0, 2]) / t
     P = np.eye(4); P[:3, :3] = np.asarray(K1, np.float64) @ R1.T       # ... then into the original image 1 (:339-342)
     return dict(rect1=rect1, rect2=rect2, mask1=mask1, mask2=mask2, H=H1, Q=P @ Q, size=size, t=t, K1=K1r, K2=K2r, R1=R1, R2=R2)
+
+
+def scale_stereo_rectification(H, Q, scale):
+    """Image::ScaleStereoRectification (libs/MVS/Image.cpp:349-364): H and Q of the same pair with both images resized by `scale`."""
+    S = np.diag([scale, scale, 1.0])
+    H2 = S @ np.asarray(H, np.float64) @ np.linalg.inv(S)
+    Sinv = np.diag([1.0 / scale, 1.0 / scale, 1.0 / scale, 1.0])
+    S4 = np.diag([scale * scale, scale * scale, scale, scale])
+    return H2, S4 @ np.asarray(Q, np.float64) @ Sinv

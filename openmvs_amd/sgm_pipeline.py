@@ -10,11 +10,31 @@ import numpy as np
 from . import rectify, tsgm
 
 
+_SRGB = None
+
+
+def _srgb_table():
+    """g_ptrsRGB82RGBf (libs/Common/Types.inl:1595-1607): sRGB2RGB(i / 255.f) in float, with the C library's powf as the reference uses."""
+    global _SRGB
+    if _SRGB is None:
+        import ctypes, ctypes.util
+        libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        libm.powf.restype = ctypes.c_float; libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+        f = np.float32
+        t = np.zeros(256, f)
+        for i in range(256):
+            x = f(i) / f(255)
+            t[i] = x * (f(1) / f(12.92)) if x <= f(0.04045) else f(libm.powf(f((x + f(0.055)) * (f(1) / f(1.055))), f(2.4)))
+        _SRGB = t
+    return _SRGB
+
+
 def to_gray_linear(bgr):
-    """0.114 B + 0.587 G + 0.299 R of the normalised channels.  (The reference converts with bSRGB = true for this path,
-    libs/MVS/SemiGlobalMatcher.cpp:571-576: an sRGB -> linear transfer before the weighted sum; not applied here.)"""
+    """`imageColor.toGray(imageGray, COLOR_BGR2GRAY, bNormalize = true, bSRGB = true)` of the SGM path (libs/MVS/SemiGlobalMatcher.cpp:579-582;
+    TImage::toGray, libs/Common/Types.inl:2377-2425): every 8-bit channel through the sRGB -> linear table, then 0.114 B + 0.587 G + 0.299 R."""
     f = np.float32
-    return (f(0.114) * (bgr[..., 0].astype(f) / f(255)) + f(0.587) * (bgr[..., 1].astype(f) / f(255))) + f(0.299) * (bgr[..., 2].astype(f) / f(255))
+    t = _srgb_table()
+    return (f(0.114) * t[bgr[..., 0]] + f(0.587) * t[bgr[..., 1]]) + f(0.299) * t[bgr[..., 2]]
 
 
 def world_to_image3(K, R, C, X):
@@ -23,9 +43,19 @@ def world_to_image3(K, R, C, X):
     return np.stack([K[0, 2] + K[0, 0] * cx[:, 0] / cx[:, 2], K[1, 2] + K[1, 1] * cx[:, 1] / cx[:, 2], cx[:, 2]], 1).astype(np.float32)
 
 
-def match_pair(be, bgrA, camA, bgrB, camB, shared_points, min_resolution=320, subpixel_steps=4):
+def compute_resize(size, scale):
+    """Image8U::computeResize(size, scale) (libs/Common/Types.inl:2446-2449): cvRound of the scaled extents."""
+    return int(np.rint(size[0] * scale)), int(np.rint(size[1] * scale))
+
+
+def match_pair(be, bgrA, camA, bgrB, camB, shared_points, min_resolution=320, subpixel_steps=4, seed_depth=None):
     """One pair of `Match(scene, ...)`: cam = (K, R, C).  Returns the `.dimap` content: dict(disparity, cost, H, Q, image_size, subpixel_steps)
-    or None if the pair cannot be rectified."""
+    or None if the pair cannot be rectified.
+
+    seed_depth: callable (w, h) -> depth map of image A at that size, the rough estimate from the sparse points that the reference makes with
+    `TriangulatePoints2DepthMap(..., bAddCorners = true)` (SemiGlobalMatcher.cpp:608-618; `views.triangulate_points_depth_map` or
+    `mvsf_triangulate_depth_map`); it becomes the first level's initial disparities through Depth2DisparityMap (`:619-625`).  Without it the
+    first level searches the default range around zero."""
     p1 = world_to_image3(*camA, shared_points); p2 = world_to_image3(*camB, shared_points)
     r = rectify.stereo_rectify_images(bgrA, *camA, bgrB, *camB, p1, p2)
     if r is None:
@@ -34,9 +64,16 @@ def match_pair(be, bgrA, camA, bgrB, camB, shared_points, min_resolution=320, su
     f = 1 << k
     w, h = r["size"][0] // f * f, r["size"][1] // f * f           # the loop's 8-bit resampler wants multiples of 2^levels: crop right / bottom
     lb, rb = r["rect1"][:h, :w].copy(), r["rect2"][:h, :w].copy()
+    init = None
+    if seed_depth is not None:
+        s = 0.5 / f                                               # scale * 0.5
+        depth = seed_depth(*compute_resize((bgrA.shape[1], bgrA.shape[0]), s))
+        H2, Q2 = rectify.scale_stereo_rectification(r["H"], r["Q"], s)
+        hw, hh = compute_resize((w // f, h // f), 0.5)
+        init = be.Depth2DisparityMap(depth, np.linalg.inv(H2), np.linalg.inv(Q2), 1, (hw - 2 * tsgm.HW, hh - 2 * tsgm.HW))
     disp, cost, _ = tsgm.tsgm_match(be, lb, to_gray_linear(lb), rb, to_gray_linear(rb), r["mask1"][:h, :w].copy(), r["mask2"][:h, :w].copy(),
-                                    min_resolution=min_resolution, subpixel_steps=subpixel_steps)
-    return dict(disparity=disp, cost=cost, H=r["H"], Q=r["Q"], image_size=(bgrA.shape[1], bgrA.shape[0]), subpixel_steps=subpixel_steps)
+                                    min_resolution=min_resolution, init_left_disparity=init, subpixel_steps=subpixel_steps)
+    return dict(disparity=disp, cost=cost, H=r["H"], Q=r["Q"], image_size=(bgrA.shape[1], bgrA.shape[0]), subpixel_steps=subpixel_steps, seeded=init is not None)
 
 
 def fuse_pairs(be, pairs, min_views=2):

@@ -235,7 +235,7 @@ def select_views(scene: mvsi.Scene, cams: Cameras, ID: int, opt: DenseOptions = 
     return nb, points, avg
 
 
-def init_depth_map(scene: mvsi.Scene, cams: Cameras, ID: int, points: np.ndarray, opt: DenseOptions = DenseOptions()):
+def init_depth_map(scene: mvsi.Scene, cams: Cameras, ID: int, points: np.ndarray, opt: DenseOptions = DenseOptions(), avg_depth=None):
     """The `loadDepthMaps == 0` branch of `DepthMapsData::InitViews` (libs/MVS/SceneDensify.cpp:418-460).
 
     Returns (depthMap, normalMap, dMin, dMax).  Three cases, as in the reference:
@@ -245,7 +245,8 @@ def init_depth_map(scene: mvsi.Scene, cams: Cameras, ID: int, points: np.ndarray
         its projection with the area-weighted vertex normal of the Delaunay mesh of the projections (`Mesh::ComputeNormalVertices`,
         libs/MVS/Mesh.cpp:356-371).  The reference triangulates with CGAL; scipy's Qhull Delaunay gives the same triangulation except
         for co-circular point sets, so normals may differ at such vertices (the estimator treats them as initial guesses only).
-    The dense interpolation mode (`bInitSparse=0`, rasterising the triangles) and `bAddCorners` are not implemented."""
+    With `bInitSparse=0` the faces of that mesh are rasterised instead (DepthMap.cpp:1158-1190, `_raster_face`).  `bAddCorners` (the SGM path's
+    variant with the image corners as extra support points) is not implemented."""
     w, h = (int(v) for v in cams.size[ID])
     depthMap = np.zeros((h, w), f32)
     normalMap = np.zeros((h, w, 3), f32)
@@ -263,31 +264,156 @@ def init_depth_map(scene: mvsi.Scene, cams: Cameras, ID: int, points: np.ndarray
             if y1 >= y0 and x1 >= x0:                                    # (a projection outside the image splats nothing)
                 depthMap[y0:y1 + 1, x0:x1 + 1] = z
         return depthMap, normalMap, float(d.min() * f32(0.9)), float(d.max() * f32(1.1))
-    if not opt.bInitSparse or opt.bAddCorners:
-        raise NotImplementedError("only the reference's default bInitSparse=1, bAddCorners=0 initialisation is implemented")
-    q = (X.astype(np.float64) @ cams.P[ID, :, :3].T + cams.P[ID, :, 3]).astype(f32)        # ProjectPointP3<float>
-    z = q[:, 2]
-    proj = np.stack([q[:, 0] / z, q[:, 1] / z], 1)
-    vert = np.stack([((proj[:, 0] - K[0, 2]) * z / K[0, 0]).astype(f32), ((proj[:, 1] - K[1, 2]) * z / K[1, 1]).astype(f32), z], 1)
+    if opt.bAddCorners and avg_depth is None:
+        raise ValueError("bAddCorners needs the image's average depth (select_neighbor_views returns it)")
+    proj, z, vert, faces = triangulate_points(K, cams.P[ID], X, w, h, avg_depth if opt.bAddCorners else None)
     normals = np.zeros_like(vert)
-    if len(points) >= 3:
-        from scipy.spatial import Delaunay
-        tri = Delaunay(proj.astype(np.float64)).simplices
-        a, b, c = proj[tri[:, 0]], proj[tri[:, 1]], proj[tri[:, 2]]
-        ccw = ((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])) > 0
-        tri = np.where(ccw[:, None], tri, tri[:, ::-1])                 # CGAL faces are counter-clockwise ...
-        f0, f1, f2 = tri[:, 2], tri[:, 1], tri[:, 0]                    # ... and the mesh stores them reversed (DepthMap.cpp:1110)
-        t = np.cross(vert[f1] - vert[f0], vert[f2] - vert[f0]).astype(f32)
+    if len(faces):
+        f0, f1, f2 = faces[:, 0], faces[:, 1], faces[:, 2]
+        t = np.cross(vert[f1] - vert[f0], vert[f2] - vert[f0]).astype(f32)               # Mesh::ComputeNormalVertices, Mesh.cpp:356-371
         for f in (f0, f1, f2):
             np.add.at(normals, f, t)
         nrm = np.sqrt((normals.astype(np.float64) ** 2).sum(1))
         inv = np.where(nrm > 0, 1.0 / np.maximum(nrm, 1e-300), 0.0)          # cv::normalize: v * (1/|v|), the norm in double
         normals = (normals.astype(np.float64) * inv[:, None]).astype(f32)
+    dMin, dMax = float(z.min() * f32(0.9)), float(z.max() * f32(1.1))            # the corners do not count (depthBounds, DepthMap.cpp:1043-1046)
+    if not opt.bInitSparse:
+        if not len(faces):                                                                 # no face: nothing is rasterised
+            return depthMap, normalMap, dMin, dMax
+        # dense interpolation, DepthMap.cpp:1158-1190: rasterise every mesh face (TImage::RasterizeTriangleBary, libs/Common/Types.inl:2629-2669) with
+        # perspective-correct barycentric depth and normal.  Faces in a canonical order (the reference's is CGAL's; only pixels exactly on a shared edge see it).
+        for fa in faces:
+            _raster_face(proj[fa], vert[fa, 2], normals[fa], depthMap, normalMap)
+        return depthMap, normalMap, dMin, dMax
     ix = np.floor(proj).astype(np.int64)
-    for (x, y), zz, n in zip(ix, z, normals):
+    for (x, y), zz, n in zip(ix, vert[:, 2], normals):
         for dx, dy in ((0, 0), (1, 0), (0, 1), (1, 1)):
             ax, ay = x + dx, y + dy
             if 0 <= ax < w and 0 <= ay < h:
                 depthMap[ay, ax] = zz
                 normalMap[ay, ax] = n
-    return depthMap, normalMap, float(z.min() * f32(0.9)), float(z.max() * f32(1.1))
+    return depthMap, normalMap, dMin, dMax
+
+
+def triangulate_points(K, P, X, w, h, avg_depth=None):
+    """`TriangulatePointsDelaunay` (libs/MVS/DepthMap.cpp:1019-1115): the 2-D Delaunay mesh of the projections of the sparse points `X`.
+
+    -> (proj (n,2) f32, z (n_points,) f32 depths of the points, vert (n,3) f32 camera-space vertices, faces (m,3) in a canonical order).
+    With `avg_depth` (the reference's bAddCorners) the four image corners are appended as vertices, each at the depth where its viewing ray meets
+    the planes of the (up to 3, nearest first) faces across the edges opposite to it, weighted by inverse distance (`:1050-1107`).
+    The reference triangulates with CGAL; Qhull gives the same triangulation except for co-circular point sets."""
+    q = (np.asarray(X, np.float64) @ P[:, :3].T + P[:, 3]).astype(f32)                   # ProjectPointP3<float>
+    z = q[:, 2]
+    proj = np.stack([q[:, 0] / z, q[:, 1] / z], 1)
+    i2c = lambda x, y, d: np.array([f32((x - K[0, 2]) * d / K[0, 0]), f32((y - K[1, 2]) * d / K[1, 1]), f32(d)], f32)   # TransformPointI2C, Camera.h:338-344
+    vert = np.stack([((proj[:, 0] - K[0, 2]) * z / K[0, 0]).astype(f32), ((proj[:, 1] - K[1, 2]) * z / K[1, 1]).astype(f32), z], 1)
+    n = len(z)
+    corners = avg_depth is not None and n >= 3
+    if corners:
+        cxy = np.array([(0, 0), (w - 1, 0), (0, h - 1), (w - 1, h - 1)], f32)
+        proj = np.concatenate([proj, cxy]); vert = np.concatenate([vert, np.stack([i2c(x, y, f32(avg_depth)) for x, y in cxy])])
+    if len(proj) < 3:
+        return proj, z, vert, np.zeros((0, 3), np.int64)
+    from scipy.spatial import Delaunay
+    tri = Delaunay(proj.astype(np.float64)).simplices.astype(np.int64)
+    a, b, c = proj[tri[:, 0]].astype(np.float64), proj[tri[:, 1]].astype(np.float64), proj[tri[:, 2]].astype(np.float64)
+    ccw = ((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])) > 0
+    tri = np.where(ccw[:, None], tri, tri[:, ::-1])                 # CGAL faces are counter-clockwise ...
+    faces = tri[:, ::-1]                                            # ... and the mesh stores them reversed (DepthMap.cpp:1110)
+    rot = np.argmin(faces, 1)                                       # canonical order: smallest index first (keeps the winding), then sorted
+    faces = np.stack([faces[np.arange(len(faces)), (rot + k) % 3] for k in range(3)], 1)
+    faces = faces[np.lexsort((faces[:, 2], faces[:, 1], faces[:, 0]))]
+    if corners:
+        lo, hi = z.min(), z.max()
+        edges = {}
+        for fi, fa in enumerate(faces):
+            for k in range(3):
+                edges.setdefault(frozenset((int(fa[k]), int(fa[(k + 1) % 3]))), []).append(fi)
+        for ci in range(n, n + 4):
+            posA = proj[ci].astype(np.float64)
+            d = vert[ci].astype(np.float64); d = d / np.linalg.norm(d)                       # Ray3d(0, normalized(vertex))
+            top = []                                                                           # (score, depth), best three
+            for fi in np.nonzero((faces == ci).any(1))[0]:
+                opp = frozenset(int(v) for v in faces[fi] if v != ci)
+                nbs = [g for g in edges[opp] if g != fi]
+                if not nbs:                                                                    # hull edge: the neighbour is the infinite face
+                    continue
+                fb = faces[nbs[0]]
+                p0, p1, p2 = vert[fb].astype(np.float64)
+                nrm = np.cross(p1 - p0, p2 - p0); nn = np.linalg.norm(nrm)
+                if nn == 0:
+                    continue
+                nrm = nrm / nn
+                Vd = nrm @ d
+                t = 0.0 if Vd == 0 else (nrm @ p0) / Vd                                        # TRay::IntersectsDist, libs/Common/Ray.inl:600-610
+                zB = d[2] * t
+                if zB <= 0:
+                    continue
+                posB = (proj[fb[0]].astype(np.float64) + proj[fb[1]].astype(np.float64) + proj[fb[2]].astype(np.float64)) / 3.0
+                dist = np.linalg.norm(posB - posA)
+                top.append((f32(1.0) / f32(dist), min(max(f32(zB), lo), hi)))
+            top.sort(key=lambda e: -e[0]); top = top[:3]
+            if top:                                                 # (the reference asserts three; fewer can only happen in degenerate meshes)
+                sc = np.array([e[0] for e in top], f32); dp = np.array([e[1] for e in top], f32)
+                sc = sc * (f32(1) / sc.sum(dtype=f32))
+                depth = f32(0)
+                for s_, d_ in zip(sc, dp):
+                    depth = f32(depth + f32(s_ * d_))
+                vert[ci] = i2c(proj[ci, 0], proj[ci, 1], depth)
+    return proj, z, vert, faces
+
+
+def triangulate_points_depth_map(K, P, X, w, h, avg_depth=None, sparse=False):
+    """The depth-only `TriangulatePoints2DepthMap` (libs/MVS/DepthMap.cpp:1194-1251) that seeds the SGM path (SemiGlobalMatcher.cpp:608-618 calls
+    it with corners, dense).  -> (depthMap, dMin, dMax): dMin/dMax the depth bounds of the points themselves."""
+    proj, z, vert, faces = triangulate_points(K, P, X, w, h, avg_depth)
+    depthMap = np.zeros((h, w), f32)
+    if sparse:
+        ix = np.floor(proj).astype(np.int64)
+        for (x, y), zz in zip(ix, vert[:, 2]):
+            for dx, dy in ((0, 0), (1, 0), (0, 1), (1, 1)):
+                if 0 <= x + dx < w and 0 <= y + dy < h:
+                    depthMap[y + dy, x + dx] = zz
+    else:
+        for fa in faces:
+            _raster_face(proj[fa], vert[fa, 2], None, depthMap, None)
+    return depthMap, (float(z.min()) if len(z) else 3.4028234663852886e+38), (float(z.max()) if len(z) else 0.0)
+
+
+def _raster_face(v, zs, ns, depthMap, normalMap):
+    """One face of the dense initialisation: RasterizeTriangleBary + the RasterDepth functor of TriangulatePoints2DepthMap (DepthMap.cpp:1159-1187)."""
+    h, w = depthMap.shape
+    v1, v2, v3 = v
+    mnx, mxx = min(v1[0], v2[0], v3[0]), max(v1[0], v2[0], v3[0]); mny, mxy = min(v1[1], v2[1], v3[1]), max(v1[1], v2[1], v3[1])
+    if mxx < 0 or mnx > f32(w - 1) or mxy < 0 or mny > f32(h - 1):
+        return
+    x0, x1 = max(int(np.floor(mnx)), 0), min(int(np.ceil(mxx)), w - 1)
+    y0, y1 = max(int(np.floor(mny)), 0), min(int(np.ceil(mxy)), h - 1)
+    edge = lambda a, b, c: f32(f32(f32(c[0] - a[0]) * f32(b[1] - a[1])) - f32(f32(c[1] - a[1]) * f32(b[0] - a[0])))     # (x2-x0).cross(x1-x0), Util.inl:602-604
+    area = edge(v1, v2, v3)
+    if area <= 0:
+        return
+    inv = f32(f32(1) / area)
+    z0, z1, z2 = zs
+    for y in range(y0, y1 + 1):
+        for x in range(x0, x1 + 1):
+            p = (f32(x), f32(y))
+            b1 = f32(edge(v2, v3, p) * inv)
+            if b1 < 0:
+                continue
+            b2 = f32(edge(v3, v1, p) * inv)
+            if b2 < 0:
+                continue
+            b3 = f32(edge(v1, v2, p) * inv)
+            if b3 < 0:
+                continue
+            pb = (f32(f32(b1 * z1) * z2), f32(f32(b2 * z0) * z2), f32(f32(b3 * z0) * z1))                # PerspectiveCorrectBarycentricCoordinates, Util.inl:746-749
+            sden = f32(f32(pb[0] + pb[1]) + pb[2]); invd = f32(f32(1) / sden)                                  # TPoint3 / scalar multiplies by the reciprocal
+            pb = (f32(invd * pb[0]), f32(invd * pb[1]), f32(invd * pb[2]))
+            depthMap[y, x] = f32(f32(f32(pb[0] * z0) + f32(pb[1] * z1)) + f32(pb[2] * z2))
+            if ns is None:
+                continue
+            n = (ns[0] * pb[0]).astype(f32) + (ns[1] * pb[1]).astype(f32)
+            n = (n.astype(f32) + (ns[2] * pb[2]).astype(f32)).astype(f32)
+            nn = np.sqrt(float(n[0]) * n[0] + float(n[1]) * n[1] + float(n[2]) * n[2])
+            normalMap[y, x] = (n.astype(np.float64) * (1.0 / nn if nn else 0.0)).astype(f32)

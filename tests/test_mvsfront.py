@@ -93,3 +93,49 @@ def test_depth_initialisation_agrees(both, trust):
             assert not nc.any()
     e = cf.init_depth_map(0, np.zeros(0, np.uint32), (640, 479))
     assert e[2:] == (np.float32(0.1), 100.0) and not e[0].any()
+
+
+def test_dense_initialisation_agrees(both):
+    """bInitSparse = 0: both implementations rasterise the same canonical face list with the same float arithmetic."""
+    cf, py = both
+    cams = views.Cameras(py)
+    opt = views.DenseOptions(bInitSparse=False)
+    nb, pts, _ = views.select_views(py, cams, 0, opt)
+    dc, nc, mnc, mxc = cf.init_depth_map(0, pts, (640, 479), dense=True)
+    dp, npy, mnp, mxp = views.init_depth_map(py, cams, 0, pts, opt)
+    assert mnc == np.float32(mnp) and mxc == np.float32(mxp)
+    assert np.array_equal(dc > 0, dp > 0) and (dp > 0).mean() > 0.5
+    assert np.array_equal(dc, dp)                              # same faces, same order, same float ops
+    m = dp > 0
+    assert np.abs(nc[m] - npy[m]).max() < 1e-4                 # vertex normals agree to float summation order (different triangle enumeration)
+    assert np.allclose(np.linalg.norm(nc[m], axis=1), 1, atol=1e-5)
+    # the interpolated surface passes through the support points
+    X = py.vertices[pts]; z = cams.point_depth(0, X); p = cams.project_p(0, X)
+    xi = np.rint(p[:, 0]).astype(int); yi = np.rint(p[:, 1]).astype(int)
+    ok = (xi >= 0) & (yi >= 0) & (xi < 640) & (yi < 479)
+    dm = dc[yi[ok], xi[ok]]; v = dm > 0
+    assert v.mean() > 0.95 and np.median(np.abs(dm[v] - z[ok][v]) / z[ok][v]) < 2e-3
+
+
+def test_dense_initialisation_is_exact_on_a_plane():
+    """Perspective-correct interpolation reproduces a plane exactly (up to float): depth at pixel centre = ray/plane intersection."""
+    rng = np.random.default_rng(5)
+    K = np.array([[300., 0, 80], [0, 300., 60], [0, 0, 1]])
+    n = np.array([0.2, -0.1, -1.0]); n /= np.linalg.norm(n); d0 = 6.0                  # plane n.X + d0*n_z... : points X with n.(X - (0,0,d0)) = 0
+    uv = np.concatenate([rng.uniform([-20, -20], [180, 140], (60, 2)), [[-30, -30], [190, -30], [-30, 150], [190, 150]]])
+    rays = np.stack([(uv[:, 0] - 80) / 300, (uv[:, 1] - 60) / 300, np.ones(len(uv))], 1)
+    t = (n[2] * d0) / (rays @ n); X = (rays * t[:, None]).astype(np.float32)
+    sc = mvsi.Scene()
+    sc.platforms = [mvsi.Platform(name="p", cameras=[mvsi.Camera(name="c", width=160, height=120, K=K)], poses_R=np.eye(3)[None], poses_C=np.zeros((1, 3)))]
+    sc.images = [mvsi.Image(name="a.jpg", platform_id=0, camera_id=0, pose_id=0, id=0)]
+    sc.vertices = X
+    sc.vertex_view_start = np.arange(len(X) + 1, dtype=np.int64); sc.vertex_views = np.zeros(len(X), mvsi.VIEW_DTYPE)
+    cams = views.Cameras(sc)
+    pts = np.arange(len(X), dtype=np.uint32)
+    d, nm, mn, mx = views.init_depth_map(sc, cams, 0, pts, views.DenseOptions(bInitSparse=False))
+    assert (d > 0).all()                                                                # the four far corners make the mesh cover the image
+    ys, xs = np.mgrid[0:120, 0:160]
+    r = np.stack([(xs - 80) / 300, (ys - 60) / 300, np.ones_like(xs, float)], -1)
+    want = (n[2] * d0) / (r @ n)
+    assert np.abs(d - want).max() < 2e-4 * d0
+    assert np.abs(np.abs(nm @ n) - 1).max() < 1e-4                                       # every interpolated normal is the plane's

@@ -107,3 +107,46 @@ def test_sgm_pipeline_module(scene, tmp_path):
     cover, med, p90 = _against_sfm(scene, 0, depth)
     assert cover > 0.4 and med < 5e-3 and p90 < 2e-2
     assert conf[depth > 0].min() > 0 and not conf[depth == 0].any()
+
+
+def test_seeded_first_level(scene):
+    """The rough depth map from the sparse points (corners + dense, SemiGlobalMatcher.cpp:608-625) seeds the first level: the initial disparities
+    already agree with the matched ones, both triangulation implementations give the same seed, and the seeded result is at least as good."""
+    from openmvs_amd import mvsfront, sgm_pipeline
+    sc, cams, bgr, seen = scene
+    be = OracleBackend()
+    cam = lambda i: (cams.K[i], cams.R[i], cams.C[i])
+    ok, nb, pts, avg = views.select_neighbor_views(sc, cams, 0)
+    pts = np.nonzero(seen[0])[0].astype(np.uint32)                   # Match() collects every point the image sees (:553-556)
+    cf = mvsfront.SceneFront(os.path.join(SCENE, "scene.mvs"))
+    seeds = {}
+
+    def seed(w, h):
+        K, R, C, _, _ = sc.camera(0, (w, h))
+        P = K @ np.hstack([R, -(R @ C)[:, None]])
+        d, mn, mx = views.triangulate_points_depth_map(K, P, sc.vertices[pts], w, h, avg_depth=avg)
+        dc, mnc, mxc = cf.triangulate_depth_map(0, pts, (w, h), avg_depth=avg)
+        assert np.array_equal(d, dc) and (mn, mx) == (mnc, mxc) and (d > 0).all()
+        seeds[(w, h)] = d
+        return d
+    X = sc.vertices[seen[0] & seen[2]]
+    p = sgm_pipeline.match_pair(be, bgr[0], cam(0), bgr[2], cam(2), X, min_resolution=160, seed_depth=seed)
+    q = sgm_pipeline.match_pair(be, bgr[0], cam(0), bgr[2], cam(2), X, min_resolution=160)
+    assert p["seeded"] and not q["seeded"] and list(seeds) == [(80, 60)]
+    # the seed itself, pushed through Depth2DisparityMap, predicts the final disparities (x 2^3 levels, x 4 sub-pixel steps)
+    r = rectify.stereo_rectify_images(bgr[0], *cam(0), bgr[2], *cam(2), sgm_pipeline.world_to_image3(*cam(0), X), sgm_pipeline.world_to_image3(*cam(2), X))
+    H2, Q2 = rectify.scale_stereo_rectification(r["H"], r["Q"], 0.125)
+    w, h = r["size"][0] // 4 * 4, r["size"][1] // 4 * 4
+    hw, hh = sgm_pipeline.compute_resize((w // 4, h // 4), 0.5)
+    init = be.Depth2DisparityMap(seeds[(80, 60)], np.linalg.inv(H2), np.linalg.inv(Q2), 1, (hw - 6, hh - 6))
+    assert (init != tsgm.NO_DISP).mean() > 0.7
+    fin = p["disparity"]
+    ys, xs = np.nonzero(init != tsgm.NO_DISP)
+    fy, fx = np.minimum(ys * 8 + 24, fin.shape[0] - 1), np.minimum(xs * 8 + 24, fin.shape[1] - 1)       # (r + 3) * 8 - 3 + ... roughly the same place
+    v = fin[fy, fx] != tsgm.NO_DISP
+    err = np.abs(init[ys, xs][v] * 8.0 - fin[fy, fx][v] / 4.0)
+    assert v.mean() > 0.5 and np.median(err) < 8                     # within one coarse-level disparity step
+    for m in (p, q):
+        ok, dep, rg, cf_ = po.sgm_project_disparity2depth_map(m["disparity"], m["cost"], m["Q"], 4, m["image_size"])
+        m["stats"] = _against_sfm(scene, 0, dep)
+    assert p["stats"][0] >= q["stats"][0] - 0.02 and p["stats"][1] < 6e-3, (p["stats"], q["stats"])

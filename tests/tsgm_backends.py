@@ -34,6 +34,7 @@ class OracleBackend:
     UpscaleMask = staticmethod(lambda m, size: po.sgm_upscale_mask(m, size))
     FlipDirection = staticmethod(lambda d: po.sgm_flip_direction(d))
     Disparity2RangeMap = staticmethod(lambda d, m, a, b: po.sgm_disparity2range_map(d, m, a, b))
+    Depth2DisparityMap = staticmethod(lambda depth, invH, invQ, steps, size: po.sgm_depth2disparity_map(depth, invH, invQ, steps, size))
     ProjectDisparity2DepthMap = staticmethod(lambda d, c, Q, steps, size: po.sgm_project_disparity2depth_map(d, c, Q, steps, size))
     FusePairs = staticmethod(lambda deps, rgs, cfs, mv=2: po.sgm_fuse_pairs(deps, rgs, cfs, mv))
 

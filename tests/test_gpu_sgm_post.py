@@ -50,9 +50,16 @@ def test_refine_on_the_resident_match(matcher):
             assert np.array_equal(c, oc)
 
 
-# The three functions below were written after the round's GPU budget was used up: their logic is verified on the CPU through the host emulation
-# (tests/test_sgm_post.py) but this is their first run on a device, hence the non-strict xfail (an XPASS is the expected outcome).
-_first_run = pytest.mark.xfail(strict=False, reason="first device run of these kernels (CPU emulation verified)")
+# NOT YET RUN ON A DEVICE.  The five functions below (8 cases) were written after the round's GPU budget was used up.  Their per-thread logic is
+# verified on the CPU through the host emulation (tests/test_sgm_post.py, tests/cpp/sgm_post_emul.cpp), nothing more.  They run in a child process
+# (`isolated`, tests/conftest.py) so that a GPU fault cannot abort the session and lose the results of the verified tests, and carry a non-strict xfail.
+# How to read the outcome: XPASS = the child passed, the kernel is confirmed on the device; XFAIL = it crashed, hung or gave a wrong answer, and the
+# reason string holds the child's exit code and output.  A green session therefore says nothing about these kernels: look for 8 XPASS (-rxX).
+_xf = pytest.mark.xfail(strict=False, reason="first device run of these kernels (CPU emulation verified only)")
+
+
+def _first_run(f):
+    return _xf(pytest.mark.isolated(f))
 
 
 @_first_run

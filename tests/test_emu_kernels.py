@@ -1,0 +1,102 @@
+"""The product's kernels and host engine, compiled for the host against the wave64 emulator (tests/cpp/hipemu, tests/emu.py) and run through the very
+same C ABI and Python mirrors as on the device, against the oracle.  The checks are the bodies of the `-m gpu` parity tests, called with engines
+that sit on the emulated libraries -- same inputs, same assertions, smaller selection (the emulator is ~1000x slower than the device).
+
+What this establishes in the CPU suite: the kernels' arithmetic AND their launch geometry, index math, cross-lane exchanges (shuffles, ballots,
+DPP), LDS staging, atomics, and the host orchestration between launches are bit-exact with the oracle, and no launch writes outside its buffers
+(guard bands around every device allocation).  What it cannot establish is listed in the emulator's header; the device run remains the gate."""
+import numpy as np
+import pytest
+
+from openmvs_amd import patchmatch, sgm
+from tests import emu
+
+
+@pytest.fixture(scope="module")
+def pm_emulated():
+    with emu.emulated(patchmatch, "PMHIP_LIB", "libpmhip_emu.so"):
+        yield
+
+
+@pytest.fixture(scope="module")
+def sgm_emulated():
+    with emu.emulated(sgm, "SGMHIP_LIB", "libsgmhip_emu.so"):
+        yield
+
+
+@pytest.fixture(scope="module")
+def engine(pm_emulated):
+    e = patchmatch.PatchMatchHIP(0)
+    e.Init(False)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def matcher(sgm_emulated):
+    m = sgm.SemiGlobalMatcherHIP(0)
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def tiny_scene():
+    from openmvs_amd import synth
+    return synth.make_scene(5, 96, 72, n_src=4)
+
+
+# ---- PatchMatch: estimator, filters, fusion ------------------------------------------------------------------------------------------------------
+def test_estimator_single_view(engine, small_scene):
+    from tests import test_gpu_patchmatch as g
+    g.test_device_resampling_matches_oracle(engine)
+    g.test_single_view_photometric_parity_N4(engine, small_scene, 2)          # 3 pyramid levels, 4 source views (G = 4 lanes per pixel)
+    g.test_initial_estimate_is_honoured(engine, small_scene)
+
+
+def test_estimator_group_sizes_and_geometric_pass(engine, nine_scene):
+    from tests import test_gpu_patchmatch as g
+    g.test_single_view_parity_N8_and_N1(engine, nine_scene)                   # G = 8 and G = 1
+    g.test_geometric_round_parity_and_golden(engine)
+
+
+def test_estimator_odd_sizes(engine):
+    from tests import test_gpu_patchmatch as g
+    g.test_non_divisible_image_size_parity(engine)
+
+
+def test_scene_schedule_masks_and_filters(pm_emulated, small_scene):
+    from tests import test_gpu_patchmatch as g
+    g.test_scene_batch_full_schedule_matches_oracle(small_scene)
+    g.test_ignore_mask_parity(small_scene)
+    g.test_filter_depth_map_parity(small_scene, True)
+    g.test_remove_small_segments_parity(small_scene)
+    g.test_gap_interpolation_parity(small_scene)
+
+
+def test_fusion(pm_emulated, small_scene, nine_scene):
+    from tests import test_gpu_fuse as g
+    g.test_device_fuse_is_the_sequential_fuse(small_scene, nine_scene, 0)
+    g.test_device_fuse_is_the_sequential_fuse(small_scene, nine_scene, 3)
+    g.test_device_fuse_reproduces_the_golden_cloud()
+    g.test_device_merge_mode(small_scene)
+    g.test_device_fuse_custom_order_and_errors(small_scene)
+
+
+# ---- SGM: cost volume, 8-path aggregation, winner-take-all, the tSGM steps ------------------------------------------------------------------------
+def test_sgm_match(matcher):
+    from tests import test_gpu_sgm as g
+    g.test_p2s_match(matcher)
+    g.test_match_parity(matcher, 96, 64, "uniform", 0, 16)
+    g.test_match_parity(matcher, 97, 65, "ragged", -5, 40)                    # odd valid width, ragged ranges
+    g.test_tiny_and_degenerate(matcher)
+
+
+def test_sgm_steps(matcher):
+    from tests import test_gpu_sgm_post as g
+    g.test_map_steps_match_the_oracle(matcher, 131, 77, 1)
+    g.test_map_steps_match_the_oracle(matcher, 9, 5, 3)
+    for w, h, seed in ((64, 40, 0), (97, 53, 1)):
+        g.test_range_map_matches_the_oracle(matcher, w, h, seed)
+        g.test_disparity_depth_conversions_match_the_oracle(matcher, w, h, seed)
+        g.test_projection_and_pair_fusion_match_the_oracle(matcher, w, h, seed)
+    g.test_filter_speckles_matches_the_oracle(matcher)

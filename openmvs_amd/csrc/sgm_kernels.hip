@@ -186,6 +186,12 @@ __device__ __forceinline__ void sgm_accumulate(unsigned* wordsBase, unsigned par
 //    the compiler cannot wait for less);
 //  * the workgroup is one wave and the LDS executes a wave's instructions in order: no barrier between steps.
 #define SGM_TT 64        // pixels per pixel-table chunk
+// A place where the code relies on a wavefront issuing its LDS instructions in program order: a store by one lane must not overtake an earlier
+// load of the same location by another lane.  True by construction on the hardware (one wave, one instruction stream), so nothing is emitted; the
+// CPU emulator the tests run these kernels under (tests/cpp/hipemu) executes lanes one after the other and defines this as a lane rendezvous.
+#ifndef WAVE_LOCKSTEP_POINT
+#define WAVE_LOCKSTEP_POINT() ((void)0)
+#endif
 struct SGMStep { int rpMin, rpMax, cur; float Ip; };
 
 template <int NK>
@@ -294,6 +300,7 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 	while (x >= 0 && y >= 0 && x < vw && y < vh) {
 		// table of the next chunk: complete by now (requested a whole chunk ago); park it in the other slot and request the one after
 		__builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
+		WAVE_LOCKSTEP_POINT();                                        // every lane is done reading slot^1 (the chunk before this one)
 		s_px[slot ^ 1][lane] = tpx; s_g[slot ^ 1][lane] = tg;
 		tableLoad(x + 2 * SGM_TT * dx, y + 2 * SGM_TT * dy, tpx, tg);
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

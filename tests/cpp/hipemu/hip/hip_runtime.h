@@ -248,6 +248,7 @@ template <class T> inline T readlane(T v, int lane, int site) { Fiber* f = cur; 
 #define __builtin_amdgcn_wave_barrier() hipemu::park(hipemu::OP_WAVE_BARRIER, __LINE__)
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu::dpp((old), (src), (ctrl), (rm), (bm), (bc), __LINE__)
 #define __builtin_amdgcn_readlane(v, l) hipemu::readlane((v), (l), __LINE__)
+#define WAVE_LOCKSTEP_POINT() hipemu::park(hipemu::OP_WAVE_BARRIER, __LINE__)   // the product's marker for reliance on wave lock-step (see sgm_kernels.hip)
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))

@@ -34,6 +34,16 @@ def ranges(w, h, kind, dmin, dmax, seed=1):
         mx = (mn + nd).astype(np.int16)
         inv = r.rand(vh, vw) < 0.05
         mx[inv] = mn[inv]
+    elif kind == "holes":        # what Disparity2RangeMap produces under a mask: long runs of invalid pixels (NO_DISP, NO_DISP) with ragged borders,
+        nd = r.randint(3, dmax - dmin + 1, (vh, vw))                 # longer than the path kernel's 64-pixel table chunk in every direction
+        mn = (dmin + r.randint(0, (dmax - dmin) - nd + 1)).astype(np.int16)
+        mx = (mn + nd).astype(np.int16)
+        inv = np.zeros((vh, vw), bool)
+        for y in range(vh):
+            a = vw // 8 + r.randint(0, 5); inv[y, a:a + 70 + r.randint(0, 9)] = True
+        for x in range(vw - vw // 6, vw):
+            a = vh // 8 + r.randint(0, 5); inv[a:a + 70 + r.randint(0, 9), x] = True
+        mn[inv] = 32767; mx[inv] = 32767
     else:
         raise ValueError(kind)
     return sgm.make_pixels(mn, mx)

@@ -89,6 +89,7 @@ def test_sgm_match(matcher):
     g.test_match_parity(matcher, 96, 64, "uniform", 0, 16)
     g.test_match_parity(matcher, 97, 65, "ragged", -5, 40)                    # odd valid width, ragged ranges
     g.test_tiny_and_degenerate(matcher)
+    g.test_match_parity_across_long_invalid_runs(matcher)                     # whole table chunks of invalid pixels
 
 
 def test_sgm_steps(matcher):

@@ -45,6 +45,17 @@ def test_match_parity(matcher, w, h, kind, dmin, dmax):
         assert (d[:, 8:w - 6 - (dmax + 8)] == 5).mean() > 0.97
 
 
+@pytest.mark.xfail(strict=False, reason="input class added after the round's GPU budget was spent; passes on the CPU emulator, not yet run on a device")
+@pytest.mark.isolated
+def test_match_parity_across_long_invalid_runs(matcher):
+    """Masked regions (ranges NO_DISP..NO_DISP) wider than the path kernel's 64-pixel table chunk: paths skip them without resetting their state
+    (SemiGlobalMatcher.cpp:1071-1072), so a whole staged chunk can be invalid.  NOT YET RUN ON A DEVICE."""
+    w, h = 230, 100                                             # lines of more than 3 chunks, so that chunk k+2 holds valid pixels where chunk k has a hole
+    lb, lg, rg = sc.stereo_pair(w, h, 5, seed=8)
+    px, n, mx = sc.ranges(w, h, "holes", -2, 12, seed=3)
+    _check(matcher, lb, lg, rg, px, n, mx)
+
+
 def test_tiny_and_degenerate(matcher):
     lb, lg, rg = sc.stereo_pair(8, 8, 0)
     px, n, mx = sc.ranges(8, 8, "uniform", -1, 2)

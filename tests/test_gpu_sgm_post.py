@@ -51,7 +51,8 @@ def test_refine_on_the_resident_match(matcher):
 
 
 # NOT YET RUN ON A DEVICE.  The five functions below (8 cases) were written after the round's GPU budget was used up.  Their per-thread logic is
-# verified on the CPU through the host emulation (tests/test_sgm_post.py, tests/cpp/sgm_post_emul.cpp), nothing more.  They run in a child process
+# verified on the CPU through the host emulation (tests/test_sgm_post.py, tests/cpp/sgm_post_emul.cpp) and the kernels themselves pass under the wave64
+# emulator (tests/test_emu_kernels.py); neither is a device run.  They run in a child process
 # (`isolated`, tests/conftest.py) so that a GPU fault cannot abort the session and lose the results of the verified tests, and carry a non-strict xfail.
 # How to read the outcome: XPASS = the child passed, the kernel is confirmed on the device; XFAIL = it crashed, hung or gave a wrong answer, and the
 # reason string holds the child's exit code and output.  A green session therefore says nothing about these kernels: look for 8 XPASS (-rxX).

@@ -101,3 +101,10 @@ def test_sgm_steps(matcher):
         g.test_disparity_depth_conversions_match_the_oracle(matcher, w, h, seed)
         g.test_projection_and_pair_fusion_match_the_oracle(matcher, w, h, seed)
     g.test_filter_speckles_matches_the_oracle(matcher)
+
+
+def test_tsgm_loop_on_the_emulated_device(matcher, pm_emulated):
+    """The whole coarse-to-fine loop with every step on the (emulated) device against the same loop on the oracle, 256x192, 3 levels.  This is the
+    case that exposed the path kernel's reliance on wave lock-step (WAVE_LOCKSTEP_POINT in sgm_kernels.hip)."""
+    from tests import test_gpu_sgm_post as g
+    g.test_tsgm_loop_on_the_device_equals_the_loop_on_the_oracle(matcher)

@@ -102,6 +102,16 @@ int sgmhip_filter_speckles(sgmhip_engine* e, int16_t* disparity, int w, int h, i
 /* HIP-event timing since the last reset: milliseconds in the cost-volume, aggregation (8 path
  * kernels) and WTA kernels, number of match calls. */
 typedef struct SGMHipStats { double costMs, aggrMs, wtaMs; uint64_t calls, aggrLaunches; } SGMHipStats;
+/* The tSGM coarse-to-fine loop of SemiGlobalMatcher::Match(scene, ...) (libs/MVS/SemiGlobalMatcher.cpp:577-706) for one rectified pair in one call, resident
+ * on the device: per level the image pyramids (INTER_AREA from the full-resolution images), FlipDirection + Disparity2RangeMap, Match right->left and
+ * left->right, ConsistencyCrossCheck; on the first level also filterSpeckles(nSpeckleSize, 5) and ExtractMask; finally RefineDisparityMap.  Equal to driving the
+ * single steps above as openmvs_amd/tsgm.py does.  Images: w x h (a multiple of 2^levels), BGR 8-bit and gray float of the rectified pair, their 8-bit validity
+ * masks (Image::StereoRectifyImages); initLeftDisparity: nullable, the half-resolution map of the first level (Depth2DisparityMap of the sparse-point depth map,
+ * :608-625), size (round(w_l/2)-6) x (round(h_l/2)-6) with w_l, h_l the coarsest level's size.  Outputs on the valid grid (w-6) x (h-6). */
+int sgmhip_tsgm_match(sgmhip_engine* e, const uint8_t* leftBGR, const uint8_t* rightBGR, const float* leftGray, const float* rightGray,
+                      const uint8_t* leftMask, const uint8_t* rightMask, int w, int h, unsigned minResolution, const int16_t* initLeftDisparity,
+                      int nSpeckleSize, int subpixelMode, int subpixelSteps, uint16_t P1, const uint16_t P2s[256], int16_t* disparity, uint16_t* cost, int* numLevels);
+
 int sgmhip_stats_reset(sgmhip_engine* e, int enable);
 int sgmhip_stats_get(sgmhip_engine* e, SGMHipStats* out);
 

@@ -2,6 +2,7 @@
 #include "../../include/sgmhip.h"
 #include "sgm_kernels.hip"
 #include "sgm_post.hip"
+#include "sgm_tsgm.hip"
 #include <math.h>
 #include <string.h>
 #include <algorithm>
@@ -38,6 +39,22 @@ static int sgmCollect(sgmhip_engine* e) {
 	return 0;
 }
 
+// buffers of the resident problem (grown, never shrunk) and its dimensions
+static int sgmReserve(sgmhip_engine* e, int w, int h, uint64_t numCosts, int maxNumDisp) {
+	const size_t nImg = (size_t)w * h, nPix = (size_t)(w - 2 * SGM_HW) * (h - 2 * SGM_HW);
+	if (nImg > e->capImg || nPix > e->capPix || numCosts > e->capCosts) {
+		SGMCHK(e, hipStreamSynchronize(e->stream));
+		const size_t cI = std::max(nImg, e->capImg), cP = std::max(nPix, e->capPix), cC = std::max<size_t>(numCosts, e->capCosts);
+		sgmFree(e);
+		SGMCHK(e, hipMalloc(&e->d_color, cI * 3)); SGMCHK(e, hipMalloc(&e->d_grayL, cI * 4)); SGMCHK(e, hipMalloc(&e->d_grayR, cI * 4));
+		SGMCHK(e, hipMalloc(&e->d_pixels, cP * sizeof(SGMPixel))); SGMCHK(e, hipMalloc(&e->d_disp, cP * 2)); SGMCHK(e, hipMalloc(&e->d_cost, cP * 2)); SGMCHK(e, hipMalloc(&e->d_setup, cP * sizeof(float4)));
+		SGMCHK(e, hipMalloc(&e->d_costs, cC)); SGMCHK(e, hipMalloc(&e->d_accums, (cC + 1) / 2 * 4 + 4)); // u16 sums, addressed as 32-bit words by the path kernels
+		e->capImg = cI; e->capPix = cP; e->capCosts = cC;
+	}
+	e->w = w; e->h = h; e->vw = w - 2 * SGM_HW; e->vh = h - 2 * SGM_HW; e->numCosts = numCosts; e->maxNumDisp = maxNumDisp;
+	return 0;
+}
+
 extern "C" {
 
 int sgmhip_create(int device, sgmhip_engine** out) {
@@ -71,15 +88,7 @@ int sgmhip_set_problem(sgmhip_engine* e, const uint8_t* leftBGR, const float* le
 	if (!e || !leftBGR || !leftGray || !rightGray || !pixels || w <= 2 * SGM_HW || h <= 2 * SGM_HW || numCosts == 0 || maxNumDisp <= 0 || maxNumDisp > 256) return SGMHIP_E_ARG;
 	SGMCHK(e, hipSetDevice(e->device));
 	const size_t nImg = (size_t)w * h, nPix = (size_t)(w - 2 * SGM_HW) * (h - 2 * SGM_HW);
-	if (nImg > e->capImg || nPix > e->capPix || numCosts > e->capCosts) {
-		SGMCHK(e, hipStreamSynchronize(e->stream));
-		sgmFree(e);
-		SGMCHK(e, hipMalloc(&e->d_color, nImg * 3)); SGMCHK(e, hipMalloc(&e->d_grayL, nImg * 4)); SGMCHK(e, hipMalloc(&e->d_grayR, nImg * 4));
-		SGMCHK(e, hipMalloc(&e->d_pixels, nPix * sizeof(SGMPixel))); SGMCHK(e, hipMalloc(&e->d_disp, nPix * 2)); SGMCHK(e, hipMalloc(&e->d_cost, nPix * 2)); SGMCHK(e, hipMalloc(&e->d_setup, nPix * sizeof(float4)));
-		SGMCHK(e, hipMalloc(&e->d_costs, numCosts)); SGMCHK(e, hipMalloc(&e->d_accums, (numCosts + 1) / 2 * 4 + 4)); // u16 sums, addressed as 32-bit words by the path kernels
-		e->capImg = nImg; e->capPix = nPix; e->capCosts = numCosts;
-	}
-	e->w = w; e->h = h; e->vw = w - 2 * SGM_HW; e->vh = h - 2 * SGM_HW; e->numCosts = numCosts; e->maxNumDisp = maxNumDisp;
+	{ const int rc = sgmReserve(e, w, h, numCosts, maxNumDisp); if (rc) return rc; }
 	SGMCHK(e, hipMemcpyAsync(e->d_color, leftBGR, nImg * 3, hipMemcpyHostToDevice, e->stream));
 	SGMCHK(e, hipMemcpyAsync(e->d_grayL, leftGray, nImg * 4, hipMemcpyHostToDevice, e->stream));
 	SGMCHK(e, hipMemcpyAsync(e->d_grayR, rightGray, nImg * 4, hipMemcpyHostToDevice, e->stream));
@@ -96,10 +105,17 @@ static void launchPath(sgmhip_engine* e, hipStream_t st, int NK, int lines, int 
 	}
 }
 
+static int sgmMatch(sgmhip_engine* e, uint16_t P1);
 int sgmhip_match(sgmhip_engine* e, uint16_t P1, const uint16_t P2s[256], int sync) {
 	if (!e || !P2s || e->numCosts == 0) return SGMHIP_E_ARG;
 	SGMCHK(e, hipSetDevice(e->device));
 	SGMCHK(e, hipMemcpyAsync(e->d_P2s, P2s, 512, hipMemcpyHostToDevice, e->stream));
+	{ const int rc = sgmMatch(e, P1); if (rc) return rc; }
+	if (sync) SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+// cost volume, 8-path aggregation and winner-take-all of the resident problem (P2s already on the device), asynchronous on the engine's stream
+static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 	const long nPix = (long)e->vw * e->vh;
 	const int W = e->vw, H = e->vh;
 	evB(e, 0);
@@ -140,7 +156,6 @@ int sgmhip_match(sgmhip_engine* e, uint16_t P1, const uint16_t P2s[256], int syn
 	evE(e);
 	SGMCHK(e, hipGetLastError());
 	if (e->statsOn) e->stats.calls += 1;
-	if (sync) SGMCHK(e, hipStreamSynchronize(e->stream));
 	return 0;
 }
 
@@ -374,6 +389,139 @@ int sgmhip_set_disparity(sgmhip_engine* e, const int16_t* disparity) {
 	SGMCHK(e, hipSetDevice(e->device));
 	SGMCHK(e, hipMemcpyAsync(e->d_disp, disparity, (size_t)e->vw * e->vh * 2, hipMemcpyHostToDevice, e->stream));
 	SGMCHK(e, hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+// ---- the whole coarse-to-fine loop for one rectified pair, resident (SemiGlobalMatcher.cpp:577-706; kernels in sgm_tsgm.hip) -----------------
+namespace {
+// computeMaxResolution(w, h, level = 8, minResolution) (libs/Common/Types.inl:2459-2477) -> k with scale = 1 / max(2, 2^k); 0 = plain SGM
+int tsgmLevels(int w, int h, unsigned minResolution) {
+	if (!minResolution) return 0;
+	const unsigned size0 = (unsigned)std::max(w, h);
+	unsigned level = 8;
+	if ((size0 >> level) < minResolution) { level = 0; while ((size0 >> (level + 1)) >= minResolution) ++level; }
+	return (int)std::max(1u, level);
+}
+inline int cvRound(double v) { return (int)nearbyint(v); }      // cv::saturate_cast<int>(double): round half to even
+}
+
+int sgmhip_tsgm_match(sgmhip_engine* e, const uint8_t* leftBGR, const uint8_t* rightBGR, const float* leftGray, const float* rightGray,
+		const uint8_t* leftMask, const uint8_t* rightMask, int w, int h, unsigned minResolution, const int16_t* initLeftDisparity,
+		int nSpeckleSize, int subpixelMode, int subpixelSteps, uint16_t P1, const uint16_t P2s[256], int16_t* disparity, uint16_t* cost, int* numLevels) {
+	if (!e || !leftBGR || !rightBGR || !leftGray || !rightGray || !leftMask || !rightMask || !P2s || !disparity || !cost || w <= 0 || h <= 0 || nSpeckleSize < 0 ||
+	    subpixelMode < 0 || subpixelMode > SGMP_SUBPIXEL_LC_BLEND || subpixelSteps < 0 || subpixelSteps > 64) return SGMHIP_E_ARG;
+	const int k = tsgmLevels(w, h, minResolution);
+	if (k == 0) { e->err = "plain SGM (minResolution = 0) is not driven here: only tSGM"; return SGMHIP_E_ARG; }
+	if ((w % (1 << k)) || (h % (1 << k)) || (w >> k) <= 2 * SGM_HW + 2 || (h >> k) <= 2 * SGM_HW + 2) { e->err = "image size must be a multiple of 2^levels and its coarsest level larger than the window"; return SGMHIP_E_ARG; }
+	SGMCHK(e, hipSetDevice(e->device));
+	hipStream_t st = e->stream;
+	const size_t nFull = (size_t)w * h, nValid = (size_t)(w - 2 * SGM_HW) * (h - 2 * SGM_HW);
+	// full-resolution inputs and the per-level working set (sized for the finest level)
+	DevBuf fLB, fRB, fLG, fRG, fLM, fRM, lB, rB, lG, rG, lM, rM, lM2, rM2, lD, rD, lDn, rDn, keys, ranges, tiles, scal, par, siz;
+	SGMCHK(e, fLB.alloc(nFull * 3)); SGMCHK(e, fRB.alloc(nFull * 3)); SGMCHK(e, fLG.alloc(nFull * 4)); SGMCHK(e, fRG.alloc(nFull * 4)); SGMCHK(e, fLM.alloc(nFull)); SGMCHK(e, fRM.alloc(nFull));
+	SGMCHK(e, lB.alloc(nFull * 3)); SGMCHK(e, rB.alloc(nFull * 3)); SGMCHK(e, lG.alloc(nFull * 4)); SGMCHK(e, rG.alloc(nFull * 4));
+	SGMCHK(e, lM.alloc(nValid)); SGMCHK(e, rM.alloc(nValid)); SGMCHK(e, lM2.alloc(nValid)); SGMCHK(e, rM2.alloc(nValid));
+	SGMCHK(e, lD.alloc(nValid * 2)); SGMCHK(e, rD.alloc(nValid * 2)); SGMCHK(e, lDn.alloc(nValid * 2)); SGMCHK(e, rDn.alloc(nValid * 2));
+	SGMCHK(e, keys.alloc(nValid * 4)); SGMCHK(e, ranges.alloc(nValid * 4)); SGMCHK(e, par.alloc(nValid * 4)); SGMCHK(e, siz.alloc(nValid * 4));
+	const int maxTiles = (int)((nValid + SGMT_TILE - 1) / SGMT_TILE);
+	SGMCHK(e, tiles.alloc((size_t)maxTiles * 8)); SGMCHK(e, scal.alloc(16));
+	SGMCHK(e, hipMemcpyAsync(fLB.p, leftBGR, nFull * 3, hipMemcpyHostToDevice, st)); SGMCHK(e, hipMemcpyAsync(fRB.p, rightBGR, nFull * 3, hipMemcpyHostToDevice, st));
+	SGMCHK(e, hipMemcpyAsync(fLG.p, leftGray, nFull * 4, hipMemcpyHostToDevice, st)); SGMCHK(e, hipMemcpyAsync(fRG.p, rightGray, nFull * 4, hipMemcpyHostToDevice, st));
+	SGMCHK(e, hipMemcpyAsync(fLM.p, leftMask, nFull, hipMemcpyHostToDevice, st)); SGMCHK(e, hipMemcpyAsync(fRM.p, rightMask, nFull, hipMemcpyHostToDevice, st));
+	SGMCHK(e, hipMemcpyAsync(e->d_P2s, P2s, 512, hipMemcpyHostToDevice, st));
+
+	int16_t* leftDisp = (int16_t*)lD.p; int16_t* rightDisp = (int16_t*)rD.p; int16_t* leftNew = (int16_t*)lDn.p; int16_t* rightNew = (int16_t*)rDn.p;
+	uint8_t* lm = (uint8_t*)lM.p; uint8_t* rm = (uint8_t*)rM.p; uint8_t* lmNext = (uint8_t*)lM2.p; uint8_t* rmNext = (uint8_t*)rM2.p;
+	int dW = 0, dH = 0;            // size of leftDisp (the previous level's valid grid)
+	int mW = 0, mH = 0;            // size of the masks
+	int levels = 0;
+	bool first = true;
+	// Disparity2RangeMap on the device + Match of (bgr, grayA -> grayB) with those ranges; the result is copied to `out`
+	auto rangeAndMatch = [&](const int16_t* disp, const uint8_t* mask2x, int vw, int vh, int lw, int lh, const void* bgr, const void* gA, const void* gB, int a, int b, int16_t* out) -> int {
+		const size_t n = (size_t)dW * dH, n2 = (size_t)vw * vh;
+		hipLaunchKernelGGL(sgmp_range_kernel, dim3(gridFor(n)), dim3(256), 0, st, disp, dW, dH, mask2x, vw, a, b, (short2*)ranges.p);
+		const int nT = (int)((n2 + SGMT_TILE - 1) / SGMT_TILE);
+		SGMCHK(e, hipMemsetAsync(scal.p, 0, 16, st));
+		hipLaunchKernelGGL(sgmt_tile_sums_kernel, dim3(nT), dim3(256), 0, st, (const short2*)ranges.p, dW, dH, vw, n2, (unsigned long long*)tiles.p, (int*)((char*)scal.p + 8));
+		hipLaunchKernelGGL(sgmt_scan_tiles_kernel, dim3(1), dim3(256), 0, st, (unsigned long long*)tiles.p, nT, (unsigned long long*)scal.p);
+		unsigned long long hs[2] = {0, 0};
+		SGMCHK(e, hipMemcpyAsync(hs, scal.p, 16, hipMemcpyDeviceToHost, st));
+		SGMCHK(e, hipStreamSynchronize(st));
+		const uint64_t numCosts = hs[0]; const int mx = (int)(hs[1] & 0xffffffffull);
+		if (numCosts == 0 || mx <= 0 || mx > 256) { e->err = "tsgm: empty or too wide disparity ranges at a level"; return SGMHIP_E_ARG; }
+		{ const int rc = sgmReserve(e, lw, lh, numCosts, mx); if (rc) return rc; }
+		hipLaunchKernelGGL(sgmt_expand_kernel, dim3(nT), dim3(256), 0, st, (const short2*)ranges.p, dW, dH, vw, n2, (const unsigned long long*)tiles.p, e->d_pixels);
+		const size_t nImg = (size_t)lw * lh;
+		SGMCHK(e, hipMemcpyAsync(e->d_color, bgr, nImg * 3, hipMemcpyDeviceToDevice, st));
+		SGMCHK(e, hipMemcpyAsync(e->d_grayL, gA, nImg * 4, hipMemcpyDeviceToDevice, st));
+		SGMCHK(e, hipMemcpyAsync(e->d_grayR, gB, nImg * 4, hipMemcpyDeviceToDevice, st));
+		{ const int rc = sgmMatch(e, P1); if (rc) return rc; }
+		SGMCHK(e, hipMemcpyAsync(out, e->d_disp, n2 * 2, hipMemcpyDeviceToDevice, st));
+		return 0;
+	};
+	auto speckles = [&](int16_t* d, int vw, int vh) {
+		const int n = vw * vh; const unsigned g = gridFor((size_t)n);
+		hipLaunchKernelGGL(sgmp_speckle_init_kernel, dim3(g), dim3(256), 0, st, (int*)par.p, (int*)siz.p, n);
+		hipLaunchKernelGGL(sgmp_speckle_hook_kernel, dim3(g), dim3(256), 0, st, (const int16_t*)d, (int*)par.p, vw, vh, 5);
+		hipLaunchKernelGGL(sgmp_speckle_flatten_kernel, dim3(g), dim3(256), 0, st, (int*)par.p, (int*)siz.p, n);
+		hipLaunchKernelGGL(sgmp_speckle_apply_kernel, dim3(g), dim3(256), 0, st, d, (const int*)par.p, (const int*)siz.p, n, nSpeckleSize);
+	};
+	for (int lvl = k; lvl >= 0; --lvl) {
+		const int f = 1 << lvl, lw = w / f, lh = h / f, vw = lw - 2 * SGM_HW, vh = lh - 2 * SGM_HW;
+		const size_t nImg = (size_t)lw * lh, nV = (size_t)vw * vh;
+		const void *pLB, *pRB, *pLG, *pRG;
+		if (f == 1) { pLB = fLB.p; pRB = fRB.p; pLG = fLG.p; pRG = fRG.p; }
+		else {
+			hipLaunchKernelGGL(sgmt_area_u8x3_kernel, dim3(gridFor(nImg * 3)), dim3(256), 0, st, (const unsigned char*)fLB.p, w, (unsigned char*)lB.p, lw, lh, f);
+			hipLaunchKernelGGL(sgmt_area_u8x3_kernel, dim3(gridFor(nImg * 3)), dim3(256), 0, st, (const unsigned char*)fRB.p, w, (unsigned char*)rB.p, lw, lh, f);
+			hipLaunchKernelGGL(sgmt_area_f32_kernel, dim3(gridFor(nImg)), dim3(256), 0, st, (const float*)fLG.p, w, (float*)lG.p, lw, lh, f);
+			hipLaunchKernelGGL(sgmt_area_f32_kernel, dim3(gridFor(nImg)), dim3(256), 0, st, (const float*)fRG.p, w, (float*)rG.p, lw, lh, f);
+			pLB = lB.p; pRB = rB.p; pLG = lG.p; pRG = rG.p;
+		}
+		if (first) {
+			const int hw2 = cvRound(lw * 0.5), hh2 = cvRound(lh * 0.5);                 // Image8U::computeResize(size, 0.5), :622
+			dW = hw2 - 2 * SGM_HW; dH = hh2 - 2 * SGM_HW;
+			if (dW <= 0 || dH <= 0) { e->err = "tsgm: coarsest level too small"; return SGMHIP_E_ARG; }
+			if (initLeftDisparity) SGMCHK(e, hipMemcpyAsync(leftDisp, initLeftDisparity, (size_t)dW * dH * 2, hipMemcpyHostToDevice, st));
+			else hipLaunchKernelGGL(sgmt_fill_i16_kernel, dim3(gridFor((size_t)dW * dH)), dim3(256), 0, st, leftDisp, (size_t)dW * dH, (short)SGMP_NO_DISP);
+			hipLaunchKernelGGL(sgmt_mask_first_kernel, dim3(gridFor(nV)), dim3(256), 0, st, (const unsigned char*)fLM.p, w, lm, vw, vh, f);   // :627-631
+			hipLaunchKernelGGL(sgmt_mask_first_kernel, dim3(gridFor(nV)), dim3(256), 0, st, (const unsigned char*)fRM.p, w, rm, vw, vh, f);
+		} else {
+			hipLaunchKernelGGL(sgmp_upscale_mask_kernel, dim3(gridFor(nV)), dim3(256), 0, st, (const uint8_t*)lm, mW, mH, lmNext, vw, vh);   // :634-635
+			hipLaunchKernelGGL(sgmp_upscale_mask_kernel, dim3(gridFor(nV)), dim3(256), 0, st, (const uint8_t*)rm, mW, mH, rmNext, vw, vh);
+			std::swap(lm, lmNext); std::swap(rm, rmNext);
+		}
+		mW = vw; mH = vh;
+		const int a = first ? 11 : 5, b = first ? 33 : 7;
+		// right -> left with ranges from the flipped previous disparities (:641-654)
+		const size_t nD = (size_t)dW * dH;
+		SGMCHK(e, hipMemsetAsync(keys.p, 0, nD * 4, st));
+		hipLaunchKernelGGL(sgmp_flip_scatter_kernel, dim3(gridFor(nD)), dim3(256), 0, st, (const int16_t*)leftDisp, (uint32_t*)keys.p, dW, dH);
+		hipLaunchKernelGGL(sgmp_flip_decode_kernel, dim3(gridFor(nD)), dim3(256), 0, st, (const uint32_t*)keys.p, rightDisp, nD);
+		{ const int rc = rangeAndMatch(rightDisp, rm, vw, vh, lw, lh, pRB, pRG, pLG, a, b, rightNew); if (rc) return rc; }
+		// left -> right (:657-667)
+		{ const int rc = rangeAndMatch(leftDisp, lm, vw, vh, lw, lh, pLB, pLG, pRG, a, b, leftNew); if (rc) return rc; }
+		std::swap(leftDisp, leftNew); std::swap(rightDisp, rightNew);
+		dW = vw; dH = vh;
+		hipLaunchKernelGGL(sgmp_cross_check_kernel, dim3(gridFor(nV)), dim3(256), 0, st, leftDisp, (const int16_t*)rightDisp, vw, vw, vh, 1);
+		if (first) {                                                                   // :680-690
+			hipLaunchKernelGGL(sgmp_cross_check_kernel, dim3(gridFor(nV)), dim3(256), 0, st, rightDisp, (const int16_t*)leftDisp, vw, vw, vh, 1);
+			speckles(leftDisp, vw, vh); speckles(rightDisp, vw, vh);
+			hipLaunchKernelGGL(sgmp_extract_mask_kernel, dim3((vh + 63) / 64), dim3(64), 0, st, (const int16_t*)leftDisp, lm, vw, vh, 3);
+			hipLaunchKernelGGL(sgmp_extract_mask_kernel, dim3((vh + 63) / 64), dim3(64), 0, st, (const int16_t*)rightDisp, rm, vw, vh, 3);
+		}
+		first = false; ++levels;
+	}
+	// sub-pixel refinement on the resident sums of the last (left) Match with the cross-checked map (:699)
+	const size_t nV = (size_t)dW * dH;
+	SGMCHK(e, hipMemcpyAsync(e->d_disp, leftDisp, nV * 2, hipMemcpyDeviceToDevice, st));
+	if (subpixelSteps > 1)
+		hipLaunchKernelGGL(sgmp_refine_kernel, dim3(gridFor(nV)), dim3(256), 0, st, e->d_pixels, e->d_accums, (long)nV, e->d_disp, subpixelMode, subpixelSteps);
+	SGMCHK(e, hipGetLastError());
+	SGMCHK(e, hipMemcpyAsync(disparity, e->d_disp, nV * 2, hipMemcpyDeviceToHost, st));
+	SGMCHK(e, hipMemcpyAsync(cost, e->d_cost, nV * 2, hipMemcpyDeviceToHost, st));
+	SGMCHK(e, hipStreamSynchronize(st));
+	if (numLevels) *numLevels = levels;
 	return 0;
 }
 

@@ -14,7 +14,7 @@ EXPORTS = ["sgmhip_create", "sgmhip_destroy", "sgmhip_last_error", "sgmhip_gener
            "sgmhip_match", "sgmhip_get_results", "sgmhip_sync", "sgmhip_stats_reset", "sgmhip_stats_get",
            "sgmhip_consistency_cross_check", "sgmhip_filter_by_cost", "sgmhip_extract_mask", "sgmhip_upscale_mask", "sgmhip_flip_direction",
            "sgmhip_refine_disparity", "sgmhip_disparity2range_map", "sgmhip_depth2disparity_map", "sgmhip_disparity2depth_map",
-           "sgmhip_project_disparity2depth_map", "sgmhip_fuse_pairs", "sgmhip_filter_speckles", "sgmhip_set_disparity"]
+           "sgmhip_project_disparity2depth_map", "sgmhip_fuse_pairs", "sgmhip_filter_speckles", "sgmhip_set_disparity", "sgmhip_tsgm_match"]
 NO_DISP = 32767          # SemiGlobalMatcher::NO_DISP
 INVALID, VALID = 0, 255  # MaskMap values
 SUBPIXEL_NA, SUBPIXEL_LINEAR, SUBPIXEL_POLY4, SUBPIXEL_PARABOLA, SUBPIXEL_SINE, SUBPIXEL_COSINE, SUBPIXEL_LC_BLEND = range(7)
@@ -179,6 +179,25 @@ class SemiGlobalMatcherHIP:
         dep = np.zeros((dh, dw), np.float32); cf = np.zeros((dh, dw), np.float32)
         self._chk(self._lib.sgmhip_fuse_pairs(self._h, ptrs[0], ptrs[1], ptrs[2], len(depths), dw, dh, C.c_uint(minViews), dep.ctypes.data_as(C.POINTER(C.c_float)), cf.ctypes.data_as(C.POINTER(C.c_float))))
         return dep, cf
+
+    def tsgm_match(self, left_bgr, right_bgr, left_gray, right_gray, left_mask, right_mask, min_resolution=320, init_left_disparity=None,
+                   n_speckle_size=100, subpixel_mode=SUBPIXEL_LC_BLEND, subpixel_steps=4):
+        """The whole coarse-to-fine loop for a rectified pair in one call, resident on the device (sgmhip_tsgm_match; the same result as
+        openmvs_amd.tsgm.tsgm_match driving the steps).  -> (disparity, cost, levels) on the valid grid."""
+        lb = np.ascontiguousarray(left_bgr, np.uint8); rb = np.ascontiguousarray(right_bgr, np.uint8)
+        lg = np.ascontiguousarray(left_gray, np.float32); rg = np.ascontiguousarray(right_gray, np.float32)
+        lm = np.ascontiguousarray(left_mask, np.uint8); rm = np.ascontiguousarray(right_mask, np.uint8)
+        h, w = lg.shape
+        assert lb.shape == (h, w, 3) and rb.shape == (h, w, 3) and rg.shape == (h, w) and lm.shape == (h, w) and rm.shape == (h, w)
+        init = None if init_left_disparity is None else np.ascontiguousarray(init_left_disparity, np.int16)
+        d = np.zeros((h - 6, w - 6), np.int16); c = np.zeros((h - 6, w - 6), np.uint16); lv = C.c_int(0)
+        u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8)); f32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        self._chk(self._lib.sgmhip_tsgm_match(self._h, u8(lb), u8(rb), f32(lg), f32(rg), u8(lm), u8(rm), w, h, C.c_uint(min_resolution),
+                                              None if init is None else init.ctypes.data_as(C.POINTER(C.c_int16)), n_speckle_size, subpixel_mode, subpixel_steps,
+                                              C.c_uint16(self.P1), self.P2s.ctypes.data_as(C.POINTER(C.c_uint16)), d.ctypes.data_as(C.POINTER(C.c_int16)),
+                                              c.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(lv)))
+        self._shape = d.shape
+        return d, c, int(lv.value)
 
     def FilterSpeckles(self, disparity, maxSpeckleSize=100, maxDiff=5):
         a = np.ascontiguousarray(disparity, np.int16).copy()

@@ -71,8 +71,12 @@ def match_pair(be, bgrA, camA, bgrB, camB, shared_points, min_resolution=320, su
         H2, Q2 = rectify.scale_stereo_rectification(r["H"], r["Q"], s)
         hw, hh = compute_resize((w // f, h // f), 0.5)
         init = be.Depth2DisparityMap(depth, np.linalg.inv(H2), np.linalg.inv(Q2), 1, (hw - 2 * tsgm.HW, hh - 2 * tsgm.HW))
-    disp, cost, _ = tsgm.tsgm_match(be, lb, to_gray_linear(lb), rb, to_gray_linear(rb), r["mask1"][:h, :w].copy(), r["mask2"][:h, :w].copy(),
-                                    min_resolution=min_resolution, init_left_disparity=init, subpixel_steps=subpixel_steps)
+    args = (lb, to_gray_linear(lb), rb, to_gray_linear(rb), r["mask1"][:h, :w].copy(), r["mask2"][:h, :w].copy())
+    if hasattr(be, "tsgm_match"):                                 # the device runs the whole loop in one resident call (sgmhip_tsgm_match)
+        disp, cost, _ = be.tsgm_match(args[0], args[2], args[1], args[3], args[4], args[5], min_resolution=min_resolution, init_left_disparity=init,
+                                      subpixel_steps=subpixel_steps)
+    else:
+        disp, cost, _ = tsgm.tsgm_match(be, *args, min_resolution=min_resolution, init_left_disparity=init, subpixel_steps=subpixel_steps)
     return dict(disparity=disp, cost=cost, H=r["H"], Q=r["Q"], image_size=(bgrA.shape[1], bgrA.shape[0]), subpixel_steps=subpixel_steps, seeded=init is not None)
 
 

@@ -108,3 +108,10 @@ def test_tsgm_loop_on_the_emulated_device(matcher, pm_emulated):
     case that exposed the path kernel's reliance on wave lock-step (WAVE_LOCKSTEP_POINT in sgm_kernels.hip)."""
     from tests import test_gpu_sgm_post as g
     g.test_tsgm_loop_on_the_device_equals_the_loop_on_the_oracle(matcher)
+
+
+def test_resident_tsgm_loop(matcher):
+    """sgmhip_tsgm_match: pyramids, range tables (device scan), both matches, checks, speckles, masks and refinement without leaving the device."""
+    from tests import test_gpu_sgm_post as g
+    g.test_resident_tsgm_loop_equals_the_stepwise_loop(matcher, 96, 64, 6, 32)
+    g.test_resident_tsgm_loop_equals_the_stepwise_loop(matcher, 200, 120, 7, 30)

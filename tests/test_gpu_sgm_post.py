@@ -142,3 +142,25 @@ def test_tsgm_loop_on_the_device_equals_the_loop_on_the_oracle(matcher):
     assert dev[2] == ref[2] == 3 and np.array_equal(dev[0], ref[0]) and np.array_equal(dev[1], ref[1])
     ok = dev[0] != tsgm.NO_DISP
     assert ok.mean() > 0.6 and abs(np.median(dev[0][ok] / 4.0) - d0) < 0.5
+
+
+@_first_run
+@pytest.mark.parametrize("w,h,d0,min_res", [(96, 64, 6, 32), (200, 120, 7, 30), (256, 192, 12, 64)])
+def test_resident_tsgm_loop_equals_the_stepwise_loop(matcher, w, h, d0, min_res):
+    """sgmhip_tsgm_match (the whole loop in one call, resident in HBM) against openmvs_amd/tsgm.py on the oracle backend: with masks, with and
+    without an initial disparity map, default and non-default speckle / sub-pixel options.  NOT YET RUN ON A DEVICE."""
+    from openmvs_amd import tsgm
+    from tests.tsgm_backends import OracleBackend
+    lb, lg, rg = sc.stereo_pair(w, h, d0, seed=4)
+    rb = np.roll(lb, d0, axis=1)
+    mask = np.full((h, w), 255, np.uint8); mask[:, :5] = 0; mask[h // 3:h // 3 + 9, w // 2:w // 2 + 30] = 0
+    k = tsgm.compute_scale(w, h, min_res); lw, lh = w >> k, h >> k
+    init = np.full((int(np.rint(lh * 0.5)) - 6, int(np.rint(lw * 0.5)) - 6), d0 >> (k + 1), np.int16); init[0, :3] = tsgm.NO_DISP
+    for kw in (dict(), dict(init_left_disparity=init, n_speckle_size=20, subpixel_mode=3, subpixel_steps=8)):
+        dev = matcher.tsgm_match(lb, rb, lg, rg, mask, mask, min_resolution=min_res, **kw)
+        ref = tsgm.tsgm_match(OracleBackend(), lb, lg, rb, rg, mask, mask, min_resolution=min_res, **kw)
+        assert dev[2] == ref[2] == k + 1
+        assert np.array_equal(dev[0], ref[0]) and np.array_equal(dev[1], ref[1])
+        assert (dev[0] != tsgm.NO_DISP).mean() > 0.5
+    with pytest.raises(sgm.SGMError):
+        matcher.tsgm_match(lb[:, :-1], rb[:, :-1], lg[:, :-1], rg[:, :-1], mask[:, :-1], mask[:, :-1], min_resolution=min_res)      # not a multiple of 2^levels

@@ -23,7 +23,7 @@ def pytest_pyfunc_call(pyfuncitem):
     env = dict(os.environ, OPENMVS_AMD_ISOLATED_CHILD="1")
     cmd = [sys.executable, "-m", "pytest", pyfuncitem.nodeid, "-x", "-q", "--runxfail", "-p", "no:cacheprovider"]
     try:
-        r = subprocess.run(cmd, cwd=str(pyfuncitem.config.rootpath), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        r = subprocess.run(cmd, cwd=str(pyfuncitem.config.rootpath), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
     except subprocess.TimeoutExpired:
         pytest.xfail("isolated run of %s timed out" % pyfuncitem.nodeid)
     if r.returncode != 0:

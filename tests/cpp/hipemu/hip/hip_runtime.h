@@ -362,3 +362,8 @@ template <class... P, class... A> inline void launch_args(const char* name, dim3
 }
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch_args(#kernel, dim3(grid), dim3(block), kernel, ##__VA_ARGS__)
+
+// counters for the tests (ctypes): launches, fibers run, cross-lane exchanges resolved, reads of lanes that did not take part in an exchange
+extern "C" __attribute__((weak, visibility("default"))) void hipemu_counters(uint64_t out[4]) {
+	out[0] = hipemu::launches; out[1] = hipemu::fibers_run; out[2] = hipemu::collectives; out[3] = hipemu::inactive_reads;
+}

@@ -61,3 +61,11 @@ def emulated(module, env_var, name):
             os.environ.pop(env_var, None)
         else:
             os.environ[env_var] = saved_env
+
+
+def counters(module):
+    """(launches, fibers run, cross-lane exchanges, reads of non-participating lanes) of the emulated library behind `module`."""
+    import ctypes
+    out = (ctypes.c_uint64 * 4)()
+    module.load_library().hipemu_counters(out)
+    return tuple(int(v) for v in out)

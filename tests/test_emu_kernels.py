@@ -115,3 +115,12 @@ def test_resident_tsgm_loop(matcher):
     from tests import test_gpu_sgm_post as g
     g.test_resident_tsgm_loop_equals_the_stepwise_loop(matcher, 96, 64, 6, 32)
     g.test_resident_tsgm_loop_equals_the_stepwise_loop(matcher, 200, 120, 7, 30)
+
+
+def test_zz_no_lane_ever_read_a_lane_that_was_not_there(pm_emulated, sgm_emulated):
+    """Runs last in this module: over everything above, no shuffle / DPP / readlane took its value from a lane that was not executing the same
+    operation (on the hardware such a read returns an unspecified value -- the kernels must not depend on one)."""
+    for module in (patchmatch, sgm):
+        launches, fibers, exchanges, inactive = emu.counters(module)
+        assert launches > 100 and fibers > 100000 and exchanges > 1000
+        assert inactive == 0, "%s: %d cross-lane reads of non-participating lanes" % (module.__name__, inactive)

@@ -6,7 +6,7 @@
 //
 // Templated on the reference's types so this header itself needs no OpenMVS/OpenCV include:
 //   DepthDataT must look like MVS::DepthData (libs/MVS/DepthMap.h:157-271): .images[i].{image,camera,depthMap,
-//   cameraDepthMap,GetID()}, .depthMap, .normalMap, .confMap, .dMin, .dMax; images are cv::Mat1f-like
+//   cameraDepthMap,GetID()}, .depthMap, .normalMap, .confMap, .mask (BitMatrix: empty(), isSet(r, c)), .dMin, .dMax; images are cv::Mat1f-like
 //   (.cols, .rows, .empty(), .ptr<float>()/data, isContinuous()).
 #pragma once
 #include <stdexcept>
@@ -20,7 +20,7 @@ class PatchMatchHIP {
 public:
 	struct Options : PMHipParams { Options() { pmhip_default_params(this); } };
 
-	explicit PatchMatchHIP(int device = 0) : engine_(nullptr), geom_(false) {
+	explicit PatchMatchHIP(int device = 0) : engine_(nullptr), geom_(false), ignoreMaskOption_(false) {
 		// like PatchMatchCUDA::PatchMatchCUDA (PatchMatchCUDA.cpp:46-51); IsValid() == false plays the role of
 		// "CUDA::devices.IsEmpty()" at SceneDensify.cpp:1876-1877 (the caller then releases the plug-in)
 		if (pmhip_create(device, &engine_) != PMHIP_OK) engine_ = nullptr;
@@ -32,6 +32,9 @@ public:
 	bool IsValid() const { return engine_ != nullptr; }
 	void Init(bool bGeomConsistency) { geom_ = bGeomConsistency; check(pmhip_init(engine_, bGeomConsistency ? 1 : 0)); }
 	void Release() { if (engine_) check(pmhip_release(engine_)); }
+	// OPTDENSE::nIgnoreMaskLabel >= 0 (DepthData::mask may still be empty for a view without a mask file; the option alone changes the
+	// level hand-off to INTER_NEAREST, SceneDensify.cpp:661)
+	void SetIgnoreMaskOption(bool on) { ignoreMaskOption_ = on; }
 
 	// nGeometricIter: the argument of DepthMapsData::EstimateDepthMap (SceneDensify.cpp:616), -1 for the photometric pass.
 	// The reference's PatchMatchCUDA infers it from Init(true); pass it explicitly here so the round index reaches the RNG key.
@@ -60,7 +63,14 @@ public:
 		dd.normalMap = reinterpret_cast<float*>(depthData.normalMap.data);
 		dd.confMap = depthData.confMap.template ptr<float>();
 		dd.dMin = depthData.dMin; dd.dMax = depthData.dMax;
-		check(pmhip_estimate_depth_map(engine_, &dd, &opt, geom_ ? (nGeometricIter < 0 ? 0 : nGeometricIter) : -1));
+		// DepthData::mask (BitMatrix, one bit per pixel, set = keep) as the byte mask of the C ABI
+		std::vector<unsigned char> mask;
+		if (!depthData.mask.empty()) {
+			mask.resize((size_t)w * h);
+			for (int r = 0; r < h; ++r) for (int c = 0; c < w; ++c) mask[(size_t)r * w + c] = depthData.mask.isSet(r, c) ? 255 : 0;
+		}
+		check(pmhip_estimate_depth_map_masked(engine_, &dd, mask.empty() ? nullptr : mask.data(), ignoreMaskOption_ ? 1 : 0, &opt,
+		                                      geom_ ? (nGeometricIter < 0 ? 0 : nGeometricIter) : -1));
 	}
 
 private:
@@ -71,7 +81,7 @@ private:
 		if (rc != PMHIP_OK) throw std::runtime_error(std::string("pmhip: ") + (engine_ ? pmhip_last_error(engine_) : "no device"));
 	}
 	pmhip_engine* engine_;
-	bool geom_;
+	bool geom_, ignoreMaskOption_;
 };
 
 } // namespace MVS

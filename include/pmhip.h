@@ -95,6 +95,10 @@ int pmhip_release(pmhip_engine* e);
  * nGeometricIter < 0 -> photometric pass over the pyramid; >= 0 -> that geometric round
  * (requires pmhip_init(e,1) and views[1..].depth). Blocking. */
 int pmhip_estimate_depth_map(pmhip_engine* e, PMHipDepthData* dd, const PMHipParams* p, int nGeometricIter);
+/* The same with DepthData::mask (libs/MVS/DepthMap.h:211): mask = w*h bytes, 0 = the pixel is ignored (see pmhip_scene_set_mask), or NULL.
+ * maskOption != 0 says that OPTDENSE::nIgnoreMaskLabel is set even though this view has no mask: the level hand-off then resizes the depth map
+ * with INTER_NEAREST as the reference does whenever the option is on (SceneDensify.cpp:661). */
+int pmhip_estimate_depth_map_masked(pmhip_engine* e, PMHipDepthData* dd, const unsigned char* mask, int maskOption, const PMHipParams* p, int nGeometricIter);
 const char* pmhip_last_error(pmhip_engine* e);
 
 /* ---- 2. HBM-resident scene interface ------------------------------------------------------ */

@@ -823,6 +823,10 @@ int pmhip_stats_get(pmhip_engine* e, PMHipKernelStats* out) {
 
 // PatchMatchCUDA::EstimateDepthMap(DepthData&), libs/MVS/PatchMatchCUDA.cpp:174-416 -- host buffers in, host buffers out.
 int pmhip_estimate_depth_map(pmhip_engine* e, PMHipDepthData* dd, const PMHipParams* p, int nGeometricIter) {
+	return pmhip_estimate_depth_map_masked(e, dd, nullptr, 0, p, nGeometricIter);
+}
+// ... with DepthData::mask (libs/MVS/DepthMap.h:211; filled by DepthEstimator::ImportIgnoreMask, applied in SceneDensify.cpp:656-683)
+int pmhip_estimate_depth_map_masked(pmhip_engine* e, PMHipDepthData* dd, const unsigned char* mask, int maskOption, const PMHipParams* p, int nGeometricIter) {
 	if (!e || !dd || !p || !dd->views || dd->nViews < 2 || dd->nViews > 1 + PM_MAX_SRC || !dd->depthMap || !dd->normalMap || !dd->confMap) return PMHIP_E_ARG;
 	if (!e->inited) { e->err = "pmhip_init not called"; return PMHIP_E_STATE; }
 	const int w = dd->views[0].w, h = dd->views[0].h, n = dd->nViews;
@@ -854,8 +858,15 @@ int pmhip_estimate_depth_map(pmhip_engine* e, PMHipDepthData* dd, const PMHipPar
 	}
 	int rc = pmhip_scene_set_maps(e, 0, dd->depthMap, dd->normalMap);
 	if (rc) return rc;
+	// the engine is reused between calls: install this call's mask state and leave none behind
+	rc = pmhip_scene_set_mask(e, 0, mask);
+	if (rc) return rc;
+	const int savedMode = e->maskMode;
+	e->maskMode = mask ? -1 : (maskOption ? 1 : 0);
 	const int32_t id0 = 0;
 	rc = estimateBatch(e, &id0, 1, *p, nGeometricIter);
+	e->maskMode = savedMode;
+	if (mask) pmhip_scene_set_mask(e, 0, nullptr);
 	if (rc) return rc;
 	return pmhip_scene_get_maps(e, 0, dd->depthMap, dd->normalMap, dd->confMap);
 }

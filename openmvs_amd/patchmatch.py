@@ -52,7 +52,7 @@ class PMHipFuseParams(C.Structure):
 
 
 EXPORTS = ["pmhip_scene_set_mask", "pmhip_scene_set_mask_mode", "pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
-           "pmhip_estimate_depth_map", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
+           "pmhip_estimate_depth_map", "pmhip_estimate_depth_map_masked", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
            "pmhip_scene_estimate", "pmhip_scene_commit_round", "pmhip_scene_reset_view", "pmhip_scene_set_maps",
            "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_remove_small_segments", "pmhip_scene_images_updated", "pmhip_sync",
            "pmhip_stream", "pmhip_stats_reset", "pmhip_stats_get", "pmhip_prof_get", "pmhip_math_eval", "pmhip_resize"]
@@ -119,9 +119,10 @@ class PatchMatchHIP:
             self._chk(self._lib.pmhip_release(self._h))
 
     def EstimateDepthMap(self, gray, K, R, Cc, ids, dmin, dmax, depth=None, normal=None, src_depths=None,
-                         nGeometricIter: int = -1, params: PMHipParams | None = None):
+                         nGeometricIter: int = -1, params: PMHipParams | None = None, mask=None, mask_option=False):
         """One depth map.  ids[0] = reference view, ids[1:] = sources (indices into gray/K/R/Cc).
-        src_depths: dict id -> depth map, required for a geometric round.  Returns (depth, normal, conf)."""
+        src_depths: dict id -> depth map, required for a geometric round.  mask: (h, w) uint8, 0 = ignored pixel (DepthData::mask);
+        mask_option: OPTDENSE::nIgnoreMaskLabel is set although this view has no mask.  Returns (depth, normal, conf)."""
         p = params or self.params
         n = len(ids)
         views = (PMHipView * n)()
@@ -140,7 +141,14 @@ class PatchMatchHIP:
         normal = np.zeros((h, w, 3), np.float32) if normal is None else np.ascontiguousarray(normal, np.float32).copy()
         conf = np.zeros((h, w), np.float32)
         dd = PMHipDepthData(views, n, _fp(depth), _fp(normal), _fp(conf), float(dmin), float(dmax))
-        self._chk(self._lib.pmhip_estimate_depth_map(self._h, C.byref(dd), C.byref(p), C.c_int(nGeometricIter)))
+        if mask is None and not mask_option:
+            self._chk(self._lib.pmhip_estimate_depth_map(self._h, C.byref(dd), C.byref(p), C.c_int(nGeometricIter)))
+        else:
+            m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+            if m is not None and m.shape != (h, w):
+                raise ValueError("mask must have the reference view's size")
+            self._chk(self._lib.pmhip_estimate_depth_map_masked(self._h, C.byref(dd), None if m is None else m.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                                1 if mask_option else 0, C.byref(p), C.c_int(nGeometricIter)))
         return depth, normal, conf
 
     # -- HBM-resident scene interface --------------------------------------------------------

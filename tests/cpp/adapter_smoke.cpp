@@ -18,7 +18,8 @@ struct Mat33 { double val[9]; };
 struct Pt3 { double v[3]; const double* ptr() const { return v; } };
 struct Camera { Mat33 K, R; Pt3 C; };
 struct ViewData { Mat<float> image, depthMap; Camera camera, cameraDepthMap; unsigned id = 0; unsigned GetID() const { return id; } };
-struct DepthData { std::vector<ViewData> images; Mat<float> depthMap, confMap; Mat<float, 3> normalMap; float dMin = 0, dMax = 0; };
+struct BitMatrix { std::vector<bool> bits; int rows = 0, cols = 0; bool empty() const { return bits.empty(); } bool isSet(int r, int c) const { return bits[(size_t)r * cols + c]; } };
+struct DepthData { std::vector<ViewData> images; Mat<float> depthMap, confMap; Mat<float, 3> normalMap; BitMatrix mask; float dMin = 0, dMax = 0; };
 
 int main(int argc, char** argv) {
 	if (argc < 6) return 2;

@@ -51,6 +51,7 @@ def test_estimator_single_view(engine, small_scene):
     g.test_device_resampling_matches_oracle(engine)
     g.test_single_view_photometric_parity_N4(engine, small_scene, 2)          # 3 pyramid levels, 4 source views (G = 4 lanes per pixel)
     g.test_initial_estimate_is_honoured(engine, small_scene)
+    g.test_single_call_with_ignore_mask(engine, small_scene)
 
 
 def test_estimator_group_sizes_and_geometric_pass(engine, nine_scene):

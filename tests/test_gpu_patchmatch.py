@@ -315,6 +315,30 @@ def test_ignore_mask_parity(small_scene):
     e.close()
 
 
+@pytest.mark.xfail(strict=False, reason="entry point added after the round's GPU budget was spent; passes on the CPU emulator, not yet run on a device")
+@pytest.mark.isolated
+def test_single_call_with_ignore_mask(engine, small_scene):
+    """pmhip_estimate_depth_map_masked (the PatchMatchCUDA-shaped call with DepthData::mask): with a mask, with the option but no mask, and a
+    plain call afterwards (the engine keeps no mask state between calls).  NOT YET RUN ON A DEVICE."""
+    sc = small_scene
+    engine.Init(False)
+    p = default_params(seed=5, nSubResolutionLevels=2)
+    ids = [1] + list(sc.neighbors[1])
+    mask = np.full((sc.height, sc.width), 255, np.uint8); mask[10:60, 40:100] = 0; mask[::9, ::4] = 0
+    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+    opt = po.default_opt(seed=5, viewID=1, nSubResolutionLevels=2)
+    for m, option in ((mask, False), (None, True)):
+        got = engine.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[1], sc.dmax[1], params=p, mask=m, mask_option=option)
+        want = po.estimate_depth_map_masked(views, len(ids), float(sc.dmin[1]), float(sc.dmax[1]), opt, m, mask_mode=True)
+        for k, what in enumerate(("depth", "normal", "conf")):
+            _same(got[k], want[k], "single call, mask %s: %s" % ("given" if m is not None else "option only", what))
+        if m is not None:
+            assert not got[0][m == 0].any() and (got[0][m != 0] > 0).mean() > 0.5
+    d, n, c = engine.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[1], sc.dmax[1], params=p)
+    od, on, oc = _oracle(sc, 1, 5, nSubResolutionLevels=2)
+    _same(d, od, "plain call after masked calls")
+
+
 def test_real_scene_from_mvs_archive_matches_oracle_and_sfm_points():
     """The reference's own pipeline fixture (tests/data/scene: 4 JPEGs 640x479 + MVSI archive): scene front end (reader, view selection,
     sparse initialisation) -> photometric pass + 2 geometric rounds seeded by the sparse maps.  Device == oracle bit for bit on real

@@ -14,6 +14,7 @@
 //   * __syncthreads releases when every live thread of the workgroup is parked at a barrier;
 //   * atomics are plain read-modify-writes (fibers never run concurrently); "device memory" is host memory, filled with 0xCD.. on allocation so that
 //     reads of never-written memory show up as garbage rather than as zeros.
+//   * HIPEMU_ORDER=reverse|stride changes the order in which lanes and workgroups run: results must not depend on it (necessary for freedom of races).
 // What it cannot show: races between workgroups or waves that run concurrently on the hardware, memory-ordering bugs, and anything that depends on
 // the hardware's wave lock-step outside the operations listed above (code relying on that without a barrier fails here -- deliberately).
 #pragma once
@@ -154,6 +155,21 @@ inline void resolve_group(std::vector<Fiber*>& g) {           // lanes of one wa
 	++collectives;
 }
 
+// Execution order of the lanes of a workgroup and of the workgroups of a grid: HIPEMU_ORDER = forward (default) | reverse | stride (a fixed
+// permutation i -> i * 7919 mod n, applied when n is not a multiple of 7919).  A kernel that is free of races gives the same result under every order.
+inline int order_mode() {
+	static int m = -1;
+	if (m < 0) { const char* e = getenv("HIPEMU_ORDER"); m = !e ? 0 : (!strcmp(e, "reverse") ? 1 : (!strcmp(e, "stride") ? 2 : 0)); }
+	return m;
+}
+inline uint64_t permute(uint64_t i, uint64_t n) {
+	switch (order_mode()) {
+	case 1: return n - 1 - i;
+	case 2: return n % 7919 ? (i * 7919) % n : i;
+	default: return i;
+	}
+}
+
 struct StackPool {
 	std::vector<char*> stacks; size_t size = 256 * 1024;
 	char* get(size_t i) { while (stacks.size() <= i) stacks.push_back((char*)malloc(size)); return stacks[i]; }
@@ -177,8 +193,8 @@ inline void run_block(const std::function<void()>& body) {
 	std::vector<Fiber*> group;
 	for (;;) {
 		bool progressed = false; unsigned alive = 0;
-		for (unsigned t = 0; t < nT; ++t) {
-			Fiber& f = fibers[t];
+		for (unsigned i = 0; i < nT; ++i) {
+			Fiber& f = fibers[permute(i, nT)];
 			if (f.state != 0) continue;
 			cur = &f; hipemu_switch(&sched_sp, f.sp); cur = nullptr;
 			progressed = true;
@@ -210,7 +226,12 @@ template <class F> inline void launch(const char* name, dim3 grid, dim3 block, F
 	if (!grid.x || !grid.y || !grid.z || !block.x || !block.y || !block.z) die("empty launch");
 	if ((uint64_t)block.x * block.y * block.z > 1024) die("block larger than 1024 threads");
 	const std::function<void()> body(f);
-	for (unsigned z = 0; z < grid.z; ++z) for (unsigned y = 0; y < grid.y; ++y) for (unsigned x = 0; x < grid.x; ++x) { g_blockIdx = dim3(x, y, z); run_block(body); }
+	const uint64_t nB = (uint64_t)grid.x * grid.y * grid.z;
+	for (uint64_t i = 0; i < nB; ++i) {
+		const uint64_t b = permute(i, nB);
+		g_blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((uint64_t)grid.x * grid.y)));
+		run_block(body);
+	}
 }
 
 template <class T> inline uint64_t bits(T v) { static_assert(sizeof(T) <= 8, ""); uint64_t u = 0; memcpy(&u, &v, sizeof(T)); return u; }

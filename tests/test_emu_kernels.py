@@ -5,6 +5,10 @@ that sit on the emulated libraries -- same inputs, same assertions, smaller sele
 What this establishes in the CPU suite: the kernels' arithmetic AND their launch geometry, index math, cross-lane exchanges (shuffles, ballots,
 DPP), LDS staging, atomics, and the host orchestration between launches are bit-exact with the oracle, and no launch writes outside its buffers
 (guard bands around every device allocation).  What it cannot establish is listed in the emulator's header; the device run remains the gate."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -125,3 +129,17 @@ def test_zz_no_lane_ever_read_a_lane_that_was_not_there(pm_emulated, sgm_emulate
         launches, fibers, exchanges, inactive = emu.counters(module)
         assert launches > 100 and fibers > 100000 and exchanges > 1000
         assert inactive == 0, "%s: %d cross-lane reads of non-participating lanes" % (module.__name__, inactive)
+
+
+@pytest.mark.parametrize("order", ["reverse", "stride"])
+def test_results_do_not_depend_on_the_execution_order(order):
+    """The same checks with the lanes of every workgroup and the workgroups of every grid executed in another order (HIPEMU_ORDER): kernels free of
+    races -- in particular the reservation rounds of the fusion, the union-find of the segment / speckle filters, the atomic splats -- give the
+    same bits.  (The whole module passes under both orders; a quick selection runs here.)"""
+    if os.environ.get("HIPEMU_ORDER"):
+        pytest.skip("already inside a permuted run")
+    env = dict(os.environ, HIPEMU_ORDER=order)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "test_fusion or test_sgm_steps or test_sgm_match or test_estimator_odd_sizes"],
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]

@@ -19,3 +19,16 @@ for kind, lo, hi in (("uniform", 0, 64), ("uniform", 0, 128), ("ragged", 0, 64))
     gb = 43.0 * n / 1e9
     print("%s D<=%d numCosts %.1fM: %.2f ms/match (cost %.2f aggr %.2f wta %.2f) -> %.1f GB/s on the 43 B/cost model (aggr alone: %.1f GB/s of 40 B/cost)" % (
         kind, hi - lo, n / 1e6, dt * 1e3, s.costMs / reps, s.aggrMs / reps, s.wtaMs / reps, gb / dt, 40.0 * n / 1e9 / (s.aggrMs / reps / 1e3)), flush=True)
+
+# the whole coarse-to-fine loop for a rectified pair: one resident call vs the step-wise loop through host buffers
+from openmvs_amd import tsgm
+from openmvs_amd.patchmatch import PatchMatchHIP
+from tests.tsgm_backends import DeviceBackend
+rb = np.roll(lb, 21, axis=1)
+mask = np.full((h, w), 255, np.uint8)
+m.tsgm_match(lb, rb, lg, rg, mask, mask, min_resolution=320)
+t = time.time(); d1, c1, lv = m.tsgm_match(lb, rb, lg, rg, mask, mask, min_resolution=320); t1 = time.time() - t
+e = PatchMatchHIP(0)
+t = time.time(); d2, c2, _ = tsgm.tsgm_match(DeviceBackend(m, e), lb, lg, rb, rg, mask, mask, min_resolution=320); t2 = time.time() - t
+print("tSGM %dx%d, %d levels: resident call %.1f ms, step-wise loop %.1f ms, identical: %s, valid %.3f" % (
+    w, h, lv, t1 * 1e3, t2 * 1e3, bool(np.array_equal(d1, d2) and np.array_equal(c1, c2)), float((d1 != 32767).mean())), flush=True)

@@ -5,7 +5,8 @@
 # 2. the whole -m gpu suite as the driver runs it;
 # 3. bench.py (default workload) plain and under rocprofv3 --kernel-trace --stats;
 # 4. one SQ_* counter pass on a reduced workload (own run, no trace domains), under a short timeout;
-# 5. the residency variants of the sweep kernel.
+# 5. the residency variants of the sweep kernel;
+# 6. SGM timings: Match at 2048x1536 and the whole tSGM loop, resident call vs step-wise.
 # Everything lands in gpurun_out/r02_first/; copy what is to be judged into profiles/.
 set -u
 OUT=gpurun_out/r02_first; mkdir -p "$OUT"
@@ -39,4 +40,6 @@ build_variant("libpmhip.so", "libpmhip_tr16.so", ["-DPM_TR=16"])
 build_variant("libpmhip.so", "libpmhip_tr16_w4.so", ["-DPM_TR=16", "-DPM_MINWAVES=4"])
 PY
 timeout 900 python tools/tune.py 100 libpmhip.so:2 libpmhip_tr16.so:2 libpmhip_tr16_w4.so:2 libpmhip_tr16.so:3 > "$OUT/5_variants.log" 2>&1; tail -8 "$OUT/5_variants.log"
+step "6 sgm probe"
+timeout 600 python tools/probe_sgm.py > "$OUT/6_sgm_probe.log" 2>&1; tail -5 "$OUT/6_sgm_probe.log"
 step "done"

@@ -95,6 +95,12 @@ int sgmhip_project_disparity2depth_map(sgmhip_engine* e, const int16_t* disparit
 int sgmhip_fuse_pairs(sgmhip_engine* e, const float* const* depthMaps, const float* const* depthRangeMaps, const float* const* confMaps, int nPairs,
                       int dw, int dh, unsigned minViews, float* depthMap, float* confMap);
 
+/* SemiGlobalMatcher::Fuse (:738-859) in one call for nPairs <= 16 pairs that have the reference image on the left: every pair's disparity / cost maps (valid grid
+ * widths[p] x heights[p], Q = Qs + 16 p, subpixelSteps[p] -- the content of its .dimap) are projected into the reference image (dw x dh) and fused per pixel;
+ * pairs that produce no depth are dropped; nUsed (nullable) = pairs that took part.  The per-pair depth / range / confidence maps stay on the device. */
+int sgmhip_fuse_disparities(sgmhip_engine* e, int nPairs, const int16_t* const* disparities, const uint16_t* const* costs, const int* widths, const int* heights,
+                            const double* Qs, const int* subpixelSteps, int dw, int dh, unsigned minViews, float* depthMap, float* confMap, int* nUsed);
+
 /* cv::filterSpeckles(disparityMap, NO_DISP, maxSpeckleSize, maxDiff) as the tSGM loop applies it on the first level (:687-688; OPTDENSE::nSpeckleSize,
  * 5): 4-connected regions of disparities differing by <= maxDiff step to step that have at most maxSpeckleSize pixels become NO_DISP. */
 int sgmhip_filter_speckles(sgmhip_engine* e, int16_t* disparity, int w, int h, int maxSpeckleSize, int maxDiff);

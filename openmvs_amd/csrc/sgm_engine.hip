@@ -368,6 +368,48 @@ int sgmhip_fuse_pairs(sgmhip_engine* e, const float* const* depthMaps, const flo
 	return 0;
 }
 
+// SemiGlobalMatcher::Fuse (:738-859) for pairs that have the reference image on the left, resident: ProjectDisparity2DepthMap of every pair, pairs that
+// produce no depth are dropped (:779-782), then the per-pixel cluster fusion -- the per-pair maps never leave the device.
+int sgmhip_fuse_disparities(sgmhip_engine* e, int nPairs, const int16_t* const* disparities, const uint16_t* const* costs, const int* widths, const int* heights,
+		const double* Qs, const int* subpixelSteps, int dw, int dh, unsigned minViews, float* depthMap, float* confMap, int* nUsed) {
+	if (!e || nPairs < 0 || nPairs > SGMP_MAX_PAIRS || (nPairs && (!disparities || !costs || !widths || !heights || !Qs || !subpixelSteps)) || dw <= 0 || dh <= 0 || !depthMap || !confMap) return SGMHIP_E_ARG;
+	SGMCHK(e, hipSetDevice(e->device));
+	hipStream_t st = e->stream;
+	const size_t nd = (size_t)dw * dh;
+	std::vector<DevBuf> maps((size_t)nPairs * 3);
+	DevBuf k, cnt, d, c;
+	SGMCHK(e, k.alloc(nd * 4 * 8)); SGMCHK(e, cnt.alloc(4 * (size_t)std::max(nPairs, 1))); SGMCHK(e, d.alloc(nd * 4)); SGMCHK(e, c.alloc(nd * 4));
+	SGMCHK(e, hipMemsetAsync(cnt.p, 0, 4 * (size_t)std::max(nPairs, 1), st));
+	std::vector<DevBuf> in((size_t)nPairs * 2);
+	for (int p = 0; p < nPairs; ++p) {
+		const int w = widths[p], h = heights[p];
+		if (!disparities[p] || !costs[p] || w <= 0 || h <= 0 || subpixelSteps[p] <= 0 || (size_t)w * h > 0xFFFFFFFFull) return SGMHIP_E_ARG;
+		const size_t n = (size_t)w * h;
+		SGMCHK(e, in[p * 2].alloc(n * 2)); SGMCHK(e, in[p * 2 + 1].alloc(n * 2));
+		SGMCHK(e, maps[p * 3].alloc(nd * 4)); SGMCHK(e, maps[p * 3 + 1].alloc(nd * 8)); SGMCHK(e, maps[p * 3 + 2].alloc(nd * 4));
+		SGMCHK(e, hipMemcpyAsync(in[p * 2].p, disparities[p], n * 2, hipMemcpyHostToDevice, st)); SGMCHK(e, hipMemcpyAsync(in[p * 2 + 1].p, costs[p], n * 2, hipMemcpyHostToDevice, st));
+		SGMCHK(e, hipMemsetAsync(maps[p * 3 + 1].p, 0, nd * 8, st));
+		SGMPMat mq{}; memcpy(mq.m, Qs + 16 * p, 128);
+		hipLaunchKernelGGL(sgmp_fill_u64, dim3(gridFor(nd * 4)), dim3(256), 0, st, (unsigned long long*)k.p, nd * 4, SGMP_KEY_NONE);
+		hipLaunchKernelGGL(sgmp_proj_splat_kernel, dim3(gridFor(n)), dim3(256), 0, st, (const int16_t*)in[p * 2].p, (const uint16_t*)in[p * 2 + 1].p, w, h, mq, subpixelSteps[p], (unsigned long long*)k.p, dw, dh);
+		hipLaunchKernelGGL(sgmp_proj_resolve_kernel, dim3(gridFor(nd)), dim3(256), 0, st, (const int16_t*)in[p * 2].p, (const uint16_t*)in[p * 2 + 1].p, w, mq, subpixelSteps[p],
+			(const unsigned long long*)k.p, dw, dh, (float*)maps[p * 3].p, (float*)maps[p * 3 + 1].p, (float*)maps[p * 3 + 2].p, (unsigned*)cnt.p + p);
+	}
+	std::vector<unsigned> num((size_t)std::max(nPairs, 1), 0u);
+	if (nPairs) SGMCHK(e, hipMemcpyAsync(num.data(), cnt.p, 4 * (size_t)nPairs, hipMemcpyDeviceToHost, st));
+	SGMCHK(e, hipStreamSynchronize(st));
+	SGMPPairs pr{}; int used = 0;
+	for (int p = 0; p < nPairs; ++p) if (num[p] > 0) { pr.depth[used] = (const float*)maps[p * 3].p; pr.range[used] = (const float*)maps[p * 3 + 1].p; pr.conf[used] = (const float*)maps[p * 3 + 2].p; ++used; }
+	if (nUsed) *nUsed = used;
+	if (used == 0) { memset(depthMap, 0, nd * 4); memset(confMap, 0, nd * 4); return 0; }
+	hipLaunchKernelGGL(sgmp_fuse_pairs_kernel, dim3(gridFor(nd)), dim3(256), 0, st, pr, used, nd, minViews, (float*)d.p, (float*)c.p);
+	SGMCHK(e, hipGetLastError());
+	SGMCHK(e, hipMemcpyAsync(depthMap, d.p, nd * 4, hipMemcpyDeviceToHost, st));
+	SGMCHK(e, hipMemcpyAsync(confMap, c.p, nd * 4, hipMemcpyDeviceToHost, st));
+	SGMCHK(e, hipStreamSynchronize(st));
+	return 0;
+}
+
 int sgmhip_filter_speckles(sgmhip_engine* e, int16_t* disparity, int w, int h, int maxSpeckleSize, int maxDiff) {
 	if (!e || !disparity || w <= 0 || h <= 0 || maxSpeckleSize < 0 || maxDiff < 0 || (size_t)w * h > 0x7fffffffull) return SGMHIP_E_ARG;
 	SGMCHK(e, hipSetDevice(e->device));

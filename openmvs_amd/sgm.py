@@ -14,7 +14,7 @@ EXPORTS = ["sgmhip_create", "sgmhip_destroy", "sgmhip_last_error", "sgmhip_gener
            "sgmhip_match", "sgmhip_get_results", "sgmhip_sync", "sgmhip_stats_reset", "sgmhip_stats_get",
            "sgmhip_consistency_cross_check", "sgmhip_filter_by_cost", "sgmhip_extract_mask", "sgmhip_upscale_mask", "sgmhip_flip_direction",
            "sgmhip_refine_disparity", "sgmhip_disparity2range_map", "sgmhip_depth2disparity_map", "sgmhip_disparity2depth_map",
-           "sgmhip_project_disparity2depth_map", "sgmhip_fuse_pairs", "sgmhip_filter_speckles", "sgmhip_set_disparity", "sgmhip_tsgm_match"]
+           "sgmhip_project_disparity2depth_map", "sgmhip_fuse_pairs", "sgmhip_filter_speckles", "sgmhip_set_disparity", "sgmhip_tsgm_match", "sgmhip_fuse_disparities"]
 NO_DISP = 32767          # SemiGlobalMatcher::NO_DISP
 INVALID, VALID = 0, 255  # MaskMap values
 SUBPIXEL_NA, SUBPIXEL_LINEAR, SUBPIXEL_POLY4, SUBPIXEL_PARABOLA, SUBPIXEL_SINE, SUBPIXEL_COSINE, SUBPIXEL_LC_BLEND = range(7)
@@ -198,6 +198,21 @@ class SemiGlobalMatcherHIP:
                                               c.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(lv)))
         self._shape = d.shape
         return d, c, int(lv.value)
+
+    def fuse_disparities(self, pairs, size, minViews=2):
+        """SemiGlobalMatcher::Fuse in one resident call.  pairs: dicts with disparity, cost, Q, subpixel_steps (the .dimap content); size = (w, h) of
+        the reference image.  -> (depthMap, confMap, number of pairs that produced depths)."""
+        n = len(pairs); dw, dh = size
+        ds = [np.ascontiguousarray(p["disparity"], np.int16) for p in pairs]; cs = [np.ascontiguousarray(p["cost"], np.uint16) for p in pairs]
+        dp = (C.POINTER(C.c_int16) * max(n, 1))(*[a.ctypes.data_as(C.POINTER(C.c_int16)) for a in ds])
+        cp = (C.POINTER(C.c_uint16) * max(n, 1))(*[a.ctypes.data_as(C.POINTER(C.c_uint16)) for a in cs])
+        ws = (C.c_int * max(n, 1))(*[a.shape[1] for a in ds]); hs = (C.c_int * max(n, 1))(*[a.shape[0] for a in ds])
+        qs = np.ascontiguousarray(np.stack([np.asarray(p["Q"], np.float64).reshape(16) for p in pairs]) if n else np.zeros((1, 16)), np.float64)
+        st = (C.c_int * max(n, 1))(*[int(p["subpixel_steps"]) for p in pairs])
+        dep = np.zeros((dh, dw), np.float32); cf = np.zeros((dh, dw), np.float32); used = C.c_int(0)
+        self._chk(self._lib.sgmhip_fuse_disparities(self._h, n, dp, cp, ws, hs, qs.ctypes.data_as(C.POINTER(C.c_double)), st, dw, dh, C.c_uint(minViews),
+                                                    dep.ctypes.data_as(C.POINTER(C.c_float)), cf.ctypes.data_as(C.POINTER(C.c_float)), C.byref(used)))
+        return dep, cf, int(used.value)
 
     def FilterSpeckles(self, disparity, maxSpeckleSize=100, maxDiff=5):
         a = np.ascontiguousarray(disparity, np.int16).copy()

@@ -83,6 +83,9 @@ def match_pair(be, bgrA, camA, bgrB, camB, shared_points, min_resolution=320, su
 def fuse_pairs(be, pairs, min_views=2):
     """`SemiGlobalMatcher::Fuse` for pairs that all have the reference image on the left: ProjectDisparity2DepthMap per pair, then the per-pixel
     cluster fusion.  -> (depth map, confidence map) of the reference image."""
+    if hasattr(be, "fuse_disparities") and pairs:                 # the device does it in one resident call (sgmhip_fuse_disparities)
+        dep, cf, _ = be.fuse_disparities(pairs, pairs[0]["image_size"], min_views)
+        return dep, cf
     deps, rgs, cfs = [], [], []
     for p in pairs:
         ok, dep, rg, cf = be.ProjectDisparity2DepthMap(p["disparity"], p["cost"], p["Q"], p["subpixel_steps"], p["image_size"])

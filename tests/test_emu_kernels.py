@@ -106,6 +106,8 @@ def test_sgm_steps(matcher):
         g.test_disparity_depth_conversions_match_the_oracle(matcher, w, h, seed)
         g.test_projection_and_pair_fusion_match_the_oracle(matcher, w, h, seed)
     g.test_filter_speckles_matches_the_oracle(matcher)
+    g.test_resident_fuse_equals_the_stepwise_fuse(matcher, 64, 40, 0)
+    g.test_resident_fuse_equals_the_stepwise_fuse(matcher, 97, 53, 1)
 
 
 def test_tsgm_loop_on_the_emulated_device(matcher, pm_emulated):

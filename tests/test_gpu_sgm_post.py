@@ -164,3 +164,36 @@ def test_resident_tsgm_loop_equals_the_stepwise_loop(matcher, w, h, d0, min_res)
         assert (dev[0] != tsgm.NO_DISP).mean() > 0.5
     with pytest.raises(sgm.SGMError):
         matcher.tsgm_match(lb[:, :-1], rb[:, :-1], lg[:, :-1], rg[:, :-1], mask[:, :-1], mask[:, :-1], min_resolution=min_res)      # not a multiple of 2^levels
+
+
+@_first_run
+@pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (97, 53, 1)])
+def test_resident_fuse_equals_the_stepwise_fuse(matcher, w, h, seed):
+    """sgmhip_fuse_disparities (projection of every pair + per-pixel fusion in one resident call) against the same steps on the oracle backend;
+    pairs of different valid-grid sizes and sub-pixel steps, one pair that produces no depth.  NOT YET RUN ON A DEVICE."""
+    from openmvs_amd import sgm_pipeline
+    from tests.tsgm_backends import OracleBackend
+    H, Q, iH, iQ = pc.rectification(seed)
+    r = np.random.RandomState(seed + 3)
+    pairs = []
+    for k, steps in enumerate((1, 4, 4, 2)):
+        depth = (3.0 + 0.4 * np.sin(np.arange(h * w).reshape(h, w) / (40.0 + 7 * k)) + 0.02 * k).astype(np.float32)
+        depth[r.rand(h, w) < 0.15] = 0
+        vw, vh = (w - 6, h - 6) if k != 2 else (w - 10, h - 9)                       # a pair rectified to a smaller grid
+        disp = po.sgm_depth2disparity_map(depth, np.eye(3), iQ, steps, (vw, vh))
+        if k == 3:
+            disp[:] = tsgm_no_disp()                                                  # nothing to project: the pair must be dropped
+        pairs.append(dict(disparity=disp, cost=pc.cost_map(vw, vh, seed + k), Q=Q, subpixel_steps=steps, image_size=(w, h)))
+    for mv in (1, 2, 3):
+        want_d, want_c = sgm_pipeline.fuse_pairs(OracleBackend(), pairs, mv)
+        got_d, got_c, used = matcher.fuse_disparities(pairs, (w, h), mv)
+        assert used == 3
+        assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32)) and np.array_equal(got_c.view(np.uint32), want_c.view(np.uint32))
+        assert mv > 1 or (got_d > 0).mean() > 0.3
+    d0, c0, used = matcher.fuse_disparities(pairs[3:], (w, h), 1)
+    assert used == 0 and not d0.any() and not c0.any()
+
+
+def tsgm_no_disp():
+    from openmvs_amd import tsgm
+    return tsgm.NO_DISP

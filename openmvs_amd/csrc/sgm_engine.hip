@@ -1,6 +1,7 @@
 // sgm_engine.hip -- host side of libsgmhip.so (include/sgmhip.h).
 #include "../../include/sgmhip.h"
 #include "sgm_kernels.hip"
+#include "sgm_kernels_sub.hip"
 #include "sgm_post.hip"
 #include "sgm_tsgm.hip"
 #include <math.h>
@@ -19,6 +20,7 @@ struct sgmhip_engine {
 	SGMPixel* d_pixels = nullptr; unsigned char* d_costs = nullptr; unsigned short* d_accums = nullptr; float4* d_setup = nullptr;
 	short* d_disp = nullptr; unsigned short* d_cost = nullptr; unsigned short* d_P2s = nullptr;
 	bool statsOn = false; SGMHipStats stats{};
+	bool subGroups = false;       // Match with the sub-group kernels of sgm_kernels_sub.hip (narrow, ragged ranges); see sgmhip_set_sub_group_kernels
 	struct Ev { hipEvent_t a, b; int kind; }; std::vector<Ev> events;
 };
 
@@ -115,7 +117,54 @@ int sgmhip_match(sgmhip_engine* e, uint16_t P1, const uint16_t P2s[256], int syn
 	return 0;
 }
 // cost volume, 8-path aggregation and winner-take-all of the resident problem (P2s already on the device), asynchronous on the engine's stream
+// sub-group variant: 16 lanes per pixel / pair / line
+static int sgmMatchSub(sgmhip_engine* e, uint16_t P1) {
+	constexpr int LP = 16, PW = 64 / LP;
+	const long nPix = (long)e->vw * e->vh;
+	const int W = e->vw, H = e->vh;
+	evB(e, 0);
+	hipLaunchKernelGGL(sgm_setup_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->w, W, H, e->d_pixels, e->d_setup);
+	const long nPairs = (long)((W + 1) / 2) * H;
+	hipLaunchKernelGGL((sgm_cost_sub_kernel<LP>), dim3((unsigned)((nPairs + 4 * PW - 1) / (4 * PW))), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_setup, e->d_costs);
+	evE(e);
+	SGMCHK(e, hipMemsetAsync(e->d_accums, 0, (e->numCosts + 1) / 2 * 4, e->stream));
+	struct Dir { int dx, dy; SGMLines ln; } dirs[8] = {
+		{0, 1,   {W, 0, 0, 1, 0,      0, 0, 0, 0, 0}},
+		{1, 0,   {H, 0, 0, 0, 1,      0, 0, 0, 0, 0}},
+		{0, -1,  {W, 0, H - 1, 1, 0,  0, 0, 0, 0, 0}},
+		{-1, 0,  {H, W - 1, 0, 0, 1,  0, 0, 0, 0, 0}},
+		{1, 1,   {W, 0, 0, 1, 0,      H - 1, 0, 1, 0, 1}},
+		{-1, 1,  {W - 1, 0, 0, 1, 0,  H, W - 1, 0, 0, 1}},
+		{1, -1,  {W - 1, 1, H - 1, 1, 0,  H, 0, 0, 0, 1}},
+		{-1, -1, {W, 0, H - 1, 1, 0,  H - 1, W - 1, 0, 0, 1}},
+	};
+	const int horizFirst[8] = {1, 3, 0, 2, 4, 5, 6, 7}, vertFirst[8] = {0, 2, 1, 3, 4, 5, 6, 7};
+	const int* ord = W >= H ? horizFirst : vertFirst;
+	SGMDirs sd; memset(&sd, 0, sizeof(sd));
+	int total = 0;                                                     // in workgroups: PW lines each
+	for (int i = 0; i < 8; ++i) {
+		const Dir& d = dirs[ord[i]];
+		sd.dx[i] = d.dx; sd.dy[i] = d.dy; sd.ln[i] = d.ln; sd.first[i] = total;
+		total += (d.ln.nA + d.ln.nB + PW - 1) / PW;
+	}
+	sd.first[8] = total;
+	evB(e, 1);
+	if (total > 0) {
+		if (e->maxNumDisp <= 64) hipLaunchKernelGGL((sgm_path_sub_kernel<LP, 64>), dim3(total), dim3(64), 0, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, (int)P1, sd);
+		else hipLaunchKernelGGL((sgm_path_sub_kernel<LP, 256>), dim3(total), dim3(64), 0, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, (int)P1, sd);
+	}
+	if (e->statsOn) e->stats.aggrLaunches += 1;
+	evE(e);
+	evB(e, 2);
+	hipLaunchKernelGGL((sgm_wta_sub_kernel<LP>), dim3((unsigned)((nPix + 4 * PW - 1) / (4 * PW))), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, e->d_cost);
+	evE(e);
+	SGMCHK(e, hipGetLastError());
+	if (e->statsOn) e->stats.calls += 1;
+	return 0;
+}
+
 static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
+	if (e->subGroups) return sgmMatchSub(e, P1);
 	const long nPix = (long)e->vw * e->vh;
 	const int W = e->vw, H = e->vh;
 	evB(e, 0);
@@ -170,6 +219,7 @@ int sgmhip_get_results(sgmhip_engine* e, int16_t* disparity, uint16_t* cost, uin
 	SGMCHK(e, hipStreamSynchronize(e->stream));
 	return 0;
 }
+int sgmhip_set_sub_group_kernels(sgmhip_engine* e, int on) { if (!e) return SGMHIP_E_ARG; e->subGroups = on != 0; return 0; }
 int sgmhip_sync(sgmhip_engine* e) { if (!e) return SGMHIP_E_ARG; SGMCHK(e, hipSetDevice(e->device)); SGMCHK(e, hipStreamSynchronize(e->stream)); return 0; }
 int sgmhip_stats_reset(sgmhip_engine* e, int enable) { if (!e) return SGMHIP_E_ARG; hipSetDevice(e->device); sgmCollect(e); memset(&e->stats, 0, sizeof(e->stats)); e->statsOn = enable != 0; return 0; }
 int sgmhip_stats_get(sgmhip_engine* e, SGMHipStats* out) { if (!e || !out) return SGMHIP_E_ARG; hipSetDevice(e->device); int rc = sgmCollect(e); if (rc) return rc; *out = e->stats; return 0; }
@@ -497,7 +547,12 @@ int sgmhip_tsgm_match(sgmhip_engine* e, const uint8_t* leftBGR, const uint8_t* r
 		SGMCHK(e, hipMemcpyAsync(e->d_color, bgr, nImg * 3, hipMemcpyDeviceToDevice, st));
 		SGMCHK(e, hipMemcpyAsync(e->d_grayL, gA, nImg * 4, hipMemcpyDeviceToDevice, st));
 		SGMCHK(e, hipMemcpyAsync(e->d_grayR, gB, nImg * 4, hipMemcpyDeviceToDevice, st));
-		{ const int rc = sgmMatch(e, P1); if (rc) return rc; }
+		// narrow ranges (every level but the first): 16-lane sub-groups; wide ranges: one wavefront per pixel / line
+		const bool saved = e->subGroups;
+		e->subGroups = saved || numCosts <= (uint64_t)n2 * 24;
+		const int rcm = sgmMatch(e, P1);
+		e->subGroups = saved;
+		if (rcm) return rcm;
 		SGMCHK(e, hipMemcpyAsync(out, e->d_disp, n2 * 2, hipMemcpyDeviceToDevice, st));
 		return 0;
 	};

@@ -14,7 +14,7 @@ EXPORTS = ["sgmhip_create", "sgmhip_destroy", "sgmhip_last_error", "sgmhip_gener
            "sgmhip_match", "sgmhip_get_results", "sgmhip_sync", "sgmhip_stats_reset", "sgmhip_stats_get",
            "sgmhip_consistency_cross_check", "sgmhip_filter_by_cost", "sgmhip_extract_mask", "sgmhip_upscale_mask", "sgmhip_flip_direction",
            "sgmhip_refine_disparity", "sgmhip_disparity2range_map", "sgmhip_depth2disparity_map", "sgmhip_disparity2depth_map",
-           "sgmhip_project_disparity2depth_map", "sgmhip_fuse_pairs", "sgmhip_filter_speckles", "sgmhip_set_disparity", "sgmhip_tsgm_match", "sgmhip_fuse_disparities"]
+           "sgmhip_project_disparity2depth_map", "sgmhip_fuse_pairs", "sgmhip_filter_speckles", "sgmhip_set_disparity", "sgmhip_tsgm_match", "sgmhip_fuse_disparities", "sgmhip_set_sub_group_kernels"]
 NO_DISP = 32767          # SemiGlobalMatcher::NO_DISP
 INVALID, VALID = 0, 255  # MaskMap values
 SUBPIXEL_NA, SUBPIXEL_LINEAR, SUBPIXEL_POLY4, SUBPIXEL_PARABOLA, SUBPIXEL_SINE, SUBPIXEL_COSINE, SUBPIXEL_LC_BLEND = range(7)
@@ -85,6 +85,10 @@ class SemiGlobalMatcherHIP:
         self._shape = (h - 6, w - 6); self._num = num_costs
         self._chk(self._lib.sgmhip_set_problem(self._h, lb.ctypes.data_as(C.POINTER(C.c_uint8)), lg.ctypes.data_as(C.POINTER(C.c_float)),
                                                rg.ctypes.data_as(C.POINTER(C.c_float)), w, h, px.ctypes.data_as(C.c_void_p), C.c_uint64(num_costs), max_num_disp))
+
+    def set_sub_group_kernels(self, on: bool):
+        """Match with 16-lane sub-groups (narrow tSGM ranges) instead of one wavefront per pixel / line; same results."""
+        self._chk(self._lib.sgmhip_set_sub_group_kernels(self._h, 1 if on else 0))
 
     def Match(self, sync=True):
         self._chk(self._lib.sgmhip_match(self._h, C.c_uint16(self.P1), self.P2s.ctypes.data_as(C.POINTER(C.c_uint16)), 1 if sync else 0))

@@ -56,6 +56,22 @@ def test_match_parity_across_long_invalid_runs(matcher):
     _check(matcher, lb, lg, rg, px, n, mx)
 
 
+@pytest.mark.xfail(strict=False, reason="kernels added after the round's GPU budget was spent; pass on the CPU emulator, not yet run on a device")
+@pytest.mark.isolated
+@pytest.mark.parametrize("w,h,kind,dmin,dmax", [(96, 64, "uniform", 0, 16), (97, 65, "ragged", -5, 40), (128, 80, "ragged", -4, 60), (70, 150, "ragged", -3, 30),
+                                               (120, 90, "ragged", 0, 200), (203, 71, "uniform", 0, 70), (230, 100, "holes", -2, 12)])
+def test_sub_group_kernels_match_parity(matcher, w, h, kind, dmin, dmax):
+    """The 16-lanes-per-pixel mapping of cost volume, path aggregation and WTA (csrc/sgm_kernels_sub.hip, the one the resident tSGM loop uses for
+    narrow ranges): the same integer-exact parity as the wide kernels, ranges narrower and wider than a sub-group.  NOT YET RUN ON A DEVICE."""
+    lb, lg, rg = sc.stereo_pair(w, h, 5, seed=w)
+    px, n, mx = sc.ranges(w, h, kind, dmin, dmax, seed=h)
+    matcher.set_sub_group_kernels(True)
+    try:
+        _check(matcher, lb, lg, rg, px, n, mx)
+    finally:
+        matcher.set_sub_group_kernels(False)
+
+
 def test_tiny_and_degenerate(matcher):
     lb, lg, rg = sc.stereo_pair(8, 8, 0)
     px, n, mx = sc.ranges(8, 8, "uniform", -1, 2)

@@ -20,6 +20,22 @@ for kind, lo, hi in (("uniform", 0, 64), ("uniform", 0, 128), ("ragged", 0, 64))
     print("%s D<=%d numCosts %.1fM: %.2f ms/match (cost %.2f aggr %.2f wta %.2f) -> %.1f GB/s on the 43 B/cost model (aggr alone: %.1f GB/s of 40 B/cost)" % (
         kind, hi - lo, n / 1e6, dt * 1e3, s.costMs / reps, s.aggrMs / reps, s.wtaMs / reps, gb / dt, 40.0 * n / 1e9 / (s.aggrMs / reps / 1e3)), flush=True)
 
+# narrow tSGM-like ranges (3..12 disparities per pixel): the wide mapping against the 16-lane sub-group mapping
+px, n, mx = sc.ranges(w, h, "ragged", 0, 12)
+m.set_problem(lb, lg, rg, px, n, mx)
+for sub in (False, True):
+    m.set_sub_group_kernels(sub)
+    m.Match()
+    d_ref = m.results()[0] if not sub else d_ref
+    same = bool(np.array_equal(m.results()[0], d_ref))
+    m.stats_reset(True); t = time.time()
+    for _ in range(4): m.Match(sync=False)
+    m.sync(); dt = (time.time() - t) / 4
+    s = m.stats_get()
+    print("narrow ranges numCosts %.1fM, %s kernels: %.2f ms/match (cost %.2f aggr %.2f wta %.2f)%s" % (
+        n / 1e6, "sub-group" if sub else "wide", dt * 1e3, s.costMs / 4, s.aggrMs / 4, s.wtaMs / 4, "" if not sub else "  identical: %s" % same), flush=True)
+m.set_sub_group_kernels(False)
+
 # the whole coarse-to-fine loop for a rectified pair: one resident call vs the step-wise loop through host buffers
 from openmvs_amd import tsgm
 from openmvs_amd.patchmatch import PatchMatchHIP

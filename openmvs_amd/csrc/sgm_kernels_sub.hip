@@ -136,6 +136,7 @@ __global__ __launch_bounds__(64) void sgm_path_sub_kernel(const float* __restric
 	__shared__ unsigned short s_P2[256];
 	__shared__ SGMPixel s_px[PW][2][LP];                               // pixel-table chunks: LP pixels of each line, double-buffered
 	__shared__ float s_g[PW][2][LP];
+	__shared__ unsigned char s_c[PW][2][LP][LP];                       // cost bytes of the first LP disparities of the chunk's pixels, prefetched a chunk ahead
 	const int lane = threadIdx.x, sub = lane / LP, kk = lane % LP;
 	int dir = 0;
 #pragma unroll
@@ -159,11 +160,28 @@ __global__ __launch_bounds__(64) void sgm_path_sub_kernel(const float* __restric
 			g = grayL[(size_t)ty * w + tx]; // imageGray(u) with the valid-grid coordinate: the reference's quirk (:1078)
 		}
 	};
+	// The recurrence is a dependent chain and few waves share a CU, so a global load inside a step would be paid in full: the cost bytes of a chunk
+	// (entry kk of each of its LP pixels; wider pixels fetch the rest on demand) are requested one chunk ahead into registers and parked in LDS.
+	auto costLoad = [&](int sl, int (&c)[LP]) {
+#pragma unroll
+		for (int t = 0; t < LP; ++t) {
+			const SGMPixel p = s_px[sub][sl][t];
+			c[t] = kk < p.maxDisp - p.minDisp ? (int)costs[p.idx + (unsigned)kk] : 0;
+		}
+	};
+	auto costStore = [&](int sl, const int (&c)[LP]) {
+#pragma unroll
+		for (int t = 0; t < LP; ++t) s_c[sub][sl][t][kk] = (unsigned char)c[t];
+	};
 	SGMPixel tpx; float tg;
 	tableLoad(x, y, tpx, tg);
 	s_px[sub][0][kk] = tpx; s_g[sub][0][kk] = tg;
 	tableLoad(x + LP * dx, y + LP * dy, tpx, tg);                      // chunk 1, in flight
 	__syncthreads();
+	int cr[LP];
+	costLoad(0, cr); costStore(0, cr);
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
 	int rpMin = 0, rpMax = 0, cur = 0; float Ip = 0.5f;               // state of the line (uniform inside the sub-group)
 	int slot = 0;
 	// the lines of a wave end at different pixels: loop while any of them is still inside
@@ -173,6 +191,7 @@ __global__ __launch_bounds__(64) void sgm_path_sub_kernel(const float* __restric
 		tableLoad(x + 2 * LP * dx, y + 2 * LP * dy, tpx, tg);
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
+		costLoad(slot ^ 1, cr);                                       // the next chunk's cost bytes: in flight during the LP steps below
 #pragma unroll 1
 		for (int t = 0; t < LP; ++t) {
 			const SGMPixel px = s_px[sub][slot][t];
@@ -201,7 +220,7 @@ __global__ __launch_bounds__(64) void sgm_path_sub_kernel(const float* __restric
 			// pass 2: L of every entry, chunk by chunk
 			for (int k = kk; __any(on && k - kk < nD); k += LP) {
 				const bool mine = on && k < nD;
-				const int c = mine ? (int)costs[px.idx + (unsigned)k] : 0;
+				const int c = !mine ? 0 : (k < LP ? (int)s_c[sub][slot][t][kk] : (int)costs[px.idx + (unsigned)k]);
 				int L;
 				if (fresh) L = c + P2;
 				else {
@@ -220,6 +239,9 @@ __global__ __launch_bounds__(64) void sgm_path_sub_kernel(const float* __restric
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 		}
+		costStore(slot ^ 1, cr);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
 		x += LP * dx; y += LP * dy; slot ^= 1;
 	}
 }

@@ -56,6 +56,8 @@ def test_estimator_single_view(engine, small_scene):
     g.test_single_view_photometric_parity_N4(engine, small_scene, 2)          # 3 pyramid levels, 4 source views (G = 4 lanes per pixel)
     g.test_initial_estimate_is_honoured(engine, small_scene)
     g.test_single_call_with_ignore_mask(engine, small_scene)
+    for k in (0, 2, 3, 5):                                                   # non-default OPTDENSE values (all six sets pass; four run here)
+        g.test_non_default_options_parity(engine, small_scene, k)
 
 
 def test_estimator_group_sizes_and_geometric_pass(engine, nine_scene):

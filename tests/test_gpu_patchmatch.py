@@ -339,6 +339,43 @@ def test_single_call_with_ignore_mask(engine, small_scene):
     _same(d, od, "plain call after masked calls")
 
 
+OPTION_SETS = [
+    dict(nEstimationIters=4, nRandomIters=8),
+    dict(fRandomDepthRatio=0.01, fRandomAngle1Range=10.0, fRandomAngle2Range=5.0),
+    dict(fRandomSmoothBonus=0.8, fRandomSmoothDepth=0.05, fRandomSmoothNormal=20.0),
+    dict(fNCCThresholdKeep=0.6, fDescriptorMinMagnitudeThreshold=0.05),
+    dict(nSubResolutionLevels=1, nEstimationIters=2),
+    dict(nSubResolutionLevels=3, nRandomIters=2),
+]
+
+
+@pytest.mark.xfail(strict=False, reason="option sets added after the round's GPU budget was spent; pass on the CPU emulator, not yet run on a device")
+@pytest.mark.isolated
+@pytest.mark.parametrize("k", range(len(OPTION_SETS)))
+def test_non_default_options_parity(engine, small_scene, k):
+    """Every OPTDENSE value the estimator reads (DepthMap.cpp:69-90 -> PMHipParams), away from its default: photometric pass, and for the first set a
+    geometric round with a non-default fEstimationGeometricWeight on top.  NOT YET RUN ON A DEVICE (the kernels are; these constants are not)."""
+    sc = small_scene
+    kw = OPTION_SETS[k]
+    engine.Init(False)
+    p = default_params(seed=21 + k, **kw)
+    ids = [2] + list(sc.neighbors[2])
+    d, n, c = engine.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[2], sc.dmax[2], params=p)
+    od, on, oc = _oracle(sc, 2, 21 + k, **kw)
+    _same(d, od, "depth %s" % kw); _same(n, on, "normal %s" % kw); _same(c, oc, "conf %s" % kw)
+    assert (d > 0).mean() > 0.4
+    if k == 0:
+        kw = dict(kw, nEstimationGeometricIters=1, fEstimationGeometricWeight=0.3)
+        src = {i: _oracle(sc, i, 21, **OPTION_SETS[0])[0] for i in ids[1:]}
+        engine.Init(True)
+        g = engine.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[2], sc.dmax[2], depth=d, normal=n, src_depths=src, nGeometricIter=0,
+                                    params=default_params(seed=21, **kw))
+        og = _oracle(sc, 2, 21, geo_iter=0, depth=od, normal=on, src=src, **kw)
+        for a, b, what in zip(g, og, ("depth", "normal", "conf")):
+            _same(a, b, "geometric, weight 0.3: " + what)
+        engine.Init(False)
+
+
 def test_real_scene_from_mvs_archive_matches_oracle_and_sfm_points():
     """The reference's own pipeline fixture (tests/data/scene: 4 JPEGs 640x479 + MVSI archive): scene front end (reader, view selection,
     sparse initialisation) -> photometric pass + 2 geometric rounds seeded by the sparse maps.  Device == oracle bit for bit on real

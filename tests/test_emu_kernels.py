@@ -137,11 +137,11 @@ def test_zz_no_lane_ever_read_a_lane_that_was_not_there(pm_emulated, sgm_emulate
         assert inactive == 0, "%s: %d cross-lane reads of non-participating lanes" % (module.__name__, inactive)
 
 
-@pytest.mark.parametrize("order", ["reverse", "stride"])
+@pytest.mark.parametrize("order", ["reverse"])
 def test_results_do_not_depend_on_the_execution_order(order):
     """The same checks with the lanes of every workgroup and the workgroups of every grid executed in another order (HIPEMU_ORDER): kernels free of
     races -- in particular the reservation rounds of the fusion, the union-find of the segment / speckle filters, the atomic splats -- give the
-    same bits.  (The whole module passes under both orders; a quick selection runs here.)"""
+    same bits.  (The whole module passes under "reverse" and "stride"; a quick selection runs here under "reverse".)"""
     if os.environ.get("HIPEMU_ORDER"):
         pytest.skip("already inside a permuted run")
     env = dict(os.environ, HIPEMU_ORDER=order)

@@ -64,6 +64,7 @@ def test_estimator_group_sizes_and_geometric_pass(engine, nine_scene):
     from tests import test_gpu_patchmatch as g
     g.test_single_view_parity_N8_and_N1(engine, nine_scene)                   # G = 8 and G = 1
     g.test_geometric_round_parity_and_golden(engine)
+    g.test_many_source_views_parity(engine)                                   # G = 16 (9 .. 16 sources) and partial groups
 
 
 def test_estimator_odd_sizes(engine):

@@ -339,6 +339,40 @@ def test_single_call_with_ignore_mask(engine, small_scene):
     _same(d, od, "plain call after masked calls")
 
 
+@pytest.mark.xfail(strict=False, reason="added after the round's GPU budget was spent; passes on the CPU emulator, not yet run on a device")
+@pytest.mark.isolated
+def test_many_source_views_parity(engine):
+    """9 .. 16 source views (G = 16 lanes per pixel, the widest instantiation, 4 pixels per wavefront) and the partial groups 5, 6; one geometric round
+    at 16; more than PMHIP_MAX_SOURCES is an argument error.  NOT YET RUN ON A DEVICE (the G = 16 kernels never were)."""
+    from openmvs_amd.patchmatch import PatchMatchError
+    sc = synth.make_scene(18, 96, 72, n_src=17)
+    ref = 8
+    engine.Init(False)
+    p = default_params(seed=9, nSubResolutionLevels=1)
+    res = {}
+    for nsrc in (16, 12, 9, 6, 5):
+        ids = [ref] + list(sc.neighbors[ref][:nsrc])
+        d, n, c = engine.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], params=p)
+        views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+        od, on, oc = po.estimate_depth_map(views, len(ids), float(sc.dmin[ref]), float(sc.dmax[ref]), po.default_opt(seed=9, viewID=ref, nSubResolutionLevels=1))
+        _same(d, od, f"depth N={nsrc}"); _same(n, on, f"normal N={nsrc}"); _same(c, oc, f"conf N={nsrc}")
+        assert (d > 0).mean() > 0.5
+        res[nsrc] = (d, n)
+    ids = [ref] + list(sc.neighbors[ref][:16])
+    src = {i: np.full((sc.height, sc.width), float(sc.dmin[ref] + sc.dmax[ref]) / 2, np.float32) for i in ids[1:]}     # any maps do: both sides read the same
+    engine.Init(True)
+    g = engine.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], depth=res[16][0], normal=res[16][1], src_depths=src, nGeometricIter=0,
+                                params=default_params(seed=9, nSubResolutionLevels=1, nEstimationGeometricIters=1))
+    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids, depth_maps=src)
+    og = po.estimate_depth_map(views, len(ids), float(sc.dmin[ref]), float(sc.dmax[ref]),
+                               po.default_opt(seed=9, viewID=ref, nSubResolutionLevels=1, nEstimationGeometricIters=1), geo_iter=0, depth=res[16][0], normal=res[16][1])
+    for a, b, what in zip(g, og, ("depth", "normal", "conf")):
+        _same(a, b, "geometric N=16 " + what)
+    engine.Init(False)
+    with pytest.raises(PatchMatchError):
+        engine.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, [ref] + list(sc.neighbors[ref][:17]), sc.dmin[ref], sc.dmax[ref], params=p)
+
+
 OPTION_SETS = [
     dict(nEstimationIters=4, nRandomIters=8),
     dict(fRandomDepthRatio=0.01, fRandomAngle1Range=10.0, fRandomAngle2Range=5.0),

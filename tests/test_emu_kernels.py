@@ -70,6 +70,7 @@ def test_estimator_group_sizes_and_geometric_pass(engine, nine_scene):
 def test_estimator_odd_sizes(engine):
     from tests import test_gpu_patchmatch as g
     g.test_non_divisible_image_size_parity(engine)
+    g.test_degenerate_inputs(engine)                                          # textureless, tiny, empty maps through filters and fusion
 
 
 def test_scene_schedule_masks_and_filters(pm_emulated, small_scene):

@@ -373,6 +373,45 @@ def test_many_source_views_parity(engine):
         engine.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, [ref] + list(sc.neighbors[ref][:17]), sc.dmin[ref], sc.dmax[ref], params=p)
 
 
+@pytest.mark.xfail(strict=False, reason="added after the round's GPU budget was spent; passes on the CPU emulator, not yet run on a device")
+@pytest.mark.isolated
+def test_degenerate_inputs(engine):
+    """Textureless images (every pixel fails the descriptor-magnitude test: empty maps), an image smaller than the patch at its coarsest level, and
+    the post-filters and the fusion on empty maps.  NOT YET RUN ON A DEVICE."""
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    sc = synth.make_scene(5, 64, 48, n_src=4)
+    engine.Init(False)
+    flat = np.full_like(sc.gray, 0.5)
+    ids = [0] + list(sc.neighbors[0])
+    d, n, c = engine.EstimateDepthMap(flat, sc.K, sc.R, sc.C, ids, sc.dmin[0], sc.dmax[0], params=default_params(seed=3))
+    views, keep = po.make_views(flat, sc.K, sc.R, sc.C, ids)
+    od, on, oc = po.estimate_depth_map(views, len(ids), float(sc.dmin[0]), float(sc.dmax[0]), po.default_opt(seed=3, viewID=0))
+    _same(d, od, "textureless depth"); _same(n, on, "textureless normal"); _same(c, oc, "textureless conf")
+    assert not d.any() and not n.any()
+    tiny = synth.make_scene(3, 24, 20, n_src=2)
+    ids = [0] + list(tiny.neighbors[0])
+    for lv in (0, 1):
+        d, n, c = engine.EstimateDepthMap(tiny.gray, tiny.K, tiny.R, tiny.C, ids, tiny.dmin[0], tiny.dmax[0], params=default_params(seed=3, nSubResolutionLevels=lv))
+        views, keep = po.make_views(tiny.gray, tiny.K, tiny.R, tiny.C, ids)
+        od, on, oc = po.estimate_depth_map(views, len(ids), float(tiny.dmin[0]), float(tiny.dmax[0]), po.default_opt(seed=3, viewID=0, nSubResolutionLevels=lv))
+        _same(d, od, "tiny depth, %d levels" % lv); _same(n, on, "tiny normal"); _same(c, oc, "tiny conf")
+    from openmvs_amd.patchmatch import PatchMatchError
+    with pytest.raises(PatchMatchError, match="too small"):                       # 6 x 5 at level 2: smaller than the 9 x 9 patch -- engine and oracle both refuse
+        engine.EstimateDepthMap(tiny.gray, tiny.K, tiny.R, tiny.C, ids, tiny.dmin[0], tiny.dmax[0], params=default_params(seed=3, nSubResolutionLevels=2))
+    with pytest.raises(RuntimeError):
+        po.estimate_depth_map(views, len(ids), float(tiny.dmin[0]), float(tiny.dmax[0]), po.default_opt(seed=3, viewID=0, nSubResolutionLevels=2))
+    e = PatchMatchHIP(0)
+    e.scene_load(sc, n_levels=0)
+    allv = list(range(sc.n_views))
+    for v in allv:
+        e.scene_reset_view(v)
+    e.scene_remove_small_segments(allv, 100, 0.01); e.scene_gap_interpolation(allv, 7, 0.01); e.scene_filter(allv)
+    assert not any(e.scene_get_maps(v)[0].any() for v in allv)
+    cloud = e.scene_fuse(allv, nMinViewsFuse=2, bEstimateColor=False)
+    assert cloud["nPoints"] == 0 and cloud["nDepths"] == 0
+    e.close()
+
+
 OPTION_SETS = [
     dict(nEstimationIters=4, nRandomIters=8),
     dict(fRandomDepthRatio=0.01, fRandomAngle1Range=10.0, fRandomAngle2Range=5.0),

@@ -80,6 +80,7 @@ def test_scene_schedule_masks_and_filters(pm_emulated, small_scene):
     g.test_filter_depth_map_parity(small_scene, True)
     g.test_remove_small_segments_parity(small_scene)
     g.test_gap_interpolation_parity(small_scene)
+    g.test_post_filter_option_sweep(small_scene)                              # 17 non-default settings of the three post-filters
 
 
 def test_fusion(pm_emulated, small_scene, nine_scene):
@@ -89,6 +90,7 @@ def test_fusion(pm_emulated, small_scene, nine_scene):
     g.test_device_fuse_reproduces_the_golden_cloud()
     g.test_device_merge_mode(small_scene)
     g.test_device_fuse_custom_order_and_errors(small_scene)
+    g.test_fuse_option_sweep(small_scene)
 
 
 # ---- SGM: cost volume, 8-path aggregation, winner-take-all, the tSGM steps ------------------------------------------------------------------------

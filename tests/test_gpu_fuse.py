@@ -42,6 +42,27 @@ def test_device_fuse_is_the_sequential_fuse(small_scene, nine_scene, case):
     e.close()
 
 
+@pytest.mark.xfail(strict=False, reason="option values added after the round's GPU budget was spent; passes on the CPU emulator, not yet run on a device")
+@pytest.mark.isolated
+def test_fuse_option_sweep(small_scene):
+    """FuseDepthMaps with thresholds and view counts away from the defaults: more views than any point has, very tight and very loose depth / normal
+    thresholds, colours without normals and the reverse.  NOT YET RUN ON A DEVICE (the kernels are; these values are not)."""
+    sc = small_scene
+    maps = fc.make_maps(sc, seed=5)
+    e = PatchMatchHIP(0)
+    _load(e, sc, maps)
+    sets = [dict(nMinViewsFuse=4), dict(nMinViewsFuse=5), dict(fDepthDiffThreshold=0.001, fNormalDiffThreshold=5.0), dict(fDepthDiffThreshold=0.2, fNormalDiffThreshold=179.0),
+            dict(bEstimateColor=True, bEstimateNormal=False), dict(bEstimateColor=False, bEstimateNormal=True), dict(nMinViewsFuse=2, fDepthDiffThreshold=0.05)]
+    some = 0
+    for kw in sets:
+        got = e.scene_fuse(_order(sc), **kw)
+        ref = po.fuse_depth_maps(*maps, list(sc.bgr), sc.K, sc.R, sc.C, [list(x) for x in sc.neighbors], **kw)
+        fc.same_cloud(got, ref, str(kw))
+        some += got["nPoints"]
+    assert some > 1000
+    e.close()
+
+
 @pytest.mark.xfail(strict=False, reason="added after the round's GPU budget was spent: verified kernels, but this fixture path has not run on a device yet")
 def test_device_fuse_reproduces_the_golden_cloud():
     """The committed fixture (tests/golden/fuse_golden_96x64.npz, written by the oracle): same inputs through the C ABI."""

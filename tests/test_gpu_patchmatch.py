@@ -242,6 +242,55 @@ def test_gap_interpolation_parity(small_scene):
     e.close()
 
 
+@pytest.mark.xfail(strict=False, reason="option values added after the round's GPU budget was spent; passes on the CPU emulator, not yet run on a device")
+@pytest.mark.isolated
+def test_post_filter_option_sweep(small_scene):
+    """The thresholds and sizes of the three post-filters away from their defaults, all on one estimate: RemoveSmallSegments (speckle size 0, 1, 15,
+    huge; loose / tight depth threshold), GapInterpolation (gap 0, 1, 3, 20), FilterDepthMap (view counts 1..3, tight / loose threshold, both
+    bFilterAdjust branches).  NOT YET RUN ON A DEVICE (the kernels are; these values are not)."""
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    sc = small_scene
+    e = PatchMatchHIP(0); e.Init(False)
+    e.scene_load(sc, n_levels=1)
+    allv = list(range(sc.n_views))
+    e.scene_estimate(allv, -1, default_params(seed=4, nSubResolutionLevels=1, nEstimationGeometricIters=0))
+    r = np.random.RandomState(3)
+    base = []
+    for v in allv:                                     # holes of assorted sizes so that every filter has something to do
+        d, n, c = e.scene_get_maps(v)
+        for _ in range(40):
+            y, x = r.randint(6, sc.height - 12), r.randint(6, sc.width - 14)
+            hh, ww = r.randint(1, 9), r.randint(1, 9)
+            d[y:y + hh, x:x + ww] = 0; n[y:y + hh, x:x + ww] = 0; c[y:y + hh, x:x + ww] = 0
+        base.append((d, n, c))
+
+    def restore():
+        for v in allv:
+            e.scene_set_maps(v, base[v][0], base[v][1]); e.scene_set_conf(v, base[v][2])
+    dep = np.stack([b[0] for b in base]); cnf = np.stack([b[2] for b in base])
+    for size, th in ((0, 0.01), (1, 0.01), (15, 0.01), (100000, 0.01), (40, 0.002), (40, 0.08)):
+        restore(); e.scene_remove_small_segments(allv, nSpeckleSize=size, fDepthDiffThreshold=th)
+        for v in allv:
+            got = e.scene_get_maps(v); want = po.remove_small_segments(*base[v], nSpeckleSize=size, fDepthDiffThreshold=th)
+            for a, b, what in zip(got, want, ("depth", "normal", "conf")):
+                _same(a, b, f"segments size {size} th {th} v{v} {what}")
+    for gap, th in ((0, 0.01), (1, 0.01), (3, 0.01), (20, 0.01), (7, 0.001), (7, 0.1)):
+        restore(); e.scene_gap_interpolation(allv, nIpolGapSize=gap, fDepthDiffThreshold=th)
+        for v in allv:
+            got = e.scene_get_maps(v); want = po.gap_interpolation(*base[v], nIpolGapSize=gap, fDepthDiffThreshold=th)
+            for a, b, what in zip(got, want, ("depth", "normal", "conf")):
+                _same(a, b, f"gap {gap} th {th} v{v} {what}")
+    for adjust, mv, mva, th in ((True, 1, 1, 0.01), (True, 3, 2, 0.01), (False, 3, 1, 0.01), (True, 2, 1, 0.001), (False, 2, 1, 0.1)):
+        restore(); e.scene_filter(allv, bAdjust=adjust, nMinViewsFilter=mv, nMinViewsFilterAdjust=mva, fDepthDiffThreshold=th)
+        for v in allv:
+            d, n, c = e.scene_get_maps(v)
+            rc, od, oc = po.filter_depth_map(dep, cnf, sc.K, sc.R, sc.C, v, list(sc.neighbors[v]), sc.dmin[v], sc.dmax[v], bAdjust=adjust,
+                                             nMinViewsFilter=mv, nMinViewsFilterAdjust=mva, fDepthDiffThreshold=th)
+            assert rc == 0
+            _same(d, od, f"filter {adjust} {mv} {mva} {th} depth v{v}"); _same(c, oc, f"filter {adjust} {mv} {mva} {th} conf v{v}")
+    e.close()
+
+
 def test_whole_dense_schedule_matches_the_oracle_pipeline(small_scene, tmp_path):
     """Scene::ComputeDepthMaps order of operations (SceneDensify.cpp:1884-1980): photometric, 2 geometric rounds, speckle + gap
     filters after the last round, cross-view filter, .dmap files -- device pipeline vs the same chain of oracle stages."""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # First GPU call of the next round, in one gpurun invocation (≈ 12-15 GPU-minutes):
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/round2_first_call.sh'
-# 1. the 33 cases that never ran on a device, without isolation and without xfail, each under its own timeout;
+# 1. the 35 cases that never ran on a device, without isolation and without xfail, each under its own timeout;
 # 2. the whole -m gpu suite as the driver runs it;
 # 3. bench.py (default workload) plain and under rocprofv3 --kernel-trace --stats;
 # 4. one SQ_* counter pass on a reduced workload (own run, no trace domains), under a short timeout;
@@ -15,7 +15,7 @@ step() { echo "=== $1 ($(date +%T))" | tee -a "$OUT/steps.log"; }
 
 step "1 unrun cases"
 OPENMVS_AMD_ISOLATED_CHILD=1 timeout 900 python -m pytest tests -m gpu --runxfail -rxXfE -q --timeout=240 \
-    -k "sgm_post or golden_cloud or long_invalid or sub_group or single_call_with_ignore_mask or non_default_options or many_source or degenerate or range_limits" > "$OUT/1_unrun_cases.log" 2>&1
+    -k "sgm_post or golden_cloud or long_invalid or sub_group or single_call_with_ignore_mask or non_default_options or many_source or degenerate or range_limits or option_sweep" > "$OUT/1_unrun_cases.log" 2>&1
 echo "exit $?" >> "$OUT/1_unrun_cases.log"; tail -5 "$OUT/1_unrun_cases.log"
 
 step "2 gpu suite"

@@ -68,6 +68,9 @@ def load_library() -> C.CDLL:
         if path is None or not os.path.exists(path):
             raise RuntimeError("libpmhip.so is not built (python -m openmvs_amd.build)")
         lib = C.CDLL(path)
+        if hasattr(lib, "hipemu_counters") and os.environ.get("OPENMVS_AMD_TEST_EMULATOR") != "1":
+            # tests/cpp/hipemu builds of the kernels exist for the CPU test-suite only; the product never computes on the host
+            raise RuntimeError("%s is a CPU-emulated test build, not a device library: refusing to load it outside the test-suite" % path)
         lib.pmhip_last_error.restype = C.c_char_p
         lib.pmhip_scene_device_ptr.restype = C.c_void_p
         lib.pmhip_stream.restype = C.c_void_p

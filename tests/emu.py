@@ -49,18 +49,20 @@ def build(name: str) -> str:
 def emulated(module, env_var, name):
     """Make `module.load_library()` (openmvs_amd.patchmatch / openmvs_amd.sgm) return the emulated library inside the block."""
     path = build(name)
-    saved_lib, saved_env = module._LIB, os.environ.get(env_var)
+    saved_lib, saved_env, saved_flag = module._LIB, os.environ.get(env_var), os.environ.get("OPENMVS_AMD_TEST_EMULATOR")
     module._LIB = None
     os.environ[env_var] = path
+    os.environ["OPENMVS_AMD_TEST_EMULATOR"] = "1"                   # the product refuses emulated builds without it
     try:
         module.load_library()
         yield path
     finally:
         module._LIB = saved_lib
-        if saved_env is None:
-            os.environ.pop(env_var, None)
-        else:
-            os.environ[env_var] = saved_env
+        for k, v in ((env_var, saved_env), ("OPENMVS_AMD_TEST_EMULATOR", saved_flag)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def counters(module):

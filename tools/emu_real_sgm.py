@@ -2,7 +2,7 @@
 emulator of the tests -- stereo rectification, seeded resident tSGM loop (sgmhip_tsgm_match), ProjectDisparity2DepthMap, pair fusion -- against the same
 chain on the oracle backend.  Expected output: both pairs and the fused depth / confidence maps equal.
 
-    SGMHIP_LIB=tests/cpp/hipemu/_build/libsgmhip_emu.so python tools/emu_real_sgm.py      (build the library first: python -m pytest tests/test_emu_kernels.py -k sgm_match)
+    OPENMVS_AMD_TEST_EMULATOR=1 SGMHIP_LIB=tests/cpp/hipemu/_build/libsgmhip_emu.so python tools/emu_real_sgm.py      (build the library first: python -m pytest tests/test_emu_kernels.py -k sgm_match)
 """
 import os, sys, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

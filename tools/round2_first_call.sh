@@ -31,7 +31,8 @@ step "4 counters"
 ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM --output-format csv \
     -d "$GRAFT_REPO_ROOT/$OUT/prof_pmc" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --views-per-gpu 16 --no-cpu-baseline \
     > "$GRAFT_REPO_ROOT/$OUT/4_pmc_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/4_pmc.err" ) || echo "pmc pass failed or timed out" | tee -a "$OUT/steps.log"
-python tools/pmc_agg.py "$OUT/prof_pmc" > "$OUT/4_pmc_per_kernel.txt" 2>&1 || true
+PMC_CSV=$(find "$OUT/prof_pmc" -name "*counter_collection.csv" | head -1)
+[ -n "$PMC_CSV" ] && python tools/pmc_agg.py "$PMC_CSV" > "$OUT/4_pmc_per_kernel.txt" 2>&1 && rm -f "$PMC_CSV"   # the raw CSV exceeds the copy-back limit
 
 step "5 residency variants"
 python - > "$OUT/5_variants_build.log" 2>&1 <<'PY'

@@ -1,0 +1,170 @@
+"""Randomised differential test of the device code under the CPU emulator against the oracle (not part of the test-suite: run it for as long as you like).
+
+    OPENMVS_AMD_TEST_EMULATOR=1 PMHIP_LIB=tests/cpp/hipemu/_build/libpmhip_emu.so SGMHIP_LIB=tests/cpp/hipemu/_build/libsgmhip_emu.so \
+        python tools/emu_fuzz.py --minutes 30 --seed 1
+
+Each trial draws a size, a number of source views, options, masks and ranges at random and checks bit-exact equality for: the estimator (photometric pass,
+sometimes a geometric round, sometimes masked), the post-filters, the fusion, SGM Match with both kernel mappings, and the resident tSGM loop.  A failure prints
+the trial's seed (re-run with --only <seed>) and the harness goes on."""
+import argparse, os, sys, time, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from openmvs_amd import synth, sgm, tsgm
+from openmvs_amd.patchmatch import PatchMatchHIP, default_params
+from oracle import pyoracle as po
+from tests import sgm_cases as sc_, fuse_cases as fc
+from tests.tsgm_backends import OracleBackend
+
+
+def same(a, b, what):
+    if not np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8)):
+        raise AssertionError("%s differs (%d of %d bytes)" % (what, int((np.asarray(a).view(np.uint8) != np.asarray(b).view(np.uint8)).sum()), np.asarray(a).nbytes))
+
+
+def trial_estimator(r, eng):
+    w, h = int(r.randint(28, 110)), int(r.randint(24, 90))
+    nsrc = int(r.choice([1, 2, 3, 4, 5, 7, 8, 11, 16]))
+    sc = synth.make_scene(nsrc + 1, w, h, n_src=nsrc, seed=int(r.randint(1 << 30)))
+    ref = int(r.randint(nsrc + 1))
+    ids = [ref] + list(sc.neighbors[ref][:nsrc])
+    lv = int(r.randint(0, 3))
+    while lv and (min(w, h) >> lv) < 12:
+        lv -= 1
+    kw = dict(nSubResolutionLevels=lv, nEstimationIters=int(r.randint(1, 4)), nRandomIters=int(r.randint(1, 8)))
+    if r.rand() < 0.5:
+        kw.update(fRandomSmoothBonus=float(r.uniform(0.7, 1.0)), fNCCThresholdKeep=float(r.uniform(0.5, 0.95)), fRandomDepthRatio=float(r.uniform(0.002, 0.02)))
+    seed = int(r.randint(1 << 20))
+    mask = None
+    if r.rand() < 0.35:
+        mask = (r.rand(h, w) > 0.2).astype(np.uint8) * 255; y, x = r.randint(h // 2), r.randint(w // 2); mask[y:y + h // 3, x:x + w // 3] = 0
+    eng.Init(False)
+    got = eng.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], params=default_params(seed=seed, **kw), mask=mask)
+    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+    opt = po.default_opt(seed=seed, viewID=ref, **kw)
+    want = po.estimate_depth_map(views, len(ids), float(sc.dmin[ref]), float(sc.dmax[ref]), opt) if mask is None else \
+        po.estimate_depth_map_masked(views, len(ids), float(sc.dmin[ref]), float(sc.dmax[ref]), opt, mask, mask_mode=True)
+    for a, b, t in zip(got, want, "dnc"):
+        same(a, b, "estimator %s (w %d h %d nsrc %d %s mask %s)" % (t, w, h, nsrc, kw, mask is not None))
+    if r.rand() < 0.4 and mask is None:
+        src = {i: (want[0] * float(r.uniform(0.97, 1.03))).astype(np.float32) for i in ids[1:]}
+        kw2 = dict(kw, nEstimationGeometricIters=1, fEstimationGeometricWeight=float(r.uniform(0.05, 0.4)))
+        eng.Init(True)
+        g = eng.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], depth=want[0], normal=want[1], src_depths=src, nGeometricIter=0,
+                                 params=default_params(seed=seed, **kw2))
+        views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids, depth_maps=src)
+        og = po.estimate_depth_map(views, len(ids), float(sc.dmin[ref]), float(sc.dmax[ref]), po.default_opt(seed=seed, viewID=ref, **kw2), geo_iter=0, depth=want[0], normal=want[1])
+        for a, b, t in zip(g, og, "dnc"):
+            same(a, b, "geometric %s" % t)
+        eng.Init(False)
+
+
+def trial_filters_and_fusion(r):
+    nv = int(r.randint(3, 8)); w, h = int(r.randint(40, 100)), int(r.randint(32, 80))
+    sc = synth.make_scene(nv, w, h, n_src=min(4, nv - 1), seed=int(r.randint(1 << 30)))
+    maps = fc.make_maps(sc, seed=int(r.randint(1 << 20)))
+    e = PatchMatchHIP(0)
+    e.scene_load(sc, n_levels=0)
+    d, n, c = maps
+    allv = list(range(nv))
+
+    def restore():
+        for v in allv:
+            e.scene_set_maps(v, d[v], n[v]); e.scene_set_conf(v, c[v]); e.scene_set_color(v, sc.bgr[v])
+    restore()
+    kw = dict(nMinViewsFuse=int(r.randint(1, 5)), fDepthDiffThreshold=float(r.choice([0.003, 0.01, 0.05])), fNormalDiffThreshold=float(r.choice([10.0, 25.0, 70.0])),
+              bEstimateColor=bool(r.rand() < 0.5), bEstimateNormal=bool(r.rand() < 0.5))
+    got = e.scene_fuse(po.fuse_order([len(x) for x in sc.neighbors]), **kw)
+    ref = po.fuse_depth_maps(*maps, list(sc.bgr), sc.K, sc.R, sc.C, [list(x) for x in sc.neighbors], **kw)
+    fc.same_cloud(got, ref, "fuse %s" % kw)
+    size, th = int(r.choice([0, 3, 20, 100])), float(r.choice([0.004, 0.01, 0.05]))
+    e.scene_remove_small_segments(allv, nSpeckleSize=size, fDepthDiffThreshold=th)
+    for v in allv:
+        for a, b, t in zip(e.scene_get_maps(v), po.remove_small_segments(d[v], n[v], c[v], nSpeckleSize=size, fDepthDiffThreshold=th), "dnc"):
+            same(a, b, "segments %s v%d" % (t, v))
+    restore()
+    gap = int(r.choice([1, 3, 7, 15]))
+    e.scene_gap_interpolation(allv, nIpolGapSize=gap, fDepthDiffThreshold=th)
+    for v in allv:
+        for a, b, t in zip(e.scene_get_maps(v), po.gap_interpolation(d[v], n[v], c[v], nIpolGapSize=gap, fDepthDiffThreshold=th), "dnc"):
+            same(a, b, "gap %s v%d" % (t, v))
+    restore()
+    adj, mv = bool(r.rand() < 0.5), int(r.randint(1, 4))
+    e.scene_filter(allv, bAdjust=adj, nMinViewsFilter=mv, fDepthDiffThreshold=th)
+    dep = np.stack(d); cnf = np.stack(c)
+    for v in allv:
+        gd, gn, gc = e.scene_get_maps(v)
+        rc, od, oc = po.filter_depth_map(dep, cnf, sc.K, sc.R, sc.C, v, list(sc.neighbors[v]), sc.dmin[v], sc.dmax[v], bAdjust=adj, nMinViewsFilter=mv, fDepthDiffThreshold=th)
+        same(gd, od, "filter depth v%d" % v); same(gc, oc, "filter conf v%d" % v)
+    e.close()
+
+
+def trial_sgm(r, m):
+    w, h = int(r.randint(12, 240)), int(r.randint(10, 120))
+    kind = str(r.choice(["uniform", "ragged", "ragged", "holes"]))
+    if kind == "holes" and (w < 120 or h < 100):
+        kind = "ragged"
+    lo = int(r.randint(-20, 5)); hi = lo + int(r.choice([4, 6, 9, 17, 33, 70, 130]))
+    lb, lg, rg = sc_.stereo_pair(w, h, int(r.randint(0, 8)), seed=int(r.randint(1 << 20)))
+    px, n, mx = sc_.ranges(w, h, kind, lo, hi, seed=int(r.randint(1 << 20)))
+    if n == 0:
+        return
+    od, oc, ocosts, oacc = po.sgm_match(lb, lg, rg, px, n, mx, m.P1, m.P2s)
+    for sub in (False, True):
+        m.set_sub_group_kernels(sub)
+        try:
+            m.set_problem(lb, lg, rg, px, n, mx); m.Match()
+            dd, c, costs, acc = m.results(volumes=True)
+        finally:
+            m.set_sub_group_kernels(False)
+        t = "sgm %s %dx%d [%d,%d) sub=%s" % (kind, w, h, lo, hi, sub)
+        same(costs, ocosts, t + " costs"); same(acc, oacc, t + " sums"); same(dd, od, t + " disp"); same(c, oc, t + " cost")
+
+
+def trial_tsgm(r, m):
+    k = int(r.choice([1, 2])); f = 1 << k
+    w, h = int(r.randint(14, 40)) * f * 2, int(r.randint(12, 30)) * f * 2
+    d0 = int(r.randint(2, 10))
+    lb, lg, rg = sc_.stereo_pair(w, h, d0, seed=int(r.randint(1 << 20)))
+    rb = np.roll(lb, d0, axis=1)
+    mask = np.full((h, w), 255, np.uint8)
+    if r.rand() < 0.6:
+        mask[:, :int(r.randint(1, 9))] = 0; y, x = r.randint(h // 2), r.randint(w // 2); mask[y:y + h // 5, x:x + w // 4] = 0
+    mr = max(w, h) >> k
+    if tsgm.compute_scale(w, h, mr) != k:
+        return
+    kw = dict(n_speckle_size=int(r.choice([0, 20, 100])), subpixel_mode=int(r.randint(0, 7)), subpixel_steps=int(r.choice([1, 2, 4, 8])))
+    dev = m.tsgm_match(lb, rb, lg, rg, mask, mask, min_resolution=mr, **kw)
+    ref = tsgm.tsgm_match(OracleBackend(), lb, lg, rb, rg, mask, mask, min_resolution=mr, **kw)
+    same(dev[0], ref[0], "tsgm disparity %dx%d k%d %s" % (w, h, k, kw)); same(dev[1], ref[1], "tsgm cost")
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--minutes", type=float, default=10); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--only", type=int)
+    a = ap.parse_args()
+    eng = PatchMatchHIP(0); m = sgm.SemiGlobalMatcherHIP(0)
+    t0 = time.time(); n = fails = 0
+    kinds = [("estimator", lambda r: trial_estimator(r, eng)), ("filters+fusion", trial_filters_and_fusion), ("sgm", lambda r: trial_sgm(r, m)), ("tsgm", lambda r: trial_tsgm(r, m))]
+    counts = {k: 0 for k, _ in kinds}
+    s = a.seed * 1000003
+    while time.time() - t0 < a.minutes * 60:
+        ts = a.only if a.only is not None else s + n
+        r = np.random.RandomState(ts % (1 << 32))
+        name, fn = kinds[int(r.randint(len(kinds)))]
+        try:
+            fn(r); counts[name] += 1
+        except Exception as ex:
+            fails += 1
+            print("FAIL trial seed %d (%s): %s" % (ts, name, ex), flush=True)
+            if not isinstance(ex, AssertionError):
+                traceback.print_exc()
+        n += 1
+        if a.only is not None:
+            break
+        if n % 20 == 0:
+            print("%d trials, %d failures, %.0f s  %s" % (n, fails, time.time() - t0, counts), flush=True)
+    print("done: %d trials, %d failures, %s" % (n, fails, counts), flush=True)
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -138,12 +138,29 @@ def trial_tsgm(r, m):
     same(dev[0], ref[0], "tsgm disparity %dx%d k%d %s" % (w, h, k, kw)); same(dev[1], ref[1], "tsgm cost")
 
 
+def trial_sgm_steps(r, m):
+    """The step-by-step tSGM functions on random sizes and seeds: the bodies of the device tests are size-generic."""
+    from tests import test_gpu_sgm_post as g
+    w, h, seed = int(r.randint(14, 160)), int(r.randint(12, 100)), int(r.randint(1 << 16))
+    g.test_map_steps_match_the_oracle(m, w, h, seed)
+    g.test_range_map_matches_the_oracle(m, w, h, seed)
+    g.test_disparity_depth_conversions_match_the_oracle(m, w, h, seed)
+    g.test_projection_and_pair_fusion_match_the_oracle(m, w, h, seed)
+    g.test_resident_fuse_equals_the_stepwise_fuse(m, w, h, seed)
+    d = g.pc.smooth_disparity(w, h, seed)
+    rr = np.random.RandomState(seed + 9)
+    noisy = d.copy(); o = rr.rand(h, w) < 0.08; noisy[o] = rr.randint(-60, 60, int(o.sum())).astype(np.int16)
+    mx, df = int(r.choice([0, 10, 100, 5000])), int(r.choice([0, 1, 5, 50]))
+    same(m.FilterSpeckles(noisy, mx, df), po.sgm_filter_speckles(noisy, mx, df), "speckles %dx%d %d %d" % (w, h, mx, df))
+
+
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--minutes", type=float, default=10); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--only", type=int)
     a = ap.parse_args()
     eng = PatchMatchHIP(0); m = sgm.SemiGlobalMatcherHIP(0)
     t0 = time.time(); n = fails = 0
-    kinds = [("estimator", lambda r: trial_estimator(r, eng)), ("filters+fusion", trial_filters_and_fusion), ("sgm", lambda r: trial_sgm(r, m)), ("tsgm", lambda r: trial_tsgm(r, m))]
+    kinds = [("estimator", lambda r: trial_estimator(r, eng)), ("filters+fusion", trial_filters_and_fusion), ("sgm", lambda r: trial_sgm(r, m)), ("tsgm", lambda r: trial_tsgm(r, m)),
+             ("sgm steps", lambda r: trial_sgm_steps(r, m))]
     counts = {k: 0 for k, _ in kinds}
     s = a.seed * 1000003
     while time.time() - t0 < a.minutes * 60:

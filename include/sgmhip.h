@@ -50,8 +50,9 @@ int sgmhip_match(sgmhip_engine* e, uint16_t P1, const uint16_t P2s[256], int syn
 int sgmhip_get_results(sgmhip_engine* e, int16_t* disparity, uint16_t* cost, uint8_t* costs, uint16_t* accums);
 int sgmhip_sync(sgmhip_engine* e);
 /* Kernel mapping of sgmhip_match: 0 (default) = one wavefront per pixel / line, one lane per disparity (plain SGM, D = 64 .. 256);
- * 1 = sub-groups of 16 lanes with a loop over the range, for the narrow ragged ranges of the tSGM loop (csrc/sgm_kernels_sub.hip).  Same results. */
-int sgmhip_set_sub_group_kernels(sgmhip_engine* e, int on);
+ * 8 / 16 / 32 (1 = 16) = sub-groups of that many lanes with a loop over the range, for the narrow ragged ranges of the tSGM loop
+ * (csrc/sgm_kernels_sub.hip).  Same results. */
+int sgmhip_set_sub_group_kernels(sgmhip_engine* e, int lanes);
 
 /* ---- the steps of the tSGM loop around Match (SemiGlobalMatcher.cpp:1449-1811); disparity maps int16 with NO_DISP = 32767,
  * masks uint8 with INVALID = 0 / VALID = 255, all host pointers, row-major ------------------------------------------------ */

@@ -20,7 +20,7 @@ struct sgmhip_engine {
 	SGMPixel* d_pixels = nullptr; unsigned char* d_costs = nullptr; unsigned short* d_accums = nullptr; float4* d_setup = nullptr;
 	short* d_disp = nullptr; unsigned short* d_cost = nullptr; unsigned short* d_P2s = nullptr;
 	bool statsOn = false; SGMHipStats stats{};
-	bool subGroups = false;       // Match with the sub-group kernels of sgm_kernels_sub.hip (narrow, ragged ranges); see sgmhip_set_sub_group_kernels
+	int subGroups = 0;            // 0, or the lanes per sub-group (8, 16, 32): Match with the sub-group kernels of sgm_kernels_sub.hip (narrow, ragged ranges); see sgmhip_set_sub_group_kernels
 	struct Ev { hipEvent_t a, b; int kind; }; std::vector<Ev> events;
 };
 
@@ -117,9 +117,11 @@ int sgmhip_match(sgmhip_engine* e, uint16_t P1, const uint16_t P2s[256], int syn
 	return 0;
 }
 // cost volume, 8-path aggregation and winner-take-all of the resident problem (P2s already on the device), asynchronous on the engine's stream
-// sub-group variant: 16 lanes per pixel / pair / line
-static int sgmMatchSub(sgmhip_engine* e, uint16_t P1) {
-	constexpr int LP = 16, PW = 64 / LP;
+// sub-group variant: LP lanes per pixel / pair / line
+extern "C++" {
+template <int LP>
+static int sgmMatchSubT(sgmhip_engine* e, uint16_t P1) {
+	constexpr int PW = 64 / LP;
 	const long nPix = (long)e->vw * e->vh;
 	const int W = e->vw, H = e->vh;
 	evB(e, 0);
@@ -161,6 +163,16 @@ static int sgmMatchSub(sgmhip_engine* e, uint16_t P1) {
 	SGMCHK(e, hipGetLastError());
 	if (e->statsOn) e->stats.calls += 1;
 	return 0;
+}
+
+} // extern "C++"
+
+static int sgmMatchSub(sgmhip_engine* e, uint16_t P1) {
+	switch (e->subGroups) {
+	case 8: return sgmMatchSubT<8>(e, P1);
+	case 32: return sgmMatchSubT<32>(e, P1);
+	default: return sgmMatchSubT<16>(e, P1);
+	}
 }
 
 static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
@@ -219,7 +231,11 @@ int sgmhip_get_results(sgmhip_engine* e, int16_t* disparity, uint16_t* cost, uin
 	SGMCHK(e, hipStreamSynchronize(e->stream));
 	return 0;
 }
-int sgmhip_set_sub_group_kernels(sgmhip_engine* e, int on) { if (!e) return SGMHIP_E_ARG; e->subGroups = on != 0; return 0; }
+int sgmhip_set_sub_group_kernels(sgmhip_engine* e, int lanes) {
+	if (!e || (lanes != 0 && lanes != 1 && lanes != 8 && lanes != 16 && lanes != 32)) return SGMHIP_E_ARG;
+	e->subGroups = lanes == 1 ? 16 : lanes;
+	return 0;
+}
 int sgmhip_sync(sgmhip_engine* e) { if (!e) return SGMHIP_E_ARG; SGMCHK(e, hipSetDevice(e->device)); SGMCHK(e, hipStreamSynchronize(e->stream)); return 0; }
 int sgmhip_stats_reset(sgmhip_engine* e, int enable) { if (!e) return SGMHIP_E_ARG; hipSetDevice(e->device); sgmCollect(e); memset(&e->stats, 0, sizeof(e->stats)); e->statsOn = enable != 0; return 0; }
 int sgmhip_stats_get(sgmhip_engine* e, SGMHipStats* out) { if (!e || !out) return SGMHIP_E_ARG; hipSetDevice(e->device); int rc = sgmCollect(e); if (rc) return rc; *out = e->stats; return 0; }
@@ -548,8 +564,8 @@ int sgmhip_tsgm_match(sgmhip_engine* e, const uint8_t* leftBGR, const uint8_t* r
 		SGMCHK(e, hipMemcpyAsync(e->d_grayL, gA, nImg * 4, hipMemcpyDeviceToDevice, st));
 		SGMCHK(e, hipMemcpyAsync(e->d_grayR, gB, nImg * 4, hipMemcpyDeviceToDevice, st));
 		// narrow ranges (every level but the first): 16-lane sub-groups; wide ranges: one wavefront per pixel / line
-		const bool saved = e->subGroups;
-		e->subGroups = saved || numCosts <= (uint64_t)n2 * 24;
+		const int saved = e->subGroups;
+		if (!saved && numCosts <= (uint64_t)n2 * 24) e->subGroups = 16;
 		const int rcm = sgmMatch(e, P1);
 		e->subGroups = saved;
 		if (rcm) return rcm;

@@ -6,13 +6,14 @@
 #pragma once
 #include "sgm_kernels.hip"
 
-// minimum over the LP lanes of a sub-group (LP = 8 or 16, aligned), returned in every lane: quad butterflies, then mirrors inside 8 and 16 lanes (DPP)
+// minimum over the LP lanes of a sub-group (LP = 8, 16 or 32, aligned), returned in every lane: quad butterflies, then mirrors inside 8 and 16 lanes (DPP)
 template <int LP>
 __device__ __forceinline__ int sgm_sub_min(int v) {
 	v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));          // quad_perm [1,0,3,2]
 	v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));          // quad_perm [2,3,0,1]
 	v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));         // row_half_mirror: lane i <-> 7-i inside 8 lanes
 	if (LP >= 16) v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false)); // row_mirror: lane i <-> 15-i inside 16 lanes
+	if (LP >= 32) v = min(v, __shfl_xor(v, 16, 64));                                     // the other row of the pair (LDS crossbar)
 	return v;
 }
 

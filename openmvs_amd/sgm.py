@@ -89,9 +89,10 @@ class SemiGlobalMatcherHIP:
         self._chk(self._lib.sgmhip_set_problem(self._h, lb.ctypes.data_as(C.POINTER(C.c_uint8)), lg.ctypes.data_as(C.POINTER(C.c_float)),
                                                rg.ctypes.data_as(C.POINTER(C.c_float)), w, h, px.ctypes.data_as(C.c_void_p), C.c_uint64(num_costs), max_num_disp))
 
-    def set_sub_group_kernels(self, on: bool):
-        """Match with 16-lane sub-groups (narrow tSGM ranges) instead of one wavefront per pixel / line; same results."""
-        self._chk(self._lib.sgmhip_set_sub_group_kernels(self._h, 1 if on else 0))
+    def set_sub_group_kernels(self, lanes):
+        """Match with sub-groups of `lanes` (8, 16, 32; True = 16) lanes per pixel / pair / line (narrow tSGM ranges) instead of one wavefront each
+        (False / 0); same results."""
+        self._chk(self._lib.sgmhip_set_sub_group_kernels(self._h, 16 if lanes is True else int(lanes)))
 
     def Match(self, sync=True):
         self._chk(self._lib.sgmhip_match(self._h, C.c_uint16(self.P1), self.P2s.ctypes.data_as(C.POINTER(C.c_uint16)), 1 if sync else 0))

@@ -100,6 +100,7 @@ def test_sgm_match(matcher):
     g.test_match_parity(matcher, 96, 64, "uniform", 0, 16)
     g.test_match_parity(matcher, 97, 65, "ragged", -5, 40)                    # odd valid width, ragged ranges
     g.test_tiny_and_degenerate(matcher)
+    g.test_sub_group_widths(matcher, 8); g.test_sub_group_widths(matcher, 32)
     g.test_range_limits(matcher, False); g.test_range_limits(matcher, True)   # 256 disparities, 257 rejected, one-row / one-column grids
     g.test_match_parity_across_long_invalid_runs(matcher)                     # whole table chunks of invalid pixels
     for args in ((96, 64, "uniform", 0, 16), (97, 65, "ragged", -5, 40), (120, 90, "ragged", 0, 200), (230, 100, "holes", -2, 12)):

@@ -95,6 +95,23 @@ def test_range_limits(matcher, sub):
         matcher.set_sub_group_kernels(False)
 
 
+@pytest.mark.xfail(strict=False, reason="kernels added after the round's GPU budget was spent; pass on the CPU emulator, not yet run on a device")
+@pytest.mark.isolated
+@pytest.mark.parametrize("lanes", [8, 32])
+def test_sub_group_widths(matcher, lanes):
+    """The other two sub-group widths (8 and 32 lanes per pixel / pair / line; 16 is covered above).  NOT YET RUN ON A DEVICE."""
+    matcher.set_sub_group_kernels(lanes)
+    try:
+        for w, h, kind, dmin, dmax in ((97, 65, "ragged", -5, 40), (230, 100, "holes", -2, 12), (120, 90, "ragged", 0, 200)):
+            lb, lg, rg = sc.stereo_pair(w, h, 5, seed=w)
+            px, n, mx = sc.ranges(w, h, kind, dmin, dmax, seed=h)
+            _check(matcher, lb, lg, rg, px, n, mx)
+    finally:
+        matcher.set_sub_group_kernels(False)
+    with pytest.raises(sgm.SGMError):
+        matcher.set_sub_group_kernels(12)
+
+
 def test_tiny_and_degenerate(matcher):
     lb, lg, rg = sc.stereo_pair(8, 8, 0)
     px, n, mx = sc.ranges(8, 8, "uniform", -1, 2)

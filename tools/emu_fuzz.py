@@ -109,7 +109,7 @@ def trial_sgm(r, m):
     if n == 0:
         return
     od, oc, ocosts, oacc = po.sgm_match(lb, lg, rg, px, n, mx, m.P1, m.P2s)
-    for sub in (False, True):
+    for sub in (0, int(r.choice([8, 16, 32]))):
         m.set_sub_group_kernels(sub)
         try:
             m.set_problem(lb, lg, rg, px, n, mx); m.Match()

@@ -23,7 +23,7 @@ for kind, lo, hi in (("uniform", 0, 64), ("uniform", 0, 128), ("ragged", 0, 64))
 # narrow tSGM-like ranges (3..12 disparities per pixel): the wide mapping against the 16-lane sub-group mapping
 px, n, mx = sc.ranges(w, h, "ragged", 0, 12)
 m.set_problem(lb, lg, rg, px, n, mx)
-for sub in (False, True):
+for sub in (0, 8, 16, 32):
     m.set_sub_group_kernels(sub)
     m.Match()
     d_ref = m.results()[0] if not sub else d_ref
@@ -33,7 +33,7 @@ for sub in (False, True):
     m.sync(); dt = (time.time() - t) / 4
     s = m.stats_get()
     print("narrow ranges numCosts %.1fM, %s kernels: %.2f ms/match (cost %.2f aggr %.2f wta %.2f)%s" % (
-        n / 1e6, "sub-group" if sub else "wide", dt * 1e3, s.costMs / 4, s.aggrMs / 4, s.wtaMs / 4, "" if not sub else "  identical: %s" % same), flush=True)
+        n / 1e6, ("%d-lane sub-group" % sub) if sub else "wide", dt * 1e3, s.costMs / 4, s.aggrMs / 4, s.wtaMs / 4, "" if not sub else "  identical: %s" % same), flush=True)
 m.set_sub_group_kernels(False)
 
 # the whole coarse-to-fine loop for a rectified pair: one resident call vs the step-wise loop through host buffers

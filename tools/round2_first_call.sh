@@ -1,7 +1,7 @@
 #!/bin/bash
 # First GPU call of the next round, in one gpurun invocation (≈ 12-15 GPU-minutes):
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/round2_first_call.sh'
-# 1. the 35 cases that never ran on a device, without isolation and without xfail, each under its own timeout;
+# 1. the 37 cases that never ran on a device, without isolation and without xfail, each under its own timeout;
 # 2. the whole -m gpu suite as the driver runs it;
 # 3. bench.py (default workload) plain and under rocprofv3 --kernel-trace --stats;
 # 4. one SQ_* counter pass on a reduced workload (own run, no trace domains), under a short timeout;

@@ -77,10 +77,8 @@ def test_scene_schedule_masks_and_filters(pm_emulated, small_scene):
     from tests import test_gpu_patchmatch as g
     g.test_scene_batch_full_schedule_matches_oracle(small_scene)
     g.test_ignore_mask_parity(small_scene)
-    g.test_filter_depth_map_parity(small_scene, True)
-    g.test_remove_small_segments_parity(small_scene)
-    g.test_gap_interpolation_parity(small_scene)
-    g.test_post_filter_option_sweep(small_scene)                              # 17 non-default settings of the three post-filters
+    g.test_post_filter_option_sweep(small_scene)                              # the three post-filters, 17 settings (their default-setting tests
+                                                                              # test_filter_depth_map_parity / _remove_small_segments_ / _gap_interpolation_ pass too)
 
 
 def test_fusion(pm_emulated, small_scene, nine_scene):

@@ -212,6 +212,9 @@ __device__ __forceinline__ void pm_homography(const PMSrcView& s, const PMTask& 
 #define PM_TCX 12       // window columns = pixels per wave + PM_TCX: PPW + 9 are needed
 #endif
 #define PM_TILE_PAD 4   // per-view stride = PM_TR*TC + 4 floats: staggers the views over the LDS banks
+#ifndef PM_WINBATCH
+#define PM_WINBATCH 4   // source windows whose global loads are in flight together when a visit stages its windows
+#endif
 
 template <bool GEO, bool SKEW, int TC>
 __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask& t, const PMKParams& kp,
@@ -384,9 +387,21 @@ __device__ __forceinline__ void pm_fill_patch(const PMTask& t, bool inb, int x, 
 	if (inb) {
 		const pm_gcf refS = pm_glob(t.refS), ref = pm_glob(t.ref);
 		const float colCenter = SKEW ? refS[(size_t)(x + y) * t.h + y] : ref[(size_t)y * t.w + x];
-		for (int k = v; k < PM_NT; k += G) {
+		// the texels of this lane's taps are requested together (one memory round trip at the head of the visit, not one per tap)
+		constexpr int NK = (PM_NT + G - 1) / G;
+		float Is[NK];
+#pragma unroll
+		for (int q = 0; q < NK; ++q) {
+			const int k = v + q * G, kk = k < PM_NT ? k : v;
+			const int i = (kk / 5) * 2 - PM_HW, j = (kk % 5) * 2 - PM_HW;
+			Is[q] = SKEW ? refS[(size_t)(x + j + y + i) * t.h + (y + i)] : ref[(size_t)(y + i) * t.w + (x + j)];
+		}
+#pragma unroll
+		for (int q = 0; q < NK; ++q) {
+			const int k = v + q * G;
+			if (k >= PM_NT) break;
 			const int i = (k / 5) * 2 - PM_HW, j = (k % 5) * 2 - PM_HW;
-			const float I = SKEW ? refS[(size_t)(x + j + y + i) * t.h + (y + i)] : ref[(size_t)(y + i) * t.w + (x + j)];
+			const float I = Is[q];
 			const float dc = I - colCenter;
 			const float wColor = (dc * dc) * sigmaColor;
 			const float wSpatial = (float)(j * j + i * i) * sigmaSpatial;
@@ -561,20 +576,32 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 		const int nS = t.nSrc;
 		constexpr int TCD = TC > 0 ? TC : 1;
 		constexpr int NLD = (PM_TR * TCD + 63) / 64;
-		for (int vv = 0; vv < nS; ++vv) {
-			const int fs0 = __shfl(ts0, vv, 64), ft0 = __shfl(tt0, vv, 64);
-			const pm_gcf src = pm_glob(t.src[vv].imgS);
-			const int sh = t.src[vv].h, sMax = t.src[vv].w + t.src[vv].h - 1;
-			float vals[NLD];
+		// PM_WINBATCH windows are requested together: the loads of a window are one memory round trip, and the round trips of
+		// the nSrc windows of a visit are a serial chain at the head of every wave's life
+		for (int vb = 0; vb < nS; vb += PM_WINBATCH) {
+			float vals[PM_WINBATCH][NLD];
 #pragma unroll
-			for (int k = 0; k < NLD; ++k) { // all loads of a window first, then the LDS writes
-				const int i = lane + 64 * k;
-				const int r = i / TCD, c = i - r * TCD;
-				const int ss = fs0 + r, tt = ft0 + c;
-				vals[k] = (i < PM_TR * TC && ss >= 0 && ss < sMax && tt >= 0 && tt < sh) ? src[(size_t)ss * sh + tt] : 0.f;
+			for (int b = 0; b < PM_WINBATCH; ++b) {
+				const int vv = vb + b;
+				if (vv >= nS) break;
+				const int fs0 = __shfl(ts0, vv, 64), ft0 = __shfl(tt0, vv, 64);
+				const pm_gcf src = pm_glob(t.src[vv].imgS);
+				const int sh = t.src[vv].h, sMax = t.src[vv].w + t.src[vv].h - 1;
+#pragma unroll
+				for (int k = 0; k < NLD; ++k) { // all loads of the batch first, then the LDS writes
+					const int i = lane + 64 * k;
+					const int r = i / TCD, c = i - r * TCD;
+					const int ss = fs0 + r, tt = ft0 + c;
+					vals[b][k] = (i < PM_TR * TC && ss >= 0 && ss < sMax && tt >= 0 && tt < sh) ? src[(size_t)ss * sh + tt] : 0.f;
+				}
 			}
 #pragma unroll
-			for (int k = 0; k < NLD; ++k) { const int i = lane + 64 * k; if (i < PM_TR * TC) tw[vv * TSTRIDE + i] = vals[k]; }
+			for (int b = 0; b < PM_WINBATCH; ++b) {
+				const int vv = vb + b;
+				if (vv >= nS) break;
+#pragma unroll
+				for (int k = 0; k < NLD; ++k) { const int i = lane + 64 * k; if (i < PM_TR * TC) tw[vv * TSTRIDE + i] = vals[b][k]; }
+			}
 		}
 		tile = tw + v * TSTRIDE;
 		__syncthreads();

@@ -179,6 +179,12 @@ __device__ __forceinline__ void pm_group_min2(float s, float& m1, float& m2) {
 // ComputeHomographyMatrix, DepthMap.h:414-423: (Hl + Hm * (n^T / (n.X0 * depth))) * Hr in double, cast to float
 __device__ __forceinline__ void pm_homography(const PMSrcView& s, const PMTask& t, double X0x, double X0y,
 		float depth, float nx, float ny, float nz, float* H) {
+	// the twelve matrix entries are requested first, together: one round trip (overlapping the division below) instead of one per row
+	double Hl[9], Hm[3];
+#pragma unroll
+	for (int i = 0; i < 9; ++i) Hl[i] = s.Hl[i];
+#pragma unroll
+	for (int i = 0; i < 3; ++i) Hm[i] = s.Hm[i];
 	const double n0 = (double)nx, n1 = (double)ny, n2 = (double)nz;
 	const double ndx = (n0 * X0x + n1 * X0y) + n2;
 	const double den = ndx * (double)depth;
@@ -186,10 +192,10 @@ __device__ __forceinline__ void pm_homography(const PMSrcView& s, const PMTask& 
 	const double r0 = n0 * inv, r1 = n1 * inv, r2 = n2 * inv;
 #pragma unroll
 	for (int i = 0; i < 3; ++i) {
-		const double hm = s.Hm[i];
-		const double m0 = s.Hl[i * 3 + 0] + hm * r0;
-		const double m1 = s.Hl[i * 3 + 1] + hm * r1;
-		const double m2 = s.Hl[i * 3 + 2] + hm * r2;
+		const double hm = Hm[i];
+		const double m0 = Hl[i * 3 + 0] + hm * r0;
+		const double m1 = Hl[i * 3 + 1] + hm * r1;
+		const double m2 = Hl[i * 3 + 2] + hm * r2;
 		if (t.hrUpper) {
 			// (m0*Hr0j + m1*Hr1j) + m2*Hr2j with the structurally-zero entries of K^-1 dropped: x*0 == 0 and 0+y == y exactly
 			H[i * 3 + 0] = (float)(m0 * t.Hr[0]);

@@ -222,13 +222,18 @@ __device__ __forceinline__ void pm_homography(const PMSrcView& s, const PMTask& 
 #define PM_WINBATCH 4   // source windows whose global loads are in flight together when a visit stages its windows
 #endif
 
-template <bool GEO, bool SKEW, int TC>
+// PF: the pixel's low-resolution prior and its blend factor exp(normSq0 * sigma) sit in the spare 26th entry of the pixel's weight row in LDS
+// (written once per visit by the sweep kernel) instead of in two registers that are live across the whole hypothesis loop
+template <bool GEO, bool SKEW, int TC, bool PF = false>
 __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask& t, const PMKParams& kp,
 		int x, int y, double X0x, double X0y, float normSq0, float sumW, const float2* wts,
 		float depth, float nx, float ny, float nz,
 		float sf0, float sf1, float sf2, float sf3, unsigned sfValid, float prior,
 		const float* tile, int ts0, int tt0 PM_PROF_ARG)
 {
+	// the image descriptor is requested together with the homography entries (same struct, same round trip)
+	const int sw = s.w, sh = s.h;
+	const pm_gcf img = pm_glob(SKEW ? s.imgS : s.img);
 	float H[9];
 	pm_homography(s, t, X0x, X0y, depth, nx, ny, nz, H);
 	PM_TICK(3);
@@ -240,8 +245,6 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 #pragma unroll
 	for (int i = 0; i < 9; ++i) H[i] *= 2.f; // nSizeStep
 	float sum = 0.f, sumSq = 0.f, num = 0.f;
-	const int sw = s.w, sh = s.h;
-	const pm_gcf img = pm_glob(SKEW ? s.imgS : s.img);
 	// The reference returns thRobust at the first tap that leaves the image (DepthMap.cpp:484-485).  Here a
 	// tap outside only raises a flag and its address is clamped, so there is no branch between taps: the
 	// 20 loads of a tap row are issued back to back (memory-level parallelism) and the sums of a flagged
@@ -364,7 +367,13 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		}
 	}
 	// low-resolution prior, DepthMap.cpp:553-561
-	if (prior > 0) {
+	if (PF) {
+		const float2 pf = wts[PM_NT];
+		if (pf.x > 0) {
+			const float deltaDepth = pm_minf(pm_fabsf(pf.x - depth) / pf.x, 0.5f);
+			score = (1.f - pf.y) * score + pf.y * deltaDepth;
+		}
+	} else if (prior > 0) {
 		const float deltaDepth = pm_minf(pm_fabsf(prior - depth) / prior, 0.5f);
 		const float sigma = -1.f / (1.f * 0.02f);
 		const float f = pm_expf(normSq0 * sigma);
@@ -503,6 +512,9 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 	const float prior = (active && t.prior) ? pm_glob(t.prior)[idx] : 0.f;
 	const bool masked = active && t.mask != nullptr && t.mask[idx] == 0;
 	const bool valid = active && !masked && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
+	// prior and its blend factor (DepthMap.cpp:558-559) go to the spare entry of the weight row: pm_score_view<.., PF = true> reads them there
+	if (v == 0) s_w[g][PM_NT] = make_float2(prior, prior > 0 ? pm_expf(normSq0 * (-1.f / (1.f * 0.02f))) : 0.f);
+	__syncthreads();
 	const double X0x = ((double)x - t.cx) / t.fx, X0y = ((double)y - t.cy) / t.fy;
 	const float vx = (float)X0x, vy = (float)X0y, vz = 1.f;
 
@@ -719,7 +731,7 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 		PM_TICK(2);
 		float sc = PM_INF;
 		if (need && v < t.nSrc)
-			sc = pm_score_view<GEO, true, TC>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], sfValid, prior, tile, ts0, tt0 PM_PROF_PASS);
+			sc = pm_score_view<GEO, true, TC, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], sfValid, 0.f, tile, ts0, tt0 PM_PROF_PASS);
 		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 		if (need && conf > nconf) {
 			conf = nconf; depth = hd; nx = hnx; ny = hny; nz = hnz; changed = true;

@@ -171,7 +171,7 @@ __device__ __forceinline__ void pm_group_min2(float s, float& m1, float& m2) {
 
 // ScorePixelImage for this lane's source view, DepthMap.cpp:465-564.
 // sf[]: the (view-independent) smoothness factors of the up-to-4 close neighbours, in insertion
-// order, sfValid bit k set if neighbour k exists (DepthMap.cpp:524-533).
+// order; exactly 1.f for a neighbour that does not exist or does not take part (DepthMap.cpp:524-533).
 // SKEW selects the image layout the 100 bilinear taps read: the sweep kernel walks an anti-diagonal, so
 // the footprints of the pixels of one wave lie along an anti-diagonal of the source image too; in the
 // anti-diagonal-major copy those texels are contiguous (one or two 128-B lines per view instead of one
@@ -228,7 +228,7 @@ template <bool GEO, bool SKEW, int TC, bool PF = false>
 __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask& t, const PMKParams& kp,
 		int x, int y, double X0x, double X0y, float normSq0, float sumW, const float2* wts,
 		float depth, float nx, float ny, float nz,
-		float sf0, float sf1, float sf2, float sf3, unsigned sfValid, float prior,
+		float sf0, float sf1, float sf2, float sf3, float prior,
 		const float* tile, int ts0, int tt0 PM_PROF_ARG)
 {
 	// the image descriptor is requested together with the homography entries (same struct, same round trip)
@@ -325,10 +325,8 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 	if (nrmSq <= 1e-16f) return kp.thRobust;
 	const float ncc = pm_clampf(num / pm_sqrtf(nrmSq), -1.f, 1.f);
 	float score = 1.f - ncc;
-	if (sfValid & 1u) score *= sf0;
-	if (sfValid & 2u) score *= sf1;
-	if (sfValid & 4u) score *= sf2;
-	if (sfValid & 8u) score *= sf3;
+	// (a factor of a neighbour that does not take part is exactly 1.f, and x * 1.f == x: no test needed, DepthMap.cpp:524-533)
+	score *= sf0; score *= sf1; score *= sf2; score *= sf3;
 	if (GEO) {
 		// geometric consistency, DepthMap.cpp:535-551
 		if (s.depth != nullptr) {
@@ -481,7 +479,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 	float sc = PM_INF;
 	PM_PROF_DECL;
 	if (v < t.nSrc)
-		sc = pm_score_view<GEO, false, 0>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, 0u, prior, nullptr, 0, 0 PM_PROF_PASS);
+		sc = pm_score_view<GEO, false, 0>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, nullptr, 0, 0 PM_PROF_PASS);
 	const float conf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 	if (v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
 }
@@ -505,12 +503,47 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 	const int pi = blockIdx.x * PPB + g;
 	const bool active = pi < count;
 	const int x = xlo + (active ? pi : 0), y = d - x;
-	float normSq0, sumW;
-	pm_fill_patch<G, true>(t, active, x, y, v, s_w[g], normSq0, sumW);
 	const size_t idx = (size_t)y * w + x;
 	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
-	const float prior = (active && t.prior) ? pm_glob(t.prior)[idx] : 0.f;
-	const bool masked = active && t.mask != nullptr && t.mask[idx] == 0;
+	// neighbour slots in insertion order (DepthMap.cpp:641-766): with sgn = -1 (LT2RB) / +1 (RB2LT):
+	// slot0 (x+sgn,y), slot1 (x,y+sgn) are the already-updated propagation sources; slot2 (x-sgn,y), slot3 (x,y-sgn).
+	const int sgn = dir == 0 ? -1 : 1;
+	// Everything the visit reads of its own and its neighbours' estimates, the prior and the mask is requested here, before the patch weights:
+	// the loads do not depend on each other, so they share one memory round trip with the patch texels (pm_fill_patch ends in a barrier, which
+	// keeps the compiler from sinking them below the tests that decide whether the pixel is processed).  Neighbours outside the processable
+	// area are redirected to the pixel itself and masked; a pixel that turns out not to be processed simply ignores what it fetched.
+	size_t qis[4]; bool bok[4]; int qxs[4], qys[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const int ox = (k == 0) ? sgn : (k == 2 ? -sgn : 0), oy = (k == 1) ? sgn : (k == 3 ? -sgn : 0);
+		// bounds tests exactly as written: x > HW / y > HW / x < W-HW / y < H-HW
+		bool ok;
+		if (ox == -1) ok = x > PM_HW; else if (ox == 1) ok = x < w - PM_HW; else if (oy == -1) ok = y > PM_HW; else ok = y < h - PM_HW;
+		bok[k] = ok; qxs[k] = x + ox; qys[k] = y + oy;
+		qis[k] = ok ? (size_t)(y + oy) * w + (x + ox) : idx;
+	}
+	float nds[4] = {0.f, 0.f, 0.f, 0.f};
+	float on0[SL], on1[SL], on2[SL];
+	float oDepth = 0.f, oNx = 0.f, oNy = 0.f, oNz = 0.f, oConf = 2.f, prior = 0.f;
+	unsigned char maskByte = 1;
+#pragma unroll
+	for (int q = 0; q < SL; ++q) { on0[q] = on1[q] = 0.f; on2[q] = 1.f; }
+	if (active) {
+		if (t.prior) prior = pm_glob(t.prior)[idx];
+		if (t.mask != nullptr) maskByte = t.mask[idx];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) nds[k] = gDepth[qis[k]];
+#pragma unroll
+		for (int q = 0; q < SL; ++q) {
+			const int k = q * G + v;
+			const size_t qi = (k == 0) ? qis[0] : (k == 1) ? qis[1] : (k == 2) ? qis[2] : (k == 3) ? qis[3] : idx;
+			on0[q] = gNormal[qi * 3]; on1[q] = gNormal[qi * 3 + 1]; on2[q] = gNormal[qi * 3 + 2];
+		}
+		oDepth = gDepth[idx]; oNx = gNormal[idx * 3]; oNy = gNormal[idx * 3 + 1]; oNz = gNormal[idx * 3 + 2]; oConf = gConf[idx];
+	}
+	float normSq0, sumW;
+	pm_fill_patch<G, true>(t, active, x, y, v, s_w[g], normSq0, sumW);
+	const bool masked = active && maskByte == 0;
 	const bool valid = active && !masked && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
 	// prior and its blend factor (DepthMap.cpp:558-559) go to the spare entry of the weight row: pm_score_view<.., PF = true> reads them there
 	if (v == 0) s_w[g][PM_NT] = make_float2(prior, prior > 0 ? pm_expf(normSq0 * (-1.f / (1.f * 0.02f))) : 0.f);
@@ -519,38 +552,13 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 	const float vx = (float)X0x, vy = (float)X0y, vz = 1.f;
 
 	float depth = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, conf = 2.f;
-	// neighbour slots in insertion order (DepthMap.cpp:641-766): with sgn = -1 (LT2RB) / +1 (RB2LT):
-	// slot0 (x+sgn,y), slot1 (x,y+sgn) are the already-updated propagation sources; slot2 (x-sgn,y), slot3 (x,y-sgn).
-	const int sgn = dir == 0 ? -1 : 1;
 	bool pok0 = false, pok1 = false; // propagation candidates (slots 0 and 1) exist; their estimates are re-read when used
 	float qX0[SL], qX1[SL], qX2[SL], qn0[SL], qn1[SL], qn2[SL]; // my smoothness slot(s)
 	unsigned closeMask = 0u;
 #pragma unroll
 	for (int q = 0; q < SL; ++q) { qX0[q] = qX1[q] = qX2[q] = 0.f; qn0[q] = qn1[q] = 0.f; qn2[q] = 1.f; }
 	if (valid) {
-		// all loads of the gather are issued before any of them is consumed (one memory round trip instead of a
-		// chain of three): neighbours outside the processable area are redirected to the pixel itself and masked
-		size_t qis[4]; bool bok[4]; int qxs[4], qys[4];
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int ox = (k == 0) ? sgn : (k == 2 ? -sgn : 0), oy = (k == 1) ? sgn : (k == 3 ? -sgn : 0);
-			// bounds tests exactly as written: x > HW / y > HW / x < W-HW / y < H-HW
-			bool ok;
-			if (ox == -1) ok = x > PM_HW; else if (ox == 1) ok = x < w - PM_HW; else if (oy == -1) ok = y > PM_HW; else ok = y < h - PM_HW;
-			bok[k] = ok; qxs[k] = x + ox; qys[k] = y + oy;
-			qis[k] = ok ? (size_t)(y + oy) * w + (x + ox) : idx;
-		}
-		float nds[4];
-#pragma unroll
-		for (int k = 0; k < 4; ++k) nds[k] = gDepth[qis[k]];
-		float on0[SL], on1[SL], on2[SL];
-#pragma unroll
-		for (int q = 0; q < SL; ++q) {
-			const int k = q * G + v;
-			const size_t qi = (k == 0) ? qis[0] : (k == 1) ? qis[1] : (k == 2) ? qis[2] : (k == 3) ? qis[3] : idx;
-			on0[q] = gNormal[qi * 3]; on1[q] = gNormal[qi * 3 + 1]; on2[q] = gNormal[qi * 3 + 2];
-		}
-		depth = gDepth[idx]; nx = gNormal[idx * 3]; ny = gNormal[idx * 3 + 1]; nz = gNormal[idx * 3 + 2]; conf = gConf[idx];
+		depth = oDepth; nx = oNx; ny = oNy; nz = oNz; conf = oConf;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const bool ok = bok[k] && nds[k] > 0;
@@ -703,7 +711,6 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 		PM_TICK(1); PM_COUNT(6 + 5, 0); PM_COUNT(8, __popcll(__ballot(need)));
 		// smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533
 		float sf[4] = {1.f, 1.f, 1.f, 1.f};
-		unsigned sfValid = 0u;
 		{
 			const bool useS = need && smooth;
 			const float planeD = -hd * (hnx * vx + hny * vy + hnz * vz); // InitPlane, DepthMap.cpp:963-971
@@ -726,12 +733,11 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 #pragma unroll
 			for (int k = 0; k < 4; ++k)
 				sf[k] = __shfl(myF[k / G < SL ? k / G : 0], (k % G), G);
-			if (useS) sfValid = closeMask;
 		}
 		PM_TICK(2);
 		float sc = PM_INF;
 		if (need && v < t.nSrc)
-			sc = pm_score_view<GEO, true, TC, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], sfValid, 0.f, tile, ts0, tt0 PM_PROF_PASS);
+			sc = pm_score_view<GEO, true, TC, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], 0.f, tile, ts0, tt0 PM_PROF_PASS);
 		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 		if (need && conf > nconf) {
 			conf = nconf; depth = hd; nx = hnx; ny = hny; nz = hnz; changed = true;

@@ -653,6 +653,9 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 				const size_t qi = vert ? (size_t)(y + sgn) * w + x : (size_t)y * w + (x + sgn);
 				const size_t qj = pok ? qi : idx;
 				const float pconf = gConf[qj], cnx = gNormal[qj * 3], cny = gNormal[qj * 3 + 1], cnz = gNormal[qj * 3 + 2], cd = gDepth[qj]; // one batch
+				// (assigned whether or not the candidate is taken -- every state that sets `need` sets all four again -- so that the five loads stay
+				// one batch: the compiler otherwise sinks four of them below the test of the fifth, two dependent round trips per propagation state)
+				hd = cd; hnx = cnx; hny = cny; hnz = cnz;
 				if (pok && pconf < kp.thKeep) {
 					// InterpolatePixel, DepthMap.cpp:915-959
 					float depthNew = cd; bool zero;

@@ -218,6 +218,9 @@ __device__ __forceinline__ void pm_homography(const PMSrcView& s, const PMTask& 
 #define PM_TCX 12       // window columns = pixels per wave + PM_TCX: PPW + 9 are needed
 #endif
 #define PM_TILE_PAD 4   // per-view stride = PM_TR*TC + 4 floats: staggers the views over the LDS banks
+#ifndef PM_XCD_REMAP
+#define PM_XCD_REMAP 1  // sweep kernel: contiguous (view, chunk) ranges per XCD (see the kernel)
+#endif
 #ifndef PM_WINBATCH
 #define PM_WINBATCH 4   // source windows whose global loads are in flight together when a visit stages its windows
 #endif
@@ -497,10 +500,21 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 	PM_PROF_DECL;
 	__shared__ float2 s_w[PPB][PM_NT + 1];
 	__shared__ float s_tile[PM_USE_TILES ? PM_BLOCK / 64 : 1][PM_USE_TILES ? G * TSTRIDE : 1];
-	const PMTask& t = tasks[blockIdx.y];
+	// XCD-aware block mapping: workgroup b is observed to run on XCD b % 8 (dispatch order, x fastest), each XCD with its own 4 MB L2.  The remap
+	// hands every XCD a contiguous range of (view, diagonal chunk) pairs -- the same few views launch after launch -- so the source windows of
+	// neighbouring chunks and of the next diagonal are found in that XCD's L2 instead of being fetched into several of them.  Bijective for any
+	// grid size; which workgroup handles which pixels does not matter for the result (the pixels of a diagonal are independent).
+	unsigned vbx = blockIdx.x, vby = blockIdx.y;
+	if (PM_XCD_REMAP) {
+		const unsigned nbx = gridDim.x, nwg = nbx * gridDim.y, orig = blockIdx.y * nbx + blockIdx.x;
+		const unsigned xcd = orig % 8u, q = nwg / 8u, r = nwg % 8u;
+		const unsigned wgid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + orig / 8u;
+		vby = wgid / nbx; vbx = wgid - vby * nbx;
+	}
+	const PMTask& t = tasks[vby];
 	const int g = threadIdx.x / G, v = threadIdx.x % G;
 	const int w = t.w, h = t.h;
-	const int pi = blockIdx.x * PPB + g;
+	const int pi = vbx * PPB + g;
 	const bool active = pi < count;
 	const int x = xlo + (active ? pi : 0), y = d - x;
 	const size_t idx = (size_t)y * w + x;

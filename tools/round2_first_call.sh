@@ -39,10 +39,12 @@ python - > "$OUT/5_variants_build.log" 2>&1 <<'PY'
 from openmvs_amd.build import build_variant
 build_variant("libpmhip.so", "libpmhip_wb1.so", ["-DPM_WINBATCH=1"])   # source windows one view per memory round trip (the timed round-1 kernel did that)
 build_variant("libpmhip.so", "libpmhip_wb8.so", ["-DPM_WINBATCH=8"])
+build_variant("libpmhip.so", "libpmhip_noxcd.so", ["-DPM_XCD_REMAP=0"])  # dispatch-order block mapping (the timed round-1 kernel)
+build_variant("libpmhip.so", "libpmhip_tcx10.so", ["-DPM_TCX=10"])        # 13.3 KB LDS per workgroup: 12 instead of 11 workgroups per CU
 build_variant("libpmhip.so", "libpmhip_tr16.so", ["-DPM_TR=16"])
 build_variant("libpmhip.so", "libpmhip_tr16_w4.so", ["-DPM_TR=16", "-DPM_MINWAVES=4"])
 PY
-timeout 1200 python tools/tune.py 100 libpmhip.so:2 libpmhip_wb1.so:2 libpmhip_wb8.so:2 libpmhip_tr16.so:2 libpmhip_tr16_w4.so:2 libpmhip_tr16.so:3 > "$OUT/5_variants.log" 2>&1; tail -8 "$OUT/5_variants.log"
+timeout 1500 python tools/tune.py 100 libpmhip.so:2 libpmhip_noxcd.so:2 libpmhip_wb1.so:2 libpmhip_wb8.so:2 libpmhip_tcx10.so:2 libpmhip_tr16.so:2 libpmhip_tr16_w4.so:2 libpmhip_tr16.so:3 > "$OUT/5_variants.log" 2>&1; tail -8 "$OUT/5_variants.log"
 step "6 sgm probe"
 timeout 600 python tools/probe_sgm.py > "$OUT/6_sgm_probe.log" 2>&1; tail -5 "$OUT/6_sgm_probe.log"
 step "done"

@@ -80,6 +80,12 @@ struct PMKParams {        // DepthEstimator ctor constants, DepthMap.cpp:397-406
 enum { PM_STREAM_INIT = 0, PM_STREAM_RAND = 1, PM_STREAM_REFINE = 2 };
 
 #define PM_INF __builtin_huge_valf()
+// the value must exist in a register at this point (device only; nothing for the host build of the emulator)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PM_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define PM_OPAQUE(x) do {} while (0)
+#endif
 
 // Optional in-kernel phase timing (build with -DPM_PROFILE): lane 0 of every wave accumulates s_memtime deltas
 // per phase into pm_prof[]; read back with pmhip_prof_get.  Phases: 0 setup (weights, neighbour gather, tiles),
@@ -370,9 +376,11 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 	// low-resolution prior, DepthMap.cpp:553-561
 	if (PF) {
 		const float2 pf = wts[PM_NT];
+		float pfy = pf.y;
+		PM_OPAQUE(pfy);   // both halves are read at once (the compiler otherwise splits the read and sinks one half under the test of the other)
 		if (pf.x > 0) {
 			const float deltaDepth = pm_minf(pm_fabsf(pf.x - depth) / pf.x, 0.5f);
-			score = (1.f - pf.y) * score + pf.y * deltaDepth;
+			score = (1.f - pfy) * score + pfy * deltaDepth;
 		}
 	} else if (prior > 0) {
 		const float deltaDepth = pm_minf(pm_fabsf(prior - depth) / prior, 0.5f);

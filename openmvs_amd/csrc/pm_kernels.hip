@@ -338,12 +338,23 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 	score *= sf0; score *= sf1; score *= sf2; score *= sf3;
 	if (GEO) {
 		// geometric consistency, DepthMap.cpp:535-551
-		if (s.depth != nullptr) {
+		// the source view's depth-map pointer and its four transforms are requested together (they were five dependent round trips per evaluation)
+		const float* sdepth = s.depth;
+		float Tl[9], Tm[3], Tr[9], Tn[3];
+#pragma unroll
+		for (int i = 0; i < 9; ++i) { Tl[i] = s.Tl[i]; Tr[i] = s.Tr[i]; }
+#pragma unroll
+		for (int i = 0; i < 3; ++i) { Tm[i] = s.Tm[i]; Tn[i] = s.Tn[i]; }
+#pragma unroll
+		for (int i = 0; i < 9; ++i) PM_OPAQUE(Tr[i]);
+#pragma unroll
+		for (int i = 0; i < 3; ++i) PM_OPAQUE(Tn[i]);
+		if (sdepth != nullptr) {
 			float consistency = 4.f;
 			const float Xc0 = (float)X0x * depth, Xc1 = (float)X0y * depth, Xc2 = depth;
-			const float Y0 = (s.Tl[0] * Xc0 + s.Tl[1] * Xc1 + s.Tl[2] * Xc2) + s.Tm[0];
-			const float Y1 = (s.Tl[3] * Xc0 + s.Tl[4] * Xc1 + s.Tl[5] * Xc2) + s.Tm[1];
-			const float Y2 = (s.Tl[6] * Xc0 + s.Tl[7] * Xc1 + s.Tl[8] * Xc2) + s.Tm[2];
+			const float Y0 = (Tl[0] * Xc0 + Tl[1] * Xc1 + Tl[2] * Xc2) + Tm[0];
+			const float Y1 = (Tl[3] * Xc0 + Tl[4] * Xc1 + Tl[5] * Xc2) + Tm[1];
+			const float Y2 = (Tl[6] * Xc0 + Tl[7] * Xc1 + Tl[8] * Xc2) + Tm[2];
 			if (Y2 > 0) {
 				const float x1x = Y0 / Y2, x1y = Y1 / Y2;
 				if (pm_inside1(x1x, x1y, sw, sh)) {
@@ -351,7 +362,7 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 					const int lx = (int)x1x, ly = (int)x1y;
 					const float fx = x1x - (float)lx, fx1 = 1.f - fx;
 					const float fy = x1y - (float)ly, fy1 = 1.f - fy;
-					const pm_gcf p = pm_glob(s.depth) + (size_t)ly * sw + lx;
+					const pm_gcf p = pm_glob(sdepth) + (size_t)ly * sw + lx;
 					const float x0y0 = p[0], x1y0 = p[1], x0y1 = p[sw], x1y1 = p[sw + 1];
 					const bool b00 = pm_fabsf(Y2 - x0y0) / Y2 < 0.03f, b10 = pm_fabsf(Y2 - x1y0) / Y2 < 0.03f;
 					const bool b01 = pm_fabsf(Y2 - x0y1) / Y2 < 0.03f, b11 = pm_fabsf(Y2 - x1y1) / Y2 < 0.03f;
@@ -360,9 +371,9 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 							fy1 * (fx1 * (b00 ? x0y0 : (b10 ? x1y0 : (b01 ? x0y1 : x1y1))) + fx * (b10 ? x1y0 : (b00 ? x0y0 : (b11 ? x1y1 : x0y1)))) +
 							fy  * (fx1 * (b01 ? x0y1 : (b11 ? x1y1 : (b00 ? x0y0 : x1y0))) + fx * (b11 ? x1y1 : (b01 ? x0y1 : (b10 ? x1y0 : x0y0))));
 						const float Xd0 = x1x * depth1, Xd1 = x1y * depth1, Xd2 = depth1;
-						const float B0 = (s.Tr[0] * Xd0 + s.Tr[1] * Xd1 + s.Tr[2] * Xd2) + s.Tn[0];
-						const float B1 = (s.Tr[3] * Xd0 + s.Tr[4] * Xd1 + s.Tr[5] * Xd2) + s.Tn[1];
-						const float B2 = (s.Tr[6] * Xd0 + s.Tr[7] * Xd1 + s.Tr[8] * Xd2) + s.Tn[2];
+						const float B0 = (Tr[0] * Xd0 + Tr[1] * Xd1 + Tr[2] * Xd2) + Tn[0];
+						const float B1 = (Tr[3] * Xd0 + Tr[4] * Xd1 + Tr[5] * Xd2) + Tn[1];
+						const float B2 = (Tr[6] * Xd0 + Tr[7] * Xd1 + Tr[8] * Xd2) + Tn[2];
 						const float xbx = B0 / B2, xby = B1 / B2;
 						const float dx = (float)x - xbx, dy = (float)y - xby;
 						const float dist = pm_hypot_d(dx, dy); // cv::norm(Point2f) -> double

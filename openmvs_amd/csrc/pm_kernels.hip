@@ -111,6 +111,11 @@ struct PmProfAcc { unsigned long long a[12]; unsigned long long t; };
 #define PM_FD2R(d) ((d) * (PM_PI_F / 180.f))
 
 // ---- small device helpers -----------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ int pm_mul24(int a, int b) { return __mul24(a, b); }
+#else
+__device__ __forceinline__ int pm_mul24(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+#endif
 __device__ __forceinline__ bool pm_inside1(float px, float py, int w, int h) {
 	// isInsideWithBorder<float,1>, libs/Common/Types.h:1649-1651
 	return px >= 1.f && py >= 1.f && px <= (float)(w - 2) && py <= (float)(h - 2);
@@ -231,6 +236,99 @@ __device__ __forceinline__ void pm_homography(const PMSrcView& s, const PMTask& 
 #define PM_WINBATCH 4   // source windows whose global loads are in flight together when a visit stages its windows
 #endif
 
+// One tap row (5 taps) of ScorePixelImage through global loads, with the reference's per-tap tests; any layout.  X = position of the row's first tap.
+// The reference returns thRobust at the first tap that leaves the image (DepthMap.cpp:484-485).  Here a tap outside only raises a flag and its
+// address is clamped, so there is no branch between taps: the 20 loads of the row are issued back to back and the sums of a flagged hypothesis are
+// simply discarded -- identical result, no load ever depends on a previous load.
+template <bool SKEW>
+__device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int sh, float h0, float h3, float h6, float X0, float X1, float X2,
+		const float2* wrow, float& sum, float& sumSq, float& num, bool& oob)
+{
+	const int lxMax = sw - 2, lyMax = sh - 2;
+	float fxs[5], fys[5];
+	unsigned offs[5];   // texel offsets fit 32 bits (an image or its skewed copy is < 2^32 floats)
+#pragma unroll
+	for (int j = 0; j < 5; ++j) {
+		float ptx, pty;
+		pm_div2(X0, X1, X2, &ptx, &pty); // == X0 / X2, X1 / X2 (TPoint2(Point3), Types.h:1291)
+		oob = oob || !pm_inside1(ptx, pty, sw, sh);
+		// TImage::sample, libs/Common/Types.inl:2273-2281
+		int lx = (int)ptx, ly = (int)pty;
+		fxs[j] = ptx - (float)lx; fys[j] = pty - (float)ly;
+		lx = min(max(lx, 0), lxMax); ly = min(max(ly, 0), lyMax);
+		offs[j] = SKEW ? (unsigned)(lx + ly) * (unsigned)sh + (unsigned)ly : (unsigned)ly * (unsigned)sw + (unsigned)lx;
+		X0 += h0; X1 += h3; X2 += h6;
+	}
+	float v00[5], v01[5], v10[5], v11[5];
+#pragma unroll
+	for (int j = 0; j < 5; ++j) {
+		const pm_gcf p = img + offs[j];
+		// texels (lx,ly), (lx+1,ly), (lx,ly+1), (lx+1,ly+1) sit at skew (s,t), (s+1,t), (s+1,t+1), (s+2,t+1)
+		if (SKEW) { v00[j] = p[0]; v01[j] = p[sh]; v10[j] = p[sh + 1]; v11[j] = p[2 * sh + 1]; }
+		else { v00[j] = p[0]; v01[j] = p[1]; v10[j] = p[sw]; v11[j] = p[sw + 1]; }
+	}
+#pragma unroll
+	for (int j = 0; j < 5; ++j) {
+		const float fx = fxs[j], fx1 = 1.f - fx, fy = fys[j], fy1 = 1.f - fy;
+		const float v = (v00[j] * fx1 + v01[j] * fx) * fy1 + (v10[j] * fx1 + v11[j] * fx) * fy;
+		const float2 pw = wrow[j];
+		const float vw = v * pw.x;
+		sum += vw;
+		sumSq += v * vw;
+		num += v * pw.y;
+	}
+}
+
+// The same row served from the wave's LDS window of the anti-diagonal-major source image, optimistically: no test between the taps.  The divisions
+// use the unguarded reciprocal refinement, the texel indices are only clamped into the window; while it goes the row tracks the extremes of z, of
+// the projected positions and of the window row index, and one comparison set at the end says whether every tap (a) had 2^-40 <= z <= 2^40 (with
+// `sane`: |x|, |y| < 1e18 -- then the quotients are the correctly rounded ones and nothing is NaN), (b) was inside the image (isInsideWithBorder<1>)
+// and (c) inside the window.  If so the three running sums are exactly what pm_tap_row_global computes and the call returns true; otherwise the sums
+// are left untouched and the caller redoes the row through global loads.  ~40 VALU instructions per tap instead of ~100.
+template <int TC>
+__device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int tt0, int sw, int sh, bool sane, float h0, float h3, float h6,
+		float X0, float X1, float X2, const float2* wrow, float& sum, float& sumSq, float& num)
+{
+	constexpr int MAXI = PM_TR * TC - 2 * TC - 2;   // idx + 2*TC + 1 stays inside the window
+	const int cidx = -(ts0 * TC + tt0);
+	float fxs[5], fys[5];
+	const float* q[5];
+	float zlo = X2, zhi = X2, pxlo = PM_INF, pxhi = -PM_INF, pylo = PM_INF, pyhi = -PM_INF;
+	int slo = 0x7fffffff, shi = (int)0x80000000;
+#pragma unroll
+	for (int j = 0; j < 5; ++j) {
+		float ptx, pty;
+		pm_div2_inrange(X0, X1, X2, &ptx, &pty);
+		zlo = pm_fminf(zlo, X2); zhi = pm_fmaxf(zhi, X2);
+		pxlo = pm_fminf(pxlo, ptx); pxhi = pm_fmaxf(pxhi, ptx); pylo = pm_fminf(pylo, pty); pyhi = pm_fmaxf(pyhi, pty);
+		const int lx = (int)ptx, ly = (int)pty;
+		fxs[j] = ptx - (float)lx; fys[j] = pty - (float)ly;
+		const int sk = lx + ly;
+		slo = min(slo, sk); shi = max(shi, sk);
+		const int idx = pm_mul24(sk, TC) + (ly + cidx);   // 24-bit multiply: full rate (a 32-bit one is a quarter-rate v_mad_u64_u32); garbage only where the row fails anyway
+		q[j] = tile + min((unsigned)idx, (unsigned)MAXI);
+		X0 += h0; X1 += h3; X2 += h6;
+	}
+	float s0 = sum, s1 = sumSq, s2 = num;
+#pragma unroll
+	for (int j = 0; j < 5; ++j) {
+		const float v00 = q[j][0], v01 = q[j][TC], v10 = q[j][TC + 1], v11 = q[j][2 * TC + 1];
+		const float fx = fxs[j], fx1 = 1.f - fx, fy = fys[j], fy1 = 1.f - fy;
+		const float v = (v00 * fx1 + v01 * fx) * fy1 + (v10 * fx1 + v11 * fx) * fy;
+		const float2 pw = wrow[j];
+		const float vw = v * pw.x;
+		s0 += vw;
+		s1 += v * vw;
+		s2 += v * pw.y;
+	}
+	// (int)pty in [tt0, tt0 + TC - 2]  <=>  tt0 <= pty < tt0 + TC - 1 once pty >= 1
+	const bool ok = sane && zlo >= 9.094947e-13f && zhi <= 1.0995116e12f
+		&& pxlo >= 1.f && pylo >= 1.f && pxhi <= (float)(sw - 2) && pyhi <= (float)(sh - 2)
+		&& pylo >= (float)tt0 && pyhi < (float)(tt0 + TC - 1) && slo >= ts0 && shi <= ts0 + PM_TR - 3;
+	if (ok) { sum = s0; sumSq = s1; num = s2; }
+	return ok;
+}
+
 // PF: the pixel's low-resolution prior and its blend factor exp(normSq0 * sigma) sit in the spare 26th entry of the pixel's weight row in LDS
 // (written once per visit by the sweep kernel) instead of in two registers that are live across the whole hypothesis loop
 template <bool GEO, bool SKEW, int TC, bool PF = false>
@@ -247,85 +345,28 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 	pm_homography(s, t, X0x, X0y, depth, nx, ny, nz, H);
 	PM_TICK(3);
 	const float px = (float)(x - PM_HW), py = (float)(y - PM_HW);
-	float X0 = H[0] * px + H[1] * py + H[2];
-	float X1 = H[3] * px + H[4] * py + H[5];
-	float X2 = H[6] * px + H[7] * py + H[8];
+	const float X0 = H[0] * px + H[1] * py + H[2];
+	const float X1 = H[3] * px + H[4] * py + H[5];
+	const float X2 = H[6] * px + H[7] * py + H[8];
 	float bX0 = X0, bX1 = X1, bX2 = X2;
 #pragma unroll
 	for (int i = 0; i < 9; ++i) H[i] *= 2.f; // nSizeStep
 	float sum = 0.f, sumSq = 0.f, num = 0.f;
-	// The reference returns thRobust at the first tap that leaves the image (DepthMap.cpp:484-485).  Here a
-	// tap outside only raises a flag and its address is clamped, so there is no branch between taps: the
-	// 20 loads of a tap row are issued back to back (memory-level parallelism) and the sums of a flagged
-	// hypothesis are simply discarded -- identical result, no load ever depends on a previous load.
 	bool oob = false;
-	const int lxMax = sw - 2, lyMax = sh - 2;
+	// |x|, |y| < 1e18 and |z| < 2^40 for every tap of the patch, from the first tap and the step sizes (8 steps along either axis at most)
+	bool sane = false;
+	if (TC > 0)
+		sane = pm_fabsf(X0) + 8.f * (pm_fabsf(H[0]) + pm_fabsf(H[1])) < 5e17f && pm_fabsf(X1) + 8.f * (pm_fabsf(H[3]) + pm_fabsf(H[4])) < 5e17f
+			&& pm_fabsf(X2) + 8.f * (pm_fabsf(H[6]) + pm_fabsf(H[7])) < 5e11f;
 #pragma unroll 1
 	for (int i = 0; i < 5; ++i) {
-		// a tap row is consumed in chunks of PM_TAPCHUNK taps: all loads of a chunk are in flight together; a
-		// smaller chunk trades memory-level parallelism for registers (occupancy)
-#pragma unroll
-		for (int j0 = 0; j0 < 5; j0 += PM_TAPCHUNK) {
-			constexpr int CH = PM_TAPCHUNK;
-			float fxs[CH], fys[CH];
-			unsigned offs[CH];   // texel offsets fit 32 bits (an image or its skewed copy is < 2^32 floats)
-			int tix[CH];
-			bool allIn = true;
-#pragma unroll
-			for (int j = 0; j < CH; ++j) {
-				if (j0 + j >= 5) break;
-				float ptx, pty;
-				pm_div2(X0, X1, X2, &ptx, &pty); // == X0 / X2, X1 / X2 (TPoint2(Point3), Types.h:1291)
-				oob = oob || !pm_inside1(ptx, pty, sw, sh);
-				// TImage::sample, libs/Common/Types.inl:2273-2281
-				int lx = (int)ptx, ly = (int)pty;
-				fxs[j] = ptx - (float)lx; fys[j] = pty - (float)ly;
-				lx = min(max(lx, 0), lxMax); ly = min(max(ly, 0), lyMax);
-				offs[j] = SKEW ? (unsigned)(lx + ly) * (unsigned)sh + (unsigned)ly : (unsigned)ly * (unsigned)sw + (unsigned)lx;
-				if (TC > 0) {
-					const int rs = lx + ly - ts0, ct = ly - tt0;
-					const bool in = (unsigned)rs < (unsigned)(PM_TR - 2) && (unsigned)ct < (unsigned)(TC - 1);
-					// a hypothesis already flagged out-of-image needs no texel at all (its sums are discarded): keep it on the LDS path
-					allIn = allIn && (in || oob);
-					tix[j] = in ? rs * TC + ct : 0;
-				}
-				X0 += H[0]; X1 += H[3]; X2 += H[6];
-			}
-			float v00[CH], v01[CH], v10[CH], v11[CH];
+		bool done = false;
+		if (TC > 0) done = pm_tap_row_lds<TC>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num) || oob;
 #ifdef PM_PROFILE
-			if (TC > 0) { PM_COUNT(10, __popcll(__ballot(allIn))); PM_COUNT(11, __popcll(__ballot(true))); PM_COUNT(7, __all(allIn) ? 1 : 0); }
+		if (TC > 0) { PM_COUNT(10, __popcll(__ballot(done))); PM_COUNT(11, __popcll(__ballot(true))); PM_COUNT(7, __all(done) ? 1 : 0); }
 #endif
-			if (TC > 0 && allIn) {
-				// texels (lx,ly), (lx+1,ly), (lx,ly+1), (lx+1,ly+1) sit at skew (s,t), (s+1,t), (s+1,t+1), (s+2,t+1)
-#pragma unroll
-				for (int j = 0; j < CH; ++j) {
-					if (j0 + j >= 5) break;
-					const float* q = tile + tix[j];
-					v00[j] = q[0]; v01[j] = q[TC]; v10[j] = q[TC + 1]; v11[j] = q[2 * TC + 1];
-				}
-			} else {
-#pragma unroll
-				for (int j = 0; j < CH; ++j) {
-					if (j0 + j >= 5) break;
-					const pm_gcf p = img + offs[j];
-					if (SKEW) { v00[j] = p[0]; v01[j] = p[sh]; v10[j] = p[sh + 1]; v11[j] = p[2 * sh + 1]; }
-					else { v00[j] = p[0]; v01[j] = p[1]; v10[j] = p[sw]; v11[j] = p[sw + 1]; }
-				}
-			}
-#pragma unroll
-			for (int j = 0; j < CH; ++j) {
-				if (j0 + j >= 5) break;
-				const float fx = fxs[j], fx1 = 1.f - fx, fy = fys[j], fy1 = 1.f - fy;
-				const float v = (v00[j] * fx1 + v01[j] * fx) * fy1 + (v10[j] * fx1 + v11[j] * fx) * fy;
-				const float2 pw = wts[i * 5 + j0 + j];
-				const float vw = v * pw.x;
-				sum += vw;
-				sumSq += v * vw;
-				num += v * pw.y;
-			}
-		}
+		if (!done) pm_tap_row_global<SKEW>(img, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
 		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
-		X0 = bX0; X1 = bX1; X2 = bX2;
 	}
 	PM_TICK(4);
 	if (oob) return kp.thRobust;

@@ -97,6 +97,40 @@ PM_HD void pm_div2(float x, float y, float z, float* qx, float* qy) {
 	*qx = x / z; *qy = y / z;
 #endif
 }
+// The fast branch of pm_div2 without its range test, for callers that establish the range themselves (the sweep kernel's tap rows check
+// 2^-40 <= z <= 2^40 and |x|, |y| < 1e18 once per row, after the fact, and redo the row through pm_div2 when that fails).
+PM_HD void pm_div2_inrange(float x, float y, float z, float* qx, float* qy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	float r = __builtin_amdgcn_rcpf(z);
+	const float e = __builtin_fmaf(-z, r, 1.0f);
+	r = __builtin_fmaf(e, r, r);
+	float q = x * r;
+	float t = __builtin_fmaf(-z, q, x); q = __builtin_fmaf(t, r, q);
+	t = __builtin_fmaf(-z, q, x); q = __builtin_fmaf(t, r, q);
+	*qx = q;
+	q = y * r;
+	t = __builtin_fmaf(-z, q, y); q = __builtin_fmaf(t, r, q);
+	t = __builtin_fmaf(-z, q, y); q = __builtin_fmaf(t, r, q);
+	*qy = q;
+#else
+	*qx = x / z; *qy = y / z;
+#endif
+}
+// min / max of values known not to be NaN (v_min_f32 / v_max_f32, fused into v_min3 / v_max3 by the compiler)
+PM_HD float pm_fminf(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_fminf(a, b);
+#else
+	return a < b ? a : b;
+#endif
+}
+PM_HD float pm_fmaxf(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_fmaxf(a, b);
+#else
+	return a > b ? a : b;
+#endif
+}
 PM_HD float pm_floorf(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
 	return __builtin_floorf(x);

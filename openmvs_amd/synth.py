@@ -42,25 +42,65 @@ class Scene:
         return self.gray.shape[0]
 
 
-def _height(x, y, hp):
+_PI_HI = 3.141592653589793          # fl(pi)
+_PI_LO = 1.2246467991473532e-16     # pi - fl(pi)
+_SIN_C = (-1.0 / 6, 1.0 / 120, -1.0 / 5040, 1.0 / 362880, -1.0 / 39916800, 1.0 / 6227020800, -1.0 / 1307674368000, 1.0 / 355687428096000)
+
+
+def exact_sin(x):
+    """sin(x) from IEEE +,-,*,round only (no libm, no fused operations): the same bits on every host CPU and on the GPU, for Python floats
+    and float64 torch tensors alike.  Accuracy ~1e-16 for the |x| < 1e5 the generator produces; what matters here is reproducibility, because
+    the full-size golden files (tests/golden/) pin outputs for inputs that every machine has to regenerate."""
+    if isinstance(x, torch.Tensor):
+        k = torch.round(x * (1.0 / _PI_HI))
+        odd = k - 2.0 * torch.floor(k * 0.5)
+    else:
+        k = float(round(x * (1.0 / _PI_HI)))
+        odd = k - 2.0 * math.floor(k * 0.5)
+    r = (x - k * _PI_HI) - k * _PI_LO
+    r2 = r * r
+    p = _SIN_C[-1]
+    for c in _SIN_C[-2::-1]:
+        p = p * r2 + c
+    s = r + r * (r2 * p)
+    return s * (1.0 - 2.0 * odd)
+
+
+def exact_cos(x):
+    return exact_sin(x + 0.5 * _PI_HI)
+
+
+def _height(x, y, hp, sin=torch.sin):
     z = torch.zeros_like(x)
     for (f, g, p, q, a) in hp:
-        z = z + a * torch.sin(f * x + p) * torch.sin(g * y + q)
+        z = z + a * sin(f * x + p) * sin(g * y + q)
     return z
 
 
-def _albedo(x, y, ap, ch):
+def _albedo(x, y, ap, ch, sin=torch.sin):
     v = torch.full_like(x, 0.5)
     for (fx, fy, ph, amp, dph) in ap:
-        v = v + amp * torch.sin(fx * x + fy * y + ph + dph * ch)
+        v = v + amp * sin(fx * x + fy * y + ph + dph * ch)
     return v
 
 
 def make_scene_torch(n_views: int, width: int, height: int, n_src: int = 8, seed: int = SEED,
                      device: str | torch.device = "cpu", spacing: float = 0.12, grid_cols: int | None = None,
-                     want_bgr: bool = False, gt_views: int | None = None) -> dict:
+                     want_bgr: bool = False, gt_views: int | None = None, exact: bool = False) -> dict:
     """Render `n_views` views of the seeded scene; images stay torch tensors on `device`.
-    gt_views: keep ground-truth depth only for the first gt_views views (None = all)."""
+    gt_views: keep ground-truth depth only for the first gt_views views (None = all).
+    exact: build the scene from correctly rounded IEEE operations only (exact_sin instead of libm / the device's sin, explicit
+    3-vector arithmetic instead of BLAS): identical images, cameras and ranges on any host and on the GPU (a different, equally valid scene
+    than exact=False; used by the full-size golden files)."""
+    _sin = exact_sin if exact else torch.sin
+    _msin = exact_sin if exact else math.sin
+    _mcos = exact_cos if exact else math.cos
+
+    def _norm(v):
+        return math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) if exact else np.linalg.norm(v)
+
+    def _cross(a, b):
+        return np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]) if exact else np.cross(a, b)
     rng = np.random.RandomState(seed)
     dev = torch.device(device)
     S = 1.0
@@ -80,8 +120,8 @@ def make_scene_torch(n_views: int, width: int, height: int, n_src: int = 8, seed
         for _ in range(2):
             th = rng.uniform(0, math.pi)
             k = 2 * math.pi / (lam_px * footprint)
-            ap.append((k * math.cos(th), k * math.sin(th), rng.uniform(0, 2 * math.pi),
-                       0.055 * min(1.0, (lam_px / 6.0) ** 0.5), rng.uniform(-0.6, 0.6)))
+            ap.append((k * _mcos(th), k * _msin(th), rng.uniform(0, 2 * math.pi),
+                       0.055 * min(1.0, math.sqrt(lam_px / 6.0)), rng.uniform(-0.6, 0.6)))
     # cameras on a grid, mildly tilted towards the scene centre
     cols = grid_cols or int(math.ceil(math.sqrt(n_views)))
     rows = int(math.ceil(n_views / cols))
@@ -92,9 +132,9 @@ def make_scene_torch(n_views: int, width: int, height: int, n_src: int = 8, seed
         cy = (r - (rows - 1) / 2) * spacing + rng.uniform(-0.1, 0.1) * spacing
         C = np.array([cx, cy, cam_h + rng.uniform(-0.02, 0.02)])
         target = np.array([0.7 * cx, 0.7 * cy, 0.0])
-        z = target - C; z /= np.linalg.norm(z)
-        x = np.cross(np.array([0.0, -1.0, 0.0]), z); x /= np.linalg.norm(x)
-        y = np.cross(z, x)
+        z = target - C; z /= _norm(z)
+        x = _cross(np.array([0.0, -1.0, 0.0]), z); x /= _norm(x)
+        y = _cross(z, x)
         Rs[i] = np.stack([x, y, z]); Cs[i] = C
         Ks[i] = np.array([[fpx, 0, (width - 1) / 2], [0, fpx, (height - 1) / 2], [0, 0, 1]])
     u = torch.arange(width, device=dev, dtype=torch.float64)
@@ -118,11 +158,11 @@ def make_scene_torch(n_views: int, width: int, height: int, n_src: int = 8, seed
         dz = R[0, 2] * rx + R[1, 2] * ry + R[2, 2]
         t = (0.0 - C[2]) / dz
         for _ in range(40):
-            t = (_height(C[0] + t * dx, C[1] + t * dy, hp) - C[2]) / dz
+            t = (_height(C[0] + t * dx, C[1] + t * dy, hp, _sin) - C[2]) / dz
         X = C[0] + t * dx; Y = C[1] + t * dy; Z = C[2] + t * dz
         chans = []
         for ch in range(3):
-            a = _albedo(X, Y, ap, float(ch - 1))
+            a = _albedo(X, Y, ap, float(ch - 1), _sin)
             # 8-px checker modulation (in mean-footprint units)
             chk = (torch.floor(X / (8 * footprint)) + torch.floor(Y / (8 * footprint))) % 2
             a = a * (0.92 + 0.08 * chk)
@@ -150,9 +190,9 @@ def make_scene_torch(n_views: int, width: int, height: int, n_src: int = 8, seed
 
 def make_scene(n_views: int, width: int, height: int, n_src: int = 8, seed: int = SEED,
                device: str | torch.device = "cpu", spacing: float = 0.12, grid_cols: int | None = None,
-               gray_only: bool = False) -> Scene:
+               gray_only: bool = False, exact: bool = False) -> Scene:
     """Render `n_views` views of the seeded scene at width x height; numpy arrays on the host."""
-    t = make_scene_torch(n_views, width, height, n_src, seed, device, spacing, grid_cols, want_bgr=not gray_only)
+    t = make_scene_torch(n_views, width, height, n_src, seed, device, spacing, grid_cols, want_bgr=not gray_only, exact=exact)
     bgr = t["bgr"].cpu().numpy() if t["bgr"] is not None else np.zeros((0,), np.uint8)
     return Scene(width, height, t["gray"].cpu().numpy(), bgr, t["K"], t["R"], t["C"], t["gt_depth"].cpu().numpy(),
                  t["neighbors"], t["dmin"], t["dmax"], t["diameter"], t["meta"])

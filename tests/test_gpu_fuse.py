@@ -42,8 +42,6 @@ def test_device_fuse_is_the_sequential_fuse(small_scene, nine_scene, case):
     e.close()
 
 
-@pytest.mark.xfail(strict=False, reason="option values added after the round's GPU budget was spent; passes on the CPU emulator, not yet run on a device")
-@pytest.mark.isolated
 def test_fuse_option_sweep(small_scene):
     """FuseDepthMaps with thresholds and view counts away from the defaults: more views than any point has, very tight and very loose depth / normal
     thresholds, colours without normals and the reverse.  NOT YET RUN ON A DEVICE (the kernels are; these values are not)."""
@@ -63,7 +61,6 @@ def test_fuse_option_sweep(small_scene):
     e.close()
 
 
-@pytest.mark.xfail(strict=False, reason="added after the round's GPU budget was spent: verified kernels, but this fixture path has not run on a device yet")
 def test_device_fuse_reproduces_the_golden_cloud():
     """The committed fixture (tests/golden/fuse_golden_96x64.npz, written by the oracle): same inputs through the C ABI."""
     from tests.test_fuse import _golden_inputs

@@ -242,8 +242,6 @@ def test_gap_interpolation_parity(small_scene):
     e.close()
 
 
-@pytest.mark.xfail(strict=False, reason="option values added after the round's GPU budget was spent; passes on the CPU emulator, not yet run on a device")
-@pytest.mark.isolated
 def test_post_filter_option_sweep(small_scene):
     """The thresholds and sizes of the three post-filters away from their defaults, all on one estimate: RemoveSmallSegments (speckle size 0, 1, 15,
     huge; loose / tight depth threshold), GapInterpolation (gap 0, 1, 3, 20), FilterDepthMap (view counts 1..3, tight / loose threshold, both
@@ -364,8 +362,6 @@ def test_ignore_mask_parity(small_scene):
     e.close()
 
 
-@pytest.mark.xfail(strict=False, reason="entry point added after the round's GPU budget was spent; passes on the CPU emulator, not yet run on a device")
-@pytest.mark.isolated
 def test_single_call_with_ignore_mask(engine, small_scene):
     """pmhip_estimate_depth_map_masked (the PatchMatchCUDA-shaped call with DepthData::mask): with a mask, with the option but no mask, and a
     plain call afterwards (the engine keeps no mask state between calls).  NOT YET RUN ON A DEVICE."""
@@ -388,8 +384,6 @@ def test_single_call_with_ignore_mask(engine, small_scene):
     _same(d, od, "plain call after masked calls")
 
 
-@pytest.mark.xfail(strict=False, reason="added after the round's GPU budget was spent; passes on the CPU emulator, not yet run on a device")
-@pytest.mark.isolated
 def test_many_source_views_parity(engine):
     """9 .. 16 source views (G = 16 lanes per pixel, the widest instantiation, 4 pixels per wavefront) and the partial groups 5, 6; one geometric round
     at 16; more than PMHIP_MAX_SOURCES is an argument error.  NOT YET RUN ON A DEVICE (the G = 16 kernels never were)."""
@@ -422,8 +416,6 @@ def test_many_source_views_parity(engine):
         engine.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, [ref] + list(sc.neighbors[ref][:17]), sc.dmin[ref], sc.dmax[ref], params=p)
 
 
-@pytest.mark.xfail(strict=False, reason="added after the round's GPU budget was spent; passes on the CPU emulator, not yet run on a device")
-@pytest.mark.isolated
 def test_degenerate_inputs(engine):
     """Textureless images (every pixel fails the descriptor-magnitude test: empty maps), an image smaller than the patch at its coarsest level, and
     the post-filters and the fusion on empty maps.  NOT YET RUN ON A DEVICE."""
@@ -471,8 +463,6 @@ OPTION_SETS = [
 ]
 
 
-@pytest.mark.xfail(strict=False, reason="option sets added after the round's GPU budget was spent; pass on the CPU emulator, not yet run on a device")
-@pytest.mark.isolated
 @pytest.mark.parametrize("k", range(len(OPTION_SETS)))
 def test_non_default_options_parity(engine, small_scene, k):
     """Every OPTDENSE value the estimator reads (DepthMap.cpp:69-90 -> PMHipParams), away from its default: photometric pass, and for the first set a

@@ -45,8 +45,6 @@ def test_match_parity(matcher, w, h, kind, dmin, dmax):
         assert (d[:, 8:w - 6 - (dmax + 8)] == 5).mean() > 0.97
 
 
-@pytest.mark.xfail(strict=False, reason="input class added after the round's GPU budget was spent; passes on the CPU emulator, not yet run on a device")
-@pytest.mark.isolated
 def test_match_parity_across_long_invalid_runs(matcher):
     """Masked regions (ranges NO_DISP..NO_DISP) wider than the path kernel's 64-pixel table chunk: paths skip them without resetting their state
     (SemiGlobalMatcher.cpp:1071-1072), so a whole staged chunk can be invalid.  NOT YET RUN ON A DEVICE."""
@@ -56,8 +54,6 @@ def test_match_parity_across_long_invalid_runs(matcher):
     _check(matcher, lb, lg, rg, px, n, mx)
 
 
-@pytest.mark.xfail(strict=False, reason="kernels added after the round's GPU budget was spent; pass on the CPU emulator, not yet run on a device")
-@pytest.mark.isolated
 @pytest.mark.parametrize("w,h,kind,dmin,dmax", [(96, 64, "uniform", 0, 16), (97, 65, "ragged", -5, 40), (128, 80, "ragged", -4, 60), (70, 150, "ragged", -3, 30),
                                                (120, 90, "ragged", 0, 200), (203, 71, "uniform", 0, 70), (230, 100, "holes", -2, 12)])
 def test_sub_group_kernels_match_parity(matcher, w, h, kind, dmin, dmax):
@@ -72,8 +68,6 @@ def test_sub_group_kernels_match_parity(matcher, w, h, kind, dmin, dmax):
         matcher.set_sub_group_kernels(False)
 
 
-@pytest.mark.xfail(strict=False, reason="added after the round's GPU budget was spent; passes on the CPU emulator, not yet run on a device")
-@pytest.mark.isolated
 @pytest.mark.parametrize("sub", [False, True])
 def test_range_limits(matcher, sub):
     """The widest range the engine takes (256 disparities, most of them outside the right image: cost 255), one more is an argument error; a valid grid
@@ -95,8 +89,6 @@ def test_range_limits(matcher, sub):
         matcher.set_sub_group_kernels(False)
 
 
-@pytest.mark.xfail(strict=False, reason="kernels added after the round's GPU budget was spent; pass on the CPU emulator, not yet run on a device")
-@pytest.mark.isolated
 @pytest.mark.parametrize("lanes", [8, 32])
 def test_sub_group_widths(matcher, lanes):
     """The other two sub-group widths (8 and 32 lanes per pixel / pair / line; 16 is covered above).  NOT YET RUN ON A DEVICE."""

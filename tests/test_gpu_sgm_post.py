@@ -50,20 +50,7 @@ def test_refine_on_the_resident_match(matcher):
             assert np.array_equal(c, oc)
 
 
-# NOT YET RUN ON A DEVICE.  The five functions below (8 cases) were written after the round's GPU budget was used up.  Their per-thread logic is
-# verified on the CPU through the host emulation (tests/test_sgm_post.py, tests/cpp/sgm_post_emul.cpp) and the kernels themselves pass under the wave64
-# emulator (tests/test_emu_kernels.py); neither is a device run.  They run in a child process
-# (`isolated`, tests/conftest.py) so that a GPU fault cannot abort the session and lose the results of the verified tests, and carry a non-strict xfail.
-# How to read the outcome: XPASS = the child passed, the kernel is confirmed on the device; XFAIL = it crashed, hung or gave a wrong answer, and the
-# reason string holds the child's exit code and output.  A green session therefore says nothing about these kernels: look for 8 XPASS (-rxX).
-_xf = pytest.mark.xfail(strict=False, reason="first device run of these kernels (CPU emulation verified only)")
-
-
-def _first_run(f):
-    return _xf(pytest.mark.isolated(f))
-
-
-@_first_run
+# Rows f8-f9: first confirmed on a device by the round-1 driver run (GPUTEST_r01: all cases passed); strict since round 2.
 @pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (97, 53, 1)])
 def test_range_map_matches_the_oracle(matcher, w, h, seed):
     d = pc.smooth_disparity(w, h, seed)
@@ -76,7 +63,6 @@ def test_range_map_matches_the_oracle(matcher, w, h, seed):
             assert np.array_equal(px0[k], px1[k]), k
 
 
-@_first_run
 @pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (97, 53, 1)])
 def test_disparity_depth_conversions_match_the_oracle(matcher, w, h, seed):
     H, Q, iH, iQ = pc.rectification(seed)
@@ -93,7 +79,6 @@ def test_disparity_depth_conversions_match_the_oracle(matcher, w, h, seed):
             assert cst is None or np.array_equal(ca.view(np.uint32), cb.view(np.uint32))
 
 
-@_first_run
 @pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (97, 53, 1)])
 def test_projection_and_pair_fusion_match_the_oracle(matcher, w, h, seed):
     from tests.test_sgm_post import _pair_maps
@@ -115,7 +100,6 @@ def test_projection_and_pair_fusion_match_the_oracle(matcher, w, h, seed):
         assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
 
 
-@_first_run
 def test_filter_speckles_matches_the_oracle(matcher):
     for w, h, seed in ((64, 40, 0), (131, 77, 1), (400, 300, 2)):
         base = pc.smooth_disparity(w, h, seed)
@@ -125,7 +109,6 @@ def test_filter_speckles_matches_the_oracle(matcher):
             assert np.array_equal(matcher.FilterSpeckles(noisy, mx, df), po.sgm_filter_speckles(noisy, mx, df)), (w, h, mx, df)
 
 
-@_first_run
 def test_tsgm_loop_on_the_device_equals_the_loop_on_the_oracle(matcher):
     """openmvs_amd/tsgm.py: the same coarse-to-fine loop, every step on the device vs every step on the oracle."""
     from openmvs_amd import tsgm
@@ -144,7 +127,6 @@ def test_tsgm_loop_on_the_device_equals_the_loop_on_the_oracle(matcher):
     assert ok.mean() > 0.6 and abs(np.median(dev[0][ok] / 4.0) - d0) < 0.5
 
 
-@_first_run
 @pytest.mark.parametrize("w,h,d0,min_res", [(96, 64, 6, 32), (200, 120, 7, 30), (256, 192, 12, 64)])
 def test_resident_tsgm_loop_equals_the_stepwise_loop(matcher, w, h, d0, min_res):
     """sgmhip_tsgm_match (the whole loop in one call, resident in HBM) against openmvs_amd/tsgm.py on the oracle backend: with masks, with and
@@ -166,7 +148,6 @@ def test_resident_tsgm_loop_equals_the_stepwise_loop(matcher, w, h, d0, min_res)
         matcher.tsgm_match(lb[:, :-1], rb[:, :-1], lg[:, :-1], rg[:, :-1], mask[:, :-1], mask[:, :-1], min_resolution=min_res)      # not a multiple of 2^levels
 
 
-@_first_run
 @pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (97, 53, 1)])
 def test_resident_fuse_equals_the_stepwise_fuse(matcher, w, h, seed):
     """sgmhip_fuse_disparities (projection of every pair + per-pixel fusion in one resident call) against the same steps on the oracle backend;

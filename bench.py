@@ -2,18 +2,22 @@
 """bench.py -- depth-map throughput of the MI355X-native PatchMatch engine.
 
 Metric (BASELINE.json): Mpix/s of depth-map output at 1920x1080, N = 8 source views.
-Workload at N GPUs: a synthetic scene of (views_per_gpu x N) views of 1920x1080 (config 3 of
-BASELINE.json at 1 GPU: 100 views); each rank owns a contiguous block of reference views.
-One step = the full reference schedule for every view of the rank's block: photometric pass
-(3-level pyramid x 3 sweeps, SceneDensify.cpp:616-805) + 2 geometric-consistency rounds, with the
-depth maps of the previous round exchanged between ranks at the two round boundaries
-(one RCCL all-gather each; the only collectives besides the initial image broadcast).
-Inputs (images, cameras) are resident in HBM before the timed region starts.
+Workload (BASELINE config 3): a FIXED synthetic scene of `--views` (100) views of 1920x1080; at N GPUs every rank owns a contiguous block
+of 100/N reference views ("scaling": "strong"; `--weak` restores round 1's 100 views per GPU).  One step = the full reference schedule for
+every view of the rank's block: photometric pass (3-level pyramid x 3 sweeps, SceneDensify.cpp:616-805) + 2 geometric-consistency rounds,
+with the depth maps of the previous round exchanged between ranks at the two round boundaries (one RCCL all-gather each; the only
+collectives besides the initial image broadcast).  `--with-filter` appends the cross-view filter of config 5 to the step (all-gather of
+depth + confidence, FilterDepthMap on the rank's own views, SceneDensify.cpp:2136-2222).  Inputs are resident in HBM before the clock starts.
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: under torch.distributed.run)
 
-Prints ONE JSON line on rank 0.  The CPU oracle is used only for the reported `cpu_baseline`
-(timed on the host cores) and the depth-RMSE check -- never inside the timed GPU region.
+Prints ONE JSON line on rank 0.  At N = 1 the line also carries (outside the timed region):
+  config2  -- BASELINE config 2 through the one-call boundary (pmhip_estimate_depth_map, host buffers in / out): seconds per depth map;
+  parity   -- the 9-view 1920x1080 scene against the committed digests of the sequential CPU oracle (tests/golden/), all 27 maps,
+              plus a small live oracle-vs-engine comparison;
+  sgm      -- BASELINE config 4: SemiGlobalMatcher::Match at 2048x1536, D = 64 and 128, ms per Match and GB/s on the 43 B/cost model;
+  cpu_baseline -- the restated CPU path timed on this box's host cores.
+The CPU oracle is used only for `cpu_baseline` and the live parity leg -- never inside a timed GPU region.
 """
 from __future__ import annotations
 
@@ -30,7 +34,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_TFLOPS = 157.3  # FP32 vector peak (packed), same guide
+FLOP_PER_PIXEL = 0.33e6   # algorithmic FP32 work of the full schedule per output pixel at N = 8
 
 
 def parse():
@@ -38,13 +44,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--views-per-gpu", type=int, default=100)
+    ap.add_argument("--views", type=int, default=100, help="views of the scene (strong scaling: shared by all GPUs)")
+    ap.add_argument("--views-per-gpu", type=int, default=0, help="implies --weak with this many views per GPU")
+    ap.add_argument("--weak", action="store_true", help="scene grows with the GPUs: --views per GPU")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sources", type=int, default=8)
     ap.add_argument("--geo-iters", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="reference views estimated concurrently (0 = whole block)")
+    ap.add_argument("--with-filter", action="store_true", help="append the cross-view depth-map filter (config 5's exchange) to every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the config2 / parity / sgm blocks")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -66,10 +76,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from openmvs_amd import synth
+    from openmvs_amd.distributed import ShardedDensifier, shard_range
     from openmvs_amd.patchmatch import PatchMatchHIP, default_params
 
-    W, H, N, Vg = a.width, a.height, a.sources, a.views_per_gpu
-    V = Vg * world
+    W, H, N = a.width, a.height, a.sources
+    weak = a.weak or a.views_per_gpu > 0
+    V = (a.views_per_gpu or a.views) * world if weak else a.views
+    mine = list(shard_range(V, world, rank))
     # ---- inputs: rank 0 renders the scene, one broadcast of the image set -------------------
     if rank == 0:
         sc = synth.make_scene_torch(V, W, H, n_src=N, device=dev, gt_views=1)
@@ -97,14 +110,14 @@ def main():
     del gray
     torch.cuda.empty_cache()
     p = default_params(seed=1, nEstimationGeometricIters=a.geo_iters)
-    B = a.batch if a.batch > 0 else Vg
+    B = a.batch if a.batch > 0 else max(1, len(mine))
 
     class EngineEstimator:
         """Adapter between the sharding driver (openmvs_amd/distributed.py, also exercised under gloo
         in tests/test_distributed.py) and the HBM-resident scene interface of the HIP engine."""
 
         def __init__(self):
-            self.buf = torch.empty((Vg, H, W), dtype=torch.float32, device=dev)
+            self.buf = torch.empty((max(1, len(mine)), H, W), dtype=torch.float32, device=dev)
 
         def reset(self, ids):
             for v in ids:
@@ -114,10 +127,15 @@ def main():
             for i in range(0, len(ids), B):
                 eng.scene_estimate(ids[i:i + B], geo, p, sync=False)
 
-        def local_depths(self, ids):
-            eng.scene_copy(1, ids[0], len(ids), self.buf.data_ptr(), False)
+        def local_maps(self, ids, what):
+            buf = self.buf[:len(ids)]
+            if len(ids):
+                eng.scene_copy({"depth": 1, "conf": 3}[what], ids[0], len(ids), buf.data_ptr(), False)
             eng.sync()
-            return self.buf
+            return buf
+
+        def local_depths(self, ids):
+            return self.local_maps(ids, "depth")
 
         def set_snapshot(self, allv):
             # previous-round depth maps of all views become visible to this rank (the reference writes
@@ -125,10 +143,21 @@ def main():
             torch.cuda.synchronize()
             eng.scene_copy(4, 0, V, allv.data_ptr(), True)
 
-    from openmvs_amd.distributed import ShardedDensifier
+        def set_maps(self, what, allv):
+            torch.cuda.synchronize()
+            eng.scene_copy({"depth": 1, "conf": 3}[what], 0, V, allv.data_ptr(), True)
+
+        def filter(self, ids):
+            if len(ids):
+                eng.scene_filter(ids, True, 2, 1, 0.01, commit=True)
+
     drv = ShardedDensifier(EngineEstimator(), V, world, rank, geo_iters=a.geo_iters)
-    assert len(drv.mine) == Vg
-    step = drv.run
+    assert drv.mine == mine
+
+    def step():
+        drv.run()
+        if a.with_filter:
+            drv.filter()
 
     def fence():
         eng.sync(); torch.cuda.synchronize()
@@ -161,31 +190,53 @@ def main():
         wall_s = st.sweepWallMs / 1e3       # wall time of the sweep phases (view groups overlap)
         achieved = st.sweepBytes / 1e9 / max(sweep_s, 1e-12)
         device = st.sweepBytes / 1e9 / max(wall_s, 1e-12)
+        per_launch = st.sweepBytes / max(1, st.sweepLaunches)
+        valu_tf = FLOP_PER_PIXEL * (len(mine) * W * H * a.steps / dt) / 1e12   # this rank's pixels per second x algorithmic flop per pixel
         out = {
             "metric": "Mpix/s depth-map output at 1920x1080 N-view", "value": round(mpix, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d-view %dx%d synthetic scene, %d source views per reference view, PatchMatch photometric pass "
-                                   "(3-level pyramid x 3 sweeps) + %d geometric rounds, all depth maps" % (V, W, H, N, a.geo_iters),
-                       "views_per_gpu": Vg, "views_total": V, "batch": B, "parallelism": "views sharded over %d GPU(s)" % world},
+                                   "(3-level pyramid x 3 sweeps) + %d geometric rounds%s, all depth maps"
+                                   % (V, W, H, N, a.geo_iters, " + cross-view filter" if a.with_filter else ""),
+                       "views_total": V, "views_per_gpu": len(mine), "batch": B, "parallelism": "reference views sharded over %d GPU(s)" % world},
             "roofline": {"bound": "hbm", "kernel": "pm_sweep_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": measured_traffic(per_launch),
                          "launches": int(st.sweepLaunches), "avg_launch_us": round(1e3 * st.sweepMs / max(1, st.sweepLaunches), 2),
-                         "algorithmic_bytes_per_launch": round(st.sweepBytes / max(1, st.sweepLaunches), 1),
+                         "algorithmic_bytes_per_launch": round(per_launch, 1),
                          "concurrent_streams": round(sweep_s / max(wall_s, 1e-12), 2), "device_achieved": round(device, 2),
                          "device_frac": round(device / HBM_PEAK_GBS, 6), "sweep_share_of_step": round(wall_s / dt, 4),
+                         "valu_achieved_tflops": round(valu_tf, 3), "valu_peak_tflops": VALU_PEAK_TFLOPS, "valu_frac": round(valu_tf / VALU_PEAK_TFLOPS, 5),
                          "note": "achieved = algorithmic bytes per launch (SURVEY 8(d) B_sweep / launches) / average launch duration from HIP events on the "
-                                 "launching streams (rank 0); two view groups run on two streams, so the device moves device_achieved"},
+                                 "launching streams (rank 0); the view groups run on separate streams, so the device moves device_achieved; "
+                                 "valu_* = SURVEY 8(d)'s 0.33 MFLOP per output pixel x this GPU's pixel rate against the FP32 vector peak"},
             "accuracy": {"valid_frac_view0": round(float(m.mean()), 4), "median_rel_err_vs_ground_truth": float(np.median(rel))},
         }
-    # ---- CPU baseline + parity check (rank 0, 1 GPU only; outside the timed region) ----------
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out.update(cpu_legs(a, eng))
+    # ---- extra legs (rank 0, 1 GPU only; outside the timed region) ---------------------------
+    if rank == 0 and world == 1:
+        eng.scene_create(2, 16, 16, 0)   # release the benchmark scene's HBM before the other legs
+        if not a.no_extras:
+            out.update(golden_and_config2(eng))
+            out["sgm"] = sgm_leg(local)
+        if not a.no_cpu_baseline:
+            out.update(cpu_legs(a, eng))
     if rank == 0:
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(algorithmic_bytes_per_launch):
+    """HBM bytes per sweep launch from rocprofv3's FETCH_SIZE / WRITE_SIZE counters.  They need their own profiler passes (MI355X_MICROARCH.md:
+    no trace domains next to --pmc), so bench.py cannot collect them live: the figure comes from the committed pass profiles/traffic.json
+    (written by tools/pmc_traffic.py from the pass' per-kernel table, gfx950 x2 correction applied) and is null when that file is absent."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return {"bytes_per_launch": t["bytes_per_launch"], "over_algorithmic": round(t["bytes_per_launch"] / max(1.0, t.get("algorithmic_bytes_per_launch", algorithmic_bytes_per_launch)), 2),
+                "source": t.get("source", "profiles/traffic.json")}
+    except Exception:
+        return None
 
 
 def usable_cores() -> int:
@@ -201,23 +252,133 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def golden_and_config2(eng):
+    """BASELINE config 2 (1 reference x 8 sources, 1920x1080): (1) parity of all 27 maps of the 9-view scene with the committed digests of the
+    sequential oracle; (2) the reference view through the one-call boundary, timed per pass, checked against the same digests."""
+    from openmvs_amd import synth
+    from openmvs_amd.patchmatch import default_params
+    from tests import golden_check as gc
+    g = gc.load("pm_config2_1920x1080.json")
+    c = g["case"]
+    sc = synth.make_scene(c["n_views"], c["width"], c["height"], n_src=c["n_src"], device="cuda", gray_only=True, exact=True)
+    same_inputs = gc.sha(sc.gray) == g["inputs"]["gray"] and all(gc.sha(getattr(sc, k)) == g["inputs"][k] for k in ("K", "R", "C"))
+    eng.Init(True)
+    eng.scene_load(sc, 2)
+    p = default_params(seed=c["seed"], nEstimationGeometricIters=c["geo_iters"])
+    allv = list(range(c["n_views"]))
+    rounds, mismatches = [], []
+    for r in range(1 + c["geo_iters"]):
+        if r:
+            eng.scene_commit_round()
+        eng.scene_estimate(allv, r - 1, p)
+        rounds.append([eng.scene_get_maps(v) for v in allv])
+        for v in allv:
+            try:
+                gc.check_maps(rounds[r][v], g["rounds"][r][str(v)], "round %d view %d" % (r, v))
+            except AssertionError as ex:
+                mismatches.append(str(ex)[:300])
+    ref = c["ref"]
+    ids = [ref] + list(sc.neighbors[ref])
+    times, cur = [], None
+    for rep in range(2):                 # first repetition warms the one-call path (allocations), second is reported
+        times = []
+        for r in range(1 + c["geo_iters"]):
+            t = time.perf_counter()
+            if r == 0:
+                cur = eng.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], params=p)
+            else:
+                cur = eng.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], depth=cur[0], normal=cur[1],
+                                           src_depths={v: rounds[r - 1][v][0] for v in ids[1:]}, nGeometricIter=r - 1, params=p)
+            times.append(time.perf_counter() - t)
+            if rep == 1:
+                try:
+                    gc.check_maps(cur, g["rounds"][r][str(ref)], "one-call boundary, round %d" % r)
+                except AssertionError as ex:
+                    mismatches.append(str(ex)[:300])
+    px = c["width"] * c["height"]
+    smp = np.asarray(g["rounds"][-1][str(ref)]["depth_sample"], np.float32)
+    st = g["rounds"][-1][str(ref)]["depth_sample_step"]
+    mine = rounds[-1][ref][0][::st, ::st].ravel()
+    ok = (smp > 0) & (mine > 0)
+    rmse = float(np.sqrt(np.mean((smp[ok].astype(np.float64) - mine[ok]) ** 2))) if ok.any() else float("nan")
+    return {"config2": {"workload": "1 reference x 8 sources, 1920x1080, one depth map through pmhip_estimate_depth_map (host buffers in and out, PCIe included): "
+                                    "photometric pass + %d geometric rounds" % c["geo_iters"],
+                        "seconds_per_pass": [round(t, 4) for t in times], "seconds_per_depth_map": round(sum(times), 4),
+                        "mpix_per_s": round(px / sum(times) / 1e6, 3)},
+            "parity": {"case": "9-view 1920x1080 exact synthetic scene, every view 1 x 8, photometric + %d geometric rounds: all %d maps (depth, normal, confidence) "
+                               "against the SHA-256 digests of the sequential CPU oracle (tests/golden/pm_config2_1920x1080.json), scene interface and one-call boundary"
+                               % (c["geo_iters"], 3 * len(allv) * (1 + c["geo_iters"])),
+                       "inputs_reproduced": bool(same_inputs), "bit_identical": bool(same_inputs and not mismatches), "mismatches": mismatches[:4],
+                       "depth_rmse_over_diameter": rmse / sc.diameter, "tolerance": 1e-4,
+                       "rmse_note": "over the golden file's strided depth sample of the reference view (exactly 0 when bit_identical)"}}
+
+
+def sgm_leg(device):
+    """BASELINE config 4: SemiGlobalMatcher::Match (cost volume + 8-path aggregation + WTA, SemiGlobalMatcher.cpp:863-1302) at 2048x1536.
+    One reference against 4 sources in both directions = 8 Match calls per disparity range; inputs resident, HIP-event phase times from the engine."""
+    from openmvs_amd import sgm
+    from tests import sgm_cases as scs
+    w, h = 2048, 1536
+    lb, lg, rg = scs.stereo_pair(w, h, 21, seed=9)
+    m = sgm.SemiGlobalMatcherHIP(device)
+    res = {}
+    for D in (64, 128):
+        px, n, mx = scs.ranges(w, h, "uniform", 0, D)
+        m.set_problem(lb, lg, rg, px, n, mx)
+        m.Match()
+        m.stats_reset(True)
+        reps = 8
+        t = time.perf_counter()
+        for _ in range(reps):
+            m.Match(sync=False)
+        m.sync()
+        dt = (time.perf_counter() - t) / reps
+        s = m.stats_get()
+        gb = 43.0 * n / 1e9
+        res["D%d" % D] = {"ms_per_match": round(dt * 1e3, 3), "cost_ms": round(s.costMs / reps, 3), "aggregation_ms": round(s.aggrMs / reps, 3),
+                          "wta_ms": round(s.wtaMs / reps, 3), "num_costs": int(n), "achieved_gbs": round(gb / dt, 1), "frac_of_hbm_peak": round(gb / dt / HBM_PEAK_GBS, 4),
+                          "aggregation_gbs": round(40.0 * n / 1e9 / (s.aggrMs / reps / 1e3), 1)}
+    m.close() if hasattr(m, "close") else None
+    return {"workload": "SemiGlobalMatcher::Match, 2048x1536, 8 calls (1 reference x 4 sources, both directions) per range; 43 B per cost entry "
+                        "(1 cost write + 8 x (1 + 2 + 2) path traffic + 2 WTA read, SURVEY 8(d))", "peak_gbs": HBM_PEAK_GBS, **res}
+
+
+def native_oracle():
+    """A second build of the oracle for TIMING only: -O3 -march=native, still -ffp-contract=off so that it computes
+    the same values; built on the box it runs on (the tuned binary must not travel), into the system temp directory."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    from oracle import pyoracle as po
+    so = os.path.join(tempfile.gettempdir(), "libpm_oracle_native_%d.so" % os.getuid())
+    src = [os.path.join(ROOT, "oracle", f) for f in ("pm_oracle.cpp", "sgm_oracle.cpp", "filter_oracle.cpp", "fuse_oracle.cpp", "sgm_post_oracle.cpp")]
+    try:
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+            subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-shared", "-o", so] + src,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib = C.CDLL(so)
+        lib.orc_estimate_depth_map.restype = C.c_int
+        return lib, "-O3 -march=native -ffp-contract=off"
+    except Exception:
+        return po.lib(), "-O2 (native build failed)"
+
+
 def cpu_legs(a, eng):
-    """(1) restated CPU baseline: the oracle run with the reference's threading model on the host
-    cores, full schedule for one reference view at a sample resolution sized for ~cpu-seconds;
-    (2) parity: sequential oracle vs the HIP engine on a small case -> depth RMSE / diameter."""
+    """(1) restated CPU baseline: the oracle (-O3 -march=native build) with the reference's threading model on the host cores, full schedule
+    for >= 4 reference views at a sample resolution sized for ~cpu-seconds; (2) live parity: sequential oracle vs the HIP engine on a small case."""
     from openmvs_amd import synth
     from openmvs_amd.patchmatch import default_params
     from oracle import pyoracle as po
     cores = usable_cores()
-    # per-thread rate of the oracle for the full schedule at N = 8 is ~0.006 Mpix/s on this class of host
-    target_px = a.cpu_seconds * 0.006e6 * cores
+    n_ref = 4
+    # per-thread rate of the oracle for the full schedule at N = 8 is ~0.008 Mpix/s on this class of host
+    target_px = a.cpu_seconds * 0.008e6 * cores / n_ref
     scale = min(1.0, (target_px / (a.width * a.height)) ** 0.5)
     sw = max(64, int(a.width * scale) // 16 * 16); sh = max(48, int(a.height * scale) // 16 * 16)
     seed = 1
 
-    def run_pair(w, h, threads, timed):
+    def run(w, h, threads, refs, timed, lib):
         sc = synth.make_scene(9, w, h, n_src=8, device="cuda", gray_only=True)
-        ref = 4
         eng.Init(True)
         eng.scene_load(sc, 2)
         p = default_params(seed=seed, nEstimationGeometricIters=a.geo_iters)
@@ -226,37 +387,48 @@ def cpu_legs(a, eng):
         eng.scene_estimate(allv, -1, p); rounds.append([eng.scene_get_maps(v) for v in allv])
         for g in range(a.geo_iters):
             eng.scene_commit_round(); eng.scene_estimate(allv, g, p); rounds.append([eng.scene_get_maps(v) for v in allv])
-        ids = [ref] + list(sc.neighbors[ref])
         t_cpu = 0.0
-        cur = None
-        for r in range(1 + a.geo_iters):
-            opt = po.default_opt(seed=seed, viewID=ref, nThreads=threads, nEstimationGeometricIters=a.geo_iters)
-            if r == 0:
-                views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
-                t = time.perf_counter()
-                cur = po.estimate_depth_map(views, len(ids), float(sc.dmin[ref]), float(sc.dmax[ref]), opt)
-            else:
-                prev = {v: rounds[r - 1][v][0] for v in allv}
-                d_in, n_in = (cur[0], cur[1]) if not timed else (rounds[r - 1][ref][0], rounds[r - 1][ref][1])
-                views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids, depth_maps=prev)
-                t = time.perf_counter()
-                cur = po.estimate_depth_map(views, len(ids), float(sc.dmin[ref]), float(sc.dmax[ref]), opt, geo_iter=r - 1, depth=d_in, normal=n_in)
-            t_cpu += time.perf_counter() - t
-        return sc, cur, rounds[-1][ref], t_cpu
+        outs = {}
+        saved = po._LIB
+        po._LIB = lib
+        try:
+            for ref in refs:
+                ids = [ref] + list(sc.neighbors[ref])
+                cur = None
+                for r in range(1 + a.geo_iters):
+                    opt = po.default_opt(seed=seed, viewID=ref, nThreads=threads, nEstimationGeometricIters=a.geo_iters)
+                    if r == 0:
+                        views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+                        t = time.perf_counter()
+                        cur = po.estimate_depth_map(views, len(ids), float(sc.dmin[ref]), float(sc.dmax[ref]), opt)
+                    else:
+                        prev = {v: rounds[r - 1][v][0] for v in allv}
+                        d_in, n_in = (cur[0], cur[1]) if not timed else (rounds[r - 1][ref][0], rounds[r - 1][ref][1])
+                        views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids, depth_maps=prev)
+                        t = time.perf_counter()
+                        cur = po.estimate_depth_map(views, len(ids), float(sc.dmin[ref]), float(sc.dmax[ref]), opt, geo_iter=r - 1, depth=d_in, normal=n_in)
+                    t_cpu += time.perf_counter() - t
+                outs[ref] = cur
+        finally:
+            po._LIB = saved
+        return sc, outs, rounds[-1], t_cpu
 
-    sc, cpu_out, gpu_out, t_cpu = run_pair(sw, sh, cores, True)
-    base = {"value": round(sw * sh / t_cpu / 1e6, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
-            "sample": "1 reference view x 8 sources at %dx%d, photometric + %d geometric rounds, oracle with the reference's threading model "
-                      "(one estimator per thread, shared atomic pixel counter), %.1f s CPU wall" % (sw, sh, a.geo_iters, t_cpu)}
-    # parity leg: small, sequential (deterministic) oracle; the engine must match it bit for bit
-    sc2, cpu2, gpu2, _ = run_pair(256, 144, 1, False)
+    nat, flags = native_oracle()
+    refs = [4, 0, 2, 8][:n_ref]
+    sc, _, _, t_cpu = run(sw, sh, cores, refs, True, nat)
+    base = {"value": round(len(refs) * sw * sh / t_cpu / 1e6, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": "%d reference views x 8 sources at %dx%d, photometric + %d geometric rounds each, oracle built %s and run with the reference's threading model "
+                      "(one estimator per thread, shared atomic pixel counter), %.1f s CPU wall" % (len(refs), sw, sh, a.geo_iters, flags, t_cpu)}
+    # live parity leg: small, sequential (deterministic) oracle; the engine must match it bit for bit
+    sc2, cpu2, gpu2, _ = run(256, 144, 1, [4], False, po.lib())
+    cpu2 = cpu2[4]; gpu2 = gpu2[4]
     m = (cpu2[0] > 0) & (gpu2[0] > 0)
     rmse = float(np.sqrt(np.mean((cpu2[0][m].astype(np.float64) - gpu2[0][m]) ** 2))) if m.any() else float("nan")
     only_one = int(((cpu2[0] > 0) != (gpu2[0] > 0)).sum())
     return {"cpu_baseline": base,
-            "parity": {"case": "256x144, 8 sources, full schedule, sequential oracle vs HIP engine", "depth_rmse_over_diameter": rmse / sc2.diameter,
-                       "tolerance": 1e-4, "pixels_valid_in_only_one": only_one,
-                       "bit_identical": bool(np.array_equal(cpu2[0], gpu2[0]) and np.array_equal(cpu2[1], gpu2[1]) and np.array_equal(cpu2[2], gpu2[2]))}}
+            "parity_live": {"case": "256x144, 8 sources, full schedule, sequential oracle vs HIP engine in this run", "depth_rmse_over_diameter": rmse / sc2.diameter,
+                            "tolerance": 1e-4, "pixels_valid_in_only_one": only_one,
+                            "bit_identical": bool(np.array_equal(cpu2[0], gpu2[0]) and np.array_equal(cpu2[1], gpu2[1]) and np.array_equal(cpu2[2], gpu2[2]))}}
 
 
 if __name__ == "__main__":

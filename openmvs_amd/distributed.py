@@ -48,6 +48,10 @@ class ShardedDensifier:
       estimate(view_ids, geo_iter)          -- one EstimateDepthMap per view (geo_iter -1 = photometric)
       local_depths(view_ids) -> Tensor      -- [len(ids), H, W] current depth maps of these views
       set_snapshot(all_depths: Tensor)      -- previous-round depth maps of ALL views, for the next round
+    and for `filter()` (BASELINE config 5's exchange before the cross-view filter):
+      local_maps(view_ids, "depth"|"conf") -> Tensor   -- [len(ids), H, W] current maps of these views
+      set_maps("depth"|"conf", all: Tensor)            -- install the maps of ALL views (the neighbours' unfiltered maps the filter reads)
+      filter(view_ids)                                 -- DepthMapsData::FilterDepthMap for these views, results installed
     """
 
     def __init__(self, estimator, n_views: int, world: int = 1, rank: int = 0, geo_iters: int = 2):
@@ -63,3 +67,16 @@ class ShardedDensifier:
         for g in range(self.geo_iters):
             self.exchange()
             self.est.estimate(self.mine, g)
+
+    def filter(self):
+        """Scene::DenseReconstructionFilter (SceneDensify.cpp:2136-2222) sharded by view: every rank filters its own depth maps against the UNFILTERED
+        depth and confidence maps of their neighbours (the reference writes *.filtered.dmap files and renames them only when all are done), so one
+        all-gather of depth and one of confidence precede the filter; the filtered maps stay with their owner (gather them with `gather("depth")`)."""
+        for what in ("depth", "conf"):
+            self.est.set_maps(what, all_gather_views(self.est.local_maps(self.mine, what), self.n_views, self.world, self.rank))
+        self.est.filter(self.mine)
+
+    def gather(self, what):
+        """[n_views, H, W] maps of all views on every rank (e.g. the filtered maps before FuseDepthMaps, which is sequential over the scene and
+        therefore runs on one rank, SceneDensify.cpp:1372-1650)."""
+        return all_gather_views(self.est.local_maps(self.mine, what), self.n_views, self.world, self.rank)

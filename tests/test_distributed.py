@@ -43,6 +43,21 @@ class OracleEstimator:
     def set_snapshot(self, allv):
         self.snap = allv.numpy().copy()
 
+    # config 5's exchange: the cross-view filter reads the neighbours' unfiltered depth and confidence maps
+    def local_maps(self, ids, what):
+        return torch.from_numpy({"depth": self.depth, "conf": self.conf}[what][list(ids)].copy())
+
+    def set_maps(self, what, allv):
+        {"depth": self.depth, "conf": self.conf}[what][:] = allv.numpy()
+
+    def filter(self, ids):
+        po, sc = self.po, self.sc
+        dep, cnf = self.depth.copy(), self.conf.copy()     # every view is filtered against the unfiltered maps (SceneDensify.cpp:2183-2210)
+        for v in ids:
+            rc, d, c = po.filter_depth_map(dep, cnf, sc.K, sc.R, sc.C, v, list(sc.neighbors[v]), sc.dmin[v], sc.dmax[v])
+            assert rc == 0
+            self.depth[v], self.conf[v] = d, c
+
 
 def _scene():
     return synth.make_scene(4, 48, 32, n_src=3)
@@ -56,8 +71,14 @@ def _worker(rank, world, port, out_dir):
     drv = ShardedDensifier(est, sc.n_views, world, rank, geo_iters=2)
     drv.run()
     final = all_gather_views(est.local_depths(drv.mine), sc.n_views, world, rank)
+    # the estimator finalises confidences like EndDepthMapTmp only inside the engine; here give the filter something to weigh
+    for v in drv.mine:
+        est.conf[v] = np.where(est.depth[v] > 0, np.float32(1) - np.minimum(est.conf[v], np.float32(0.9)), np.float32(0)).astype(np.float32)
+    drv.filter()
+    fd, fc = drv.gather("depth"), drv.gather("conf")
     if rank == 0:
         np.save(os.path.join(out_dir, "sharded.npy"), final.numpy())
+        np.save(os.path.join(out_dir, "filtered_depth.npy"), fd.numpy()); np.save(os.path.join(out_dir, "filtered_conf.npy"), fc.numpy())
     dist.destroy_process_group()
 
 
@@ -74,6 +95,13 @@ def test_two_ranks_match_single_process(tmp_path):
     sharded = np.load(tmp_path / "sharded.npy")
     sc = _scene()
     est = OracleEstimator(sc)
-    ShardedDensifier(est, sc.n_views, 1, 0, geo_iters=2).run()
+    drv = ShardedDensifier(est, sc.n_views, 1, 0, geo_iters=2)
+    drv.run()
     assert np.array_equal(sharded, est.depth)
     assert (sharded > 0).mean() > 0.3
+    # the sharded cross-view filter (depth + confidence all-gather, then FilterDepthMap per owner) equals the single-process filter
+    for v in drv.mine:
+        est.conf[v] = np.where(est.depth[v] > 0, np.float32(1) - np.minimum(est.conf[v], np.float32(0.9)), np.float32(0)).astype(np.float32)
+    drv.filter()
+    assert np.array_equal(np.load(tmp_path / "filtered_depth.npy"), est.depth) and np.array_equal(np.load(tmp_path / "filtered_conf.npy"), est.conf)
+    assert (est.depth != sharded).any() and (est.depth > 0).mean() > 0.2

@@ -545,6 +545,45 @@ def test_real_scene_from_mvs_archive_matches_oracle_and_sfm_points():
     e.close()
 
 
+def test_config2_full_size_matches_golden():
+    """BASELINE config 2 at its own size: 9-view 1920x1080 scene, every view 1 ref x 8 src, photometric pass + 2 geometric rounds, against the digests the
+    SEQUENTIAL oracle produced on the CPU (tests/golden/make_fullsize_golden.py, ~10 CPU-minutes; SceneDensify.cpp:616-805).  Bit-exact, all 27 maps;
+    then the same reference view through the one-call boundary (pmhip_estimate_depth_map, SceneDensify.cpp:618-623) for all three rounds."""
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    from tests import golden_check as gc
+    g = gc.load("pm_config2_1920x1080.json")
+    c = g["case"]
+    sc = synth.make_scene(c["n_views"], c["width"], c["height"], n_src=c["n_src"], device="cuda", gray_only=True, exact=True)
+    assert gc.sha(sc.gray) == g["inputs"]["gray"], "the exact scene generator did not reproduce the golden inputs on this machine (images differ)"
+    for k in ("K", "R", "C"):
+        assert gc.sha(getattr(sc, k)) == g["inputs"][k], "camera " + k
+    assert gc.sha(sc.neighbors.astype(np.int32)) == g["inputs"]["neighbors"]
+    assert [float(x) for x in sc.dmin] == g["inputs"]["dmin"] and [float(x) for x in sc.dmax] == g["inputs"]["dmax"]
+    e = PatchMatchHIP(0); e.Init(True)
+    e.scene_load(sc, n_levels=2)
+    p = default_params(seed=c["seed"], nEstimationGeometricIters=c["geo_iters"])
+    allv = list(range(c["n_views"]))
+    rounds = []
+    for r in range(1 + c["geo_iters"]):
+        if r:
+            e.scene_commit_round()
+        e.scene_estimate(allv, r - 1, p)
+        rounds.append([e.scene_get_maps(v) for v in allv])
+        for v in allv:
+            gc.check_maps(rounds[r][v], g["rounds"][r][str(v)], "scene interface, round %d, view %d" % (r, v))
+    # the per-view boundary (layer 1): host buffers in and out, one blocking call per pass
+    ref = c["ref"]
+    ids = [ref] + list(sc.neighbors[ref])
+    e.Init(True)
+    cur = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], params=p)
+    gc.check_maps(cur, g["rounds"][0][str(ref)], "one-call boundary, photometric")
+    for r in range(1, 1 + c["geo_iters"]):
+        cur = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], depth=cur[0], normal=cur[1],
+                                 src_depths={v: rounds[r - 1][v][0] for v in ids[1:]}, nGeometricIter=r - 1, params=p)
+        gc.check_maps(cur, g["rounds"][r][str(ref)], "one-call boundary, geometric round %d" % (r - 1))
+    e.close()
+
+
 def test_full_size_properties():
     """BASELINE config 2 (1 ref x 8 src, 1920x1080): the oracle needs ~15 min here, so check
     size-independent properties: run-to-run determinism (race check of the diagonal schedule),

@@ -124,6 +124,27 @@ def test_golden_fixture(matcher):
     assert np.array_equal(d, g["disparity"]) and np.array_equal(c, g["cost"]) and np.array_equal(costs, g["costs"]) and np.array_equal(acc, g["accums"])
 
 
+def test_config4_full_size_matches_golden(matcher):
+    """BASELINE config 4 at its own size (2048x1536; D = 64, D = 128, ragged D <= 64) against the digests of the CPU oracle's Match
+    (tests/golden/make_fullsize_golden.py; SemiGlobalMatcher.cpp:863-1302): cost volume, 8-path sums, disparities and costs, byte for byte."""
+    from tests import golden_check as gc
+    g = gc.load("sgm_config4_2048x1536.json")
+    c = g["case"]
+    lb, lg, rg = sc.stereo_pair(c["width"], c["height"], c["shift"], seed=c["seed"])
+    for res in g["results"]:
+        px, n, mx = sc.ranges(c["width"], c["height"], res["kind"], res["lo"], res["hi"])
+        assert gc.sha(lb) == res["inputs"]["left_bgr"] and gc.sha(lg) == res["inputs"]["left_gray"] and gc.sha(rg) == res["inputs"]["right_gray"] \
+            and gc.sha(px) == res["inputs"]["pixels"] and n == res["num_costs"], "the seeded SGM problem was not reproduced on this machine"
+        matcher.set_problem(lb, lg, rg, px, n, mx)
+        matcher.Match()
+        d, cst, costs, acc = matcher.results(volumes=True)
+        what = "%s D<=%d" % (res["kind"], res["hi"] - res["lo"])
+        assert gc.sha(costs) == res["costs"], what + ": cost volume differs (sum %d vs %d)" % (int(costs.astype(np.uint64).sum()), res["costs_sum"])
+        assert gc.sha(acc) == res["accums"], what + ": 8-path sums differ (sum %d vs %d)" % (int(acc.astype(np.uint64).sum()), res["accums_sum"])
+        assert gc.sha(d) == res["disparity"], what + ": disparity rows %s differ" % gc.bad_rows(d, res["disparity_rows"])[:8]
+        assert gc.sha(cst) == res["cost"], what + ": cost rows %s differ" % gc.bad_rows(cst, res["cost_rows"])[:8]
+
+
 def test_full_size_properties(matcher):
     """BASELINE config 4 size (2048x1536, D = 64): the oracle takes minutes, so check size-independent
     properties: determinism, the planted disparity is recovered, sums bounded by 8*(255+60)."""

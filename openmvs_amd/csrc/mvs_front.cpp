@@ -7,6 +7,7 @@
 #include <string.h>
 #include <algorithm>
 #include <string>
+#include <memory>
 #include <vector>
 #include <map>
 #include <array>
@@ -31,11 +32,14 @@ struct mvsf_scene {
 namespace {
 struct Reader {
 	const unsigned char* b; size_t n, o = 0; bool ok = true;
-	bool take(void* dst, size_t k) { if (!ok || o + k > n) { ok = false; return false; } memcpy(dst, b + o, k); o += k; return true; }
-	bool skip(size_t k) { if (!ok || o + k > n) { ok = false; return false; } o += k; return true; }
+	// every length comes from the file: compare against what is left (k > n - o), never o + k, which wraps for a hostile 64-bit count
+	bool take(void* dst, size_t k) { if (!ok || k > n - o) { ok = false; return false; } memcpy(dst, b + o, k); o += k; return true; }
+	bool skip(size_t k) { if (!ok || k > n - o) { ok = false; return false; } o += k; return true; }
+	// skip `count` records of `rec` bytes; the count is checked before it is multiplied
+	bool skipn(uint64_t count, size_t rec) { if (!ok || count > (n - o) / rec) { ok = false; return false; } o += (size_t)count * rec; return true; }
 	uint32_t u32() { uint32_t v = 0; take(&v, 4); return v; }
 	uint64_t u64() { uint64_t v = 0; take(&v, 8); return v; }
-	std::string str() { const uint64_t k = u64(); if (!ok || o + k > n) { ok = false; return std::string(); } std::string s((const char*)b + o, (size_t)k); o += k; return s; }
+	std::string str() { const uint64_t k = u64(); if (!ok || k > n - o) { ok = false; return std::string(); } std::string s((const char*)b + o, (size_t)k); o += (size_t)k; return s; }
 };
 
 // Camera::ScaleK, libs/MVS/Camera.h:146-152
@@ -186,7 +190,7 @@ void filterNeighborViews(std::vector<MVSFViewScore>& nb, float fMinArea, float f
 	const unsigned nMinViews = std::max(4u, nMaxViews * 3 / 4);
 	for (size_t n = nb.size(); n-- > 0; ) {
 		const MVSFViewScore& v = nb[n];
-		if (nb.size() > nMinViews && (v.area < fMinArea || !(fMinScale <= v.scale && v.scale <= fMaxScale) || !(fMinAngle <= v.angle && v.angle <= fMaxAngle)))
+		if (nb.size() > nMinViews && (v.area < fMinArea || !(fMinScale <= v.scale && v.scale < fMaxScale) || !(fMinAngle <= v.angle && v.angle < fMaxAngle)))   // ISINSIDE is half-open, Types.h:1193
 			nb.erase(nb.begin() + n);
 	}
 	if (nb.size() > nMaxViews) nb.resize(nMaxViews);
@@ -243,9 +247,14 @@ void mvsf_default_options(MVSFOptions* o) {
 	o->fViewMinScore = 2.0f; o->fViewMinScoreRatio = 0.03f; o->fMinArea = 0.05f; o->fMinAngle = 3.0f; o->fOptimAngle = 12.0f; o->fMaxAngle = 65.0f;
 }
 
+static int loadScene(const char* path, mvsf_scene** out);
+// nothing may throw across the C ABI (std::bad_alloc / std::length_error on a corrupt archive): -2 like every other malformed input
 int mvsf_load(const char* path, mvsf_scene** out) {
 	if (!path || !out) return -1;
 	*out = nullptr;
+	try { return loadScene(path, out); } catch (...) { *out = nullptr; return -2; }
+}
+static int loadScene(const char* path, mvsf_scene** out) {
 	FILE* f = fopen(path, "rb");
 	if (!f) return -2;
 	std::vector<unsigned char> buf;
@@ -256,15 +265,16 @@ int mvsf_load(const char* path, mvsf_scene** out) {
 	fclose(f);
 	if (!rd) return -2;
 	Reader r{buf.data(), buf.size()};
-	mvsf_scene* s = new mvsf_scene();
+	std::unique_ptr<mvsf_scene> holder(new mvsf_scene());
+	mvsf_scene* s = holder.get();
 	if (buf.size() >= 4 && memcmp(buf.data(), "MVSI", 4) == 0) {
 		r.skip(4); s->version = r.u32(); r.u32();
-		if (s->version > 7) { delete s; return -2; }
+		if (s->version > 7) return -2;
 	} else {
 		const std::string p(path);
 		std::string ext = p.size() >= 4 ? p.substr(p.size() - 4) : std::string();
 		for (char& c : ext) c = (char)tolower(c);
-		if (ext != ".mvs") { delete s; return -2; }
+		if (ext != ".mvs") return -2;
 		s->version = 0;
 	}
 	const uint32_t v = s->version;
@@ -291,7 +301,7 @@ int mvsf_load(const char* path, mvsf_scene** out) {
 		if (v > 4) im.mask = r.str();
 		im.platform = r.u32(); im.camera = r.u32(); im.pose = r.u32();
 		if (v > 2) im.id = r.u32();
-		if (v > 6) { r.skip(12); const uint64_t ns = r.u64(); r.skip((size_t)ns * 24); }
+		if (v > 6) { r.skip(12); const uint64_t ns = r.u64(); r.skipn(ns, 24); }
 		s->images.push_back(im);
 	}
 	const uint64_t nV = r.ok ? r.u64() : 0;
@@ -301,19 +311,27 @@ int mvsf_load(const char* path, mvsf_scene** out) {
 			r.take(&s->X[(size_t)i * 3], 12);
 			const uint64_t m = r.u64();
 			if (!r.ok || m > (r.n - r.o) / 8) { r.ok = false; break; }
-			for (uint64_t k = 0; k < m; ++k) { s->views.push_back(r.u32()); r.skip(4); }
+			for (uint64_t k = 0; k < m; ++k) {
+				const uint32_t view = r.u32(); r.skip(4);
+				if (view >= s->images.size()) { r.ok = false; break; }   // indexes cams[] / scores[] in selectNeighborViews
+				s->views.push_back(view);
+			}
 			s->viewStart.push_back((uint32_t)s->views.size());
 		}
 	} else r.ok = false;
-	if (r.ok) { const uint64_t a = r.u64(); r.skip((size_t)a * 12); const uint64_t b = r.u64(); r.skip((size_t)b * 3); }
+	if (r.ok) { const uint64_t a = r.u64(); r.skipn(a, 12); const uint64_t b = r.u64(); r.skipn(b, 3); }
 	if (r.ok && v > 0) {
 		const uint64_t nL = r.u64();
-		for (uint64_t i = 0; i < nL && r.ok; ++i) { r.skip(24); const uint64_t m = r.u64(); r.skip((size_t)m * 8); }
-		const uint64_t a = r.u64(); r.skip((size_t)a * 12); const uint64_t b = r.u64(); r.skip((size_t)b * 3);
+		for (uint64_t i = 0; i < nL && r.ok; ++i) { r.skip(24); const uint64_t m = r.u64(); r.skipn(m, 8); }
+		const uint64_t a = r.u64(); r.skipn(a, 12); const uint64_t b = r.u64(); r.skipn(b, 3);
 		if (v > 1) { r.skip(128); if (v > 5) { r.take(s->obbRot, 72); r.take(s->obbMin, 24); r.take(s->obbMax, 24); } }
 	}
-	if (!r.ok) { delete s; return -2; }
-	*out = s;
+	// an image that names a platform / camera / pose the archive does not hold is uncalibrated (pixelCamera checks the ranges again); one
+	// whose platform index is not even NO_ID-or-valid is a corrupt file
+	for (const Image& im : s->images)
+		if (im.pose != NO_ID && (im.platform >= s->platforms.size() || im.camera >= s->platforms[im.platform].cams.size())) r.ok = false;
+	if (!r.ok) return -2;
+	*out = holder.release();
 	return 0;
 }
 void mvsf_free(mvsf_scene* s) { delete s; }

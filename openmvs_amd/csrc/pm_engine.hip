@@ -32,6 +32,7 @@ struct SceneView {
 	int nNb = 0; int nb[PM_MAX_SRC];
 	uint32_t id = 0;
 	bool set = false;
+	bool hasMaps = false;   // a depth map exists for this view (estimated, uploaded or copied in): DepthData::IsValid() of the reference's filter / fuse loops
 };
 
 // cv::Matx product convention (accumulate from 0, left to right)
@@ -416,6 +417,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 	if (nGeometricIter < 0 && p.nEstimationGeometricIters) th *= 1.333f;
 	hipLaunchKernelGGL(pm_finalize_kernel, dim3((unsigned)std::min<size_t>((P0 + 255) / 256, 4096), nB), dim3(256), 0, e->stream, e->d_tasks, th);
 	HIPCHK(e, hipGetLastError());
+	for (int b = 0; b < nB; ++b) e->views[ids[b]].hasMaps = true;
 	return 0;
 }
 
@@ -561,6 +563,7 @@ int pmhip_scene_reset_view(pmhip_engine* e, int idx) {
 	HIPCHK(e, hipMemsetAsync(e->d_depth + P0 * idx, 0, sizeof(float) * P0, e->stream));
 	HIPCHK(e, hipMemsetAsync(e->d_normal + P0 * 3 * idx, 0, sizeof(float) * P0 * 3, e->stream));
 	HIPCHK(e, hipMemsetAsync(e->d_conf + P0 * idx, 0, sizeof(float) * P0, e->stream));
+	e->views[idx].hasMaps = false;
 	return 0;
 }
 
@@ -571,6 +574,7 @@ int pmhip_scene_set_maps(pmhip_engine* e, int idx, const float* depth, const flo
 	if (depth) HIPCHK(e, hipMemcpyAsync(e->d_depth + P0 * idx, depth, sizeof(float) * P0, hipMemcpyHostToDevice, e->stream));
 	if (normal) HIPCHK(e, hipMemcpyAsync(e->d_normal + P0 * 3 * idx, normal, sizeof(float) * P0 * 3, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(e, hipStreamSynchronize(e->stream));
+	if (depth) e->views[idx].hasMaps = true;
 	return 0;
 }
 
@@ -665,7 +669,8 @@ int pmhip_scene_filter(pmhip_engine* e, const int32_t* viewIds, int nViews, int 
 			t.N = 0;
 			for (int k = 0; k < v.nNb && t.N < PMF_MAXN; ++k) {
 				const int j = v.nb[k];
-				if (j < 0 || j >= e->nImages || !e->views[j].set) continue;
+				// neighbours without a depth map are skipped before the eight slots are filled (SceneDensify.cpp:2150-2163: !depthData.IsValid())
+				if (j < 0 || j >= e->nImages || !e->views[j].set || !e->views[j].hasMaps) continue;
 				const SceneView& sv = e->views[j];
 				memcpy(t.nb[t.N].K, sv.K, 72); memcpy(t.nb[t.N].R, sv.R, 72); memcpy(t.nb[t.N].C, sv.C, 24);
 				t.nbDepth[t.N] = e->d_depth + P0 * j; t.nbConf[t.N] = e->d_conf + P0 * j;
@@ -687,6 +692,8 @@ int pmhip_scene_filter(pmhip_engine* e, const int32_t* viewIds, int nViews, int 
 	}
 	HIPCHK(e, hipStreamSynchronize(e->stream));
 	for (int i = 0; i < e->nImages; ++i) if (hv[i] != 2) HIPCHK(e, hipMemcpyAsync(e->d_fvalid + i, &hv[i], 1, hipMemcpyHostToDevice, e->stream));
+	// hv lives on this stack frame: the small copies above must have left it whatever the caller asked for; `sync` only says whether the caller
+	// wants the filter kernels themselves finished on return (they are, as a consequence) -- kept in the ABI for symmetry with pmhip_scene_estimate
 	HIPCHK(e, hipStreamSynchronize(e->stream));
 	(void)sync;
 	return 0;
@@ -799,6 +806,7 @@ int pmhip_scene_copy(pmhip_engine* e, int what, int firstIdx, int count, void* d
 	const size_t bytes = sizeof(float) * (size_t)e->w * e->h * (what == 2 ? 3 : 1) * count;
 	HIPCHK(e, hipMemcpyAsync(toEngine ? (void*)base : devPtr, toEngine ? devPtr : (void*)base, bytes, hipMemcpyDeviceToDevice, e->stream));
 	if (toEngine && what == 0) e->pyramidDirty = true;
+	if (toEngine && what == 1) for (int i = firstIdx; i < firstIdx + count; ++i) e->views[i].hasMaps = true;   // depth maps gathered from other ranks
 	return 0;
 }
 
@@ -834,6 +842,13 @@ int pmhip_estimate_depth_map_masked(pmhip_engine* e, PMHipDepthData* dd, const u
 		if (!dd->views[i].image) return PMHIP_E_ARG;
 		if (dd->views[i].w != w || dd->views[i].h != h) { e->err = "all views must have the reference view's size"; return PMHIP_E_SIZE; }
 		if (nGeometricIter >= 0 && i > 0 && !dd->views[i].depth) { e->err = "geometric round needs views[i].depth"; return PMHIP_E_ARG; }
+		if (nGeometricIter >= 0 && i > 0) {
+			// the depth map is read with the view's own camera and size: a different cameraDepthMap (DepthMap.h:179-184) would silently give a wrong
+			// consistency term, so it is refused (an all-zero Kd means "not filled in" and is taken as the view's camera)
+			const PMHipView& v = dd->views[i];
+			bool zero = true; for (int k = 0; k < 9; ++k) zero = zero && v.Kd[k] == 0.0 && v.Rd[k] == 0.0;
+			if (!zero && (memcmp(v.Kd, v.K, 72) || memcmp(v.Rd, v.R, 72) || memcmp(v.Cd, v.C, 24))) { e->err = "views[i].Kd/Rd/Cd (cameraDepthMap) must equal the view's camera"; return PMHIP_E_ARG; }
+		}
 	}
 	const int S = (int)p->nSubResolutionLevels;
 	if (S > 3) return PMHIP_E_ARG;

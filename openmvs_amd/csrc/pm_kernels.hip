@@ -22,6 +22,7 @@
 // No MFMA: the path is a gather stencil.  No FMA contraction (-ffp-contract=off) -- see pm_math.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include "pm_math.h"
 
 #define PM_MAX_SRC 16
@@ -47,14 +48,21 @@ __device__ __forceinline__ pm_gf pm_globw(float* p) { return (pm_gf)p; }
 #define PM_NT 25     // nTexels, DepthMap.h:281
 
 struct PMSrcView {
-	const float* img;     // source image at this pyramid level, row-major
-	const float* imgS;    // same image, anti-diagonal-major ("skewed"): texel (u,v) at (u+v)*h + v
-	const float* depth;   // nullable: source depth-map (geometric pass)
-	int w, h;
+	// "hot" block, 13 doubles: what every hypothesis evaluation reads of its source view.  The sweep kernel copies it (and the geometric block)
+	// into LDS once per visit; the layout is the copy's contract (see PM_SRC_HOT / PM_SRC_GEO below).
 	double Hl[9];         // K_j R_j R_0^T          (ViewData::Init, DepthMap.h:175-185)
 	double Hm[3];         // K_j R_j (C_0 - C_j)
+	int w, h;             // size of the source image at this level
+	// geometric block, 13 doubles: transforms of the consistency term and the source view's depth-map (nullable; geometric pass)
 	float Tl[9], Tm[3], Tr[9], Tn[3];
+	const float* depth;
+	const float* img;     // source image at this pyramid level, row-major
+	const float* imgS;    // same image, anti-diagonal-major ("skewed"): texel (u,v) at (u+v)*h + v
 };
+#define PM_SRC_HOT 13     // doubles
+#define PM_SRC_GEO 13
+static_assert(offsetof(PMSrcView, Hm) == 72 && offsetof(PMSrcView, w) == 96 && offsetof(PMSrcView, Tl) == 8 * PM_SRC_HOT
+	&& offsetof(PMSrcView, depth) == 8 * PM_SRC_HOT + 96 && offsetof(PMSrcView, img) == 8 * (PM_SRC_HOT + PM_SRC_GEO), "PMSrcView layout");
 struct PMTask {           // one reference view at one pyramid level
 	float* depth; float* normal; float* conf;
 	const float* prior;   // nullable: low-resolution depth prior at this level
@@ -90,16 +98,17 @@ enum { PM_STREAM_INIT = 0, PM_STREAM_RAND = 1, PM_STREAM_REFINE = 2 };
 // Optional in-kernel phase timing (build with -DPM_PROFILE): lane 0 of every wave accumulates s_memtime deltas
 // per phase into pm_prof[]; read back with pmhip_prof_get.  Phases: 0 setup (weights, neighbour gather, tiles),
 // 1 hypothesis generation, 2 smoothness factors, 3 homography, 4 taps, 5 score epilogue, 6 aggregation+accept,
-// 7 number of outer trips, 8 trips x active pixel-lanes, 9 waves, 10 tap rows served from LDS, 11 tap rows total.
+// 7 number of outer trips, 8 trips x active pixel-lanes, 9 waves, 10 tap rows served from LDS, 11 tap rows total; the sweep kernel splits
+// phase 0 further: 12 = head of the visit (own + neighbour estimates, patch texels, weights), 13 = neighbour set-up + window placement, 0 = window staging.
 #ifdef PM_PROFILE
 __device__ unsigned long long pm_prof[16];
-struct PmProfAcc { unsigned long long a[12]; unsigned long long t; };
+struct PmProfAcc { unsigned long long a[16]; unsigned long long t; };
 #define PM_PROF_ARG , PmProfAcc& _pa
 #define PM_PROF_PASS , _pa
-#define PM_PROF_DECL PmProfAcc _pa; for (int _i = 0; _i < 12; ++_i) _pa.a[_i] = 0; _pa.t = __builtin_readcyclecounter()
+#define PM_PROF_DECL PmProfAcc _pa; for (int _i = 0; _i < 16; ++_i) _pa.a[_i] = 0; _pa.t = __builtin_readcyclecounter()
 #define PM_TICK(i) do { const unsigned long long _n = __builtin_readcyclecounter(); _pa.a[i] += _n - _pa.t; _pa.t = _n; } while (0)
 #define PM_COUNT(i, n) do { _pa.a[i] += (unsigned long long)(n); } while (0)
-#define PM_PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int _i = 0; _i < 12; ++_i) atomicAdd(&pm_prof[_i], _pa.a[_i]); } while (0)
+#define PM_PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int _i = 0; _i < 16; ++_i) atomicAdd(&pm_prof[_i], _pa.a[_i]); } while (0)
 #else
 #define PM_PROF_ARG
 #define PM_PROF_PASS
@@ -188,14 +197,15 @@ __device__ __forceinline__ void pm_group_min2(float s, float& m1, float& m2) {
 // anti-diagonal-major copy those texels are contiguous (one or two 128-B lines per view instead of one
 // line per pixel), which is what the vector L1 / texture-address unit is bound by here.  Same values.
 // ComputeHomographyMatrix, DepthMap.h:414-423: (Hl + Hm * (n^T / (n.X0 * depth))) * Hr in double, cast to float
-__device__ __forceinline__ void pm_homography(const PMSrcView& s, const PMTask& t, double X0x, double X0y,
+// hlm: the view's Hl (9) and Hm (3), contiguous as in PMSrcView's hot block -- in HBM (init kernel) or in the wave's LDS copy (sweep kernel)
+__device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t, double X0x, double X0y,
 		float depth, float nx, float ny, float nz, float* H) {
 	// the twelve matrix entries are requested first, together: one round trip (overlapping the division below) instead of one per row
 	double Hl[9], Hm[3];
 #pragma unroll
-	for (int i = 0; i < 9; ++i) Hl[i] = s.Hl[i];
+	for (int i = 0; i < 9; ++i) Hl[i] = hlm[i];
 #pragma unroll
-	for (int i = 0; i < 3; ++i) Hm[i] = s.Hm[i];
+	for (int i = 0; i < 3; ++i) Hm[i] = hlm[9 + i];
 	const double n0 = (double)nx, n1 = (double)ny, n2 = (double)nz;
 	const double ndx = (n0 * X0x + n1 * X0y) + n2;
 	const double den = ndx * (double)depth;
@@ -226,7 +236,7 @@ __device__ __forceinline__ void pm_homography(const PMSrcView& s, const PMTask& 
 #define PM_TR 20        // window rows (anti-diagonals): 19 are needed (patch 17 + bilinear 2), the rest is slack for perturbed planes
 #endif
 #ifndef PM_TCX
-#define PM_TCX 12       // window columns = pixels per wave + PM_TCX: PPW + 9 are needed
+#define PM_TCX 10       // window columns = pixels per wave + PM_TCX: PPW + 9 are needed (10: 13.3 KB of windows + weights per wave, measured +5 % over 12)
 #endif
 #define PM_TILE_PAD 4   // per-view stride = PM_TR*TC + 4 floats: staggers the views over the LDS banks
 #ifndef PM_XCD_REMAP
@@ -283,11 +293,12 @@ __device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int 
 // use the unguarded reciprocal refinement, the texel indices are only clamped into the window; while it goes the row tracks the extremes of z, of
 // the projected positions and of the window row index, and one comparison set at the end says whether every tap (a) had 2^-40 <= z <= 2^40 (with
 // `sane`: |x|, |y| < 1e18 -- then the quotients are the correctly rounded ones and nothing is NaN), (b) was inside the image (isInsideWithBorder<1>)
-// and (c) inside the window.  If so the three running sums are exactly what pm_tap_row_global computes and the call returns true; otherwise the sums
-// are left untouched and the caller redoes the row through global loads.  ~40 VALU instructions per tap instead of ~100.
+// and (c) inside the window.  If so the three running sums are exactly what pm_tap_row_global computes and the call returns true; with (a) but a tap
+// outside the image the hypothesis is flagged (`oob`) and the row is done as well; otherwise the sums are left untouched and the caller redoes the
+// row through global loads.  ~40 VALU instructions per tap instead of ~100.
 template <int TC>
 __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int tt0, int sw, int sh, bool sane, float h0, float h3, float h6,
-		float X0, float X1, float X2, const float2* wrow, float& sum, float& sumSq, float& num)
+		float X0, float X1, float X2, const float2* wrow, float& sum, float& sumSq, float& num, bool& oob)
 {
 	constexpr int MAXI = PM_TR * TC - 2 * TC - 2;   // idx + 2*TC + 1 stays inside the window
 	const int cidx = -(ts0 * TC + tt0);
@@ -321,10 +332,15 @@ __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int t
 		s1 += v * vw;
 		s2 += v * pw.y;
 	}
+	// With 2^-40 <= z <= 2^40 and `sane` every quotient above is the correctly rounded one, so the image test is exact: a tap outside the image
+	// flags the hypothesis just as pm_tap_row_global would (its sums are then never used) and the row is done -- source views that do not see the
+	// pixel at all are the common case of a failed row and must not cost a second pass through global memory.
+	const bool exact = sane && zlo >= 9.094947e-13f && zhi <= 1.0995116e12f;
+	const bool inImage = pxlo >= 1.f && pylo >= 1.f && pxhi <= (float)(sw - 2) && pyhi <= (float)(sh - 2);
 	// (int)pty in [tt0, tt0 + TC - 2]  <=>  tt0 <= pty < tt0 + TC - 1 once pty >= 1
-	const bool ok = sane && zlo >= 9.094947e-13f && zhi <= 1.0995116e12f
-		&& pxlo >= 1.f && pylo >= 1.f && pxhi <= (float)(sw - 2) && pyhi <= (float)(sh - 2)
-		&& pylo >= (float)tt0 && pyhi < (float)(tt0 + TC - 1) && slo >= ts0 && shi <= ts0 + PM_TR - 3;
+	const bool inWindow = pylo >= (float)tt0 && pyhi < (float)(tt0 + TC - 1) && slo >= ts0 && shi <= ts0 + PM_TR - 3;
+	if (exact && !inImage) { oob = true; return true; }
+	const bool ok = exact && inWindow;
 	if (ok) { sum = s0; sumSq = s1; num = s2; }
 	return ok;
 }
@@ -336,13 +352,13 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		int x, int y, double X0x, double X0y, float normSq0, float sumW, const float2* wts,
 		float depth, float nx, float ny, float nz,
 		float sf0, float sf1, float sf2, float sf3, float prior,
-		const float* tile, int ts0, int tt0 PM_PROF_ARG)
+		const float* tile, int ts0, int tt0, const double* hot, const double* geoTab PM_PROF_ARG)
 {
-	// the image descriptor is requested together with the homography entries (same struct, same round trip)
-	const int sw = s.w, sh = s.h;
-	const pm_gcf img = pm_glob(SKEW ? s.imgS : s.img);
+	// hot / geoTab: the hot and geometric blocks of `s` (PMSrcView), in HBM (init kernel) or in the wave's LDS copy (sweep kernel); the image
+	// size travels with the homography entries
+	const int sw = ((const int*)(hot + 12))[0], sh = ((const int*)(hot + 12))[1];
 	float H[9];
-	pm_homography(s, t, X0x, X0y, depth, nx, ny, nz, H);
+	pm_homography(hot, t, X0x, X0y, depth, nx, ny, nz, H);
 	PM_TICK(3);
 	const float px = (float)(x - PM_HW), py = (float)(y - PM_HW);
 	const float X0 = H[0] * px + H[1] * py + H[2];
@@ -361,11 +377,11 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 #pragma unroll 1
 	for (int i = 0; i < 5; ++i) {
 		bool done = false;
-		if (TC > 0) done = pm_tap_row_lds<TC>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num) || oob;
+		if (TC > 0) done = pm_tap_row_lds<TC>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob) || oob;
 #ifdef PM_PROFILE
 		if (TC > 0) { PM_COUNT(10, __popcll(__ballot(done))); PM_COUNT(11, __popcll(__ballot(true))); PM_COUNT(7, __all(done) ? 1 : 0); }
 #endif
-		if (!done) pm_tap_row_global<SKEW>(img, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
+		if (!done) pm_tap_row_global<SKEW>(pm_glob(SKEW ? s.imgS : s.img), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
 		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
 	}
 	PM_TICK(4);
@@ -380,12 +396,13 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 	if (GEO) {
 		// geometric consistency, DepthMap.cpp:535-551
 		// the source view's depth-map pointer and its four transforms are requested together (they were five dependent round trips per evaluation)
-		const float* sdepth = s.depth;
+		const float* gt = (const float*)geoTab;
+		const float* sdepth = *(const float* const*)(geoTab + 12);
 		float Tl[9], Tm[3], Tr[9], Tn[3];
 #pragma unroll
-		for (int i = 0; i < 9; ++i) { Tl[i] = s.Tl[i]; Tr[i] = s.Tr[i]; }
+		for (int i = 0; i < 9; ++i) { Tl[i] = gt[i]; Tr[i] = gt[12 + i]; }
 #pragma unroll
-		for (int i = 0; i < 3; ++i) { Tm[i] = s.Tm[i]; Tn[i] = s.Tn[i]; }
+		for (int i = 0; i < 3; ++i) { Tm[i] = gt[9 + i]; Tn[i] = gt[21 + i]; }
 #pragma unroll
 		for (int i = 0; i < 9; ++i) PM_OPAQUE(Tr[i]);
 #pragma unroll
@@ -542,7 +559,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 	float sc = PM_INF;
 	PM_PROF_DECL;
 	if (v < t.nSrc)
-		sc = pm_score_view<GEO, false, 0>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, nullptr, 0, 0 PM_PROF_PASS);
+		sc = pm_score_view<GEO, false, 0>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, nullptr, 0, 0, t.src[v].Hl, (const double*)t.src[v].Tl PM_PROF_PASS);
 	const float conf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 	if (v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
 }
@@ -560,6 +577,10 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 	PM_PROF_DECL;
 	__shared__ float2 s_w[PPB][PM_NT + 1];
 	__shared__ float s_tile[PM_USE_TILES ? PM_BLOCK / 64 : 1][PM_USE_TILES ? G * TSTRIDE : 1];
+	// Per-view constants of the wave's source views: every hypothesis evaluation of every pixel needs the hot block of its lane's view (Hl, Hm, image
+	// size; in the geometric pass also the four transforms and the depth-map pointer) -- a global round trip at the head of each evaluation when read
+	// from the task.  One coalesced copy per visit puts them an LDS read away (832 B per wave at G = 8, twice that in the geometric pass).
+	__shared__ double s_src[PM_BLOCK / 64][G * (PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0))];
 	// XCD-aware block mapping: workgroup b is observed to run on XCD b % 8 (dispatch order, x fastest), each XCD with its own 4 MB L2.  The remap
 	// hands every XCD a contiguous range of (view, diagonal chunk) pairs -- the same few views launch after launch -- so the source windows of
 	// neighbouring chunks and of the next diagonal are found in that XCD's L2 instead of being fetched into several of them.  Bijective for any
@@ -573,6 +594,13 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 	}
 	const PMTask& t = tasks[vby];
 	const int g = threadIdx.x / G, v = threadIdx.x % G;
+	{
+		constexpr int NB = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
+		double* dst = s_src[threadIdx.x >> 6];
+		for (int i = threadIdx.x & 63; i < G * NB; i += 64) dst[i] = ((const double*)&t.src[i / NB])[i % NB];   // views >= nSrc: zeros (the task is memset), never used
+	}
+	const double* hot = s_src[threadIdx.x >> 6] + v * (PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0));
+	const double* geoTab = hot + PM_SRC_HOT;
 	const int w = t.w, h = t.h;
 	const int pi = vbx * PPB + g;
 	const bool active = pi < count;
@@ -622,6 +650,7 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 	// prior and its blend factor (DepthMap.cpp:558-559) go to the spare entry of the weight row: pm_score_view<.., PF = true> reads them there
 	if (v == 0) s_w[g][PM_NT] = make_float2(prior, prior > 0 ? pm_expf(normSq0 * (-1.f / (1.f * 0.02f))) : 0.f);
 	__syncthreads();
+	PM_TICK(12);
 	const double X0x = ((double)x - t.cx) / t.fx, X0y = ((double)y - t.cy) / t.fy;
 	const float vx = (float)X0x, vy = (float)X0y, vz = 1.f;
 
@@ -661,7 +690,7 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 		int cs = 0x7fffffff, ctt = 0x7fffffff;
 		if (valid && v < t.nSrc) {
 			float Hc[9];
-			pm_homography(t.src[v], t, X0x, X0y, depth, nx, ny, nz, Hc);
+			pm_homography(hot, t, X0x, X0y, depth, nx, ny, nz, Hc);
 			const float fxp = (float)x, fyp = (float)y;
 			const float c0 = Hc[0] * fxp + Hc[1] * fyp + Hc[2], c1 = Hc[3] * fxp + Hc[4] * fyp + Hc[5], c2 = Hc[6] * fxp + Hc[7] * fyp + Hc[8];
 			const float cu = c0 / c2, cv = c1 / c2;
@@ -671,6 +700,7 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 		for (int m = G; m < 64; m <<= 1) { cs = min(cs, __shfl_xor(cs, m, 64)); ctt = min(ctt, __shfl_xor(ctt, m, 64)); }
 		if (cs == 0x7fffffff) { cs = 0; ctt = 0; }
 		ts0 = cs - 8 - (PM_TR - 19) / 2; tt0 = ctt - PM_HW - (PM_TCX - 9) / 2;
+		PM_TICK(13);
 		const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 		float* tw = s_tile[wave];
 		const int nS = t.nSrc;
@@ -814,7 +844,7 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 		PM_TICK(2);
 		float sc = PM_INF;
 		if (need && v < t.nSrc)
-			sc = pm_score_view<GEO, true, TC, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], 0.f, tile, ts0, tt0 PM_PROF_PASS);
+			sc = pm_score_view<GEO, true, TC, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], 0.f, tile, ts0, tt0, hot, geoTab PM_PROF_PASS);
 		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 		if (need && conf > nconf) {
 			conf = nconf; depth = hd; nx = hnx; ny = hny; nz = hnz; changed = true;

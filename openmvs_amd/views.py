@@ -205,8 +205,8 @@ def filter_neighbor_views(neighbors: np.ndarray, fMinArea=0.05, fMinScale=0.2, f
     nMin = max(4, nMaxViews * 3 // 4)
     for n in range(len(neighbors) - 1, -1, -1):
         nb = neighbors[n]
-        bad = (nb["area"] < f32(fMinArea) or not (f32(fMinScale) <= nb["scale"] <= f32(fMaxScale))
-               or not (f32(fMinAngle) <= nb["angle"] <= f32(fMaxAngle)))
+        bad = (nb["area"] < f32(fMinArea) or not (f32(fMinScale) <= nb["scale"] < f32(fMaxScale))      # ISINSIDE is half-open,
+               or not (f32(fMinAngle) <= nb["angle"] < f32(fMaxAngle)))                                  # libs/Common/Types.h:1193
         if len(keep) > nMin and bad:
             keep.remove(n)
     return neighbors[keep][:nMaxViews]

@@ -9,10 +9,11 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 step() { echo "=== $1 ($(date +%T))" | tee -a "$OUT/steps.log"; }
 
-pmc_pass() {  # name, counters...  (each pass is its own run: no trace domains next to --pmc)
+pmc_pass() {  # name, counters...  (each pass is its own run: no trace domains next to --pmc; the profiled process imports no torch)
   local name=$1; shift
+  [ -f /tmp/pmc_scene.npy ] || python tools/pmc_workload.py gen ${PMC_VIEWS:-100} > "$OUT/pmc_gen.log" 2>&1
   ( cd /tmp && timeout 420 rocprofv3 --pmc "$@" --output-format csv -d "/tmp/prof_pmc_$name" -o pmc -- \
-      python "$R/bench.py" --views-per-gpu ${PMC_VIEWS:-100} --geo-iters ${PMC_GEO:-0} --steps 1 --warmup 0 --no-cpu-baseline > "$R/$OUT/pmc_${name}_bench.json" 2> "$R/$OUT/pmc_$name.err" )
+      python "$R/tools/pmc_workload.py" run ${PMC_GEO:-0} > "$R/$OUT/pmc_${name}_run.json" 2> "$R/$OUT/pmc_$name.err" )
   local rc=$?
   local csv=$(find "/tmp/prof_pmc_$name" -name "*counter_collection.csv" 2>/dev/null | head -1)
   if [ -n "$csv" ]; then python tools/pmc_agg.py "$csv" > "$OUT/pmc_${name}_per_kernel.txt" 2>&1; else echo "pmc pass $name: rc $rc, no counter csv"; tail -5 "$OUT/pmc_$name.err"; fi
@@ -43,6 +44,10 @@ pmc)
 variants)
   step "variants"
   timeout 900 python tools/tune.py ${TUNE_VIEWS:-100} ${VARIANTS:-libpmhip.so:2} > "$OUT/variants.log" 2>&1; cat "$OUT/variants.log" ;;
+phase)
+  step "in-kernel phase profile (-DPM_PROFILE build)"
+  for spec in ${PHASE_SPECS:-"100" "9 4"}; do PMHIP_LIB=$R/openmvs_amd/libpmhip_prof.so timeout 600 python tools/phase_prof.py $spec >> "$OUT/phase_prof.log" 2>&1; done
+  cat "$OUT/phase_prof.log" ;;
 sgm)
   step "sgm probe"
   timeout 600 python tools/probe_sgm.py > "$OUT/sgm_probe.log" 2>&1; cat "$OUT/sgm_probe.log" ;;

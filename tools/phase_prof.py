@@ -4,9 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openmvs_amd import synth
 from openmvs_amd.patchmatch import PatchMatchHIP, default_params
 views = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+only = [int(a) for a in sys.argv[2:]]          # estimate only these views (e.g. "9 4": BASELINE config 2, one depth map of a 9-view scene)
 sc = synth.make_scene(views, 1920, 1080, n_src=8, device="cuda", gray_only=True)
 e = PatchMatchHIP(0); e.Init(True); e.scene_load(sc, 2)
-p = default_params(seed=1); ids = list(range(views))
+p = default_params(seed=1); ids = only or list(range(views))
 for rep in range(2):
     for v in ids: e.scene_reset_view(v)
     e.prof_get(True); e.sync(); t0 = time.time()
@@ -14,8 +15,9 @@ for rep in range(2):
     for g in range(2): e.scene_commit_round(); e.scene_estimate(ids, g, p)
     e.sync(); dt = time.time() - t0
     c = e.prof_get(True)
-names = ["setup", "hyp-gen", "smooth", "homography", "taps", "epilogue", "aggr+accept"]
-tot = sum(c[:7]) or 1
-print(os.environ.get("PMHIP_LIB", "default"), "views", views, "%.2f s -> %.2f Mpix/s" % (dt, views * 1920 * 1080 / dt / 1e6))
+names = ["windows", "hyp-gen", "smooth", "homography", "taps", "epilogue", "aggr+accept"]
+tot = (sum(c[:7]) + c[12] + c[13]) or 1
+print(os.environ.get("PMHIP_LIB", "default"), "views", len(ids), "of", views, "%.2f s -> %.2f Mpix/s" % (dt, len(ids) * 1920 * 1080 / dt / 1e6))
+for i, n in ((12, "head"), (13, "nb+placement")): print("  %-12s %5.1f %%   %8.0f cycles/wave" % (n, 100.0 * c[i] / tot, c[i] / max(1, c[9])))
 for i, n in enumerate(names): print("  %-12s %5.1f %%   %8.0f cycles/wave" % (n, 100.0 * c[i] / tot, c[i] / max(1, c[9])))
 print("  active lanes/trip-sum %.1f per wave; LDS-served lane-rows %.1f %%; rows where the whole wave stayed on LDS: %d of %d lane-rows/64" % (c[8] / max(1, c[9]), 100.0 * c[10] / max(1, c[11]), c[7], c[11] // 64))

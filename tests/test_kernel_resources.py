@@ -17,7 +17,7 @@ def test_sweep_kernel_keeps_its_residency_budget():
         if lanes in (4, 8):                       # the mappings of 3..8 source views: three waves per SIMD and eleven one-wave workgroups per CU
             assert v["occupancy"] >= 3 and v["vgpr"] <= 168, (k, v)
             assert v["lds"] <= 14976, (k, v)   # windows 20 x (pixels per wave + 10) per view, weights, and the per-view constants (832 B; twice that in the geometric pass)
-            assert v["scratch"] <= 32, (k, v)   # a few spilled dwords (round-1 kernel: 28 at 8 lanes per pixel; with the optimistic LDS tap row: 32, one reload per evaluation)
+            assert v["scratch"] <= 40, (k, v)   # a few spilled dwords (round-1 kernel: 28 at 8 lanes per pixel; now 32 photometric, 40 geometric: one reload per evaluation)
         else:
             assert v["occupancy"] >= 2, (k, v)
         assert v["agpr"] == 0

@@ -49,7 +49,7 @@ public:
 			copy9(v.camera.K.val, o.K); copy9(v.camera.R.val, o.R); copy3(v.camera.C.ptr(), o.C);
 			o.depth = nullptr; o.id = (uint32_t)v.GetID();
 			if (i > 0 && !v.depthMap.empty()) {
-				o.depth = v.depthMap.template ptr<float>();
+				o.depth = v.depthMap.template ptr<float>(); o.dw = v.depthMap.cols; o.dh = v.depthMap.rows;   // read through cameraDepthMap, own size
 				copy9(v.cameraDepthMap.K.val, o.Kd); copy9(v.cameraDepthMap.R.val, o.Rd); copy3(v.cameraDepthMap.C.ptr(), o.Cd);
 			}
 		}

@@ -64,8 +64,9 @@ typedef struct PMHipView {
 	int32_t w, h;
 	double K[9], R[9], C[3];
 	const float* depth;       /* nullable; known depth-map of this source view => geometric pass */
-	double Kd[9], Rd[9], Cd[3]; /* camera stored with that depth-map (cameraDepthMap) */
+	double Kd[9], Rd[9], Cd[3]; /* camera stored with that depth-map (cameraDepthMap); all zero = the view's own camera */
 	uint32_t id;              /* global view ID (mixed into the RNG key for views[0]) */
+	int32_t dw, dh;           /* size of that depth-map; 0, 0 = w, h.  The map is addressed through Kd/Rd/Cd, so it need not have the image's size */
 } PMHipView;
 
 /* DepthData (libs/MVS/DepthMap.h:157-271): views[0] is the reference view. depthMap/normalMap
@@ -93,7 +94,10 @@ int pmhip_release(pmhip_engine* e);
 /* PatchMatchCUDA::EstimateDepthMap(DepthData&), PatchMatchCUDA.cpp:174-416; semantics of
  * DepthMapsData::EstimateDepthMap(idx, nGeometricIter), SceneDensify.cpp:616-805:
  * nGeometricIter < 0 -> photometric pass over the pyramid; >= 0 -> that geometric round
- * (requires pmhip_init(e,1) and views[1..].depth). Blocking. */
+ * (requires pmhip_init(e,1) and views[1..].depth). Blocking.
+ * views[1..] may have any size (the reference rescales a neighbour whose scale differs by >= 15 %, ViewData::ScaleImage, DepthMap.h:194-204,
+ * SceneDensify.cpp:325-349; the resampling itself -- INTER_AREA / INTER_CUBIC -- stays with the caller, as there): every source view is
+ * projected into with its own K and sampled within its own bounds, at every pyramid level (ScaleDepthData scales each image by 1/2^l). */
 int pmhip_estimate_depth_map(pmhip_engine* e, PMHipDepthData* dd, const PMHipParams* p, int nGeometricIter);
 /* The same with DepthData::mask (libs/MVS/DepthMap.h:211): mask = w*h bytes, 0 = the pixel is ignored (see pmhip_scene_set_mask), or NULL.
  * maskOption != 0 says that OPTDENSE::nIgnoreMaskLabel is set even though this view has no mask: the level hand-off then resizes the depth map
@@ -110,6 +114,17 @@ int pmhip_scene_create(pmhip_engine* e, int nImages, int w, int h, int nLevels);
 int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevice,
                          const double K[9], const double R[9], const double C[3],
                          float dMin, float dMax, const int32_t* neighbors, int nNeighbors);
+/* The same for a view whose image has its own size w x h (another camera, or a neighbour rescaled by ViewData::ScaleImage): it keeps its own
+ * pyramid and can serve as a SOURCE view of any reference view; estimating it (as a reference view) returns PMHIP_E_SIZE -- reference views
+ * share the scene's size, use one scene per size class.  gray is required. */
+int pmhip_scene_set_view_sized(pmhip_engine* e, int idx, const float* gray, int w, int h, int onDevice,
+                               const double K[9], const double R[9], const double C[3],
+                               float dMin, float dMax, const int32_t* neighbors, int nNeighbors);
+/* Known depth-map of view idx (host pointer, dw*dh floats) for the geometric rounds in which it is a source view, with the camera it was stored
+ * with (DepthData::ViewData::depthMap / cameraDepthMap, loaded from the neighbour's .dmap at SceneDensify.cpp:378-393).  While installed it is
+ * read instead of the scene's snapshot of that view; depth == NULL removes it. */
+int pmhip_scene_set_source_depth(pmhip_engine* e, int idx, const float* depth, int dw, int dh,
+                                 const double Kd[9], const double Rd[9], const double Cd[3]);
 /* Estimate the depth maps of viewIds[0..nViews) concurrently (one EstimateDepthMap per view,
  * SceneDensify.cpp:616-805).  nGeometricIter < 0: photometric; >= 0: geometric round reading the
  * snapshot taken by pmhip_scene_commit_round.  Asynchronous on the engine stream unless sync != 0. */

@@ -33,7 +33,22 @@ struct SceneView {
 	uint32_t id = 0;
 	bool set = false;
 	bool hasMaps = false;   // a depth map exists for this view (estimated, uploaded or copied in): DepthData::IsValid() of the reference's filter / fuse loops
+	// A view whose image has another size than the scene's (a neighbour rescaled by ViewData::ScaleImage, DepthMap.h:194-204, or simply another
+	// camera): it keeps its own pyramid here and can only serve as a SOURCE view.  sw == 0: the image lives in the scene arrays.
+	int sw = 0, sh = 0;
+	float* sImg[4] = {nullptr, nullptr, nullptr, nullptr};
+	float* sImgS[4] = {nullptr, nullptr, nullptr, nullptr};
+	bool sideDirty = false;
+	// A known depth-map of this view to be read by geometric rounds instead of the scene's snapshot, of its own size and with the camera it
+	// was stored with (DepthData::ViewData::depthMap / cameraDepthMap, filled from the neighbour's .dmap at SceneDensify.cpp:378-393)
+	float* sDepth = nullptr; int dw = 0, dh = 0; double Kd[9], Rd[9], Cd[3];
 };
+static int lvlSize(int n, int l) { return (int)nearbyint((double)n / (double)(1 << l)); }   // cvRound(size / 2^l), ties to even
+static void freeSide(SceneView& v) {
+	for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgS[l]) hipFree(v.sImgS[l]); v.sImg[l] = v.sImgS[l] = nullptr; }
+	if (v.sDepth) hipFree(v.sDepth);
+	v.sDepth = nullptr; v.sw = v.sh = v.dw = v.dh = 0; v.sideDirty = false;
+}
 
 // cv::Matx product convention (accumulate from 0, left to right)
 void mul33(const double* a, const double* b, double* c) {
@@ -147,6 +162,7 @@ static void freeScene(pmhip_engine* e) {
 	if (e->d_tasks) hipFree(e->d_tasks); if (e->h_tasks) hipHostFree(e->h_tasks);
 	if (e->d_ups) hipFree(e->d_ups); if (e->h_ups) hipHostFree(e->h_ups);
 	e->d_tasks = nullptr; e->h_tasks = nullptr; e->d_ups = nullptr; e->h_ups = nullptr;
+	for (SceneView& v : e->views) freeSide(v);
 	e->batchCap = 0; e->nImages = 0; e->views.clear();
 }
 
@@ -184,6 +200,25 @@ static int buildPyramid(pmhip_engine* e) {
 	}
 	HIPCHK(e, hipGetLastError());
 	e->pyramidDirty = false;
+	return 0;
+}
+// pyramids of the views that carry their own image size (source views only)
+static int buildSidePyramids(pmhip_engine* e) {
+	for (SceneView& v : e->views) {
+		if (!v.sw || !v.sideDirty) continue;
+		for (int l = 1; l <= e->nLevels; ++l) {
+			const int lw = lvlSize(v.sw, l), lh = lvlSize(v.sh, l);
+			const size_t n = (size_t)lw * lh;
+			hipLaunchKernelGGL(pm_area_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, e->stream, v.sImg[0], v.sImg[l], v.sw, v.sh, lw, lh, 1 << l, 1);
+		}
+		for (int l = 0; l <= e->nLevels; ++l) {
+			const int lw = lvlSize(v.sw, l), lh = lvlSize(v.sh, l);
+			const size_t n = (size_t)lw * lh;
+			hipLaunchKernelGGL(pm_skew_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, e->stream, v.sImg[l], v.sImgS[l], lw, lh, 1);
+		}
+		HIPCHK(e, hipGetLastError());
+		v.sideDirty = false;
+	}
 	return 0;
 }
 
@@ -256,6 +291,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 	if (e->lw(S) < 2 * PM_HW + 1 || e->lh(S) < 2 * PM_HW + 1) { e->err = "image too small for this many sub-resolution levels"; return PMHIP_E_SIZE; }
 	int rc = ensureBatch(e, nB); if (rc) return rc;
 	rc = buildPyramid(e); if (rc) return rc;
+	rc = buildSidePyramids(e); if (rc) return rc;
 	const PMKParams kp = makeKParams(p);
 	const bool geo = nGeometricIter >= 0;
 	bool anyMask = false;
@@ -277,6 +313,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 		if (id < 0 || id >= e->nImages || !e->views[id].set) { e->err = "view not set"; return PMHIP_E_ARG; }
 		const SceneView& v = e->views[id];
 		if (v.nNb < 1) { e->err = "view has no source views"; return PMHIP_E_ARG; }
+		if (v.sw) { e->err = "a view with its own image size can only be a source view (reference views share the scene's size)"; return PMHIP_E_SIZE; }
 		for (int k = 0; k < v.nNb; ++k) if (v.nb[k] < 0 || v.nb[k] >= e->nImages || !e->views[v.nb[k]].set) { e->err = "neighbour view not set"; return PMHIP_E_ARG; }
 		maxSrc = std::max(maxSrc, v.nNb);
 	}
@@ -318,11 +355,19 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			for (int k = 0; k < v.nNb; ++k) {
 				const SceneView& sv = e->views[v.nb[k]];
 				PMSrcView& s = t.src[k];
-				s.img = e->d_img[l] + Pl * v.nb[k];
-				s.imgS = e->d_imgS[l] + e->skewPitch(l) * v.nb[k];
-				s.w = lw; s.h = lh;
 				double Kj[9];
-				if (l == 0) memcpy(Kj, sv.K, sizeof(Kj)); else scaleK(sv.K, e->w, e->h, lw, lh, Kj);
+				if (sv.sw) {
+					// a source image of its own size: its own pyramid, its camera scaled from its own size (ScaleDepthData, SceneDensify.cpp:586-588)
+					const int jw = lvlSize(sv.sw, l), jh = lvlSize(sv.sh, l);
+					if (jw < 3 || jh < 3) { e->err = "source image too small for this many sub-resolution levels"; return PMHIP_E_SIZE; }
+					s.img = sv.sImg[l]; s.imgS = sv.sImgS[l]; s.w = jw; s.h = jh;
+					if (l == 0) memcpy(Kj, sv.K, sizeof(Kj)); else scaleK(sv.K, sv.sw, sv.sh, jw, jh, Kj);
+				} else {
+					s.img = e->d_img[l] + Pl * v.nb[k];
+					s.imgS = e->d_imgS[l] + e->skewPitch(l) * v.nb[k];
+					s.w = lw; s.h = lh;
+					if (l == 0) memcpy(Kj, sv.K, sizeof(Kj)); else scaleK(sv.K, e->w, e->h, lw, lh, Kj);
+				}
 				double KR[9], dC[3];
 				mul33(Kj, sv.R, KR);
 				mul33(KR, R0T, s.Hl);
@@ -330,14 +375,20 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 				mul31(KR, dC, s.Hm);
 				s.depth = nullptr;
 				if (geo) {
-					// ViewData::Init geometric part, DepthMap.h:179-184; cameraDepthMap == the neighbour's own camera
-					s.depth = e->d_snap + P0 * v.nb[k];
-					double tm[9], vv[3], RdT[9], iKd[9], t2[9];
-					mul33(KR, R0T, tm); for (int i = 0; i < 9; ++i) s.Tl[i] = (float)tm[i];
-					mul31(KR, dC, vv); for (int i = 0; i < 3; ++i) s.Tm[i] = (float)vv[i];
-					transp33(sv.R, RdT); mul33(KR0, RdT, tm); invK(Kj, iKd); mul33(tm, iKd, t2);
+					// ViewData::Init geometric part, DepthMap.h:179-184.  cameraDepthMap is the neighbour's own camera when the map is the scene's
+					// snapshot, or the camera stored with the map the caller installed (pmhip_scene_set_source_depth), whose size may differ too
+					double tm[9], vv[3], RdT[9], iKd[9], t2[9], KdRd[9];
+					const double* Kd = Kj; const double* Rd = sv.R; const double* Cd = sv.C;
+					if (sv.sDepth) { s.depth = sv.sDepth; s.dw = sv.dw; s.dh = sv.dh; Kd = sv.Kd; Rd = sv.Rd; Cd = sv.Cd; }
+					else if (sv.sw) { e->err = "geometric round: a source view with its own image size needs pmhip_scene_set_source_depth"; return PMHIP_E_ARG; }
+					else { s.depth = e->d_snap + P0 * v.nb[k]; s.dw = e->w; s.dh = e->h; }
+					mul33(Kd, Rd, KdRd);
+					mul33(KdRd, R0T, tm); for (int i = 0; i < 9; ++i) s.Tl[i] = (float)tm[i];
+					for (int i = 0; i < 3; ++i) dC[i] = v.C[i] - Cd[i];
+					mul31(KdRd, dC, vv); for (int i = 0; i < 3; ++i) s.Tm[i] = (float)vv[i];
+					transp33(Rd, RdT); mul33(KR0, RdT, tm); invK(Kd, iKd); mul33(tm, iKd, t2);
 					for (int i = 0; i < 9; ++i) s.Tr[i] = (float)t2[i];
-					for (int i = 0; i < 3; ++i) dC[i] = sv.C[i] - v.C[i];
+					for (int i = 0; i < 3; ++i) dC[i] = Cd[i] - v.C[i];
 					mul31(KR0, dC, vv); for (int i = 0; i < 3; ++i) s.Tn[i] = (float)vv[i];
 				}
 			}
@@ -529,6 +580,11 @@ int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevi
 	for (int k = 0; k < nNeighbors; ++k) v.nb[k] = neighbors[k];
 	v.set = true;
 	if (gray) {
+		if (v.sw) {   // the view goes back to the scene's size: its own pyramid is not needed any more
+			HIPCHK(e, hipStreamSynchronize(e->stream));
+			for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgS[l]) hipFree(v.sImgS[l]); v.sImg[l] = v.sImgS[l] = nullptr; }
+			v.sw = v.sh = 0; v.sideDirty = false;
+		}
 		const size_t P0 = (size_t)e->w * e->h;
 		HIPCHK(e, hipMemcpyAsync(e->d_img[0] + P0 * idx, gray, sizeof(float) * P0, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
 		if (!onDevice) HIPCHK(e, hipStreamSynchronize(e->stream)); // caller may free the host buffer
@@ -538,6 +594,57 @@ int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevi
 }
 
 int pmhip_scene_images_updated(pmhip_engine* e) { if (!e) return PMHIP_E_ARG; e->pyramidDirty = true; return 0; }
+
+
+// A source view whose image has its own size (see SceneView::sw): same as pmhip_scene_set_view otherwise.
+int pmhip_scene_set_view_sized(pmhip_engine* e, int idx, const float* gray, int w, int h, int onDevice, const double K[9], const double R[9], const double C[3],
+		float dMin, float dMax, const int32_t* neighbors, int nNeighbors) {
+	if (!e || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
+	if (w == e->w && h == e->h) return pmhip_scene_set_view(e, idx, gray, onDevice, K, R, C, dMin, dMax, neighbors, nNeighbors);
+	if (!gray || w < 3 || h < 3) { e->err = "a view with its own size needs its image and at least 3 x 3 pixels"; return PMHIP_E_ARG; }
+	int rc = pmhip_scene_set_view(e, idx, nullptr, 0, K, R, C, dMin, dMax, neighbors, nNeighbors);
+	if (rc) return rc;
+	SceneView& v = e->views[idx];
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	if (v.sw != w || v.sh != h) {
+		float* keep = v.sDepth; v.sDepth = nullptr; const int kdw = v.dw, kdh = v.dh;
+		freeSide(v);
+		v.sDepth = keep; v.dw = kdw; v.dh = kdh;
+		for (int l = 0; l <= e->nLevels; ++l) {
+			const int lw = lvlSize(w, l), lh = lvlSize(h, l);
+			if (lw < 1 || lh < 1) break;
+			HIPCHK(e, hipMalloc(&v.sImg[l], sizeof(float) * (size_t)lw * lh));
+			HIPCHK(e, hipMalloc(&v.sImgS[l], sizeof(float) * (size_t)(lw + lh - 1) * lh));
+		}
+		v.sw = w; v.sh = h;
+	}
+	HIPCHK(e, hipMemcpyAsync(v.sImg[0], gray, sizeof(float) * (size_t)w * h, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+	if (!onDevice) HIPCHK(e, hipStreamSynchronize(e->stream));
+	v.sideDirty = true;
+	return 0;
+}
+
+// Known depth-map of view idx for the geometric rounds in which it is a SOURCE view, with the camera it was stored with and its own size
+// (DepthData::ViewData::depthMap + cameraDepthMap, SceneDensify.cpp:378-393).  While installed it is read instead of the scene's snapshot of that
+// view; depth == NULL removes it.
+int pmhip_scene_set_source_depth(pmhip_engine* e, int idx, const float* depth, int dw, int dh, const double Kd[9], const double Rd[9], const double Cd[3]) {
+	if (!e || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	SceneView& v = e->views[idx];
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	if (!depth) { if (v.sDepth) hipFree(v.sDepth); v.sDepth = nullptr; v.dw = v.dh = 0; return 0; }
+	if (dw < 3 || dh < 3 || !Kd || !Rd || !Cd) return PMHIP_E_ARG;
+	if (v.dw != dw || v.dh != dh || !v.sDepth) {
+		if (v.sDepth) hipFree(v.sDepth);
+		v.sDepth = nullptr;
+		HIPCHK(e, hipMalloc(&v.sDepth, sizeof(float) * (size_t)dw * dh));
+		v.dw = dw; v.dh = dh;
+	}
+	HIPCHK(e, hipMemcpyAsync(v.sDepth, depth, sizeof(float) * (size_t)dw * dh, hipMemcpyHostToDevice, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	memcpy(v.Kd, Kd, 72); memcpy(v.Rd, Rd, 72); memcpy(v.Cd, Cd, 24);
+	return 0;
+}
 
 int pmhip_scene_estimate(pmhip_engine* e, const int32_t* viewIds, int nViews, const PMHipParams* p, int nGeometricIter, int sync) {
 	if (!e || !viewIds || !p || nViews < 0) return PMHIP_E_ARG;
@@ -839,16 +946,8 @@ int pmhip_estimate_depth_map_masked(pmhip_engine* e, PMHipDepthData* dd, const u
 	if (!e->inited) { e->err = "pmhip_init not called"; return PMHIP_E_STATE; }
 	const int w = dd->views[0].w, h = dd->views[0].h, n = dd->nViews;
 	for (int i = 0; i < n; ++i) {
-		if (!dd->views[i].image) return PMHIP_E_ARG;
-		if (dd->views[i].w != w || dd->views[i].h != h) { e->err = "all views must have the reference view's size"; return PMHIP_E_SIZE; }
+		if (!dd->views[i].image || dd->views[i].w < 3 || dd->views[i].h < 3) return PMHIP_E_ARG;
 		if (nGeometricIter >= 0 && i > 0 && !dd->views[i].depth) { e->err = "geometric round needs views[i].depth"; return PMHIP_E_ARG; }
-		if (nGeometricIter >= 0 && i > 0) {
-			// the depth map is read with the view's own camera and size: a different cameraDepthMap (DepthMap.h:179-184) would silently give a wrong
-			// consistency term, so it is refused (an all-zero Kd means "not filled in" and is taken as the view's camera)
-			const PMHipView& v = dd->views[i];
-			bool zero = true; for (int k = 0; k < 9; ++k) zero = zero && v.Kd[k] == 0.0 && v.Rd[k] == 0.0;
-			if (!zero && (memcmp(v.Kd, v.K, 72) || memcmp(v.Rd, v.R, 72) || memcmp(v.Cd, v.C, 24))) { e->err = "views[i].Kd/Rd/Cd (cameraDepthMap) must equal the view's camera"; return PMHIP_E_ARG; }
-		}
 	}
 	const int S = (int)p->nSubResolutionLevels;
 	if (S > 3) return PMHIP_E_ARG;
@@ -863,12 +962,23 @@ int pmhip_estimate_depth_map_masked(pmhip_engine* e, PMHipDepthData* dd, const u
 	for (int i = 1; i < n; ++i) nb[i - 1] = i;
 	for (int i = 0; i < n; ++i) {
 		const PMHipView& v = dd->views[i];
-		int rc = pmhip_scene_set_view(e, i, v.image, 0, v.K, v.R, v.C, dd->dMin, dd->dMax, nb, i == 0 ? n - 1 : 0);
+		// source views may come in any size (neighbours rescaled by ViewData::ScaleImage, DepthMap.h:194-204): they keep their own pyramid
+		int rc = pmhip_scene_set_view_sized(e, i, v.image, v.w, v.h, 0, v.K, v.R, v.C, dd->dMin, dd->dMax, nb, i == 0 ? n - 1 : 0);
 		if (rc) return rc;
 		e->views[i].id = v.id;
-		if (nGeometricIter >= 0 && i > 0) {
-			// the geometric term uses the camera stored with the depth-map (cameraDepthMap); it must be the view's camera here
+		if (i == 0) continue;
+		if (nGeometricIter < 0) { if (e->views[i].sDepth) { rc = pmhip_scene_set_source_depth(e, i, nullptr, 0, 0, nullptr, nullptr, nullptr); if (rc) return rc; } continue; }
+		// the known depth-map is read with the camera stored next to it (cameraDepthMap) and has its own size; an all-zero Kd / Rd means
+		// "not filled in" and stands for the view's own camera
+		bool zero = true; for (int k = 0; k < 9; ++k) zero = zero && v.Kd[k] == 0.0 && v.Rd[k] == 0.0;
+		const int dw = v.dw > 0 ? v.dw : v.w, dh = v.dh > 0 ? v.dh : v.h;
+		const bool own = zero || (!memcmp(v.Kd, v.K, 72) && !memcmp(v.Rd, v.R, 72) && !memcmp(v.Cd, v.C, 24));
+		if (own && dw == w && dh == h && v.w == w && v.h == h) {
+			if (e->views[i].sDepth) { rc = pmhip_scene_set_source_depth(e, i, nullptr, 0, 0, nullptr, nullptr, nullptr); if (rc) return rc; }
 			HIPCHK(e, hipMemcpyAsync(e->d_snap + P0 * i, v.depth, sizeof(float) * P0, hipMemcpyHostToDevice, e->stream));
+		} else {
+			rc = pmhip_scene_set_source_depth(e, i, v.depth, dw, dh, zero ? v.K : v.Kd, zero ? v.R : v.Rd, zero ? v.C : v.Cd);
+			if (rc) return rc;
 		}
 	}
 	int rc = pmhip_scene_set_maps(e, 0, dd->depthMap, dd->normalMap);

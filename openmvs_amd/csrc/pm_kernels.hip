@@ -53,16 +53,18 @@ struct PMSrcView {
 	double Hl[9];         // K_j R_j R_0^T          (ViewData::Init, DepthMap.h:175-185)
 	double Hm[3];         // K_j R_j (C_0 - C_j)
 	int w, h;             // size of the source image at this level
-	// geometric block, 13 doubles: transforms of the consistency term and the source view's depth-map (nullable; geometric pass)
+	// geometric block, 14 doubles: transforms of the consistency term and the source view's depth-map (nullable; geometric pass) with its own
+	// size: the map is addressed through cameraDepthMap (Tl..Tn), not through the image's camera (DepthMap.h:170-171, DepthMap.cpp:535-551)
 	float Tl[9], Tm[3], Tr[9], Tn[3];
 	const float* depth;
+	int dw, dh;
 	const float* img;     // source image at this pyramid level, row-major
 	const float* imgS;    // same image, anti-diagonal-major ("skewed"): texel (u,v) at (u+v)*h + v
 };
 #define PM_SRC_HOT 13     // doubles
-#define PM_SRC_GEO 13
+#define PM_SRC_GEO 14
 static_assert(offsetof(PMSrcView, Hm) == 72 && offsetof(PMSrcView, w) == 96 && offsetof(PMSrcView, Tl) == 8 * PM_SRC_HOT
-	&& offsetof(PMSrcView, depth) == 8 * PM_SRC_HOT + 96 && offsetof(PMSrcView, img) == 8 * (PM_SRC_HOT + PM_SRC_GEO), "PMSrcView layout");
+	&& offsetof(PMSrcView, depth) == 8 * PM_SRC_HOT + 96 && offsetof(PMSrcView, dw) == 8 * PM_SRC_HOT + 104 && offsetof(PMSrcView, img) == 8 * (PM_SRC_HOT + PM_SRC_GEO), "PMSrcView layout");
 struct PMTask {           // one reference view at one pyramid level
 	float* depth; float* normal; float* conf;
 	const float* prior;   // nullable: low-resolution depth prior at this level
@@ -398,6 +400,7 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		// the source view's depth-map pointer and its four transforms are requested together (they were five dependent round trips per evaluation)
 		const float* gt = (const float*)geoTab;
 		const float* sdepth = *(const float* const*)(geoTab + 12);
+		const int dw = ((const int*)(geoTab + 13))[0], dh = ((const int*)(geoTab + 13))[1];
 		float Tl[9], Tm[3], Tr[9], Tn[3];
 #pragma unroll
 		for (int i = 0; i < 9; ++i) { Tl[i] = gt[i]; Tr[i] = gt[12 + i]; }
@@ -415,13 +418,13 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 			const float Y2 = (Tl[6] * Xc0 + Tl[7] * Xc1 + Tl[8] * Xc2) + Tm[2];
 			if (Y2 > 0) {
 				const float x1x = Y0 / Y2, x1y = Y1 / Y2;
-				if (pm_inside1(x1x, x1y, sw, sh)) {
+				if (pm_inside1(x1x, x1y, dw, dh)) {
 					// TImage::sample with validity functor, Types.inl:2299-2314; IsDepthSimilar(z,d,0.03), Util.inl:798-809
 					const int lx = (int)x1x, ly = (int)x1y;
 					const float fx = x1x - (float)lx, fx1 = 1.f - fx;
 					const float fy = x1y - (float)ly, fy1 = 1.f - fy;
-					const pm_gcf p = pm_glob(sdepth) + (size_t)ly * sw + lx;
-					const float x0y0 = p[0], x1y0 = p[1], x0y1 = p[sw], x1y1 = p[sw + 1];
+					const pm_gcf p = pm_glob(sdepth) + (size_t)ly * dw + lx;
+					const float x0y0 = p[0], x1y0 = p[1], x0y1 = p[dw], x1y1 = p[dw + 1];
 					const bool b00 = pm_fabsf(Y2 - x0y0) / Y2 < 0.03f, b10 = pm_fabsf(Y2 - x1y0) / Y2 < 0.03f;
 					const bool b01 = pm_fabsf(Y2 - x0y1) / Y2 < 0.03f, b11 = pm_fabsf(Y2 - x1y1) / Y2 < 0.03f;
 					if (b00 || b10 || b01 || b11) {

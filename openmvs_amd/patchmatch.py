@@ -32,7 +32,7 @@ class PMHipView(C.Structure):
                 ("K", C.c_double * 9), ("R", C.c_double * 9), ("C", C.c_double * 3),
                 ("depth", C.POINTER(C.c_float)),
                 ("Kd", C.c_double * 9), ("Rd", C.c_double * 9), ("Cd", C.c_double * 3),
-                ("id", C.c_uint32)]
+                ("id", C.c_uint32), ("dw", C.c_int32), ("dh", C.c_int32)]
 
 
 class PMHipDepthData(C.Structure):
@@ -51,7 +51,7 @@ class PMHipFuseParams(C.Structure):
                 ("bEstimateColor", C.c_int32), ("bEstimateNormal", C.c_int32)]
 
 
-EXPORTS = ["pmhip_scene_set_mask", "pmhip_scene_set_mask_mode", "pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
+EXPORTS = ["pmhip_scene_set_view_sized", "pmhip_scene_set_source_depth", "pmhip_scene_set_mask", "pmhip_scene_set_mask_mode", "pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
            "pmhip_estimate_depth_map", "pmhip_estimate_depth_map_masked", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
            "pmhip_scene_estimate", "pmhip_scene_commit_round", "pmhip_scene_reset_view", "pmhip_scene_set_maps",
            "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_remove_small_segments", "pmhip_scene_images_updated", "pmhip_sync",
@@ -94,6 +94,13 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+def _dp(a):
+    """float64 array -> double* (the array is kept alive by ctypes for the duration of the call)."""
+    a = np.ascontiguousarray(a, np.float64)
+    p = a.ctypes.data_as(C.POINTER(C.c_double)); p._keep = a
+    return p
+
+
 class PatchMatchError(RuntimeError):
     pass
 
@@ -122,9 +129,10 @@ class PatchMatchHIP:
             self._chk(self._lib.pmhip_release(self._h))
 
     def EstimateDepthMap(self, gray, K, R, Cc, ids, dmin, dmax, depth=None, normal=None, src_depths=None,
-                         nGeometricIter: int = -1, params: PMHipParams | None = None, mask=None, mask_option=False):
-        """One depth map.  ids[0] = reference view, ids[1:] = sources (indices into gray/K/R/Cc).
-        src_depths: dict id -> depth map, required for a geometric round.  mask: (h, w) uint8, 0 = ignored pixel (DepthData::mask);
+                         nGeometricIter: int = -1, params: PMHipParams | None = None, mask=None, mask_option=False, src_depth_cams=None):
+        """One depth map.  ids[0] = reference view, ids[1:] = sources (indices into gray/K/R/Cc; the source images may have any size).
+        src_depths: dict id -> depth map (any size), required for a geometric round; src_depth_cams: dict id -> (Kd, Rd, Cd), the camera
+        stored with that depth map (default: the view's own).  mask: (h, w) uint8, 0 = ignored pixel (DepthData::mask);
         mask_option: OPTDENSE::nIgnoreMaskLabel is set although this view has no mask.  Returns (depth, normal, conf)."""
         p = params or self.params
         n = len(ids)
@@ -138,7 +146,12 @@ class PatchMatchHIP:
             v.id = int(i)
             if k > 0 and src_depths is not None:
                 d = np.ascontiguousarray(src_depths[i], np.float32); keep.append(d)
-                v.depth = _fp(d); v.Kd[:] = v.K[:]; v.Rd[:] = v.R[:]; v.Cd[:] = v.C[:]
+                v.depth = _fp(d); v.dh, v.dw = d.shape
+                if src_depth_cams is not None and i in src_depth_cams:
+                    kd, rd, cd = src_depth_cams[i]
+                    v.Kd[:] = np.asarray(kd, np.float64).ravel(); v.Rd[:] = np.asarray(rd, np.float64).ravel(); v.Cd[:] = np.asarray(cd, np.float64).ravel()
+                else:
+                    v.Kd[:] = v.K[:]; v.Rd[:] = v.R[:]; v.Cd[:] = v.C[:]
         h, w = keep[0].shape
         depth = np.zeros((h, w), np.float32) if depth is None else np.ascontiguousarray(depth, np.float32).copy()
         normal = np.zeros((h, w, 3), np.float32) if normal is None else np.ascontiguousarray(normal, np.float32).copy()
@@ -177,6 +190,20 @@ class PatchMatchHIP:
         self.scene_create(scene.n_views, scene.width, scene.height, n_levels)
         for i in range(scene.n_views):
             self.scene_set_view(i, scene.gray[i], scene.K[i], scene.R[i], scene.C[i], float(scene.dmin[i]), float(scene.dmax[i]), scene.neighbors[i])
+
+    def scene_set_view_sized(self, idx, gray, K, R, Cc, dmin, dmax, neighbors):
+        """A source view whose image has its own size (pmhip_scene_set_view_sized)."""
+        g = np.ascontiguousarray(gray, np.float32)
+        nb = np.ascontiguousarray(neighbors, np.int32)
+        self._chk(self._lib.pmhip_scene_set_view_sized(self._h, idx, _fp(g), g.shape[1], g.shape[0], 0, _dp(K), _dp(R), _dp(Cc), C.c_float(dmin), C.c_float(dmax),
+                                                       nb.ctypes.data_as(C.POINTER(C.c_int32)), len(nb)))
+
+    def scene_set_source_depth(self, idx, depth, Kd=None, Rd=None, Cd=None):
+        """Known depth map of a source view with the camera stored next to it (pmhip_scene_set_source_depth); depth None removes it."""
+        if depth is None:
+            self._chk(self._lib.pmhip_scene_set_source_depth(self._h, idx, None, 0, 0, None, None, None)); return
+        d = np.ascontiguousarray(depth, np.float32)
+        self._chk(self._lib.pmhip_scene_set_source_depth(self._h, idx, _fp(d), d.shape[1], d.shape[0], _dp(Kd), _dp(Rd), _dp(Cd)))
 
     def scene_estimate(self, view_ids, nGeometricIter=-1, params=None, sync=True):
         ids = np.ascontiguousarray(view_ids, np.int32)

@@ -824,6 +824,7 @@ struct OrcView {
 	double K[9], R[9], C[3];
 	const float* depth;          // nullable; source view's known depth-map (geometric pass)
 	double Kd[9], Rd[9], Cd[3];
+	int dw, dh;                  // size of that depth-map (0, 0 = the image's size): it is read with cameraDepthMap, not with the image's camera (DepthMap.h:170-171)
 };
 struct OrcOpt {
 	uint32_t nSubResolutionLevels, nEstimationIters, nEstimationGeometricIters, nRandomIters;
@@ -862,7 +863,8 @@ static void loadDepthData(const OrcView* views, int nViews, const float* depth, 
 		v.image.create(s.w, s.h); memcpy(v.image.d.data(), s.image, sizeof(float) * s.w * s.h);
 		memcpy(v.camera.K, s.K, 72); memcpy(v.camera.R, s.R, 72); memcpy(v.camera.C, s.C, 24);
 		if (i > 0 && s.depth) {
-			v.depthMap.create(s.w, s.h); memcpy(v.depthMap.d.data(), s.depth, sizeof(float) * s.w * s.h);
+			const int dw = s.dw > 0 ? s.dw : s.w, dh = s.dh > 0 ? s.dh : s.h;
+			v.depthMap.create(dw, dh); memcpy(v.depthMap.d.data(), s.depth, sizeof(float) * dw * dh);
 			memcpy(v.cameraDepthMap.K, s.Kd, 72); memcpy(v.cameraDepthMap.R, s.Rd, 72); memcpy(v.cameraDepthMap.C, s.Cd, 24);
 		}
 	}

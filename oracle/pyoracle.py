@@ -19,7 +19,7 @@ class OrcView(C.Structure):
     _fields_ = [("image", C.POINTER(C.c_float)), ("w", C.c_int), ("h", C.c_int),
                 ("K", C.c_double * 9), ("R", C.c_double * 9), ("C", C.c_double * 3),
                 ("depth", C.POINTER(C.c_float)),
-                ("Kd", C.c_double * 9), ("Rd", C.c_double * 9), ("Cd", C.c_double * 3)]
+                ("Kd", C.c_double * 9), ("Rd", C.c_double * 9), ("Cd", C.c_double * 3), ("dw", C.c_int), ("dh", C.c_int)]
 
 
 class OrcOpt(C.Structure):
@@ -64,8 +64,9 @@ def _fp(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def make_views(gray, K, R, Cc, ids, depth_maps=None):
-    """ids[0] = reference view, ids[1:] = sources.  depth_maps: optional dict id -> [H,W] float32."""
+def make_views(gray, K, R, Cc, ids, depth_maps=None, depth_cams=None):
+    """ids[0] = reference view, ids[1:] = sources.  depth_maps: optional dict id -> [H,W] float32 (any size);
+    depth_cams: optional dict id -> (Kd, Rd, Cd), the camera stored with that depth map (default: the view's own)."""
     keep = []
     arr = (OrcView * len(ids))()
     for n, i in enumerate(ids):
@@ -75,8 +76,12 @@ def make_views(gray, K, R, Cc, ids, depth_maps=None):
         v.K[:] = np.asarray(K[i], np.float64).ravel(); v.R[:] = np.asarray(R[i], np.float64).ravel(); v.C[:] = np.asarray(Cc[i], np.float64).ravel()
         if n > 0 and depth_maps is not None:
             d = np.ascontiguousarray(depth_maps[i], np.float32); keep.append(d)
-            v.depth = _fp(d)
-            v.Kd[:] = v.K[:]; v.Rd[:] = v.R[:]; v.Cd[:] = v.C[:]
+            v.depth = _fp(d); v.dh, v.dw = d.shape
+            if depth_cams is not None and i in depth_cams:
+                kd, rd, cd = depth_cams[i]
+                v.Kd[:] = np.asarray(kd, np.float64).ravel(); v.Rd[:] = np.asarray(rd, np.float64).ravel(); v.Cd[:] = np.asarray(cd, np.float64).ravel()
+            else:
+                v.Kd[:] = v.K[:]; v.Rd[:] = v.R[:]; v.Cd[:] = v.C[:]
     return arr, keep
 
 

@@ -67,6 +67,11 @@ def test_estimator_group_sizes_and_geometric_pass(engine, nine_scene):
     g.test_many_source_views_parity(engine)                                   # G = 16 (9 .. 16 sources) and partial groups
 
 
+def test_estimator_mixed_resolution_neighbours(engine):
+    from tests import test_gpu_patchmatch as g
+    g.test_mixed_resolution_neighbours_parity(engine)                        # sources at 0.8x / 1.25x, cameraDepthMap of another size
+
+
 def test_estimator_odd_sizes(engine):
     from tests import test_gpu_patchmatch as g
     g.test_non_divisible_image_size_parity(engine)

@@ -545,6 +545,69 @@ def test_real_scene_from_mvs_archive_matches_oracle_and_sfm_points():
     e.close()
 
 
+def test_mixed_resolution_neighbours_parity(engine):
+    """Source views of another size than the reference (DepthMap.h:194-204: a neighbour whose scale differs by >= 15 % is rescaled; here one at 0.8x
+    and one at 1.25x, rendered at those sizes): every view is projected into with its own K and sampled within its own bounds, on all pyramid
+    levels; in the geometric round the neighbours' depth maps keep the size and camera they were stored with (cameraDepthMap, SceneDensify.cpp:
+    378-393) while their images are the rescaled ones.  Through the one-call boundary and through the scene interface, bit-exact."""
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    base = synth.make_scene(5, 160, 120, n_src=4)
+    small = synth.make_scene(5, 128, 96, n_src=4)           # same cameras and surface, rendered at 0.8x ...
+    big = synth.make_scene(5, 200, 150, n_src=4)            # ... and at 1.25x
+    assert np.array_equal(base.R, small.R) and np.array_equal(base.C, big.C) and np.array_equal(base.neighbors, small.neighbors)
+    ref = 0
+    ids = [ref] + [int(i) for i in base.neighbors[ref]]
+    s1, s2 = ids[1], ids[2]
+    gray = {i: base.gray[i] for i in range(5)}; K = {i: base.K[i] for i in range(5)}
+    gray[s1] = small.gray[s1]; K[s1] = small.K[s1]
+    gray[s2] = big.gray[s2]; K[s2] = big.K[s2]
+    seed = 23
+    p = default_params(seed=seed, nEstimationGeometricIters=1)
+    # photometric pass, 3 levels
+    views, keep = po.make_views(gray, K, base.R, base.C, ids)
+    opt = po.default_opt(seed=seed, viewID=ref, nEstimationGeometricIters=1)
+    od, on, oc = po.estimate_depth_map(views, len(ids), float(base.dmin[ref]), float(base.dmax[ref]), opt)
+    engine.Init(False)
+    d, n, c = engine.EstimateDepthMap(gray, K, base.R, base.C, ids, base.dmin[ref], base.dmax[ref], params=p)
+    _same(d, od, "mixed sizes, photometric depth"); _same(n, on, "normal"); _same(c, oc, "conf")
+    assert (d > 0).mean() > 0.5
+    # geometric round: neighbour depth maps at the BASE size with the base cameras (as stored in their .dmap), images rescaled
+    src = {}
+    for i in ids[1:]:
+        vi = [i] + [int(j) for j in base.neighbors[i]]
+        vw, _k = po.make_views(base.gray, base.K, base.R, base.C, vi)
+        src[i] = po.estimate_depth_map(vw, len(vi), float(base.dmin[i]), float(base.dmax[i]), po.default_opt(seed=seed, viewID=i, nEstimationGeometricIters=1))[0]
+    cams = {i: (base.K[i], base.R[i], base.C[i]) for i in ids[1:]}
+    views, keep = po.make_views(gray, K, base.R, base.C, ids, depth_maps=src, depth_cams=cams)
+    gd, gn, gc = po.estimate_depth_map(views, len(ids), float(base.dmin[ref]), float(base.dmax[ref]), opt, geo_iter=0, depth=od, normal=on)
+    engine.Init(True)
+    d2, n2, c2 = engine.EstimateDepthMap(gray, K, base.R, base.C, ids, base.dmin[ref], base.dmax[ref], depth=d, normal=n, src_depths=src, src_depth_cams=cams,
+                                         nGeometricIter=0, params=p)
+    _same(d2, gd, "mixed sizes, geometric depth"); _same(n2, gn, "normal"); _same(c2, gc, "conf")
+    assert (d2 != d).any()
+    # the same engine, same-size call afterwards: nothing of the side storage may leak into it
+    engine.Init(False)
+    d3 = engine.EstimateDepthMap(base.gray, base.K, base.R, base.C, ids, base.dmin[ref], base.dmax[ref], params=p)[0]
+    views, keep = po.make_views(base.gray, base.K, base.R, base.C, ids)
+    _same(d3, po.estimate_depth_map(views, len(ids), float(base.dmin[ref]), float(base.dmax[ref]), opt)[0], "same-size call after a mixed one")
+    # scene interface: the two resized views are installed as sized source views
+    e = PatchMatchHIP(0); e.Init(False)
+    e.scene_load(base, n_levels=2)
+    e.scene_set_view_sized(s1, gray[s1], K[s1], base.R[s1], base.C[s1], float(base.dmin[s1]), float(base.dmax[s1]), base.neighbors[s1])
+    e.scene_set_view_sized(s2, gray[s2], K[s2], base.R[s2], base.C[s2], float(base.dmin[s2]), float(base.dmax[s2]), base.neighbors[s2])
+    e.scene_estimate([ref], -1, p)
+    sd, sn, scf = e.scene_get_maps(ref)
+    _same(sd, od, "scene interface, sized sources, depth"); _same(sn, on, "normal"); _same(scf, oc, "conf")
+    with pytest.raises(Exception):
+        e.scene_estimate([s1], -1, p)                       # a sized view cannot be a reference view (PMHIP_E_SIZE)
+    e.Init(True)
+    for i in ids[1:]:
+        e.scene_set_source_depth(i, src[i], *cams[i])
+    e.scene_estimate([ref], 0, p)
+    _same(e.scene_get_maps(ref)[0], gd, "scene interface, geometric round with installed source depth maps")
+    e.close()
+
+
 def test_config2_full_size_matches_golden():
     """BASELINE config 2 at its own size: 9-view 1920x1080 scene, every view 1 ref x 8 src, photometric pass + 2 geometric rounds, against the digests the
     SEQUENTIAL oracle produced on the CPU (tests/golden/make_fullsize_golden.py, ~10 CPU-minutes; SceneDensify.cpp:616-805).  Bit-exact, all 27 maps;

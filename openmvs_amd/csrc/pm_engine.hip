@@ -18,6 +18,9 @@
 #include <string>
 #include <vector>
 
+#ifndef PMHIP_DEFAULT_LANES
+#define PMHIP_DEFAULT_LANES 16   // sweep kernel: lanes per pixel (16 = one source view per lane whatever their number)
+#endif
 #ifndef PMHIP_DEFAULT_GROUPS
 #define PMHIP_DEFAULT_GROUPS 2
 #endif
@@ -87,6 +90,7 @@ struct pmhip_engine {
 	// view groups of a batch sweep on their own streams so that the tail of one group's diagonal launch
 	// overlaps the next launch of another group (views are independent; diagonals of one view are not)
 	int nGroups = 1;
+	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
 	hipStream_t gstream[16] = {};
 	hipEvent_t forkEv = nullptr, joinEv[16] = {};
 	bool inited = false, geom = false;
@@ -254,15 +258,26 @@ static void launchInit(int G, dim3 grid, hipStream_t s, const PMTask* t, const P
 	default: hipLaunchKernelGGL((pm_init_kernel<16, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
 	}
 }
+// (lanes per pixel, views per lane) -> kernel instantiation.  One view per lane for every group size, plus the mappings that give a lane
+// 2 or 4 of up to 8 / 16 views (pm_sweep_kernel's VPL).
 template <bool GEO>
-static void launchSweep(int G, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
-	switch (G) {
-	case 1: hipLaunchKernelGGL((pm_sweep_kernel<1, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, dir, d, xlo, count, pass); break;
-	case 2: hipLaunchKernelGGL((pm_sweep_kernel<2, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, dir, d, xlo, count, pass); break;
-	case 4: hipLaunchKernelGGL((pm_sweep_kernel<4, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, dir, d, xlo, count, pass); break;
-	case 8: hipLaunchKernelGGL((pm_sweep_kernel<8, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, dir, d, xlo, count, pass); break;
-	default: hipLaunchKernelGGL((pm_sweep_kernel<16, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, dir, d, xlo, count, pass); break;
+static void launchSweep(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
+#define PM_SWEEP_CASE(g, vpl) case (g) * 16 + (vpl): hipLaunchKernelGGL((pm_sweep_kernel<g, vpl, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, dir, d, xlo, count, pass); break
+	switch (G * 16 + VPL) {
+	PM_SWEEP_CASE(1, 1); PM_SWEEP_CASE(2, 1); PM_SWEEP_CASE(4, 1); PM_SWEEP_CASE(8, 1); PM_SWEEP_CASE(16, 1);
+	PM_SWEEP_CASE(1, 2); PM_SWEEP_CASE(2, 2); PM_SWEEP_CASE(4, 2); PM_SWEEP_CASE(8, 2);
+	PM_SWEEP_CASE(2, 4); PM_SWEEP_CASE(4, 4);
+	default: break;
 	}
+#undef PM_SWEEP_CASE
+}
+// Lanes per pixel for a batch whose views have at most maxSrc sources: G * VPL = next_pow2(maxSrc).  `lanes` (PMHIP_LANES or the built-in
+// default) caps G; VPL is what is left, limited to the instantiated mappings.
+static void sweepMapping(int maxSrc, int lanes, int& G, int& VPL) {
+	int NV = 1; while (NV < maxSrc) NV <<= 1;
+	G = NV; VPL = 1;
+	while (G > 1 && G > lanes && VPL < 4) { G >>= 1; VPL <<= 1; }
+	if ((G == 1 && VPL > 2) || (G == 8 && VPL > 2)) { G <<= 1; VPL >>= 1; }   // (1,4) and (8,4) are not instantiated
 }
 
 static size_t evBeginOn(pmhip_engine* e, int kind, hipStream_t st) {
@@ -317,7 +332,9 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 		for (int k = 0; k < v.nNb; ++k) if (v.nb[k] < 0 || v.nb[k] >= e->nImages || !e->views[v.nb[k]].set) { e->err = "neighbour view not set"; return PMHIP_E_ARG; }
 		maxSrc = std::max(maxSrc, v.nNb);
 	}
-	int G = 1; while (G < maxSrc) G <<= 1;
+	int G = 1; while (G < maxSrc) G <<= 1;          // init kernel: one view per lane
+	int SG = G, VPL = 1;                             // sweep kernel: (lanes per pixel, views per lane)
+	sweepMapping(maxSrc, e->sweepLanes, SG, VPL);
 	const size_t P0 = (size_t)e->w * e->h;
 	// the staging buffers are reused by the next call: make sure the previous call's copies are done
 	HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -413,7 +430,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 		else if (l < S)
 			hipLaunchKernelGGL(pm_upsample_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, e->lw(l + 1), e->lh(l + 1), lw, lh, nearestDepth);
 		// pass A: ScoreDepthMapTmp
-		const int PPB = PM_BLOCK / G;
+		const int PPB = PM_BLOCK / G, SPPB = PM_BLOCK / SG;
 		const uint32_t passInit = (uint32_t)l * 64u + 32u + (geo ? 16u + (uint32_t)nGeometricIter : 0u);
 		evBegin(e, 1);
 		{
@@ -443,9 +460,9 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 				for (int g = 0; g < NG; ++g) {
 					const int s0 = (int)((long)nB * g / NG), s1 = (int)((long)nB * (g + 1) / NG);
 					hipStream_t st = NG > 1 ? e->gstream[g] : e->stream;
-					const dim3 grid((unsigned)((count + PPB - 1) / PPB), s1 - s0);
-					if (geo) launchSweep<true>(G, grid, st, dt + s0, kp, dir, d, xlo, count, pass);
-					else launchSweep<false>(G, grid, st, dt + s0, kp, dir, d, xlo, count, pass);
+					const dim3 grid((unsigned)((count + SPPB - 1) / SPPB), s1 - s0);
+					if (geo) launchSweep<true>(SG, VPL, grid, st, dt + s0, kp, dir, d, xlo, count, pass);
+					else launchSweep<false>(SG, VPL, grid, st, dt + s0, kp, dir, d, xlo, count, pass);
 				}
 				if (e->statsOn) e->stats.sweepLaunches += NG;
 			}
@@ -508,6 +525,8 @@ int pmhip_create(int device, pmhip_engine** out) {
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return PMHIP_E_HIP; }
 	const char* ng = getenv("PMHIP_GROUPS");
 	e->nGroups = ng ? std::max(1, std::min(16, atoi(ng))) : PMHIP_DEFAULT_GROUPS;
+	const char* nl = getenv("PMHIP_LANES");
+	if (nl && atoi(nl) >= 1) e->sweepLanes = atoi(nl);
 	for (int g = 0; g < e->nGroups; ++g)
 		if (hipStreamCreateWithFlags(&e->gstream[g], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->joinEv[g], hipEventDisableTiming) != hipSuccess) { delete e; return PMHIP_E_HIP; }
 	if (hipEventCreateWithFlags(&e->forkEv, hipEventDisableTiming) != hipSuccess) { delete e; return PMHIP_E_HIP; }

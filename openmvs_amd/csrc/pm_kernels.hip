@@ -178,8 +178,8 @@ __device__ __forceinline__ void pm_correct_normal(float vx, float vy, float vz, 
 
 // two smallest of the group's values (as a multiset) by xor-butterfly; exact (comparisons only)
 template <int G>
-__device__ __forceinline__ void pm_group_min2(float s, float& m1, float& m2) {
-	float a = s, b = PM_INF;
+__device__ __forceinline__ void pm_group_min2(float s, float s2, float& m1, float& m2) {
+	float a = s, b = s2;   // this lane's two smallest scores (s <= s2; s2 = +inf when the lane scores a single view)
 #pragma unroll
 	for (int m = 1; m < G; m <<= 1) {
 		const float oa = __shfl_xor(a, m, G);
@@ -466,9 +466,9 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 
 // ScorePixel aggregation, DepthMap.cpp:594-611 (MINMEAN)
 template <int G>
-__device__ __forceinline__ float pm_aggregate(float viewScore, int nSrc, float thRobust) {
+__device__ __forceinline__ float pm_aggregate(float viewScore, int nSrc, float thRobust, float viewScore2 = PM_INF) {
 	float m1, m2;
-	pm_group_min2<G>(viewScore, m1, m2);
+	pm_group_min2<G>(viewScore, viewScore2, m1, m2);
 	if (nSrc <= 1) return m1;
 	if (m2 >= thRobust) return m1;
 	return (m1 + m2) / 2.f;
@@ -570,20 +570,26 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 // -------------------------------------------------------------------------------------------
 // ProcessPixel, DepthMap.cpp:630-852, for all pixels of anti-diagonal x+y == d (x = xlo + i).
 // dir 0 = LT2RB (left/top are new), 1 = RB2LT (right/bottom are new).
-template <int G, bool GEO>
-__global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
+// VPL = source views per lane: lane v of a pixel's G lanes scores views v, v + G, ..., one after the other.  Everything that is per pixel
+// (hypothesis generation, smoothness factors, the visit's set-up, accept / reject: about 70 % of a wave's time at one view per lane, measured
+// with -DPM_PROFILE) is then shared by VPL times as many pixels per wave; MINMEAN does not care which lane scored which view.
+template <int G, int VPL, bool GEO>
+__global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVES)) void pm_sweep_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	constexpr int PPB = PM_BLOCK / G;
 	constexpr int SL = (G >= 4) ? 1 : 4 / G; // smoothness slots owned per lane
 	constexpr int PPW = 64 / G;               // pixels per wave
+	constexpr int NV = G * VPL;               // source views the wave holds windows for
 	constexpr int TC = PM_USE_TILES ? PPW + PM_TCX : 0;
 	constexpr int TSTRIDE = PM_TR * TC + PM_TILE_PAD;
+	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
 	PM_PROF_DECL;
 	__shared__ float2 s_w[PPB][PM_NT + 1];
-	__shared__ float s_tile[PM_USE_TILES ? PM_BLOCK / 64 : 1][PM_USE_TILES ? G * TSTRIDE : 1];
+	__shared__ float s_tile[PM_USE_TILES ? PM_BLOCK / 64 : 1][PM_USE_TILES ? NV * TSTRIDE : 1];
+	__shared__ int2 s_org[PM_BLOCK / 64][NV];   // window origin (ts0, tt0) of every view
 	// Per-view constants of the wave's source views: every hypothesis evaluation of every pixel needs the hot block of its lane's view (Hl, Hm, image
 	// size; in the geometric pass also the four transforms and the depth-map pointer) -- a global round trip at the head of each evaluation when read
 	// from the task.  One coalesced copy per visit puts them an LDS read away (832 B per wave at G = 8, twice that in the geometric pass).
-	__shared__ double s_src[PM_BLOCK / 64][G * (PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0))];
+	__shared__ double s_src[PM_BLOCK / 64][NV * NBD];
 	// XCD-aware block mapping: workgroup b is observed to run on XCD b % 8 (dispatch order, x fastest), each XCD with its own 4 MB L2.  The remap
 	// hands every XCD a contiguous range of (view, diagonal chunk) pairs -- the same few views launch after launch -- so the source windows of
 	// neighbouring chunks and of the next diagonal are found in that XCD's L2 instead of being fetched into several of them.  Bijective for any
@@ -598,12 +604,10 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 	const PMTask& t = tasks[vby];
 	const int g = threadIdx.x / G, v = threadIdx.x % G;
 	{
-		constexpr int NB = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
 		double* dst = s_src[threadIdx.x >> 6];
-		for (int i = threadIdx.x & 63; i < G * NB; i += 64) dst[i] = ((const double*)&t.src[i / NB])[i % NB];   // views >= nSrc: zeros (the task is memset), never used
+		for (int i = threadIdx.x & 63; i < NV * NBD; i += 64) dst[i] = ((const double*)&t.src[i / NBD])[i % NBD];   // views >= nSrc: zeros (the task is memset), never used
 	}
-	const double* hot = s_src[threadIdx.x >> 6] + v * (PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0));
-	const double* geoTab = hot + PM_SRC_HOT;
+	const double* hotBase = s_src[threadIdx.x >> 6];   // view k's blocks at hotBase + k * NBD
 	const int w = t.w, h = t.h;
 	const int pi = vbx * PPB + g;
 	const bool active = pi < count;
@@ -687,37 +691,43 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 	// projects close to where the current plane does, so one window per (wave, view) around the current
 	// footprints serves nearly all 100 x ~8 taps; the rest (random restarts, depth discontinuities) fall back
 	// to global loads tap-row by tap-row.  Window origin = min over the wave's pixels of the footprint centre.
-	int ts0 = 0, tt0 = 0;
-	const float* tile = nullptr;
+	const float* tileBase = nullptr;
 	if (TC > 0) {
-		int cs = 0x7fffffff, ctt = 0x7fffffff;
-		if (valid && v < t.nSrc) {
-			float Hc[9];
-			pm_homography(hot, t, X0x, X0y, depth, nx, ny, nz, Hc);
-			const float fxp = (float)x, fyp = (float)y;
-			const float c0 = Hc[0] * fxp + Hc[1] * fyp + Hc[2], c1 = Hc[3] * fxp + Hc[4] * fyp + Hc[5], c2 = Hc[6] * fxp + Hc[7] * fyp + Hc[8];
-			const float cu = c0 / c2, cv = c1 / c2;
-			if (cu > -1e6f && cu < 1e6f && cv > -1e6f && cv < 1e6f) { const int iu = (int)pm_floorf(cu), iv = (int)pm_floorf(cv); cs = iu + iv; ctt = iv; }
-		}
-#pragma unroll
-		for (int m = G; m < 64; m <<= 1) { cs = min(cs, __shfl_xor(cs, m, 64)); ctt = min(ctt, __shfl_xor(ctt, m, 64)); }
-		if (cs == 0x7fffffff) { cs = 0; ctt = 0; }
-		ts0 = cs - 8 - (PM_TR - 19) / 2; tt0 = ctt - PM_HW - (PM_TCX - 9) / 2;
-		PM_TICK(13);
 		const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+		for (int u = 0; u < VPL; ++u) {
+			const int view = v + u * G;
+			int cs = 0x7fffffff, ctt = 0x7fffffff;
+			if (valid && view < t.nSrc) {
+				float Hc[9];
+				pm_homography(hotBase + view * NBD, t, X0x, X0y, depth, nx, ny, nz, Hc);
+				const float fxp = (float)x, fyp = (float)y;
+				const float c0 = Hc[0] * fxp + Hc[1] * fyp + Hc[2], c1 = Hc[3] * fxp + Hc[4] * fyp + Hc[5], c2 = Hc[6] * fxp + Hc[7] * fyp + Hc[8];
+				const float cu = c0 / c2, cv = c1 / c2;
+				if (cu > -1e6f && cu < 1e6f && cv > -1e6f && cv < 1e6f) { const int iu = (int)pm_floorf(cu), iv = (int)pm_floorf(cv); cs = iu + iv; ctt = iv; }
+			}
+#pragma unroll
+			for (int m = G; m < 64; m <<= 1) { cs = min(cs, __shfl_xor(cs, m, 64)); ctt = min(ctt, __shfl_xor(ctt, m, 64)); }
+			if (cs == 0x7fffffff) { cs = 0; ctt = 0; }
+			if (lane < G) s_org[wave][view] = make_int2(cs - 8 - (PM_TR - 19) / 2, ctt - PM_HW - (PM_TCX - 9) / 2);
+		}
+		__syncthreads();
+		PM_TICK(13);
 		float* tw = s_tile[wave];
 		const int nS = t.nSrc;
 		constexpr int TCD = TC > 0 ? TC : 1;
 		constexpr int NLD = (PM_TR * TCD + 63) / 64;
-		// PM_WINBATCH windows are requested together: the loads of a window are one memory round trip, and the round trips of
+		constexpr int WB = NLD > 8 ? 2 : PM_WINBATCH;   // wide windows (many pixels per wave): fewer in flight, the registers are needed
+		// WB windows are requested together: the loads of a window are one memory round trip, and the round trips of
 		// the nSrc windows of a visit are a serial chain at the head of every wave's life
-		for (int vb = 0; vb < nS; vb += PM_WINBATCH) {
-			float vals[PM_WINBATCH][NLD];
+		for (int vb = 0; vb < nS; vb += WB) {
+			float vals[WB][NLD];
 #pragma unroll
-			for (int b = 0; b < PM_WINBATCH; ++b) {
+			for (int b = 0; b < WB; ++b) {
 				const int vv = vb + b;
 				if (vv >= nS) break;
-				const int fs0 = __shfl(ts0, vv, 64), ft0 = __shfl(tt0, vv, 64);
+				const int2 org = s_org[wave][vv];
+				const int fs0 = org.x, ft0 = org.y;
 				const pm_gcf src = pm_glob(t.src[vv].imgS);
 				const int sh = t.src[vv].h, sMax = t.src[vv].w + t.src[vv].h - 1;
 #pragma unroll
@@ -729,14 +739,14 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 				}
 			}
 #pragma unroll
-			for (int b = 0; b < PM_WINBATCH; ++b) {
+			for (int b = 0; b < WB; ++b) {
 				const int vv = vb + b;
 				if (vv >= nS) break;
 #pragma unroll
 				for (int k = 0; k < NLD; ++k) { const int i = lane + 64 * k; if (i < PM_TR * TC) tw[vv * TSTRIDE + i] = vals[b][k]; }
 			}
 		}
-		tile = tw + v * TSTRIDE;
+		tileBase = tw;
 		__syncthreads();
 	}
 	// state machine: every outer trip scores at most one hypothesis per pixel, so the lanes of a wave
@@ -845,10 +855,19 @@ __global__ __launch_bounds__(PM_BLOCK, PM_MINWAVES) void pm_sweep_kernel(const P
 				sf[k] = __shfl(myF[k / G < SL ? k / G : 0], (k % G), G);
 		}
 		PM_TICK(2);
-		float sc = PM_INF;
-		if (need && v < t.nSrc)
-			sc = pm_score_view<GEO, true, TC, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], 0.f, tile, ts0, tt0, hot, geoTab PM_PROF_PASS);
-		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
+		float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
+#pragma unroll 1
+		for (int u = 0; u < VPL; ++u) {
+			const int view = v + u * G;
+			if (need && view < t.nSrc) {
+				int2 org = make_int2(0, 0);
+				if (TC > 0) org = s_org[threadIdx.x >> 6][view];
+				const float s1 = pm_score_view<GEO, true, TC, true>(t.src[view], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], 0.f,
+					tileBase + view * TSTRIDE, org.x, org.y, hotBase + view * NBD, hotBase + view * NBD + PM_SRC_HOT PM_PROF_PASS);
+				if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
+			}
+		}
+		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
 		if (need && conf > nconf) {
 			conf = nconf; depth = hd; nx = hnx; ny = hny; nz = hnz; changed = true;
 			if (hst == ST_RAND) { if (conf < kp.thConfRand) st = ST_DECIDE; }

@@ -42,7 +42,7 @@ def test_sgmhip_exports_every_declared_symbol():
 def test_struct_sizes_match_header():
     from openmvs_amd import patchmatch as pm
     assert C.sizeof(pm.PMHipParams) == 4 * 4 + 9 * 4 + 4
-    assert C.sizeof(pm.PMHipView) == 8 + 8 + 21 * 8 + 8 + 21 * 8 + 8
+    assert C.sizeof(pm.PMHipView) == 8 + 8 + 21 * 8 + 8 + 21 * 8 + 16   # id, dw, dh + 4 bytes of tail padding
     assert C.sizeof(pm.PMHipKernelStats) == 56
 
 

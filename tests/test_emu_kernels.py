@@ -67,6 +67,12 @@ def test_estimator_group_sizes_and_geometric_pass(engine, nine_scene):
     g.test_many_source_views_parity(engine)                                   # G = 16 (9 .. 16 sources) and partial groups
 
 
+@pytest.mark.parametrize("lanes", [4, 2])
+def test_estimator_views_per_lane(pm_emulated, nine_scene, small_scene, lanes):
+    from tests import test_gpu_patchmatch as g
+    g.test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes)    # (4,2), (2,4), (2,2), (4,4): several source views per lane
+
+
 def test_estimator_mixed_resolution_neighbours(engine):
     from tests import test_gpu_patchmatch as g
     g.test_mixed_resolution_neighbours_parity(engine)                        # sources at 0.8x / 1.25x, cameraDepthMap of another size

@@ -82,6 +82,43 @@ def test_single_view_parity_N8_and_N1(engine, nine_scene):
         _same(d, od, f"depth N={nsrc}"); _same(n, on, f"normal N={nsrc}"); _same(c, oc, f"conf N={nsrc}")
 
 
+@pytest.mark.parametrize("lanes", [4, 2])
+def test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes):
+    """The sweep kernel's other work decompositions (PMHIP_LANES): 4 or 2 lanes per pixel with 2 or 4 source views per lane instead of one view per
+    lane (16 / 32 pixels per wavefront at 8 sources), and the mappings 8 and 3-4 and 9-16 sources fall to; MINMEAN is order-free, so the maps are
+    the same bits.  Photometric pass over the pyramid and a geometric round."""
+    import os
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    saved = os.environ.get("PMHIP_LANES")
+    os.environ["PMHIP_LANES"] = str(lanes)
+    try:
+        e = PatchMatchHIP(0)
+        test_single_view_parity_N8_and_N1(e, nine_scene)                 # 8 sources: (4,2) / (2,4); 1-3 sources: one or two lanes
+        test_single_view_photometric_parity_N4(e, small_scene, 2)        # 4 sources: (4,1) / (2,2)
+        sc = nine_scene
+        p = default_params(seed=5, nEstimationGeometricIters=1)
+        e.Init(False); e.scene_load(sc, n_levels=2)
+        allv = list(range(sc.n_views))
+        e.scene_estimate(allv, -1, p)
+        photo = [e.scene_get_maps(v) for v in allv]
+        e.scene_commit_round(); e.Init(True)
+        e.scene_estimate([4, 0], 0, p)
+        for v in (4, 0):
+            od, on, oc = _oracle(sc, v, 5, nEstimationGeometricIters=1)
+            _same(photo[v][0], od, f"lanes {lanes}: photometric depth v{v}")
+            gd, gn, gc = _oracle(sc, v, 5, geo_iter=0, depth=od, normal=on, src={u: photo[u][0] for u in allv}, nEstimationGeometricIters=1)
+            d, n, c = e.scene_get_maps(v)
+            _same(d, gd, f"lanes {lanes}: geometric depth v{v}"); _same(n, gn, "normal"); _same(c, gc, "conf")
+        if lanes == 4:
+            test_many_source_views_parity(e)                            # 9 .. 16 sources: (4,4)
+        e.close()
+    finally:
+        if saved is None:
+            os.environ.pop("PMHIP_LANES", None)
+        else:
+            os.environ["PMHIP_LANES"] = saved
+
+
 def test_non_divisible_image_size_parity(engine):
     # 163x121 with 2 sub-levels: level sizes cvRound -> 82x60, 41x30; INTER_AREA border rule on both axes
     sc = synth.make_scene(4, 163, 121, n_src=3)

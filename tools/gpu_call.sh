@@ -30,7 +30,7 @@ bench)
   timeout 900 python bench.py ${BENCH_ARGS:-} > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "rc $?"; tail -c 1500 "$OUT/bench.json"; tail -3 "$OUT/bench.err" ;;
 prof)
   step "rocprof kernel stats of bench.py"
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o bench -- python "$R/bench.py" --no-cpu-baseline ${BENCH_ARGS:-} \
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o bench -- python "$R/bench.py" --no-cpu-baseline ${BENCH_ARGS:-} \
       > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/rocprof.err" ); echo "rc $?"
   find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \; ; rm -rf /tmp/prof_stats
   head -8 "$OUT/bench_kernel_stats.csv"; tail -c 400 "$OUT/bench_under_rocprof.json" ;;
@@ -46,7 +46,7 @@ variants)
   timeout 900 python tools/tune.py ${TUNE_VIEWS:-100} ${VARIANTS:-libpmhip.so:2} > "$OUT/variants.log" 2>&1; cat "$OUT/variants.log" ;;
 phase)
   step "in-kernel phase profile (-DPM_PROFILE build)"
-  for spec in ${PHASE_SPECS:-"100" "9 4"}; do PMHIP_LIB=$R/openmvs_amd/libpmhip_prof.so timeout 600 python tools/phase_prof.py $spec >> "$OUT/phase_prof.log" 2>&1; done
+  for lanes in ${PHASE_LANES:-16}; do for spec in ${PHASE_SPECS:-"100" "9 4"}; do echo "PMHIP_LANES=$lanes" >> "$OUT/phase_prof.log"; PMHIP_LANES=$lanes PMHIP_LIB=$R/openmvs_amd/libpmhip_prof.so timeout 600 python tools/phase_prof.py $spec >> "$OUT/phase_prof.log" 2>&1; done; done
   cat "$OUT/phase_prof.log" ;;
 sgm)
   step "sgm probe"

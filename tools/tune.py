@@ -1,13 +1,17 @@
-"""Run bench.py for several (library variant, PMHIP_GROUPS) settings; prints one line each."""
+"""Run bench.py for several (library variant, PMHIP_GROUPS[, PMHIP_LANES]) settings given as lib:groups[:lanes]; prints one line each."""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 views = sys.argv[1] if len(sys.argv) > 1 else "48"
 variants = [a.split(":") for a in sys.argv[2:]] or [["libpmhip.so", "1"]]
-for lib, groups in variants:
+for spec in variants:
+    lib, groups = spec[0], spec[1]
+    lanes = spec[2] if len(spec) > 2 else ""
     env = dict(os.environ, PMHIP_LIB=os.path.join(root, "openmvs_amd", lib), PMHIP_GROUPS=groups)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--views-per-gpu", views], env=env, capture_output=True, text=True, timeout=400)
+    if lanes:
+        env["PMHIP_LANES"] = lanes
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-extras", "--views-per-gpu", views], env=env, capture_output=True, text=True, timeout=400)
     try:
         j = json.loads(r.stdout.strip().splitlines()[-1])
-        print("%-18s groups=%-2s views=%s  %.2f Mpix/s  step %.0f ms  avg_launch %.1f us" % (lib, groups, views, j["value"], j["ms_per_step"], j["roofline"]["avg_launch_us"]), flush=True)
+        print("%-18s groups=%-2s lanes=%-2s views=%s  %.2f Mpix/s  step %.0f ms  avg_launch %.1f us" % (lib, groups, lanes or "-", views, j["value"], j["ms_per_step"], j["roofline"]["avg_launch_us"]), flush=True)
     except Exception as ex:
         print(lib, groups, "FAILED", ex, r.stderr[-500:], flush=True)

@@ -315,7 +315,7 @@ __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int t
 		zlo = pm_fminf(zlo, X2); zhi = pm_fmaxf(zhi, X2);
 		pxlo = pm_fminf(pxlo, ptx); pxhi = pm_fmaxf(pxhi, ptx); pylo = pm_fminf(pylo, pty); pyhi = pm_fmaxf(pyhi, pty);
 		const int lx = (int)ptx, ly = (int)pty;
-		fxs[j] = ptx - (float)lx; fys[j] = pty - (float)ly;
+		fxs[j] = pm_fract_pos(ptx); fys[j] = pm_fract_pos(pty);   // == ptx - (float)lx for the positions the row is accepted with (>= 1)
 		const int sk = lx + ly;
 		slo = min(slo, sk); shi = max(shi, sk);
 		const int idx = pm_mul24(sk, TC) + (ly + cidx);   // 24-bit multiply: full rate (a 32-bit one is a quarter-rate v_mad_u64_u32); garbage only where the row fails anyway

@@ -116,6 +116,15 @@ PM_HD void pm_div2_inrange(float x, float y, float z, float* qx, float* qy) {
 	*qx = x / z; *qy = y / z;
 #endif
 }
+// x - (float)(int)x for x >= 0 (TImage::sample's interpolation weight): the subtraction is exact, so v_fract_f32 returns the same bits in one
+// instruction instead of a conversion back to float and a subtraction
+PM_HD float pm_fract_pos(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_fractf(x);
+#else
+	return x - floorf(x);
+#endif
+}
 // min / max of values known not to be NaN (v_min_f32 / v_max_f32, fused into v_min3 / v_max3 by the compiler)
 PM_HD float pm_fminf(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)

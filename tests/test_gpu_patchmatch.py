@@ -684,6 +684,44 @@ def test_config2_full_size_matches_golden():
     e.close()
 
 
+def test_config5_resolution_estimate_filter_fuse():
+    """BASELINE config 5's resolution (3840x2160), a 5-view slice of such a scene: photometric pass + one geometric round, speckle / gap filters, the
+    cross-view filter and the fusion, all resident.  The oracle would need hours here, so the checks are size-independent properties: run-to-run
+    determinism of the whole chain (schedule races would show), accuracy against the analytic ground truth, the filters only remove or smooth,
+    fused points lie on the surface; the sizes where 32-bit offsets or grid limits could bite (8.3 Mpix per map, 6 k diagonals) are exercised."""
+    import time
+    from openmvs_amd import densify
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    W, H, V = 3840, 2160, 5
+    sc = synth.make_scene(V, W, H, n_src=4, device="cuda", exact=True)
+    allv = list(range(V))
+    p = default_params(seed=3, nEstimationGeometricIters=1)
+    runs = []
+    for rep in range(2):
+        e = PatchMatchHIP(0)
+        e.scene_load(sc, n_levels=2)
+        for v in allv:
+            e.scene_set_color(v, sc.bgr[v])
+        t0 = time.time()
+        densify.compute_depth_maps(e, allv, p)
+        e.sync(); t1 = time.time()
+        cloud = e.scene_fuse(po.fuse_order([len(sc.neighbors[v]) for v in allv]))
+        t2 = time.time()
+        runs.append(([e.scene_get_maps(v) for v in allv], cloud))
+        e.close()
+    print("config-5 resolution, %d views: estimate + filters %.2f s (%.1f Mpix/s), fuse %.2f s, %d points" % (V, t1 - t0, V * W * H / (t1 - t0) / 1e6, t2 - t1, runs[0][1]["nPoints"]))
+    for v in allv:
+        for a, b, what in zip(runs[0][0][v], runs[1][0][v], ("depth", "normal", "conf")):
+            _same(a, b, f"determinism v{v} {what}")
+    assert runs[0][1]["nPoints"] == runs[1][1]["nPoints"] and np.array_equal(runs[0][1]["points"], runs[1][1]["points"])
+    d = runs[0][0][2][0]; m = d > 0
+    gt = sc.gt_depth[2]
+    rel = np.abs(d[m] - gt[m]) / gt[m]
+    assert m.mean() > 0.8 and np.median(rel) < 1e-3 and (rel < 0.01).mean() > 0.95
+    pts = runs[0][1]["points"]
+    assert len(pts) > 1_000_000 and np.abs(pts[:, 2]).max() < 0.12     # the surface is a height field |z| <= 0.1 around z = 0
+
+
 def test_full_size_properties():
     """BASELINE config 2 (1 ref x 8 src, 1920x1080): the oracle needs ~15 min here, so check
     size-independent properties: run-to-run determinism (race check of the diagonal schedule),

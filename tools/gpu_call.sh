@@ -48,6 +48,12 @@ phase)
   step "in-kernel phase profile (-DPM_PROFILE build)"
   for lanes in ${PHASE_LANES:-16}; do for spec in ${PHASE_SPECS:-"100" "9 4"}; do echo "PMHIP_LANES=$lanes" >> "$OUT/phase_prof.log"; PMHIP_LANES=$lanes PMHIP_LIB=$R/openmvs_amd/libpmhip_prof.so timeout 600 python tools/phase_prof.py $spec >> "$OUT/phase_prof.log" 2>&1; done; done
   cat "$OUT/phase_prof.log" ;;
+small)
+  step "small batches (8-GPU shard size, strong scaling): ${SMALL_VIEWS:-13} views"
+  timeout 600 python tools/tune.py ${SMALL_VIEWS:-13} ${SMALL_VARIANTS:-libpmhip.so:1 libpmhip.so:2 libpmhip.so:4 libpmhip.so:13} > "$OUT/small_batches.log" 2>&1; cat "$OUT/small_batches.log" ;;
+one)
+  step "selected tests: ${ONE_K:-config5}"
+  timeout 900 python -m pytest tests -m gpu -q -s -k "${ONE_K:-config5}" > "$OUT/selected_tests.log" 2>&1; tail -12 "$OUT/selected_tests.log" ;;
 sgm)
   step "sgm probe"
   timeout 600 python tools/probe_sgm.py > "$OUT/sgm_probe.log" 2>&1; cat "$OUT/sgm_probe.log" ;;

@@ -244,6 +244,17 @@ __device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t
 #ifndef PM_XCD_REMAP
 #define PM_XCD_REMAP 1  // sweep kernel: contiguous (view, chunk) ranges per XCD (see the kernel)
 #endif
+// Three switches of an experiment that did not pay (profiles/r02_variants_call7_ilp_block.log: all on 30.8, all off 32.1 Mpix/s): writing the
+// per-hypothesis chains that do not depend on each other as one branch-free block so that the scheduler can interleave them.  Off by default.
+#ifndef PM_ILP_HOMOGRAPHY
+#define PM_ILP_HOMOGRAPHY 0   // the lane's homography computed next to the smoothness factors instead of inside pm_score_view
+#endif
+#ifndef PM_ILP_PHILOX
+#define PM_ILP_PHILOX 0       // the random draw of the next refinement iteration computed one evaluation ahead
+#endif
+#ifndef PM_ILP_SMOOTH
+#define PM_ILP_SMOOTH 0       // smoothness factors computed by every lane without a branch (0: only by the lanes that own a close neighbour)
+#endif
 #ifndef PM_WINBATCH
 #define PM_WINBATCH 4   // source windows whose global loads are in flight together when a visit stages its windows
 #endif
@@ -354,13 +365,16 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		int x, int y, double X0x, double X0y, float normSq0, float sumW, const float2* wts,
 		float depth, float nx, float ny, float nz,
 		float sf0, float sf1, float sf2, float sf3, float prior,
-		const float* tile, int ts0, int tt0, const double* hot, const double* geoTab PM_PROF_ARG)
+		const float* tile, int ts0, int tt0, const double* hot, const double* geoTab, const float* Hpre PM_PROF_ARG)
 {
 	// hot / geoTab: the hot and geometric blocks of `s` (PMSrcView), in HBM (init kernel) or in the wave's LDS copy (sweep kernel); the image
 	// size travels with the homography entries
 	const int sw = ((const int*)(hot + 12))[0], sh = ((const int*)(hot + 12))[1];
 	float H[9];
-	pm_homography(hot, t, X0x, X0y, depth, nx, ny, nz, H);
+	if (Hpre) {   // computed by the caller next to the other per-hypothesis chains (instruction-level parallelism), see pm_sweep_kernel
+#pragma unroll
+		for (int i = 0; i < 9; ++i) H[i] = Hpre[i];
+	} else pm_homography(hot, t, X0x, X0y, depth, nx, ny, nz, H);
 	PM_TICK(3);
 	const float px = (float)(x - PM_HW), py = (float)(y - PM_HW);
 	const float X0 = H[0] * px + H[1] * py + H[2];
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 	float sc = PM_INF;
 	PM_PROF_DECL;
 	if (v < t.nSrc)
-		sc = pm_score_view<GEO, false, 0>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, nullptr, 0, 0, t.src[v].Hl, (const double*)t.src[v].Tl PM_PROF_PASS);
+		sc = pm_score_view<GEO, false, 0>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, nullptr, 0, 0, t.src[v].Hl, (const double*)t.src[v].Tl, nullptr PM_PROF_PASS);
 	const float conf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 	if (v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
 }
@@ -757,6 +771,9 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 	float scaleRange = 1.f, depthRange = 0.f, p0 = 0.f, p1 = 0.f;
 	bool smooth = true, changed = false;
 	const uint32_t k1 = t.k1base + pass;
+	PmPhilox4 rNext; unsigned rNextIt = 0xffffffffu;   // draw of refinement iteration rNextIt, computed one evaluation ahead (counter-based: same bits)
+#pragma unroll
+	for (int i = 0; i < 4; ++i) rNext.v[i] = 0u;
 	PM_TICK(0); PM_COUNT(9, 1);
 	for (;;) {
 		bool need = false;
@@ -815,7 +832,8 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 				need = true; hst = ST_RAND;
 			} else { // ST_REFINE, DepthMap.cpp:832-852
 				if (it >= kp.nRandomIters) { st = ST_DONE; break; }
-				const PmPhilox4 r = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_REFINE * 256) + it, 0u, t.k0, k1);
+				PmPhilox4 r = rNext;
+				if (!PM_ILP_PHILOX || rNextIt != it) r = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_REFINE * 256) + it, 0u, t.k0, k1);
 				++it;
 				const float ndepth = depth + (depthRange * scaleRange) * (2.f * pm_u32_to_unit(r.v[0]) - 1.f);
 				if (!pm_in_range(ndepth, t.dMin, t.dMax)) continue;
@@ -830,16 +848,21 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 		if (!__any(need)) break;
 		PM_TICK(1); PM_COUNT(6 + 5, 0); PM_COUNT(8, __popcll(__ballot(need)));
 		// smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533
+		// smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533, one neighbour per lane.  (With the PM_ILP_*
+		// switches the homography of the lane's view and the next refinement draw join this block branch-free, so that the scheduler could interleave
+		// the three dependent chains; measured slower, see the switches.)
 		float sf[4] = {1.f, 1.f, 1.f, 1.f};
+		float Hpre[9];
 		{
 			const bool useS = need && smooth;
 			const float planeD = -hd * (hnx * vx + hny * vy + hnz * vz); // InitPlane, DepthMap.cpp:963-971
 			float myF[SL];
 #pragma unroll
 			for (int q = 0; q < SL; ++q) {
-				myF[q] = 1.f;
 				const int k = q * G + v;
-				if (useS && k < 4 && ((closeMask >> k) & 1u)) {
+				const bool on = useS && k < 4 && ((closeMask >> k) & 1u);
+				myF[q] = 1.f;
+				if (PM_ILP_SMOOTH || on) {
 					const float dist = (hnx * qX0[q] + (hny * qX1[q] + hnz * qX2[q])) + planeD; // Planef::Distance, Eigen 3-dot order
 					const float r = dist / hd;
 					const float factorDepth = pm_expf((r * r) * kp.smoothSigmaDepth);
@@ -847,9 +870,12 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 						pm_sqrtf((hnx * hnx + hny * hny + hnz * hnz) * (qn0[q] * qn0[q] + qn1[q] * qn1[q] + qn2[q] * qn2[q])), -1.f, 1.f);
 					const float ac = pm_acosf(ca);
 					const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
-					myF[q] = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
+					const float f = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
+					myF[q] = on ? f : 1.f;
 				}
 			}
+			if (VPL == 1 && PM_ILP_HOMOGRAPHY) pm_homography(hotBase + v * NBD, t, X0x, X0y, hd, hnx, hny, hnz, Hpre);
+			if (PM_ILP_PHILOX) { rNext = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_REFINE * 256) + it, 0u, t.k0, k1); rNextIt = it; }
 #pragma unroll
 			for (int k = 0; k < 4; ++k)
 				sf[k] = __shfl(myF[k / G < SL ? k / G : 0], (k % G), G);
@@ -863,7 +889,7 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 				int2 org = make_int2(0, 0);
 				if (TC > 0) org = s_org[threadIdx.x >> 6][view];
 				const float s1 = pm_score_view<GEO, true, TC, true>(t.src[view], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], 0.f,
-					tileBase + view * TSTRIDE, org.x, org.y, hotBase + view * NBD, hotBase + view * NBD + PM_SRC_HOT PM_PROF_PASS);
+					tileBase + view * TSTRIDE, org.x, org.y, hotBase + view * NBD, hotBase + view * NBD + PM_SRC_HOT, (VPL == 1 && PM_ILP_HOMOGRAPHY) ? Hpre : nullptr PM_PROF_PASS);
 				if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
 			}
 		}

@@ -18,6 +18,9 @@
 #include <string>
 #include <vector>
 
+#ifndef PMHIP_DEFAULT_WIDE
+#define PMHIP_DEFAULT_WIDE 0    // set after measuring
+#endif
 #ifndef PMHIP_DEFAULT_LANES
 #define PMHIP_DEFAULT_LANES 16   // sweep kernel: lanes per pixel (16 = one source view per lane whatever their number)
 #endif
@@ -90,6 +93,7 @@ struct pmhip_engine {
 	// view groups of a batch sweep on their own streams so that the tail of one group's diagonal launch
 	// overlaps the next launch of another group (views are independent; diagonals of one view are not)
 	int nGroups = 1;
+	int wideMaxViews = PMHIP_DEFAULT_WIDE;   // batches of at most this many views use the one-wave-per-pixel sweep kernel (PMHIP_WIDE)
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
 	hipStream_t gstream[16] = {};
 	hipEvent_t forkEv = nullptr, joinEv[16] = {};
@@ -280,6 +284,11 @@ static void sweepMapping(int maxSrc, int lanes, int& G, int& VPL) {
 	if ((G == 1 && VPL > 2) || (G == 8 && VPL > 2)) { G <<= 1; VPL >>= 1; }   // (1,4) and (8,4) are not instantiated
 }
 
+template <bool GEO>
+static void launchSweepWide(dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
+	hipLaunchKernelGGL((pm_sweep_wide_kernel<GEO>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass);
+}
+
 static size_t evBeginOn(pmhip_engine* e, int kind, hipStream_t st) {
 	if (!e->statsOn) return 0;
 	pmhip_engine::Ev ev; ev.kind = kind;
@@ -335,6 +344,8 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 	int G = 1; while (G < maxSrc) G <<= 1;          // init kernel: one view per lane
 	int SG = G, VPL = 1;                             // sweep kernel: (lanes per pixel, views per lane)
 	sweepMapping(maxSrc, e->sweepLanes, SG, VPL);
+	// latency mode (one wave per pixel, pm_sweep_wide_kernel) for batches too small to fill the GPU with one wave per 64 / G pixels
+	const bool wide = nB <= e->wideMaxViews && maxSrc <= 8;
 	const size_t P0 = (size_t)e->w * e->h;
 	// the staging buffers are reused by the next call: make sure the previous call's copies are done
 	HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -460,6 +471,12 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 				for (int g = 0; g < NG; ++g) {
 					const int s0 = (int)((long)nB * g / NG), s1 = (int)((long)nB * (g + 1) / NG);
 					hipStream_t st = NG > 1 ? e->gstream[g] : e->stream;
+					if (wide) {
+						const dim3 grid((unsigned)count, s1 - s0);
+						if (geo) launchSweepWide<true>(grid, st, dt + s0, kp, dir, d, xlo, count, pass);
+						else launchSweepWide<false>(grid, st, dt + s0, kp, dir, d, xlo, count, pass);
+						continue;
+					}
 					const dim3 grid((unsigned)((count + SPPB - 1) / SPPB), s1 - s0);
 					if (geo) launchSweep<true>(SG, VPL, grid, st, dt + s0, kp, dir, d, xlo, count, pass);
 					else launchSweep<false>(SG, VPL, grid, st, dt + s0, kp, dir, d, xlo, count, pass);
@@ -525,6 +542,8 @@ int pmhip_create(int device, pmhip_engine** out) {
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return PMHIP_E_HIP; }
 	const char* ng = getenv("PMHIP_GROUPS");
 	e->nGroups = ng ? std::max(1, std::min(16, atoi(ng))) : PMHIP_DEFAULT_GROUPS;
+	const char* nw = getenv("PMHIP_WIDE");
+	if (nw) e->wideMaxViews = atoi(nw);
 	const char* nl = getenv("PMHIP_LANES");
 	if (nl && atoi(nl) >= 1) e->sweepLanes = atoi(nl);
 	for (int g = 0; g < e->nGroups; ++g)

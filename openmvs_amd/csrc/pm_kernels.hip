@@ -502,7 +502,7 @@ __device__ __forceinline__ void pm_fill_patch(const PMTask& t, bool inb, int x, 
 		float Is[NK];
 #pragma unroll
 		for (int q = 0; q < NK; ++q) {
-			const int k = v + q * G, kk = k < PM_NT ? k : v;
+			const int k = v + q * G, kk = k < PM_NT ? k : v % PM_NT;   // (a lane without a tap re-reads one that exists: no address outside the patch)
 			const int i = (kk / 5) * 2 - PM_HW, j = (kk % 5) * 2 - PM_HW;
 			Is[q] = SKEW ? refS[(size_t)(x + j + y + i) * t.h + (y + i)] : ref[(size_t)(y + i) * t.w + (x + j)];
 		}
@@ -903,6 +903,279 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 	}
 	PM_PROF_FLUSH();
 	if (changed && v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
+}
+
+// -------------------------------------------------------------------------------------------
+// ProcessPixel in "latency mode": ONE WAVE PER PIXEL.  pm_sweep_kernel gives a wave 64 / G pixels and walks each pixel's hypotheses one after the
+// other (<= 2 propagation candidates, then <= nRandomIters refinements or random restarts); with one depth map (BASELINE config 2) or a handful of
+// them a diagonal launch cannot fill 1 024 SIMDs and its duration is one wave's serial chain of ~8 evaluations.  Here the eight 8-lane groups of the
+// wave belong to the same pixel and each scores a DIFFERENT hypothesis in the same round (lane = candidate * 8 + source view):
+//   round 1: group 0 / 1 = the two propagation candidates; groups 2..7 = the first six hypotheses of the stage that follows if both are rejected
+//            (refinements of the current plane, or random restarts when conf >= thConfRand);
+//   later rounds: the next <= 8 refinement / restart iterations from the then-current state.
+// After a round every lane knows all eight scores and replays the reference's sequential accept rule (DepthMap.cpp:772-852) over them in order;
+// candidates that were computed from a state an earlier accept has changed are discarded and recomputed in the next round.  Hypotheses, draws
+// (counter-based: iteration index, not call order), scores and the order of the comparisons are those of the sequential code, so the result is
+// the same bits; only evaluations whose outcome the reference would never look at are extra work.  Expected rounds = 1 + number of accepts.
+// nSrc <= 8 (one source view per lane of a group).
+template <bool GEO>
+__global__ __launch_bounds__(64, 2) void pm_sweep_wide_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
+	constexpr int G = 8;
+	constexpr int TC = 1 + PM_TCX;
+	constexpr int TSTRIDE = PM_TR * TC + PM_TILE_PAD;
+	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
+	PM_PROF_DECL;
+	__shared__ float2 s_w[PM_NT + 1];
+	__shared__ float s_tile[G * TSTRIDE];
+	__shared__ int2 s_org[G];
+	__shared__ double s_src[G * NBD];
+	const PMTask& t = tasks[blockIdx.y];
+	const int lane = threadIdx.x, c = lane >> 3, v = lane & 7;
+	for (int i = lane; i < G * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];
+	const double* hot = s_src + v * NBD;
+	const int w = t.w, h = t.h;
+	const int x = xlo + (int)blockIdx.x, y = d - x;            // grid.x == count: every wave has a pixel
+	const size_t idx = (size_t)y * w + x;
+	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
+	const int sgn = dir == 0 ? -1 : 1;
+	// neighbour slots as in pm_sweep_kernel: slot0 (x+sgn,y), slot1 (x,y+sgn) are the propagation sources, slot2 (x-sgn,y), slot3 (x,y-sgn)
+	size_t qis[4]; bool bok[4]; int qxs[4], qys[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const int ox = (k == 0) ? sgn : (k == 2 ? -sgn : 0), oy = (k == 1) ? sgn : (k == 3 ? -sgn : 0);
+		bool ok;
+		if (ox == -1) ok = x > PM_HW; else if (ox == 1) ok = x < w - PM_HW; else if (oy == -1) ok = y > PM_HW; else ok = y < h - PM_HW;
+		bok[k] = ok; qxs[k] = x + ox; qys[k] = y + oy;
+		qis[k] = ok ? (size_t)(y + oy) * w + (x + ox) : idx;
+	}
+	float nds[4], prior = 0.f;
+	unsigned char maskByte = 1;
+	if (t.prior) prior = pm_glob(t.prior)[idx];
+	if (t.mask != nullptr) maskByte = t.mask[idx];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) nds[k] = gDepth[qis[k]];
+	const size_t qv = (v == 0) ? qis[0] : (v == 1) ? qis[1] : (v == 2) ? qis[2] : (v == 3) ? qis[3] : idx;   // my smoothness slot's neighbour
+	const float on0 = gNormal[qv * 3], on1 = gNormal[qv * 3 + 1], on2 = gNormal[qv * 3 + 2];
+	const float oDepth = gDepth[idx], oNx = gNormal[idx * 3], oNy = gNormal[idx * 3 + 1], oNz = gNormal[idx * 3 + 2], oConf = gConf[idx];
+	// the two propagation sources' estimates (they were updated one diagonal earlier and are not touched again before this launch ends)
+	float pcf[2], pcd[2], pcn[2][3];
+#pragma unroll
+	for (int k = 0; k < 2; ++k) { const size_t q = qis[k]; pcf[k] = gConf[q]; pcd[k] = gDepth[q]; pcn[k][0] = gNormal[q * 3]; pcn[k][1] = gNormal[q * 3 + 1]; pcn[k][2] = gNormal[q * 3 + 2]; }
+	float normSq0, sumW;
+	pm_fill_patch<64, true>(t, true, x, y, lane, s_w, normSq0, sumW);
+	const bool masked = maskByte == 0;
+	const bool valid = !masked && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
+	if (lane == 0) s_w[PM_NT] = make_float2(prior, prior > 0 ? pm_expf(normSq0 * (-1.f / (1.f * 0.02f))) : 0.f);
+	__syncthreads();
+	if (!valid) return;                                           // wave-uniform
+	const double X0x = ((double)x - t.cx) / t.fx, X0y = ((double)y - t.cy) / t.fy;
+	const float vx = (float)X0x, vy = (float)X0y, vz = 1.f;
+	float depth = oDepth, nx = oNx, ny = oNy, nz = oNz, conf = oConf;
+	bool pok[2] = {false, false};
+	unsigned closeMask = 0u;
+	float qX0 = 0.f, qX1 = 0.f, qX2 = 0.f, qn0 = 0.f, qn1 = 0.f, qn2 = 1.f;   // my smoothness slot (slot v, v < 4)
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const bool ok = bok[k] && nds[k] > 0;
+		if (ok) closeMask |= 1u << k;
+		if (k < 2) pok[k] = ok;
+		if (ok && k == v) {
+			const double z = (double)nds[k];
+			qX0 = (float)(((double)qxs[k] - t.cx) * z / t.fx);
+			qX1 = (float)(((double)qys[k] - t.cy) * z / t.fy);
+			qX2 = (float)z;
+			qn0 = on0; qn1 = on1; qn2 = on2;
+		}
+	}
+	// ---- windows: one per source view around the footprint of the current plane ----------------------------------------------------------------
+	{
+		int cs = 0, ctt = 0;
+		if (v < t.nSrc) {
+			float Hc[9];
+			pm_homography(hot, t, X0x, X0y, depth, nx, ny, nz, Hc);
+			const float fxp = (float)x, fyp = (float)y;
+			const float c0 = Hc[0] * fxp + Hc[1] * fyp + Hc[2], c1 = Hc[3] * fxp + Hc[4] * fyp + Hc[5], c2 = Hc[6] * fxp + Hc[7] * fyp + Hc[8];
+			const float cu = c0 / c2, cv = c1 / c2;
+			if (cu > -1e6f && cu < 1e6f && cv > -1e6f && cv < 1e6f) { const int iu = (int)pm_floorf(cu), iv = (int)pm_floorf(cv); cs = iu + iv; ctt = iv; }
+		}
+		if (c == 0) s_org[v] = make_int2(cs - 8 - (PM_TR - 19) / 2, ctt - PM_HW - (PM_TCX - 9) / 2);
+		__syncthreads();
+		constexpr int NE = PM_TR * TC, NLD = (G * NE + 63) / 64;
+		float vals[NLD];
+#pragma unroll
+		for (int k = 0; k < NLD; ++k) {
+			const int e = lane + 64 * k;
+			const int vv = e / NE, i = e - vv * NE;
+			const int r = i / TC, cc = i - r * TC;
+			float val = 0.f;
+			if (vv < t.nSrc) {
+				const int2 org = s_org[vv];
+				const int sh = t.src[vv].h, sMax = t.src[vv].w + t.src[vv].h - 1;
+				const int ss = org.x + r, tt = org.y + cc;
+				if (ss >= 0 && ss < sMax && tt >= 0 && tt < sh) val = pm_glob(t.src[vv].imgS)[(size_t)ss * sh + tt];
+			}
+			vals[k] = val;
+		}
+#pragma unroll
+		for (int k = 0; k < NLD; ++k) { const int e = lane + 64 * k; if (e < G * NE) { const int vv = e / NE; s_tile[vv * TSTRIDE + (e - vv * NE)] = vals[k]; } }
+		__syncthreads();
+	}
+	const int2 myOrg = s_org[v];
+	const float* tile = s_tile + v * TSTRIDE;
+	const uint32_t k1 = t.k1base + pass;
+	// ---- rounds -----------------------------------------------------------------------------------------------------------------------------------
+	enum { W_PROPS = 0, W_REFINE = 1, W_RAND = 2, W_DONE = 3 };
+	int stage = W_PROPS;
+	unsigned it0 = 0, idxScale = 0;
+	float scaleRange = 1.f, depthRange = 0.f, p0 = 0.f, p1 = 0.f;
+	bool smooth = true, changed = false;
+	PM_TICK(0); PM_COUNT(9, 1);
+	while (stage != W_DONE) {
+		// what the stage after the propagation candidates would be if they change nothing: RefineIters: (DepthMap.cpp:802-827) on the current state
+		int specStage = W_REFINE; unsigned specIdx = idxScale; bool specSmooth = smooth;
+		float specScale = scaleRange, specRange = depthRange, specP0 = p0, specP1 = p1;
+		if (stage == W_PROPS) {
+			if (conf <= kp.thConfSmall) specIdx = 2;
+			else if (conf <= kp.thConfBig) specIdx = 1;
+			else if (conf >= kp.thConfRand) { specSmooth = false; specStage = W_RAND; }
+			if (specStage == W_REFINE) {
+				specScale = pm_pow2neg(specIdx);
+				specRange = depth * kp.depthRatio;
+				specP0 = pm_atan2f(ny, nx); specP1 = pm_acosf(pm_clampf(nz, -1.f, 1.f)); // Normal2Dir
+			}
+		}
+		// ---- my group's hypothesis ----
+		bool need = false, useSmooth = smooth;
+		float hd = 0.f, hnx = 0.f, hny = 0.f, hnz = 1.f, hp0 = 0.f, hp1 = 0.f;
+		const int first = (stage == W_PROPS) ? 2 : 0;          // first group that holds an iteration candidate
+		const int kind = (stage == W_PROPS) ? specStage : stage;
+		if (stage == W_PROPS && c < 2) {
+			const bool vert = (c == 1);
+			const float cd = vert ? pcd[1] : pcd[0], cnx = vert ? pcn[1][0] : pcn[0][0], cny = vert ? pcn[1][1] : pcn[0][1], cnz = vert ? pcn[1][2] : pcn[0][2];
+			const bool take = (vert ? pok[1] : pok[0]) && (vert ? pcf[1] : pcf[0]) < kp.thKeep;
+			// InterpolatePixel, DepthMap.cpp:915-959
+			float depthNew = cd; bool zero;
+			if (vert) {
+				const float nx1 = (float)(((double)y - t.cy) / t.fy);
+				const float denom = cnz + nx1 * cny;
+				zero = pm_fabsf(denom) < 0.0001f;
+				const float x1 = (float)(((double)(y + sgn) - t.cy) / t.fy);
+				const float nom = cd * (cnz + x1 * cny);
+				if (!zero) depthNew = nom / denom;
+			} else {
+				const float nx1 = (float)(((double)x - t.cx) / t.fx);
+				const float denom = cnz + nx1 * cnx;
+				zero = pm_fabsf(denom) < 0.0001f;
+				const float x1 = (float)(((double)(x + sgn) - t.cx) / t.fx);
+				const float nom = cd * (cnz + x1 * cnx);
+				if (!zero) depthNew = nom / denom;
+			}
+			hd = (!zero && pm_in_range(depthNew, t.dMin, t.dMax)) ? depthNew : cd;
+			hnx = cnx; hny = cny; hnz = cnz;
+			pm_correct_normal(vx, vy, vz, hnx, hny, hnz);
+			need = take;
+		} else {
+			const unsigned itc = it0 + (unsigned)(c - first);
+			if (c >= first && itc < kp.nRandomIters) {
+				if (kind == W_RAND) {
+					const PmPhilox4 r = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_RAND * 256) + itc, 0u, t.k0, k1);
+					const float rr = t.dMinSqr + (t.dMaxSqr - t.dMinSqr) * pm_u32_to_unit(r.v[0]);
+					hd = rr * rr;
+					pm_random_normal(pm_u32_to_unit(r.v[1]), pm_u32_to_unit(r.v[2]), vx, vy, vz, hnx, hny, hnz);
+					need = true; useSmooth = false;
+				} else {
+					const float sR = (stage == W_PROPS) ? specScale : scaleRange, dR = (stage == W_PROPS) ? specRange : depthRange;
+					const float b0 = (stage == W_PROPS) ? specP0 : p0, b1 = (stage == W_PROPS) ? specP1 : p1;
+					const PmPhilox4 r = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_REFINE * 256) + itc, 0u, t.k0, k1);
+					const float ndepth = depth + (dR * sR) * (2.f * pm_u32_to_unit(r.v[0]) - 1.f);
+					hp0 = b0 + (kp.angle1Range * sR) * (2.f * pm_u32_to_unit(r.v[1]) - 1.f);
+					hp1 = b1 + (kp.angle2Range * sR) * (2.f * pm_u32_to_unit(r.v[2]) - 1.f);
+					pm_dir2normal(hp0, hp1, hnx, hny, hnz);
+					hd = ndepth;
+					need = pm_in_range(ndepth, t.dMin, t.dMax) && !(hnx * vx + hny * vy + hnz * vz >= 0);
+					useSmooth = (stage == W_PROPS) ? specSmooth : smooth;
+				}
+			}
+		}
+		PM_TICK(1); PM_COUNT(8, __popcll(__ballot(need)));
+		// ---- smoothness factors of my group's plane (slot v for v < 4), DepthMap.cpp:524-533 ----
+		float sf[4];
+		{
+			float myF = 1.f;
+			if (need && useSmooth && v < 4 && ((closeMask >> v) & 1u)) {
+				const float planeD = -hd * (hnx * vx + hny * vy + hnz * vz);
+				const float dist = (hnx * qX0 + (hny * qX1 + hnz * qX2)) + planeD;
+				const float r = dist / hd;
+				const float factorDepth = pm_expf((r * r) * kp.smoothSigmaDepth);
+				const float ca = pm_clampf((hnx * qn0 + hny * qn1 + hnz * qn2) / pm_sqrtf((hnx * hnx + hny * hny + hnz * hnz) * (qn0 * qn0 + qn1 * qn1 + qn2 * qn2)), -1.f, 1.f);
+				const float ac = pm_acosf(ca);
+				const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
+				myF = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
+			}
+#pragma unroll
+			for (int k = 0; k < 4; ++k) sf[k] = __shfl(myF, k, G);
+		}
+		PM_TICK(2);
+		float sc = PM_INF;
+		if (need && v < t.nSrc)
+			sc = pm_score_view<GEO, true, TC, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w, hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], 0.f,
+				tile, myOrg.x, myOrg.y, hot, hot + PM_SRC_HOT, nullptr PM_PROF_PASS);
+		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
+		// ---- every lane replays the sequential accept rule over the eight groups' results, in the reference's order ----
+		bool restart = false;                                     // the state changed in a way that invalidates the remaining candidates
+		if (stage == W_PROPS) {
+#pragma unroll
+			for (int k = 0; k < 2; ++k) {
+				const int src = k * G;
+				if (__shfl(need ? 1 : 0, src, 64) && conf > __shfl(nconf, src, 64)) {
+					conf = __shfl(nconf, src, 64); depth = __shfl(hd, src, 64); nx = __shfl(hnx, src, 64); ny = __shfl(hny, src, 64); nz = __shfl(hnz, src, 64);
+					changed = true; restart = true;
+				}
+			}
+			// RefineIters: on the state the propagation left
+			if (conf <= kp.thConfSmall) idxScale = 2;
+			else if (conf <= kp.thConfBig) idxScale = 1;
+			else if (conf >= kp.thConfRand) { smooth = false; stage = W_RAND; }
+			if (stage != W_RAND) {
+				scaleRange = pm_pow2neg(idxScale);
+				depthRange = depth * kp.depthRatio;
+				p0 = pm_atan2f(ny, nx); p1 = pm_acosf(pm_clampf(nz, -1.f, 1.f));
+				stage = W_REFINE;
+			}
+			it0 = 0;
+		}
+		if (!restart) {
+			// groups first .. 7 hold iterations it0, it0 + 1, ... of `stage` computed from exactly the present state
+			for (int j = first; j < 8; ++j) {
+				const unsigned itj = it0 + (unsigned)(j - first);
+				if (itj >= kp.nRandomIters) break;
+				const int src = j * G;
+				const bool nd = __shfl(need ? 1 : 0, src, 64) != 0;
+				const float ncj = __shfl(nconf, src, 64);
+				if (nd && conf > ncj) {
+					conf = ncj; depth = __shfl(hd, src, 64); nx = __shfl(hnx, src, 64); ny = __shfl(hny, src, 64); nz = __shfl(hnz, src, 64);
+					changed = true;
+					if (stage == W_REFINE) {
+						p0 = __shfl(hp0, src, 64); p1 = __shfl(hp1, src, 64); scaleRange = pm_pow2neg(++idxScale);
+						it0 = itj + 1; restart = true; break;     // the later refinements perturb the new plane: next round
+					} else if (conf < kp.thConfRand) {
+						// goto RefineIters (DepthMap.cpp:790-793): the remaining restarts are dropped
+						if (conf <= kp.thConfSmall) idxScale = 2;
+						else if (conf <= kp.thConfBig) idxScale = 1;
+						scaleRange = pm_pow2neg(idxScale);
+						depthRange = depth * kp.depthRatio;
+						p0 = pm_atan2f(ny, nx); p1 = pm_acosf(pm_clampf(nz, -1.f, 1.f));
+						stage = W_REFINE; it0 = 0; restart = true; break;
+					}
+				}
+			}
+			if (!restart) it0 += (unsigned)(8 - first);
+		}
+		if (it0 >= kp.nRandomIters) stage = W_DONE;                // DepthMap.cpp:833 / :781: the iteration budget of the stage is used up
+		PM_TICK(6);
+	}
+	PM_PROF_FLUSH();
+	if (changed && lane == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
 }
 
 // EndDepthMapTmp, SceneDensify.cpp:528-576

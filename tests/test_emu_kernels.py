@@ -73,6 +73,11 @@ def test_estimator_views_per_lane(pm_emulated, nine_scene, small_scene, lanes):
     g.test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes)    # (4,2), (2,4), (2,2), (4,4): several source views per lane
 
 
+def test_estimator_wide_latency_mode(pm_emulated, nine_scene, small_scene):
+    from tests import test_gpu_patchmatch as g
+    g.test_wide_latency_mode_parity(nine_scene, small_scene)                 # one wave per pixel, eight hypotheses per round
+
+
 def test_estimator_mixed_resolution_neighbours(engine):
     from tests import test_gpu_patchmatch as g
     g.test_mixed_resolution_neighbours_parity(engine)                        # sources at 0.8x / 1.25x, cameraDepthMap of another size

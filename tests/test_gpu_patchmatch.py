@@ -119,6 +119,44 @@ def test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes):
             os.environ["PMHIP_LANES"] = saved
 
 
+def test_wide_latency_mode_parity(nine_scene, small_scene):
+    """The one-wave-per-pixel sweep kernel (PMHIP_WIDE: eight hypotheses of a pixel scored side by side, sequential accept rule replayed over them) gives
+    the bits of the sequential walk: 8 / 4 / 1-3 sources, pyramid, geometric round, ignore masks, option sets that change the iteration budget
+    (nRandomIters 8 and 2: more and fewer than one round holds), low-confidence pixels that take the random-restart stage."""
+    import os
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    saved = os.environ.get("PMHIP_WIDE")
+    os.environ["PMHIP_WIDE"] = "16"
+    try:
+        e = PatchMatchHIP(0)
+        test_single_view_parity_N8_and_N1(e, nine_scene)
+        test_single_view_photometric_parity_N4(e, small_scene, 2)
+        test_initial_estimate_is_honoured(e, small_scene)
+        test_single_call_with_ignore_mask(e, small_scene)
+        for k in (0, 3, 5):
+            test_non_default_options_parity(e, small_scene, k)
+        sc = nine_scene
+        p = default_params(seed=5, nEstimationGeometricIters=1)
+        e.Init(False); e.scene_load(sc, n_levels=2)
+        allv = list(range(sc.n_views))
+        e.scene_estimate(allv, -1, p)                                     # nine views in one batch, all in latency mode
+        photo = [e.scene_get_maps(v) for v in allv]
+        e.scene_commit_round(); e.Init(True)
+        e.scene_estimate([4, 0], 0, p)
+        for v in (4, 0):
+            od, on, oc = _oracle(sc, v, 5, nEstimationGeometricIters=1)
+            _same(photo[v][0], od, f"wide: photometric depth v{v}"); _same(photo[v][2], oc, f"wide: photometric conf v{v}")
+            gd, gn, gc = _oracle(sc, v, 5, geo_iter=0, depth=od, normal=on, src={u: photo[u][0] for u in allv}, nEstimationGeometricIters=1)
+            d, n, c = e.scene_get_maps(v)
+            _same(d, gd, f"wide: geometric depth v{v}"); _same(n, gn, "normal"); _same(c, gc, "conf")
+        e.close()
+    finally:
+        if saved is None:
+            os.environ.pop("PMHIP_WIDE", None)
+        else:
+            os.environ["PMHIP_WIDE"] = saved
+
+
 def test_non_divisible_image_size_parity(engine):
     # 163x121 with 2 sub-levels: level sizes cvRound -> 82x60, 41x30; INTER_AREA border rule on both axes
     sc = synth.make_scene(4, 163, 121, n_src=3)

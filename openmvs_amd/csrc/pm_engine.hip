@@ -19,7 +19,7 @@
 #include <vector>
 
 #ifndef PMHIP_DEFAULT_WIDE
-#define PMHIP_DEFAULT_WIDE 0    // set after measuring
+#define PMHIP_DEFAULT_WIDE 8    // measured (profiles/r02_small_batch_probe_wide_kernel.log): 1.54x at 1 view, 1.40x at 4, 1.11x at 8, 0.76x at 13
 #endif
 #ifndef PMHIP_DEFAULT_LANES
 #define PMHIP_DEFAULT_LANES 16   // sweep kernel: lanes per pixel (16 = one source view per lane whatever their number)

@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The engine picks the one-wave-per-pixel sweep kernel for batches of <= 8 reference views (PMHIP_WIDE); nearly every test case is that small, so
+# under the product default the regular sweep kernel -- the one that carries the benchmark -- would hardly be exercised.  The suite therefore pins the
+# regular kernel and tests the latency-mode kernel by name (test_wide_latency_mode_parity, the one-call part of test_config2_full_size_matches_golden).
+os.environ.setdefault("PMHIP_WIDE", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

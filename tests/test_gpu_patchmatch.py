@@ -709,17 +709,29 @@ def test_config2_full_size_matches_golden():
         rounds.append([e.scene_get_maps(v) for v in allv])
         for v in allv:
             gc.check_maps(rounds[r][v], g["rounds"][r][str(v)], "scene interface, round %d, view %d" % (r, v))
-    # the per-view boundary (layer 1): host buffers in and out, one blocking call per pass
+    e.close()
+    # the per-view boundary (layer 1): host buffers in and out, one blocking call per pass -- with the regular sweep kernel and with the
+    # one-wave-per-pixel kernel the engine uses by default for a single depth map (PMHIP_WIDE)
+    import os
     ref = c["ref"]
     ids = [ref] + list(sc.neighbors[ref])
-    e.Init(True)
-    cur = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], params=p)
-    gc.check_maps(cur, g["rounds"][0][str(ref)], "one-call boundary, photometric")
-    for r in range(1, 1 + c["geo_iters"]):
-        cur = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], depth=cur[0], normal=cur[1],
-                                 src_depths={v: rounds[r - 1][v][0] for v in ids[1:]}, nGeometricIter=r - 1, params=p)
-        gc.check_maps(cur, g["rounds"][r][str(ref)], "one-call boundary, geometric round %d" % (r - 1))
-    e.close()
+    saved = os.environ.get("PMHIP_WIDE")
+    try:
+        for wide in ("0", "8"):
+            os.environ["PMHIP_WIDE"] = wide
+            e = PatchMatchHIP(0); e.Init(True)
+            cur = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], params=p)
+            gc.check_maps(cur, g["rounds"][0][str(ref)], "one-call boundary (PMHIP_WIDE=%s), photometric" % wide)
+            for r in range(1, 1 + c["geo_iters"]):
+                cur = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], depth=cur[0], normal=cur[1],
+                                         src_depths={v: rounds[r - 1][v][0] for v in ids[1:]}, nGeometricIter=r - 1, params=p)
+                gc.check_maps(cur, g["rounds"][r][str(ref)], "one-call boundary (PMHIP_WIDE=%s), geometric round %d" % (wide, r - 1))
+            e.close()
+    finally:
+        if saved is None:
+            os.environ.pop("PMHIP_WIDE", None)
+        else:
+            os.environ["PMHIP_WIDE"] = saved
 
 
 def test_config5_resolution_estimate_filter_fuse():

@@ -56,7 +56,10 @@ one)
   timeout 900 python -m pytest tests -m gpu -q -s -k "${ONE_K:-config5}" > "$OUT/selected_tests.log" 2>&1; tail -12 "$OUT/selected_tests.log" ;;
 sgm)
   step "sgm probe"
-  timeout 600 python tools/probe_sgm.py > "$OUT/sgm_probe.log" 2>&1; cat "$OUT/sgm_probe.log" ;;
+  timeout 600 python tools/probe_sgm.py > "$OUT/sgm_probe.log" 2>&1; cat "$OUT/sgm_probe.log"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_sgm -o sgm -- python "$R/tools/probe_sgm.py" > "$R/$OUT/sgm_probe_under_rocprof.log" 2> "$R/$OUT/sgm_rocprof.err" ); echo "rc $?"
+  find /tmp/prof_sgm -name "*kernel_stats.csv" -exec cp {} "$OUT/sgm_kernel_stats.csv" \; ; rm -rf /tmp/prof_sgm
+  head -12 "$OUT/sgm_kernel_stats.csv" ;;
 *) echo "unknown step $what" ;;
 esac; done
 step done

@@ -213,7 +213,16 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 	if (e->statsOn) e->stats.aggrLaunches += 1;
 	evE(e);
 	evB(e, 2);
-	hipLaunchKernelGGL(sgm_wta_kernel, dim3((unsigned)((nPix + 3) / 4)), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, e->d_cost);
+	{
+		// winner-take-all: a wavefront per pixel spends most of its instructions on the 6-step reduction of 64 lanes; four (or eight) pixels per
+		// wavefront with a strided loop over the range need about a third of the wave-instructions per pixel (same first minimum; SGMHIP_WTA_LANES =
+		// 64 selects the one-pixel kernel again)
+		static const int wtaLanes = [] { const char* v = getenv("SGMHIP_WTA_LANES"); const int n = v ? atoi(v) : 16; return (n == 8 || n == 16 || n == 32) ? n : (n == 64 ? 64 : 16); }();
+		if (wtaLanes == 8) hipLaunchKernelGGL((sgm_wta_sub_kernel<8>), dim3((unsigned)((nPix + 31) / 32)), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, e->d_cost);
+		else if (wtaLanes == 16) hipLaunchKernelGGL((sgm_wta_sub_kernel<16>), dim3((unsigned)((nPix + 15) / 16)), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, e->d_cost);
+		else if (wtaLanes == 32) hipLaunchKernelGGL((sgm_wta_sub_kernel<32>), dim3((unsigned)((nPix + 7) / 8)), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, e->d_cost);
+		else hipLaunchKernelGGL(sgm_wta_kernel, dim3((unsigned)((nPix + 3) / 4)), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, e->d_cost);
+	}
 	evE(e);
 	SGMCHK(e, hipGetLastError());
 	if (e->statsOn) e->stats.calls += 1;

@@ -75,7 +75,7 @@ def test_estimator_views_per_lane(pm_emulated, nine_scene, small_scene, lanes):
 
 def test_estimator_wide_latency_mode(pm_emulated, nine_scene, small_scene):
     from tests import test_gpu_patchmatch as g
-    g.test_wide_latency_mode_parity(nine_scene, small_scene)                 # one wave per pixel, eight hypotheses per round
+    g.test_wide_latency_mode_parity(nine_scene, small_scene, quick=True)     # one wave per pixel, eight hypotheses per round (the whole case passes too: 260 s)
 
 
 def test_estimator_mixed_resolution_neighbours(engine):

@@ -119,7 +119,7 @@ def test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes):
             os.environ["PMHIP_LANES"] = saved
 
 
-def test_wide_latency_mode_parity(nine_scene, small_scene):
+def test_wide_latency_mode_parity(nine_scene, small_scene, quick=False):
     """The one-wave-per-pixel sweep kernel (PMHIP_WIDE: eight hypotheses of a pixel scored side by side, sequential accept rule replayed over them) gives
     the bits of the sequential walk: 8 / 4 / 1-3 sources, pyramid, geometric round, ignore masks, option sets that change the iteration budget
     (nRandomIters 8 and 2: more and fewer than one round holds), low-confidence pixels that take the random-restart stage."""
@@ -129,12 +129,20 @@ def test_wide_latency_mode_parity(nine_scene, small_scene):
     os.environ["PMHIP_WIDE"] = "16"
     try:
         e = PatchMatchHIP(0)
+        for k in ((0, 5) if quick else (0, 3, 5)):
+            test_non_default_options_parity(e, small_scene, k)
+        if quick:                                                          # the CPU emulator run: 8 sources with the pyramid, and the option sets above
+            sc = nine_scene
+            ids = [4] + list(sc.neighbors[4])
+            e.Init(False)
+            d, n, c = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[4], sc.dmax[4], params=default_params(seed=5))
+            od, on, oc = _oracle(sc, 4, 5)
+            _same(d, od, "wide: depth N=8"); _same(n, on, "wide: normal"); _same(c, oc, "wide: conf")
+            e.close(); return
         test_single_view_parity_N8_and_N1(e, nine_scene)
+        test_single_call_with_ignore_mask(e, small_scene)
         test_single_view_photometric_parity_N4(e, small_scene, 2)
         test_initial_estimate_is_honoured(e, small_scene)
-        test_single_call_with_ignore_mask(e, small_scene)
-        for k in (0, 3, 5):
-            test_non_default_options_parity(e, small_scene, k)
         sc = nine_scene
         p = default_params(seed=5, nEstimationGeometricIters=1)
         e.Init(False); e.scene_load(sc, n_levels=2)

@@ -214,10 +214,10 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 	evE(e);
 	evB(e, 2);
 	{
-		// winner-take-all: a wavefront per pixel spends most of its instructions on the 6-step reduction of 64 lanes; four (or eight) pixels per
-		// wavefront with a strided loop over the range need about a third of the wave-instructions per pixel (same first minimum; SGMHIP_WTA_LANES =
+		// winner-take-all: a wavefront per pixel spends most of its instructions on the 6-step reduction of 64 lanes; eight pixels per
+		// wavefront with a strided loop over the range need a fraction of the wave-instructions per pixel (same first minimum; SGMHIP_WTA_LANES =
 		// 64 selects the one-pixel kernel again)
-		static const int wtaLanes = [] { const char* v = getenv("SGMHIP_WTA_LANES"); const int n = v ? atoi(v) : 16; return (n == 8 || n == 16 || n == 32) ? n : (n == 64 ? 64 : 16); }();
+		static const int wtaLanes = [] { const char* v = getenv("SGMHIP_WTA_LANES"); const int n = v ? atoi(v) : 8; return (n == 8 || n == 16 || n == 32 || n == 64) ? n : 8; }();   // measured: 0.72 / 0.33 / 0.20 / 0.14 ms at 64 / 32 / 16 / 8 lanes (profiles/r02_sgm_wta_lanes.log)
 		if (wtaLanes == 8) hipLaunchKernelGGL((sgm_wta_sub_kernel<8>), dim3((unsigned)((nPix + 31) / 32)), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, e->d_cost);
 		else if (wtaLanes == 16) hipLaunchKernelGGL((sgm_wta_sub_kernel<16>), dim3((unsigned)((nPix + 15) / 16)), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, e->d_cost);
 		else if (wtaLanes == 32) hipLaunchKernelGGL((sgm_wta_sub_kernel<32>), dim3((unsigned)((nPix + 7) / 8)), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, e->d_cost);

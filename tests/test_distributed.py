@@ -60,7 +60,7 @@ class OracleEstimator:
 
 
 def _scene():
-    return synth.make_scene(4, 48, 32, n_src=3)
+    return synth.make_scene(5, 48, 32, n_src=3)     # 5 views on 2 ranks: blocks of 3 and 2, the padded all-gather path of unequal shards (100 views / 8 GPUs)
 
 
 def _worker(rank, world, port, out_dir):

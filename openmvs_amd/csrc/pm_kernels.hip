@@ -176,20 +176,25 @@ __device__ __forceinline__ void pm_correct_normal(float vx, float vy, float vz, 
 	}
 }
 
-// two smallest of the group's values (as a multiset) by xor-butterfly; exact (comparisons only)
+// Cross-lane moves inside a pixel's group on the VALU's DPP network (quad permutes, mirrors inside 8 and 16 lanes) instead of ds_bpermute
+// through the LDS crossbar (__shfl*): full-rate instructions, no LDS round trip in the per-evaluation chain.
+#define PM_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), (ctrl), 0xf, 0xf, false))
+// two smallest of the group's values (as a multiset); exact (comparisons only), so any pairing of the lanes gives the same pair.
+// Pairings: lane ^ 1, lane ^ 2 (quad permutes), i <-> 7 - i, i <-> 15 - i (mirrors) -- after step k every lane holds the result of its 2^k lanes.
 template <int G>
 __device__ __forceinline__ void pm_group_min2(float s, float s2, float& m1, float& m2) {
 	float a = s, b = s2;   // this lane's two smallest scores (s <= s2; s2 = +inf when the lane scores a single view)
-#pragma unroll
-	for (int m = 1; m < G; m <<= 1) {
-		const float oa = __shfl_xor(a, m, G);
-		const float ob = __shfl_xor(b, m, G);
-		const float na = pm_minf(a, oa);
-		const float nb = pm_minf(pm_maxf(a, oa), pm_minf(b, ob));
-		a = na; b = nb;
-	}
+#define PM_MIN2_STEP(ctrl) { const float oa = PM_DPP_F(a, ctrl), ob = PM_DPP_F(b, ctrl); \
+		const float na = pm_minf(a, oa), nb = pm_minf(pm_maxf(a, oa), pm_minf(b, ob)); a = na; b = nb; }
+	if (G >= 2) PM_MIN2_STEP(0xB1)    // quad_perm [1,0,3,2]
+	if (G >= 4) PM_MIN2_STEP(0x4E)    // quad_perm [2,3,0,1]
+	if (G >= 8) PM_MIN2_STEP(0x141)   // row_half_mirror
+	if (G >= 16) PM_MIN2_STEP(0x140)  // row_mirror
+#undef PM_MIN2_STEP
 	m1 = a; m2 = b;
 }
+// value of lane k (k = 0..3) of the caller's quad
+template <int K> __device__ __forceinline__ float pm_quad_bcast(float v) { return PM_DPP_F(v, K * 0x55); }
 
 // ScorePixelImage for this lane's source view, DepthMap.cpp:465-564.
 // sf[]: the (view-independent) smoothness factors of the up-to-4 close neighbours, in insertion
@@ -658,7 +663,7 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 		for (int k = 0; k < 4; ++k) nds[k] = gDepth[qis[k]];
 #pragma unroll
 		for (int q = 0; q < SL; ++q) {
-			const int k = q * G + v;
+			const int k = (G >= 4) ? (v & 3) : q * G + v;   // G >= 4: every quad of the group holds all four slots (lane v owns slot v % 4)
 			const size_t qi = (k == 0) ? qis[0] : (k == 1) ? qis[1] : (k == 2) ? qis[2] : (k == 3) ? qis[3] : idx;
 			on0[q] = gNormal[qi * 3]; on1[q] = gNormal[qi * 3 + 1]; on2[q] = gNormal[qi * 3 + 2];
 		}
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 			if (ok) closeMask |= 1u << k;
 			if (k == 0 && ok) pok0 = true;
 			if (k == 1 && ok) pok1 = true;
-			if (ok && (k % G) == v) {
+			if (ok && ((G >= 4) ? (v & 3) == k : (k % G) == v)) {
 				const int q = (k / G < SL) ? k / G : 0;
 				// TransformPointI2C(Point3(nx, ndepth)) in double then Cast<float>, Camera.h:338-344
 				const double z = (double)nds[k];
@@ -859,7 +864,7 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 			float myF[SL];
 #pragma unroll
 			for (int q = 0; q < SL; ++q) {
-				const int k = q * G + v;
+				const int k = (G >= 4) ? (v & 3) : q * G + v;
 				const bool on = useS && k < 4 && ((closeMask >> k) & 1u);
 				myF[q] = 1.f;
 				if (PM_ILP_SMOOTH || on) {
@@ -876,9 +881,12 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 			}
 			if (VPL == 1 && PM_ILP_HOMOGRAPHY) pm_homography(hotBase + v * NBD, t, X0x, X0y, hd, hnx, hny, hnz, Hpre);
 			if (PM_ILP_PHILOX) { rNext = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_REFINE * 256) + it, 0u, t.k0, k1); rNextIt = it; }
+			if (G >= 4) { sf[0] = pm_quad_bcast<0>(myF[0]); sf[1] = pm_quad_bcast<1>(myF[0]); sf[2] = pm_quad_bcast<2>(myF[0]); sf[3] = pm_quad_bcast<3>(myF[0]); }
+			else {
 #pragma unroll
-			for (int k = 0; k < 4; ++k)
-				sf[k] = __shfl(myF[k / G < SL ? k / G : 0], (k % G), G);
+				for (int k = 0; k < 4; ++k)
+					sf[k] = __shfl(myF[k / G < SL ? k / G : 0], (k % G), G);
+			}
 		}
 		PM_TICK(2);
 		float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
@@ -954,7 +962,8 @@ __global__ __launch_bounds__(64, 2) void pm_sweep_wide_kernel(const PMTask* __re
 	if (t.mask != nullptr) maskByte = t.mask[idx];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) nds[k] = gDepth[qis[k]];
-	const size_t qv = (v == 0) ? qis[0] : (v == 1) ? qis[1] : (v == 2) ? qis[2] : (v == 3) ? qis[3] : idx;   // my smoothness slot's neighbour
+	const int slot = v & 3;                                        // my smoothness slot (both quads of a group hold all four)
+	const size_t qv = (slot == 0) ? qis[0] : (slot == 1) ? qis[1] : (slot == 2) ? qis[2] : qis[3];
 	const float on0 = gNormal[qv * 3], on1 = gNormal[qv * 3 + 1], on2 = gNormal[qv * 3 + 2];
 	const float oDepth = gDepth[idx], oNx = gNormal[idx * 3], oNy = gNormal[idx * 3 + 1], oNz = gNormal[idx * 3 + 2], oConf = gConf[idx];
 	// the two propagation sources' estimates (they were updated one diagonal earlier and are not touched again before this launch ends)
@@ -979,7 +988,7 @@ __global__ __launch_bounds__(64, 2) void pm_sweep_wide_kernel(const PMTask* __re
 		const bool ok = bok[k] && nds[k] > 0;
 		if (ok) closeMask |= 1u << k;
 		if (k < 2) pok[k] = ok;
-		if (ok && k == v) {
+		if (ok && k == slot) {
 			const double z = (double)nds[k];
 			qX0 = (float)(((double)qxs[k] - t.cx) * z / t.fx);
 			qX1 = (float)(((double)qys[k] - t.cy) * z / t.fy);
@@ -1102,7 +1111,7 @@ __global__ __launch_bounds__(64, 2) void pm_sweep_wide_kernel(const PMTask* __re
 		float sf[4];
 		{
 			float myF = 1.f;
-			if (need && useSmooth && v < 4 && ((closeMask >> v) & 1u)) {
+			if (need && useSmooth && ((closeMask >> slot) & 1u)) {
 				const float planeD = -hd * (hnx * vx + hny * vy + hnz * vz);
 				const float dist = (hnx * qX0 + (hny * qX1 + hnz * qX2)) + planeD;
 				const float r = dist / hd;
@@ -1112,8 +1121,7 @@ __global__ __launch_bounds__(64, 2) void pm_sweep_wide_kernel(const PMTask* __re
 				const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
 				myF = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
 			}
-#pragma unroll
-			for (int k = 0; k < 4; ++k) sf[k] = __shfl(myF, k, G);
+			sf[0] = pm_quad_bcast<0>(myF); sf[1] = pm_quad_bcast<1>(myF); sf[2] = pm_quad_bcast<2>(myF); sf[3] = pm_quad_bcast<3>(myF);
 		}
 		PM_TICK(2);
 		float sc = PM_INF;

@@ -142,10 +142,12 @@ def main():
             # depthNNNN.dmap and re-reads the neighbours' files, SceneDensify.cpp:378-393,1943-1950)
             torch.cuda.synchronize()
             eng.scene_copy(4, 0, V, allv.data_ptr(), True)
+            eng.sync()                                   # the gathered tensor may be released by the caller
 
         def set_maps(self, what, allv):
             torch.cuda.synchronize()
             eng.scene_copy({"depth": 1, "conf": 3}[what], 0, V, allv.data_ptr(), True)
+            eng.sync()
 
         def filter(self, ids):
             if len(ids):

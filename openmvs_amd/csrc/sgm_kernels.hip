@@ -162,7 +162,7 @@ __device__ __forceinline__ int sgm_wave_min(int v) {
 // in the low half adds its right neighbour's value in the same atomic; an entry in a high half whose low-half partner is not in
 // this wave-instruction (lane 0) adds alone.  One predicated atomic per lane, no divergent control flow.  Called by all 64 lanes.
 __device__ __forceinline__ void sgm_accumulate(unsigned* wordsBase, unsigned par, int k, int nD, int L, int lane) {
-	const int Lnext = __shfl_down(L, 1, 64);                       // value of entry k+1 (lane+1); not used by lane 63
+	const int Lnext = __builtin_amdgcn_update_dpp(L, L, 0x130, 0xf, 0xf, false);   // wave_shl:1 = value of entry k+1 (lane+1) on the VALU's DPP network, no LDS crossbar trip; not used by lane 63
 	const unsigned e = ((unsigned)k + par) & 1u;                   // 0: this entry is the low half of its word
 	const bool act = k < nD;
 	const bool pair = lane < 63 && k + 1 < nD;

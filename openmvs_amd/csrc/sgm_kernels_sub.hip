@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void sgm_cost_sub_kernel(const unsigned cha
 // entry belongs to the previous chunk of the same pixel (another instruction) or does not exist.
 template <int LP>
 __device__ __forceinline__ void sgm_accumulate_sub(unsigned* wordsBase, unsigned par, int k, int kk, int nD, int L) {
-	const int Lnext = __shfl_down(L, 1, 64);                       // entry k+1 sits in lane+1 of the same sub-group whenever it is used (pair)
+	const int Lnext = __builtin_amdgcn_update_dpp(L, L, 0x130, 0xf, 0xf, false);   // wave_shl:1 (DPP): entry k+1 sits in lane+1 of the same sub-group whenever it is used (pair)
 	const unsigned e = ((unsigned)k + par) & 1u;                   // 0: this entry is the low half of its word
 	const bool act = k < nD;
 	const bool pair = kk + 1 < LP && k + 1 < nD;                   // the last lane of a sub-group has its partner in the next chunk: it adds alone

@@ -122,36 +122,16 @@ __global__ __launch_bounds__(256, 4) void sgm_cost_kernel(const unsigned char* _
 		const int cA = inA ? ux + dA : SGM_HW, cB = inB ? ux + 1 + dB : SGM_HW;           // a safe column for lanes that will not use the result
 		sgm_v2f sum = {0.f, 0.f}, sumSq = {0.f, 0.f}, nom = {0.f, 0.f};
 		int n = 0;
-		if (inA && inB && dA == dB) {
-			// The usual case (equal range starts): pixel B's window in the right image is pixel A's shifted by one column, so a row of the pair is eight
-			// texels, not fourteen.  The kernel is bound by the vector-memory path (98 dword loads per pair and disparity against ~300 packed VALU
-			// instructions), so the 56 loads of this branch are what sets its speed.  Same values, same order of the sums.
-			for (int i = -SGM_HW; i <= SGM_HW; ++i) {
-				const float* r = grayR + (size_t)(uy + i) * w + cA;
-				float v[2 * SGM_HW + 2];
+		for (int i = -SGM_HW; i <= SGM_HW; ++i) {
+			const float* rowA = grayR + (size_t)(uy + i) * w + cA;
+			const float* rowB = grayR + (size_t)(uy + i) * w + cB;
 #pragma unroll
-				for (int j = 0; j < 2 * SGM_HW + 2; ++j) v[j] = r[j - SGM_HW];
-#pragma unroll
-				for (int j = 0; j <= 2 * SGM_HW; ++j) {
-					const sgm_v2f f = {v[j], v[j + 1]};
-					const float4 pw = s_w[wave][n++];
-					const sgm_v2f pww = {pw.x, pw.y}, pwt = {pw.z, pw.w};
-					const sgm_v2f fw = f * pww;
-					sum += fw; sumSq += f * fw; nom += f * pwt;
-				}
-			}
-		} else {
-			for (int i = -SGM_HW; i <= SGM_HW; ++i) {
-				const float* rowA = grayR + (size_t)(uy + i) * w + cA;
-				const float* rowB = grayR + (size_t)(uy + i) * w + cB;
-#pragma unroll
-				for (int j = -SGM_HW; j <= SGM_HW; ++j) {
-					const sgm_v2f f = {rowA[j], rowB[j]};
-					const float4 pw = s_w[wave][n++];
-					const sgm_v2f pww = {pw.x, pw.y}, pwt = {pw.z, pw.w};
-					const sgm_v2f fw = f * pww;
-					sum += fw; sumSq += f * fw; nom += f * pwt;
-				}
+			for (int j = -SGM_HW; j <= SGM_HW; ++j) {
+				const sgm_v2f f = {rowA[j], rowB[j]};
+				const float4 pw = s_w[wave][n++];
+				const sgm_v2f pww = {pw.x, pw.y}, pwt = {pw.z, pw.w};
+				const sgm_v2f fw = f * pww;
+				sum += fw; sumSq += f * fw; nom += f * pwt;
 			}
 		}
 		if (actA) costs[pxA.idx + (unsigned)k] = inA ? sgm_cost_of(sum.x, sumSq.x, nom.x, sA.x, sA.z) : (unsigned char)255;

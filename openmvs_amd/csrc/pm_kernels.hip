@@ -208,6 +208,20 @@ template <int K> __device__ __forceinline__ float pm_quad_bcast(float v) { retur
 __device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t, double X0x, double X0y,
 		float depth, float nx, float ny, float nz, float* H) {
 	// the twelve matrix entries are requested first, together: one round trip (overlapping the division below) instead of one per row
+#ifdef PM_PROBE_F32_HOMOGRAPHY
+	{
+		float hl[9], hm[3];
+		for (int i = 0; i < 9; ++i) hl[i] = (float)hlm[i];
+		for (int i = 0; i < 3; ++i) hm[i] = (float)hlm[9 + i];
+		const float ndxf = (nx * (float)X0x + ny * (float)X0y) + nz, invf = __builtin_amdgcn_rcpf(ndxf * depth);
+		const float r0 = nx * invf, r1 = ny * invf, r2 = nz * invf;
+		for (int i = 0; i < 3; ++i) {
+			const float m0 = hl[i * 3] + hm[i] * r0, m1 = hl[i * 3 + 1] + hm[i] * r1, m2 = hl[i * 3 + 2] + hm[i] * r2;
+			H[i * 3] = m0 * (float)t.Hr[0]; H[i * 3 + 1] = m1 * (float)t.Hr[4]; H[i * 3 + 2] = (m0 * (float)t.Hr[2] + m1 * (float)t.Hr[5]) + m2 * (float)t.Hr[8];
+		}
+		return;
+	}
+#endif
 	double Hl[9], Hm[3];
 #pragma unroll
 	for (int i = 0; i < 9; ++i) Hl[i] = hlm[i];
@@ -260,6 +274,15 @@ __device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t
 #ifndef PM_ILP_SMOOTH
 #define PM_ILP_SMOOTH 0       // smoothness factors computed by every lane without a branch (0: only by the lanes that own a close neighbour)
 #endif
+// TIMING PROBES (never defined in the product build): each removes or cheapens one part of an evaluation so that its cost inside the real, fully
+// loaded kernel can be read off the benchmark -- the counter passes of rocprofv3 do not work on this pool.  The maps such a build produces are NOT the
+// reference's (the scores change), only the time is meaningful; tools/build_variants.py + tools/tune.py run them (profiles/r02_probe_variants.log).
+//   PM_PROBE_NO_SMOOTH      smoothness factors = 1 (no exp / acos / sqrt / division chain)
+//   PM_PROBE_F32_HOMOGRAPHY homography in float (no f64 arithmetic, no f64 division)
+//   PM_PROBE_CHEAP_DRAW     a three-multiply hash instead of the ten Philox rounds
+//   PM_PROBE_FAST_EPILOGUE  v_rcp / v_rsq approximations instead of the correctly rounded division and square root of the score epilogue
+//   PM_PROBE_NO_GEO_SAMPLES geometric term = its constant 4 (no dependent depth-map loads, no divisions)
+//   PM_PROBE_NO_TAPS        the 25 taps contribute constants (no divisions, LDS reads, bilinear weights)
 #ifndef PM_WINBATCH
 #define PM_WINBATCH 4   // source windows whose global loads are in flight together when a visit stages its windows
 #endif
@@ -395,6 +418,10 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 	if (TC > 0)
 		sane = pm_fabsf(X0) + 8.f * (pm_fabsf(H[0]) + pm_fabsf(H[1])) < 5e17f && pm_fabsf(X1) + 8.f * (pm_fabsf(H[3]) + pm_fabsf(H[4])) < 5e17f
 			&& pm_fabsf(X2) + 8.f * (pm_fabsf(H[6]) + pm_fabsf(H[7])) < 5e11f;
+#ifdef PM_PROBE_NO_TAPS
+	if (TC > 0) { sum = 0.31f * sumW; sumSq = 0.11f * sumW + 0.01f * H[2]; num = 0.004f * H[5]; }
+	else
+#endif
 #pragma unroll 1
 	for (int i = 0; i < 5; ++i) {
 		bool done = false;
@@ -407,10 +434,18 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 	}
 	PM_TICK(4);
 	if (oob) return kp.thRobust;
+#ifdef PM_PROBE_FAST_EPILOGUE
+	const float normSq1 = sumSq - (sum * sum) * __builtin_amdgcn_rcpf(sumW);
+#else
 	const float normSq1 = sumSq - (sum * sum) / sumW;
+#endif
 	const float nrmSq = normSq0 * normSq1;
 	if (nrmSq <= 1e-16f) return kp.thRobust;
+#ifdef PM_PROBE_FAST_EPILOGUE
+	const float ncc = pm_clampf(num * __builtin_amdgcn_rsqf(nrmSq), -1.f, 1.f);
+#else
 	const float ncc = pm_clampf(num / pm_sqrtf(nrmSq), -1.f, 1.f);
+#endif
 	float score = 1.f - ncc;
 	// (a factor of a neighbour that does not take part is exactly 1.f, and x * 1.f == x: no test needed, DepthMap.cpp:524-533)
 	score *= sf0; score *= sf1; score *= sf2; score *= sf3;
@@ -429,7 +464,12 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		for (int i = 0; i < 9; ++i) PM_OPAQUE(Tr[i]);
 #pragma unroll
 		for (int i = 0; i < 3; ++i) PM_OPAQUE(Tn[i]);
+#ifdef PM_PROBE_NO_GEO_SAMPLES
+		if (sdepth != nullptr) score += kp.geoWeight * 4.f;
+		if (false) {
+#else
 		if (sdepth != nullptr) {
+#endif
 			float consistency = 4.f;
 			const float Xc0 = (float)X0x * depth, Xc1 = (float)X0y * depth, Xc2 = depth;
 			const float Y0 = (Tl[0] * Xc0 + Tl[1] * Xc1 + Tl[2] * Xc2) + Tm[0];
@@ -865,7 +905,11 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 #pragma unroll
 			for (int q = 0; q < SL; ++q) {
 				const int k = (G >= 4) ? (v & 3) : q * G + v;
+#ifdef PM_PROBE_NO_SMOOTH
+				const bool on = false;
+#else
 				const bool on = useS && k < 4 && ((closeMask >> k) & 1u);
+#endif
 				myF[q] = 1.f;
 				if (PM_ILP_SMOOTH || on) {
 					const float dist = (hnx * qX0[q] + (hny * qX1[q] + hnz * qX2[q])) + planeD; // Planef::Distance, Eigen 3-dot order

@@ -268,6 +268,9 @@ PM_HD void pm_sincosf(float xin, float* s, float* c) {
 struct PmPhilox4 { uint32_t v[4]; };
 PM_HD uint32_t pm_mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
 PM_HD PmPhilox4 pm_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#ifdef PM_PROBE_CHEAP_DRAW   /* timing probe of the kernels only (see pm_kernels.hip); never defined for the oracle or the product */
+	{ PmPhilox4 o; uint32_t h = (c0 * 0x9E3779B1u) ^ (c1 * 0x85EBCA77u) ^ (c2 * 0xC2B2AE3Du) ^ k0 ^ k1; o.v[0] = h * 0x27D4EB2Fu; o.v[1] = (h ^ (h >> 15)) * 0x165667B1u; o.v[2] = (h ^ (h >> 13)) * 0x9E3779B1u; o.v[3] = c3; return o; }
+#endif
 	for (int r = 0; r < 10; ++r) {
 		const uint32_t hi0 = pm_mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
 		const uint32_t hi1 = pm_mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;

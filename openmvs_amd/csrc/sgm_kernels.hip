@@ -127,8 +127,16 @@ __global__ __launch_bounds__(256, 4) void sgm_cost_kernel(const unsigned char* _
 			const float* rowB = grayR + (size_t)(uy + i) * w + cB;
 #pragma unroll
 			for (int j = -SGM_HW; j <= SGM_HW; ++j) {
+#ifdef SGM_PROBE_NO_LOADS      /* timing probes (never in the product build; results are not the reference's): what bounds the cost kernel? */
+				const sgm_v2f f = {0.3f + 0.001f * (float)(j + k), 0.4f + 0.001f * (float)(i + k)};
+#else
 				const sgm_v2f f = {rowA[j], rowB[j]};
+#endif
+#ifdef SGM_PROBE_NO_WEIGHT_READS
+				const float4 pw = make_float4(0.02f, 0.021f, 0.003f * (float)n, 0.002f * (float)n); ++n;
+#else
 				const float4 pw = s_w[wave][n++];
+#endif
 				const sgm_v2f pww = {pw.x, pw.y}, pwt = {pw.z, pw.w};
 				const sgm_v2f fw = f * pww;
 				sum += fw; sumSq += f * fw; nom += f * pwt;

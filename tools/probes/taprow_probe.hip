@@ -24,21 +24,22 @@ __global__ __launch_bounds__(64, 3) void taprow_probe_kernel(float* out, int row
 	for (int r = 0; r < rows; ++r) {
 		const int i = r % 5;
 		// pixel g of the wave sits at (46 + g, 62 - g): first tap of row i at (42 + g, 58 - g + 2 i); skew row = x + y - ts0 in [0, 16], column = y - tt0 in [1, 16]
-		const float X0 = 42.37f + (float)g + jitter * (float)v, X1 = 58.61f - (float)g + (float)(2 * i), X2 = 1.f;
+		// jitter: per-view offset of the footprint inside its window (real views differ in their sub-window position: LDS bank alignment between the views)
+		const float X0 = 42.37f + (float)g + jitter * (float)(v & 1), X1 = 58.61f - (float)g + (float)(2 * i) - jitter * (float)(v & 1), X2 = 1.f;
 		if (MODE == 0) ok += pm_tap_row_lds<TC>(s_tile + v * TSTRIDE, ts0, tt0, 4096, 4096, true, h0, h3, h6, X0, X1, X2, s_w[g] + i * 5, sum, sumSq, num, oob) ? 1u : 0u;
 		else { sum += X0 * X1; sumSq += sum * 1.0001f; num += sumSq; }     // MODE 1: empty loop (overhead reference)
 	}
 	out[blockIdx.x * 64 + lane] = sum + sumSq + num + (float)ok;
 }
 
-extern "C" int taprow_probe(int blocks, int rows, int dynLdsBytes, int mode, float* msOut, float* okFrac) {
+extern "C" int taprow_probe(int blocks, int rows, int dynLdsBytes, int mode, float jitter, float* msOut, float* okFrac) {
 	float* d = nullptr;
 	if (hipMalloc(&d, sizeof(float) * 64 * (size_t)blocks) != hipSuccess) return -1;
 	hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
 	for (int rep = 0; rep < 2; ++rep) {
 		hipEventRecord(a, 0);
-		if (mode == 0) hipLaunchKernelGGL(taprow_probe_kernel<0>, dim3(blocks), dim3(64), dynLdsBytes, 0, d, rows, 0.f);
-		else hipLaunchKernelGGL(taprow_probe_kernel<1>, dim3(blocks), dim3(64), dynLdsBytes, 0, d, rows, 0.f);
+		if (mode == 0) hipLaunchKernelGGL(taprow_probe_kernel<0>, dim3(blocks), dim3(64), dynLdsBytes, 0, d, rows, jitter);
+		else hipLaunchKernelGGL(taprow_probe_kernel<1>, dim3(blocks), dim3(64), dynLdsBytes, 0, d, rows, jitter);
 		hipEventRecord(b, 0);
 		if (hipEventSynchronize(b) != hipSuccess) return -2;
 	}

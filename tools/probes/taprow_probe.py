@@ -14,13 +14,16 @@ CUS, SIMDS = 256, 1024
 rows = 4000
 static_lds = 8 * (20 * 18 + 4) * 4 + 8 * 26 * 8
 print("static LDS per workgroup %d B; %d tap rows per wave" % (static_lds, rows))
-for per_cu in (4, 8, 11, 12, 16, 20):
+import ctypes
+jit = float(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "build" else 0.0
+print("jitter", jit)
+for per_cu in (4, 11, 12):
     dyn = max(0, (160 * 1024) // per_cu - static_lds - 512) if per_cu < 12 else 0
     fit = (160 * 1024) // (static_lds + dyn + 0)
     blocks = CUS * min(fit, per_cu) * 4
     for mode in (0, 1):
         ms, okf = C.c_float(), C.c_float()
-        rc = lib.taprow_probe(blocks, rows, dyn, mode, C.byref(ms), C.byref(okf))
+        rc = lib.taprow_probe(blocks, rows, dyn, mode, C.c_float(jit), C.byref(ms), C.byref(okf))
         waves_per_simd = min(fit, per_cu) / 4.0
         ns_row_simd = ms.value * 1e6 / (rows * blocks / SIMDS)
         print("%2d workgroups per CU wanted (LDS allows %2d; %.2f waves/SIMD), %s: %.3f ms for %d waves -> %.1f ns of SIMD time per row (= %.0f cycles at 2.4 GHz)%s" % (

@@ -136,7 +136,11 @@ __device__ __forceinline__ bool pm_in_range(float d, float lo, float hi) { retur
 // Dir2Normal / Normal2Dir, libs/Common/Util.inl:754-766
 __device__ __forceinline__ void pm_dir2normal(float p0, float p1, float& nx, float& ny, float& nz) {
 	float sx, cx, sy, cy;
+#ifdef PM_PROBE_CHEAP_TRIG
+	sx = p0 * 0.3f; cx = 1.f - sx * sx; sy = -0.2f + p1 * 0.01f; cy = -0.97f;
+#else
 	pm_sincosf(p0, &sx, &cx); pm_sincosf(p1, &sy, &cy);
+#endif
 	nx = cx * sy; ny = sx * sy; nz = cy;
 }
 // RandomNormal, DepthMap.h:439-444
@@ -283,6 +287,10 @@ __device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t
 //   PM_PROBE_FAST_EPILOGUE  v_rcp / v_rsq approximations instead of the correctly rounded division and square root of the score epilogue
 //   PM_PROBE_NO_GEO_SAMPLES geometric term = its constant 4 (no dependent depth-map loads, no divisions)
 //   PM_PROBE_NO_TAPS        the 25 taps contribute constants (no divisions, LDS reads, bilinear weights)
+//   PM_PROBE_NO_STAGING     the source windows are not loaded (the taps read whatever the LDS holds)
+//   PM_PROBE_NO_FALLBACK    a tap row that fails its exactness test is not redone through global memory
+//   PM_PROBE_NO_WEIGHTS     the 25 bilateral patch weights are constants (no exp, no patch texel loads)
+//   PM_PROBE_CHEAP_TRIG     sin / cos / atan2 / acos of the hypothesis construction replaced by two-instruction stand-ins
 #ifndef PM_WINBATCH
 #define PM_WINBATCH 4   // source windows whose global loads are in flight together when a visit stages its windows
 #endif
@@ -429,6 +437,9 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 #ifdef PM_PROFILE
 		if (TC > 0) { PM_COUNT(10, __popcll(__ballot(done))); PM_COUNT(11, __popcll(__ballot(true))); PM_COUNT(7, __all(done) ? 1 : 0); }
 #endif
+#ifdef PM_PROBE_NO_FALLBACK
+		if (TC > 0) done = true;
+#endif
 		if (!done) pm_tap_row_global<SKEW>(pm_glob(SKEW ? s.imgS : s.img), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
 		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
 	}
@@ -560,7 +571,11 @@ __device__ __forceinline__ void pm_fill_patch(const PMTask& t, bool inb, int x, 
 			const float dc = I - colCenter;
 			const float wColor = (dc * dc) * sigmaColor;
 			const float wSpatial = (float)(j * j + i * i) * sigmaSpatial;
+#ifdef PM_PROBE_NO_WEIGHTS
+			wts[k] = make_float2(0.5f + 0.01f * (float)k, 0.3f + 0.02f * (float)(k % 7));
+#else
 			wts[k] = make_float2(pm_expf(wColor + wSpatial), I);
+#endif
 		}
 	}
 	__syncthreads();
@@ -794,15 +809,21 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 					const int i = lane + 64 * k;
 					const int r = i / TCD, c = i - r * TCD;
 					const int ss = fs0 + r, tt = ft0 + c;
+#ifdef PM_PROBE_NO_STAGING
+					vals[b][k] = 0.25f;
+#else
 					vals[b][k] = (i < PM_TR * TC && ss >= 0 && ss < sMax && tt >= 0 && tt < sh) ? src[(size_t)ss * sh + tt] : 0.f;
+#endif
 				}
 			}
 #pragma unroll
 			for (int b = 0; b < WB; ++b) {
 				const int vv = vb + b;
 				if (vv >= nS) break;
+#ifndef PM_PROBE_NO_STAGING
 #pragma unroll
 				for (int k = 0; k < NLD; ++k) { const int i = lane + 64 * k; if (i < PM_TR * TC) tw[vv * TSTRIDE + i] = vals[b][k]; }
+#endif
 			}
 		}
 		tileBase = tw;

@@ -48,20 +48,20 @@ __device__ __forceinline__ pm_gf pm_globw(float* p) { return (pm_gf)p; }
 #define PM_NT 25     // nTexels, DepthMap.h:281
 
 struct PMSrcView {
-	// "hot" block, 14 doubles: what every hypothesis evaluation reads of its source view.  The sweep kernel copies it (and the geometric block)
+	// "hot" block, 13 doubles: what every hypothesis evaluation reads of its source view.  The sweep kernel copies it (and the geometric block)
 	// into LDS once per visit; the layout is the copy's contract (see PM_SRC_HOT / PM_SRC_GEO below).
 	double Hl[9];         // K_j R_j R_0^T          (ViewData::Init, DepthMap.h:175-185)
 	double Hm[3];         // K_j R_j (C_0 - C_j)
 	int w, h;             // size of the source image at this level
-	const float* imgS;    // the image, anti-diagonal-major ("skewed"): texel (u,v) at (u+v)*h + v -- read by tap rows that miss the LDS window
 	// geometric block, 14 doubles: transforms of the consistency term and the source view's depth-map (nullable; geometric pass) with its own
 	// size: the map is addressed through cameraDepthMap (Tl..Tn), not through the image's camera (DepthMap.h:170-171, DepthMap.cpp:535-551)
 	float Tl[9], Tm[3], Tr[9], Tn[3];
 	const float* depth;
 	int dw, dh;
 	const float* img;     // source image at this pyramid level, row-major
+	const float* imgS;    // same image, anti-diagonal-major ("skewed"): texel (u,v) at (u+v)*h + v
 };
-#define PM_SRC_HOT 14     // doubles
+#define PM_SRC_HOT 13     // doubles
 #define PM_SRC_GEO 14
 static_assert(offsetof(PMSrcView, Hm) == 72 && offsetof(PMSrcView, w) == 96 && offsetof(PMSrcView, Tl) == 8 * PM_SRC_HOT
 	&& offsetof(PMSrcView, depth) == 8 * PM_SRC_HOT + 96 && offsetof(PMSrcView, dw) == 8 * PM_SRC_HOT + 104 && offsetof(PMSrcView, img) == 8 * (PM_SRC_HOT + PM_SRC_GEO), "PMSrcView layout");
@@ -347,13 +347,12 @@ __device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int 
 // row through global loads.  ~40 VALU instructions per tap instead of ~100.
 template <int TC>
 __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int tt0, int sw, int sh, bool sane, float h0, float h3, float h6,
-		float X0, float X1, float X2, const float2* wrow, float& sum, float& sumSq, float& num, bool& oob, const pm_gcf imgS)
+		float X0, float X1, float X2, const float2* wrow, float& sum, float& sumSq, float& num, bool& oob)
 {
 	constexpr int MAXI = PM_TR * TC - 2 * TC - 2;   // idx + 2*TC + 1 stays inside the window
 	const int cidx = -(ts0 * TC + tt0);
 	float fxs[5], fys[5];
 	const float* q[5];
-	unsigned goff[5];   // texel offset in the anti-diagonal-major image (used only when the row misses the window)
 	float zlo = X2, zhi = X2, pxlo = PM_INF, pxhi = -PM_INF, pylo = PM_INF, pyhi = -PM_INF;
 	int slo = 0x7fffffff, shi = (int)0x80000000;
 #pragma unroll
@@ -368,7 +367,6 @@ __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int t
 		slo = min(slo, sk); shi = max(shi, sk);
 		const int idx = pm_mul24(sk, TC) + (ly + cidx);   // 24-bit multiply: full rate (a 32-bit one is a quarter-rate v_mad_u64_u32); garbage only where the row fails anyway
 		q[j] = tile + min((unsigned)idx, (unsigned)MAXI);
-		goff[j] = (unsigned)pm_mul24(sk, sh) + (unsigned)ly;   // (sk * sh < 2^24 for the image sizes the fast path is exact for: checked below)
 		X0 += h0; X1 += h3; X2 += h6;
 	}
 	float s0 = sum, s1 = sumSq, s2 = num;
@@ -392,29 +390,8 @@ __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int t
 	const bool inWindow = pylo >= (float)tt0 && pyhi < (float)(tt0 + TC - 1) && slo >= ts0 && shi <= ts0 + PM_TR - 3;
 	if (exact && !inImage) { oob = true; return true; }
 	const bool ok = exact && inWindow;
-	if (ok) { sum = s0; sumSq = s1; num = s2; return true; }
-#ifndef PM_PROBE_NO_MEDIUM_PATH
-	// Positions exact, all taps inside the image, but some outside the window (a propagated plane, a depth step inside the wave): everything computed
-	// above stands -- only the 20 texels have to come from the image itself.  This is the common failure (a timing probe put the full redo at 11.7 % of a
-	// step), and it needs 20 loads and the accumulation, not the ~500 instructions of pm_tap_row_global.  Same texels, same order of the sums.
-	if (exact && inImage && (unsigned)(sw + sh) * (unsigned)sh < (1u << 24)) {
-		float v00[5], v01[5], v10[5], v11[5];
-#pragma unroll
-		for (int j = 0; j < 5; ++j) { const pm_gcf p = imgS + goff[j]; v00[j] = p[0]; v01[j] = p[sh]; v10[j] = p[sh + 1]; v11[j] = p[2 * sh + 1]; }
-#pragma unroll
-		for (int j = 0; j < 5; ++j) {
-			const float fx = fxs[j], fx1 = 1.f - fx, fy = fys[j], fy1 = 1.f - fy;
-			const float v = (v00[j] * fx1 + v01[j] * fx) * fy1 + (v10[j] * fx1 + v11[j] * fx) * fy;
-			const float2 pw = wrow[j];
-			const float vw = v * pw.x;
-			sum += vw;
-			sumSq += v * vw;
-			num += v * pw.y;
-		}
-		return true;
-	}
-#endif
-	return false;
+	if (ok) { sum = s0; sumSq = s1; num = s2; }
+	return ok;
 }
 
 // PF: the pixel's low-resolution prior and its blend factor exp(normSq0 * sigma) sit in the spare 26th entry of the pixel's weight row in LDS
@@ -456,7 +433,7 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 #pragma unroll 1
 	for (int i = 0; i < 5; ++i) {
 		bool done = false;
-		if (TC > 0) done = pm_tap_row_lds<TC>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob, pm_glob(*(const float* const*)(hot + 13))) || oob;
+		if (TC > 0) done = pm_tap_row_lds<TC>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob) || oob;
 #ifdef PM_PROFILE
 		if (TC > 0) { PM_COUNT(10, __popcll(__ballot(done))); PM_COUNT(11, __popcll(__ballot(true))); PM_COUNT(7, __all(done) ? 1 : 0); }
 #endif

@@ -17,8 +17,8 @@ def test_sweep_kernel_keeps_its_residency_budget():
         vpl = int(k.split("pm_sweep_kernelILi")[1].split("ELi")[1].split("E")[0])
         if lanes in (4, 8) and vpl == 1:                       # the mappings of 3..8 source views: three waves per SIMD and eleven one-wave workgroups per CU
             assert v["occupancy"] >= 3 and v["vgpr"] <= 168, (k, v)
-            assert v["lds"] <= 15168, (k, v)   # windows 20 x (pixels per wave + 10) per view, weights, and the per-view constants (832 B; twice that in the geometric pass)
-            assert v["scratch"] <= 80, (k, v)   # spilled dwords (round-1 kernel: 28 at 8 lanes per pixel; now 64 photometric, 80 geometric)
+            assert v["lds"] <= 15104, (k, v)   # windows 20 x (pixels per wave + 10) per view, weights, and the per-view constants (832 B; twice that in the geometric pass)
+            assert v["scratch"] <= 60, (k, v)   # a few spilled dwords (round-1 kernel: 28 at 8 lanes per pixel; now 44 photometric, 60 geometric)
         else:
             assert v["occupancy"] >= (1 if vpl >= 4 else 2), (k, v)
         assert v["agpr"] == 0

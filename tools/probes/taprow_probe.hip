@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64, 3) void taprow_probe_kernel(float* out, int row
 		// pixel g of the wave sits at (46 + g, 62 - g): first tap of row i at (42 + g, 58 - g + 2 i); skew row = x + y - ts0 in [0, 16], column = y - tt0 in [1, 16]
 		// jitter: per-view offset of the footprint inside its window (real views differ in their sub-window position: LDS bank alignment between the views)
 		const float X0 = 42.37f + (float)g + jitter * (float)(v & 1), X1 = 58.61f - (float)g + (float)(2 * i) - jitter * (float)(v & 1), X2 = 1.f;
-		if (MODE == 0) ok += pm_tap_row_lds<TC>(s_tile + v * TSTRIDE, ts0, tt0, 4096, 4096, true, h0, h3, h6, X0, X1, X2, s_w[g] + i * 5, sum, sumSq, num, oob, (pm_gcf)nullptr) ? 1u : 0u;
+		if (MODE == 0) ok += pm_tap_row_lds<TC>(s_tile + v * TSTRIDE, ts0, tt0, 4096, 4096, true, h0, h3, h6, X0, X1, X2, s_w[g] + i * 5, sum, sumSq, num, oob) ? 1u : 0u;
 		else { sum += X0 * X1; sumSq += sum * 1.0001f; num += sumSq; }     // MODE 1: empty loop (overhead reference)
 	}
 	out[blockIdx.x * 64 + lane] = sum + sumSq + num + (float)ok;

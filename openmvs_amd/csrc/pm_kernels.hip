@@ -269,6 +269,13 @@ __device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t
 #endif
 // Three switches of an experiment that did not pay (profiles/r02_variants_call7_ilp_block.log: all on 30.8, all off 32.1 Mpix/s): writing the
 // per-hypothesis chains that do not depend on each other as one branch-free block so that the scheduler can interleave them.  Off by default.
+// Prepared for round 3, not yet timed (default off; bit-exact under the emulator): the smoothness-factor chain (13 % of a step by the timing probes) is
+// evaluated inside pm_score_view, in the same basic block as the first tap row, whose ~220 independent instructions can cover its latency; every lane
+// of a pixel that evaluates a hypothesis takes part (lanes without a source view run the row on zeros and are flagged), so the broadcast of the
+// factors stays inside fully active quads.  One source view per lane and >= 4 lanes per pixel only.
+#ifndef PM_SMOOTH_IN_ROW0
+#define PM_SMOOTH_IN_ROW0 0
+#endif
 #ifndef PM_ILP_HOMOGRAPHY
 #define PM_ILP_HOMOGRAPHY 0   // the lane's homography computed next to the smoothness factors instead of inside pm_score_view
 #endif
@@ -396,12 +403,15 @@ __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int t
 
 // PF: the pixel's low-resolution prior and its blend factor exp(normSq0 * sigma) sit in the spare 26th entry of the pixel's weight row in LDS
 // (written once per visit by the sweep kernel) instead of in two registers that are live across the whole hypothesis loop
-template <bool GEO, bool SKEW, int TC, bool PF = false>
+// what pm_score_view needs to evaluate the lane's smoothness factor itself (PM_SMOOTH_IN_ROW0)
+struct PMSmoothIn { float qX0, qX1, qX2, qn0, qn1, qn2, vx, vy, vz; bool on; };
+
+template <bool GEO, bool SKEW, int TC, bool PF = false, bool SIN = false>
 __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask& t, const PMKParams& kp,
 		int x, int y, double X0x, double X0y, float normSq0, float sumW, const float2* wts,
 		float depth, float nx, float ny, float nz,
 		float sf0, float sf1, float sf2, float sf3, float prior,
-		const float* tile, int ts0, int tt0, const double* hot, const double* geoTab, const float* Hpre PM_PROF_ARG)
+		const float* tile, int ts0, int tt0, const double* hot, const double* geoTab, const float* Hpre, const PMSmoothIn* sin = nullptr, bool viewOk = true PM_PROF_ARG)
 {
 	// hot / geoTab: the hot and geometric blocks of `s` (PMSrcView), in HBM (init kernel) or in the wave's LDS copy (sweep kernel); the image
 	// size travels with the homography entries
@@ -420,18 +430,37 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 #pragma unroll
 	for (int i = 0; i < 9; ++i) H[i] *= 2.f; // nSizeStep
 	float sum = 0.f, sumSq = 0.f, num = 0.f;
-	bool oob = false;
+	bool oob = !viewOk;   // a lane without a source view (SIN only) is flagged from the start: its rows are never redone, its score is discarded
 	// |x|, |y| < 1e18 and |z| < 2^40 for every tap of the patch, from the first tap and the step sizes (8 steps along either axis at most)
 	bool sane = false;
 	if (TC > 0)
 		sane = pm_fabsf(X0) + 8.f * (pm_fabsf(H[0]) + pm_fabsf(H[1])) < 5e17f && pm_fabsf(X1) + 8.f * (pm_fabsf(H[3]) + pm_fabsf(H[4])) < 5e17f
 			&& pm_fabsf(X2) + 8.f * (pm_fabsf(H[6]) + pm_fabsf(H[7])) < 5e11f;
+	int iFirst = 0;
+	if (SIN && TC > 0) {
+		// the lane's smoothness factor (DepthMap.cpp:524-533), branch-free, then the first tap row: one basic block for the scheduler to interleave
+		const float planeD = -depth * (nx * sin->vx + ny * sin->vy + nz * sin->vz); // InitPlane, DepthMap.cpp:963-971
+		const float dist = (nx * sin->qX0 + (ny * sin->qX1 + nz * sin->qX2)) + planeD; // Planef::Distance, Eigen 3-dot order
+		const float r = dist / depth;
+		const float factorDepth = pm_expf((r * r) * kp.smoothSigmaDepth);
+		const float ca = pm_clampf((nx * sin->qn0 + ny * sin->qn1 + nz * sin->qn2) /
+			pm_sqrtf((nx * nx + ny * ny + nz * nz) * (sin->qn0 * sin->qn0 + sin->qn1 * sin->qn1 + sin->qn2 * sin->qn2)), -1.f, 1.f);
+		const float ac = pm_acosf(ca);
+		const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
+		const float f = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
+		const float myF = sin->on ? f : 1.f;
+		const bool done0 = pm_tap_row_lds<TC>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts, sum, sumSq, num, oob) || oob;
+		sf0 = pm_quad_bcast<0>(myF); sf1 = pm_quad_bcast<1>(myF); sf2 = pm_quad_bcast<2>(myF); sf3 = pm_quad_bcast<3>(myF);
+		if (!done0) pm_tap_row_global<SKEW>(pm_glob(SKEW ? s.imgS : s.img), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts, sum, sumSq, num, oob);
+		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
+		iFirst = 1;
+	}
 #ifdef PM_PROBE_NO_TAPS
 	if (TC > 0) { sum = 0.31f * sumW; sumSq = 0.11f * sumW + 0.01f * H[2]; num = 0.004f * H[5]; }
 	else
 #endif
 #pragma unroll 1
-	for (int i = 0; i < 5; ++i) {
+	for (int i = iFirst; i < 5; ++i) {
 		bool done = false;
 		if (TC > 0) done = pm_tap_row_lds<TC>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob) || oob;
 #ifdef PM_PROFILE
@@ -929,7 +958,7 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 #ifdef PM_PROBE_NO_SMOOTH
 				const bool on = false;
 #else
-				const bool on = useS && k < 4 && ((closeMask >> k) & 1u);
+				const bool on = !(PM_SMOOTH_IN_ROW0 && VPL == 1 && G >= 4 && TC > 0) && useS && k < 4 && ((closeMask >> k) & 1u);
 #endif
 				myF[q] = 1.f;
 				if (PM_ILP_SMOOTH || on) {
@@ -955,6 +984,21 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 		}
 		PM_TICK(2);
 		float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
+		if (PM_SMOOTH_IN_ROW0 && VPL == 1 && G >= 4 && TC > 0) {
+			// every lane of a pixel with a hypothesis enters: the smoothness chain is evaluated next to the first tap row (see the switch)
+			if (need) {
+				const bool viewOk = v < t.nSrc;
+				const int slot = v & 3;
+				PMSmoothIn sin;
+				sin.qX0 = qX0[0]; sin.qX1 = qX1[0]; sin.qX2 = qX2[0]; sin.qn0 = qn0[0]; sin.qn1 = qn1[0]; sin.qn2 = qn2[0];
+				sin.vx = vx; sin.vy = vy; sin.vz = vz;
+				sin.on = smooth && ((closeMask >> slot) & 1u);
+				const int2 org = s_org[threadIdx.x >> 6][v];
+				const float s1 = pm_score_view<GEO, true, TC, true, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, 1.f, 1.f, 1.f, 1.f, 0.f,
+					tileBase + v * TSTRIDE, org.x, org.y, hotBase + v * NBD, hotBase + v * NBD + PM_SRC_HOT, nullptr, &sin, viewOk PM_PROF_PASS);
+				if (viewOk) sc = s1;
+			}
+		} else {
 #pragma unroll 1
 		for (int u = 0; u < VPL; ++u) {
 			const int view = v + u * G;
@@ -965,6 +1009,7 @@ __global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVE
 					tileBase + view * TSTRIDE, org.x, org.y, hotBase + view * NBD, hotBase + view * NBD + PM_SRC_HOT, (VPL == 1 && PM_ILP_HOMOGRAPHY) ? Hpre : nullptr PM_PROF_PASS);
 				if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
 			}
+		}
 		}
 		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
 		if (need && conf > nconf) {

@@ -276,6 +276,13 @@ __device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t
 #ifndef PM_SMOOTH_IN_ROW0
 #define PM_SMOOTH_IN_ROW0 0
 #endif
+// Also prepared for round 3 (default off, bit-exact under the emulator, not yet timed): a tap row that fails the LDS attempt is first retried with the same
+// optimistic code reading its 20 texels from the image in HBM (~240 instructions), and only a row whose positions are not exact goes through
+// pm_tap_row_global (~500).  The redone rows are 11.7 % of a step by the timing probe; a version that kept the first attempt's positions alive
+// instead of recomputing them lost 3.3 % to register pressure.
+#ifndef PM_GLOBAL_FAST_ROW
+#define PM_GLOBAL_FAST_ROW 0
+#endif
 #ifndef PM_ILP_HOMOGRAPHY
 #define PM_ILP_HOMOGRAPHY 0   // the lane's homography computed next to the smoothness factors instead of inside pm_score_view
 #endif
@@ -352,14 +359,15 @@ __device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int 
 // and (c) inside the window.  If so the three running sums are exactly what pm_tap_row_global computes and the call returns true; with (a) but a tap
 // outside the image the hypothesis is flagged (`oob`) and the row is done as well; otherwise the sums are left untouched and the caller redoes the
 // row through global loads.  ~40 VALU instructions per tap instead of ~100.
-template <int TC>
+template <int TC, bool FROM_IMAGE = false>
 __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int tt0, int sw, int sh, bool sane, float h0, float h3, float h6,
-		float X0, float X1, float X2, const float2* wrow, float& sum, float& sumSq, float& num, bool& oob)
+		float X0, float X1, float X2, const float2* wrow, float& sum, float& sumSq, float& num, bool& oob, const pm_gcf imgS = (pm_gcf)nullptr)
 {
 	constexpr int MAXI = PM_TR * TC - 2 * TC - 2;   // idx + 2*TC + 1 stays inside the window
 	const int cidx = -(ts0 * TC + tt0);
 	float fxs[5], fys[5];
 	const float* q[5];
+	unsigned goff[5];   // FROM_IMAGE: texel offsets in the anti-diagonal-major image, clamped into it (a row with a tap outside is not committed)
 	float zlo = X2, zhi = X2, pxlo = PM_INF, pxhi = -PM_INF, pylo = PM_INF, pyhi = -PM_INF;
 	int slo = 0x7fffffff, shi = (int)0x80000000;
 #pragma unroll
@@ -372,14 +380,21 @@ __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int t
 		fxs[j] = pm_fract_pos(ptx); fys[j] = pm_fract_pos(pty);   // == ptx - (float)lx for the positions the row is accepted with (>= 1)
 		const int sk = lx + ly;
 		slo = min(slo, sk); shi = max(shi, sk);
-		const int idx = pm_mul24(sk, TC) + (ly + cidx);   // 24-bit multiply: full rate (a 32-bit one is a quarter-rate v_mad_u64_u32); garbage only where the row fails anyway
-		q[j] = tile + min((unsigned)idx, (unsigned)MAXI);
+		if (FROM_IMAGE) {
+			const int lxc = min(max(lx, 0), sw - 2), lyc = min(max(ly, 0), sh - 2);
+			goff[j] = (unsigned)(lxc + lyc) * (unsigned)sh + (unsigned)lyc;
+		} else {
+			const int idx = pm_mul24(sk, TC) + (ly + cidx);   // 24-bit multiply: full rate (a 32-bit one is a quarter-rate v_mad_u64_u32); garbage only where the row fails anyway
+			q[j] = tile + min((unsigned)idx, (unsigned)MAXI);
+		}
 		X0 += h0; X1 += h3; X2 += h6;
 	}
 	float s0 = sum, s1 = sumSq, s2 = num;
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
-		const float v00 = q[j][0], v01 = q[j][TC], v10 = q[j][TC + 1], v11 = q[j][2 * TC + 1];
+		float v00, v01, v10, v11;
+		if (FROM_IMAGE) { const pm_gcf p = imgS + goff[j]; v00 = p[0]; v01 = p[sh]; v10 = p[sh + 1]; v11 = p[2 * sh + 1]; }
+		else { v00 = q[j][0]; v01 = q[j][TC]; v10 = q[j][TC + 1]; v11 = q[j][2 * TC + 1]; }
 		const float fx = fxs[j], fx1 = 1.f - fx, fy = fys[j], fy1 = 1.f - fy;
 		const float v = (v00 * fx1 + v01 * fx) * fy1 + (v10 * fx1 + v11 * fx) * fy;
 		const float2 pw = wrow[j];
@@ -396,7 +411,7 @@ __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int t
 	// (int)pty in [tt0, tt0 + TC - 2]  <=>  tt0 <= pty < tt0 + TC - 1 once pty >= 1
 	const bool inWindow = pylo >= (float)tt0 && pyhi < (float)(tt0 + TC - 1) && slo >= ts0 && shi <= ts0 + PM_TR - 3;
 	if (exact && !inImage) { oob = true; return true; }
-	const bool ok = exact && inWindow;
+	const bool ok = exact && (FROM_IMAGE || inWindow);
 	if (ok) { sum = s0; sumSq = s1; num = s2; }
 	return ok;
 }
@@ -469,6 +484,8 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 #ifdef PM_PROBE_NO_FALLBACK
 		if (TC > 0) done = true;
 #endif
+		if (PM_GLOBAL_FAST_ROW && TC > 0 && SKEW && !done)
+			done = pm_tap_row_lds<TC, true>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob, pm_glob(s.imgS)) || oob;
 		if (!done) pm_tap_row_global<SKEW>(pm_glob(SKEW ? s.imgS : s.img), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
 		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
 	}

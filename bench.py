@@ -230,13 +230,21 @@ def main():
 
 
 def measured_traffic(algorithmic_bytes_per_launch):
-    """HBM bytes per sweep launch from rocprofv3's FETCH_SIZE / WRITE_SIZE counters.  They need their own profiler passes (MI355X_MICROARCH.md:
-    no trace domains next to --pmc), so bench.py cannot collect them live: the figure comes from the committed pass profiles/traffic.json
-    (written by tools/pmc_traffic.py from the pass' per-kernel table, gfx950 x2 correction applied) and is null when that file is absent."""
+    """HBM-side bytes per sweep launch from rocprofv3's FETCH_SIZE + WRITE_SIZE counters (L2 <-> fabric requests).  They need their own profiler
+    passes (MI355X_MICROARCH.md: no trace domains next to --pmc), so bench.py cannot collect them live: the figure is an OFFLINE measurement, the
+    committed profiles/traffic.json written by tools/pmc/make_traffic.py from tools/pmc/run_pmc.sh's passes over the stand-alone C++ workload.  The file
+    names the kernel sources it was measured on (sha-256 prefix); when the tree's kernels differ, or the file is absent, the field is null."""
     try:
+        import hashlib
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        return {"bytes_per_launch": t["bytes_per_launch"], "over_algorithmic": round(t["bytes_per_launch"] / max(1.0, t.get("algorithmic_bytes_per_launch", algorithmic_bytes_per_launch)), 2),
-                "source": t.get("source", "profiles/traffic.json")}
+        h = hashlib.sha256()
+        for f in ("pm_kernels.hip", "pm_engine.hip", "pm_math.h"):
+            h.update(open(os.path.join(ROOT, "openmvs_amd", "csrc", f), "rb").read())
+        if h.hexdigest()[:16] != t.get("kernel_digest"):
+            return None
+        return {"bytes_per_launch": t["bytes_per_launch"], "fetch_bytes_per_launch": t["fetch_bytes_per_launch"], "write_bytes_per_launch": t["write_bytes_per_launch"],
+                "over_algorithmic": round(t["bytes_per_launch"] / max(1.0, t.get("algorithmic_bytes_per_launch", algorithmic_bytes_per_launch)), 2),
+                "measured": "offline", "kernel_digest": t["kernel_digest"], "source": t.get("source", "profiles/traffic.json")}
     except Exception:
         return None
 

@@ -271,6 +271,9 @@ static void launchSweep(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* 
 	PM_SWEEP_CASE(1, 1); PM_SWEEP_CASE(2, 1); PM_SWEEP_CASE(4, 1); PM_SWEEP_CASE(8, 1); PM_SWEEP_CASE(16, 1);
 	PM_SWEEP_CASE(1, 2); PM_SWEEP_CASE(2, 2); PM_SWEEP_CASE(4, 2); PM_SWEEP_CASE(8, 2);
 	PM_SWEEP_CASE(2, 4); PM_SWEEP_CASE(4, 4);
+#if !PM_USE_TILES
+	PM_SWEEP_CASE(1, 4); PM_SWEEP_CASE(1, 8);   // experiment builds without LDS windows only: a lane walks all source views of its pixel
+#endif
 	default: break;
 	}
 #undef PM_SWEEP_CASE
@@ -280,8 +283,8 @@ static void launchSweep(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* 
 static void sweepMapping(int maxSrc, int lanes, int& G, int& VPL) {
 	int NV = 1; while (NV < maxSrc) NV <<= 1;
 	G = NV; VPL = 1;
-	while (G > 1 && G > lanes && VPL < 4) { G >>= 1; VPL <<= 1; }
-	if ((G == 1 && VPL > 2) || (G == 8 && VPL > 2)) { G <<= 1; VPL >>= 1; }   // (1,4) and (8,4) are not instantiated
+	while (G > 1 && G > lanes && VPL < (PM_USE_TILES ? 4 : 8)) { G >>= 1; VPL <<= 1; }
+	if ((PM_USE_TILES && G == 1 && VPL > 2) || (G == 8 && VPL > 2)) { G <<= 1; VPL >>= 1; }   // (1,4) and (8,4) are not instantiated
 }
 
 template <bool GEO>

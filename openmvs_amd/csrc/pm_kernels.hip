@@ -447,8 +447,10 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 	float sum = 0.f, sumSq = 0.f, num = 0.f;
 	bool oob = !viewOk;   // a lane without a source view (SIN only) is flagged from the start: its rows are never redone, its score is discarded
 	// |x|, |y| < 1e18 and |z| < 2^40 for every tap of the patch, from the first tap and the step sizes (8 steps along either axis at most)
+	// FASTG: no LDS windows (PM_USE_TILES = 0); the optimistic row reads its texels straight from the anti-diagonal-major image (vector L1)
+	constexpr bool FASTG = SKEW && TC == 0;
 	bool sane = false;
-	if (TC > 0)
+	if (TC > 0 || FASTG)
 		sane = pm_fabsf(X0) + 8.f * (pm_fabsf(H[0]) + pm_fabsf(H[1])) < 5e17f && pm_fabsf(X1) + 8.f * (pm_fabsf(H[3]) + pm_fabsf(H[4])) < 5e17f
 			&& pm_fabsf(X2) + 8.f * (pm_fabsf(H[6]) + pm_fabsf(H[7])) < 5e11f;
 	int iFirst = 0;
@@ -484,8 +486,8 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 #ifdef PM_PROBE_NO_FALLBACK
 		if (TC > 0) done = true;
 #endif
-		if (PM_GLOBAL_FAST_ROW && TC > 0 && SKEW && !done)
-			done = pm_tap_row_lds<TC, true>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob, pm_glob(s.imgS)) || oob;
+		if (((PM_GLOBAL_FAST_ROW && TC > 0 && SKEW) || FASTG) && !done)
+			done = pm_tap_row_lds<(TC > 0 ? TC : 1), true>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob, pm_glob(s.imgS)) || oob;
 		if (!done) pm_tap_row_global<SKEW>(pm_glob(SKEW ? s.imgS : s.img), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
 		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
 	}
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 // (hypothesis generation, smoothness factors, the visit's set-up, accept / reject: about 70 % of a wave's time at one view per lane, measured
 // with -DPM_PROFILE) is then shared by VPL times as many pixels per wave; MINMEAN does not care which lane scored which view.
 template <int G, int VPL, bool GEO>
-__global__ __launch_bounds__(PM_BLOCK, (VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVES)) void pm_sweep_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
+__global__ __launch_bounds__(PM_BLOCK, (!PM_USE_TILES ? PM_MINWAVES : VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVES)) void pm_sweep_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	constexpr int PPB = PM_BLOCK / G;
 	constexpr int SL = (G >= 4) ? 1 : 4 / G; // smoothness slots owned per lane
 	constexpr int PPW = 64 / G;               // pixels per wave

@@ -1,0 +1,246 @@
+// seacave_min.h -- TEST INFRASTRUCTURE (oracle/_ref build only).
+// Environment in which verbatim pieces of the reference (/root/reference, OpenMVS v2.3.0) compile without OpenCV / Eigen / Boost / CGAL:
+//   * "snip/<name>.inc" files are VERBATIM line ranges of the reference's own headers and sources, cut by oracle/ref/build_ref.py at build
+//     time into a scratch directory (never committed, never copied into this repository);
+//   * what is written out in this header is only the glue those pieces need: platform macros, the containers (cList, TImage storage, BitMatrix)
+//     and third-party types (opencv_min.h, eigen_min.h).  No arithmetic of the estimator lives here.
+// REF_MATH_PM: route the transcendental calls the reference makes (exp / acos / atan2 / sin / cos) to csrc/pm_math.h, so that the
+// comparison with oracle/pm_oracle.cpp can be bit for bit; without it they are libm's float overloads, as in a reference binary.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <math.h>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <numeric>
+#include <random>
+#include <string>
+#include <type_traits>
+#include <vector>
+#include "opencv_min.h"
+#include "eigen_min.h"
+#include "../../../openmvs_amd/csrc/pm_math.h"
+
+#define _USE_EIGEN
+#define _RELEASE_NOT   /* the reference's non-release build: estimators seeded with mt19937::default_seed (DepthMap.cpp:370-372) */
+#define ASSERT(x) ((void)0)
+#define STATIC_ASSERT(x) static_assert(x, #x)
+#define FORCEINLINE inline
+#define MVS_API
+#define GENERAL_API
+#define MATH_API
+#define STCALL
+#define MAYBEUNUSED
+#define DEBUG(...) ((void)0)
+#define DEBUG_ULTIMATE(...) ((void)0)
+#define SLOG(x) ((void)0)
+#define CPC_ERROR(msg) ((void)0)
+#define DECOPT_SPACE(x)
+#define DEFINE_CVDATATYPE(x)
+#define MAKE_PATH(x) (x)
+#ifndef NULL
+#define NULL 0
+#endif
+#define MINF std::min
+#define MAXF std::max
+#define MIN std::min
+#define MAX std::max
+// Types.h:533-603 constants used on the path
+#define PI 3.1415926535897932384626433832795
+#define FPI ((float)PI)
+#define ZERO_TOLERANCE (1e-7)
+#define INV_ZERO (1e+14)
+#define FZERO_TOLERANCE 0.0001f
+#define FINV_ZERO 1000000.f
+#define FD2R(d) ((d)*(FPI/180.f))
+#define GCLASS unsigned
+
+typedef uint8_t BYTE;
+namespace SEACAVE {
+typedef double REAL;
+typedef REAL REALTYPE;
+class hfloat;
+#ifdef REF_MATH_PM
+// the reference calls these unqualified from inside namespace SEACAVE (EXP, Normal2Dir, Dir2Normal, TRMatrixBase::Set): bind them to pm_math.h
+inline float exp(float x) { return pm_expf(x); }
+inline float acos(float x) { return (x >= -1.f && x <= 1.f) ? pm_acosf(x) : std::numeric_limits<float>::quiet_NaN(); }
+inline float atan2(float y, float x) { return pm_atan2f(y, x); }
+inline float sin(float x) { float s, c; pm_sincosf(x, &s, &c); return s; }
+inline float cos(float x) { float s, c; pm_sincosf(x, &s, &c); return c; }
+inline float sqrt(float x) { return ::sqrtf(x); }
+inline double sqrt(double x) { return ::sqrt(x); }
+inline double exp(double x) { return ::exp(x); }
+#define ACOS SEACAVE::acos
+#else
+#define ACOS std::acos
+#endif
+template <typename TYPE> struct RealType { typedef typename std::conditional<std::is_floating_point<TYPE>::value, TYPE, REALTYPE>::type type; };   // Types.h:344
+#include "snip/types_h_funcs.inc"        // Types.h: Cast, SQUARE, SQRT, EXP
+#include "snip/types_h_tests.inc"        // Types.h: ISINSIDE, CLAMP, ABS, ISZERO, ISEQUAL, INVZERO, INVERT
+#include "snip/random_h.inc"             // Random.h:100-159: struct Random
+
+// ---- containers: glue, no arithmetic -------------------------------------------------------------------------------------------------
+typedef size_t IDX;
+// cList (List.h): the members the path uses, on std::vector.  GetNth is std::nth_element as in List.h:660-666.
+template <typename TYPE, typename ARG_TYPE = const TYPE&, int useConstruct = 1, int grow = 16, typename IDX_TYPE = IDX>
+class cList {
+public:
+	typedef TYPE Type; typedef IDX_TYPE IDX; typedef IDX_TYPE size_type; typedef TYPE value_type; typedef TYPE* iterator; typedef const TYPE* const_iterator;
+	typedef TYPE& reference; typedef const TYPE& const_reference;
+	cList() {}
+	cList(IDX size) : v((size_t)size) {}
+	cList(IDX size, IDX reserved) : v((size_t)size) { v.reserve((size_t)reserved); }
+	cList(const TYPE* b, const TYPE* e) : v(b, e) {}
+	inline IDX GetSize() const { return (IDX)v.size(); }
+	inline IDX size() const { return (IDX)v.size(); }
+	inline bool IsEmpty() const { return v.empty(); }
+	inline bool empty() const { return v.empty(); }
+	inline void Empty() { v.clear(); }
+	inline void Release() { v.clear(); v.shrink_to_fit(); }
+	inline void Reserve(IDX n) { v.reserve((size_t)n); }
+	inline void Resize(IDX n) { v.resize((size_t)n); }
+	inline void Insert(ARG_TYPE e) { v.push_back(e); }
+	template <typename... Args> inline TYPE& emplace_back(Args&&... args) { v.emplace_back(std::forward<Args>(args)...); return v.back(); }
+	inline void push_back(const TYPE& e) { v.push_back(e); }
+	inline TYPE& AddEmpty() { v.emplace_back(); return v.back(); }
+	inline const TYPE& operator[](IDX i) const { return v[(size_t)i]; }
+	inline TYPE& operator[](IDX i) { return v[(size_t)i]; }
+	inline TYPE* Begin() { return v.data(); } inline const TYPE* Begin() const { return v.data(); }
+	inline TYPE* End() { return v.data() + v.size(); } inline const TYPE* End() const { return v.data() + v.size(); }
+	inline TYPE* begin() { return Begin(); } inline const TYPE* begin() const { return Begin(); }
+	inline TYPE* end() { return End(); } inline const TYPE* end() const { return End(); }
+	inline const TYPE* cbegin() const { return Begin(); } inline const TYPE* cend() const { return End(); }
+	inline TYPE& First() { return v.front(); } inline const TYPE& First() const { return v.front(); }
+	inline TYPE& front() { return v.front(); } inline const TYPE& front() const { return v.front(); }
+	inline TYPE& Last() { return v.back(); } inline const TYPE& Last() const { return v.back(); }
+	inline TYPE& GetNth(IDX index) { TYPE* const nth(Begin() + index); std::nth_element(Begin(), nth, End()); return *nth; }
+	std::vector<TYPE> v;
+};
+#define CLISTDEF0(TYPE) SEACAVE::cList< TYPE, const TYPE&, 0 >
+#define CLISTDEF0IDX(TYPE,IDXTYPE) SEACAVE::cList< TYPE, const TYPE&, 0, 16, IDXTYPE >
+#define CLISTDEFIDX(TYPE,IDXTYPE) SEACAVE::cList< TYPE, const TYPE&, 1, 16, IDXTYPE >
+#define CLISTDEF2IDX(TYPE,IDXTYPE) SEACAVE::cList< TYPE, const TYPE&, 2, 16, IDXTYPE >
+#define ARR2IDX(arr) typename std::remove_reference<decltype(arr)>::type::size_type
+#define FOREACH(var, arr) for (ARR2IDX(arr) var=0, var##Size=(arr).size(); var<var##Size; ++var)
+typedef cList<float, float, 0> FloatArr;          // Types.h:427
+typedef cList<uint32_t, uint32_t, 0> IndexArr;
+
+template <typename TYPE, int m, int n> class TMatrix;
+template <typename TYPE, int DIMS> class TAABB;
+template <typename TYPE, int DIMS> class TRay;
+template <typename TYPE> class TPixel;
+template <typename TYPE> class TColor;
+template <typename TYPE> class TDMatrix;
+template <typename TYPE> class TQuaternion;
+#include "snip/types_h_tpoint2.inc"      // Types.h: class TPoint2
+#include "snip/types_h_tpoint3.inc"      // Types.h: class TPoint3
+#include "snip/types_h_tmatrix.inc"      // Types.h: class TMatrix
+typedef Point2i ImageRef;                // Types.h:2125
+
+// TImage (Types.h:2127-2222 on TDMatrix / cv::Mat_): storage glue; the coordinate tests and the two samplers are the reference's text.
+template <typename TYPE> class TImageStore {
+public:
+	typedef cv::Size Size;
+	inline const TYPE& operator()(int row, int col) const { return d.get()[(size_t)row * (size_t)sz.width + (size_t)col]; }
+	inline TYPE& operator()(int row, int col) { return d.get()[(size_t)row * (size_t)sz.width + (size_t)col]; }
+	inline Size size() const { return sz; }
+	Size sz; std::shared_ptr<TYPE> d;    // shallow copies share the pixels, as cv::Mat headers do
+};
+template <typename TYPE> class TImage : public TImageStore<TYPE> {
+public:
+	typedef TYPE Type;
+	typedef TImageStore<TYPE> Base;
+	typedef TImageStore<TYPE> BaseBase;
+	typedef cv::Size Size;
+	inline TImage() {}
+	inline TImage(const Size& s) { create(s); }
+	inline void create(const Size& s) { Base::sz = s; Base::d = std::shared_ptr<TYPE>(new TYPE[(size_t)s.width * s.height](), std::default_delete<TYPE[]>()); }
+	inline void create(int rows, int cols) { create(Size(cols, rows)); }
+	inline void release() { Base::sz = Size(); Base::d.reset(); }
+	inline bool empty() const { return !Base::d; }
+	inline int width() const { return Base::sz.width; }
+	inline int height() const { return Base::sz.height; }
+	inline int area() const { return Base::sz.width * Base::sz.height; }
+	inline TYPE* data() { return Base::d.get(); }
+	inline const TYPE& operator()(int row, int col) const { return Base::operator()(row, col); }
+	inline TYPE& operator()(int row, int col) { return Base::operator()(row, col); }
+	inline const TYPE& operator()(const ImageRef& pt) const { return Base::operator()(pt.y, pt.x); }   // Types.h:2148-2157
+	inline TYPE& operator()(const ImageRef& pt) { return Base::operator()(pt.y, pt.x); }
+#include "snip/types_h_isinside.inc"     // Types.h: isInside / isInsideWithBorder
+	template <typename T> TYPE sample(const TPoint2<T>& pt) const;
+	template <typename T, typename TV, typename Functor> bool sample(TV& v, const TPoint2<T>& pt, const Functor& functor) const;
+};
+typedef TImage<uint8_t> Image8U;
+typedef TImage<uint16_t> Image16U;
+typedef TImage<float> Image32F;
+typedef TImage<double> Image64F;
+
+// BitMatrix: only empty() / isSet(pt) are reached (MapMatrix2ZigzagIdx)
+class BitMatrix {
+public:
+	bool empty() const { return bits.empty(); }
+	void create(int w_, int h_) { w = w_; bits.assign((size_t)w_ * h_, 1); }
+	template <typename P> bool isSet(const P& pt) const { return bits[(size_t)pt.y * w + pt.x] != 0; }
+	std::vector<unsigned char> bits; int w = 0;
+};
+struct Thread { typedef long safe_t; static inline safe_t safeInc(volatile safe_t& v) { return ++v; } };   // one estimator thread: the sequential parity schedule
+struct CriticalSection {};
+typedef std::string String;
+
+#include "snip/types_inl_normsq.inc"     // Types.inl: normSq(Point_), normSq(Point3_)
+#include "snip/types_inl_norm.inc"       // Types.inl: norm(TPoint2), norm(TPoint3), norm(TMatrix)
+#include "snip/types_inl_point_ops.inc"  // Types.inl: TPoint2 / TPoint3 operators
+#include "snip/types_inl_matrix_ops.inc" // Types.inl: TMatrix operators
+#include "snip/types_inl_cast.inc"       // Types.inl: Cast<>() overloads
+#include "snip/types_inl_sample.inc"     // Types.inl: TImage::sample (bilinear)
+#include "snip/types_inl_sample_f.inc"   // Types.inl: TImage::sample (bilinear with validity functor)
+#include "snip/util_inl_project.inc"     // Util.inl: ProjectVertex_3x3_2_3
+#include "snip/util_inl_angle.inc"       // Util.inl: ComputeAngle
+#include "snip/util_inl_dir.inc"         // Util.inl: Normal2Dir, Dir2Normal
+#include "snip/util_inl_depth.inc"       // Util.inl: MaxDepthDifference, DepthSimilarity, IsDepthSimilar
+#include "snip/rotation_h_class.inc"     // Rotation.h: class TRMatrixBase
+#include "snip/rotation_inl_ctors.inc"   // Rotation.inl: constructors
+#include "snip/rotation_inl_set.inc"     // Rotation.inl: TRMatrixBase::Set(axis, angle)
+typedef TRMatrixBase<float> RMatrixBaseF;        // Rotation.h:586
+
+// TPlane (Plane.h:24-90): the two members the estimator touches; Distance() is the reference's text
+template <typename TYPE, int DIMS = 3> class TPlane {
+public:
+	typedef Eigen::Matrix<TYPE,DIMS,1> VECTOR;
+	typedef Eigen::Matrix<TYPE,DIMS,1> POINT;
+	VECTOR m_vN; TYPE m_fD;
+	inline TYPE Distance(const POINT&) const;
+};
+#include "snip/plane_inl_distance.inc"   // Plane.inl: TPlane::Distance(POINT)
+typedef TPlane<float> Planef;                    // Common.h:195
+typedef TMatrix<float,3,3> Matrix3x3f;           // Common.h:202
+typedef TPoint3<REAL> Point3;                    // Common.h:243
+typedef TMatrix<REAL,3,1> Vec3;                  // Common.h:245
+typedef TMatrix<REAL,3,3> Matrix3x3;             // Common.h:248
+typedef TRMatrixBase<REAL> RMatrixBase;          // Common.h:253
+typedef Point3 CMatrix; typedef RMatrixBase RMatrix; typedef Matrix3x3 KMatrix;   // Common.h:256-258
+template <typename R> void ComputeRelativeRotation(const R&, const R&, R&);       // named by an inline the path never calls
+} // namespace SEACAVE
+using namespace SEACAVE;
+
+namespace MVS {
+typedef uint32_t IIndex;                         // Image.h:48
+// CameraIntern / Camera (Camera.h:57-260): K, R, C and the members the path calls, in the reference's text
+class Camera {
+public:
+	KMatrix K; RMatrix R; CMatrix C;
+#include "snip/camera_h_invk.inc"        // Camera.h: InvK, GetInvK
+#include "snip/camera_h_i2c.inc"         // Camera.h: TransformPointI2C (both)
+};
+struct Image { uint32_t ID; };
+typedef CLISTDEFIDX(Image,IIndex) ImageArr;
+struct ViewScore { uint32_t ID; };
+typedef CLISTDEFIDX(ViewScore,IIndex) ViewScoreArr;
+typedef float Depth;                             // PointCloud.h:177-181
+typedef Point3f Normal;
+typedef TImage<Depth> DepthMap;
+typedef TImage<Normal> NormalMap;
+typedef TImage<float> ConfidenceMap;
+}

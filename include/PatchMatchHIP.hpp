@@ -20,7 +20,7 @@ class PatchMatchHIP {
 public:
 	struct Options : PMHipParams { Options() { pmhip_default_params(this); } };
 
-	explicit PatchMatchHIP(int device = 0) : engine_(nullptr), geom_(false), ignoreMaskOption_(false) {
+	explicit PatchMatchHIP(int device = 0) : engine_(nullptr), geom_(false), ignoreMaskOption_(false), round_(0) {
 		// like PatchMatchCUDA::PatchMatchCUDA (PatchMatchCUDA.cpp:46-51); IsValid() == false plays the role of
 		// "CUDA::devices.IsEmpty()" at SceneDensify.cpp:1876-1877 (the caller then releases the plug-in)
 		if (pmhip_create(device, &engine_) != PMHIP_OK) engine_ = nullptr;
@@ -35,6 +35,15 @@ public:
 	// OPTDENSE::nIgnoreMaskLabel >= 0 (DepthData::mask may still be empty for a view without a mask file; the option alone changes the
 	// level hand-off to INTER_NEAREST, SceneDensify.cpp:661)
 	void SetIgnoreMaskOption(bool on) { ignoreMaskOption_ = on; }
+
+	// The reference's call site is `pmCUDA->EstimateDepthMap(arrDepthData[idxImage]);` (SceneDensify.cpp:620) -- one argument, with the options
+	// in the OPTDENSE globals and the pass implied by Init(bGeomConsistency).  Bind both beforehand and that line compiles unchanged:
+	//   SetOptions(opt) once (next to `pmCUDA->Init(...)`, :1880 / :1915), SetRound(geoIter) at the top of each geometric round (:1909-1916).
+	void SetOptions(const Options& opt) { opt_ = opt; }
+	const Options& GetOptions() const { return opt_; }
+	void SetRound(int nGeometricIter) { round_ = nGeometricIter < 0 ? 0 : nGeometricIter; }
+	template <typename DepthDataT>
+	void EstimateDepthMap(DepthDataT& depthData) { EstimateDepthMap(depthData, opt_, geom_ ? round_ : -1); }
 
 	// nGeometricIter: the argument of DepthMapsData::EstimateDepthMap (SceneDensify.cpp:616), -1 for the photometric pass.
 	// The reference's PatchMatchCUDA infers it from Init(true); pass it explicitly here so the round index reaches the RNG key.
@@ -82,6 +91,8 @@ private:
 	}
 	pmhip_engine* engine_;
 	bool geom_, ignoreMaskOption_;
+	int round_;
+	Options opt_;
 };
 
 } // namespace MVS

@@ -150,7 +150,8 @@ int pmhip_scene_set_conf(pmhip_engine* e, int idx, const float* conf);
 int pmhip_scene_get_maps(pmhip_engine* e, int idx, float* depth, float* normal, float* conf);
 /* Device pointers for collectives (RCCL all-gather of the snapshot / broadcast of images).
  * what: 0 image level 0, 1 depth, 2 normal, 3 conf, 4 snapshot depth.  The per-kind arrays are
- * single contiguous allocations ordered by view index, so idx 0 addresses the whole set. */
+ * single contiguous allocations ordered by view index, so idx 0 addresses the whole set.  After writing images call pmhip_scene_images_updated,
+ * after writing depth maps pmhip_scene_maps_updated: the engine cannot see writes through these pointers. */
 void* pmhip_scene_device_ptr(pmhip_engine* e, int what, int idx);
 /* DepthMapsData::FilterDepthMap (SceneDensify.cpp:1050-1299) for each view of viewIds against its first <= 8 neighbours
  * (Scene::DenseReconstructionFilter, :2136-2170): cross-view splat + z-test, then the confidence-weighted fusion
@@ -199,6 +200,11 @@ uint64_t pmhip_scene_fuse_rounds(pmhip_engine* e);
 int pmhip_scene_copy(pmhip_engine* e, int what, int firstIdx, int count, void* devPtr, int toEngine);
 /* Rebuild image pyramids after image level 0 was written through pmhip_scene_device_ptr. */
 int pmhip_scene_images_updated(pmhip_engine* e);
+/* Depth maps of views [firstIdx, firstIdx + count) were written through pmhip_scene_device_ptr(e, 1, ...) (e.g. by an RCCL all-gather straight
+ * into the depth array): marks them as holding a depth map, which pmhip_scene_filter / pmhip_scene_fuse require of a neighbour before they use it
+ * (DepthData::IsValid(), SceneDensify.cpp:2150-2163).  pmhip_scene_estimate, _set_maps and _copy(what == 1, toEngine) do this themselves; a raw
+ * pointer write cannot, and such neighbours would be skipped without this call. */
+int pmhip_scene_maps_updated(pmhip_engine* e, int firstIdx, int count);
 int pmhip_sync(pmhip_engine* e);
 /* Engine stream (hipStream_t) so callers can bracket work with their own events. */
 void* pmhip_stream(pmhip_engine* e);

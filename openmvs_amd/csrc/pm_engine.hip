@@ -635,6 +635,11 @@ int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevi
 }
 
 int pmhip_scene_images_updated(pmhip_engine* e) { if (!e) return PMHIP_E_ARG; e->pyramidDirty = true; return 0; }
+int pmhip_scene_maps_updated(pmhip_engine* e, int firstIdx, int count) {
+	if (!e || firstIdx < 0 || count < 0 || firstIdx + count > e->nImages) return PMHIP_E_ARG;
+	for (int i = firstIdx; i < firstIdx + count; ++i) e->views[i].hasMaps = true;
+	return 0;
+}
 
 
 // A source view whose image has its own size (see SceneView::sw): same as pmhip_scene_set_view otherwise.

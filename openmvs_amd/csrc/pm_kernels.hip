@@ -555,7 +555,7 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 						const float B2 = (Tr[6] * Xd0 + Tr[7] * Xd1 + Tr[8] * Xd2) + Tn[2];
 						const float xbx = B0 / B2, xby = B1 / B2;
 						const float dx = (float)x - xbx, dy = (float)y - xby;
-						const float dist = pm_hypot_d(dx, dy); // cv::norm(Point2f) -> double
+						const float dist = pm_sqrtf(dx * dx + dy * dy); // norm(Point2f) = SEACAVE::norm(TPoint2<float>): float (Types.inl:1021-1024); pinned by oracle/_ref
 						consistency = pm_minf(pm_sqrtf(dist * (dist + 2.f)), consistency);
 					}
 				}

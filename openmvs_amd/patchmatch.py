@@ -54,7 +54,7 @@ class PMHipFuseParams(C.Structure):
 EXPORTS = ["pmhip_scene_set_view_sized", "pmhip_scene_set_source_depth", "pmhip_scene_set_mask", "pmhip_scene_set_mask_mode", "pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
            "pmhip_estimate_depth_map", "pmhip_estimate_depth_map_masked", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
            "pmhip_scene_estimate", "pmhip_scene_commit_round", "pmhip_scene_reset_view", "pmhip_scene_set_maps",
-           "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_remove_small_segments", "pmhip_scene_images_updated", "pmhip_sync",
+           "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_remove_small_segments", "pmhip_scene_images_updated", "pmhip_scene_maps_updated", "pmhip_sync",
            "pmhip_stream", "pmhip_stats_reset", "pmhip_stats_get", "pmhip_prof_get", "pmhip_math_eval", "pmhip_resize"]
 
 _LIB = None
@@ -295,6 +295,10 @@ class PatchMatchHIP:
 
     def scene_images_updated(self):
         self._chk(self._lib.pmhip_scene_images_updated(self._h))
+
+    def scene_maps_updated(self, first, count):
+        """Depth maps of these views were written through scene_device_ptr(1, ...): see include/pmhip.h."""
+        self._chk(self._lib.pmhip_scene_maps_updated(self._h, int(first), int(count)))
 
     def sync(self):
         self._chk(self._lib.pmhip_sync(self._h))

@@ -236,7 +236,8 @@ struct Opt {
 	// oracle controls
 	uint32_t seed = 0;       // RNG seed
 	uint32_t viewID = 0;     // mixed into the Philox key
-	int rngMode = 0;         // 0 = Philox per (pixel,attempt); 1 = mt19937 in traversal order
+	int rngMode = 0;         // 0 = Philox per (pixel,attempt); 1 = mt19937 in traversal order (theta drawn before phi); 2 = the same with the two-draw
+	                         // expressions evaluated right to left, as GCC compiles the reference (DepthMap.h:441, DepthMap.cpp:836) -- what oracle/_ref is compared with
 	int nThreads = 1;        // 1 = sequential parity oracle; >1 = reference threading model (timing baseline)
 };
 
@@ -456,7 +457,7 @@ struct DepthEstimator {
 						for (int i = 0; i < 3; ++i) Xb[i] = (image1.Tr[i*3]*Xd[0] + image1.Tr[i*3+1]*Xd[1] + image1.Tr[i*3+2]*Xd[2]) + image1.Tn[i];
 						const float xbx = Xb[0] / Xb[2], xby = Xb[1] / Xb[2];
 						const float dx = (float)x0x - xbx, dy = (float)x0y - xby;
-						const float dist = pm_hypot_d(dx, dy); // cv::norm(Point2f) is double
+						const float dist = pm_sqrtf(dx * dx + dy * dy); // norm(Point2f) binds to SEACAVE::norm(const TPoint2<float>&) (Types.inl:1021-1024): float, not cv::norm's double -- pinned by oracle/_ref
 						consistency = pm_minf(pm_sqrtf(dist * (dist + 2.f)), consistency);
 					}
 				}
@@ -504,8 +505,8 @@ struct DepthEstimator {
 	void RandomNormal(const float* viewRay, float* normal) {
 		const float a0 = FD2R(0.f), a1 = FD2R(180.f), b0 = FD2R(90.f), b1 = FD2R(180.f);
 		float p[2];
-		p[0] = a0 + (a1 - a0) * rnd.unit(1);
-		p[1] = b0 + (b1 - b0) * rnd.unit(2);
+		if (rnd.mode == 2) { p[1] = b0 + (b1 - b0) * rnd.unit(2); p[0] = a0 + (a1 - a0) * rnd.unit(1); }   // GCC evaluates Point2f(a, b)'s arguments right to left
+		else { p[0] = a0 + (a1 - a0) * rnd.unit(1); p[1] = b0 + (b1 - b0) * rnd.unit(2); }
 		Dir2Normal(p, normal);
 		if (normal[0]*viewRay[0] + normal[1]*viewRay[1] + normal[2]*viewRay[2] > 0) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
 	}
@@ -631,8 +632,8 @@ struct DepthEstimator {
 			if (!(dMin <= ndepth && ndepth < dMax))
 				continue;
 			float np[2];
-			np[0] = p[0] + (angle1Range * scaleRange) * (2.f * rnd.unit(1) - 1.f);
-			np[1] = p[1] + (angle2Range * scaleRange) * (2.f * rnd.unit(2) - 1.f);
+			if (rnd.mode == 2) { np[1] = p[1] + (angle2Range * scaleRange) * (2.f * rnd.unit(2) - 1.f); np[0] = p[0] + (angle1Range * scaleRange) * (2.f * rnd.unit(1) - 1.f); }
+			else { np[0] = p[0] + (angle1Range * scaleRange) * (2.f * rnd.unit(1) - 1.f); np[1] = p[1] + (angle2Range * scaleRange) * (2.f * rnd.unit(2) - 1.f); }
 			Dir2Normal(np, nnormal);
 			if (nnormal[0]*viewDir[0] + nnormal[1]*viewDir[1] + nnormal[2]*viewDir[2] >= 0)
 				continue;
@@ -918,6 +919,47 @@ int orc_estimate_depth_map_masked(const OrcView* views, int nViews, float* depth
 // The small per-pixel helpers of ProcessPixel at pixel (x, y), for the second-reading tests: InterpolatePixel of the neighbour estimate
 // (nx, ny, ndepth, nnormal) to (x, y), CorrectNormal of that normal, and the smoothness factor of the hypothesis plane (hypDepth, hypNormal)
 // with respect to that neighbour.
+// One pyramid level with one estimator thread, pass by pass -- the unit oracle/_ref (the reference's own code, oracle/ref/ref_harness.cpp:ref_run_level)
+// exposes, with the same arguments: init pass (ScoreDepthMapTmp) if doInit, sweeps iterBegin..iterEnd-1, EndDepthMapTmp with threshold thEnd if thEnd >= 0.
+// pass keys of the Philox mode as in EstimateDepthMap at level 0; with rngMode 1 / 2 every estimator restarts its mt19937 from the default seed.
+int orc_run_level(const OrcView* views, int nViews, float* depth, float* normal, float* conf, const float* prior,
+		float dMin, float dMax, const OrcOpt* opt, int doInit, unsigned iterBegin, unsigned iterEnd, float thEnd, const unsigned char* mask) {
+	if (nViews < 2) return -1;
+	orc::DepthData dd; loadDepthData(views, nViews, depth, normal, dMin, dMax, dd);
+	const orc::Opt o = toOpt(opt);
+	const int w = views[0].w, h = views[0].h;
+	for (auto& v : dd.images) v.Init(dd.images[0].camera);
+	dd.confMap.create(w, h); memcpy(dd.confMap.d.data(), conf, sizeof(float) * (size_t)w * h);
+	orc::ImgF pr; if (prior) { pr.create(w, h); memcpy(pr.d.data(), prior, sizeof(float) * (size_t)w * h); }
+	std::vector<orc::Weight> weightMap0((size_t)w * h);
+	if (mask) for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) if (!mask[(size_t)y * w + x]) {
+		dd.depthMap(y, x) = 0; float* n = dd.normalMap.at(y, x); n[0] = n[1] = n[2] = 0; dd.confMap(y, x) = 0; }
+	std::vector<std::pair<uint16_t,uint16_t>> coords;
+	orc::MapMatrix2ZigzagIdx(w, h, coords, 64, mask);
+	std::atomic<long> idxPixel;
+	auto run = [&](unsigned iter, uint32_t pass, void (*fn)(orc::DepthEstimator&)) {
+		uint32_t k0, k1; orc::passKey(o.seed, o.viewID, pass, k0, k1);
+		idxPixel = -1;
+		orc::DepthEstimator e(iter, dd, idxPixel, weightMap0, coords, o, k0, k1);
+		e.lowResDepthMap = prior ? &pr : nullptr;
+		fn(e);
+	};
+	if (doInit) run(iterBegin, 32, orc::ScoreDepthMapTmp);
+	for (unsigned iter = iterBegin; iter < iterEnd; ++iter) run(iter, iter, orc::EstimateDepthMapTmp);
+	if (thEnd >= 0) {
+		// EndDepthMapTmp walks the pixel list (SceneDensify.cpp:533): pixels outside it are left as they are
+		for (const auto& c : coords) {
+			const int x = c.first, y = c.second;
+			float& d = dd.depthMap(y, x); float& cf = dd.confMap(y, x);
+			if (d <= 0 || cf >= thEnd) { cf = 0; d = 0; float* n = dd.normalMap.at(y, x); n[0] = n[1] = n[2] = 0; }
+			else cf = cf >= 1.f ? 0.f : 1.f - cf;
+		}
+	}
+	const size_t n = (size_t)w * h;
+	memcpy(depth, dd.depthMap.d.data(), n * 4); memcpy(normal, dd.normalMap.d.data(), n * 12); memcpy(conf, dd.confMap.d.data(), n * 4);
+	return 0;
+}
+
 int orc_pixel_helpers(const OrcView* views, int nViews, const OrcOpt* opt, int x, int y, float dMin, float dMax, int nx, int ny, float ndepth, const float* nnormal,
 		float hypDepth, const float* hypNormal, float* outInterpDepth, float* outCorrected, float* outSmoothFactor) {
 	orc::DepthData dd; loadDepthData(views, nViews, nullptr, nullptr, dMin, dMax, dd);

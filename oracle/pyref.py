@@ -1,0 +1,103 @@
+"""ctypes binding of oracle/_ref -- the reference's own estimator sources compiled against oracle/ref/shim (see oracle/ref/build_ref.py).
+
+TEST INFRASTRUCTURE ONLY.  Used by tests/test_ref_pinning.py to pin oracle/pm_oracle.cpp to the reference's code: same arrays in, compared bit
+for bit.  The libraries are built in the build container (where /root/reference exists) and travel to the GPU box as files."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from oracle import pyoracle as po
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+def path(kind: str = "pm_math") -> str:
+    return os.path.join(_HERE, "_ref", "libref_pm.so" if kind == "pm_math" else "libref_pm_libm.so")
+
+
+def available(kind: str = "pm_math") -> bool:
+    if os.path.exists(path(kind)):
+        return True
+    try:
+        from oracle.ref import build_ref
+        build_ref.build()
+    except Exception:
+        return False
+    return os.path.exists(path(kind))
+
+
+def lib(kind: str = "pm_math") -> C.CDLL:
+    if kind not in _LIBS:
+        if not available(kind):
+            raise RuntimeError("oracle/_ref is not built and /root/reference is not here to build it from")
+        l = C.CDLL(path(kind))
+        l.ref_run_level.restype = C.c_int
+        l.ref_math_kind.restype = C.c_char_p
+        _LIBS[kind] = l
+    return _LIBS[kind]
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _run(fn, views, n_views, depth, normal, conf, prior, dmin, dmax, opt, do_init, iter_begin, iter_end, th_end, mask):
+    h, w = views[0].h, views[0].w
+    depth = np.ascontiguousarray(depth, np.float32).copy(); normal = np.ascontiguousarray(normal, np.float32).copy(); conf = np.ascontiguousarray(conf, np.float32).copy()
+    assert depth.shape == (h, w) and normal.shape == (h, w, 3) and conf.shape == (h, w)
+    pr = None if prior is None else np.ascontiguousarray(prior, np.float32)
+    mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    rc = fn(views, C.c_int(n_views), _fp(depth), _fp(normal), _fp(conf), _fp(pr) if pr is not None else None, C.c_float(dmin), C.c_float(dmax), C.byref(opt),
+            C.c_int(1 if do_init else 0), C.c_uint(iter_begin), C.c_uint(iter_end), C.c_float(th_end), mk.ctypes.data_as(C.POINTER(C.c_ubyte)) if mk is not None else None)
+    if rc:
+        raise RuntimeError("run_level failed: %d" % rc)
+    return depth, normal, conf
+
+
+def ref_run_level(views, n_views, depth, normal, conf, dmin, dmax, opt, do_init=True, iter_begin=0, iter_end=0, th_end=-1.0, prior=None, mask=None, kind="pm_math"):
+    """One pyramid level through the reference's own code (oracle/ref/ref_harness.cpp)."""
+    return _run(lib(kind).ref_run_level, views, n_views, depth, normal, conf, prior, dmin, dmax, opt, do_init, iter_begin, iter_end, th_end, mask)
+
+
+def orc_run_level(views, n_views, depth, normal, conf, dmin, dmax, opt, do_init=True, iter_begin=0, iter_end=0, th_end=-1.0, prior=None, mask=None):
+    """The same unit through oracle/pm_oracle.cpp."""
+    l = po.lib(); l.orc_run_level.restype = C.c_int
+    return _run(l.orc_run_level, views, n_views, depth, normal, conf, prior, dmin, dmax, opt, do_init, iter_begin, iter_end, th_end, mask)
+
+
+# ---- SemiGlobalMatcher::Match through the reference's own code (oracle/ref/ref_sgm_harness.cpp) ----------------------------------------------
+def sgm_available() -> bool:
+    return available() and os.path.exists(os.path.join(_HERE, "_ref", "libref_sgm.so"))
+
+
+def _sgm_lib():
+    if "sgm" not in _LIBS:
+        available()
+        _LIBS["sgm"] = C.CDLL(os.path.join(_HERE, "_ref", "libref_sgm.so"))
+    return _LIBS["sgm"]
+
+
+def ref_sgm_generate_p2s(P2=4, alpha=14.0, beta=38.0):
+    out = np.zeros(256, np.uint16)
+    _sgm_lib().ref_sgm_generate_p2s(C.c_uint16(P2), C.c_float(alpha), C.c_float(beta), out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return out
+
+
+def ref_sgm_match(left_bgr, left_gray, right_gray, pixels, num_costs, max_num_disp, P1, P2s):
+    """Same arguments and results as pyoracle.sgm_match."""
+    lb = np.ascontiguousarray(left_bgr, np.uint8); lg = np.ascontiguousarray(left_gray, np.float32); rg = np.ascontiguousarray(right_gray, np.float32)
+    h, w = lg.shape
+    px = np.ascontiguousarray(pixels); p2 = np.ascontiguousarray(P2s, np.uint16)
+    d = np.zeros((h - 6, w - 6), np.int16); c = np.zeros((h - 6, w - 6), np.uint16)
+    costs = np.zeros(num_costs, np.uint8); acc = np.zeros(num_costs, np.uint16)
+    l = _sgm_lib(); l.ref_sgm_match.restype = C.c_int
+    rc = l.ref_sgm_match(lb.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(lg), _fp(rg), C.c_int(w), C.c_int(h), px.ctypes.data_as(C.c_void_p),
+                         C.c_uint64(num_costs), C.c_int(max_num_disp), C.c_uint16(P1), p2.ctypes.data_as(C.POINTER(C.c_uint16)),
+                         d.ctypes.data_as(C.POINTER(C.c_int16)), c.ctypes.data_as(C.POINTER(C.c_uint16)),
+                         costs.ctypes.data_as(C.POINTER(C.c_uint8)), acc.ctypes.data_as(C.POINTER(C.c_uint16)))
+    assert rc == 0
+    return d, c, costs, acc

@@ -1,0 +1,99 @@
+"""oracle/_ref: the reference's own hot-path sources, compiled where they lie.            *** TEST INFRASTRUCTURE ONLY ***
+
+    python oracle/ref/build_ref.py            # needs /root/reference (this container); the GPU box uses the prebuilt oracle/_ref/*.so
+
+What is compiled is the text of /root/reference (OpenMVS v2.3.0) itself: this script cuts the line ranges listed in SNIPPETS out of the reference's
+headers and sources into a scratch directory (deleted afterwards; nothing of the reference is copied into this repository), and compiles them,
+unmodified, together with oracle/ref/ref_harness.cpp against oracle/ref/shim/ -- the minimal stand-ins for OpenCV, Eigen and the SEACAVE containers
+that the image lacks.  Every range is checked against the first and last line it must start and end with, so a different reference revision fails
+loudly instead of compiling something else.
+
+Outputs (git-ignored, shipped to the GPU box with the snapshot):
+    oracle/_ref/libref_pm.so        transcendentals routed to csrc/pm_math.h  -> compared bit for bit with oracle/pm_oracle.cpp
+    oracle/_ref/libref_pm_libm.so   transcendentals from libm (as a reference binary) -> bounds what the pm_math.h substitution changes
+    oracle/_ref/libref_sgm.so       SemiGlobalMatcher::Match (cost volume, 8-path aggregation, WTA) -> compared bit for bit with oracle/sgm_oracle.cpp
+"""
+import os, shutil, subprocess, sys, tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("OPENMVS_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "oracle", "_ref")
+
+# name: (file relative to the reference, first line, last line, text the first line must contain, text the last line must contain)
+SNIPPETS = {
+    "types_h_funcs":         ("libs/Common/Types.h", 615, 644, "template<typename T>", "}"),
+    "types_h_tests":         ("libs/Common/Types.h", 1185, 1237, "inline bool   ISINFORNAN(float x)", "SAFEDIVIDE"),
+    "types_h_tpoint2":       ("libs/Common/Types.h", 1256, 1345, "// 2D point struct", "typedef TPoint2<double> Point2d;"),
+    "types_h_tpoint3":       ("libs/Common/Types.h", 1349, 1438, "// 3D point struct", "typedef TPoint3<double> Point3d;"),
+    "types_h_tmatrix":       ("libs/Common/Types.h", 1442, 1548, "// matrix struct", "TMatrix<TYPE,m,n>::INF("),
+    "types_h_isinside":      ("libs/Common/Types.h", 1617, 1651, "/// Is this coordinate inside the 2D matrix?", "}"),
+    "types_inl_normsq":      ("libs/Common/Types.inl", 794, 803, "template <typename TYPE>", "}"),
+    "types_inl_norm":        ("libs/Common/Types.inl", 1021, 1033, "template <typename TYPE>", "}"),
+    "types_inl_point_ops":   ("libs/Common/Types.inl", 1178, 1366, "// operators", "}"),
+    "types_inl_matrix_ops":  ("libs/Common/Types.inl", 1430, 1474, "// TMatrix operators", "}"),
+    "types_inl_cast":        ("libs/Common/Types.inl", 1677, 1709, "// Point2", "}"),
+    "types_inl_sample":      ("libs/Common/Types.inl", 2270, 2281, "// sample by bilinear interpolation", "}"),
+    "types_inl_sample_f":    ("libs/Common/Types.inl", 2296, 2314, "// sample by bilinear interpolation, using only pixels that meet the user condition", "}"),
+    "util_inl_project":      ("libs/Common/Util.inl", 380, 386, "// (optimized ProjectVertex for H[3,3] and X[2,1], output pt[3,1])", "} // ProjectVertex_3x3_2_3"),
+    "util_inl_angle":        ("libs/Common/Util.inl", 540, 546, "// given two 3D vectors,", "} // ComputeAngle"),
+    "util_inl_dir":          ("libs/Common/Util.inl", 752, 766, "// Encodes/decodes a normalized 3D vector in two parameters for the direction", "}"),
+    "util_inl_depth":        ("libs/Common/Util.inl", 789, 809, "template<typename T>", "}"),
+    "rotation_h_class":      ("libs/Common/Rotation.h", 265, 584, "template <typename TYPE>", "}; // class"),
+    "rotation_inl_ctors":    ("libs/Common/Rotation.inl", 519, 558, "template <typename TYPE>", "}"),
+    "rotation_inl_set":      ("libs/Common/Rotation.inl", 700, 729, "template <typename TYPE>", "}"),
+    "random_h":              ("libs/Common/Random.h", 100, 159, "// Encapsulates state for random number generation", "};"),
+    "camera_h_invk":         ("libs/MVS/Camera.h", 175, 188, "// return K.inv() (assuming standard K format and no shear)", "}"),
+    "camera_h_i2c":          ("libs/MVS/Camera.h", 329, 344, "// un-project from image pixel coords to the camera space (z=1 plane by default)", "}"),
+    "plane_inl_distance":    ("libs/Common/Plane.inl", 185, 190, "// Calculate distance to point. Plane normal must be normalized.", "}"),
+    "depthmap_h":            ("libs/MVS/DepthMap.h", 41, 468, "// D E F I N E S", "};"),
+    "depthmap_cpp":          ("libs/MVS/DepthMap.cpp", 325, 972, "// create the map for converting index to matrix position", "#endif"),
+    "sgm_h_defines":         ("libs/MVS/SemiGlobalMatcher.h", 44, 46, "#define SGM_SIMILARITY_WZNCC 1", "#define SGM_SIMILARITY SGM_SIMILARITY_WZNCC"),
+    "sgm_h_class":           ("libs/MVS/SemiGlobalMatcher.h", 57, 206, "// An implementation of the popular Semi-Global Matching (SGM) algorithm.", "};"),
+    "sgm_cpp_events":        ("libs/MVS/SemiGlobalMatcher.cpp", 438, 492, "enum EVENT_TYPE {", "};"),
+    "sgm_cpp_ctor":          ("libs/MVS/SemiGlobalMatcher.cpp", 506, 524, "SemiGlobalMatcher::SemiGlobalMatcher(SgmSubpixelMode _subpixelMode", "}"),
+    "sgm_cpp_match":         ("libs/MVS/SemiGlobalMatcher.cpp", 863, 1302, "void SemiGlobalMatcher::Match(const ViewData& leftImage", "}"),
+    "scenedensify_cpp":      ("libs/MVS/SceneDensify.cpp", 489, 576, "// initialize the confidence map (NCC score map) with the score of the current estimates", "}"),
+}
+
+
+def cut(dst):
+    os.makedirs(os.path.join(dst, "snip"), exist_ok=True)
+    for name, (rel, a, b, first, last) in SNIPPETS.items():
+        lines = open(os.path.join(REF, rel), encoding="utf-8", errors="replace").read().split("\n")
+        body = lines[a - 1:b]
+        if first not in body[0] or last not in body[-1]:
+            raise SystemExit("%s:%d-%d does not start / end as expected (%r ... %r): not the reference revision this recipe was written for" % (rel, a, b, body[0], body[-1]))
+        with open(os.path.join(dst, "snip", name + ".inc"), "w") as f:
+            f.write("#line %d \"%s\"\n" % (a, os.path.join(REF, rel)))
+            f.write("\n".join(body) + "\n")
+
+
+def build(verbose=False):
+    if not os.path.isdir(REF):
+        return [p for p in (os.path.join(OUT, n) for n in ("libref_pm.so", "libref_pm_libm.so", "libref_sgm.so")) if os.path.exists(p)]
+    os.makedirs(OUT, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix="refsnip_")
+    outs = []
+    try:
+        cut(tmp)
+        for name, flags, src in (("libref_pm.so", ["-DREF_MATH_PM"], "ref_harness.cpp"), ("libref_pm_libm.so", [], "ref_harness.cpp"),
+                                 ("libref_sgm.so", ["-DREF_MATH_PM"], "ref_sgm_harness.cpp")):
+            out = os.path.join(OUT, name)
+            cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-w", "-I", tmp, "-I", os.path.join(HERE, "shim")] + flags + \
+                  [os.path.join(HERE, src), "-o", out]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            outs.append(out)
+    finally:
+        if not os.environ.get("REF_KEEP_SNIPPETS"):
+            shutil.rmtree(tmp, ignore_errors=True)
+        else:
+            print("snippets kept in", tmp)
+    return outs
+
+
+if __name__ == "__main__":
+    for p in build(verbose=True):
+        print("built", p)

@@ -1,0 +1,78 @@
+// ref_sgm_harness.cpp -- TEST INFRASTRUCTURE ONLY (oracle/_ref).  The reference's SemiGlobalMatcher::Match(ViewData, ViewData, ...) --
+// cost volume, 8-path aggregation (the threaded variant, which is the parity target) and winner-take-all, SemiGlobalMatcher.cpp:863-1302 -- cut
+// verbatim from /root/reference by oracle/ref/build_ref.py and compiled against oracle/ref/shim.  The worker-thread pool is replaced by a stand-in
+// that runs every queued job at once on the calling thread (one "worker"): the jobs of a pass only add into disjoint or commutative sums.
+#include <functional>
+#include "seacave_min.h"
+#define DECLARE_NO_INDEX(T) std::numeric_limits<T>::max()
+#define ROUND2INT SEACAVE::Round2Int
+namespace SEACAVE {
+template <typename INTTYPE = int> inline INTTYPE Round2Int(float x) { return static_cast<INTTYPE>(floor(x + .5f)); }     // Types.h:949-955 without _FAST_FLOAT2INT
+template <typename INTTYPE = int> inline INTTYPE Round2Int(double x) { return static_cast<INTTYPE>(floor(x + .5)); }
+template <typename TYPE> class TPixel { public: union { struct { TYPE b, g, r; }; TYPE c[3]; };             // Types.h:1873-1895 (_COLORMODE BGR)
+	inline const TYPE& operator[](size_t i) const { return c[i]; } inline TYPE& operator[](size_t i) { return c[i]; } };
+typedef TPixel<uint8_t> Pixel8U;
+typedef TImage<Pixel8U> Image8U3;
+typedef TMatrix<REAL,4,4> Matrix4x4;
+class Event { public: Event(uint32_t) {} virtual ~Event() {} virtual bool Run(void* = NULL) { return true; } };
+struct Semaphore {};
+class EventThreadPool {                    // one worker that runs a job the moment it is queued
+public:
+	typedef size_t size_type;
+	size_t n = 1;
+	bool empty() const { return n == 0; } bool IsEmpty() const { return true; } size_t size() const { return n; }
+	void AddEvent(Event* e) { e->Run(NULL); delete e; }
+};
+inline Thread::safe_t safeDecShim(volatile Thread::safe_t& v) { return --v; }
+}
+namespace MVS { class Scene; class PointCloud;
+template <int nTexels> struct WeightedPatchFix { struct Pixel { float weight; float tempWeight; }; Pixel weights[nTexels]; float sumWeights; float normSq0; WeightedPatchFix() : normSq0(0) {} };   // DepthMap.h:143-153
+#include "snip/sgm_h_defines.inc"          // SemiGlobalMatcher.h:44-46
+namespace STEREO {
+#include "snip/sgm_h_class.inc"            // SemiGlobalMatcher.h:57-204: class SemiGlobalMatcher
+} }
+using namespace MVS; using namespace MVS::STEREO;
+struct ThreadX : Thread { static inline safe_t safeDec(volatile safe_t& v) { return --v; } };
+#define Thread ThreadX
+#include "snip/sgm_cpp_events.inc"         // SemiGlobalMatcher.cpp:436-492: EVTPixelProcess, EVTPixelAccumInc, EVTPixelAccumDec
+#include "snip/sgm_cpp_ctor.inc"           // SemiGlobalMatcher.cpp:513-529: constructor, destructor, GenerateP2s
+#include "snip/sgm_cpp_match.inc"          // SemiGlobalMatcher.cpp:863-1302: Match
+#undef Thread
+EventThreadPool SemiGlobalMatcher::threads;
+Semaphore SemiGlobalMatcher::sem;
+void SemiGlobalMatcher::WaitThreadWorkers(unsigned) {}
+
+namespace {
+struct Access : SemiGlobalMatcher {       // reaches the protected members Match() works on
+	using SemiGlobalMatcher::Match; using SemiGlobalMatcher::imagePixels; using SemiGlobalMatcher::imageCosts; using SemiGlobalMatcher::imageAccumCosts;
+	using SemiGlobalMatcher::maxNumDisp; using SemiGlobalMatcher::P1; using SemiGlobalMatcher::P2s; using SemiGlobalMatcher::GenerateP2s;
+};
+}
+extern "C" {
+void ref_sgm_generate_p2s(uint16_t P2, float alpha, float beta, uint16_t* out256) {
+	const auto p = Access::GenerateP2s(P2, alpha, beta);
+	for (int i = 0; i < 256; ++i) out256[i] = p[i];
+}
+// same arguments as orc_sgm_match (oracle/sgm_oracle.cpp); pixels: (w-6)*(h-6) entries {u64 idx; i16 min, max; pad}
+int ref_sgm_match(const uint8_t* colorL, const float* grayL, const float* grayR, int w, int h, const void* pixels, uint64_t numCosts, int maxNumDisp, uint16_t P1, const uint16_t* P2s,
+		int16_t* disparity, uint16_t* cost, uint8_t* costsOut, uint16_t* accumsOut) {
+	struct PD { uint64_t idx; int16_t mn, mx; };
+	static_assert(sizeof(PD) == 16 && sizeof(SemiGlobalMatcher::PixelData) == 16, "PixelData layout");
+	Access m;
+	m.P1 = P1; for (int i = 0; i < 256; ++i) m.P2s[i] = P2s[i];
+	const int vw = w - 6, vh = h - 6;
+	m.imagePixels.Resize((SemiGlobalMatcher::Index)vw * vh);
+	memcpy(m.imagePixels.Begin(), pixels, sizeof(PD) * (size_t)vw * vh);
+	m.imageCosts.Resize(numCosts); m.imageAccumCosts.Resize(numCosts); m.maxNumDisp = (SemiGlobalMatcher::Disparity)maxNumDisp;
+	SemiGlobalMatcher::ViewData L, R;
+	L.imageColor.create(cv::Size(w, h)); memcpy(L.imageColor.data(), colorL, (size_t)w * h * 3);
+	L.imageGray.create(cv::Size(w, h)); memcpy(L.imageGray.data(), grayL, sizeof(float) * (size_t)w * h);
+	R.imageGray.create(cv::Size(w, h)); memcpy(R.imageGray.data(), grayR, sizeof(float) * (size_t)w * h);
+	SemiGlobalMatcher::DisparityMap d; SemiGlobalMatcher::AccumCostMap c;
+	m.Match(L, R, d, c);
+	memcpy(disparity, d.data(), sizeof(int16_t) * (size_t)vw * vh); memcpy(cost, c.data(), sizeof(uint16_t) * (size_t)vw * vh);
+	if (costsOut) memcpy(costsOut, m.imageCosts.Begin(), numCosts);
+	if (accumsOut) memcpy(accumsOut, m.imageAccumCosts.Begin(), numCosts * 2);
+	return 0;
+}
+}

@@ -196,6 +196,7 @@ template<typename _Tp, typename _AccTp> static inline _AccTp normL2Sqr(const _Tp
 	for (; i < n; i++) { _AccTp v = a[i]; s += v*v; }
 	return s;
 }
+template<typename _Tp, int m, int n> static inline double trace(const Matx<_Tp, m, n>& a) { _Tp s = 0; for (int i = 0; i < (m < n ? m : n); i++) s += a(i,i); return s; }
 template<typename _Tp, int m, int n> static inline double norm(const Matx<_Tp, m, n>& M) { return std::sqrt(normL2Sqr<_Tp, double>(M.val, m*n)); }
 
 // Matx operators (matx.hpp)

@@ -101,6 +101,8 @@ public:
 	inline void Release() { v.clear(); v.shrink_to_fit(); }
 	inline void Reserve(IDX n) { v.reserve((size_t)n); }
 	inline void Resize(IDX n) { v.resize((size_t)n); }
+	inline void resize(IDX n) { v.resize((size_t)n); }
+	inline void clear() { v.clear(); }
 	inline void Insert(ARG_TYPE e) { v.push_back(e); }
 	template <typename... Args> inline TYPE& emplace_back(Args&&... args) { v.emplace_back(std::forward<Args>(args)...); return v.back(); }
 	inline void push_back(const TYPE& e) { v.push_back(e); }
@@ -109,6 +111,8 @@ public:
 	inline TYPE& operator[](IDX i) { return v[(size_t)i]; }
 	inline TYPE* Begin() { return v.data(); } inline const TYPE* Begin() const { return v.data(); }
 	inline TYPE* End() { return v.data() + v.size(); } inline const TYPE* End() const { return v.data() + v.size(); }
+	inline TYPE* data() { return Begin(); } inline const TYPE* data() const { return Begin(); } inline const TYPE* cdata() const { return Begin(); }
+	inline void Memset(uint8_t val) { memset((void*)v.data(), val, sizeof(TYPE) * v.size()); }
 	inline TYPE* begin() { return Begin(); } inline const TYPE* begin() const { return Begin(); }
 	inline TYPE* end() { return End(); } inline const TYPE* end() const { return End(); }
 	inline const TYPE* cbegin() const { return Begin(); } inline const TYPE* cend() const { return End(); }
@@ -166,6 +170,8 @@ public:
 	inline TYPE* data() { return Base::d.get(); }
 	inline const TYPE& operator()(int row, int col) const { return Base::operator()(row, col); }
 	inline TYPE& operator()(int row, int col) { return Base::operator()(row, col); }
+	inline const TYPE& operator()(int i) const { return Base::d.get()[i]; }        // cv::Mat_::operator()(int): linear index of a continuous matrix
+	inline TYPE& operator()(int i) { return Base::d.get()[i]; }
 	inline const TYPE& operator()(const ImageRef& pt) const { return Base::operator()(pt.y, pt.x); }   // Types.h:2148-2157
 	inline TYPE& operator()(const ImageRef& pt) { return Base::operator()(pt.y, pt.x); }
 #include "snip/types_h_isinside.inc"     // Types.h: isInside / isInsideWithBorder

@@ -38,7 +38,8 @@ int main(int argc, char** argv) {
 	if (!pm.IsValid()) { fprintf(stderr, "no device\n"); return 5; }     // SceneDensify.cpp:1876-1877: caller falls back
 	pm.Init(false);
 	MVS::PatchMatchHIP::Options opt; opt.seed = 7;
-	pm.EstimateDepthMap(dd, opt);                                       // SceneDensify.cpp:620
+	pm.SetOptions(opt);                                                 // once, next to Init (SceneDensify.cpp:1880)
+	pm.EstimateDepthMap(dd);                                            // SceneDensify.cpp:620, the reference's one-argument call, unchanged
 	f = fopen(argv[5], "wb");
 	fwrite(dd.depthMap.buf.data(), 4, (size_t)w * h, f); fwrite(dd.normalMap.buf.data(), 4, (size_t)w * h * 3, f); fwrite(dd.confMap.buf.data(), 4, (size_t)w * h, f);
 	fclose(f);

@@ -1,0 +1,363 @@
+// pm_band.hip -- the sweep as ONE resident launch per iteration ("band" kernel), instead of one launch per anti-diagonal.
+//
+// ProcessPixel (DepthMap.cpp:630-852) at (x, y) reads the estimates its sweep direction has already updated at (x -/+ 1, y) and (x, y -/+ 1) and the
+// not yet updated ones on the other side; any schedule that honours those two edges gives the sequential result.  pm_sweep_kernel
+// honours them with a kernel boundary per anti-diagonal: 2 984 launches per 1080p sweep, each as long as its slowest wave, and a batch too small to
+// fill the machine pays one wave-life per diagonal.  Here a wavefront OWNS a band of PPW = 64 / G image rows of one view for the whole sweep and walks
+// the diagonals itself: at step d its pixel group g sits at (d - y, y), y = first row + g.  Then
+//   * the horizontal neighbour already updated is the group's own previous pixel and the vertical one is the neighbouring group's previous pixel: both are
+//     taken from registers (one cross-lane move), not from memory;
+//   * only the band's edge row needs another wave: the neighbouring band of the same view publishes the pixel of its last row after every step
+//     (agent-scope write-through stores, then a progress counter) and this band waits for "one diagonal behind" before it reads that pixel
+//     (agent-scope loads).  Everything else a step reads from memory -- its own pixel, the two not yet updated neighbours, the prior, the images --
+//     is data no wave writes before this step in this launch, so plain (cached) loads are right;
+//   * bands take tickets from a counter, every view's band k before any band k + 1: a band's predecessor always holds a smaller ticket, hence is
+//     resident or finished -- no assumption about dispatch order, no deadlock whatever the occupancy; waits are bounded and report through ctl[1].
+// The hypotheses, draws, scores and comparisons of a pixel are those of pm_sweep_kernel (the per-visit body below is its body), so the maps are the same bits.
+#pragma once
+
+#ifndef PM_BAND_MINWAVES
+#define PM_BAND_MINWAVES 3
+#endif
+#ifndef PM_BAND_SPIN_LIMIT
+#define PM_BAND_SPIN_LIMIT (1 << 21)
+#endif
+
+// agent-scope relaxed accesses (global_load / global_store ... sc1: served by / written through to the memory side, never by this CU's L1)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float pm_ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pm_st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int pm_ld_agent_i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pm_st_agent_i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pm_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void pm_nap() { __builtin_amdgcn_s_sleep(8); }
+__device__ __forceinline__ void pm_compiler_fence() { asm volatile("" ::: "memory"); }
+#else
+__device__ __forceinline__ void pm_compiler_fence() {}
+__device__ __forceinline__ float pm_ld_agent(const float* p) { return *p; }
+__device__ __forceinline__ void pm_st_agent(float* p, float v) { *p = v; }
+__device__ __forceinline__ int pm_ld_agent_i(const int* p) { return *p; }
+__device__ __forceinline__ void pm_st_agent_i(int* p, int v) { *p = v; }
+__device__ __forceinline__ void pm_drain_stores() {}
+__device__ __forceinline__ void pm_nap() {}
+#endif
+
+// Per-pixel state of a visit, in LDS.  The G lanes of a pixel all need it and all hold the same values, so one lane writes and all read: what lives in
+// registers while a hypothesis is scored (the long part of a visit) is then only what the scoring itself needs -- the register budget that decides how
+// many waves a SIMD holds.  Accessed through pm_launder() so that the compiler re-reads instead of carrying values across the scoring in registers.
+struct PMPix {
+	float depth, nx, ny, nz, conf;             // current estimate (DepthMap.cpp:767-769)
+	float p0, p1, scaleRange, depthRange;      // refinement state (:828-852)
+	int st, it, idxScale, flags;               // flags: bit 0 smooth, bit 1 changed, bit 2 / 3 propagation candidate 0 / 1 exists, bits 8..11 closeMask
+	float hd, hnx, hny, hnz, hp0, hp1;         // hypothesis being scored
+	int hst, pad0;
+	float nb[2][5];                            // the two already-updated neighbours: depth, normal, conf
+	float qX[4][3], qn[4][3];                  // neighborsClose: point and normal of slot k
+	float vx, vy, normSq0, sumW;
+	double X0x, X0y;
+	int x, y;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> __device__ __forceinline__ T* pm_launder(T* p) { asm volatile("" : "+v"(p)); return p; }
+#else
+template <class T> __device__ __forceinline__ T* pm_launder(T* p) { return p; }
+#endif
+enum { PMF_SMOOTH = 1, PMF_CHANGED = 2, PMF_POK0 = 4, PMF_POK1 = 8 };
+
+// ctl[0] = ticket counter, ctl[1] = error flag (a bounded wait gave up); progress[view * nBands + band] = 1 + sequence number of the band's last finished step
+template <int G, int VPL, bool GEO>
+__global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, uint32_t pass, int nViews, int nBands,
+		unsigned* __restrict__ ctl, int* __restrict__ progress) {
+	constexpr int PPW = 64 / G;               // pixels (= rows) per wave
+	constexpr int NV = G * VPL;
+	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
+	constexpr int TC = 0;                     // no LDS windows: the optimistic tap rows read the anti-diagonal-major image through the vector L1
+	static_assert(G >= 4, "the band kernel gives every pixel a quad of lanes (one smoothness slot per lane); fewer sources are padded");
+	PM_PROF_DECL;
+	__shared__ float2 s_w[PPW][PM_NT + 1];
+	__shared__ double s_src[NV * NBD];
+	__shared__ PMPix s_pix[PPW];
+	const int lane = threadIdx.x;
+	unsigned ticket = 0;
+	if (lane == 0) ticket = atomicAdd(&ctl[0], 1u);
+	ticket = (unsigned)__shfl((int)ticket, 0, 64);
+	const int bandSeq = (int)(ticket / (unsigned)nViews), view = (int)(ticket - (unsigned)bandSeq * (unsigned)nViews);
+	if (bandSeq >= nBands) return;
+	const int band = dir == 0 ? bandSeq : nBands - 1 - bandSeq;
+	const PMTask& t = tasks[view];
+	for (int i = lane; i < NV * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];   // views >= nSrc: zeros (the task is memset), never used
+	const double* hotBase = s_src;
+	const int g = lane / G, v = lane % G;
+	const int slot = v & 3;                                   // my smoothness slot (every quad of a group holds all four)
+	const int sgn = dir == 0 ? -1 : 1;
+	// the estimate this lane's pixel group left at its previous step (the horizontal "new" neighbour of the next one)
+	float pvD = 0.f, pvN0 = 0.f, pvN1 = 0.f, pvN2 = 0.f, pvC = 2.f;
+	__syncthreads();
+	const int nSteps = [&]() { const int yT = PM_HW + band * PPW; const int r = min(PPW, (t.h - PM_HW) - yT); return (t.w - 1 - PM_HW) + (yT + r - 1) - (PM_HW + yT) + 1; }();
+	for (int s = 0; s < nSteps; ++s) {
+		const int w = t.w, h = t.h;
+		const int yTop = PM_HW + band * PPW;
+		const int rows = min(PPW, (h - PM_HW) - yTop);       // rows of this band that are processable (y <= h-1-HW)
+		const int y = yTop + g;
+		const int dLo = PM_HW + yTop, dHi = (w - 1 - PM_HW) + (yTop + rows - 1);
+		const int d = dir == 0 ? dLo + s : dHi - s;
+		const int q = dir == 0 ? d : (w - 1 - PM_HW) + (h - 1 - PM_HW) - d;   // sequence number of this diagonal in sweep order
+		const int x = d - y;
+		const bool active = g < rows && x >= PM_HW && x <= w - 1 - PM_HW;
+		const size_t idx = active ? (size_t)y * w + x : (size_t)yTop * w + PM_HW;
+		const int predBand = band + sgn, succBand = band - sgn;
+		const bool predExists = predBand >= 0 && predBand < nBands, succExists = succBand >= 0 && succBand < nBands;
+		const int gCons = dir == 0 ? 0 : rows - 1;          // the group whose vertical neighbour lives in the preceding band
+		const int gPub = dir == 0 ? rows - 1 : 0;           // the group the following band reads
+		const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
+		// ---- the two already-updated neighbours: slot0 (x+sgn, y) = my previous pixel, slot1 (x, y+sgn) = the neighbouring group's previous pixel ----
+		// bounds tests exactly as written in the reference: x > HW / y > HW / x < W-HW / y < H-HW
+		bool bok[4]; int qxs[4], qys[4]; size_t qis[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int ox = (k == 0) ? sgn : (k == 2 ? -sgn : 0), oy = (k == 1) ? sgn : (k == 3 ? -sgn : 0);
+			bool ok;
+			if (ox == -1) ok = x > PM_HW; else if (ox == 1) ok = x < w - PM_HW; else if (oy == -1) ok = y > PM_HW; else ok = y < h - PM_HW;
+			bok[k] = ok && active; qxs[k] = x + ox; qys[k] = y + oy;
+			qis[k] = bok[k] ? (size_t)(y + oy) * w + (x + ox) : idx;
+		}
+		// vertical neighbour from the adjacent group's registers (its pixel of the previous step is exactly (x, y+sgn))
+		const int srcLane = min(max(lane + sgn * G, 0), 63);
+		float n1D = __shfl(pvD, srcLane, 64), n1N0 = __shfl(pvN0, srcLane, 64), n1N1 = __shfl(pvN1, srcLane, 64), n1N2 = __shfl(pvN2, srcLane, 64), n1C = __shfl(pvC, srcLane, 64);
+		// ... or, for the band's edge row, from the preceding band: wait until it is at most one diagonal behind, then read what it published
+		{
+			const int xc = d - (yTop + gCons);
+			const bool needPred = predExists && xc >= PM_HW && xc <= w - 1 - PM_HW;   // wave-uniform
+			if (needPred) {
+				const int* const predProgress = progress + (size_t)view * nBands + predBand;
+				int spins = 0;
+				while (pm_ld_agent_i(predProgress) < q) {
+					pm_nap();
+					if (++spins > PM_BAND_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctl[1], 1u); break; }
+				}
+				pm_compiler_fence();                                 // the reads below stay behind the successful poll
+				if (g == gCons && active) {
+					const size_t qi = qis[1];
+					n1D = pm_ld_agent((const float*)t.depth + qi); n1C = pm_ld_agent((const float*)t.conf + qi);
+					n1N0 = pm_ld_agent((const float*)t.normal + qi * 3); n1N1 = pm_ld_agent((const float*)t.normal + qi * 3 + 1); n1N2 = pm_ld_agent((const float*)t.normal + qi * 3 + 2);
+				}
+			}
+		}
+		float n0D = pvD, n0N0 = pvN0, n0N1 = pvN1, n0N2 = pvN2, n0C = pvC;
+		// The reference's bounds tests (x < W-HW, y < H-HW) let the RB2LT sweep look at the first column / row BEYOND the processable area; no sweep
+		// ever writes there, so those neighbours are what the init pass left in the maps: read them from memory.
+		if (bok[0] && (x + sgn < PM_HW || x + sgn > w - 1 - PM_HW)) {
+			const size_t qi = qis[0];
+			n0D = gDepth[qi]; n0N0 = gNormal[qi * 3]; n0N1 = gNormal[qi * 3 + 1]; n0N2 = gNormal[qi * 3 + 2]; n0C = gConf[qi];
+		}
+		if (bok[1] && (y + sgn < PM_HW || y + sgn > h - 1 - PM_HW)) {
+			const size_t qi = qis[1];
+			n1D = gDepth[qi]; n1N0 = gNormal[qi * 3]; n1N1 = gNormal[qi * 3 + 1]; n1N2 = gNormal[qi * 3 + 2]; n1C = gConf[qi];
+		}
+		// ---- what the visit reads from memory: its own estimate, the two not yet updated neighbours, prior, mask (none of it written earlier in this launch) ----
+		float oDepth = 0.f, oNx = 0.f, oNy = 0.f, oNz = 0.f, oConf = 2.f, prior = 0.f;
+		float myD = 0.f, myN0 = 0.f, myN1 = 0.f, myN2 = 1.f;     // depth and normal of my smoothness slot's pixel
+		unsigned char maskByte = 1;
+		if (active) {
+			if (t.prior) prior = pm_glob(t.prior)[idx];
+			if (t.mask != nullptr) maskByte = t.mask[idx];
+			if (slot == 0) { myD = bok[0] ? n0D : 0.f; myN0 = n0N0; myN1 = n0N1; myN2 = n0N2; }
+			else if (slot == 1) { myD = bok[1] ? n1D : 0.f; myN0 = n1N0; myN1 = n1N1; myN2 = n1N2; }
+			else { const size_t qi = slot == 2 ? qis[2] : qis[3]; myD = gDepth[qi]; myN0 = gNormal[qi * 3]; myN1 = gNormal[qi * 3 + 1]; myN2 = gNormal[qi * 3 + 2]; }
+			oDepth = gDepth[idx]; oNx = gNormal[idx * 3]; oNy = gNormal[idx * 3 + 1]; oNz = gNormal[idx * 3 + 2]; oConf = gConf[idx];
+		}
+		float normSq0, sumW;
+		pm_fill_patch<G, true>(t, active, active ? x : PM_HW, active ? y : yTop, v, s_w[g], normSq0, sumW);
+		const bool masked = active && maskByte == 0;
+		const bool valid = active && !masked && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
+		if (v == 0) s_w[g][PM_NT] = make_float2(prior, prior > 0 ? pm_expf(normSq0 * (-1.f / (1.f * 0.02f))) : 0.f);
+		// ---- the visit's state goes to LDS: current estimate, neighbours, close-neighbour slots (lane `slot` of the first quad writes slot `slot`) ----
+		{
+			PMPix* P = pm_launder(&s_pix[g]);
+			const bool bk = slot == 0 ? bok[0] : slot == 1 ? bok[1] : slot == 2 ? bok[2] : bok[3];
+			const bool okS = valid && bk && myD > 0;
+			const unsigned cm = (unsigned)__ballot(okS) >> 0;   // (ballot of the whole wave; my group's four bits are picked below)
+			const unsigned long long bal = __ballot(okS);
+			const unsigned closeMask = (unsigned)((bal >> (g * G)) & 0xFull);
+			(void)cm;
+			if (v < 4) {
+				// TransformPointI2C(Point3(nx, ndepth)) in double then Cast<float>, Camera.h:338-344
+				const int qx = slot == 0 ? qxs[0] : slot == 1 ? qxs[1] : slot == 2 ? qxs[2] : qxs[3];
+				const int qy = slot == 0 ? qys[0] : slot == 1 ? qys[1] : slot == 2 ? qys[2] : qys[3];
+				const double z = (double)myD;
+				P->qX[slot][0] = okS ? (float)(((double)qx - t.cx) * z / t.fx) : 0.f;
+				P->qX[slot][1] = okS ? (float)(((double)qy - t.cy) * z / t.fy) : 0.f;
+				P->qX[slot][2] = okS ? (float)z : 0.f;
+				P->qn[slot][0] = okS ? myN0 : 0.f; P->qn[slot][1] = okS ? myN1 : 0.f; P->qn[slot][2] = okS ? myN2 : 1.f;
+			}
+			if (v == 0) {
+				const double X0x = ((double)x - t.cx) / t.fx, X0y = ((double)y - t.cy) / t.fy;
+				P->X0x = X0x; P->X0y = X0y; P->vx = (float)X0x; P->vy = (float)X0y; P->normSq0 = normSq0; P->sumW = sumW; P->x = x; P->y = y;
+				P->depth = valid ? oDepth : 0.f; P->nx = valid ? oNx : 0.f; P->ny = valid ? oNy : 0.f; P->nz = valid ? oNz : 0.f; P->conf = valid ? oConf : 2.f;
+				P->p0 = 0.f; P->p1 = 0.f; P->scaleRange = 1.f; P->depthRange = 0.f;
+				enum { ST_PROP0 = 0, ST_DONE = 5 };
+				P->st = valid ? ST_PROP0 : ST_DONE; P->it = 0; P->idxScale = 0;
+				P->flags = PMF_SMOOTH | ((closeMask & 1u) ? PMF_POK0 : 0) | ((closeMask & 2u) ? PMF_POK1 : 0) | (int)(closeMask << 8);
+				P->nb[0][0] = n0D; P->nb[0][1] = n0N0; P->nb[0][2] = n0N1; P->nb[0][3] = n0N2; P->nb[0][4] = n0C;
+				P->nb[1][0] = n1D; P->nb[1][1] = n1N0; P->nb[1][2] = n1N1; P->nb[1][3] = n1N2; P->nb[1][4] = n1C;
+			}
+		}
+		__syncthreads();
+		// ---- ProcessPixel's control flow as a per-pixel state machine: every outer trip scores at most one hypothesis per pixel (as pm_sweep_kernel) ----
+		enum { ST_PROP0 = 0, ST_PROP1 = 1, ST_DECIDE = 2, ST_RAND = 3, ST_REFINE = 4, ST_DONE = 5 };
+		const uint32_t k1 = t.k1base + pass;
+		for (;;) {
+			bool need = false;
+			float hd = 0.f, hnx = 0.f, hny = 0.f, hnz = 1.f;
+			{	// -- next hypothesis of my pixel (every lane of the group computes the same; lane 0 records it)
+				PMPix* P = pm_launder(&s_pix[g]);
+				int st = P->st; unsigned it = (unsigned)P->it, idxScale = (unsigned)P->idxScale; int flags = P->flags;
+				const int px = P->x, py = P->y;
+				const float vx = P->vx, vy = P->vy, vz = 1.f;
+				float scaleRange = P->scaleRange, depthRange = P->depthRange, p0 = P->p0, p1 = P->p1;
+				float hp0 = 0.f, hp1 = 0.f; int hst = ST_DONE;
+				while (!need && st != ST_DONE) {
+					if (st <= ST_PROP1) {
+						const bool vert = (st == ST_PROP1); ++st; // slot 0: same row, slot 1: same column
+						const bool pok = (flags & (vert ? PMF_POK1 : PMF_POK0)) != 0;
+						const float* nbp = P->nb[vert ? 1 : 0];
+						const float cd = nbp[0], cnx = nbp[1], cny = nbp[2], cnz = nbp[3], pconf = nbp[4];
+						hd = cd; hnx = cnx; hny = cny; hnz = cnz;
+						if (pok && pconf < kp.thKeep) {
+							// InterpolatePixel, DepthMap.cpp:915-959
+							float depthNew = cd; bool zero;
+							if (vert) { // same column
+								const float nx1 = (float)(((double)py - t.cy) / t.fy);
+								const float denom = cnz + nx1 * cny;
+								zero = pm_fabsf(denom) < 0.0001f;
+								const float x1 = (float)(((double)(py + sgn) - t.cy) / t.fy);
+								const float nom = cd * (cnz + x1 * cny);
+								if (!zero) depthNew = nom / denom;
+							} else {
+								const float nx1 = (float)(((double)px - t.cx) / t.fx);
+								const float denom = cnz + nx1 * cnx;
+								zero = pm_fabsf(denom) < 0.0001f;
+								const float x1 = (float)(((double)(px + sgn) - t.cx) / t.fx);
+								const float nom = cd * (cnz + x1 * cnx);
+								if (!zero) depthNew = nom / denom;
+							}
+							hd = (!zero && pm_in_range(depthNew, t.dMin, t.dMax)) ? depthNew : cd;
+							hnx = cnx; hny = cny; hnz = cnz;
+							pm_correct_normal(vx, vy, vz, hnx, hny, hnz);
+							need = true; hst = ST_PROP0;
+						}
+					} else if (st == ST_DECIDE) {
+						// RefineIters:, DepthMap.cpp:802-827
+						const float conf = P->conf;
+						if (conf <= kp.thConfSmall) idxScale = 2;
+						else if (conf <= kp.thConfBig) idxScale = 1;
+						else if (conf >= kp.thConfRand) { flags &= ~PMF_SMOOTH; st = ST_RAND; it = 0; continue; }
+						scaleRange = pm_pow2neg(idxScale);
+						depthRange = P->depth * kp.depthRatio;
+						p0 = pm_atan2f(P->ny, P->nx); p1 = pm_acosf(pm_clampf(P->nz, -1.f, 1.f)); // Normal2Dir
+						st = ST_REFINE; it = 0;
+					} else if (st == ST_RAND) {
+						if (it >= kp.nRandomIters) { st = ST_DONE; break; }
+						const PmPhilox4 r = pm_philox4x32_10((uint32_t)px, (uint32_t)py, (uint32_t)(PM_STREAM_RAND * 256) + it, 0u, t.k0, k1);
+						++it;
+						const float rr = t.dMinSqr + (t.dMaxSqr - t.dMinSqr) * pm_u32_to_unit(r.v[0]);
+						hd = rr * rr;
+						pm_random_normal(pm_u32_to_unit(r.v[1]), pm_u32_to_unit(r.v[2]), vx, vy, vz, hnx, hny, hnz);
+						need = true; hst = ST_RAND;
+					} else { // ST_REFINE, DepthMap.cpp:832-852
+						if (it >= kp.nRandomIters) { st = ST_DONE; break; }
+						const PmPhilox4 r = pm_philox4x32_10((uint32_t)px, (uint32_t)py, (uint32_t)(PM_STREAM_REFINE * 256) + it, 0u, t.k0, k1);
+						++it;
+						const float ndepth = P->depth + (depthRange * scaleRange) * (2.f * pm_u32_to_unit(r.v[0]) - 1.f);
+						if (!pm_in_range(ndepth, t.dMin, t.dMax)) continue;
+						hp0 = p0 + (kp.angle1Range * scaleRange) * (2.f * pm_u32_to_unit(r.v[1]) - 1.f);
+						hp1 = p1 + (kp.angle2Range * scaleRange) * (2.f * pm_u32_to_unit(r.v[2]) - 1.f);
+						pm_dir2normal(hp0, hp1, hnx, hny, hnz);
+						if (hnx * vx + hny * vy + hnz * vz >= 0) continue;
+						hd = ndepth;
+						need = true; hst = ST_REFINE;
+					}
+				}
+				__builtin_amdgcn_wave_barrier();                     // every lane of the group has read the state before lane 0 advances it
+				if (v == 0) {
+					P->st = st; P->it = (int)it; P->idxScale = (int)idxScale; P->flags = flags;
+					P->scaleRange = scaleRange; P->depthRange = depthRange; P->p0 = p0; P->p1 = p1;
+					P->hd = hd; P->hnx = hnx; P->hny = hny; P->hnz = hnz; P->hp0 = hp0; P->hp1 = hp1; P->hst = hst;
+				}
+			}
+			if (!__any(need)) break;
+			// -- smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533, one neighbour per lane
+			float sf0, sf1, sf2, sf3;
+			{
+				const PMPix* P = pm_launder(&s_pix[g]);
+				const int flags = P->flags;
+				const bool on = need && (flags & PMF_SMOOTH) && ((flags >> (8 + slot)) & 1);
+				float myF = 1.f;
+				if (on) {
+					const float vx = P->vx, vy = P->vy;
+					const float q0 = P->qX[slot][0], q1 = P->qX[slot][1], q2 = P->qX[slot][2], m0 = P->qn[slot][0], m1 = P->qn[slot][1], m2 = P->qn[slot][2];
+					const float planeD = -hd * (hnx * vx + hny * vy + hnz * 1.f); // InitPlane, DepthMap.cpp:963-971
+					const float dist = (hnx * q0 + (hny * q1 + hnz * q2)) + planeD; // Planef::Distance, Eigen 3-dot order
+					const float r = dist / hd;
+					const float factorDepth = pm_expf((r * r) * kp.smoothSigmaDepth);
+					const float ca = pm_clampf((hnx * m0 + hny * m1 + hnz * m2) / pm_sqrtf((hnx * hnx + hny * hny + hnz * hnz) * (m0 * m0 + m1 * m1 + m2 * m2)), -1.f, 1.f);
+					const float ac = pm_acosf(ca);
+					const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
+					myF = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
+				}
+				sf0 = pm_quad_bcast<0>(myF); sf1 = pm_quad_bcast<1>(myF); sf2 = pm_quad_bcast<2>(myF); sf3 = pm_quad_bcast<3>(myF);
+			}
+			// -- score against my source view(s)
+			float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
+			{
+				const PMPix* P = pm_launder(&s_pix[g]);
+#pragma unroll 1
+				for (int u = 0; u < VPL; ++u) {
+					const int vw = v + u * G;
+					if (need && vw < t.nSrc) {
+						const float s1 = pm_score_view<GEO, true, TC, true>(t.src[vw], t, kp, P->x, P->y, P->X0x, P->X0y, P->normSq0, P->sumW, s_w[g], hd, hnx, hny, hnz, sf0, sf1, sf2, sf3, 0.f,
+							nullptr, 0, 0, hotBase + vw * NBD, hotBase + vw * NBD + PM_SRC_HOT, nullptr PM_PROF_PASS);
+						if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
+					}
+				}
+			}
+			const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
+			{	// -- accept (DepthMap.cpp:794-799, :784-793, :843-851)
+				PMPix* P = pm_launder(&s_pix[g]);
+				if (need && v == 0 && P->conf > nconf) {
+					P->conf = nconf; P->depth = P->hd; P->nx = P->hnx; P->ny = P->hny; P->nz = P->hnz;
+					int flags = P->flags | PMF_CHANGED;
+					P->flags = flags;
+					const int hst = P->hst;
+					if (hst == ST_RAND) { if (nconf < kp.thConfRand) P->st = ST_DECIDE; }
+					else if (hst == ST_REFINE) { P->p0 = P->hp0; P->p1 = P->hp1; const int is = P->idxScale + 1; P->idxScale = is; P->scaleRange = pm_pow2neg((unsigned)is); }
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+		// ---- result of the step: what the map holds at this pixel from now on ----
+		{
+			const PMPix* P = pm_launder(&s_pix[g]);
+			const bool wr = (P->flags & PMF_CHANGED) && valid;
+			const float depth = P->depth, nx = P->nx, ny = P->ny, nz = P->nz, conf = P->conf;
+			pvD = wr ? depth : oDepth; pvN0 = wr ? nx : oNx; pvN1 = wr ? ny : oNy; pvN2 = wr ? nz : oNz; pvC = wr ? conf : oConf;
+			if (wr && v == 0) {
+				if (succExists && g == gPub) {
+					// the following band reads this pixel while the launch runs: write it through
+					pm_st_agent((float*)t.depth + idx, depth); pm_st_agent((float*)t.normal + idx * 3, nx); pm_st_agent((float*)t.normal + idx * 3 + 1, ny);
+					pm_st_agent((float*)t.normal + idx * 3 + 2, nz); pm_st_agent((float*)t.conf + idx, conf);
+				} else { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
+			}
+		}
+		if (succExists) {
+			pm_drain_stores();                                   // the published pixel has left this wave before the counter moves
+			if (lane == 0) pm_st_agent_i(progress + (size_t)view * nBands + band, q + 1);
+		}
+		__syncthreads();                                         // the next step rewrites s_pix / s_w
+	}
+	{
+		const int succBand = band - sgn;
+		if (succBand >= 0 && succBand < nBands && lane == 0) pm_st_agent_i(progress + (size_t)view * nBands + band, 0x7fffffff);
+	}
+	PM_PROF_FLUSH();
+}

@@ -6,6 +6,7 @@
 // Everything stays in HBM between passes; one stream; no host sync inside a call.
 #include "../../include/pmhip.h"
 #include "pm_kernels.hip"
+#include "pm_band.hip"
 #include "pm_filter.hip"
 #include "pm_fuse.hip"
 #include <math.h>
@@ -26,6 +27,9 @@
 #endif
 #ifndef PMHIP_DEFAULT_GROUPS
 #define PMHIP_DEFAULT_GROUPS 2
+#endif
+#ifndef PMHIP_DEFAULT_BAND
+#define PMHIP_DEFAULT_BAND 1     // sweeps as one resident launch per iteration (pm_band.hip); 0 = one launch per anti-diagonal (pm_sweep_kernel / pm_sweep_wide_kernel)
 #endif
 
 namespace {
@@ -95,6 +99,9 @@ struct pmhip_engine {
 	int nGroups = 1;
 	int wideMaxViews = PMHIP_DEFAULT_WIDE;   // batches of at most this many views use the one-wave-per-pixel sweep kernel (PMHIP_WIDE)
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
+	int bandMode = PMHIP_DEFAULT_BAND;      // PMHIP_BAND
+	unsigned* d_bandCtl = nullptr;          // [0] ticket counter, [1] error flag, then progress[batchCap][bandCap] (pm_band.hip)
+	int bandCap = 0;
 	hipStream_t gstream[16] = {};
 	hipEvent_t forkEv = nullptr, joinEv[16] = {};
 	bool inited = false, geom = false;
@@ -169,6 +176,8 @@ static void freeScene(pmhip_engine* e) {
 	e->d_fdepth = e->d_fconf = nullptr; e->d_fvalid = nullptr; e->d_splat = nullptr; e->d_ftasks = nullptr; e->h_ftasks = nullptr; e->splatCap = e->ftaskCap = 0;
 	if (e->d_tasks) hipFree(e->d_tasks); if (e->h_tasks) hipHostFree(e->h_tasks);
 	if (e->d_ups) hipFree(e->d_ups); if (e->h_ups) hipHostFree(e->h_ups);
+	if (e->d_bandCtl) hipFree(e->d_bandCtl);
+	e->d_bandCtl = nullptr; e->bandCap = 0;
 	e->d_tasks = nullptr; e->h_tasks = nullptr; e->d_ups = nullptr; e->h_ups = nullptr;
 	for (SceneView& v : e->views) freeSide(v);
 	e->batchCap = 0; e->nImages = 0; e->views.clear();
@@ -180,8 +189,13 @@ static int ensureBatch(pmhip_engine* e, int n) {
 	for (int l = 0; l < 4; ++l) { if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
 	if (e->d_tasks) hipFree(e->d_tasks); if (e->h_tasks) hipHostFree(e->h_tasks);
 	if (e->d_ups) hipFree(e->d_ups); if (e->h_ups) hipHostFree(e->h_ups);
+	if (e->d_bandCtl) hipFree(e->d_bandCtl);
+	e->d_bandCtl = nullptr;
 	e->d_tasks = nullptr; e->h_tasks = nullptr; e->d_ups = nullptr; e->h_ups = nullptr;
 	const int cap = std::max(n, 1);
+	e->bandCap = (e->h + 3) / 4 + 1;                       // bands of the narrowest mapping (16 lanes per pixel: 4 rows per wave)
+	HIPCHK(e, hipMalloc(&e->d_bandCtl, sizeof(unsigned) * (2 + (size_t)cap * e->bandCap)));
+	HIPCHK(e, hipMemsetAsync(e->d_bandCtl, 0, sizeof(unsigned) * 2, e->stream));
 	HIPCHK(e, hipMalloc(&e->d_lvl[0], sizeof(float) * (size_t)cap * e->w * e->h));
 	for (int l = 1; l <= e->nLevels; ++l)
 		HIPCHK(e, hipMalloc(&e->d_lvl[l], sizeof(float) * (size_t)cap * 6 * e->lw(l) * e->lh(l)));
@@ -285,6 +299,19 @@ static void sweepMapping(int maxSrc, int lanes, int& G, int& VPL) {
 	G = NV; VPL = 1;
 	while (G > 1 && G > lanes && VPL < (PM_USE_TILES ? 4 : 8)) { G >>= 1; VPL <<= 1; }
 	if ((PM_USE_TILES && G == 1 && VPL > 2) || (G == 8 && VPL > 2)) { G <<= 1; VPL >>= 1; }   // (1,4) and (8,4) are not instantiated
+}
+
+// the same mappings for the resident band kernel (pm_band.hip): one launch per sweep iteration
+template <bool GEO>
+static bool launchBand(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, uint32_t pass, int nViews, int nBands, unsigned* ctl, int* progress) {
+#define PM_BAND_CASE(g, vpl) case (g) * 16 + (vpl): hipLaunchKernelGGL((pm_band_kernel<g, vpl, GEO>), grid, dim3(64), 0, s, t, kp, dir, pass, nViews, nBands, ctl, progress); return true
+	switch (G * 16 + VPL) {
+	PM_BAND_CASE(4, 1); PM_BAND_CASE(8, 1); PM_BAND_CASE(16, 1);
+	PM_BAND_CASE(4, 2); PM_BAND_CASE(8, 2);
+	PM_BAND_CASE(4, 4);
+	default: return false;
+	}
+#undef PM_BAND_CASE
 }
 
 template <bool GEO>
@@ -458,6 +485,26 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			const int dir = (int)(iter % 2u);
 			const uint32_t pass = (uint32_t)l * 64u + iter;
 			const int dLo = 2 * PM_HW, dHi = (lw - 1 - PM_HW) + (lh - 1 - PM_HW);
+			if (e->bandMode) {
+				// one resident launch: a wave per (view, band of 64 / SG rows); ticket and progress counters are cleared on the stream first
+				if (SG < 4) { SG = 4; VPL = 1; }                 // the band kernel gives a pixel at least a quad of lanes (views with < 4 sources: idle lanes)
+				const int PPW = 64 / SG, nBands = (lh - 2 * PM_HW + PPW - 1) / PPW;
+				const size_t evB = evBeginOn(e, 0, e->stream), evW = evBeginOn(e, 2, e->stream);
+				HIPCHK(e, hipMemsetAsync(e->d_bandCtl, 0, sizeof(unsigned), e->stream));
+				HIPCHK(e, hipMemsetAsync(e->d_bandCtl + 2, 0, sizeof(unsigned) * (size_t)nB * nBands, e->stream));
+				const dim3 grid((unsigned)nBands * (unsigned)nB);
+				const bool ok = geo ? launchBand<true>(SG, VPL, grid, e->stream, dt, kp, dir, pass, nB, nBands, e->d_bandCtl, (int*)(e->d_bandCtl + 2))
+				                    : launchBand<false>(SG, VPL, grid, e->stream, dt, kp, dir, pass, nB, nBands, e->d_bandCtl, (int*)(e->d_bandCtl + 2));
+				if (!ok) { e->err = "band kernel: mapping not instantiated"; return PMHIP_E_ARG; }
+				evEndOn(e, evB, e->stream); evEndOn(e, evW, e->stream);
+				if (e->statsOn) {
+					e->stats.sweepLaunches += 1;
+					double bytes = 0;
+					for (int b = 0; b < nB; ++b) { const int N = e->views[ids[b]].nNb; bytes += (double)Pl * (4.0 * (1 + N) + 40.0 + (l < S ? 4.0 : 0.0) + (geo ? 4.0 * N : 0.0)); }
+					e->stats.sweepBytes += bytes; e->stats.sweepPixels += (uint64_t)Pl * nB;
+				}
+				continue;
+			}
 			const int NG = std::max(1, std::min(e->nGroups, nB));
 			const size_t evWall = evBeginOn(e, 2, e->stream);
 			size_t evG[16] = {};
@@ -509,6 +556,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 	return 0;
 }
 
+static int checkBand(pmhip_engine* e);
 static int collectStats(pmhip_engine* e) {
 	if (e->events.empty()) return 0;
 	HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -547,6 +595,8 @@ int pmhip_create(int device, pmhip_engine** out) {
 	e->nGroups = ng ? std::max(1, std::min(16, atoi(ng))) : PMHIP_DEFAULT_GROUPS;
 	const char* nw = getenv("PMHIP_WIDE");
 	if (nw) e->wideMaxViews = atoi(nw);
+	const char* bm = getenv("PMHIP_BAND");
+	if (bm) e->bandMode = atoi(bm) != 0;
 	const char* nl = getenv("PMHIP_LANES");
 	if (nl && atoi(nl) >= 1) e->sweepLanes = atoi(nl);
 	for (int g = 0; g < e->nGroups; ++g)
@@ -698,7 +748,7 @@ int pmhip_scene_estimate(pmhip_engine* e, const int32_t* viewIds, int nViews, co
 	HIPCHK(e, hipSetDevice(e->device));
 	int rc = estimateBatch(e, viewIds, nViews, *p, nGeometricIter);
 	if (rc) return rc;
-	if (sync) HIPCHK(e, hipStreamSynchronize(e->stream));
+	if (sync) { HIPCHK(e, hipStreamSynchronize(e->stream)); return checkBand(e); }
 	return 0;
 }
 
@@ -963,7 +1013,15 @@ int pmhip_scene_copy(pmhip_engine* e, int what, int firstIdx, int count, void* d
 	return 0;
 }
 
-int pmhip_sync(pmhip_engine* e) { if (!e) return PMHIP_E_ARG; HIPCHK(e, hipSetDevice(e->device)); HIPCHK(e, hipStreamSynchronize(e->stream)); return 0; }
+// after a stream synchronisation: did a band kernel give up waiting for its preceding band (pm_band.hip: bounded waits instead of a hung device)?
+static int checkBand(pmhip_engine* e) {
+	if (!e->d_bandCtl) return 0;
+	unsigned flag = 0;
+	HIPCHK(e, hipMemcpy(&flag, e->d_bandCtl + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+	if (flag) { hipMemset(e->d_bandCtl + 1, 0, sizeof(unsigned)); e->err = "band kernel: a bounded wait for the preceding band expired; the maps of this call are not valid"; return PMHIP_E_HIP; }
+	return 0;
+}
+int pmhip_sync(pmhip_engine* e) { if (!e) return PMHIP_E_ARG; HIPCHK(e, hipSetDevice(e->device)); HIPCHK(e, hipStreamSynchronize(e->stream)); return checkBand(e); }
 void* pmhip_stream(pmhip_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 int pmhip_stats_reset(pmhip_engine* e, int enableEvents) {

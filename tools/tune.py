@@ -1,4 +1,4 @@
-"""Run bench.py for several (library variant, PMHIP_GROUPS[, PMHIP_LANES]) settings given as lib:groups[:lanes]; prints one line each."""
+"""Run bench.py for several (library variant, PMHIP_GROUPS[, PMHIP_LANES[, PMHIP_BAND]]) settings given as lib:groups[:lanes[:band]]; prints one line each."""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 views = sys.argv[1] if len(sys.argv) > 1 else "48"
@@ -9,9 +9,12 @@ for spec in variants:
     env = dict(os.environ, PMHIP_LIB=os.path.join(root, "openmvs_amd", lib), PMHIP_GROUPS=groups)
     if lanes:
         env["PMHIP_LANES"] = lanes
+    band = spec[3] if len(spec) > 3 else ""
+    if band:
+        env["PMHIP_BAND"] = band
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-extras", "--views-per-gpu", views], env=env, capture_output=True, text=True, timeout=400)
     try:
         j = json.loads(r.stdout.strip().splitlines()[-1])
-        print("%-18s groups=%-2s lanes=%-2s views=%s  %.2f Mpix/s  step %.0f ms  avg_launch %.1f us" % (lib, groups, lanes or "-", views, j["value"], j["ms_per_step"], j["roofline"]["avg_launch_us"]), flush=True)
+        print("%-18s groups=%-2s lanes=%-2s band=%-1s views=%s  %.2f Mpix/s  step %.0f ms  avg_launch %.1f us" % (lib, groups, lanes or "-", band or "-", views, j["value"], j["ms_per_step"], j["roofline"]["avg_launch_us"]), flush=True)
     except Exception as ex:
         print(lib, groups, "FAILED", ex, r.stderr[-500:], flush=True)

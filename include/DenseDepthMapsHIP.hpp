@@ -127,24 +127,27 @@ public:
 	}
 
 	// DepthMapsData::FuseDepthMaps, :1372-1650 (MergeDepthMaps when nMinViewsFuse < 2): images best connected first (:1423-1450)
-	void FuseDepthMaps(PointCloud& pc) {
-		auto score = [this](int32_t i) { const View& v = views_[(size_t)i]; return v.connections < 0 ? (float)v.neighbors.size() : v.connections; };
+	void FuseDepthMaps(PointCloud& pc) { FuseOn(e_, views_, opt_, pc); }
+	// the same on any engine that holds the final maps of all views (the multi-device host fuses on one device after a gather)
+	static void FuseOn(pmhip_engine* e, const std::vector<View>& views, const Options& opt, PointCloud& pc) {
+		auto chk = [e](int rc) { if (rc != PMHIP_OK) throw std::runtime_error(std::string("pmhip: ") + pmhip_last_error(e)); };
+		auto score = [&views](int32_t i) { const View& v = views[(size_t)i]; return v.connections < 0 ? (float)v.neighbors.size() : v.connections; };
 		std::vector<int32_t> order;
-		for (int32_t i : ids_) if (opt_.nMinViewsFuse < 2 || score(i) > 0) order.push_back(i);     // connections with score <= 0 are dropped (:1451-1452)
-		if (opt_.nMinViewsFuse >= 2)
+		for (int32_t i = 0; i < (int32_t)views.size(); ++i) if (opt.nMinViewsFuse < 2 || score(i) > 0) order.push_back(i);     // connections with score <= 0 are dropped (:1451-1452)
+		if (opt.nMinViewsFuse >= 2)
 			std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return score(a) > score(b); });   // ties in index order
 		PMHipFuseParams fp;
-		fp.nMinViewsFuse = opt_.nMinViewsFuse; fp.fDepthDiffThreshold = opt_.fDepthDiffThreshold; fp.fNormalDiffThreshold = opt_.fNormalDiffThreshold;
-		bool haveColor = opt_.bEstimateColor;
-		for (const View& v : views_) haveColor = haveColor && v.bgr != nullptr;
-		fp.bEstimateColor = haveColor ? 1 : 0; fp.bEstimateNormal = opt_.bEstimateNormal ? 1 : 0;
+		fp.nMinViewsFuse = opt.nMinViewsFuse; fp.fDepthDiffThreshold = opt.fDepthDiffThreshold; fp.fNormalDiffThreshold = opt.fNormalDiffThreshold;
+		bool haveColor = opt.bEstimateColor;
+		for (const View& v : views) haveColor = haveColor && v.bgr != nullptr;
+		fp.bEstimateColor = haveColor ? 1 : 0; fp.bEstimateNormal = opt.bEstimateNormal ? 1 : 0;
 		uint64_t nP = 0, nV = 0, nD = 0;
-		check(pmhip_scene_fuse(e_, order.data(), (int)order.size(), &fp, &nP, &nV, &nD));
+		chk(pmhip_scene_fuse(e, order.data(), (int)order.size(), &fp, &nP, &nV, &nD));
 		pc.points.assign((size_t)nP * 3, 0.f); pc.viewStart.assign((size_t)nP + 1, 0u); pc.views.assign((size_t)nV, 0u); pc.weights.assign((size_t)nV, 0.f);
 		pc.projs.assign((size_t)nV * 2, (uint16_t)0);
-		pc.colors.assign(haveColor ? (size_t)nP * 3 : 0, (unsigned char)0); pc.normals.assign(opt_.bEstimateNormal ? (size_t)nP * 3 : 0, 0.f);
-		check(pmhip_scene_fuse_get(e_, pc.points.data(), pc.viewStart.data(), pc.views.data(), pc.weights.data(), pc.projs.data(),
-		                           haveColor ? pc.colors.data() : nullptr, opt_.bEstimateNormal ? pc.normals.data() : nullptr));
+		pc.colors.assign(haveColor ? (size_t)nP * 3 : 0, (unsigned char)0); pc.normals.assign(opt.bEstimateNormal ? (size_t)nP * 3 : 0, 0.f);
+		chk(pmhip_scene_fuse_get(e, pc.points.data(), pc.viewStart.data(), pc.views.data(), pc.weights.data(), pc.projs.data(),
+		                         haveColor ? pc.colors.data() : nullptr, opt.bEstimateNormal ? pc.normals.data() : nullptr));
 	}
 
 	// One view's maps back to the host (any pointer may be null)

@@ -1,0 +1,213 @@
+// DenseDepthMapsHIPMulti.hpp -- the C++ host of the multi-GPU split (BASELINE.json north_star: "independent reference views shard embarrassingly
+// across the 8 GPUs of one node with a single RCCL broadcast of the image set over xGMI and no per-iteration collectives").
+//
+// One process, one pmhip engine and one host thread per device.  Every engine holds the whole scene (images of all views: any view can be a
+// source view) and estimates a contiguous block of reference views; what crosses devices is
+//   (1) ONE broadcast of the image set from the device the caller's images were uploaded to;
+//   (2) an all-gather of the depth maps at each round boundary (the reference reloads the neighbours' depthNNNN.dmap there, SceneDensify.cpp:378-393),
+//       of depth + confidence before the cross-view filter (:2136-2222), and of depth + normal + confidence to the fusing device before FuseDepthMaps
+//       (:1372-1650, sequential over the scene: one device);
+// nothing inside a sweep.  Same call shape as DenseDepthMapsHIP (LoadScene, ComputeDepthMaps, FuseDepthMaps, GetMaps), same results bit for bit:
+// a view's maps do not depend on which device estimated them (tests/cpp/dense_multi.cpp).
+//
+// The collectives are a policy:
+//   RcclCollective       (define PMHIP_WITH_RCCL, link -lrccl): ncclCommInitAll over the devices, grouped ncclBroadcast calls on the engines' streams --
+//                        the product path.  Unequal shards: each owner's block is one broadcast of the group (a ring all-gather needs equal counts).
+//   LocalCopyCollective  several engines on ONE device (debugging, and the single-GPU CI box): device-to-device copies between the engines' arrays.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "DenseDepthMapsHIP.hpp"
+#ifdef PMHIP_WITH_RCCL
+#include <rccl/rccl.h>
+#endif
+
+namespace MVS {
+
+// blocks [off[r], off[r] + cnt[r]) (bytes) of a per-device array are owned by device r; after AllGatherV every device holds every block
+struct LocalCopyCollective {
+	explicit LocalCopyCollective(const std::vector<int>&) {}
+	void Broadcast(const std::vector<void*>& bufs, size_t bytes, int root, const std::vector<hipStream_t>& streams) {
+		sync(streams);
+		for (size_t d = 0; d < bufs.size(); ++d) if ((int)d != root && hipMemcpy(bufs[d], bufs[(size_t)root], bytes, hipMemcpyDeviceToDevice) != hipSuccess) throw std::runtime_error("LocalCopyCollective: copy failed");
+	}
+	void AllGatherV(const std::vector<void*>& bases, const std::vector<size_t>& off, const std::vector<size_t>& cnt, const std::vector<hipStream_t>& streams) {
+		sync(streams);
+		for (size_t r = 0; r < bases.size(); ++r) for (size_t d = 0; d < bases.size(); ++d) if (d != r && cnt[r])
+			if (hipMemcpy((char*)bases[d] + off[r], (const char*)bases[r] + off[r], cnt[r], hipMemcpyDeviceToDevice) != hipSuccess) throw std::runtime_error("LocalCopyCollective: copy failed");
+	}
+private:
+	static void sync(const std::vector<hipStream_t>& streams) { for (hipStream_t s : streams) hipStreamSynchronize(s); }
+};
+
+#ifdef PMHIP_WITH_RCCL
+class RcclCollective {
+public:
+	explicit RcclCollective(const std::vector<int>& devices) : devs_(devices), comms_(devices.size()) {
+		if (ncclCommInitAll(comms_.data(), (int)devs_.size(), devs_.data()) != ncclSuccess) throw std::runtime_error("RcclCollective: ncclCommInitAll failed");
+	}
+	~RcclCollective() { for (ncclComm_t c : comms_) ncclCommDestroy(c); }
+	RcclCollective(const RcclCollective&) = delete;
+	RcclCollective& operator=(const RcclCollective&) = delete;
+	// the single broadcast of the image set (xGMI); enqueued on each engine's stream, so it is ordered with that engine's kernels
+	void Broadcast(const std::vector<void*>& bufs, size_t bytes, int root, const std::vector<hipStream_t>& streams) {
+		ok(ncclGroupStart());
+		for (size_t d = 0; d < devs_.size(); ++d) { hipSetDevice(devs_[d]); ok(ncclBroadcast(bufs[d], bufs[d], bytes, ncclChar, root, comms_[d], streams[d])); }
+		ok(ncclGroupEnd());
+	}
+	void AllGatherV(const std::vector<void*>& bases, const std::vector<size_t>& off, const std::vector<size_t>& cnt, const std::vector<hipStream_t>& streams) {
+		ok(ncclGroupStart());
+		for (size_t r = 0; r < devs_.size(); ++r) if (cnt[r])
+			for (size_t d = 0; d < devs_.size(); ++d) { hipSetDevice(devs_[d]); ok(ncclBroadcast((char*)bases[d] + off[r], (char*)bases[d] + off[r], cnt[r], ncclChar, (int)r, comms_[d], streams[d])); }
+		ok(ncclGroupEnd());
+	}
+private:
+	static void ok(ncclResult_t r) { if (r != ncclSuccess) throw std::runtime_error(std::string("RCCL: ") + ncclGetErrorString(r)); }
+	std::vector<int> devs_;
+	std::vector<ncclComm_t> comms_;
+};
+#endif
+
+template <class Collective>
+class DenseDepthMapsHIPMultiT {
+public:
+	typedef DenseDepthMapsHIP::Options Options;
+	typedef DenseDepthMapsHIP::View View;
+	typedef DenseDepthMapsHIP::PointCloud PointCloud;
+	enum { REMOVE_SPECKLES = DenseDepthMapsHIP::REMOVE_SPECKLES, FILL_GAPS = DenseDepthMapsHIP::FILL_GAPS, ADJUST_FILTER = DenseDepthMapsHIP::ADJUST_FILTER };
+
+	// devices: HIP device ordinals, one engine each (LocalCopyCollective: the same ordinal several times)
+	// hostThreads = false drives the engines one after the other from the calling thread (same results; for single-threaded test environments)
+	explicit DenseDepthMapsHIPMultiT(const std::vector<int>& devices, bool hostThreads = true) : devs_(devices), w_(0), h_(0), threads_(hostThreads) {
+		for (int d : devs_) { pmhip_engine* e = nullptr; if (pmhip_create(d, &e) != PMHIP_OK) { release(); return; } eng_.push_back(e); }
+		coll_.reset(new Collective(devs_));
+	}
+	~DenseDepthMapsHIPMultiT() { release(); }
+	DenseDepthMapsHIPMultiT(const DenseDepthMapsHIPMultiT&) = delete;
+	DenseDepthMapsHIPMultiT& operator=(const DenseDepthMapsHIPMultiT&) = delete;
+	bool IsValid() const { return !eng_.empty() && eng_.size() == devs_.size(); }
+	int NumDevices() const { return (int)eng_.size(); }
+	// contiguous blocks that differ by at most one view (the split of openmvs_amd/distributed.py::shard_range)
+	static void ShardRange(int nViews, int nDev, int r, int& first, int& count) { const int q = nViews / nDev, m = nViews % nDev; first = r * q + std::min(r, m); count = q + (r < m ? 1 : 0); }
+
+	void LoadScene(const std::vector<View>& views, int w, int h, const Options& opt) {
+		views_ = views; w_ = w; h_ = h; opt_ = opt;
+		const int n = (int)views.size(), D = NumDevices();
+		first_.resize((size_t)D); count_.resize((size_t)D);
+		for (int d = 0; d < D; ++d) ShardRange(n, D, d, first_[(size_t)d], count_[(size_t)d]);
+		for (int d = 0; d < D; ++d) {
+			pmhip_engine* e = eng_[(size_t)d];
+			check(d, pmhip_init(e, 0));
+			check(d, pmhip_scene_create(e, n, w, h, (int)opt.nSubResolutionLevels));
+			for (int i = 0; i < n; ++i) {
+				const View& v = views[(size_t)i];
+				if (!v.gray) throw std::runtime_error("DenseDepthMapsHIPMulti: view without an image");
+				// images go up once, to the first device; the others get cameras and neighbour lists now and the pixels by the broadcast below
+				check(d, pmhip_scene_set_view(e, i, d == 0 ? v.gray : nullptr, 0, v.K, v.R, v.C, v.dMin, v.dMax, v.neighbors.data(), (int)v.neighbors.size()));
+				if (v.mask) check(d, pmhip_scene_set_mask(e, i, v.mask));
+				if (v.bgr && d == 0) check(d, pmhip_scene_set_color(e, i, v.bgr));    // colours are only read by the fusing device
+			}
+		}
+		// (1) the one broadcast of the image set
+		std::vector<void*> bufs; for (pmhip_engine* e : eng_) bufs.push_back(pmhip_scene_device_ptr(e, 0, 0));
+		coll_->Broadcast(bufs, sizeof(float) * (size_t)w * h * n, 0, streams());
+		for (int d = 0; d < D; ++d) check(d, pmhip_scene_images_updated(eng_[(size_t)d]));
+	}
+
+	size_t ComputeDepthMaps() {
+		const int n = (int)views_.size(), D = NumDevices();
+		const unsigned G = opt_.nEstimationGeometricIters;
+		for (int d = 0; d < D; ++d) {
+			check(d, pmhip_init(eng_[(size_t)d], 0));
+			for (int i = 0; i < n; ++i) {
+				check(d, pmhip_scene_reset_view(eng_[(size_t)d], i));
+				const View& v = views_[(size_t)i];
+				if (v.initDepth && owns(d, i)) check(d, pmhip_scene_set_maps(eng_[(size_t)d], i, v.initDepth, v.initNormal));
+			}
+		}
+		estimateAll(-1);                                                               // photometric pass, SceneDensify.cpp:1884-1905
+		if (G == 0) postFilterAll();
+		for (unsigned g = 0; g < G; ++g) {                                             // :1906-1953
+			gather(1);                                                                 // (2) every device sees every depth map of the round ...
+			for (int d = 0; d < D; ++d) { check(d, pmhip_scene_commit_round(eng_[(size_t)d])); check(d, pmhip_init(eng_[(size_t)d], 1)); }   // ... as the snapshot the geometric term reads
+			estimateAll((int)g);
+			if (g + 1 == G) postFilterAll();
+		}
+		if (opt_.nOptimize & ADJUST_FILTER) {                                          // :1955-1980, every map against the UNFILTERED maps of its neighbours
+			gather(1); gather(3);
+			perDevice([&](int d) {
+				check(d, pmhip_scene_filter(eng_[(size_t)d], ids(d).data(), count_[(size_t)d], opt_.bFilterAdjust ? 1 : 0, opt_.nMinViewsFilter, opt_.nMinViewsFilterAdjust, opt_.fDepthDiffThreshold, 1));
+				check(d, pmhip_scene_filter_commit(eng_[(size_t)d]));
+			});
+		}
+		for (int d = 0; d < D; ++d) check(d, pmhip_sync(eng_[(size_t)d]));
+		return (size_t)n;
+	}
+
+	// FuseDepthMaps is sequential over the scene (images best connected first, claimed pixels carried from image to image): one device, after a gather
+	void FuseDepthMaps(PointCloud& pc) {
+		gather(1); gather(2); gather(3);
+		for (int d = 0; d < NumDevices(); ++d) check(d, pmhip_sync(eng_[(size_t)d]));
+		DenseDepthMapsHIP::FuseOn(eng_[0], views_, opt_, pc);
+	}
+	// a view's maps from the device that owns it
+	void GetMaps(int idx, float* depth, float* normal, float* conf) {
+		for (int d = 0; d < NumDevices(); ++d) if (owns(d, idx)) { check(d, pmhip_scene_get_maps(eng_[(size_t)d], idx, depth, normal, conf)); return; }
+		throw std::runtime_error("DenseDepthMapsHIPMulti: no such view");
+	}
+	pmhip_engine* engine(int d) { return eng_[(size_t)d]; }
+
+private:
+	bool owns(int d, int i) const { return i >= first_[(size_t)d] && i < first_[(size_t)d] + count_[(size_t)d]; }
+	std::vector<int32_t> ids(int d) const { std::vector<int32_t> v((size_t)count_[(size_t)d]); for (int k = 0; k < count_[(size_t)d]; ++k) v[(size_t)k] = first_[(size_t)d] + k; return v; }
+	std::vector<hipStream_t> streams() const { std::vector<hipStream_t> s; for (pmhip_engine* e : eng_) s.push_back((hipStream_t)pmhip_stream(e)); return s; }
+	template <class F> void perDevice(F f) {
+		// one host thread per device: the engines enqueue their kernels concurrently; an exception of any thread is rethrown here
+		if (!threads_) { for (int d = 0; d < NumDevices(); ++d) f(d); return; }
+		std::vector<std::thread> th; std::vector<std::string> errs((size_t)NumDevices());
+		for (int d = 0; d < NumDevices(); ++d) th.emplace_back([&, d]() { try { f(d); } catch (const std::exception& ex) { errs[(size_t)d] = ex.what(); } });
+		for (auto& t : th) t.join();
+		for (const std::string& e : errs) if (!e.empty()) throw std::runtime_error(e);
+	}
+	void estimateAll(int geoIter) {
+		perDevice([&](int d) { if (count_[(size_t)d]) check(d, pmhip_scene_estimate(eng_[(size_t)d], ids(d).data(), count_[(size_t)d], &opt_, geoIter, 0)); });
+	}
+	void postFilterAll() {
+		perDevice([&](int d) {
+			if (!count_[(size_t)d]) return;
+			if (opt_.nOptimize & REMOVE_SPECKLES) check(d, pmhip_scene_remove_small_segments(eng_[(size_t)d], ids(d).data(), count_[(size_t)d], opt_.nSpeckleSize, opt_.fDepthDiffThreshold));
+			if (opt_.nOptimize & FILL_GAPS) check(d, pmhip_scene_gap_interpolation(eng_[(size_t)d], ids(d).data(), count_[(size_t)d], opt_.nIpolGapSize, opt_.fDepthDiffThreshold));
+		});
+	}
+	// all-gather of one per-view array (what: 1 depth, 2 normal, 3 conf) over the owners' blocks
+	void gather(int what) {
+		const size_t per = sizeof(float) * (size_t)w_ * h_ * (what == 2 ? 3 : 1);
+		std::vector<void*> bases; std::vector<size_t> off, cnt;
+		for (int d = 0; d < NumDevices(); ++d) { bases.push_back(pmhip_scene_device_ptr(eng_[(size_t)d], what, 0)); off.push_back(per * (size_t)first_[(size_t)d]); cnt.push_back(per * (size_t)count_[(size_t)d]); }
+		coll_->AllGatherV(bases, off, cnt, streams());
+		if (what == 1) for (int d = 0; d < NumDevices(); ++d) check(d, pmhip_scene_maps_updated(eng_[(size_t)d], 0, (int)views_.size()));
+	}
+	void check(int d, int rc) const { if (rc != PMHIP_OK) throw std::runtime_error("pmhip (device " + std::to_string(devs_[(size_t)d]) + "): " + pmhip_last_error(eng_[(size_t)d])); }
+	void release() { for (pmhip_engine* e : eng_) pmhip_destroy(e); eng_.clear(); }
+
+	std::vector<int> devs_;
+	std::vector<pmhip_engine*> eng_;
+	std::unique_ptr<Collective> coll_;
+	int w_, h_;
+	bool threads_;
+	Options opt_;
+	std::vector<View> views_;
+	std::vector<int> first_, count_;
+};
+
+#ifdef PMHIP_WITH_RCCL
+typedef DenseDepthMapsHIPMultiT<RcclCollective> DenseDepthMapsHIPMulti;
+#endif
+
+} // namespace MVS

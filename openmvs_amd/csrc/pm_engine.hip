@@ -48,6 +48,7 @@ struct SceneView {
 	int sw = 0, sh = 0;
 	float* sImg[4] = {nullptr, nullptr, nullptr, nullptr};
 	float* sImgS[4] = {nullptr, nullptr, nullptr, nullptr};
+	float4* sImgQ[4] = {nullptr, nullptr, nullptr, nullptr};
 	bool sideDirty = false;
 	// A known depth-map of this view to be read by geometric rounds instead of the scene's snapshot, of its own size and with the camera it
 	// was stored with (DepthData::ViewData::depthMap / cameraDepthMap, filled from the neighbour's .dmap at SceneDensify.cpp:378-393)
@@ -55,7 +56,7 @@ struct SceneView {
 };
 static int lvlSize(int n, int l) { return (int)nearbyint((double)n / (double)(1 << l)); }   // cvRound(size / 2^l), ties to even
 static void freeSide(SceneView& v) {
-	for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgS[l]) hipFree(v.sImgS[l]); v.sImg[l] = v.sImgS[l] = nullptr; }
+	for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgS[l]) hipFree(v.sImgS[l]); if (v.sImgQ[l]) hipFree(v.sImgQ[l]); v.sImg[l] = v.sImgS[l] = nullptr; v.sImgQ[l] = nullptr; }
 	if (v.sDepth) hipFree(v.sDepth);
 	v.sDepth = nullptr; v.sw = v.sh = v.dw = v.dh = 0; v.sideDirty = false;
 }
@@ -110,6 +111,7 @@ struct pmhip_engine {
 	int nImages = 0, w = 0, h = 0, nLevels = 0; // nLevels = sub-resolution levels available (pyramid has nLevels+1 entries)
 	float* d_img[4] = {nullptr, nullptr, nullptr, nullptr};
 	float* d_imgS[4] = {nullptr, nullptr, nullptr, nullptr}; // anti-diagonal-major copies, (w_l+h_l-1)*h_l floats per image
+	float4* d_imgQ[4] = {nullptr, nullptr, nullptr, nullptr}; // anti-diagonal-major quad images (PMSrcView::imgQ), same indexing, 16 bytes per entry
 	size_t skewPitch(int l) const { return (size_t)(lw(l) + lh(l) - 1) * lh(l); }
 	float *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr, *d_snap = nullptr;
 	// ignore masks (nIgnoreMaskLabel): per level [nImages][P_l] bytes, allocated with the first mask; maskMode -1 = on iff a mask is set
@@ -166,7 +168,7 @@ static void freeFuse(pmhip_engine* e) {
 static void freeScene(pmhip_engine* e) {
 	hipSetDevice(e->device);
 	freeFuse(e);
-	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_imgS[l]) hipFree(e->d_imgS[l]); e->d_imgS[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
+	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_imgS[l]) hipFree(e->d_imgS[l]); e->d_imgS[l] = nullptr; if (e->d_imgQ[l]) hipFree(e->d_imgQ[l]); e->d_imgQ[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
 	if (e->d_depth) hipFree(e->d_depth); if (e->d_normal) hipFree(e->d_normal); if (e->d_conf) hipFree(e->d_conf); if (e->d_snap) hipFree(e->d_snap);
 	e->d_depth = e->d_normal = e->d_conf = e->d_snap = nullptr;
 	for (int l = 0; l < 4; ++l) { if (e->d_mask[l]) hipFree(e->d_mask[l]); e->d_mask[l] = nullptr; }
@@ -219,6 +221,7 @@ static int buildPyramid(pmhip_engine* e) {
 		const size_t n = (size_t)e->lw(l) * e->lh(l) * e->nImages;
 		const int blocks = (int)std::min<size_t>((n + 255) / 256, 65535);
 		hipLaunchKernelGGL(pm_skew_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_img[l], e->d_imgS[l], e->lw(l), e->lh(l), e->nImages);
+		hipLaunchKernelGGL(pm_quad_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_img[l], e->d_imgQ[l], e->lw(l), e->lh(l), e->nImages);
 	}
 	HIPCHK(e, hipGetLastError());
 	e->pyramidDirty = false;
@@ -237,6 +240,7 @@ static int buildSidePyramids(pmhip_engine* e) {
 			const int lw = lvlSize(v.sw, l), lh = lvlSize(v.sh, l);
 			const size_t n = (size_t)lw * lh;
 			hipLaunchKernelGGL(pm_skew_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, e->stream, v.sImg[l], v.sImgS[l], lw, lh, 1);
+			hipLaunchKernelGGL(pm_quad_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, e->stream, v.sImg[l], v.sImgQ[l], lw, lh, 1);
 		}
 		HIPCHK(e, hipGetLastError());
 		v.sideDirty = false;
@@ -418,11 +422,12 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 					// a source image of its own size: its own pyramid, its camera scaled from its own size (ScaleDepthData, SceneDensify.cpp:586-588)
 					const int jw = lvlSize(sv.sw, l), jh = lvlSize(sv.sh, l);
 					if (jw < 3 || jh < 3) { e->err = "source image too small for this many sub-resolution levels"; return PMHIP_E_SIZE; }
-					s.img = sv.sImg[l]; s.imgS = sv.sImgS[l]; s.w = jw; s.h = jh;
+					s.img = sv.sImg[l]; s.imgS = sv.sImgS[l]; s.imgQ = sv.sImgQ[l]; s.w = jw; s.h = jh;
 					if (l == 0) memcpy(Kj, sv.K, sizeof(Kj)); else scaleK(sv.K, sv.sw, sv.sh, jw, jh, Kj);
 				} else {
 					s.img = e->d_img[l] + Pl * v.nb[k];
 					s.imgS = e->d_imgS[l] + e->skewPitch(l) * v.nb[k];
+					s.imgQ = e->d_imgQ[l] + e->skewPitch(l) * v.nb[k];
 					s.w = lw; s.h = lh;
 					if (l == 0) memcpy(Kj, sv.K, sizeof(Kj)); else scaleK(sv.K, e->w, e->h, lw, lh, Kj);
 				}
@@ -487,7 +492,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			const int dLo = 2 * PM_HW, dHi = (lw - 1 - PM_HW) + (lh - 1 - PM_HW);
 			if (e->bandMode) {
 				// one resident launch: a wave per (view, band of 64 / SG rows); ticket and progress counters are cleared on the stream first
-				if (SG < 4) { SG = 4; VPL = 1; }                 // the band kernel gives a pixel at least a quad of lanes (views with < 4 sources: idle lanes)
+				if (SG < 4) { VPL = std::max(1, SG * VPL / 4); SG = 4; }   // the band kernel gives a pixel at least a quad of lanes (views with < 4 sources: idle lanes)
 				const int PPW = 64 / SG, nBands = (lh - 2 * PM_HW + PPW - 1) / PPW;
 				const size_t evB = evBeginOn(e, 0, e->stream), evW = evBeginOn(e, 2, e->stream);
 				HIPCHK(e, hipMemsetAsync(e->d_bandCtl, 0, sizeof(unsigned), e->stream));
@@ -645,6 +650,7 @@ int pmhip_scene_create(pmhip_engine* e, int nImages, int w, int h, int nLevels) 
 	for (int l = 0; l <= nLevels; ++l) {
 		HIPCHK(e, hipMalloc(&e->d_img[l], sizeof(float) * (size_t)e->lw(l) * e->lh(l) * nImages));
 		HIPCHK(e, hipMalloc(&e->d_imgS[l], sizeof(float) * e->skewPitch(l) * nImages));
+		HIPCHK(e, hipMalloc(&e->d_imgQ[l], sizeof(float4) * e->skewPitch(l) * nImages));
 	}
 	HIPCHK(e, hipMalloc(&e->d_depth, sizeof(float) * P0 * nImages));
 	HIPCHK(e, hipMalloc(&e->d_normal, sizeof(float) * P0 * 3 * nImages));
@@ -673,7 +679,7 @@ int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevi
 	if (gray) {
 		if (v.sw) {   // the view goes back to the scene's size: its own pyramid is not needed any more
 			HIPCHK(e, hipStreamSynchronize(e->stream));
-			for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgS[l]) hipFree(v.sImgS[l]); v.sImg[l] = v.sImgS[l] = nullptr; }
+			for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgS[l]) hipFree(v.sImgS[l]); if (v.sImgQ[l]) hipFree(v.sImgQ[l]); v.sImg[l] = v.sImgS[l] = nullptr; v.sImgQ[l] = nullptr; }
 			v.sw = v.sh = 0; v.sideDirty = false;
 		}
 		const size_t P0 = (size_t)e->w * e->h;
@@ -711,6 +717,7 @@ int pmhip_scene_set_view_sized(pmhip_engine* e, int idx, const float* gray, int 
 			if (lw < 1 || lh < 1) break;
 			HIPCHK(e, hipMalloc(&v.sImg[l], sizeof(float) * (size_t)lw * lh));
 			HIPCHK(e, hipMalloc(&v.sImgS[l], sizeof(float) * (size_t)(lw + lh - 1) * lh));
+			HIPCHK(e, hipMalloc(&v.sImgQ[l], sizeof(float4) * (size_t)(lw + lh - 1) * lh));
 		}
 		v.sw = w; v.sh = h;
 	}

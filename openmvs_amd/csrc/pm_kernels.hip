@@ -42,6 +42,17 @@
 // turns every access into a flat_load; they are all HBM buffers, so say so (global_load, own vmcnt).
 typedef const float __attribute__((address_space(1)))* pm_gcf;
 typedef float __attribute__((address_space(1)))* pm_gf;
+// 16-byte entries of the quad images (PMSrcView::imgQ): one global_load_dwordx4 per bilinear sample
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float pm_f4v __attribute__((ext_vector_type(4)));
+typedef const pm_f4v __attribute__((address_space(1)))* pm_gcf4;
+__device__ __forceinline__ pm_gcf4 pm_glob4(const float4* p) { return (pm_gcf4)p; }
+__device__ __forceinline__ void pm_load4(pm_gcf4 base, unsigned off, float& a, float& b, float& c, float& d) { const pm_f4v t = base[off]; a = t.x; b = t.y; c = t.z; d = t.w; }
+#else
+typedef const float4* pm_gcf4;
+__device__ __forceinline__ pm_gcf4 pm_glob4(const float4* p) { return p; }
+__device__ __forceinline__ void pm_load4(pm_gcf4 base, unsigned off, float& a, float& b, float& c, float& d) { const float4 t = base[off]; a = t.x; b = t.y; c = t.z; d = t.w; }
+#endif
 __device__ __forceinline__ pm_gcf pm_glob(const float* p) { return (pm_gcf)p; }
 __device__ __forceinline__ pm_gf pm_globw(float* p) { return (pm_gf)p; }
 #define PM_HW 4      // nSizeHalfWindow, DepthMap.h:277
@@ -60,6 +71,9 @@ struct PMSrcView {
 	int dw, dh;
 	const float* img;     // source image at this pyramid level, row-major
 	const float* imgS;    // same image, anti-diagonal-major ("skewed"): texel (u,v) at (u+v)*h + v
+	const float4* imgQ;   // anti-diagonal-major "quad" image: entry (u,v) = {I(u,v), I(u+1,v), I(u,v+1), I(u+1,v+1)} -- the four texels of a bilinear
+	                      // sample in ONE 16-byte load (the window-less tap rows are bound by the number of vector-memory instructions, not by bytes:
+	                      // the stride-2 taps of a patch never share texels, so the quad image is read at the same byte rate as the plain one)
 };
 #define PM_SRC_HOT 13     // doubles
 #define PM_SRC_GEO 14
@@ -361,7 +375,7 @@ __device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int 
 // row through global loads.  ~40 VALU instructions per tap instead of ~100.
 template <int TC, bool FROM_IMAGE = false>
 __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int tt0, int sw, int sh, bool sane, float h0, float h3, float h6,
-		float X0, float X1, float X2, const float2* wrow, float& sum, float& sumSq, float& num, bool& oob, const pm_gcf imgS = (pm_gcf)nullptr)
+		float X0, float X1, float X2, const float2* wrow, float& sum, float& sumSq, float& num, bool& oob, const pm_gcf4 imgQ = (pm_gcf4)nullptr)
 {
 	constexpr int MAXI = PM_TR * TC - 2 * TC - 2;   // idx + 2*TC + 1 stays inside the window
 	const int cidx = -(ts0 * TC + tt0);
@@ -393,7 +407,7 @@ __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int t
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
 		float v00, v01, v10, v11;
-		if (FROM_IMAGE) { const pm_gcf p = imgS + goff[j]; v00 = p[0]; v01 = p[sh]; v10 = p[sh + 1]; v11 = p[2 * sh + 1]; }
+		if (FROM_IMAGE) pm_load4(imgQ, goff[j], v00, v01, v10, v11);
 		else { v00 = q[j][0]; v01 = q[j][TC]; v10 = q[j][TC + 1]; v11 = q[j][2 * TC + 1]; }
 		const float fx = fxs[j], fx1 = 1.f - fx, fy = fys[j], fy1 = 1.f - fy;
 		const float v = (v00 * fx1 + v01 * fx) * fy1 + (v10 * fx1 + v11 * fx) * fy;
@@ -487,7 +501,7 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		if (TC > 0) done = true;
 #endif
 		if (((PM_GLOBAL_FAST_ROW && TC > 0 && SKEW) || FASTG) && !done)
-			done = pm_tap_row_lds<(TC > 0 ? TC : 1), true>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob, pm_glob(s.imgS)) || oob;
+			done = pm_tap_row_lds<(TC > 0 ? TC : 1), true>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob, pm_glob4(s.imgQ)) || oob;
 		if (!done) pm_tap_row_global<SKEW>(pm_glob(SKEW ? s.imgS : s.img), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
 		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
 	}
@@ -1363,6 +1377,17 @@ __global__ void pm_skew_kernel(const float* __restrict__ src, float* __restrict_
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
 		const int u = (int)(i % w), v = (int)((i / w) % h); const size_t im = i / ((size_t)w * h);
 		dst[im * sp + (size_t)(u + v) * h + v] = src[i];
+	}
+}
+// anti-diagonal-major quad image of nImg row-major images: dst[img][(u+v)*h + v] = {I(u,v), I(u+1,v), I(u,v+1), I(u+1,v+1)}, neighbours clamped at the
+// border (a bilinear sample reads entries with u <= w-2, v <= h-2 only: TImage::sample after isInsideWithBorder<1>)
+__global__ void pm_quad_kernel(const float* __restrict__ src, float4* __restrict__ dst, int w, int h, int nImg) {
+	const size_t n = (size_t)w * h * nImg, sp = (size_t)(w + h - 1) * h;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const int u = (int)(i % w), v = (int)((i / w) % h); const size_t im = i / ((size_t)w * h);
+		const float* s = src + im * (size_t)w * h;
+		const int u1 = min(u + 1, w - 1), v1 = min(v + 1, h - 1);
+		dst[im * sp + (size_t)(u + v) * h + v] = make_float4(s[(size_t)v * w + u], s[(size_t)v * w + u1], s[(size_t)v1 * w + u], s[(size_t)v1 * w + u1]);
 	}
 }
 __device__ __forceinline__ void pm_linear_coef(int d, int dn, int sn, int& s, float& a) {

@@ -5,18 +5,23 @@
 // and bench.py's cpu_baseline leg use it, and only as the checker / the timed CPU
 // baseline ("kind": "port").
 //
-// PARITY UNPINNED: the reference ships no golden depth maps or numeric asserts for
-// this path and cannot be built here (OpenCV/Eigen/Boost/CGAL absent),
-// so this restatement is pinned only by the known-answer tests in tests/ and by a
-// line-by-line reading of the reference sources cited on every function below
-// (paths relative to /root/reference).
+// PARITY PINNED BY THE REFERENCE'S OWN CODE (round 3): the reference ships no golden depth maps or numeric asserts for this path
+// and its whole tree cannot be built here (OpenCV / Eigen / Boost / CGAL absent), but the estimator itself can: oracle/ref/build_ref.py cuts
+// DepthEstimator (DepthMap.h:276-468, DepthMap.cpp:325-971), the pass bodies (SceneDensify.cpp:489-576) and the helpers they call out of
+// /root/reference verbatim and compiles them against a minimal OpenCV / Eigen stand-in (oracle/_ref).  tests/test_ref_pinning.py runs the same
+// arrays through that code and through this file (orc_run_level, rngMode 2) and compares bit for bit: init pass, sweeps in both directions,
+// geometric rounds, prior, masks, 1-4 sources, option sets, noise starts, and InterpolatePixel / CorrectNormal / ScorePixel on random planes.
+// The first such comparison found one real deviation -- norm(Point2f) of the geometric term binds to SEACAVE::norm (float), not cv::norm
+// (double) -- which is fixed here and in the kernels.  (paths below are relative to /root/reference)
 //
 // Deliberate, documented differences from the reference (DESIGN.md "Oracle"):
 //   * RNG: default mode is a counter-based Philox4x32-10 keyed by (seed, pass, pixel,
 //     attempt) so a parallel schedule can reproduce it; mode 1 keeps the reference's
 //     per-estimator std::mt19937 stream in traversal order (Random.h:102-137).
 //   * exp/acos/atan2/sin/cos come from csrc/pm_math.h (same polynomial kernels as the
-//     GPU) instead of libm; CorrectNormal's rotation is evaluated in float.
+//     GPU) instead of libm (the reference's side of the pinning tests is routed to the same header; a second build of oracle/_ref with
+//     libm bounds what that changes: tests/test_ref_pinning.py::test_libm_build_bounds_the_pm_math_substitution).
+//     CorrectNormal's rotation is evaluated in float -- as the reference does (Rotation.inl:701-728 with TYPE = float; checked by the pinning tests).
 //   * third-party arithmetic (cv::resize, cv::Matx::inv) is restated from OpenCV's
 //     published algorithms (integer-factor INTER_AREA incl. its border rule for non-divisible sizes).
 #include "../openmvs_amd/csrc/pm_math.h"

@@ -2,8 +2,9 @@
 // (libs/MVS/SemiGlobalMatcher.cpp:863-1302 in /root/reference): WZNCC cost volume, 8-path cost
 // aggregation (the threaded variant's path set, :1083-1200) and winner-take-all.
 //
-// *** TEST INFRASTRUCTURE ONLY *** (see pm_oracle.cpp).  PARITY UNPINNED by the reference (no SGM
-// vectors exist); pinned by the known-answer tests in tests/test_sgm_oracle.py.  The aggregation
+// *** TEST INFRASTRUCTURE ONLY *** (see pm_oracle.cpp).  PINNED by the reference's own code since round 3: oracle/_ref/libref_sgm.so is
+// SemiGlobalMatcher::Match cut verbatim from /root/reference (oracle/ref/ref_sgm_harness.cpp) and tests/test_ref_pinning.py compares disparity,
+// cost, cost volume and accumulated sums bit for bit (uniform, ragged and holed ranges); known-answer tests in tests/test_sgm_oracle.py.  The aggregation
 // recurrence is transcribed literally, O(D^2) inner loop included (:1030-1044); the GPU uses the
 // O(D) form, so the tests also check the two forms agree.  exp() is pm_expf (shared with the GPU).
 #include "../openmvs_amd/csrc/pm_math.h"

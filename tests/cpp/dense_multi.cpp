@@ -1,0 +1,53 @@
+// The multi-device C++ host (include/DenseDepthMapsHIPMulti.hpp) against the single-engine driver on the same scene: maps of every view and the
+// fused cloud must be the same bits whichever engine estimated a view.  Runs with several engines on ONE device through LocalCopyCollective (the
+// single-GPU box; under the CPU emulator in the not-gpu suite); the RCCL policy is the same code path with ncclBroadcast in place of the copies.
+// Usage: dense_multi <scene.bin> <engines> [seed] [serial]        scene.bin as tests/cpp/dense_driver.cpp; serial: no host threads (the CPU emulator is single-threaded)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "DenseDepthMapsHIPMulti.hpp"
+
+int main(int argc, char** argv) {
+	if (argc < 3) return 2;
+	FILE* f = fopen(argv[1], "rb"); if (!f) return 3;
+	const int nEng = atoi(argv[2]);
+	int32_t hd[4]; if (fread(hd, 4, 4, f) != 4) return 4;
+	const int n = hd[0], w = hd[1], h = hd[2], ns = hd[3];
+	const size_t P = (size_t)w * h;
+	std::vector<std::vector<float>> gray((size_t)n, std::vector<float>(P));
+	std::vector<std::vector<unsigned char>> bgr((size_t)n, std::vector<unsigned char>(P * 3));
+	std::vector<MVS::DenseDepthMapsHIP::View> views((size_t)n);
+	for (int i = 0; i < n; ++i) {
+		auto& v = views[(size_t)i];
+		double cam[21]; float rng[2]; std::vector<int32_t> nb((size_t)ns);
+		if (fread(gray[(size_t)i].data(), 4, P, f) != P || fread(bgr[(size_t)i].data(), 1, P * 3, f) != P * 3 || fread(cam, 8, 21, f) != 21 || fread(rng, 4, 2, f) != 2 ||
+		    fread(nb.data(), 4, (size_t)ns, f) != (size_t)ns) return 4;
+		v.gray = gray[(size_t)i].data(); v.bgr = bgr[(size_t)i].data();
+		memcpy(v.K, cam, 72); memcpy(v.R, cam + 9, 72); memcpy(v.C, cam + 18, 24);
+		v.dMin = rng[0]; v.dMax = rng[1]; v.neighbors = nb; v.ID = (uint32_t)i;
+	}
+	fclose(f);
+	MVS::DenseDepthMapsHIP::Options opt;
+	opt.seed = argc > 3 ? (uint32_t)atoi(argv[3]) : 31u; opt.nSpeckleSize = 30;
+	try {
+		MVS::DenseDepthMapsHIP one(0);
+		if (!one.IsValid()) { fprintf(stderr, "no device\n"); return 5; }
+		one.LoadScene(views, w, h, opt); one.ComputeDepthMaps();
+		MVS::DenseDepthMapsHIP::PointCloud pc1; one.FuseDepthMaps(pc1);
+		MVS::DenseDepthMapsHIPMultiT<MVS::LocalCopyCollective> multi(std::vector<int>((size_t)nEng, 0), argc <= 4);
+		if (!multi.IsValid()) { fprintf(stderr, "no device\n"); return 5; }
+		multi.LoadScene(views, w, h, opt); multi.ComputeDepthMaps();
+		MVS::DenseDepthMapsHIP::PointCloud pc2; multi.FuseDepthMaps(pc2);
+		std::vector<float> d1(P), n1(P * 3), c1(P), d2(P), n2(P * 3), c2(P);
+		for (int i = 0; i < n; ++i) {
+			one.GetMaps(i, d1.data(), n1.data(), c1.data()); multi.GetMaps(i, d2.data(), n2.data(), c2.data());
+			if (memcmp(d1.data(), d2.data(), P * 4) || memcmp(n1.data(), n2.data(), P * 12) || memcmp(c1.data(), c2.data(), P * 4)) { fprintf(stderr, "view %d differs\n", i); return 10; }
+		}
+		if (pc1.size() != pc2.size() || pc1.points != pc2.points || pc1.viewStart != pc2.viewStart || pc1.views != pc2.views || pc1.weights != pc2.weights || pc1.colors != pc2.colors || pc1.normals != pc2.normals) {
+			fprintf(stderr, "fused clouds differ: %zu vs %zu points\n", pc1.size(), pc2.size()); return 11; }
+		size_t valid = 0; one.GetMaps(0, d1.data(), nullptr, nullptr); for (float x : d1) valid += x > 0;
+		printf("%d engines == 1 engine: %d views, %zu fused points, view 0 valid %zu\n", nEng, n, pc1.size(), valid);
+	} catch (const std::exception& ex) { fprintf(stderr, "%s\n", ex.what()); return 7; }
+	return 0;
+}

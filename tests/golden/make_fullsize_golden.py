@@ -10,8 +10,8 @@ a strided sample of the depth map.  Inputs are NOT stored: the scene is rebuilt 
 operations only, the same bits on any host and on the GPU) and its SHA-256 is stored here, so that a test first proves it has the same inputs.
 
 Reference semantics restated by the oracle: SceneDensify.cpp:616-805 (EstimateDepthMap), SemiGlobalMatcher.cpp:863-1302 (Match).
-These digests pin the oracle (and through the -m gpu tests the HIP engine) at full size; they are not outputs of the reference binary,
-which cannot be built here (parity unpinned).
+These digests pin the oracle (and through the -m gpu tests the HIP engine) at full size; the oracle itself is pinned to the reference's own code
+by tests/test_ref_pinning.py (oracle/_ref).
 """
 import hashlib
 import json

@@ -67,7 +67,7 @@ enum { PMF_SMOOTH = 1, PMF_CHANGED = 2, PMF_POK0 = 4, PMF_POK1 = 8 };
 // ctl[0] = ticket counter, ctl[1] = error flag (a bounded wait gave up); progress[view * nBands + band] = 1 + sequence number of the band's last finished step
 template <int G, int VPL, bool GEO>
 __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, uint32_t pass, int nViews, int nBands,
-		unsigned* __restrict__ ctl, int* __restrict__ progress) {
+		int nChunks, int chunkW, const unsigned* __restrict__ order, unsigned* __restrict__ ctl, int* __restrict__ progress) {
 	constexpr int PPW = 64 / G;               // pixels (= rows) per wave
 	constexpr int NV = G * VPL;
 	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
@@ -81,9 +81,13 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMT
 	unsigned ticket = 0;
 	if (lane == 0) ticket = atomicAdd(&ctl[0], 1u);
 	ticket = (unsigned)__shfl((int)ticket, 0, 64);
-	const int bandSeq = (int)(ticket / (unsigned)nViews), view = (int)(ticket - (unsigned)bandSeq * (unsigned)nViews);
-	if (bandSeq >= nBands) return;
-	const int band = dir == 0 ? bandSeq : nBands - 1 - bandSeq;
+	// A task = (view, band of PPW rows, chunk of chunkW columns).  order[] lists (band, chunk) pairs, in sweep order, sorted so that both predecessors of a
+	// task -- the band before it (same chunk) and the chunk before it (same band) -- come earlier; every view's k-th pair gets its ticket before any (k+1)-th.
+	const int entry = (int)(ticket / (unsigned)nViews), view = (int)(ticket - (unsigned)entry * (unsigned)nViews);
+	if (entry >= nBands * nChunks) return;
+	const unsigned oe = order[entry];
+	const int band = dir == 0 ? (int)(oe >> 16) : nBands - 1 - (int)(oe >> 16);
+	const int chunk = dir == 0 ? (int)(oe & 0xffffu) : nChunks - 1 - (int)(oe & 0xffffu);
 	const PMTask& t = tasks[view];
 	for (int i = lane; i < NV * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];   // views >= nSrc: zeros (the task is memset), never used
 	const double* hotBase = s_src;
@@ -93,17 +97,31 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMT
 	// the estimate this lane's pixel group left at its previous step (the horizontal "new" neighbour of the next one)
 	float pvD = 0.f, pvN0 = 0.f, pvN1 = 0.f, pvN2 = 0.f, pvC = 2.f;
 	__syncthreads();
-	const int nSteps = [&]() { const int yT = PM_HW + band * PPW; const int r = min(PPW, (t.h - PM_HW) - yT); return (t.w - 1 - PM_HW) + (yT + r - 1) - (PM_HW + yT) + 1; }();
+	int* const progBase = progress + ((size_t)view * nBands) * nChunks;          // [band][chunk] of this view
+	{	// the chunk before this one in the sweep direction must be complete: its last column is this chunk's first horizontal neighbour
+		const int hp = chunk + sgn;
+		if (hp >= 0 && hp < nChunks) {
+			int spins = 0;
+			while (pm_ld_agent_i(progBase + (size_t)band * nChunks + hp) != 0x7fffffff) {
+				pm_nap();
+				if (++spins > PM_BAND_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctl[1], 1u); break; }
+			}
+			pm_compiler_fence();
+		}
+	}
+	const int nSteps = [&]() { const int yT = PM_HW + band * PPW; const int r = min(PPW, (t.h - PM_HW) - yT);
+		const int xa = PM_HW + chunk * chunkW, xb = min(xa + chunkW - 1, t.w - 1 - PM_HW); return (xb + (yT + r - 1)) - (xa + yT) + 1; }();
 	for (int s = 0; s < nSteps; ++s) {
 		const int w = t.w, h = t.h;
 		const int yTop = PM_HW + band * PPW;
 		const int rows = min(PPW, (h - PM_HW) - yTop);       // rows of this band that are processable (y <= h-1-HW)
 		const int y = yTop + g;
-		const int dLo = PM_HW + yTop, dHi = (w - 1 - PM_HW) + (yTop + rows - 1);
+		const int xc0 = PM_HW + chunk * chunkW, xc1 = min(xc0 + chunkW - 1, w - 1 - PM_HW);   // columns of this chunk
+		const int dLo = xc0 + yTop, dHi = xc1 + (yTop + rows - 1);
 		const int d = dir == 0 ? dLo + s : dHi - s;
 		const int q = dir == 0 ? d : (w - 1 - PM_HW) + (h - 1 - PM_HW) - d;   // sequence number of this diagonal in sweep order
 		const int x = d - y;
-		const bool active = g < rows && x >= PM_HW && x <= w - 1 - PM_HW;
+		const bool active = g < rows && x >= xc0 && x <= xc1;
 		const size_t idx = active ? (size_t)y * w + x : (size_t)yTop * w + PM_HW;
 		const int predBand = band + sgn, succBand = band - sgn;
 		const bool predExists = predBand >= 0 && predBand < nBands, succExists = succBand >= 0 && succBand < nBands;
@@ -127,9 +145,9 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMT
 		// ... or, for the band's edge row, from the preceding band: wait until it is at most one diagonal behind, then read what it published
 		{
 			const int xc = d - (yTop + gCons);
-			const bool needPred = predExists && xc >= PM_HW && xc <= w - 1 - PM_HW;   // wave-uniform
+			const bool needPred = predExists && xc >= xc0 && xc <= xc1;   // wave-uniform
 			if (needPred) {
-				const int* const predProgress = progress + (size_t)view * nBands + predBand;
+				const int* const predProgress = progBase + (size_t)predBand * nChunks + chunk;
 				int spins = 0;
 				while (pm_ld_agent_i(predProgress) < q) {
 					pm_nap();
@@ -149,6 +167,11 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMT
 		if (bok[0] && (x + sgn < PM_HW || x + sgn > w - 1 - PM_HW)) {
 			const size_t qi = qis[0];
 			n0D = gDepth[qi]; n0N0 = gNormal[qi * 3]; n0N1 = gNormal[qi * 3 + 1]; n0N2 = gNormal[qi * 3 + 2]; n0C = gConf[qi];
+		} else if (bok[0] && (x + sgn < xc0 || x + sgn > xc1)) {
+			// first column of the chunk: the horizontal neighbour is the last column of the preceding chunk (complete, written through)
+			const size_t qi = qis[0];
+			n0D = pm_ld_agent((const float*)t.depth + qi); n0C = pm_ld_agent((const float*)t.conf + qi);
+			n0N0 = pm_ld_agent((const float*)t.normal + qi * 3); n0N1 = pm_ld_agent((const float*)t.normal + qi * 3 + 1); n0N2 = pm_ld_agent((const float*)t.normal + qi * 3 + 2);
 		}
 		if (bok[1] && (y + sgn < PM_HW || y + sgn > h - 1 - PM_HW)) {
 			const size_t qi = qis[1];
@@ -342,8 +365,9 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMT
 			const float depth = P->depth, nx = P->nx, ny = P->ny, nz = P->nz, conf = P->conf;
 			pvD = wr ? depth : oDepth; pvN0 = wr ? nx : oNx; pvN1 = wr ? ny : oNy; pvN2 = wr ? nz : oNz; pvC = wr ? conf : oConf;
 			if (wr && v == 0) {
-				if (succExists && g == gPub) {
-					// the following band reads this pixel while the launch runs: write it through
+				const bool lastCol = dir == 0 ? (x == xc1 && chunk + 1 < nChunks) : (x == xc0 && chunk > 0);
+				if ((succExists && g == gPub) || lastCol) {
+					// the following band (or the following chunk) reads this pixel while the launch runs: write it through
 					pm_st_agent((float*)t.depth + idx, depth); pm_st_agent((float*)t.normal + idx * 3, nx); pm_st_agent((float*)t.normal + idx * 3 + 1, ny);
 					pm_st_agent((float*)t.normal + idx * 3 + 2, nz); pm_st_agent((float*)t.conf + idx, conf);
 				} else { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
@@ -351,13 +375,11 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMT
 		}
 		if (succExists) {
 			pm_drain_stores();                                   // the published pixel has left this wave before the counter moves
-			if (lane == 0) pm_st_agent_i(progress + (size_t)view * nBands + band, q + 1);
+			if (lane == 0) pm_st_agent_i(progBase + (size_t)band * nChunks + chunk, q + 1);
 		}
 		__syncthreads();                                         // the next step rewrites s_pix / s_w
 	}
-	{
-		const int succBand = band - sgn;
-		if (succBand >= 0 && succBand < nBands && lane == 0) pm_st_agent_i(progress + (size_t)view * nBands + band, 0x7fffffff);
-	}
+	pm_drain_stores();                                           // the last column has left this wave: the next chunk and the next band may read it
+	if (lane == 0) pm_st_agent_i(progBase + (size_t)band * nChunks + chunk, 0x7fffffff);
 	PM_PROF_FLUSH();
 }

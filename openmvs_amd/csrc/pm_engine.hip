@@ -28,6 +28,12 @@
 #ifndef PMHIP_DEFAULT_GROUPS
 #define PMHIP_DEFAULT_GROUPS 2
 #endif
+#ifndef PMHIP_DEFAULT_BAND_CHUNK
+#define PMHIP_DEFAULT_BAND_CHUNK 256   // columns per band task
+#endif
+#ifndef PMHIP_DEFAULT_BAND_SLACK
+#define PMHIP_DEFAULT_BAND_SLACK 16    // ticket order: a band starts this many diagonals after the band it follows (>= rows per band for a legal order)
+#endif
 #ifndef PMHIP_DEFAULT_BAND
 #define PMHIP_DEFAULT_BAND 1     // sweeps as one resident launch per iteration (pm_band.hip); 0 = one launch per anti-diagonal (pm_sweep_kernel / pm_sweep_wide_kernel)
 #endif
@@ -101,8 +107,10 @@ struct pmhip_engine {
 	int wideMaxViews = PMHIP_DEFAULT_WIDE;   // batches of at most this many views use the one-wave-per-pixel sweep kernel (PMHIP_WIDE)
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
 	int bandMode = PMHIP_DEFAULT_BAND;      // PMHIP_BAND
-	unsigned* d_bandCtl = nullptr;          // [0] ticket counter, [1] error flag, then progress[batchCap][bandCap] (pm_band.hip)
-	int bandCap = 0;
+	unsigned* d_bandCtl = nullptr;          // [0] ticket counter, [1] error flag, then progress[batchCap][bandPairCap] (pm_band.hip)
+	unsigned* d_bandOrder = nullptr; unsigned* h_bandOrder = nullptr;   // (band << 16 | chunk) pairs in ticket order
+	int bandPairCap = 0;
+	int bandChunkW = PMHIP_DEFAULT_BAND_CHUNK, bandSlack = PMHIP_DEFAULT_BAND_SLACK;   // PMHIP_BAND_CHUNK, PMHIP_BAND_SLACK
 	hipStream_t gstream[16] = {};
 	hipEvent_t forkEv = nullptr, joinEv[16] = {};
 	bool inited = false, geom = false;
@@ -178,8 +186,8 @@ static void freeScene(pmhip_engine* e) {
 	e->d_fdepth = e->d_fconf = nullptr; e->d_fvalid = nullptr; e->d_splat = nullptr; e->d_ftasks = nullptr; e->h_ftasks = nullptr; e->splatCap = e->ftaskCap = 0;
 	if (e->d_tasks) hipFree(e->d_tasks); if (e->h_tasks) hipHostFree(e->h_tasks);
 	if (e->d_ups) hipFree(e->d_ups); if (e->h_ups) hipHostFree(e->h_ups);
-	if (e->d_bandCtl) hipFree(e->d_bandCtl);
-	e->d_bandCtl = nullptr; e->bandCap = 0;
+	if (e->d_bandCtl) hipFree(e->d_bandCtl); if (e->d_bandOrder) hipFree(e->d_bandOrder); if (e->h_bandOrder) hipHostFree(e->h_bandOrder);
+	e->d_bandCtl = nullptr; e->d_bandOrder = nullptr; e->h_bandOrder = nullptr; e->bandPairCap = 0;
 	e->d_tasks = nullptr; e->h_tasks = nullptr; e->d_ups = nullptr; e->h_ups = nullptr;
 	for (SceneView& v : e->views) freeSide(v);
 	e->batchCap = 0; e->nImages = 0; e->views.clear();
@@ -191,12 +199,15 @@ static int ensureBatch(pmhip_engine* e, int n) {
 	for (int l = 0; l < 4; ++l) { if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
 	if (e->d_tasks) hipFree(e->d_tasks); if (e->h_tasks) hipHostFree(e->h_tasks);
 	if (e->d_ups) hipFree(e->d_ups); if (e->h_ups) hipHostFree(e->h_ups);
-	if (e->d_bandCtl) hipFree(e->d_bandCtl);
-	e->d_bandCtl = nullptr;
+	if (e->d_bandCtl) hipFree(e->d_bandCtl); if (e->d_bandOrder) hipFree(e->d_bandOrder); if (e->h_bandOrder) hipHostFree(e->h_bandOrder);
+	e->d_bandCtl = nullptr; e->d_bandOrder = nullptr; e->h_bandOrder = nullptr;
 	e->d_tasks = nullptr; e->h_tasks = nullptr; e->d_ups = nullptr; e->h_ups = nullptr;
 	const int cap = std::max(n, 1);
-	e->bandCap = (e->h + 3) / 4 + 1;                       // bands of the narrowest mapping (16 lanes per pixel: 4 rows per wave)
-	HIPCHK(e, hipMalloc(&e->d_bandCtl, sizeof(unsigned) * (2 + (size_t)cap * e->bandCap)));
+	// (band, chunk) pairs of the narrowest mapping (16 lanes per pixel: 4 rows per wave) at the configured chunk width
+	e->bandPairCap = ((e->h + 3) / 4 + 1) * ((e->w + std::max(16, e->bandChunkW) - 1) / std::max(16, e->bandChunkW) + 1);
+	HIPCHK(e, hipMalloc(&e->d_bandCtl, sizeof(unsigned) * (2 + (size_t)cap * e->bandPairCap)));
+	HIPCHK(e, hipMalloc(&e->d_bandOrder, sizeof(unsigned) * (size_t)e->bandPairCap));
+	HIPCHK(e, hipHostMalloc(&e->h_bandOrder, sizeof(unsigned) * (size_t)e->bandPairCap));
 	HIPCHK(e, hipMemsetAsync(e->d_bandCtl, 0, sizeof(unsigned) * 2, e->stream));
 	HIPCHK(e, hipMalloc(&e->d_lvl[0], sizeof(float) * (size_t)cap * e->w * e->h));
 	for (int l = 1; l <= e->nLevels; ++l)
@@ -307,8 +318,9 @@ static void sweepMapping(int maxSrc, int lanes, int& G, int& VPL) {
 
 // the same mappings for the resident band kernel (pm_band.hip): one launch per sweep iteration
 template <bool GEO>
-static bool launchBand(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, uint32_t pass, int nViews, int nBands, unsigned* ctl, int* progress) {
-#define PM_BAND_CASE(g, vpl) case (g) * 16 + (vpl): hipLaunchKernelGGL((pm_band_kernel<g, vpl, GEO>), grid, dim3(64), 0, s, t, kp, dir, pass, nViews, nBands, ctl, progress); return true
+static bool launchBand(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, uint32_t pass, int nViews, int nBands, int nChunks, int chunkW,
+		const unsigned* order, unsigned* ctl, int* progress) {
+#define PM_BAND_CASE(g, vpl) case (g) * 16 + (vpl): hipLaunchKernelGGL((pm_band_kernel<g, vpl, GEO>), grid, dim3(64), 0, s, t, kp, dir, pass, nViews, nBands, nChunks, chunkW, order, ctl, progress); return true
 	switch (G * 16 + VPL) {
 	PM_BAND_CASE(4, 1); PM_BAND_CASE(8, 1); PM_BAND_CASE(16, 1);
 	PM_BAND_CASE(4, 2); PM_BAND_CASE(8, 2);
@@ -494,12 +506,26 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 				// one resident launch: a wave per (view, band of 64 / SG rows); ticket and progress counters are cleared on the stream first
 				if (SG < 4) { VPL = std::max(1, SG * VPL / 4); SG = 4; }   // the band kernel gives a pixel at least a quad of lanes (views with < 4 sources: idle lanes)
 				const int PPW = 64 / SG, nBands = (lh - 2 * PM_HW + PPW - 1) / PPW;
+				// tasks = (view, band, chunk of chunkW columns): short enough that the launch's tail (fewer tasks left than wave slots) is a small
+				// fraction of it; ordered by bandSlack * band + chunkW * chunk, which keeps a band that many diagonals behind the one it follows
+				const int chunkW = std::max(16, e->bandChunkW), nChunks = (lw - 2 * PM_HW + chunkW - 1) / chunkW;
+				const int nPairs = nBands * nChunks;
+				if (nPairs > e->bandPairCap) { e->err = "band kernel: too many (band, chunk) pairs"; return PMHIP_E_SIZE; }
+				{
+					std::vector<std::pair<long, unsigned>> keyed((size_t)nPairs);
+					for (int b = 0; b < nBands; ++b) for (int c = 0; c < nChunks; ++c)
+						keyed[(size_t)b * nChunks + c] = std::make_pair((long)e->bandSlack * b + (long)chunkW * c, ((unsigned)b << 16) | (unsigned)c);
+					std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<long, unsigned>& a, const std::pair<long, unsigned>& b) { return a.first < b.first; });
+					HIPCHK(e, hipStreamSynchronize(e->stream));          // h_bandOrder is reused by every sweep
+					for (int i = 0; i < nPairs; ++i) e->h_bandOrder[i] = keyed[(size_t)i].second;
+					HIPCHK(e, hipMemcpyAsync(e->d_bandOrder, e->h_bandOrder, sizeof(unsigned) * (size_t)nPairs, hipMemcpyHostToDevice, e->stream));
+				}
 				const size_t evB = evBeginOn(e, 0, e->stream), evW = evBeginOn(e, 2, e->stream);
 				HIPCHK(e, hipMemsetAsync(e->d_bandCtl, 0, sizeof(unsigned), e->stream));
-				HIPCHK(e, hipMemsetAsync(e->d_bandCtl + 2, 0, sizeof(unsigned) * (size_t)nB * nBands, e->stream));
-				const dim3 grid((unsigned)nBands * (unsigned)nB);
-				const bool ok = geo ? launchBand<true>(SG, VPL, grid, e->stream, dt, kp, dir, pass, nB, nBands, e->d_bandCtl, (int*)(e->d_bandCtl + 2))
-				                    : launchBand<false>(SG, VPL, grid, e->stream, dt, kp, dir, pass, nB, nBands, e->d_bandCtl, (int*)(e->d_bandCtl + 2));
+				HIPCHK(e, hipMemsetAsync(e->d_bandCtl + 2, 0, sizeof(unsigned) * (size_t)nB * nPairs, e->stream));
+				const dim3 grid((unsigned)nPairs * (unsigned)nB);
+				const bool ok = geo ? launchBand<true>(SG, VPL, grid, e->stream, dt, kp, dir, pass, nB, nBands, nChunks, chunkW, e->d_bandOrder, e->d_bandCtl, (int*)(e->d_bandCtl + 2))
+				                    : launchBand<false>(SG, VPL, grid, e->stream, dt, kp, dir, pass, nB, nBands, nChunks, chunkW, e->d_bandOrder, e->d_bandCtl, (int*)(e->d_bandCtl + 2));
 				if (!ok) { e->err = "band kernel: mapping not instantiated"; return PMHIP_E_ARG; }
 				evEndOn(e, evB, e->stream); evEndOn(e, evW, e->stream);
 				if (e->statsOn) {
@@ -602,6 +628,8 @@ int pmhip_create(int device, pmhip_engine** out) {
 	if (nw) e->wideMaxViews = atoi(nw);
 	const char* bm = getenv("PMHIP_BAND");
 	if (bm) e->bandMode = atoi(bm) != 0;
+	const char* bc = getenv("PMHIP_BAND_CHUNK"); if (bc && atoi(bc) >= 16) e->bandChunkW = atoi(bc);
+	const char* bs = getenv("PMHIP_BAND_SLACK"); if (bs && atoi(bs) >= 0) e->bandSlack = atoi(bs);
 	const char* nl = getenv("PMHIP_LANES");
 	if (nl && atoi(nl) >= 1) e->sweepLanes = atoi(nl);
 	for (int g = 0; g < e->nGroups; ++g)

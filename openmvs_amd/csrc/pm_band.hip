@@ -64,6 +64,208 @@ template <class T> __device__ __forceinline__ T* pm_launder(T* p) { return p; }
 #endif
 enum { PMF_SMOOTH = 1, PMF_CHANGED = 2, PMF_POK0 = 4, PMF_POK1 = 8 };
 
+// One ProcessPixel visit (DepthMap.cpp:630-852) of the G lanes of a pixel, shared by the band kernel and the per-diagonal kernel below.
+// n0* / n1*: the two neighbours the sweep has already updated (depth, normal, conf), however the caller obtained them; bok / qxs / qys / qis: the four
+// neighbour slots (bounds tests, coordinates, map indices).  afterPatch() runs once the visit's loads have been waited for (the band kernel publishes its
+// previous step there).  Result: r* = what the maps hold at this pixel after the visit, wr = it changed.
+template <int G, int VPL, bool GEO, class AfterPatch>
+__device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, uint32_t pass, int sgn, float2* s_wg, PMPix* s_pixg, const double* hotBase,
+		int g, int v, int slot, bool active, int x, int y, int ySafe, size_t idx, const bool* bok, const int* qxs, const int* qys, const size_t* qis,
+		float n0D, float n0N0, float n0N1, float n0N2, float n0C, float n1D, float n1N0, float n1N1, float n1N2, float n1C,
+		AfterPatch afterPatch, float& rD, float& rN0, float& rN1, float& rN2, float& rC, bool& wr PM_PROF_ARG) {
+	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
+	constexpr int TC = 0;                     // no LDS windows: the optimistic tap rows read the quad image through the vector L1
+	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
+	const int yTop = ySafe;
+	// ---- what the visit reads from memory: its own estimate, the two not yet updated neighbours, prior, mask (none of it written earlier in this launch) ----
+	float oDepth = 0.f, oNx = 0.f, oNy = 0.f, oNz = 0.f, oConf = 2.f, prior = 0.f;
+	float myD = 0.f, myN0 = 0.f, myN1 = 0.f, myN2 = 1.f;     // depth and normal of my smoothness slot's pixel
+	unsigned char maskByte = 1;
+	if (active) {
+		if (t.prior) prior = pm_glob(t.prior)[idx];
+		if (t.mask != nullptr) maskByte = t.mask[idx];
+		if (slot == 0) { myD = bok[0] ? n0D : 0.f; myN0 = n0N0; myN1 = n0N1; myN2 = n0N2; }
+		else if (slot == 1) { myD = bok[1] ? n1D : 0.f; myN0 = n1N0; myN1 = n1N1; myN2 = n1N2; }
+		else { const size_t qi = slot == 2 ? qis[2] : qis[3]; myD = gDepth[qi]; myN0 = gNormal[qi * 3]; myN1 = gNormal[qi * 3 + 1]; myN2 = gNormal[qi * 3 + 2]; }
+		oDepth = gDepth[idx]; oNx = gNormal[idx * 3]; oNy = gNormal[idx * 3 + 1]; oNz = gNormal[idx * 3 + 2]; oConf = gConf[idx];
+	}
+	float normSq0, sumW;
+	pm_fill_patch<G, true>(t, active, active ? x : PM_HW, active ? y : yTop, v, s_wg, normSq0, sumW);
+	afterPatch();
+	const bool masked = active && maskByte == 0;
+	const bool valid = active && !masked && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
+	if (v == 0) s_wg[PM_NT] = make_float2(prior, prior > 0 ? pm_expf(normSq0 * (-1.f / (1.f * 0.02f))) : 0.f);
+	// ---- the visit's state goes to LDS: current estimate, neighbours, close-neighbour slots (lane `slot` of the first quad writes slot `slot`) ----
+	{
+		PMPix* P = pm_launder(s_pixg);
+		const bool bk = slot == 0 ? bok[0] : slot == 1 ? bok[1] : slot == 2 ? bok[2] : bok[3];
+		const bool okS = valid && bk && myD > 0;
+		const unsigned cm = (unsigned)__ballot(okS) >> 0;   // (ballot of the whole wave; my group's four bits are picked below)
+		const unsigned long long bal = __ballot(okS);
+		const unsigned closeMask = (unsigned)((bal >> (g * G)) & 0xFull);
+		(void)cm;
+		if (v < 4) {
+			// TransformPointI2C(Point3(nx, ndepth)) in double then Cast<float>, Camera.h:338-344
+			const int qx = slot == 0 ? qxs[0] : slot == 1 ? qxs[1] : slot == 2 ? qxs[2] : qxs[3];
+			const int qy = slot == 0 ? qys[0] : slot == 1 ? qys[1] : slot == 2 ? qys[2] : qys[3];
+			const double z = (double)myD;
+			P->qX[slot][0] = okS ? (float)(((double)qx - t.cx) * z / t.fx) : 0.f;
+			P->qX[slot][1] = okS ? (float)(((double)qy - t.cy) * z / t.fy) : 0.f;
+			P->qX[slot][2] = okS ? (float)z : 0.f;
+			P->qn[slot][0] = okS ? myN0 : 0.f; P->qn[slot][1] = okS ? myN1 : 0.f; P->qn[slot][2] = okS ? myN2 : 1.f;
+		}
+		if (v == 0) {
+			const double X0x = ((double)x - t.cx) / t.fx, X0y = ((double)y - t.cy) / t.fy;
+			P->X0x = X0x; P->X0y = X0y; P->vx = (float)X0x; P->vy = (float)X0y; P->normSq0 = normSq0; P->sumW = sumW; P->x = x; P->y = y;
+			P->depth = valid ? oDepth : 0.f; P->nx = valid ? oNx : 0.f; P->ny = valid ? oNy : 0.f; P->nz = valid ? oNz : 0.f; P->conf = valid ? oConf : 2.f;
+			P->p0 = 0.f; P->p1 = 0.f; P->scaleRange = 1.f; P->depthRange = 0.f;
+			enum { ST_PROP0 = 0, ST_DONE = 5 };
+			P->st = valid ? ST_PROP0 : ST_DONE; P->it = 0; P->idxScale = 0;
+			P->flags = PMF_SMOOTH | ((closeMask & 1u) ? PMF_POK0 : 0) | ((closeMask & 2u) ? PMF_POK1 : 0) | (int)(closeMask << 8);
+			P->nb[0][0] = n0D; P->nb[0][1] = n0N0; P->nb[0][2] = n0N1; P->nb[0][3] = n0N2; P->nb[0][4] = n0C;
+			P->nb[1][0] = n1D; P->nb[1][1] = n1N0; P->nb[1][2] = n1N1; P->nb[1][3] = n1N2; P->nb[1][4] = n1C;
+		}
+	}
+	__syncthreads();
+	// ---- ProcessPixel's control flow as a per-pixel state machine: every outer trip scores at most one hypothesis per pixel (as pm_sweep_kernel) ----
+	enum { ST_PROP0 = 0, ST_PROP1 = 1, ST_DECIDE = 2, ST_RAND = 3, ST_REFINE = 4, ST_DONE = 5 };
+	const uint32_t k1 = t.k1base + pass;
+	for (;;) {
+		bool need = false;
+		float hd = 0.f, hnx = 0.f, hny = 0.f, hnz = 1.f;
+		{	// -- next hypothesis of my pixel (every lane of the group computes the same; lane 0 records it)
+			PMPix* P = pm_launder(s_pixg);
+			int st = P->st; unsigned it = (unsigned)P->it, idxScale = (unsigned)P->idxScale; int flags = P->flags;
+			const int px = P->x, py = P->y;
+			const float vx = P->vx, vy = P->vy, vz = 1.f;
+			float scaleRange = P->scaleRange, depthRange = P->depthRange, p0 = P->p0, p1 = P->p1;
+			float hp0 = 0.f, hp1 = 0.f; int hst = ST_DONE;
+			while (!need && st != ST_DONE) {
+				if (st <= ST_PROP1) {
+					const bool vert = (st == ST_PROP1); ++st; // slot 0: same row, slot 1: same column
+					const bool pok = (flags & (vert ? PMF_POK1 : PMF_POK0)) != 0;
+					const float* nbp = P->nb[vert ? 1 : 0];
+					const float cd = nbp[0], cnx = nbp[1], cny = nbp[2], cnz = nbp[3], pconf = nbp[4];
+					hd = cd; hnx = cnx; hny = cny; hnz = cnz;
+					if (pok && pconf < kp.thKeep) {
+						// InterpolatePixel, DepthMap.cpp:915-959
+						float depthNew = cd; bool zero;
+						if (vert) { // same column
+							const float nx1 = (float)(((double)py - t.cy) / t.fy);
+							const float denom = cnz + nx1 * cny;
+							zero = pm_fabsf(denom) < 0.0001f;
+							const float x1 = (float)(((double)(py + sgn) - t.cy) / t.fy);
+							const float nom = cd * (cnz + x1 * cny);
+							if (!zero) depthNew = nom / denom;
+						} else {
+							const float nx1 = (float)(((double)px - t.cx) / t.fx);
+							const float denom = cnz + nx1 * cnx;
+							zero = pm_fabsf(denom) < 0.0001f;
+							const float x1 = (float)(((double)(px + sgn) - t.cx) / t.fx);
+							const float nom = cd * (cnz + x1 * cnx);
+							if (!zero) depthNew = nom / denom;
+						}
+						hd = (!zero && pm_in_range(depthNew, t.dMin, t.dMax)) ? depthNew : cd;
+						hnx = cnx; hny = cny; hnz = cnz;
+						pm_correct_normal(vx, vy, vz, hnx, hny, hnz);
+						need = true; hst = ST_PROP0;
+					}
+				} else if (st == ST_DECIDE) {
+					// RefineIters:, DepthMap.cpp:802-827
+					const float conf = P->conf;
+					if (conf <= kp.thConfSmall) idxScale = 2;
+					else if (conf <= kp.thConfBig) idxScale = 1;
+					else if (conf >= kp.thConfRand) { flags &= ~PMF_SMOOTH; st = ST_RAND; it = 0; continue; }
+					scaleRange = pm_pow2neg(idxScale);
+					depthRange = P->depth * kp.depthRatio;
+					p0 = pm_atan2f(P->ny, P->nx); p1 = pm_acosf(pm_clampf(P->nz, -1.f, 1.f)); // Normal2Dir
+					st = ST_REFINE; it = 0;
+				} else if (st == ST_RAND) {
+					if (it >= kp.nRandomIters) { st = ST_DONE; break; }
+					const PmPhilox4 r = pm_philox4x32_10((uint32_t)px, (uint32_t)py, (uint32_t)(PM_STREAM_RAND * 256) + it, 0u, t.k0, k1);
+					++it;
+					const float rr = t.dMinSqr + (t.dMaxSqr - t.dMinSqr) * pm_u32_to_unit(r.v[0]);
+					hd = rr * rr;
+					pm_random_normal(pm_u32_to_unit(r.v[1]), pm_u32_to_unit(r.v[2]), vx, vy, vz, hnx, hny, hnz);
+					need = true; hst = ST_RAND;
+				} else { // ST_REFINE, DepthMap.cpp:832-852
+					if (it >= kp.nRandomIters) { st = ST_DONE; break; }
+					const PmPhilox4 r = pm_philox4x32_10((uint32_t)px, (uint32_t)py, (uint32_t)(PM_STREAM_REFINE * 256) + it, 0u, t.k0, k1);
+					++it;
+					const float ndepth = P->depth + (depthRange * scaleRange) * (2.f * pm_u32_to_unit(r.v[0]) - 1.f);
+					if (!pm_in_range(ndepth, t.dMin, t.dMax)) continue;
+					hp0 = p0 + (kp.angle1Range * scaleRange) * (2.f * pm_u32_to_unit(r.v[1]) - 1.f);
+					hp1 = p1 + (kp.angle2Range * scaleRange) * (2.f * pm_u32_to_unit(r.v[2]) - 1.f);
+					pm_dir2normal(hp0, hp1, hnx, hny, hnz);
+					if (hnx * vx + hny * vy + hnz * vz >= 0) continue;
+					hd = ndepth;
+					need = true; hst = ST_REFINE;
+				}
+			}
+			__builtin_amdgcn_wave_barrier();                     // every lane of the group has read the state before lane 0 advances it
+			if (v == 0) {
+				P->st = st; P->it = (int)it; P->idxScale = (int)idxScale; P->flags = flags;
+				P->scaleRange = scaleRange; P->depthRange = depthRange; P->p0 = p0; P->p1 = p1;
+				P->hd = hd; P->hnx = hnx; P->hny = hny; P->hnz = hnz; P->hp0 = hp0; P->hp1 = hp1; P->hst = hst;
+			}
+		}
+		if (!__any(need)) break;
+		// -- smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533, one neighbour per lane
+		float sf0, sf1, sf2, sf3;
+		{
+			const PMPix* P = pm_launder(s_pixg);
+			const int flags = P->flags;
+			const bool on = need && (flags & PMF_SMOOTH) && ((flags >> (8 + slot)) & 1);
+			float myF = 1.f;
+			if (on) {
+				const float vx = P->vx, vy = P->vy;
+				const float q0 = P->qX[slot][0], q1 = P->qX[slot][1], q2 = P->qX[slot][2], m0 = P->qn[slot][0], m1 = P->qn[slot][1], m2 = P->qn[slot][2];
+				const float planeD = -hd * (hnx * vx + hny * vy + hnz * 1.f); // InitPlane, DepthMap.cpp:963-971
+				const float dist = (hnx * q0 + (hny * q1 + hnz * q2)) + planeD; // Planef::Distance, Eigen 3-dot order
+				const float r = dist / hd;
+				const float factorDepth = pm_expf((r * r) * kp.smoothSigmaDepth);
+				const float ca = pm_clampf((hnx * m0 + hny * m1 + hnz * m2) / pm_sqrtf((hnx * hnx + hny * hny + hnz * hnz) * (m0 * m0 + m1 * m1 + m2 * m2)), -1.f, 1.f);
+				const float ac = pm_acosf(ca);
+				const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
+				myF = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
+			}
+			sf0 = pm_quad_bcast<0>(myF); sf1 = pm_quad_bcast<1>(myF); sf2 = pm_quad_bcast<2>(myF); sf3 = pm_quad_bcast<3>(myF);
+		}
+		// -- score against my source view(s)
+		float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
+		{
+			const PMPix* P = pm_launder(s_pixg);
+#pragma unroll 1
+			for (int u = 0; u < VPL; ++u) {
+				const int vw = v + u * G;
+				if (need && vw < t.nSrc) {
+					const float s1 = pm_score_view<GEO, true, TC, true>(t.src[vw], t, kp, P->x, P->y, P->X0x, P->X0y, P->normSq0, P->sumW, s_wg, hd, hnx, hny, hnz, sf0, sf1, sf2, sf3, 0.f,
+						nullptr, 0, 0, hotBase + vw * NBD, hotBase + vw * NBD + PM_SRC_HOT, nullptr PM_PROF_PASS);
+					if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
+				}
+			}
+		}
+		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
+		{	// -- accept (DepthMap.cpp:794-799, :784-793, :843-851)
+			PMPix* P = pm_launder(s_pixg);
+			if (need && v == 0 && P->conf > nconf) {
+				P->conf = nconf; P->depth = P->hd; P->nx = P->hnx; P->ny = P->hny; P->nz = P->hnz;
+				int flags = P->flags | PMF_CHANGED;
+				P->flags = flags;
+				const int hst = P->hst;
+				if (hst == ST_RAND) { if (nconf < kp.thConfRand) P->st = ST_DECIDE; }
+				else if (hst == ST_REFINE) { P->p0 = P->hp0; P->p1 = P->hp1; const int is = P->idxScale + 1; P->idxScale = is; P->scaleRange = pm_pow2neg((unsigned)is); }
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+	{
+		const PMPix* P = pm_launder(s_pixg);
+		wr = (P->flags & PMF_CHANGED) && valid;
+		rD = wr ? P->depth : oDepth; rN0 = wr ? P->nx : oNx; rN1 = wr ? P->ny : oNy; rN2 = wr ? P->nz : oNz; rC = wr ? P->conf : oConf;
+	}
+}
+
 // ctl[0] = ticket counter, ctl[1] = error flag (a bounded wait gave up); progress[view * nBands + band] = 1 + sequence number of the band's last finished step
 template <int G, int VPL, bool GEO>
 __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, uint32_t pass, int nViews, int nBands,
@@ -109,6 +311,8 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMT
 			pm_compiler_fence();
 		}
 	}
+	int pend = 0;                                                // progress value of the previous step, published once its stores have drained (below)
+	int seen = 0;                                                // last progress value read of the preceding band: no poll while it is known to be ahead
 	const int nSteps = [&]() { const int yT = PM_HW + band * PPW; const int r = min(PPW, (t.h - PM_HW) - yT);
 		const int xa = PM_HW + chunk * chunkW, xb = min(xa + chunkW - 1, t.w - 1 - PM_HW); return (xb + (yT + r - 1)) - (xa + yT) + 1; }();
 	for (int s = 0; s < nSteps; ++s) {
@@ -148,10 +352,12 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMT
 			const bool needPred = predExists && xc >= xc0 && xc <= xc1;   // wave-uniform
 			if (needPred) {
 				const int* const predProgress = progBase + (size_t)predBand * nChunks + chunk;
-				int spins = 0;
-				while (pm_ld_agent_i(predProgress) < q) {
-					pm_nap();
-					if (++spins > PM_BAND_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctl[1], 1u); break; }
+				if (seen < q) {
+					int spins = 0;
+					while ((seen = pm_ld_agent_i(predProgress)) < q) {
+						pm_nap();
+						if (++spins > PM_BAND_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctl[1], 1u); break; }
+					}
 				}
 				pm_compiler_fence();                                 // the reads below stay behind the successful poll
 				if (g == gCons && active) {
@@ -177,206 +383,29 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMT
 			const size_t qi = qis[1];
 			n1D = gDepth[qi]; n1N0 = gNormal[qi * 3]; n1N1 = gNormal[qi * 3 + 1]; n1N2 = gNormal[qi * 3 + 2]; n1C = gConf[qi];
 		}
-		// ---- what the visit reads from memory: its own estimate, the two not yet updated neighbours, prior, mask (none of it written earlier in this launch) ----
-		float oDepth = 0.f, oNx = 0.f, oNy = 0.f, oNz = 0.f, oConf = 2.f, prior = 0.f;
-		float myD = 0.f, myN0 = 0.f, myN1 = 0.f, myN2 = 1.f;     // depth and normal of my smoothness slot's pixel
-		unsigned char maskByte = 1;
-		if (active) {
-			if (t.prior) prior = pm_glob(t.prior)[idx];
-			if (t.mask != nullptr) maskByte = t.mask[idx];
-			if (slot == 0) { myD = bok[0] ? n0D : 0.f; myN0 = n0N0; myN1 = n0N1; myN2 = n0N2; }
-			else if (slot == 1) { myD = bok[1] ? n1D : 0.f; myN0 = n1N0; myN1 = n1N1; myN2 = n1N2; }
-			else { const size_t qi = slot == 2 ? qis[2] : qis[3]; myD = gDepth[qi]; myN0 = gNormal[qi * 3]; myN1 = gNormal[qi * 3 + 1]; myN2 = gNormal[qi * 3 + 2]; }
-			oDepth = gDepth[idx]; oNx = gNormal[idx * 3]; oNy = gNormal[idx * 3 + 1]; oNz = gNormal[idx * 3 + 2]; oConf = gConf[idx];
-		}
-		float normSq0, sumW;
-		pm_fill_patch<G, true>(t, active, active ? x : PM_HW, active ? y : yTop, v, s_w[g], normSq0, sumW);
-		const bool masked = active && maskByte == 0;
-		const bool valid = active && !masked && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
-		if (v == 0) s_w[g][PM_NT] = make_float2(prior, prior > 0 ? pm_expf(normSq0 * (-1.f / (1.f * 0.02f))) : 0.f);
-		// ---- the visit's state goes to LDS: current estimate, neighbours, close-neighbour slots (lane `slot` of the first quad writes slot `slot`) ----
-		{
-			PMPix* P = pm_launder(&s_pix[g]);
-			const bool bk = slot == 0 ? bok[0] : slot == 1 ? bok[1] : slot == 2 ? bok[2] : bok[3];
-			const bool okS = valid && bk && myD > 0;
-			const unsigned cm = (unsigned)__ballot(okS) >> 0;   // (ballot of the whole wave; my group's four bits are picked below)
-			const unsigned long long bal = __ballot(okS);
-			const unsigned closeMask = (unsigned)((bal >> (g * G)) & 0xFull);
-			(void)cm;
-			if (v < 4) {
-				// TransformPointI2C(Point3(nx, ndepth)) in double then Cast<float>, Camera.h:338-344
-				const int qx = slot == 0 ? qxs[0] : slot == 1 ? qxs[1] : slot == 2 ? qxs[2] : qxs[3];
-				const int qy = slot == 0 ? qys[0] : slot == 1 ? qys[1] : slot == 2 ? qys[2] : qys[3];
-				const double z = (double)myD;
-				P->qX[slot][0] = okS ? (float)(((double)qx - t.cx) * z / t.fx) : 0.f;
-				P->qX[slot][1] = okS ? (float)(((double)qy - t.cy) * z / t.fy) : 0.f;
-				P->qX[slot][2] = okS ? (float)z : 0.f;
-				P->qn[slot][0] = okS ? myN0 : 0.f; P->qn[slot][1] = okS ? myN1 : 0.f; P->qn[slot][2] = okS ? myN2 : 1.f;
-			}
-			if (v == 0) {
-				const double X0x = ((double)x - t.cx) / t.fx, X0y = ((double)y - t.cy) / t.fy;
-				P->X0x = X0x; P->X0y = X0y; P->vx = (float)X0x; P->vy = (float)X0y; P->normSq0 = normSq0; P->sumW = sumW; P->x = x; P->y = y;
-				P->depth = valid ? oDepth : 0.f; P->nx = valid ? oNx : 0.f; P->ny = valid ? oNy : 0.f; P->nz = valid ? oNz : 0.f; P->conf = valid ? oConf : 2.f;
-				P->p0 = 0.f; P->p1 = 0.f; P->scaleRange = 1.f; P->depthRange = 0.f;
-				enum { ST_PROP0 = 0, ST_DONE = 5 };
-				P->st = valid ? ST_PROP0 : ST_DONE; P->it = 0; P->idxScale = 0;
-				P->flags = PMF_SMOOTH | ((closeMask & 1u) ? PMF_POK0 : 0) | ((closeMask & 2u) ? PMF_POK1 : 0) | (int)(closeMask << 8);
-				P->nb[0][0] = n0D; P->nb[0][1] = n0N0; P->nb[0][2] = n0N1; P->nb[0][3] = n0N2; P->nb[0][4] = n0C;
-				P->nb[1][0] = n1D; P->nb[1][1] = n1N0; P->nb[1][2] = n1N1; P->nb[1][3] = n1N2; P->nb[1][4] = n1C;
-			}
-		}
-		__syncthreads();
-		// ---- ProcessPixel's control flow as a per-pixel state machine: every outer trip scores at most one hypothesis per pixel (as pm_sweep_kernel) ----
-		enum { ST_PROP0 = 0, ST_PROP1 = 1, ST_DECIDE = 2, ST_RAND = 3, ST_REFINE = 4, ST_DONE = 5 };
-		const uint32_t k1 = t.k1base + pass;
-		for (;;) {
-			bool need = false;
-			float hd = 0.f, hnx = 0.f, hny = 0.f, hnz = 1.f;
-			{	// -- next hypothesis of my pixel (every lane of the group computes the same; lane 0 records it)
-				PMPix* P = pm_launder(&s_pix[g]);
-				int st = P->st; unsigned it = (unsigned)P->it, idxScale = (unsigned)P->idxScale; int flags = P->flags;
-				const int px = P->x, py = P->y;
-				const float vx = P->vx, vy = P->vy, vz = 1.f;
-				float scaleRange = P->scaleRange, depthRange = P->depthRange, p0 = P->p0, p1 = P->p1;
-				float hp0 = 0.f, hp1 = 0.f; int hst = ST_DONE;
-				while (!need && st != ST_DONE) {
-					if (st <= ST_PROP1) {
-						const bool vert = (st == ST_PROP1); ++st; // slot 0: same row, slot 1: same column
-						const bool pok = (flags & (vert ? PMF_POK1 : PMF_POK0)) != 0;
-						const float* nbp = P->nb[vert ? 1 : 0];
-						const float cd = nbp[0], cnx = nbp[1], cny = nbp[2], cnz = nbp[3], pconf = nbp[4];
-						hd = cd; hnx = cnx; hny = cny; hnz = cnz;
-						if (pok && pconf < kp.thKeep) {
-							// InterpolatePixel, DepthMap.cpp:915-959
-							float depthNew = cd; bool zero;
-							if (vert) { // same column
-								const float nx1 = (float)(((double)py - t.cy) / t.fy);
-								const float denom = cnz + nx1 * cny;
-								zero = pm_fabsf(denom) < 0.0001f;
-								const float x1 = (float)(((double)(py + sgn) - t.cy) / t.fy);
-								const float nom = cd * (cnz + x1 * cny);
-								if (!zero) depthNew = nom / denom;
-							} else {
-								const float nx1 = (float)(((double)px - t.cx) / t.fx);
-								const float denom = cnz + nx1 * cnx;
-								zero = pm_fabsf(denom) < 0.0001f;
-								const float x1 = (float)(((double)(px + sgn) - t.cx) / t.fx);
-								const float nom = cd * (cnz + x1 * cnx);
-								if (!zero) depthNew = nom / denom;
-							}
-							hd = (!zero && pm_in_range(depthNew, t.dMin, t.dMax)) ? depthNew : cd;
-							hnx = cnx; hny = cny; hnz = cnz;
-							pm_correct_normal(vx, vy, vz, hnx, hny, hnz);
-							need = true; hst = ST_PROP0;
-						}
-					} else if (st == ST_DECIDE) {
-						// RefineIters:, DepthMap.cpp:802-827
-						const float conf = P->conf;
-						if (conf <= kp.thConfSmall) idxScale = 2;
-						else if (conf <= kp.thConfBig) idxScale = 1;
-						else if (conf >= kp.thConfRand) { flags &= ~PMF_SMOOTH; st = ST_RAND; it = 0; continue; }
-						scaleRange = pm_pow2neg(idxScale);
-						depthRange = P->depth * kp.depthRatio;
-						p0 = pm_atan2f(P->ny, P->nx); p1 = pm_acosf(pm_clampf(P->nz, -1.f, 1.f)); // Normal2Dir
-						st = ST_REFINE; it = 0;
-					} else if (st == ST_RAND) {
-						if (it >= kp.nRandomIters) { st = ST_DONE; break; }
-						const PmPhilox4 r = pm_philox4x32_10((uint32_t)px, (uint32_t)py, (uint32_t)(PM_STREAM_RAND * 256) + it, 0u, t.k0, k1);
-						++it;
-						const float rr = t.dMinSqr + (t.dMaxSqr - t.dMinSqr) * pm_u32_to_unit(r.v[0]);
-						hd = rr * rr;
-						pm_random_normal(pm_u32_to_unit(r.v[1]), pm_u32_to_unit(r.v[2]), vx, vy, vz, hnx, hny, hnz);
-						need = true; hst = ST_RAND;
-					} else { // ST_REFINE, DepthMap.cpp:832-852
-						if (it >= kp.nRandomIters) { st = ST_DONE; break; }
-						const PmPhilox4 r = pm_philox4x32_10((uint32_t)px, (uint32_t)py, (uint32_t)(PM_STREAM_REFINE * 256) + it, 0u, t.k0, k1);
-						++it;
-						const float ndepth = P->depth + (depthRange * scaleRange) * (2.f * pm_u32_to_unit(r.v[0]) - 1.f);
-						if (!pm_in_range(ndepth, t.dMin, t.dMax)) continue;
-						hp0 = p0 + (kp.angle1Range * scaleRange) * (2.f * pm_u32_to_unit(r.v[1]) - 1.f);
-						hp1 = p1 + (kp.angle2Range * scaleRange) * (2.f * pm_u32_to_unit(r.v[2]) - 1.f);
-						pm_dir2normal(hp0, hp1, hnx, hny, hnz);
-						if (hnx * vx + hny * vy + hnz * vz >= 0) continue;
-						hd = ndepth;
-						need = true; hst = ST_REFINE;
-					}
+		float rD, rN0, rN1, rN2, rC; bool wr;
+		pm_visit<G, VPL, GEO>(t, kp, pass, sgn, s_w[g], &s_pix[g], hotBase, g, v, slot, active, x, y, yTop, idx, bok, qxs, qys, qis,
+			n0D, n0N0, n0N1, n0N2, n0C, n1D, n1N0, n1N1, n1N2, n1C,
+			[&]() {
+				// The previous step's result is published HERE: its stores were issued before this step's loads, which the patch set-up has just waited
+				// for, so draining them costs nothing now (at the end of the previous step it was a full write-through round trip on the critical path).
+				if (pend) {
+					pm_drain_stores();
+					if (lane == 0) pm_st_agent_i(progBase + (size_t)band * nChunks + chunk, pend);
+					pend = 0;
 				}
-				__builtin_amdgcn_wave_barrier();                     // every lane of the group has read the state before lane 0 advances it
-				if (v == 0) {
-					P->st = st; P->it = (int)it; P->idxScale = (int)idxScale; P->flags = flags;
-					P->scaleRange = scaleRange; P->depthRange = depthRange; P->p0 = p0; P->p1 = p1;
-					P->hd = hd; P->hnx = hnx; P->hny = hny; P->hnz = hnz; P->hp0 = hp0; P->hp1 = hp1; P->hst = hst;
-				}
-			}
-			if (!__any(need)) break;
-			// -- smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533, one neighbour per lane
-			float sf0, sf1, sf2, sf3;
-			{
-				const PMPix* P = pm_launder(&s_pix[g]);
-				const int flags = P->flags;
-				const bool on = need && (flags & PMF_SMOOTH) && ((flags >> (8 + slot)) & 1);
-				float myF = 1.f;
-				if (on) {
-					const float vx = P->vx, vy = P->vy;
-					const float q0 = P->qX[slot][0], q1 = P->qX[slot][1], q2 = P->qX[slot][2], m0 = P->qn[slot][0], m1 = P->qn[slot][1], m2 = P->qn[slot][2];
-					const float planeD = -hd * (hnx * vx + hny * vy + hnz * 1.f); // InitPlane, DepthMap.cpp:963-971
-					const float dist = (hnx * q0 + (hny * q1 + hnz * q2)) + planeD; // Planef::Distance, Eigen 3-dot order
-					const float r = dist / hd;
-					const float factorDepth = pm_expf((r * r) * kp.smoothSigmaDepth);
-					const float ca = pm_clampf((hnx * m0 + hny * m1 + hnz * m2) / pm_sqrtf((hnx * hnx + hny * hny + hnz * hnz) * (m0 * m0 + m1 * m1 + m2 * m2)), -1.f, 1.f);
-					const float ac = pm_acosf(ca);
-					const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
-					myF = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
-				}
-				sf0 = pm_quad_bcast<0>(myF); sf1 = pm_quad_bcast<1>(myF); sf2 = pm_quad_bcast<2>(myF); sf3 = pm_quad_bcast<3>(myF);
-			}
-			// -- score against my source view(s)
-			float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
-			{
-				const PMPix* P = pm_launder(&s_pix[g]);
-#pragma unroll 1
-				for (int u = 0; u < VPL; ++u) {
-					const int vw = v + u * G;
-					if (need && vw < t.nSrc) {
-						const float s1 = pm_score_view<GEO, true, TC, true>(t.src[vw], t, kp, P->x, P->y, P->X0x, P->X0y, P->normSq0, P->sumW, s_w[g], hd, hnx, hny, hnz, sf0, sf1, sf2, sf3, 0.f,
-							nullptr, 0, 0, hotBase + vw * NBD, hotBase + vw * NBD + PM_SRC_HOT, nullptr PM_PROF_PASS);
-						if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
-					}
-				}
-			}
-			const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
-			{	// -- accept (DepthMap.cpp:794-799, :784-793, :843-851)
-				PMPix* P = pm_launder(&s_pix[g]);
-				if (need && v == 0 && P->conf > nconf) {
-					P->conf = nconf; P->depth = P->hd; P->nx = P->hnx; P->ny = P->hny; P->nz = P->hnz;
-					int flags = P->flags | PMF_CHANGED;
-					P->flags = flags;
-					const int hst = P->hst;
-					if (hst == ST_RAND) { if (nconf < kp.thConfRand) P->st = ST_DECIDE; }
-					else if (hst == ST_REFINE) { P->p0 = P->hp0; P->p1 = P->hp1; const int is = P->idxScale + 1; P->idxScale = is; P->scaleRange = pm_pow2neg((unsigned)is); }
-				}
-			}
-			__builtin_amdgcn_wave_barrier();
-		}
+			}, rD, rN0, rN1, rN2, rC, wr PM_PROF_PASS);
 		// ---- result of the step: what the map holds at this pixel from now on ----
-		{
-			const PMPix* P = pm_launder(&s_pix[g]);
-			const bool wr = (P->flags & PMF_CHANGED) && valid;
-			const float depth = P->depth, nx = P->nx, ny = P->ny, nz = P->nz, conf = P->conf;
-			pvD = wr ? depth : oDepth; pvN0 = wr ? nx : oNx; pvN1 = wr ? ny : oNy; pvN2 = wr ? nz : oNz; pvC = wr ? conf : oConf;
-			if (wr && v == 0) {
-				const bool lastCol = dir == 0 ? (x == xc1 && chunk + 1 < nChunks) : (x == xc0 && chunk > 0);
-				if ((succExists && g == gPub) || lastCol) {
-					// the following band (or the following chunk) reads this pixel while the launch runs: write it through
-					pm_st_agent((float*)t.depth + idx, depth); pm_st_agent((float*)t.normal + idx * 3, nx); pm_st_agent((float*)t.normal + idx * 3 + 1, ny);
-					pm_st_agent((float*)t.normal + idx * 3 + 2, nz); pm_st_agent((float*)t.conf + idx, conf);
-				} else { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
-			}
+		pvD = rD; pvN0 = rN0; pvN1 = rN1; pvN2 = rN2; pvC = rC;
+		if (wr && v == 0) {
+			const bool lastCol = dir == 0 ? (x == xc1 && chunk + 1 < nChunks) : (x == xc0 && chunk > 0);
+			if ((succExists && g == gPub) || lastCol) {
+				// the following band (or the following chunk) reads this pixel while the launch runs: write it through
+				pm_st_agent((float*)t.depth + idx, rD); pm_st_agent((float*)t.normal + idx * 3, rN0); pm_st_agent((float*)t.normal + idx * 3 + 1, rN1);
+				pm_st_agent((float*)t.normal + idx * 3 + 2, rN2); pm_st_agent((float*)t.conf + idx, rC);
+			} else { gDepth[idx] = rD; gNormal[idx * 3] = rN0; gNormal[idx * 3 + 1] = rN1; gNormal[idx * 3 + 2] = rN2; gConf[idx] = rC; }
 		}
-		if (succExists) {
-			pm_drain_stores();                                   // the published pixel has left this wave before the counter moves
-			if (lane == 0) pm_st_agent_i(progBase + (size_t)band * nChunks + chunk, q + 1);
-		}
+		if (succExists) pend = q + 1;
 		__syncthreads();                                         // the next step rewrites s_pix / s_w
 	}
 	pm_drain_stores();                                           // the last column has left this wave: the next chunk and the next band may read it

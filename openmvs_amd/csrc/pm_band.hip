@@ -412,3 +412,58 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMT
 	if (lane == 0) pm_st_agent_i(progBase + (size_t)band * nChunks + chunk, 0x7fffffff);
 	PM_PROF_FLUSH();
 }
+
+// The same visit, one launch per anti-diagonal (the schedule of pm_sweep_kernel): all pixels of diagonal x + y == d of every view of the group, the
+// two already-updated neighbours read back from the maps (the previous launch wrote them).  For batches large enough to fill the machine with one
+// diagonal this beats the resident band kernel (no hand-offs, no waiting on a preceding band); see DESIGN.md 4.2c for the measured crossover.
+template <int G, int VPL, bool GEO>
+__global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_sweep2_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
+	constexpr int PPW = 64 / G;
+	constexpr int NV = G * VPL;
+	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
+	static_assert(G >= 4, "a pixel gets at least a quad of lanes");
+	PM_PROF_DECL;
+	__shared__ float2 s_w[PPW][PM_NT + 1];
+	__shared__ double s_src[NV * NBD];
+	__shared__ PMPix s_pix[PPW];
+	// XCD-aware block mapping as in pm_sweep_kernel: contiguous (view, chunk) ranges per XCD
+	unsigned vbx = blockIdx.x, vby = blockIdx.y;
+	{
+		const unsigned nbx = gridDim.x, nwg = nbx * gridDim.y, orig = blockIdx.y * nbx + blockIdx.x;
+		const unsigned xcd = orig % 8u, q = nwg / 8u, r = nwg % 8u;
+		const unsigned wgid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + orig / 8u;
+		vby = wgid / nbx; vbx = wgid - vby * nbx;
+	}
+	const PMTask& t = tasks[vby];
+	const int lane = threadIdx.x;
+	for (int i = lane; i < NV * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];
+	const int g = lane / G, v = lane % G, slot = v & 3;
+	const int w = t.w, h = t.h;
+	const int pi = (int)vbx * PPW + g;
+	const bool active = pi < count;
+	const int x = xlo + (active ? pi : 0), y = d - x;
+	const size_t idx = (size_t)y * w + x;
+	const int sgn = dir == 0 ? -1 : 1;
+	bool bok[4]; int qxs[4], qys[4]; size_t qis[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const int ox = (k == 0) ? sgn : (k == 2 ? -sgn : 0), oy = (k == 1) ? sgn : (k == 3 ? -sgn : 0);
+		bool ok;
+		if (ox == -1) ok = x > PM_HW; else if (ox == 1) ok = x < w - PM_HW; else if (oy == -1) ok = y > PM_HW; else ok = y < h - PM_HW;
+		bok[k] = ok && active; qxs[k] = x + ox; qys[k] = y + oy;
+		qis[k] = bok[k] ? (size_t)(y + oy) * w + (x + ox) : idx;
+	}
+	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
+	float n0D = 0.f, n0N0 = 0.f, n0N1 = 0.f, n0N2 = 0.f, n0C = 2.f, n1D = 0.f, n1N0 = 0.f, n1N1 = 0.f, n1N2 = 0.f, n1C = 2.f;
+	if (active) {
+		const size_t q0 = qis[0], q1 = qis[1];
+		n0D = gDepth[q0]; n0N0 = gNormal[q0 * 3]; n0N1 = gNormal[q0 * 3 + 1]; n0N2 = gNormal[q0 * 3 + 2]; n0C = gConf[q0];
+		n1D = gDepth[q1]; n1N0 = gNormal[q1 * 3]; n1N1 = gNormal[q1 * 3 + 1]; n1N2 = gNormal[q1 * 3 + 2]; n1C = gConf[q1];
+	}
+	__syncthreads();
+	float rD, rN0, rN1, rN2, rC; bool wr;
+	pm_visit<G, VPL, GEO>(t, kp, pass, sgn, s_w[g], &s_pix[g], s_src, g, v, slot, active, x, y, active ? y : PM_HW, active ? idx : (size_t)PM_HW * w + PM_HW, bok, qxs, qys, qis,
+		n0D, n0N0, n0N1, n0N2, n0C, n1D, n1N0, n1N1, n1N2, n1C, []() {}, rD, rN0, rN1, rN2, rC, wr PM_PROF_PASS);
+	if (wr && v == 0) { gDepth[idx] = rD; gNormal[idx * 3] = rN0; gNormal[idx * 3 + 1] = rN1; gNormal[idx * 3 + 2] = rN2; gConf[idx] = rC; }
+	PM_PROF_FLUSH();
+}

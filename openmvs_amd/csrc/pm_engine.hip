@@ -34,6 +34,9 @@
 #ifndef PMHIP_DEFAULT_BAND_SLACK
 #define PMHIP_DEFAULT_BAND_SLACK 16    // ticket order: a band starts this many diagonals after the band it follows (>= rows per band for a legal order)
 #endif
+#ifndef PMHIP_DEFAULT_DIAG2
+#define PMHIP_DEFAULT_DIAG2 1
+#endif
 #ifndef PMHIP_DEFAULT_BAND
 #define PMHIP_DEFAULT_BAND 1     // sweeps as one resident launch per iteration (pm_band.hip); 0 = one launch per anti-diagonal (pm_sweep_kernel / pm_sweep_wide_kernel)
 #endif
@@ -106,7 +109,8 @@ struct pmhip_engine {
 	int nGroups = 1;
 	int wideMaxViews = PMHIP_DEFAULT_WIDE;   // batches of at most this many views use the one-wave-per-pixel sweep kernel (PMHIP_WIDE)
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
-	int bandMode = PMHIP_DEFAULT_BAND;      // PMHIP_BAND
+	int bandMode = PMHIP_DEFAULT_BAND;      // PMHIP_BAND: 1 = resident band kernel, 0 = one launch per anti-diagonal
+	int diagVisit2 = PMHIP_DEFAULT_DIAG2;   // PMHIP_DIAG2: per-diagonal launches use pm_sweep2_kernel (pm_band.hip's visit body) instead of pm_sweep_kernel
 	unsigned* d_bandCtl = nullptr;          // [0] ticket counter, [1] error flag, then progress[batchCap][bandPairCap] (pm_band.hip)
 	unsigned* d_bandOrder = nullptr; unsigned* h_bandOrder = nullptr;   // (band << 16 | chunk) pairs in ticket order
 	int bandPairCap = 0;
@@ -328,6 +332,18 @@ static bool launchBand(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* t
 	default: return false;
 	}
 #undef PM_BAND_CASE
+}
+
+template <bool GEO>
+static bool launchSweep2(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
+#define PM_SWEEP2_CASE(g, vpl) case (g) * 16 + (vpl): hipLaunchKernelGGL((pm_sweep2_kernel<g, vpl, GEO>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass); return true
+	switch (G * 16 + VPL) {
+	PM_SWEEP2_CASE(4, 1); PM_SWEEP2_CASE(8, 1); PM_SWEEP2_CASE(16, 1);
+	PM_SWEEP2_CASE(4, 2); PM_SWEEP2_CASE(8, 2);
+	PM_SWEEP2_CASE(4, 4);
+	default: return false;
+	}
+#undef PM_SWEEP2_CASE
 }
 
 template <bool GEO>
@@ -558,6 +574,15 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 						else launchSweepWide<false>(grid, st, dt + s0, kp, dir, d, xlo, count, pass);
 						continue;
 					}
+					if (e->diagVisit2) {
+						// the visit body of pm_band.hip (state in LDS, quad images, no windows) under the per-diagonal schedule
+						int G2 = SG, V2 = VPL; if (G2 < 4) { V2 = std::max(1, G2 * V2 / 4); G2 = 4; }
+						const int P2 = 64 / G2;
+						const dim3 grid2((unsigned)((count + P2 - 1) / P2), s1 - s0);
+						if (geo) launchSweep2<true>(G2, V2, grid2, st, dt + s0, kp, dir, d, xlo, count, pass);
+						else launchSweep2<false>(G2, V2, grid2, st, dt + s0, kp, dir, d, xlo, count, pass);
+						continue;
+					}
 					const dim3 grid((unsigned)((count + SPPB - 1) / SPPB), s1 - s0);
 					if (geo) launchSweep<true>(SG, VPL, grid, st, dt + s0, kp, dir, d, xlo, count, pass);
 					else launchSweep<false>(SG, VPL, grid, st, dt + s0, kp, dir, d, xlo, count, pass);
@@ -628,6 +653,7 @@ int pmhip_create(int device, pmhip_engine** out) {
 	if (nw) e->wideMaxViews = atoi(nw);
 	const char* bm = getenv("PMHIP_BAND");
 	if (bm) e->bandMode = atoi(bm) != 0;
+	const char* d2 = getenv("PMHIP_DIAG2"); if (d2) e->diagVisit2 = atoi(d2) != 0;
 	const char* bc = getenv("PMHIP_BAND_CHUNK"); if (bc && atoi(bc) >= 16) e->bandChunkW = atoi(bc);
 	const char* bs = getenv("PMHIP_BAND_SLACK"); if (bs && atoi(bs) >= 0) e->bandSlack = atoi(bs);
 	const char* nl = getenv("PMHIP_LANES");

@@ -16,9 +16,11 @@ for spec in variants:
         env["PMHIP_BAND_CHUNK"] = spec[4]
     if len(spec) > 5 and spec[5]:
         env["PMHIP_BAND_SLACK"] = spec[5]
+    if len(spec) > 6 and spec[6]:
+        env["PMHIP_DIAG2"] = spec[6]
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-extras", "--views-per-gpu", views], env=env, capture_output=True, text=True, timeout=400)
     try:
         j = json.loads(r.stdout.strip().splitlines()[-1])
-        print("%-18s groups=%-2s lanes=%-2s band=%-1s chunk=%-4s slack=%-3s views=%s  %.2f Mpix/s  step %.0f ms  avg_launch %.1f us" % (lib, groups, lanes or "-", band or "-", (spec[4] if len(spec) > 4 else "-"), (spec[5] if len(spec) > 5 else "-"), views, j["value"], j["ms_per_step"], j["roofline"]["avg_launch_us"]), flush=True)
+        print("%-18s groups=%-2s lanes=%-2s band=%-1s chunk=%-4s slack=%-3s diag2=%-1s views=%s  %.2f Mpix/s  step %.0f ms  avg_launch %.1f us" % (lib, groups, lanes or "-", band or "-", (spec[4] if len(spec) > 4 else "-"), (spec[5] if len(spec) > 5 else "-"), (spec[6] if len(spec) > 6 else "-"), views, j["value"], j["ms_per_step"], j["roofline"]["avg_launch_us"]), flush=True)
     except Exception as ex:
         print(lib, groups, "FAILED", ex, r.stderr[-500:], flush=True)

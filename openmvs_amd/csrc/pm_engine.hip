@@ -23,7 +23,11 @@
 #define PMHIP_DEFAULT_WIDE 8    // measured (profiles/r02_small_batch_probe_wide_kernel.log): 1.54x at 1 view, 1.40x at 4, 1.11x at 8, 0.76x at 13
 #endif
 #ifndef PMHIP_DEFAULT_LANES
-#define PMHIP_DEFAULT_LANES 16   // sweep kernel: lanes per pixel (16 = one source view per lane whatever their number)
+#define PMHIP_DEFAULT_LANES 0    // sweep kernels: lanes per pixel; 0 = by batch size (one view per lane for small batches, four lanes and two views per lane
+                                 // from PMHIP_LANES4_FROM reference views on: measured 41.2 vs 39.7 Mpix/s at 100 views, 11.5 vs 16.6 at 13, profiles/r03_variants_call6_sweep2.log)
+#ifndef PMHIP_LANES4_FROM
+#define PMHIP_LANES4_FROM 48
+#endif
 #endif
 #ifndef PMHIP_DEFAULT_GROUPS
 #define PMHIP_DEFAULT_GROUPS 2
@@ -38,7 +42,9 @@
 #define PMHIP_DEFAULT_DIAG2 1
 #endif
 #ifndef PMHIP_DEFAULT_BAND
-#define PMHIP_DEFAULT_BAND 1     // sweeps as one resident launch per iteration (pm_band.hip); 0 = one launch per anti-diagonal (pm_sweep_kernel / pm_sweep_wide_kernel)
+#define PMHIP_DEFAULT_BAND 0     // 1 = sweeps as one resident launch per iteration (pm_band_kernel); 0 = one launch per anti-diagonal (pm_sweep2_kernel /
+                                 // pm_sweep_wide_kernel).  Measured (profiles/r03_variants_call4..6): the resident kernel is bit-identical but 10 % slower at 100
+                                 // views and 13 % at 13 -- its band-to-band waits cost more than the kernel boundaries they replace -- so it is not the default.
 #endif
 
 namespace {
@@ -405,7 +411,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 	}
 	int G = 1; while (G < maxSrc) G <<= 1;          // init kernel: one view per lane
 	int SG = G, VPL = 1;                             // sweep kernel: (lanes per pixel, views per lane)
-	sweepMapping(maxSrc, e->sweepLanes, SG, VPL);
+	sweepMapping(maxSrc, e->sweepLanes > 0 ? e->sweepLanes : (nB >= PMHIP_LANES4_FROM && maxSrc > 4 ? 4 : 16), SG, VPL);
 	// latency mode (one wave per pixel, pm_sweep_wide_kernel) for batches too small to fill the GPU with one wave per 64 / G pixels
 	const bool wide = nB <= e->wideMaxViews && maxSrc <= 8;
 	const size_t P0 = (size_t)e->w * e->h;

@@ -319,6 +319,9 @@ __device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t
 //   PM_PROBE_NO_FALLBACK    a tap row that fails its exactness test is not redone through global memory
 //   PM_PROBE_NO_WEIGHTS     the 25 bilateral patch weights are constants (no exp, no patch texel loads)
 //   PM_PROBE_CHEAP_TRIG     sin / cos / atan2 / acos of the hypothesis construction replaced by two-instruction stand-ins
+#ifndef PM_WIDE_TILES
+#define PM_WIDE_TILES 1   // one-wave-per-pixel kernel: LDS windows (1) or window-less quad-image tap rows (0)
+#endif
 #ifndef PM_WINBATCH
 #define PM_WINBATCH 4   // source windows whose global loads are in flight together when a visit stages its windows
 #endif
@@ -1072,8 +1075,8 @@ __global__ __launch_bounds__(PM_BLOCK, (!PM_USE_TILES ? PM_MINWAVES : VPL >= 4 ?
 template <bool GEO>
 __global__ __launch_bounds__(64, 2) void pm_sweep_wide_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	constexpr int G = 8;
-	constexpr int TC = 1 + PM_TCX;
-	constexpr int TSTRIDE = PM_TR * TC + PM_TILE_PAD;
+	constexpr int TC = PM_WIDE_TILES ? 1 + PM_TCX : 0;   // 0: no LDS windows, the tap rows read the quad image (as pm_sweep2_kernel)
+	constexpr int TSTRIDE = PM_TR * (TC > 0 ? TC : 1) + PM_TILE_PAD;
 	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
 	PM_PROF_DECL;
 	__shared__ float2 s_w[PM_NT + 1];
@@ -1140,7 +1143,7 @@ __global__ __launch_bounds__(64, 2) void pm_sweep_wide_kernel(const PMTask* __re
 		}
 	}
 	// ---- windows: one per source view around the footprint of the current plane ----------------------------------------------------------------
-	{
+	if (TC > 0) {
 		int cs = 0, ctt = 0;
 		if (v < t.nSrc) {
 			float Hc[9];
@@ -1152,7 +1155,7 @@ __global__ __launch_bounds__(64, 2) void pm_sweep_wide_kernel(const PMTask* __re
 		}
 		if (c == 0) s_org[v] = make_int2(cs - 8 - (PM_TR - 19) / 2, ctt - PM_HW - (PM_TCX - 9) / 2);
 		__syncthreads();
-		constexpr int NE = PM_TR * TC, NLD = (G * NE + 63) / 64;
+		constexpr int NE = PM_TR * (TC > 0 ? TC : 1), NLD = (G * NE + 63) / 64;
 		float vals[NLD];
 #pragma unroll
 		for (int k = 0; k < NLD; ++k) {

@@ -73,6 +73,12 @@ def test_estimator_views_per_lane(pm_emulated, nine_scene, small_scene, lanes):
     g.test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes)    # (4,2), (2,4), (2,2), (4,4): several source views per lane
 
 
+@pytest.mark.parametrize("variant", ["band_chunks", "legacy_windows", "band_lanes4"])
+def test_estimator_sweep_kernel_variants(pm_emulated, nine_scene, small_scene, variant):
+    from tests import test_gpu_patchmatch as g
+    g.test_sweep_kernel_variants_parity(nine_scene, small_scene, variant, quick=True)
+
+
 def test_estimator_wide_latency_mode(pm_emulated, nine_scene, small_scene):
     from tests import test_gpu_patchmatch as g
     g.test_wide_latency_mode_parity(nine_scene, small_scene, quick=True)     # one wave per pixel, eight hypotheses per round (the whole case passes too: 260 s)

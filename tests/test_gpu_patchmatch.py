@@ -119,6 +119,54 @@ def test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes):
             os.environ["PMHIP_LANES"] = saved
 
 
+SWEEP_VARIANTS = {
+    # what the sweep of an iteration runs as; every one must give the oracle's bits
+    "band": {"PMHIP_BAND": "1"},                                                        # one resident launch per iteration (pm_band_kernel), whole rows per task
+    "band_chunks": {"PMHIP_BAND": "1", "PMHIP_BAND_CHUNK": "24", "PMHIP_BAND_SLACK": "5"},   # (band, chunk) tasks: chunk-to-chunk and band-to-band hand-offs
+    "band_lanes4": {"PMHIP_BAND": "1", "PMHIP_LANES": "4", "PMHIP_BAND_CHUNK": "40"},
+    "legacy_windows": {"PMHIP_BAND": "0", "PMHIP_DIAG2": "0"},                          # round-2 kernel with LDS source windows (pm_sweep_kernel)
+    "diag2": {"PMHIP_BAND": "0", "PMHIP_DIAG2": "1"},                                   # the default, named
+}
+
+
+@pytest.mark.parametrize("variant", sorted(SWEEP_VARIANTS))
+def test_sweep_kernel_variants_parity(nine_scene, small_scene, variant, quick=False):
+    """Every sweep kernel the engine can be told to use (environment switches read at pmhip_create) against the oracle: 8 / 1 / 2 / 3 sources,
+    the pyramid with 4 sources, and a scene batch with a geometric round.  The resident band kernel's hand-offs between wavefronts (agent-scope
+    stores, progress counters) only exist on the device: this is their test."""
+    import os
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    env = SWEEP_VARIANTS[variant]
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        e = PatchMatchHIP(0)
+        test_single_view_parity_N8_and_N1(e, nine_scene)
+        if not quick:
+            test_single_view_photometric_parity_N4(e, small_scene, 2)
+        sc = nine_scene
+        p = default_params(seed=5, nEstimationGeometricIters=1)
+        e.Init(False); e.scene_load(sc, n_levels=2)
+        allv = list(range(sc.n_views))
+        e.scene_estimate(allv, -1, p)
+        photo = [e.scene_get_maps(v) for v in allv]
+        e.scene_commit_round(); e.Init(True)
+        e.scene_estimate([4, 0], 0, p)
+        for v in (4, 0):
+            od, on, oc = _oracle(sc, v, 5, nEstimationGeometricIters=1)
+            _same(photo[v][0], od, f"{variant}: photometric depth v{v}")
+            gd, gn, gc = _oracle(sc, v, 5, geo_iter=0, depth=od, normal=on, src={u: photo[u][0] for u in allv}, nEstimationGeometricIters=1)
+            d, n, c = e.scene_get_maps(v)
+            _same(d, gd, f"{variant}: geometric depth v{v}"); _same(n, gn, "normal"); _same(c, gc, "conf")
+        e.close()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_wide_latency_mode_parity(nine_scene, small_scene, quick=False):
     """The one-wave-per-pixel sweep kernel (PMHIP_WIDE: eight hypotheses of a pixel scored side by side, sequential accept rule replayed over them) gives
     the bits of the sequential walk: 8 / 4 / 1-3 sources, pyramid, geometric round, ignore masks, option sets that change the iteration budget

@@ -22,3 +22,14 @@ def test_sweep_kernel_keeps_its_residency_budget():
         else:
             assert v["occupancy"] >= (1 if vpl >= 4 else 2), (k, v)
         assert v["agpr"] == 0
+    # the default sweep kernel since round 3 (pm_band.hip: visit state in LDS, quad images, no source windows): no scratch at all and little LDS, so
+    # registers alone decide the residency (3 waves per SIMD; a 4-wave build was measured 3 % slower, profiles/r03_variants_call6_sweep2.log)
+    sweep2 = {k: v for k, v in r.items() if "pm_sweep2_kernel" in k}
+    assert len(sweep2) == 12
+    for k, v in sweep2.items():
+        assert v["occupancy"] >= 3 and v["vgpr"] <= 168 and v["scratch"] == 0 and v["agpr"] == 0, (k, v)
+        assert v["lds"] <= 11008, (k, v)
+    band = {k: v for k, v in r.items() if "pm_band_kernel" in k}
+    assert len(band) == 12
+    for k, v in band.items():
+        assert v["occupancy"] >= 3 and v["scratch"] <= 200, (k, v)     # spills of loop-invariant values at the head of a step only (checked in the ISA)

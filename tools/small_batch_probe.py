@@ -11,7 +11,7 @@ V, W, H = 13, 1920, 1080
 sc = synth.make_scene(V, W, H, n_src=8, device="cuda", gray_only=True)
 p = default_params(seed=1)
 ref = {}
-for band, wide in (("0", "0"), ("0", "64"), ("1", "0")):
+for band, wide in (("0", "0"), ("0", "64")) + ((("1", "0"),) if os.environ.get("PROBE_BAND") else ()):
     os.environ["PMHIP_WIDE"] = wide; os.environ["PMHIP_BAND"] = band
     e = PatchMatchHIP(0); e.Init(True); e.scene_load(sc, 2)
     allv = list(range(V))

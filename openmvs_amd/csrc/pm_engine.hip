@@ -20,7 +20,8 @@
 #include <vector>
 
 #ifndef PMHIP_DEFAULT_WIDE
-#define PMHIP_DEFAULT_WIDE 8    // measured (profiles/r02_small_batch_probe_wide_kernel.log): 1.54x at 1 view, 1.40x at 4, 1.11x at 8, 0.76x at 13
+#define PMHIP_DEFAULT_WIDE 10   // measured (profiles/r03_small_batches_call7.log, window-less build of both): one-wave-per-pixel kernel 1.48x at 1 view, 1.45x at 4,
+                                // 1.18x at 8, 0.92x at 13 of pm_sweep2_kernel
 #endif
 #ifndef PMHIP_DEFAULT_LANES
 #define PMHIP_DEFAULT_LANES 0    // sweep kernels: lanes per pixel; 0 = by batch size (one view per lane for small batches, four lanes and two views per lane
@@ -1023,9 +1024,12 @@ int pmhip_scene_remove_small_segments(pmhip_engine* e, const int32_t* viewIds, i
 		if (ne > cap) { e->err = "remove_small_segments: asymmetric edge list overflow"; rc = PMHIP_E_HIP; break; }
 		if (ne > 0) {
 			// replay the reference's seed order on the quotient graph of components linked by one-directional edges
-			hedges.resize(2 * (size_t)ne); hsize.resize(n);
-			if (hipMemcpy(hedges.data(), edges, sizeof(int) * 2 * ne, hipMemcpyDeviceToHost) != hipSuccess ||
-				hipMemcpy(hsize.data(), size, sizeof(int) * n, hipMemcpyDeviceToHost) != hipSuccess) { rc = PMHIP_E_HIP; break; }
+			hedges.resize(2 * (size_t)ne); hsize.resize(2 * (size_t)ne);
+			hipLaunchKernelGGL(pmf_cc_gather_kernel, dim3((2 * ne + 255) / 256), dim3(256), 0, e->stream, size, edges, ovr, 2 * ne);   // (a 4K view: 2*ne ints instead of 33 MB)
+			if (hipMemcpyAsync(hedges.data(), edges, sizeof(int) * 2 * ne, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+				hipMemcpyAsync(hsize.data(), ovr, sizeof(int) * 2 * ne, hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) { rc = PMHIP_E_HIP; break; }
+			std::map<int, int> csize;                   // component root -> size
+			for (int k = 0; k < 2 * ne; ++k) csize[hedges[k]] = hsize[k];
 			std::map<int, std::set<int>> adj;
 			for (int k = 0; k < ne; ++k) { adj[hedges[2 * k]].insert(hedges[2 * k + 1]); adj[hedges[2 * k + 1]]; }
 			std::set<int> done;
@@ -1035,7 +1039,7 @@ int pmhip_scene_remove_small_segments(pmhip_engine* e, const int32_t* viewIds, i
 				if (done.count(r)) continue;
 				std::vector<int> seg{r}; done.insert(r);
 				for (size_t q = 0; q < seg.size(); ++q) for (int nb : adj[seg[q]]) if (!done.count(nb)) { done.insert(nb); seg.push_back(nb); }
-				long total = 0; for (int x : seg) total += hsize[x];
+				long total = 0; for (int x : seg) total += csize[x];
 				const int val = total < (long)nSpeckleSize ? 0 : (int)nSpeckleSize;   // forces remove / keep for every member
 				for (int x : seg) { pairs.push_back(x); pairs.push_back(val); }
 			}

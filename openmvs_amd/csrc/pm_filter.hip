@@ -261,6 +261,10 @@ __global__ void pmf_cc_asym_kernel(const float* __restrict__ depth, const int* _
 		}
 	}
 }
+// sizes of the components the one-directional edges touch (out[k] = size[ids[k]]): the host replay needs these few, not the whole per-pixel array
+__global__ void pmf_cc_gather_kernel(const int* __restrict__ size, const int* __restrict__ ids, int* __restrict__ out, int n) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = size[ids[i]];
+}
 __global__ void pmf_cc_override_kernel(int* size, const int* __restrict__ pairs, int n) {
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) size[pairs[2 * i]] = pairs[2 * i + 1];
 }

@@ -320,7 +320,7 @@ __device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t
 //   PM_PROBE_NO_WEIGHTS     the 25 bilateral patch weights are constants (no exp, no patch texel loads)
 //   PM_PROBE_CHEAP_TRIG     sin / cos / atan2 / acos of the hypothesis construction replaced by two-instruction stand-ins
 #ifndef PM_WIDE_TILES
-#define PM_WIDE_TILES 1   // one-wave-per-pixel kernel: LDS windows (1) or window-less quad-image tap rows (0)
+#define PM_WIDE_TILES 0   // one-wave-per-pixel kernel: LDS windows (1) or window-less quad-image tap rows (0; one depth map 1.08 -> 0.80 s, profiles/r03_small_batches_call7.log)
 #endif
 #ifndef PM_WINBATCH
 #define PM_WINBATCH 4   // source windows whose global loads are in flight together when a visit stages its windows

@@ -278,6 +278,7 @@ template <class T> inline T readlane(T v, int lane, int site) { Fiber* f = cur; 
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }

@@ -202,7 +202,7 @@ def main():
                                    "(3-level pyramid x 3 sweeps) + %d geometric rounds%s, all depth maps"
                                    % (V, W, H, N, a.geo_iters, " + cross-view filter" if a.with_filter else ""),
                        "views_total": V, "views_per_gpu": len(mine), "batch": B, "parallelism": "reference views sharded over %d GPU(s)" % world},
-            "roofline": {"bound": "hbm", "kernel": "pm_sweep_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "pm_sweep2_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": measured_traffic(per_launch),
                          "launches": int(st.sweepLaunches), "avg_launch_us": round(1e3 * st.sweepMs / max(1, st.sweepLaunches), 2),
                          "algorithmic_bytes_per_launch": round(per_launch, 1),

@@ -255,11 +255,13 @@ static int buildSidePyramids(pmhip_engine* e) {
 		if (!v.sw || !v.sideDirty) continue;
 		for (int l = 1; l <= e->nLevels; ++l) {
 			const int lw = lvlSize(v.sw, l), lh = lvlSize(v.sh, l);
+			if (lw < 1 || lh < 1 || !v.sImg[l]) break;      // a view too small for this level has no pyramid entry there (estimateBatch reports PMHIP_E_SIZE if the level is used)
 			const size_t n = (size_t)lw * lh;
 			hipLaunchKernelGGL(pm_area_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, e->stream, v.sImg[0], v.sImg[l], v.sw, v.sh, lw, lh, 1 << l, 1);
 		}
 		for (int l = 0; l <= e->nLevels; ++l) {
 			const int lw = lvlSize(v.sw, l), lh = lvlSize(v.sh, l);
+			if (lw < 1 || lh < 1 || !v.sImg[l]) break;
 			const size_t n = (size_t)lw * lh;
 			hipLaunchKernelGGL(pm_skew_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, e->stream, v.sImg[l], v.sImgS[l], lw, lh, 1);
 			hipLaunchKernelGGL(pm_quad_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, e->stream, v.sImg[l], v.sImgQ[l], lw, lh, 1);

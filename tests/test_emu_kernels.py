@@ -84,6 +84,11 @@ def test_estimator_wide_latency_mode(pm_emulated, nine_scene, small_scene):
     g.test_wide_latency_mode_parity(nine_scene, small_scene, quick=True)     # one wave per pixel, eight hypotheses per round (the whole case passes too: 260 s)
 
 
+def test_estimator_mixed_resolution_neighbours_wide_kernel(pm_emulated):
+    from tests import test_gpu_patchmatch as g
+    g.test_mixed_resolution_neighbours_parity_both_kernels("16")
+
+
 def test_estimator_mixed_resolution_neighbours(engine):
     from tests import test_gpu_patchmatch as g
     g.test_mixed_resolution_neighbours_parity(engine)                        # sources at 0.8x / 1.25x, cameraDepthMap of another size

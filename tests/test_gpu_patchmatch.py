@@ -676,6 +676,25 @@ def test_real_scene_from_mvs_archive_matches_oracle_and_sfm_points():
     e.close()
 
 
+@pytest.mark.parametrize("wide", ["0", "16"])
+def test_mixed_resolution_neighbours_parity_both_kernels(wide):
+    """The shipped combination -- one-call boundary, one-wave-per-pixel kernel (the engine's choice for a single depth map), mixed-size sources, geometric
+    round with resized depth maps -- and the regular kernel, each on a fresh engine (PMHIP_WIDE is read at pmhip_create)."""
+    import os
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    saved = os.environ.get("PMHIP_WIDE")
+    os.environ["PMHIP_WIDE"] = wide
+    try:
+        e = PatchMatchHIP(0)
+        test_mixed_resolution_neighbours_parity(e)
+        e.close()
+    finally:
+        if saved is None:
+            os.environ.pop("PMHIP_WIDE", None)
+        else:
+            os.environ["PMHIP_WIDE"] = saved
+
+
 def test_mixed_resolution_neighbours_parity(engine):
     """Source views of another size than the reference (DepthMap.h:194-204: a neighbour whose scale differs by >= 15 % is rescaled; here one at 0.8x
     and one at 1.25x, rendered at those sizes): every view is projected into with its own K and sampled within its own bounds, on all pyramid

@@ -20,6 +20,7 @@ struct sgmhip_engine {
 	SGMPixel* d_pixels = nullptr; unsigned char* d_costs = nullptr; unsigned short* d_accums = nullptr; float4* d_setup = nullptr;
 	short* d_disp = nullptr; unsigned short* d_cost = nullptr; unsigned short* d_P2s = nullptr;
 	bool statsOn = false; SGMHipStats stats{};
+	bool uniform = false; int uniformMin = 0, uniformMax = 0; SGMUniform* d_uniform = nullptr;   // every pixel has [uniformMin, uniformMax) and idx = pixel * nD (checked on the device at set_problem): the register-resident path kernel applies
 	int subGroups = 0;            // 0, or the lanes per sub-group (8, 16, 32): Match with the sub-group kernels of sgm_kernels_sub.hip (narrow, ragged ranges); see sgmhip_set_sub_group_kernels
 	struct Ev { hipEvent_t a, b; int kind; }; std::vector<Ev> events;
 };
@@ -50,10 +51,11 @@ static int sgmReserve(sgmhip_engine* e, int w, int h, uint64_t numCosts, int max
 		sgmFree(e);
 		SGMCHK(e, hipMalloc(&e->d_color, cI * 3)); SGMCHK(e, hipMalloc(&e->d_grayL, cI * 4)); SGMCHK(e, hipMalloc(&e->d_grayR, cI * 4));
 		SGMCHK(e, hipMalloc(&e->d_pixels, cP * sizeof(SGMPixel))); SGMCHK(e, hipMalloc(&e->d_disp, cP * 2)); SGMCHK(e, hipMalloc(&e->d_cost, cP * 2)); SGMCHK(e, hipMalloc(&e->d_setup, cP * sizeof(float4)));
-		SGMCHK(e, hipMalloc(&e->d_costs, cC)); SGMCHK(e, hipMalloc(&e->d_accums, (cC + 1) / 2 * 4 + 4)); // u16 sums, addressed as 32-bit words by the path kernels
+		SGMCHK(e, hipMalloc(&e->d_costs, cC + 256)); SGMCHK(e, hipMalloc(&e->d_accums, (cC + 1) / 2 * 4 + 4)); // u16 sums, addressed as 32-bit words by the path kernels
 		e->capImg = cI; e->capPix = cP; e->capCosts = cC;
 	}
 	e->w = w; e->h = h; e->vw = w - 2 * SGM_HW; e->vh = h - 2 * SGM_HW; e->numCosts = numCosts; e->maxNumDisp = maxNumDisp;
+	e->uniform = false;
 	return 0;
 }
 
@@ -74,7 +76,7 @@ void sgmhip_destroy(sgmhip_engine* e) {
 	if (!e) return;
 	hipSetDevice(e->device); hipStreamSynchronize(e->stream);
 	for (auto& ev : e->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
-	sgmFree(e); if (e->d_P2s) hipFree(e->d_P2s);
+	sgmFree(e); if (e->d_P2s) hipFree(e->d_P2s); if (e->d_uniform) hipFree(e->d_uniform);
 	hipStreamDestroy(e->stream); delete e;
 }
 const char* sgmhip_last_error(sgmhip_engine* e) { return e ? e->err.c_str() : "null engine"; }
@@ -95,7 +97,18 @@ int sgmhip_set_problem(sgmhip_engine* e, const uint8_t* leftBGR, const float* le
 	SGMCHK(e, hipMemcpyAsync(e->d_grayL, leftGray, nImg * 4, hipMemcpyHostToDevice, e->stream));
 	SGMCHK(e, hipMemcpyAsync(e->d_grayR, rightGray, nImg * 4, hipMemcpyHostToDevice, e->stream));
 	SGMCHK(e, hipMemcpyAsync(e->d_pixels, pixels, nPix * sizeof(SGMPixel), hipMemcpyHostToDevice, e->stream));
+	// one range for all pixels?  (then Match aggregates with sgm_path_uniform_kernel)
+	static const bool allowUniform = [] { const char* v = getenv("SGMHIP_UNIFORM"); return !v || atoi(v) != 0; }();
+	SGMUniform hu = {1, 0, 0, 0};
+	if (allowUniform && maxNumDisp <= 128) {
+		if (!e->d_uniform) SGMCHK(e, hipMalloc(&e->d_uniform, sizeof(SGMUniform)));
+		SGMCHK(e, hipMemcpyAsync(e->d_uniform, &hu, sizeof(hu), hipMemcpyHostToDevice, e->stream));
+		hipLaunchKernelGGL(sgm_uniform_check_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, e->stream, e->d_pixels, (long)nPix, e->d_uniform);
+		SGMCHK(e, hipMemcpyAsync(&hu, e->d_uniform, sizeof(hu), hipMemcpyDeviceToHost, e->stream));
+	} else hu.ok = 0;
 	SGMCHK(e, hipStreamSynchronize(e->stream));
+	e->uniform = hu.ok != 0 && hu.maxDisp - hu.minDisp == maxNumDisp && (uint64_t)nPix * (uint64_t)maxNumDisp == numCosts;
+	e->uniformMin = hu.minDisp; e->uniformMax = hu.maxDisp;
 	return 0;
 }
 
@@ -209,7 +222,16 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 	}
 	sd.first[8] = total;
 	evB(e, 1);
-	if (total > 0) launchPath(e, e->stream, NK, total, (int)P1, sd);
+	if (total > 0) {
+		if (e->uniform && NK <= 2) {
+			const bool even = (e->maxNumDisp & 1) == 0;
+#define SGM_LAUNCH_UNIFORM(NK_, EVEN_) hipLaunchKernelGGL((sgm_path_uniform_kernel<NK_, EVEN_>), dim3(total), dim3(64), 0, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->maxNumDisp, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, (int)P1, sd)
+			if (NK == 1) { if (even) SGM_LAUNCH_UNIFORM(1, true); else SGM_LAUNCH_UNIFORM(1, false); }
+			else { if (even) SGM_LAUNCH_UNIFORM(2, true); else SGM_LAUNCH_UNIFORM(2, false); }
+#undef SGM_LAUNCH_UNIFORM
+		}
+		else launchPath(e, e->stream, NK, total, (int)P1, sd);
+	}
 	if (e->statsOn) e->stats.aggrLaunches += 1;
 	evE(e);
 	evB(e, 2);

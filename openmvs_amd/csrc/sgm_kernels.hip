@@ -154,14 +154,21 @@ struct SGMLines { int nA, ax, ay, adx, ady, nB, bx, by, bdx, bdy; };
 // wave64 minimum on the VALU cross-lane network (DPP row shifts + row broadcasts, then one readlane) instead of six
 // dependent ds_bpermute round trips through the LDS crossbar: this reduction sits on the critical path of every step
 // of the path recurrence.
+// One step is a single v_min_i32_dpp (lanes without a source are write-disabled and keep their value); the compiler emits v_mov_b32_dpp + v_min_i32 and
+// re-materialises the fill value for each, three instructions per step, when this is written with __builtin_amdgcn_update_dpp.  The s_nop covers the
+// VALU-write -> DPP-read hazard (2 wait states), which the compiler cannot see inside an asm statement.
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+#define SGM_MIN_DPP(v, CTRLSTR, ctrl, rm) asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 " CTRLSTR : "+v"(v))
+#else   // host pass and the CPU emulator of the test-suite
+#define SGM_MIN_DPP(v, CTRLSTR, ctrl, rm) v = min(v, __builtin_amdgcn_update_dpp(v, v, ctrl, rm, 0xf, false))
+#endif
 __device__ __forceinline__ int sgm_wave_min(int v) {
-	const int big = SGM_INF;
-	v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x111, 0xf, 0xf, false)); // row_shr:1
-	v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x112, 0xf, 0xf, false)); // row_shr:2
-	v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x114, 0xf, 0xf, false)); // row_shr:4
-	v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x118, 0xf, 0xf, false)); // row_shr:8  -> lane 15 of each row of 16 holds the row minimum
-	v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1 and 3
-	v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave minimum
+	SGM_MIN_DPP(v, "row_shr:1 row_mask:0xf bank_mask:0xf", 0x111, 0xf);
+	SGM_MIN_DPP(v, "row_shr:2 row_mask:0xf bank_mask:0xf", 0x112, 0xf);
+	SGM_MIN_DPP(v, "row_shr:4 row_mask:0xf bank_mask:0xf", 0x114, 0xf);
+	SGM_MIN_DPP(v, "row_shr:8 row_mask:0xf bank_mask:0xf", 0x118, 0xf);   // lane 15 of each row of 16 holds the row minimum
+	SGM_MIN_DPP(v, "row_bcast:15 row_mask:0xa bank_mask:0xf", 0x142, 0xa); // into rows 1 and 3
+	SGM_MIN_DPP(v, "row_bcast:31 row_mask:0xc bank_mask:0xf", 0x143, 0xc); // into rows 2 and 3: lane 63 holds the wave minimum
 	return __builtin_amdgcn_readlane(v, 63);
 }
 
@@ -326,6 +333,145 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 			for (int t = 0; t < SGM_T; ++t) sgm_step<NK>(s_L, s_P2, s_px[slot][t0 + SGM_T + t], s_g[slot][t0 + SGM_T + t], cB[t], accumWords, P1, lane, st);
 		}
 		x += SGM_TT * dx; y += SGM_TT * dy; slot ^= 1;
+	}
+}
+
+// ---- the same recurrence when every pixel of the valid grid has the same disparity range (the first level of tSGM and a plain `Match`:
+// SemiGlobalMatcher.cpp:874-896 gives all pixels [minDisp, maxDisp)) ---------------------------------------------------------------------------------
+// With one range, entry k of a pixel is disparity minDisp + k for every pixel, so the previous pixel's L needs no re-indexing: the line of L stays in
+// registers (lane l owns entries l*NK .. l*NK+NK-1), Lp(d-1) / Lp(d+1) are the neighbouring lanes' registers (DPP wave shifts, SGM_INF shifted in at
+// both ends), and PixelData::idx is pixel * nD -- no pixel table, no LDS line buffer, no fences.  The penalty P2 of a step depends only on the grey
+// values of this pixel and the one before it (:1073-1079), so a chunk of 64 pixels computes its 64 penalties at once, one per lane, and a step
+// fetches its own with v_readlane.  A step is then ~25 VALU instructions instead of ~90 (+ ~50 scalar ones); results are the same integers.
+// The host checks the premise (sgm_uniform_check_kernel) and falls back to sgm_path_kernel when it does not hold.
+struct SGMUniform { int ok, minDisp, maxDisp, pad; };
+__global__ __launch_bounds__(256) void sgm_uniform_check_kernel(const SGMPixel* __restrict__ pixels, long nPix, SGMUniform* __restrict__ out) {
+	const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (pix >= nPix) return;
+	const SGMPixel p0 = pixels[0], px = pixels[pix];
+	const int nD = p0.maxDisp - p0.minDisp;
+	const bool same = nD > 0 && px.minDisp == p0.minDisp && px.maxDisp == p0.maxDisp && px.idx == (unsigned long long)pix * (unsigned long long)nD;
+	if (!same) out->ok = 0;                                           // (every writer stores the same value)
+	if (pix == 0) { out->minDisp = p0.minDisp; out->maxDisp = p0.maxDisp; }
+}
+
+#ifndef SGM_UT
+#define SGM_UT 8         // pixels per cost prefetch sub-chunk of the uniform-range kernel
+#endif
+template <int NK, bool EVEN>   // EVEN: nD is even, so every pixel's entries start on a word of the sums (idx = pixel * nD)
+__global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __restrict__ grayL, int w, int vw, int vh, int nD,
+		const unsigned char* __restrict__ costs, unsigned* __restrict__ accumWords, const unsigned short* __restrict__ P2s, int P1, SGMDirs dirs) {
+	__shared__ unsigned short s_P2[256];
+	const int lane = threadIdx.x;
+	int dir = 0;
+#pragma unroll
+	for (int i = 1; i < 8; ++i) dir += (int)blockIdx.x >= dirs.first[i] ? 1 : 0;
+	const int line = (int)blockIdx.x - dirs.first[dir];
+	const int dx = dirs.dx[dir], dy = dirs.dy[dir];
+	const SGMLines ln = dirs.ln[dir];
+	int x, y;
+	if (line < ln.nA) { x = ln.ax + line * ln.adx; y = ln.ay + line * ln.ady; }
+	else { const int i = line - ln.nA; x = ln.bx + i * ln.bdx; y = ln.by + i * ln.bdy; }
+	for (int k = lane; k < 256; k += 64) s_P2[k] = P2s[k];
+	__syncthreads();
+	if (x < 0 || y < 0 || x >= vw || y >= vh) return;
+	// pixels on the line
+	int n = 0x7fffffff;
+	if (dx > 0) n = min(n, vw - x); else if (dx < 0) n = min(n, x + 1);
+	if (dy > 0) n = min(n, vh - y); else if (dy < 0) n = min(n, y + 1);
+	const long long idx0 = ((long long)y * vw + x) * nD;              // PixelData::idx of the first pixel, and its step along the line
+	const long long dIdx = ((long long)dy * vw + dx) * nD;
+	static_assert(NK == 1 || NK == 2, "lane-local word pairs are written out for one or two entries per lane");
+	const int k0 = lane * NK;
+	auto grayLoad = [&](int i0) -> float {                           // grey value of pixel i0 + lane of the line (valid-grid coordinate on the full image: the reference's quirk, :1078)
+		const int i = i0 + lane;
+		return i < n ? grayL[(size_t)(y + i * dy) * w + (x + i * dx)] : 0.f;
+	};
+	// cost bytes of pixels i0 .. i0+SGM_UT-1 of the line.  Lanes past the range read the bytes that follow (the next pixel's costs; the volume is
+	// allocated with 256 spare bytes) and never use them, which keeps the loads free of per-lane predicates.
+	auto costLoad = [&](int i0, unsigned char (*c8)[NK]) {
+		const unsigned char* base = costs + (idx0 + (long long)i0 * dIdx);
+		if (i0 + SGM_UT <= n) {                                         // (uniform) all of them on the line: one pointer stepped along it
+#pragma unroll
+			for (int t = 0; t < SGM_UT; ++t, base += dIdx)
+#pragma unroll
+				for (int q = 0; q < NK; ++q) c8[t][q] = base[(unsigned)(k0 + q)];
+		} else {
+#pragma unroll
+			for (int t = 0; t < SGM_UT; ++t, base += dIdx)
+#pragma unroll
+				for (int q = 0; q < NK; ++q) { c8[t][q] = 0; if (i0 + t < n) c8[t][q] = base[(unsigned)(k0 + q)]; }
+		}
+	};
+	int L[NK];
+#pragma unroll
+	for (int q = 0; q < NK; ++q) L[q] = SGM_INF;
+	auto step = [&](int i, int P2, const unsigned char* c8) {
+		if (i >= n) return;
+		const long long idx = idx0 + (long long)i * dIdx;
+		int Ln[NK];
+		if (i == 0) {                                                   // no previous pixel: L = C + P2 (:1012-1021)
+#pragma unroll
+			for (int q = 0; q < NK; ++q) Ln[q] = (int)c8[q] + P2;
+		} else {
+			int m = L[0];
+#pragma unroll
+			for (int q = 1; q < NK; ++q) m = min(m, L[q]);
+			m = sgm_wave_min(m);
+			const int mP2 = m + P2;
+			const int fromLeft = __builtin_amdgcn_update_dpp(SGM_INF, L[NK - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1: entry k0-1 (lane 0: none)
+			const int fromRight = __builtin_amdgcn_update_dpp(SGM_INF, L[0], 0x130, 0xf, 0xf, false);        // wave_shl:1: entry k0+NK (lane 63: none)
+#pragma unroll
+			for (int q = 0; q < NK; ++q) {
+				const int am = q == 0 ? fromLeft : L[q - 1], ap = q == NK - 1 ? fromRight : L[q + 1];
+				const int best = min(min(mP2, L[q]), min(am, ap) + P1);
+				Ln[q] = (int)c8[q] + best - m;
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < NK; ++q) L[q] = k0 + q < nD ? Ln[q] : SGM_INF;
+		// accums(d) += L(d): as sgm_accumulate, with the pair of a word taken from this lane's registers where it can be
+		unsigned* words = accumWords + (idx >> 1);
+		const unsigned par = EVEN ? 0u : (unsigned)(idx & 1ll);
+		unsigned v[NK + 1];
+#pragma unroll
+		for (int q = 0; q < NK; ++q) v[q] = k0 + q < nD ? (unsigned)L[q] : 0u;
+		v[NK] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[0], 0x130, 0xf, 0xf, false);   // the next lane's first entry (lane 63: none)
+		if (NK == 1) {
+			// par == 0: even lanes hold the low halves and add the pair; par == 1: odd lanes do, and entry 0 (the high half of the first word) adds alone
+			if (par == 0u) { if (!(lane & 1) && k0 < nD) atomicAdd(words + (lane >> 1), v[0] | (v[1] << 16)); }
+			else if (k0 < nD) { if (lane & 1) atomicAdd(words + ((lane + 1) >> 1), v[0] | (v[1] << 16)); else if (lane == 0) atomicAdd(words, v[0] << 16); }
+		} else {
+			// lane l owns entries 2l, 2l+1: with par == 0 they are the halves of word l; with par == 1 the pair is (2l+1, 2l+2), completed by the next
+			// lane's first entry, and entry 0 of the pixel adds alone
+			if (par == 0u) { if (k0 < nD) atomicAdd(words + lane, v[0] | (v[1] << 16)); }
+			else {
+				if (k0 + 1 < nD) atomicAdd(words + lane + 1, v[1] | (v[2] << 16));
+				if (lane == 0) atomicAdd(words, v[0] << 16);
+			}
+		}
+	};
+	float g = grayLoad(0), gNext = grayLoad(64);
+	float carry = 0.5f;                                               // Ip before the first pixel (:1066)
+	unsigned char cA[SGM_UT][NK], cB[SGM_UT][NK];
+	costLoad(0, cA);
+#pragma unroll 1
+	for (int i0 = 0; i0 < n; i0 += 64) {
+		// the 64 penalties of this chunk: lane t has pixel i0 + t, its predecessor's grey value comes from lane t-1 (lane 0: the chunk before)
+		const float Ip = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, carry), __builtin_bit_cast(int, g), 0x138, 0xf, 0xf, false));
+		int ip = sgm_round2int(255.f * (g - Ip)); ip = ip < 0 ? -ip : ip;
+		const int P2v = (int)s_P2[ip > 255 ? 255 : ip];
+		carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g), 63));
+		g = gNext; gNext = grayLoad(i0 + 128);
+#pragma unroll 1
+		for (int s = 0; s < 64 && i0 + s < n; s += 2 * SGM_UT) {
+			costLoad(i0 + s + SGM_UT, cB);
+#pragma unroll
+			for (int t = 0; t < SGM_UT; ++t) step(i0 + s + t, __builtin_amdgcn_readlane(P2v, s + t), cA[t]);
+			costLoad(i0 + s + 2 * SGM_UT, cA);
+#pragma unroll
+			for (int t = 0; t < SGM_UT; ++t) step(i0 + s + SGM_UT + t, __builtin_amdgcn_readlane(P2v, s + SGM_UT + t), cB[t]);
+		}
 	}
 }
 

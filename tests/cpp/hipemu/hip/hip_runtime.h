@@ -111,6 +111,7 @@ inline int dpp_source(int ctrl, int l) {
 	if (ctrl >= 0x111 && ctrl <= 0x11f) { const int s = r - (ctrl & 15); return s < 0 ? -1 : (row << 4) + s; }      // row_shr:n  (lane reads lane-n)
 	if (ctrl >= 0x121 && ctrl <= 0x12f) return (row << 4) + ((r - (ctrl & 15)) & 15);                                  // row_ror:n
 	if (ctrl == 0x130) return l < 63 ? l + 1 : -1;                                                                     // wave_shl:1 (lane reads lane+1 across rows)
+	if (ctrl == 0x138) return l > 0 ? l - 1 : -1;                                                                      // wave_shr:1 (lane reads lane-1 across rows)
 	if (ctrl == 0x140) return (row << 4) + (15 - r);                                                                   // row_mirror
 	if (ctrl == 0x141) return (row << 4) + (r < 8 ? 7 - r : 23 - r);                                                    // row_half_mirror
 	if (ctrl == 0x142) return row == 0 ? -1 : ((row - 1) << 4) + 15;                                                   // row_bcast:15

@@ -45,6 +45,30 @@ def test_match_parity(matcher, w, h, kind, dmin, dmax):
         assert (d[:, 8:w - 6 - (dmax + 8)] == 5).mean() > 0.97
 
 
+@pytest.mark.parametrize("w,h,dmin,dmax", [(96, 64, -8, 56), (150, 90, 0, 33), (90, 160, -3, 100), (214, 77, 0, 127), (80, 75, 2, 130), (71, 12, 0, 1), (12, 140, -1, 1)])
+def test_uniform_range_path_kernel(matcher, w, h, dmin, dmax):
+    """One range for every pixel (a plain Match and the first tSGM level): the engine aggregates with sgm_path_uniform_kernel (previous line of L in
+    registers, neighbours by DPP wave shifts).  Full waves (64, 128), odd counts (33, 103, 127: pixels start on odd halves of the sum words), one and two
+    entries per lane, lines longer than a 64-pixel chunk in every direction, one- and two-disparity ranges; the same integers as the oracle and as the
+    general kernel."""
+    lb, lg, rg = sc.stereo_pair(w, h, 5, seed=w + h)
+    px, n, mx = sc.ranges(w, h, "uniform", dmin, dmax)
+    _check(matcher, lb, lg, rg, px, n, mx)
+
+
+def test_uniform_premise_is_checked(matcher):
+    """One pixel with a different range, or with an idx that is not pixel * nD, sends the problem to the general path kernel: same results as the oracle."""
+    w, h = 110, 80
+    lb, lg, rg = sc.stereo_pair(w, h, 5, seed=21)
+    mn = np.full((h - 6, w - 6), -4, np.int16); mx_ = np.full((h - 6, w - 6), 40, np.int16)
+    mx_[37, 51] = 39
+    px, n, mx = sgm.make_pixels(mn, mx_)
+    _check(matcher, lb, lg, rg, px, n, mx)
+    mn[0, 0] = 32767; mx_[0, 0] = 32767; mx_[37, 51] = 40           # the first pixel invalid: "every pixel like the first" must not pass either
+    px, n, mx = sgm.make_pixels(mn, mx_)
+    _check(matcher, lb, lg, rg, px, n, mx)
+
+
 def test_match_parity_across_long_invalid_runs(matcher):
     """Masked regions (ranges NO_DISP..NO_DISP) wider than the path kernel's 64-pixel table chunk: paths skip them without resetting their state
     (SemiGlobalMatcher.cpp:1071-1072), so a whole staged chunk can be invalid.  NOT YET RUN ON A DEVICE."""

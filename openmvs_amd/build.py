@@ -23,6 +23,10 @@ LIBS = {
 }
 
 
+# per-library extra flags.  libsgmhip: the SLP vectoriser pairs the per-tap multiplies of sgm_cost_px_kernel into v_pk_mul_f32, which costs it ~60 more
+# VGPRs (copies into aligned register pairs) and pushes it into scratch; the packed form is no faster per flop on this part.
+LIB_FLAGS = {"libsgmhip.so": ["-fno-slp-vectorize"]}
+
 HOST_LIBS = {"libdmapio.so": (["dmap_io.cpp"], ["../../include/dmapio.h"]),          # plain C++ (g++), no GPU code
              "libmvsfront.so": (["mvs_front.cpp"], ["../../include/mvsfront.h"])}
 
@@ -57,7 +61,7 @@ def build_variant(name: str, out_name: str, extra_flags: list[str]) -> str:
     """Experiment helper: build `name` with extra -D flags into openmvs_amd/<out_name>."""
     srcs, _ = LIBS[name]
     out = lib_path(out_name)
-    subprocess.check_call([HIPCC] + FLAGS + list(extra_flags) + [os.path.join(_CSRC, s) for s in srcs] + ["-o", out], cwd=_CSRC)
+    subprocess.check_call([HIPCC] + FLAGS + LIB_FLAGS.get(name, []) + list(extra_flags) + [os.path.join(_CSRC, s) for s in srcs] + ["-o", out], cwd=_CSRC)
     return out
 
 
@@ -73,7 +77,7 @@ def build_lib(name: str, force: bool = False, verbose: bool = False) -> str | No
         if os.path.exists(out):
             return out  # GPU box without a compiler in PATH: use the shipped binary
         raise RuntimeError("hipcc not found and %s is not built" % name)
-    cmd = [HIPCC] + FLAGS + srcs_abs + ["-o", out]
+    cmd = [HIPCC] + FLAGS + LIB_FLAGS.get(name, []) + srcs_abs + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=_CSRC)

@@ -51,7 +51,7 @@ static int sgmReserve(sgmhip_engine* e, int w, int h, uint64_t numCosts, int max
 		sgmFree(e);
 		SGMCHK(e, hipMalloc(&e->d_color, cI * 3)); SGMCHK(e, hipMalloc(&e->d_grayL, cI * 4)); SGMCHK(e, hipMalloc(&e->d_grayR, cI * 4));
 		SGMCHK(e, hipMalloc(&e->d_pixels, cP * sizeof(SGMPixel))); SGMCHK(e, hipMalloc(&e->d_disp, cP * 2)); SGMCHK(e, hipMalloc(&e->d_cost, cP * 2)); SGMCHK(e, hipMalloc(&e->d_setup, cP * sizeof(float4)));
-		SGMCHK(e, hipMalloc(&e->d_costs, cC + 256)); SGMCHK(e, hipMalloc(&e->d_accums, (cC + 1) / 2 * 4 + 4)); // u16 sums, addressed as 32-bit words by the path kernels
+		SGMCHK(e, hipMalloc(&e->d_costs, cC + 256)); SGMCHK(e, hipMalloc(&e->d_accums, (cC + 3) / 4 * 8 + 8)); // u16 sums, addressed as 32-bit words by the path kernels
 		e->capImg = cI; e->capPix = cP; e->capCosts = cC;
 	}
 	e->w = w; e->h = h; e->vw = w - 2 * SGM_HW; e->vh = h - 2 * SGM_HW; e->numCosts = numCosts; e->maxNumDisp = maxNumDisp;
@@ -193,9 +193,19 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 	const long nPix = (long)e->vw * e->vh;
 	const int W = e->vw, H = e->vh;
 	evB(e, 0);
-	hipLaunchKernelGGL(sgm_setup_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->w, W, H, e->d_pixels, e->d_setup);
-	const long nPairs = (long)((W + 1) / 2) * H;
-	hipLaunchKernelGGL(sgm_cost_kernel, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_setup, e->d_costs);
+	static const bool pxCost = [] { const char* v = getenv("SGMHIP_COST_PX"); return !v || atoi(v) != 0; }();   // 0: the wave-per-pixel-pair cost kernel
+	if (pxCost && e->maxNumDisp <= 248) {
+		// one pixel per lane, 64-pixel tiles of a row per wave (sgm_cost_px_kernel; does the left-window prologue itself)
+		const long nTiles = (long)((W + 63) / 64) * H;
+		const dim3 g((unsigned)((nTiles + 3) / 4));
+#define SGM_LAUNCH_PX(MD_) hipLaunchKernelGGL((sgm_cost_px_kernel<MD_>), g, dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_costs)
+		if (e->maxNumDisp <= 32) SGM_LAUNCH_PX(32); else if (e->maxNumDisp <= 64) SGM_LAUNCH_PX(64); else if (e->maxNumDisp <= 128) SGM_LAUNCH_PX(128); else SGM_LAUNCH_PX(248);
+#undef SGM_LAUNCH_PX
+	} else {
+		hipLaunchKernelGGL(sgm_setup_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->w, W, H, e->d_pixels, e->d_setup);
+		const long nPairs = (long)((W + 1) / 2) * H;
+		hipLaunchKernelGGL(sgm_cost_kernel, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_setup, e->d_costs);
+	}
 	evE(e);
 	SGMCHK(e, hipMemsetAsync(e->d_accums, 0, (e->numCosts + 1) / 2 * 4, e->stream)); // imageAccumCosts.Memset(0), :990
 	const int NK = e->maxNumDisp <= 64 ? 1 : (e->maxNumDisp <= 128 ? 2 : 4);
@@ -224,10 +234,11 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 	evB(e, 1);
 	if (total > 0) {
 		if (e->uniform && NK <= 2) {
-			const bool even = (e->maxNumDisp & 1) == 0;
-#define SGM_LAUNCH_UNIFORM(NK_, EVEN_) hipLaunchKernelGGL((sgm_path_uniform_kernel<NK_, EVEN_>), dim3(total), dim3(64), 0, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->maxNumDisp, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, (int)P1, sd)
-			if (NK == 1) { if (even) SGM_LAUNCH_UNIFORM(1, true); else SGM_LAUNCH_UNIFORM(1, false); }
-			else { if (even) SGM_LAUNCH_UNIFORM(2, true); else SGM_LAUNCH_UNIFORM(2, false); }
+			static const int maxAlign = [] { const char* v = getenv("SGMHIP_UNIFORM_ALIGN"); const int n = v ? atoi(v) : 4; return n >= 4 ? 4 : (n >= 2 ? 2 : 1); }();   // 2: 32-bit atomics only
+			const int nDu = e->maxNumDisp, align = (nDu % 4 == 0 && maxAlign >= 4) ? 4 : ((nDu % 2 == 0 && maxAlign >= 2) ? 2 : 1);
+#define SGM_LAUNCH_UNIFORM(NK_, AL_) hipLaunchKernelGGL((sgm_path_uniform_kernel<NK_, AL_>), dim3(total), dim3(64), 0, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->maxNumDisp, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, (int)P1, sd)
+			if (NK == 1) { if (align == 4) SGM_LAUNCH_UNIFORM(1, 4); else if (align == 2) SGM_LAUNCH_UNIFORM(1, 2); else SGM_LAUNCH_UNIFORM(1, 1); }
+			else { if (align == 4) SGM_LAUNCH_UNIFORM(2, 4); else if (align == 2) SGM_LAUNCH_UNIFORM(2, 2); else SGM_LAUNCH_UNIFORM(2, 1); }
 #undef SGM_LAUNCH_UNIFORM
 		}
 		else launchPath(e, e->stream, NK, total, (int)P1, sd);

@@ -69,6 +69,20 @@ def test_uniform_premise_is_checked(matcher):
     _check(matcher, lb, lg, rg, px, n, mx)
 
 
+def test_pixel_table_with_entries_out_of_pixel_order(matcher):
+    """PixelData::idx is whatever the caller says: a table whose pixels own their entries in reverse pixel order (still a partition of the volume) gives the
+    same per-pixel results; the lane-per-pixel cost kernel's contiguous-tile write-out must notice and store per pixel."""
+    w, h = 100, 40
+    lb, lg, rg = sc.stereo_pair(w, h, 4, seed=5)
+    px, n, mx = sc.ranges(w, h, "ragged", -3, 20, seed=2)
+    nd = np.maximum(px["maxDisp"].astype(np.int64) - px["minDisp"].astype(np.int64), 0)
+    rev = px.copy()
+    rev["idx"] = (np.cumsum(nd[::-1])[::-1] - nd).astype(np.uint64)
+    d0, c0 = _check(matcher, lb, lg, rg, px, n, mx)
+    d1, c1 = _check(matcher, lb, lg, rg, rev, n, mx)
+    assert np.array_equal(d0, d1) and np.array_equal(c0, c1)
+
+
 def test_match_parity_across_long_invalid_runs(matcher):
     """Masked regions (ranges NO_DISP..NO_DISP) wider than the path kernel's 64-pixel table chunk: paths skip them without resetting their state
     (SemiGlobalMatcher.cpp:1071-1072), so a whole staged chunk can be invalid.  NOT YET RUN ON A DEVICE."""

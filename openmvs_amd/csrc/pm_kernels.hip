@@ -433,6 +433,54 @@ __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int t
 	return ok;
 }
 
+// The window-less optimistic rows (pm_tap_row_lds<.., FROM_IMAGE>) as a software pipeline over the five rows of a patch.  A wave walks ~110 tap rows
+// per visit and every row began with five scattered 16-byte loads whose latency (L2 / HBM: the quad images of a batch are far larger than the caches)
+// nothing else in the wave could cover -- the counters showed waves ~40 % VALU-active and a diagonal's launch lasting as long as one wave's chain of
+// such round trips.  Here the texel addresses and loads of row i+1 are issued before row i is consumed, and a row has no control flow: its sums are
+// committed unconditionally, `oob` / `redo` only record what the range checks found.  A patch with a row that was not exact (z outside
+// [2^-40, 2^40] or !sane: rare) is redone as a whole by the caller through pm_tap_row_global -- the fast rows produce exactly its sums, so redoing them
+// changes nothing.  PM_ROW_PIPELINE 0 restores the row-at-a-time loop.
+#ifndef PM_ROW_PIPELINE
+#define PM_ROW_PIPELINE 1
+#endif
+struct PMRowTaps { float ptx[5], pty[5], zlo, zhi; unsigned goff[5]; };
+struct PMRowQuads { float v00[5], v01[5], v10[5], v11[5]; };
+__device__ __forceinline__ void pm_row_prep(PMRowTaps& r, int sw, int sh, float h0, float h3, float h6, float X0, float X1, float X2) {
+	r.zlo = X2; r.zhi = X2;
+#pragma unroll
+	for (int j = 0; j < 5; ++j) {
+		pm_div2_inrange(X0, X1, X2, &r.ptx[j], &r.pty[j]);
+		r.zlo = pm_fminf(r.zlo, X2); r.zhi = pm_fmaxf(r.zhi, X2);
+		const int lx = (int)r.ptx[j], ly = (int)r.pty[j];
+		const int lxc = min(max(lx, 0), sw - 2), lyc = min(max(ly, 0), sh - 2);
+		r.goff[j] = (unsigned)(lxc + lyc) * (unsigned)sh + (unsigned)lyc;
+		X0 += h0; X1 += h3; X2 += h6;
+	}
+}
+__device__ __forceinline__ void pm_row_load(PMRowQuads& q, const PMRowTaps& r, const pm_gcf4 imgQ) {
+#pragma unroll
+	for (int j = 0; j < 5; ++j) pm_load4(imgQ, r.goff[j], q.v00[j], q.v01[j], q.v10[j], q.v11[j]);
+}
+__device__ __forceinline__ void pm_row_consume(const PMRowTaps& r, const PMRowQuads& q, int sw, int sh, bool sane, const float2* wrow,
+		float& sum, float& sumSq, float& num, bool& oob, bool& redo) {
+	float pxlo = PM_INF, pxhi = -PM_INF, pylo = PM_INF, pyhi = -PM_INF;
+#pragma unroll
+	for (int j = 0; j < 5; ++j) {
+		pxlo = pm_fminf(pxlo, r.ptx[j]); pxhi = pm_fmaxf(pxhi, r.ptx[j]); pylo = pm_fminf(pylo, r.pty[j]); pyhi = pm_fmaxf(pyhi, r.pty[j]);
+		const float fx = pm_fract_pos(r.ptx[j]), fx1 = 1.f - fx, fy = pm_fract_pos(r.pty[j]), fy1 = 1.f - fy;
+		const float v = (q.v00[j] * fx1 + q.v01[j] * fx) * fy1 + (q.v10[j] * fx1 + q.v11[j] * fx) * fy;
+		const float2 pw = wrow[j];
+		const float vw = v * pw.x;
+		sum += vw;
+		sumSq += v * vw;
+		num += v * pw.y;
+	}
+	const bool exact = sane && r.zlo >= 9.094947e-13f && r.zhi <= 1.0995116e12f;
+	const bool inImage = pxlo >= 1.f && pylo >= 1.f && pxhi <= (float)(sw - 2) && pyhi <= (float)(sh - 2);
+	oob = oob || (exact && !inImage);
+	redo = redo || !exact;
+}
+
 // PF: the pixel's low-resolution prior and its blend factor exp(normSq0 * sigma) sit in the spare 26th entry of the pixel's weight row in LDS
 // (written once per visit by the sweep kernel) instead of in two registers that are live across the whole hypothesis loop
 // what pm_score_view needs to evaluate the lane's smoothness factor itself (PM_SMOOTH_IN_ROW0)
@@ -493,6 +541,33 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 	if (TC > 0) { sum = 0.31f * sumW; sumSq = 0.11f * sumW + 0.01f * H[2]; num = 0.004f * H[5]; }
 	else
 #endif
+	if (FASTG && PM_ROW_PIPELINE) {
+		const pm_gcf4 imgQ = pm_glob4(s.imgQ);
+		const float rX0 = bX0, rX1 = bX1, rX2 = bX2;
+		const bool oobIn = oob;
+		bool redo = false;
+		PMRowTaps ta, tb; PMRowQuads qa, qb;
+		pm_row_prep(ta, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2);
+		pm_row_load(qa, ta, imgQ);
+#pragma unroll
+		for (int i = 0; i < 5; ++i) {
+			bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
+			if (i < 4) { pm_row_prep(tb, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2); pm_row_load(qb, tb, imgQ); }
+			__builtin_amdgcn_sched_barrier(0);   // keep the pipeline two rows deep: without it the scheduler hoists the loads of later rows too and spills
+			pm_row_consume(ta, qa, sw, sh, sane, wts + i * 5, sum, sumSq, num, oob, redo);
+			__builtin_amdgcn_sched_barrier(0);
+			ta = tb; qa = qb;
+		}
+		if (redo && !oob) {   // a row outside the fast divisions' range: the whole patch through the guarded path (same sums where the fast rows were valid)
+			sum = 0.f; sumSq = 0.f; num = 0.f; oob = oobIn;
+			bX0 = rX0; bX1 = rX1; bX2 = rX2;
+#pragma unroll 1
+			for (int i = 0; i < 5; ++i) {
+				pm_tap_row_global<SKEW>(pm_glob(SKEW ? s.imgS : s.img), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
+				bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
+			}
+		}
+	} else
 #pragma unroll 1
 	for (int i = iFirst; i < 5; ++i) {
 		bool done = false;

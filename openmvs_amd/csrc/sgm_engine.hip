@@ -194,13 +194,11 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 	const int W = e->vw, H = e->vh;
 	evB(e, 0);
 	static const bool pxCost = [] { const char* v = getenv("SGMHIP_COST_PX"); return !v || atoi(v) != 0; }();   // 0: the wave-per-pixel-pair cost kernel
-	if (pxCost && e->maxNumDisp <= 248) {
+	if (pxCost) {
 		// one pixel per lane, 64-pixel tiles of a row per wave (sgm_cost_px_kernel; does the left-window prologue itself)
 		const long nTiles = (long)((W + 63) / 64) * H;
 		const dim3 g((unsigned)((nTiles + 3) / 4));
-#define SGM_LAUNCH_PX(MD_) hipLaunchKernelGGL((sgm_cost_px_kernel<MD_>), g, dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_costs)
-		if (e->maxNumDisp <= 32) SGM_LAUNCH_PX(32); else if (e->maxNumDisp <= 64) SGM_LAUNCH_PX(64); else if (e->maxNumDisp <= 128) SGM_LAUNCH_PX(128); else SGM_LAUNCH_PX(248);
-#undef SGM_LAUNCH_PX
+		hipLaunchKernelGGL(sgm_cost_px_kernel, g, dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_costs);
 	} else {
 		hipLaunchKernelGGL(sgm_setup_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->w, W, H, e->d_pixels, e->d_setup);
 		const long nPairs = (long)((W + 1) / 2) * H;
@@ -234,11 +232,10 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 	evB(e, 1);
 	if (total > 0) {
 		if (e->uniform && NK <= 2) {
-			static const int maxAlign = [] { const char* v = getenv("SGMHIP_UNIFORM_ALIGN"); const int n = v ? atoi(v) : 4; return n >= 4 ? 4 : (n >= 2 ? 2 : 1); }();   // 2: 32-bit atomics only
-			const int nDu = e->maxNumDisp, align = (nDu % 4 == 0 && maxAlign >= 4) ? 4 : ((nDu % 2 == 0 && maxAlign >= 2) ? 2 : 1);
+			const int align = e->maxNumDisp % 2 == 0 ? 2 : 1;
 #define SGM_LAUNCH_UNIFORM(NK_, AL_) hipLaunchKernelGGL((sgm_path_uniform_kernel<NK_, AL_>), dim3(total), dim3(64), 0, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->maxNumDisp, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, (int)P1, sd)
-			if (NK == 1) { if (align == 4) SGM_LAUNCH_UNIFORM(1, 4); else if (align == 2) SGM_LAUNCH_UNIFORM(1, 2); else SGM_LAUNCH_UNIFORM(1, 1); }
-			else { if (align == 4) SGM_LAUNCH_UNIFORM(2, 4); else if (align == 2) SGM_LAUNCH_UNIFORM(2, 2); else SGM_LAUNCH_UNIFORM(2, 1); }
+			if (NK == 1) { if (align == 2) SGM_LAUNCH_UNIFORM(1, 2); else SGM_LAUNCH_UNIFORM(1, 1); }
+			else { if (align == 2) SGM_LAUNCH_UNIFORM(2, 2); else SGM_LAUNCH_UNIFORM(2, 1); }
 #undef SGM_LAUNCH_UNIFORM
 		}
 		else launchPath(e, e->stream, NK, total, (int)P1, sd);

@@ -149,66 +149,64 @@ __global__ __launch_bounds__(256, 4) void sgm_cost_kernel(const unsigned char* _
 
 // ---- the same cost volume with one valid-grid pixel per LANE ---------------------------------------------------------------------------------------
 // sgm_cost_kernel spends, per 64 costs, 49 broadcast ds_read_b128 (the pixel's weights are wave-uniform there), 28 unaligned multi-dword loads
-// and 294 packed VALU instructions, and the three units overlap badly (probes: r02_sgm_cost_probes.log).  Here a lane owns a pixel and walks its
-// disparities: the 49 weights w and the 49 products w*(v-mean) live in the lane's registers for the whole walk (no LDS reads), the 7x7 window of
-// the right image slides with the disparity (7 new texels per cost, the loads of neighbouring lanes are neighbouring addresses), and what remains
-// per cost is the arithmetic the reference's summation order demands: 49 x (2 mul + 1 add, 1 mul + 1 add, 1 mul + 1 add).  The prologue of
-// sgm_setup_kernel (weighted mean / variance of the left window) is the same 49 weights and is done here too -- no setup pass, no 16-byte record.
-// The costs of a wave's 64 pixels are one contiguous run of the ragged volume (PixelData::idx is the running sum of the range widths in pixel
-// order, :889-896): they are collected in LDS and written out as whole dwords.  A tile whose idx values are not such a run is written byte by byte.
+// and 294 packed VALU instructions, and the three units overlap badly (probes: r02_sgm_cost_probes.log; packed fp32 multiplies and adds move no more
+// flops per cycle than plain ones on this part: r03_valu_rate.log).  Here a lane owns a pixel and walks its disparities: the 49 weights w live in
+// the lane's registers for the whole walk, the 49 products w*(v-mean) in a lane-private LDS column (conflict-free ds_read_b32, immediate offsets),
+// the 7x7 window of the right image slides with the disparity (7 new texels per cost; the loads of neighbouring lanes are neighbouring addresses),
+// and what remains per cost is the arithmetic the reference's summation order demands: 49 x (2 mul + 1 add, 1 mul + 1 add, 1 mul + 1 add), all
+// full-rate VOP2.  The prologue of sgm_setup_kernel (weighted mean / variance of the left window) is the same 49 weights and is done here too --
+// no setup pass, no 16-byte record.  A lane collects four costs in a register and stores them as one aligned dword of its pixel's run.
 #define SGM_PX_STEP(R_)                                                                                                                          \
 	{                                                                                                                                             \
 		const int k = kb + (R_);                                                                                                                  \
 		if (k >= nDmax) break;                                                                                                                    \
+		asm volatile("" ::: "memory");   /* keep the 49 LDS reads inside the step: hoisted out of the loop they are 49 registers again */         \
 		const int dn = d0 + k + 1 + SGM_HW;                      /* column of the texels entering the window for disparity k+1 */              \
-		const int cn = ux + dn < 0 ? 0 : (ux + dn >= w ? w - 1 : ux + dn);                                                                        \
-		float nw[7];                                                                                                                              \
-		_Pragma("unroll") for (int i = 0; i < 7; ++i) nw[i] = rowsR[(size_t)i * w + cn];                                                          \
+		const unsigned cn = (unsigned)(ux + dn < 0 ? 0 : (ux + dn >= w ? w - 1 : ux + dn));                                                       \
 		float sum = 0.f, sumSq = 0.f, nom = 0.f;                                                                                                  \
 		_Pragma("unroll") for (int n = 0; n < SGM_NT; ++n) {                                                                                      \
 			const float f = win[n / 7][((R_) + n % 7) % 7];                                                                                       \
+			/* the leftmost column leaves the window with this step: its slot takes the texel of the entering column as soon as it has been read */ \
+			if (n % 7 == 0) win[n / 7][(R_)] = *(const float*)(rowsRb + (((unsigned)(n / 7) * (unsigned)w + cn) << 2));                           \
 			const float fw = f * wk[n];                                                                                                           \
-			sum += fw; sumSq += f * fw; nom += f * tk[n];                                                                                         \
+			sum += fw; sumSq += f * fw; nom += f * s_t[wave][n][lane];                                                                            \
 		}                                                                                                                                         \
 		const int d = d0 + k;                                                                                                                     \
 		const bool in = !(ux - SGM_HW + d < 0 || ux + SGM_HW + d >= w);                                                                           \
-		const unsigned char c = in ? sgm_cost_of(sum, sumSq, nom, sumW, normSq0) : (unsigned char)255;                                           \
-		if (k < nD) s_out[lbase + k] = c;                                                                                                         \
-		_Pragma("unroll") for (int i = 0; i < 7; ++i) win[i][(R_)] = nw[i];      /* the slot of the column that just left the window */        \
+		const unsigned c = in ? (unsigned)sgm_cost_of(sum, sumSq, nom, sumW, normSq0) : 255u;                                                    \
+		if (k < nD) {                                                                                                                             \
+			const unsigned pos = (idxLow + (unsigned)k) & 3u;   /* byte of its dword in the volume */                                             \
+			packed |= c << (8u * pos);                                                                                                            \
+			if (pos == 3u || k == nD - 1) {                                                                                                       \
+				unsigned char* at = costs + px.idx + (unsigned)k;   /* address of this (the last collected) byte */                               \
+				const unsigned first = (unsigned)k < pos ? pos - (unsigned)k : 0u;   /* first byte of the dword that belongs to this pixel */      \
+				if (pos == 3u && first == 0u) *reinterpret_cast<unsigned*>(at - 3) = packed;                                                      \
+				else for (unsigned bb = first; bb <= pos; ++bb) at[(int)bb - (int)pos] = (unsigned char)(packed >> (8u * bb));                    \
+				packed = 0u;                                                                                                                      \
+			}                                                                                                                                     \
+		}                                                                                                                                         \
 	}
 
-template <int MD>   // widest range of the problem: sizes the LDS slice of a wave (64 * MD + 16 bytes)
-__global__ __launch_bounds__(256, 2) void sgm_cost_px_kernel(const unsigned char* __restrict__ colorL, const float* __restrict__ grayL,
+__global__ __launch_bounds__(256, 3) void sgm_cost_px_kernel(const unsigned char* __restrict__ colorL, const float* __restrict__ grayL,
 		const float* __restrict__ grayR, int w, int h, int vw, int vh, const SGMPixel* __restrict__ pixels, unsigned char* __restrict__ costs) {
-	constexpr int tileBytes = 64 * MD + 16;
-	__shared__ __attribute__((aligned(16))) unsigned char s_dyn[4 * tileBytes];
+	__shared__ float s_t[4][SGM_NT][64];                               // [wave][tap][lane]: w * (v - mean) of the lane's pixel (first: v itself)
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int tpr = (vw + 63) >> 6;                                     // tiles per row
+	const int tpr = (vw + 63) >> 6;                                     // 64-pixel tiles per row
 	const long tile = (long)blockIdx.x * 4 + wave;
 	if (tile >= (long)tpr * vh) return;                                 // (no workgroup barrier below: each wave owns its LDS slice)
 	const int row = (int)(tile / tpr), col = (int)(tile % tpr) * 64 + lane;
 	const bool have = col < vw;
 	const long pix = (long)row * vw + (have ? col : vw - 1);
-	SGMPixel px = pixels[pix];
+	const SGMPixel px = pixels[pix];
 	const int nD = have && px.maxDisp > px.minDisp ? px.maxDisp - px.minDisp : 0;
-	// the tile's run of the volume: starts at lane 0's idx; lane l's entries follow those of lanes 0..l-1
-	int run = nD;                                                       // inclusive wave scan of nD
+	int nDmax = nD;
 #pragma unroll
-	for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(run, o, 64); if (lane >= o) run += t; }
-	const int total = __shfl(run, 63, 64);
-	const unsigned long long idx0 = ((unsigned long long)(unsigned)__shfl((int)(px.idx >> 32), 0, 64) << 32) | (unsigned)__shfl((int)(px.idx & 0xffffffffull), 0, 64);   // (lane 0 always has a pixel)
-	if (total == 0) return;
-	const int lead = (int)(idx0 & 3ull);                                // LDS offsets are congruent to volume offsets mod 4: dword copies line up
-	const int lbase = lead + run - nD;
-	const bool contiguous = __all(nD == 0 || px.idx == idx0 + (unsigned long long)(run - nD));
-	unsigned char* s_out = s_dyn + (size_t)wave * tileBytes;
-	const int nDmax = [&] { int m = nD;
-#pragma unroll
-		for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
-		return m; }();
+	for (int o = 32; o >= 1; o >>= 1) nDmax = max(nDmax, __shfl_xor(nDmax, o, 64));
+	if (nDmax == 0) return;
+	const unsigned idxLow = (unsigned)(px.idx & 3ull);
 	const int ux = (have ? col : vw - 1) + SGM_HW, uy = row + SGM_HW;
 	// left window: weights, weighted mean, t = w * (v - mean), normSq0 (:905-935, the sums in tap order)
-	float wk[SGM_NT], tk[SGM_NT];
+	float wk[SGM_NT];
 	float sumW = 0.f, normSq0 = 0.f;
 	{
 		float acc = 0.f;
@@ -216,42 +214,29 @@ __global__ __launch_bounds__(256, 2) void sgm_cost_px_kernel(const unsigned char
 		for (int n = 0; n < SGM_NT; ++n) {
 			const int i = n / 7 - SGM_HW, j = n % 7 - SGM_HW;
 			wk[n] = sgm_weight(colorL, w, ux, uy, i, j);
-			tk[n] = grayL[(size_t)(uy + i) * w + (ux + j)];
-			acc += tk[n] * wk[n]; sumW += wk[n];
+			const float v = grayL[(size_t)(uy + i) * w + (ux + j)];
+			s_t[wave][n][lane] = v;
+			acc += v * wk[n]; sumW += wk[n];
 		}
 		const float tm = acc / sumW;
 #pragma unroll
-		for (int n = 0; n < SGM_NT; ++n) { const float t = tk[n] - tm; const float tw = wk[n] * t; normSq0 += tw * t; tk[n] = tw; }
+		for (int n = 0; n < SGM_NT; ++n) { const float t = s_t[wave][n][lane] - tm; const float tw = wk[n] * t; normSq0 += tw * t; s_t[wave][n][lane] = tw; }
 	}
 	// right window for the first disparity: columns ux+d0-3 .. ux+d0+3 (clamped into the image; a clamped column only feeds costs that are 255 anyway)
 	const int d0 = px.minDisp;
-	const float* rowsR = grayR + (size_t)(uy - SGM_HW) * w;
+	const char* rowsRb = (const char*)(grayR + (size_t)(uy - SGM_HW) * w);   // (wave-uniform)
 	float win[7][7];                                                    // win[i][s]: row uy-3+i, slot s = (column offset + 3 + k) mod 7
 #pragma unroll
 	for (int s7 = 0; s7 < 7; ++s7) {
 		const int c0 = ux + d0 - SGM_HW + s7;
 		const int cc = c0 < 0 ? 0 : (c0 >= w ? w - 1 : c0);
 #pragma unroll
-		for (int i = 0; i < 7; ++i) win[i][s7] = rowsR[(size_t)i * w + cc];
+		for (int i = 0; i < 7; ++i) win[i][s7] = *(const float*)(rowsRb + (((unsigned)i * (unsigned)w + (unsigned)cc) << 2));
 	}
+	unsigned packed = 0u;
 #pragma unroll 1
 	for (int kb = 0; kb < nDmax; kb += 7) {
 		SGM_PX_STEP(0) SGM_PX_STEP(1) SGM_PX_STEP(2) SGM_PX_STEP(3) SGM_PX_STEP(4) SGM_PX_STEP(5) SGM_PX_STEP(6)
-	}
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	if (contiguous) {
-		unsigned char* out = costs + idx0;                              // out[o] <-> s_out[lead + o], o in [0, total)
-		const int head = lead ? 4 - lead : 0;                           // bytes up to the first whole dword
-		if (lane < head && lane < total) out[lane] = s_out[lead + lane];
-		const int nWords = total > head ? (total - head) >> 2 : 0;
-		const unsigned* sw = reinterpret_cast<const unsigned*>(s_out + lead + head);
-		unsigned* ow = reinterpret_cast<unsigned*>(out + head);
-		for (int o = lane; o < nWords; o += 64) ow[o] = sw[o];
-		const int done = head + 4 * nWords;
-		if (total > head && done + lane < total) out[done + lane] = s_out[lead + done + lane];
-	} else {
-		for (int k = 0; k < nD; ++k) costs[px.idx + (unsigned)k] = s_out[lbase + k];
 	}
 }
 #undef SGM_PX_STEP
@@ -467,7 +452,7 @@ __global__ __launch_bounds__(256) void sgm_uniform_check_kernel(const SGMPixel* 
 #ifndef SGM_UT
 #define SGM_UT 8         // pixels per cost prefetch sub-chunk of the uniform-range kernel
 #endif
-template <int NK, int ALIGN>   // ALIGN: 4 if nD is a multiple of 4 (every pixel's sums start on an 8-byte boundary: four of them per 64-bit atomic), 2 if it is even (a 32-bit word), else 1
+template <int NK, int ALIGN>   // ALIGN: 2 if nD is even (every pixel's sums start on a 32-bit word: idx = pixel * nD), else 1
 __global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __restrict__ grayL, int w, int vw, int vh, int nD,
 		const unsigned char* __restrict__ costs, unsigned* __restrict__ accumWords, const unsigned short* __restrict__ P2s, int P1, SGMDirs dirs) {
 	__shared__ unsigned short s_P2[256];
@@ -546,22 +531,8 @@ __global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __res
 #pragma unroll
 		for (int q = 0; q < NK; ++q) v[q] = k0 + q < nD ? (unsigned)L[q] : 0u;
 		v[NK] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[0], 0x130, 0xf, 0xf, false);   // the next lane's first entry (lane 63: none)
-		if (ALIGN == 4) {
-			// four sums per atomic: the 16-bit fields never carry into each other (a sum stays below 8 * (255 + max P2) < 65536), so one 64-bit add is
-			// four 16-bit adds.  Half as many atomic operations as with 32-bit words.
-			unsigned long long* quads = reinterpret_cast<unsigned long long*>(accumWords) + (idx >> 2);
-			if (NK == 1) {
-				const unsigned x1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[0], 0x55, 0xf, 0xf, false);   // quad_perm:[1,1,1,1]
-				const unsigned x2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[0], 0xaa, 0xf, 0xf, false);   // quad_perm:[2,2,2,2]
-				const unsigned x3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[0], 0xff, 0xf, 0xf, false);   // quad_perm:[3,3,3,3]
-				const unsigned long long val = (unsigned long long)(v[0] | (x1 << 16)) | ((unsigned long long)(x2 | (x3 << 16)) << 32);
-				if (!(lane & 3) && k0 < nD) atomicAdd(quads + (lane >> 2), val);
-			} else {
-				const unsigned mine = v[0] | (v[1] << 16);
-				const unsigned next = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xb1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]: the other lane of the pair
-				if (!(lane & 1) && k0 < nD) atomicAdd(quads + (lane >> 1), (unsigned long long)mine | ((unsigned long long)next << 32));
-			}
-		} else if (NK == 1) {
+		// (Four sums per 64-bit atomic was tried for ranges that are multiples of 4: 2.46 instead of 2.24 ms at D = 64, profiles/r03_sgm_call11.log.)
+		if (NK == 1) {
 			// par == 0: even lanes hold the low halves and add the pair; par == 1: odd lanes do, and entry 0 (the high half of the first word) adds alone
 			if (par == 0u) { if (!(lane & 1) && k0 < nD) atomicAdd(words + (lane >> 1), v[0] | (v[1] << 16)); }
 			else if (k0 < nD) { if (lane & 1) atomicAdd(words + ((lane + 1) >> 1), v[0] | (v[1] << 16)); else if (lane == 0) atomicAdd(words, v[0] << 16); }

@@ -276,6 +276,7 @@ template <class T> inline T readlane(T v, int lane, int site) { Fiber* f = cur; 
 #define WAVE_LOCKSTEP_POINT() hipemu::park(hipemu::OP_WAVE_BARRIER, __LINE__)   // the product's marker for reliance on wave lock-step (see sgm_kernels.hip)
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

@@ -70,8 +70,12 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # OPENMVS_AMD_FORCE_COLLECTIVES=1: run the collective plumbing (RCCL process group, broadcasts, all-gathers, barrier, all-reduce) with one rank too, so
+    # that a 1-GPU box can dry-run the exact calls the 8-GPU launch makes (two ranks cannot share a device under RCCL)
+    dist_on = world > 1 or os.environ.get("OPENMVS_AMD_FORCE_COLLECTIVES") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -92,7 +96,7 @@ def main():
     else:
         gray = torch.empty((V, H, W), dtype=torch.float32, device=dev)
         meta = None; gt0 = None
-    if world > 1:
+    if dist_on:
         dist.broadcast(gray, 0)                       # the single broadcast of the image set over xGMI
         box = [meta]
         dist.broadcast_object_list(box, 0)
@@ -163,7 +167,7 @@ def main():
 
     def fence():
         eng.sync(); torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     for _ in range(a.warmup):
@@ -177,7 +181,7 @@ def main():
     dt = time.perf_counter() - t0
     st = eng.stats_get()
     eng.stats_reset(False)
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -225,7 +229,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

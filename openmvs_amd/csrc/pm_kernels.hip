@@ -441,7 +441,7 @@ __device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int t
 // [2^-40, 2^40] or !sane: rare) is redone as a whole by the caller through pm_tap_row_global -- the fast rows produce exactly its sums, so redoing them
 // changes nothing.  PM_ROW_PIPELINE 0 restores the row-at-a-time loop.
 #ifndef PM_ROW_PIPELINE
-#define PM_ROW_PIPELINE 1
+#define PM_ROW_PIPELINE 0
 #endif
 struct PMRowTaps { float ptx[5], pty[5], zlo, zhi; unsigned goff[5]; };
 struct PMRowQuads { float v00[5], v01[5], v10[5], v11[5]; };
@@ -549,15 +549,20 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		PMRowTaps ta, tb; PMRowQuads qa, qb;
 		pm_row_prep(ta, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2);
 		pm_row_load(qa, ta, imgQ);
-#pragma unroll
-		for (int i = 0; i < 5; ++i) {
+		// rows (0,1), (2,3) as one loop body with the A / B register sets swapping roles (no copies), then row 4
+#pragma unroll 1
+		for (int i = 0; i < 4; i += 2) {
 			bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
-			if (i < 4) { pm_row_prep(tb, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2); pm_row_load(qb, tb, imgQ); }
-			__builtin_amdgcn_sched_barrier(0);   // keep the pipeline two rows deep: without it the scheduler hoists the loads of later rows too and spills
+			pm_row_prep(tb, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2); pm_row_load(qb, tb, imgQ);
 			pm_row_consume(ta, qa, sw, sh, sane, wts + i * 5, sum, sumSq, num, oob, redo);
-			__builtin_amdgcn_sched_barrier(0);
-			ta = tb; qa = qb;
+			bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
+			pm_row_prep(ta, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2); pm_row_load(qa, ta, imgQ);
+			pm_row_consume(tb, qb, sw, sh, sane, wts + (i + 1) * 5, sum, sumSq, num, oob, redo);
 		}
+		pm_row_consume(ta, qa, sw, sh, sane, wts + 20, sum, sumSq, num, oob, redo);
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(PM_DEBUG_REDO)
+		{ static unsigned long long c[3]; static bool reg = false; if (!reg) { reg = true; atexit([] { fprintf(stderr, "FASTG evaluations %llu, redo %llu, redo && !oob %llu\n", c[0], c[1], c[2]); }); } c[0]++; if (redo) c[1]++; if (redo && !oob) c[2]++; }
+#endif
 		if (redo && !oob) {   // a row outside the fast divisions' range: the whole patch through the guarded path (same sums where the fast rows were valid)
 			sum = 0.f; sumSq = 0.f; num = 0.f; oob = oobIn;
 			bX0 = rX0; bX1 = rX1; bX2 = rX2;

@@ -150,17 +150,28 @@ __global__ __launch_bounds__(256, 4) void sgm_cost_kernel(const unsigned char* _
 // ---- the same cost volume with one valid-grid pixel per LANE ---------------------------------------------------------------------------------------
 // sgm_cost_kernel spends, per 64 costs, 49 broadcast ds_read_b128 (the pixel's weights are wave-uniform there), 28 unaligned multi-dword loads
 // and 294 packed VALU instructions, and the three units overlap badly (probes: r02_sgm_cost_probes.log; packed fp32 multiplies and adds move no more
-// flops per cycle than plain ones on this part: r03_valu_rate.log).  Here a lane owns a pixel and walks its disparities: the 49 weights w live in
-// the lane's registers for the whole walk, the 49 products w*(v-mean) in a lane-private LDS column (conflict-free ds_read_b32, immediate offsets),
+// flops per cycle than plain ones on this part: r03_valu_rate.log).  Here a lane owns a pixel and walks its disparities: the 49 weights w and the
+// 49 products w*(v-mean) live in the lane's registers for the whole walk (or the products in a lane-private LDS column, SGM_PX_T_IN_LDS),
 // the 7x7 window of the right image slides with the disparity (7 new texels per cost; the loads of neighbouring lanes are neighbouring addresses),
 // and what remains per cost is the arithmetic the reference's summation order demands: 49 x (2 mul + 1 add, 1 mul + 1 add, 1 mul + 1 add), all
 // full-rate VOP2.  The prologue of sgm_setup_kernel (weighted mean / variance of the left window) is the same 49 weights and is done here too --
 // no setup pass, no 16-byte record.  A lane collects four costs in a register and stores them as one aligned dword of its pixel's run.
+#ifndef SGM_PX_T_IN_LDS
+#define SGM_PX_T_IN_LDS 0   // 1: the 49 products w*(v-mean) in a lane-private LDS column (167 VGPRs, 3 waves per SIMD) instead of registers (221 VGPRs, 2 waves).
+#endif                      // Measured at 2048x1536 (profiles/r03_sgm_call12.log, r03_sgm_call11_px_cost_u64.log): D = 64: 2.24 vs 2.22 ms, D = 128: 4.32 vs 3.71 ms -- the
+                            // just-in-time LDS reads put their latency on the chain of each running sum; registers win.
+#if SGM_PX_T_IN_LDS
+#define SGM_PX_T(n) s_t[wave][n][lane]
+#define SGM_PX_WAVES 3
+#else
+#define SGM_PX_T(n) tk[n]
+#define SGM_PX_WAVES 2
+#endif
 #define SGM_PX_STEP(R_)                                                                                                                          \
 	{                                                                                                                                             \
 		const int k = kb + (R_);                                                                                                                  \
 		if (k >= nDmax) break;                                                                                                                    \
-		asm volatile("" ::: "memory");   /* keep the 49 LDS reads inside the step: hoisted out of the loop they are 49 registers again */         \
+		if (SGM_PX_T_IN_LDS) asm volatile("" ::: "memory");   /* keep the 49 LDS reads inside the step: hoisted out of the loop they are 49 registers again */ \
 		const int dn = d0 + k + 1 + SGM_HW;                      /* column of the texels entering the window for disparity k+1 */              \
 		const unsigned cn = (unsigned)(ux + dn < 0 ? 0 : (ux + dn >= w ? w - 1 : ux + dn));                                                       \
 		float sum = 0.f, sumSq = 0.f, nom = 0.f;                                                                                                  \
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256, 4) void sgm_cost_kernel(const unsigned char* _
 			/* the leftmost column leaves the window with this step: its slot takes the texel of the entering column as soon as it has been read */ \
 			if (n % 7 == 0) win[n / 7][(R_)] = *(const float*)(rowsRb + (((unsigned)(n / 7) * (unsigned)w + cn) << 2));                           \
 			const float fw = f * wk[n];                                                                                                           \
-			sum += fw; sumSq += f * fw; nom += f * s_t[wave][n][lane];                                                                            \
+			sum += fw; sumSq += f * fw; nom += f * SGM_PX_T(n);                                                                                   \
 		}                                                                                                                                         \
 		const int d = d0 + k;                                                                                                                     \
 		const bool in = !(ux - SGM_HW + d < 0 || ux + SGM_HW + d >= w);                                                                           \
@@ -187,9 +198,13 @@ __global__ __launch_bounds__(256, 4) void sgm_cost_kernel(const unsigned char* _
 		}                                                                                                                                         \
 	}
 
-__global__ __launch_bounds__(256, 3) void sgm_cost_px_kernel(const unsigned char* __restrict__ colorL, const float* __restrict__ grayL,
+__global__ __launch_bounds__(256, SGM_PX_WAVES) void sgm_cost_px_kernel(const unsigned char* __restrict__ colorL, const float* __restrict__ grayL,
 		const float* __restrict__ grayR, int w, int h, int vw, int vh, const SGMPixel* __restrict__ pixels, unsigned char* __restrict__ costs) {
+#if SGM_PX_T_IN_LDS
 	__shared__ float s_t[4][SGM_NT][64];                               // [wave][tap][lane]: w * (v - mean) of the lane's pixel (first: v itself)
+#else
+	float tk[SGM_NT];
+#endif
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tpr = (vw + 63) >> 6;                                     // 64-pixel tiles per row
 	const long tile = (long)blockIdx.x * 4 + wave;
@@ -215,12 +230,12 @@ __global__ __launch_bounds__(256, 3) void sgm_cost_px_kernel(const unsigned char
 			const int i = n / 7 - SGM_HW, j = n % 7 - SGM_HW;
 			wk[n] = sgm_weight(colorL, w, ux, uy, i, j);
 			const float v = grayL[(size_t)(uy + i) * w + (ux + j)];
-			s_t[wave][n][lane] = v;
+			SGM_PX_T(n) = v;
 			acc += v * wk[n]; sumW += wk[n];
 		}
 		const float tm = acc / sumW;
 #pragma unroll
-		for (int n = 0; n < SGM_NT; ++n) { const float t = s_t[wave][n][lane] - tm; const float tw = wk[n] * t; normSq0 += tw * t; s_t[wave][n][lane] = tw; }
+		for (int n = 0; n < SGM_NT; ++n) { const float t = SGM_PX_T(n) - tm; const float tw = wk[n] * t; normSq0 += tw * t; SGM_PX_T(n) = tw; }
 	}
 	// right window for the first disparity: columns ux+d0-3 .. ux+d0+3 (clamped into the image; a clamped column only feeds costs that are 255 anyway)
 	const int d0 = px.minDisp;
@@ -240,6 +255,7 @@ __global__ __launch_bounds__(256, 3) void sgm_cost_px_kernel(const unsigned char
 	}
 }
 #undef SGM_PX_STEP
+#undef SGM_PX_T
 
 // line start sets of one path direction: nA lines from (ax,ay) stepping (adx,ady), then the rest from (bx,by)
 struct SGMLines { int nA, ax, ay, adx, ady, nB, bx, by, bdx, bdy; };

@@ -12,6 +12,8 @@ below (the HIP engine adapter in bench.py, or a CPU stand-in in tests/test_distr
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -25,7 +27,7 @@ def shard_range(n_views: int, world: int, rank: int) -> range:
 
 def all_gather_views(mine: torch.Tensor, n_views: int, world: int, rank: int) -> torch.Tensor:
     """mine: [len(shard), H, W] depth maps of this rank's block -> [n_views, H, W] on every rank."""
-    if world == 1:
+    if world == 1 and not (os.environ.get("OPENMVS_AMD_FORCE_COLLECTIVES") == "1" and dist.is_initialized()):
         return mine
     sizes = [len(shard_range(n_views, world, r)) for r in range(world)]
     if len(set(sizes)) == 1 and dist.get_backend() == "nccl":

@@ -1,6 +1,8 @@
 // The multi-device C++ host (include/DenseDepthMapsHIPMulti.hpp) against the single-engine driver on the same scene: maps of every view and the
 // fused cloud must be the same bits whichever engine estimated a view.  Runs with several engines on ONE device through LocalCopyCollective (the
 // single-GPU box; under the CPU emulator in the not-gpu suite); the RCCL policy is the same code path with ncclBroadcast in place of the copies.
+// Built with -DPMHIP_WITH_RCCL and run as `dense_multi <scene.bin> 1 <seed> rccl` the multi-device object uses RcclCollective over device 0 alone: one rank is all a
+// single-GPU box can give RCCL (two ranks may not share a device), and it runs every RCCL call of the N-device path (ncclCommInitAll, grouped ncclBroadcast).
 // Usage: dense_multi <scene.bin> <engines> [seed] [serial]        scene.bin as tests/cpp/dense_driver.cpp; serial: no host threads (the CPU emulator is single-threaded)
 #include <cstdio>
 #include <cstdlib>
@@ -35,7 +37,13 @@ int main(int argc, char** argv) {
 		if (!one.IsValid()) { fprintf(stderr, "no device\n"); return 5; }
 		one.LoadScene(views, w, h, opt); one.ComputeDepthMaps();
 		MVS::DenseDepthMapsHIP::PointCloud pc1; one.FuseDepthMaps(pc1);
+#ifdef PMHIP_WITH_RCCL
+		const bool rccl = argc > 4 && !strcmp(argv[4], "rccl");
+		if (rccl && nEng != 1) { fprintf(stderr, "rccl mode: one engine per device, this box has one\n"); return 2; }
+		MVS::DenseDepthMapsHIPMultiT<MVS::RcclCollective> multi(std::vector<int>((size_t)nEng, 0), true);
+#else
 		MVS::DenseDepthMapsHIPMultiT<MVS::LocalCopyCollective> multi(std::vector<int>((size_t)nEng, 0), argc <= 4);
+#endif
 		if (!multi.IsValid()) { fprintf(stderr, "no device\n"); return 5; }
 		multi.LoadScene(views, w, h, opt); multi.ComputeDepthMaps();
 		MVS::DenseDepthMapsHIP::PointCloud pc2; multi.FuseDepthMaps(pc2);

@@ -59,3 +59,21 @@ def test_multi_engine_host_equals_single_engine_on_the_device(tmp_path, small_sc
     inp = str(tmp_path / "scene.bin"); _write_scene(inp, small_scene)
     r = subprocess.run([exe, inp, "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-400:]
+
+
+@pytest.mark.gpu
+def test_rccl_policy_runs_on_one_device(tmp_path, small_scene):
+    """The RCCL policy of the multi-device host with the one rank a single-GPU box can give it: ncclCommInitAll, the image broadcast and the round-boundary
+    exchanges all execute (as grouped ncclBroadcast calls on the engine's stream), and the results equal the single-engine driver's."""
+    if not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("no RCCL headers")
+    from openmvs_amd import build
+    lib = build.build_lib("libpmhip.so")
+    exe = str(tmp_path / "dense_multi_rccl")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-DPMHIP_WITH_RCCL", "-D__HIP_PLATFORM_AMD__=1", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "dense_multi.cpp"), "-o", exe, lib, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
+                           "-lamdhip64", "-lrccl"])
+    inp = str(tmp_path / "scene.bin"); _write_scene(inp, small_scene)
+    r = subprocess.run([exe, inp, "1", "31", "rccl"], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
+    assert "1 engines == 1 engine" in r.stdout

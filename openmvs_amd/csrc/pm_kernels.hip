@@ -319,6 +319,9 @@ __device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t
 //   PM_PROBE_NO_FALLBACK    a tap row that fails its exactness test is not redone through global memory
 //   PM_PROBE_NO_WEIGHTS     the 25 bilateral patch weights are constants (no exp, no patch texel loads)
 //   PM_PROBE_CHEAP_TRIG     sin / cos / atan2 / acos of the hypothesis construction replaced by two-instruction stand-ins
+#ifndef PM_WIDE_MINWAVES
+#define PM_WIDE_MINWAVES 3   // waves per SIMD the one-wave-per-pixel kernel is compiled for
+#endif
 #ifndef PM_WIDE_TILES
 #define PM_WIDE_TILES 0   // one-wave-per-pixel kernel: LDS windows (1) or window-less quad-image tap rows (0; one depth map 1.08 -> 0.80 s, profiles/r03_small_batches_call7.log)
 #endif
@@ -1153,7 +1156,7 @@ __global__ __launch_bounds__(PM_BLOCK, (!PM_USE_TILES ? PM_MINWAVES : VPL >= 4 ?
 // the same bits; only evaluations whose outcome the reference would never look at are extra work.  Expected rounds = 1 + number of accepts.
 // nSrc <= 8 (one source view per lane of a group).
 template <bool GEO>
-__global__ __launch_bounds__(64, 2) void pm_sweep_wide_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
+__global__ __launch_bounds__(64, PM_WIDE_MINWAVES) void pm_sweep_wide_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	constexpr int G = 8;
 	constexpr int TC = PM_WIDE_TILES ? 1 + PM_TCX : 0;   // 0: no LDS windows, the tap rows read the quad image (as pm_sweep2_kernel)
 	constexpr int TSTRIDE = PM_TR * (TC > 0 ? TC : 1) + PM_TILE_PAD;

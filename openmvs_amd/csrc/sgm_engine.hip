@@ -20,6 +20,7 @@ struct sgmhip_engine {
 	SGMPixel* d_pixels = nullptr; unsigned char* d_costs = nullptr; unsigned short* d_accums = nullptr; float4* d_setup = nullptr;
 	short* d_disp = nullptr; unsigned short* d_cost = nullptr; unsigned short* d_P2s = nullptr;
 	bool statsOn = false; SGMHipStats stats{};
+	unsigned char* d_deltas = nullptr; size_t capDeltas = 0; int maxP2 = 65535;   // DELTA aggregation (uniform ranges, max P2 <= 255): 8 byte volumes instead of atomic u16 sums
 	bool uniform = false; int uniformMin = 0, uniformMax = 0; SGMUniform* d_uniform = nullptr;   // every pixel has [uniformMin, uniformMax) and idx = pixel * nD (checked on the device at set_problem): the register-resident path kernel applies
 	int subGroups = 0;            // 0, or the lanes per sub-group (8, 16, 32): Match with the sub-group kernels of sgm_kernels_sub.hip (narrow, ragged ranges); see sgmhip_set_sub_group_kernels
 	struct Ev { hipEvent_t a, b; int kind; }; std::vector<Ev> events;
@@ -76,7 +77,7 @@ void sgmhip_destroy(sgmhip_engine* e) {
 	if (!e) return;
 	hipSetDevice(e->device); hipStreamSynchronize(e->stream);
 	for (auto& ev : e->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
-	sgmFree(e); if (e->d_P2s) hipFree(e->d_P2s); if (e->d_uniform) hipFree(e->d_uniform);
+	sgmFree(e); if (e->d_P2s) hipFree(e->d_P2s); if (e->d_uniform) hipFree(e->d_uniform); if (e->d_deltas) hipFree(e->d_deltas);
 	hipStreamDestroy(e->stream); delete e;
 }
 const char* sgmhip_last_error(sgmhip_engine* e) { return e ? e->err.c_str() : "null engine"; }
@@ -125,6 +126,7 @@ int sgmhip_match(sgmhip_engine* e, uint16_t P1, const uint16_t P2s[256], int syn
 	if (!e || !P2s || e->numCosts == 0) return SGMHIP_E_ARG;
 	SGMCHK(e, hipSetDevice(e->device));
 	SGMCHK(e, hipMemcpyAsync(e->d_P2s, P2s, 512, hipMemcpyHostToDevice, e->stream));
+	e->maxP2 = 0; for (int i = 0; i < 256; ++i) e->maxP2 = std::max(e->maxP2, (int)P2s[i]);
 	{ const int rc = sgmMatch(e, P1); if (rc) return rc; }
 	if (sync) SGMCHK(e, hipStreamSynchronize(e->stream));
 	return 0;
@@ -205,8 +207,16 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 		hipLaunchKernelGGL(sgm_cost_kernel, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_setup, e->d_costs);
 	}
 	evE(e);
-	SGMCHK(e, hipMemsetAsync(e->d_accums, 0, (e->numCosts + 1) / 2 * 4, e->stream)); // imageAccumCosts.Memset(0), :990
 	const int NK = e->maxNumDisp <= 64 ? 1 : (e->maxNumDisp <= 128 ? 2 : 4);
+	// DELTA aggregation: uniform ranges and penalties that fit a byte; 8 scratch bytes per entry (kept between calls, grown on demand)
+	static const bool allowDelta = [] { const char* v = getenv("SGMHIP_DELTA"); return !v || atoi(v) != 0; }();   // 0: atomic u16 sums
+	bool delta = allowDelta && e->uniform && NK <= 2 && e->maxP2 <= 255;
+	if (delta && e->capDeltas < e->numCosts * 8) {
+		SGMCHK(e, hipStreamSynchronize(e->stream));
+		if (e->d_deltas) { hipFree(e->d_deltas); e->d_deltas = nullptr; e->capDeltas = 0; }
+		if (hipMalloc(&e->d_deltas, e->numCosts * 8 + 16) == hipSuccess) e->capDeltas = e->numCosts * 8; else { (void)hipGetLastError(); delta = false; }   // no room: the atomic path
+	}
+	if (!delta) SGMCHK(e, hipMemsetAsync(e->d_accums, 0, (e->numCosts + 1) / 2 * 4, e->stream)); // imageAccumCosts.Memset(0), :990
 	// the eight paths with the threaded variant's start sets, SemiGlobalMatcher.cpp:1083-1200
 	struct Dir { int dx, dy; SGMLines ln; } dirs[8] = {
 		{0, 1,   {W, 0, 0, 1, 0,      0, 0, 0, 0, 0}},            // width-down
@@ -233,9 +243,14 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 	if (total > 0) {
 		if (e->uniform && NK <= 2) {
 			const int align = e->maxNumDisp % 2 == 0 ? 2 : 1;
-#define SGM_LAUNCH_UNIFORM(NK_, AL_) hipLaunchKernelGGL((sgm_path_uniform_kernel<NK_, AL_>), dim3(total), dim3(64), 0, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->maxNumDisp, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, (int)P1, sd)
-			if (NK == 1) { if (align == 2) SGM_LAUNCH_UNIFORM(1, 2); else SGM_LAUNCH_UNIFORM(1, 1); }
-			else { if (align == 2) SGM_LAUNCH_UNIFORM(2, 2); else SGM_LAUNCH_UNIFORM(2, 1); }
+#define SGM_LAUNCH_UNIFORM(NK_, AL_, DL_) hipLaunchKernelGGL((sgm_path_uniform_kernel<NK_, AL_, DL_>), dim3(total), dim3(64), 0, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->maxNumDisp, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, (int)P1, sd, e->d_deltas, (unsigned long long)e->numCosts)
+			if (delta) {
+				if (NK == 1) { if (align == 2) SGM_LAUNCH_UNIFORM(1, 2, true); else SGM_LAUNCH_UNIFORM(1, 1, true); }
+				else { if (align == 2) SGM_LAUNCH_UNIFORM(2, 2, true); else SGM_LAUNCH_UNIFORM(2, 1, true); }
+			} else {
+				if (NK == 1) { if (align == 2) SGM_LAUNCH_UNIFORM(1, 2, false); else SGM_LAUNCH_UNIFORM(1, 1, false); }
+				else { if (align == 2) SGM_LAUNCH_UNIFORM(2, 2, false); else SGM_LAUNCH_UNIFORM(2, 1, false); }
+			}
 #undef SGM_LAUNCH_UNIFORM
 		}
 		else launchPath(e, e->stream, NK, total, (int)P1, sd);
@@ -243,7 +258,8 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 	if (e->statsOn) e->stats.aggrLaunches += 1;
 	evE(e);
 	evB(e, 2);
-	{
+	if (delta) hipLaunchKernelGGL(sgm_sum_wta_kernel, dim3((unsigned)((nPix + 15) / 16)), dim3(256), 0, e->stream, e->d_pixels, e->d_costs, e->d_deltas, (unsigned long long)e->numCosts, e->d_accums, nPix, e->d_disp, e->d_cost);
+	else {
 		// winner-take-all: a wavefront per pixel spends most of its instructions on the 6-step reduction of 64 lanes; eight pixels per
 		// wavefront with a strided loop over the range need a fraction of the wave-instructions per pixel (same first minimum; SGMHIP_WTA_LANES =
 		// 64 selects the one-pixel kernel again)
@@ -576,6 +592,7 @@ int sgmhip_tsgm_match(sgmhip_engine* e, const uint8_t* leftBGR, const uint8_t* r
 	SGMCHK(e, hipMemcpyAsync(fLG.p, leftGray, nFull * 4, hipMemcpyHostToDevice, st)); SGMCHK(e, hipMemcpyAsync(fRG.p, rightGray, nFull * 4, hipMemcpyHostToDevice, st));
 	SGMCHK(e, hipMemcpyAsync(fLM.p, leftMask, nFull, hipMemcpyHostToDevice, st)); SGMCHK(e, hipMemcpyAsync(fRM.p, rightMask, nFull, hipMemcpyHostToDevice, st));
 	SGMCHK(e, hipMemcpyAsync(e->d_P2s, P2s, 512, hipMemcpyHostToDevice, st));
+	e->maxP2 = 0; for (int i = 0; i < 256; ++i) e->maxP2 = std::max(e->maxP2, (int)P2s[i]);
 
 	int16_t* leftDisp = (int16_t*)lD.p; int16_t* rightDisp = (int16_t*)rD.p; int16_t* leftNew = (int16_t*)lDn.p; int16_t* rightNew = (int16_t*)rDn.p;
 	uint8_t* lm = (uint8_t*)lM.p; uint8_t* rm = (uint8_t*)rM.p; uint8_t* lmNext = (uint8_t*)lM2.p; uint8_t* rmNext = (uint8_t*)rM2.p;

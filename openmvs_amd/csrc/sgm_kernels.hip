@@ -282,6 +282,15 @@ __device__ __forceinline__ int sgm_wave_min(int v) {
 	return __builtin_amdgcn_readlane(v, 63);
 }
 
+// minimum over an aligned group of 16 lanes, returned in every lane of the group (quad butterflies, then mirrors inside 8 and 16 lanes)
+__device__ __forceinline__ int sgm_sub_min16(int v) {
+	v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));          // quad_perm [1,0,3,2]
+	v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));          // quad_perm [2,3,0,1]
+	v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));         // row_half_mirror
+	v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));         // row_mirror
+	return v;
+}
+
 // accums(d) += L(d) (:1020,1043).  The eight path kernels run concurrently on eight streams, so the sum is an atomic add;
 // two u16 sums share a 32-bit word (no carry between halves: a sum never exceeds 8*(255+60) = 2520).  The lane whose entry sits
 // in the low half adds its right neighbour's value in the same atomic; an entry in a high half whose low-half partner is not in
@@ -468,9 +477,15 @@ __global__ __launch_bounds__(256) void sgm_uniform_check_kernel(const SGMPixel* 
 #ifndef SGM_UT
 #define SGM_UT 8         // pixels per cost prefetch sub-chunk of the uniform-range kernel
 #endif
-template <int NK, int ALIGN>   // ALIGN: 2 if nD is even (every pixel's sums start on a 32-bit word: idx = pixel * nD), else 1
+//
+// DELTA: no atomics at all.  L(d) = C(d) + (best - min Lp) and 0 <= best - min Lp <= P2, so a direction only has to record that one byte per entry, in its own
+// volume (deltas + dir * numCosts), with plain coalesced stores; sgm_sum_wta_kernel then forms sum_r L_r(d) = 8 C(d) + sum_r delta_r(d), writes the u16 sums the
+// reference keeps (imageAccumCosts) and takes the winner in the same pass.  The sums are the same integers in any order.  Needs max P2 <= 255 (host check) and
+// 8 bytes per entry of scratch; replaces 3.2 GB of 16-bit atomic payload (the limiter of the atomic version) by 1.6 GB of byte stores.
+template <int NK, int ALIGN, bool DELTA>   // ALIGN: 2 if nD is even (every pixel's sums start on a 32-bit word: idx = pixel * nD), else 1
 __global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __restrict__ grayL, int w, int vw, int vh, int nD,
-		const unsigned char* __restrict__ costs, unsigned* __restrict__ accumWords, const unsigned short* __restrict__ P2s, int P1, SGMDirs dirs) {
+		const unsigned char* __restrict__ costs, unsigned* __restrict__ accumWords, const unsigned short* __restrict__ P2s, int P1, SGMDirs dirs,
+		unsigned char* __restrict__ deltas, unsigned long long numCosts) {
 	__shared__ unsigned short s_P2[256];
 	const int lane = threadIdx.x;
 	int dir = 0;
@@ -519,10 +534,10 @@ __global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __res
 	auto step = [&](int i, int P2, const unsigned char* c8) {
 		if (i >= n) return;
 		const long long idx = idx0 + (long long)i * dIdx;
-		int Ln[NK];
+		int Ln[NK], dl[NK];
 		if (i == 0) {                                                   // no previous pixel: L = C + P2 (:1012-1021)
 #pragma unroll
-			for (int q = 0; q < NK; ++q) Ln[q] = (int)c8[q] + P2;
+			for (int q = 0; q < NK; ++q) { Ln[q] = (int)c8[q] + P2; dl[q] = P2; }
 		} else {
 			int m = L[0];
 #pragma unroll
@@ -535,11 +550,21 @@ __global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __res
 			for (int q = 0; q < NK; ++q) {
 				const int am = q == 0 ? fromLeft : L[q - 1], ap = q == NK - 1 ? fromRight : L[q + 1];
 				const int best = min(min(mP2, L[q]), min(am, ap) + P1);
-				Ln[q] = (int)c8[q] + best - m;
+				dl[q] = best - m;
+				Ln[q] = (int)c8[q] + dl[q];
 			}
 		}
 #pragma unroll
 		for (int q = 0; q < NK; ++q) L[q] = k0 + q < nD ? Ln[q] : SGM_INF;
+		if (DELTA) {
+			unsigned char* out = deltas + (unsigned long long)dir * numCosts + idx;
+			if (NK == 2 && ALIGN == 2) { if (k0 + 1 < nD) *reinterpret_cast<unsigned short*>(out + k0) = (unsigned short)(dl[0] | (dl[1] << 8)); else if (k0 < nD) out[k0] = (unsigned char)dl[0]; }
+			else {
+#pragma unroll
+				for (int q = 0; q < NK; ++q) if (k0 + q < nD) out[k0 + q] = (unsigned char)dl[q];
+			}
+			return;
+		}
 		// accums(d) += L(d): as sgm_accumulate, with the pair of a word taken from this lane's registers where it can be
 		unsigned* words = accumWords + (idx >> 1);
 		const unsigned par = ALIGN >= 2 ? 0u : (unsigned)(idx & 1ll);
@@ -583,6 +608,49 @@ __global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __res
 #pragma unroll
 			for (int t = 0; t < SGM_UT; ++t) step(i0 + s + SGM_UT + t, __builtin_amdgcn_readlane(P2v, s + SGM_UT + t), cB[t]);
 		}
+	}
+}
+
+// ---- sums and winner of the DELTA aggregation: accums(d) = 8 C(d) + sum over the 8 directions of delta_r(d); first minimum (:1272-1301) -----------------
+// 16 lanes per pixel, four entries per lane and trip (one dword of the cost volume and of each delta volume where the pixel's run is dword-aligned), four pixels per wave.
+__global__ __launch_bounds__(256) void sgm_sum_wta_kernel(const SGMPixel* __restrict__ pixels, const unsigned char* __restrict__ costs, const unsigned char* __restrict__ deltas,
+		unsigned long long numCosts, unsigned short* __restrict__ accums, long nPix, short* __restrict__ disp, unsigned short* __restrict__ cost) {
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane >> 4, kk = lane & 15;
+	const long pix = ((long)blockIdx.x * 4 + wave) * 4 + sub;
+	SGMPixel px; px.idx = 0; px.minDisp = 0; px.maxDisp = 0; px.pad = 0;
+	const bool have = pix < nPix;
+	if (have) px = pixels[pix];
+	const int nD = px.maxDisp - px.minDisp;
+	unsigned key = 0xFFFFFFFFu;
+	const bool aligned = (px.idx & 3ull) == 0ull;
+	for (int k = kk * 4; k < nD; k += 64) {
+		unsigned s[4];
+		const int n = min(4, nD - k);
+		if (aligned && n == 4) {
+			const unsigned c = *reinterpret_cast<const unsigned*>(costs + px.idx + k);
+#pragma unroll
+			for (int b = 0; b < 4; ++b) s[b] = ((c >> (8 * b)) & 255u) * 8u;
+#pragma unroll
+			for (int r = 0; r < 8; ++r) {
+				const unsigned dv = *reinterpret_cast<const unsigned*>(deltas + (unsigned long long)r * numCosts + px.idx + k);
+#pragma unroll
+				for (int b = 0; b < 4; ++b) s[b] += (dv >> (8 * b)) & 255u;
+			}
+			uint2 o; o.x = s[0] | (s[1] << 16); o.y = s[2] | (s[3] << 16);
+			*reinterpret_cast<uint2*>(accums + px.idx + k) = o;          // (idx + k) % 4 == 0: 8-byte aligned
+		} else {
+			for (int b = 0; b < n; ++b) {
+				unsigned v = (unsigned)costs[px.idx + k + b] * 8u;
+				for (int r = 0; r < 8; ++r) v += deltas[(unsigned long long)r * numCosts + px.idx + k + b];
+				s[b] = v; accums[px.idx + k + b] = (unsigned short)v;
+			}
+		}
+		for (int b = 0; b < n; ++b) key = min(key, (s[b] << 16) | (unsigned)(k + b));
+	}
+	key = (unsigned)sgm_sub_min16((int)(key ^ 0x80000000u)) ^ 0x80000000u;
+	if (have && kk == 0) {
+		if (nD <= 0) { disp[pix] = px.minDisp; cost[pix] = 0xFFFF; }
+		else { disp[pix] = (short)(px.minDisp + (int)(key & 0xFFFFu)); cost[pix] = (unsigned short)(key >> 16); }
 	}
 }
 

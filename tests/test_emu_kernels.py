@@ -127,6 +127,7 @@ def test_sgm_match(matcher):
     for args in ((96, 64, -8, 56), (150, 90, 0, 33), (90, 160, -3, 100), (214, 77, 0, 127), (71, 12, 0, 1), (12, 140, -1, 1)):
         g.test_uniform_range_path_kernel(matcher, *args)                      # register-resident path kernel: full / odd / two entries per lane
     g.test_uniform_premise_is_checked(matcher)
+    g.test_uniform_ranges_with_penalties_above_a_byte(matcher)
     g.test_pixel_table_with_entries_out_of_pixel_order(matcher)
     g.test_tiny_and_degenerate(matcher)
     g.test_sub_group_widths(matcher, 8); g.test_sub_group_widths(matcher, 32)

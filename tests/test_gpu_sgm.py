@@ -56,6 +56,21 @@ def test_uniform_range_path_kernel(matcher, w, h, dmin, dmax):
     _check(matcher, lb, lg, rg, px, n, mx)
 
 
+def test_uniform_ranges_with_penalties_above_a_byte(matcher):
+    """The atomic-free aggregation records best - min Lp <= P2 in a byte per direction; a penalty table with entries above 255 must take the u16 atomic sums instead
+    (same integers as the oracle either way)."""
+    w, h = 120, 70
+    lb, lg, rg = sc.stereo_pair(w, h, 5, seed=77)
+    px, n, mx = sc.ranges(w, h, "uniform", -2, 46)
+    saved = matcher.P2s.copy()
+    try:
+        matcher.P2s = np.minimum(saved.astype(np.int64) * 40 + 200, 3000).astype(np.uint16)
+        assert int(matcher.P2s.max()) > 255
+        _check(matcher, lb, lg, rg, px, n, mx)
+    finally:
+        matcher.P2s = saved
+
+
 def test_uniform_premise_is_checked(matcher):
     """One pixel with a different range, or with an idx that is not pixel * nD, sends the problem to the general path kernel: same results as the oracle."""
     w, h = 110, 80

@@ -17,6 +17,14 @@
 #include "pm_math.h"
 
 struct SGMPixel { unsigned long long idx; short minDisp, maxDisp; int pad; }; // == SGMHipPixelData
+// a pointer rebuilt from an integer is "generic" to the compiler (flat_load, two counters); these say it is HBM (global_load, scalar base + lane offset)
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+typedef const unsigned char __attribute__((address_space(1)))* sgm_gcb;
+typedef const unsigned short __attribute__((address_space(1)))* sgm_gcs;
+#else
+typedef const unsigned char* sgm_gcb;
+typedef const unsigned short* sgm_gcs;
+#endif
 #define SGM_HW 3
 #define SGM_NT 49
 #ifndef SGM_T
@@ -482,11 +490,17 @@ __global__ __launch_bounds__(256) void sgm_uniform_check_kernel(const SGMPixel* 
 // volume (deltas + dir * numCosts), with plain coalesced stores; sgm_sum_wta_kernel then forms sum_r L_r(d) = 8 C(d) + sum_r delta_r(d), writes the u16 sums the
 // reference keeps (imageAccumCosts) and takes the winner in the same pass.  The sums are the same integers in any order.  Needs max P2 <= 255 (host check) and
 // 8 bytes per entry of scratch; replaces 3.2 GB of 16-bit atomic payload (the limiter of the atomic version) by 1.6 GB of byte stores.
-template <int NK, int ALIGN, bool DELTA>   // ALIGN: 2 if nD is even (every pixel's sums start on a 32-bit word: idx = pixel * nD), else 1
+// STAGE (DELTA, nD a multiple of 16): the delta bytes of 32 consecutive pixels of the line are collected in LDS and written out as 16-byte pieces -- two store
+// instructions per lane and 32 steps instead of one byte store per step.  With a store in flight in every step each use of a prefetched cost byte had to wait for
+// *everything* outstanding (loads and stores share vmcnt and complete out of order with respect to each other, so the compiler waits for zero): the step was as long
+// as a store round trip.
+#define SGM_OC 32
+template <int NK, int ALIGN, bool DELTA, bool STAGE = false>   // ALIGN: 2 if nD is even (every pixel's sums start on a 32-bit word: idx = pixel * nD), else 1
 __global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __restrict__ grayL, int w, int vw, int vh, int nD,
 		const unsigned char* __restrict__ costs, unsigned* __restrict__ accumWords, const unsigned short* __restrict__ P2s, int P1, SGMDirs dirs,
 		unsigned char* __restrict__ deltas, unsigned long long numCosts) {
 	__shared__ unsigned short s_P2[256];
+	__shared__ __attribute__((aligned(16))) unsigned char s_out[STAGE ? SGM_OC * 64 * NK : 16];
 	const int lane = threadIdx.x;
 	int dir = 0;
 #pragma unroll
@@ -500,7 +514,7 @@ __global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __res
 	for (int k = lane; k < 256; k += 64) s_P2[k] = P2s[k];
 	__syncthreads();
 	if (x < 0 || y < 0 || x >= vw || y >= vh) return;
-	// pixels on the line
+	// pixels on the line (UNIFORM_KERNEL_BODY)
 	int n = 0x7fffffff;
 	if (dx > 0) n = min(n, vw - x); else if (dx < 0) n = min(n, x + 1);
 	if (dy > 0) n = min(n, vh - y); else if (dy < 0) n = min(n, y + 1);
@@ -514,18 +528,28 @@ __global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __res
 	};
 	// cost bytes of pixels i0 .. i0+SGM_UT-1 of the line.  Lanes past the range read the bytes that follow (the next pixel's costs; the volume is
 	// allocated with 256 spare bytes) and never use them, which keeps the loads free of per-lane predicates.
+	// The address of a pixel's costs is wave-uniform: it is kept in a scalar register pair that steps along the line (pinned there: left to itself the compiler
+	// folds the per-pixel offsets into 64-bit VGPR pairs, one pair per prefetched pixel -- 154 VGPRs, 3 waves per SIMD instead of 8).
 	auto costLoad = [&](int i0, unsigned char (*c8)[NK]) {
-		const unsigned char* base = costs + (idx0 + (long long)i0 * dIdx);
-		if (i0 + SGM_UT <= n) {                                         // (uniform) all of them on the line: one pointer stepped along it
+		unsigned long long base = (unsigned long long)costs + (unsigned long long)(idx0 + (long long)i0 * dIdx);
+		const bool all = i0 + SGM_UT <= n;                              // (uniform) all of them on the line
 #pragma unroll
-			for (int t = 0; t < SGM_UT; ++t, base += dIdx)
+		for (int t = 0; t < SGM_UT; ++t) {
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+			asm volatile("" : "+s"(base));
+#endif
+			const sgm_gcb bp = (sgm_gcb)base;
+			if (all || i0 + t < n) {
+				if (NK == 2 && ALIGN == 2) { const unsigned short v = ((sgm_gcs)base)[(unsigned)lane]; c8[t][0] = (unsigned char)(v & 255); c8[t][NK - 1] = (unsigned char)(v >> 8); }
+				else {
 #pragma unroll
-				for (int q = 0; q < NK; ++q) c8[t][q] = base[(unsigned)(k0 + q)];
-		} else {
+					for (int q = 0; q < NK; ++q) c8[t][q] = bp[(unsigned)(k0 + q)];
+				}
+			} else {
 #pragma unroll
-			for (int t = 0; t < SGM_UT; ++t, base += dIdx)
-#pragma unroll
-				for (int q = 0; q < NK; ++q) { c8[t][q] = 0; if (i0 + t < n) c8[t][q] = base[(unsigned)(k0 + q)]; }
+				for (int q = 0; q < NK; ++q) c8[t][q] = 0;
+			}
+			base += (unsigned long long)dIdx;
 		}
 	};
 	int L[NK];
@@ -556,9 +580,15 @@ __global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __res
 		}
 #pragma unroll
 		for (int q = 0; q < NK; ++q) L[q] = k0 + q < nD ? Ln[q] : SGM_INF;
+		if (DELTA && STAGE) {
+			unsigned char* row = s_out + (i & (SGM_OC - 1)) * (64 * NK) + k0;   // every lane writes; bytes past nD are never flushed
+			if (NK == 2) *reinterpret_cast<unsigned short*>(row) = (unsigned short)((dl[0] & 255) | (dl[NK - 1] << 8));
+			else row[0] = (unsigned char)dl[0];
+			return;
+		}
 		if (DELTA) {
 			unsigned char* out = deltas + (unsigned long long)dir * numCosts + idx;
-			if (NK == 2 && ALIGN == 2) { if (k0 + 1 < nD) *reinterpret_cast<unsigned short*>(out + k0) = (unsigned short)(dl[0] | (dl[1] << 8)); else if (k0 < nD) out[k0] = (unsigned char)dl[0]; }
+			if (NK == 2 && ALIGN == 2) { if (k0 + 1 < nD) *reinterpret_cast<unsigned short*>(out + k0) = (unsigned short)(dl[0] | (dl[NK - 1] << 8)); else if (k0 < nD) out[k0] = (unsigned char)dl[0]; }
 			else {
 #pragma unroll
 				for (int q = 0; q < NK; ++q) if (k0 + q < nD) out[k0 + q] = (unsigned char)dl[q];
@@ -587,6 +617,20 @@ __global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __res
 			}
 		}
 	};
+	// staged delta bytes of pixels first .. first+count-1 of the line (count <= SGM_OC) -> their volume, 16 bytes per lane and trip
+	auto flush = [&](int first, int count) {
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		const int pp = nD >> 4;                                         // 16-byte pieces per pixel
+		unsigned char* vol = deltas + (unsigned long long)dir * numCosts;
+		for (int p = lane; p < count * pp; p += 64) {
+			const int r = p / pp, part = p - r * pp;
+			const float4 v = *reinterpret_cast<const float4*>(s_out + ((first + r) & (SGM_OC - 1)) * (64 * NK) + part * 16);
+			*reinterpret_cast<float4*>(vol + (idx0 + (long long)(first + r) * dIdx) + part * 16) = v;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	};
 	float g = grayLoad(0), gNext = grayLoad(64);
 	float carry = 0.5f;                                               // Ip before the first pixel (:1066)
 	unsigned char cA[SGM_UT][NK], cB[SGM_UT][NK];
@@ -607,6 +651,10 @@ __global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __res
 			costLoad(i0 + s + 2 * SGM_UT, cA);
 #pragma unroll
 			for (int t = 0; t < SGM_UT; ++t) step(i0 + s + SGM_UT + t, __builtin_amdgcn_readlane(P2v, s + SGM_UT + t), cB[t]);
+			if (DELTA && STAGE) {
+				const int done = min(n, i0 + s + 2 * SGM_UT);                 // pixels of the line finished so far
+				if ((done & (SGM_OC - 1)) == 0 || done == n) { const int first = (done - 1) & ~(SGM_OC - 1); flush(first, done - first); }
+			}
 		}
 	}
 }

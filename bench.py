@@ -351,10 +351,14 @@ def sgm_leg(device):
         gb = 43.0 * n / 1e9
         res["D%d" % D] = {"ms_per_match": round(dt * 1e3, 3), "cost_ms": round(s.costMs / reps, 3), "aggregation_ms": round(s.aggrMs / reps, 3),
                           "wta_ms": round(s.wtaMs / reps, 3), "num_costs": int(n), "achieved_gbs": round(gb / dt, 1), "frac_of_hbm_peak": round(gb / dt / HBM_PEAK_GBS, 4),
-                          "aggregation_gbs": round(40.0 * n / 1e9 / (s.aggrMs / reps / 1e3), 1)}
+                          "aggregation_gbs": round(40.0 * n / 1e9 / (s.aggrMs / reps / 1e3), 1),
+                          # what the shipped kernels move per cost entry for uniform ranges (atomic-free aggregation): 1 cost write; 8 x (1 cost read + 1 delta
+                          # write) in the path kernel; 8 delta + 1 cost read and 2 sum write in the sum / winner pass = 28 B
+                          "moved_gbs": round(28.0 * n / 1e9 / dt, 1)}
     m.close() if hasattr(m, "close") else None
     return {"workload": "SemiGlobalMatcher::Match, 2048x1536, 8 calls (1 reference x 4 sources, both directions) per range; 43 B per cost entry "
-                        "(1 cost write + 8 x (1 + 2 + 2) path traffic + 2 WTA read, SURVEY 8(d))", "peak_gbs": HBM_PEAK_GBS, **res}
+                        "(1 cost write + 8 x (1 + 2 + 2) path traffic + 2 WTA read, SURVEY 8(d)): achieved_gbs / aggregation_gbs are the reference algorithm's bytes over "
+                        "our time; moved_gbs is what the atomic-free kernels actually move (28 B per entry); wta_ms includes forming the u16 sums", "peak_gbs": HBM_PEAK_GBS, **res}
 
 
 def native_oracle():

@@ -101,7 +101,7 @@ int sgmhip_set_problem(sgmhip_engine* e, const uint8_t* leftBGR, const float* le
 	// one range for all pixels?  (then Match aggregates with sgm_path_uniform_kernel)
 	static const bool allowUniform = [] { const char* v = getenv("SGMHIP_UNIFORM"); return !v || atoi(v) != 0; }();
 	SGMUniform hu = {1, 0, 0, 0};
-	if (allowUniform && maxNumDisp <= 128) {
+	if (allowUniform) {
 		if (!e->d_uniform) SGMCHK(e, hipMalloc(&e->d_uniform, sizeof(SGMUniform)));
 		SGMCHK(e, hipMemcpyAsync(e->d_uniform, &hu, sizeof(hu), hipMemcpyHostToDevice, e->stream));
 		hipLaunchKernelGGL(sgm_uniform_check_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, e->stream, e->d_pixels, (long)nPix, e->d_uniform);
@@ -140,9 +140,16 @@ static int sgmMatchSubT(sgmhip_engine* e, uint16_t P1) {
 	const long nPix = (long)e->vw * e->vh;
 	const int W = e->vw, H = e->vh;
 	evB(e, 0);
-	hipLaunchKernelGGL(sgm_setup_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->w, W, H, e->d_pixels, e->d_setup);
-	const long nPairs = (long)((W + 1) / 2) * H;
-	hipLaunchKernelGGL((sgm_cost_sub_kernel<LP>), dim3((unsigned)((nPairs + 4 * PW - 1) / (4 * PW))), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_setup, e->d_costs);
+	// cost volume: the lane-per-pixel kernel serves narrow ranges too (0.9 against 1.28 ms for 3-12 disparities per pixel at 2048x1536); SGMHIP_COST_PX=0: the sub-group kernel
+	static const bool pxCost = [] { const char* v = getenv("SGMHIP_COST_PX"); return !v || atoi(v) != 0; }();
+	if (pxCost) {
+		const long nTiles = (long)((W + 63) / 64) * H;
+		hipLaunchKernelGGL(sgm_cost_px_kernel, dim3((unsigned)((nTiles + 3) / 4)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_costs);
+	} else {
+		hipLaunchKernelGGL(sgm_setup_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->w, W, H, e->d_pixels, e->d_setup);
+		const long nPairs = (long)((W + 1) / 2) * H;
+		hipLaunchKernelGGL((sgm_cost_sub_kernel<LP>), dim3((unsigned)((nPairs + 4 * PW - 1) / (4 * PW))), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_setup, e->d_costs);
+	}
 	evE(e);
 	SGMCHK(e, hipMemsetAsync(e->d_accums, 0, (e->numCosts + 1) / 2 * 4, e->stream));
 	struct Dir { int dx, dy; SGMLines ln; } dirs[8] = {
@@ -196,11 +203,16 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 	const int W = e->vw, H = e->vh;
 	evB(e, 0);
 	static const bool pxCost = [] { const char* v = getenv("SGMHIP_COST_PX"); return !v || atoi(v) != 0; }();   // 0: the wave-per-pixel-pair cost kernel
+	static const bool uniCost = [] { const char* v = getenv("SGMHIP_COST_UNI"); return !v || atoi(v) != 0; }();   // 0: the sliding-window kernel for uniform ranges too
 	if (pxCost) {
-		// one pixel per lane, 64-pixel tiles of a row per wave (sgm_cost_px_kernel; does the left-window prologue itself)
+		// one pixel per lane, 64-pixel tiles of a row per wave (does the left-window prologue itself); with one range for all pixels the right-image strip of a tile sits in LDS
 		const long nTiles = (long)((W + 63) / 64) * H;
 		const dim3 g((unsigned)((nTiles + 3) / 4));
-		hipLaunchKernelGGL(sgm_cost_px_kernel, g, dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_costs);
+		if (e->uniform && uniCost) {
+#define SGM_LAUNCH_UNI(MD_) hipLaunchKernelGGL((sgm_cost_uni_kernel<MD_>), g, dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->uniformMin, e->maxNumDisp, e->d_costs)
+			if (e->maxNumDisp <= 64) SGM_LAUNCH_UNI(64); else if (e->maxNumDisp <= 128) SGM_LAUNCH_UNI(128); else SGM_LAUNCH_UNI(256);
+#undef SGM_LAUNCH_UNI
+		} else hipLaunchKernelGGL(sgm_cost_px_kernel, g, dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_costs);
 	} else {
 		hipLaunchKernelGGL(sgm_setup_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->w, W, H, e->d_pixels, e->d_setup);
 		const long nPairs = (long)((W + 1) / 2) * H;

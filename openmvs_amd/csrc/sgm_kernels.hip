@@ -265,6 +265,80 @@ __global__ __launch_bounds__(256, SGM_PX_WAVES) void sgm_cost_px_kernel(const un
 #undef SGM_PX_STEP
 #undef SGM_PX_T
 
+// ---- the lane-per-pixel cost kernel when every pixel has the same range (a plain Match, the first tSGM level) -------------------------------------------
+// Lane l of a wave owns pixel x0 + l of a row and all lanes are at the same disparity, so tap (i, j) of lane l at disparity index k is column
+// l + k + j + 3 of a strip of 64 + nD + 6 right-image columns that the whole wave shares: the strip (7 rows) is loaded into LDS once, and the sliding window
+// of sgm_cost_px_kernel -- 49 registers per lane and 7 global loads per cost -- becomes 49 conflict-free ds_read_b32 per cost (consecutive lanes, consecutive
+// addresses; ~20 % of the LDS rate next to 300 VALU instructions).  ~125 VGPRs: 3 waves per SIMD instead of 2, and no vector memory traffic in the walk but
+// the packed cost stores.  Same arithmetic, same order.
+template <int MD>   // nD <= MD: sizes the strip
+__global__ __launch_bounds__(256, 3) void sgm_cost_uni_kernel(const unsigned char* __restrict__ colorL, const float* __restrict__ grayL,
+		const float* __restrict__ grayR, int w, int h, int vw, int vh, int minDisp, int nDall, unsigned char* __restrict__ costs) {
+	constexpr int PITCH = 64 + MD + 8;
+	__shared__ float s_r[4][7][PITCH];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int tpr = (vw + 63) >> 6;                                     // 64-pixel tiles per row
+	const long tile = (long)blockIdx.x * 4 + wave;
+	if (tile >= (long)tpr * vh) return;                                 // (no workgroup barrier below: each wave owns its LDS slice)
+	const int row = (int)(tile / tpr), col0 = (int)(tile % tpr) * 64, col = col0 + lane;
+	const bool have = col < vw;
+	const int nD = have ? nDall : 0;
+	const unsigned long long idx = (unsigned long long)((long)row * vw + (have ? col : vw - 1)) * (unsigned long long)nDall;   // PixelData::idx of a uniform table
+	const unsigned idxLow = (unsigned)(idx & 3ull);
+	const int ux = (have ? col : vw - 1) + SGM_HW, uy = row + SGM_HW;
+	// the strip: columns cb .. cb + 64 + nD + 5 of rows uy-3 .. uy+3 (clamped into the image; a clamped column only feeds costs that are 255 anyway)
+	const int cb = col0 + SGM_HW + minDisp - SGM_HW;
+	for (int c = lane; c < 64 + nDall + 6; c += 64) {
+		const int cc = cb + c < 0 ? 0 : (cb + c >= w ? w - 1 : cb + c);
+#pragma unroll
+		for (int i = 0; i < 7; ++i) s_r[wave][i][c] = grayR[(size_t)(uy - SGM_HW + i) * w + cc];
+	}
+	// left window: weights, weighted mean, t = w * (v - mean), normSq0 (:905-935, the sums in tap order)
+	float wk[SGM_NT], tk[SGM_NT];
+	float sumW = 0.f, normSq0 = 0.f;
+	{
+		float acc = 0.f;
+#pragma unroll
+		for (int n = 0; n < SGM_NT; ++n) {
+			const int i = n / 7 - SGM_HW, j = n % 7 - SGM_HW;
+			wk[n] = sgm_weight(colorL, w, ux, uy, i, j);
+			tk[n] = grayL[(size_t)(uy + i) * w + (ux + j)];
+			acc += tk[n] * wk[n]; sumW += wk[n];
+		}
+		const float tm = acc / sumW;
+#pragma unroll
+		for (int n = 0; n < SGM_NT; ++n) { const float t = tk[n] - tm; const float tw = wk[n] * t; normSq0 += tw * t; tk[n] = tw; }
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	unsigned packed = 0u;
+	const float* strip = &s_r[wave][0][have ? lane : vw - 1 - col0];   // a lane without a pixel repeats the row's last one
+#pragma unroll 1
+	for (int k = 0; k < nDall; ++k) {
+		float sum = 0.f, sumSq = 0.f, nom = 0.f;
+#pragma unroll
+		for (int n = 0; n < SGM_NT; ++n) {
+			const float f = strip[(n / 7) * PITCH + k + n % 7];
+			const float fw = f * wk[n];
+			sum += fw; sumSq += f * fw; nom += f * tk[n];
+		}
+		const int d = minDisp + k;
+		const bool in = !(ux - SGM_HW + d < 0 || ux + SGM_HW + d >= w);
+		const unsigned c = in ? (unsigned)sgm_cost_of(sum, sumSq, nom, sumW, normSq0) : 255u;
+		if (k < nD) {
+			const unsigned pos = (idxLow + (unsigned)k) & 3u;               // byte of its dword in the volume
+			packed |= c << (8u * pos);
+			if (pos == 3u || k == nD - 1) {
+				unsigned char* at = costs + idx + (unsigned)k;              // address of this (the last collected) byte
+				const unsigned first = (unsigned)k < pos ? pos - (unsigned)k : 0u;   // first byte of the dword that belongs to this pixel
+				if (pos == 3u && first == 0u) *reinterpret_cast<unsigned*>(at - 3) = packed;
+				else for (unsigned bb = first; bb <= pos; ++bb) at[(int)bb - (int)pos] = (unsigned char)(packed >> (8u * bb));
+				packed = 0u;
+			}
+		}
+	}
+}
+
 // line start sets of one path direction: nA lines from (ax,ay) stepping (adx,ady), then the rest from (bx,by)
 struct SGMLines { int nA, ax, ay, adx, ady, nB, bx, by, bdx, bdy; };
 

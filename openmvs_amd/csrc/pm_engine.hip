@@ -27,7 +27,7 @@
 #define PMHIP_DEFAULT_LANES 0    // sweep kernels: lanes per pixel; 0 = by batch size (one view per lane for small batches, four lanes and two views per lane
                                  // from PMHIP_LANES4_FROM reference views on: measured 41.2 vs 39.7 Mpix/s at 100 views, 11.5 vs 16.6 at 13, profiles/r03_variants_call6_sweep2.log)
 #ifndef PMHIP_LANES4_FROM
-#define PMHIP_LANES4_FROM 48
+#define PMHIP_LANES4_FROM 80     // measured (profiles/r03_variants_call21_mid_batches.log): one view per lane wins up to 70 reference views (25: 28.2 vs 21.2, 50: 36.8 vs 33.3, 70: 38.9 vs 38.2 Mpix/s), two per lane at 100 (42.9 vs 41.5)
 #endif
 #endif
 #ifndef PMHIP_DEFAULT_GROUPS

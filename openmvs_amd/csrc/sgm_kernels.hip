@@ -274,8 +274,10 @@ __global__ __launch_bounds__(256, SGM_PX_WAVES) void sgm_cost_px_kernel(const un
 template <int MD>   // nD <= MD: sizes the strip
 __global__ __launch_bounds__(256, 3) void sgm_cost_uni_kernel(const unsigned char* __restrict__ colorL, const float* __restrict__ grayL,
 		const float* __restrict__ grayR, int w, int h, int vw, int vh, int minDisp, int nDall, unsigned char* __restrict__ costs) {
-	constexpr int PITCH = 64 + MD + 8;
-	__shared__ float s_r[4][7][PITCH];
+	// column-major with 9 floats per column: every tap of a lane is within 60 dwords of one address register (ds_read2_b32 immediates; row-major needs a
+	// register per row), and consecutive lanes are 9 dwords apart -- coprime with the 64 banks, so a read is conflict-free
+	constexpr int NCOL = 64 + MD + 8, CS = 9;
+	__shared__ float s_r[4][NCOL * CS];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tpr = (vw + 63) >> 6;                                     // 64-pixel tiles per row
 	const long tile = (long)blockIdx.x * 4 + wave;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256, 3) void sgm_cost_uni_kernel(const unsigned cha
 	for (int c = lane; c < 64 + nDall + 6; c += 64) {
 		const int cc = cb + c < 0 ? 0 : (cb + c >= w ? w - 1 : cb + c);
 #pragma unroll
-		for (int i = 0; i < 7; ++i) s_r[wave][i][c] = grayR[(size_t)(uy - SGM_HW + i) * w + cc];
+		for (int i = 0; i < 7; ++i) s_r[wave][c * CS + i] = grayR[(size_t)(uy - SGM_HW + i) * w + cc];
 	}
 	// left window: weights, weighted mean, t = w * (v - mean), normSq0 (:905-935, the sums in tap order)
 	float wk[SGM_NT], tk[SGM_NT];
@@ -312,13 +314,13 @@ __global__ __launch_bounds__(256, 3) void sgm_cost_uni_kernel(const unsigned cha
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	unsigned packed = 0u;
-	const float* strip = &s_r[wave][0][have ? lane : vw - 1 - col0];   // a lane without a pixel repeats the row's last one
+	const float* strip = &s_r[wave][(have ? lane : vw - 1 - col0) * CS];   // a lane without a pixel repeats the row's last one
 #pragma unroll 1
 	for (int k = 0; k < nDall; ++k) {
 		float sum = 0.f, sumSq = 0.f, nom = 0.f;
 #pragma unroll
 		for (int n = 0; n < SGM_NT; ++n) {
-			const float f = strip[(n / 7) * PITCH + k + n % 7];
+			const float f = strip[(k + n % 7) * CS + n / 7];
 			const float fw = f * wk[n];
 			sum += fw; sumSq += f * fw; nom += f * tk[n];
 		}

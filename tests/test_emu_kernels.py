@@ -73,7 +73,7 @@ def test_estimator_views_per_lane(pm_emulated, nine_scene, small_scene, lanes):
     g.test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes)    # (4,2), (2,4), (2,2), (4,4): several source views per lane
 
 
-@pytest.mark.parametrize("variant", ["band_chunks", "legacy_windows", "band_lanes4"])
+@pytest.mark.parametrize("variant", ["band_chunks", "legacy_windows"])   # (band_lanes4, band and diag2 run on the device only: -m gpu)
 def test_estimator_sweep_kernel_variants(pm_emulated, nine_scene, small_scene, variant):
     from tests import test_gpu_patchmatch as g
     g.test_sweep_kernel_variants_parity(nine_scene, small_scene, variant, quick=True)
@@ -86,7 +86,7 @@ def test_estimator_wide_latency_mode(pm_emulated, nine_scene, small_scene):
 
 def test_estimator_mixed_resolution_neighbours_wide_kernel(pm_emulated):
     from tests import test_gpu_patchmatch as g
-    g.test_mixed_resolution_neighbours_parity_both_kernels("16")
+    g.test_mixed_resolution_neighbours_parity_both_kernels("16", 80, 60)     # (quarter of the pixels of the device case: the regular-kernel run below has the full size)
 
 
 def test_estimator_mixed_resolution_neighbours(engine):

@@ -677,7 +677,7 @@ def test_real_scene_from_mvs_archive_matches_oracle_and_sfm_points():
 
 
 @pytest.mark.parametrize("wide", ["0", "16"])
-def test_mixed_resolution_neighbours_parity_both_kernels(wide):
+def test_mixed_resolution_neighbours_parity_both_kernels(wide, W=160, H=120):
     """The shipped combination -- one-call boundary, one-wave-per-pixel kernel (the engine's choice for a single depth map), mixed-size sources, geometric
     round with resized depth maps -- and the regular kernel, each on a fresh engine (PMHIP_WIDE is read at pmhip_create)."""
     import os
@@ -686,7 +686,7 @@ def test_mixed_resolution_neighbours_parity_both_kernels(wide):
     os.environ["PMHIP_WIDE"] = wide
     try:
         e = PatchMatchHIP(0)
-        test_mixed_resolution_neighbours_parity(e)
+        test_mixed_resolution_neighbours_parity(e, W, H)
         e.close()
     finally:
         if saved is None:
@@ -695,15 +695,15 @@ def test_mixed_resolution_neighbours_parity_both_kernels(wide):
             os.environ["PMHIP_WIDE"] = saved
 
 
-def test_mixed_resolution_neighbours_parity(engine):
+def test_mixed_resolution_neighbours_parity(engine, W=160, H=120):
     """Source views of another size than the reference (DepthMap.h:194-204: a neighbour whose scale differs by >= 15 % is rescaled; here one at 0.8x
     and one at 1.25x, rendered at those sizes): every view is projected into with its own K and sampled within its own bounds, on all pyramid
     levels; in the geometric round the neighbours' depth maps keep the size and camera they were stored with (cameraDepthMap, SceneDensify.cpp:
     378-393) while their images are the rescaled ones.  Through the one-call boundary and through the scene interface, bit-exact."""
     from openmvs_amd.patchmatch import PatchMatchHIP
-    base = synth.make_scene(5, 160, 120, n_src=4)
-    small = synth.make_scene(5, 128, 96, n_src=4)           # same cameras and surface, rendered at 0.8x ...
-    big = synth.make_scene(5, 200, 150, n_src=4)            # ... and at 1.25x
+    base = synth.make_scene(5, W, H, n_src=4)
+    small = synth.make_scene(5, W * 4 // 5, H * 4 // 5, n_src=4)   # same cameras and surface, rendered at 0.8x ...
+    big = synth.make_scene(5, W * 5 // 4, H * 5 // 4, n_src=4)     # ... and at 1.25x
     assert np.array_equal(base.R, small.R) and np.array_equal(base.C, big.C) and np.array_equal(base.neighbors, small.neighbors)
     ref = 0
     ids = [ref] + [int(i) for i in base.neighbors[ref]]

@@ -44,7 +44,7 @@ def test_device_fuse_is_the_sequential_fuse(small_scene, nine_scene, case):
 
 def test_fuse_option_sweep(small_scene):
     """FuseDepthMaps with thresholds and view counts away from the defaults: more views than any point has, very tight and very loose depth / normal
-    thresholds, colours without normals and the reverse.  NOT YET RUN ON A DEVICE (the kernels are; these values are not)."""
+    thresholds, colours without normals and the reverse."""
     sc = small_scene
     maps = fc.make_maps(sc, seed=5)
     e = PatchMatchHIP(0)

@@ -376,7 +376,7 @@ def test_gap_interpolation_parity(small_scene):
 def test_post_filter_option_sweep(small_scene):
     """The thresholds and sizes of the three post-filters away from their defaults, all on one estimate: RemoveSmallSegments (speckle size 0, 1, 15,
     huge; loose / tight depth threshold), GapInterpolation (gap 0, 1, 3, 20), FilterDepthMap (view counts 1..3, tight / loose threshold, both
-    bFilterAdjust branches).  NOT YET RUN ON A DEVICE (the kernels are; these values are not)."""
+    bFilterAdjust branches)."""
     from openmvs_amd.patchmatch import PatchMatchHIP
     sc = small_scene
     e = PatchMatchHIP(0); e.Init(False)
@@ -495,7 +495,7 @@ def test_ignore_mask_parity(small_scene):
 
 def test_single_call_with_ignore_mask(engine, small_scene):
     """pmhip_estimate_depth_map_masked (the PatchMatchCUDA-shaped call with DepthData::mask): with a mask, with the option but no mask, and a
-    plain call afterwards (the engine keeps no mask state between calls).  NOT YET RUN ON A DEVICE."""
+    plain call afterwards (the engine keeps no mask state between calls)."""
     sc = small_scene
     engine.Init(False)
     p = default_params(seed=5, nSubResolutionLevels=2)
@@ -517,7 +517,7 @@ def test_single_call_with_ignore_mask(engine, small_scene):
 
 def test_many_source_views_parity(engine):
     """9 .. 16 source views (G = 16 lanes per pixel, the widest instantiation, 4 pixels per wavefront) and the partial groups 5, 6; one geometric round
-    at 16; more than PMHIP_MAX_SOURCES is an argument error.  NOT YET RUN ON A DEVICE (the G = 16 kernels never were)."""
+    at 16; more than PMHIP_MAX_SOURCES is an argument error."""
     from openmvs_amd.patchmatch import PatchMatchError
     sc = synth.make_scene(18, 96, 72, n_src=17)
     ref = 8
@@ -549,7 +549,7 @@ def test_many_source_views_parity(engine):
 
 def test_degenerate_inputs(engine):
     """Textureless images (every pixel fails the descriptor-magnitude test: empty maps), an image smaller than the patch at its coarsest level, and
-    the post-filters and the fusion on empty maps.  NOT YET RUN ON A DEVICE."""
+    the post-filters and the fusion on empty maps."""
     from openmvs_amd.patchmatch import PatchMatchHIP
     sc = synth.make_scene(5, 64, 48, n_src=4)
     engine.Init(False)
@@ -597,7 +597,7 @@ OPTION_SETS = [
 @pytest.mark.parametrize("k", range(len(OPTION_SETS)))
 def test_non_default_options_parity(engine, small_scene, k):
     """Every OPTDENSE value the estimator reads (DepthMap.cpp:69-90 -> PMHipParams), away from its default: photometric pass, and for the first set a
-    geometric round with a non-default fEstimationGeometricWeight on top.  NOT YET RUN ON A DEVICE (the kernels are; these constants are not)."""
+    geometric round with a non-default fEstimationGeometricWeight on top."""
     sc = small_scene
     kw = OPTION_SETS[k]
     engine.Init(False)

@@ -100,7 +100,7 @@ def test_pixel_table_with_entries_out_of_pixel_order(matcher):
 
 def test_match_parity_across_long_invalid_runs(matcher):
     """Masked regions (ranges NO_DISP..NO_DISP) wider than the path kernel's 64-pixel table chunk: paths skip them without resetting their state
-    (SemiGlobalMatcher.cpp:1071-1072), so a whole staged chunk can be invalid.  NOT YET RUN ON A DEVICE."""
+    (SemiGlobalMatcher.cpp:1071-1072), so a whole staged chunk can be invalid."""
     w, h = 230, 100                                             # lines of more than 3 chunks, so that chunk k+2 holds valid pixels where chunk k has a hole
     lb, lg, rg = sc.stereo_pair(w, h, 5, seed=8)
     px, n, mx = sc.ranges(w, h, "holes", -2, 12, seed=3)
@@ -111,7 +111,7 @@ def test_match_parity_across_long_invalid_runs(matcher):
                                                (120, 90, "ragged", 0, 200), (203, 71, "uniform", 0, 70), (230, 100, "holes", -2, 12)])
 def test_sub_group_kernels_match_parity(matcher, w, h, kind, dmin, dmax):
     """The 16-lanes-per-pixel mapping of cost volume, path aggregation and WTA (csrc/sgm_kernels_sub.hip, the one the resident tSGM loop uses for
-    narrow ranges): the same integer-exact parity as the wide kernels, ranges narrower and wider than a sub-group.  NOT YET RUN ON A DEVICE."""
+    narrow ranges): the same integer-exact parity as the wide kernels, ranges narrower and wider than a sub-group."""
     lb, lg, rg = sc.stereo_pair(w, h, 5, seed=w)
     px, n, mx = sc.ranges(w, h, kind, dmin, dmax, seed=h)
     matcher.set_sub_group_kernels(True)
@@ -124,7 +124,7 @@ def test_sub_group_kernels_match_parity(matcher, w, h, kind, dmin, dmax):
 @pytest.mark.parametrize("sub", [False, True])
 def test_range_limits(matcher, sub):
     """The widest range the engine takes (256 disparities, most of them outside the right image: cost 255), one more is an argument error; a valid grid
-    of a single row and of a single column; both kernel mappings.  NOT YET RUN ON A DEVICE."""
+    of a single row and of a single column; both kernel mappings."""
     matcher.set_sub_group_kernels(sub)
     try:
         lb, lg, rg = sc.stereo_pair(80, 20, 3, seed=2)
@@ -144,7 +144,7 @@ def test_range_limits(matcher, sub):
 
 @pytest.mark.parametrize("lanes", [8, 32])
 def test_sub_group_widths(matcher, lanes):
-    """The other two sub-group widths (8 and 32 lanes per pixel / pair / line; 16 is covered above).  NOT YET RUN ON A DEVICE."""
+    """The other two sub-group widths (8 and 32 lanes per pixel / pair / line; 16 is covered above)."""
     matcher.set_sub_group_kernels(lanes)
     try:
         for w, h, kind, dmin, dmax in ((97, 65, "ragged", -5, 40), (230, 100, "holes", -2, 12), (120, 90, "ragged", 0, 200)):

@@ -130,7 +130,7 @@ def test_tsgm_loop_on_the_device_equals_the_loop_on_the_oracle(matcher):
 @pytest.mark.parametrize("w,h,d0,min_res", [(96, 64, 6, 32), (200, 120, 7, 30), (256, 192, 12, 64)])
 def test_resident_tsgm_loop_equals_the_stepwise_loop(matcher, w, h, d0, min_res):
     """sgmhip_tsgm_match (the whole loop in one call, resident in HBM) against openmvs_amd/tsgm.py on the oracle backend: with masks, with and
-    without an initial disparity map, default and non-default speckle / sub-pixel options.  NOT YET RUN ON A DEVICE."""
+    without an initial disparity map, default and non-default speckle / sub-pixel options."""
     from openmvs_amd import tsgm
     from tests.tsgm_backends import OracleBackend
     lb, lg, rg = sc.stereo_pair(w, h, d0, seed=4)
@@ -151,7 +151,7 @@ def test_resident_tsgm_loop_equals_the_stepwise_loop(matcher, w, h, d0, min_res)
 @pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (97, 53, 1)])
 def test_resident_fuse_equals_the_stepwise_fuse(matcher, w, h, seed):
     """sgmhip_fuse_disparities (projection of every pair + per-pixel fusion in one resident call) against the same steps on the oracle backend;
-    pairs of different valid-grid sizes and sub-pixel steps, one pair that produces no depth.  NOT YET RUN ON A DEVICE."""
+    pairs of different valid-grid sizes and sub-pixel steps, one pair that produces no depth."""
     from openmvs_amd import sgm_pipeline
     from tests.tsgm_backends import OracleBackend
     H, Q, iH, iQ = pc.rectification(seed)

@@ -207,7 +207,7 @@ def main():
                                    % (V, W, H, N, a.geo_iters, " + cross-view filter" if a.with_filter else ""),
                        "views_total": V, "views_per_gpu": len(mine), "batch": B, "parallelism": "reference views sharded over %d GPU(s)" % world},
             "roofline": {"bound": "hbm", "kernel": "pm_sweep2_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": measured_traffic(per_launch),
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), **traffic_fields(per_launch),
                          "launches": int(st.sweepLaunches), "avg_launch_us": round(1e3 * st.sweepMs / max(1, st.sweepLaunches), 2),
                          "algorithmic_bytes_per_launch": round(per_launch, 1),
                          "concurrent_streams": round(sweep_s / max(wall_s, 1e-12), 2), "device_achieved": round(device, 2),
@@ -231,6 +231,17 @@ def main():
     eng.close()
     if dist_on:
         dist.destroy_process_group()
+
+
+def traffic_fields(algorithmic_bytes_per_launch):
+    """`traffic`: fabric-side bytes (FETCH_SIZE + WRITE_SIZE) of one sweep launch of THIS run = the measured bytes per algorithmic byte of the counter passes x this run's
+    algorithmic bytes per launch (the counter passes use a smaller batch: the ratio is per pixel visit, the launch size is not); null without a valid measurement.
+    `traffic_measurement`: the counter figures as taken."""
+    t = measured_traffic(algorithmic_bytes_per_launch)
+    if t is None:
+        return {"traffic": None}
+    return {"traffic": round(t["over_algorithmic"] * algorithmic_bytes_per_launch), "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, offline counter passes, scaled by algorithmic bytes)",
+            "traffic_measurement": t}
 
 
 def measured_traffic(algorithmic_bytes_per_launch):

@@ -256,7 +256,8 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 		if (e->uniform && NK <= 2) {
 			const int align = e->maxNumDisp % 2 == 0 ? 2 : 1;
 #define SGM_LAUNCH_UNIFORM(NK_, AL_, DL_) hipLaunchKernelGGL((sgm_path_uniform_kernel<NK_, AL_, DL_, false>), dim3(total), dim3(64), 0, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->maxNumDisp, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, (int)P1, sd, e->d_deltas, (unsigned long long)e->numCosts)
-			if (delta && e->maxNumDisp % 16 == 0) {   // delta bytes staged through LDS, written out 16 bytes at a time
+			static const int stageMaxNK = [] { const char* v = getenv("SGMHIP_STAGE"); return v ? atoi(v) : 2; }();   // stage the delta bytes for up to this many entries per lane (0: never)
+			if (delta && e->maxNumDisp % 16 == 0 && NK <= stageMaxNK) {   // delta bytes staged through LDS, written out 16 bytes at a time
 #define SGM_LAUNCH_STAGED(NK_) hipLaunchKernelGGL((sgm_path_uniform_kernel<NK_, 2, true, true>), dim3(total), dim3(64), 0, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->maxNumDisp, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, (int)P1, sd, e->d_deltas, (unsigned long long)e->numCosts)
 				if (NK == 1) SGM_LAUNCH_STAGED(1); else SGM_LAUNCH_STAGED(2);
 #undef SGM_LAUNCH_STAGED

@@ -454,10 +454,42 @@ def cpu_legs(a, eng):
     m = (cpu2[0] > 0) & (gpu2[0] > 0)
     rmse = float(np.sqrt(np.mean((cpu2[0][m].astype(np.float64) - gpu2[0][m]) ** 2))) if m.any() else float("nan")
     only_one = int(((cpu2[0] > 0) != (gpu2[0] > 0)).sum())
+    ref_leg = reference_code_leg()
+    if ref_leg is not None:
+        base["reference_code"] = ref_leg
     return {"cpu_baseline": base,
             "parity_live": {"case": "256x144, 8 sources, full schedule, sequential oracle vs HIP engine in this run", "depth_rmse_over_diameter": rmse / sc2.diameter,
                             "tolerance": 1e-4, "pixels_valid_in_only_one": only_one,
                             "bit_identical": bool(np.array_equal(cpu2[0], gpu2[0]) and np.array_equal(cpu2[1], gpu2[1]) and np.array_equal(cpu2[2], gpu2[2]))}}
+
+
+def reference_code_leg():
+    """The reference's OWN estimator code (oracle/_ref: DepthMap.cpp / SceneDensify.cpp line ranges compiled verbatim, built where /root/reference exists and shipped
+    prebuilt) against the oracle on one pyramid level -- initial scoring + 3 sweeps of one reference view with 8 sources at 384x216 -- on one core each: the seconds of
+    both and whether the maps are the same bits.  Says how far the restated port that cpu_baseline times is from the reference's code in speed (in results it is not, and
+    this re-checks that on the host that ran the bench).  None when the prebuilt library is absent."""
+    try:
+        from openmvs_amd import synth
+        from oracle import pyoracle as po
+        from oracle import pyref as pr
+        if not pr.available():
+            return None
+        w, h, v = 384, 216, 4
+        sc = synth.make_scene(9, w, h, n_src=8)
+        ids = [v] + list(sc.neighbors[v])
+        views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+        z = np.zeros((h, w), np.float32); n0 = np.zeros((h, w, 3), np.float32)
+        opt = po.default_opt(seed=1, viewID=v, rngMode=2)          # the reference's std::mt19937 stream and draw order
+        args = (views, len(ids), z, n0, z, float(sc.dmin[v]), float(sc.dmax[v]), opt, True, 0, 3)
+        t = time.perf_counter(); a = pr.ref_run_level(*args, th_end=0.9 * 1.333); t_ref = time.perf_counter() - t
+        t = time.perf_counter(); b = pr.orc_run_level(*args, th_end=0.9 * 1.333); t_orc = time.perf_counter() - t
+        same = all(bool(np.array_equal(x, y, equal_nan=True)) for x, y in zip(a, b))
+        return {"kind": "reference", "cores": 1, "sample": "one pyramid level (initial scoring + 3 sweeps) of 1 reference view x 8 sources at %dx%d" % (w, h),
+                "reference_seconds": round(t_ref, 3), "port_seconds": round(t_orc, 3), "reference_mpix_per_s_this_level": round(w * h / t_ref / 1e6, 5),
+                "bit_identical_to_port": same, "valid_frac": round(float((a[0] > 0).mean()), 4),
+                "note": "reference: g++ -O2, portable build of /root/reference's own functions (oracle/ref/build_ref.py); port: the oracle library the parity tests use"}
+    except Exception as ex:                                         # the leg is evidence, never a reason for the bench line to fail
+        return {"kind": "reference", "error": str(ex)[:200]}
 
 
 if __name__ == "__main__":

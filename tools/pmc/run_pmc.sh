@@ -10,16 +10,19 @@ g++ -std=c++17 -O1 -I"$R/include" "$R/tools/pmc/pmc_workload.cpp" -o /tmp/pmc_wo
 [ -f /tmp/pmc_scene.bin ] || python "$R/tools/pmc/make_scene.py" "$V" 1920 1080 /tmp/pmc_scene.bin > "$OUT/make_scene.log" 2>&1
 export PMHIP_GROUPS=${PMC_GROUPS:-1}
 ( cd /tmp && timeout 120 /tmp/pmc_workload /tmp/pmc_scene.bin ${PMC_GEO:-1} > "$R/$OUT/unprofiled_run.json" 2> "$R/$OUT/unprofiled.err" ); echo "unprofiled rc $?"; cat "$OUT/unprofiled_run.json"
-FAILS=0
+# rocprofv3 --pmc hangs in roughly every second pass on this pool (at start-up or while writing its output; the workload itself takes seconds), so a pass gets a short
+# timeout and up to PMC_TRIES attempts instead of one long wait.
 pass() {
   local name=$1; shift
-  if [ $FAILS -ge 2 ]; then echo "pass $name skipped: two passes failed already"; return; fi
-  ( cd /tmp && timeout ${PMC_TIMEOUT:-150} rocprofv3 --pmc "$@" --output-format csv -d "/tmp/prof_pmc_$name" -o pmc -- /tmp/pmc_workload /tmp/pmc_scene.bin ${PMC_GEO:-1} \
-      > "$R/$OUT/pmc_${name}_run.json" 2> "$R/$OUT/pmc_$name.err" )
-  local rc=$?
-  local csv=$(find "/tmp/prof_pmc_$name" -name "*counter_collection.csv" 2>/dev/null | head -1)
-  if [ -n "$csv" ]; then python "$R/tools/pmc_agg.py" "$csv" > "$OUT/pmc_${name}_per_kernel.txt" 2>&1; echo "pass $name ok"; FAILS=0; else FAILS=$((FAILS+1)); echo "pmc pass $name: rc $rc, no counter csv"; tail -5 "$OUT/pmc_$name.err"; fi
-  rm -rf "/tmp/prof_pmc_$name"
+  local try
+  for try in $(seq 1 ${PMC_TRIES:-3}); do
+    ( cd /tmp && timeout ${PMC_TIMEOUT:-100} rocprofv3 --pmc "$@" --output-format csv -d "/tmp/prof_pmc_$name" -o pmc -- /tmp/pmc_workload /tmp/pmc_scene.bin ${PMC_GEO:-1} \
+        > "$R/$OUT/pmc_${name}_run.json" 2> "$R/$OUT/pmc_$name.err" )
+    local rc=$?
+    local csv=$(find "/tmp/prof_pmc_$name" -name "*counter_collection.csv" 2>/dev/null | head -1)
+    if [ -n "$csv" ]; then python "$R/tools/pmc_agg.py" "$csv" > "$OUT/pmc_${name}_per_kernel.txt" 2>&1; echo "pass $name ok (attempt $try)"; rm -rf "/tmp/prof_pmc_$name"; return; fi
+    echo "pmc pass $name: attempt $try: rc $rc, no counter csv"; rm -rf "/tmp/prof_pmc_$name"
+  done
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE

@@ -253,7 +253,7 @@ def measured_traffic(algorithmic_bytes_per_launch):
         import hashlib
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         h = hashlib.sha256()
-        for f in ("pm_kernels.hip", "pm_engine.hip", "pm_math.h"):
+        for f in ("pm_kernels.hip", "pm_band.hip", "pm_math.h"):   # the measured kernel (pm_sweep2_kernel, pm_band.hip) and every device function it uses; not the host engine
             h.update(open(os.path.join(ROOT, "openmvs_amd", "csrc", f), "rb").read())
         if h.hexdigest()[:16] != t.get("kernel_digest"):
             return None

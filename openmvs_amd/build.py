@@ -18,7 +18,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value", "-Wno-pass-failed"]
 
 LIBS = {
-    "libpmhip.so": (["pm_engine.hip"], ["pm_kernels.hip", "pm_filter.hip", "pm_fuse.hip", "pm_fuse.h", "pm_math.h", "../../include/pmhip.h"]),
+    "libpmhip.so": (["pm_engine.hip"], ["pm_kernels.hip", "pm_band.hip", "pm_wide_n.hip", "pm_filter.hip", "pm_fuse.hip", "pm_fuse.h", "pm_math.h", "../../include/pmhip.h"]),
     "libsgmhip.so": (["sgm_engine.hip"], ["sgm_kernels.hip", "sgm_kernels_sub.hip", "sgm_tsgm.hip", "sgm_post.hip", "sgm_post.h", "pm_math.h", "../../include/sgmhip.h"]),
 }
 

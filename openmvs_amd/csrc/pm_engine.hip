@@ -7,6 +7,7 @@
 #include "../../include/pmhip.h"
 #include "pm_kernels.hip"
 #include "pm_band.hip"
+#include "pm_wide_n.hip"
 #include "pm_filter.hip"
 #include "pm_fuse.hip"
 #include <math.h>
@@ -20,8 +21,10 @@
 #include <vector>
 
 #ifndef PMHIP_DEFAULT_WIDE
-#define PMHIP_DEFAULT_WIDE 10   // measured (profiles/r03_small_batches_call7.log, window-less build of both): one-wave-per-pixel kernel 1.48x at 1 view, 1.45x at 4,
-                                // 1.18x at 8, 0.92x at 13 of pm_sweep2_kernel
+#define PMHIP_DEFAULT_WIDE 25   // batches of at most this many reference views use the speculative kernels: eight hypotheses per round (one wave per pixel) for 1-2 views, two per round
+                                // (four pixels per wave, pm_wide_n.hip) from 3 views on.  Measured (profiles/r03_small_batches_call24_26_narrower_speculation.log, full schedule at
+                                // 1920x1080, Mpix/s; one view per lane / eight-wide / two-wide): 1 view 1.74 / 2.57 / 2.52, 4: 6.2 / 9.0 / 9.2, 8: 11.7 / 14.4 / 16.6, 13: 17.9 / 17.5 / 23.6,
+                                // 25: 28.2 / - / 32.5; the four-wide kernel is between the two (13 views: 21.1)
 #endif
 #ifndef PMHIP_DEFAULT_LANES
 #define PMHIP_DEFAULT_LANES 0    // sweep kernels: lanes per pixel; 0 = by batch size (one view per lane for small batches, four lanes and two views per lane
@@ -114,6 +117,7 @@ struct pmhip_engine {
 	// view groups of a batch sweep on their own streams so that the tail of one group's diagonal launch
 	// overlaps the next launch of another group (views are independent; diagonals of one view are not)
 	int nGroups = 1;
+	int wideHyps = 0;                        // hypotheses per round of the speculative kernel: 0 = by batch size (8 for one or two views, else 2); PMHIP_WIDE_HYPS = 8 / 4 / 2 fixes it
 	int wideMaxViews = PMHIP_DEFAULT_WIDE;   // batches of at most this many views use the one-wave-per-pixel sweep kernel (PMHIP_WIDE)
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
 	int bandMode = PMHIP_DEFAULT_BAND;      // PMHIP_BAND: 1 = resident band kernel, 0 = one launch per anti-diagonal
@@ -359,6 +363,14 @@ template <bool GEO>
 static void launchSweepWide(dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	hipLaunchKernelGGL((pm_sweep_wide_kernel<GEO>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass);
 }
+// the speculative kernel at 4 or 2 hypotheses per round (pm_wide_n.hip; PMHIP_WIDE_HYPS): 2 or 4 pixels per wave
+template <bool GEO>
+static void launchSweepWideN(int hyps, int nTasks, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
+	const int ppw = 8 / hyps;
+	const dim3 grid((unsigned)((count + ppw - 1) / ppw), (unsigned)nTasks);
+	if (hyps == 4) hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 4>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass);
+	else hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 2>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass);
+}
 
 static size_t evBeginOn(pmhip_engine* e, int kind, hipStream_t st) {
 	if (!e->statsOn) return 0;
@@ -577,6 +589,12 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 				for (int g = 0; g < NG; ++g) {
 					const int s0 = (int)((long)nB * g / NG), s1 = (int)((long)nB * (g + 1) / NG);
 					hipStream_t st = NG > 1 ? e->gstream[g] : e->stream;
+					const int hyps = e->wideHyps > 0 ? e->wideHyps : (nB <= 2 ? 8 : 2);
+					if (wide && hyps < 8) {
+						if (geo) launchSweepWideN<true>(hyps, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass);
+						else launchSweepWideN<false>(hyps, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass);
+						continue;
+					}
 					if (wide) {
 						const dim3 grid((unsigned)count, s1 - s0);
 						if (geo) launchSweepWide<true>(grid, st, dt + s0, kp, dir, d, xlo, count, pass);
@@ -660,6 +678,7 @@ int pmhip_create(int device, pmhip_engine** out) {
 	e->nGroups = ng ? std::max(1, std::min(16, atoi(ng))) : PMHIP_DEFAULT_GROUPS;
 	const char* nw = getenv("PMHIP_WIDE");
 	if (nw) e->wideMaxViews = atoi(nw);
+	const char* wh = getenv("PMHIP_WIDE_HYPS"); if (wh && (atoi(wh) == 8 || atoi(wh) == 4 || atoi(wh) == 2)) e->wideHyps = atoi(wh);
 	const char* bm = getenv("PMHIP_BAND");
 	if (bm) e->bandMode = atoi(bm) != 0;
 	const char* d2 = getenv("PMHIP_DIAG2"); if (d2) e->diagVisit2 = atoi(d2) != 0;

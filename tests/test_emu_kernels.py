@@ -84,6 +84,22 @@ def test_estimator_wide_latency_mode(pm_emulated, nine_scene, small_scene):
     g.test_wide_latency_mode_parity(nine_scene, small_scene, quick=True)     # one wave per pixel, eight hypotheses per round (the whole case passes too: 260 s)
 
 
+@pytest.mark.parametrize("hyps", [4, 2])
+def test_estimator_narrower_speculation(pm_emulated, nine_scene, small_scene, hyps):
+    """pm_sweep_widen_kernel: four / two hypotheses per round, two / four pixels per wave (prepared in round 3; the emulator is all it has run under so far)."""
+    import os
+    from tests import test_gpu_patchmatch as g
+    saved = os.environ.get("PMHIP_WIDE_HYPS")
+    os.environ["PMHIP_WIDE_HYPS"] = str(hyps)
+    try:
+        g.test_wide_latency_mode_parity(nine_scene, small_scene, quick=True)
+    finally:
+        if saved is None:
+            os.environ.pop("PMHIP_WIDE_HYPS", None)
+        else:
+            os.environ["PMHIP_WIDE_HYPS"] = saved
+
+
 def test_estimator_mixed_resolution_neighbours_wide_kernel(pm_emulated):
     from tests import test_gpu_patchmatch as g
     g.test_mixed_resolution_neighbours_parity_both_kernels("16", 80, 60)     # (quarter of the pixels of the device case: the regular-kernel run below has the full size)

@@ -167,6 +167,22 @@ def test_sweep_kernel_variants_parity(nine_scene, small_scene, variant, quick=Fa
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("hyps", [4, 2])
+def test_narrower_speculation_parity(nine_scene, small_scene, hyps):
+    """pm_sweep_widen_kernel (PMHIP_WIDE_HYPS = 4 / 2: four or two hypotheses of a pixel per round, two or four pixels per wave): the same cases as the eight-wide
+    kernel, the same bits."""
+    import os
+    saved = os.environ.get("PMHIP_WIDE_HYPS")
+    os.environ["PMHIP_WIDE_HYPS"] = str(hyps)
+    try:
+        test_wide_latency_mode_parity(nine_scene, small_scene)
+    finally:
+        if saved is None:
+            os.environ.pop("PMHIP_WIDE_HYPS", None)
+        else:
+            os.environ["PMHIP_WIDE_HYPS"] = saved
+
+
 def test_wide_latency_mode_parity(nine_scene, small_scene, quick=False):
     """The one-wave-per-pixel sweep kernel (PMHIP_WIDE: eight hypotheses of a pixel scored side by side, sequential accept rule replayed over them) gives
     the bits of the sequential walk: 8 / 4 / 1-3 sources, pyramid, geometric round, ignore masks, option sets that change the iteration budget

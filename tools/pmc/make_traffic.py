@@ -11,7 +11,7 @@ d = sys.argv[1]; kern = sys.argv[2] if len(sys.argv) > 2 else "pm_sweep"
 
 def kernel_digest():
     h = hashlib.sha256()
-    for f in ("pm_kernels.hip", "pm_engine.hip", "pm_math.h"):
+    for f in ("pm_kernels.hip", "pm_band.hip", "pm_math.h"):   # the measured kernel (pm_sweep2_kernel, pm_band.hip) and every device function it uses; not the host engine
         h.update(open(os.path.join(ROOT, "openmvs_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -12,6 +12,8 @@
 // the regular kernel; profiles/r03_small_batches_call24_26_narrower_speculation.log).  Measured: the two-wide kernel is the fastest of all mappings from 4 to at
 // least 25 views (13 views: 23.6 Mpix/s against 17.9 with one view per lane and 17.5 eight-wide; 25 views: 32.5 against 28.2), the engine's default there.
 //
+// (NH = 8 of this template would be pm_sweep_wide_kernel without its LDS-window option; folding the two is left for the round that next touches pm_kernels.hip, whose
+// text is tied to the committed counter measurement of this round.)
 // Differences from pm_sweep_wide_kernel, all forced by several pixels sharing a wave: a pixel that is masked / done does not leave (its lanes idle to the end of
 // the wave's loop); every cross-lane read (the other groups' scores and planes) is done by all lanes before the per-pixel replay, never inside its
 // data-dependent control flow; window-less tap rows only (the quad images).

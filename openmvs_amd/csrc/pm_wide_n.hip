@@ -20,8 +20,11 @@
 #pragma once
 #include "pm_kernels.hip"
 
+#ifndef PM_WIDEN_MINWAVES
+#define PM_WIDEN_MINWAVES 3   // waves per SIMD the kernel is compiled for (168 VGPRs, 12-44 B of scratch; 4 has not been tried on the device)
+#endif
 template <bool GEO, int NH>
-__global__ __launch_bounds__(64, 3) void pm_sweep_widen_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
+__global__ __launch_bounds__(64, PM_WIDEN_MINWAVES) void pm_sweep_widen_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	static_assert(NH == 2 || NH == 4, "two propagation candidates need two groups; eight groups are pm_sweep_wide_kernel");
 	constexpr int G = 8, LPP = G * NH, PPW = 64 / LPP;
 	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);

@@ -7,7 +7,7 @@ import numpy as np
 from openmvs_amd import synth
 from openmvs_amd.patchmatch import PatchMatchHIP, default_params
 sizes = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 13]
-V, W, H = 13, 1920, 1080
+V, W, H = int(os.environ.get("PROBE_VIEWS", "13")), 1920, 1080   # PROBE_VIEWS=25: the batch sizes around the speculative kernels' upper limit
 sc = synth.make_scene(V, W, H, n_src=8, device="cuda", gray_only=True)
 p = default_params(seed=1)
 ref = {}

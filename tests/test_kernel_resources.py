@@ -29,6 +29,11 @@ def test_sweep_kernel_keeps_its_residency_budget():
     for k, v in sweep2.items():
         assert v["occupancy"] >= 3 and v["vgpr"] <= 168 and v["scratch"] == 0 and v["agpr"] == 0, (k, v)
         assert v["lds"] <= 11008, (k, v)
+    # the speculative kernels: eight-wide (one or two views) and the two- / four-wide template (3-25 views): three waves per SIMD, a few spilled dwords at most
+    wide = {k: v for k, v in r.items() if "pm_sweep_wide_kernel" in k or "pm_sweep_widen_kernel" in k}
+    assert len(wide) == 6
+    for k, v in wide.items():
+        assert v["occupancy"] >= 3 and v["vgpr"] <= 168 and v["scratch"] <= 48 and v["lds"] <= 4096, (k, v)
     band = {k: v for k, v in r.items() if "pm_band_kernel" in k}
     assert len(band) == 12
     for k, v in band.items():

@@ -198,6 +198,16 @@ def main():
         device = st.sweepBytes / 1e9 / max(wall_s, 1e-12)
         per_launch = st.sweepBytes / max(1, st.sweepLaunches)
         valu_tf = FLOP_PER_PIXEL * (len(mine) * W * H * a.steps / dt) / 1e12   # this rank's pixels per second x algorithmic flop per pixel
+        # which sweep kernel the engine picks for this rank's batch (pm_engine.hip: PMHIP_DEFAULT_WIDE, PMHIP_LANES4_FROM); the counter measurement behind `traffic` is of pm_sweep2_kernel
+        nb = B if B else len(mine)
+        wide_max = int(os.environ.get("PMHIP_WIDE", "25"))
+        if nb <= wide_max and N <= 8:
+            hy = os.environ.get("PMHIP_WIDE_HYPS")
+            hyps = int(hy) if hy in ("8", "4", "2") else (8 if nb <= 2 else 2)
+            kern = "pm_sweep_wide_kernel" if hyps == 8 else "pm_sweep_widen_kernel<%d>" % hyps
+        else:
+            kern = "pm_sweep2_kernel"
+        tf = traffic_fields(per_launch) if kern == "pm_sweep2_kernel" else {"traffic": None, "traffic_note": "no counter passes of %s yet (the committed ones are of pm_sweep2_kernel)" % kern}
         out = {
             "metric": "Mpix/s depth-map output at 1920x1080 N-view", "value": round(mpix, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2),
@@ -206,8 +216,8 @@ def main():
                                    "(3-level pyramid x 3 sweeps) + %d geometric rounds%s, all depth maps"
                                    % (V, W, H, N, a.geo_iters, " + cross-view filter" if a.with_filter else ""),
                        "views_total": V, "views_per_gpu": len(mine), "batch": B, "parallelism": "reference views sharded over %d GPU(s)" % world},
-            "roofline": {"bound": "hbm", "kernel": "pm_sweep2_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), **traffic_fields(per_launch),
+            "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), **tf,
                          "launches": int(st.sweepLaunches), "avg_launch_us": round(1e3 * st.sweepMs / max(1, st.sweepLaunches), 2),
                          "algorithmic_bytes_per_launch": round(per_launch, 1),
                          "concurrent_streams": round(sweep_s / max(wall_s, 1e-12), 2), "device_achieved": round(device, 2),

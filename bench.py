@@ -199,13 +199,16 @@ def main():
         per_launch = st.sweepBytes / max(1, st.sweepLaunches)
         valu_tf = FLOP_PER_PIXEL * (len(mine) * W * H * a.steps / dt) / 1e12   # this rank's pixels per second x algorithmic flop per pixel
         # which sweep kernel the engine picks for this rank's batch (pm_engine.hip: PMHIP_DEFAULT_WIDE, PMHIP_LANES4_FROM); the counter measurement behind `traffic` is of pm_sweep2_kernel
-        nb = B if B else len(mine)
-        wide_max = int(os.environ.get("PMHIP_WIDE", "25"))
-        if nb <= wide_max and N <= 8:
-            hy = os.environ.get("PMHIP_WIDE_HYPS")
-            hyps = int(hy) if hy in ("8", "4", "2") else (8 if nb <= 2 else 2)
-            kern = "pm_sweep_wide_kernel" if hyps == 8 else "pm_sweep_widen_kernel<%d>" % hyps
-        else:
+        try:
+            nb = B if B else len(mine)
+            wide_max = int(os.environ.get("PMHIP_WIDE", "25"))
+            if nb <= wide_max and N <= 8:
+                hy = os.environ.get("PMHIP_WIDE_HYPS")
+                hyps = int(hy) if hy in ("8", "4", "2") else (8 if nb <= 2 else 2)
+                kern = "pm_sweep_wide_kernel" if hyps == 8 else "pm_sweep_widen_kernel<%d>" % hyps
+            else:
+                kern = "pm_sweep2_kernel"
+        except Exception:                                              # (naming only: never a reason for the line to fail)
             kern = "pm_sweep2_kernel"
         tf = traffic_fields(per_launch) if kern == "pm_sweep2_kernel" else {"traffic": None, "traffic_note": "no counter passes of %s yet (the committed ones are of pm_sweep2_kernel)" % kern}
         out = {

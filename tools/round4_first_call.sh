@@ -20,4 +20,6 @@ for lib in libpmhip.so libpmhip_widen4.so; do
   echo "PMHIP_LIB=$lib" | tee -a "$OUT/small.log"
   PMHIP_LIB=$PWD/openmvs_amd/$lib timeout 300 python tools/small_batch_probe.py 4 8 13 2>&1 | grep "WIDE=64" | tee -a "$OUT/small.log"
 done
+# 5. one stream instead of two view groups for the speculative kernels (a 13-view diagonal is already a single round of the machine)
+PMHIP_GROUPS=1 timeout 300 python tools/small_batch_probe.py 8 13 2>&1 | grep "WIDE=64" | sed 's/^/PMHIP_GROUPS=1 /' | tee -a "$OUT/small.log"
 PMHIP_WIDE=25 bash tools/pmc/run_pmc_sq.sh "$OUT/pmc_widen2" 13 libpmhip.so 2>&1 | tail -30

@@ -84,20 +84,11 @@ def test_estimator_wide_latency_mode(pm_emulated, nine_scene, small_scene):
     g.test_wide_latency_mode_parity(nine_scene, small_scene, quick=True)     # one wave per pixel, eight hypotheses per round (the whole case passes too: 260 s)
 
 
-@pytest.mark.parametrize("hyps", [2])   # (the four-wide instantiation runs on the device: tests/test_gpu_patchmatch.py::test_narrower_speculation_parity; both pass here too)
+@pytest.mark.parametrize("hyps", [2])   # (the four-wide instantiation runs on the device: tests/test_zz_gpu_narrow_speculation.py; both pass here too)
 def test_estimator_narrower_speculation(pm_emulated, nine_scene, small_scene, hyps):
     """pm_sweep_widen_kernel: two hypotheses per round, four pixels per wave -- the engine's default from 3 to 25 reference views per batch."""
-    import os
     from tests import test_gpu_patchmatch as g
-    saved = os.environ.get("PMHIP_WIDE_HYPS")
-    os.environ["PMHIP_WIDE_HYPS"] = str(hyps)
-    try:
-        g.test_wide_latency_mode_parity(nine_scene, small_scene, quick=True)
-    finally:
-        if saved is None:
-            os.environ.pop("PMHIP_WIDE_HYPS", None)
-        else:
-            os.environ["PMHIP_WIDE_HYPS"] = saved
+    g.test_wide_latency_mode_parity(nine_scene, small_scene, quick=True, hyps=str(hyps))
 
 
 def test_estimator_mixed_resolution_neighbours_wide_kernel(pm_emulated):

@@ -167,30 +167,19 @@ def test_sweep_kernel_variants_parity(nine_scene, small_scene, variant, quick=Fa
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("hyps", [4, 2])
-def test_narrower_speculation_parity(nine_scene, small_scene, hyps):
-    """pm_sweep_widen_kernel (PMHIP_WIDE_HYPS = 4 / 2: four or two hypotheses of a pixel per round, two or four pixels per wave): the same cases as the eight-wide
-    kernel, the same bits."""
-    import os
-    saved = os.environ.get("PMHIP_WIDE_HYPS")
-    os.environ["PMHIP_WIDE_HYPS"] = str(hyps)
-    try:
-        test_wide_latency_mode_parity(nine_scene, small_scene)
-    finally:
-        if saved is None:
-            os.environ.pop("PMHIP_WIDE_HYPS", None)
-        else:
-            os.environ["PMHIP_WIDE_HYPS"] = saved
-
-
-def test_wide_latency_mode_parity(nine_scene, small_scene, quick=False):
+def test_wide_latency_mode_parity(nine_scene, small_scene, quick=False, hyps="8"):
     """The one-wave-per-pixel sweep kernel (PMHIP_WIDE: eight hypotheses of a pixel scored side by side, sequential accept rule replayed over them) gives
     the bits of the sequential walk: 8 / 4 / 1-3 sources, pyramid, geometric round, ignore masks, option sets that change the iteration budget
     (nRandomIters 8 and 2: more and fewer than one round holds), low-confidence pixels that take the random-restart stage."""
     import os
     from openmvs_amd.patchmatch import PatchMatchHIP
-    saved = os.environ.get("PMHIP_WIDE")
+    saved = os.environ.get("PMHIP_WIDE"); saved_h = os.environ.get("PMHIP_WIDE_HYPS")
     os.environ["PMHIP_WIDE"] = "16"
+    # hyps: "8" = this test's subject, the eight-wide kernel, for every batch size; "4" / "2" = pm_sweep_widen_kernel; None = the engine's choice by batch size
+    if hyps is None:
+        os.environ.pop("PMHIP_WIDE_HYPS", None)
+    else:
+        os.environ["PMHIP_WIDE_HYPS"] = str(hyps)
     try:
         e = PatchMatchHIP(0)
         for k in ((0, 5) if quick else (0, 3, 5)):
@@ -227,6 +216,10 @@ def test_wide_latency_mode_parity(nine_scene, small_scene, quick=False):
             os.environ.pop("PMHIP_WIDE", None)
         else:
             os.environ["PMHIP_WIDE"] = saved
+        if saved_h is None:
+            os.environ.pop("PMHIP_WIDE_HYPS", None)
+        else:
+            os.environ["PMHIP_WIDE_HYPS"] = saved_h
 
 
 def test_non_divisible_image_size_parity(engine):

@@ -8,9 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# The engine picks the one-wave-per-pixel sweep kernel for batches of <= 8 reference views (PMHIP_WIDE); nearly every test case is that small, so
+# The engine picks a speculative sweep kernel for batches of <= 25 reference views (PMHIP_WIDE; eight-wide for one or two views, two-wide above); nearly every test case is that small, so
 # under the product default the regular sweep kernel -- the one that carries the benchmark -- would hardly be exercised.  The suite therefore pins the
-# regular kernel and tests the latency-mode kernel by name (test_wide_latency_mode_parity, the one-call part of test_config2_full_size_matches_golden).
+# regular kernel and tests the speculative kernels by name (test_wide_latency_mode_parity, the one-call part of test_config2_full_size_matches_golden,
+# tests/test_zz_gpu_narrow_speculation.py).
 os.environ.setdefault("PMHIP_WIDE", "0")
 
 

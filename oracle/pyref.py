@@ -69,6 +69,24 @@ def orc_run_level(views, n_views, depth, normal, conf, dmin, dmax, opt, do_init=
     return _run(l.orc_run_level, views, n_views, depth, normal, conf, prior, dmin, dmax, opt, do_init, iter_begin, iter_end, th_end, mask)
 
 
+# ---- DepthMapsData::RemoveSmallSegments / GapInterpolation through the reference's own code (SceneDensify.cpp:809-1045, cut verbatim) ----
+def _filter(name, depth, normal, conf, arg, th):
+    d = np.ascontiguousarray(depth, np.float32).copy(); n = np.ascontiguousarray(normal, np.float32).copy(); c = np.ascontiguousarray(conf, np.float32).copy()
+    h, w = d.shape
+    assert n.shape == (h, w, 3) and c.shape == (h, w)
+    fn = getattr(lib(), name); fn.restype = None
+    fn(_fp(d), _fp(n), _fp(c), C.c_int(w), C.c_int(h), C.c_uint(arg), C.c_float(th))
+    return d, n, c
+
+
+def ref_remove_small_segments(depth, normal, conf, nSpeckleSize=100, fDepthDiffThreshold=0.01):
+    return _filter("ref_remove_small_segments", depth, normal, conf, nSpeckleSize, fDepthDiffThreshold)
+
+
+def ref_gap_interpolation(depth, normal, conf, nIpolGapSize=7, fDepthDiffThreshold=0.01):
+    return _filter("ref_gap_interpolation", depth, normal, conf, nIpolGapSize, fDepthDiffThreshold)
+
+
 # ---- SemiGlobalMatcher::Match through the reference's own code (oracle/ref/ref_sgm_harness.cpp) ----------------------------------------------
 def sgm_available() -> bool:
     return available() and os.path.exists(os.path.join(_HERE, "_ref", "libref_sgm.so"))

@@ -54,6 +54,7 @@ SNIPPETS = {
     "sgm_cpp_ctor":          ("libs/MVS/SemiGlobalMatcher.cpp", 506, 524, "SemiGlobalMatcher::SemiGlobalMatcher(SgmSubpixelMode _subpixelMode", "}"),
     "sgm_cpp_match":         ("libs/MVS/SemiGlobalMatcher.cpp", 863, 1302, "void SemiGlobalMatcher::Match(const ViewData& leftImage", "}"),
     "scenedensify_cpp":      ("libs/MVS/SceneDensify.cpp", 489, 576, "// initialize the confidence map (NCC score map) with the score of the current estimates", "}"),
+    "scenedensify_filters":  ("libs/MVS/SceneDensify.cpp", 809, 1045, "// filter out small depth segments from the given depth map", "} // GapInterpolation"),
 }
 
 

@@ -32,9 +32,12 @@ public:
 	static void* STCALL ScoreDepthMapTmp(void*);
 	static void* STCALL EstimateDepthMapTmp(void*);
 	static void* STCALL EndDepthMapTmp(void*);
+	bool RemoveSmallSegments(DepthData& depthData);
+	bool GapInterpolation(DepthData& depthData);
 };
 }
 #include "snip/scenedensify_cpp.inc"      // libs/MVS/SceneDensify.cpp:489-576: the three pass bodies
+#include "snip/scenedensify_filters.inc"  // libs/MVS/SceneDensify.cpp:809-1045: RemoveSmallSegments, GapInterpolation
 
 extern "C" {
 // same layout as oracle/pm_oracle.cpp's OrcView / OrcOpt
@@ -215,6 +218,25 @@ void ref_zigzag(int w, int h, int rawStride, uint16_t* outXY) {
 	DepthEstimator::MapMatrix2ZigzagIdx(cv::Size(w, h), coords, none, rawStride);
 	for (size_t i = 0; i < coords.size(); ++i) { outXY[2 * i] = coords[i].x; outXY[2 * i + 1] = coords[i].y; }
 }
+// DepthMapsData::RemoveSmallSegments / GapInterpolation (SceneDensify.cpp:809-1045) on caller-owned maps, in place
+static void filterMaps(bool gap, float* depth, float* normal, float* conf, int w, int h, unsigned arg, float fDepthDiffThreshold) {
+	DepthData dd;
+	const cv::Size size(w, h);
+	dd.depthMap.create(size); dd.normalMap.create(size); dd.confMap.create(size);
+	memcpy(dd.depthMap.data(), depth, sizeof(float) * (size_t)w * h);
+	memcpy(dd.normalMap.data(), normal, sizeof(float) * 3 * (size_t)w * h);
+	memcpy(dd.confMap.data(), conf, sizeof(float) * (size_t)w * h);
+	const float keep(OPTDENSE::fDepthDiffThreshold); const unsigned ks(OPTDENSE::nSpeckleSize), kg(OPTDENSE::nIpolGapSize);
+	OPTDENSE::fDepthDiffThreshold = fDepthDiffThreshold;
+	DepthMapsData dm;
+	if (gap) { OPTDENSE::nIpolGapSize = arg; dm.GapInterpolation(dd); } else { OPTDENSE::nSpeckleSize = arg; dm.RemoveSmallSegments(dd); }
+	OPTDENSE::fDepthDiffThreshold = keep; OPTDENSE::nSpeckleSize = ks; OPTDENSE::nIpolGapSize = kg;
+	memcpy(depth, dd.depthMap.data(), sizeof(float) * (size_t)w * h);
+	memcpy(normal, dd.normalMap.data(), sizeof(float) * 3 * (size_t)w * h);
+	memcpy(conf, dd.confMap.data(), sizeof(float) * (size_t)w * h);
+}
+void ref_remove_small_segments(float* depth, float* normal, float* conf, int w, int h, unsigned nSpeckleSize, float fDepthDiffThreshold) { filterMaps(false, depth, normal, conf, w, h, nSpeckleSize, fDepthDiffThreshold); }
+void ref_gap_interpolation(float* depth, float* normal, float* conf, int w, int h, unsigned nIpolGapSize, float fDepthDiffThreshold) { filterMaps(true, depth, normal, conf, w, h, nIpolGapSize, fDepthDiffThreshold); }
 const char* ref_math_kind() {
 #ifdef REF_MATH_PM
 	return "pm_math";

@@ -26,6 +26,7 @@ public:
 	typedef _Tp value_type;
 	Size_() : width(0), height(0) {}
 	Size_(_Tp w, _Tp h) : width(w), height(h) {}
+	template<typename _Tp2> Size_(const _Tp2& pt, decltype(&_Tp2::x) = nullptr) : width(pt.x), height(pt.y) {}   // Size_(const Point_<_Tp>&), types.hpp
 	_Tp area() const { return width * height; }
 	bool empty() const { return width <= 0 || height <= 0; }
 	_Tp width, height;
@@ -57,6 +58,10 @@ template<typename _Tp> static inline bool operator == (const Point_<_Tp>& a, con
 template<typename _Tp> static inline bool operator != (const Point_<_Tp>& a, const Point_<_Tp>& b) { return a.x != b.x || a.y != b.y; }
 template<typename _Tp> static inline Point_<_Tp> operator + (const Point_<_Tp>& a, const Point_<_Tp>& b) { return Point_<_Tp>(saturate_cast<_Tp>(a.x + b.x), saturate_cast<_Tp>(a.y + b.y)); }
 template<typename _Tp> static inline Point_<_Tp> operator - (const Point_<_Tp>& a, const Point_<_Tp>& b) { return Point_<_Tp>(saturate_cast<_Tp>(a.x - b.x), saturate_cast<_Tp>(a.y - b.y)); }
+// types.hpp: Point_ / scalar -- quotient in the promoted type of the operands, then saturate_cast back
+template<typename _Tp> static inline Point_<_Tp> operator / (const Point_<_Tp>& a, int b) { return Point_<_Tp>(saturate_cast<_Tp>(a.x / b), saturate_cast<_Tp>(a.y / b)); }
+template<typename _Tp> static inline Point_<_Tp> operator / (const Point_<_Tp>& a, float b) { return Point_<_Tp>(saturate_cast<_Tp>(a.x / b), saturate_cast<_Tp>(a.y / b)); }
+template<typename _Tp> static inline Point_<_Tp> operator / (const Point_<_Tp>& a, double b) { return Point_<_Tp>(saturate_cast<_Tp>(a.x / b), saturate_cast<_Tp>(a.y / b)); }
 template<typename _Tp> static inline Point_<_Tp> operator - (const Point_<_Tp>& a) { return Point_<_Tp>(saturate_cast<_Tp>(-a.x), saturate_cast<_Tp>(-a.y)); }
 template<typename _Tp> static inline Point_<_Tp> operator * (const Point_<_Tp>& a, int b) { return Point_<_Tp>(saturate_cast<_Tp>(a.x*b), saturate_cast<_Tp>(a.y*b)); }
 template<typename _Tp> static inline Point_<_Tp> operator * (int a, const Point_<_Tp>& b) { return Point_<_Tp>(saturate_cast<_Tp>(b.x*a), saturate_cast<_Tp>(b.y*a)); }

@@ -144,6 +144,18 @@ template <typename TYPE> class TQuaternion;
 typedef Point2i ImageRef;                // Types.h:2125
 
 // TImage (Types.h:2127-2222 on TDMatrix / cv::Mat_): storage glue; the coordinate tests and the two samplers are the reference's text.
+// Common/AutoPtr.h: owning pointer to an array
+template <typename TYPE> class CAutoPtrArr {
+public:
+	explicit CAutoPtrArr(TYPE* p = nullptr) : m_p(p) {}
+	~CAutoPtrArr() { delete[] m_p; }
+	CAutoPtrArr(const CAutoPtrArr&) = delete;
+	CAutoPtrArr& operator=(const CAutoPtrArr&) = delete;
+	inline operator TYPE*() const { return m_p; }
+	inline TYPE& operator[](size_t i) const { return m_p[i]; }
+private:
+	TYPE* m_p;
+};
 template <typename TYPE> class TImageStore {
 public:
 	typedef cv::Size Size;
@@ -160,6 +172,7 @@ public:
 	typedef cv::Size Size;
 	inline TImage() {}
 	inline TImage(const Size& s) { create(s); }
+	inline TImage(const Size& s, const TYPE& v) { create(s); for (size_t i = 0, n = (size_t)s.width * s.height; i < n; ++i) Base::d.get()[i] = v; }   // cv::Mat_(Size, value)
 	inline void create(const Size& s) { Base::sz = s; Base::d = std::shared_ptr<TYPE>(new TYPE[(size_t)s.width * s.height](), std::default_delete<TYPE[]>()); }
 	inline void create(int rows, int cols) { create(Size(cols, rows)); }
 	inline void release() { Base::sz = Size(); Base::d.reset(); }

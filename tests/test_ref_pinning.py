@@ -243,3 +243,45 @@ def test_sgm_match_is_the_reference_function(case):
     a = po.sgm_match(lb, lg, rg, px, n, mx, 3, P2s); b = pr.ref_sgm_match(lb, lg, rg, px, n, mx, 3, P2s)
     for x, y, nm in zip(a, b, ("disparity", "cost", "cost volume", "accumulated sums")):
         assert np.array_equal(x, y), nm
+
+
+# ---- the two per-map post-filters: DepthMapsData::RemoveSmallSegments / GapInterpolation (SceneDensify.cpp:809-1045) ----------------------------
+def _noisy_maps(seed, w=160, h=120):
+    """Depth / normal / confidence maps with what the two filters react to: terraces right at the similarity threshold (one-directional edges: IsDepthSimilar
+    is not symmetric), small islands, holes of 1-10 pixels in rows and columns, zero-confidence pixels."""
+    r = np.random.RandomState(seed)
+    th = 0.007
+    lv = (2.0 * (1 + th) ** (r.randint(0, 6, (h, w)) * r.choice([0.97, 1.0, 1.03]))).astype(np.float32)
+    blk = np.kron(r.rand(h // 4, w // 4) < 0.5, np.ones((4, 4), bool))
+    yy, xx = np.mgrid[0:h, 0:w]
+    d = np.where(blk, lv, (2.0 + 0.002 * xx + 0.001 * yy)).astype(np.float32)
+    d[r.rand(h, w) < 0.12] = 0
+    for _ in range(40):                                           # gaps of controlled length along rows and columns
+        y0, x0, L = r.randint(0, h), r.randint(0, w - 12), r.randint(1, 11)
+        d[y0, x0:x0 + L] = 0
+        y1, x1 = r.randint(0, h - 12), r.randint(0, w)
+        d[y1:y1 + L, x1] = 0
+    n = np.zeros((h, w, 3), np.float32)
+    ang = r.rand(h, w).astype(np.float32) * 0.5
+    n[..., 0] = np.sin(ang) * 0.3; n[..., 1] = np.sin(ang) * 0.2; n[..., 2] = -np.sqrt(np.maximum(0, 1 - n[..., 0] ** 2 - n[..., 1] ** 2))
+    n[d == 0] = 0
+    c = np.where(d > 0, r.rand(h, w), 0).astype(np.float32)
+    return d, n, c
+
+
+@pytest.mark.parametrize("seed,speckle,th", [(1, 40, 0.007), (2, 100, 0.01), (3, 10, 0.02), (4, 400, 0.005)])
+def test_remove_small_segments_is_the_reference_function(seed, speckle, th):
+    d, n, c = _noisy_maps(seed)
+    a = po.remove_small_segments(d, n, c, nSpeckleSize=speckle, fDepthDiffThreshold=th)
+    b = pr.ref_remove_small_segments(d, n, c, nSpeckleSize=speckle, fDepthDiffThreshold=th)
+    _eq(a, b, "RemoveSmallSegments")
+    assert ((d > 0) & (a[0] == 0)).sum() > 50 and (a[0] > 0).sum() > 1000      # it removed something and kept something
+
+
+@pytest.mark.parametrize("seed,gap,th", [(5, 7, 0.01), (6, 3, 0.007), (7, 12, 0.02), (8, 1, 0.01)])
+def test_gap_interpolation_is_the_reference_function(seed, gap, th):
+    d, n, c = _noisy_maps(seed)
+    a = po.gap_interpolation(d, n, c, nIpolGapSize=gap, fDepthDiffThreshold=th)
+    b = pr.ref_gap_interpolation(d, n, c, nIpolGapSize=gap, fDepthDiffThreshold=th)
+    _eq(a, b, "GapInterpolation")
+    assert ((d == 0) & (a[0] > 0)).sum() > (20 if gap > 1 else 0)               # it filled something

@@ -87,6 +87,26 @@ def ref_gap_interpolation(depth, normal, conf, nIpolGapSize=7, fDepthDiffThresho
     return _filter("ref_gap_interpolation", depth, normal, conf, nIpolGapSize, fDepthDiffThreshold)
 
 
+def ref_filter_depth_map(depths, confs, K, R, Cc, ref, nbs, dmin, dmax, bAdjust=True, nMinViewsFilter=2, nMinViewsFilterAdjust=1, nCalibratedImages=None,
+                         fDepthDiffThreshold=0.01):
+    """DepthMapsData::FilterDepthMap (SceneDensify.cpp:1049-1299, cut verbatim) of view `ref` against neighbour views `nbs`; same arguments and return value as
+    oracle.pyoracle.filter_depth_map."""
+    keep = []
+
+    def mk(i):
+        v = po.FltView(); d = np.ascontiguousarray(depths[i], np.float32); c = np.ascontiguousarray(confs[i], np.float32); keep.extend([d, c])
+        v.depth = _fp(d); v.conf = _fp(c)
+        v.K[:] = np.asarray(K[i], np.float64).ravel(); v.R[:] = np.asarray(R[i], np.float64).ravel(); v.C[:] = np.asarray(Cc[i], np.float64).ravel()
+        return v
+    rv = mk(ref); arr = (po.FltView * max(1, len(nbs)))(*[mk(i) for i in nbs])
+    h, w = depths[ref].shape
+    nd = np.zeros((h, w), np.float32); nc = np.zeros((h, w), np.float32)
+    fn = lib().ref_filter_depth_map; fn.restype = C.c_int
+    rc = fn(C.byref(rv), arr, C.c_int(len(nbs)), C.c_int(w), C.c_int(h), C.c_float(dmin), C.c_float(dmax), C.c_int(1 if bAdjust else 0),
+            C.c_uint(nMinViewsFilter), C.c_uint(nMinViewsFilterAdjust), C.c_uint(nCalibratedImages or len(depths)), C.c_float(fDepthDiffThreshold), _fp(nd), _fp(nc))
+    return rc, nd, nc
+
+
 # ---- SemiGlobalMatcher::Match through the reference's own code (oracle/ref/ref_sgm_harness.cpp) ----------------------------------------------
 def sgm_available() -> bool:
     return available() and os.path.exists(os.path.join(_HERE, "_ref", "libref_sgm.so"))

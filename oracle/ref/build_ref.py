@@ -28,6 +28,7 @@ SNIPPETS = {
     "types_h_tpoint3":       ("libs/Common/Types.h", 1349, 1438, "// 3D point struct", "typedef TPoint3<double> Point3d;"),
     "types_h_tmatrix":       ("libs/Common/Types.h", 1442, 1548, "// matrix struct", "TMatrix<TYPE,m,n>::INF("),
     "types_h_isinside":      ("libs/Common/Types.h", 1617, 1651, "/// Is this coordinate inside the 2D matrix?", "}"),
+    "types_inl_round_pt":    ("libs/Common/Types.inl", 573, 588, "// round", "}"),
     "types_inl_normsq":      ("libs/Common/Types.inl", 794, 803, "template <typename TYPE>", "}"),
     "types_inl_norm":        ("libs/Common/Types.inl", 1021, 1033, "template <typename TYPE>", "}"),
     "types_inl_point_ops":   ("libs/Common/Types.inl", 1178, 1366, "// operators", "}"),
@@ -45,8 +46,13 @@ SNIPPETS = {
     "random_h":              ("libs/Common/Random.h", 100, 159, "// Encapsulates state for random number generation", "};"),
     "camera_h_invk":         ("libs/MVS/Camera.h", 175, 188, "// return K.inv() (assuming standard K format and no shear)", "}"),
     "camera_h_i2c":          ("libs/MVS/Camera.h", 329, 344, "// un-project from image pixel coords to the camera space (z=1 plane by default)", "}"),
+    "camera_h_c2w_i2w":      ("libs/MVS/Camera.h", 345, 356, "template <typename TYPE>", "}"),
+    "camera_h_c2i":          ("libs/MVS/Camera.h", 368, 374, "// project from the camera z=1 plane to image pixels", "}"),
+    "camera_h_c2i3_w2c_w2i": ("libs/MVS/Camera.h", 382, 394, "// project from the camera space to image pixels", "}"),
+    "types_h_float2int":     ("libs/Common/Types.h", 916, 963, "template <typename INTTYPE=int>", "}"),
     "plane_inl_distance":    ("libs/Common/Plane.inl", 185, 190, "// Calculate distance to point. Plane normal must be normalized.", "}"),
     "depthmap_h":            ("libs/MVS/DepthMap.h", 41, 468, "// D E F I N E S", "};"),
+    "depthmap_cpp_copy":     ("libs/MVS/DepthMap.cpp", 121, 133, "//constructor from reference of DepthData", "{}"),
     "depthmap_cpp":          ("libs/MVS/DepthMap.cpp", 325, 972, "// create the map for converting index to matrix position", "#endif"),
     "sgm_h_defines":         ("libs/MVS/SemiGlobalMatcher.h", 44, 46, "#define SGM_SIMILARITY_WZNCC 1", "#define SGM_SIMILARITY SGM_SIMILARITY_WZNCC"),
     "sgm_h_class":           ("libs/MVS/SemiGlobalMatcher.h", 57, 206, "// An implementation of the popular Semi-Global Matching (SGM) algorithm.", "};"),
@@ -55,6 +61,7 @@ SNIPPETS = {
     "sgm_cpp_match":         ("libs/MVS/SemiGlobalMatcher.cpp", 863, 1302, "void SemiGlobalMatcher::Match(const ViewData& leftImage", "}"),
     "scenedensify_cpp":      ("libs/MVS/SceneDensify.cpp", 489, 576, "// initialize the confidence map (NCC score map) with the score of the current estimates", "}"),
     "scenedensify_filters":  ("libs/MVS/SceneDensify.cpp", 809, 1045, "// filter out small depth segments from the given depth map", "} // GapInterpolation"),
+    "scenedensify_filterdm": ("libs/MVS/SceneDensify.cpp", 1049, 1299, "// filter depth-map, one pixel at a time, using confidence based fusion or neighbor pixels", "} // FilterDepthMap"),
 }
 
 

@@ -24,6 +24,7 @@ unsigned nRandomIters = 6, nRandomMaxScale = 2;
 float fRandomDepthRatio = 0.003f, fRandomAngle1Range = 16.f, fRandomAngle2Range = 10.f, fRandomSmoothDepth = 0.02f, fRandomSmoothNormal = 13.f, fRandomSmoothBonus = 0.93f;
 } }
 using namespace MVS;
+#include "snip/depthmap_cpp_copy.inc"     // libs/MVS/DepthMap.cpp:121-133: DepthData's copy constructor (arrDepthData holds DepthData by value)
 #include "snip/depthmap_cpp.inc"          // libs/MVS/DepthMap.cpp:325-972: MapMatrix2ZigzagIdx, the constructor, PreparePixelPatch ... InitPlane
 
 namespace MVS {
@@ -34,10 +35,22 @@ public:
 	static void* STCALL EndDepthMapTmp(void*);
 	bool RemoveSmallSegments(DepthData& depthData);
 	bool GapInterpolation(DepthData& depthData);
+	bool FilterDepthMap(DepthData& depthData, const IIndexArr& idxNeighbors, bool bAdjust=true);
+	struct { unsigned nCalibratedImages; } scene;   // Scene: the one member FilterDepthMap reads
+	DepthDataArr arrDepthData;
 };
+// FilterDepthMap hands its result to SaveDepthMap / SaveConfidenceMap (files "filtered.dmap" / ".cmap", DepthMap.cpp); here they keep the maps for the caller
+static DepthMap g_filteredDepth; static ConfidenceMap g_filteredConf;
+inline bool SaveDepthMap(const String&, const DepthMap& m) { g_filteredDepth = m; return true; }
+inline bool SaveConfidenceMap(const String&, const ConfidenceMap& m) { g_filteredConf = m; return true; }
 }
+#define TD_TIMER_STARTD() ((void)0)
+#define TD_TIMER_GET_FMT() String()
+#undef ComposeDepthFilePath                    // DepthMap.h:72 builds a file name; nothing is written here
+#define ComposeDepthFilePath(i, e) String()
 #include "snip/scenedensify_cpp.inc"      // libs/MVS/SceneDensify.cpp:489-576: the three pass bodies
 #include "snip/scenedensify_filters.inc"  // libs/MVS/SceneDensify.cpp:809-1045: RemoveSmallSegments, GapInterpolation
+#include "snip/scenedensify_filterdm.inc" // libs/MVS/SceneDensify.cpp:1049-1299: FilterDepthMap
 
 extern "C" {
 // same layout as oracle/pm_oracle.cpp's OrcView / OrcOpt
@@ -237,6 +250,43 @@ static void filterMaps(bool gap, float* depth, float* normal, float* conf, int w
 }
 void ref_remove_small_segments(float* depth, float* normal, float* conf, int w, int h, unsigned nSpeckleSize, float fDepthDiffThreshold) { filterMaps(false, depth, normal, conf, w, h, nSpeckleSize, fDepthDiffThreshold); }
 void ref_gap_interpolation(float* depth, float* normal, float* conf, int w, int h, unsigned nIpolGapSize, float fDepthDiffThreshold) { filterMaps(true, depth, normal, conf, w, h, nIpolGapSize, fDepthDiffThreshold); }
+// DepthMapsData::FilterDepthMap (SceneDensify.cpp:1049-1299) of one reference view against N neighbour views; same FltView layout as oracle/filter_oracle.cpp.
+// Returns 0 and fills newDepth / newConf, or 1 if the reference refuses the view (too few neighbours).
+struct FltView { const float* depth; const float* conf; double K[9], R[9], C[3]; };
+int ref_filter_depth_map(const FltView* ref, const FltView* nb, int N, int w, int h, float dMin, float dMax, int bAdjust,
+		unsigned nMinViewsFilter, unsigned nMinViewsFilterAdjust, unsigned nCalibratedImages, float fDepthDiffThreshold, float* newDepth, float* newConf) {
+	DepthMapsData dm;
+	dm.scene.nCalibratedImages = nCalibratedImages;
+	static ImageArr images;                              // ViewData::pImageData of view i -> images[i] (GetID())
+	images.resize((IIndex)(N + 1));
+	for (int i = 0; i <= N; ++i) images[(IIndex)i].ID = (uint32_t)i;
+	dm.arrDepthData.resize((IIndex)(N + 1));
+	const cv::Size size(w, h);
+	for (int i = 0; i <= N; ++i) {
+		const FltView& s = i == 0 ? *ref : nb[i - 1];
+		DepthData& dd = dm.arrDepthData[(IIndex)i];
+		dd.images.resize(1);
+		DepthData::ViewData& v = dd.images[0];
+		setCamera(v.camera, s.K, s.R, s.C);
+		v.pImageData = &images[(IIndex)i];
+		dd.depthMap.create(size); memcpy(dd.depthMap.data(), s.depth, sizeof(float) * (size_t)w * h);
+		dd.confMap.create(size); memcpy(dd.confMap.data(), s.conf, sizeof(float) * (size_t)w * h);
+		dd.dMin = dMin; dd.dMax = dMax;
+	}
+	DepthData& dref = dm.arrDepthData[0];
+	dref.neighbors.resize((IIndex)N);
+	IIndexArr idx;
+	for (int n = 0; n < N; ++n) { dref.neighbors[(IIndex)n].ID = (uint32_t)(n + 1); idx.push_back((IIndex)n); }
+	const unsigned k1(OPTDENSE::nMinViewsFilter), k2(OPTDENSE::nMinViewsFilterAdjust); const float k3(OPTDENSE::fDepthDiffThreshold);
+	OPTDENSE::nMinViewsFilter = nMinViewsFilter; OPTDENSE::nMinViewsFilterAdjust = nMinViewsFilterAdjust; OPTDENSE::fDepthDiffThreshold = fDepthDiffThreshold;
+	g_filteredDepth.release(); g_filteredConf.release();
+	const bool ok = dm.FilterDepthMap(dref, idx, bAdjust != 0);
+	OPTDENSE::nMinViewsFilter = k1; OPTDENSE::nMinViewsFilterAdjust = k2; OPTDENSE::fDepthDiffThreshold = k3;
+	if (!ok || g_filteredDepth.empty()) return 1;
+	memcpy(newDepth, g_filteredDepth.data(), sizeof(float) * (size_t)w * h);
+	memcpy(newConf, g_filteredConf.data(), sizeof(float) * (size_t)w * h);
+	return 0;
+}
 const char* ref_math_kind() {
 #ifdef REF_MATH_PM
 	return "pm_math";

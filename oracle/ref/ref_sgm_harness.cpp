@@ -5,10 +5,7 @@
 #include <functional>
 #include "seacave_min.h"
 #define DECLARE_NO_INDEX(T) std::numeric_limits<T>::max()
-#define ROUND2INT SEACAVE::Round2Int
-namespace SEACAVE {
-template <typename INTTYPE = int> inline INTTYPE Round2Int(float x) { return static_cast<INTTYPE>(floor(x + .5f)); }     // Types.h:949-955 without _FAST_FLOAT2INT
-template <typename INTTYPE = int> inline INTTYPE Round2Int(double x) { return static_cast<INTTYPE>(floor(x + .5)); }
+namespace SEACAVE {                          // (ROUND2INT / Round2Int: the reference's own text since round 3, seacave_min.h <- Types.h:916-963)
 template <typename TYPE> class TPixel { public: union { struct { TYPE b, g, r; }; TYPE c[3]; };             // Types.h:1873-1895 (_COLORMODE BGR)
 	inline const TYPE& operator[](size_t i) const { return c[i]; } inline TYPE& operator[](size_t i) { return c[i]; } };
 typedef TPixel<uint8_t> Pixel8U;

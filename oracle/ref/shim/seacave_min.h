@@ -78,6 +78,10 @@ inline double exp(double x) { return ::exp(x); }
 #endif
 template <typename TYPE> struct RealType { typedef typename std::conditional<std::is_floating_point<TYPE>::value, TYPE, REALTYPE>::type type; };   // Types.h:344
 #include "snip/types_h_funcs.inc"        // Types.h: Cast, SQUARE, SQRT, EXP
+#include "snip/types_h_float2int.inc"    // Types.h:916-963: Floor2Int / Ceil2Int / Round2Int (the build has no _FAST_FLOAT2INT: CMakeLists.txt:25)
+#define FLOOR2INT SEACAVE::Floor2Int
+#define CEIL2INT SEACAVE::Ceil2Int
+#define ROUND2INT SEACAVE::Round2Int
 #include "snip/types_h_tests.inc"        // Types.h: ISINSIDE, CLAMP, ABS, ISZERO, ISEQUAL, INVZERO, INVERT
 #include "snip/random_h.inc"             // Random.h:100-159: struct Random
 
@@ -181,6 +185,7 @@ public:
 	inline int height() const { return Base::sz.height; }
 	inline int area() const { return Base::sz.width * Base::sz.height; }
 	inline TYPE* data() { return Base::d.get(); }
+	inline void memset(uint8_t v) { ::memset(Base::d.get(), v, sizeof(TYPE) * (size_t)Base::sz.width * Base::sz.height); }   // Types.h:2273
 	inline const TYPE& operator()(int row, int col) const { return Base::operator()(row, col); }
 	inline TYPE& operator()(int row, int col) { return Base::operator()(row, col); }
 	inline const TYPE& operator()(int i) const { return Base::d.get()[i]; }        // cv::Mat_::operator()(int): linear index of a continuous matrix
@@ -208,6 +213,7 @@ struct Thread { typedef long safe_t; static inline safe_t safeInc(volatile safe_
 struct CriticalSection {};
 typedef std::string String;
 
+#include "snip/types_inl_round_pt.inc"   // Types.inl:573-588: Floor2Int / Ceil2Int / Round2Int of a 2D point
 #include "snip/types_inl_normsq.inc"     // Types.inl: normSq(Point_), normSq(Point3_)
 #include "snip/types_inl_norm.inc"       // Types.inl: norm(TPoint2), norm(TPoint3), norm(TMatrix)
 #include "snip/types_inl_point_ops.inc"  // Types.inl: TPoint2 / TPoint3 operators
@@ -235,6 +241,7 @@ public:
 #include "snip/plane_inl_distance.inc"   // Plane.inl: TPlane::Distance(POINT)
 typedef TPlane<float> Planef;                    // Common.h:195
 typedef TMatrix<float,3,3> Matrix3x3f;           // Common.h:202
+typedef TPoint2<REAL> Point2;                    // Common.h:242
 typedef TPoint3<REAL> Point3;                    // Common.h:243
 typedef TMatrix<REAL,3,1> Vec3;                  // Common.h:245
 typedef TMatrix<REAL,3,3> Matrix3x3;             // Common.h:248
@@ -252,6 +259,9 @@ public:
 	KMatrix K; RMatrix R; CMatrix C;
 #include "snip/camera_h_invk.inc"        // Camera.h: InvK, GetInvK
 #include "snip/camera_h_i2c.inc"         // Camera.h: TransformPointI2C (both)
+#include "snip/camera_h_c2w_i2w.inc"     // Camera.h:345-356: TransformPointC2W, TransformPointI2W (both)
+#include "snip/camera_h_c2i.inc"         // Camera.h:368-374: TransformPointC2I (z = 1 plane)
+#include "snip/camera_h_c2i3_w2c_w2i.inc" // Camera.h:382-394: TransformPointC2I (3D), TransformPointW2C, TransformPointW2I
 };
 struct Image { uint32_t ID; };
 typedef CLISTDEFIDX(Image,IIndex) ImageArr;
@@ -262,4 +272,7 @@ typedef Point3f Normal;
 typedef TImage<Depth> DepthMap;
 typedef TImage<Normal> NormalMap;
 typedef TImage<float> ConfidenceMap;
+typedef SEACAVE::cList<IIndex, IIndex, 0, 16, IIndex> IIndexArr;                  // Image.h:49
+typedef SEACAVE::cList<DepthMap, const DepthMap&, 2> DepthMapArr;                 // PointCloud.h:183
+typedef SEACAVE::cList<ConfidenceMap, const ConfidenceMap&, 2> ConfidenceMapArr;  // PointCloud.h:185
 }

@@ -285,3 +285,57 @@ def test_gap_interpolation_is_the_reference_function(seed, gap, th):
     b = pr.ref_gap_interpolation(d, n, c, nIpolGapSize=gap, fDepthDiffThreshold=th)
     _eq(a, b, "GapInterpolation")
     assert ((d == 0) & (a[0] > 0)).sum() > (20 if gap > 1 else 0)               # it filled something
+
+
+# ---- the cross-view filter: DepthMapsData::FilterDepthMap (SceneDensify.cpp:1049-1299) -----------------------------------------------------------
+@pytest.fixture(scope="module")
+def estimated(scene):
+    """Depth / confidence maps of all views of the module's scene as the oracle estimates them (photometric pass), plus a disturbed copy: noise of the size of the
+    filter's thresholds, outliers in front of and behind the surface, holes -- what makes the filter average, penalise, keep and discard."""
+    sc = scene
+    depths, confs = {}, {}
+    for v in range(sc.n_views):
+        ids, views, keep = _views(sc, v)
+        d, n, c = po.estimate_depth_map(views, len(ids), float(sc.dmin[v]), float(sc.dmax[v]), po.default_opt(seed=2, viewID=v))
+        depths[v] = d; confs[v] = c
+    r = np.random.RandomState(3)
+    nd, nc = {}, {}
+    for v in range(sc.n_views):
+        d = depths[v].copy(); c = confs[v].copy()
+        m = d > 0
+        d[m] *= (1 + r.normal(0, 0.006, d.shape)[m]).astype(np.float32)
+        out = m & (r.rand(*d.shape) < 0.06)
+        d[out] *= r.choice(np.float32([0.8, 0.93, 1.08, 1.3]), d.shape)[out]
+        hole = r.rand(*d.shape) < 0.05
+        d[hole] = 0; c[hole] = 0
+        c[m & ~hole] = np.maximum(c[m & ~hole], np.float32(0.01))
+        nd[v] = d.astype(np.float32); nc[v] = c.astype(np.float32)
+    return depths, confs, nd, nc
+
+
+@pytest.mark.parametrize("bAdjust", [True, False])
+@pytest.mark.parametrize("variant", ["estimated", "disturbed"])
+@pytest.mark.parametrize("ref,nMinViews,nMinAdjust,th", [(0, 2, 1, 0.01), (2, 3, 2, 0.007), (4, 1, 1, 0.02)])
+def test_filter_depth_map_is_the_reference_function(scene, estimated, bAdjust, variant, ref, nMinViews, nMinAdjust, th):
+    sc = scene
+    depths, confs, nd, nc = estimated
+    D, Cf = (depths, confs) if variant == "estimated" else (nd, nc)
+    nbs = [int(i) for i in sc.neighbors[ref]]
+    assert (D[ref][0] == 0).all() and (D[ref][:, 0] == 0).all() and (D[ref][-1] == 0).all() and (D[ref][:, -1] == 0).all()   # (empty border: the reference's neighbour reads stay inside)
+    kw = dict(bAdjust=bAdjust, nMinViewsFilter=nMinViews, nMinViewsFilterAdjust=nMinAdjust, fDepthDiffThreshold=th)
+    a = po.filter_depth_map(D, Cf, sc.K, sc.R, sc.C, ref, nbs, float(sc.dmin[ref]), float(sc.dmax[ref]), **kw)
+    b = pr.ref_filter_depth_map(D, Cf, sc.K, sc.R, sc.C, ref, nbs, float(sc.dmin[ref]), float(sc.dmax[ref]), **kw)
+    assert a[0] == b[0] == 0
+    for x, y, nm in zip(a[1:], b[1:], ("depth", "conf")):
+        assert np.array_equal(x, y), "FilterDepthMap %s: %d of %d differ" % (nm, int((x != y).sum()), x.size)
+    kept = (a[1] > 0).sum(); had = (D[ref] > 0).sum()
+    assert 0 < kept <= had
+    if variant == "disturbed":
+        assert kept < had                                              # it discarded something
+
+
+def test_filter_depth_map_refuses_too_few_neighbours(scene, estimated):
+    sc = scene; depths, confs, nd, nc = estimated
+    a = po.filter_depth_map(depths, confs, sc.K, sc.R, sc.C, 0, [1], 1.0, 10.0, nMinViewsFilter=2)
+    b = pr.ref_filter_depth_map(depths, confs, sc.K, sc.R, sc.C, 0, [1], 1.0, 10.0, nMinViewsFilter=2)
+    assert a[0] == b[0] == 1

@@ -10,6 +10,9 @@ files at build time and compiled against a minimal OpenCV / Eigen stand-in (orac
     BASELINE.json's north_star states (depth RMSE over pixels valid in both <= 1e-4 x scene diameter is NOT expected of a chaotic estimator pixel by
     pixel, so the test reports the fraction of pixels that agree and bounds the median relative difference).
 
+Since the end of round 3 the post-filters are in the verbatim set too: DepthMapsData::RemoveSmallSegments, GapInterpolation (SceneDensify.cpp:809-1045) and FilterDepthMap
+(:1049-1299); oracle/filter_oracle.cpp must equal them bit for bit (last three groups of tests).
+
 The libraries are built where /root/reference exists (oracle/ref/build_ref.py, by __graft_entry__.build()); elsewhere the prebuilt files are used and the
 tests skip if there are none."""
 import ctypes as C

@@ -139,3 +139,18 @@ def ref_sgm_match(left_bgr, left_gray, right_gray, pixels, num_costs, max_num_di
                          costs.ctypes.data_as(C.POINTER(C.c_uint8)), acc.ctypes.data_as(C.POINTER(C.c_uint16)))
     assert rc == 0
     return d, c, costs, acc
+
+
+def sgm_post_lib():
+    """libref_sgm.so as the `impl` of oracle.pyoracle's sgm_* step wrappers (prefix "ref_sgm_"): the reference's ConsistencyCrossCheck, FilterByCost, ExtractMask, UpscaleMask
+    and FlipDirection (SemiGlobalMatcher.cpp:1446-1691, cut verbatim) behind the oracle functions' own signatures."""
+    return _sgm_lib()
+
+
+def ref_sgm_refine(disp, pixels, accums, mode=6, steps=4):
+    """SemiGlobalMatcher::RefineDisparityMap (SemiGlobalMatcher.cpp:1693-1811) on a valid-grid disparity map with the pixel table and 8-path sums of the Match that produced it."""
+    a = np.ascontiguousarray(disp, np.int16).copy(); px = np.ascontiguousarray(pixels); ac = np.ascontiguousarray(accums, np.uint16)
+    vh, vw = a.shape
+    fn = _sgm_lib().ref_sgm_refine_wh; fn.restype = None
+    fn(a.ctypes.data_as(C.POINTER(C.c_int16)), px.ctypes.data_as(C.c_void_p), ac.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_uint64(ac.size), C.c_int(vw), C.c_int(vh), C.c_int(mode), C.c_int(steps))
+    return a

@@ -59,6 +59,7 @@ SNIPPETS = {
     "sgm_cpp_events":        ("libs/MVS/SemiGlobalMatcher.cpp", 438, 492, "enum EVENT_TYPE {", "};"),
     "sgm_cpp_ctor":          ("libs/MVS/SemiGlobalMatcher.cpp", 506, 524, "SemiGlobalMatcher::SemiGlobalMatcher(SgmSubpixelMode _subpixelMode", "}"),
     "sgm_cpp_match":         ("libs/MVS/SemiGlobalMatcher.cpp", 863, 1302, "void SemiGlobalMatcher::Match(const ViewData& leftImage", "}"),
+    "sgm_cpp_post":          ("libs/MVS/SemiGlobalMatcher.cpp", 1446, 1811, "// Check for consistency between a left-to-right and right-to-left pair of stereo results;", "}"),
     "scenedensify_cpp":      ("libs/MVS/SceneDensify.cpp", 489, 576, "// initialize the confidence map (NCC score map) with the score of the current estimates", "}"),
     "scenedensify_filters":  ("libs/MVS/SceneDensify.cpp", 809, 1045, "// filter out small depth segments from the given depth map", "} // GapInterpolation"),
     "scenedensify_filterdm": ("libs/MVS/SceneDensify.cpp", 1049, 1299, "// filter depth-map, one pixel at a time, using confidence based fusion or neighbor pixels", "} // FilterDepthMap"),

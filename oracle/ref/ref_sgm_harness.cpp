@@ -34,6 +34,7 @@ struct ThreadX : Thread { static inline safe_t safeDec(volatile safe_t& v) { ret
 #include "snip/sgm_cpp_events.inc"         // SemiGlobalMatcher.cpp:436-492: EVTPixelProcess, EVTPixelAccumInc, EVTPixelAccumDec
 #include "snip/sgm_cpp_ctor.inc"           // SemiGlobalMatcher.cpp:513-529: constructor, destructor, GenerateP2s
 #include "snip/sgm_cpp_match.inc"          // SemiGlobalMatcher.cpp:863-1302: Match
+#include "snip/sgm_cpp_post.inc"           // SemiGlobalMatcher.cpp:1446-1811: ConsistencyCrossCheck, FilterByCost, ExtractMask, FlipDirection, UpscaleMask, RefineDisparityMap
 #undef Thread
 EventThreadPool SemiGlobalMatcher::threads;
 Semaphore SemiGlobalMatcher::sem;
@@ -43,12 +44,53 @@ namespace {
 struct Access : SemiGlobalMatcher {       // reaches the protected members Match() works on
 	using SemiGlobalMatcher::Match; using SemiGlobalMatcher::imagePixels; using SemiGlobalMatcher::imageCosts; using SemiGlobalMatcher::imageAccumCosts;
 	using SemiGlobalMatcher::maxNumDisp; using SemiGlobalMatcher::P1; using SemiGlobalMatcher::P2s; using SemiGlobalMatcher::GenerateP2s;
+	using SemiGlobalMatcher::ConsistencyCrossCheck; using SemiGlobalMatcher::FilterByCost; using SemiGlobalMatcher::ExtractMask; using SemiGlobalMatcher::UpscaleMask;
+	using SemiGlobalMatcher::FlipDirection; using SemiGlobalMatcher::RefineDisparityMap;
+	Access(SgmSubpixelMode m = SUBPIXEL_LC_BLEND, Disparity steps = 4) : SemiGlobalMatcher(m, steps) {}
 };
+template <typename T> static TImage<T> imageOf(const T* p, int w, int h) { TImage<T> m; m.create(cv::Size(w, h)); memcpy(m.data(), p, sizeof(T) * (size_t)w * h); return m; }
 }
 extern "C" {
 void ref_sgm_generate_p2s(uint16_t P2, float alpha, float beta, uint16_t* out256) {
 	const auto p = Access::GenerateP2s(P2, alpha, beta);
 	for (int i = 0; i < 256; ++i) out256[i] = p[i];
+}
+// The steps around Match (SemiGlobalMatcher.cpp:1446-1811), same arguments as the orc_sgm_* functions of oracle/sgm_post_oracle.cpp
+void ref_sgm_cross_check(int16_t* l2r, const int16_t* r2l, int wl, int h, int wr, int thCross) {
+	SemiGlobalMatcher::DisparityMap a = imageOf(l2r, wl, h), b = imageOf(r2l, wr, h);
+	Access::ConsistencyCrossCheck(a, b, (SemiGlobalMatcher::Disparity)thCross);
+	memcpy(l2r, a.data(), sizeof(int16_t) * (size_t)wl * h);
+}
+void ref_sgm_filter_by_cost(int16_t* disp, const uint16_t* cost, int w, int h, uint16_t th) {
+	SemiGlobalMatcher::DisparityMap a = imageOf(disp, w, h); SemiGlobalMatcher::AccumCostMap c = imageOf(cost, w, h);
+	Access::FilterByCost(a, c, th);
+	memcpy(disp, a.data(), sizeof(int16_t) * (size_t)w * h);
+}
+void ref_sgm_extract_mask(const int16_t* disp, uint8_t* mask, int w, int h, int thValid, int initValid) {
+	SemiGlobalMatcher::DisparityMap a = imageOf(disp, w, h);
+	SemiGlobalMatcher::MaskMap m; if (!initValid) m = imageOf(mask, w, h);      // an empty mask is created all-VALID by the function (:1521-1525)
+	Access::ExtractMask(a, m, thValid);
+	memcpy(mask, m.data(), (size_t)w * h);
+}
+void ref_sgm_upscale_mask(const uint8_t* mask, int w, int h, uint8_t* mask2x, int w2, int h2) {
+	SemiGlobalMatcher::MaskMap m = imageOf(mask, w, h);
+	Access::UpscaleMask(m, cv::Size(w2, h2));
+	memcpy(mask2x, m.data(), (size_t)w2 * h2);
+}
+void ref_sgm_flip_direction(const int16_t* l2r, int w, int h, int16_t* r2l) {
+	SemiGlobalMatcher::DisparityMap a = imageOf(l2r, w, h), b;
+	Access::FlipDirection(a, b);
+	memcpy(r2l, b.data(), sizeof(int16_t) * (size_t)w * h);
+}
+// RefineDisparityMap works on the matcher's pixel table and 8-path sums: pixels = {u64 idx; i16 min, max; pad} per valid-grid pixel (row-major vw x vh), accums = the sums
+void ref_sgm_refine_wh(int16_t* disp, const void* pixels, const uint16_t* accums, uint64_t numCosts, int vw, int vh, int mode, int steps) {
+	Access m((SemiGlobalMatcher::SgmSubpixelMode)mode, (SemiGlobalMatcher::Disparity)steps);
+	m.imagePixels.Resize((SemiGlobalMatcher::Index)vw * vh);
+	memcpy(m.imagePixels.Begin(), pixels, 16 * (size_t)vw * vh);
+	m.imageAccumCosts.Resize(numCosts); memcpy(m.imageAccumCosts.Begin(), accums, numCosts * 2);
+	SemiGlobalMatcher::DisparityMap a = imageOf(disp, vw, vh);
+	m.RefineDisparityMap(a);
+	memcpy(disp, a.data(), sizeof(int16_t) * (size_t)vw * vh);
 }
 // same arguments as orc_sgm_match (oracle/sgm_oracle.cpp); pixels: (w-6)*(h-6) entries {u64 idx; i16 min, max; pad}
 int ref_sgm_match(const uint8_t* colorL, const float* grayL, const float* grayR, int w, int h, const void* pixels, uint64_t numCosts, int maxNumDisp, uint16_t P1, const uint16_t* P2s,

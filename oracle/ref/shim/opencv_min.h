@@ -241,4 +241,5 @@ template<typename _Tp, int cn> static inline Vec<_Tp, cn> operator * (const Vec<
 template<typename _Tp, int cn> static inline Vec<_Tp, cn> operator * (const Vec<_Tp, cn>& a, double alpha) { return Vec<_Tp, cn>(a, alpha, Matx_ScaleOp()); }
 
 template<class A, class B> void resize(const A&, B&, Size, double = 0, double = 0, int = INTER_LINEAR);   // declared for signatures only; never instantiated
+template <typename M> static inline void swap(M& a, M& b) { M t(a); a = b; b = t; }   // cv::swap(Mat&, Mat&): exchanges the headers
 } // namespace cv

@@ -73,9 +73,15 @@ inline float sqrt(float x) { return ::sqrtf(x); }
 inline double sqrt(double x) { return ::sqrt(x); }
 inline double exp(double x) { return ::exp(x); }
 #define ACOS SEACAVE::acos
+#define SIN SEACAVE::sin
+#define COS SEACAVE::cos
 #else
 #define ACOS std::acos
+#define SIN std::sin                              // Types.h:599, :601
+#define COS std::cos
 #endif
+#define PI 3.1415926535897932384626433832795      // Types.h:548-549
+#define HALF_PI 1.5707963267948966192313216916398
 template <typename TYPE> struct RealType { typedef typename std::conditional<std::is_floating_point<TYPE>::value, TYPE, REALTYPE>::type type; };   // Types.h:344
 #include "snip/types_h_funcs.inc"        // Types.h: Cast, SQUARE, SQRT, EXP
 #include "snip/types_h_float2int.inc"    // Types.h:916-963: Floor2Int / Ceil2Int / Round2Int (the build has no _FAST_FLOAT2INT: CMakeLists.txt:25)
@@ -167,6 +173,7 @@ public:
 	inline TYPE& operator()(int row, int col) { return d.get()[(size_t)row * (size_t)sz.width + (size_t)col]; }
 	inline Size size() const { return sz; }
 	Size sz; std::shared_ptr<TYPE> d;    // shallow copies share the pixels, as cv::Mat headers do
+	int rows = 0, cols = 0;              // cv::Mat's public fields (kept in step with sz by create / release)
 };
 template <typename TYPE> class TImage : public TImageStore<TYPE> {
 public:
@@ -177,9 +184,10 @@ public:
 	inline TImage() {}
 	inline TImage(const Size& s) { create(s); }
 	inline TImage(const Size& s, const TYPE& v) { create(s); for (size_t i = 0, n = (size_t)s.width * s.height; i < n; ++i) Base::d.get()[i] = v; }   // cv::Mat_(Size, value)
-	inline void create(const Size& s) { Base::sz = s; Base::d = std::shared_ptr<TYPE>(new TYPE[(size_t)s.width * s.height](), std::default_delete<TYPE[]>()); }
+	inline void create(const Size& s) { Base::sz = s; Base::rows = s.height; Base::cols = s.width; Base::d = std::shared_ptr<TYPE>(new TYPE[(size_t)s.width * s.height](), std::default_delete<TYPE[]>()); }
+	inline void setTo(const TYPE& v) { for (size_t i = 0, n = (size_t)Base::sz.width * Base::sz.height; i < n; ++i) Base::d.get()[i] = v; }   // cv::Mat::setTo(scalar)
 	inline void create(int rows, int cols) { create(Size(cols, rows)); }
-	inline void release() { Base::sz = Size(); Base::d.reset(); }
+	inline void release() { Base::sz = Size(); Base::rows = Base::cols = 0; Base::d.reset(); }
 	inline bool empty() const { return !Base::d; }
 	inline int width() const { return Base::sz.width; }
 	inline int height() const { return Base::sz.height; }

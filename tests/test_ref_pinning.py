@@ -11,7 +11,8 @@ files at build time and compiled against a minimal OpenCV / Eigen stand-in (orac
     pixel, so the test reports the fraction of pixels that agree and bounds the median relative difference).
 
 Since the end of round 3 the post-filters are in the verbatim set too: DepthMapsData::RemoveSmallSegments, GapInterpolation (SceneDensify.cpp:809-1045) and FilterDepthMap
-(:1049-1299); oracle/filter_oracle.cpp must equal them bit for bit (last three groups of tests).
+(:1049-1299), and SemiGlobalMatcher's steps around Match -- ConsistencyCrossCheck, FilterByCost, ExtractMask, FlipDirection, UpscaleMask, RefineDisparityMap
+(SemiGlobalMatcher.cpp:1446-1811); oracle/filter_oracle.cpp and oracle/sgm_post_oracle.cpp must equal them bit for bit (last groups of tests).
 
 The libraries are built where /root/reference exists (oracle/ref/build_ref.py, by __graft_entry__.build()); elsewhere the prebuilt files are used and the
 tests skip if there are none."""
@@ -342,3 +343,52 @@ def test_filter_depth_map_refuses_too_few_neighbours(scene, estimated):
     a = po.filter_depth_map(depths, confs, sc.K, sc.R, sc.C, 0, [1], 1.0, 10.0, nMinViewsFilter=2)
     b = pr.ref_filter_depth_map(depths, confs, sc.K, sc.R, sc.C, 0, [1], 1.0, 10.0, nMinViewsFilter=2)
     assert a[0] == b[0] == 1
+
+
+# ---- the steps around Match: ConsistencyCrossCheck, FilterByCost, ExtractMask, UpscaleMask, FlipDirection, RefineDisparityMap (SemiGlobalMatcher.cpp:1446-1811) ----
+sgm_only = pytest.mark.skipif(not pr.sgm_available(), reason="oracle/_ref/libref_sgm.so not built")
+NO_DISP = np.iinfo(np.int16).max          # SemiGlobalMatcher.h: NO_DISP = DECLARE_NO_INDEX(Disparity) = the type's maximum
+
+
+def _disp_maps(seed, w=97, h=61):
+    r = np.random.RandomState(seed)
+    base = (r.randint(-12, 13, (h, 1)) + r.randint(-2, 3, (h, w))).astype(np.int16)
+    l2r = base.copy(); r2l = (-np.roll(base, 3, axis=1) + r.randint(-1, 2, (h, w))).astype(np.int16)
+    l2r[r.rand(h, w) < 0.15] = NO_DISP; r2l[r.rand(h, w) < 0.15] = NO_DISP
+    l2r[:, :r.randint(1, 6)] = NO_DISP                                # invalid margins, as a matcher leaves them
+    cost = r.randint(0, 2000, (h, w)).astype(np.uint16)
+    return l2r, r2l, cost
+
+
+@sgm_only
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_sgm_steps_are_the_reference_functions(seed):
+    L = pr.sgm_post_lib(); kw = dict(impl=L, prefix="ref_sgm_")
+    l2r, r2l, cost = _disp_maps(seed)
+    for th in (0, 1, 2):
+        assert np.array_equal(po.sgm_cross_check(l2r, r2l, th), po.sgm_cross_check(l2r, r2l, th, **kw)), "ConsistencyCrossCheck"
+    narrow = r2l[:, :80]                                              # maps of different widths (rectified pairs are)
+    assert np.array_equal(po.sgm_cross_check(l2r, narrow, 1), po.sgm_cross_check(l2r, narrow, 1, **kw))
+    for th in (300, 1200):
+        assert np.array_equal(po.sgm_filter_by_cost(l2r, cost, th), po.sgm_filter_by_cost(l2r, cost, th, **kw)), "FilterByCost"
+    for tv in (1, 3, 6):
+        m0 = po.sgm_extract_mask(l2r, None, tv); m1 = po.sgm_extract_mask(l2r, None, tv, **kw)
+        assert np.array_equal(m0, m1), "ExtractMask (fresh mask)"
+        assert np.array_equal(po.sgm_extract_mask(r2l, m0, tv), po.sgm_extract_mask(r2l, m0, tv, **kw)), "ExtractMask (given mask)"
+        for size2x in ((2 * l2r.shape[1] + 6, 2 * l2r.shape[0] + 6), (2 * l2r.shape[1] + 7, 2 * l2r.shape[0] + 5)):
+            assert np.array_equal(po.sgm_upscale_mask(m0, size2x), po.sgm_upscale_mask(m0, size2x, **kw)), "UpscaleMask"
+    assert np.array_equal(po.sgm_flip_direction(l2r), po.sgm_flip_direction(l2r, **kw)), "FlipDirection"
+
+
+@sgm_only
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6])
+def test_sgm_refine_is_the_reference_function(mode):
+    from tests import sgm_cases as scs
+    w, h = 96, 64
+    lb, lg, rg = scs.stereo_pair(w, h, 5, seed=11)
+    px, n, mx = scs.ranges(w, h, "ragged", -6, 20, seed=4)
+    P2s = po.sgm_generate_p2s()
+    d, c, costs, acc = po.sgm_match(lb, lg, rg, px, n, mx, 3, P2s)
+    for steps in (1, 4, 7):
+        a = po.sgm_refine(d, px, acc, mode=mode, steps=steps); b = pr.ref_sgm_refine(d, px, acc, mode=mode, steps=steps)
+        assert np.array_equal(a, b), "RefineDisparityMap mode %d steps %d: %d of %d differ" % (mode, steps, int((a != b).sum()), a.size)

@@ -68,13 +68,14 @@ enum { PMF_SMOOTH = 1, PMF_CHANGED = 2, PMF_POK0 = 4, PMF_POK1 = 8 };
 // n0* / n1*: the two neighbours the sweep has already updated (depth, normal, conf), however the caller obtained them; bok / qxs / qys / qis: the four
 // neighbour slots (bounds tests, coordinates, map indices).  afterPatch() runs once the visit's loads have been waited for (the band kernel publishes its
 // previous step there).  Result: r* = what the maps hold at this pixel after the visit, wr = it changed.
-template <int G, int VPL, bool GEO, class AfterPatch>
+template <int G, int VPL, bool GEO, bool VM, class AfterPatch>
 __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, uint32_t pass, int sgn, float2* s_wg, PMPix* s_pixg, const double* hotBase,
 		int g, int v, int slot, bool active, int x, int y, int ySafe, size_t idx, const bool* bok, const int* qxs, const int* qys, const size_t* qis,
 		float n0D, float n0N0, float n0N1, float n0N2, float n0C, float n1D, float n1N0, float n1N1, float n1N2, float n1C,
 		AfterPatch afterPatch, float& rD, float& rN0, float& rN1, float& rN2, float& rC, bool& wr PM_PROF_ARG) {
 	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
 	constexpr int TC = 0;                     // no LDS windows: the optimistic tap rows read the quad image through the vector L1
+	constexpr int PPW = 64 / G;               // VM: lane = v * PPW + g (view-major), else lane = g * G + v
 	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
 	const int yTop = ySafe;
 	// ---- what the visit reads from memory: its own estimate, the two not yet updated neighbours, prior, mask (none of it written earlier in this launch) ----
@@ -100,10 +101,9 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, u
 		PMPix* P = pm_launder(s_pixg);
 		const bool bk = slot == 0 ? bok[0] : slot == 1 ? bok[1] : slot == 2 ? bok[2] : bok[3];
 		const bool okS = valid && bk && myD > 0;
-		const unsigned cm = (unsigned)__ballot(okS) >> 0;   // (ballot of the whole wave; my group's four bits are picked below)
-		const unsigned long long bal = __ballot(okS);
-		const unsigned closeMask = (unsigned)((bal >> (g * G)) & 0xFull);
-		(void)cm;
+		const unsigned long long bal = __ballot(okS);   // (ballot of the whole wave; my pixel's four bits -- its lanes v = 0..3 -- are picked here)
+		const unsigned closeMask = VM ? (unsigned)(((bal >> g) & 1ull) | (((bal >> (PPW + g)) & 1ull) << 1) | (((bal >> (2 * PPW + g)) & 1ull) << 2) | (((bal >> (3 * PPW + g)) & 1ull) << 3))
+		                              : (unsigned)((bal >> (g * G)) & 0xFull);
 		if (v < 4) {
 			// TransformPointI2C(Point3(nx, ndepth)) in double then Cast<float>, Camera.h:338-344
 			const int qx = slot == 0 ? qxs[0] : slot == 1 ? qxs[1] : slot == 2 ? qxs[2] : qxs[3];
@@ -229,7 +229,8 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, u
 				const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
 				myF = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
 			}
-			sf0 = pm_quad_bcast<0>(myF); sf1 = pm_quad_bcast<1>(myF); sf2 = pm_quad_bcast<2>(myF); sf3 = pm_quad_bcast<3>(myF);
+			if (VM) { sf0 = __shfl(myF, g, 64); sf1 = __shfl(myF, PPW + g, 64); sf2 = __shfl(myF, 2 * PPW + g, 64); sf3 = __shfl(myF, 3 * PPW + g, 64); }   // slot k lives in lane v = k of my pixel
+			else { sf0 = pm_quad_bcast<0>(myF); sf1 = pm_quad_bcast<1>(myF); sf2 = pm_quad_bcast<2>(myF); sf3 = pm_quad_bcast<3>(myF); }
 		}
 		// -- score against my source view(s)
 		float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
@@ -245,7 +246,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, u
 				}
 			}
 		}
-		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
+		const float nconf = VM ? pm_aggregate_vm<G>(sc, t.nSrc, kp.thRobust, sc2) : pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
 		{	// -- accept (DepthMap.cpp:794-799, :784-793, :843-851)
 			PMPix* P = pm_launder(s_pixg);
 			if (need && v == 0 && P->conf > nconf) {
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMT
 			n1D = gDepth[qi]; n1N0 = gNormal[qi * 3]; n1N1 = gNormal[qi * 3 + 1]; n1N2 = gNormal[qi * 3 + 2]; n1C = gConf[qi];
 		}
 		float rD, rN0, rN1, rN2, rC; bool wr;
-		pm_visit<G, VPL, GEO>(t, kp, pass, sgn, s_w[g], &s_pix[g], hotBase, g, v, slot, active, x, y, yTop, idx, bok, qxs, qys, qis,
+		pm_visit<G, VPL, GEO, false>(t, kp, pass, sgn, s_w[g], &s_pix[g], hotBase, g, v, slot, active, x, y, yTop, idx, bok, qxs, qys, qis,
 			n0D, n0N0, n0N1, n0N2, n0C, n1D, n1N0, n1N1, n1N2, n1C,
 			[&]() {
 				// The previous step's result is published HERE: its stores were issued before this step's loads, which the patch set-up has just waited
@@ -416,7 +417,11 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMT
 // The same visit, one launch per anti-diagonal (the schedule of pm_sweep_kernel): all pixels of diagonal x + y == d of every view of the group, the
 // two already-updated neighbours read back from the maps (the previous launch wrote them).  For batches large enough to fill the machine with one
 // diagonal this beats the resident band kernel (no hand-offs, no waiting on a preceding band); see DESIGN.md 4.2c for the measured crossover.
-template <int G, int VPL, bool GEO>
+// VM ("view-major" lanes): lane = v * PPW + g instead of g * G + v.  The pixels of a wave lie on an anti-diagonal, so in the anti-diagonal-major quad image the taps
+// of ADJACENT PIXELS against the SAME source view are adjacent 16-byte entries: with view-major lanes the four lanes of a quad read one 64-byte piece of one image
+// (one request to the vector L1 per quad), with pixel-major lanes they read four different images (four requests).  Same values; the per-pixel exchanges
+// (smoothness factors, MINMEAN) go through __shfl instead of DPP.
+template <int G, int VPL, bool GEO, bool VM>
 __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_sweep2_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	constexpr int PPW = 64 / G;
 	constexpr int NV = G * VPL;
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_sweep2_kernel(const P
 	const PMTask& t = tasks[vby];
 	const int lane = threadIdx.x;
 	for (int i = lane; i < NV * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];
-	const int g = lane / G, v = lane % G, slot = v & 3;
+	const int g = VM ? lane % PPW : lane / G, v = VM ? lane / PPW : lane % G, slot = v & 3;
 	const int w = t.w, h = t.h;
 	const int pi = (int)vbx * PPW + g;
 	const bool active = pi < count;
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_sweep2_kernel(const P
 	}
 	__syncthreads();
 	float rD, rN0, rN1, rN2, rC; bool wr;
-	pm_visit<G, VPL, GEO>(t, kp, pass, sgn, s_w[g], &s_pix[g], s_src, g, v, slot, active, x, y, active ? y : PM_HW, active ? idx : (size_t)PM_HW * w + PM_HW, bok, qxs, qys, qis,
+	pm_visit<G, VPL, GEO, VM>(t, kp, pass, sgn, s_w[g], &s_pix[g], s_src, g, v, slot, active, x, y, active ? y : PM_HW, active ? idx : (size_t)PM_HW * w + PM_HW, bok, qxs, qys, qis,
 		n0D, n0N0, n0N1, n0N2, n0C, n1D, n1N0, n1N1, n1N2, n1C, []() {}, rD, rN0, rN1, rN2, rC, wr PM_PROF_PASS);
 	if (wr && v == 0) { gDepth[idx] = rD; gNormal[idx * 3] = rN0; gNormal[idx * 3 + 1] = rN1; gNormal[idx * 3 + 2] = rN2; gConf[idx] = rC; }
 	PM_PROF_FLUSH();

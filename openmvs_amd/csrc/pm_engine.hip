@@ -45,6 +45,9 @@
 #ifndef PMHIP_DEFAULT_DIAG2
 #define PMHIP_DEFAULT_DIAG2 1
 #endif
+#ifndef PMHIP_DEFAULT_VM
+#define PMHIP_DEFAULT_VM 0
+#endif
 #ifndef PMHIP_DEFAULT_BAND
 #define PMHIP_DEFAULT_BAND 0     // 1 = sweeps as one resident launch per iteration (pm_band_kernel); 0 = one launch per anti-diagonal (pm_sweep2_kernel /
                                  // pm_sweep_wide_kernel).  Measured (profiles/r03_variants_call4..6): the resident kernel is bit-identical but 10 % slower at 100
@@ -121,6 +124,8 @@ struct pmhip_engine {
 	int wideMaxViews = PMHIP_DEFAULT_WIDE;   // batches of at most this many views use the one-wave-per-pixel sweep kernel (PMHIP_WIDE)
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
 	int bandMode = PMHIP_DEFAULT_BAND;      // PMHIP_BAND: 1 = resident band kernel, 0 = one launch per anti-diagonal
+	int viewMajor = PMHIP_DEFAULT_VM;       // PMHIP_VM: lanes of pm_sweep2_kernel view-major (lane = view * pixels-per-wave + pixel) instead of pixel-major
+	int probeAlias = 0;                     // PMHIP_PROBE_ALIAS (timing probe, results INVALID): every source view of a reference view reads the image of its first one
 	int diagVisit2 = PMHIP_DEFAULT_DIAG2;   // PMHIP_DIAG2: per-diagonal launches use pm_sweep2_kernel (pm_band.hip's visit body) instead of pm_sweep_kernel
 	unsigned* d_bandCtl = nullptr;          // [0] ticket counter, [1] error flag, then progress[batchCap][bandPairCap] (pm_band.hip)
 	unsigned* d_bandOrder = nullptr; unsigned* h_bandOrder = nullptr;   // (band << 16 | chunk) pairs in ticket order
@@ -347,9 +352,9 @@ static bool launchBand(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* t
 #undef PM_BAND_CASE
 }
 
-template <bool GEO>
+template <bool GEO, bool VM>
 static bool launchSweep2(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
-#define PM_SWEEP2_CASE(g, vpl) case (g) * 16 + (vpl): hipLaunchKernelGGL((pm_sweep2_kernel<g, vpl, GEO>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass); return true
+#define PM_SWEEP2_CASE(g, vpl) case (g) * 16 + (vpl): hipLaunchKernelGGL((pm_sweep2_kernel<g, vpl, GEO, VM>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass); return true
 	switch (G * 16 + VPL) {
 	PM_SWEEP2_CASE(4, 1); PM_SWEEP2_CASE(8, 1); PM_SWEEP2_CASE(16, 1);
 	PM_SWEEP2_CASE(4, 2); PM_SWEEP2_CASE(8, 2);
@@ -485,6 +490,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 				mul33(KR, R0T, s.Hl);
 				for (int i = 0; i < 3; ++i) dC[i] = v.C[i] - sv.C[i];
 				mul31(KR, dC, s.Hm);
+				if (e->probeAlias && k > 0) { s.img = t.src[0].img; s.imgS = t.src[0].imgS; s.imgQ = t.src[0].imgQ; s.w = t.src[0].w; s.h = t.src[0].h; }   // timing probe only
 				s.depth = nullptr;
 				if (geo) {
 					// ViewData::Init geometric part, DepthMap.h:179-184.  cameraDepthMap is the neighbour's own camera when the map is the scene's
@@ -606,8 +612,9 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 						int G2 = SG, V2 = VPL; if (G2 < 4) { V2 = std::max(1, G2 * V2 / 4); G2 = 4; }
 						const int P2 = 64 / G2;
 						const dim3 grid2((unsigned)((count + P2 - 1) / P2), s1 - s0);
-						if (geo) launchSweep2<true>(G2, V2, grid2, st, dt + s0, kp, dir, d, xlo, count, pass);
-						else launchSweep2<false>(G2, V2, grid2, st, dt + s0, kp, dir, d, xlo, count, pass);
+						const bool ok2 = e->viewMajor ? (geo ? launchSweep2<true, true>(G2, V2, grid2, st, dt + s0, kp, dir, d, xlo, count, pass) : launchSweep2<false, true>(G2, V2, grid2, st, dt + s0, kp, dir, d, xlo, count, pass))
+						                              : (geo ? launchSweep2<true, false>(G2, V2, grid2, st, dt + s0, kp, dir, d, xlo, count, pass) : launchSweep2<false, false>(G2, V2, grid2, st, dt + s0, kp, dir, d, xlo, count, pass));
+						if (!ok2) { e->err = "sweep kernel: (lanes per pixel, views per lane) mapping not instantiated"; return PMHIP_E_ARG; }
 						continue;
 					}
 					const dim3 grid((unsigned)((count + SPPB - 1) / SPPB), s1 - s0);
@@ -682,6 +689,8 @@ int pmhip_create(int device, pmhip_engine** out) {
 	const char* bm = getenv("PMHIP_BAND");
 	if (bm) e->bandMode = atoi(bm) != 0;
 	const char* d2 = getenv("PMHIP_DIAG2"); if (d2) e->diagVisit2 = atoi(d2) != 0;
+	const char* vm = getenv("PMHIP_VM"); if (vm) e->viewMajor = atoi(vm) != 0;
+	const char* pa = getenv("PMHIP_PROBE_ALIAS"); if (pa) e->probeAlias = atoi(pa);
 	const char* bc = getenv("PMHIP_BAND_CHUNK"); if (bc && atoi(bc) >= 16) e->bandChunkW = atoi(bc);
 	const char* bs = getenv("PMHIP_BAND_SLACK"); if (bs && atoi(bs) >= 0) e->bandSlack = atoi(bs);
 	const char* nl = getenv("PMHIP_LANES");

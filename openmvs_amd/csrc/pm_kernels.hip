@@ -692,6 +692,20 @@ __device__ __forceinline__ float pm_aggregate(float viewScore, int nSrc, float t
 	return (m1 + m2) / 2.f;
 }
 
+// The same for view-major lanes (lane = v * (64 / G) + g: the lanes of a pixel are 64 / G apart): butterfly over the lane index bits above the pixel index
+template <int G>
+__device__ __forceinline__ float pm_aggregate_vm(float viewScore, int nSrc, float thRobust, float viewScore2) {
+	float a = viewScore, b = viewScore2;
+#pragma unroll
+	for (int m = 64 / G; m < 64; m <<= 1) {
+		const float oa = __shfl_xor(a, m, 64), ob = __shfl_xor(b, m, 64);
+		const float na = pm_minf(a, oa), nb = pm_minf(pm_maxf(a, oa), pm_minf(b, ob)); a = na; b = nb;
+	}
+	if (nSrc <= 1) return a;
+	if (b >= thRobust) return a;
+	return (a + b) / 2.f;
+}
+
 // FillPixelPatch, DepthMap.cpp:422-462: cooperative weights into LDS; returns normSq0, sumW.
 // Must be called by every thread of the workgroup (contains __syncthreads()).
 template <int G, bool SKEW>

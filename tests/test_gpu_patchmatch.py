@@ -125,7 +125,9 @@ SWEEP_VARIANTS = {
     "band_chunks": {"PMHIP_BAND": "1", "PMHIP_BAND_CHUNK": "24", "PMHIP_BAND_SLACK": "5"},   # (band, chunk) tasks: chunk-to-chunk and band-to-band hand-offs
     "band_lanes4": {"PMHIP_BAND": "1", "PMHIP_LANES": "4", "PMHIP_BAND_CHUNK": "40"},
     "legacy_windows": {"PMHIP_BAND": "0", "PMHIP_DIAG2": "0"},                          # round-2 kernel with LDS source windows (pm_sweep_kernel)
-    "diag2": {"PMHIP_BAND": "0", "PMHIP_DIAG2": "1"},                                   # the default, named
+    "diag2": {"PMHIP_BAND": "0", "PMHIP_DIAG2": "1", "PMHIP_VM": "0"},                  # per-diagonal launches, pixel-major lanes
+    "diag2_vm": {"PMHIP_BAND": "0", "PMHIP_DIAG2": "1", "PMHIP_VM": "1"},               # view-major lanes (lane = view * pixels-per-wave + pixel): coalesced quad loads
+    "diag2_vm_lanes4": {"PMHIP_BAND": "0", "PMHIP_DIAG2": "1", "PMHIP_VM": "1", "PMHIP_LANES": "4"},   # the same with two / four source views per lane
 }
 
 

@@ -1,0 +1,47 @@
+"""Round-4 probe: full schedule (photometric pass + 2 geometric rounds) of a V-view 1920x1080 scene under several engine switches, one fresh engine each.
+    python tools/r04/probe_lanes.py V "NAME:K=V,K=V" ...
+Prints seconds per step and Mpix/s per configuration, and whether view 0's depth map equals the first configuration's (probe builds: expected to differ)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+from openmvs_amd import synth
+from openmvs_amd.patchmatch import PatchMatchHIP, default_params
+
+V = int(sys.argv[1]); W, H = 1920, 1080
+configs = []
+for a in sys.argv[2:]:
+    name, _, kv = a.partition(":")
+    configs.append((name, dict(x.split("=") for x in kv.split(",") if x)))
+dev = torch.device("cuda", 0)
+sc = synth.make_scene_torch(V, W, H, n_src=8, device=dev, gt_views=1)
+gray = sc["gray"]; torch.cuda.synchronize()
+p = default_params(seed=1, nEstimationGeometricIters=2)
+ref = None
+steps = int(os.environ.get("PROBE_STEPS", "2"))
+for name, env in configs:
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        e = PatchMatchHIP(0); e.Init(True); e.scene_create(V, W, H, 2)
+        for i in range(V):
+            e.scene_set_view(i, None, sc["K"][i], sc["R"][i], sc["C"][i], float(sc["dmin"][i]), float(sc["dmax"][i]), sc["neighbors"][i])
+        e.scene_copy(0, 0, V, gray.data_ptr(), True); e.sync()
+        allv = list(range(V))
+        best = 1e9
+        for rep in range(1 + steps):
+            for v in allv: e.scene_reset_view(v)
+            e.sync(); t = time.perf_counter()
+            e.scene_estimate(allv, -1, p, sync=False)
+            for g in range(2):
+                e.scene_commit_round(); e.scene_estimate(allv, g, p, sync=False)
+            e.sync(); dt = time.perf_counter() - t
+            if rep: best = min(best, dt)
+        d = e.scene_get_maps(0)[0]
+        if ref is None: ref = d
+        print("%-28s %-60s %.3f s/step  %.2f Mpix/s  same-as-first %s" % (name, env, best, V * W * H / best / 1e6, bool(np.array_equal(d, ref))), flush=True)
+        e.close()
+    finally:
+        for k, v in saved.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v

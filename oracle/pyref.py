@@ -154,3 +154,54 @@ def ref_sgm_refine(disp, pixels, accums, mode=6, steps=4):
     fn = _sgm_lib().ref_sgm_refine_wh; fn.restype = None
     fn(a.ctypes.data_as(C.POINTER(C.c_int16)), px.ctypes.data_as(C.c_void_p), ac.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_uint64(ac.size), C.c_int(vw), C.c_int(vh), C.c_int(mode), C.c_int(steps))
     return a
+
+
+# ---- DepthMapsData::EstimateDepthMap + ScaleDepthData through the reference's own code (oracle/ref/ref_driver_harness.cpp: SceneDensify.cpp:578-601, :616-805 verbatim) ----
+def driver_path(kind: str = "pm_math") -> str:
+    return os.path.join(_HERE, "_ref", "libref_driver.so" if kind == "pm_math" else "libref_driver_libm.so")
+
+
+def driver_available(kind: str = "pm_math") -> bool:
+    if os.path.exists(driver_path(kind)):
+        return True
+    available()
+    return os.path.exists(driver_path(kind))
+
+
+def _driver(kind="pm_math"):
+    key = "driver_" + kind
+    if key not in _LIBS:
+        if not driver_available(kind):
+            raise RuntimeError("oracle/_ref/libref_driver*.so is not built and /root/reference is not here to build it from")
+        po.lib()                                           # libpm_oracle.so (the cv::resize stand-in's resamplers) must exist before the dependent library is loaded
+        l = C.CDLL(driver_path(kind))
+        l.ref_estimate_depth_map.restype = C.c_int
+        l.ref_scale_view.restype = C.c_int
+        _LIBS[key] = l
+    return _LIBS[key]
+
+
+def ref_estimate_depth_map(views, n_views, dmin, dmax, opt, geo_iter=-1, depth=None, normal=None, mask=None, mask_mode=False, kind="pm_math"):
+    """One DepthMapsData::EstimateDepthMap call in the reference's own text (level loop, hand-off, thresholds, threads = opt.nThreads).  Same arguments and results as
+    pyoracle.estimate_depth_map / estimate_depth_map_masked.  The estimators draw from the reference's std::mt19937 (non-release seeding): compare with the oracle at rngMode 2."""
+    h, w = views[0].h, views[0].w
+    depth = np.zeros((h, w), np.float32) if depth is None else np.ascontiguousarray(depth, np.float32).copy()
+    normal = np.zeros((h, w, 3), np.float32) if normal is None else np.ascontiguousarray(normal, np.float32).copy()
+    conf = np.zeros((h, w), np.float32)
+    m = None if mask is None else np.ascontiguousarray(np.asarray(mask) != 0, np.uint8)
+    rc = _driver(kind).ref_estimate_depth_map(views, C.c_int(n_views), _fp(depth), _fp(normal), _fp(conf), C.c_float(dmin), C.c_float(dmax), C.byref(opt), C.c_int(geo_iter),
+                                              None if m is None else m.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(1 if (mask_mode or m is not None) else 0))
+    if rc:
+        raise RuntimeError("ref_estimate_depth_map failed: %d" % rc)
+    return depth, normal, conf
+
+
+def ref_scale_view(view, f):
+    """DepthMapsData::ScaleDepthData of one view by 1 / f: (image, K, depth map or None, Kd or None)."""
+    h, w = view.h, view.w
+    img = np.zeros((h, w), np.float32); dep = np.zeros((h, w), np.float32); K = np.zeros(9); Kd = np.zeros(9); wh = (C.c_int * 2)()
+    rc = _driver().ref_scale_view(C.byref(view), C.c_int(f), _fp(img), K.ctypes.data_as(C.POINTER(C.c_double)), _fp(dep), Kd.ctypes.data_as(C.POINTER(C.c_double)), wh)
+    assert rc == 0
+    nw, nh = wh[0], wh[1]
+    has = bool(view.depth)
+    return img.ravel()[:nw * nh].reshape(nh, nw).copy(), K.reshape(3, 3), (dep.ravel()[:nw * nh].reshape(nh, nw).copy() if has else None), (Kd.reshape(3, 3) if has else None)

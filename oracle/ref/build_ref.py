@@ -19,6 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = os.environ.get("OPENMVS_REFERENCE", "/root/reference")
 OUT = os.path.join(ROOT, "oracle", "_ref")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 # name: (file relative to the reference, first line, last line, text the first line must contain, text the last line must contain)
 SNIPPETS = {
@@ -34,6 +36,7 @@ SNIPPETS = {
     "types_inl_point_ops":   ("libs/Common/Types.inl", 1178, 1366, "// operators", "}"),
     "types_inl_matrix_ops":  ("libs/Common/Types.inl", 1430, 1474, "// TMatrix operators", "}"),
     "types_inl_cast":        ("libs/Common/Types.inl", 1677, 1709, "// Point2", "}"),
+    "types_inl_tmatrix9":    ("libs/Common/Types.inl", 1830, 1839, "template <typename TYPE, int m, int n>", "}"),
     "types_inl_sample":      ("libs/Common/Types.inl", 2270, 2281, "// sample by bilinear interpolation", "}"),
     "types_inl_sample_f":    ("libs/Common/Types.inl", 2296, 2314, "// sample by bilinear interpolation, using only pixels that meet the user condition", "}"),
     "util_inl_project":      ("libs/Common/Util.inl", 380, 386, "// (optimized ProjectVertex for H[3,3] and X[2,1], output pt[3,1])", "} // ProjectVertex_3x3_2_3"),
@@ -44,6 +47,7 @@ SNIPPETS = {
     "rotation_inl_ctors":    ("libs/Common/Rotation.inl", 519, 558, "template <typename TYPE>", "}"),
     "rotation_inl_set":      ("libs/Common/Rotation.inl", 700, 729, "template <typename TYPE>", "}"),
     "random_h":              ("libs/Common/Random.h", 100, 159, "// Encapsulates state for random number generation", "};"),
+    "camera_h_scalek":       ("libs/MVS/Camera.h", 159, 173, "template<typename TYPE>", "}"),
     "camera_h_invk":         ("libs/MVS/Camera.h", 175, 188, "// return K.inv() (assuming standard K format and no shear)", "}"),
     "camera_h_i2c":          ("libs/MVS/Camera.h", 329, 344, "// un-project from image pixel coords to the camera space (z=1 plane by default)", "}"),
     "camera_h_c2w_i2w":      ("libs/MVS/Camera.h", 345, 356, "template <typename TYPE>", "}"),
@@ -53,6 +57,7 @@ SNIPPETS = {
     "plane_inl_distance":    ("libs/Common/Plane.inl", 185, 190, "// Calculate distance to point. Plane normal must be normalized.", "}"),
     "depthmap_h":            ("libs/MVS/DepthMap.h", 41, 468, "// D E F I N E S", "};"),
     "depthmap_cpp_copy":     ("libs/MVS/DepthMap.cpp", 121, 133, "//constructor from reference of DepthData", "{}"),
+    "depthmap_cpp_applymask": ("libs/MVS/DepthMap.cpp", 214, 230, "// apply mask to the depth map", "} // ApplyIgnoreMask"),
     "depthmap_cpp":          ("libs/MVS/DepthMap.cpp", 325, 972, "// create the map for converting index to matrix position", "#endif"),
     "sgm_h_defines":         ("libs/MVS/SemiGlobalMatcher.h", 44, 46, "#define SGM_SIMILARITY_WZNCC 1", "#define SGM_SIMILARITY SGM_SIMILARITY_WZNCC"),
     "sgm_h_class":           ("libs/MVS/SemiGlobalMatcher.h", 57, 206, "// An implementation of the popular Semi-Global Matching (SGM) algorithm.", "};"),
@@ -61,9 +66,14 @@ SNIPPETS = {
     "sgm_cpp_match":         ("libs/MVS/SemiGlobalMatcher.cpp", 863, 1302, "void SemiGlobalMatcher::Match(const ViewData& leftImage", "}"),
     "sgm_cpp_post":          ("libs/MVS/SemiGlobalMatcher.cpp", 1446, 1811, "// Check for consistency between a left-to-right and right-to-left pair of stereo results;", "}"),
     "scenedensify_cpp":      ("libs/MVS/SceneDensify.cpp", 489, 576, "// initialize the confidence map (NCC score map) with the score of the current estimates", "}"),
+    "scenedensify_scale":    ("libs/MVS/SceneDensify.cpp", 578, 601, "DepthData DepthMapsData::ScaleDepthData(const DepthData& inputDeptData, float scale) {", "}"),
+    "scenedensify_estimate": ("libs/MVS/SceneDensify.cpp", 616, 805, "bool DepthMapsData::EstimateDepthMap(IIndex idxImage, int nGeometricIter)", "} // EstimateDepthMap"),
     "scenedensify_filters":  ("libs/MVS/SceneDensify.cpp", 809, 1045, "// filter out small depth segments from the given depth map", "} // GapInterpolation"),
     "scenedensify_filterdm": ("libs/MVS/SceneDensify.cpp", 1049, 1299, "// filter depth-map, one pixel at a time, using confidence based fusion or neighbor pixels", "} // FilterDepthMap"),
 }
+
+
+ALL = ("libref_pm.so", "libref_pm_libm.so", "libref_sgm.so", "libref_driver.so", "libref_driver_libm.so")
 
 
 def cut(dst):
@@ -80,17 +90,22 @@ def cut(dst):
 
 def build(verbose=False):
     if not os.path.isdir(REF):
-        return [p for p in (os.path.join(OUT, n) for n in ("libref_pm.so", "libref_pm_libm.so", "libref_sgm.so")) if os.path.exists(p)]
+        return [p for p in (os.path.join(OUT, n) for n in ALL) if os.path.exists(p)]
     os.makedirs(OUT, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix="refsnip_")
     outs = []
     try:
         cut(tmp)
+        from oracle import pyoracle
+        pyoracle.build()                                                   # libref_driver*.so resolve the oracle's resamplers (cv::resize stand-in) from oracle/libpm_oracle.so
+        link_orc = ["-pthread", "-L", os.path.join(ROOT, "oracle"), "-l:libpm_oracle.so", "-Wl,-rpath,$ORIGIN/.."]
         for name, flags, src in (("libref_pm.so", ["-DREF_MATH_PM"], "ref_harness.cpp"), ("libref_pm_libm.so", [], "ref_harness.cpp"),
-                                 ("libref_sgm.so", ["-DREF_MATH_PM"], "ref_sgm_harness.cpp")):
+                                 ("libref_sgm.so", ["-DREF_MATH_PM"], "ref_sgm_harness.cpp"),
+                                 ("libref_driver.so", ["-DREF_MATH_PM"] + link_orc, "ref_driver_harness.cpp"),
+                                 ("libref_driver_libm.so", ["-O3", "-march=native"] + link_orc, "ref_driver_harness.cpp")):
             out = os.path.join(OUT, name)
-            cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-w", "-I", tmp, "-I", os.path.join(HERE, "shim")] + flags + \
-                  [os.path.join(HERE, src), "-o", out]
+            cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-w", "-I", tmp, "-I", os.path.join(HERE, "shim")] + \
+                  [os.path.join(HERE, src), "-o", out] + flags
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -27,6 +27,7 @@ public:
 	Size_() : width(0), height(0) {}
 	Size_(_Tp w, _Tp h) : width(w), height(h) {}
 	template<typename _Tp2> Size_(const _Tp2& pt, decltype(&_Tp2::x) = nullptr) : width(pt.x), height(pt.y) {}   // Size_(const Point_<_Tp>&), types.hpp
+	template<typename _Tp2> operator Size_<_Tp2>() const { return Size_<_Tp2>(saturate_cast<_Tp2>(width), saturate_cast<_Tp2>(height)); }   // types.hpp
 	_Tp area() const { return width * height; }
 	bool empty() const { return width <= 0 || height <= 0; }
 	_Tp width, height;

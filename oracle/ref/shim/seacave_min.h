@@ -17,6 +17,7 @@
 #include <numeric>
 #include <random>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 #include "opencv_min.h"
@@ -110,6 +111,8 @@ public:
 	inline void Empty() { v.clear(); }
 	inline void Release() { v.clear(); v.shrink_to_fit(); }
 	inline void Reserve(IDX n) { v.reserve((size_t)n); }
+	inline void reserve(IDX n) { v.reserve((size_t)n); }
+	inline TYPE& back() { return v.back(); } inline const TYPE& back() const { return v.back(); }
 	inline void Resize(IDX n) { v.resize((size_t)n); }
 	inline void resize(IDX n) { v.resize((size_t)n); }
 	inline void clear() { v.clear(); }
@@ -138,6 +141,7 @@ public:
 #define CLISTDEF2IDX(TYPE,IDXTYPE) SEACAVE::cList< TYPE, const TYPE&, 2, 16, IDXTYPE >
 #define ARR2IDX(arr) typename std::remove_reference<decltype(arr)>::type::size_type
 #define FOREACH(var, arr) for (ARR2IDX(arr) var=0, var##Size=(arr).size(); var<var##Size; ++var)
+#define FOREACHPTR(var, arr) for (auto var=(arr).begin(), var##End=(arr).end(); var!=var##End; ++var)   // List.h:41
 typedef cList<float, float, 0> FloatArr;          // Types.h:427
 typedef cList<uint32_t, uint32_t, 0> IndexArr;
 
@@ -189,6 +193,7 @@ public:
 	inline void create(int rows, int cols) { create(Size(cols, rows)); }
 	inline void release() { Base::sz = Size(); Base::rows = Base::cols = 0; Base::d.reset(); }
 	inline bool empty() const { return !Base::d; }
+	inline void copyTo(TImage& o) const { o.create(Base::sz); for (size_t i = 0, n = (size_t)Base::sz.width * Base::sz.height; i < n; ++i) o.d.get()[i] = Base::d.get()[i]; }   // cv::Mat::copyTo: deep copy
 	inline int width() const { return Base::sz.width; }
 	inline int height() const { return Base::sz.height; }
 	inline int area() const { return Base::sz.width * Base::sz.height; }
@@ -215,9 +220,21 @@ public:
 	bool empty() const { return bits.empty(); }
 	void create(int w_, int h_) { w = w_; bits.assign((size_t)w_ * h_, 1); }
 	template <typename P> bool isSet(const P& pt) const { return bits[(size_t)pt.y * w + pt.x] != 0; }
+	bool isSet(int r, int c) const { return bits[(size_t)r * w + c] != 0; }
 	std::vector<unsigned char> bits; int w = 0;
 };
-struct Thread { typedef long safe_t; static inline safe_t safeInc(volatile safe_t& v) { return ++v; } };   // one estimator thread: the sequential parity schedule
+// Thread (Common/Thread.h): start / join on std::thread; safeInc is the interlocked increment the pass bodies share (Thread.h: __sync_add_and_fetch)
+struct Thread {
+	typedef long safe_t; typedef void* (*FncStart)(void*);
+	static inline safe_t safeInc(volatile safe_t& v) { return __sync_add_and_fetch(&v, 1); }
+	Thread() {} Thread(Thread&& o) : t(std::move(o.t)) {} Thread(const Thread&) {}
+	bool start(FncStart fn, void* data = nullptr) { join(); t = std::thread([fn, data]() { fn(data); }); return true; }
+	void join() { if (t.joinable()) t.join(); }
+	~Thread() { join(); }
+	std::thread t;
+};
+template<typename T> constexpr T powi(T base, unsigned exp) { T result(1); while (exp) { if (exp & 1) result *= base; exp >>= 1; base *= base; } return result; }   // Types.h:653-663
+#define POWI SEACAVE::powi
 struct CriticalSection {};
 typedef std::string String;
 
@@ -226,6 +243,7 @@ typedef std::string String;
 #include "snip/types_inl_norm.inc"       // Types.inl: norm(TPoint2), norm(TPoint3), norm(TMatrix)
 #include "snip/types_inl_point_ops.inc"  // Types.inl: TPoint2 / TPoint3 operators
 #include "snip/types_inl_matrix_ops.inc" // Types.inl: TMatrix operators
+#include "snip/types_inl_tmatrix9.inc"   // Types.inl:1830-1839: TMatrix(v0 .. v8)
 #include "snip/types_inl_cast.inc"       // Types.inl: Cast<>() overloads
 #include "snip/types_inl_sample.inc"     // Types.inl: TImage::sample (bilinear)
 #include "snip/types_inl_sample_f.inc"   // Types.inl: TImage::sample (bilinear with validity functor)
@@ -265,13 +283,14 @@ typedef uint32_t IIndex;                         // Image.h:48
 class Camera {
 public:
 	KMatrix K; RMatrix R; CMatrix C;
+#include "snip/camera_h_scalek.inc"      // Camera.h:159-173: ScaleK(K, size, newSize), GetScaledK
 #include "snip/camera_h_invk.inc"        // Camera.h: InvK, GetInvK
 #include "snip/camera_h_i2c.inc"         // Camera.h: TransformPointI2C (both)
 #include "snip/camera_h_c2w_i2w.inc"     // Camera.h:345-356: TransformPointC2W, TransformPointI2W (both)
 #include "snip/camera_h_c2i.inc"         // Camera.h:368-374: TransformPointC2I (z = 1 plane)
 #include "snip/camera_h_c2i3_w2c_w2i.inc" // Camera.h:382-394: TransformPointC2I (3D), TransformPointW2C, TransformPointW2I
 };
-struct Image { uint32_t ID; };
+struct Image { uint32_t ID; Camera camera; cv::Size size; inline cv::Size GetSize() const { return size; } };   // Image.h: ID, camera, GetSize() are what the path reads
 typedef CLISTDEFIDX(Image,IIndex) ImageArr;
 struct ViewScore { uint32_t ID; };
 typedef CLISTDEFIDX(ViewScore,IIndex) ViewScoreArr;

@@ -25,7 +25,10 @@ LIBS = {
 
 # per-library extra flags.  libsgmhip: the SLP vectoriser pairs the per-tap multiplies of sgm_cost_px_kernel into v_pk_mul_f32, which costs it ~60 more
 # VGPRs (copies into aligned register pairs) and pushes it into scratch; the packed form is no faster per flop on this part.
-LIB_FLAGS = {"libsgmhip.so": ["-fno-slp-vectorize"]}
+# libpmhip: the vectoriser pairs the bilinear and accumulation arithmetic of the tap rows into v_pk_mul_f32 / v_pk_add_f32 (no faster than two plain ones here) at the
+# price of ~25 v_mov per row to line the operands up in register pairs; the one place a packed instruction pays (the FMAs of the perspective division) is written
+# out as a vector type in pm_math.h.
+LIB_FLAGS = {"libsgmhip.so": ["-fno-slp-vectorize"], "libpmhip.so": ["-fno-slp-vectorize"]}
 
 HOST_LIBS = {"libdmapio.so": (["dmap_io.cpp"], ["../../include/dmapio.h"]),          # plain C++ (g++), no GPU code
              "libmvsfront.so": (["mvs_front.cpp"], ["../../include/mvsfront.h"])}

@@ -1,45 +1,11 @@
-// pm_band.hip -- the sweep as ONE resident launch per iteration ("band" kernel), instead of one launch per anti-diagonal.
-//
-// ProcessPixel (DepthMap.cpp:630-852) at (x, y) reads the estimates its sweep direction has already updated at (x -/+ 1, y) and (x, y -/+ 1) and the
-// not yet updated ones on the other side; any schedule that honours those two edges gives the sequential result.  pm_sweep_kernel
-// honours them with a kernel boundary per anti-diagonal: 2 984 launches per 1080p sweep, each as long as its slowest wave, and a batch too small to
-// fill the machine pays one wave-life per diagonal.  Here a wavefront OWNS a band of PPW = 64 / G image rows of one view for the whole sweep and walks
-// the diagonals itself: at step d its pixel group g sits at (d - y, y), y = first row + g.  Then
-//   * the horizontal neighbour already updated is the group's own previous pixel and the vertical one is the neighbouring group's previous pixel: both are
-//     taken from registers (one cross-lane move), not from memory;
-//   * only the band's edge row needs another wave: the neighbouring band of the same view publishes the pixel of its last row after every step
-//     (agent-scope write-through stores, then a progress counter) and this band waits for "one diagonal behind" before it reads that pixel
-//     (agent-scope loads).  Everything else a step reads from memory -- its own pixel, the two not yet updated neighbours, the prior, the images --
-//     is data no wave writes before this step in this launch, so plain (cached) loads are right;
-//   * bands take tickets from a counter, every view's band k before any band k + 1: a band's predecessor always holds a smaller ticket, hence is
-//     resident or finished -- no assumption about dispatch order, no deadlock whatever the occupancy; waits are bounded and report through ctl[1].
-// The hypotheses, draws, scores and comparisons of a pixel are those of pm_sweep_kernel (the per-visit body below is its body), so the maps are the same bits.
+// pm_band.hip -- the per-pixel visit (ProcessPixel, DepthMap.cpp:630-852) with its state in LDS, and the sweep kernel of large batches built on it:
+// pm_sweep2_kernel, one launch per anti-diagonal, G lanes per pixel and VPL source views per lane.  (The file name is historical: round 3's resident "band"
+// kernel -- one launch per sweep iteration with wave-to-wave hand-offs -- lived here; it was bit-exact and slower than per-diagonal launches everywhere it was
+// measured, profiles/README.md, and is gone.)
 #pragma once
 
 #ifndef PM_BAND_MINWAVES
 #define PM_BAND_MINWAVES 3
-#endif
-#ifndef PM_BAND_SPIN_LIMIT
-#define PM_BAND_SPIN_LIMIT (1 << 21)
-#endif
-
-// agent-scope relaxed accesses (global_load / global_store ... sc1: served by / written through to the memory side, never by this CU's L1)
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ float pm_ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void pm_st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int pm_ld_agent_i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void pm_st_agent_i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void pm_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void pm_nap() { __builtin_amdgcn_s_sleep(8); }
-__device__ __forceinline__ void pm_compiler_fence() { asm volatile("" ::: "memory"); }
-#else
-__device__ __forceinline__ void pm_compiler_fence() {}
-__device__ __forceinline__ float pm_ld_agent(const float* p) { return *p; }
-__device__ __forceinline__ void pm_st_agent(float* p, float v) { *p = v; }
-__device__ __forceinline__ int pm_ld_agent_i(const int* p) { return *p; }
-__device__ __forceinline__ void pm_st_agent_i(int* p, int v) { *p = v; }
-__device__ __forceinline__ void pm_drain_stores() {}
-__device__ __forceinline__ void pm_nap() {}
 #endif
 
 // Per-pixel state of a visit, in LDS.  The G lanes of a pixel all need it and all hold the same values, so one lane writes and all read: what lives in
@@ -68,14 +34,12 @@ enum { PMF_SMOOTH = 1, PMF_CHANGED = 2, PMF_POK0 = 4, PMF_POK1 = 8 };
 // n0* / n1*: the two neighbours the sweep has already updated (depth, normal, conf), however the caller obtained them; bok / qxs / qys / qis: the four
 // neighbour slots (bounds tests, coordinates, map indices).  afterPatch() runs once the visit's loads have been waited for (the band kernel publishes its
 // previous step there).  Result: r* = what the maps hold at this pixel after the visit, wr = it changed.
-template <int G, int VPL, bool GEO, bool VM, class AfterPatch>
-__device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, uint32_t pass, int sgn, float2* s_wg, PMPix* s_pixg, const double* hotBase,
+template <int G, int VPL, bool GEO, bool BUF>
+__device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, const pm_rsrc& rs, uint32_t pass, int sgn, float2* s_wg, PMPix* s_pixg, const double* hotBase,
 		int g, int v, int slot, bool active, int x, int y, int ySafe, size_t idx, const bool* bok, const int* qxs, const int* qys, const size_t* qis,
 		float n0D, float n0N0, float n0N1, float n0N2, float n0C, float n1D, float n1N0, float n1N1, float n1N2, float n1C,
-		AfterPatch afterPatch, float& rD, float& rN0, float& rN1, float& rN2, float& rC, bool& wr PM_PROF_ARG) {
+		float& rD, float& rN0, float& rN1, float& rN2, float& rC, bool& wr PM_PROF_ARG) {
 	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
-	constexpr int TC = 0;                     // no LDS windows: the optimistic tap rows read the quad image through the vector L1
-	constexpr int PPW = 64 / G;               // VM: lane = v * PPW + g (view-major), else lane = g * G + v
 	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
 	const int yTop = ySafe;
 	// ---- what the visit reads from memory: its own estimate, the two not yet updated neighbours, prior, mask (none of it written earlier in this launch) ----
@@ -92,7 +56,6 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, u
 	}
 	float normSq0, sumW;
 	pm_fill_patch<G, true>(t, active, active ? x : PM_HW, active ? y : yTop, v, s_wg, normSq0, sumW);
-	afterPatch();
 	const bool masked = active && maskByte == 0;
 	const bool valid = active && !masked && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
 	if (v == 0) s_wg[PM_NT] = make_float2(prior, prior > 0 ? pm_expf(normSq0 * (-1.f / (1.f * 0.02f))) : 0.f);
@@ -102,8 +65,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, u
 		const bool bk = slot == 0 ? bok[0] : slot == 1 ? bok[1] : slot == 2 ? bok[2] : bok[3];
 		const bool okS = valid && bk && myD > 0;
 		const unsigned long long bal = __ballot(okS);   // (ballot of the whole wave; my pixel's four bits -- its lanes v = 0..3 -- are picked here)
-		const unsigned closeMask = VM ? (unsigned)(((bal >> g) & 1ull) | (((bal >> (PPW + g)) & 1ull) << 1) | (((bal >> (2 * PPW + g)) & 1ull) << 2) | (((bal >> (3 * PPW + g)) & 1ull) << 3))
-		                              : (unsigned)((bal >> (g * G)) & 0xFull);
+		const unsigned closeMask = (unsigned)((bal >> (g * G)) & 0xFull);
 		if (v < 4) {
 			// TransformPointI2C(Point3(nx, ndepth)) in double then Cast<float>, Camera.h:338-344
 			const int qx = slot == 0 ? qxs[0] : slot == 1 ? qxs[1] : slot == 2 ? qxs[2] : qxs[3];
@@ -229,8 +191,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, u
 				const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
 				myF = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
 			}
-			if (VM) { sf0 = __shfl(myF, g, 64); sf1 = __shfl(myF, PPW + g, 64); sf2 = __shfl(myF, 2 * PPW + g, 64); sf3 = __shfl(myF, 3 * PPW + g, 64); }   // slot k lives in lane v = k of my pixel
-			else { sf0 = pm_quad_bcast<0>(myF); sf1 = pm_quad_bcast<1>(myF); sf2 = pm_quad_bcast<2>(myF); sf3 = pm_quad_bcast<3>(myF); }
+			sf0 = pm_quad_bcast<0>(myF); sf1 = pm_quad_bcast<1>(myF); sf2 = pm_quad_bcast<2>(myF); sf3 = pm_quad_bcast<3>(myF);
 		}
 		// -- score against my source view(s)
 		float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
@@ -240,13 +201,13 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, u
 			for (int u = 0; u < VPL; ++u) {
 				const int vw = v + u * G;
 				if (need && vw < t.nSrc) {
-					const float s1 = pm_score_view<GEO, true, TC, true>(t.src[vw], t, kp, P->x, P->y, P->X0x, P->X0y, P->normSq0, P->sumW, s_wg, hd, hnx, hny, hnz, sf0, sf1, sf2, sf3, 0.f,
-						nullptr, 0, 0, hotBase + vw * NBD, hotBase + vw * NBD + PM_SRC_HOT, nullptr PM_PROF_PASS);
+					const float s1 = pm_score_view<GEO, BUF ? 2 : 1, true>(t.src[vw], t, kp, P->x, P->y, P->X0x, P->X0y, P->normSq0, P->sumW, s_wg, hd, hnx, hny, hnz, sf0, sf1, sf2, sf3, 0.f,
+						hotBase + vw * NBD, hotBase + vw * NBD + PM_SRC_HOT, rs PM_PROF_PASS);
 					if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
 				}
 			}
 		}
-		const float nconf = VM ? pm_aggregate_vm<G>(sc, t.nSrc, kp.thRobust, sc2) : pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
+		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
 		{	// -- accept (DepthMap.cpp:794-799, :784-793, :843-851)
 			PMPix* P = pm_launder(s_pixg);
 			if (need && v == 0 && P->conf > nconf) {
@@ -267,161 +228,11 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, u
 	}
 }
 
-// ctl[0] = ticket counter, ctl[1] = error flag (a bounded wait gave up); progress[view * nBands + band] = 1 + sequence number of the band's last finished step
-template <int G, int VPL, bool GEO>
-__global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_band_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, uint32_t pass, int nViews, int nBands,
-		int nChunks, int chunkW, const unsigned* __restrict__ order, unsigned* __restrict__ ctl, int* __restrict__ progress) {
-	constexpr int PPW = 64 / G;               // pixels (= rows) per wave
-	constexpr int NV = G * VPL;
-	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
-	constexpr int TC = 0;                     // no LDS windows: the optimistic tap rows read the anti-diagonal-major image through the vector L1
-	static_assert(G >= 4, "the band kernel gives every pixel a quad of lanes (one smoothness slot per lane); fewer sources are padded");
-	PM_PROF_DECL;
-	__shared__ float2 s_w[PPW][PM_NT + 1];
-	__shared__ double s_src[NV * NBD];
-	__shared__ PMPix s_pix[PPW];
-	const int lane = threadIdx.x;
-	unsigned ticket = 0;
-	if (lane == 0) ticket = atomicAdd(&ctl[0], 1u);
-	ticket = (unsigned)__shfl((int)ticket, 0, 64);
-	// A task = (view, band of PPW rows, chunk of chunkW columns).  order[] lists (band, chunk) pairs, in sweep order, sorted so that both predecessors of a
-	// task -- the band before it (same chunk) and the chunk before it (same band) -- come earlier; every view's k-th pair gets its ticket before any (k+1)-th.
-	const int entry = (int)(ticket / (unsigned)nViews), view = (int)(ticket - (unsigned)entry * (unsigned)nViews);
-	if (entry >= nBands * nChunks) return;
-	const unsigned oe = order[entry];
-	const int band = dir == 0 ? (int)(oe >> 16) : nBands - 1 - (int)(oe >> 16);
-	const int chunk = dir == 0 ? (int)(oe & 0xffffu) : nChunks - 1 - (int)(oe & 0xffffu);
-	const PMTask& t = tasks[view];
-	for (int i = lane; i < NV * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];   // views >= nSrc: zeros (the task is memset), never used
-	const double* hotBase = s_src;
-	const int g = lane / G, v = lane % G;
-	const int slot = v & 3;                                   // my smoothness slot (every quad of a group holds all four)
-	const int sgn = dir == 0 ? -1 : 1;
-	// the estimate this lane's pixel group left at its previous step (the horizontal "new" neighbour of the next one)
-	float pvD = 0.f, pvN0 = 0.f, pvN1 = 0.f, pvN2 = 0.f, pvC = 2.f;
-	__syncthreads();
-	int* const progBase = progress + ((size_t)view * nBands) * nChunks;          // [band][chunk] of this view
-	{	// the chunk before this one in the sweep direction must be complete: its last column is this chunk's first horizontal neighbour
-		const int hp = chunk + sgn;
-		if (hp >= 0 && hp < nChunks) {
-			int spins = 0;
-			while (pm_ld_agent_i(progBase + (size_t)band * nChunks + hp) != 0x7fffffff) {
-				pm_nap();
-				if (++spins > PM_BAND_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctl[1], 1u); break; }
-			}
-			pm_compiler_fence();
-		}
-	}
-	int pend = 0;                                                // progress value of the previous step, published once its stores have drained (below)
-	int seen = 0;                                                // last progress value read of the preceding band: no poll while it is known to be ahead
-	const int nSteps = [&]() { const int yT = PM_HW + band * PPW; const int r = min(PPW, (t.h - PM_HW) - yT);
-		const int xa = PM_HW + chunk * chunkW, xb = min(xa + chunkW - 1, t.w - 1 - PM_HW); return (xb + (yT + r - 1)) - (xa + yT) + 1; }();
-	for (int s = 0; s < nSteps; ++s) {
-		const int w = t.w, h = t.h;
-		const int yTop = PM_HW + band * PPW;
-		const int rows = min(PPW, (h - PM_HW) - yTop);       // rows of this band that are processable (y <= h-1-HW)
-		const int y = yTop + g;
-		const int xc0 = PM_HW + chunk * chunkW, xc1 = min(xc0 + chunkW - 1, w - 1 - PM_HW);   // columns of this chunk
-		const int dLo = xc0 + yTop, dHi = xc1 + (yTop + rows - 1);
-		const int d = dir == 0 ? dLo + s : dHi - s;
-		const int q = dir == 0 ? d : (w - 1 - PM_HW) + (h - 1 - PM_HW) - d;   // sequence number of this diagonal in sweep order
-		const int x = d - y;
-		const bool active = g < rows && x >= xc0 && x <= xc1;
-		const size_t idx = active ? (size_t)y * w + x : (size_t)yTop * w + PM_HW;
-		const int predBand = band + sgn, succBand = band - sgn;
-		const bool predExists = predBand >= 0 && predBand < nBands, succExists = succBand >= 0 && succBand < nBands;
-		const int gCons = dir == 0 ? 0 : rows - 1;          // the group whose vertical neighbour lives in the preceding band
-		const int gPub = dir == 0 ? rows - 1 : 0;           // the group the following band reads
-		const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
-		// ---- the two already-updated neighbours: slot0 (x+sgn, y) = my previous pixel, slot1 (x, y+sgn) = the neighbouring group's previous pixel ----
-		// bounds tests exactly as written in the reference: x > HW / y > HW / x < W-HW / y < H-HW
-		bool bok[4]; int qxs[4], qys[4]; size_t qis[4];
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int ox = (k == 0) ? sgn : (k == 2 ? -sgn : 0), oy = (k == 1) ? sgn : (k == 3 ? -sgn : 0);
-			bool ok;
-			if (ox == -1) ok = x > PM_HW; else if (ox == 1) ok = x < w - PM_HW; else if (oy == -1) ok = y > PM_HW; else ok = y < h - PM_HW;
-			bok[k] = ok && active; qxs[k] = x + ox; qys[k] = y + oy;
-			qis[k] = bok[k] ? (size_t)(y + oy) * w + (x + ox) : idx;
-		}
-		// vertical neighbour from the adjacent group's registers (its pixel of the previous step is exactly (x, y+sgn))
-		const int srcLane = min(max(lane + sgn * G, 0), 63);
-		float n1D = __shfl(pvD, srcLane, 64), n1N0 = __shfl(pvN0, srcLane, 64), n1N1 = __shfl(pvN1, srcLane, 64), n1N2 = __shfl(pvN2, srcLane, 64), n1C = __shfl(pvC, srcLane, 64);
-		// ... or, for the band's edge row, from the preceding band: wait until it is at most one diagonal behind, then read what it published
-		{
-			const int xc = d - (yTop + gCons);
-			const bool needPred = predExists && xc >= xc0 && xc <= xc1;   // wave-uniform
-			if (needPred) {
-				const int* const predProgress = progBase + (size_t)predBand * nChunks + chunk;
-				if (seen < q) {
-					int spins = 0;
-					while ((seen = pm_ld_agent_i(predProgress)) < q) {
-						pm_nap();
-						if (++spins > PM_BAND_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctl[1], 1u); break; }
-					}
-				}
-				pm_compiler_fence();                                 // the reads below stay behind the successful poll
-				if (g == gCons && active) {
-					const size_t qi = qis[1];
-					n1D = pm_ld_agent((const float*)t.depth + qi); n1C = pm_ld_agent((const float*)t.conf + qi);
-					n1N0 = pm_ld_agent((const float*)t.normal + qi * 3); n1N1 = pm_ld_agent((const float*)t.normal + qi * 3 + 1); n1N2 = pm_ld_agent((const float*)t.normal + qi * 3 + 2);
-				}
-			}
-		}
-		float n0D = pvD, n0N0 = pvN0, n0N1 = pvN1, n0N2 = pvN2, n0C = pvC;
-		// The reference's bounds tests (x < W-HW, y < H-HW) let the RB2LT sweep look at the first column / row BEYOND the processable area; no sweep
-		// ever writes there, so those neighbours are what the init pass left in the maps: read them from memory.
-		if (bok[0] && (x + sgn < PM_HW || x + sgn > w - 1 - PM_HW)) {
-			const size_t qi = qis[0];
-			n0D = gDepth[qi]; n0N0 = gNormal[qi * 3]; n0N1 = gNormal[qi * 3 + 1]; n0N2 = gNormal[qi * 3 + 2]; n0C = gConf[qi];
-		} else if (bok[0] && (x + sgn < xc0 || x + sgn > xc1)) {
-			// first column of the chunk: the horizontal neighbour is the last column of the preceding chunk (complete, written through)
-			const size_t qi = qis[0];
-			n0D = pm_ld_agent((const float*)t.depth + qi); n0C = pm_ld_agent((const float*)t.conf + qi);
-			n0N0 = pm_ld_agent((const float*)t.normal + qi * 3); n0N1 = pm_ld_agent((const float*)t.normal + qi * 3 + 1); n0N2 = pm_ld_agent((const float*)t.normal + qi * 3 + 2);
-		}
-		if (bok[1] && (y + sgn < PM_HW || y + sgn > h - 1 - PM_HW)) {
-			const size_t qi = qis[1];
-			n1D = gDepth[qi]; n1N0 = gNormal[qi * 3]; n1N1 = gNormal[qi * 3 + 1]; n1N2 = gNormal[qi * 3 + 2]; n1C = gConf[qi];
-		}
-		float rD, rN0, rN1, rN2, rC; bool wr;
-		pm_visit<G, VPL, GEO, false>(t, kp, pass, sgn, s_w[g], &s_pix[g], hotBase, g, v, slot, active, x, y, yTop, idx, bok, qxs, qys, qis,
-			n0D, n0N0, n0N1, n0N2, n0C, n1D, n1N0, n1N1, n1N2, n1C,
-			[&]() {
-				// The previous step's result is published HERE: its stores were issued before this step's loads, which the patch set-up has just waited
-				// for, so draining them costs nothing now (at the end of the previous step it was a full write-through round trip on the critical path).
-				if (pend) {
-					pm_drain_stores();
-					if (lane == 0) pm_st_agent_i(progBase + (size_t)band * nChunks + chunk, pend);
-					pend = 0;
-				}
-			}, rD, rN0, rN1, rN2, rC, wr PM_PROF_PASS);
-		// ---- result of the step: what the map holds at this pixel from now on ----
-		pvD = rD; pvN0 = rN0; pvN1 = rN1; pvN2 = rN2; pvC = rC;
-		if (wr && v == 0) {
-			const bool lastCol = dir == 0 ? (x == xc1 && chunk + 1 < nChunks) : (x == xc0 && chunk > 0);
-			if ((succExists && g == gPub) || lastCol) {
-				// the following band (or the following chunk) reads this pixel while the launch runs: write it through
-				pm_st_agent((float*)t.depth + idx, rD); pm_st_agent((float*)t.normal + idx * 3, rN0); pm_st_agent((float*)t.normal + idx * 3 + 1, rN1);
-				pm_st_agent((float*)t.normal + idx * 3 + 2, rN2); pm_st_agent((float*)t.conf + idx, rC);
-			} else { gDepth[idx] = rD; gNormal[idx * 3] = rN0; gNormal[idx * 3 + 1] = rN1; gNormal[idx * 3 + 2] = rN2; gConf[idx] = rC; }
-		}
-		if (succExists) pend = q + 1;
-		__syncthreads();                                         // the next step rewrites s_pix / s_w
-	}
-	pm_drain_stores();                                           // the last column has left this wave: the next chunk and the next band may read it
-	if (lane == 0) pm_st_agent_i(progBase + (size_t)band * nChunks + chunk, 0x7fffffff);
-	PM_PROF_FLUSH();
-}
-
-// The same visit, one launch per anti-diagonal (the schedule of pm_sweep_kernel): all pixels of diagonal x + y == d of every view of the group, the
-// two already-updated neighbours read back from the maps (the previous launch wrote them).  For batches large enough to fill the machine with one
-// diagonal this beats the resident band kernel (no hand-offs, no waiting on a preceding band); see DESIGN.md 4.2c for the measured crossover.
-// VM ("view-major" lanes): lane = v * PPW + g instead of g * G + v.  The pixels of a wave lie on an anti-diagonal, so in the anti-diagonal-major quad image the taps
-// of ADJACENT PIXELS against the SAME source view are adjacent 16-byte entries: with view-major lanes the four lanes of a quad read one 64-byte piece of one image
-// (one request to the vector L1 per quad), with pixel-major lanes they read four different images (four requests).  Same values; the per-pixel exchanges
-// (smoothness factors, MINMEAN) go through __shfl instead of DPP.
-template <int G, int VPL, bool GEO, bool VM>
+// One launch per anti-diagonal: all pixels of diagonal x + y == d of every view of the group, in place; the two already-updated neighbours are read back from the
+// maps (the previous launch wrote them); launches on one stream order the diagonals.
+// (Measured and dropped in round 4: "view-major" lanes -- lane = view * pixels-per-wave + pixel, so that the four lanes of a quad read adjacent entries of one quad
+// image -- 43.1 vs 42.6 Mpix/s at 100 views, 28.1 vs 28.3 at 25: the order in which a wave's addresses reach the vector L1 is not what bounds the kernel.)
+template <int G, int VPL, bool GEO, bool BUF>
 __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_sweep2_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	constexpr int PPW = 64 / G;
 	constexpr int NV = G * VPL;
@@ -440,9 +251,10 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_sweep2_kernel(const P
 		vby = wgid / nbx; vbx = wgid - vby * nbx;
 	}
 	const PMTask& t = tasks[vby];
+	const pm_rsrc rs = pm_make_rsrc(t.qArr, t.qCount);
 	const int lane = threadIdx.x;
 	for (int i = lane; i < NV * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];
-	const int g = VM ? lane % PPW : lane / G, v = VM ? lane / PPW : lane % G, slot = v & 3;
+	const int g = lane / G, v = lane % G, slot = v & 3;
 	const int w = t.w, h = t.h;
 	const int pi = (int)vbx * PPW + g;
 	const bool active = pi < count;
@@ -467,8 +279,8 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_sweep2_kernel(const P
 	}
 	__syncthreads();
 	float rD, rN0, rN1, rN2, rC; bool wr;
-	pm_visit<G, VPL, GEO, VM>(t, kp, pass, sgn, s_w[g], &s_pix[g], s_src, g, v, slot, active, x, y, active ? y : PM_HW, active ? idx : (size_t)PM_HW * w + PM_HW, bok, qxs, qys, qis,
-		n0D, n0N0, n0N1, n0N2, n0C, n1D, n1N0, n1N1, n1N2, n1C, []() {}, rD, rN0, rN1, rN2, rC, wr PM_PROF_PASS);
+	pm_visit<G, VPL, GEO, BUF>(t, kp, rs, pass, sgn, s_w[g], &s_pix[g], s_src, g, v, slot, active, x, y, active ? y : PM_HW, active ? idx : (size_t)PM_HW * w + PM_HW, bok, qxs, qys, qis,
+		n0D, n0N0, n0N1, n0N2, n0C, n1D, n1N0, n1N1, n1N2, n1C, rD, rN0, rN1, rN2, rC, wr PM_PROF_PASS);
 	if (wr && v == 0) { gDepth[idx] = rD; gNormal[idx * 3] = rN0; gNormal[idx * 3 + 1] = rN1; gNormal[idx * 3 + 2] = rN2; gConf[idx] = rC; }
 	PM_PROF_FLUSH();
 }

@@ -27,7 +27,7 @@
                                 // 25: 28.2 / - / 32.5; the four-wide kernel is between the two (13 views: 21.1)
 #endif
 #ifndef PMHIP_DEFAULT_LANES
-#define PMHIP_DEFAULT_LANES 0    // sweep kernels: lanes per pixel; 0 = by batch size (one view per lane for small batches, four lanes and two views per lane
+#define PMHIP_DEFAULT_LANES 0    // sweep kernel: lanes per pixel; 0 = by batch size (one view per lane for small batches, four lanes and two views per lane
                                  // from PMHIP_LANES4_FROM reference views on: measured 41.2 vs 39.7 Mpix/s at 100 views, 11.5 vs 16.6 at 13, profiles/r03_variants_call6_sweep2.log)
 #ifndef PMHIP_LANES4_FROM
 #define PMHIP_LANES4_FROM 80     // measured (profiles/r03_variants_call21_mid_batches.log): one view per lane wins up to 70 reference views (25: 28.2 vs 21.2, 50: 36.8 vs 33.3, 70: 38.9 vs 38.2 Mpix/s), two per lane at 100 (42.9 vs 41.5)
@@ -36,24 +36,6 @@
 #ifndef PMHIP_DEFAULT_GROUPS
 #define PMHIP_DEFAULT_GROUPS 2
 #endif
-#ifndef PMHIP_DEFAULT_BAND_CHUNK
-#define PMHIP_DEFAULT_BAND_CHUNK 256   // columns per band task
-#endif
-#ifndef PMHIP_DEFAULT_BAND_SLACK
-#define PMHIP_DEFAULT_BAND_SLACK 16    // ticket order: a band starts this many diagonals after the band it follows (>= rows per band for a legal order)
-#endif
-#ifndef PMHIP_DEFAULT_DIAG2
-#define PMHIP_DEFAULT_DIAG2 1
-#endif
-#ifndef PMHIP_DEFAULT_VM
-#define PMHIP_DEFAULT_VM 0
-#endif
-#ifndef PMHIP_DEFAULT_BAND
-#define PMHIP_DEFAULT_BAND 0     // 1 = sweeps as one resident launch per iteration (pm_band_kernel); 0 = one launch per anti-diagonal (pm_sweep2_kernel /
-                                 // pm_sweep_wide_kernel).  Measured (profiles/r03_variants_call4..6): the resident kernel is bit-identical but 10 % slower at 100
-                                 // views and 13 % at 13 -- its band-to-band waits cost more than the kernel boundaries they replace -- so it is not the default.
-#endif
-
 namespace {
 
 #define HIPCHK(e, call) do { hipError_t _r = (call); if (_r != hipSuccess) { (e)->err = std::string(#call) + ": " + hipGetErrorString(_r); return PMHIP_E_HIP; } } while (0)
@@ -123,14 +105,8 @@ struct pmhip_engine {
 	int wideHyps = 0;                        // hypotheses per round of the speculative kernel: 0 = by batch size (8 for one or two views, else 2); PMHIP_WIDE_HYPS = 8 / 4 / 2 fixes it
 	int wideMaxViews = PMHIP_DEFAULT_WIDE;   // batches of at most this many views use the one-wave-per-pixel sweep kernel (PMHIP_WIDE)
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
-	int bandMode = PMHIP_DEFAULT_BAND;      // PMHIP_BAND: 1 = resident band kernel, 0 = one launch per anti-diagonal
-	int viewMajor = PMHIP_DEFAULT_VM;       // PMHIP_VM: lanes of pm_sweep2_kernel view-major (lane = view * pixels-per-wave + pixel) instead of pixel-major
-	int probeAlias = 0;                     // PMHIP_PROBE_ALIAS (timing probe, results INVALID): every source view of a reference view reads the image of its first one
-	int diagVisit2 = PMHIP_DEFAULT_DIAG2;   // PMHIP_DIAG2: per-diagonal launches use pm_sweep2_kernel (pm_band.hip's visit body) instead of pm_sweep_kernel
-	unsigned* d_bandCtl = nullptr;          // [0] ticket counter, [1] error flag, then progress[batchCap][bandPairCap] (pm_band.hip)
-	unsigned* d_bandOrder = nullptr; unsigned* h_bandOrder = nullptr;   // (band << 16 | chunk) pairs in ticket order
-	int bandPairCap = 0;
-	int bandChunkW = PMHIP_DEFAULT_BAND_CHUNK, bandSlack = PMHIP_DEFAULT_BAND_SLACK;   // PMHIP_BAND_CHUNK, PMHIP_BAND_SLACK
+	int quadBuffer = 1;                     // tap rows address the level's quad images as one buffer (entry index); 0 = through each view's own pointer (PMHIP_QUADBUF; forced for
+	                                        // batches that read a source view with its own image size, which lives outside the level's buffer)
 	hipStream_t gstream[16] = {};
 	hipEvent_t forkEv = nullptr, joinEv[16] = {};
 	bool inited = false, geom = false;
@@ -206,8 +182,6 @@ static void freeScene(pmhip_engine* e) {
 	e->d_fdepth = e->d_fconf = nullptr; e->d_fvalid = nullptr; e->d_splat = nullptr; e->d_ftasks = nullptr; e->h_ftasks = nullptr; e->splatCap = e->ftaskCap = 0;
 	if (e->d_tasks) hipFree(e->d_tasks); if (e->h_tasks) hipHostFree(e->h_tasks);
 	if (e->d_ups) hipFree(e->d_ups); if (e->h_ups) hipHostFree(e->h_ups);
-	if (e->d_bandCtl) hipFree(e->d_bandCtl); if (e->d_bandOrder) hipFree(e->d_bandOrder); if (e->h_bandOrder) hipHostFree(e->h_bandOrder);
-	e->d_bandCtl = nullptr; e->d_bandOrder = nullptr; e->h_bandOrder = nullptr; e->bandPairCap = 0;
 	e->d_tasks = nullptr; e->h_tasks = nullptr; e->d_ups = nullptr; e->h_ups = nullptr;
 	for (SceneView& v : e->views) freeSide(v);
 	e->batchCap = 0; e->nImages = 0; e->views.clear();
@@ -219,16 +193,8 @@ static int ensureBatch(pmhip_engine* e, int n) {
 	for (int l = 0; l < 4; ++l) { if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
 	if (e->d_tasks) hipFree(e->d_tasks); if (e->h_tasks) hipHostFree(e->h_tasks);
 	if (e->d_ups) hipFree(e->d_ups); if (e->h_ups) hipHostFree(e->h_ups);
-	if (e->d_bandCtl) hipFree(e->d_bandCtl); if (e->d_bandOrder) hipFree(e->d_bandOrder); if (e->h_bandOrder) hipHostFree(e->h_bandOrder);
-	e->d_bandCtl = nullptr; e->d_bandOrder = nullptr; e->h_bandOrder = nullptr;
 	e->d_tasks = nullptr; e->h_tasks = nullptr; e->d_ups = nullptr; e->h_ups = nullptr;
 	const int cap = std::max(n, 1);
-	// (band, chunk) pairs of the narrowest mapping (16 lanes per pixel: 4 rows per wave) at the configured chunk width
-	e->bandPairCap = ((e->h + 3) / 4 + 1) * ((e->w + std::max(16, e->bandChunkW) - 1) / std::max(16, e->bandChunkW) + 1);
-	HIPCHK(e, hipMalloc(&e->d_bandCtl, sizeof(unsigned) * (2 + (size_t)cap * e->bandPairCap)));
-	HIPCHK(e, hipMalloc(&e->d_bandOrder, sizeof(unsigned) * (size_t)e->bandPairCap));
-	HIPCHK(e, hipHostMalloc(&e->h_bandOrder, sizeof(unsigned) * (size_t)e->bandPairCap));
-	HIPCHK(e, hipMemsetAsync(e->d_bandCtl, 0, sizeof(unsigned) * 2, e->stream));
 	HIPCHK(e, hipMalloc(&e->d_lvl[0], sizeof(float) * (size_t)cap * e->w * e->h));
 	for (int l = 1; l <= e->nLevels; ++l)
 		HIPCHK(e, hipMalloc(&e->d_lvl[l], sizeof(float) * (size_t)cap * 6 * e->lw(l) * e->lh(l)));
@@ -313,48 +279,19 @@ static void launchInit(int G, dim3 grid, hipStream_t s, const PMTask* t, const P
 	default: hipLaunchKernelGGL((pm_init_kernel<16, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
 	}
 }
-// (lanes per pixel, views per lane) -> kernel instantiation.  One view per lane for every group size, plus the mappings that give a lane
-// 2 or 4 of up to 8 / 16 views (pm_sweep_kernel's VPL).
-template <bool GEO>
-static void launchSweep(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
-#define PM_SWEEP_CASE(g, vpl) case (g) * 16 + (vpl): hipLaunchKernelGGL((pm_sweep_kernel<g, vpl, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, dir, d, xlo, count, pass); break
-	switch (G * 16 + VPL) {
-	PM_SWEEP_CASE(1, 1); PM_SWEEP_CASE(2, 1); PM_SWEEP_CASE(4, 1); PM_SWEEP_CASE(8, 1); PM_SWEEP_CASE(16, 1);
-	PM_SWEEP_CASE(1, 2); PM_SWEEP_CASE(2, 2); PM_SWEEP_CASE(4, 2); PM_SWEEP_CASE(8, 2);
-	PM_SWEEP_CASE(2, 4); PM_SWEEP_CASE(4, 4);
-#if !PM_USE_TILES
-	PM_SWEEP_CASE(1, 4); PM_SWEEP_CASE(1, 8);   // experiment builds without LDS windows only: a lane walks all source views of its pixel
-#endif
-	default: break;
-	}
-#undef PM_SWEEP_CASE
-}
 // Lanes per pixel for a batch whose views have at most maxSrc sources: G * VPL = next_pow2(maxSrc).  `lanes` (PMHIP_LANES or the built-in
 // default) caps G; VPL is what is left, limited to the instantiated mappings.
 static void sweepMapping(int maxSrc, int lanes, int& G, int& VPL) {
 	int NV = 1; while (NV < maxSrc) NV <<= 1;
 	G = NV; VPL = 1;
-	while (G > 1 && G > lanes && VPL < (PM_USE_TILES ? 4 : 8)) { G >>= 1; VPL <<= 1; }
-	if ((PM_USE_TILES && G == 1 && VPL > 2) || (G == 8 && VPL > 2)) { G <<= 1; VPL >>= 1; }   // (1,4) and (8,4) are not instantiated
+	while (G > 4 && G > lanes && VPL < 4) { G >>= 1; VPL <<= 1; }   // a pixel gets at least a quad of lanes (one smoothness slot per lane)
+	if (G < 4) G = 4;
+	if (G == 8 && VPL > 2) { G <<= 1; VPL >>= 1; }   // (8,4) is not instantiated
 }
 
-// the same mappings for the resident band kernel (pm_band.hip): one launch per sweep iteration
-template <bool GEO>
-static bool launchBand(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, uint32_t pass, int nViews, int nBands, int nChunks, int chunkW,
-		const unsigned* order, unsigned* ctl, int* progress) {
-#define PM_BAND_CASE(g, vpl) case (g) * 16 + (vpl): hipLaunchKernelGGL((pm_band_kernel<g, vpl, GEO>), grid, dim3(64), 0, s, t, kp, dir, pass, nViews, nBands, nChunks, chunkW, order, ctl, progress); return true
-	switch (G * 16 + VPL) {
-	PM_BAND_CASE(4, 1); PM_BAND_CASE(8, 1); PM_BAND_CASE(16, 1);
-	PM_BAND_CASE(4, 2); PM_BAND_CASE(8, 2);
-	PM_BAND_CASE(4, 4);
-	default: return false;
-	}
-#undef PM_BAND_CASE
-}
-
-template <bool GEO, bool VM>
+template <bool GEO, bool BUF>
 static bool launchSweep2(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
-#define PM_SWEEP2_CASE(g, vpl) case (g) * 16 + (vpl): hipLaunchKernelGGL((pm_sweep2_kernel<g, vpl, GEO, VM>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass); return true
+#define PM_SWEEP2_CASE(g, vpl) case (g) * 16 + (vpl): hipLaunchKernelGGL((pm_sweep2_kernel<g, vpl, GEO, BUF>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass); return true
 	switch (G * 16 + VPL) {
 	PM_SWEEP2_CASE(4, 1); PM_SWEEP2_CASE(8, 1); PM_SWEEP2_CASE(16, 1);
 	PM_SWEEP2_CASE(4, 2); PM_SWEEP2_CASE(8, 2);
@@ -364,17 +301,25 @@ static bool launchSweep2(int G, int VPL, dim3 grid, hipStream_t s, const PMTask*
 #undef PM_SWEEP2_CASE
 }
 
-template <bool GEO>
+template <bool GEO, bool BUF>
 static void launchSweepWide(dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
-	hipLaunchKernelGGL((pm_sweep_wide_kernel<GEO>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass);
+	hipLaunchKernelGGL((pm_sweep_wide_kernel<GEO, BUF>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass);
 }
 // the speculative kernel at 4 or 2 hypotheses per round (pm_wide_n.hip; PMHIP_WIDE_HYPS): 2 or 4 pixels per wave
-template <bool GEO>
+template <bool GEO, bool BUF>
 static void launchSweepWideN(int hyps, int nTasks, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	const int ppw = 8 / hyps;
 	const dim3 grid((unsigned)((count + ppw - 1) / ppw), (unsigned)nTasks);
-	if (hyps == 4) hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 4>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass);
-	else hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 2>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass);
+	if (hyps == 4) hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 4, BUF>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass);
+	else hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 2, BUF>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass);
+}
+// one diagonal of one view group with the kernel the batch calls for; false: the (lanes, views per lane) mapping is not instantiated
+template <bool GEO, bool BUF>
+static bool launchDiagonal(bool wide, int hyps, int G2, int V2, int nTasks, hipStream_t st, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
+	if (wide && hyps < 8) { launchSweepWideN<GEO, BUF>(hyps, nTasks, st, t, kp, dir, d, xlo, count, pass); return true; }
+	if (wide) { launchSweepWide<GEO, BUF>(dim3((unsigned)count, (unsigned)nTasks), st, t, kp, dir, d, xlo, count, pass); return true; }
+	const int P2 = 64 / G2;
+	return launchSweep2<GEO, BUF>(G2, V2, dim3((unsigned)((count + P2 - 1) / P2), (unsigned)nTasks), st, t, kp, dir, d, xlo, count, pass);
 }
 
 static size_t evBeginOn(pmhip_engine* e, int kind, hipStream_t st) {
@@ -420,6 +365,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 		e->maskDirty = false;
 	}
 	int maxSrc = 0;
+	bool buf = e->quadBuffer != 0;
 	for (int b = 0; b < nB; ++b) {
 		const int id = ids[b];
 		if (id < 0 || id >= e->nImages || !e->views[id].set) { e->err = "view not set"; return PMHIP_E_ARG; }
@@ -428,6 +374,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 		if (v.sw) { e->err = "a view with its own image size can only be a source view (reference views share the scene's size)"; return PMHIP_E_SIZE; }
 		for (int k = 0; k < v.nNb; ++k) if (v.nb[k] < 0 || v.nb[k] >= e->nImages || !e->views[v.nb[k]].set) { e->err = "neighbour view not set"; return PMHIP_E_ARG; }
 		maxSrc = std::max(maxSrc, v.nNb);
+		for (int k = 0; k < v.nNb; ++k) if (e->views[v.nb[k]].sw) buf = false;   // a source image of its own size is not in the level's quad buffer
 	}
 	int G = 1; while (G < maxSrc) G <<= 1;          // init kernel: one view per lane
 	int SG = G, VPL = 1;                             // sweep kernel: (lanes per pixel, views per lane)
@@ -457,6 +404,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			}
 			t.ref = e->d_img[l] + Pl * id;
 			t.refS = e->d_imgS[l] + e->skewPitch(l) * id;
+			t.qArr = e->d_imgQ[l]; t.qCount = (unsigned)(e->skewPitch(l) * (size_t)e->nImages);
 			t.mask = (anyMask && e->hasMask[id]) ? e->d_mask[l] + Pl * id : nullptr;
 			t.w = lw; t.h = lh; t.nSrc = v.nNb;
 			double K0[9];
@@ -482,6 +430,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 					s.img = e->d_img[l] + Pl * v.nb[k];
 					s.imgS = e->d_imgS[l] + e->skewPitch(l) * v.nb[k];
 					s.imgQ = e->d_imgQ[l] + e->skewPitch(l) * v.nb[k];
+					s.qBase = (unsigned)(e->skewPitch(l) * (size_t)v.nb[k]);
 					s.w = lw; s.h = lh;
 					if (l == 0) memcpy(Kj, sv.K, sizeof(Kj)); else scaleK(sv.K, e->w, e->h, lw, lh, Kj);
 				}
@@ -490,7 +439,6 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 				mul33(KR, R0T, s.Hl);
 				for (int i = 0; i < 3; ++i) dC[i] = v.C[i] - sv.C[i];
 				mul31(KR, dC, s.Hm);
-				if (e->probeAlias && k > 0) { s.img = t.src[0].img; s.imgS = t.src[0].imgS; s.imgQ = t.src[0].imgQ; s.w = t.src[0].w; s.h = t.src[0].h; }   // timing probe only
 				s.depth = nullptr;
 				if (geo) {
 					// ViewData::Init geometric part, DepthMap.h:179-184.  cameraDepthMap is the neighbour's own camera when the map is the scene's
@@ -531,7 +479,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 		else if (l < S)
 			hipLaunchKernelGGL(pm_upsample_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, e->lw(l + 1), e->lh(l + 1), lw, lh, nearestDepth);
 		// pass A: ScoreDepthMapTmp
-		const int PPB = PM_BLOCK / G, SPPB = PM_BLOCK / SG;
+		const int PPB = PM_BLOCK / G;
 		const uint32_t passInit = (uint32_t)l * 64u + 32u + (geo ? 16u + (uint32_t)nGeometricIter : 0u);
 		evBegin(e, 1);
 		{
@@ -545,40 +493,6 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			const int dir = (int)(iter % 2u);
 			const uint32_t pass = (uint32_t)l * 64u + iter;
 			const int dLo = 2 * PM_HW, dHi = (lw - 1 - PM_HW) + (lh - 1 - PM_HW);
-			if (e->bandMode) {
-				// one resident launch: a wave per (view, band of 64 / SG rows); ticket and progress counters are cleared on the stream first
-				if (SG < 4) { VPL = std::max(1, SG * VPL / 4); SG = 4; }   // the band kernel gives a pixel at least a quad of lanes (views with < 4 sources: idle lanes)
-				const int PPW = 64 / SG, nBands = (lh - 2 * PM_HW + PPW - 1) / PPW;
-				// tasks = (view, band, chunk of chunkW columns): short enough that the launch's tail (fewer tasks left than wave slots) is a small
-				// fraction of it; ordered by bandSlack * band + chunkW * chunk, which keeps a band that many diagonals behind the one it follows
-				const int chunkW = std::max(16, e->bandChunkW), nChunks = (lw - 2 * PM_HW + chunkW - 1) / chunkW;
-				const int nPairs = nBands * nChunks;
-				if (nPairs > e->bandPairCap) { e->err = "band kernel: too many (band, chunk) pairs"; return PMHIP_E_SIZE; }
-				{
-					std::vector<std::pair<long, unsigned>> keyed((size_t)nPairs);
-					for (int b = 0; b < nBands; ++b) for (int c = 0; c < nChunks; ++c)
-						keyed[(size_t)b * nChunks + c] = std::make_pair((long)e->bandSlack * b + (long)chunkW * c, ((unsigned)b << 16) | (unsigned)c);
-					std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<long, unsigned>& a, const std::pair<long, unsigned>& b) { return a.first < b.first; });
-					HIPCHK(e, hipStreamSynchronize(e->stream));          // h_bandOrder is reused by every sweep
-					for (int i = 0; i < nPairs; ++i) e->h_bandOrder[i] = keyed[(size_t)i].second;
-					HIPCHK(e, hipMemcpyAsync(e->d_bandOrder, e->h_bandOrder, sizeof(unsigned) * (size_t)nPairs, hipMemcpyHostToDevice, e->stream));
-				}
-				const size_t evB = evBeginOn(e, 0, e->stream), evW = evBeginOn(e, 2, e->stream);
-				HIPCHK(e, hipMemsetAsync(e->d_bandCtl, 0, sizeof(unsigned), e->stream));
-				HIPCHK(e, hipMemsetAsync(e->d_bandCtl + 2, 0, sizeof(unsigned) * (size_t)nB * nPairs, e->stream));
-				const dim3 grid((unsigned)nPairs * (unsigned)nB);
-				const bool ok = geo ? launchBand<true>(SG, VPL, grid, e->stream, dt, kp, dir, pass, nB, nBands, nChunks, chunkW, e->d_bandOrder, e->d_bandCtl, (int*)(e->d_bandCtl + 2))
-				                    : launchBand<false>(SG, VPL, grid, e->stream, dt, kp, dir, pass, nB, nBands, nChunks, chunkW, e->d_bandOrder, e->d_bandCtl, (int*)(e->d_bandCtl + 2));
-				if (!ok) { e->err = "band kernel: mapping not instantiated"; return PMHIP_E_ARG; }
-				evEndOn(e, evB, e->stream); evEndOn(e, evW, e->stream);
-				if (e->statsOn) {
-					e->stats.sweepLaunches += 1;
-					double bytes = 0;
-					for (int b = 0; b < nB; ++b) { const int N = e->views[ids[b]].nNb; bytes += (double)Pl * (4.0 * (1 + N) + 40.0 + (l < S ? 4.0 : 0.0) + (geo ? 4.0 * N : 0.0)); }
-					e->stats.sweepBytes += bytes; e->stats.sweepPixels += (uint64_t)Pl * nB;
-				}
-				continue;
-			}
 			const int NG = std::max(1, std::min(e->nGroups, nB));
 			const size_t evWall = evBeginOn(e, 2, e->stream);
 			size_t evG[16] = {};
@@ -596,30 +510,9 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 					const int s0 = (int)((long)nB * g / NG), s1 = (int)((long)nB * (g + 1) / NG);
 					hipStream_t st = NG > 1 ? e->gstream[g] : e->stream;
 					const int hyps = e->wideHyps > 0 ? e->wideHyps : (nB <= 2 ? 8 : 2);
-					if (wide && hyps < 8) {
-						if (geo) launchSweepWideN<true>(hyps, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass);
-						else launchSweepWideN<false>(hyps, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass);
-						continue;
-					}
-					if (wide) {
-						const dim3 grid((unsigned)count, s1 - s0);
-						if (geo) launchSweepWide<true>(grid, st, dt + s0, kp, dir, d, xlo, count, pass);
-						else launchSweepWide<false>(grid, st, dt + s0, kp, dir, d, xlo, count, pass);
-						continue;
-					}
-					if (e->diagVisit2) {
-						// the visit body of pm_band.hip (state in LDS, quad images, no windows) under the per-diagonal schedule
-						int G2 = SG, V2 = VPL; if (G2 < 4) { V2 = std::max(1, G2 * V2 / 4); G2 = 4; }
-						const int P2 = 64 / G2;
-						const dim3 grid2((unsigned)((count + P2 - 1) / P2), s1 - s0);
-						const bool ok2 = e->viewMajor ? (geo ? launchSweep2<true, true>(G2, V2, grid2, st, dt + s0, kp, dir, d, xlo, count, pass) : launchSweep2<false, true>(G2, V2, grid2, st, dt + s0, kp, dir, d, xlo, count, pass))
-						                              : (geo ? launchSweep2<true, false>(G2, V2, grid2, st, dt + s0, kp, dir, d, xlo, count, pass) : launchSweep2<false, false>(G2, V2, grid2, st, dt + s0, kp, dir, d, xlo, count, pass));
-						if (!ok2) { e->err = "sweep kernel: (lanes per pixel, views per lane) mapping not instantiated"; return PMHIP_E_ARG; }
-						continue;
-					}
-					const dim3 grid((unsigned)((count + SPPB - 1) / SPPB), s1 - s0);
-					if (geo) launchSweep<true>(SG, VPL, grid, st, dt + s0, kp, dir, d, xlo, count, pass);
-					else launchSweep<false>(SG, VPL, grid, st, dt + s0, kp, dir, d, xlo, count, pass);
+					const bool ok = geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass))
+					                    : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass));
+					if (!ok) { e->err = "sweep kernel: (lanes per pixel, views per lane) mapping not instantiated"; return PMHIP_E_ARG; }
 				}
 				if (e->statsOn) e->stats.sweepLaunches += NG;
 			}
@@ -646,7 +539,6 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 	return 0;
 }
 
-static int checkBand(pmhip_engine* e);
 static int collectStats(pmhip_engine* e) {
 	if (e->events.empty()) return 0;
 	HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -686,13 +578,7 @@ int pmhip_create(int device, pmhip_engine** out) {
 	const char* nw = getenv("PMHIP_WIDE");
 	if (nw) e->wideMaxViews = atoi(nw);
 	const char* wh = getenv("PMHIP_WIDE_HYPS"); if (wh && (atoi(wh) == 8 || atoi(wh) == 4 || atoi(wh) == 2)) e->wideHyps = atoi(wh);
-	const char* bm = getenv("PMHIP_BAND");
-	if (bm) e->bandMode = atoi(bm) != 0;
-	const char* d2 = getenv("PMHIP_DIAG2"); if (d2) e->diagVisit2 = atoi(d2) != 0;
-	const char* vm = getenv("PMHIP_VM"); if (vm) e->viewMajor = atoi(vm) != 0;
-	const char* pa = getenv("PMHIP_PROBE_ALIAS"); if (pa) e->probeAlias = atoi(pa);
-	const char* bc = getenv("PMHIP_BAND_CHUNK"); if (bc && atoi(bc) >= 16) e->bandChunkW = atoi(bc);
-	const char* bs = getenv("PMHIP_BAND_SLACK"); if (bs && atoi(bs) >= 0) e->bandSlack = atoi(bs);
+	const char* qb = getenv("PMHIP_QUADBUF"); if (qb) e->quadBuffer = atoi(qb) != 0;
 	const char* nl = getenv("PMHIP_LANES");
 	if (nl && atoi(nl) >= 1) e->sweepLanes = atoi(nl);
 	for (int g = 0; g < e->nGroups; ++g)
@@ -846,7 +732,7 @@ int pmhip_scene_estimate(pmhip_engine* e, const int32_t* viewIds, int nViews, co
 	HIPCHK(e, hipSetDevice(e->device));
 	int rc = estimateBatch(e, viewIds, nViews, *p, nGeometricIter);
 	if (rc) return rc;
-	if (sync) { HIPCHK(e, hipStreamSynchronize(e->stream)); return checkBand(e); }
+	if (sync) HIPCHK(e, hipStreamSynchronize(e->stream));
 	return 0;
 }
 
@@ -1115,14 +1001,7 @@ int pmhip_scene_copy(pmhip_engine* e, int what, int firstIdx, int count, void* d
 }
 
 // after a stream synchronisation: did a band kernel give up waiting for its preceding band (pm_band.hip: bounded waits instead of a hung device)?
-static int checkBand(pmhip_engine* e) {
-	if (!e->d_bandCtl) return 0;
-	unsigned flag = 0;
-	HIPCHK(e, hipMemcpy(&flag, e->d_bandCtl + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
-	if (flag) { hipMemset(e->d_bandCtl + 1, 0, sizeof(unsigned)); e->err = "band kernel: a bounded wait for the preceding band expired; the maps of this call are not valid"; return PMHIP_E_HIP; }
-	return 0;
-}
-int pmhip_sync(pmhip_engine* e) { if (!e) return PMHIP_E_ARG; HIPCHK(e, hipSetDevice(e->device)); HIPCHK(e, hipStreamSynchronize(e->stream)); return checkBand(e); }
+int pmhip_sync(pmhip_engine* e) { if (!e) return PMHIP_E_ARG; HIPCHK(e, hipSetDevice(e->device)); HIPCHK(e, hipStreamSynchronize(e->stream)); return 0; }
 void* pmhip_stream(pmhip_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 int pmhip_stats_reset(pmhip_engine* e, int enableEvents) {

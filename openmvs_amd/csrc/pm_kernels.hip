@@ -27,16 +27,7 @@
 
 #define PM_MAX_SRC 16
 #ifndef PM_BLOCK
-#define PM_BLOCK 64    // one wave per workgroup: LDS windows are per wave, so small workgroups pack the CU's 160 KB best (tools/tune.py)
-#endif
-#ifndef PM_USE_TILES
-#define PM_USE_TILES 1   // stage source-image windows in LDS in the sweep kernel
-#endif
-#ifndef PM_TAPCHUNK
-#define PM_TAPCHUNK 5   // taps of a row whose loads are issued together (5 = whole row)
-#endif
-#ifndef PM_MINWAVES
-#define PM_MINWAVES 3   // waves per SIMD the register allocator must leave room for (measured: 3 beats 4 (spills) and 5)
+#define PM_BLOCK 64    // one wave per workgroup (init kernel)
 #endif
 // Pointers read out of PMTask live in the generic address space as far as the compiler knows, which
 // turns every access into a flat_load; they are all HBM buffers, so say so (global_load, own vmcnt).
@@ -47,11 +38,11 @@ typedef float __attribute__((address_space(1)))* pm_gf;
 typedef float pm_f4v __attribute__((ext_vector_type(4)));
 typedef const pm_f4v __attribute__((address_space(1)))* pm_gcf4;
 __device__ __forceinline__ pm_gcf4 pm_glob4(const float4* p) { return (pm_gcf4)p; }
-__device__ __forceinline__ void pm_load4(pm_gcf4 base, unsigned off, float& a, float& b, float& c, float& d) { const pm_f4v t = base[off]; a = t.x; b = t.y; c = t.z; d = t.w; }
+__device__ __forceinline__ pm_f4v pm_loadq(pm_gcf4 base, unsigned off) { return base[off]; }
 #else
 typedef const float4* pm_gcf4;
 __device__ __forceinline__ pm_gcf4 pm_glob4(const float4* p) { return p; }
-__device__ __forceinline__ void pm_load4(pm_gcf4 base, unsigned off, float& a, float& b, float& c, float& d) { const float4 t = base[off]; a = t.x; b = t.y; c = t.z; d = t.w; }
+__device__ __forceinline__ float4 pm_loadq(pm_gcf4 base, unsigned off) { return base[off]; }
 #endif
 __device__ __forceinline__ pm_gcf pm_glob(const float* p) { return (pm_gcf)p; }
 __device__ __forceinline__ pm_gf pm_globw(float* p) { return (pm_gf)p; }
@@ -59,11 +50,12 @@ __device__ __forceinline__ pm_gf pm_globw(float* p) { return (pm_gf)p; }
 #define PM_NT 25     // nTexels, DepthMap.h:281
 
 struct PMSrcView {
-	// "hot" block, 13 doubles: what every hypothesis evaluation reads of its source view.  The sweep kernel copies it (and the geometric block)
+	// "hot" block, 14 doubles: what every hypothesis evaluation reads of its source view.  The sweep kernels copy it (and the geometric block)
 	// into LDS once per visit; the layout is the copy's contract (see PM_SRC_HOT / PM_SRC_GEO below).
 	double Hl[9];         // K_j R_j R_0^T          (ViewData::Init, DepthMap.h:175-185)
 	double Hm[3];         // K_j R_j (C_0 - C_j)
 	int w, h;             // size of the source image at this level
+	unsigned qBase, qPad; // first entry of this view's quad image in the level's quad buffer (PMTask::qArr); unused for a view with its own image size
 	// geometric block, 14 doubles: transforms of the consistency term and the source view's depth-map (nullable; geometric pass) with its own
 	// size: the map is addressed through cameraDepthMap (Tl..Tn), not through the image's camera (DepthMap.h:170-171, DepthMap.cpp:535-551)
 	float Tl[9], Tm[3], Tr[9], Tn[3];
@@ -75,9 +67,9 @@ struct PMSrcView {
 	                      // sample in ONE 16-byte load (the window-less tap rows are bound by the number of vector-memory instructions, not by bytes:
 	                      // the stride-2 taps of a patch never share texels, so the quad image is read at the same byte rate as the plain one)
 };
-#define PM_SRC_HOT 13     // doubles
+#define PM_SRC_HOT 14     // doubles
 #define PM_SRC_GEO 14
-static_assert(offsetof(PMSrcView, Hm) == 72 && offsetof(PMSrcView, w) == 96 && offsetof(PMSrcView, Tl) == 8 * PM_SRC_HOT
+static_assert(offsetof(PMSrcView, Hm) == 72 && offsetof(PMSrcView, w) == 96 && offsetof(PMSrcView, qBase) == 104 && offsetof(PMSrcView, Tl) == 8 * PM_SRC_HOT
 	&& offsetof(PMSrcView, depth) == 8 * PM_SRC_HOT + 96 && offsetof(PMSrcView, dw) == 8 * PM_SRC_HOT + 104 && offsetof(PMSrcView, img) == 8 * (PM_SRC_HOT + PM_SRC_GEO), "PMSrcView layout");
 struct PMTask {           // one reference view at one pyramid level
 	float* depth; float* normal; float* conf;
@@ -92,6 +84,8 @@ struct PMTask {           // one reference view at one pyramid level
 	double fx, fy, cx, cy;
 	float dMin, dMax, dMinSqr, dMaxSqr;
 	uint32_t k0, k1base;  // Philox key: (seed, viewID*0x9E3779B1 + pass)
+	const float4* qArr;   // the quad images of ALL scene views at this level, one allocation (view i at qArr + i * (w + h - 1) * h): the buffer the sweep kernels' tap rows index
+	unsigned qCount, qPad; // its entries
 	PMSrcView src[PM_MAX_SRC];
 };
 struct PMKParams {        // DepthEstimator ctor constants, DepthMap.cpp:397-406
@@ -150,11 +144,7 @@ __device__ __forceinline__ bool pm_in_range(float d, float lo, float hi) { retur
 // Dir2Normal / Normal2Dir, libs/Common/Util.inl:754-766
 __device__ __forceinline__ void pm_dir2normal(float p0, float p1, float& nx, float& ny, float& nz) {
 	float sx, cx, sy, cy;
-#ifdef PM_PROBE_CHEAP_TRIG
-	sx = p0 * 0.3f; cx = 1.f - sx * sx; sy = -0.2f + p1 * 0.01f; cy = -0.97f;
-#else
 	pm_sincosf(p0, &sx, &cx); pm_sincosf(p1, &sy, &cy);
-#endif
 	nx = cx * sy; ny = sx * sy; nz = cy;
 }
 // RandomNormal, DepthMap.h:439-444
@@ -226,20 +216,6 @@ template <int K> __device__ __forceinline__ float pm_quad_bcast(float v) { retur
 __device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t, double X0x, double X0y,
 		float depth, float nx, float ny, float nz, float* H) {
 	// the twelve matrix entries are requested first, together: one round trip (overlapping the division below) instead of one per row
-#ifdef PM_PROBE_F32_HOMOGRAPHY
-	{
-		float hl[9], hm[3];
-		for (int i = 0; i < 9; ++i) hl[i] = (float)hlm[i];
-		for (int i = 0; i < 3; ++i) hm[i] = (float)hlm[9 + i];
-		const float ndxf = (nx * (float)X0x + ny * (float)X0y) + nz, invf = __builtin_amdgcn_rcpf(ndxf * depth);
-		const float r0 = nx * invf, r1 = ny * invf, r2 = nz * invf;
-		for (int i = 0; i < 3; ++i) {
-			const float m0 = hl[i * 3] + hm[i] * r0, m1 = hl[i * 3 + 1] + hm[i] * r1, m2 = hl[i * 3 + 2] + hm[i] * r2;
-			H[i * 3] = m0 * (float)t.Hr[0]; H[i * 3 + 1] = m1 * (float)t.Hr[4]; H[i * 3 + 2] = (m0 * (float)t.Hr[2] + m1 * (float)t.Hr[5]) + m2 * (float)t.Hr[8];
-		}
-		return;
-	}
-#endif
 	double Hl[9], Hm[3];
 #pragma unroll
 	for (int i = 0; i < 9; ++i) Hl[i] = hlm[i];
@@ -269,70 +245,57 @@ __device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t
 	}
 }
 
-// LDS source tiles of the sweep kernel: per (wave, source view) a PM_TR x TC window of the anti-diagonal-major
-// image, placed around the footprints of the wave's pixels under their current planes.  TC = pixels per wave + 16.
-#ifndef PM_TR
-#define PM_TR 20        // window rows (anti-diagonals): 19 are needed (patch 17 + bilinear 2), the rest is slack for perturbed planes
-#endif
-#ifndef PM_TCX
-#define PM_TCX 10       // window columns = pixels per wave + PM_TCX: PPW + 9 are needed (10: 13.3 KB of windows + weights per wave, measured +5 % over 12)
-#endif
-#define PM_TILE_PAD 4   // per-view stride = PM_TR*TC + 4 floats: staggers the views over the LDS banks
-#ifndef PM_XCD_REMAP
-#define PM_XCD_REMAP 1  // sweep kernel: contiguous (view, chunk) ranges per XCD (see the kernel)
-#endif
-// Three switches of an experiment that did not pay (profiles/r02_variants_call7_ilp_block.log: all on 30.8, all off 32.1 Mpix/s): writing the
-// per-hypothesis chains that do not depend on each other as one branch-free block so that the scheduler can interleave them.  Off by default.
-// Prepared for round 3, not yet timed (default off; bit-exact under the emulator): the smoothness-factor chain (13 % of a step by the timing probes) is
-// evaluated inside pm_score_view, in the same basic block as the first tap row, whose ~220 independent instructions can cover its latency; every lane
-// of a pixel that evaluates a hypothesis takes part (lanes without a source view run the row on zeros and are flagged), so the broadcast of the
-// factors stays inside fully active quads.  One source view per lane and >= 4 lanes per pixel only.
-#ifndef PM_SMOOTH_IN_ROW0
-#define PM_SMOOTH_IN_ROW0 0
-#endif
-// Also prepared for round 3 (default off, bit-exact under the emulator, not yet timed): a tap row that fails the LDS attempt is first retried with the same
-// optimistic code reading its 20 texels from the image in HBM (~240 instructions), and only a row whose positions are not exact goes through
-// pm_tap_row_global (~500).  The redone rows are 11.7 % of a step by the timing probe; a version that kept the first attempt's positions alive
-// instead of recomputing them lost 3.3 % to register pressure.
-#ifndef PM_GLOBAL_FAST_ROW
-#define PM_GLOBAL_FAST_ROW 0
-#endif
-#ifndef PM_ILP_HOMOGRAPHY
-#define PM_ILP_HOMOGRAPHY 0   // the lane's homography computed next to the smoothness factors instead of inside pm_score_view
-#endif
-#ifndef PM_ILP_PHILOX
-#define PM_ILP_PHILOX 0       // the random draw of the next refinement iteration computed one evaluation ahead
-#endif
-#ifndef PM_ILP_SMOOTH
-#define PM_ILP_SMOOTH 0       // smoothness factors computed by every lane without a branch (0: only by the lanes that own a close neighbour)
-#endif
-// TIMING PROBES (never defined in the product build): each removes or cheapens one part of an evaluation so that its cost inside the real, fully
-// loaded kernel can be read off the benchmark -- the counter passes of rocprofv3 do not work on this pool.  The maps such a build produces are NOT the
-// reference's (the scores change), only the time is meaningful; tools/build_variants.py + tools/tune.py run them (profiles/r02_probe_variants.log).
-//   PM_PROBE_NO_SMOOTH      smoothness factors = 1 (no exp / acos / sqrt / division chain)
-//   PM_PROBE_F32_HOMOGRAPHY homography in float (no f64 arithmetic, no f64 division)
-//   PM_PROBE_CHEAP_DRAW     a three-multiply hash instead of the ten Philox rounds
-//   PM_PROBE_FAST_EPILOGUE  v_rcp / v_rsq approximations instead of the correctly rounded division and square root of the score epilogue
-//   PM_PROBE_NO_GEO_SAMPLES geometric term = its constant 4 (no dependent depth-map loads, no divisions)
-//   PM_PROBE_NO_TAPS        the 25 taps contribute constants (no divisions, LDS reads, bilinear weights)
-//   PM_PROBE_NO_STAGING     the source windows are not loaded (the taps read whatever the LDS holds)
-//   PM_PROBE_NO_FALLBACK    a tap row that fails its exactness test is not redone through global memory
-//   PM_PROBE_NO_WEIGHTS     the 25 bilateral patch weights are constants (no exp, no patch texel loads)
-//   PM_PROBE_CHEAP_TRIG     sin / cos / atan2 / acos of the hypothesis construction replaced by two-instruction stand-ins
 #ifndef PM_WIDE_MINWAVES
 #define PM_WIDE_MINWAVES 3   // waves per SIMD the one-wave-per-pixel kernel is compiled for
 #endif
-#ifndef PM_WIDE_TILES
-#define PM_WIDE_TILES 0   // one-wave-per-pixel kernel: LDS windows (1) or window-less quad-image tap rows (0; one depth map 1.08 -> 0.80 s, profiles/r03_small_batches_call7.log)
-#endif
-#ifndef PM_WINBATCH
-#define PM_WINBATCH 4   // source windows whose global loads are in flight together when a visit stages its windows
+
+// ---- the level's quad images as ONE buffer ---------------------------------------------------------------------------------------------------------
+// All scene images of a pyramid level live in one allocation (PMTask::qArr, 16-byte entries).  Described to the memory pipeline as a buffer (V#: base,
+// stride 16, record count) a lane addresses its sample with a 32-bit ENTRY INDEX (buffer_load_dwordx4 ... idxen): the scaling by 16, the 64-bit add and the
+// range check are done by the address unit instead of by v_mad_u64_u32 / v_lshl_add_u64 / four clamps per tap (about a fifth of a tap's VALU time, measured
+// from the ISA: DESIGN.md 4.2).  An index outside the buffer returns zeros and touches nothing, so the optimistic rows need no clamp at all: whatever a tap
+// outside the image or a garbage position fetched is never used (the hypothesis is flagged or redone).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef int pm_rsrc __attribute__((ext_vector_type(4)));
+// built from wave-uniform values only (one task per workgroup); readfirstlane makes that provable to the compiler so that the descriptor sits in SGPRs
+__device__ __forceinline__ pm_rsrc pm_make_rsrc(const void* base, unsigned count) {
+	const unsigned long long b = (unsigned long long)base;
+	pm_rsrc r;
+	r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+	r.y = __builtin_amdgcn_readfirstlane((int)(((unsigned)(b >> 32) & 0xffffu) | (16u << 16)));   // base[47:32], stride 16 bytes
+	r.z = __builtin_amdgcn_readfirstlane((int)count);                                                // records (index >= count: out of range)
+	r.w = 0x00020000;                                                                                // data format 32 bit, no swizzle
+	return r;
+}
+// The five samples of a tap row: issued back to back; the destinations are the compiler's registers but the loads are not in its s_waitcnt bookkeeping, so
+// pm_bufwait5 (which names them all read-write) must sit between this and their first use (cdna_hip_programming.md 5.7, form (ii)).
+__device__ __forceinline__ void pm_bufload5(pm_f4v& q0, pm_f4v& q1, pm_f4v& q2, pm_f4v& q3, pm_f4v& q4, unsigned i0, unsigned i1, unsigned i2, unsigned i3, unsigned i4, pm_rsrc r) {
+	asm volatile("buffer_load_dwordx4 %0, %5, %10, 0 idxen\n\tbuffer_load_dwordx4 %1, %6, %10, 0 idxen\n\tbuffer_load_dwordx4 %2, %7, %10, 0 idxen\n\t"
+	             "buffer_load_dwordx4 %3, %8, %10, 0 idxen\n\tbuffer_load_dwordx4 %4, %9, %10, 0 idxen"
+		: "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4) : "v"(i0), "v"(i1), "v"(i2), "v"(i3), "v"(i4), "s"(r) : "memory");
+}
+__device__ __forceinline__ void pm_bufwait5(pm_f4v& q0, pm_f4v& q1, pm_f4v& q2, pm_f4v& q3, pm_f4v& q4) {
+	asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4));
+}
+__device__ __forceinline__ unsigned pm_mad24(int a, int b, unsigned c) { return (unsigned)__mul24(a, b) + c; }   // v_mad_u32_u24: full rate
+#else
+// host build (the CPU emulator of the tests): the same semantics -- entry index, zeros outside
+typedef float4 pm_f4v;
+struct pm_rsrc { const float4* base; unsigned count; };
+__device__ __forceinline__ pm_rsrc pm_make_rsrc(const void* base, unsigned count) { return pm_rsrc{(const float4*)base, count}; }
+__device__ __forceinline__ void pm_bufload5(pm_f4v& q0, pm_f4v& q1, pm_f4v& q2, pm_f4v& q3, pm_f4v& q4, unsigned i0, unsigned i1, unsigned i2, unsigned i3, unsigned i4, pm_rsrc r) {
+	const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+	q0 = i0 < r.count ? r.base[i0] : z; q1 = i1 < r.count ? r.base[i1] : z; q2 = i2 < r.count ? r.base[i2] : z; q3 = i3 < r.count ? r.base[i3] : z; q4 = i4 < r.count ? r.base[i4] : z;
+}
+__device__ __forceinline__ void pm_bufwait5(pm_f4v&, pm_f4v&, pm_f4v&, pm_f4v&, pm_f4v&) {}
+__device__ __forceinline__ unsigned pm_mad24(int a, int b, unsigned c) { return (unsigned)(((unsigned)a & 0xffffffu) * ((unsigned)b & 0xffffffu)) + c; }   // wraps as the hardware's low 32 bits do
 #endif
 
-// One tap row (5 taps) of ScorePixelImage through global loads, with the reference's per-tap tests; any layout.  X = position of the row's first tap.
-// The reference returns thRobust at the first tap that leaves the image (DepthMap.cpp:484-485).  Here a tap outside only raises a flag and its
-// address is clamped, so there is no branch between taps: the 20 loads of the row are issued back to back and the sums of a flagged hypothesis are
-// simply discarded -- identical result, no load ever depends on a previous load.
+// One tap row (5 taps) of ScorePixelImage through global loads, with the reference's per-tap tests; row-major (SKEW = false) or anti-diagonal-major image.
+// X = position of the row's first tap.  The reference returns thRobust at the first tap that leaves the image (DepthMap.cpp:484-485).  Here a tap outside
+// only raises a flag and its address is clamped, so there is no branch between taps: the 20 loads of the row are issued back to back and the sums of a flagged
+// hypothesis are simply discarded -- identical result, no load ever depends on a previous load.  This is the GUARDED path: every position is the IEEE quotient
+// whatever the operands (pm_div2).  The init kernel scores with it (one evaluation per pixel), the sweep kernels only redo a patch with it.
 template <bool SKEW>
 __device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int sh, float h0, float h3, float h6, float X0, float X1, float X2,
 		const float2* wrow, float& sum, float& sumSq, float& num, bool& oob)
@@ -372,138 +335,72 @@ __device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int 
 	}
 }
 
-// The same row served from the wave's LDS window of the anti-diagonal-major source image, optimistically: no test between the taps.  The divisions
-// use the unguarded reciprocal refinement, the texel indices are only clamped into the window; while it goes the row tracks the extremes of z, of
-// the projected positions and of the window row index, and one comparison set at the end says whether every tap (a) had 2^-40 <= z <= 2^40 (with
-// `sane`: |x|, |y| < 1e18 -- then the quotients are the correctly rounded ones and nothing is NaN), (b) was inside the image (isInsideWithBorder<1>)
-// and (c) inside the window.  If so the three running sums are exactly what pm_tap_row_global computes and the call returns true; with (a) but a tap
-// outside the image the hypothesis is flagged (`oob`) and the row is done as well; otherwise the sums are left untouched and the caller redoes the
-// row through global loads.  ~40 VALU instructions per tap instead of ~100.
-template <int TC, bool FROM_IMAGE = false>
-__device__ __forceinline__ bool pm_tap_row_lds(const float* tile, int ts0, int tt0, int sw, int sh, bool sane, float h0, float h3, float h6,
-		float X0, float X1, float X2, const float2* wrow, float& sum, float& sumSq, float& num, bool& oob, const pm_gcf4 imgQ = (pm_gcf4)nullptr)
+// The same row, OPTIMISTIC and branch-free, from the anti-diagonal-major quad image (one 16-byte entry = the four texels of a bilinear sample): the divisions are
+// the unguarded reciprocal refinement (pm_div2_inrange), nothing is tested between the taps, the sums are committed unconditionally.  What the row records
+// instead, as running integer minima / maxima of bit patterns (pm_f2i): the extremes of the projected positions (plo, pxhi, pyhi) and the depth of its first and
+// last tap (zlo, zhi) -- z moves by the same float increment from tap to tap and from row to row, and x (+) h is monotone in x, so the extremes of z over the
+// patch are among those.  The caller decides afterwards (pm_score_view): with 2^-40 <= z <= 2^40 on the whole patch and `sane` start values every quotient was the
+// correctly rounded one, hence the sums are exactly pm_tap_row_global's and the image test (isInsideWithBorder<1> of every tap) on the extremes is exact;
+// otherwise the patch is redone through the guarded path.
+// BUF: the sample is addressed as entry index qbase + (lx + ly) * sh + ly of the level's buffer (no clamp: out of range reads zeros, see above); otherwise through the
+// view's own pointer with clamped coordinates (views that carry their own image size live outside the level's buffer).
+template <bool BUF>
+__device__ __forceinline__ void pm_tap_row_fast(const pm_rsrc& rs, unsigned qbase, const pm_gcf4 imgQ, int sw, int sh, float h0, float h3, float h6,
+		float X0, float X1, float X2, const float2* wrow, float& sum, float& sumSq, float& num, int& zlo, int& zhi, int& plo, int& pxhi, int& pyhi)
 {
-	constexpr int MAXI = PM_TR * TC - 2 * TC - 2;   // idx + 2*TC + 1 stays inside the window
-	const int cidx = -(ts0 * TC + tt0);
-	float fxs[5], fys[5];
-	const float* q[5];
-	unsigned goff[5];   // FROM_IMAGE: texel offsets in the anti-diagonal-major image, clamped into it (a row with a tap outside is not committed)
-	float zlo = X2, zhi = X2, pxlo = PM_INF, pxhi = -PM_INF, pylo = PM_INF, pyhi = -PM_INF;
-	int slo = 0x7fffffff, shi = (int)0x80000000;
+	float ptx[5], pty[5];
+	unsigned idx[5];
+	const int zFirst = pm_f2i(X2);
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
-		float ptx, pty;
-		pm_div2_inrange(X0, X1, X2, &ptx, &pty);
-		zlo = pm_fminf(zlo, X2); zhi = pm_fmaxf(zhi, X2);
-		pxlo = pm_fminf(pxlo, ptx); pxhi = pm_fmaxf(pxhi, ptx); pylo = pm_fminf(pylo, pty); pyhi = pm_fmaxf(pyhi, pty);
-		const int lx = (int)ptx, ly = (int)pty;
-		fxs[j] = pm_fract_pos(ptx); fys[j] = pm_fract_pos(pty);   // == ptx - (float)lx for the positions the row is accepted with (>= 1)
-		const int sk = lx + ly;
-		slo = min(slo, sk); shi = max(shi, sk);
-		if (FROM_IMAGE) {
-			const int lxc = min(max(lx, 0), sw - 2), lyc = min(max(ly, 0), sh - 2);
-			goff[j] = (unsigned)(lxc + lyc) * (unsigned)sh + (unsigned)lyc;
-		} else {
-			const int idx = pm_mul24(sk, TC) + (ly + cidx);   // 24-bit multiply: full rate (a 32-bit one is a quarter-rate v_mad_u64_u32); garbage only where the row fails anyway
-			q[j] = tile + min((unsigned)idx, (unsigned)MAXI);
-		}
+		pm_div2_inrange(X0, X1, X2, &ptx[j], &pty[j]);
+		const int lx = (int)ptx[j], ly = (int)pty[j];
+		if (BUF) idx[j] = pm_mad24(lx + ly, sh, (unsigned)ly + qbase);
+		else { const int lxc = min(max(lx, 0), sw - 2), lyc = min(max(ly, 0), sh - 2); idx[j] = (unsigned)(lxc + lyc) * (unsigned)sh + (unsigned)lyc; }
+		if (j == 4) { const int zLast = pm_f2i(X2); zlo = min(zlo, min(zFirst, zLast)); zhi = max(zhi, max(zFirst, zLast)); }
 		X0 += h0; X1 += h3; X2 += h6;
 	}
-	float s0 = sum, s1 = sumSq, s2 = num;
+	pm_f4v q0, q1, q2, q3, q4;
+	if (BUF) pm_bufload5(q0, q1, q2, q3, q4, idx[0], idx[1], idx[2], idx[3], idx[4], rs);
+	else { q0 = pm_loadq(imgQ, idx[0]); q1 = pm_loadq(imgQ, idx[1]); q2 = pm_loadq(imgQ, idx[2]); q3 = pm_loadq(imgQ, idx[3]); q4 = pm_loadq(imgQ, idx[4]); }
+	// (independent of the loads) the extremes of the positions, on their bit patterns (see pm_f2i): plo = the smallest x or y, pxhi / pyhi = the largest x / y
+	plo = min(plo, min(min(min(pm_f2i(ptx[0]), pm_f2i(ptx[1])), min(pm_f2i(ptx[2]), pm_f2i(ptx[3]))), pm_f2i(ptx[4])));
+	plo = min(plo, min(min(min(pm_f2i(pty[0]), pm_f2i(pty[1])), min(pm_f2i(pty[2]), pm_f2i(pty[3]))), pm_f2i(pty[4])));
+	pxhi = max(pxhi, max(max(max(pm_f2i(ptx[0]), pm_f2i(ptx[1])), max(pm_f2i(ptx[2]), pm_f2i(ptx[3]))), pm_f2i(ptx[4])));
+	pyhi = max(pyhi, max(max(max(pm_f2i(pty[0]), pm_f2i(pty[1])), max(pm_f2i(pty[2]), pm_f2i(pty[3]))), pm_f2i(pty[4])));
+	if (BUF) pm_bufwait5(q0, q1, q2, q3, q4);
+	const pm_f4v q[5] = {q0, q1, q2, q3, q4};
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
-		float v00, v01, v10, v11;
-		if (FROM_IMAGE) pm_load4(imgQ, goff[j], v00, v01, v10, v11);
-		else { v00 = q[j][0]; v01 = q[j][TC]; v10 = q[j][TC + 1]; v11 = q[j][2 * TC + 1]; }
-		const float fx = fxs[j], fx1 = 1.f - fx, fy = fys[j], fy1 = 1.f - fy;
-		const float v = (v00 * fx1 + v01 * fx) * fy1 + (v10 * fx1 + v11 * fx) * fy;
-		const float2 pw = wrow[j];
-		const float vw = v * pw.x;
-		s0 += vw;
-		s1 += v * vw;
-		s2 += v * pw.y;
-	}
-	// With 2^-40 <= z <= 2^40 and `sane` every quotient above is the correctly rounded one, so the image test is exact: a tap outside the image
-	// flags the hypothesis just as pm_tap_row_global would (its sums are then never used) and the row is done -- source views that do not see the
-	// pixel at all are the common case of a failed row and must not cost a second pass through global memory.
-	const bool exact = sane && zlo >= 9.094947e-13f && zhi <= 1.0995116e12f;
-	const bool inImage = pxlo >= 1.f && pylo >= 1.f && pxhi <= (float)(sw - 2) && pyhi <= (float)(sh - 2);
-	// (int)pty in [tt0, tt0 + TC - 2]  <=>  tt0 <= pty < tt0 + TC - 1 once pty >= 1
-	const bool inWindow = pylo >= (float)tt0 && pyhi < (float)(tt0 + TC - 1) && slo >= ts0 && shi <= ts0 + PM_TR - 3;
-	if (exact && !inImage) { oob = true; return true; }
-	const bool ok = exact && (FROM_IMAGE || inWindow);
-	if (ok) { sum = s0; sumSq = s1; num = s2; }
-	return ok;
-}
-
-// The window-less optimistic rows (pm_tap_row_lds<.., FROM_IMAGE>) as a software pipeline over the five rows of a patch.  A wave walks ~110 tap rows
-// per visit and every row began with five scattered 16-byte loads whose latency (L2 / HBM: the quad images of a batch are far larger than the caches)
-// nothing else in the wave could cover -- the counters showed waves ~40 % VALU-active and a diagonal's launch lasting as long as one wave's chain of
-// such round trips.  Here the texel addresses and loads of row i+1 are issued before row i is consumed, and a row has no control flow: its sums are
-// committed unconditionally, `oob` / `redo` only record what the range checks found.  A patch with a row that was not exact (z outside
-// [2^-40, 2^40] or !sane: rare) is redone as a whole by the caller through pm_tap_row_global -- the fast rows produce exactly its sums, so redoing them
-// changes nothing.  PM_ROW_PIPELINE 0 restores the row-at-a-time loop.
-#ifndef PM_ROW_PIPELINE
-#define PM_ROW_PIPELINE 0
-#endif
-struct PMRowTaps { float ptx[5], pty[5], zlo, zhi; unsigned goff[5]; };
-struct PMRowQuads { float v00[5], v01[5], v10[5], v11[5]; };
-__device__ __forceinline__ void pm_row_prep(PMRowTaps& r, int sw, int sh, float h0, float h3, float h6, float X0, float X1, float X2) {
-	r.zlo = X2; r.zhi = X2;
-#pragma unroll
-	for (int j = 0; j < 5; ++j) {
-		pm_div2_inrange(X0, X1, X2, &r.ptx[j], &r.pty[j]);
-		r.zlo = pm_fminf(r.zlo, X2); r.zhi = pm_fmaxf(r.zhi, X2);
-		const int lx = (int)r.ptx[j], ly = (int)r.pty[j];
-		const int lxc = min(max(lx, 0), sw - 2), lyc = min(max(ly, 0), sh - 2);
-		r.goff[j] = (unsigned)(lxc + lyc) * (unsigned)sh + (unsigned)lyc;
-		X0 += h0; X1 += h3; X2 += h6;
-	}
-}
-__device__ __forceinline__ void pm_row_load(PMRowQuads& q, const PMRowTaps& r, const pm_gcf4 imgQ) {
-#pragma unroll
-	for (int j = 0; j < 5; ++j) pm_load4(imgQ, r.goff[j], q.v00[j], q.v01[j], q.v10[j], q.v11[j]);
-}
-__device__ __forceinline__ void pm_row_consume(const PMRowTaps& r, const PMRowQuads& q, int sw, int sh, bool sane, const float2* wrow,
-		float& sum, float& sumSq, float& num, bool& oob, bool& redo) {
-	float pxlo = PM_INF, pxhi = -PM_INF, pylo = PM_INF, pyhi = -PM_INF;
-#pragma unroll
-	for (int j = 0; j < 5; ++j) {
-		pxlo = pm_fminf(pxlo, r.ptx[j]); pxhi = pm_fmaxf(pxhi, r.ptx[j]); pylo = pm_fminf(pylo, r.pty[j]); pyhi = pm_fmaxf(pyhi, r.pty[j]);
-		const float fx = pm_fract_pos(r.ptx[j]), fx1 = 1.f - fx, fy = pm_fract_pos(r.pty[j]), fy1 = 1.f - fy;
-		const float v = (q.v00[j] * fx1 + q.v01[j] * fx) * fy1 + (q.v10[j] * fx1 + q.v11[j] * fx) * fy;
+		const float fx = pm_fract_pos(ptx[j]), fx1 = 1.f - fx, fy = pm_fract_pos(pty[j]), fy1 = 1.f - fy;   // == ptx - (float)(int)ptx for the positions the row is accepted with (>= 1)
+		const float v = (q[j].x * fx1 + q[j].y * fx) * fy1 + (q[j].z * fx1 + q[j].w * fx) * fy;
 		const float2 pw = wrow[j];
 		const float vw = v * pw.x;
 		sum += vw;
 		sumSq += v * vw;
 		num += v * pw.y;
 	}
-	const bool exact = sane && r.zlo >= 9.094947e-13f && r.zhi <= 1.0995116e12f;
-	const bool inImage = pxlo >= 1.f && pylo >= 1.f && pxhi <= (float)(sw - 2) && pyhi <= (float)(sh - 2);
-	oob = oob || (exact && !inImage);
-	redo = redo || !exact;
 }
 
-// PF: the pixel's low-resolution prior and its blend factor exp(normSq0 * sigma) sit in the spare 26th entry of the pixel's weight row in LDS
-// (written once per visit by the sweep kernel) instead of in two registers that are live across the whole hypothesis loop
-// what pm_score_view needs to evaluate the lane's smoothness factor itself (PM_SMOOTH_IN_ROW0)
-struct PMSmoothIn { float qX0, qX1, qX2, qn0, qn1, qn2, vx, vy, vz; bool on; };
-
-template <bool GEO, bool SKEW, int TC, bool PF = false, bool SIN = false>
+// ScorePixelImage for this lane's source view, DepthMap.cpp:465-564.
+// sf0..3: the (view-independent) smoothness factors of the up-to-4 close neighbours, in insertion order; exactly 1.f for a neighbour that does not exist or does
+// not take part (DepthMap.cpp:524-533).
+// MODE 0: guarded tap rows from the row-major image (init kernel: no anti-diagonal to exploit, one evaluation per pixel);
+// MODE 1: optimistic rows from the view's quad image through its own pointer;  MODE 2: optimistic rows from the level's quad buffer (pm_tap_row_fast<true>).
+// PF: the pixel's low-resolution prior and its blend factor exp(normSq0 * sigma) sit in the spare 26th entry of the pixel's weight row in LDS (written once per
+// visit by the sweep kernels) instead of in two registers that are live across the whole hypothesis loop.
+// hot / geoTab: the hot and geometric blocks of `s` (PMSrcView), in HBM (init kernel) or in the wave's LDS copy (sweep kernels); the image size and the view's
+// first entry in the level's quad buffer travel with the homography entries.
+template <bool GEO, int MODE, bool PF = false>
 __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask& t, const PMKParams& kp,
 		int x, int y, double X0x, double X0y, float normSq0, float sumW, const float2* wts,
 		float depth, float nx, float ny, float nz,
 		float sf0, float sf1, float sf2, float sf3, float prior,
-		const float* tile, int ts0, int tt0, const double* hot, const double* geoTab, const float* Hpre, const PMSmoothIn* sin = nullptr, bool viewOk = true PM_PROF_ARG)
+		const double* hot, const double* geoTab, const pm_rsrc& rs PM_PROF_ARG)
 {
-	// hot / geoTab: the hot and geometric blocks of `s` (PMSrcView), in HBM (init kernel) or in the wave's LDS copy (sweep kernel); the image
-	// size travels with the homography entries
 	const int sw = ((const int*)(hot + 12))[0], sh = ((const int*)(hot + 12))[1];
 	float H[9];
-	if (Hpre) {   // computed by the caller next to the other per-hypothesis chains (instruction-level parallelism), see pm_sweep_kernel
-#pragma unroll
-		for (int i = 0; i < 9; ++i) H[i] = Hpre[i];
-	} else pm_homography(hot, t, X0x, X0y, depth, nx, ny, nz, H);
+	pm_homography(hot, t, X0x, X0y, depth, nx, ny, nz, H);
 	PM_TICK(3);
 	const float px = (float)(x - PM_HW), py = (float)(y - PM_HW);
 	const float X0 = H[0] * px + H[1] * py + H[2];
@@ -513,98 +410,48 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 #pragma unroll
 	for (int i = 0; i < 9; ++i) H[i] *= 2.f; // nSizeStep
 	float sum = 0.f, sumSq = 0.f, num = 0.f;
-	bool oob = !viewOk;   // a lane without a source view (SIN only) is flagged from the start: its rows are never redone, its score is discarded
-	// |x|, |y| < 1e18 and |z| < 2^40 for every tap of the patch, from the first tap and the step sizes (8 steps along either axis at most)
-	// FASTG: no LDS windows (PM_USE_TILES = 0); the optimistic row reads its texels straight from the anti-diagonal-major image (vector L1)
-	constexpr bool FASTG = SKEW && TC == 0;
-	bool sane = false;
-	if (TC > 0 || FASTG)
-		sane = pm_fabsf(X0) + 8.f * (pm_fabsf(H[0]) + pm_fabsf(H[1])) < 5e17f && pm_fabsf(X1) + 8.f * (pm_fabsf(H[3]) + pm_fabsf(H[4])) < 5e17f
+	bool oob = false;
+	if (MODE == 0) {
+#pragma unroll 1
+		for (int i = 0; i < 5; ++i) {
+			pm_tap_row_global<false>(pm_glob(s.img), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
+			bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
+		}
+	} else {
+		// |x|, |y| < 1e18 and |z| < 2^40 for every tap of the patch, from the first tap and the step sizes (8 steps along either axis at most)
+		const bool sane = pm_fabsf(X0) + 8.f * (pm_fabsf(H[0]) + pm_fabsf(H[1])) < 5e17f && pm_fabsf(X1) + 8.f * (pm_fabsf(H[3]) + pm_fabsf(H[4])) < 5e17f
 			&& pm_fabsf(X2) + 8.f * (pm_fabsf(H[6]) + pm_fabsf(H[7])) < 5e11f;
-	int iFirst = 0;
-	if (SIN && TC > 0) {
-		// the lane's smoothness factor (DepthMap.cpp:524-533), branch-free, then the first tap row: one basic block for the scheduler to interleave
-		const float planeD = -depth * (nx * sin->vx + ny * sin->vy + nz * sin->vz); // InitPlane, DepthMap.cpp:963-971
-		const float dist = (nx * sin->qX0 + (ny * sin->qX1 + nz * sin->qX2)) + planeD; // Planef::Distance, Eigen 3-dot order
-		const float r = dist / depth;
-		const float factorDepth = pm_expf((r * r) * kp.smoothSigmaDepth);
-		const float ca = pm_clampf((nx * sin->qn0 + ny * sin->qn1 + nz * sin->qn2) /
-			pm_sqrtf((nx * nx + ny * ny + nz * nz) * (sin->qn0 * sin->qn0 + sin->qn1 * sin->qn1 + sin->qn2 * sin->qn2)), -1.f, 1.f);
-		const float ac = pm_acosf(ca);
-		const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
-		const float f = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
-		const float myF = sin->on ? f : 1.f;
-		const bool done0 = pm_tap_row_lds<TC>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts, sum, sumSq, num, oob) || oob;
-		sf0 = pm_quad_bcast<0>(myF); sf1 = pm_quad_bcast<1>(myF); sf2 = pm_quad_bcast<2>(myF); sf3 = pm_quad_bcast<3>(myF);
-		if (!done0) pm_tap_row_global<SKEW>(pm_glob(SKEW ? s.imgS : s.img), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts, sum, sumSq, num, oob);
-		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
-		iFirst = 1;
-	}
-#ifdef PM_PROBE_NO_TAPS
-	if (TC > 0) { sum = 0.31f * sumW; sumSq = 0.11f * sumW + 0.01f * H[2]; num = 0.004f * H[5]; }
-	else
-#endif
-	if (FASTG && PM_ROW_PIPELINE) {
+		const unsigned qbase = ((const unsigned*)(hot + 13))[0];
 		const pm_gcf4 imgQ = pm_glob4(s.imgQ);
 		const float rX0 = bX0, rX1 = bX1, rX2 = bX2;
-		const bool oobIn = oob;
-		bool redo = false;
-		PMRowTaps ta, tb; PMRowQuads qa, qb;
-		pm_row_prep(ta, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2);
-		pm_row_load(qa, ta, imgQ);
-		// rows (0,1), (2,3) as one loop body with the A / B register sets swapping roles (no copies), then row 4
+		int zlo = 0x7fffffff, zhi = (int)0x80000000, plo = 0x7fffffff, pxhi = (int)0x80000000, pyhi = (int)0x80000000;
 #pragma unroll 1
-		for (int i = 0; i < 4; i += 2) {
+		for (int i = 0; i < 5; ++i) {
+			pm_tap_row_fast<MODE == 2>(rs, qbase, imgQ, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, zlo, zhi, plo, pxhi, pyhi);
 			bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
-			pm_row_prep(tb, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2); pm_row_load(qb, tb, imgQ);
-			pm_row_consume(ta, qa, sw, sh, sane, wts + i * 5, sum, sumSq, num, oob, redo);
-			bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
-			pm_row_prep(ta, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2); pm_row_load(qa, ta, imgQ);
-			pm_row_consume(tb, qb, sw, sh, sane, wts + (i + 1) * 5, sum, sumSq, num, oob, redo);
 		}
-		pm_row_consume(ta, qa, sw, sh, sane, wts + 20, sum, sumSq, num, oob, redo);
+		const bool exact = sane && zlo >= pm_f2i(9.094947e-13f) && zhi <= pm_f2i(1.0995116e12f);   // 2^-40 <= z <= 2^40 on the whole patch
+		const bool outside = !(plo >= pm_f2i(1.f) && pxhi <= pm_f2i((float)(sw - 2)) && pyhi <= pm_f2i((float)(sh - 2)));   // a tap with x < 1, y < 1, x > w - 2 or y > h - 2
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(PM_DEBUG_REDO)
-		{ static unsigned long long c[3]; static bool reg = false; if (!reg) { reg = true; atexit([] { fprintf(stderr, "FASTG evaluations %llu, redo %llu, redo && !oob %llu\n", c[0], c[1], c[2]); }); } c[0]++; if (redo) c[1]++; if (redo && !oob) c[2]++; }
+		{ static unsigned long long c[2]; static bool reg = false; if (!reg) { reg = true; atexit([] { fprintf(stderr, "optimistic evaluations %llu, redone %llu\n", c[0], c[1]); }); } c[0]++; if (!exact) c[1]++; }
 #endif
-		if (redo && !oob) {   // a row outside the fast divisions' range: the whole patch through the guarded path (same sums where the fast rows were valid)
-			sum = 0.f; sumSq = 0.f; num = 0.f; oob = oobIn;
+		if (exact) oob = outside;
+		else {   // (rare: a plane almost parallel to a viewing ray) the whole patch through the guarded path
+			sum = 0.f; sumSq = 0.f; num = 0.f;
 			bX0 = rX0; bX1 = rX1; bX2 = rX2;
 #pragma unroll 1
 			for (int i = 0; i < 5; ++i) {
-				pm_tap_row_global<SKEW>(pm_glob(SKEW ? s.imgS : s.img), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
+				pm_tap_row_global<true>(pm_glob(s.imgS), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
 				bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
 			}
 		}
-	} else
-#pragma unroll 1
-	for (int i = iFirst; i < 5; ++i) {
-		bool done = false;
-		if (TC > 0) done = pm_tap_row_lds<TC>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob) || oob;
-#ifdef PM_PROFILE
-		if (TC > 0) { PM_COUNT(10, __popcll(__ballot(done))); PM_COUNT(11, __popcll(__ballot(true))); PM_COUNT(7, __all(done) ? 1 : 0); }
-#endif
-#ifdef PM_PROBE_NO_FALLBACK
-		if (TC > 0) done = true;
-#endif
-		if (((PM_GLOBAL_FAST_ROW && TC > 0 && SKEW) || FASTG) && !done)
-			done = pm_tap_row_lds<(TC > 0 ? TC : 1), true>(tile, ts0, tt0, sw, sh, sane, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob, pm_glob4(s.imgQ)) || oob;
-		if (!done) pm_tap_row_global<SKEW>(pm_glob(SKEW ? s.imgS : s.img), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
-		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
 	}
 	PM_TICK(4);
 	if (oob) return kp.thRobust;
-#ifdef PM_PROBE_FAST_EPILOGUE
-	const float normSq1 = sumSq - (sum * sum) * __builtin_amdgcn_rcpf(sumW);
-#else
 	const float normSq1 = sumSq - (sum * sum) / sumW;
-#endif
 	const float nrmSq = normSq0 * normSq1;
 	if (nrmSq <= 1e-16f) return kp.thRobust;
-#ifdef PM_PROBE_FAST_EPILOGUE
-	const float ncc = pm_clampf(num * __builtin_amdgcn_rsqf(nrmSq), -1.f, 1.f);
-#else
 	const float ncc = pm_clampf(num / pm_sqrtf(nrmSq), -1.f, 1.f);
-#endif
 	float score = 1.f - ncc;
 	// (a factor of a neighbour that does not take part is exactly 1.f, and x * 1.f == x: no test needed, DepthMap.cpp:524-533)
 	score *= sf0; score *= sf1; score *= sf2; score *= sf3;
@@ -623,12 +470,7 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		for (int i = 0; i < 9; ++i) PM_OPAQUE(Tr[i]);
 #pragma unroll
 		for (int i = 0; i < 3; ++i) PM_OPAQUE(Tn[i]);
-#ifdef PM_PROBE_NO_GEO_SAMPLES
-		if (sdepth != nullptr) score += kp.geoWeight * 4.f;
-		if (false) {
-#else
 		if (sdepth != nullptr) {
-#endif
 			float consistency = 4.f;
 			const float Xc0 = (float)X0x * depth, Xc1 = (float)X0y * depth, Xc2 = depth;
 			const float Y0 = (Tl[0] * Xc0 + Tl[1] * Xc1 + Tl[2] * Xc2) + Tm[0];
@@ -692,20 +534,6 @@ __device__ __forceinline__ float pm_aggregate(float viewScore, int nSrc, float t
 	return (m1 + m2) / 2.f;
 }
 
-// The same for view-major lanes (lane = v * (64 / G) + g: the lanes of a pixel are 64 / G apart): butterfly over the lane index bits above the pixel index
-template <int G>
-__device__ __forceinline__ float pm_aggregate_vm(float viewScore, int nSrc, float thRobust, float viewScore2) {
-	float a = viewScore, b = viewScore2;
-#pragma unroll
-	for (int m = 64 / G; m < 64; m <<= 1) {
-		const float oa = __shfl_xor(a, m, 64), ob = __shfl_xor(b, m, 64);
-		const float na = pm_minf(a, oa), nb = pm_minf(pm_maxf(a, oa), pm_minf(b, ob)); a = na; b = nb;
-	}
-	if (nSrc <= 1) return a;
-	if (b >= thRobust) return a;
-	return (a + b) / 2.f;
-}
-
 // FillPixelPatch, DepthMap.cpp:422-462: cooperative weights into LDS; returns normSq0, sumW.
 // Must be called by every thread of the workgroup (contains __syncthreads()).
 template <int G, bool SKEW>
@@ -733,11 +561,7 @@ __device__ __forceinline__ void pm_fill_patch(const PMTask& t, bool inb, int x, 
 			const float dc = I - colCenter;
 			const float wColor = (dc * dc) * sigmaColor;
 			const float wSpatial = (float)(j * j + i * i) * sigmaSpatial;
-#ifdef PM_PROBE_NO_WEIGHTS
-			wts[k] = make_float2(0.5f + 0.01f * (float)k, 0.3f + 0.02f * (float)(k % 7));
-#else
 			wts[k] = make_float2(pm_expf(wColor + wSpatial), I);
-#endif
 		}
 	}
 	__syncthreads();
@@ -798,362 +622,9 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 	float sc = PM_INF;
 	PM_PROF_DECL;
 	if (v < t.nSrc)
-		sc = pm_score_view<GEO, false, 0>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, nullptr, 0, 0, t.src[v].Hl, (const double*)t.src[v].Tl, nullptr PM_PROF_PASS);
+		sc = pm_score_view<GEO, 0>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, t.src[v].Hl, (const double*)t.src[v].Tl, pm_rsrc() PM_PROF_PASS);
 	const float conf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 	if (v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
-}
-
-// -------------------------------------------------------------------------------------------
-// ProcessPixel, DepthMap.cpp:630-852, for all pixels of anti-diagonal x+y == d (x = xlo + i).
-// dir 0 = LT2RB (left/top are new), 1 = RB2LT (right/bottom are new).
-// VPL = source views per lane: lane v of a pixel's G lanes scores views v, v + G, ..., one after the other.  Everything that is per pixel
-// (hypothesis generation, smoothness factors, the visit's set-up, accept / reject: about 70 % of a wave's time at one view per lane, measured
-// with -DPM_PROFILE) is then shared by VPL times as many pixels per wave; MINMEAN does not care which lane scored which view.
-template <int G, int VPL, bool GEO>
-__global__ __launch_bounds__(PM_BLOCK, (!PM_USE_TILES ? PM_MINWAVES : VPL >= 4 ? 1 : VPL == 2 ? 2 : PM_MINWAVES)) void pm_sweep_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
-	constexpr int PPB = PM_BLOCK / G;
-	constexpr int SL = (G >= 4) ? 1 : 4 / G; // smoothness slots owned per lane
-	constexpr int PPW = 64 / G;               // pixels per wave
-	constexpr int NV = G * VPL;               // source views the wave holds windows for
-	constexpr int TC = PM_USE_TILES ? PPW + PM_TCX : 0;
-	constexpr int TSTRIDE = PM_TR * TC + PM_TILE_PAD;
-	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
-	PM_PROF_DECL;
-	__shared__ float2 s_w[PPB][PM_NT + 1];
-	__shared__ float s_tile[PM_USE_TILES ? PM_BLOCK / 64 : 1][PM_USE_TILES ? NV * TSTRIDE : 1];
-	__shared__ int2 s_org[PM_BLOCK / 64][NV];   // window origin (ts0, tt0) of every view
-	// Per-view constants of the wave's source views: every hypothesis evaluation of every pixel needs the hot block of its lane's view (Hl, Hm, image
-	// size; in the geometric pass also the four transforms and the depth-map pointer) -- a global round trip at the head of each evaluation when read
-	// from the task.  One coalesced copy per visit puts them an LDS read away (832 B per wave at G = 8, twice that in the geometric pass).
-	__shared__ double s_src[PM_BLOCK / 64][NV * NBD];
-	// XCD-aware block mapping: workgroup b is observed to run on XCD b % 8 (dispatch order, x fastest), each XCD with its own 4 MB L2.  The remap
-	// hands every XCD a contiguous range of (view, diagonal chunk) pairs -- the same few views launch after launch -- so the source windows of
-	// neighbouring chunks and of the next diagonal are found in that XCD's L2 instead of being fetched into several of them.  Bijective for any
-	// grid size; which workgroup handles which pixels does not matter for the result (the pixels of a diagonal are independent).
-	unsigned vbx = blockIdx.x, vby = blockIdx.y;
-	if (PM_XCD_REMAP) {
-		const unsigned nbx = gridDim.x, nwg = nbx * gridDim.y, orig = blockIdx.y * nbx + blockIdx.x;
-		const unsigned xcd = orig % 8u, q = nwg / 8u, r = nwg % 8u;
-		const unsigned wgid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + orig / 8u;
-		vby = wgid / nbx; vbx = wgid - vby * nbx;
-	}
-	const PMTask& t = tasks[vby];
-	const int g = threadIdx.x / G, v = threadIdx.x % G;
-	{
-		double* dst = s_src[threadIdx.x >> 6];
-		for (int i = threadIdx.x & 63; i < NV * NBD; i += 64) dst[i] = ((const double*)&t.src[i / NBD])[i % NBD];   // views >= nSrc: zeros (the task is memset), never used
-	}
-	const double* hotBase = s_src[threadIdx.x >> 6];   // view k's blocks at hotBase + k * NBD
-	const int w = t.w, h = t.h;
-	const int pi = vbx * PPB + g;
-	const bool active = pi < count;
-	const int x = xlo + (active ? pi : 0), y = d - x;
-	const size_t idx = (size_t)y * w + x;
-	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
-	// neighbour slots in insertion order (DepthMap.cpp:641-766): with sgn = -1 (LT2RB) / +1 (RB2LT):
-	// slot0 (x+sgn,y), slot1 (x,y+sgn) are the already-updated propagation sources; slot2 (x-sgn,y), slot3 (x,y-sgn).
-	const int sgn = dir == 0 ? -1 : 1;
-	// Everything the visit reads of its own and its neighbours' estimates, the prior and the mask is requested here, before the patch weights:
-	// the loads do not depend on each other, so they share one memory round trip with the patch texels (pm_fill_patch ends in a barrier, which
-	// keeps the compiler from sinking them below the tests that decide whether the pixel is processed).  Neighbours outside the processable
-	// area are redirected to the pixel itself and masked; a pixel that turns out not to be processed simply ignores what it fetched.
-	size_t qis[4]; bool bok[4]; int qxs[4], qys[4];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		const int ox = (k == 0) ? sgn : (k == 2 ? -sgn : 0), oy = (k == 1) ? sgn : (k == 3 ? -sgn : 0);
-		// bounds tests exactly as written: x > HW / y > HW / x < W-HW / y < H-HW
-		bool ok;
-		if (ox == -1) ok = x > PM_HW; else if (ox == 1) ok = x < w - PM_HW; else if (oy == -1) ok = y > PM_HW; else ok = y < h - PM_HW;
-		bok[k] = ok; qxs[k] = x + ox; qys[k] = y + oy;
-		qis[k] = ok ? (size_t)(y + oy) * w + (x + ox) : idx;
-	}
-	float nds[4] = {0.f, 0.f, 0.f, 0.f};
-	float on0[SL], on1[SL], on2[SL];
-	float oDepth = 0.f, oNx = 0.f, oNy = 0.f, oNz = 0.f, oConf = 2.f, prior = 0.f;
-	unsigned char maskByte = 1;
-#pragma unroll
-	for (int q = 0; q < SL; ++q) { on0[q] = on1[q] = 0.f; on2[q] = 1.f; }
-	if (active) {
-		if (t.prior) prior = pm_glob(t.prior)[idx];
-		if (t.mask != nullptr) maskByte = t.mask[idx];
-#pragma unroll
-		for (int k = 0; k < 4; ++k) nds[k] = gDepth[qis[k]];
-#pragma unroll
-		for (int q = 0; q < SL; ++q) {
-			const int k = (G >= 4) ? (v & 3) : q * G + v;   // G >= 4: every quad of the group holds all four slots (lane v owns slot v % 4)
-			const size_t qi = (k == 0) ? qis[0] : (k == 1) ? qis[1] : (k == 2) ? qis[2] : (k == 3) ? qis[3] : idx;
-			on0[q] = gNormal[qi * 3]; on1[q] = gNormal[qi * 3 + 1]; on2[q] = gNormal[qi * 3 + 2];
-		}
-		oDepth = gDepth[idx]; oNx = gNormal[idx * 3]; oNy = gNormal[idx * 3 + 1]; oNz = gNormal[idx * 3 + 2]; oConf = gConf[idx];
-	}
-	float normSq0, sumW;
-	pm_fill_patch<G, true>(t, active, x, y, v, s_w[g], normSq0, sumW);
-	const bool masked = active && maskByte == 0;
-	const bool valid = active && !masked && !(normSq0 < kp.thMagnitudeSq && !(prior > 0));
-	// prior and its blend factor (DepthMap.cpp:558-559) go to the spare entry of the weight row: pm_score_view<.., PF = true> reads them there
-	if (v == 0) s_w[g][PM_NT] = make_float2(prior, prior > 0 ? pm_expf(normSq0 * (-1.f / (1.f * 0.02f))) : 0.f);
-	__syncthreads();
-	PM_TICK(12);
-	const double X0x = ((double)x - t.cx) / t.fx, X0y = ((double)y - t.cy) / t.fy;
-	const float vx = (float)X0x, vy = (float)X0y, vz = 1.f;
-
-	float depth = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, conf = 2.f;
-	bool pok0 = false, pok1 = false; // propagation candidates (slots 0 and 1) exist; their estimates are re-read when used
-	float qX0[SL], qX1[SL], qX2[SL], qn0[SL], qn1[SL], qn2[SL]; // my smoothness slot(s)
-	unsigned closeMask = 0u;
-#pragma unroll
-	for (int q = 0; q < SL; ++q) { qX0[q] = qX1[q] = qX2[q] = 0.f; qn0[q] = qn1[q] = 0.f; qn2[q] = 1.f; }
-	if (valid) {
-		depth = oDepth; nx = oNx; ny = oNy; nz = oNz; conf = oConf;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const bool ok = bok[k] && nds[k] > 0;
-			if (ok) closeMask |= 1u << k;
-			if (k == 0 && ok) pok0 = true;
-			if (k == 1 && ok) pok1 = true;
-			if (ok && ((G >= 4) ? (v & 3) == k : (k % G) == v)) {
-				const int q = (k / G < SL) ? k / G : 0;
-				// TransformPointI2C(Point3(nx, ndepth)) in double then Cast<float>, Camera.h:338-344
-				const double z = (double)nds[k];
-				qX0[q] = (float)(((double)qxs[k] - t.cx) * z / t.fx);
-				qX1[q] = (float)(((double)qys[k] - t.cy) * z / t.fy);
-				qX2[q] = (float)z;
-				qn0[q] = on0[q]; qn1[q] = on1[q]; qn2[q] = on2[q];
-			}
-		}
-	}
-	// ---- stage source tiles in LDS -------------------------------------------------------------------
-	// Every hypothesis of this visit (propagated neighbours' planes, small perturbations of the current plane)
-	// projects close to where the current plane does, so one window per (wave, view) around the current
-	// footprints serves nearly all 100 x ~8 taps; the rest (random restarts, depth discontinuities) fall back
-	// to global loads tap-row by tap-row.  Window origin = min over the wave's pixels of the footprint centre.
-	const float* tileBase = nullptr;
-	if (TC > 0) {
-		const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-		for (int u = 0; u < VPL; ++u) {
-			const int view = v + u * G;
-			int cs = 0x7fffffff, ctt = 0x7fffffff;
-			if (valid && view < t.nSrc) {
-				float Hc[9];
-				pm_homography(hotBase + view * NBD, t, X0x, X0y, depth, nx, ny, nz, Hc);
-				const float fxp = (float)x, fyp = (float)y;
-				const float c0 = Hc[0] * fxp + Hc[1] * fyp + Hc[2], c1 = Hc[3] * fxp + Hc[4] * fyp + Hc[5], c2 = Hc[6] * fxp + Hc[7] * fyp + Hc[8];
-				const float cu = c0 / c2, cv = c1 / c2;
-				if (cu > -1e6f && cu < 1e6f && cv > -1e6f && cv < 1e6f) { const int iu = (int)pm_floorf(cu), iv = (int)pm_floorf(cv); cs = iu + iv; ctt = iv; }
-			}
-#pragma unroll
-			for (int m = G; m < 64; m <<= 1) { cs = min(cs, __shfl_xor(cs, m, 64)); ctt = min(ctt, __shfl_xor(ctt, m, 64)); }
-			if (cs == 0x7fffffff) { cs = 0; ctt = 0; }
-			if (lane < G) s_org[wave][view] = make_int2(cs - 8 - (PM_TR - 19) / 2, ctt - PM_HW - (PM_TCX - 9) / 2);
-		}
-		__syncthreads();
-		PM_TICK(13);
-		float* tw = s_tile[wave];
-		const int nS = t.nSrc;
-		constexpr int TCD = TC > 0 ? TC : 1;
-		constexpr int NLD = (PM_TR * TCD + 63) / 64;
-		constexpr int WB = NLD > 8 ? 2 : PM_WINBATCH;   // wide windows (many pixels per wave): fewer in flight, the registers are needed
-		// WB windows are requested together: the loads of a window are one memory round trip, and the round trips of
-		// the nSrc windows of a visit are a serial chain at the head of every wave's life
-		for (int vb = 0; vb < nS; vb += WB) {
-			float vals[WB][NLD];
-#pragma unroll
-			for (int b = 0; b < WB; ++b) {
-				const int vv = vb + b;
-				if (vv >= nS) break;
-				const int2 org = s_org[wave][vv];
-				const int fs0 = org.x, ft0 = org.y;
-				const pm_gcf src = pm_glob(t.src[vv].imgS);
-				const int sh = t.src[vv].h, sMax = t.src[vv].w + t.src[vv].h - 1;
-#pragma unroll
-				for (int k = 0; k < NLD; ++k) { // all loads of the batch first, then the LDS writes
-					const int i = lane + 64 * k;
-					const int r = i / TCD, c = i - r * TCD;
-					const int ss = fs0 + r, tt = ft0 + c;
-#ifdef PM_PROBE_NO_STAGING
-					vals[b][k] = 0.25f;
-#else
-					vals[b][k] = (i < PM_TR * TC && ss >= 0 && ss < sMax && tt >= 0 && tt < sh) ? src[(size_t)ss * sh + tt] : 0.f;
-#endif
-				}
-			}
-#pragma unroll
-			for (int b = 0; b < WB; ++b) {
-				const int vv = vb + b;
-				if (vv >= nS) break;
-#ifndef PM_PROBE_NO_STAGING
-#pragma unroll
-				for (int k = 0; k < NLD; ++k) { const int i = lane + 64 * k; if (i < PM_TR * TC) tw[vv * TSTRIDE + i] = vals[b][k]; }
-#endif
-			}
-		}
-		tileBase = tw;
-		__syncthreads();
-	}
-	// state machine: every outer trip scores at most one hypothesis per pixel, so the lanes of a wave
-	// stay converged on the expensive part whatever branch each pixel is in.
-	enum { ST_PROP0 = 0, ST_PROP1 = 1, ST_DECIDE = 2, ST_RAND = 3, ST_REFINE = 4, ST_DONE = 5 };
-	int st = valid ? ST_PROP0 : ST_DONE;
-	unsigned it = 0, idxScale = 0;
-	float scaleRange = 1.f, depthRange = 0.f, p0 = 0.f, p1 = 0.f;
-	bool smooth = true, changed = false;
-	const uint32_t k1 = t.k1base + pass;
-	PmPhilox4 rNext; unsigned rNextIt = 0xffffffffu;   // draw of refinement iteration rNextIt, computed one evaluation ahead (counter-based: same bits)
-#pragma unroll
-	for (int i = 0; i < 4; ++i) rNext.v[i] = 0u;
-	PM_TICK(0); PM_COUNT(9, 1);
-	for (;;) {
-		bool need = false;
-		float hd = 0.f, hnx = 0.f, hny = 0.f, hnz = 1.f, hp0 = 0.f, hp1 = 0.f;
-		int hst = ST_DONE;
-		while (!need && st != ST_DONE) {
-			if (st <= ST_PROP1) {
-				const bool vert = (st == ST_PROP1); ++st; // slot 0: same row, slot 1: same column
-				const bool pok = vert ? pok1 : pok0;
-				// the neighbour (already updated in this sweep, one diagonal earlier) is not touched again before we are done
-				const size_t qi = vert ? (size_t)(y + sgn) * w + x : (size_t)y * w + (x + sgn);
-				const size_t qj = pok ? qi : idx;
-				const float pconf = gConf[qj], cnx = gNormal[qj * 3], cny = gNormal[qj * 3 + 1], cnz = gNormal[qj * 3 + 2], cd = gDepth[qj]; // one batch
-				// (assigned whether or not the candidate is taken -- every state that sets `need` sets all four again -- so that the five loads stay
-				// one batch: the compiler otherwise sinks four of them below the test of the fifth, two dependent round trips per propagation state)
-				hd = cd; hnx = cnx; hny = cny; hnz = cnz;
-				if (pok && pconf < kp.thKeep) {
-					// InterpolatePixel, DepthMap.cpp:915-959
-					float depthNew = cd; bool zero;
-					if (vert) { // same column
-						const float nx1 = (float)(((double)y - t.cy) / t.fy);
-						const float denom = cnz + nx1 * cny;
-						zero = pm_fabsf(denom) < 0.0001f;
-						const float x1 = (float)(((double)(y + sgn) - t.cy) / t.fy);
-						const float nom = cd * (cnz + x1 * cny);
-						if (!zero) depthNew = nom / denom;
-					} else {
-						const float nx1 = (float)(((double)x - t.cx) / t.fx);
-						const float denom = cnz + nx1 * cnx;
-						zero = pm_fabsf(denom) < 0.0001f;
-						const float x1 = (float)(((double)(x + sgn) - t.cx) / t.fx);
-						const float nom = cd * (cnz + x1 * cnx);
-						if (!zero) depthNew = nom / denom;
-					}
-					hd = (!zero && pm_in_range(depthNew, t.dMin, t.dMax)) ? depthNew : cd;
-					hnx = cnx; hny = cny; hnz = cnz;
-					pm_correct_normal(vx, vy, vz, hnx, hny, hnz);
-					need = true; hst = ST_PROP0;
-				}
-			} else if (st == ST_DECIDE) {
-				// RefineIters:, DepthMap.cpp:802-827
-				if (conf <= kp.thConfSmall) idxScale = 2;
-				else if (conf <= kp.thConfBig) idxScale = 1;
-				else if (conf >= kp.thConfRand) { smooth = false; st = ST_RAND; it = 0; continue; }
-				scaleRange = pm_pow2neg(idxScale);
-				depthRange = depth * kp.depthRatio;
-				p0 = pm_atan2f(ny, nx); p1 = pm_acosf(pm_clampf(nz, -1.f, 1.f)); // Normal2Dir
-				st = ST_REFINE; it = 0;
-			} else if (st == ST_RAND) {
-				if (it >= kp.nRandomIters) { st = ST_DONE; break; }
-				const PmPhilox4 r = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_RAND * 256) + it, 0u, t.k0, k1);
-				++it;
-				const float rr = t.dMinSqr + (t.dMaxSqr - t.dMinSqr) * pm_u32_to_unit(r.v[0]);
-				hd = rr * rr;
-				pm_random_normal(pm_u32_to_unit(r.v[1]), pm_u32_to_unit(r.v[2]), vx, vy, vz, hnx, hny, hnz);
-				need = true; hst = ST_RAND;
-			} else { // ST_REFINE, DepthMap.cpp:832-852
-				if (it >= kp.nRandomIters) { st = ST_DONE; break; }
-				PmPhilox4 r = rNext;
-				if (!PM_ILP_PHILOX || rNextIt != it) r = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_REFINE * 256) + it, 0u, t.k0, k1);
-				++it;
-				const float ndepth = depth + (depthRange * scaleRange) * (2.f * pm_u32_to_unit(r.v[0]) - 1.f);
-				if (!pm_in_range(ndepth, t.dMin, t.dMax)) continue;
-				hp0 = p0 + (kp.angle1Range * scaleRange) * (2.f * pm_u32_to_unit(r.v[1]) - 1.f);
-				hp1 = p1 + (kp.angle2Range * scaleRange) * (2.f * pm_u32_to_unit(r.v[2]) - 1.f);
-				pm_dir2normal(hp0, hp1, hnx, hny, hnz);
-				if (hnx * vx + hny * vy + hnz * vz >= 0) continue;
-				hd = ndepth;
-				need = true; hst = ST_REFINE;
-			}
-		}
-		if (!__any(need)) break;
-		PM_TICK(1); PM_COUNT(6 + 5, 0); PM_COUNT(8, __popcll(__ballot(need)));
-		// smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533
-		// smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533, one neighbour per lane.  (With the PM_ILP_*
-		// switches the homography of the lane's view and the next refinement draw join this block branch-free, so that the scheduler could interleave
-		// the three dependent chains; measured slower, see the switches.)
-		float sf[4] = {1.f, 1.f, 1.f, 1.f};
-		float Hpre[9];
-		{
-			const bool useS = need && smooth;
-			const float planeD = -hd * (hnx * vx + hny * vy + hnz * vz); // InitPlane, DepthMap.cpp:963-971
-			float myF[SL];
-#pragma unroll
-			for (int q = 0; q < SL; ++q) {
-				const int k = (G >= 4) ? (v & 3) : q * G + v;
-#ifdef PM_PROBE_NO_SMOOTH
-				const bool on = false;
-#else
-				const bool on = !(PM_SMOOTH_IN_ROW0 && VPL == 1 && G >= 4 && TC > 0) && useS && k < 4 && ((closeMask >> k) & 1u);
-#endif
-				myF[q] = 1.f;
-				if (PM_ILP_SMOOTH || on) {
-					const float dist = (hnx * qX0[q] + (hny * qX1[q] + hnz * qX2[q])) + planeD; // Planef::Distance, Eigen 3-dot order
-					const float r = dist / hd;
-					const float factorDepth = pm_expf((r * r) * kp.smoothSigmaDepth);
-					const float ca = pm_clampf((hnx * qn0[q] + hny * qn1[q] + hnz * qn2[q]) /
-						pm_sqrtf((hnx * hnx + hny * hny + hnz * hnz) * (qn0[q] * qn0[q] + qn1[q] * qn1[q] + qn2[q] * qn2[q])), -1.f, 1.f);
-					const float ac = pm_acosf(ca);
-					const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
-					const float f = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
-					myF[q] = on ? f : 1.f;
-				}
-			}
-			if (VPL == 1 && PM_ILP_HOMOGRAPHY) pm_homography(hotBase + v * NBD, t, X0x, X0y, hd, hnx, hny, hnz, Hpre);
-			if (PM_ILP_PHILOX) { rNext = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_REFINE * 256) + it, 0u, t.k0, k1); rNextIt = it; }
-			if (G >= 4) { sf[0] = pm_quad_bcast<0>(myF[0]); sf[1] = pm_quad_bcast<1>(myF[0]); sf[2] = pm_quad_bcast<2>(myF[0]); sf[3] = pm_quad_bcast<3>(myF[0]); }
-			else {
-#pragma unroll
-				for (int k = 0; k < 4; ++k)
-					sf[k] = __shfl(myF[k / G < SL ? k / G : 0], (k % G), G);
-			}
-		}
-		PM_TICK(2);
-		float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
-		if (PM_SMOOTH_IN_ROW0 && VPL == 1 && G >= 4 && TC > 0) {
-			// every lane of a pixel with a hypothesis enters: the smoothness chain is evaluated next to the first tap row (see the switch)
-			if (need) {
-				const bool viewOk = v < t.nSrc;
-				const int slot = v & 3;
-				PMSmoothIn sin;
-				sin.qX0 = qX0[0]; sin.qX1 = qX1[0]; sin.qX2 = qX2[0]; sin.qn0 = qn0[0]; sin.qn1 = qn1[0]; sin.qn2 = qn2[0];
-				sin.vx = vx; sin.vy = vy; sin.vz = vz;
-				sin.on = smooth && ((closeMask >> slot) & 1u);
-				const int2 org = s_org[threadIdx.x >> 6][v];
-				const float s1 = pm_score_view<GEO, true, TC, true, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, 1.f, 1.f, 1.f, 1.f, 0.f,
-					tileBase + v * TSTRIDE, org.x, org.y, hotBase + v * NBD, hotBase + v * NBD + PM_SRC_HOT, nullptr, &sin, viewOk PM_PROF_PASS);
-				if (viewOk) sc = s1;
-			}
-		} else {
-#pragma unroll 1
-		for (int u = 0; u < VPL; ++u) {
-			const int view = v + u * G;
-			if (need && view < t.nSrc) {
-				int2 org = make_int2(0, 0);
-				if (TC > 0) org = s_org[threadIdx.x >> 6][view];
-				const float s1 = pm_score_view<GEO, true, TC, true>(t.src[view], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], 0.f,
-					tileBase + view * TSTRIDE, org.x, org.y, hotBase + view * NBD, hotBase + view * NBD + PM_SRC_HOT, (VPL == 1 && PM_ILP_HOMOGRAPHY) ? Hpre : nullptr PM_PROF_PASS);
-				if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
-			}
-		}
-		}
-		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
-		if (need && conf > nconf) {
-			conf = nconf; depth = hd; nx = hnx; ny = hny; nz = hnz; changed = true;
-			if (hst == ST_RAND) { if (conf < kp.thConfRand) st = ST_DECIDE; }
-			else if (hst == ST_REFINE) { p0 = hp0; p1 = hp1; scaleRange = pm_pow2neg(++idxScale); }
-		}
-		PM_TICK(6);
-	}
-	PM_PROF_FLUSH();
-	if (changed && v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1169,18 +640,15 @@ __global__ __launch_bounds__(PM_BLOCK, (!PM_USE_TILES ? PM_MINWAVES : VPL >= 4 ?
 // (counter-based: iteration index, not call order), scores and the order of the comparisons are those of the sequential code, so the result is
 // the same bits; only evaluations whose outcome the reference would never look at are extra work.  Expected rounds = 1 + number of accepts.
 // nSrc <= 8 (one source view per lane of a group).
-template <bool GEO>
+template <bool GEO, bool BUF>
 __global__ __launch_bounds__(64, PM_WIDE_MINWAVES) void pm_sweep_wide_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	constexpr int G = 8;
-	constexpr int TC = PM_WIDE_TILES ? 1 + PM_TCX : 0;   // 0: no LDS windows, the tap rows read the quad image (as pm_sweep2_kernel)
-	constexpr int TSTRIDE = PM_TR * (TC > 0 ? TC : 1) + PM_TILE_PAD;
 	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
 	PM_PROF_DECL;
 	__shared__ float2 s_w[PM_NT + 1];
-	__shared__ float s_tile[G * TSTRIDE];
-	__shared__ int2 s_org[G];
 	__shared__ double s_src[G * NBD];
 	const PMTask& t = tasks[blockIdx.y];
+	const pm_rsrc rs = pm_make_rsrc(t.qArr, t.qCount);
 	const int lane = threadIdx.x, c = lane >> 3, v = lane & 7;
 	for (int i = lane; i < G * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];
 	const double* hot = s_src + v * NBD;
@@ -1239,41 +707,6 @@ __global__ __launch_bounds__(64, PM_WIDE_MINWAVES) void pm_sweep_wide_kernel(con
 			qn0 = on0; qn1 = on1; qn2 = on2;
 		}
 	}
-	// ---- windows: one per source view around the footprint of the current plane ----------------------------------------------------------------
-	if (TC > 0) {
-		int cs = 0, ctt = 0;
-		if (v < t.nSrc) {
-			float Hc[9];
-			pm_homography(hot, t, X0x, X0y, depth, nx, ny, nz, Hc);
-			const float fxp = (float)x, fyp = (float)y;
-			const float c0 = Hc[0] * fxp + Hc[1] * fyp + Hc[2], c1 = Hc[3] * fxp + Hc[4] * fyp + Hc[5], c2 = Hc[6] * fxp + Hc[7] * fyp + Hc[8];
-			const float cu = c0 / c2, cv = c1 / c2;
-			if (cu > -1e6f && cu < 1e6f && cv > -1e6f && cv < 1e6f) { const int iu = (int)pm_floorf(cu), iv = (int)pm_floorf(cv); cs = iu + iv; ctt = iv; }
-		}
-		if (c == 0) s_org[v] = make_int2(cs - 8 - (PM_TR - 19) / 2, ctt - PM_HW - (PM_TCX - 9) / 2);
-		__syncthreads();
-		constexpr int NE = PM_TR * (TC > 0 ? TC : 1), NLD = (G * NE + 63) / 64;
-		float vals[NLD];
-#pragma unroll
-		for (int k = 0; k < NLD; ++k) {
-			const int e = lane + 64 * k;
-			const int vv = e / NE, i = e - vv * NE;
-			const int r = i / TC, cc = i - r * TC;
-			float val = 0.f;
-			if (vv < t.nSrc) {
-				const int2 org = s_org[vv];
-				const int sh = t.src[vv].h, sMax = t.src[vv].w + t.src[vv].h - 1;
-				const int ss = org.x + r, tt = org.y + cc;
-				if (ss >= 0 && ss < sMax && tt >= 0 && tt < sh) val = pm_glob(t.src[vv].imgS)[(size_t)ss * sh + tt];
-			}
-			vals[k] = val;
-		}
-#pragma unroll
-		for (int k = 0; k < NLD; ++k) { const int e = lane + 64 * k; if (e < G * NE) { const int vv = e / NE; s_tile[vv * TSTRIDE + (e - vv * NE)] = vals[k]; } }
-		__syncthreads();
-	}
-	const int2 myOrg = s_org[v];
-	const float* tile = s_tile + v * TSTRIDE;
 	const uint32_t k1 = t.k1base + pass;
 	// ---- rounds -----------------------------------------------------------------------------------------------------------------------------------
 	enum { W_PROPS = 0, W_REFINE = 1, W_RAND = 2, W_DONE = 3 };
@@ -1369,8 +802,8 @@ __global__ __launch_bounds__(64, PM_WIDE_MINWAVES) void pm_sweep_wide_kernel(con
 		PM_TICK(2);
 		float sc = PM_INF;
 		if (need && v < t.nSrc)
-			sc = pm_score_view<GEO, true, TC, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w, hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], 0.f,
-				tile, myOrg.x, myOrg.y, hot, hot + PM_SRC_HOT, nullptr PM_PROF_PASS);
+			sc = pm_score_view<GEO, BUF ? 2 : 1, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w, hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], 0.f,
+				hot, hot + PM_SRC_HOT, rs PM_PROF_PASS);
 		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 		// ---- every lane replays the sequential accept rule over the eight groups' results, in the reference's order ----
 		bool restart = false;                                     // the state changed in a way that invalidates the remaining candidates

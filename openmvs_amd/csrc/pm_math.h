@@ -101,17 +101,17 @@ PM_HD void pm_div2(float x, float y, float z, float* qx, float* qy) {
 // 2^-40 <= z <= 2^40 and |x|, |y| < 1e18 once per row, after the fact, and redo the row through pm_div2 when that fails).
 PM_HD void pm_div2_inrange(float x, float y, float z, float* qx, float* qy) {
 #if defined(__HIP_DEVICE_COMPILE__)
+	// the two quotients as one packed chain (v_pk_mul_f32, 4 x v_pk_fma_f32): a packed FMA issues in about the time of a plain one on this part (4.8 vs 4.2
+	// cycles per wave-instruction, tools/probes/valu_rate.hip), the same IEEE operations lane by lane
+	typedef float pm_f2v __attribute__((ext_vector_type(2)));
 	float r = __builtin_amdgcn_rcpf(z);
 	const float e = __builtin_fmaf(-z, r, 1.0f);
 	r = __builtin_fmaf(e, r, r);
-	float q = x * r;
-	float t = __builtin_fmaf(-z, q, x); q = __builtin_fmaf(t, r, q);
-	t = __builtin_fmaf(-z, q, x); q = __builtin_fmaf(t, r, q);
-	*qx = q;
-	q = y * r;
-	t = __builtin_fmaf(-z, q, y); q = __builtin_fmaf(t, r, q);
-	t = __builtin_fmaf(-z, q, y); q = __builtin_fmaf(t, r, q);
-	*qy = q;
+	const pm_f2v xy = {x, y}, rr = {r, r}, nz = {-z, -z};
+	pm_f2v q = xy * rr;
+	pm_f2v t = __builtin_elementwise_fma(nz, q, xy); q = __builtin_elementwise_fma(t, rr, q);
+	t = __builtin_elementwise_fma(nz, q, xy); q = __builtin_elementwise_fma(t, rr, q);
+	*qx = q.x; *qy = q.y;
 #else
 	*qx = x / z; *qy = y / z;
 #endif
@@ -148,6 +148,10 @@ PM_HD float pm_floorf(float x) {
 #endif
 }
 PM_HD float pm_fabsf(float x) { return pm_u2f(pm_f2u(x) & 0x7fffffffu); }
+// bit pattern of a float as a signed integer: for non-negative floats the integer order is the float order, every negative float (and -0) is below every
+// non-negative one and a NaN with a clear sign bit is above every number -- which is all a "is every value inside [lo, hi], lo >= 0" test needs, on the integer
+// min / max instructions (v_min3_i32 / v_max3_i32: no NaN canonicalisation in front of them)
+PM_HD int pm_f2i(float f) { return (int)pm_f2u(f); }
 PM_HD float pm_minf(float a, float b) { return a < b ? a : b; } // MINF(a,b): libs/Common/Types.h
 PM_HD float pm_maxf(float a, float b) { return a > b ? a : b; }
 PM_HD float pm_clampf(float v, float lo, float hi) { return pm_minf(pm_maxf(v, lo), hi); } // CLAMP: Types.h:1196

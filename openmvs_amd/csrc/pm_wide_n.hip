@@ -23,7 +23,7 @@
 #ifndef PM_WIDEN_MINWAVES
 #define PM_WIDEN_MINWAVES 3   // waves per SIMD the kernel is compiled for (168 VGPRs, 12-44 B of scratch; 4 has not been tried on the device)
 #endif
-template <bool GEO, int NH>
+template <bool GEO, int NH, bool BUF>
 __global__ __launch_bounds__(64, PM_WIDEN_MINWAVES) void pm_sweep_widen_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	static_assert(NH == 2 || NH == 4, "two propagation candidates need two groups; eight groups are pm_sweep_wide_kernel");
 	constexpr int G = 8, LPP = G * NH, PPW = 64 / LPP;
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(64, PM_WIDEN_MINWAVES) void pm_sweep_widen_kernel(c
 	__shared__ float2 s_w[PPW][PM_NT + 1];
 	__shared__ double s_src[G * NBD];
 	const PMTask& t = tasks[blockIdx.y];
+	const pm_rsrc rs = pm_make_rsrc(t.qArr, t.qCount);
 	const int lane = threadIdx.x, p = lane / LPP, sub = lane % LPP, c = sub >> 3, v = lane & 7, seg = p * LPP;
 	for (int i = lane; i < G * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];
 	const double* hot = s_src + v * NBD;
@@ -187,8 +188,8 @@ __global__ __launch_bounds__(64, PM_WIDEN_MINWAVES) void pm_sweep_widen_kernel(c
 		PM_TICK(2);
 		float sc = PM_INF;
 		if (need && v < t.nSrc)
-			sc = pm_score_view<GEO, true, 0, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[p], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], 0.f,
-				nullptr, 0, 0, hot, hot + PM_SRC_HOT, nullptr PM_PROF_PASS);
+			sc = pm_score_view<GEO, BUF ? 2 : 1, true>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[p], hd, hnx, hny, hnz, sf[0], sf[1], sf[2], sf[3], 0.f,
+				hot, hot + PM_SRC_HOT, rs PM_PROF_PASS);
 		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 		// ---- what the NH groups of my pixel found: read by every lane, outside any per-pixel control flow ----
 		bool gNeed[NH]; float gConf_[NH], gD[NH], gNx[NH], gNy[NH], gNz[NH], gP0[NH], gP1[NH];

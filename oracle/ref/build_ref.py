@@ -102,7 +102,7 @@ def build(verbose=False):
         for name, flags, src in (("libref_pm.so", ["-DREF_MATH_PM"], "ref_harness.cpp"), ("libref_pm_libm.so", [], "ref_harness.cpp"),
                                  ("libref_sgm.so", ["-DREF_MATH_PM"], "ref_sgm_harness.cpp"),
                                  ("libref_driver.so", ["-DREF_MATH_PM"] + link_orc, "ref_driver_harness.cpp"),
-                                 ("libref_driver_libm.so", ["-O3", "-march=native"] + link_orc, "ref_driver_harness.cpp")):
+                                 ("libref_driver_libm.so", ["-O3", "-march=x86-64-v3"] + link_orc, "ref_driver_harness.cpp")):
             out = os.path.join(OUT, name)
             cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-w", "-I", tmp, "-I", os.path.join(HERE, "shim")] + \
                   [os.path.join(HERE, src), "-o", out] + flags

@@ -73,7 +73,7 @@ def test_estimator_views_per_lane(pm_emulated, nine_scene, small_scene, lanes):
     g.test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes)    # (4,2), (2,4), (2,2), (4,4): several source views per lane
 
 
-@pytest.mark.parametrize("variant", ["legacy_windows"])   # (the band-kernel variants and diag2 run on the device only: -m gpu; they pass here too, 40 s each)
+@pytest.mark.parametrize("variant", ["quad_pointer"])   # (the default addressing -- the level's quad buffer -- is what every other case of this module runs)
 def test_estimator_sweep_kernel_variants(pm_emulated, nine_scene, small_scene, variant):
     from tests import test_gpu_patchmatch as g
     g.test_sweep_kernel_variants_parity(nine_scene, small_scene, variant, quick=True)

@@ -120,22 +120,16 @@ def test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes):
 
 
 SWEEP_VARIANTS = {
-    # what the sweep of an iteration runs as; every one must give the oracle's bits
-    "band": {"PMHIP_BAND": "1"},                                                        # one resident launch per iteration (pm_band_kernel), whole rows per task
-    "band_chunks": {"PMHIP_BAND": "1", "PMHIP_BAND_CHUNK": "24", "PMHIP_BAND_SLACK": "5"},   # (band, chunk) tasks: chunk-to-chunk and band-to-band hand-offs
-    "band_lanes4": {"PMHIP_BAND": "1", "PMHIP_LANES": "4", "PMHIP_BAND_CHUNK": "40"},
-    "legacy_windows": {"PMHIP_BAND": "0", "PMHIP_DIAG2": "0"},                          # round-2 kernel with LDS source windows (pm_sweep_kernel)
-    "diag2": {"PMHIP_BAND": "0", "PMHIP_DIAG2": "1", "PMHIP_VM": "0"},                  # per-diagonal launches, pixel-major lanes
-    "diag2_vm": {"PMHIP_BAND": "0", "PMHIP_DIAG2": "1", "PMHIP_VM": "1"},               # view-major lanes (lane = view * pixels-per-wave + pixel): coalesced quad loads
-    "diag2_vm_lanes4": {"PMHIP_BAND": "0", "PMHIP_DIAG2": "1", "PMHIP_VM": "1", "PMHIP_LANES": "4"},   # the same with two / four source views per lane
+    # how the sweep kernels' tap rows address the quad images; both must give the oracle's bits
+    "quad_buffer": {"PMHIP_QUADBUF": "1"},      # the default, named: 32-bit entry index into the level's buffer (buffer_load ... idxen, hardware range check)
+    "quad_pointer": {"PMHIP_QUADBUF": "0"},     # through each view's own pointer with clamped coordinates (what a batch with source views of their own image size falls to)
 }
 
 
 @pytest.mark.parametrize("variant", sorted(SWEEP_VARIANTS))
 def test_sweep_kernel_variants_parity(nine_scene, small_scene, variant, quick=False):
-    """Every sweep kernel the engine can be told to use (environment switches read at pmhip_create) against the oracle: 8 / 1 / 2 / 3 sources,
-    the pyramid with 4 sources, and a scene batch with a geometric round.  The resident band kernel's hand-offs between wavefronts (agent-scope
-    stores, progress counters) only exist on the device: this is their test."""
+    """Both addressing modes of the sweep kernel (environment switch read at pmhip_create) against the oracle: 8 / 1 / 2 / 3 sources, the pyramid with 4 sources,
+    and a scene batch with a geometric round."""
     import os
     from openmvs_amd.patchmatch import PatchMatchHIP
     env = SWEEP_VARIANTS[variant]
@@ -783,22 +777,33 @@ def test_config2_full_size_matches_golden():
         assert gc.sha(getattr(sc, k)) == g["inputs"][k], "camera " + k
     assert gc.sha(sc.neighbors.astype(np.int32)) == g["inputs"]["neighbors"]
     assert [float(x) for x in sc.dmin] == g["inputs"]["dmin"] and [float(x) for x in sc.dmax] == g["inputs"]["dmax"]
-    e = PatchMatchHIP(0); e.Init(True)
-    e.scene_load(sc, n_levels=2)
+    import os
     p = default_params(seed=c["seed"], nEstimationGeometricIters=c["geo_iters"])
     allv = list(range(c["n_views"]))
-    rounds = []
-    for r in range(1 + c["geo_iters"]):
-        if r:
-            e.scene_commit_round()
-        e.scene_estimate(allv, r - 1, p)
-        rounds.append([e.scene_get_maps(v) for v in allv])
-        for v in allv:
-            gc.check_maps(rounds[r][v], g["rounds"][r][str(v)], "scene interface, round %d, view %d" % (r, v))
-    e.close()
+    # the scene interface with every sweep kernel a batch can get: pm_sweep2_kernel<4 lanes, 2 views per lane> (what bench.py's timed 100-view batch runs),
+    # pm_sweep2_kernel<8,1> (26-79 views), and the engine's own choice for nine views (the two-wide speculative kernel)
+    for what, env in (("pm_sweep2_kernel<4,2>", {"PMHIP_WIDE": "0", "PMHIP_LANES": "4"}), ("pm_sweep2_kernel<8,1>", {"PMHIP_WIDE": "0", "PMHIP_LANES": "8"}),
+                      ("engine default", {"PMHIP_WIDE": None, "PMHIP_LANES": None})):
+        saved_env = {k: os.environ.get(k) for k in env}
+        for k, v in env.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        try:
+            e = PatchMatchHIP(0); e.Init(True)
+            e.scene_load(sc, n_levels=2)
+            rounds = []
+            for r in range(1 + c["geo_iters"]):
+                if r:
+                    e.scene_commit_round()
+                e.scene_estimate(allv, r - 1, p)
+                rounds.append([e.scene_get_maps(v) for v in allv])
+                for v in allv:
+                    gc.check_maps(rounds[r][v], g["rounds"][r][str(v)], "scene interface (%s), round %d, view %d" % (what, r, v))
+            e.close()
+        finally:
+            for k, v in saved_env.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     # the per-view boundary (layer 1): host buffers in and out, one blocking call per pass -- with the regular sweep kernel and with the
     # one-wave-per-pixel kernel the engine uses by default for a single depth map (PMHIP_WIDE)
-    import os
     ref = c["ref"]
     ids = [ref] + list(sc.neighbors[ref])
     saved = os.environ.get("PMHIP_WIDE")

@@ -434,103 +434,138 @@ def native_oracle():
 
 
 def cpu_legs(a, eng):
-    """(1) restated CPU baseline: the oracle (-O3 -march=native build) with the reference's threading model on the host cores, full schedule
-    for >= 4 reference views at a sample resolution sized for ~cpu-seconds; (2) live parity: sequential oracle vs the HIP engine on a small case."""
+    """cpu_baseline: the REFERENCE'S OWN CODE on this box's host cores -- oracle/_ref/libref_driver_libm.so = DepthMapsData::EstimateDepthMap, ScaleDepthData, the pass
+    bodies and the DepthEstimator cut verbatim from /root/reference (oracle/ref/build_ref.py, g++ -O3 -march=x86-64-v3, libm, std::mt19937), with the reference's own
+    threading (scene.nMaxThreads = the usable cores: one estimator per thread on the shared pixel counter, SceneDensify.cpp:631-750) -- on >= 4 reference views x 8
+    sources at the benchmark's own 1920x1080, full schedule (3-level pyramid + 2 geometric rounds).  OpenCV's resize is the oracle's restatement (un-vendored
+    dependency).  `port` beside it: the restated oracle (oracle/pm_oracle.cpp) with the same threading on a smaller sample.  parity_live: sequential oracle vs the
+    engine on a small case, bit for bit.  tolerance: what north_star's 1e-4 x diameter means against a reference BINARY (libm, mt19937, racy threads)."""
     from openmvs_amd import synth
     from openmvs_amd.patchmatch import default_params
     from oracle import pyoracle as po
     cores = usable_cores()
-    n_ref = 4
-    # per-thread rate of the oracle for the full schedule at N = 8 is ~0.008 Mpix/s on this class of host
-    target_px = a.cpu_seconds * 0.008e6 * cores / n_ref
-    scale = min(1.0, (target_px / (a.width * a.height)) ** 0.5)
-    sw = max(64, int(a.width * scale) // 16 * 16); sh = max(48, int(a.height * scale) // 16 * 16)
     seed = 1
 
-    def run(w, h, threads, refs, timed, lib):
-        sc = synth.make_scene(9, w, h, n_src=8, device="cuda", gray_only=True)
+    def engine_rounds(sc):
         eng.Init(True)
         eng.scene_load(sc, 2)
         p = default_params(seed=seed, nEstimationGeometricIters=a.geo_iters)
-        allv = list(range(9))
+        allv = list(range(sc.n_views))
         rounds = []
         eng.scene_estimate(allv, -1, p); rounds.append([eng.scene_get_maps(v) for v in allv])
         for g in range(a.geo_iters):
             eng.scene_commit_round(); eng.scene_estimate(allv, g, p); rounds.append([eng.scene_get_maps(v) for v in allv])
-        t_cpu = 0.0
-        outs = {}
-        saved = po._LIB
-        po._LIB = lib
-        try:
-            for ref in refs:
-                ids = [ref] + list(sc.neighbors[ref])
-                cur = None
-                for r in range(1 + a.geo_iters):
-                    opt = po.default_opt(seed=seed, viewID=ref, nThreads=threads, nEstimationGeometricIters=a.geo_iters)
-                    if r == 0:
-                        views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
-                        t = time.perf_counter()
-                        cur = po.estimate_depth_map(views, len(ids), float(sc.dmin[ref]), float(sc.dmax[ref]), opt)
-                    else:
-                        prev = {v: rounds[r - 1][v][0] for v in allv}
-                        d_in, n_in = (cur[0], cur[1]) if not timed else (rounds[r - 1][ref][0], rounds[r - 1][ref][1])
-                        views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids, depth_maps=prev)
-                        t = time.perf_counter()
-                        cur = po.estimate_depth_map(views, len(ids), float(sc.dmin[ref]), float(sc.dmax[ref]), opt, geo_iter=r - 1, depth=d_in, normal=n_in)
-                    t_cpu += time.perf_counter() - t
-                outs[ref] = cur
-        finally:
-            po._LIB = saved
-        return sc, outs, rounds[-1], t_cpu
+        return rounds
 
+    def cpu_schedule(sc, rounds, refs, threads, estimate, chain):
+        """photometric pass + geometric rounds of every view of `refs` through `estimate`; chain: feed a round with the CPU's own previous maps (parity) instead of the
+        engine's (timing: decouples the views).  Returns ({ref: final maps}, seconds)."""
+        t_cpu = 0.0; outs = {}
+        allv = list(range(sc.n_views))
+        for ref in refs:
+            ids = [ref] + list(sc.neighbors[ref])
+            cur = None
+            for r in range(1 + a.geo_iters):
+                if r == 0:
+                    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
+                    t = time.perf_counter(); cur = estimate(views, len(ids), ref, -1, None, None); t_cpu += time.perf_counter() - t
+                else:
+                    prev = {v: rounds[r - 1][v][0] for v in allv}
+                    d_in, n_in = (cur[0], cur[1]) if chain else (rounds[r - 1][ref][0], rounds[r - 1][ref][1])
+                    views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids, depth_maps=prev)
+                    t = time.perf_counter(); cur = estimate(views, len(ids), ref, r - 1, d_in, n_in); t_cpu += time.perf_counter() - t
+            outs[ref] = cur
+        return outs, t_cpu
+
+    out = {}
+    # ---- the reference's own code, threaded, at 1920x1080 ---------------------------------------------------------------------------------------------------
+    base = None
+    try:
+        from oracle import pyref as pr
+        have_ref = pr.driver_available("libm")
+    except Exception:
+        have_ref = False
+    if have_ref:
+        W, H = a.width, a.height
+        sc = synth.make_scene(9, W, H, n_src=8, device="cuda", gray_only=False)
+        rounds = engine_rounds(sc)
+        refs = [4, 0, 2, 8]
+
+        def est_ref(views, n, ref, geo, d, nrm):
+            opt = po.default_opt(seed=seed, viewID=ref, nThreads=cores, rngMode=2, nEstimationGeometricIters=a.geo_iters)
+            return pr.ref_estimate_depth_map(views, n, float(sc.dmin[ref]), float(sc.dmax[ref]), opt, geo_iter=geo, depth=d, normal=nrm, kind="libm")
+        outs, t_ref = cpu_schedule(sc, rounds, refs, cores, est_ref, False)
+        base = {"value": round(len(refs) * W * H / t_ref / 1e6, 5), "unit": "Mpix/s", "cores": cores, "kind": "reference",
+                "sample": "%d reference views x 8 sources at %dx%d, photometric pass (3-level pyramid x 3 sweeps) + %d geometric rounds each, through the reference's own "
+                          "DepthMapsData::EstimateDepthMap / DepthEstimator code (oracle/_ref: verbatim line ranges of SceneDensify.cpp and DepthMap.cpp, g++ -O3 -march=x86-64-v3, "
+                          "libm, std::mt19937) with scene.nMaxThreads = %d estimator threads on the shared pixel counter; cv::resize = the oracle's restatement; %.1f s CPU wall"
+                          % (len(refs), W, H, a.geo_iters, cores, t_ref)}
+        # ---- what the 1e-4 x diameter tolerance means against a reference binary (information; the gate is bit-identity with the oracle) --------------------
+        def cmp(x, y):
+            m = (x > 0) & (y > 0)
+            rm = float(np.sqrt(np.mean((x[m].astype(np.float64) - y[m]) ** 2))) / sc.diameter if m.any() else float("nan")
+            return {"depth_rmse_over_diameter": rm, "median_abs_over_diameter": float(np.median(np.abs(x[m].astype(np.float64) - y[m]))) / sc.diameter if m.any() else float("nan"),
+                    "valid_in_only_one": int(((x > 0) != (y > 0)).sum()), "valid_in_both": int(m.sum())}
+        v0 = refs[0]
+        ids0 = [v0] + list(sc.neighbors[v0])
+        views0, keep0 = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids0)
+        t = time.perf_counter()
+        ref_a = est_ref(views0, len(ids0), v0, -1, None, None)          # two runs of the reference's photometric pass: its racy thread schedule makes them differ
+        ref_b = est_ref(views0, len(ids0), v0, -1, None, None)
+        t_tol = time.perf_counter() - t
+        hip = rounds[0][v0]
+        gt = sc.gt_depth[v0]
+
+        def vs_gt(x):
+            m = x > 0
+            return {"depth_rmse_over_diameter": float(np.sqrt(np.mean((x[m].astype(np.float64) - gt[m]) ** 2))) / sc.diameter, "valid_frac": float(m.mean())}
+        out["tolerance"] = {"case": "view %d of the 9-view %dx%d scene, photometric pass (end-of-pass threshold x 1.333), depth maps" % (v0, W, H),
+                            "hip_vs_reference_code": cmp(hip[0], ref_a[0]), "reference_code_run_a_vs_run_b": cmp(ref_a[0], ref_b[0]),
+                            "hip_vs_ground_truth": vs_gt(hip[0]), "reference_code_vs_ground_truth": vs_gt(ref_a[0]),
+                            "north_star_tolerance": 1e-4, "seconds": round(t_tol, 1),
+                            "note": "reference code = oracle/_ref (libm, std::mt19937, %d racy threads); HIP = this engine (pm_math.h, Philox).  The estimator is chaotic pixel by pixel: the "
+                                    "reference does not reproduce ITSELF within 1e-4 x diameter from run to run, so the tolerance is met by construction against the sequential oracle "
+                                    "(bit-identical) and reported here against the reference's own run-to-run spread" % cores}
+    # ---- the restated port with the same threading, smaller sample (kept beside the reference figure) -------------------------------------------------------
     nat, flags = native_oracle()
-    refs = [4, 0, 2, 8][:n_ref]
-    sc, _, _, t_cpu = run(sw, sh, cores, refs, True, nat)
-    base = {"value": round(len(refs) * sw * sh / t_cpu / 1e6, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
-            "sample": "%d reference views x 8 sources at %dx%d, photometric + %d geometric rounds each, oracle built %s and run with the reference's threading model "
-                      "(one estimator per thread, shared atomic pixel counter), %.1f s CPU wall" % (len(refs), sw, sh, a.geo_iters, flags, t_cpu)}
-    # live parity leg: small, sequential (deterministic) oracle; the engine must match it bit for bit
-    sc2, cpu2, gpu2, _ = run(256, 144, 1, [4], False, po.lib())
-    cpu2 = cpu2[4]; gpu2 = gpu2[4]
+    n_ref = 4
+    target_px = min(a.cpu_seconds, 8.0) * 0.008e6 * cores / n_ref      # per-thread rate of the oracle for the full schedule at N = 8 is ~0.008 Mpix/s on this class of host
+    scale = min(1.0, (target_px / (a.width * a.height)) ** 0.5)
+    sw = max(64, int(a.width * scale) // 16 * 16); sh = max(48, int(a.height * scale) // 16 * 16)
+    scp = synth.make_scene(9, sw, sh, n_src=8, device="cuda", gray_only=True)
+    rounds_p = engine_rounds(scp)
+
+    def est_port(lib, threads):
+        def f(views, n, ref, geo, d, nrm):
+            saved = po._LIB; po._LIB = lib
+            try:
+                opt = po.default_opt(seed=seed, viewID=ref, nThreads=threads, nEstimationGeometricIters=a.geo_iters)
+                return po.estimate_depth_map(views, n, float(cur_sc.dmin[ref]), float(cur_sc.dmax[ref]), opt, geo_iter=geo, depth=d, normal=nrm)
+            finally:
+                po._LIB = saved
+        return f
+    cur_sc = scp
+    refs_p = [4, 0, 2, 8][:n_ref]
+    _, t_port = cpu_schedule(scp, rounds_p, refs_p, cores, est_port(nat, cores), False)
+    port = {"value": round(len(refs_p) * sw * sh / t_port / 1e6, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": "%d reference views x 8 sources at %dx%d, full schedule, oracle/pm_oracle.cpp built %s with the reference's threading model, %.1f s CPU wall" % (len(refs_p), sw, sh, flags, t_port)}
+    if base is None:
+        base = port
+    else:
+        base["port"] = port
+    out["cpu_baseline"] = base
+    # ---- live parity leg: small, sequential (deterministic) oracle; the engine must match it bit for bit -----------------------------------------------------
+    sc2 = synth.make_scene(9, 256, 144, n_src=8, device="cuda", gray_only=True)
+    rounds2 = engine_rounds(sc2)
+    cur_sc = sc2
+    cpu2, _ = cpu_schedule(sc2, rounds2, [4], 1, est_port(po.lib(), 1), True)
+    cpu2 = cpu2[4]; gpu2 = rounds2[-1][4]
     m = (cpu2[0] > 0) & (gpu2[0] > 0)
     rmse = float(np.sqrt(np.mean((cpu2[0][m].astype(np.float64) - gpu2[0][m]) ** 2))) if m.any() else float("nan")
-    only_one = int(((cpu2[0] > 0) != (gpu2[0] > 0)).sum())
-    ref_leg = reference_code_leg()
-    if ref_leg is not None:
-        base["reference_code"] = ref_leg
-    return {"cpu_baseline": base,
-            "parity_live": {"case": "256x144, 8 sources, full schedule, sequential oracle vs HIP engine in this run", "depth_rmse_over_diameter": rmse / sc2.diameter,
-                            "tolerance": 1e-4, "pixels_valid_in_only_one": only_one,
-                            "bit_identical": bool(np.array_equal(cpu2[0], gpu2[0]) and np.array_equal(cpu2[1], gpu2[1]) and np.array_equal(cpu2[2], gpu2[2]))}}
-
-
-def reference_code_leg():
-    """The reference's OWN estimator code (oracle/_ref: DepthMap.cpp / SceneDensify.cpp line ranges compiled verbatim, built where /root/reference exists and shipped
-    prebuilt) against the oracle on one pyramid level -- initial scoring + 3 sweeps of one reference view with 8 sources at 384x216 -- on one core each: the seconds of
-    both and whether the maps are the same bits.  Says how far the restated port that cpu_baseline times is from the reference's code in speed (in results it is not, and
-    this re-checks that on the host that ran the bench).  None when the prebuilt library is absent."""
-    try:
-        from openmvs_amd import synth
-        from oracle import pyoracle as po
-        from oracle import pyref as pr
-        if not pr.available():
-            return None
-        w, h, v = 384, 216, 4
-        sc = synth.make_scene(9, w, h, n_src=8)
-        ids = [v] + list(sc.neighbors[v])
-        views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, ids)
-        z = np.zeros((h, w), np.float32); n0 = np.zeros((h, w, 3), np.float32)
-        opt = po.default_opt(seed=1, viewID=v, rngMode=2)          # the reference's std::mt19937 stream and draw order
-        args = (views, len(ids), z, n0, z, float(sc.dmin[v]), float(sc.dmax[v]), opt, True, 0, 3)
-        t = time.perf_counter(); a = pr.ref_run_level(*args, th_end=0.9 * 1.333); t_ref = time.perf_counter() - t
-        t = time.perf_counter(); b = pr.orc_run_level(*args, th_end=0.9 * 1.333); t_orc = time.perf_counter() - t
-        same = all(bool(np.array_equal(x, y, equal_nan=True)) for x, y in zip(a, b))
-        return {"kind": "reference", "cores": 1, "sample": "one pyramid level (initial scoring + 3 sweeps) of 1 reference view x 8 sources at %dx%d" % (w, h),
-                "reference_seconds": round(t_ref, 3), "port_seconds": round(t_orc, 3), "reference_mpix_per_s_this_level": round(w * h / t_ref / 1e6, 5),
-                "bit_identical_to_port": same, "valid_frac": round(float((a[0] > 0).mean()), 4),
-                "note": "reference: g++ -O2, portable build of /root/reference's own functions (oracle/ref/build_ref.py); port: the oracle library the parity tests use"}
-    except Exception as ex:                                         # the leg is evidence, never a reason for the bench line to fail
-        return {"kind": "reference", "error": str(ex)[:200]}
+    out["parity_live"] = {"case": "256x144, 8 sources, full schedule, sequential oracle vs HIP engine in this run", "depth_rmse_over_diameter": rmse / sc2.diameter,
+                          "tolerance": 1e-4, "pixels_valid_in_only_one": int(((cpu2[0] > 0) != (gpu2[0] > 0)).sum()),
+                          "bit_identical": bool(np.array_equal(cpu2[0], gpu2[0]) and np.array_equal(cpu2[1], gpu2[1]) and np.array_equal(cpu2[2], gpu2[2]))}
+    return out
 
 
 if __name__ == "__main__":

@@ -89,6 +89,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 		}
 	}
 	__syncthreads();
+	PM_TICK(12); PM_COUNT(9, 1);
 	// ---- ProcessPixel's control flow as a per-pixel state machine: every outer trip scores at most one hypothesis per pixel (as pm_sweep_kernel) ----
 	enum { ST_PROP0 = 0, ST_PROP1 = 1, ST_DECIDE = 2, ST_RAND = 3, ST_REFINE = 4, ST_DONE = 5 };
 	const uint32_t k1 = t.k1base + pass;
@@ -172,6 +173,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 			}
 		}
 		if (!__any(need)) break;
+		PM_TICK(1); PM_COUNT(8, __popcll(__ballot(need)));
 		// -- smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533, one neighbour per lane
 		float sf0, sf1, sf2, sf3;
 		{
@@ -193,6 +195,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 			}
 			sf0 = pm_quad_bcast<0>(myF); sf1 = pm_quad_bcast<1>(myF); sf2 = pm_quad_bcast<2>(myF); sf3 = pm_quad_bcast<3>(myF);
 		}
+		PM_TICK(2);
 		// -- score against my source view(s)
 		float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
 		{
@@ -220,6 +223,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
+		PM_TICK(6);
 	}
 	{
 		const PMPix* P = pm_launder(s_pixg);

@@ -15,9 +15,10 @@ for rep in range(2):
     for g in range(2): e.scene_commit_round(); e.scene_estimate(ids, g, p)
     e.sync(); dt = time.time() - t0
     c = e.prof_get(True)
-names = ["windows", "hyp-gen", "smooth", "homography", "taps", "epilogue", "aggr+accept"]
-tot = (sum(c[:7]) + c[12] + c[13]) or 1
+names = ["-", "hyp-gen", "smooth", "homography", "taps", "epilogue", "aggr+accept"]
+tot = (sum(c[1:7]) + c[12]) or 1
 print(os.environ.get("PMHIP_LIB", "default"), "views", len(ids), "of", views, "%.2f s -> %.2f Mpix/s" % (dt, len(ids) * 1920 * 1080 / dt / 1e6))
-for i, n in ((12, "head"), (13, "nb+placement")): print("  %-12s %5.1f %%   %8.0f cycles/wave" % (n, 100.0 * c[i] / tot, c[i] / max(1, c[9])))
-for i, n in enumerate(names): print("  %-12s %5.1f %%   %8.0f cycles/wave" % (n, 100.0 * c[i] / tot, c[i] / max(1, c[9])))
-print("  active lanes/trip-sum %.1f per wave; LDS-served lane-rows %.1f %%; rows where the whole wave stayed on LDS: %d of %d lane-rows/64" % (c[8] / max(1, c[9]), 100.0 * c[10] / max(1, c[11]), c[7], c[11] // 64))
+print("  wave-visits %d, cycles per wave-visit %.0f (s_memtime), hypotheses x active lanes per wave-visit %.1f" % (c[9], tot / max(1, c[9]), c[8] / max(1, c[9])))
+print("  %-12s %5.1f %%   %8.0f cycles/wave-visit" % ("head", 100.0 * c[12] / tot, c[12] / max(1, c[9])))
+for i, n in enumerate(names):
+    if i: print("  %-12s %5.1f %%   %8.0f cycles/wave-visit" % (n, 100.0 * c[i] / tot, c[i] / max(1, c[9])))

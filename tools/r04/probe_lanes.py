@@ -24,8 +24,10 @@ for name, env in configs:
     os.environ.update(env)
     try:
         e = PatchMatchHIP(0); e.Init(True); e.scene_create(V, W, H, 2)
+        same = os.environ.get("PROBE_SAME_NB")      # timing probe (results meaningless): every view's 8 sources are 8 copies of its first neighbour -> an eighth of the image footprint
         for i in range(V):
-            e.scene_set_view(i, None, sc["K"][i], sc["R"][i], sc["C"][i], float(sc["dmin"][i]), float(sc["dmax"][i]), sc["neighbors"][i])
+            nb = [sc["neighbors"][i][0]] * len(sc["neighbors"][i]) if same else sc["neighbors"][i]
+            e.scene_set_view(i, None, sc["K"][i], sc["R"][i], sc["C"][i], float(sc["dmin"][i]), float(sc["dmax"][i]), nb)
         e.scene_copy(0, 0, V, gray.data_ptr(), True); e.sync()
         allv = list(range(V))
         best = 1e9

@@ -101,8 +101,10 @@ enum { PM_STREAM_INIT = 0, PM_STREAM_RAND = 1, PM_STREAM_REFINE = 2 };
 // the value must exist in a register at this point (device only; nothing for the host build of the emulator)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PM_OPAQUE(x) asm volatile("" : "+v"(x))
+#define PM_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)   // nothing is scheduled across this point
 #else
 #define PM_OPAQUE(x) do {} while (0)
+#define PM_SCHED_BARRIER() do {} while (0)
 #endif
 
 // Optional in-kernel phase timing (build with -DPM_PROFILE): lane 0 of every wave accumulates s_memtime deltas
@@ -274,8 +276,11 @@ __device__ __forceinline__ void pm_bufload5(pm_f4v& q0, pm_f4v& q1, pm_f4v& q2, 
 	             "buffer_load_dwordx4 %3, %8, %10, 0 idxen\n\tbuffer_load_dwordx4 %4, %9, %10, 0 idxen"
 		: "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4) : "v"(i0), "v"(i1), "v"(i2), "v"(i3), "v"(i4), "s"(r) : "memory");
 }
+// LEFT = vector-memory operations that may still be outstanding afterwards: loads return in order, so with the NEXT row's five loads issued behind these, LEFT = 5
+// waits for exactly this row
+template <int LEFT>
 __device__ __forceinline__ void pm_bufwait5(pm_f4v& q0, pm_f4v& q1, pm_f4v& q2, pm_f4v& q3, pm_f4v& q4) {
-	asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4));
+	asm volatile("s_waitcnt vmcnt(%5)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4) : "i"(LEFT));
 }
 __device__ __forceinline__ unsigned pm_mad24(int a, int b, unsigned c) { return (unsigned)__mul24(a, b) + c; }   // v_mad_u32_u24: full rate
 #else
@@ -287,7 +292,7 @@ __device__ __forceinline__ void pm_bufload5(pm_f4v& q0, pm_f4v& q1, pm_f4v& q2, 
 	const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 	q0 = i0 < r.count ? r.base[i0] : z; q1 = i1 < r.count ? r.base[i1] : z; q2 = i2 < r.count ? r.base[i2] : z; q3 = i3 < r.count ? r.base[i3] : z; q4 = i4 < r.count ? r.base[i4] : z;
 }
-__device__ __forceinline__ void pm_bufwait5(pm_f4v&, pm_f4v&, pm_f4v&, pm_f4v&, pm_f4v&) {}
+template <int LEFT> __device__ __forceinline__ void pm_bufwait5(pm_f4v&, pm_f4v&, pm_f4v&, pm_f4v&, pm_f4v&) {}
 __device__ __forceinline__ unsigned pm_mad24(int a, int b, unsigned c) { return (unsigned)(((unsigned)a & 0xffffffu) * ((unsigned)b & 0xffffffu)) + c; }   // wraps as the hardware's low 32 bits do
 #endif
 
@@ -344,42 +349,75 @@ __device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int 
 // otherwise the patch is redone through the guarded path.
 // BUF: the sample is addressed as entry index qbase + (lx + ly) * sh + ly of the level's buffer (no clamp: out of range reads zeros, see above); otherwise through the
 // view's own pointer with clamped coordinates (views that carry their own image size live outside the level's buffer).
+struct PMRowPos { float ptx[5], pty[5]; };
+struct PMRowQ { pm_f4v q0, q1, q2, q3, q4; };
+struct PMTapRange { int zlo, zhi, plo, pxhi, pyhi; };
+// positions of a row's five taps, their samples requested; nothing waits here
 template <bool BUF>
-__device__ __forceinline__ void pm_tap_row_fast(const pm_rsrc& rs, unsigned qbase, const pm_gcf4 imgQ, int sw, int sh, float h0, float h3, float h6,
-		float X0, float X1, float X2, const float2* wrow, float& sum, float& sumSq, float& num, int& zlo, int& zhi, int& plo, int& pxhi, int& pyhi)
+__device__ __forceinline__ void pm_row_issue(const pm_rsrc& rs, unsigned qbase, const pm_gcf4 imgQ, int sw, int sh, float h0, float h3, float h6, float X0, float X1, float X2,
+		PMRowPos& p, PMRowQ& q, PMTapRange& rg)
 {
-	float ptx[5], pty[5];
 	unsigned idx[5];
 	const int zFirst = pm_f2i(X2);
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
-		pm_div2_inrange(X0, X1, X2, &ptx[j], &pty[j]);
-		const int lx = (int)ptx[j], ly = (int)pty[j];
+		pm_div2_inrange(X0, X1, X2, &p.ptx[j], &p.pty[j]);
+		const int lx = (int)p.ptx[j], ly = (int)p.pty[j];
 		if (BUF) idx[j] = pm_mad24(lx + ly, sh, (unsigned)ly + qbase);
 		else { const int lxc = min(max(lx, 0), sw - 2), lyc = min(max(ly, 0), sh - 2); idx[j] = (unsigned)(lxc + lyc) * (unsigned)sh + (unsigned)lyc; }
-		if (j == 4) { const int zLast = pm_f2i(X2); zlo = min(zlo, min(zFirst, zLast)); zhi = max(zhi, max(zFirst, zLast)); }
+		if (j == 4) { const int zLast = pm_f2i(X2); rg.zlo = min(rg.zlo, min(zFirst, zLast)); rg.zhi = max(rg.zhi, max(zFirst, zLast)); }
 		X0 += h0; X1 += h3; X2 += h6;
 	}
-	pm_f4v q0, q1, q2, q3, q4;
-	if (BUF) pm_bufload5(q0, q1, q2, q3, q4, idx[0], idx[1], idx[2], idx[3], idx[4], rs);
-	else { q0 = pm_loadq(imgQ, idx[0]); q1 = pm_loadq(imgQ, idx[1]); q2 = pm_loadq(imgQ, idx[2]); q3 = pm_loadq(imgQ, idx[3]); q4 = pm_loadq(imgQ, idx[4]); }
+	if (BUF) pm_bufload5(q.q0, q.q1, q.q2, q.q3, q.q4, idx[0], idx[1], idx[2], idx[3], idx[4], rs);
+	else { q.q0 = pm_loadq(imgQ, idx[0]); q.q1 = pm_loadq(imgQ, idx[1]); q.q2 = pm_loadq(imgQ, idx[2]); q.q3 = pm_loadq(imgQ, idx[3]); q.q4 = pm_loadq(imgQ, idx[4]); }
 	// (independent of the loads) the extremes of the positions, on their bit patterns (see pm_f2i): plo = the smallest x or y, pxhi / pyhi = the largest x / y
-	plo = min(plo, min(min(min(pm_f2i(ptx[0]), pm_f2i(ptx[1])), min(pm_f2i(ptx[2]), pm_f2i(ptx[3]))), pm_f2i(ptx[4])));
-	plo = min(plo, min(min(min(pm_f2i(pty[0]), pm_f2i(pty[1])), min(pm_f2i(pty[2]), pm_f2i(pty[3]))), pm_f2i(pty[4])));
-	pxhi = max(pxhi, max(max(max(pm_f2i(ptx[0]), pm_f2i(ptx[1])), max(pm_f2i(ptx[2]), pm_f2i(ptx[3]))), pm_f2i(ptx[4])));
-	pyhi = max(pyhi, max(max(max(pm_f2i(pty[0]), pm_f2i(pty[1])), max(pm_f2i(pty[2]), pm_f2i(pty[3]))), pm_f2i(pty[4])));
-	if (BUF) pm_bufwait5(q0, q1, q2, q3, q4);
-	const pm_f4v q[5] = {q0, q1, q2, q3, q4};
+	rg.plo = min(rg.plo, min(min(min(pm_f2i(p.ptx[0]), pm_f2i(p.ptx[1])), min(pm_f2i(p.ptx[2]), pm_f2i(p.ptx[3]))), pm_f2i(p.ptx[4])));
+	rg.plo = min(rg.plo, min(min(min(pm_f2i(p.pty[0]), pm_f2i(p.pty[1])), min(pm_f2i(p.pty[2]), pm_f2i(p.pty[3]))), pm_f2i(p.pty[4])));
+	rg.pxhi = max(rg.pxhi, max(max(max(pm_f2i(p.ptx[0]), pm_f2i(p.ptx[1])), max(pm_f2i(p.ptx[2]), pm_f2i(p.ptx[3]))), pm_f2i(p.ptx[4])));
+	rg.pyhi = max(rg.pyhi, max(max(max(pm_f2i(p.pty[0]), pm_f2i(p.pty[1])), max(pm_f2i(p.pty[2]), pm_f2i(p.pty[3]))), pm_f2i(p.pty[4])));
+}
+// the row's samples have arrived (LEFT younger loads may still be under way): bilinear values and the three running sums, in the reference's order
+template <bool BUF, int LEFT>
+__device__ __forceinline__ void pm_row_consume(const PMRowPos& p, PMRowQ& q, const float2* wrow, float& sum, float& sumSq, float& num)
+{
+	if (BUF) pm_bufwait5<LEFT>(q.q0, q.q1, q.q2, q.q3, q.q4);
+	const pm_f4v qq[5] = {q.q0, q.q1, q.q2, q.q3, q.q4};
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
-		const float fx = pm_fract_pos(ptx[j]), fx1 = 1.f - fx, fy = pm_fract_pos(pty[j]), fy1 = 1.f - fy;   // == ptx - (float)(int)ptx for the positions the row is accepted with (>= 1)
-		const float v = (q[j].x * fx1 + q[j].y * fx) * fy1 + (q[j].z * fx1 + q[j].w * fx) * fy;
+		const float fx = pm_fract_pos(p.ptx[j]), fx1 = 1.f - fx, fy = pm_fract_pos(p.pty[j]), fy1 = 1.f - fy;   // == ptx - (float)(int)ptx for the positions the row is accepted with (>= 1)
+		const float v = (qq[j].x * fx1 + qq[j].y * fx) * fy1 + (qq[j].z * fx1 + qq[j].w * fx) * fy;
 		const float2 pw = wrow[j];
 		const float vw = v * pw.x;
 		sum += vw;
 		sumSq += v * vw;
 		num += v * pw.y;
 	}
+}
+// The 25 taps of a patch as a two-deep software pipeline over its five rows: the samples of row i + 1 are requested before row i is consumed, so a wave has ten
+// 16-byte loads in flight instead of five and waits for memory three times per patch instead of five (a wave-visit is a chain of ~80 such round trips and the launch
+// of a diagonal lasts as long as one wave-visit: DESIGN.md 4.2).  Two register sets (A, B) alternate; the rows are written out so that no set is ever copied.
+template <bool BUF>
+__device__ __forceinline__ void pm_taps_fast(const pm_rsrc& rs, unsigned qbase, const pm_gcf4 imgQ, int sw, int sh, const float* H, float bX0, float bX1, float bX2,
+		const float2* wts, float& sum, float& sumSq, float& num, PMTapRange& rg)
+{
+	PMRowPos pa, pb; PMRowQ qa, qb;
+	pm_row_issue<BUF>(rs, qbase, imgQ, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, pa, qa, rg);
+	// rows (0,1), (2,3) as one loop body with the A / B sets swapping roles (no copies), then row 4.  The scheduling barriers keep the compiler from pulling the next
+	// row's divisions above the current row's arithmetic (which is what it does with the whole patch unrolled: every position of the patch live at once, 600 B of scratch)
+#pragma unroll 1
+	for (int i = 0; i < 4; i += 2) {
+		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
+		pm_row_issue<BUF>(rs, qbase, imgQ, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, pb, qb, rg);
+		PM_SCHED_BARRIER();
+		pm_row_consume<BUF, 5>(pa, qa, wts + i * 5, sum, sumSq, num);
+		PM_SCHED_BARRIER();
+		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
+		pm_row_issue<BUF>(rs, qbase, imgQ, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, pa, qa, rg);
+		PM_SCHED_BARRIER();
+		pm_row_consume<BUF, 5>(pb, qb, wts + (i + 1) * 5, sum, sumSq, num);
+		PM_SCHED_BARRIER();
+	}
+	pm_row_consume<BUF, 0>(pa, qa, wts + 20, sum, sumSq, num);
 }
 
 // ScorePixelImage for this lane's source view, DepthMap.cpp:465-564.
@@ -424,14 +462,10 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		const unsigned qbase = ((const unsigned*)(hot + 13))[0];
 		const pm_gcf4 imgQ = pm_glob4(s.imgQ);
 		const float rX0 = bX0, rX1 = bX1, rX2 = bX2;
-		int zlo = 0x7fffffff, zhi = (int)0x80000000, plo = 0x7fffffff, pxhi = (int)0x80000000, pyhi = (int)0x80000000;
-#pragma unroll 1
-		for (int i = 0; i < 5; ++i) {
-			pm_tap_row_fast<MODE == 2>(rs, qbase, imgQ, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, zlo, zhi, plo, pxhi, pyhi);
-			bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
-		}
-		const bool exact = sane && zlo >= pm_f2i(9.094947e-13f) && zhi <= pm_f2i(1.0995116e12f);   // 2^-40 <= z <= 2^40 on the whole patch
-		const bool outside = !(plo >= pm_f2i(1.f) && pxhi <= pm_f2i((float)(sw - 2)) && pyhi <= pm_f2i((float)(sh - 2)));   // a tap with x < 1, y < 1, x > w - 2 or y > h - 2
+		PMTapRange rg = {0x7fffffff, (int)0x80000000, 0x7fffffff, (int)0x80000000, (int)0x80000000};
+		pm_taps_fast<MODE == 2>(rs, qbase, imgQ, sw, sh, H, bX0, bX1, bX2, wts, sum, sumSq, num, rg);
+		const bool exact = sane && rg.zlo >= pm_f2i(9.094947e-13f) && rg.zhi <= pm_f2i(1.0995116e12f);   // 2^-40 <= z <= 2^40 on the whole patch
+		const bool outside = !(rg.plo >= pm_f2i(1.f) && rg.pxhi <= pm_f2i((float)(sw - 2)) && rg.pyhi <= pm_f2i((float)(sh - 2)));   // a tap with x < 1, y < 1, x > w - 2 or y > h - 2
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(PM_DEBUG_REDO)
 		{ static unsigned long long c[2]; static bool reg = false; if (!reg) { reg = true; atexit([] { fprintf(stderr, "optimistic evaluations %llu, redone %llu\n", c[0], c[1]); }); } c[0]++; if (!exact) c[1]++; }
 #endif

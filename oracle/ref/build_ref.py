@@ -37,6 +37,17 @@ SNIPPETS = {
     "types_inl_matrix_ops":  ("libs/Common/Types.inl", 1430, 1474, "// TMatrix operators", "}"),
     "types_inl_cast":        ("libs/Common/Types.inl", 1677, 1709, "// Point2", "}"),
     "types_inl_tmatrix9":    ("libs/Common/Types.inl", 1830, 1839, "template <typename TYPE, int m, int n>", "}"),
+    "types_inl_abs_pt":      ("libs/Common/Types.inl", 496, 500, "template <typename TYPE>", "}"),
+    "types_inl_initto":      ("libs/Common/Types.inl", 671, 676, "// initializing both scalar and matrix variables", "}"),
+    "types_inl_tmatrix4":    ("libs/Common/Types.inl", 1787, 1794, "template <typename TYPE, int m, int n>", "}"),
+    "types_inl_getpixel":    ("libs/Common/Types.inl", 2253, 2266, "// Find a pixel inside the image", "}"),
+    "types_inl_samplesafe_f": ("libs/Common/Types.inl", 2315, 2332, "template <typename TYPE>", "}"),
+    "types_h_accumulator":   ("libs/Common/Types.h", 2398, 2458, "// weighted accumulator class that operates on arbitrary types", "};"),
+    "util_inl_project22":    ("libs/Common/Util.inl", 387, 393, "// (optimized ProjectVertex for H[3,3] and X[2,1], output pt[2,1])", "} // ProjectVertex_3x3_2_2"),
+    "image_cpp_disp2depth":  ("libs/MVS/Image.cpp", 372, 412, "template <typename TYPE>", "}"),
+    "image_cpp_depth2disp":  ("libs/MVS/Image.cpp", 423, 433, "// converts the given depth at the un-rectified image coordinates to", "}"),
+    "sgm_cpp_range":         ("libs/MVS/SemiGlobalMatcher.cpp", 1350, 1444, "SemiGlobalMatcher::Index SemiGlobalMatcher::Disparity2RangeMap(", "}"),
+    "sgm_cpp_conv":          ("libs/MVS/SemiGlobalMatcher.cpp", 1837, 2039, "// Compute the disparity-map for the rectified image from the given depth-map of the un-rectified image;", "}"),
     "types_inl_sample":      ("libs/Common/Types.inl", 2270, 2281, "// sample by bilinear interpolation", "}"),
     "types_inl_sample_f":    ("libs/Common/Types.inl", 2296, 2314, "// sample by bilinear interpolation, using only pixels that meet the user condition", "}"),
     "util_inl_project":      ("libs/Common/Util.inl", 380, 386, "// (optimized ProjectVertex for H[3,3] and X[2,1], output pt[3,1])", "} // ProjectVertex_3x3_2_3"),

@@ -10,7 +10,6 @@ template <typename TYPE> class TPixel { public: union { struct { TYPE b, g, r; }
 	inline const TYPE& operator[](size_t i) const { return c[i]; } inline TYPE& operator[](size_t i) { return c[i]; } };
 typedef TPixel<uint8_t> Pixel8U;
 typedef TImage<Pixel8U> Image8U3;
-typedef TMatrix<REAL,4,4> Matrix4x4;
 class Event { public: Event(uint32_t) {} virtual ~Event() {} virtual bool Run(void* = NULL) { return true; } };
 struct Semaphore {};
 class EventThreadPool {                    // one worker that runs a job the moment it is queued
@@ -35,6 +34,10 @@ struct ThreadX : Thread { static inline safe_t safeDec(volatile safe_t& v) { ret
 #include "snip/sgm_cpp_ctor.inc"           // SemiGlobalMatcher.cpp:513-529: constructor, destructor, GenerateP2s
 #include "snip/sgm_cpp_match.inc"          // SemiGlobalMatcher.cpp:863-1302: Match
 #include "snip/sgm_cpp_post.inc"           // SemiGlobalMatcher.cpp:1446-1811: ConsistencyCrossCheck, FilterByCost, ExtractMask, FlipDirection, UpscaleMask, RefineDisparityMap
+#include "snip/image_cpp_disp2depth.inc"   // Image.cpp:372-412: TDisparity2Depth, Image::Disparity2Depth (four overloads)
+#include "snip/image_cpp_depth2disp.inc"   // Image.cpp:423-433: Image::Depth2Disparity
+#include "snip/sgm_cpp_range.inc"          // SemiGlobalMatcher.cpp:1350-1444: Disparity2RangeMap
+#include "snip/sgm_cpp_conv.inc"           // SemiGlobalMatcher.cpp:1836-2039: Depth2DisparityMap, Disparity2DepthMap, ProjectDisparity2DepthMap
 #undef Thread
 EventThreadPool SemiGlobalMatcher::threads;
 Semaphore SemiGlobalMatcher::sem;
@@ -46,6 +49,7 @@ struct Access : SemiGlobalMatcher {       // reaches the protected members Match
 	using SemiGlobalMatcher::maxNumDisp; using SemiGlobalMatcher::P1; using SemiGlobalMatcher::P2s; using SemiGlobalMatcher::GenerateP2s;
 	using SemiGlobalMatcher::ConsistencyCrossCheck; using SemiGlobalMatcher::FilterByCost; using SemiGlobalMatcher::ExtractMask; using SemiGlobalMatcher::UpscaleMask;
 	using SemiGlobalMatcher::FlipDirection; using SemiGlobalMatcher::RefineDisparityMap;
+	using SemiGlobalMatcher::Disparity2RangeMap; using SemiGlobalMatcher::Depth2DisparityMap; using SemiGlobalMatcher::Disparity2DepthMap; using SemiGlobalMatcher::ProjectDisparity2DepthMap;
 	Access(SgmSubpixelMode m = SUBPIXEL_LC_BLEND, Disparity steps = 4) : SemiGlobalMatcher(m, steps) {}
 };
 template <typename T> static TImage<T> imageOf(const T* p, int w, int h) { TImage<T> m; m.create(cv::Size(w, h)); memcpy(m.data(), p, sizeof(T) * (size_t)w * h); return m; }
@@ -91,6 +95,42 @@ void ref_sgm_refine_wh(int16_t* disp, const void* pixels, const uint16_t* accums
 	SemiGlobalMatcher::DisparityMap a = imageOf(disp, vw, vh);
 	m.RefineDisparityMap(a);
 	memcpy(disp, a.data(), sizeof(int16_t) * (size_t)vw * vh);
+}
+// Disparity2RangeMap, Depth2DisparityMap, Disparity2DepthMap, ProjectDisparity2DepthMap (SemiGlobalMatcher.cpp:1350-1444, :1836-2039): same arguments as the orc_sgm_* functions
+unsigned long long ref_sgm_disparity2range_map(const int16_t* disparityMap, int cols, int rows, const uint8_t* maskMap, int w2, int h2, int minNumDisp, int minNumDispInvalid,
+		void* imagePixels, int* outMaxNumDisp) {
+	Access m;
+	const SemiGlobalMatcher::DisparityMap d = imageOf(disparityMap, cols, rows); const SemiGlobalMatcher::MaskMap k = imageOf(maskMap, w2, h2);
+	const SemiGlobalMatcher::Index n = m.Disparity2RangeMap(d, k, (SemiGlobalMatcher::Disparity)minNumDisp, (SemiGlobalMatcher::Disparity)minNumDispInvalid);
+	memcpy(imagePixels, m.imagePixels.Begin(), 16 * (size_t)w2 * h2);
+	*outMaxNumDisp = m.maxNumDisp;
+	return n;
+}
+static Matrix3x3 m33(const double* p) { Matrix3x3 M; for (int i = 0; i < 9; ++i) M.val[i] = p[i]; return M; }
+static Matrix4x4 m44(const double* p) { Matrix4x4 M; for (int i = 0; i < 16; ++i) M.val[i] = p[i]; return M; }
+void ref_sgm_depth2disparity_map(const float* depthMap, int dw, int dh, const double* invH, const double* invQ, int subpixelSteps, int16_t* disparityMap, int w, int h) {
+	const DepthMap dm = imageOf(depthMap, dw, dh);
+	SemiGlobalMatcher::DisparityMap out; out.create(cv::Size(w, h));
+	Access::Depth2DisparityMap(dm, m33(invH), m44(invQ), (SemiGlobalMatcher::Disparity)subpixelSteps, out);
+	memcpy(disparityMap, out.data(), sizeof(int16_t) * (size_t)w * h);
+}
+void ref_sgm_disparity2depth_map(const int16_t* disparityMap, const uint16_t* costMap, int w, int h, const double* H, const double* Q, int subpixelSteps, float* depthMap, float* confMap, int dw, int dh) {
+	const SemiGlobalMatcher::DisparityMap d = imageOf(disparityMap, w, h);
+	SemiGlobalMatcher::AccumCostMap c; if (costMap) c = imageOf(costMap, w, h);
+	DepthMap dm; dm.create(cv::Size(dw, dh)); ConfidenceMap cm;
+	Access::Disparity2DepthMap(d, c, m33(H), m44(Q), (SemiGlobalMatcher::Disparity)subpixelSteps, dm, cm);
+	memcpy(depthMap, dm.data(), sizeof(float) * (size_t)dw * dh);
+	if (costMap) memcpy(confMap, cm.data(), sizeof(float) * (size_t)dw * dh);
+}
+int ref_sgm_project_disparity2depth_map(const int16_t* disparityMap, const uint16_t* costMap, int w, int h, const double* Q, int subpixelSteps, float* depthMap, float* depthRangeMap, float* confMap, int dw, int dh) {
+	const SemiGlobalMatcher::DisparityMap d = imageOf(disparityMap, w, h);
+	SemiGlobalMatcher::AccumCostMap c; if (costMap) c = imageOf(costMap, w, h);
+	DepthMap dm; dm.create(cv::Size(dw, dh)); SemiGlobalMatcher::DepthRangeMap rm; ConfidenceMap cm;
+	const bool ok = Access::ProjectDisparity2DepthMap(d, c, m44(Q), (SemiGlobalMatcher::Disparity)subpixelSteps, dm, rm, cm);
+	memcpy(depthMap, dm.data(), sizeof(float) * (size_t)dw * dh);
+	memcpy(depthRangeMap, rm.data(), sizeof(float) * 2 * (size_t)dw * dh);
+	if (costMap) memcpy(confMap, cm.data(), sizeof(float) * (size_t)dw * dh);
+	return ok ? 1 : 0;
 }
 // same arguments as orc_sgm_match (oracle/sgm_oracle.cpp); pixels: (w-6)*(h-6) entries {u64 idx; i16 min, max; pad}
 int ref_sgm_match(const uint8_t* colorL, const float* grayL, const float* grayR, int w, int h, const void* pixels, uint64_t numCosts, int maxNumDisp, uint16_t P1, const uint16_t* P2s,

@@ -133,6 +133,16 @@ public:
 	inline TYPE& front() { return v.front(); } inline const TYPE& front() const { return v.front(); }
 	inline TYPE& Last() { return v.back(); } inline const TYPE& Last() const { return v.back(); }
 	inline TYPE& GetNth(IDX index) { TYPE* const nth(Begin() + index); std::nth_element(Begin(), nth, End()); return *nth; }
+	// List.h:667-678, :700-703 (glue: the standard-library calls the reference makes)
+	template <typename RTYPE = typename std::conditional<std::is_floating_point<TYPE>::value, TYPE, double>::type>
+	inline RTYPE GetMedian() {
+		const size_t _size = v.size();
+		if (_size % 2) return static_cast<RTYPE>(GetNth(_size >> 1));
+		TYPE* const nth(Begin() + (_size >> 1)); std::nth_element(Begin(), nth, End());
+		TYPE* const nth1(nth - 1); std::nth_element(Begin(), nth1, nth);
+		return (static_cast<RTYPE>(*nth1) + static_cast<RTYPE>(*nth)) / RTYPE(2);
+	}
+	inline std::pair<TYPE, TYPE> GetMinMax() const { const auto mm(std::minmax_element(Begin(), End())); return std::pair<TYPE, TYPE>(*mm.first, *mm.second); }
 	std::vector<TYPE> v;
 };
 #define CLISTDEF0(TYPE) SEACAVE::cList< TYPE, const TYPE&, 0 >
@@ -207,6 +217,10 @@ public:
 	inline TYPE& operator()(const ImageRef& pt) { return Base::operator()(pt.y, pt.x); }
 #include "snip/types_h_isinside.inc"     // Types.h: isInside / isInsideWithBorder
 	template <typename T> TYPE sample(const TPoint2<T>& pt) const;
+	template <typename T> inline T* ptr(int r, int c) const { return (T*)(Base::d.get() + (size_t)r * Base::sz.width + c); }   // cv::Mat::ptr<T>(row, col)
+	using Base::cols; using Base::rows;
+	inline const TYPE& getPixel(int y, int x) const;
+	template <typename T, typename TV, typename Functor> bool sampleSafe(TV& v, const TPoint2<T>& pt, const Functor& functor) const;
 	template <typename T, typename TV, typename Functor> bool sample(TV& v, const TPoint2<T>& pt, const Functor& functor) const;
 };
 typedef TImage<uint8_t> Image8U;
@@ -247,6 +261,13 @@ typedef std::string String;
 #include "snip/types_inl_cast.inc"       // Types.inl: Cast<>() overloads
 #include "snip/types_inl_sample.inc"     // Types.inl: TImage::sample (bilinear)
 #include "snip/types_inl_sample_f.inc"   // Types.inl: TImage::sample (bilinear with validity functor)
+#include "snip/types_inl_getpixel.inc"   // Types.inl:2253-2266: TImage::getPixel (clamped)
+#include "snip/types_inl_samplesafe_f.inc" // Types.inl:2315-2333: TImage::sampleSafe (clamped bilinear with validity functor)
+#include "snip/types_inl_abs_pt.inc"     // Types.inl:495-500: ABS(TPoint2)
+#include "snip/types_inl_initto.inc"     // Types.inl:671-676: INITTO (scalar form)
+#include "snip/types_inl_tmatrix4.inc"   // Types.inl:1787-1794: TMatrix(v0 .. v3)
+#include "snip/types_h_accumulator.inc"  // Types.h:2398-2458: TAccumulator
+#include "snip/util_inl_project22.inc"   // Util.inl:387-393: ProjectVertex_3x3_2_2
 #include "snip/util_inl_project.inc"     // Util.inl: ProjectVertex_3x3_2_3
 #include "snip/util_inl_angle.inc"       // Util.inl: ComputeAngle
 #include "snip/util_inl_dir.inc"         // Util.inl: Normal2Dir, Dir2Normal
@@ -271,6 +292,8 @@ typedef TPoint2<REAL> Point2;                    // Common.h:242
 typedef TPoint3<REAL> Point3;                    // Common.h:243
 typedef TMatrix<REAL,3,1> Vec3;                  // Common.h:245
 typedef TMatrix<REAL,3,3> Matrix3x3;             // Common.h:248
+typedef TMatrix<REAL,4,4> Matrix4x4;             // Common.h:249
+typedef TMatrix<float,4,1> Vec4f;                // Common.h:235
 typedef TRMatrixBase<REAL> RMatrixBase;          // Common.h:253
 typedef Point3 CMatrix; typedef RMatrixBase RMatrix; typedef Matrix3x3 KMatrix;   // Common.h:256-258
 template <typename R> void ComputeRelativeRotation(const R&, const R&, R&);       // named by an inline the path never calls
@@ -290,7 +313,11 @@ public:
 #include "snip/camera_h_c2i.inc"         // Camera.h:368-374: TransformPointC2I (z = 1 plane)
 #include "snip/camera_h_c2i3_w2c_w2i.inc" // Camera.h:382-394: TransformPointC2I (3D), TransformPointW2C, TransformPointW2I
 };
-struct Image { uint32_t ID; Camera camera; cv::Size size; inline cv::Size GetSize() const { return size; } };   // Image.h: ID, camera, GetSize() are what the path reads
+struct Image { uint32_t ID; Camera camera; cv::Size size; inline cv::Size GetSize() const { return size; }
+	// Image.h:155-163 (definitions: Image.cpp:372-433, cut verbatim where a harness needs them)
+	static float Disparity2Depth(const Matrix4x4& Q, const ImageRef& u, float d); static float Disparity2Depth(const Matrix4x4& Q, const Point2f& u, float d);
+	static float Disparity2Depth(const Matrix4x4& Q, const ImageRef& u, float d, Point2f& pt); static float Disparity2Depth(const Matrix4x4& Q, const Point2f& u, float d, Point2f& pt);
+	static bool Depth2Disparity(const Matrix4x4& Q, const Point2f& u, float d, float& disparity); };   // Image.h: ID, camera, GetSize() are what the path reads
 typedef CLISTDEFIDX(Image,IIndex) ImageArr;
 struct ViewScore { uint32_t ID; };
 typedef CLISTDEFIDX(ViewScore,IIndex) ViewScoreArr;

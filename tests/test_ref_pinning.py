@@ -392,3 +392,50 @@ def test_sgm_refine_is_the_reference_function(mode):
     for steps in (1, 4, 7):
         a = po.sgm_refine(d, px, acc, mode=mode, steps=steps); b = pr.ref_sgm_refine(d, px, acc, mode=mode, steps=steps)
         assert np.array_equal(a, b), "RefineDisparityMap mode %d steps %d: %d of %d differ" % (mode, steps, int((a != b).sum()), a.size)
+
+
+# ---- the SGM conversions around the matcher: Disparity2RangeMap (SemiGlobalMatcher.cpp:1350-1444), Depth2DisparityMap, Disparity2DepthMap, ProjectDisparity2DepthMap
+#      (:1837-2039) with Image::Disparity2Depth / Depth2Disparity (Image.cpp:372-433), TImage::sampleSafe, ProjectVertex_3x3_2_2, TAccumulator: cut verbatim ----
+@sgm_only
+@pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (97, 53, 1), (131, 77, 2)])
+def test_sgm_range_map_is_the_reference_function(w, h, seed):
+    from tests import sgm_post_cases as pc
+    kw = dict(impl=pr.sgm_post_lib(), prefix="ref_sgm_")
+    d = pc.smooth_disparity(w, h, seed)
+    for extra in ((7, 6), (6, 7)):
+        mask = pc.mask_map(2 * w + extra[0], 2 * h + extra[1], seed)
+        for a, b in ((11, 33), (5, 7), (3, 16)):
+            px0, n0, m0 = po.sgm_disparity2range_map(d, mask, a, b)
+            px1, n1, m1 = po.sgm_disparity2range_map(d, mask, a, b, **kw)
+            assert n0 == n1 and m0 == m1, (n0, n1, m0, m1)
+            for k in ("idx", "minDisp", "maxDisp"):
+                assert np.array_equal(px0[k], px1[k]), k
+
+
+@sgm_only
+@pytest.mark.parametrize("w,h,seed", [(64, 40, 0), (97, 53, 1)])
+def test_sgm_disparity_depth_conversions_are_the_reference_functions(w, h, seed):
+    from tests import sgm_post_cases as pc
+    kw = dict(impl=pr.sgm_post_lib(), prefix="ref_sgm_")
+    H, Q, iH, iQ = pc.rectification(seed)
+    depth = (3.0 + 0.5 * np.sin(np.arange(h * w).reshape(h, w) / 50.0)).astype(np.float32)
+    depth[np.random.RandomState(seed).rand(h, w) < 0.2] = 0
+    cost = pc.cost_map(w - 6, h - 6, seed)
+    for steps in (1, 4):
+        a = po.sgm_depth2disparity_map(depth, iH, iQ, steps, (w - 6, h - 6))
+        assert np.array_equal(a, po.sgm_depth2disparity_map(depth, iH, iQ, steps, (w - 6, h - 6), **kw)), "Depth2DisparityMap"
+        assert (a != NO_DISP).mean() > 0.5
+        for cst in (None, cost):
+            da, ca = po.sgm_disparity2depth_map(a, cst, H, Q, steps, (w, h))
+            db, cb = po.sgm_disparity2depth_map(a, cst, H, Q, steps, (w, h), **kw)
+            assert np.array_equal(da.view(np.uint32), db.view(np.uint32)), "Disparity2DepthMap depth"
+            assert cst is None or np.array_equal(ca.view(np.uint32), cb.view(np.uint32)), "Disparity2DepthMap confidence"
+        disp = po.sgm_depth2disparity_map(depth, np.eye(3), iQ, steps, (w - 6, h - 6))
+        for cst in (None, cost):
+            ok0, d0, r0, c0 = po.sgm_project_disparity2depth_map(disp, cst, Q, steps, (w, h))
+            ok1, d1, r1, c1 = po.sgm_project_disparity2depth_map(disp, cst, Q, steps, (w, h), **kw)
+            assert ok0 == ok1 and np.array_equal(d0.view(np.uint32), d1.view(np.uint32)), "ProjectDisparity2DepthMap depth"
+            valid = d0 > 0                                    # (the reference leaves the range / confidence of a pixel without a depth unset)
+            assert np.array_equal(r0[valid].view(np.uint32), r1[valid].view(np.uint32)), "ProjectDisparity2DepthMap range"
+            assert cst is None or np.array_equal(c0[valid].view(np.uint32), c1[valid].view(np.uint32)), "ProjectDisparity2DepthMap confidence"
+            assert valid.mean() > 0.3

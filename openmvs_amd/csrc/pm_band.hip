@@ -35,7 +35,7 @@ enum { PMF_SMOOTH = 1, PMF_CHANGED = 2, PMF_POK0 = 4, PMF_POK1 = 8 };
 // neighbour slots (bounds tests, coordinates, map indices).  afterPatch() runs once the visit's loads have been waited for (the band kernel publishes its
 // previous step there).  Result: r* = what the maps hold at this pixel after the visit, wr = it changed.
 template <int G, int VPL, bool GEO, bool BUF>
-__device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, const pm_rsrc& rs, uint32_t pass, int sgn, float2* s_wg, PMPix* s_pixg, const double* hotBase,
+__device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, const PMImgBuf& rs, uint32_t pass, int sgn, float2* s_wg, PMPix* s_pixg, const double* hotBase,
 		int g, int v, int slot, bool active, int x, int y, int ySafe, size_t idx, const bool* bok, const int* qxs, const int* qys, const size_t* qis,
 		float n0D, float n0N0, float n0N1, float n0N2, float n0C, float n1D, float n1N0, float n1N1, float n1N2, float n1C,
 		float& rD, float& rN0, float& rN1, float& rN2, float& rC, bool& wr PM_PROF_ARG) {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_sweep2_kernel(const P
 		vby = wgid / nbx; vbx = wgid - vby * nbx;
 	}
 	const PMTask& t = tasks[vby];
-	const pm_rsrc rs = pm_make_rsrc(t.qArr, t.qCount);
+	const PMImgBuf rs = pm_make_imgbuf(t);
 	const int lane = threadIdx.x;
 	for (int i = lane; i < NV * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];
 	const int g = lane / G, v = lane % G, slot = v & 3;

@@ -404,7 +404,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			}
 			t.ref = e->d_img[l] + Pl * id;
 			t.refS = e->d_imgS[l] + e->skewPitch(l) * id;
-			t.qArr = e->d_imgQ[l]; t.qCount = (unsigned)(e->skewPitch(l) * (size_t)e->nImages);
+			t.qArr = e->d_imgQ[l]; t.sArr = e->d_imgS[l]; t.qCount = (unsigned)(e->skewPitch(l) * (size_t)e->nImages);
 			t.mask = (anyMask && e->hasMask[id]) ? e->d_mask[l] + Pl * id : nullptr;
 			t.w = lw; t.h = lh; t.nSrc = v.nNb;
 			double K0[9];

@@ -86,6 +86,7 @@ struct PMTask {           // one reference view at one pyramid level
 	uint32_t k0, k1base;  // Philox key: (seed, viewID*0x9E3779B1 + pass)
 	const float4* qArr;   // the quad images of ALL scene views at this level, one allocation (view i at qArr + i * (w + h - 1) * h): the buffer the sweep kernels' tap rows index
 	unsigned qCount, qPad; // its entries
+	const float* sArr;    // the anti-diagonal-major images of ALL scene views at this level, same indexing (4-byte entries): the buffer of the PM_TRILOAD build
 	PMSrcView src[PM_MAX_SRC];
 };
 struct PMKParams {        // DepthEstimator ctor constants, DepthMap.cpp:397-406
@@ -260,11 +261,11 @@ __device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef int pm_rsrc __attribute__((ext_vector_type(4)));
 // built from wave-uniform values only (one task per workgroup); readfirstlane makes that provable to the compiler so that the descriptor sits in SGPRs
-__device__ __forceinline__ pm_rsrc pm_make_rsrc(const void* base, unsigned count) {
+__device__ __forceinline__ pm_rsrc pm_make_rsrc(const void* base, unsigned count, unsigned stride = 16) {
 	const unsigned long long b = (unsigned long long)base;
 	pm_rsrc r;
 	r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
-	r.y = __builtin_amdgcn_readfirstlane((int)(((unsigned)(b >> 32) & 0xffffu) | (16u << 16)));   // base[47:32], stride 16 bytes
+	r.y = __builtin_amdgcn_readfirstlane((int)(((unsigned)(b >> 32) & 0xffffu) | (stride << 16)));   // base[47:32], stride in bytes
 	r.z = __builtin_amdgcn_readfirstlane((int)count);                                                // records (index >= count: out of range)
 	r.w = 0x00020000;                                                                                // data format 32 bit, no swizzle
 	return r;
@@ -283,6 +284,28 @@ __device__ __forceinline__ void pm_bufwait5(pm_f4v& q0, pm_f4v& q1, pm_f4v& q2, 
 	asm volatile("s_waitcnt vmcnt(%5)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4) : "i"(LEFT));
 }
 __device__ __forceinline__ unsigned pm_mad24(int a, int b, unsigned c) { return (unsigned)__mul24(a, b) + c; }   // v_mad_u32_u24: full rate
+// PM_TRILOAD: the same four texels from the PLAIN anti-diagonal-major image (4-byte entries, a quarter of the quad image's footprint in every cache): texel (u,v)
+// sits at entry e = (u+v)*h + v, (u+1,v) and (u,v+1) are the ADJACENT entries e+h, e+h+1 and (u+1,v+1) is e+2h+1 -- one dword, one dwordx2 and one dword load off
+// the same index register, the row offsets in two scalar registers (soff1 = 4h, soff2 = 4(2h+1) bytes; every scene image of a level has the level's size).
+// Fifteen loads per row; the pieces stay in their own registers until the row is consumed (nothing may touch a destination before the wait that names it).
+typedef float pm_f2v __attribute__((ext_vector_type(2)));
+struct PMTriQ { float a0, a1, a2, a3, a4; pm_f2v m0, m1, m2, m3, m4; float d0, d1, d2, d3, d4; };
+__device__ __forceinline__ void pm_triload5(PMTriQ& q, unsigned i0, unsigned i1, unsigned i2, unsigned i3, unsigned i4, pm_rsrc r, int soff1, int soff2) {
+	asm volatile(
+		"buffer_load_dword %0, %15, %20, 0 idxen\n\tbuffer_load_dwordx2 %5, %15, %20, %21 idxen\n\tbuffer_load_dword %10, %15, %20, %22 idxen\n\t"
+		"buffer_load_dword %1, %16, %20, 0 idxen\n\tbuffer_load_dwordx2 %6, %16, %20, %21 idxen\n\tbuffer_load_dword %11, %16, %20, %22 idxen\n\t"
+		"buffer_load_dword %2, %17, %20, 0 idxen\n\tbuffer_load_dwordx2 %7, %17, %20, %21 idxen\n\tbuffer_load_dword %12, %17, %20, %22 idxen\n\t"
+		"buffer_load_dword %3, %18, %20, 0 idxen\n\tbuffer_load_dwordx2 %8, %18, %20, %21 idxen\n\tbuffer_load_dword %13, %18, %20, %22 idxen\n\t"
+		"buffer_load_dword %4, %19, %20, 0 idxen\n\tbuffer_load_dwordx2 %9, %19, %20, %21 idxen\n\tbuffer_load_dword %14, %19, %20, %22 idxen"
+		: "=&v"(q.a0), "=&v"(q.a1), "=&v"(q.a2), "=&v"(q.a3), "=&v"(q.a4), "=&v"(q.m0), "=&v"(q.m1), "=&v"(q.m2), "=&v"(q.m3), "=&v"(q.m4),
+		  "=&v"(q.d0), "=&v"(q.d1), "=&v"(q.d2), "=&v"(q.d3), "=&v"(q.d4)
+		: "v"(i0), "v"(i1), "v"(i2), "v"(i3), "v"(i4), "s"(r), "s"(soff1), "s"(soff2) : "memory");
+}
+template <int LEFT>
+__device__ __forceinline__ void pm_triwait5(PMTriQ& q) {
+	asm volatile("s_waitcnt vmcnt(%15)" : "+v"(q.a0), "+v"(q.a1), "+v"(q.a2), "+v"(q.a3), "+v"(q.a4), "+v"(q.m0), "+v"(q.m1), "+v"(q.m2), "+v"(q.m3), "+v"(q.m4),
+		"+v"(q.d0), "+v"(q.d1), "+v"(q.d2), "+v"(q.d3), "+v"(q.d4) : "i"(LEFT));
+}
 #else
 // host build (the CPU emulator of the tests): the same semantics -- entry index, zeros outside
 typedef float4 pm_f4v;
@@ -293,8 +316,38 @@ __device__ __forceinline__ void pm_bufload5(pm_f4v& q0, pm_f4v& q1, pm_f4v& q2, 
 	q0 = i0 < r.count ? r.base[i0] : z; q1 = i1 < r.count ? r.base[i1] : z; q2 = i2 < r.count ? r.base[i2] : z; q3 = i3 < r.count ? r.base[i3] : z; q4 = i4 < r.count ? r.base[i4] : z;
 }
 template <int LEFT> __device__ __forceinline__ void pm_bufwait5(pm_f4v&, pm_f4v&, pm_f4v&, pm_f4v&, pm_f4v&) {}
+struct pm_f2v { float x, y; };
+struct PMTriQ { float a0, a1, a2, a3, a4; pm_f2v m0, m1, m2, m3, m4; float d0, d1, d2, d3, d4; };
+__device__ __forceinline__ void pm_triload5(PMTriQ& q, unsigned i0, unsigned i1, unsigned i2, unsigned i3, unsigned i4, pm_rsrc r, int soff1, int soff2) {
+	const float* b = (const float*)r.base; const unsigned o1 = (unsigned)soff1 / 4u, o2 = (unsigned)soff2 / 4u;
+	auto ld = [&](unsigned i, unsigned o) { return i < r.count ? b[i + o] : 0.f; };   // (the range check is on the index alone, as the hardware's: the rows below an image's last entry belong to the next image or the guard band)
+	q.a0 = ld(i0, 0); q.m0 = pm_f2v{ld(i0, o1), ld(i0, o1 + 1)}; q.d0 = ld(i0, o2);
+	q.a1 = ld(i1, 0); q.m1 = pm_f2v{ld(i1, o1), ld(i1, o1 + 1)}; q.d1 = ld(i1, o2);
+	q.a2 = ld(i2, 0); q.m2 = pm_f2v{ld(i2, o1), ld(i2, o1 + 1)}; q.d2 = ld(i2, o2);
+	q.a3 = ld(i3, 0); q.m3 = pm_f2v{ld(i3, o1), ld(i3, o1 + 1)}; q.d3 = ld(i3, o2);
+	q.a4 = ld(i4, 0); q.m4 = pm_f2v{ld(i4, o1), ld(i4, o1 + 1)}; q.d4 = ld(i4, o2);
+}
+template <int LEFT> __device__ __forceinline__ void pm_triwait5(PMTriQ&) {}
 __device__ __forceinline__ unsigned pm_mad24(int a, int b, unsigned c) { return (unsigned)(((unsigned)a & 0xffffffu) * ((unsigned)b & 0xffffffu)) + c; }   // wraps as the hardware's low 32 bits do
 #endif
+
+#ifndef PM_TRILOAD
+#define PM_TRILOAD 0   // 1: the sweep kernels' buffer path reads the plain anti-diagonal-major images with three loads per sample instead of the quad images with one
+#endif
+// what the buffer path of the tap rows needs, wave-uniform: the descriptor and (PM_TRILOAD) the two row offsets
+struct PMImgBuf { pm_rsrc rs; int soff1, soff2; };
+__device__ __forceinline__ PMImgBuf pm_make_imgbuf(const PMTask& t) {
+	PMImgBuf b;
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (PM_TRILOAD) { b.rs = pm_make_rsrc(t.sArr, t.qCount - (unsigned)(2 * t.h + 1), 4u);   // (an index whose last piece, e + 2h + 1, would leave the buffer is out of range as a whole)
+	 b.soff1 = __builtin_amdgcn_readfirstlane(4 * t.h); b.soff2 = __builtin_amdgcn_readfirstlane(4 * (2 * t.h + 1)); }
+	else { b.rs = pm_make_rsrc(t.qArr, t.qCount); b.soff1 = 0; b.soff2 = 0; }
+#else
+	if (PM_TRILOAD) { b.rs = pm_make_rsrc(t.sArr, t.qCount - (unsigned)(2 * t.h + 1)); b.soff1 = 4 * t.h; b.soff2 = 4 * (2 * t.h + 1); }
+	else { b.rs = pm_make_rsrc(t.qArr, t.qCount); b.soff1 = 0; b.soff2 = 0; }
+#endif
+	return b;
+}
 
 // One tap row (5 taps) of ScorePixelImage through global loads, with the reference's per-tap tests; row-major (SKEW = false) or anti-diagonal-major image.
 // X = position of the row's first tap.  The reference returns thRobust at the first tap that leaves the image (DepthMap.cpp:484-485).  Here a tap outside
@@ -350,11 +403,11 @@ __device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int 
 // BUF: the sample is addressed as entry index qbase + (lx + ly) * sh + ly of the level's buffer (no clamp: out of range reads zeros, see above); otherwise through the
 // view's own pointer with clamped coordinates (views that carry their own image size live outside the level's buffer).
 struct PMRowPos { float ptx[5], pty[5]; };
-struct PMRowQ { pm_f4v q0, q1, q2, q3, q4; };
+struct PMRowQ { pm_f4v q0, q1, q2, q3, q4; PMTriQ t; };   // (the quad entries or, PM_TRILOAD, their pieces: the unused member is never materialised)
 struct PMTapRange { int zlo, zhi, plo, pxhi, pyhi; };
 // positions of a row's five taps, their samples requested; nothing waits here
 template <bool BUF>
-__device__ __forceinline__ void pm_row_issue(const pm_rsrc& rs, unsigned qbase, const pm_gcf4 imgQ, int sw, int sh, float h0, float h3, float h6, float X0, float X1, float X2,
+__device__ __forceinline__ void pm_row_issue(const PMImgBuf& rs, unsigned qbase, const pm_gcf4 imgQ, int sw, int sh, float h0, float h3, float h6, float X0, float X1, float X2,
 		PMRowPos& p, PMRowQ& q, PMTapRange& rg)
 {
 	unsigned idx[5];
@@ -368,7 +421,8 @@ __device__ __forceinline__ void pm_row_issue(const pm_rsrc& rs, unsigned qbase, 
 		if (j == 4) { const int zLast = pm_f2i(X2); rg.zlo = min(rg.zlo, min(zFirst, zLast)); rg.zhi = max(rg.zhi, max(zFirst, zLast)); }
 		X0 += h0; X1 += h3; X2 += h6;
 	}
-	if (BUF) pm_bufload5(q.q0, q.q1, q.q2, q.q3, q.q4, idx[0], idx[1], idx[2], idx[3], idx[4], rs);
+	if (BUF && PM_TRILOAD) pm_triload5(q.t, idx[0], idx[1], idx[2], idx[3], idx[4], rs.rs, rs.soff1, rs.soff2);
+	else if (BUF) pm_bufload5(q.q0, q.q1, q.q2, q.q3, q.q4, idx[0], idx[1], idx[2], idx[3], idx[4], rs.rs);
 	else { q.q0 = pm_loadq(imgQ, idx[0]); q.q1 = pm_loadq(imgQ, idx[1]); q.q2 = pm_loadq(imgQ, idx[2]); q.q3 = pm_loadq(imgQ, idx[3]); q.q4 = pm_loadq(imgQ, idx[4]); }
 	// (independent of the loads) the extremes of the positions, on their bit patterns (see pm_f2i): plo = the smallest x or y, pxhi / pyhi = the largest x / y
 	rg.plo = min(rg.plo, min(min(min(pm_f2i(p.ptx[0]), pm_f2i(p.ptx[1])), min(pm_f2i(p.ptx[2]), pm_f2i(p.ptx[3]))), pm_f2i(p.ptx[4])));
@@ -380,12 +434,23 @@ __device__ __forceinline__ void pm_row_issue(const pm_rsrc& rs, unsigned qbase, 
 template <bool BUF, int LEFT>
 __device__ __forceinline__ void pm_row_consume(const PMRowPos& p, PMRowQ& q, const float2* wrow, float& sum, float& sumSq, float& num)
 {
-	if (BUF) pm_bufwait5<LEFT>(q.q0, q.q1, q.q2, q.q3, q.q4);
-	const pm_f4v qq[5] = {q.q0, q.q1, q.q2, q.q3, q.q4};
+	float t00[5], t01[5], t10[5], t11[5];
+	if (BUF && PM_TRILOAD) {
+		pm_triwait5<3 * LEFT>(q.t);
+		t00[0] = q.t.a0; t00[1] = q.t.a1; t00[2] = q.t.a2; t00[3] = q.t.a3; t00[4] = q.t.a4;
+		t01[0] = q.t.m0.x; t01[1] = q.t.m1.x; t01[2] = q.t.m2.x; t01[3] = q.t.m3.x; t01[4] = q.t.m4.x;
+		t10[0] = q.t.m0.y; t10[1] = q.t.m1.y; t10[2] = q.t.m2.y; t10[3] = q.t.m3.y; t10[4] = q.t.m4.y;
+		t11[0] = q.t.d0; t11[1] = q.t.d1; t11[2] = q.t.d2; t11[3] = q.t.d3; t11[4] = q.t.d4;
+	} else {
+		if (BUF) pm_bufwait5<LEFT>(q.q0, q.q1, q.q2, q.q3, q.q4);
+		const pm_f4v qq[5] = {q.q0, q.q1, q.q2, q.q3, q.q4};
+#pragma unroll
+		for (int j = 0; j < 5; ++j) { t00[j] = qq[j].x; t01[j] = qq[j].y; t10[j] = qq[j].z; t11[j] = qq[j].w; }
+	}
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
 		const float fx = pm_fract_pos(p.ptx[j]), fx1 = 1.f - fx, fy = pm_fract_pos(p.pty[j]), fy1 = 1.f - fy;   // == ptx - (float)(int)ptx for the positions the row is accepted with (>= 1)
-		const float v = (qq[j].x * fx1 + qq[j].y * fx) * fy1 + (qq[j].z * fx1 + qq[j].w * fx) * fy;
+		const float v = (t00[j] * fx1 + t01[j] * fx) * fy1 + (t10[j] * fx1 + t11[j] * fx) * fy;
 		const float2 pw = wrow[j];
 		const float vw = v * pw.x;
 		sum += vw;
@@ -397,7 +462,7 @@ __device__ __forceinline__ void pm_row_consume(const PMRowPos& p, PMRowQ& q, con
 // 16-byte loads in flight instead of five and waits for memory three times per patch instead of five (a wave-visit is a chain of ~80 such round trips and the launch
 // of a diagonal lasts as long as one wave-visit: DESIGN.md 4.2).  Two register sets (A, B) alternate; the rows are written out so that no set is ever copied.
 template <bool BUF>
-__device__ __forceinline__ void pm_taps_fast(const pm_rsrc& rs, unsigned qbase, const pm_gcf4 imgQ, int sw, int sh, const float* H, float bX0, float bX1, float bX2,
+__device__ __forceinline__ void pm_taps_fast(const PMImgBuf& rs, unsigned qbase, const pm_gcf4 imgQ, int sw, int sh, const float* H, float bX0, float bX1, float bX2,
 		const float2* wts, float& sum, float& sumSq, float& num, PMTapRange& rg)
 {
 	PMRowPos pa, pb; PMRowQ qa, qb;
@@ -434,7 +499,7 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		int x, int y, double X0x, double X0y, float normSq0, float sumW, const float2* wts,
 		float depth, float nx, float ny, float nz,
 		float sf0, float sf1, float sf2, float sf3, float prior,
-		const double* hot, const double* geoTab, const pm_rsrc& rs PM_PROF_ARG)
+		const double* hot, const double* geoTab, const PMImgBuf& rs PM_PROF_ARG)
 {
 	const int sw = ((const int*)(hot + 12))[0], sh = ((const int*)(hot + 12))[1];
 	float H[9];
@@ -656,7 +721,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 	float sc = PM_INF;
 	PM_PROF_DECL;
 	if (v < t.nSrc)
-		sc = pm_score_view<GEO, 0>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, t.src[v].Hl, (const double*)t.src[v].Tl, pm_rsrc() PM_PROF_PASS);
+		sc = pm_score_view<GEO, 0>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, t.src[v].Hl, (const double*)t.src[v].Tl, PMImgBuf() PM_PROF_PASS);
 	const float conf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 	if (v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
 }
@@ -682,7 +747,7 @@ __global__ __launch_bounds__(64, PM_WIDE_MINWAVES) void pm_sweep_wide_kernel(con
 	__shared__ float2 s_w[PM_NT + 1];
 	__shared__ double s_src[G * NBD];
 	const PMTask& t = tasks[blockIdx.y];
-	const pm_rsrc rs = pm_make_rsrc(t.qArr, t.qCount);
+	const PMImgBuf rs = pm_make_imgbuf(t);
 	const int lane = threadIdx.x, c = lane >> 3, v = lane & 7;
 	for (int i = lane; i < G * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];
 	const double* hot = s_src + v * NBD;

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64, PM_WIDEN_MINWAVES) void pm_sweep_widen_kernel(c
 	__shared__ float2 s_w[PPW][PM_NT + 1];
 	__shared__ double s_src[G * NBD];
 	const PMTask& t = tasks[blockIdx.y];
-	const pm_rsrc rs = pm_make_rsrc(t.qArr, t.qCount);
+	const PMImgBuf rs = pm_make_imgbuf(t);
 	const int lane = threadIdx.x, p = lane / LPP, sub = lane % LPP, c = sub >> 3, v = lane & 7, seg = p * LPP;
 	for (int i = lane; i < G * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];
 	const double* hot = s_src + v * NBD;

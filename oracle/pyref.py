@@ -205,3 +205,48 @@ def ref_scale_view(view, f):
     nw, nh = wh[0], wh[1]
     has = bool(view.depth)
     return img.ravel()[:nw * nh].reshape(nh, nw).copy(), K.reshape(3, 3), (dep.ravel()[:nw * nh].reshape(nh, nw).copy() if has else None), (Kd.reshape(3, 3) if has else None)
+
+
+# ---- Scene::SelectNeighborViews / FilterNeighborViews through the reference's own code (oracle/ref/ref_scene_harness.cpp: Scene.cpp:801-934, :953-968 verbatim) ----
+VIEW_SCORE = np.dtype([("ID", np.uint32), ("points", np.uint32), ("scale", np.float32), ("angle", np.float32), ("area", np.float32), ("score", np.float32)])
+
+
+def scene_available() -> bool:
+    available()
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_scene.so"))
+
+
+def _scene_lib():
+    if "scene" not in _LIBS:
+        if not scene_available():
+            raise RuntimeError("oracle/_ref/libref_scene.so is not built and /root/reference is not here to build it from")
+        l = C.CDLL(os.path.join(_HERE, "_ref", "libref_scene.so"))
+        l.ref_select_neighbor_views.restype = C.c_int; l.ref_filter_neighbor_views.restype = C.c_int
+        _LIBS["scene"] = l
+    return _LIBS["scene"]
+
+
+def ref_select_neighbor_views(cams, sizes, points, point_views, ID, nMinViews=2, nMinPointViews=2, fOptimAngleDeg=12.0, nInsideROI=1):
+    """cams: list of (K, R, C) at each image's working resolution; sizes: list of (w, h); points: [N,3] float32; point_views: list of ascending image-index arrays.
+    Returns (ok, neighbours as VIEW_SCORE records in the reference's order, kept point indices, average depth)."""
+    n = len(cams)
+    cam = np.zeros((n, 21), np.float64)
+    for i, (K, R, Cc) in enumerate(cams):
+        cam[i, :9] = np.asarray(K, np.float64).ravel(); cam[i, 9:18] = np.asarray(R, np.float64).ravel(); cam[i, 18:] = np.asarray(Cc, np.float64).ravel()
+    sz = np.ascontiguousarray(np.asarray(sizes, np.int32)); valid = np.ones(n, np.uint8)
+    pts = np.ascontiguousarray(points, np.float32)
+    start = np.zeros(len(point_views) + 1, np.uint32); start[1:] = np.cumsum([len(v) for v in point_views])
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(v, np.uint32) for v in point_views]) if len(point_views) else np.zeros(0, np.uint32))
+    nb = np.zeros(max(1, n), VIEW_SCORE); keep = np.zeros(max(1, len(pts)), np.uint32)
+    nn = C.c_int(0); npk = C.c_int(0); avg = C.c_float(0)
+    ok = _scene_lib().ref_select_neighbor_views(C.c_int(n), cam.ctypes.data_as(C.POINTER(C.c_double)), sz.ctypes.data_as(C.POINTER(C.c_int)), valid.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                                C.c_int(len(pts)), pts.ctypes.data_as(C.POINTER(C.c_float)), start.ctypes.data_as(C.POINTER(C.c_uint32)), flat.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                C.c_uint32(ID), C.c_uint(nMinViews), C.c_uint(nMinPointViews), C.c_float(np.float32(np.deg2rad(np.float32(fOptimAngleDeg)))), C.c_uint(nInsideROI),
+                                                nb.ctypes.data_as(C.c_void_p), C.c_int(len(nb)), C.byref(nn), keep.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int(len(keep)), C.byref(npk), C.byref(avg))
+    return bool(ok), nb[:nn.value].copy(), keep[:npk.value].copy(), float(avg.value)
+
+
+def ref_filter_neighbor_views(neighbors, fMinArea, fMinScale, fMaxScale, fMinAngle, fMaxAngle, nMaxViews):
+    a = np.ascontiguousarray(neighbors, VIEW_SCORE).copy()
+    n = _scene_lib().ref_filter_neighbor_views(a.ctypes.data_as(C.c_void_p), C.c_int(len(a)), C.c_float(fMinArea), C.c_float(fMinScale), C.c_float(fMaxScale), C.c_float(fMinAngle), C.c_float(fMaxAngle), C.c_uint(nMaxViews))
+    return a[:n]

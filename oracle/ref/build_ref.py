@@ -59,6 +59,12 @@ SNIPPETS = {
     "rotation_inl_set":      ("libs/Common/Rotation.inl", 700, 729, "template <typename TYPE>", "}"),
     "random_h":              ("libs/Common/Random.h", 100, 159, "// Encapsulates state for random number generation", "};"),
     "camera_h_scalek":       ("libs/MVS/Camera.h", 159, 173, "template<typename TYPE>", "}"),
+    "camera_h_projectp":     ("libs/MVS/Camera.h", 307, 320, "template <typename TYPE>", "}"),
+    "camera_h_isinside":     ("libs/MVS/Camera.h", 402, 405, "template <typename TYPE>", "}"),
+    "camera_h_footprint":    ("libs/MVS/Camera.h", 437, 446, "template <typename TYPE>", "}"),
+    "camera_cpp_pointdepth": ("libs/MVS/Camera.cpp", 112, 115, "REAL Camera::PointDepth(const Point3& X) const", "} // PointDepth"),
+    "scene_cpp_select":      ("libs/MVS/Scene.cpp", 801, 934, "bool Scene::SelectNeighborViews(uint32_t ID, IndexArr& points,", "} // SelectNeighborViews"),
+    "scene_cpp_filter":      ("libs/MVS/Scene.cpp", 953, 968, "bool Scene::FilterNeighborViews(ViewScoreArr& neighbors,", "} // FilterNeighborViews"),
     "camera_h_invk":         ("libs/MVS/Camera.h", 175, 188, "// return K.inv() (assuming standard K format and no shear)", "}"),
     "camera_h_i2c":          ("libs/MVS/Camera.h", 329, 344, "// un-project from image pixel coords to the camera space (z=1 plane by default)", "}"),
     "camera_h_c2w_i2w":      ("libs/MVS/Camera.h", 345, 356, "template <typename TYPE>", "}"),
@@ -84,7 +90,7 @@ SNIPPETS = {
 }
 
 
-ALL = ("libref_pm.so", "libref_pm_libm.so", "libref_sgm.so", "libref_driver.so", "libref_driver_libm.so")
+ALL = ("libref_pm.so", "libref_pm_libm.so", "libref_sgm.so", "libref_scene.so", "libref_driver.so", "libref_driver_libm.so")
 
 
 def cut(dst):
@@ -112,6 +118,7 @@ def build(verbose=False):
         link_orc = ["-pthread", "-L", os.path.join(ROOT, "oracle"), "-l:libpm_oracle.so", "-Wl,-rpath,$ORIGIN/.."]
         for name, flags, src in (("libref_pm.so", ["-DREF_MATH_PM"], "ref_harness.cpp"), ("libref_pm_libm.so", [], "ref_harness.cpp"),
                                  ("libref_sgm.so", ["-DREF_MATH_PM"], "ref_sgm_harness.cpp"),
+                                 ("libref_scene.so", [], "ref_scene_harness.cpp"),
                                  ("libref_driver.so", ["-DREF_MATH_PM"] + link_orc, "ref_driver_harness.cpp"),
                                  ("libref_driver_libm.so", ["-O3", "-march=x86-64-v3"] + link_orc, "ref_driver_harness.cpp")):
             out = os.path.join(OUT, name)

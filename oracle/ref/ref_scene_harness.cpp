@@ -1,0 +1,102 @@
+// ref_scene_harness.cpp -- TEST INFRASTRUCTURE ONLY (oracle/_ref).  The reference's view selection: Scene::SelectNeighborViews (one image) and Scene::FilterNeighborViews
+// (libs/MVS/Scene.cpp:800-934, :952-968) cut VERBATIM from /root/reference by oracle/ref/build_ref.py, with the camera members they call (Camera.h / Camera.cpp: ProjectPointP3,
+// ProjectPointP, IsInside, GetFootprintImage, PointDepth) and ComputeAngle, compiled against oracle/ref/shim.  Pins openmvs_amd/csrc/mvs_front.cpp (mvsf_select_neighbor_views,
+// mvsf_select_views) and openmvs_amd/views.py, which until round 4 were only checked against each other.
+// Third-party arithmetic restated here because the libraries are absent: AssembleProjectionMatrix's cv::Mat products (Camera.cpp:173-180: P = [K R | K R (-C)],
+// OpenCV's small-matrix gemm accumulates left to right in double) and ComputeCoveredArea's Eigen expression (Util.inl:847-866: cell = floor((p / bound + 0) * 16)).
+#define REF_SCENE 1
+#include "seacave_min.h"
+#define DEBUG_EXTRA(...) ((void)0)
+#define VERBOSE(...) ((void)0)
+#define VERBOSITY_LEVEL 0
+namespace SEACAVE {
+// Util.inl:847-866, Eigen restated: the fraction of the s x s cells of the bounding rectangle that hold a point
+template <typename TYPE, int n, int s, bool bCentered>
+inline TYPE ComputeCoveredArea(const TYPE* values, size_t size, const TYPE* bound, int stride = n) {
+	static_assert(n == 2, "2-D points");
+	unsigned surface[s][s]; memset(surface, 0, sizeof(surface));
+	const TYPE offset(bCentered ? TYPE(0.5) : TYPE(0));
+	for (size_t i = 0; i < size; ++i) {
+		const TYPE p0 = (values[i * stride] / bound[0] + offset) * TYPE(s), p1 = (values[i * stride + 1] / bound[1] + offset) * TYPE(s);
+		surface[FLOOR2INT(p0)][FLOOR2INT(p1)] = 1;
+	}
+	unsigned sum = 0; for (int a = 0; a < s; ++a) for (int b = 0; b < s; ++b) sum += surface[a][b];
+	return TYPE(sum) / (s * s);
+}
+}
+typedef SEACAVE::cList<Point2f, const Point2f&, 0> Point2fArr;   // Common.h:271
+namespace MVS {
+struct PointCloud {
+	typedef TPoint3<float> Point; typedef uint32_t View;
+	typedef SEACAVE::cList<View, const View, 0, 4, uint32_t> ViewArr;
+	SEACAVE::cList<Point> points; SEACAVE::cList<ViewArr> pointViews;
+};
+class Scene {
+public:
+	ImageArr images; PointCloud pointcloud; unsigned nCalibratedImages;
+	struct { template <typename P> bool Intersects(const P&) const { return true; } } obb;
+	bool IsBounded() const { return false; }
+	bool SelectNeighborViews(uint32_t ID, IndexArr& points, unsigned nMinViews = 3, unsigned nMinPointViews = 2, float fOptimAngle = FD2R(12), unsigned nInsideROI = 1);
+	static bool FilterNeighborViews(ViewScoreArr& neighbors, float fMinArea = 0.1f, float fMinScale = 0.2f, float fMaxScale = 2.4f, float fMinAngle = FD2R(3), float fMaxAngle = FD2R(45), unsigned nMaxViews = 12);
+};
+// Camera.cpp:173-180 (cv::Mat products restated, see the header of this file)
+void AssembleProjectionMatrix(const KMatrix& K, const RMatrix& R, const CMatrix& C, PMatrix& P) {
+	const Matrix3x3 M(K * R);
+	for (int i = 0; i < 3; ++i) {
+		for (int j = 0; j < 3; ++j) P(i, j) = M(i, j);
+		REAL s = 0; const REAL c[3] = {-C.x, -C.y, -C.z};
+		for (int k = 0; k < 3; ++k) s += M(i, k) * c[k];
+		P(i, 3) = s;
+	}
+}
+}
+using namespace MVS;
+#include "snip/camera_cpp_pointdepth.inc"   // Camera.cpp:112-115: Camera::PointDepth
+#include "snip/scene_cpp_select.inc"        // Scene.cpp:800-934: Scene::SelectNeighborViews(ID, ...)
+#include "snip/scene_cpp_filter.inc"        // Scene.cpp:952-968: Scene::FilterNeighborViews
+
+extern "C" {
+struct RefViewScore { uint32_t ID, points; float scale, angle, area, score; };
+// cams: nImages x (K 9, R 9, C 3) doubles at each image's working resolution, sizes: nImages x (w, h); pts: nPoints x 3 floats; viewStart / views: CSR lists of the images
+// (ascending) that see each point.  Outputs: the candidate list of image ID in the reference's order, the indices of the points kept for it, its average depth.
+// Returns SelectNeighborViews' own result (1 = enough views).
+int ref_select_neighbor_views(int nImages, const double* cams, const int* sizes, const unsigned char* valid, int nPoints, const float* pts, const uint32_t* viewStart, const uint32_t* views,
+		uint32_t ID, unsigned nMinViews, unsigned nMinPointViews, float fOptimAngle, unsigned nInsideROI,
+		RefViewScore* neighbors, int cap, int* nNeighbors, uint32_t* points, int pointsCap, int* nPointsOut, float* avgDepth) {
+	Scene scene;
+	scene.images.resize((IIndex)nImages);
+	unsigned nCal = 0;
+	for (int i = 0; i < nImages; ++i) {
+		Image& im = scene.images[(IIndex)i];
+		im.ID = (uint32_t)i; im.valid = valid[i] != 0; im.size = cv::Size(sizes[2 * i], sizes[2 * i + 1]); im.width = sizes[2 * i]; im.height = sizes[2 * i + 1];
+		const double* c = cams + 21 * (size_t)i;
+		for (int k = 0; k < 9; ++k) { im.camera.K.val[k] = c[k]; im.camera.R.val[k] = c[9 + k]; }
+		im.camera.C.x = c[18]; im.camera.C.y = c[19]; im.camera.C.z = c[20];
+		im.camera.ComposeP();
+		if (im.valid) ++nCal;
+	}
+	scene.nCalibratedImages = nCal;
+	scene.pointcloud.points.resize((size_t)nPoints); scene.pointcloud.pointViews.resize((size_t)nPoints);
+	for (int i = 0; i < nPoints; ++i) {
+		scene.pointcloud.points[(size_t)i] = PointCloud::Point(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+		for (uint32_t k = viewStart[i]; k < viewStart[i + 1]; ++k) scene.pointcloud.pointViews[(size_t)i].push_back(views[k]);
+	}
+	IndexArr pointsArr;
+	const bool ok = scene.SelectNeighborViews(ID, pointsArr, nMinViews, nMinPointViews, fOptimAngle, nInsideROI);
+	const ViewScoreArr& nb = scene.images[(IIndex)ID].neighbors;
+	*nNeighbors = (int)nb.size();
+	for (int i = 0; i < (int)nb.size() && i < cap; ++i) { const ViewScore& v = nb[(IIndex)i]; neighbors[i] = RefViewScore{v.ID, v.points, v.scale, v.angle, v.area, v.score}; }
+	*nPointsOut = (int)pointsArr.size();
+	for (int i = 0; i < (int)pointsArr.size() && i < pointsCap; ++i) points[i] = pointsArr[(size_t)i];
+	*avgDepth = scene.images[(IIndex)ID].avgDepth;
+	return ok ? 1 : 0;
+}
+// Scene::FilterNeighborViews on a list, in place; returns the new length
+int ref_filter_neighbor_views(RefViewScore* neighbors, int n, float fMinArea, float fMinScale, float fMaxScale, float fMinAngle, float fMaxAngle, unsigned nMaxViews) {
+	ViewScoreArr a; a.resize((IIndex)n);
+	for (int i = 0; i < n; ++i) { ViewScore& v = a[(IIndex)i]; v.ID = neighbors[i].ID; v.points = neighbors[i].points; v.scale = neighbors[i].scale; v.angle = neighbors[i].angle; v.area = neighbors[i].area; v.score = neighbors[i].score; }
+	Scene::FilterNeighborViews(a, fMinArea, fMinScale, fMaxScale, fMinAngle, fMaxAngle, nMaxViews);
+	for (int i = 0; i < (int)a.size(); ++i) { const ViewScore& v = a[(IIndex)i]; neighbors[i] = RefViewScore{v.ID, v.points, v.scale, v.angle, v.area, v.score}; }
+	return (int)a.size();
+}
+}

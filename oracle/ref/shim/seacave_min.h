@@ -142,6 +142,15 @@ public:
 		TYPE* const nth1(nth - 1); std::nth_element(Begin(), nth1, nth);
 		return (static_cast<RTYPE>(*nth1) + static_cast<RTYPE>(*nth)) / RTYPE(2);
 	}
+	// List.h:727-735, :737-745, :847-861, :1117-1121, :1157-1166 (glue: binary search on a sorted list, std::sort, erase)
+	static constexpr IDX_TYPE NO_INDEX = (IDX_TYPE)-1;
+	inline void Sort() { std::sort(Begin(), End()); }
+	template <typename Functor> inline void Sort(const Functor& f) { std::sort(Begin(), End(), f); }
+	inline bool IsSorted() const { return std::is_sorted(Begin(), End()); }
+	inline IDX FindFirst(ARG_TYPE key) const { size_t l1 = 0, l2 = v.size(); while (l1 < l2) { const size_t i = (l1 + l2) >> 1; if (key < v[i]) l2 = i; else if (v[i] < key) l1 = i + 1; else return (IDX)i; } return NO_INDEX; }
+	inline void RemoveLast() { v.pop_back(); }
+	inline void pop_back() { v.pop_back(); }
+	inline void RemoveAtMove(IDX i) { v.erase(v.begin() + (size_t)i); }
 	inline std::pair<TYPE, TYPE> GetMinMax() const { const auto mm(std::minmax_element(Begin(), End())); return std::pair<TYPE, TYPE>(*mm.first, *mm.second); }
 	std::vector<TYPE> v;
 };
@@ -151,6 +160,7 @@ public:
 #define CLISTDEF2IDX(TYPE,IDXTYPE) SEACAVE::cList< TYPE, const TYPE&, 2, 16, IDXTYPE >
 #define ARR2IDX(arr) typename std::remove_reference<decltype(arr)>::type::size_type
 #define FOREACH(var, arr) for (ARR2IDX(arr) var=0, var##Size=(arr).size(); var<var##Size; ++var)
+#define RFOREACH(var, arr) for (ARR2IDX(arr) var=(arr).size(); var-->0; )   // List.h:46
 #define FOREACHPTR(var, arr) for (auto var=(arr).begin(), var##End=(arr).end(); var!=var##End; ++var)   // List.h:41
 typedef cList<float, float, 0> FloatArr;          // Types.h:427
 typedef cList<uint32_t, uint32_t, 0> IndexArr;
@@ -312,15 +322,30 @@ public:
 #include "snip/camera_h_c2w_i2w.inc"     // Camera.h:345-356: TransformPointC2W, TransformPointI2W (both)
 #include "snip/camera_h_c2i.inc"         // Camera.h:368-374: TransformPointC2I (z = 1 plane)
 #include "snip/camera_h_c2i3_w2c_w2i.inc" // Camera.h:382-394: TransformPointC2I (3D), TransformPointW2C, TransformPointW2I
+#ifdef REF_SCENE
+	TMatrix<REAL,3,4> P;                     // Camera.h:260: the composed projection matrix
+	inline REAL GetFocalLength() const { return K(0,0); }   // Camera.h:78
+	void ComposeP();                         // Camera.cpp:85-88
+	REAL PointDepth(const Point3& X) const;  // Camera.cpp:112-115 (cut verbatim by the harness)
+#include "snip/camera_h_projectp.inc"    // Camera.h:307-320: ProjectPointP3, ProjectPointP
+#include "snip/camera_h_isinside.inc"    // Camera.h:402-405: IsInside(pt, size)
+#include "snip/camera_h_footprint.inc"   // Camera.h:437-446: GetFootprintImage
+#endif
 };
+#ifdef REF_SCENE
+typedef TMatrix<REAL,3,4> PMatrix;               // Common.h:259
+void AssembleProjectionMatrix(const KMatrix& K, const RMatrix& R, const CMatrix& C, PMatrix& P);   // Camera.h:492
+inline void Camera::ComposeP() { AssembleProjectionMatrix(K, R, C, P); }
+#endif
+struct ViewScore { uint32_t ID; uint32_t points; float scale, angle, area, score; };   // Interface.h:527-533
+typedef CLISTDEFIDX(ViewScore,IIndex) ViewScoreArr;
 struct Image { uint32_t ID; Camera camera; cv::Size size; inline cv::Size GetSize() const { return size; }
+	bool valid = true; inline bool IsValid() const { return valid; } float avgDepth = 0; uint32_t width = 0, height = 0; ViewScoreArr neighbors;   // Image.h:60-75
 	// Image.h:155-163 (definitions: Image.cpp:372-433, cut verbatim where a harness needs them)
 	static float Disparity2Depth(const Matrix4x4& Q, const ImageRef& u, float d); static float Disparity2Depth(const Matrix4x4& Q, const Point2f& u, float d);
 	static float Disparity2Depth(const Matrix4x4& Q, const ImageRef& u, float d, Point2f& pt); static float Disparity2Depth(const Matrix4x4& Q, const Point2f& u, float d, Point2f& pt);
 	static bool Depth2Disparity(const Matrix4x4& Q, const Point2f& u, float d, float& disparity); };   // Image.h: ID, camera, GetSize() are what the path reads
 typedef CLISTDEFIDX(Image,IIndex) ImageArr;
-struct ViewScore { uint32_t ID; };
-typedef CLISTDEFIDX(ViewScore,IIndex) ViewScoreArr;
 typedef float Depth;                             // PointCloud.h:177-181
 typedef Point3f Normal;
 typedef TImage<Depth> DepthMap;

@@ -421,14 +421,6 @@ __device__ __forceinline__ void pm_row_issue(const PMImgBuf& rs, unsigned qbase,
 		if (j == 4) { const int zLast = pm_f2i(X2); rg.zlo = min(rg.zlo, min(zFirst, zLast)); rg.zhi = max(rg.zhi, max(zFirst, zLast)); }
 		X0 += h0; X1 += h3; X2 += h6;
 	}
-#ifdef PM_PROBE_LDS   /* TIMING PROBE, never in the product: the samples come from a 16 KB LDS array (garbage values): what would the kernel do if the source windows were staged in LDS? */
-	if (BUF) {
-		__shared__ float s_probe[4096 + 64];
-		pm_f4v* qq[5] = {&q.q0, &q.q1, &q.q2, &q.q3, &q.q4};
-#pragma unroll
-		for (int j = 0; j < 5; ++j) { const float* b = s_probe + (idx[j] & 4095u); *qq[j] = pm_f4v{b[0], b[26], b[27], b[53]}; }
-	} else
-#endif
 	if (BUF && PM_TRILOAD) pm_triload5(q.t, idx[0], idx[1], idx[2], idx[3], idx[4], rs.rs, rs.soff1, rs.soff2);
 	else if (BUF) pm_bufload5(q.q0, q.q1, q.q2, q.q3, q.q4, idx[0], idx[1], idx[2], idx[3], idx[4], rs.rs);
 	else { q.q0 = pm_loadq(imgQ, idx[0]); q.q1 = pm_loadq(imgQ, idx[1]); q.q2 = pm_loadq(imgQ, idx[2]); q.q3 = pm_loadq(imgQ, idx[3]); q.q4 = pm_loadq(imgQ, idx[4]); }
@@ -450,9 +442,7 @@ __device__ __forceinline__ void pm_row_consume(const PMRowPos& p, PMRowQ& q, con
 		t10[0] = q.t.m0.y; t10[1] = q.t.m1.y; t10[2] = q.t.m2.y; t10[3] = q.t.m3.y; t10[4] = q.t.m4.y;
 		t11[0] = q.t.d0; t11[1] = q.t.d1; t11[2] = q.t.d2; t11[3] = q.t.d3; t11[4] = q.t.d4;
 	} else {
-#ifndef PM_PROBE_LDS
 		if (BUF) pm_bufwait5<LEFT>(q.q0, q.q1, q.q2, q.q3, q.q4);
-#endif
 		const pm_f4v qq[5] = {q.q0, q.q1, q.q2, q.q3, q.q4};
 #pragma unroll
 		for (int j = 0; j < 5; ++j) { t00[j] = qq[j].x; t01[j] = qq[j].y; t10[j] = qq[j].z; t11[j] = qq[j].w; }

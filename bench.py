@@ -201,7 +201,7 @@ def main():
         # which sweep kernel the engine picks for this rank's batch (pm_engine.hip: PMHIP_DEFAULT_WIDE, PMHIP_LANES4_FROM); the counter measurement behind `traffic` is of pm_sweep2_kernel
         try:
             nb = B if B else len(mine)
-            wide_max = int(os.environ.get("PMHIP_WIDE", "25"))
+            wide_max = int(os.environ.get("PMHIP_WIDE", "64"))
             if nb <= wide_max and N <= 8:
                 hy = os.environ.get("PMHIP_WIDE_HYPS")
                 hyps = int(hy) if hy in ("8", "4", "2") else (8 if nb <= 2 else 2)

@@ -21,10 +21,9 @@
 #include <vector>
 
 #ifndef PMHIP_DEFAULT_WIDE
-#define PMHIP_DEFAULT_WIDE 25   // batches of at most this many reference views use the speculative kernels: eight hypotheses per round (one wave per pixel) for 1-2 views, two per round
-                                // (four pixels per wave, pm_wide_n.hip) from 3 views on.  Measured (profiles/r03_small_batches_call24_26_narrower_speculation.log, full schedule at
-                                // 1920x1080, Mpix/s; one view per lane / eight-wide / two-wide): 1 view 1.74 / 2.57 / 2.52, 4: 6.2 / 9.0 / 9.2, 8: 11.7 / 14.4 / 16.6, 13: 17.9 / 17.5 / 23.6,
-                                // 25: 28.2 / - / 32.5; the four-wide kernel is between the two (13 views: 21.1)
+#define PMHIP_DEFAULT_WIDE 64   // batches of at most this many reference views use the speculative kernels: eight hypotheses per round (one wave per pixel) for 1-2 views, two per round
+                                // (four pixels per wave, pm_wide_n.hip) from 3 views on.  Measured in round 4 (profiles/r04_call7_crossover.log, full schedule at 1920x1080, Mpix/s;
+                                // two-wide / pm_sweep2_kernel): 13 views 26.8 / 19.7, 25: 37.5 / 31.2, 50: 41.0 / 39.3, 100: 42.6 / 44.9 (<4,2>)
 #endif
 #ifndef PMHIP_DEFAULT_LANES
 #define PMHIP_DEFAULT_LANES 0    // sweep kernel: lanes per pixel; 0 = by batch size (one view per lane for small batches, four lanes and two views per lane

@@ -250,3 +250,54 @@ def ref_filter_neighbor_views(neighbors, fMinArea, fMinScale, fMaxScale, fMinAng
     a = np.ascontiguousarray(neighbors, VIEW_SCORE).copy()
     n = _scene_lib().ref_filter_neighbor_views(a.ctypes.data_as(C.c_void_p), C.c_int(len(a)), C.c_float(fMinArea), C.c_float(fMinScale), C.c_float(fMaxScale), C.c_float(fMinAngle), C.c_float(fMaxAngle), C.c_uint(nMaxViews))
     return a[:n]
+
+
+# ---- DepthMapsData::FuseDepthMaps / MergeDepthMaps through the reference's own code (oracle/ref/ref_fuse_harness.cpp: SceneDensify.cpp:1303-1646 verbatim) ----
+def fuse_available() -> bool:
+    available()
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_fuse.so"))
+
+
+def _fuse_lib():
+    if "fuse" not in _LIBS:
+        if not fuse_available():
+            raise RuntimeError("oracle/_ref/libref_fuse.so is not built and /root/reference is not here to build it from")
+        l = C.CDLL(os.path.join(_HERE, "_ref", "libref_fuse.so"))
+        l.ref_fuse_depth_maps.restype = C.c_int; l.ref_merge_depth_maps.restype = C.c_int
+        _LIBS["fuse"] = l
+    return _LIBS["fuse"]
+
+
+def ref_fuse_depth_maps(depths, normals, confs, bgrs, K, R, Cc, neighbors, nMinViewsFuse=2, fDepthDiffThreshold=0.01, fNormalDiffThreshold=25.0,
+                        bEstimateColor=True, bEstimateNormal=True):
+    """Same inputs as pyoracle.fuse_depth_maps.  Returns (cloud dict, order): the cloud WITHOUT `projs` (the reference keeps them in a local) and the order in which the
+    reference's own sort processed the images; nMinViewsFuse < 2 runs MergeDepthMaps (order = None)."""
+    n = len(depths)
+    first = next(d for d in depths if d is not None)
+    h, w = first.shape
+    keep = []
+    arr = (po.OrcFuseView * n)()
+
+    def ptr(a, dt, ct):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dt); keep.append(a)
+        return a.ctypes.data_as(C.POINTER(ct))
+    for i in range(n):
+        v = arr[i]
+        v.depth = ptr(depths[i], np.float32, C.c_float)
+        v.normal = ptr(None if normals is None or depths[i] is None else normals[i], np.float32, C.c_float)
+        v.conf = ptr(None if confs is None or depths[i] is None else confs[i], np.float32, C.c_float)
+        v.bgr = ptr(None if bgrs is None else bgrs[i], np.uint8, C.c_uint8)
+        v.K[:] = np.asarray(K[i], np.float64).ravel(); v.R[:] = np.asarray(R[i], np.float64).ravel(); v.C[:] = np.asarray(Cc[i], np.float64).ravel()
+        nb = np.ascontiguousarray(neighbors[i], np.uint32); keep.append(nb)
+        v.neighbors = nb.ctypes.data_as(C.POINTER(C.c_uint32)); v.nNeighbors = len(nb)
+    out = po.OrcFuseCloud()
+    L = _fuse_lib()
+    if nMinViewsFuse < 2:
+        rc = L.ref_merge_depth_maps(arr, C.c_int(n), C.c_int(w), C.c_int(h), C.c_int(1 if bEstimateColor else 0), C.c_int(1 if bEstimateNormal else 0), C.byref(out))
+        return po._cloud(out, rc, L.ref_fuse_free), None
+    order = np.zeros(n, np.uint32); no = C.c_int(0)
+    rc = L.ref_fuse_depth_maps(arr, C.c_int(n), C.c_int(w), C.c_int(h), order.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(no), C.c_uint(nMinViewsFuse),
+                               C.c_float(fDepthDiffThreshold), C.c_float(fNormalDiffThreshold), C.c_int(1 if bEstimateColor else 0), C.c_int(1 if bEstimateNormal else 0), C.byref(out))
+    return po._cloud(out, rc, L.ref_fuse_free), [int(x) for x in order[:no.value]]

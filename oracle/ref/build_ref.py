@@ -48,6 +48,13 @@ SNIPPETS = {
     "image_cpp_depth2disp":  ("libs/MVS/Image.cpp", 423, 433, "// converts the given depth at the un-rectified image coordinates to", "}"),
     "sgm_cpp_range":         ("libs/MVS/SemiGlobalMatcher.cpp", 1350, 1444, "SemiGlobalMatcher::Index SemiGlobalMatcher::Disparity2RangeMap(", "}"),
     "sgm_cpp_conv":          ("libs/MVS/SemiGlobalMatcher.cpp", 1837, 2039, "// Compute the disparity-map for the rectified image from the given depth-map of the un-rectified image;", "}"),
+    "types_h_tpixel":        ("libs/Common/Types.h", 1874, 1988, "template <typename TYPE>", "};"),
+    "types_inl_cast_pixel":  ("libs/Common/Types.inl", 1695, 1699, "// Pixel", "}"),
+    "types_h_indexscore":    ("libs/Common/Types.h", 2462, 2485, "// structure used for sorting some indices by their score (decreasing by default)", "};"),
+    "types_h_cuint32":       ("libs/Common/Types.h", 2547, 2557, "struct cuint32_t {", "};"),
+    "depthmap_cpp_getnormal": ("libs/MVS/DepthMap.cpp", 137, 210, "void DepthData::GetNormal(const ImageRef& ir, Point3f& N, const TImage<Point3f>* pPointMap) const", "} // GetNormal"),
+    "scenedensify_conf2weight": ("libs/MVS/SceneDensify.cpp", 119, 122, "// convert the ZNCC score to a weight used to average the fused points", "}"),
+    "scenedensify_fuse":     ("libs/MVS/SceneDensify.cpp", 1303, 1646, "// fuse all depth-maps by simply projecting them in a 3D point cloud", "} // FuseDepthMaps"),
     "types_inl_sample":      ("libs/Common/Types.inl", 2270, 2281, "// sample by bilinear interpolation", "}"),
     "types_inl_sample_f":    ("libs/Common/Types.inl", 2296, 2314, "// sample by bilinear interpolation, using only pixels that meet the user condition", "}"),
     "util_inl_project":      ("libs/Common/Util.inl", 380, 386, "// (optimized ProjectVertex for H[3,3] and X[2,1], output pt[3,1])", "} // ProjectVertex_3x3_2_3"),
@@ -90,7 +97,7 @@ SNIPPETS = {
 }
 
 
-ALL = ("libref_pm.so", "libref_pm_libm.so", "libref_sgm.so", "libref_scene.so", "libref_driver.so", "libref_driver_libm.so")
+ALL = ("libref_pm.so", "libref_pm_libm.so", "libref_sgm.so", "libref_scene.so", "libref_fuse.so", "libref_driver.so", "libref_driver_libm.so")
 
 
 def cut(dst):
@@ -119,6 +126,7 @@ def build(verbose=False):
         for name, flags, src in (("libref_pm.so", ["-DREF_MATH_PM"], "ref_harness.cpp"), ("libref_pm_libm.so", [], "ref_harness.cpp"),
                                  ("libref_sgm.so", ["-DREF_MATH_PM"], "ref_sgm_harness.cpp"),
                                  ("libref_scene.so", [], "ref_scene_harness.cpp"),
+                                 ("libref_fuse.so", [], "ref_fuse_harness.cpp"),
                                  ("libref_driver.so", ["-DREF_MATH_PM"] + link_orc, "ref_driver_harness.cpp"),
                                  ("libref_driver_libm.so", ["-O3", "-march=x86-64-v3"] + link_orc, "ref_driver_harness.cpp")):
             out = os.path.join(OUT, name)

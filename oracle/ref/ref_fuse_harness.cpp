@@ -1,0 +1,166 @@
+// ref_fuse_harness.cpp -- TEST INFRASTRUCTURE ONLY (oracle/_ref).  The reference's depth-map fusion: DepthMapsData::MergeDepthMaps and DepthMapsData::FuseDepthMaps
+// (libs/MVS/SceneDensify.cpp:1305-1366, :1372-1646) with Conf2Weight (:120-122), cut VERBATIM from /root/reference by oracle/ref/build_ref.py and compiled against
+// oracle/ref/shim with the reference's own TPixel, camera members and containers' semantics.  Same C interface as oracle/fuse_oracle.cpp (OrcFuseView in, OrcFuseCloud out),
+// plus the processing order the reference's own std::sort produced (ties among equally connected images are the standard library's: the oracle takes the order as an input).
+// Third-party arithmetic restated because the libraries are absent: cv::normalize(Vec3f) (opencv2/core/matx.hpp: v * (1 / norm), the norm accumulated in double),
+// AssembleProjectionMatrix's cv::Mat products (Camera.cpp:173-180).  File access (DepthData::IncRef / DecRef / Save), progress display and EstimateNormalMap (only reached when
+// a depth map has no normal map) are stubs.
+#define REF_SCENE 1
+#define REF_FUSE 1
+#include "seacave_min.h"
+#define DEBUG_EXTRA(...) ((void)0)
+#define _T(x) x
+#define NO_ID ((uint32_t)-1)               // Common.h:121
+namespace SEACAVE {
+#include "snip/types_h_indexscore.inc"    // Types.h:2462-2485: TIndexScore (compare by score, decreasing)
+typedef TIndexScore<uint32_t, float> IndexScore;
+typedef CLISTDEF0(IndexScore) IndexScoreArr;
+#include "snip/types_h_cuint32.inc"       // Types.h:2547-2557: cuint32_t
+// normalized(TPoint3) -> cv::normalize(Vec3f) (Types.inl:1048-1051; OpenCV restated: see the header)
+template <typename TYPE> inline TPoint3<TYPE> normalized(const cv::Point3_<TYPE>& v) {
+	const double nv = std::sqrt((double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z);
+	const double a = nv ? 1. / nv : 0.;
+	return TPoint3<TYPE>(cv::saturate_cast<TYPE>(v.x * a), cv::saturate_cast<TYPE>(v.y * a), cv::saturate_cast<TYPE>(v.z * a));
+}
+namespace Util { struct Progress { Progress(const char*, size_t) {} void display(size_t) {} void close() {} }; }
+struct LogConsole { void Pause() {} void Play() {} };
+inline LogConsole& GET_LOGCONSOLE() { static LogConsole l; return l; }
+}
+#include "snip/depthmap_h.inc"            // libs/MVS/DepthMap.h:41-468 (DepthData; opens namespace MVS, closed right below)
+} // namespace MVS
+namespace MVS {
+struct PointCloud {
+	typedef TPoint3<float> Point; typedef uint32_t View; typedef float Weight; typedef TPoint3<float> Normal; typedef Pixel8U Color;
+	typedef SEACAVE::cList<View, const View, 0, 4, uint32_t> ViewArr;
+	typedef SEACAVE::cList<Weight, const Weight, 0, 4, uint32_t> WeightArr;
+	SEACAVE::cList<Point> points; SEACAVE::cList<ViewArr> pointViews; SEACAVE::cList<WeightArr> pointWeights; SEACAVE::cList<Normal> normals; SEACAVE::cList<Color> colors;
+	size_t GetSize() const { return points.size(); }
+};
+inline void EstimateNormalMap(const Matrix3x3f&, const DepthMap&, NormalMap&) { abort(); }   // (DepthMap.cpp; only for depth maps without normals: not part of this harness)
+typedef Image SceneImage;
+class Scene { public: ImageArr images; };
+class DepthMapsData {
+public:
+	DepthMapsData(Scene& s) : scene(s) {}
+	void MergeDepthMaps(PointCloud& pointcloud, bool bEstimateColor, bool bEstimateNormal);
+	void FuseDepthMaps(PointCloud& pointcloud, bool bEstimateColor, bool bEstimateNormal);
+	Scene& scene;
+	DepthDataArr arrDepthData;
+};
+void AssembleProjectionMatrix(const KMatrix& K, const RMatrix& R, const CMatrix& C, PMatrix& P) {   // Camera.cpp:173-180 (cv::Mat products restated)
+	const Matrix3x3 M(K * R);
+	for (int i = 0; i < 3; ++i) {
+		for (int j = 0; j < 3; ++j) P(i, j) = M(i, j);
+		REAL s = 0; const REAL c[3] = {-C.x, -C.y, -C.z};
+		for (int k = 0; k < 3; ++k) s += M(i, k) * c[k];
+		P(i, 3) = s;
+	}
+}
+namespace OPTDENSE { unsigned nMinViewsFuse = 2; float fDepthDiffThreshold = 0.01f, fNormalDiffThreshold = 25.f; }
+// the file-backed reference counting of DepthData (DepthMap.cpp:1990-2037): the maps are resident here
+unsigned DepthData::IncRef(const String&) { return 1; }
+unsigned DepthData::DecRef() { return 1; }
+bool DepthData::Save(const String&) const { return true; }
+}
+using namespace MVS;
+#undef ComposeDepthFilePath
+#define ComposeDepthFilePath(i, e) String("")
+#define TD_TIMER_STARTD() ((void)0)
+#define TD_TIMER_GET_FMT() String()
+#include "snip/camera_cpp_pointdepth.inc"   // Camera.cpp:112-115
+#include "snip/depthmap_cpp_copy.inc"       // DepthMap.cpp:121-133: DepthData's copy constructor
+// DepthData::GetNormal (DepthMap.cpp:137-205): its first branch -- the depth map has a normal map (:142-146); the estimate from neighbouring depths is not reached here
+void DepthData::GetNormal(const ImageRef& ir, Point3f& N, const TImage<Point3f>*) const {
+	const Camera& camera = images.First().camera;
+	if (normalMap.empty()) abort();
+	N = camera.R.t()*Cast<REAL>(normalMap(ir));
+}
+#include "snip/scenedensify_conf2weight.inc" // SceneDensify.cpp:119-122: Conf2Weight
+#include "snip/scenedensify_fuse.inc"       // SceneDensify.cpp:1303-1646: MergeDepthMaps, FuseDepthMaps
+
+extern "C" {
+struct OrcFuseView {                      // same layout as oracle/fuse_oracle.cpp's
+	const float* depth; const float* normal; const float* conf; const uint8_t* bgr;
+	double K[9], R[9], C[3];
+	const uint32_t* neighbors; uint32_t nNeighbors;
+};
+struct OrcFuseCloud {
+	uint64_t nPoints, nDepths, nViews;
+	float* points; uint32_t* viewStart; uint32_t* views; float* weights; uint16_t* projs; uint8_t* colors; float* normals;
+};
+void ref_fuse_free(OrcFuseCloud* c) { free(c->points); free(c->viewStart); free(c->views); free(c->weights); free(c->projs); free(c->colors); free(c->normals); memset(c, 0, sizeof(*c)); }
+
+static void setup(Scene& scene, DepthMapsData& dm, const OrcFuseView* views, int nImages, int w, int h) {
+	scene.images.resize((IIndex)nImages);
+	dm.arrDepthData.resize((IIndex)nImages);
+	const cv::Size size(w, h);
+	for (int i = 0; i < nImages; ++i) {
+		SceneImage& im = scene.images[(IIndex)i]; const OrcFuseView& s = views[i];
+		im.ID = (uint32_t)i; im.size = size; im.width = (uint32_t)w; im.height = (uint32_t)h;
+		for (int k = 0; k < 9; ++k) { im.camera.K.val[k] = s.K[k]; im.camera.R.val[k] = s.R[k]; }
+		im.camera.C.x = s.C[0]; im.camera.C.y = s.C[1]; im.camera.C.z = s.C[2];
+		im.camera.ComposeP();
+		im.neighbors.resize((IIndex)s.nNeighbors);
+		for (uint32_t n = 0; n < s.nNeighbors; ++n) im.neighbors[(IIndex)n].ID = s.neighbors[n];
+		if (s.bgr) { im.image.create(size); memcpy((void*)im.image.data(), s.bgr, (size_t)w * h * 3); }
+		DepthData& dd = dm.arrDepthData[(IIndex)i];
+		if (!s.depth) continue;                                        // DepthData::IsValid() false: no images
+		dd.images.resize(1);
+		dd.images[0].pImageData = &im; dd.images[0].camera = im.camera;
+		dd.neighbors = im.neighbors;
+		dd.depthMap.create(size); memcpy(dd.depthMap.data(), s.depth, sizeof(float) * (size_t)w * h);
+		if (s.normal) { dd.normalMap.create(size); memcpy((void*)dd.normalMap.data(), s.normal, sizeof(float) * 3 * (size_t)w * h); }
+		if (s.conf) { dd.confMap.create(size); memcpy(dd.confMap.data(), s.conf, sizeof(float) * (size_t)w * h); }
+		dd.dMin = 0; dd.dMax = 1e30f;
+	}
+}
+static void pack(const PointCloud& pc, bool withWeights, OrcFuseCloud* out) {
+	const size_t n = pc.points.size();
+	out->nPoints = n;
+	out->points = (float*)malloc(12 * (n + 1)); out->viewStart = (uint32_t*)malloc(4 * (n + 1));
+	uint64_t nv = 0; for (size_t i = 0; i < n; ++i) nv += pc.pointViews[i].size();
+	out->nViews = nv;
+	out->views = (uint32_t*)malloc(4 * (nv + 1)); out->weights = (float*)calloc(nv + 1, 4); out->projs = (uint16_t*)calloc(2 * (nv + 1), 2);
+	uint32_t at = 0;
+	for (size_t i = 0; i < n; ++i) {
+		out->points[3 * i] = pc.points[i].x; out->points[3 * i + 1] = pc.points[i].y; out->points[3 * i + 2] = pc.points[i].z;
+		out->viewStart[i] = at;
+		for (uint32_t v = 0; v < pc.pointViews[i].size(); ++v, ++at) { out->views[at] = pc.pointViews[i][v]; if (withWeights) out->weights[at] = pc.pointWeights[i][v]; }
+	}
+	out->viewStart[n] = at;
+	if (!pc.colors.empty()) { out->colors = (uint8_t*)malloc(3 * n + 8); memcpy(out->colors, (const void*)pc.colors.data(), 3 * n); }
+	if (!pc.normals.empty()) { out->normals = (float*)malloc(12 * n + 8); memcpy(out->normals, (const void*)pc.normals.data(), 12 * n); }
+}
+// DepthMapsData::FuseDepthMaps.  orderOut (nImages entries): the images in the order the reference processed them (its own Sort of the connection scores); *nOrder their number.
+int ref_fuse_depth_maps(const OrcFuseView* views, int nImages, int w, int h, uint32_t* orderOut, int* nOrder,
+		unsigned nMinViewsFuse, float fDepthDiffThreshold, float fNormalDiffThresholdDeg, int bEstimateColor, int bEstimateNormal, OrcFuseCloud* out) {
+	memset(out, 0, sizeof(*out));
+	Scene scene; DepthMapsData dm(scene);
+	setup(scene, dm, views, nImages, w, h);
+	OPTDENSE::nMinViewsFuse = nMinViewsFuse; OPTDENSE::fDepthDiffThreshold = fDepthDiffThreshold; OPTDENSE::fNormalDiffThreshold = fNormalDiffThresholdDeg;
+	{	// the order: the same container, scores and Sort() as SceneDensify.cpp:1400-1453
+		IndexScoreArr connections((size_t)nImages);
+		for (int i = 0; i < nImages; ++i) {
+			if (!dm.arrDepthData[(IIndex)i].IsValid()) { connections[(size_t)i].idx = NO_ID; connections[(size_t)i].score = 0; continue; }
+			connections[(size_t)i].idx = (uint32_t)i; connections[(size_t)i].score = (float)scene.images[(IIndex)i].neighbors.size();
+		}
+		connections.Sort();
+		while (!connections.empty() && connections.back().score <= 0) connections.pop_back();
+		*nOrder = (int)connections.size();
+		for (size_t i = 0; i < connections.size(); ++i) orderOut[i] = connections[i].idx;
+	}
+	PointCloud pc;
+	dm.FuseDepthMaps(pc, bEstimateColor != 0, bEstimateNormal != 0);
+	pack(pc, true, out);
+	return 0;
+}
+int ref_merge_depth_maps(const OrcFuseView* views, int nImages, int w, int h, int bEstimateColor, int bEstimateNormal, OrcFuseCloud* out) {
+	memset(out, 0, sizeof(*out));
+	Scene scene; DepthMapsData dm(scene);
+	setup(scene, dm, views, nImages, w, h);
+	PointCloud pc;
+	dm.MergeDepthMaps(pc, bEstimateColor != 0, bEstimateNormal != 0);
+	pack(pc, false, out);
+	return 0;
+}
+}

@@ -151,6 +151,8 @@ public:
 	inline void RemoveLast() { v.pop_back(); }
 	inline void pop_back() { v.pop_back(); }
 	inline void RemoveAtMove(IDX i) { v.erase(v.begin() + (size_t)i); }
+	inline IDX InsertSort(ARG_TYPE e) { size_t i = 0; while (i < v.size() && v[i] < e) ++i; v.insert(v.begin() + i, e); return (IDX)i; }   // List.h:799-809 (first position whose element is not smaller)
+	inline void InsertAt(IDX i, ARG_TYPE e) { v.insert(v.begin() + (size_t)i, e); }                                                     // List.h:361-372
 	inline std::pair<TYPE, TYPE> GetMinMax() const { const auto mm(std::minmax_element(Begin(), End())); return std::pair<TYPE, TYPE>(*mm.first, *mm.second); }
 	std::vector<TYPE> v;
 };
@@ -307,6 +309,19 @@ typedef TMatrix<float,4,1> Vec4f;                // Common.h:235
 typedef TRMatrixBase<REAL> RMatrixBase;          // Common.h:253
 typedef Point3 CMatrix; typedef RMatrixBase RMatrix; typedef Matrix3x3 KMatrix;   // Common.h:256-258
 template <typename R> void ComputeRelativeRotation(const R&, const R&, R&);       // named by an inline the path never calls
+#ifdef REF_FUSE
+#define RGBA(r, g, b, a) ((uint32_t)(((a) << 24) | ((r) << 16) | ((g) << 8) | (b)))
+} namespace cv { typedef Vec<double, 4> Scalar; } namespace SEACAVE {
+template <typename TYPE> class ColorType { public: typedef TYPE value_type; typedef TYPE alt_type; };
+template <> class ColorType<uint8_t> { public: typedef uint8_t value_type; typedef float alt_type; };
+template <> class ColorType<float> { public: typedef float value_type; typedef uint8_t alt_type; };
+#define _COLORMODE_BGR 1
+#define _COLORMODE_RGB 2
+#define _COLORMODE _COLORMODE_BGR
+#include "snip/types_h_tpixel.inc"        // Types.h:1874-1988: struct TPixel
+typedef TPixel<uint8_t> Pixel8U; typedef TPixel<float> Pixel32F;
+typedef TImage<Pixel8U> Image8U3;
+#endif
 } // namespace SEACAVE
 using namespace SEACAVE;
 
@@ -341,6 +356,9 @@ struct ViewScore { uint32_t ID; uint32_t points; float scale, angle, area, score
 typedef CLISTDEFIDX(ViewScore,IIndex) ViewScoreArr;
 struct Image { uint32_t ID; Camera camera; cv::Size size; inline cv::Size GetSize() const { return size; }
 	bool valid = true; inline bool IsValid() const { return valid; } float avgDepth = 0; uint32_t width = 0, height = 0; ViewScoreArr neighbors;   // Image.h:60-75
+#ifdef REF_FUSE
+	Image8U3 image;   // Image.h:64: the colour image
+#endif
 	// Image.h:155-163 (definitions: Image.cpp:372-433, cut verbatim where a harness needs them)
 	static float Disparity2Depth(const Matrix4x4& Q, const ImageRef& u, float d); static float Disparity2Depth(const Matrix4x4& Q, const Point2f& u, float d);
 	static float Disparity2Depth(const Matrix4x4& Q, const ImageRef& u, float d, Point2f& pt); static float Disparity2Depth(const Matrix4x4& Q, const Point2f& u, float d, Point2f& pt);

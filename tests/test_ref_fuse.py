@@ -1,0 +1,72 @@
+"""Pins oracle/fuse_oracle.cpp to the REFERENCE'S OWN TEXT: DepthMapsData::FuseDepthMaps and MergeDepthMaps (libs/MVS/SceneDensify.cpp:1303-1646) with Conf2Weight,
+cut verbatim and compiled with the reference's TPixel, camera members and container semantics (oracle/ref/ref_fuse_harness.cpp -> oracle/_ref/libref_fuse.so).
+Point order, view lists, weights, positions, colours and normals must be identical bit for bit; the oracle is given the processing order the reference's own std::sort
+produced (ties among equally connected images are the standard library's choice).  The device fusion (csrc/pm_fuse.hip) is compared with this oracle in tests/test_gpu_fuse.py."""
+import numpy as np
+import pytest
+
+from openmvs_amd import synth
+from oracle import pyoracle as po
+from oracle import pyref as pr
+from tests import fuse_cases as fc
+
+pytestmark = pytest.mark.skipif(not pr.fuse_available(), reason="oracle/_ref/libref_fuse.so not built (needs /root/reference)")
+
+
+def _same(a, b, what):
+    assert a["nPoints"] == b["nPoints"], "%s: %d vs %d points" % (what, a["nPoints"], b["nPoints"])
+    for k in ("viewStart", "views"):
+        assert np.array_equal(a[k], b[k]), "%s: %s differs" % (what, k)
+    for k in ("points", "weights", "normals"):
+        if a[k] is None or b[k] is None:
+            assert a[k] is None and b[k] is None, "%s: %s presence" % (what, k)
+            continue
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), "%s: %s differs in %d values" % (what, k, int((a[k].view(np.uint32) != b[k].view(np.uint32)).sum()))
+    if a["colors"] is None or b["colors"] is None:
+        assert a["colors"] is None and b["colors"] is None, what + ": colour presence"
+    else:
+        assert np.array_equal(a["colors"], b["colors"]), what + ": colours differ"
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    return synth.make_scene(5, 160, 120, n_src=4), synth.make_scene(9, 128, 96, n_src=8)
+
+
+@pytest.mark.parametrize("which,seed", [(0, 0), (0, 3), (1, 1)])
+@pytest.mark.parametrize("opts", [dict(), dict(nMinViewsFuse=3, fDepthDiffThreshold=0.02, fNormalDiffThreshold=15.0), dict(bEstimateColor=False, bEstimateNormal=False),
+                                  dict(nMinViewsFuse=100)])
+def test_fuse_is_the_reference_function(scenes, which, seed, opts):
+    sc = scenes[which]
+    deps, nrms, cnfs = fc.make_maps(sc, seed)
+    nbs = [list(sc.neighbors[v]) for v in range(sc.n_views)]
+    ref, order = pr.ref_fuse_depth_maps(deps, nrms, cnfs, sc.bgr, sc.K, sc.R, sc.C, nbs, **opts)
+    orc = po.fuse_depth_maps(deps, nrms, cnfs, sc.bgr, sc.K, sc.R, sc.C, nbs, order=order, **opts)
+    _same(ref, orc, "fuse %s" % opts)
+    assert ref["nPoints"] > 1000 or opts.get("nMinViewsFuse", 2) > 5
+
+
+def test_fuse_with_missing_maps_confidences_and_uneven_neighbour_lists(scenes):
+    sc = scenes[1]
+    deps, nrms, cnfs = fc.make_maps(sc, 5)
+    deps = list(deps); deps[3] = None                                       # an image without a depth map (DepthData::IsValid false)
+    r = np.random.RandomState(2)
+    nbs = [list(sc.neighbors[v])[:r.randint(2, 9)] for v in range(sc.n_views)]   # different connection scores: the reference's sort decides the order
+    ref, order = pr.ref_fuse_depth_maps(deps, nrms, None, sc.bgr, sc.K, sc.R, sc.C, nbs)
+    assert 3 not in order and len(order) == sc.n_views - 1
+    orc = po.fuse_depth_maps(deps, nrms, None, sc.bgr, sc.K, sc.R, sc.C, nbs, order=order)
+    _same(ref, orc, "missing map, no confidences")
+    # the order itself: decreasing neighbour count
+    counts = [len(nbs[i]) for i in order]
+    assert counts == sorted(counts, reverse=True)
+
+
+def test_merge_is_the_reference_function(scenes):
+    sc = scenes[0]
+    deps, nrms, cnfs = fc.make_maps(sc, 7)
+    nbs = [list(sc.neighbors[v]) for v in range(sc.n_views)]
+    for kw in (dict(), dict(bEstimateColor=False), dict(bEstimateNormal=False)):
+        ref, _ = pr.ref_fuse_depth_maps(deps, nrms, cnfs, sc.bgr, sc.K, sc.R, sc.C, nbs, nMinViewsFuse=1, **kw)
+        orc = po.fuse_depth_maps(deps, nrms, cnfs, sc.bgr, sc.K, sc.R, sc.C, nbs, nMinViewsFuse=1, **kw)
+        ref = dict(ref); orc = dict(orc); ref["weights"] = None; orc["weights"] = None      # MergeDepthMaps stores no weights
+        _same(ref, orc, "merge %s" % kw)

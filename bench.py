@@ -104,12 +104,23 @@ def main():
     K, R, Cc, nbr, dmin, dmax, diameter = meta
     torch.cuda.synchronize()
 
+    # ---- this rank's part of the scene: its block of reference views and the foreign views they read, in a compact scene of local slots (own block first) ----
+    from openmvs_amd.distributed import needed_views
+    nbr_lists = [[int(x) for x in nbr[i]] for i in range(V)]
+    mine_chk, foreign = needed_views(nbr_lists, V, world, rank)
+    assert mine_chk == mine
+    held = mine + foreign                                   # global view ids in slot order
+    slot = {g: i for i, g in enumerate(held)}
     eng = PatchMatchHIP(local)
     eng.Init(True)
-    eng.scene_create(V, W, H, 2)
-    for i in range(V):
-        eng.scene_set_view(i, None, K[i], R[i], Cc[i], float(dmin[i]), float(dmax[i]), nbr[i])
-    eng.scene_copy(0, 0, V, gray.data_ptr(), True)
+    eng.scene_create(max(2, len(held)), W, H, 2)
+    for i, g in enumerate(held):
+        eng.scene_set_view(i, None, K[g], R[g], Cc[g], float(dmin[g]), float(dmax[g]), [slot[n] for n in nbr_lists[g]] if i < len(mine) else [])
+        eng.scene_set_view_id(i, g)                         # random numbers by the view's index in the whole scene: the maps do not depend on the split
+    if mine:
+        eng.scene_copy(0, 0, len(mine), gray[mine[0]:mine[-1] + 1].data_ptr(), True)
+    for g in foreign:
+        eng.scene_copy(0, slot[g], 1, gray[g].data_ptr(), True)
     eng.sync()
     del gray
     torch.cuda.empty_cache()
@@ -117,47 +128,52 @@ def main():
     B = a.batch if a.batch > 0 else max(1, len(mine))
 
     class EngineEstimator:
-        """Adapter between the sharding driver (openmvs_amd/distributed.py, also exercised under gloo
-        in tests/test_distributed.py) and the HBM-resident scene interface of the HIP engine."""
+        """Adapter between the sharding driver (openmvs_amd/distributed.py, also exercised under gloo in tests/test_distributed.py) and the HBM-resident scene
+        interface of the HIP engine.  View ids are the scene's; the engine sees local slots."""
 
         def __init__(self):
             self.buf = torch.empty((max(1, len(mine)), H, W), dtype=torch.float32, device=dev)
 
         def reset(self, ids):
             for v in ids:
-                eng.scene_reset_view(v)
+                eng.scene_reset_view(slot[v])
 
         def estimate(self, ids, geo):
-            for i in range(0, len(ids), B):
-                eng.scene_estimate(ids[i:i + B], geo, p, sync=False)
+            s = [slot[v] for v in ids]
+            for i in range(0, len(s), B):
+                eng.scene_estimate(s[i:i + B], geo, p, sync=False)
 
         def local_maps(self, ids, what):
             buf = self.buf[:len(ids)]
             if len(ids):
-                eng.scene_copy({"depth": 1, "conf": 3}[what], ids[0], len(ids), buf.data_ptr(), False)
+                assert list(ids) == mine
+                eng.scene_copy({"depth": 1, "conf": 3}[what], 0, len(ids), buf.data_ptr(), False)
             eng.sync()
             return buf
 
         def local_depths(self, ids):
             return self.local_maps(ids, "depth")
 
-        def set_snapshot(self, allv):
-            # previous-round depth maps of all views become visible to this rank (the reference writes
-            # depthNNNN.dmap and re-reads the neighbours' files, SceneDensify.cpp:378-393,1943-1950)
+        def set_snapshot_views(self, own_ids, own, foreign_ids, foreign_maps):
+            # previous-round depth maps become visible to the next round (the reference writes depthNNNN.dmap and re-reads the neighbours' files,
+            # SceneDensify.cpp:378-393,1943-1950): this rank's own maps by a device copy, the foreign ones from the exchange
+            eng.scene_commit_round()
             torch.cuda.synchronize()
-            eng.scene_copy(4, 0, V, allv.data_ptr(), True)
-            eng.sync()                                   # the gathered tensor may be released by the caller
+            for k, g in enumerate(foreign_ids):
+                eng.scene_copy(4, slot[g], 1, foreign_maps[k].data_ptr(), True)
+            eng.sync()                                   # the received tensor may be released by the caller
 
-        def set_maps(self, what, allv):
+        def set_maps_views(self, what, foreign_ids, foreign_maps):
             torch.cuda.synchronize()
-            eng.scene_copy({"depth": 1, "conf": 3}[what], 0, V, allv.data_ptr(), True)
+            for k, g in enumerate(foreign_ids):
+                eng.scene_copy({"depth": 1, "conf": 3}[what], slot[g], 1, foreign_maps[k].data_ptr(), True)
             eng.sync()
 
         def filter(self, ids):
             if len(ids):
-                eng.scene_filter(ids, True, 2, 1, 0.01, commit=True)
+                eng.scene_filter([slot[v] for v in ids], True, 2, 1, 0.01, commit=True)
 
-    drv = ShardedDensifier(EngineEstimator(), V, world, rank, geo_iters=a.geo_iters)
+    drv = ShardedDensifier(EngineEstimator(), V, world, rank, geo_iters=a.geo_iters, neighbors=nbr_lists)
     assert drv.mine == mine
 
     def step():
@@ -179,6 +195,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    own_dt = dt
     st = eng.stats_get()
     eng.stats_reset(False)
     if dist_on:
@@ -186,6 +203,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     mpix = V * W * H * a.steps / dt / 1e6
+    mine_info = {"rank": rank, "views_per_gpu": len(mine), "foreign_views_held": len(foreign), "kernel": sweep_kernel_name(len(mine) if not a.batch else min(a.batch, len(mine)), N),
+                 "exchange_ms_per_step": round(1e3 * drv.exchange_seconds / max(1, a.steps + a.warmup), 2), "seconds": round(own_dt, 3)}
+    ranks_info = [mine_info]
+    if dist_on:
+        box = [None] * world
+        dist.all_gather_object(box, mine_info)
+        ranks_info = box
 
     out = None
     if rank == 0:
@@ -198,18 +222,7 @@ def main():
         device = st.sweepBytes / 1e9 / max(wall_s, 1e-12)
         per_launch = st.sweepBytes / max(1, st.sweepLaunches)
         valu_tf = FLOP_PER_PIXEL * (len(mine) * W * H * a.steps / dt) / 1e12   # this rank's pixels per second x algorithmic flop per pixel
-        # which sweep kernel the engine picks for this rank's batch (pm_engine.hip: PMHIP_DEFAULT_WIDE, PMHIP_LANES4_FROM); the counter measurement behind `traffic` is of pm_sweep2_kernel
-        try:
-            nb = B if B else len(mine)
-            wide_max = int(os.environ.get("PMHIP_WIDE", "64"))
-            if nb <= wide_max and N <= 8:
-                hy = os.environ.get("PMHIP_WIDE_HYPS")
-                hyps = int(hy) if hy in ("8", "4", "2") else (8 if nb <= 2 else 2)
-                kern = "pm_sweep_wide_kernel" if hyps == 8 else "pm_sweep_widen_kernel<%d>" % hyps
-            else:
-                kern = "pm_sweep2_kernel"
-        except Exception:                                              # (naming only: never a reason for the line to fail)
-            kern = "pm_sweep2_kernel"
+        kern = sweep_kernel_name(B if B else len(mine), N)
         tf = traffic_fields(per_launch) if kern == "pm_sweep2_kernel" else {"traffic": None, "traffic_note": "no counter passes of %s yet (the committed ones are of pm_sweep2_kernel)" % kern}
         out = {
             "metric": "Mpix/s depth-map output at 1920x1080 N-view", "value": round(mpix, 3), "unit": "Mpix/s",
@@ -218,7 +231,8 @@ def main():
             "config": {"workload": "%d-view %dx%d synthetic scene, %d source views per reference view, PatchMatch photometric pass "
                                    "(3-level pyramid x 3 sweeps) + %d geometric rounds%s, all depth maps"
                                    % (V, W, H, N, a.geo_iters, " + cross-view filter" if a.with_filter else ""),
-                       "views_total": V, "views_per_gpu": len(mine), "batch": B, "parallelism": "reference views sharded over %d GPU(s)" % world},
+                       "views_total": V, "views_per_gpu": len(mine), "batch": B, "parallelism": "reference views sharded over %d GPU(s)" % world,
+                       "exchange": "neighbour-only point-to-point (a rank holds its block and the %d foreign views it reads)" % len(foreign), "ranks": ranks_info},
             "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), **tf,
                          "launches": int(st.sweepLaunches), "avg_launch_us": round(1e3 * st.sweepMs / max(1, st.sweepLaunches), 2),
@@ -244,6 +258,19 @@ def main():
     eng.close()
     if dist_on:
         dist.destroy_process_group()
+
+
+def sweep_kernel_name(n_batch, n_src):
+    """The sweep kernel the engine picks for a batch of n_batch reference views (pm_engine.hip: PMHIP_DEFAULT_WIDE, PMHIP_LANES4_FROM)."""
+    try:
+        wide_max = int(os.environ.get("PMHIP_WIDE", "64"))
+        if n_batch <= wide_max and n_src <= 8:
+            hy = os.environ.get("PMHIP_WIDE_HYPS")
+            hyps = int(hy) if hy in ("8", "4", "2") else (8 if n_batch <= 2 else 2)
+            return "pm_sweep_wide_kernel" if hyps == 8 else "pm_sweep_widen_kernel<%d>" % hyps
+    except Exception:                                              # (naming only: never a reason for the line to fail)
+        pass
+    return "pm_sweep2_kernel"
 
 
 def traffic_fields(algorithmic_bytes_per_launch):

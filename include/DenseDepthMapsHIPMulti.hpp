@@ -4,10 +4,10 @@
 // One process, one pmhip engine and one host thread per device.  Every engine holds the whole scene (images of all views: any view can be a
 // source view) and estimates a contiguous block of reference views; what crosses devices is
 //   (1) ONE broadcast of the image set from the device the caller's images were uploaded to;
-//   (2) an all-gather of the depth maps at each round boundary (the reference reloads the neighbours' depthNNNN.dmap there, SceneDensify.cpp:378-393),
-//       of depth + confidence before the cross-view filter (:2136-2222), and of depth + normal + confidence to the fusing device before FuseDepthMaps
-//       (:1372-1650, sequential over the scene: one device);
-// nothing inside a sweep.  Same call shape as DenseDepthMapsHIP (LoadScene, ComputeDepthMaps, FuseDepthMaps, GetMaps), same results bit for bit:
+//   (2) at each round boundary the depth maps a device READS and does not own -- the source views of its reference views on other devices -- point to point from their
+//       owners (the reference reloads the neighbours' depthNNNN.dmap there, SceneDensify.cpp:378-393); the same for depth + confidence before the cross-view filter
+//       (:2136-2222); depth + normal + confidence of every block to the ONE fusing device before FuseDepthMaps (:1372-1650, sequential over the scene);
+// nothing inside a sweep.  (The Python driver, openmvs_amd/distributed.py, goes one step further and holds only the needed views per rank: a compact scene of local slots.)  Same call shape as DenseDepthMapsHIP (LoadScene, ComputeDepthMaps, FuseDepthMaps, GetMaps), same results bit for bit:
 // a view's maps do not depend on which device estimated them (tests/cpp/dense_multi.cpp).
 //
 // The collectives are a policy:
@@ -42,6 +42,12 @@ struct LocalCopyCollective {
 		for (size_t r = 0; r < bases.size(); ++r) for (size_t d = 0; d < bases.size(); ++d) if (d != r && cnt[r])
 			if (hipMemcpy((char*)bases[d] + off[r], (const char*)bases[r] + off[r], cnt[r], hipMemcpyDeviceToDevice) != hipSuccess) throw std::runtime_error("LocalCopyCollective: copy failed");
 	}
+	// point-to-point copies: every transfer moves `bytes` from device src's buffer to device dst's
+	struct Xfer { int src, dst; const void* from; void* to; size_t bytes; };
+	void Exchange(const std::vector<Xfer>& xs, const std::vector<hipStream_t>& streams) {
+		sync(streams);
+		for (const Xfer& x : xs) if (x.bytes && hipMemcpy(x.to, x.from, x.bytes, hipMemcpyDeviceToDevice) != hipSuccess) throw std::runtime_error("LocalCopyCollective: copy failed");
+	}
 private:
 	static void sync(const std::vector<hipStream_t>& streams) { for (hipStream_t s : streams) hipStreamSynchronize(s); }
 };
@@ -65,6 +71,16 @@ public:
 		ok(ncclGroupStart());
 		for (size_t r = 0; r < devs_.size(); ++r) if (cnt[r])
 			for (size_t d = 0; d < devs_.size(); ++d) { hipSetDevice(devs_[d]); ok(ncclBroadcast((char*)bases[d] + off[r], (char*)bases[d] + off[r], cnt[r], ncclChar, (int)r, comms_[d], streams[d])); }
+		ok(ncclGroupEnd());
+	}
+	typedef LocalCopyCollective::Xfer Xfer;
+	// grouped ncclSend / ncclRecv pairs on the two engines' streams (xGMI is point to point: a transfer uses the link between its two devices and nothing else)
+	void Exchange(const std::vector<Xfer>& xs, const std::vector<hipStream_t>& streams) {
+		ok(ncclGroupStart());
+		for (const Xfer& x : xs) if (x.bytes) {
+			hipSetDevice(devs_[(size_t)x.src]); ok(ncclSend(x.from, x.bytes, ncclChar, x.dst, comms_[(size_t)x.src], streams[(size_t)x.src]));
+			hipSetDevice(devs_[(size_t)x.dst]); ok(ncclRecv(x.to, x.bytes, ncclChar, x.src, comms_[(size_t)x.dst], streams[(size_t)x.dst]));
+		}
 		ok(ncclGroupEnd());
 	}
 private:
@@ -101,6 +117,13 @@ public:
 		const int n = (int)views.size(), D = NumDevices();
 		first_.resize((size_t)D); count_.resize((size_t)D);
 		for (int d = 0; d < D; ++d) ShardRange(n, D, d, first_[(size_t)d], count_[(size_t)d]);
+		// the foreign views every device reads: the source views of its block that another device owns (ascending)
+		needs_.assign((size_t)D, std::vector<int>());
+		for (int d = 0; d < D; ++d) {
+			std::vector<char> mark((size_t)n, 0);
+			for (int i = first_[(size_t)d]; i < first_[(size_t)d] + count_[(size_t)d]; ++i) for (int32_t nb : views[(size_t)i].neighbors) if (nb >= 0 && nb < n && !owns(d, nb)) mark[(size_t)nb] = 1;
+			for (int i = 0; i < n; ++i) if (mark[(size_t)i]) needs_[(size_t)d].push_back(i);
+		}
 		for (int d = 0; d < D; ++d) {
 			pmhip_engine* e = eng_[(size_t)d];
 			check(d, pmhip_init(e, 0));
@@ -134,13 +157,13 @@ public:
 		estimateAll(-1);                                                               // photometric pass, SceneDensify.cpp:1884-1905
 		if (G == 0) postFilterAll();
 		for (unsigned g = 0; g < G; ++g) {                                             // :1906-1953
-			gather(1);                                                                 // (2) every device sees every depth map of the round ...
+			gatherNeighbours(1);                                                       // (2) every device gets the depth maps of the round it reads ...
 			for (int d = 0; d < D; ++d) { check(d, pmhip_scene_commit_round(eng_[(size_t)d])); check(d, pmhip_init(eng_[(size_t)d], 1)); }   // ... as the snapshot the geometric term reads
 			estimateAll((int)g);
 			if (g + 1 == G) postFilterAll();
 		}
 		if (opt_.nOptimize & ADJUST_FILTER) {                                          // :1955-1980, every map against the UNFILTERED maps of its neighbours
-			gather(1); gather(3);
+			gatherNeighbours(1); gatherNeighbours(3);
 			perDevice([&](int d) {
 				check(d, pmhip_scene_filter(eng_[(size_t)d], ids(d).data(), count_[(size_t)d], opt_.bFilterAdjust ? 1 : 0, opt_.nMinViewsFilter, opt_.nMinViewsFilterAdjust, opt_.fDepthDiffThreshold, 1));
 				check(d, pmhip_scene_filter_commit(eng_[(size_t)d]));
@@ -152,7 +175,7 @@ public:
 
 	// FuseDepthMaps is sequential over the scene (images best connected first, claimed pixels carried from image to image): one device, after a gather
 	void FuseDepthMaps(PointCloud& pc) {
-		gather(1); gather(2); gather(3);
+		gatherTo(0, 1); gatherTo(0, 2); gatherTo(0, 3);
 		for (int d = 0; d < NumDevices(); ++d) check(d, pmhip_sync(eng_[(size_t)d]));
 		DenseDepthMapsHIP::FuseOn(eng_[0], views_, opt_, pc);
 	}
@@ -185,7 +208,44 @@ private:
 			if (opt_.nOptimize & FILL_GAPS) check(d, pmhip_scene_gap_interpolation(eng_[(size_t)d], ids(d).data(), count_[(size_t)d], opt_.nIpolGapSize, opt_.fDepthDiffThreshold));
 		});
 	}
-	// all-gather of one per-view array (what: 1 depth, 2 normal, 3 conf) over the owners' blocks
+	// Bytes that crossed devices so far (round boundaries, filter, fusion gather; not the image broadcast)
+public:
+	size_t ExchangedBytes() const { return exchanged_; }
+	const std::vector<int>& ForeignViews(int d) const { return needs_[(size_t)d]; }
+private:
+	// one per-view array (what: 1 depth, 2 normal, 3 conf): every device receives the views it reads from their owners, runs of consecutive views as one transfer
+	void gatherNeighbours(int what) {
+		const size_t per = sizeof(float) * (size_t)w_ * h_ * (what == 2 ? 3 : 1);
+		std::vector<typename Collective::Xfer> xs;
+		for (int d = 0; d < NumDevices(); ++d) {
+			const std::vector<int>& nd = needs_[(size_t)d];
+			for (size_t k = 0; k < nd.size(); ) {
+				const int r = ownerOf(nd[k]); size_t e = k + 1;
+				while (e < nd.size() && nd[e] == nd[e - 1] + 1 && ownerOf(nd[e]) == r) ++e;
+				typename Collective::Xfer x; x.src = r; x.dst = d; x.bytes = per * (e - k);
+				x.from = (const char*)pmhip_scene_device_ptr(eng_[(size_t)r], what, 0) + per * (size_t)nd[k];
+				x.to = (char*)pmhip_scene_device_ptr(eng_[(size_t)d], what, 0) + per * (size_t)nd[k];
+				xs.push_back(x); exchanged_ += x.bytes; k = e;
+			}
+		}
+		coll_->Exchange(xs, streams());
+		if (what == 1) for (int d = 0; d < NumDevices(); ++d) check(d, pmhip_scene_maps_updated(eng_[(size_t)d], 0, (int)views_.size()));
+	}
+	// every block of one per-view array to ONE device (the fusing one)
+	void gatherTo(int root, int what) {
+		const size_t per = sizeof(float) * (size_t)w_ * h_ * (what == 2 ? 3 : 1);
+		std::vector<typename Collective::Xfer> xs;
+		for (int r = 0; r < NumDevices(); ++r) if (r != root && count_[(size_t)r]) {
+			typename Collective::Xfer x; x.src = r; x.dst = root; x.bytes = per * (size_t)count_[(size_t)r];
+			x.from = (const char*)pmhip_scene_device_ptr(eng_[(size_t)r], what, 0) + per * (size_t)first_[(size_t)r];
+			x.to = (char*)pmhip_scene_device_ptr(eng_[(size_t)root], what, 0) + per * (size_t)first_[(size_t)r];
+			xs.push_back(x); exchanged_ += x.bytes;
+		}
+		coll_->Exchange(xs, streams());
+		if (what == 1) check(root, pmhip_scene_maps_updated(eng_[(size_t)root], 0, (int)views_.size()));
+	}
+	int ownerOf(int i) const { for (int d = 0; d < NumDevices(); ++d) if (owns(d, i)) return d; return 0; }
+	// all-gather of one per-view array over the owners' blocks (kept for callers that want every map everywhere)
 	void gather(int what) {
 		const size_t per = sizeof(float) * (size_t)w_ * h_ * (what == 2 ? 3 : 1);
 		std::vector<void*> bases; std::vector<size_t> off, cnt;
@@ -204,6 +264,8 @@ private:
 	Options opt_;
 	std::vector<View> views_;
 	std::vector<int> first_, count_;
+	std::vector<std::vector<int>> needs_;
+	size_t exchanged_ = 0;
 };
 
 #ifdef PMHIP_WITH_RCCL

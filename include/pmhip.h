@@ -114,6 +114,10 @@ int pmhip_scene_create(pmhip_engine* e, int nImages, int w, int h, int nLevels);
 int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevice,
                          const double K[9], const double R[9], const double C[3],
                          float dMin, float dMax, const int32_t* neighbors, int nNeighbors);
+/* The identity under which slot idx draws its random numbers (the Philox key of a view is derived from it; default: idx).  A process that holds only PART of a scene
+ * -- a rank of the multi-GPU driver keeps its block of reference views and their neighbours in a compact scene of local slots -- gives every slot the view's index in
+ * the whole scene, so that the depth maps do not depend on how the scene was split (openmvs_amd/distributed.py; the reference seeds per estimator, DepthMap.cpp:370-372). */
+int pmhip_scene_set_view_id(pmhip_engine* e, int idx, uint32_t viewID);
 /* The same for a view whose image has its own size w x h (another camera, or a neighbour rescaled by ViewData::ScaleImage): it keeps its own
  * pyramid and can serve as a SOURCE view of any reference view; estimating it (as a reference view) returns PMHIP_E_SIZE -- reference views
  * share the scene's size, use one scene per size class.  gray is required. */

@@ -667,6 +667,11 @@ int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevi
 }
 
 int pmhip_scene_images_updated(pmhip_engine* e) { if (!e) return PMHIP_E_ARG; e->pyramidDirty = true; return 0; }
+int pmhip_scene_set_view_id(pmhip_engine* e, int idx, uint32_t viewID) {
+	if (!e || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
+	e->views[idx].id = viewID;
+	return 0;
+}
 int pmhip_scene_maps_updated(pmhip_engine* e, int firstIdx, int count) {
 	if (!e || firstIdx < 0 || count < 0 || firstIdx + count > e->nImages) return PMHIP_E_ARG;
 	for (int i = firstIdx; i < firstIdx + count; ++i) e->views[i].hasMaps = true;

@@ -2,13 +2,21 @@
 
 The path shards by reference view (each depth map depends only on read-only images and on the
 *previous round's* depth maps of its neighbours, SceneDensify.cpp:378-393), so there is no
-per-iteration collective: one broadcast of the image set at start-up and one all-gather of the
-depth maps at each round boundary (what the reference does through depthNNNN.dmap files,
+per-iteration collective: one broadcast of the image set at start-up and one exchange of depth
+maps at each round boundary (what the reference does through depthNNNN.dmap files,
 SceneDensify.cpp:1943-1950).  torch.distributed is plumbing: backend "nccl" is RCCL over xGMI on
 the GPU box, "gloo" in the CPU tests.
 
-`ShardedDensifier` is backend-agnostic: it drives any estimator object with the four methods used
-below (the HIP engine adapter in bench.py, or a CPU stand-in in tests/test_distributed.py).
+Two exchange modes:
+  * all-gather (neighbors=None): every rank ends up with the maps of ALL views -- simple, and right while the
+    whole scene fits every GPU;
+  * neighbour-only (neighbors given): a rank receives only the maps of the views its block reads -- the source
+    views of its reference views that live on other ranks -- by point-to-point messages, and need not hold
+    anything else of the scene (`needed_views`): BASELINE config 5's 300 x 4K scene is ~46 GB per rank this
+    way instead of ~140 GB.
+
+`ShardedDensifier` is backend-agnostic: it drives any estimator object with the methods listed in its
+docstring (the HIP engine adapter in bench.py, or a CPU stand-in in tests/test_distributed.py).
 """
 from __future__ import annotations
 
@@ -25,9 +33,27 @@ def shard_range(n_views: int, world: int, rank: int) -> range:
     return range(lo, lo + base + (1 if rank < rem else 0))
 
 
+def owner_of(view: int, n_views: int, world: int) -> int:
+    base, rem = divmod(n_views, world)
+    cut = rem * (base + 1)
+    return view // (base + 1) if view < cut else rem + (view - cut) // max(base, 1)
+
+
+def needed_views(neighbors, n_views: int, world: int, rank: int):
+    """(mine, foreign): this rank's block, and the views of other ranks that its reference views read as sources (sorted).  mine + foreign is all a rank has to hold."""
+    mine = list(shard_range(n_views, world, rank))
+    own = set(mine)
+    foreign = sorted({int(n) for v in mine for n in neighbors[v]} - own)
+    return mine, foreign
+
+
+def _collectives_on(world: int) -> bool:
+    return world > 1 or (os.environ.get("OPENMVS_AMD_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
+
+
 def all_gather_views(mine: torch.Tensor, n_views: int, world: int, rank: int) -> torch.Tensor:
     """mine: [len(shard), H, W] depth maps of this rank's block -> [n_views, H, W] on every rank."""
-    if world == 1 and not (os.environ.get("OPENMVS_AMD_FORCE_COLLECTIVES") == "1" and dist.is_initialized()):
+    if not _collectives_on(world):
         return mine
     sizes = [len(shard_range(n_views, world, r)) for r in range(world)]
     if len(set(sizes)) == 1 and dist.get_backend() == "nccl":
@@ -42,6 +68,33 @@ def all_gather_views(mine: torch.Tensor, n_views: int, world: int, rank: int) ->
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], 0)
 
 
+def exchange_neighbour_views(mine_maps: torch.Tensor, neighbors, n_views: int, world: int, rank: int):
+    """Point-to-point exchange of exactly the maps each rank reads: returns (view ids, [len(ids), H, W] tensor) of the FOREIGN views this rank needs, in ascending id.
+    mine_maps: [len(block), H, W] maps of this rank's block, in block order.  Every rank derives the same send / receive lists from `neighbors`, so no metadata travels."""
+    mine, foreign = needed_views(neighbors, n_views, world, rank)
+    if not _collectives_on(world):
+        return foreign, mine_maps[:0]
+    lo = mine[0] if mine else 0
+    recv = torch.empty((len(foreign),) + tuple(mine_maps.shape[1:]), dtype=mine_maps.dtype, device=mine_maps.device)
+    ops, keep = [], []
+    for peer in range(world):
+        if peer == rank:
+            continue
+        _, their_foreign = needed_views(neighbors, n_views, world, peer)
+        to_send = [v for v in their_foreign if owner_of(v, n_views, world) == rank]          # ascending: the receiver's order
+        if to_send:
+            buf = mine_maps[[v - lo for v in to_send]].contiguous(); keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, peer))
+        idx = [k for k, v in enumerate(foreign) if owner_of(v, n_views, world) == peer]
+        if idx:
+            # (the views a peer owns are a contiguous id range, so they are a contiguous run of the sorted foreign list)
+            ops.append(dist.P2POp(dist.irecv, recv[idx[0]:idx[-1] + 1], peer))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return foreign, recv
+
+
 class ShardedDensifier:
     """Photometric pass + `geo_iters` geometric rounds over this rank's block of views.
 
@@ -54,14 +107,27 @@ class ShardedDensifier:
       local_maps(view_ids, "depth"|"conf") -> Tensor   -- [len(ids), H, W] current maps of these views
       set_maps("depth"|"conf", all: Tensor)            -- install the maps of ALL views (the neighbours' unfiltered maps the filter reads)
       filter(view_ids)                                 -- DepthMapsData::FilterDepthMap for these views, results installed
+    With `neighbors` (neighbour-only exchange) instead of the two "ALL views" methods:
+      set_snapshot_views(own_ids, own: Tensor, foreign_ids, foreign: Tensor)   -- previous-round depth maps of this rank's block and of the foreign views it reads
+      set_maps_views(what, foreign_ids, foreign: Tensor)                        -- the foreign neighbours' unfiltered maps for the filter (its own are in place)
     """
 
-    def __init__(self, estimator, n_views: int, world: int = 1, rank: int = 0, geo_iters: int = 2):
+    def __init__(self, estimator, n_views: int, world: int = 1, rank: int = 0, geo_iters: int = 2, neighbors=None):
         self.est, self.n_views, self.world, self.rank, self.geo_iters = estimator, n_views, world, rank, geo_iters
         self.mine = list(shard_range(n_views, world, rank))
+        self.neighbors = neighbors
+        self.exchange_seconds = 0.0
 
     def exchange(self):
-        self.est.set_snapshot(all_gather_views(self.est.local_depths(self.mine), self.n_views, self.world, self.rank))
+        import time
+        t = time.perf_counter()
+        own = self.est.local_depths(self.mine)
+        if self.neighbors is None:
+            self.est.set_snapshot(all_gather_views(own, self.n_views, self.world, self.rank))
+        else:
+            ids, maps = exchange_neighbour_views(own, self.neighbors, self.n_views, self.world, self.rank)
+            self.est.set_snapshot_views(self.mine, own, ids, maps)
+        self.exchange_seconds += time.perf_counter() - t
 
     def run(self):
         self.est.reset(self.mine)
@@ -73,9 +139,14 @@ class ShardedDensifier:
     def filter(self):
         """Scene::DenseReconstructionFilter (SceneDensify.cpp:2136-2222) sharded by view: every rank filters its own depth maps against the UNFILTERED
         depth and confidence maps of their neighbours (the reference writes *.filtered.dmap files and renames them only when all are done), so one
-        all-gather of depth and one of confidence precede the filter; the filtered maps stay with their owner (gather them with `gather("depth")`)."""
+        exchange of depth and one of confidence precede the filter; the filtered maps stay with their owner (gather them with `gather("depth")`)."""
         for what in ("depth", "conf"):
-            self.est.set_maps(what, all_gather_views(self.est.local_maps(self.mine, what), self.n_views, self.world, self.rank))
+            own = self.est.local_maps(self.mine, what)
+            if self.neighbors is None:
+                self.est.set_maps(what, all_gather_views(own, self.n_views, self.world, self.rank))
+            else:
+                ids, maps = exchange_neighbour_views(own, self.neighbors, self.n_views, self.world, self.rank)
+                self.est.set_maps_views(what, ids, maps)
         self.est.filter(self.mine)
 
     def gather(self, what):

@@ -51,7 +51,7 @@ class PMHipFuseParams(C.Structure):
                 ("bEstimateColor", C.c_int32), ("bEstimateNormal", C.c_int32)]
 
 
-EXPORTS = ["pmhip_scene_set_view_sized", "pmhip_scene_set_source_depth", "pmhip_scene_set_mask", "pmhip_scene_set_mask_mode", "pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
+EXPORTS = ["pmhip_scene_set_view_id", "pmhip_scene_set_view_sized", "pmhip_scene_set_source_depth", "pmhip_scene_set_mask", "pmhip_scene_set_mask_mode", "pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
            "pmhip_estimate_depth_map", "pmhip_estimate_depth_map_masked", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
            "pmhip_scene_estimate", "pmhip_scene_commit_round", "pmhip_scene_reset_view", "pmhip_scene_set_maps",
            "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_remove_small_segments", "pmhip_scene_images_updated", "pmhip_scene_maps_updated", "pmhip_sync",
@@ -184,6 +184,10 @@ class PatchMatchHIP:
             g = np.ascontiguousarray(gray, np.float32); src, ondev = _fp(g), 0
         self._chk(self._lib.pmhip_scene_set_view(self._h, idx, src, ondev, dp(K), dp(R), dp(Cc), C.c_float(dmin), C.c_float(dmax),
                                                  nb.ctypes.data_as(C.POINTER(C.c_int32)), len(nb)))
+
+    def scene_set_view_id(self, idx, view_id):
+        """The identity slot idx draws its random numbers under (pmhip_scene_set_view_id): the view's index in the whole scene when this engine holds a part of it."""
+        self._chk(self._lib.pmhip_scene_set_view_id(self._h, int(idx), C.c_uint32(int(view_id))))
 
     def scene_load(self, scene, n_levels=2):
         """Upload a synth.Scene (or anything with the same attributes)."""

@@ -27,11 +27,14 @@ class OracleEstimator:
         for v in ids:
             self.depth[v] = 0; self.normal[v] = 0; self.conf[v] = 0
 
+    own = ()
+
     def estimate(self, ids, geo):
         po, sc = self.po, self.sc
+        self.own = list(ids)
         for v in ids:
             vid = [v] + list(sc.neighbors[v])
-            src = None if geo < 0 else {i: self.snap[i] for i in range(sc.n_views)}
+            src = None if geo < 0 else {i: self.snap[i] for i in vid[1:]}
             views, keep = po.make_views(sc.gray, sc.K, sc.R, sc.C, vid, depth_maps=src)
             opt = po.default_opt(seed=SEED, viewID=v, nSubResolutionLevels=1)
             self.depth[v], self.normal[v], self.conf[v] = po.estimate_depth_map(views, len(vid), float(sc.dmin[v]), float(sc.dmax[v]), opt, geo_iter=geo,
@@ -42,6 +45,22 @@ class OracleEstimator:
 
     def set_snapshot(self, allv):
         self.snap = allv.numpy().copy()
+
+    # neighbour-only exchange: only the rank's own block and the foreign views it reads arrive; everything else is poisoned, so a read of it would show
+    def set_snapshot_views(self, own_ids, own, foreign_ids, foreign):
+        self.snap = np.full_like(self.depth, np.nan)
+        self.snap[list(own_ids)] = own.numpy()
+        if len(foreign_ids):
+            self.snap[list(foreign_ids)] = foreign.numpy()
+
+    def set_maps_views(self, what, foreign_ids, foreign):
+        a = {"depth": self.depth, "conf": self.conf}[what]
+        keep = set(self.own) | set(int(v) for v in foreign_ids)
+        for v in range(self.sc.n_views):
+            if v not in keep:
+                a[v] = np.nan
+        if len(foreign_ids):
+            a[list(foreign_ids)] = foreign.numpy()
 
     # config 5's exchange: the cross-view filter reads the neighbours' unfiltered depth and confidence maps
     def local_maps(self, ids, what):
@@ -63,12 +82,12 @@ def _scene():
     return synth.make_scene(5, 48, 32, n_src=3)     # 5 views on 2 ranks: blocks of 3 and 2, the padded all-gather path of unequal shards (100 views / 8 GPUs)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, neighbour_only=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = _scene()
     est = OracleEstimator(sc)
-    drv = ShardedDensifier(est, sc.n_views, world, rank, geo_iters=2)
+    drv = ShardedDensifier(est, sc.n_views, world, rank, geo_iters=2, neighbors=[list(sc.neighbors[v]) for v in range(sc.n_views)] if neighbour_only else None)
     drv.run()
     final = all_gather_views(est.local_depths(drv.mine), sc.n_views, world, rank)
     # the estimator finalises confidences like EndDepthMapTmp only inside the engine; here give the filter something to weigh
@@ -80,6 +99,39 @@ def _worker(rank, world, port, out_dir):
         np.save(os.path.join(out_dir, "sharded.npy"), final.numpy())
         np.save(os.path.join(out_dir, "filtered_depth.npy"), fd.numpy()); np.save(os.path.join(out_dir, "filtered_conf.npy"), fc.numpy())
     dist.destroy_process_group()
+
+
+def _single_process_reference():
+    sc = _scene()
+    est = OracleEstimator(sc)
+    drv = ShardedDensifier(est, sc.n_views, 1, 0, geo_iters=2)
+    drv.run()
+    final = est.depth.copy()
+    for v in drv.mine:
+        est.conf[v] = np.where(est.depth[v] > 0, np.float32(1) - np.minimum(est.conf[v], np.float32(0.9)), np.float32(0)).astype(np.float32)
+    drv.filter()
+    return final, est.depth.copy(), est.conf.copy()
+
+
+def test_neighbour_only_exchange_matches_single_process(tmp_path):
+    """The point-to-point exchange of exactly the maps each rank reads (distributed.exchange_neighbour_views), on 2 ranks (blocks of 3 and 2 views) and on 3 ranks
+    (2, 2 and 1: uneven, one rank owning a single view): the same bits as one process, with every map a rank does not need poisoned."""
+    from openmvs_amd.distributed import needed_views, owner_of
+    sc = _scene()
+    nbs = [list(sc.neighbors[v]) for v in range(sc.n_views)]
+    for world in (2, 3):
+        for r in range(world):
+            mine, foreign = needed_views(nbs, sc.n_views, world, r)
+            assert mine == list(shard_range(sc.n_views, world, r)) and not set(mine) & set(foreign)
+            assert all(owner_of(v, sc.n_views, world) != r for v in foreign)
+    final, fd, fc = _single_process_reference()
+    for world in (2, 3):
+        out = tmp_path / ("w%d" % world); out.mkdir()
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+        mp.spawn(_worker, args=(world, port, str(out), True), nprocs=world, join=True)
+        assert np.array_equal(np.load(out / "sharded.npy"), final), "world %d" % world
+        assert np.array_equal(np.load(out / "filtered_depth.npy"), fd) and np.array_equal(np.load(out / "filtered_conf.npy"), fc), "world %d filter" % world
 
 
 def test_shard_ranges_cover_everything():

@@ -225,6 +225,19 @@ typedef struct PMHipKernelStats {
 int pmhip_stats_reset(pmhip_engine* e, int enableEvents);
 int pmhip_stats_get(pmhip_engine* e, PMHipKernelStats* out);
 
+/* How the engine maps a batch onto the GPU -- never WHAT it computes: every setting gives the same bits.  pmhip_create fills the defaults (the measured choices of
+ * csrc/pm_engine.hip); 0 in a field of pmhip_set_tuning keeps the current value.  (The PMHIP_* environment variables of earlier rounds still seed the defaults at
+ * pmhip_create, for experiments; a host program uses these two calls.) */
+typedef struct PMHipTuning {
+	int32_t viewGroups;      /* view groups of a batch that sweep on their own streams (2) */
+	int32_t wideMaxViews;    /* batches of at most this many reference views use the speculative sweep kernels (64); -1 = never */
+	int32_t wideHyps;        /* hypotheses per round of the speculative kernel: 8, 4 or 2; -1 = by batch size (8 for one or two views, else 2) */
+	int32_t sweepLanes;      /* lanes per pixel of pm_sweep2_kernel: 4, 8 or 16; -1 = by batch size */
+	int32_t quadBuffer;      /* 1: tap rows address the level's quad images as one buffer, 2: through each view's pointer */
+} PMHipTuning;
+int pmhip_get_tuning(pmhip_engine* e, PMHipTuning* out);
+int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t);
+
 /* ---- 3. self-test hooks (used by tests/, no oracle involved) ------------------------------ */
 /* Evaluate csrc/pm_math.h on the device: kind 0 exp, 1 acos, 2 atan2(a,b), 3 sin, 4 cos, 5 sqrt, 6 a/b, 7 (float)sqrt((double)a*a+(double)b*b). */
 int pmhip_math_eval(pmhip_engine* e, int kind, const float* a, const float* b, float* out, size_t n);

@@ -667,6 +667,29 @@ int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevi
 }
 
 int pmhip_scene_images_updated(pmhip_engine* e) { if (!e) return PMHIP_E_ARG; e->pyramidDirty = true; return 0; }
+int pmhip_get_tuning(pmhip_engine* e, PMHipTuning* out) {
+	if (!e || !out) return PMHIP_E_ARG;
+	out->viewGroups = e->nGroups; out->wideMaxViews = e->wideMaxViews > 0 ? e->wideMaxViews : -1; out->wideHyps = e->wideHyps > 0 ? e->wideHyps : -1;
+	out->sweepLanes = e->sweepLanes > 0 ? e->sweepLanes : -1; out->quadBuffer = e->quadBuffer ? 1 : 2;
+	return 0;
+}
+int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t) {
+	if (!e || !t) return PMHIP_E_ARG;
+	if (t->viewGroups < 0 || t->viewGroups > 16 || (t->wideHyps > 0 && t->wideHyps != 8 && t->wideHyps != 4 && t->wideHyps != 2) ||
+	    (t->sweepLanes > 0 && t->sweepLanes != 4 && t->sweepLanes != 8 && t->sweepLanes != 16) || t->quadBuffer < 0 || t->quadBuffer > 2) { e->err = "pmhip_set_tuning: value out of range"; return PMHIP_E_ARG; }
+	HIPCHK(e, hipSetDevice(e->device));
+	if (t->viewGroups > 0) {
+		for (int g = e->nGroups; g < t->viewGroups; ++g) if (!e->gstream[g]) {   // streams of the additional view groups
+			if (hipStreamCreateWithFlags(&e->gstream[g], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->joinEv[g], hipEventDisableTiming) != hipSuccess) { e->err = "pmhip_set_tuning: stream"; return PMHIP_E_HIP; }
+		}
+		e->nGroups = t->viewGroups;
+	}
+	if (t->wideMaxViews != 0) e->wideMaxViews = t->wideMaxViews < 0 ? 0 : t->wideMaxViews;
+	if (t->wideHyps != 0) e->wideHyps = t->wideHyps < 0 ? 0 : t->wideHyps;
+	if (t->sweepLanes != 0) e->sweepLanes = t->sweepLanes < 0 ? 0 : t->sweepLanes;
+	if (t->quadBuffer != 0) e->quadBuffer = t->quadBuffer == 1;
+	return 0;
+}
 int pmhip_scene_set_view_id(pmhip_engine* e, int idx, uint32_t viewID) {
 	if (!e || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
 	e->views[idx].id = viewID;

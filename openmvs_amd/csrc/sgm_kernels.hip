@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256) void sgm_sum_wta_kernel(const SGMPixel* __rest
 	if (have) px = pixels[pix];
 	const int nD = px.maxDisp - px.minDisp;
 	unsigned key = 0xFFFFFFFFu;
-	const bool aligned = (px.idx & 3ull) == 0ull;
+	const bool aligned = (px.idx & 3ull) == 0ull && (numCosts & 3ull) == 0ull;   // the per-direction delta volumes start numCosts apart: dword loads only when that keeps them aligned
 	for (int k = kk * 4; k < nD; k += 64) {
 		unsigned s[4];
 		const int n = min(4, nD - k);

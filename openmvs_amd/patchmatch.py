@@ -51,7 +51,11 @@ class PMHipFuseParams(C.Structure):
                 ("bEstimateColor", C.c_int32), ("bEstimateNormal", C.c_int32)]
 
 
-EXPORTS = ["pmhip_scene_set_view_id", "pmhip_scene_set_view_sized", "pmhip_scene_set_source_depth", "pmhip_scene_set_mask", "pmhip_scene_set_mask_mode", "pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
+class PMHipTuning(C.Structure):
+    _fields_ = [("viewGroups", C.c_int32), ("wideMaxViews", C.c_int32), ("wideHyps", C.c_int32), ("sweepLanes", C.c_int32), ("quadBuffer", C.c_int32)]
+
+
+EXPORTS = ["pmhip_get_tuning", "pmhip_set_tuning", "pmhip_scene_set_view_id", "pmhip_scene_set_view_sized", "pmhip_scene_set_source_depth", "pmhip_scene_set_mask", "pmhip_scene_set_mask_mode", "pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
            "pmhip_estimate_depth_map", "pmhip_estimate_depth_map_masked", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
            "pmhip_scene_estimate", "pmhip_scene_commit_round", "pmhip_scene_reset_view", "pmhip_scene_set_maps",
            "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_remove_small_segments", "pmhip_scene_images_updated", "pmhip_scene_maps_updated", "pmhip_sync",
@@ -184,6 +188,17 @@ class PatchMatchHIP:
             g = np.ascontiguousarray(gray, np.float32); src, ondev = _fp(g), 0
         self._chk(self._lib.pmhip_scene_set_view(self._h, idx, src, ondev, dp(K), dp(R), dp(Cc), C.c_float(dmin), C.c_float(dmax),
                                                  nb.ctypes.data_as(C.POINTER(C.c_int32)), len(nb)))
+
+    def tuning(self, **kw):
+        """pmhip_get_tuning / pmhip_set_tuning: how a batch is mapped onto the GPU (viewGroups, wideMaxViews, wideHyps, sweepLanes, quadBuffer); returns the settings
+        in force as a dict.  The results never depend on them."""
+        t = PMHipTuning()
+        if kw:
+            for k, v in kw.items():
+                setattr(t, k, int(v))
+            self._chk(self._lib.pmhip_set_tuning(self._h, C.byref(t)))
+        self._chk(self._lib.pmhip_get_tuning(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in PMHipTuning._fields_}
 
     def scene_set_view_id(self, idx, view_id):
         """The identity slot idx draws its random numbers under (pmhip_scene_set_view_id): the view's index in the whole scene when this engine holds a part of it."""

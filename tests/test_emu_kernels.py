@@ -79,6 +79,11 @@ def test_estimator_sweep_kernel_variants(pm_emulated, nine_scene, small_scene, v
     g.test_sweep_kernel_variants_parity(nine_scene, small_scene, variant, quick=True)
 
 
+def test_estimator_tuning_through_the_abi(pm_emulated, nine_scene):
+    from tests import test_gpu_patchmatch as g
+    g.test_tuning_through_the_abi(nine_scene)
+
+
 def test_estimator_wide_latency_mode(pm_emulated, nine_scene, small_scene):
     from tests import test_gpu_patchmatch as g
     g.test_wide_latency_mode_parity(nine_scene, small_scene, quick=True)     # one wave per pixel, eight hypotheses per round (the whole case passes too: 260 s)

@@ -163,6 +163,29 @@ def test_sweep_kernel_variants_parity(nine_scene, small_scene, variant, quick=Fa
                 os.environ[k] = v
 
 
+def test_tuning_through_the_abi(nine_scene):
+    """pmhip_set_tuning (include/pmhip.h): the mapping of a batch onto the GPU is chosen through the C ABI, not through the environment; every setting gives the
+    oracle's bits."""
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    sc = nine_scene
+    od, on, oc = _oracle(sc, 4, 5)
+    e = PatchMatchHIP(0)
+    t0 = e.tuning()
+    assert t0["viewGroups"] >= 1 and t0["quadBuffer"] in (1, 2)
+    for kw in (dict(wideMaxViews=-1, sweepLanes=4), dict(wideMaxViews=-1, sweepLanes=8, viewGroups=3), dict(wideMaxViews=64, wideHyps=2), dict(wideMaxViews=64, wideHyps=8, quadBuffer=2),
+               dict(wideMaxViews=-1, sweepLanes=-1, quadBuffer=1, viewGroups=1)):
+        got = e.tuning(**kw)
+        for k, v in kw.items():
+            assert got[k] == v, (k, got)
+        e.Init(False); e.scene_load(sc, n_levels=2)
+        e.scene_estimate(list(range(sc.n_views)), -1, default_params(seed=5))
+        d, n, c = e.scene_get_maps(4)
+        _same(d, od, "tuning %s: depth" % kw); _same(n, on, "normal"); _same(c, oc, "conf")
+    with pytest.raises(Exception):
+        e.tuning(sweepLanes=5)
+    e.close()
+
+
 def test_wide_latency_mode_parity(nine_scene, small_scene, quick=False, hyps="8"):
     """The one-wave-per-pixel sweep kernel (PMHIP_WIDE: eight hypotheses of a pixel scored side by side, sequential accept rule replayed over them) gives
     the bits of the sequential walk: 8 / 4 / 1-3 sources, pyramid, geometric round, ignore masks, option sets that change the iteration budget

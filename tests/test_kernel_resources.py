@@ -18,9 +18,11 @@ def test_sweep_kernels_keep_their_residency_budget():
     for k, v in sweep2.items():
         assert v["occupancy"] >= 3 and v["vgpr"] <= 168 and v["scratch"] == 0 and v["agpr"] == 0, (k, v)
         assert v["lds"] <= 11264, (k, v)
-    # the speculative kernels: eight-wide (one or two views) and the two- / four-wide template (3-25 views): three waves per SIMD, a few spilled dwords at most
+    # the speculative kernels: eight-wide (one or two views) and the two- / four-wide template (3-64 views): three waves per SIMD; the two-deep tap-row pipeline costs them
+    # a few spilled dwords (measured worth it: 25 views 33.9 -> 37.5 Mpix/s, 13 views 23.6 -> 27.0; the pointer-path instantiations, which only batches with own-size
+    # source views use, spill the most)
     wide = {k: v for k, v in r.items() if "pm_sweep_wide_kernel" in k or "pm_sweep_widen_kernel" in k}
     assert len(wide) == 12
     for k, v in wide.items():
-        assert v["occupancy"] >= 3 and v["vgpr"] <= 168 and v["scratch"] <= 64 and v["lds"] <= 4096, (k, v)
+        assert v["occupancy"] >= 3 and v["vgpr"] <= 168 and v["scratch"] <= 96 and v["lds"] <= 4096, (k, v)
     assert not any("pm_band_kernel" in k or "pm_sweep_kernel" in k for k in r)     # round 3's resident band kernel and round 2's LDS-window kernel are gone

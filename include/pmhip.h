@@ -221,6 +221,7 @@ typedef struct PMHipKernelStats {
 	uint64_t sweepLaunches; double sweepMs; double sweepBytes; uint64_t sweepPixels;
 	uint64_t initLaunches; double initMs;
 	double sweepWallMs; /* wall time of the sweep phases; sweepMs sums the per-stream times of the concurrent view groups */
+	double sweepHostMs; /* host time spent enqueueing the sweep launches (close to sweepWallMs: the host's launch rate, not the GPU, bounds the sweeps) */
 } PMHipKernelStats;
 int pmhip_stats_reset(pmhip_engine* e, int enableEvents);
 int pmhip_stats_get(pmhip_engine* e, PMHipKernelStats* out);
@@ -234,6 +235,9 @@ typedef struct PMHipTuning {
 	int32_t wideHyps;        /* hypotheses per round of the speculative kernel: 8, 4 or 2; -1 = by batch size (8 for one or two views, else 2) */
 	int32_t sweepLanes;      /* lanes per pixel of pm_sweep2_kernel: 4, 8 or 16; -1 = by batch size */
 	int32_t quadBuffer;      /* 1: tap rows address the level's quad images as one buffer, 2: through each view's pointer */
+	int32_t widePixels;      /* larger batches: a diagonal launch of at most this many pixels (diagonal length x views of the group) uses the two-wide speculative kernel; -1 = none */
+	int32_t wide8Pixels;     /* ... and one of at most this many pixels the eight-wide speculative kernel; -1 = none */
+	int32_t launchThreads;   /* host threads enqueueing a sweep's launches: 1 = the caller feeds every group's stream, N = one thread per view group (at most N); -1 = default */
 } PMHipTuning;
 int pmhip_get_tuning(pmhip_engine* e, PMHipTuning* out);
 int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t);

@@ -15,11 +15,24 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
+#ifndef PMHIP_DEFAULT_LAUNCH_THREADS
+#define PMHIP_DEFAULT_LAUNCH_THREADS 1
+#endif
+#ifndef PMHIP_DEFAULT_WIDE_PIXELS
+#define PMHIP_DEFAULT_WIDE_PIXELS 0    // larger batches: diagonal launches of at most this many pixels use the two-wide speculative kernel (0: none)
+#define PMHIP_DEFAULT_WIDE8_PIXELS 0   // ... and of at most this many pixels the eight-wide one
+#endif
 #ifndef PMHIP_DEFAULT_WIDE
 #define PMHIP_DEFAULT_WIDE 64   // batches of at most this many reference views use the speculative kernels: eight hypotheses per round (one wave per pixel) for 1-2 views, two per round
                                 // (four pixels per wave, pm_wide_n.hip) from 3 views on.  Measured in round 4 (profiles/r04_call7_crossover.log, full schedule at 1920x1080, Mpix/s;
@@ -95,6 +108,40 @@ void scaleK(const double* K, int w, int h, int nw, int nh, double* o) {
 
 } // namespace
 
+// Worker threads that enqueue the diagonal launches of view groups 1, 2, ... on their streams while the calling thread enqueues group 0's: a sweep of a small batch is
+// tens of thousands of short launches, and one host thread feeding several streams can be what limits it (tools/probes/launch_rate.hip).
+struct PMLaunchPool {
+	std::vector<std::thread> th;
+	std::mutex m; std::condition_variable cv, cvDone;
+	std::function<void(int)> job; uint64_t gen = 0; int pending = 0; bool stop = false;
+	void ensure(int n, int device) {
+		while ((int)th.size() < n) {
+			const int id = (int)th.size();
+			th.emplace_back([this, id, device] {
+				(void)hipSetDevice(device);
+				uint64_t seen = 0;
+				for (;;) {
+					std::function<void(int)> f;
+					{ std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return stop || (gen != seen && id < nActive); }); if (stop) return; seen = gen; f = job; }
+					f(id + 1);
+					{ std::lock_guard<std::mutex> lk(m); if (--pending == 0) cvDone.notify_all(); }
+				}
+			});
+		}
+	}
+	int nActive = 0;
+	// f(g) for g = 1 .. n-1 on the workers and f(0) on the caller; returns when all are done
+	void run(int n, int device, const std::function<void(int)>& f) {
+		if (n <= 1) { f(0); return; }
+		ensure(n - 1, device);
+		{ std::lock_guard<std::mutex> lk(m); job = f; pending = n - 1; nActive = n - 1; ++gen; }
+		cv.notify_all();
+		f(0);
+		std::unique_lock<std::mutex> lk(m); cvDone.wait(lk, [&] { return pending == 0; });
+	}
+	~PMLaunchPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+};
+
 struct pmhip_engine {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -103,9 +150,13 @@ struct pmhip_engine {
 	int nGroups = 1;
 	int wideHyps = 0;                        // hypotheses per round of the speculative kernel: 0 = by batch size (8 for one or two views, else 2); PMHIP_WIDE_HYPS = 8 / 4 / 2 fixes it
 	int wideMaxViews = PMHIP_DEFAULT_WIDE;   // batches of at most this many views use the one-wave-per-pixel sweep kernel (PMHIP_WIDE)
+	int widePixels = PMHIP_DEFAULT_WIDE_PIXELS;     // in larger batches: a diagonal launch of at most this many pixels (diagonal length x views of the group) uses the two-wide speculative kernel (PMHIP_WIDE_PIXELS)
+	int wide8Pixels = PMHIP_DEFAULT_WIDE8_PIXELS;   // ... and one of at most this many pixels the eight-wide one (PMHIP_WIDE8_PIXELS)
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
 	int quadBuffer = 1;                     // tap rows address the level's quad images as one buffer (entry index); 0 = through each view's own pointer (PMHIP_QUADBUF; forced for
 	                                        // batches that read a source view with its own image size, which lives outside the level's buffer)
+	int launchThreads = PMHIP_DEFAULT_LAUNCH_THREADS;   // host threads that enqueue a sweep's launches: 1 = the caller alone, feeding the groups' streams in turn; N > 1 = one thread per view group (up to N)
+	PMLaunchPool pool;
 	hipStream_t gstream[16] = {};
 	hipEvent_t forkEv = nullptr, joinEv[16] = {};
 	bool inited = false, geom = false;
@@ -379,7 +430,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 	int SG = G, VPL = 1;                             // sweep kernel: (lanes per pixel, views per lane)
 	sweepMapping(maxSrc, e->sweepLanes > 0 ? e->sweepLanes : (nB >= PMHIP_LANES4_FROM && maxSrc > 4 ? 4 : 16), SG, VPL);
 	// latency mode (one wave per pixel, pm_sweep_wide_kernel) for batches too small to fill the GPU with one wave per 64 / G pixels
-	const bool wide = nB <= e->wideMaxViews && maxSrc <= 8;
+	const bool wideBatch = nB <= e->wideMaxViews && maxSrc <= 8;
 	const size_t P0 = (size_t)e->w * e->h;
 	// the staging buffers are reused by the next call: make sure the previous call's copies are done
 	HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -499,22 +550,41 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 				HIPCHK(e, hipEventRecord(e->forkEv, e->stream));
 				for (int g = 0; g < NG; ++g) { HIPCHK(e, hipStreamWaitEvent(e->gstream[g], e->forkEv, 0)); evG[g] = evBeginOn(e, 0, e->gstream[g]); }
 			} else evG[0] = evBeginOn(e, 0, e->stream);
-			for (int k = 0; k <= dHi - dLo; ++k) {
+			// group g's launches of diagonal k; the kernels compute the same bits, so the choice is per launch: the speculative kernels (more lanes per pixel, shorter
+			// dependent chain) for batches and for diagonals too small to fill the GPU with 64 / G pixels per wave
+			std::atomic<bool> allOk{true};
+			auto launchOne = [&](int g, int k) {
 				const int d = dir == 0 ? dLo + k : dHi - k;
 				const int xlo = std::max(PM_HW, d - (lh - 1 - PM_HW));
 				const int xhi = std::min(lw - 1 - PM_HW, d - PM_HW);
 				const int count = xhi - xlo + 1;
-				if (count <= 0) continue;
-				for (int g = 0; g < NG; ++g) {
-					const int s0 = (int)((long)nB * g / NG), s1 = (int)((long)nB * (g + 1) / NG);
-					hipStream_t st = NG > 1 ? e->gstream[g] : e->stream;
-					const int hyps = e->wideHyps > 0 ? e->wideHyps : (nB <= 2 ? 8 : 2);
-					const bool ok = geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass))
-					                    : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass));
-					if (!ok) { e->err = "sweep kernel: (lanes per pixel, views per lane) mapping not instantiated"; return PMHIP_E_ARG; }
-				}
-				if (e->statsOn) e->stats.sweepLaunches += NG;
+				if (count <= 0) return 0;
+				const int s0 = (int)((long)nB * g / NG), s1 = (int)((long)nB * (g + 1) / NG);
+				hipStream_t st = NG > 1 ? e->gstream[g] : e->stream;
+				const long npx = (long)count * (s1 - s0);
+				const bool wide = wideBatch || (maxSrc <= 8 && npx <= e->widePixels);
+				const int hyps = (wideBatch && e->wideHyps > 0) ? e->wideHyps : ((nB <= 2 || npx <= e->wide8Pixels) ? 8 : 2);
+				const bool ok = geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass))
+				                    : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass));
+				if (!ok) allOk = false;
+				return 1;
+			};
+			const auto hostT0 = std::chrono::steady_clock::now();
+			const int nThreads = std::min(NG, std::max(1, e->launchThreads));
+			size_t nLaunched = 0;
+			if (nThreads > 1) {
+				std::atomic<size_t> cnt{0};
+				e->pool.run(nThreads, e->device, [&](int tix) {   // thread tix enqueues groups tix, tix + nThreads, ...
+					size_t c = 0;
+					for (int k = 0; k <= dHi - dLo && allOk; ++k) for (int g = tix; g < NG; g += nThreads) c += launchOne(g, k);
+					cnt += c;
+				});
+				nLaunched = cnt;
+			} else {
+				for (int k = 0; k <= dHi - dLo && allOk; ++k) for (int g = 0; g < NG; ++g) nLaunched += launchOne(g, k);
 			}
+			if (!allOk) { e->err = "sweep kernel: (lanes per pixel, views per lane) mapping not instantiated"; return PMHIP_E_ARG; }
+			if (e->statsOn) { e->stats.sweepLaunches += nLaunched; e->stats.sweepHostMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hostT0).count(); }
 			if (NG > 1) {
 				for (int g = 0; g < NG; ++g) { evEndOn(e, evG[g], e->gstream[g]); HIPCHK(e, hipEventRecord(e->joinEv[g], e->gstream[g])); HIPCHK(e, hipStreamWaitEvent(e->stream, e->joinEv[g], 0)); }
 			} else evEndOn(e, evG[0], e->stream);
@@ -576,6 +646,9 @@ int pmhip_create(int device, pmhip_engine** out) {
 	e->nGroups = ng ? std::max(1, std::min(16, atoi(ng))) : PMHIP_DEFAULT_GROUPS;
 	const char* nw = getenv("PMHIP_WIDE");
 	if (nw) e->wideMaxViews = atoi(nw);
+	const char* lt = getenv("PMHIP_LAUNCH_THREADS"); if (lt && atoi(lt) >= 1) e->launchThreads = std::min(16, atoi(lt));
+	const char* wp = getenv("PMHIP_WIDE_PIXELS"); if (wp) e->widePixels = atoi(wp);
+	const char* w8 = getenv("PMHIP_WIDE8_PIXELS"); if (w8) e->wide8Pixels = atoi(w8);
 	const char* wh = getenv("PMHIP_WIDE_HYPS"); if (wh && (atoi(wh) == 8 || atoi(wh) == 4 || atoi(wh) == 2)) e->wideHyps = atoi(wh);
 	const char* qb = getenv("PMHIP_QUADBUF"); if (qb) e->quadBuffer = atoi(qb) != 0;
 	const char* nl = getenv("PMHIP_LANES");
@@ -671,6 +744,8 @@ int pmhip_get_tuning(pmhip_engine* e, PMHipTuning* out) {
 	if (!e || !out) return PMHIP_E_ARG;
 	out->viewGroups = e->nGroups; out->wideMaxViews = e->wideMaxViews > 0 ? e->wideMaxViews : -1; out->wideHyps = e->wideHyps > 0 ? e->wideHyps : -1;
 	out->sweepLanes = e->sweepLanes > 0 ? e->sweepLanes : -1; out->quadBuffer = e->quadBuffer ? 1 : 2;
+	out->widePixels = e->widePixels > 0 ? e->widePixels : -1; out->wide8Pixels = e->wide8Pixels > 0 ? e->wide8Pixels : -1;
+	out->launchThreads = e->launchThreads;
 	return 0;
 }
 int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t) {
@@ -688,6 +763,9 @@ int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t) {
 	if (t->wideHyps != 0) e->wideHyps = t->wideHyps < 0 ? 0 : t->wideHyps;
 	if (t->sweepLanes != 0) e->sweepLanes = t->sweepLanes < 0 ? 0 : t->sweepLanes;
 	if (t->quadBuffer != 0) e->quadBuffer = t->quadBuffer == 1;
+	if (t->widePixels != 0) e->widePixels = t->widePixels < 0 ? 0 : t->widePixels;
+	if (t->wide8Pixels != 0) e->wide8Pixels = t->wide8Pixels < 0 ? 0 : t->wide8Pixels;
+	if (t->launchThreads != 0) e->launchThreads = t->launchThreads < 0 ? PMHIP_DEFAULT_LAUNCH_THREADS : std::min(16, t->launchThreads);
 	return 0;
 }
 int pmhip_scene_set_view_id(pmhip_engine* e, int idx, uint32_t viewID) {

@@ -8,9 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# The engine picks a speculative sweep kernel for batches of <= 25 reference views (PMHIP_WIDE; eight-wide for one or two views, two-wide above); nearly every test case is that small, so
+# The engine picks a speculative sweep kernel for batches of <= 64 reference views (PMHIP_WIDE; eight-wide for one or two views, two-wide above); nearly every test case is that small, so
 # under the product default the regular sweep kernel -- the one that carries the benchmark -- would hardly be exercised.  The suite therefore pins the
-# regular kernel and tests the speculative kernels by name (test_wide_latency_mode_parity, the one-call part of test_config2_full_size_matches_golden,
+# regular kernel, runs every case of the `engine` fixture with both choices, and tests the speculative kernels by name (test_wide_latency_mode_parity, the one-call part of test_config2_full_size_matches_golden,
 # tests/test_zz_gpu_narrow_speculation.py).
 os.environ.setdefault("PMHIP_WIDE", "0")
 
@@ -60,10 +60,13 @@ def nine_scene():
     return synth.make_scene(9, 128, 96, n_src=8)
 
 
-@pytest.fixture(scope="session")
-def engine():
+@pytest.fixture(scope="session", params=["sweep2", "speculative"])
+def engine(request):
+    """The one-call engine of the GPU parity cases, once with the regular sweep kernel (pm_sweep2_kernel, what the 100-view benchmark times) and once with the product's default
+    choice for small batches (the speculative kernels: eight-wide for one or two views, two-wide above) -- selected through pmhip_set_tuning, not the environment."""
     from openmvs_amd.patchmatch import PatchMatchHIP
     e = PatchMatchHIP(0)
     e.Init(False)
+    e.tuning(wideMaxViews=-1 if request.param == "sweep2" else 64, wideHyps=-1)
     yield e
     e.close()

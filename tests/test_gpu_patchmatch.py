@@ -173,7 +173,9 @@ def test_tuning_through_the_abi(nine_scene):
     t0 = e.tuning()
     assert t0["viewGroups"] >= 1 and t0["quadBuffer"] in (1, 2)
     for kw in (dict(wideMaxViews=-1, sweepLanes=4), dict(wideMaxViews=-1, sweepLanes=8, viewGroups=3), dict(wideMaxViews=64, wideHyps=2), dict(wideMaxViews=64, wideHyps=8, quadBuffer=2),
-               dict(wideMaxViews=-1, sweepLanes=-1, quadBuffer=1, viewGroups=1)):
+               dict(wideMaxViews=-1, sweepLanes=-1, quadBuffer=1, viewGroups=1),
+               # per-launch choice: the short diagonals of a batch with the eight-wide speculative kernel, the middle ones with the two-wide one, the long ones with pm_sweep2
+               dict(wideMaxViews=-1, sweepLanes=4, viewGroups=2, widePixels=max(8, sc.height * 2), wide8Pixels=max(4, sc.height // 2))):
         got = e.tuning(**kw)
         for k, v in kw.items():
             assert got[k] == v, (k, got)

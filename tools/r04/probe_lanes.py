@@ -37,11 +37,12 @@ for name, env in configs:
             e.scene_estimate(allv, -1, p, sync=False)
             for g in range(2):
                 e.scene_commit_round(); e.scene_estimate(allv, g, p, sync=False)
+            tq = time.perf_counter() - t                      # the host has enqueued everything (no sync inside the calls): host-bound if this is the whole step
             e.sync(); dt = time.perf_counter() - t
-            if rep: best = min(best, dt)
+            if rep and dt < best: best = dt; enq = tq
         d = e.scene_get_maps(0)[0]
         if ref is None: ref = d
-        print("%-28s %-60s %.3f s/step  %.2f Mpix/s  same-as-first %s" % (name, env, best, V * W * H / best / 1e6, bool(np.array_equal(d, ref))), flush=True)
+        print("%-28s %-60s %.3f s/step (host enqueue %.3f s)  %.2f Mpix/s  same-as-first %s" % (name, env, best, enq, V * W * H / best / 1e6, bool(np.array_equal(d, ref))), flush=True)
         e.close()
     finally:
         for k, v in saved.items():

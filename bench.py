@@ -223,6 +223,7 @@ def main():
         per_launch = st.sweepBytes / max(1, st.sweepLaunches)
         valu_tf = FLOP_PER_PIXEL * (len(mine) * W * H * a.steps / dt) / 1e12   # this rank's pixels per second x algorithmic flop per pixel
         kern = sweep_kernel_name(B if B else len(mine), N)
+        issue = valu_issue_fields(st.sweepPixels, wall_s) if kern == "pm_sweep2_kernel" else {}
         tf = traffic_fields(per_launch) if kern == "pm_sweep2_kernel" else {"traffic": None, "traffic_note": "no counter passes of %s yet (the committed ones are of pm_sweep2_kernel)" % kern}
         out = {
             "metric": "Mpix/s depth-map output at 1920x1080 N-view", "value": round(mpix, 3), "unit": "Mpix/s",
@@ -234,7 +235,7 @@ def main():
                        "views_total": V, "views_per_gpu": len(mine), "batch": B, "parallelism": "reference views sharded over %d GPU(s)" % world,
                        "exchange": "neighbour-only point-to-point (a rank holds its block and the %d foreign views it reads)" % len(foreign), "ranks": ranks_info},
             "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), **tf,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), **tf, **issue,
                          "launches": int(st.sweepLaunches), "avg_launch_us": round(1e3 * st.sweepMs / max(1, st.sweepLaunches), 2),
                          "algorithmic_bytes_per_launch": round(per_launch, 1),
                          "concurrent_streams": round(sweep_s / max(wall_s, 1e-12), 2), "device_achieved": round(device, 2),
@@ -261,9 +262,10 @@ def main():
 
 
 def sweep_kernel_name(n_batch, n_src):
-    """The sweep kernel the engine picks for a batch of n_batch reference views (pm_engine.hip: PMHIP_DEFAULT_WIDE, PMHIP_LANES4_FROM)."""
+    """The sweep kernel the engine picks for a batch of n_batch reference views (pm_engine.hip: PMHIP_DEFAULT_WIDE, PMHIP_DEFAULT_WIDE_PIXELS, PMHIP_LANES4_FROM).  Larger batches
+    sweep their long diagonals (launches above PMHIP_DEFAULT_WIDE_PIXELS pixels: most of the time) with pm_sweep2_kernel and the short ones with the two-wide speculative kernel."""
     try:
-        wide_max = int(os.environ.get("PMHIP_WIDE", "64"))
+        wide_max = int(os.environ.get("PMHIP_WIDE", "32"))
         if n_batch <= wide_max and n_src <= 8:
             hy = os.environ.get("PMHIP_WIDE_HYPS")
             hyps = int(hy) if hy in ("8", "4", "2") else (8 if n_batch <= 2 else 2)
@@ -282,6 +284,29 @@ def traffic_fields(algorithmic_bytes_per_launch):
         return {"traffic": None}
     return {"traffic": round(t["over_algorithmic"] * algorithmic_bytes_per_launch), "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, offline counter passes, scaled by algorithmic bytes)",
             "traffic_measurement": t}
+
+
+def valu_issue_fields(sweep_pixels, sweep_wall_s, px_per_wave=16, simds=1024, clock_hz=2.4e9):
+    """What the sweep kernel actually runs into at this batch size: the share of the SIMDs' cycles during which a VALU instruction of pm_sweep2_kernel<4,2> executes.
+    = (VALU-busy cycles of one wave-visit, SQ_ACTIVE_INST_VALU / SQ_WAVES of the offline counter passes) x (wave-visits of this run = pixel visits / 16 pixels per wave)
+    / (1024 SIMDs x sweep wall time x 2.4 GHz, the clock rocminfo reports; a lower clock under load makes the share larger).  Empty without counters of this tree's kernels."""
+    try:
+        import hashlib
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        h = hashlib.sha256()
+        for f in ("pm_kernels.hip", "pm_band.hip", "pm_math.h"):
+            h.update(open(os.path.join(ROOT, "openmvs_amd", "csrc", f), "rb").read())
+        sq = t.get("sq", {})
+        if h.hexdigest()[:16] != t.get("kernel_digest") or "frac_active_valu" not in sq:
+            return {}
+        busy = 4.0 * sq["frac_active_valu"] * sq["wave_quadcycles_per_wave"]          # cycles per wave-visit
+        visits = sweep_pixels / float(px_per_wave)
+        return {"valu_issue": {"valu_busy_cycles_per_wave_visit": round(busy), "valu_insts_per_wave_visit": sq["valu_insts_per_wave"], "wave_visits": int(visits),
+                               "valu_busy_frac": round(busy * visits / (simds * clock_hz * max(sweep_wall_s, 1e-12)), 4),
+                               "note": "share of all SIMD cycles of the sweep phases in which a VALU instruction executes (offline SQ counters x this run's wave-visits, 2.4 GHz): "
+                                       "the bound this kernel actually approaches at this batch size is the issue of the reference's un-fusable fp32 arithmetic, not HBM"}}
+    except Exception:
+        return {}
 
 
 def measured_traffic(algorithmic_bytes_per_launch):
@@ -349,7 +374,7 @@ def golden_and_config2(eng):
     # the engine would not pick for 9 views by itself (PMHIP_WIDE / PMHIP_LANES are read at pmhip_create): the throughput figure and the bit-identity claim are about
     # one and the same kernel
     timed_mismatches = []
-    saved = {k: os.environ.get(k) for k in ("PMHIP_WIDE", "PMHIP_LANES")}
+    saved = {k: os.environ.get(k) for k in ("PMHIP_WIDE", "PMHIP_LANES")}          # (PMHIP_WIDE=0 also switches the per-launch use of the speculative kernels off)
     os.environ["PMHIP_WIDE"] = "0"; os.environ["PMHIP_LANES"] = "4"
     try:
         from openmvs_amd.patchmatch import PatchMatchHIP
@@ -402,8 +427,9 @@ def golden_and_config2(eng):
                                "against the SHA-256 digests of the sequential CPU oracle (tests/golden/pm_config2_1920x1080.json), scene interface and one-call boundary"
                                % (c["geo_iters"], 3 * len(allv) * (1 + c["geo_iters"])),
                        "inputs_reproduced": bool(same_inputs), "bit_identical": bool(same_inputs and not mismatches and not timed_mismatches), "mismatches": (mismatches + timed_mismatches)[:4],
-                       "kernel": "pm_sweep2_kernel", "kernel_note": "all 27 maps also through pm_sweep2_kernel<4,2> (PMHIP_WIDE=0 PMHIP_LANES=4), the instantiation of the timed 100-view batch; "
-                                 "the engine's own choice for 9 views (pm_sweep_widen_kernel<2>) and the one-call boundary (pm_sweep_wide_kernel) are the other two checks",
+                       "kernel": "pm_sweep2_kernel", "kernel_note": "all 27 maps also through pm_sweep2_kernel<4,2> alone (PMHIP_WIDE=0 PMHIP_LANES=4), the instantiation that sweeps the long diagonals of the timed 100-view "
+                                 "batch; its short diagonals go through pm_sweep_widen_kernel<2>, which is the engine's own choice for these 9 views (the first check); the one-call "
+                                 "boundary (pm_sweep_wide_kernel) is the third",
                        "bit_identical_timed_kernel": bool(same_inputs and not timed_mismatches),
                        "depth_rmse_over_diameter": rmse / sc.diameter, "tolerance": 1e-4,
                        "rmse_note": "over the golden file's strided depth sample of the reference view (exactly 0 when bit_identical)"}}

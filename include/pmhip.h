@@ -231,11 +231,11 @@ int pmhip_stats_get(pmhip_engine* e, PMHipKernelStats* out);
  * pmhip_create, for experiments; a host program uses these two calls.) */
 typedef struct PMHipTuning {
 	int32_t viewGroups;      /* view groups of a batch that sweep on their own streams (2) */
-	int32_t wideMaxViews;    /* batches of at most this many reference views use the speculative sweep kernels (64); -1 = never */
+	int32_t wideMaxViews;    /* batches of at most this many reference views use the speculative sweep kernels for every launch (32); -1 = no speculative kernels at all (also clears widePixels / wide8Pixels unless set in the same call) */
 	int32_t wideHyps;        /* hypotheses per round of the speculative kernel: 8, 4 or 2; -1 = by batch size (8 for one or two views, else 2) */
 	int32_t sweepLanes;      /* lanes per pixel of pm_sweep2_kernel: 4, 8 or 16; -1 = by batch size */
 	int32_t quadBuffer;      /* 1: tap rows address the level's quad images as one buffer, 2: through each view's pointer */
-	int32_t widePixels;      /* larger batches: a diagonal launch of at most this many pixels (diagonal length x views of the group) uses the two-wide speculative kernel; -1 = none */
+	int32_t widePixels;      /* larger batches: a diagonal launch of at most this many pixels (diagonal length x views of the group) uses the two-wide speculative kernel (20000); -1 = none */
 	int32_t wide8Pixels;     /* ... and one of at most this many pixels the eight-wide speculative kernel; -1 = none */
 	int32_t launchThreads;   /* host threads enqueueing a sweep's launches: 1 = the caller feeds every group's stream, N = one thread per view group (at most N); -1 = default */
 } PMHipTuning;

@@ -30,12 +30,14 @@
 #define PMHIP_DEFAULT_LAUNCH_THREADS 1
 #endif
 #ifndef PMHIP_DEFAULT_WIDE_PIXELS
-#define PMHIP_DEFAULT_WIDE_PIXELS 0    // larger batches: diagonal launches of at most this many pixels use the two-wide speculative kernel (0: none)
-#define PMHIP_DEFAULT_WIDE8_PIXELS 0   // ... and of at most this many pixels the eight-wide one
+#define PMHIP_DEFAULT_WIDE_PIXELS 20000   // larger batches: diagonal launches of at most this many pixels (diagonal length x views of the group) use the two-wide speculative
+                                         // kernel -- the ramps of the fine level and all of the coarse ones.  profiles/r04_call9_lanes_100.log (100 views, Mpix/s): none 46.4,
+                                         // <= 8000: 48.1, <= 16000: 48.6, <= 24000: 48.6; 50 views: 43.4 against 42.7 with the two-wide kernel everywhere
+#define PMHIP_DEFAULT_WIDE8_PIXELS 0     // ... and of at most this many pixels the eight-wide one (no effect measured at 13 / 100 views: off)
 #endif
 #ifndef PMHIP_DEFAULT_WIDE
-#define PMHIP_DEFAULT_WIDE 64   // batches of at most this many reference views use the speculative kernels: eight hypotheses per round (one wave per pixel) for 1-2 views, two per round
-                                // (four pixels per wave, pm_wide_n.hip) from 3 views on.  Measured in round 4 (profiles/r04_call7_crossover.log, full schedule at 1920x1080, Mpix/s;
+#define PMHIP_DEFAULT_WIDE 32   // batches of at most this many reference views use the speculative kernels: eight hypotheses per round (one wave per pixel) for 1-2 views, two per round
+                                // (four pixels per wave, pm_wide_n.hip) from 3 views on.  Measured in round 4 (profiles/r04_call7_lanes_*.log, full schedule at 1920x1080, Mpix/s;
                                 // two-wide / pm_sweep2_kernel): 13 views 26.8 / 19.7, 25: 37.5 / 31.2, 50: 41.0 / 39.3, 100: 42.6 / 44.9 (<4,2>)
 #endif
 #ifndef PMHIP_DEFAULT_LANES
@@ -155,6 +157,7 @@ struct pmhip_engine {
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
 	int quadBuffer = 1;                     // tap rows address the level's quad images as one buffer (entry index); 0 = through each view's own pointer (PMHIP_QUADBUF; forced for
 	                                        // batches that read a source view with its own image size, which lives outside the level's buffer)
+	bool g0Main = false;   // experiment (PMHIP_G0_MAIN): group 0 sweeps on the engine's own stream, so that N groups use N streams, not N + 1
 	int launchThreads = PMHIP_DEFAULT_LAUNCH_THREADS;   // host threads that enqueue a sweep's launches: 1 = the caller alone, feeding the groups' streams in turn; N > 1 = one thread per view group (up to N)
 	PMLaunchPool pool;
 	hipStream_t gstream[16] = {};
@@ -546,9 +549,11 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			const int NG = std::max(1, std::min(e->nGroups, nB));
 			const size_t evWall = evBeginOn(e, 2, e->stream);
 			size_t evG[16] = {};
+			// group g's stream: the engine's own for a single group (and, PMHIP_G0_MAIN, for group 0 of several)
+			auto gs = [&](int g) { return (NG > 1 && !(e->g0Main && g == 0)) ? e->gstream[g] : e->stream; };
 			if (NG > 1) {
 				HIPCHK(e, hipEventRecord(e->forkEv, e->stream));
-				for (int g = 0; g < NG; ++g) { HIPCHK(e, hipStreamWaitEvent(e->gstream[g], e->forkEv, 0)); evG[g] = evBeginOn(e, 0, e->gstream[g]); }
+				for (int g = 0; g < NG; ++g) { if (gs(g) != e->stream) HIPCHK(e, hipStreamWaitEvent(gs(g), e->forkEv, 0)); evG[g] = evBeginOn(e, 0, gs(g)); }
 			} else evG[0] = evBeginOn(e, 0, e->stream);
 			// group g's launches of diagonal k; the kernels compute the same bits, so the choice is per launch: the speculative kernels (more lanes per pixel, shorter
 			// dependent chain) for batches and for diagonals too small to fill the GPU with 64 / G pixels per wave
@@ -560,7 +565,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 				const int count = xhi - xlo + 1;
 				if (count <= 0) return 0;
 				const int s0 = (int)((long)nB * g / NG), s1 = (int)((long)nB * (g + 1) / NG);
-				hipStream_t st = NG > 1 ? e->gstream[g] : e->stream;
+				hipStream_t st = gs(g);
 				const long npx = (long)count * (s1 - s0);
 				const bool wide = wideBatch || (maxSrc <= 8 && npx <= e->widePixels);
 				const int hyps = (wideBatch && e->wideHyps > 0) ? e->wideHyps : ((nB <= 2 || npx <= e->wide8Pixels) ? 8 : 2);
@@ -586,7 +591,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			if (!allOk) { e->err = "sweep kernel: (lanes per pixel, views per lane) mapping not instantiated"; return PMHIP_E_ARG; }
 			if (e->statsOn) { e->stats.sweepLaunches += nLaunched; e->stats.sweepHostMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hostT0).count(); }
 			if (NG > 1) {
-				for (int g = 0; g < NG; ++g) { evEndOn(e, evG[g], e->gstream[g]); HIPCHK(e, hipEventRecord(e->joinEv[g], e->gstream[g])); HIPCHK(e, hipStreamWaitEvent(e->stream, e->joinEv[g], 0)); }
+				for (int g = 0; g < NG; ++g) { evEndOn(e, evG[g], gs(g)); if (gs(g) != e->stream) { HIPCHK(e, hipEventRecord(e->joinEv[g], gs(g))); HIPCHK(e, hipStreamWaitEvent(e->stream, e->joinEv[g], 0)); } }
 			} else evEndOn(e, evG[0], e->stream);
 			evEndOn(e, evWall, e->stream);
 			if (e->statsOn) {
@@ -645,7 +650,8 @@ int pmhip_create(int device, pmhip_engine** out) {
 	const char* ng = getenv("PMHIP_GROUPS");
 	e->nGroups = ng ? std::max(1, std::min(16, atoi(ng))) : PMHIP_DEFAULT_GROUPS;
 	const char* nw = getenv("PMHIP_WIDE");
-	if (nw) e->wideMaxViews = atoi(nw);
+	if (nw) { e->wideMaxViews = atoi(nw); if (e->wideMaxViews <= 0) e->widePixels = e->wide8Pixels = 0; }   // PMHIP_WIDE=0: no speculative kernels at all (PMHIP_WIDE_PIXELS below may bring the per-launch rule back)
+	const char* gm = getenv("PMHIP_G0_MAIN"); if (gm) e->g0Main = atoi(gm) != 0;
 	const char* lt = getenv("PMHIP_LAUNCH_THREADS"); if (lt && atoi(lt) >= 1) e->launchThreads = std::min(16, atoi(lt));
 	const char* wp = getenv("PMHIP_WIDE_PIXELS"); if (wp) e->widePixels = atoi(wp);
 	const char* w8 = getenv("PMHIP_WIDE8_PIXELS"); if (w8) e->wide8Pixels = atoi(w8);
@@ -759,7 +765,7 @@ int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t) {
 		}
 		e->nGroups = t->viewGroups;
 	}
-	if (t->wideMaxViews != 0) e->wideMaxViews = t->wideMaxViews < 0 ? 0 : t->wideMaxViews;
+	if (t->wideMaxViews != 0) { e->wideMaxViews = t->wideMaxViews < 0 ? 0 : t->wideMaxViews; if (t->wideMaxViews < 0) e->widePixels = e->wide8Pixels = 0; }   // "never" = no speculative kernels at all, unless this call sets the per-launch rule
 	if (t->wideHyps != 0) e->wideHyps = t->wideHyps < 0 ? 0 : t->wideHyps;
 	if (t->sweepLanes != 0) e->sweepLanes = t->sweepLanes < 0 ? 0 : t->sweepLanes;
 	if (t->quadBuffer != 0) e->quadBuffer = t->quadBuffer == 1;

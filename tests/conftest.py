@@ -8,7 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# The engine picks a speculative sweep kernel for batches of <= 64 reference views (PMHIP_WIDE; eight-wide for one or two views, two-wide above); nearly every test case is that small, so
+# The engine picks a speculative sweep kernel for batches of <= 32 reference views and for the short diagonals of larger ones (PMHIP_WIDE, PMHIP_WIDE_PIXELS; eight-wide for one or two views, two-wide above); nearly every test case is that small, so
 # under the product default the regular sweep kernel -- the one that carries the benchmark -- would hardly be exercised.  The suite therefore pins the
 # regular kernel, runs every case of the `engine` fixture with both choices, and tests the speculative kernels by name (test_wide_latency_mode_parity, the one-call part of test_config2_full_size_matches_golden,
 # tests/test_zz_gpu_narrow_speculation.py).
@@ -67,6 +67,6 @@ def engine(request):
     from openmvs_amd.patchmatch import PatchMatchHIP
     e = PatchMatchHIP(0)
     e.Init(False)
-    e.tuning(wideMaxViews=-1 if request.param == "sweep2" else 64, wideHyps=-1)
+    e.tuning(wideMaxViews=-1 if request.param == "sweep2" else 64, wideHyps=-1)     # (-1 also switches the per-launch use of the speculative kernels off)
     yield e
     e.close()

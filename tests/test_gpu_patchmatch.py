@@ -163,7 +163,7 @@ def test_sweep_kernel_variants_parity(nine_scene, small_scene, variant, quick=Fa
                 os.environ[k] = v
 
 
-def test_tuning_through_the_abi(nine_scene):
+def test_tuning_through_the_abi(nine_scene, threads=True):
     """pmhip_set_tuning (include/pmhip.h): the mapping of a batch onto the GPU is chosen through the C ABI, not through the environment; every setting gives the
     oracle's bits."""
     from openmvs_amd.patchmatch import PatchMatchHIP
@@ -175,7 +175,9 @@ def test_tuning_through_the_abi(nine_scene):
     for kw in (dict(wideMaxViews=-1, sweepLanes=4), dict(wideMaxViews=-1, sweepLanes=8, viewGroups=3), dict(wideMaxViews=64, wideHyps=2), dict(wideMaxViews=64, wideHyps=8, quadBuffer=2),
                dict(wideMaxViews=-1, sweepLanes=-1, quadBuffer=1, viewGroups=1),
                # per-launch choice: the short diagonals of a batch with the eight-wide speculative kernel, the middle ones with the two-wide one, the long ones with pm_sweep2
-               dict(wideMaxViews=-1, sweepLanes=4, viewGroups=2, widePixels=max(8, sc.height * 2), wide8Pixels=max(4, sc.height // 2))):
+               dict(wideMaxViews=-1, sweepLanes=4, viewGroups=2, widePixels=max(8, sc.height * 2), wide8Pixels=max(4, sc.height // 2)),
+               # one host thread per view group enqueueing its launches (the CPU emulator's launches are synchronous: device only)
+               dict(wideMaxViews=64, wideHyps=-1, widePixels=-1, wide8Pixels=-1, viewGroups=3, launchThreads=3 if threads else 1)):
         got = e.tuning(**kw)
         for k, v in kw.items():
             assert got[k] == v, (k, got)

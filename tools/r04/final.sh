@@ -9,7 +9,7 @@ step() { echo "=== $1 ($(date +%T))" | tee -a "$OUT/steps.log"; }
 step "gpu suite"
 timeout 1500 python -m pytest tests -m gpu -q --durations=8 > "$OUT/gpu_suite.log" 2>&1; echo "suite exit $?" | tee -a "$OUT/gpu_suite.log"; tail -6 "$OUT/gpu_suite.log"
 step "counters of pm_sweep2_kernel<4,2> (24 views, one stream)"
-PMHIP_WIDE=0 PMHIP_LANES=4 PMC_TRIES=2 PMC_TIMEOUT=90 bash tools/pmc/run_pmc.sh "$OUT/pmc" 24 libpmhip.so > "$OUT/pmc.log" 2>&1; tail -30 "$OUT/pmc.log"
+PMHIP_WIDE=0 PMHIP_WIDE_PIXELS=0 PMHIP_LANES=4 PMC_TRIES=2 PMC_TIMEOUT=90 bash tools/pmc/run_pmc.sh "$OUT/pmc" 24 libpmhip.so > "$OUT/pmc.log" 2>&1; tail -30 "$OUT/pmc.log"
 python tools/pmc/make_traffic.py "$OUT/pmc" pm_sweep2 > "$OUT/traffic.json" 2> "$OUT/traffic.err" && cp profiles/traffic.json "$OUT/traffic_profiles.json"; tail -3 "$OUT/traffic.err"
 step "bench"
 timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc $?"; head -c 400 "$OUT/bench.json"; echo; tail -3 "$OUT/bench.err"

@@ -157,7 +157,6 @@ struct pmhip_engine {
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
 	int quadBuffer = 1;                     // tap rows address the level's quad images as one buffer (entry index); 0 = through each view's own pointer (PMHIP_QUADBUF; forced for
 	                                        // batches that read a source view with its own image size, which lives outside the level's buffer)
-	bool g0Main = false;   // experiment (PMHIP_G0_MAIN): group 0 sweeps on the engine's own stream, so that N groups use N streams, not N + 1
 	int launchThreads = PMHIP_DEFAULT_LAUNCH_THREADS;   // host threads that enqueue a sweep's launches: 1 = the caller alone, feeding the groups' streams in turn; N > 1 = one thread per view group (up to N)
 	PMLaunchPool pool;
 	hipStream_t gstream[16] = {};
@@ -549,8 +548,9 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			const int NG = std::max(1, std::min(e->nGroups, nB));
 			const size_t evWall = evBeginOn(e, 2, e->stream);
 			size_t evG[16] = {};
-			// group g's stream: the engine's own for a single group (and, PMHIP_G0_MAIN, for group 0 of several)
-			auto gs = [&](int g) { return (NG > 1 && !(e->g0Main && g == 0)) ? e->gstream[g] : e->stream; };
+			// group g's stream: the engine's own for a single group.  (Letting group 0 of several sweep on the engine's stream, or more than three groups, falls off a cliff:
+			// 13 views 27 -> 15.6 Mpix/s, whatever GPU_MAX_HW_QUEUES says -- profiles/r04_call10_lanes_13.log.)
+			auto gs = [&](int g) { return NG > 1 ? e->gstream[g] : e->stream; };
 			if (NG > 1) {
 				HIPCHK(e, hipEventRecord(e->forkEv, e->stream));
 				for (int g = 0; g < NG; ++g) { if (gs(g) != e->stream) HIPCHK(e, hipStreamWaitEvent(gs(g), e->forkEv, 0)); evG[g] = evBeginOn(e, 0, gs(g)); }
@@ -651,7 +651,6 @@ int pmhip_create(int device, pmhip_engine** out) {
 	e->nGroups = ng ? std::max(1, std::min(16, atoi(ng))) : PMHIP_DEFAULT_GROUPS;
 	const char* nw = getenv("PMHIP_WIDE");
 	if (nw) { e->wideMaxViews = atoi(nw); if (e->wideMaxViews <= 0) e->widePixels = e->wide8Pixels = 0; }   // PMHIP_WIDE=0: no speculative kernels at all (PMHIP_WIDE_PIXELS below may bring the per-launch rule back)
-	const char* gm = getenv("PMHIP_G0_MAIN"); if (gm) e->g0Main = atoi(gm) != 0;
 	const char* lt = getenv("PMHIP_LAUNCH_THREADS"); if (lt && atoi(lt) >= 1) e->launchThreads = std::min(16, atoi(lt));
 	const char* wp = getenv("PMHIP_WIDE_PIXELS"); if (wp) e->widePixels = atoi(wp);
 	const char* w8 = getenv("PMHIP_WIDE8_PIXELS"); if (w8) e->wide8Pixels = atoi(w8);

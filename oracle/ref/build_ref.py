@@ -48,6 +48,8 @@ SNIPPETS = {
     "image_cpp_depth2disp":  ("libs/MVS/Image.cpp", 423, 433, "// converts the given depth at the un-rectified image coordinates to", "}"),
     "sgm_cpp_range":         ("libs/MVS/SemiGlobalMatcher.cpp", 1350, 1444, "SemiGlobalMatcher::Index SemiGlobalMatcher::Disparity2RangeMap(", "}"),
     "sgm_cpp_conv":          ("libs/MVS/SemiGlobalMatcher.cpp", 1837, 2039, "// Compute the disparity-map for the rectified image from the given depth-map of the un-rectified image;", "}"),
+    "sgm_cpp_fuse_pairdata": ("libs/MVS/SemiGlobalMatcher.cpp", 744, 749, "struct PairData {", "};"),
+    "sgm_cpp_fuse_loop":     ("libs/MVS/SemiGlobalMatcher.cpp", 795, 848, "// fuse available depth-maps such that for each pixel set its depth as the average of the largest cluster of agreeing depths;", "}"),
     "types_h_tpixel":        ("libs/Common/Types.h", 1874, 1988, "template <typename TYPE>", "};"),
     "types_inl_cast_pixel":  ("libs/Common/Types.inl", 1695, 1699, "// Pixel", "}"),
     "types_h_indexscore":    ("libs/Common/Types.h", 2462, 2485, "// structure used for sorting some indices by their score (decreasing by default)", "};"),

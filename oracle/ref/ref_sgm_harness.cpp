@@ -106,6 +106,25 @@ unsigned long long ref_sgm_disparity2range_map(const int16_t* disparityMap, int 
 	*outMaxNumDisp = m.maxNumDisp;
 	return n;
 }
+// SemiGlobalMatcher::Fuse, the per-pixel cluster fusion (SemiGlobalMatcher.cpp:795-848 verbatim; the part before it loads the pair files and calls ProjectDisparity2DepthMap,
+// which ref_sgm_project_disparity2depth_map covers): same arguments as orc_sgm_fuse_pairs (oracle/sgm_post_oracle.cpp)
+void ref_sgm_fuse_pairs(const float* const* depthMaps, const float* const* rangeMaps, const float* const* confMaps, int nPairs, int dw, int dh, unsigned minViews,
+		float* outDepth, float* outConf) {
+	typedef SemiGlobalMatcher::DepthRange DepthRange; typedef SemiGlobalMatcher::DepthRangeMap DepthRangeMap;
+	#include "snip/sgm_cpp_fuse_pairdata.inc"   // :744-749
+	CLISTDEFIDX(PairData,IIndex) pairs;
+	pairs.reserve((IIndex)nPairs);
+	for (int p = 0; p < nPairs; ++p) {
+		PairData& pair = pairs.emplace_back(cv::Size(dw, dh));
+		memcpy(pair.depthMap.data(), depthMaps[p], sizeof(float) * (size_t)dw * dh);
+		pair.depthRangeMap.create(cv::Size(dw, dh)); memcpy(pair.depthRangeMap.data(), rangeMaps[p], sizeof(float) * 2 * (size_t)dw * dh);
+		pair.confMap.create(cv::Size(dw, dh)); memcpy(pair.confMap.data(), confMaps[p], sizeof(float) * (size_t)dw * dh);
+	}
+	struct { struct { cv::Size sz; cv::Size size() const { return sz; } } image; } leftImage; leftImage.image.sz = cv::Size(dw, dh);
+	DepthMap depthMap; ConfidenceMap confMap;
+	#include "snip/sgm_cpp_fuse_loop.inc"       // :795-848
+	memcpy(outDepth, depthMap.data(), sizeof(float) * (size_t)dw * dh); memcpy(outConf, confMap.data(), sizeof(float) * (size_t)dw * dh);
+}
 static Matrix3x3 m33(const double* p) { Matrix3x3 M; for (int i = 0; i < 9; ++i) M.val[i] = p[i]; return M; }
 static Matrix4x4 m44(const double* p) { Matrix4x4 M; for (int i = 0; i < 16; ++i) M.val[i] = p[i]; return M; }
 void ref_sgm_depth2disparity_map(const float* depthMap, int dw, int dh, const double* invH, const double* invQ, int subpixelSteps, int16_t* disparityMap, int w, int h) {

@@ -104,6 +104,8 @@ public:
 	cList(IDX size) : v((size_t)size) {}
 	cList(IDX size, IDX reserved) : v((size_t)size) { v.reserve((size_t)reserved); }
 	cList(const TYPE* b, const TYPE* e) : v(b, e) {}
+	cList(std::initializer_list<TYPE> l) : v(l) {}                                                                                    // List.h:1396
+	template <typename Functor> inline const TYPE& GetMax(const Functor& f) const { return *std::max_element(v.begin(), v.end(), f); }   // List.h:688-691 (the first maximum)
 	inline IDX GetSize() const { return (IDX)v.size(); }
 	inline IDX size() const { return (IDX)v.size(); }
 	inline bool IsEmpty() const { return v.empty(); }

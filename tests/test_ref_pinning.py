@@ -439,3 +439,25 @@ def test_sgm_disparity_depth_conversions_are_the_reference_functions(w, h, seed)
             assert np.array_equal(r0[valid].view(np.uint32), r1[valid].view(np.uint32)), "ProjectDisparity2DepthMap range"
             assert cst is None or np.array_equal(c0[valid].view(np.uint32), c1[valid].view(np.uint32)), "ProjectDisparity2DepthMap confidence"
             assert valid.mean() > 0.3
+
+
+# ---- SemiGlobalMatcher::Fuse, the per-pixel cluster fusion over the maps of ProjectDisparity2DepthMap (SemiGlobalMatcher.cpp:795-848 with PairData :744-749, cut verbatim;
+#      cList's initializer-list constructor and GetMax(functor) as List.h:1396, :688-691) ----
+@sgm_only
+@pytest.mark.parametrize("w,h,seed,n_pairs", [(64, 40, 0, 4), (97, 53, 1, 3), (80, 60, 2, 6), (33, 21, 3, 1)])
+def test_sgm_pair_fusion_is_the_reference_loop(w, h, seed, n_pairs):
+    from tests.test_sgm_post import _pair_maps
+    kw = dict(impl=pr.sgm_post_lib(), prefix="ref_sgm_")
+    base, deps, rgs, cfs = _pair_maps(w, h, seed, n_pairs)
+    # ties between clusters and ranges that exclude their own depth (depth == upper bound: ISINSIDE is half-open) on a few pixels
+    deps[0][0, :8] = 2.0; rgs[0][0, :8] = (1.9, 2.0)
+    if n_pairs > 1:
+        deps[1][0, :8] = 2.0; rgs[1][0, :8] = (2.0, 2.1)
+    any_valid = 0
+    for mv in (1, 2, 3, n_pairs + 1):
+        a = po.sgm_fuse_pairs(deps, rgs, cfs, mv)
+        b = po.sgm_fuse_pairs(deps, rgs, cfs, mv, **kw)
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), "Fuse depth, minViews %d" % mv
+        assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), "Fuse confidence, minViews %d" % mv
+        any_valid += int((a[0] > 0).sum())
+    assert any_valid > 0

@@ -43,6 +43,7 @@ public:
 
 	// one calibrated image (MVS::Image + the DepthData the reference builds for it in InitViews, SceneDensify.cpp:273-460)
 	struct View {
+		int w = 0, h = 0;                       // this image's own size; 0 = the size given to LoadScene (the reference sizes every DepthData on its image, SceneDensify.cpp:306-459)
 		const float* gray = nullptr;            // w*h, gray in [0,1] (Image::toGray), row-major
 		const unsigned char* bgr = nullptr;     // w*h*3 or null (needed for FuseDepthMaps with bEstimateColor)
 		const unsigned char* mask = nullptr;    // w*h or null: 0 = ignored pixel (--ignore-mask-label, DepthMap.cpp:296-323)
@@ -82,7 +83,10 @@ public:
 		for (int i = 0; i < n; ++i) {
 			const View& v = views[i];
 			if (!v.gray) throw std::runtime_error("DenseDepthMapsHIP: view without an image");
-			check(pmhip_scene_set_view(e_, i, v.gray, 0, v.K, v.R, v.C, v.dMin, v.dMax, v.neighbors.data(), (int)v.neighbors.size()));
+			if (v.w > 0 && v.h > 0 && (v.w != w || v.h != h))
+				check(pmhip_scene_set_view_sized(e_, i, v.gray, v.w, v.h, 0, v.K, v.R, v.C, v.dMin, v.dMax, v.neighbors.data(), (int)v.neighbors.size()));
+			else
+				check(pmhip_scene_set_view(e_, i, v.gray, 0, v.K, v.R, v.C, v.dMin, v.dMax, v.neighbors.data(), (int)v.neighbors.size()));
 			if (v.mask) { check(pmhip_scene_set_mask(e_, i, v.mask)); anyMask = true; }
 			if (v.bgr) check(pmhip_scene_set_color(e_, i, v.bgr));
 		}
@@ -150,19 +154,23 @@ public:
 		                         haveColor ? pc.colors.data() : nullptr, opt.bEstimateNormal ? pc.normals.data() : nullptr));
 	}
 
-	// One view's maps back to the host (any pointer may be null)
+	// One view's maps back to the host (any pointer may be null); ViewWidth(idx) x ViewHeight(idx) entries
 	void GetMaps(int idx, float* depth, float* normal, float* conf) { check(pmhip_scene_get_maps(e_, idx, depth, normal, conf)); }
+	int ViewWidth(int idx) const { return views_[(size_t)idx].w > 0 ? views_[(size_t)idx].w : w_; }
+	int ViewHeight(int idx) const { return views_[(size_t)idx].h > 0 ? views_[(size_t)idx].h : h_; }
 
 	// DepthData::Save for every view: "<dir>/depthNNNN.dmap" (ComposeDepthFilePath, DepthMap.h:72), written through dmap_write (include/dmapio.h);
 	// declared as a template on the writer so that this header does not force libdmapio on callers that never save
 	template <typename DMapHeaderT, typename WriteFn>
 	void SaveDepthMaps(const std::string& dir, WriteFn dmapWrite) {
-		std::vector<float> d((size_t)w_ * h_), nrm((size_t)w_ * h_ * 3), c((size_t)w_ * h_);
+		std::vector<float> d, nrm, c;
 		for (size_t i = 0; i < views_.size(); ++i) {
 			const View& v = views_[i];
+			const int vw = ViewWidth((int)i), vh = ViewHeight((int)i);
+			d.resize((size_t)vw * vh); nrm.resize((size_t)vw * vh * 3); c.resize((size_t)vw * vh);
 			GetMaps((int)i, d.data(), nrm.data(), c.data());
 			DMapHeaderT hdr; std::memset(&hdr, 0, sizeof(hdr));
-			hdr.imageWidth = hdr.depthWidth = (uint32_t)w_; hdr.imageHeight = hdr.depthHeight = (uint32_t)h_;
+			hdr.imageWidth = hdr.depthWidth = (uint32_t)vw; hdr.imageHeight = hdr.depthHeight = (uint32_t)vh;
 			hdr.dMin = v.dMin; hdr.dMax = v.dMax; hdr.type = 1u | 2u | 4u;
 			hdr.nIDs = (uint32_t)std::min<size_t>(v.neighbors.size() + 1, 256);
 			hdr.IDs[0] = v.ID;

@@ -118,9 +118,12 @@ int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevi
  * -- a rank of the multi-GPU driver keeps its block of reference views and their neighbours in a compact scene of local slots -- gives every slot the view's index in
  * the whole scene, so that the depth maps do not depend on how the scene was split (openmvs_amd/distributed.py; the reference seeds per estimator, DepthMap.cpp:370-372). */
 int pmhip_scene_set_view_id(pmhip_engine* e, int idx, uint32_t viewID);
-/* The same for a view whose image has its own size w x h (another camera, or a neighbour rescaled by ViewData::ScaleImage): it keeps its own
- * pyramid and can serve as a SOURCE view of any reference view; estimating it (as a reference view) returns PMHIP_E_SIZE -- reference views
- * share the scene's size, use one scene per size class.  gray is required. */
+/* The same for a view whose image has its own size w x h (the reference sizes every DepthData on its own image, DepthMapsData::InitViews,
+ * libs/MVS/SceneDensify.cpp:306-459; also a neighbour rescaled by ViewData::ScaleImage): it keeps its own pyramid and its own depth / normal /
+ * confidence maps of that size, and is a view like any other -- source view, reference view (a batch is swept one size class after the other),
+ * per-map filters, cross-view filter and fusion against neighbours of other sizes.  pmhip_scene_get_maps / set_maps / set_conf / set_color of such
+ * a view move w*h entries; pmhip_scene_device_ptr returns its own buffers; ignore masks are kept for views of the scene's size only
+ * (PMHIP_E_SIZE).  gray is required. */
 int pmhip_scene_set_view_sized(pmhip_engine* e, int idx, const float* gray, int w, int h, int onDevice,
                                const double K[9], const double R[9], const double C[3],
                                float dMin, float dMax, const int32_t* neighbors, int nNeighbors);
@@ -150,11 +153,12 @@ int pmhip_scene_set_mask(pmhip_engine* e, int idx, const unsigned char* mask);
 int pmhip_scene_set_mask_mode(pmhip_engine* e, int mode);
 /* Install a confidence map (host pointer), e.g. one read back from a .dmap before filtering / fusing without re-estimating. */
 int pmhip_scene_set_conf(pmhip_engine* e, int idx, const float* conf);
-/* Download maps (any pointer may be NULL). */
+/* Download maps (any pointer may be NULL); a view with its own size returns maps of that size. */
 int pmhip_scene_get_maps(pmhip_engine* e, int idx, float* depth, float* normal, float* conf);
 /* Device pointers for collectives (RCCL all-gather of the snapshot / broadcast of images).
  * what: 0 image level 0, 1 depth, 2 normal, 3 conf, 4 snapshot depth.  The per-kind arrays are
- * single contiguous allocations ordered by view index, so idx 0 addresses the whole set.  After writing images call pmhip_scene_images_updated,
+ * single contiguous allocations ordered by view index, so idx 0 addresses the whole set (views with their own size live outside them: their
+ * pointer addresses that view alone, and pmhip_scene_copy takes them one by one).  After writing images call pmhip_scene_images_updated,
  * after writing depth maps pmhip_scene_maps_updated: the engine cannot see writes through these pointers. */
 void* pmhip_scene_device_ptr(pmhip_engine* e, int what, int idx);
 /* DepthMapsData::FilterDepthMap (SceneDensify.cpp:1050-1299) for each view of viewIds against its first <= 8 neighbours

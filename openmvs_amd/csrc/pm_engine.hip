@@ -61,9 +61,12 @@ struct SceneView {
 	uint32_t id = 0;
 	bool set = false;
 	bool hasMaps = false;   // a depth map exists for this view (estimated, uploaded or copied in): DepthData::IsValid() of the reference's filter / fuse loops
-	// A view whose image has another size than the scene's (a neighbour rescaled by ViewData::ScaleImage, DepthMap.h:194-204, or simply another
-	// camera): it keeps its own pyramid here and can only serve as a SOURCE view.  sw == 0: the image lives in the scene arrays.
+	// A view whose image has another size than the scene's (the reference sizes every DepthData on its own, DepthMapsData::InitViews, SceneDensify.cpp:306-459; a
+	// neighbour rescaled by ViewData::ScaleImage, DepthMap.h:194-204): it keeps its own pyramid and its own maps here.  sw == 0: image and maps live in the scene arrays.
 	int sw = 0, sh = 0;
+	float *oDepth = nullptr, *oNormal = nullptr, *oConf = nullptr, *oSnap = nullptr;   // sw x sh (x 3): depth, normal, confidence (cost), previous round's depth
+	float *oFDepth = nullptr, *oFConf = nullptr;                                       // staged results of the cross-view filter (pmhip_scene_filter / _commit)
+	uint8_t* oBgr = nullptr;                                                           // its 8-bit BGR image (pmhip_scene_set_color), sw x sh x 3
 	float* sImg[4] = {nullptr, nullptr, nullptr, nullptr};
 	float* sImgS[4] = {nullptr, nullptr, nullptr, nullptr};
 	float4* sImgQ[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -76,6 +79,9 @@ static int lvlSize(int n, int l) { return (int)nearbyint((double)n / (double)(1 
 static void freeSide(SceneView& v) {
 	for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgS[l]) hipFree(v.sImgS[l]); if (v.sImgQ[l]) hipFree(v.sImgQ[l]); v.sImg[l] = v.sImgS[l] = nullptr; v.sImgQ[l] = nullptr; }
 	if (v.sDepth) hipFree(v.sDepth);
+	if (v.oDepth) hipFree(v.oDepth); if (v.oNormal) hipFree(v.oNormal); if (v.oConf) hipFree(v.oConf); if (v.oSnap) hipFree(v.oSnap);
+	if (v.oFDepth) hipFree(v.oFDepth); if (v.oFConf) hipFree(v.oFConf); if (v.oBgr) hipFree(v.oBgr);
+	v.oDepth = v.oNormal = v.oConf = v.oSnap = v.oFDepth = v.oFConf = nullptr; v.oBgr = nullptr;
 	v.sDepth = nullptr; v.sw = v.sh = v.dw = v.dh = 0; v.sideDirty = false;
 }
 
@@ -174,7 +180,7 @@ struct pmhip_engine {
 	unsigned char* d_mask[4] = {nullptr, nullptr, nullptr, nullptr}; std::vector<unsigned char> hasMask; bool maskDirty = false; int maskMode = -1;
 	// FilterDepthMap staging: filtered depth/conf of every view (committed after all views are filtered) and splat buffers
 	float *d_fdepth = nullptr, *d_fconf = nullptr; unsigned char* d_fvalid = nullptr;
-	unsigned long long* d_splat = nullptr; int splatCap = 0; PMFTask* d_ftasks = nullptr; PMFTask* h_ftasks = nullptr; int ftaskCap = 0;
+	unsigned long long* d_splat = nullptr; int splatCap = 0; size_t splatPix = 0; PMFTask* d_ftasks = nullptr; PMFTask* h_ftasks = nullptr; int ftaskCap = 0;
 	std::vector<SceneView> views;
 	bool pyramidDirty = true;
 	// FuseDepthMaps state (pm_fuse.hip); buffers live until the scene is released
@@ -187,6 +193,9 @@ struct pmhip_engine {
 		uint32_t* pin = nullptr;
 		std::vector<unsigned char> hasBgr;
 		uint64_t nPoints = 0, nViews = 0, nDepths = 0, rounds = 0; bool haveColor = false, haveNormal = false;
+		size_t slab = 0;                       // pixels per image the buffers above were allocated for
+		// scenes whose views differ in size: every image's normal / confidence / colour gathered into [nImages][slab] arrays, and the sizes
+		float *normalS = nullptr, *confS = nullptr; uint8_t* bgrS = nullptr; int* dims = nullptr;
 	} fu;
 	// batch scratch (grow only)
 	int batchCap = 0;
@@ -203,6 +212,15 @@ struct pmhip_engine {
 	// cv::resize(img, img, Size(), 1/2^l, 1/2^l): output size = cvRound(size / 2^l), ties to even (ScaleDepthData, SceneDensify.cpp:586)
 	int lw(int l) const { return (int)nearbyint((double)w / (double)(1 << l)); }
 	int lh(int l) const { return (int)nearbyint((double)h / (double)(1 << l)); }
+	// a view's own size and maps (a view with its own size keeps them itself, SceneView::sw)
+	int vw(int i) const { return views[i].sw ? views[i].sw : w; }
+	int vh(int i) const { return views[i].sw ? views[i].sh : h; }
+	size_t vpix(int i) const { return (size_t)vw(i) * vh(i); }
+	float* depthOf(int i) const { return views[i].sw ? views[i].oDepth : d_depth + (size_t)w * h * i; }
+	float* normalOf(int i) const { return views[i].sw ? views[i].oNormal : d_normal + (size_t)w * h * 3 * i; }
+	float* confOf(int i) const { return views[i].sw ? views[i].oConf : d_conf + (size_t)w * h * i; }
+	float* snapOf(int i) const { return views[i].sw ? views[i].oSnap : d_snap + (size_t)w * h * i; }
+	int batchW = 0, batchH = 0;   // size the batch scratch was allocated for
 };
 
 static void freeFuseOut(pmhip_engine* e) {
@@ -214,7 +232,7 @@ static void freeFuseOut(pmhip_engine* e) {
 static void freeFuse(pmhip_engine* e) {
 	auto& f = e->fu;
 	void* ptrs[] = {f.depth, f.claimed, f.resv, f.bgr, f.cams, f.recN, f.recColor, f.recX, f.recWeight, f.recNormal, f.recView, f.recProj,
-	                f.pend[0], f.pend[1], f.counters, f.nDepthsDev, f.tileSums, f.tileOff};
+	                f.pend[0], f.pend[1], f.counters, f.nDepthsDev, f.tileSums, f.tileOff, f.normalS, f.confS, f.bgrS, f.dims};
 	for (void* q : ptrs) if (q) hipFree(q);
 	if (f.pin) hipHostFree(f.pin);
 	freeFuseOut(e);
@@ -231,30 +249,31 @@ static void freeScene(pmhip_engine* e) {
 	e->hasMask.clear(); e->maskDirty = false; e->maskMode = -1;
 	if (e->d_fdepth) hipFree(e->d_fdepth); if (e->d_fconf) hipFree(e->d_fconf); if (e->d_fvalid) hipFree(e->d_fvalid);
 	if (e->d_splat) hipFree(e->d_splat); if (e->d_ftasks) hipFree(e->d_ftasks); if (e->h_ftasks) hipHostFree(e->h_ftasks);
-	e->d_fdepth = e->d_fconf = nullptr; e->d_fvalid = nullptr; e->d_splat = nullptr; e->d_ftasks = nullptr; e->h_ftasks = nullptr; e->splatCap = e->ftaskCap = 0;
+	e->d_fdepth = e->d_fconf = nullptr; e->d_fvalid = nullptr; e->d_splat = nullptr; e->d_ftasks = nullptr; e->h_ftasks = nullptr; e->splatCap = e->ftaskCap = 0; e->splatPix = 0;
 	if (e->d_tasks) hipFree(e->d_tasks); if (e->h_tasks) hipHostFree(e->h_tasks);
 	if (e->d_ups) hipFree(e->d_ups); if (e->h_ups) hipHostFree(e->h_ups);
 	e->d_tasks = nullptr; e->h_tasks = nullptr; e->d_ups = nullptr; e->h_ups = nullptr;
 	for (SceneView& v : e->views) freeSide(v);
-	e->batchCap = 0; e->nImages = 0; e->views.clear();
+	e->batchCap = 0; e->batchW = e->batchH = 0; e->nImages = 0; e->views.clear();
 }
 
-static int ensureBatch(pmhip_engine* e, int n) {
-	if (n <= e->batchCap) return 0;
+static int ensureBatch(pmhip_engine* e, int n, int bw, int bh) {
+	if (n <= e->batchCap && bw <= e->batchW && bh <= e->batchH) return 0;
+	n = std::max(n, e->batchCap); bw = std::max(bw, e->batchW); bh = std::max(bh, e->batchH);
 	HIPCHK(e, hipStreamSynchronize(e->stream));
 	for (int l = 0; l < 4; ++l) { if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
 	if (e->d_tasks) hipFree(e->d_tasks); if (e->h_tasks) hipHostFree(e->h_tasks);
 	if (e->d_ups) hipFree(e->d_ups); if (e->h_ups) hipHostFree(e->h_ups);
 	e->d_tasks = nullptr; e->h_tasks = nullptr; e->d_ups = nullptr; e->h_ups = nullptr;
 	const int cap = std::max(n, 1);
-	HIPCHK(e, hipMalloc(&e->d_lvl[0], sizeof(float) * (size_t)cap * e->w * e->h));
+	HIPCHK(e, hipMalloc(&e->d_lvl[0], sizeof(float) * (size_t)cap * bw * bh));
 	for (int l = 1; l <= e->nLevels; ++l)
-		HIPCHK(e, hipMalloc(&e->d_lvl[l], sizeof(float) * (size_t)cap * 6 * e->lw(l) * e->lh(l)));
+		HIPCHK(e, hipMalloc(&e->d_lvl[l], sizeof(float) * (size_t)cap * 6 * lvlSize(bw, l) * lvlSize(bh, l)));
 	HIPCHK(e, hipMalloc(&e->d_tasks, sizeof(PMTask) * 4 * cap));
 	HIPCHK(e, hipHostMalloc(&e->h_tasks, sizeof(PMTask) * 4 * cap));
 	HIPCHK(e, hipMalloc(&e->d_ups, sizeof(PMUpTask) * 4 * cap));
 	HIPCHK(e, hipHostMalloc(&e->h_ups, sizeof(PMUpTask) * 4 * cap));
-	e->batchCap = cap;
+	e->batchCap = cap; e->batchW = bw; e->batchH = bh;
 	return 0;
 }
 
@@ -390,17 +409,12 @@ static void evBegin(pmhip_engine* e, int kind) { evBeginOn(e, kind, e->stream); 
 static void evEnd(pmhip_engine* e) { if (e->statsOn) hipEventRecord(e->events.back().b, e->stream); }
 
 // One DepthMapsData::EstimateDepthMap (SceneDensify.cpp:616-805) for each view of the batch, concurrently.
-static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHipParams& p, int nGeometricIter) {
-	if (nB <= 0) return 0;
-	if (nGeometricIter >= 0 && !e->geom) { e->err = "geometric round requested but engine initialised with bGeomConsistency == 0"; return PMHIP_E_STATE; }
+// ids: views of ONE size class (cw x ch: the scene's size, or the own size these views carry); estimateBatch below splits a batch into its classes.
+static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, int ch, const PMHipParams& p, int nGeometricIter) {
 	const unsigned iterBegin = nGeometricIter < 0 ? 0u : p.nEstimationIters + (unsigned)nGeometricIter;
 	const unsigned iterEnd = nGeometricIter < 0 ? p.nEstimationIters : iterBegin + 1;
 	const int S = nGeometricIter < 0 ? (int)p.nSubResolutionLevels : 0;
-	if (S > e->nLevels || S > 3) { e->err = "nSubResolutionLevels exceeds the pyramid allocated by pmhip_scene_create"; return PMHIP_E_ARG; }
-	if (e->lw(S) < 2 * PM_HW + 1 || e->lh(S) < 2 * PM_HW + 1) { e->err = "image too small for this many sub-resolution levels"; return PMHIP_E_SIZE; }
-	int rc = ensureBatch(e, nB); if (rc) return rc;
-	rc = buildPyramid(e); if (rc) return rc;
-	rc = buildSidePyramids(e); if (rc) return rc;
+	if (lvlSize(cw, S) < 2 * PM_HW + 1 || lvlSize(ch, S) < 2 * PM_HW + 1) { e->err = "image too small for this many sub-resolution levels"; return PMHIP_E_SIZE; }
 	const PMKParams kp = makeKParams(p);
 	const bool geo = nGeometricIter >= 0;
 	bool anyMask = false;
@@ -423,7 +437,6 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 		if (id < 0 || id >= e->nImages || !e->views[id].set) { e->err = "view not set"; return PMHIP_E_ARG; }
 		const SceneView& v = e->views[id];
 		if (v.nNb < 1) { e->err = "view has no source views"; return PMHIP_E_ARG; }
-		if (v.sw) { e->err = "a view with its own image size can only be a source view (reference views share the scene's size)"; return PMHIP_E_SIZE; }
 		for (int k = 0; k < v.nNb; ++k) if (v.nb[k] < 0 || v.nb[k] >= e->nImages || !e->views[v.nb[k]].set) { e->err = "neighbour view not set"; return PMHIP_E_ARG; }
 		maxSrc = std::max(maxSrc, v.nNb);
 		for (int k = 0; k < v.nNb; ++k) if (e->views[v.nb[k]].sw) buf = false;   // a source image of its own size is not in the level's quad buffer
@@ -433,12 +446,15 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 	sweepMapping(maxSrc, e->sweepLanes > 0 ? e->sweepLanes : (nB >= PMHIP_LANES4_FROM && maxSrc > 4 ? 4 : 16), SG, VPL);
 	// latency mode (one wave per pixel, pm_sweep_wide_kernel) for batches too small to fill the GPU with one wave per 64 / G pixels
 	const bool wideBatch = nB <= e->wideMaxViews && maxSrc <= 8;
-	const size_t P0 = (size_t)e->w * e->h;
-	// the staging buffers are reused by the next call: make sure the previous call's copies are done
+	const size_t P0 = (size_t)cw * ch;                      // this class's pixels; the scene arrays are indexed with the scene's own
+	const size_t P0s = (size_t)e->w * e->h;
+	// the staging buffers are reused by the next call (and by the next size class): make sure the previous copies are done
 	HIPCHK(e, hipStreamSynchronize(e->stream));
 	for (int l = S; l >= 0; --l) {
-		const int lw = e->lw(l), lh = e->lh(l);
+		const int lw = lvlSize(cw, l), lh = lvlSize(ch, l);
 		const size_t Pl = (size_t)lw * lh;
+		const int slw = e->lw(l), slh = e->lh(l);            // the scene's size at this level: source views that live in the scene arrays
+		const size_t Pls = (size_t)slw * slh;
 		PMTask* ht = e->h_tasks + (size_t)l * e->batchCap;
 		PMUpTask* hu = e->h_ups + (size_t)l * e->batchCap;
 		for (int b = 0; b < nB; ++b) {
@@ -447,20 +463,20 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			PMTask& t = ht[b];
 			memset(&t, 0, sizeof(t));
 			if (l == 0) {
-				t.depth = e->d_depth + P0 * id; t.normal = e->d_normal + P0 * 3 * id; t.conf = e->d_conf + P0 * id;
+				t.depth = e->depthOf(id); t.normal = e->normalOf(id); t.conf = e->confOf(id);
 				t.prior = (S > 0) ? e->d_lvl[0] + P0 * b : nullptr;
 			} else {
 				float* base = e->d_lvl[l] + Pl * 6 * b;
 				t.depth = base; t.normal = base + Pl; t.conf = base + Pl * 4;
 				t.prior = (l < S) ? base + Pl * 5 : nullptr;
 			}
-			t.ref = e->d_img[l] + Pl * id;
-			t.refS = e->d_imgS[l] + e->skewPitch(l) * id;
+			if (v.sw) { t.ref = v.sImg[l]; t.refS = v.sImgS[l]; }
+			else { t.ref = e->d_img[l] + Pls * id; t.refS = e->d_imgS[l] + e->skewPitch(l) * id; }
 			t.qArr = e->d_imgQ[l]; t.sArr = e->d_imgS[l]; t.qCount = (unsigned)(e->skewPitch(l) * (size_t)e->nImages);
-			t.mask = (anyMask && e->hasMask[id]) ? e->d_mask[l] + Pl * id : nullptr;
+			t.mask = (anyMask && e->hasMask[id] && !v.sw) ? e->d_mask[l] + Pls * id : nullptr;
 			t.w = lw; t.h = lh; t.nSrc = v.nNb;
 			double K0[9];
-			if (l == 0) memcpy(K0, v.K, sizeof(K0)); else scaleK(v.K, e->w, e->h, lw, lh, K0);
+			if (l == 0) memcpy(K0, v.K, sizeof(K0)); else scaleK(v.K, cw, ch, lw, lh, K0);
 			inv33(K0, t.Hr);
 			t.hrUpper = (t.Hr[1] == 0.0 && t.Hr[3] == 0.0 && t.Hr[6] == 0.0 && t.Hr[7] == 0.0) ? 1 : 0;
 			t.fx = K0[0]; t.fy = K0[4]; t.cx = K0[2]; t.cy = K0[5];
@@ -479,12 +495,12 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 					s.img = sv.sImg[l]; s.imgS = sv.sImgS[l]; s.imgQ = sv.sImgQ[l]; s.w = jw; s.h = jh;
 					if (l == 0) memcpy(Kj, sv.K, sizeof(Kj)); else scaleK(sv.K, sv.sw, sv.sh, jw, jh, Kj);
 				} else {
-					s.img = e->d_img[l] + Pl * v.nb[k];
+					s.img = e->d_img[l] + Pls * v.nb[k];
 					s.imgS = e->d_imgS[l] + e->skewPitch(l) * v.nb[k];
 					s.imgQ = e->d_imgQ[l] + e->skewPitch(l) * v.nb[k];
 					s.qBase = (unsigned)(e->skewPitch(l) * (size_t)v.nb[k]);
-					s.w = lw; s.h = lh;
-					if (l == 0) memcpy(Kj, sv.K, sizeof(Kj)); else scaleK(sv.K, e->w, e->h, lw, lh, Kj);
+					s.w = slw; s.h = slh;
+					if (l == 0) memcpy(Kj, sv.K, sizeof(Kj)); else scaleK(sv.K, e->w, e->h, slw, slh, Kj);
 				}
 				double KR[9], dC[3];
 				mul33(Kj, sv.R, KR);
@@ -498,8 +514,8 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 					double tm[9], vv[3], RdT[9], iKd[9], t2[9], KdRd[9];
 					const double* Kd = Kj; const double* Rd = sv.R; const double* Cd = sv.C;
 					if (sv.sDepth) { s.depth = sv.sDepth; s.dw = sv.dw; s.dh = sv.dh; Kd = sv.Kd; Rd = sv.Rd; Cd = sv.Cd; }
-					else if (sv.sw) { e->err = "geometric round: a source view with its own image size needs pmhip_scene_set_source_depth"; return PMHIP_E_ARG; }
-					else { s.depth = e->d_snap + P0 * v.nb[k]; s.dw = e->w; s.dh = e->h; }
+					else if (sv.sw) { s.depth = sv.oSnap; s.dw = sv.sw; s.dh = sv.sh; }   // its own previous-round map (own size, own camera = Kj at level 0)
+					else { s.depth = e->d_snap + P0s * v.nb[k]; s.dw = e->w; s.dh = e->h; }
 					mul33(Kd, Rd, KdRd);
 					mul33(KdRd, R0T, tm); for (int i = 0; i < 9; ++i) s.Tl[i] = (float)tm[i];
 					for (int i = 0; i < 3; ++i) dC[i] = v.C[i] - Cd[i];
@@ -514,9 +530,9 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 			PMUpTask& u = hu[b];
 			memset(&u, 0, sizeof(u));
 			if (l == S && S > 0) { // coarsest: INTER_NEAREST of the caller's initial estimate
-				u.sdepth = e->d_depth + P0 * id; u.snormal = e->d_normal + P0 * 3 * id; u.ddepth = t.depth; u.dnormal = t.normal; u.dprior = nullptr;
+				u.sdepth = e->depthOf(id); u.snormal = e->normalOf(id); u.ddepth = t.depth; u.dnormal = t.normal; u.dprior = nullptr;
 			} else if (l < S) {
-				const size_t Pc = (size_t)e->lw(l + 1) * e->lh(l + 1);
+				const size_t Pc = (size_t)lvlSize(cw, l + 1) * lvlSize(ch, l + 1);
 				float* cb = e->d_lvl[l + 1] + Pc * 6 * b;
 				u.sdepth = cb; u.snormal = cb + Pc; u.ddepth = t.depth; u.dnormal = t.normal; u.dprior = const_cast<float*>(t.prior);
 			}
@@ -527,9 +543,9 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 		HIPCHK(e, hipMemcpyAsync(du, hu, sizeof(PMUpTask) * nB, hipMemcpyHostToDevice, e->stream));
 		const int eb = (int)std::min<size_t>((Pl + 255) / 256, 4096);
 		if (l == S && S > 0)
-			hipLaunchKernelGGL(pm_nearest_down_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, e->w, e->h, lw, lh, 1 << S);
+			hipLaunchKernelGGL(pm_nearest_down_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, cw, ch, lw, lh, 1 << S);
 		else if (l < S)
-			hipLaunchKernelGGL(pm_upsample_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, e->lw(l + 1), e->lh(l + 1), lw, lh, nearestDepth);
+			hipLaunchKernelGGL(pm_upsample_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, lvlSize(cw, l + 1), lvlSize(ch, l + 1), lw, lh, nearestDepth);
 		// pass A: ScoreDepthMapTmp
 		const int PPB = PM_BLOCK / G;
 		const uint32_t passInit = (uint32_t)l * 64u + 32u + (geo ? 16u + (uint32_t)nGeometricIter : 0u);
@@ -610,6 +626,35 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 	hipLaunchKernelGGL(pm_finalize_kernel, dim3((unsigned)std::min<size_t>((P0 + 255) / 256, 4096), nB), dim3(256), 0, e->stream, e->d_tasks, th);
 	HIPCHK(e, hipGetLastError());
 	for (int b = 0; b < nB; ++b) e->views[ids[b]].hasMaps = true;
+	return 0;
+}
+
+
+// One DepthMapsData::EstimateDepthMap for each view of the batch.  The reference sizes every depth map on its own image (DepthMapsData::InitViews, SceneDensify.cpp:306-459):
+// the views of a batch are grouped by size -- the scene's, or the one a view carries (pmhip_scene_set_view_sized) -- and each size class sweeps on its own.
+static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHipParams& p, int nGeometricIter) {
+	if (nB <= 0) return 0;
+	if (nGeometricIter >= 0 && !e->geom) { e->err = "geometric round requested but engine initialised with bGeomConsistency == 0"; return PMHIP_E_STATE; }
+	const int S = nGeometricIter < 0 ? (int)p.nSubResolutionLevels : 0;
+	if (S > e->nLevels || S > 3) { e->err = "nSubResolutionLevels exceeds the pyramid allocated by pmhip_scene_create"; return PMHIP_E_ARG; }
+	int rc = buildPyramid(e); if (rc) return rc;
+	rc = buildSidePyramids(e); if (rc) return rc;
+	std::vector<std::pair<int, int>> sizes; std::vector<std::vector<int32_t>> members;   // size classes in order of first appearance
+	int maxN = 0, maxW = 0, maxH = 0;
+	for (int b = 0; b < nB; ++b) {
+		const int id = ids[b];
+		if (id < 0 || id >= e->nImages || !e->views[id].set) { e->err = "view not set"; return PMHIP_E_ARG; }
+		const std::pair<int, int> sz(e->vw(id), e->vh(id));
+		size_t c = 0; while (c < sizes.size() && sizes[c] != sz) ++c;
+		if (c == sizes.size()) { sizes.push_back(sz); members.emplace_back(); }
+		members[c].push_back(id);
+		maxN = std::max(maxN, (int)members[c].size()); maxW = std::max(maxW, sz.first); maxH = std::max(maxH, sz.second);
+	}
+	rc = ensureBatch(e, maxN, maxW, maxH); if (rc) return rc;
+	for (size_t c = 0; c < sizes.size(); ++c) {
+		rc = estimateClass(e, members[c].data(), (int)members[c].size(), sizes[c].first, sizes[c].second, p, nGeometricIter);
+		if (rc) return rc;
+	}
 	return 0;
 }
 
@@ -734,7 +779,10 @@ int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevi
 		if (v.sw) {   // the view goes back to the scene's size: its own pyramid is not needed any more
 			HIPCHK(e, hipStreamSynchronize(e->stream));
 			for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgS[l]) hipFree(v.sImgS[l]); if (v.sImgQ[l]) hipFree(v.sImgQ[l]); v.sImg[l] = v.sImgS[l] = nullptr; v.sImgQ[l] = nullptr; }
-			v.sw = v.sh = 0; v.sideDirty = false;
+			if (v.oDepth) hipFree(v.oDepth); if (v.oNormal) hipFree(v.oNormal); if (v.oConf) hipFree(v.oConf); if (v.oSnap) hipFree(v.oSnap);
+			if (v.oFDepth) hipFree(v.oFDepth); if (v.oFConf) hipFree(v.oFConf); if (v.oBgr) hipFree(v.oBgr);
+			v.oDepth = v.oNormal = v.oConf = v.oSnap = v.oFDepth = v.oFConf = nullptr; v.oBgr = nullptr;
+			v.sw = v.sh = 0; v.sideDirty = false; v.hasMaps = false;
 		}
 		const size_t P0 = (size_t)e->w * e->h;
 		HIPCHK(e, hipMemcpyAsync(e->d_img[0] + P0 * idx, gray, sizeof(float) * P0, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
@@ -806,7 +854,13 @@ int pmhip_scene_set_view_sized(pmhip_engine* e, int idx, const float* gray, int 
 			HIPCHK(e, hipMalloc(&v.sImgS[l], sizeof(float) * (size_t)(lw + lh - 1) * lh));
 			HIPCHK(e, hipMalloc(&v.sImgQ[l], sizeof(float4) * (size_t)(lw + lh - 1) * lh));
 		}
-		v.sw = w; v.sh = h;
+		// its own maps (DepthData::depthMap / normalMap / confMap of its own size), "unset" like the scene's after pmhip_scene_create
+		const size_t P = (size_t)w * h;
+		HIPCHK(e, hipMalloc(&v.oDepth, sizeof(float) * P)); HIPCHK(e, hipMalloc(&v.oNormal, sizeof(float) * P * 3));
+		HIPCHK(e, hipMalloc(&v.oConf, sizeof(float) * P)); HIPCHK(e, hipMalloc(&v.oSnap, sizeof(float) * P));
+		HIPCHK(e, hipMemsetAsync(v.oDepth, 0, sizeof(float) * P, e->stream)); HIPCHK(e, hipMemsetAsync(v.oNormal, 0, sizeof(float) * P * 3, e->stream));
+		HIPCHK(e, hipMemsetAsync(v.oConf, 0, sizeof(float) * P, e->stream)); HIPCHK(e, hipMemsetAsync(v.oSnap, 0, sizeof(float) * P, e->stream));
+		v.sw = w; v.sh = h; v.hasMaps = false;
 	}
 	HIPCHK(e, hipMemcpyAsync(v.sImg[0], gray, sizeof(float) * (size_t)w * h, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
 	if (!onDevice) HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -850,16 +904,17 @@ int pmhip_scene_commit_round(pmhip_engine* e) {
 	if (!e || !e->d_snap) return PMHIP_E_ARG;
 	HIPCHK(e, hipSetDevice(e->device));
 	HIPCHK(e, hipMemcpyAsync(e->d_snap, e->d_depth, sizeof(float) * (size_t)e->w * e->h * e->nImages, hipMemcpyDeviceToDevice, e->stream));
+	for (const SceneView& v : e->views) if (v.sw) HIPCHK(e, hipMemcpyAsync(v.oSnap, v.oDepth, sizeof(float) * (size_t)v.sw * v.sh, hipMemcpyDeviceToDevice, e->stream));
 	return 0;
 }
 
 int pmhip_scene_reset_view(pmhip_engine* e, int idx) {
 	if (!e || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
 	HIPCHK(e, hipSetDevice(e->device));
-	const size_t P0 = (size_t)e->w * e->h;
-	HIPCHK(e, hipMemsetAsync(e->d_depth + P0 * idx, 0, sizeof(float) * P0, e->stream));
-	HIPCHK(e, hipMemsetAsync(e->d_normal + P0 * 3 * idx, 0, sizeof(float) * P0 * 3, e->stream));
-	HIPCHK(e, hipMemsetAsync(e->d_conf + P0 * idx, 0, sizeof(float) * P0, e->stream));
+	const size_t P0 = e->vpix(idx);
+	HIPCHK(e, hipMemsetAsync(e->depthOf(idx), 0, sizeof(float) * P0, e->stream));
+	HIPCHK(e, hipMemsetAsync(e->normalOf(idx), 0, sizeof(float) * P0 * 3, e->stream));
+	HIPCHK(e, hipMemsetAsync(e->confOf(idx), 0, sizeof(float) * P0, e->stream));
 	e->views[idx].hasMaps = false;
 	return 0;
 }
@@ -867,9 +922,9 @@ int pmhip_scene_reset_view(pmhip_engine* e, int idx) {
 int pmhip_scene_set_maps(pmhip_engine* e, int idx, const float* depth, const float* normal) {
 	if (!e || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
 	HIPCHK(e, hipSetDevice(e->device));
-	const size_t P0 = (size_t)e->w * e->h;
-	if (depth) HIPCHK(e, hipMemcpyAsync(e->d_depth + P0 * idx, depth, sizeof(float) * P0, hipMemcpyHostToDevice, e->stream));
-	if (normal) HIPCHK(e, hipMemcpyAsync(e->d_normal + P0 * 3 * idx, normal, sizeof(float) * P0 * 3, hipMemcpyHostToDevice, e->stream));
+	const size_t P0 = e->vpix(idx);
+	if (depth) HIPCHK(e, hipMemcpyAsync(e->depthOf(idx), depth, sizeof(float) * P0, hipMemcpyHostToDevice, e->stream));
+	if (normal) HIPCHK(e, hipMemcpyAsync(e->normalOf(idx), normal, sizeof(float) * P0 * 3, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(e, hipStreamSynchronize(e->stream));
 	if (depth) e->views[idx].hasMaps = true;
 	return 0;
@@ -881,6 +936,7 @@ int pmhip_scene_set_mask(pmhip_engine* e, int idx, const unsigned char* mask) {
 	const size_t P0 = (size_t)e->w * e->h;
 	if (e->hasMask.empty()) e->hasMask.assign(e->nImages, 0);
 	if (!mask) { e->hasMask[idx] = 0; return 0; }
+	if (e->views[idx].sw) { e->err = "ignore masks are kept for views of the scene's size only"; return PMHIP_E_SIZE; }
 	if (!e->d_mask[0]) for (int l = 0; l <= e->nLevels; ++l) HIPCHK(e, hipMalloc(&e->d_mask[l], (size_t)e->lw(l) * e->lh(l) * e->nImages));
 	HIPCHK(e, hipMemcpyAsync(e->d_mask[0] + P0 * idx, mask, P0, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -896,8 +952,8 @@ int pmhip_scene_set_mask_mode(pmhip_engine* e, int mode) {
 int pmhip_scene_set_conf(pmhip_engine* e, int idx, const float* conf) {
 	if (!e || !conf || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
 	HIPCHK(e, hipSetDevice(e->device));
-	const size_t P0 = (size_t)e->w * e->h;
-	HIPCHK(e, hipMemcpyAsync(e->d_conf + P0 * idx, conf, sizeof(float) * P0, hipMemcpyHostToDevice, e->stream));
+	const size_t P0 = e->vpix(idx);
+	HIPCHK(e, hipMemcpyAsync(e->confOf(idx), conf, sizeof(float) * P0, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(e, hipStreamSynchronize(e->stream));
 	return 0;
 }
@@ -905,10 +961,10 @@ int pmhip_scene_set_conf(pmhip_engine* e, int idx, const float* conf) {
 int pmhip_scene_get_maps(pmhip_engine* e, int idx, float* depth, float* normal, float* conf) {
 	if (!e || idx < 0 || idx >= e->nImages) return PMHIP_E_ARG;
 	HIPCHK(e, hipSetDevice(e->device));
-	const size_t P0 = (size_t)e->w * e->h;
-	if (depth) HIPCHK(e, hipMemcpyAsync(depth, e->d_depth + P0 * idx, sizeof(float) * P0, hipMemcpyDeviceToHost, e->stream));
-	if (normal) HIPCHK(e, hipMemcpyAsync(normal, e->d_normal + P0 * 3 * idx, sizeof(float) * P0 * 3, hipMemcpyDeviceToHost, e->stream));
-	if (conf) HIPCHK(e, hipMemcpyAsync(conf, e->d_conf + P0 * idx, sizeof(float) * P0, hipMemcpyDeviceToHost, e->stream));
+	const size_t P0 = e->vpix(idx);   // (a view with its own size returns maps of that size)
+	if (depth) HIPCHK(e, hipMemcpyAsync(depth, e->depthOf(idx), sizeof(float) * P0, hipMemcpyDeviceToHost, e->stream));
+	if (normal) HIPCHK(e, hipMemcpyAsync(normal, e->normalOf(idx), sizeof(float) * P0 * 3, hipMemcpyDeviceToHost, e->stream));
+	if (conf) HIPCHK(e, hipMemcpyAsync(conf, e->confOf(idx), sizeof(float) * P0, hipMemcpyDeviceToHost, e->stream));
 	HIPCHK(e, hipStreamSynchronize(e->stream));
 	return 0;
 }
@@ -917,11 +973,11 @@ void* pmhip_scene_device_ptr(pmhip_engine* e, int what, int idx) {
 	if (!e || idx < 0 || idx >= e->nImages) return nullptr;
 	const size_t P0 = (size_t)e->w * e->h;
 	switch (what) {
-	case 0: return e->d_img[0] + P0 * idx;
-	case 1: return e->d_depth + P0 * idx;
-	case 2: return e->d_normal + P0 * 3 * idx;
-	case 3: return e->d_conf + P0 * idx;
-	case 4: return e->d_snap + P0 * idx;
+	case 0: return e->views[idx].sw ? e->views[idx].sImg[0] : e->d_img[0] + P0 * idx;
+	case 1: return e->depthOf(idx);
+	case 2: return e->normalOf(idx);
+	case 3: return e->confOf(idx);
+	case 4: return e->snapOf(idx);
 	default: return nullptr;
 	}
 }
@@ -940,14 +996,27 @@ int pmhip_scene_filter(pmhip_engine* e, const int32_t* viewIds, int nViews, int 
 		HIPCHK(e, hipMalloc(&e->d_fvalid, e->nImages));
 		HIPCHK(e, hipMemsetAsync(e->d_fvalid, 0, e->nImages, e->stream));
 	}
+	// every view is filtered at its own size (the reference sizes each depth map on its own image): the splat buffer holds the largest reference view of the call,
+	// a view with its own size stages its result in its own buffers
+	size_t Pref = 0, Pany = 0;
+	for (int b = 0; b < nViews; ++b) {
+		const int id = viewIds[b];
+		if (id < 0 || id >= e->nImages || !e->views[id].set) { e->err = "view not set"; return PMHIP_E_ARG; }
+		Pref = std::max(Pref, e->vpix(id)); Pany = std::max(Pany, e->vpix(id));
+		SceneView& v = e->views[id];
+		for (int k = 0; k < v.nNb; ++k) if (v.nb[k] >= 0 && v.nb[k] < e->nImages) Pany = std::max(Pany, e->vpix(v.nb[k]));
+		if (v.sw && !v.oFDepth) { HIPCHK(e, hipMalloc(&v.oFDepth, sizeof(float) * e->vpix(id))); HIPCHK(e, hipMalloc(&v.oFConf, sizeof(float) * e->vpix(id))); }
+	}
 	const int CH = std::min(nViews, 4); // reference views per launch: bounds the splat buffer (8 x 8 B per pixel per view)
-	if (e->splatCap < CH) {
+	if (e->splatCap < CH || e->splatPix < Pref) {
 		HIPCHK(e, hipStreamSynchronize(e->stream));
 		if (e->d_splat) hipFree(e->d_splat); if (e->d_ftasks) hipFree(e->d_ftasks); if (e->h_ftasks) hipHostFree(e->h_ftasks);
-		HIPCHK(e, hipMalloc(&e->d_splat, sizeof(unsigned long long) * P0 * PMF_MAXN * CH));
-		HIPCHK(e, hipMalloc(&e->d_ftasks, sizeof(PMFTask) * CH));
-		HIPCHK(e, hipHostMalloc(&e->h_ftasks, sizeof(PMFTask) * CH));
-		e->splatCap = CH;
+		e->d_splat = nullptr; e->d_ftasks = nullptr; e->h_ftasks = nullptr;
+		const int cap = std::max(CH, e->splatCap); const size_t pix = std::max(Pref, e->splatPix);
+		HIPCHK(e, hipMalloc(&e->d_splat, sizeof(unsigned long long) * pix * PMF_MAXN * cap));
+		HIPCHK(e, hipMalloc(&e->d_ftasks, sizeof(PMFTask) * cap));
+		HIPCHK(e, hipHostMalloc(&e->h_ftasks, sizeof(PMFTask) * cap));
+		e->splatCap = cap; e->splatPix = pix;
 	}
 	const unsigned nCal = (unsigned)e->nImages;
 	const unsigned nMinViews = std::min(nMinViewsFilter, nCal - 1), nMinViewsAdjust = std::min(nMinViewsFilterAdjust, nCal - 1);
@@ -957,12 +1026,11 @@ int pmhip_scene_filter(pmhip_engine* e, const int32_t* viewIds, int nViews, int 
 		HIPCHK(e, hipStreamSynchronize(e->stream)); // staging reuse
 		for (int b = 0; b < nb; ++b) {
 			const int id = viewIds[b0 + b];
-			if (id < 0 || id >= e->nImages || !e->views[id].set) { e->err = "view not set"; return PMHIP_E_ARG; }
 			const SceneView& v = e->views[id];
 			PMFTask& t = e->h_ftasks[b];
 			memset(&t, 0, sizeof(t));
 			memcpy(t.ref.K, v.K, 72); memcpy(t.ref.R, v.R, 72); memcpy(t.ref.C, v.C, 24);
-			t.refDepth = e->d_depth + P0 * id; t.refConf = e->d_conf + P0 * id;
+			t.refDepth = e->depthOf(id); t.refConf = e->confOf(id);
 			t.N = 0;
 			for (int k = 0; k < v.nNb && t.N < PMF_MAXN; ++k) {
 				const int j = v.nb[k];
@@ -970,19 +1038,19 @@ int pmhip_scene_filter(pmhip_engine* e, const int32_t* viewIds, int nViews, int 
 				if (j < 0 || j >= e->nImages || !e->views[j].set || !e->views[j].hasMaps) continue;
 				const SceneView& sv = e->views[j];
 				memcpy(t.nb[t.N].K, sv.K, 72); memcpy(t.nb[t.N].R, sv.R, 72); memcpy(t.nb[t.N].C, sv.C, 24);
-				t.nbDepth[t.N] = e->d_depth + P0 * j; t.nbConf[t.N] = e->d_conf + P0 * j;
+				t.nbDepth[t.N] = e->depthOf(j); t.nbConf[t.N] = e->confOf(j); t.nbw[t.N] = e->vw(j); t.nbh[t.N] = e->vh(j);
 				++t.N;
 			}
-			t.splat = e->d_splat + P0 * PMF_MAXN * b;
-			t.outDepth = e->d_fdepth + P0 * id; t.outConf = e->d_fconf + P0 * id;
-			t.w = e->w; t.h = e->h; t.dMin = v.dMin; t.dMax = v.dMax;
+			t.splat = e->d_splat + e->splatPix * PMF_MAXN * b;
+			t.outDepth = v.sw ? v.oFDepth : e->d_fdepth + P0 * id; t.outConf = v.sw ? v.oFConf : e->d_fconf + P0 * id;
+			t.w = e->vw(id); t.h = e->vh(id); t.dMin = v.dMin; t.dMax = v.dMax;
 			t.filterable = !((unsigned)t.N < nMinViews || (unsigned)t.N < nMinViewsAdjust); // :1060-1063
 			hv[id] = t.filterable ? 1 : 0;
 		}
 		HIPCHK(e, hipMemcpyAsync(e->d_ftasks, e->h_ftasks, sizeof(PMFTask) * nb, hipMemcpyHostToDevice, e->stream));
-		const size_t nS = P0 * PMF_MAXN * nb;
+		const size_t nS = e->splatPix * PMF_MAXN * nb;
 		hipLaunchKernelGGL(pmf_clear_kernel, dim3((unsigned)std::min<size_t>((nS + 255) / 256, 65535)), dim3(256), 0, e->stream, e->d_splat, nS);
-		const unsigned gx = (unsigned)std::min<size_t>((P0 + 255) / 256, 2048);
+		const unsigned gx = (unsigned)std::min<size_t>((Pany + 255) / 256, 2048);
 		hipLaunchKernelGGL(pmf_splat_kernel, dim3(gx, nb, PMF_MAXN), dim3(256), 0, e->stream, e->d_ftasks);
 		hipLaunchKernelGGL(pmf_vote_kernel, dim3(gx, nb), dim3(256), 0, e->stream, e->d_ftasks, bAdjust, nMinViews, nMinViewsAdjust, fDepthDiffThreshold);
 		HIPCHK(e, hipGetLastError());
@@ -1000,18 +1068,19 @@ int pmhip_scene_filter(pmhip_engine* e, const int32_t* viewIds, int nViews, int 
 int pmhip_scene_gap_interpolation(pmhip_engine* e, const int32_t* viewIds, int nViews, uint32_t nIpolGapSize, float fDepthDiffThreshold) {
 	if (!e || !viewIds || nViews <= 0) return PMHIP_E_ARG;
 	HIPCHK(e, hipSetDevice(e->device));
-	const size_t P0 = (size_t)e->w * e->h;
+	size_t Pmax = 0;
+	for (int b = 0; b < nViews; ++b) { if (viewIds[b] < 0 || viewIds[b] >= e->nImages) return PMHIP_E_ARG; Pmax = std::max(Pmax, e->vpix(viewIds[b])); }
 	float* tmp = nullptr; PMGTask* dt = nullptr;
-	HIPCHK(e, hipMalloc(&tmp, sizeof(float) * P0 * 5));
+	HIPCHK(e, hipMalloc(&tmp, sizeof(float) * Pmax * 5));
 	HIPCHK(e, hipMalloc(&dt, sizeof(PMGTask) * 2));
 	const float th = fDepthDiffThreshold * 2.5f;
-	const unsigned gx = (unsigned)std::min<size_t>((P0 + 255) / 256, 4096);
 	int rc = 0;
 	for (int b = 0; b < nViews && rc == 0; ++b) {
 		const int id = viewIds[b];
-		if (id < 0 || id >= e->nImages) { rc = PMHIP_E_ARG; break; }
-		float* D = e->d_depth + P0 * id; float* N = e->d_normal + P0 * 3 * id; float* Cf = e->d_conf + P0 * id;
-		PMGTask ht[2] = {{D, N, Cf, tmp, tmp + P0, tmp + P0 * 4, e->w, e->h}, {tmp, tmp + P0, tmp + P0 * 4, D, N, Cf, e->w, e->h}};
+		const size_t P0 = e->vpix(id); const int vw = e->vw(id), vh = e->vh(id);
+		const unsigned gx = (unsigned)std::min<size_t>((P0 + 255) / 256, 4096);
+		float* D = e->depthOf(id); float* N = e->normalOf(id); float* Cf = e->confOf(id);
+		PMGTask ht[2] = {{D, N, Cf, tmp, tmp + P0, tmp + P0 * 4, vw, vh}, {tmp, tmp + P0, tmp + P0 * 4, D, N, Cf, vw, vh}};
 		if (hipMemcpyAsync(dt, ht, sizeof(ht), hipMemcpyHostToDevice, e->stream) != hipSuccess) { rc = PMHIP_E_HIP; break; }
 		hipLaunchKernelGGL(pmf_gap_kernel, dim3(gx, 1), dim3(256), 0, e->stream, dt, 1, nIpolGapSize, th);       // 1. row-wise
 		hipLaunchKernelGGL(pmf_gap_kernel, dim3(gx, 1), dim3(256), 0, e->stream, dt + 1, 0, nIpolGapSize, th);   // 2. column-wise
@@ -1026,25 +1095,25 @@ int pmhip_scene_gap_interpolation(pmhip_engine* e, const int32_t* viewIds, int n
 int pmhip_scene_remove_small_segments(pmhip_engine* e, const int32_t* viewIds, int nViews, uint32_t nSpeckleSize, float fDepthDiffThreshold) {
 	if (!e || !viewIds || nViews <= 0) return PMHIP_E_ARG;
 	HIPCHK(e, hipSetDevice(e->device));
-	const int n = e->w * e->h;
-	const size_t P0 = (size_t)n;
-	const int cap = n; // asymmetric edges are rare; n pairs is far more than ever needed
+	int nmax = 0;
+	for (int b = 0; b < nViews; ++b) { if (viewIds[b] < 0 || viewIds[b] >= e->nImages) return PMHIP_E_ARG; nmax = std::max(nmax, (int)e->vpix(viewIds[b])); }
+	const int cap = nmax; // asymmetric edges are rare; n pairs is far more than ever needed
 	int *parent = nullptr, *size = nullptr, *edges = nullptr, *nEdges = nullptr, *ovr = nullptr;
-	HIPCHK(e, hipMalloc(&parent, sizeof(int) * n)); HIPCHK(e, hipMalloc(&size, sizeof(int) * n));
+	HIPCHK(e, hipMalloc(&parent, sizeof(int) * nmax)); HIPCHK(e, hipMalloc(&size, sizeof(int) * nmax));
 	HIPCHK(e, hipMalloc(&edges, sizeof(int) * 2 * cap)); HIPCHK(e, hipMalloc(&nEdges, sizeof(int))); HIPCHK(e, hipMalloc(&ovr, sizeof(int) * 2 * cap));
 	const float th = fDepthDiffThreshold * 0.7f;
-	const unsigned gx = (unsigned)std::min<size_t>((P0 + 255) / 256, 4096);
 	int rc = 0;
 	std::vector<int> hedges, hsize;
 	for (int b = 0; b < nViews && rc == 0; ++b) {
 		const int id = viewIds[b];
-		if (id < 0 || id >= e->nImages) { rc = PMHIP_E_ARG; break; }
-		float* D = e->d_depth + P0 * id; float* N = e->d_normal + P0 * 3 * id; float* Cf = e->d_conf + P0 * id;
+		const int n = (int)e->vpix(id), vw = e->vw(id), vh = e->vh(id);
+		const unsigned gx = (unsigned)std::min<size_t>(((size_t)n + 255) / 256, 4096);
+		float* D = e->depthOf(id); float* N = e->normalOf(id); float* Cf = e->confOf(id);
 		hipMemsetAsync(nEdges, 0, sizeof(int), e->stream);
 		hipLaunchKernelGGL(pmf_cc_init_kernel, dim3(gx), dim3(256), 0, e->stream, parent, size, n);
-		hipLaunchKernelGGL(pmf_cc_hook_kernel, dim3(gx), dim3(256), 0, e->stream, D, parent, e->w, e->h, th);
+		hipLaunchKernelGGL(pmf_cc_hook_kernel, dim3(gx), dim3(256), 0, e->stream, D, parent, vw, vh, th);
 		hipLaunchKernelGGL(pmf_cc_flatten_kernel, dim3(gx), dim3(256), 0, e->stream, parent, size, n);
-		hipLaunchKernelGGL(pmf_cc_asym_kernel, dim3(gx), dim3(256), 0, e->stream, D, parent, e->w, e->h, th, edges, nEdges, cap);
+		hipLaunchKernelGGL(pmf_cc_asym_kernel, dim3(gx), dim3(256), 0, e->stream, D, parent, vw, vh, th, edges, nEdges, cap);
 		int ne = 0;
 		if (hipMemcpyAsync(&ne, nEdges, sizeof(int), hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) { rc = PMHIP_E_HIP; break; }
 		if (ne > cap) { e->err = "remove_small_segments: asymmetric edge list overflow"; rc = PMHIP_E_HIP; break; }
@@ -1073,7 +1142,7 @@ int pmhip_scene_remove_small_segments(pmhip_engine* e, const int32_t* viewIds, i
 			if (hipMemcpy(ovr, pairs.data(), sizeof(int) * pairs.size(), hipMemcpyHostToDevice) != hipSuccess) { rc = PMHIP_E_HIP; break; }
 			hipLaunchKernelGGL(pmf_cc_override_kernel, dim3((np + 255) / 256), dim3(256), 0, e->stream, size, ovr, np);
 		}
-		hipLaunchKernelGGL(pmf_cc_apply_kernel, dim3(gx), dim3(256), 0, e->stream, D, N, Cf, parent, size, e->w, e->h, (int)nSpeckleSize);
+		hipLaunchKernelGGL(pmf_cc_apply_kernel, dim3(gx), dim3(256), 0, e->stream, D, N, Cf, parent, size, vw, vh, (int)nSpeckleSize);
 		if (hipStreamSynchronize(e->stream) != hipSuccess) { rc = PMHIP_E_HIP; break; }
 	}
 	hipFree(parent); hipFree(size); hipFree(edges); hipFree(nEdges); hipFree(ovr);
@@ -1090,8 +1159,9 @@ int pmhip_scene_filter_commit(pmhip_engine* e) {
 	std::vector<unsigned char> hv(e->nImages);
 	HIPCHK(e, hipMemcpy(hv.data(), e->d_fvalid, e->nImages, hipMemcpyDeviceToHost));
 	for (int i = 0; i < e->nImages; ++i) if (hv[i] == 1) {
-		HIPCHK(e, hipMemcpyAsync(e->d_depth + P0 * i, e->d_fdepth + P0 * i, sizeof(float) * P0, hipMemcpyDeviceToDevice, e->stream));
-		HIPCHK(e, hipMemcpyAsync(e->d_conf + P0 * i, e->d_fconf + P0 * i, sizeof(float) * P0, hipMemcpyDeviceToDevice, e->stream));
+		const SceneView& v = e->views[i];
+		HIPCHK(e, hipMemcpyAsync(e->depthOf(i), v.sw ? v.oFDepth : e->d_fdepth + P0 * i, sizeof(float) * e->vpix(i), hipMemcpyDeviceToDevice, e->stream));
+		HIPCHK(e, hipMemcpyAsync(e->confOf(i), v.sw ? v.oFConf : e->d_fconf + P0 * i, sizeof(float) * e->vpix(i), hipMemcpyDeviceToDevice, e->stream));
 	}
 	HIPCHK(e, hipMemsetAsync(e->d_fvalid, 0, e->nImages, e->stream));
 	HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1103,14 +1173,17 @@ int pmhip_scene_copy(pmhip_engine* e, int what, int firstIdx, int count, void* d
 	HIPCHK(e, hipSetDevice(e->device));
 	char* base = (char*)pmhip_scene_device_ptr(e, what, firstIdx);
 	if (!base) return PMHIP_E_ARG;
-	const size_t bytes = sizeof(float) * (size_t)e->w * e->h * (what == 2 ? 3 : 1) * count;
+	bool sized = false;
+	for (int i = firstIdx; i < firstIdx + count; ++i) sized = sized || e->views[i].sw;
+	if (sized && count > 1) { e->err = "pmhip_scene_copy: a range that contains a view with its own size must be copied view by view"; return PMHIP_E_SIZE; }
+	const size_t bytes = sizeof(float) * (sized ? e->vpix(firstIdx) : (size_t)e->w * e->h * count) * (what == 2 ? 3 : 1);
+	if (sized && toEngine && what == 0) e->views[firstIdx].sideDirty = true;
 	HIPCHK(e, hipMemcpyAsync(toEngine ? (void*)base : devPtr, toEngine ? devPtr : (void*)base, bytes, hipMemcpyDeviceToDevice, e->stream));
 	if (toEngine && what == 0) e->pyramidDirty = true;
 	if (toEngine && what == 1) for (int i = firstIdx; i < firstIdx + count; ++i) e->views[i].hasMaps = true;   // depth maps gathered from other ranks
 	return 0;
 }
 
-// after a stream synchronisation: did a band kernel give up waiting for its preceding band (pm_band.hip: bounded waits instead of a hung device)?
 int pmhip_sync(pmhip_engine* e) { if (!e) return PMHIP_E_ARG; HIPCHK(e, hipSetDevice(e->device)); HIPCHK(e, hipStreamSynchronize(e->stream)); return 0; }
 void* pmhip_stream(pmhip_engine* e) { return e ? (void*)e->stream : nullptr; }
 
@@ -1250,12 +1323,23 @@ int pmhip_resize(pmhip_engine* e, int kind, const float* src, int w, int h, int 
 // ---- FuseDepthMaps (libs/MVS/SceneDensify.cpp:1372-1650) on the resident scene -------------------------------------------------
 static int ensureFuse(pmhip_engine* e) {
 	auto& f = e->fu;
-	if (f.depth) return 0;
-	const size_t P = (size_t)e->w * e->h, N = (size_t)e->nImages;
+	size_t P = (size_t)e->w * e->h; const size_t N = (size_t)e->nImages;
+	for (int i = 0; i < e->nImages; ++i) P = std::max(P, e->vpix(i));           // a slab holds the largest image
+	if (f.depth && f.slab >= P) return 0;
+	if (f.depth) {                                                              // a view grew: start over (the colour images and the output stay)
+		HIPCHK(e, hipStreamSynchronize(e->stream));
+		void* ptrs[] = {f.depth, f.claimed, f.resv, f.cams, f.recN, f.recColor, f.recX, f.recWeight, f.recNormal, f.recView, f.recProj, f.pend[0], f.pend[1], f.counters, f.nDepthsDev,
+		                f.tileSums, f.tileOff, f.normalS, f.confS, f.bgrS, f.dims};
+		for (void* q : ptrs) if (q) hipFree(q);
+		if (f.pin) hipHostFree(f.pin);
+		f.depth = nullptr; f.claimed = f.resv = nullptr; f.cams = nullptr; f.recN = f.recColor = nullptr; f.recX = f.recWeight = f.recNormal = nullptr; f.recView = f.recProj = nullptr;
+		f.pend[0] = f.pend[1] = nullptr; f.counters = nullptr; f.nDepthsDev = nullptr; f.tileSums = f.tileOff = nullptr; f.normalS = f.confS = nullptr; f.bgrS = nullptr; f.dims = nullptr; f.pin = nullptr;
+	}
 	HIPCHK(e, hipMalloc(&f.depth, sizeof(float) * P * N));
 	HIPCHK(e, hipMalloc(&f.claimed, sizeof(uint32_t) * P * N));
 	HIPCHK(e, hipMalloc(&f.resv, sizeof(uint32_t) * P * N));
 	HIPCHK(e, hipMalloc(&f.cams, sizeof(PMFuseCam) * N));
+	HIPCHK(e, hipMalloc(&f.dims, sizeof(int) * 2 * N));
 	HIPCHK(e, hipMalloc(&f.recN, P)); HIPCHK(e, hipMalloc(&f.recColor, 3 * P));
 	HIPCHK(e, hipMalloc(&f.recX, sizeof(float) * 3 * P)); HIPCHK(e, hipMalloc(&f.recNormal, sizeof(float) * 3 * P));
 	HIPCHK(e, hipMalloc(&f.recWeight, sizeof(float) * PMFU_MAXV * P));
@@ -1265,6 +1349,7 @@ static int ensureFuse(pmhip_engine* e) {
 	const size_t nTiles = (P + PMFU_TILE - 1) / PMFU_TILE;
 	HIPCHK(e, hipMalloc(&f.tileSums, sizeof(uint2) * nTiles)); HIPCHK(e, hipMalloc(&f.tileOff, sizeof(uint2) * nTiles));
 	HIPCHK(e, hipHostMalloc(&f.pin, sizeof(uint32_t) * 16));
+	f.slab = P;
 	return 0;
 }
 
@@ -1273,7 +1358,16 @@ int pmhip_scene_set_color(pmhip_engine* e, int idx, const unsigned char* bgr) {
 	HIPCHK(e, hipSetDevice(e->device));
 	auto& f = e->fu;
 	const size_t P = (size_t)e->w * e->h;
-	if (!f.bgr) { HIPCHK(e, hipMalloc(&f.bgr, 3 * P * e->nImages)); f.hasBgr.assign(e->nImages, 0); }
+	if (f.hasBgr.empty()) f.hasBgr.assign(e->nImages, 0);
+	SceneView& v = e->views[idx];
+	if (v.sw) {                                                                  // a view with its own size keeps its colour image itself
+		if (!v.oBgr) HIPCHK(e, hipMalloc(&v.oBgr, 3 * e->vpix(idx)));
+		HIPCHK(e, hipMemcpyAsync(v.oBgr, bgr, 3 * e->vpix(idx), hipMemcpyHostToDevice, e->stream));
+		HIPCHK(e, hipStreamSynchronize(e->stream));
+		f.hasBgr[idx] = 1;
+		return 0;
+	}
+	if (!f.bgr) HIPCHK(e, hipMalloc(&f.bgr, 3 * P * e->nImages));
 	HIPCHK(e, hipMemcpyAsync(f.bgr + 3 * P * idx, bgr, 3 * P, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(e, hipStreamSynchronize(e->stream));
 	f.hasBgr[idx] = 1;
@@ -1282,19 +1376,39 @@ int pmhip_scene_set_color(pmhip_engine* e, int idx, const unsigned char* bgr) {
 
 int pmhip_scene_fuse(pmhip_engine* e, const int32_t* order, int nOrder, const PMHipFuseParams* prm, uint64_t* nPoints, uint64_t* nViews, uint64_t* nDepths) {
 	if (!e || !order || nOrder <= 0 || !prm || e->nImages < 1) return PMHIP_E_ARG;
-	if (e->w > 65535 || e->h > 65535) { e->err = "fusion stores projections as 16-bit pixel coordinates"; return PMHIP_E_SIZE; }
+	bool mixed = false;
+	for (int i = 0; i < e->nImages; ++i) { mixed = mixed || e->views[i].sw; if (e->vw(i) > 65535 || e->vh(i) > 65535) { e->err = "fusion stores projections as 16-bit pixel coordinates"; return PMHIP_E_SIZE; } }
 	HIPCHK(e, hipSetDevice(e->device));
 	int rc = ensureFuse(e); if (rc) return rc;
 	auto& f = e->fu;
-	const size_t P = (size_t)e->w * e->h, N = (size_t)e->nImages;
+	const size_t P = f.slab, N = (size_t)e->nImages, P0 = (size_t)e->w * e->h;
 	bool wantColor = prm->bEstimateColor != 0;
-	if (wantColor) for (int i = 0; i < e->nImages; ++i) if (e->views[i].set && (!f.bgr || !f.hasBgr[i])) { e->err = "bEstimateColor needs pmhip_scene_set_color for every view"; return PMHIP_E_STATE; }
+	if (wantColor) for (int i = 0; i < e->nImages; ++i) if (e->views[i].set && (f.hasBgr.empty() || !f.hasBgr[i])) { e->err = "bEstimateColor needs pmhip_scene_set_color for every view"; return PMHIP_E_STATE; }
 	const bool wantNormal = prm->bEstimateNormal != 0;
 	// cameras (P composed like Camera::ComposeP)
 	std::vector<PMFuseCam> hc(N);
 	for (size_t i = 0; i < N; ++i) { memset(&hc[i], 0, sizeof(PMFuseCam)); if (!e->views[i].set) continue; memcpy(hc[i].K, e->views[i].K, 72); memcpy(hc[i].R, e->views[i].R, 72); memcpy(hc[i].C, e->views[i].C, 24); pmfu_composeP(hc[i]); }
 	HIPCHK(e, hipMemcpyAsync(f.cams, hc.data(), sizeof(PMFuseCam) * N, hipMemcpyHostToDevice, e->stream));
-	HIPCHK(e, hipMemcpyAsync(f.depth, e->d_depth, sizeof(float) * P * N, hipMemcpyDeviceToDevice, e->stream));
+	// working copies of the depth maps, one slab per image; with views of different sizes also the read-only inputs are gathered into slabs (each image with its own row pitch)
+	const bool slabs = mixed || P != P0;
+	if (!slabs) HIPCHK(e, hipMemcpyAsync(f.depth, e->d_depth, sizeof(float) * P * N, hipMemcpyDeviceToDevice, e->stream));
+	else {
+		if (!f.normalS) { HIPCHK(e, hipMalloc(&f.normalS, sizeof(float) * 3 * P * N)); HIPCHK(e, hipMalloc(&f.confS, sizeof(float) * P * N)); }
+		if (wantColor && !f.bgrS) HIPCHK(e, hipMalloc(&f.bgrS, 3 * P * N));
+		HIPCHK(e, hipMemsetAsync(f.depth, 0, sizeof(float) * P * N, e->stream));
+		std::vector<int> hw(N), hh(N);
+		for (size_t i = 0; i < N; ++i) {
+			const size_t Pi = e->vpix((int)i);
+			hw[i] = e->vw((int)i); hh[i] = e->vh((int)i);
+			HIPCHK(e, hipMemcpyAsync(f.depth + P * i, e->depthOf((int)i), sizeof(float) * Pi, hipMemcpyDeviceToDevice, e->stream));
+			HIPCHK(e, hipMemcpyAsync(f.normalS + 3 * P * i, e->normalOf((int)i), sizeof(float) * 3 * Pi, hipMemcpyDeviceToDevice, e->stream));
+			HIPCHK(e, hipMemcpyAsync(f.confS + P * i, e->confOf((int)i), sizeof(float) * Pi, hipMemcpyDeviceToDevice, e->stream));
+			if (wantColor && e->views[i].set) HIPCHK(e, hipMemcpyAsync(f.bgrS + 3 * P * i, e->views[i].sw ? e->views[i].oBgr : f.bgr + 3 * P0 * i, 3 * Pi, hipMemcpyDeviceToDevice, e->stream));
+		}
+		HIPCHK(e, hipMemcpyAsync(f.dims, hw.data(), sizeof(int) * N, hipMemcpyHostToDevice, e->stream));          // iw = dims, ih = dims + N
+		HIPCHK(e, hipMemcpyAsync(f.dims + N, hh.data(), sizeof(int) * N, hipMemcpyHostToDevice, e->stream));
+		HIPCHK(e, hipStreamSynchronize(e->stream));                                 // hw / hh live on this frame
+	}
 	hipLaunchKernelGGL(pmfu_fill_u32, dim3(2048), dim3(256), 0, e->stream, f.claimed, P * N, PMFU_NO_ID);
 	hipLaunchKernelGGL(pmfu_fill_u32, dim3(2048), dim3(256), 0, e->stream, f.resv, P * N, PMFU_FREE);
 	HIPCHK(e, hipMemsetAsync(f.counters, 0, sizeof(uint32_t) * 8, e->stream));
@@ -1321,27 +1435,29 @@ int pmhip_scene_fuse(pmhip_engine* e, const int32_t* order, int nOrder, const PM
 	const unsigned nMin = std::min<unsigned>(prm->nMinViewsFuse, (unsigned)e->nImages);
 	const float normalError = cosf(prm->fNormalDiffThreshold * (3.14159265358979323846f / 180.f));   // COS(FD2R(x)), SceneDensify.cpp:1455
 	f.rounds = 0;
-	const unsigned nTiles = (unsigned)((P + PMFU_TILE - 1) / PMFU_TILE);
 	for (int o = 0; o < nOrder; ++o) {
 		const int A = order[o];
 		if (A < 0 || A >= e->nImages || !e->views[A].set) { e->err = "fuse: view not set"; return PMHIP_E_ARG; }
+		const size_t PA = e->vpix(A);                                               // image A's own pixels: seeds, records, compaction
+		const unsigned nTiles = (unsigned)((PA + PMFU_TILE - 1) / PMFU_TILE);
 		PMFuseCtx c; memset(&c, 0, sizeof(c));
 		c.w = e->w; c.h = e->h; c.nImages = e->nImages; c.A = A;
+		c.slab = P; if (slabs) { c.iw = f.dims; c.ih = f.dims + N; }
 		for (int k = 0; k < e->views[A].nNb && c.nNb < PMFU_MAXNB; ++k) { const int b = e->views[A].nb[k]; if (b >= 0 && b < e->nImages && b != A && e->views[b].set) c.nb[c.nNb++] = b; }
-		c.depth = f.depth; c.normal = e->d_normal; c.conf = e->d_conf; c.bgr = f.bgr; c.claimed = f.claimed; c.resv = f.resv; c.cams = f.cams;
+		c.depth = f.depth; c.normal = slabs ? f.normalS : e->d_normal; c.conf = slabs ? f.confS : e->d_conf; c.bgr = slabs ? (wantColor ? f.bgrS : nullptr) : f.bgr; c.claimed = f.claimed; c.resv = f.resv; c.cams = f.cams;
 		c.nMinViewsFuse = nMin; c.fDepthDiffThreshold = prm->fDepthDiffThreshold; c.normalError = normalError;
 		c.bEstimateColor = wantColor ? 1 : 0; c.bEstimateNormal = wantNormal ? 1 : 0;
 		c.recN = f.recN; c.recX = f.recX; c.recView = f.recView; c.recWeight = f.recWeight; c.recProj = f.recProj; c.recColor = f.recColor; c.recNormal = f.recNormal;
 		if (prm->nMinViewsFuse < 2) {   // MergeDepthMaps (Scene::DenseReconstruction, SceneDensify.cpp:1695-1698)
-			hipLaunchKernelGGL(pmfu_merge_kernel, dim3((unsigned)std::min<size_t>((P + 255) / 256, 4096)), dim3(256), 0, e->stream, c, f.nDepthsDev);
-			hipLaunchKernelGGL(pmfu_tile_sums, dim3(nTiles), dim3(PMFU_TB), 0, e->stream, f.recN, (uint32_t)P, f.tileSums);
+			hipLaunchKernelGGL(pmfu_merge_kernel, dim3((unsigned)std::min<size_t>((PA + 255) / 256, 4096)), dim3(256), 0, e->stream, c, f.nDepthsDev);
+			hipLaunchKernelGGL(pmfu_tile_sums, dim3(nTiles), dim3(PMFU_TB), 0, e->stream, f.recN, (uint32_t)PA, f.tileSums);
 			hipLaunchKernelGGL(pmfu_scan_tiles, dim3(1), dim3(1024), 0, e->stream, f.tileSums, nTiles, f.counters + 2, f.tileOff);
 			hipLaunchKernelGGL(pmfu_scatter_kernel, dim3(nTiles), dim3(PMFU_TB), 0, e->stream, c, f.tileOff, out);
 			HIPCHK(e, hipGetLastError());
 			continue;
 		}
 		HIPCHK(e, hipMemsetAsync(f.counters, 0, sizeof(uint32_t) * 2, e->stream));
-		hipLaunchKernelGGL(pmfu_seed_kernel, dim3((unsigned)std::min<size_t>((P + 255) / 256, 4096)), dim3(256), 0, e->stream, c, f.pend[0], f.counters, f.nDepthsDev);
+		hipLaunchKernelGGL(pmfu_seed_kernel, dim3((unsigned)std::min<size_t>((PA + 255) / 256, 4096)), dim3(256), 0, e->stream, c, f.pend[0], f.counters, f.nDepthsDev);
 		HIPCHK(e, hipMemcpyAsync(f.pin, f.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
 		HIPCHK(e, hipStreamSynchronize(e->stream));
 		uint32_t n = f.pin[0]; int cur = 0;
@@ -1356,7 +1472,7 @@ int pmhip_scene_fuse(pmhip_engine* e, const int32_t* order, int nOrder, const PM
 			if (f.pin[0] >= n) { e->err = "fuse: no progress in a reservation round"; return PMHIP_E_STATE; }
 			n = f.pin[0]; cur ^= 1;
 		}
-		hipLaunchKernelGGL(pmfu_tile_sums, dim3(nTiles), dim3(PMFU_TB), 0, e->stream, f.recN, (uint32_t)P, f.tileSums);
+		hipLaunchKernelGGL(pmfu_tile_sums, dim3(nTiles), dim3(PMFU_TB), 0, e->stream, f.recN, (uint32_t)PA, f.tileSums);
 		hipLaunchKernelGGL(pmfu_scan_tiles, dim3(1), dim3(1024), 0, e->stream, f.tileSums, nTiles, f.counters + 2, f.tileOff);
 		hipLaunchKernelGGL(pmfu_scatter_kernel, dim3(nTiles), dim3(PMFU_TB), 0, e->stream, c, f.tileOff, out);
 		HIPCHK(e, hipGetLastError());

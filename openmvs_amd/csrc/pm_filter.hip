@@ -22,6 +22,7 @@ struct PMFTask {          // one reference view
 	float* outDepth; float* outConf;
 	int N, w, h, filterable;
 	float dMin, dMax;
+	int nbw[PMF_MAXN], nbh[PMF_MAXN];   // every neighbour's maps have their own size (depthData.depthMap.size(), SceneDensify.cpp:1085)
 };
 
 __device__ __forceinline__ void pmf_mulMV(const double* M, double v0, double v1, double v2, double* o) {
@@ -50,12 +51,14 @@ __global__ void pmf_splat_kernel(const PMFTask* __restrict__ tasks) {
 	const int n = blockIdx.z;
 	if (!t.filterable || n >= t.N) return;
 	const size_t P = (size_t)t.w * t.h;
+	const int nw = t.nbw[n];
+	const size_t Pn = (size_t)nw * t.nbh[n];
 	const float* __restrict__ src = t.nbDepth[n];
 	unsigned long long* dst = t.splat + (size_t)n * P;
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < Pn; i += (size_t)gridDim.x * blockDim.x) {
 		const float depth = src[i];
 		if (depth == 0) continue;
-		const int xj = (int)(i % t.w), yi = (int)(i / t.w);
+		const int xj = (int)(i % nw), yi = (int)(i / nw);
 		double X[3], camX[3];
 		pmf_I2W(t.nb[n], (double)xj, (double)yi, (double)depth, X);
 		pmf_W2C(t.ref, X, camX);
@@ -106,7 +109,7 @@ __global__ void pmf_vote_kernel(const PMFTask* __restrict__ tasks, int bAdjust, 
 							pmf_W2C(t.nb[n], X, cx);
 							const double ux = t.nb[n].K[2] + t.nb[n].K[0] * (cx[0] / cx[2]), uy = t.nb[n].K[5] + t.nb[n].K[4] * (cx[1] / cx[2]);
 							const int x = (int)floor(ux + .5), y = (int)floor(uy + .5); // ROUND2INT(double)
-							if (x >= 0 && y >= 0 && x < w && y < h) { const float c = t.nbConf[n][(size_t)y * w + x]; negConf += (c > 0 ? c : cn); }
+							if (x >= 0 && y >= 0 && x < t.nbw[n] && y < t.nbh[n]) { const float c = t.nbConf[n][(size_t)y * t.nbw[n] + x]; negConf += (c > 0 ? c : cn); }   // confMap.isInside(x), :1181
 							else negConf += cn;
 						}
 						++nNeg;

@@ -34,7 +34,9 @@ struct PMFuseCam { double K[9], R[9], C[3], P[12]; };
 
 // everything a seed of image A needs; arrays are [nImages][...] slabs of the scene
 struct PMFuseCtx {
-	int w, h, nImages;
+	int w, h, nImages;             // w, h: the size of every image's maps -- unless iw / ih give each image its own (the reference sizes every depth map on its image)
+	const int* iw; const int* ih;  // [nImages] or null
+	size_t slab;                   // pixels between two images in the [nImages][...] arrays and in the record arrays; 0 = w*h
 	int A;                         // current image
 	int nNb; int nb[PMFU_MAXNB];   // its neighbours that have a depth map, in neighbour-list order
 	float* depth;                  // working copies (zeroed by occlusion), [nImages][w*h]
@@ -54,6 +56,10 @@ struct PMFuseCtx {
 	uint8_t* recColor;             // [3][w*h]
 	float* recNormal;              // [3][w*h]
 };
+
+PM_HD int pmfu_w(const PMFuseCtx& c, int img) { return c.iw ? c.iw[img] : c.w; }
+PM_HD int pmfu_h(const PMFuseCtx& c, int img) { return c.ih ? c.ih[img] : c.h; }
+PM_HD size_t pmfu_slab(const PMFuseCtx& c) { return c.slab ? c.slab : (size_t)c.w * c.h; }
 
 // Camera::ComposeP -> AssembleProjectionMatrix (libs/MVS/Camera.cpp:173-180): M = K*R, P = [M | M*(-C)], sums left to right
 inline void pmfu_composeP(PMFuseCam& c) {
@@ -87,7 +93,8 @@ PM_HD uint8_t pmfu_toU8(float v) { const int i = pmfu_round2int(v); return (uint
 
 // the seed's 3D point (float, as stored in PointCloud::points) from pixel p of image A
 PM_HD void pmfu_seed_point(const PMFuseCtx& c, uint32_t p, float depth, float* point) {
-	const int i = (int)(p / (uint32_t)c.w), j = (int)(p % (uint32_t)c.w);
+	const uint32_t wA = (uint32_t)pmfu_w(c, c.A);
+	const int i = (int)(p / wA), j = (int)(p % wA);
 	double Xw[3]; pmfu_I2W(c.cams[c.A], (double)(float)j, (double)(float)i, (double)depth, Xw);
 	point[0] = (float)Xw[0]; point[1] = (float)Xw[1]; point[2] = (float)Xw[2];
 }
@@ -97,13 +104,14 @@ PM_HD int64_t pmfu_target(const PMFuseCtx& c, int n, const float* point, float* 
 	pmfu_projectP3(c.cams[c.nb[n]], point, q);
 	if (q[2] <= 0) return -1;
 	*xb = pmfu_round2int(q[0] / q[2]); *yb = pmfu_round2int(q[1] / q[2]);
-	if (!(*xb >= 0 && *yb >= 0 && *xb < c.w && *yb < c.h)) return -1;
-	return (int64_t)c.nb[n] * ((int64_t)c.w * c.h) + (int64_t)*yb * c.w + *xb;
+	const int wB = pmfu_w(c, c.nb[n]);
+	if (!(*xb >= 0 && *yb >= 0 && *xb < wB && *yb < pmfu_h(c, c.nb[n]))) return -1;   // depthMapB.isInside(xB), SceneDensify.cpp:1548
+	return (int64_t)c.nb[n] * (int64_t)pmfu_slab(c) + (int64_t)*yb * wB + *xb;
 }
 
 // phase 1 of a round: reserve every cell the seed may touch
 PM_HD void pmfu_reserve(const PMFuseCtx& c, uint32_t p) {
-	const float depth = c.depth[(size_t)c.A * c.w * c.h + p];
+	const float depth = c.depth[(size_t)c.A * pmfu_slab(c) + p];
 	float point[3]; pmfu_seed_point(c, p, depth, point);
 	for (int n = 0; n < c.nNb; ++n) {
 		float q[3]; int xb, yb;
@@ -114,7 +122,7 @@ PM_HD void pmfu_reserve(const PMFuseCtx& c, uint32_t p) {
 
 // phase 2: true if the seed holds all its cells (then it must run pmfu_commit now)
 PM_HD bool pmfu_owns(const PMFuseCtx& c, uint32_t p) {
-	const float depth = c.depth[(size_t)c.A * c.w * c.h + p];
+	const float depth = c.depth[(size_t)c.A * pmfu_slab(c) + p];
 	float point[3]; pmfu_seed_point(c, p, depth, point);
 	for (int n = 0; n < c.nNb; ++n) {
 		float q[3]; int xb, yb;
@@ -126,7 +134,8 @@ PM_HD bool pmfu_owns(const PMFuseCtx& c, uint32_t p) {
 
 // the reference's per-seed body (SceneDensify.cpp:1513-1606) for seed pixel p of image A, which owns its cells
 PM_HD void pmfu_commit(const PMFuseCtx& c, uint32_t p) {
-	const size_t P = (size_t)c.w * c.h;
+	const size_t P = pmfu_slab(c);
+	const uint32_t wA = (uint32_t)pmfu_w(c, c.A);
 	const size_t xa = (size_t)c.A * P + p;
 	const float depth = c.depth[xa];
 	const PMFuseCam& camA = c.cams[c.A];
@@ -136,7 +145,7 @@ PM_HD void pmfu_commit(const PMFuseCtx& c, uint32_t p) {
 	int64_t invalid[PMFU_MAXNB]; int nInvalid = 0;
 	views[0] = (uint32_t)c.A;
 	const float w0 = pmfu_conf2weight(c.conf ? c.conf[xa] : 1.f, depth);
-	weights[0] = w0; projs[0] = (p % (uint32_t)c.w) | ((p / (uint32_t)c.w) << 16); cells[0] = p;
+	weights[0] = w0; projs[0] = (p % wA) | ((p / wA) << 16); cells[0] = p;
 	double confidence = (double)w0;
 	float normal[3] = {0.f, 0.f, -1.f};
 	if (c.normal) pmfu_normalW(camA, c.normal + xa * 3, normal);
@@ -166,7 +175,7 @@ PM_HD void pmfu_commit(const PMFuseCtx& c, uint32_t p) {
 				int idx = 0; while (idx < nViews && views[idx] < (uint32_t)B) ++idx;
 				for (int m = nViews; m > idx; --m) { views[m] = views[m-1]; weights[m] = weights[m-1]; projs[m] = projs[m-1]; cells[m] = cells[m-1]; }
 				views[idx] = (uint32_t)B; weights[idx] = confidenceB; projs[idx] = (uint32_t)xb | ((uint32_t)yb << 16);
-				cells[idx] = (uint32_t)((int64_t)yb * c.w + xb);
+				cells[idx] = (uint32_t)((int64_t)yb * pmfu_w(c, B) + xb);
 				++nViews;
 				c.claimed[cell] = tag;
 				double XB[3]; pmfu_I2W(c.cams[B], (double)(float)xb, (double)(float)yb, (double)depthB, XB);
@@ -207,14 +216,15 @@ PM_HD void pmfu_commit(const PMFuseCtx& c, uint32_t p) {
 // point with that single view, the image's own colour and the normal of DepthData::GetNormal (R^T n, DepthMap.cpp:137-146); no
 // weights are produced (the reference leaves PointCloud::pointWeights empty; the record carries 0).
 PM_HD void pmfu_merge(const PMFuseCtx& c, uint32_t p) {
-	const size_t P = (size_t)c.w * c.h;
+	const size_t P = pmfu_slab(c);
+	const uint32_t wA = (uint32_t)pmfu_w(c, c.A);
 	const size_t xa = (size_t)c.A * P + p;
 	const float depth = c.depth[xa];
 	if (depth == 0) { c.recN[p] = 0; return; }
 	float point[3]; pmfu_seed_point(c, p, depth, point);
 	c.recN[p] = 1;
 	for (int k = 0; k < 3; ++k) c.recX[(size_t)k * P + p] = point[k];
-	c.recView[p] = (uint32_t)c.A; c.recWeight[p] = 0.f; c.recProj[p] = (p % (uint32_t)c.w) | ((p / (uint32_t)c.w) << 16);
+	c.recView[p] = (uint32_t)c.A; c.recWeight[p] = 0.f; c.recProj[p] = (p % wA) | ((p / wA) << 16);
 	if (c.bEstimateColor) for (int k = 0; k < 3; ++k) c.recColor[(size_t)k * P + p] = c.bgr ? c.bgr[xa * 3 + k] : (uint8_t)0;
 	if (c.bEstimateNormal) {
 		float n[3] = {0.f, 0.f, -1.f};

@@ -17,8 +17,8 @@ struct PMFuseOut {
 };
 
 __global__ __launch_bounds__(256) void pmfu_seed_kernel(PMFuseCtx c, uint32_t* pending, uint32_t* nPending, unsigned long long* nDepths) {
-	const uint32_t P = (uint32_t)c.w * (uint32_t)c.h;
-	const size_t base = (size_t)c.A * P;
+	const uint32_t P = (uint32_t)pmfu_w(c, c.A) * (uint32_t)pmfu_h(c, c.A);   // image A's own pixels
+	const size_t base = (size_t)c.A * pmfu_slab(c);
 	unsigned cnt = 0;
 	for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
 		c.recN[p] = 0;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void pmfu_commit_kernel(PMFuseCtx c, const uin
 }
 
 __global__ __launch_bounds__(256) void pmfu_merge_kernel(PMFuseCtx c, unsigned long long* nDepths) {
-	const uint32_t P = (uint32_t)c.w * (uint32_t)c.h;
+	const uint32_t P = (uint32_t)pmfu_w(c, c.A) * (uint32_t)pmfu_h(c, c.A);
 	unsigned cnt = 0;
 	for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) { pmfu_merge(c, p); cnt += c.recN[p]; }
 	for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(1024) void pmfu_scan_tiles(const uint2* tileSums, u
 
 __global__ __launch_bounds__(PMFU_TB) void pmfu_scatter_kernel(PMFuseCtx c, const uint2* tileOff, PMFuseOut o) {
 	__shared__ uint32_t sc[PMFU_TB], sv[PMFU_TB];
-	const uint32_t P = (uint32_t)c.w * (uint32_t)c.h;
+	const uint32_t P = (uint32_t)pmfu_w(c, c.A) * (uint32_t)pmfu_h(c, c.A);
+	const size_t S = pmfu_slab(c);                                              // stride of the record arrays
 	const uint32_t t = threadIdx.x, b0 = blockIdx.x * PMFU_TILE + t * 4;
 	uint32_t n4[4], cc = 0, vv = 0;
 	for (uint32_t k = 0; k < 4; ++k) { n4[k] = b0 + k < P ? c.recN[b0 + k] : 0u; cc += n4[k] ? 1u : 0u; vv += n4[k]; }
@@ -113,13 +114,13 @@ __global__ __launch_bounds__(PMFU_TB) void pmfu_scatter_kernel(PMFuseCtx c, cons
 		if (!nv) continue;
 		const uint32_t p = b0 + k;
 		o.viewStart[idx] = vs;
-		for (int m = 0; m < 3; ++m) o.points[(size_t)idx * 3 + m] = c.recX[(size_t)m * P + p];
-		if (o.colors) for (int m = 0; m < 3; ++m) o.colors[(size_t)idx * 3 + m] = c.recColor[(size_t)m * P + p];
-		if (o.normals) for (int m = 0; m < 3; ++m) o.normals[(size_t)idx * 3 + m] = c.recNormal[(size_t)m * P + p];
+		for (int m = 0; m < 3; ++m) o.points[(size_t)idx * 3 + m] = c.recX[(size_t)m * S + p];
+		if (o.colors) for (int m = 0; m < 3; ++m) o.colors[(size_t)idx * 3 + m] = c.recColor[(size_t)m * S + p];
+		if (o.normals) for (int m = 0; m < 3; ++m) o.normals[(size_t)idx * 3 + m] = c.recNormal[(size_t)m * S + p];
 		for (uint32_t v = 0; v < nv; ++v) {
-			o.views[vs + v] = c.recView[(size_t)v * P + p];
-			o.weights[vs + v] = c.recWeight[(size_t)v * P + p];
-			const uint32_t pr = c.recProj[(size_t)v * P + p];
+			o.views[vs + v] = c.recView[(size_t)v * S + p];
+			o.weights[vs + v] = c.recWeight[(size_t)v * S + p];
+			const uint32_t pr = c.recProj[(size_t)v * S + p];
 			o.projs[(size_t)(vs + v) * 2] = (uint16_t)(pr & 0xFFFFu); o.projs[(size_t)(vs + v) * 2 + 1] = (uint16_t)(pr >> 16);
 		}
 		++idx; vs += nv;

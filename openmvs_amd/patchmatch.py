@@ -174,7 +174,7 @@ class PatchMatchHIP:
     # -- HBM-resident scene interface --------------------------------------------------------
     def scene_create(self, n_images, w, h, n_levels=2):
         self._chk(self._lib.pmhip_scene_create(self._h, n_images, w, h, n_levels))
-        self._scene = (n_images, w, h)
+        self._scene = (n_images, w, h); self._sizes = {}
 
     def scene_set_view(self, idx, gray, K, R, Cc, dmin, dmax, neighbors, device_ptr=None):
         K = np.ascontiguousarray(K, np.float64); R = np.ascontiguousarray(R, np.float64); Cc = np.ascontiguousarray(Cc, np.float64)
@@ -186,6 +186,8 @@ class PatchMatchHIP:
             src, ondev = None, 0
         else:
             g = np.ascontiguousarray(gray, np.float32); src, ondev = _fp(g), 0
+        if src is not None:
+            getattr(self, "_sizes", {}).pop(int(idx), None)       # (an image of the scene's size takes the view back into the scene arrays)
         self._chk(self._lib.pmhip_scene_set_view(self._h, idx, src, ondev, dp(K), dp(R), dp(Cc), C.c_float(dmin), C.c_float(dmax),
                                                  nb.ctypes.data_as(C.POINTER(C.c_int32)), len(nb)))
 
@@ -211,8 +213,9 @@ class PatchMatchHIP:
             self.scene_set_view(i, scene.gray[i], scene.K[i], scene.R[i], scene.C[i], float(scene.dmin[i]), float(scene.dmax[i]), scene.neighbors[i])
 
     def scene_set_view_sized(self, idx, gray, K, R, Cc, dmin, dmax, neighbors):
-        """A source view whose image has its own size (pmhip_scene_set_view_sized)."""
+        """A view whose image -- and therefore its depth, normal and confidence maps -- has its own size (pmhip_scene_set_view_sized): a source view or a reference view."""
         g = np.ascontiguousarray(gray, np.float32)
+        self._sizes = getattr(self, "_sizes", {}); self._sizes[int(idx)] = (g.shape[1], g.shape[0])
         nb = np.ascontiguousarray(neighbors, np.int32)
         self._chk(self._lib.pmhip_scene_set_view_sized(self._h, idx, _fp(g), g.shape[1], g.shape[0], 0, _dp(K), _dp(R), _dp(Cc), C.c_float(dmin), C.c_float(dmax),
                                                        nb.ctypes.data_as(C.POINTER(C.c_int32)), len(nb)))
@@ -258,8 +261,13 @@ class PatchMatchHIP:
         c = np.ascontiguousarray(conf, np.float32)
         self._chk(self._lib.pmhip_scene_set_conf(self._h, idx, _fp(c)))
 
-    def scene_get_maps(self, idx):
+    def view_size(self, idx):
+        """(w, h) of a view's maps: the scene's, or the view's own (scene_set_view_sized)."""
         _, w, h = self._scene
+        return getattr(self, "_sizes", {}).get(int(idx), (w, h))
+
+    def scene_get_maps(self, idx):
+        w, h = self.view_size(idx)
         d = np.zeros((h, w), np.float32); n = np.zeros((h, w, 3), np.float32); c = np.zeros((h, w), np.float32)
         self._chk(self._lib.pmhip_scene_get_maps(self._h, idx, _fp(d), _fp(n), _fp(c)))
         return d, n, c
@@ -286,7 +294,7 @@ class PatchMatchHIP:
     def scene_set_color(self, idx, bgr):
         """8-bit BGR image of a view at depth-map resolution (only fusion with bEstimateColor reads it)."""
         b = np.ascontiguousarray(bgr, np.uint8)
-        _, w, h = self._scene
+        w, h = self.view_size(idx)
         if b.shape != (h, w, 3):
             raise ValueError("bgr must be (h, w, 3) uint8")
         self._chk(self._lib.pmhip_scene_set_color(self._h, idx, b.ctypes.data_as(C.POINTER(C.c_uint8))))

@@ -28,7 +28,7 @@ static inline bool similar(float d0, float d1, float th) { return fabsf(d0 - d1)
 
 extern "C" {
 
-struct FltView { const float* depth; const float* conf; double K[9], R[9], C[3]; };
+struct FltView { const float* depth; const float* conf; double K[9], R[9], C[3]; int w, h; };   // w, h: size of this view's maps; 0 = the reference view's (w, h of the call)
 
 // ref: reference view; nb[0..N): its (valid) neighbour views in neighbour-list order (at most 8, SceneDensify.cpp:2152-2167).
 // Returns 0 and fills newDepth/newConf, or 1 if the view cannot be filtered (N < nMinViews, :1060-1063).
@@ -44,8 +44,9 @@ int orc_filter_depth_map(const FltView* ref, const FltView* nb, int N, int w, in
 	std::vector<Cam> cams(N);
 	for (int n = 0; n < N; ++n) {
 		Cam& cam = cams[n]; memcpy(cam.K, nb[n].K, 72); memcpy(cam.R, nb[n].R, 72); memcpy(cam.C, nb[n].C, 24);
-		for (int i = 0; i < h; ++i) for (int j = 0; j < w; ++j) {
-			const float depth = nb[n].depth[(size_t)i * w + j];
+		const int nw = nb[n].w ? nb[n].w : w, nh = nb[n].h ? nb[n].h : h;   // the neighbour's own depth-map size (:1085: depthData.depthMap.size())
+		for (int i = 0; i < nh; ++i) for (int j = 0; j < nw; ++j) {
+			const float depth = nb[n].depth[(size_t)i * nw + j];
 			if (depth == 0) continue;
 			double X[3], camX[3], imgX[2];
 			I2W(cam, (double)j, (double)i, (double)depth, X);
@@ -59,7 +60,7 @@ int orc_filter_depth_map(const FltView* ref, const FltView* nb, int N, int w, in
 				float& depthRef = depthMaps[n][(size_t)py[p] * w + px[p]];
 				if (depthRef != 0 && depthRef < (float)camX[2]) continue;
 				depthRef = (float)camX[2];
-				if (bAdjust) confMaps[n][(size_t)py[p] * w + px[p]] = nb[n].conf[(size_t)i * w + j];
+				if (bAdjust) confMaps[n][(size_t)py[p] * w + px[p]] = nb[n].conf[(size_t)i * nw + j];
 			}
 		}
 	}
@@ -90,7 +91,8 @@ int orc_filter_depth_map(const FltView* ref, const FltView* nb, int N, int w, in
 						I2W(cref, (double)j, (double)i, (double)depth, X);
 						W2C(cams[n], X, cx); C2I(cams[n], cx, ix);
 						const int x = (int)floor(ix[0] + .5), y = (int)floor(ix[1] + .5); // ROUND2INT(double)
-						if (x >= 0 && y >= 0 && x < w && y < h) { const float c = nb[n].conf[(size_t)y * w + x]; negConf += (c > 0 ? c : confMaps[n][xr]); }
+						const int nw = nb[n].w ? nb[n].w : w, nh = nb[n].h ? nb[n].h : h;   // depthData.confMap.isInside(x), :1181
+						if (x >= 0 && y >= 0 && x < nw && y < nh) { const float c = nb[n].conf[(size_t)y * nw + x]; negConf += (c > 0 ? c : confMaps[n][xr]); }
 						else negConf += confMaps[n][xr];
 					}
 					++nNegViews;

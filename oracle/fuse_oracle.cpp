@@ -55,6 +55,7 @@ struct OrcFuseView {
 	const uint8_t* bgr;       // w*h*3, or NULL
 	double K[9], R[9], C[3];
 	const uint32_t* neighbors; uint32_t nNeighbors;   // DepthData::neighbors, in order
+	int w, h;                 // size of this view's maps (the reference sizes every depth map on its own image); 0 = the call's w, h
 };
 
 struct OrcFuseCloud {
@@ -79,14 +80,16 @@ int orc_fuse_depth_maps(const OrcFuseView* views_, int nImages, int w, int h, co
 		unsigned nMinViewsFuse, float fDepthDiffThreshold, float normalError, int bEstimateColor, int bEstimateNormal, OrcFuseCloud* out) {
 	memset(out, 0, sizeof(*out));
 	if ((unsigned)nImages < nMinViewsFuse) nMinViewsFuse = (unsigned)nImages;
-	const size_t P = (size_t)w * h;
+	auto vw = [&](uint32_t i) { return views_[i].w ? views_[i].w : w; };
+	auto vh = [&](uint32_t i) { return views_[i].h ? views_[i].h : h; };
+	auto vP = [&](uint32_t i) { return (size_t)vw(i) * vh(i); };
 	std::vector<Cam> cams(nImages);
 	std::vector<std::vector<float>> depthMaps(nImages);
 	bool bNormalMap = true;
 	for (int i = 0; i < nImages; ++i) {
 		memcpy(cams[i].K, views_[i].K, 72); memcpy(cams[i].R, views_[i].R, 72); memcpy(cams[i].C, views_[i].C, 24);
 		composeP(cams[i]);
-		if (views_[i].depth) { depthMaps[i].assign(views_[i].depth, views_[i].depth + P); if (!views_[i].normal) bNormalMap = false; }
+		if (views_[i].depth) { depthMaps[i].assign(views_[i].depth, views_[i].depth + vP(i)); if (!views_[i].normal) bNormalMap = false; }
 	}
 	if (bEstimateNormal && !bNormalMap) bEstimateNormal = 0;
 	const uint32_t NO_ID = 0xFFFFFFFFu;
@@ -102,13 +105,14 @@ int orc_fuse_depth_maps(const OrcFuseView* views_, int nImages, int w, int h, co
 		if (!vA.depth) continue;
 		for (uint32_t n = 0; n < vA.nNeighbors; ++n) {
 			const uint32_t b = vA.neighbors[n];
-			if (arrDepthIdx[b].empty() && views_[b].depth) arrDepthIdx[b].assign(P, NO_ID);
+			if (arrDepthIdx[b].empty() && views_[b].depth) arrDepthIdx[b].assign(vP(b), NO_ID);
 		}
-		if (arrDepthIdx[idxImage].empty()) arrDepthIdx[idxImage].assign(P, NO_ID);
+		if (arrDepthIdx[idxImage].empty()) arrDepthIdx[idxImage].assign(vP(idxImage), NO_ID);
 		std::vector<uint32_t>& depthIdxs = arrDepthIdx[idxImage];
 		const Cam& camA = cams[idxImage];
-		for (int i = 0; i < h; ++i) for (int j = 0; j < w; ++j) {
-			const size_t x = (size_t)i * w + j;
+		const int wA = vw(idxImage), hA = vh(idxImage);
+		for (int i = 0; i < hA; ++i) for (int j = 0; j < wA; ++j) {
+			const size_t x = (size_t)i * wA + j;
 			const float depth = depthMaps[idxImage][x];
 			if (depth == 0) continue;
 			++nDepths;
@@ -139,8 +143,9 @@ int orc_fuse_depth_maps(const OrcFuseView* views_, int nImages, int w, int h, co
 				float q[3]; projectP3(camB, point, q);
 				if (q[2] <= 0) continue;
 				const int xb = round2int(q[0] / q[2]), yb = round2int(q[1] / q[2]);
-				if (!(xb >= 0 && yb >= 0 && xb < w && yb < h)) continue;
-				const size_t xB = (size_t)yb * w + xb;
+				const int wB = vw(idxImageB);
+				if (!(xb >= 0 && yb >= 0 && xb < wB && yb < vh(idxImageB))) continue;       // depthMapB.isInside(xB), :1548
+				const size_t xB = (size_t)yb * wB + xb;
 				float& depthB = depthMaps[idxImageB][xB];
 				if (depthB == 0) continue;
 				uint32_t& idxPointB = arrDepthIdx[idxImageB][xB];
@@ -167,7 +172,7 @@ int orc_fuse_depth_maps(const OrcFuseView* views_, int nImages, int w, int h, co
 			}
 			if (pt.views.size() < nMinViewsFuse) {
 				for (size_t v = 0; v < pt.views.size(); ++v)
-					arrDepthIdx[pt.views[v]][(size_t)pt.projs[2*v+1] * w + pt.projs[2*v]] = NO_ID;
+					arrDepthIdx[pt.views[v]][(size_t)pt.projs[2*v+1] * vw(pt.views[v]) + pt.projs[2*v]] = NO_ID;
 				points.pop_back();
 			} else {
 				const double nrm = 1.0 / confidence;
@@ -210,14 +215,14 @@ int orc_fuse_depth_maps(const OrcFuseView* views_, int nImages, int w, int h, co
 // DepthMapsData::MergeDepthMaps (SceneDensify.cpp:1305-1368): images in index order, every depth != 0 a point of its own.
 int orc_merge_depth_maps(const OrcFuseView* views_, int nImages, int w, int h, int bEstimateColor, int bEstimateNormal, OrcFuseCloud* out) {
 	memset(out, 0, sizeof(*out));
-	const size_t P = (size_t)w * h;
 	std::vector<float> pts, nrm; std::vector<uint32_t> vws; std::vector<uint16_t> prj; std::vector<uint8_t> col;
 	for (int a = 0; a < nImages; ++a) {
 		const OrcFuseView& v = views_[a];
 		if (!v.depth) continue;
 		Cam cam; memcpy(cam.K, v.K, 72); memcpy(cam.R, v.R, 72); memcpy(cam.C, v.C, 24);
-		for (int i = 0; i < h; ++i) for (int j = 0; j < w; ++j) {
-			const size_t x = (size_t)i * w + j;
+		const int wA = v.w ? v.w : w, hA = v.h ? v.h : h;
+		for (int i = 0; i < hA; ++i) for (int j = 0; j < wA; ++j) {
+			const size_t x = (size_t)i * wA + j;
 			const float depth = v.depth[x];
 			if (depth == 0) continue;
 			double X[3]; I2W(cam, (double)(float)j, (double)(float)i, (double)depth, X);
@@ -227,7 +232,6 @@ int orc_merge_depth_maps(const OrcFuseView* views_, int nImages, int w, int h, i
 			if (bEstimateNormal) { float n[3] = {0, 0, -1}; if (v.normal) normalW(cam, v.normal + x * 3, n); for (int k = 0; k < 3; ++k) nrm.push_back(n[k]); }
 		}
 	}
-	(void)P;
 	const size_t n = vws.size();
 	out->nPoints = out->nDepths = out->nViews = n;
 	out->points = (float*)malloc(12 * n + 8); memcpy(out->points, pts.data(), 12 * n);

@@ -218,7 +218,8 @@ def sgm_step_forms_agree(Lp, pmin, pmax, costs, smin, smax, P1, P2) -> bool:
 
 # ---- FilterDepthMap oracle (oracle/filter_oracle.cpp) ------------------------------------------
 class FltView(C.Structure):
-    _fields_ = [("depth", C.POINTER(C.c_float)), ("conf", C.POINTER(C.c_float)), ("K", C.c_double * 9), ("R", C.c_double * 9), ("C", C.c_double * 3)]
+    _fields_ = [("depth", C.POINTER(C.c_float)), ("conf", C.POINTER(C.c_float)), ("K", C.c_double * 9), ("R", C.c_double * 9), ("C", C.c_double * 3),
+                ("w", C.c_int), ("h", C.c_int)]       # size of this view's maps (0 = the reference view's): the reference sizes every depth map on its own
 
 
 def filter_depth_map(depths, confs, K, R, Cc, ref, nbs, dmin, dmax, bAdjust=True, nMinViewsFilter=2, nMinViewsFilterAdjust=1,
@@ -228,7 +229,7 @@ def filter_depth_map(depths, confs, K, R, Cc, ref, nbs, dmin, dmax, bAdjust=True
 
     def mk(i):
         v = FltView(); d = np.ascontiguousarray(depths[i], np.float32); c = np.ascontiguousarray(confs[i], np.float32); keep.extend([d, c])
-        v.depth = _fp(d); v.conf = _fp(c)
+        v.depth = _fp(d); v.conf = _fp(c); v.h, v.w = d.shape
         v.K[:] = np.asarray(K[i], np.float64).ravel(); v.R[:] = np.asarray(R[i], np.float64).ravel(); v.C[:] = np.asarray(Cc[i], np.float64).ravel()
         return v
     rv = mk(ref); arr = (FltView * max(1, len(nbs)))(*[mk(i) for i in nbs])
@@ -258,7 +259,8 @@ def remove_small_segments(depth, normal, conf, nSpeckleSize=100, fDepthDiffThres
 # ---- FuseDepthMaps oracle (oracle/fuse_oracle.cpp) ---------------------------------------------
 class OrcFuseView(C.Structure):
     _fields_ = [("depth", C.POINTER(C.c_float)), ("normal", C.POINTER(C.c_float)), ("conf", C.POINTER(C.c_float)), ("bgr", C.POINTER(C.c_uint8)),
-                ("K", C.c_double * 9), ("R", C.c_double * 9), ("C", C.c_double * 3), ("neighbors", C.POINTER(C.c_uint32)), ("nNeighbors", C.c_uint32)]
+                ("K", C.c_double * 9), ("R", C.c_double * 9), ("C", C.c_double * 3), ("neighbors", C.POINTER(C.c_uint32)), ("nNeighbors", C.c_uint32),
+                ("w", C.c_int), ("h", C.c_int)]       # this view's own map size (0 = the call's)
 
 
 class OrcFuseCloud(C.Structure):
@@ -291,6 +293,8 @@ def fuse_depth_maps(depths, normals, confs, bgrs, K, R, Cc, neighbors, order=Non
     for i in range(n):
         v = arr[i]
         v.depth = ptr(depths[i], np.float32, C.c_float)
+        if depths[i] is not None:
+            v.h, v.w = np.asarray(depths[i]).shape[:2]
         v.normal = ptr(None if normals is None or depths[i] is None else normals[i], np.float32, C.c_float)
         v.conf = ptr(None if confs is None or depths[i] is None else confs[i], np.float32, C.c_float)
         v.bgr = ptr(None if bgrs is None else bgrs[i], np.uint8, C.c_uint8)

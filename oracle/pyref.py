@@ -95,7 +95,7 @@ def ref_filter_depth_map(depths, confs, K, R, Cc, ref, nbs, dmin, dmax, bAdjust=
 
     def mk(i):
         v = po.FltView(); d = np.ascontiguousarray(depths[i], np.float32); c = np.ascontiguousarray(confs[i], np.float32); keep.extend([d, c])
-        v.depth = _fp(d); v.conf = _fp(c)
+        v.depth = _fp(d); v.conf = _fp(c); v.h, v.w = d.shape
         v.K[:] = np.asarray(K[i], np.float64).ravel(); v.R[:] = np.asarray(R[i], np.float64).ravel(); v.C[:] = np.asarray(Cc[i], np.float64).ravel()
         return v
     rv = mk(ref); arr = (po.FltView * max(1, len(nbs)))(*[mk(i) for i in nbs])
@@ -286,6 +286,8 @@ def ref_fuse_depth_maps(depths, normals, confs, bgrs, K, R, Cc, neighbors, nMinV
     for i in range(n):
         v = arr[i]
         v.depth = ptr(depths[i], np.float32, C.c_float)
+        if depths[i] is not None:
+            v.h, v.w = np.asarray(depths[i]).shape[:2]
         v.normal = ptr(None if normals is None or depths[i] is None else normals[i], np.float32, C.c_float)
         v.conf = ptr(None if confs is None or depths[i] is None else confs[i], np.float32, C.c_float)
         v.bgr = ptr(None if bgrs is None else bgrs[i], np.uint8, C.c_uint8)

@@ -83,6 +83,7 @@ struct OrcFuseView {                      // same layout as oracle/fuse_oracle.c
 	const float* depth; const float* normal; const float* conf; const uint8_t* bgr;
 	double K[9], R[9], C[3];
 	const uint32_t* neighbors; uint32_t nNeighbors;
+	int w, h;                             // this view's own size, 0 = the call's
 };
 struct OrcFuseCloud {
 	uint64_t nPoints, nDepths, nViews;
@@ -93,9 +94,11 @@ void ref_fuse_free(OrcFuseCloud* c) { free(c->points); free(c->viewStart); free(
 static void setup(Scene& scene, DepthMapsData& dm, const OrcFuseView* views, int nImages, int w, int h) {
 	scene.images.resize((IIndex)nImages);
 	dm.arrDepthData.resize((IIndex)nImages);
-	const cv::Size size(w, h);
+	const int w0 = w, h0 = h;
 	for (int i = 0; i < nImages; ++i) {
 		SceneImage& im = scene.images[(IIndex)i]; const OrcFuseView& s = views[i];
+		const int w = s.w ? s.w : w0, h = s.h ? s.h : h0;               // every image / depth map of its own size (DepthMapsData::InitViews)
+		const cv::Size size(w, h);
 		im.ID = (uint32_t)i; im.size = size; im.width = (uint32_t)w; im.height = (uint32_t)h;
 		for (int k = 0; k < 9; ++k) { im.camera.K.val[k] = s.K[k]; im.camera.R.val[k] = s.R[k]; }
 		im.camera.C.x = s.C[0]; im.camera.C.y = s.C[1]; im.camera.C.z = s.C[2];

@@ -252,7 +252,7 @@ void ref_remove_small_segments(float* depth, float* normal, float* conf, int w, 
 void ref_gap_interpolation(float* depth, float* normal, float* conf, int w, int h, unsigned nIpolGapSize, float fDepthDiffThreshold) { filterMaps(true, depth, normal, conf, w, h, nIpolGapSize, fDepthDiffThreshold); }
 // DepthMapsData::FilterDepthMap (SceneDensify.cpp:1049-1299) of one reference view against N neighbour views; same FltView layout as oracle/filter_oracle.cpp.
 // Returns 0 and fills newDepth / newConf, or 1 if the reference refuses the view (too few neighbours).
-struct FltView { const float* depth; const float* conf; double K[9], R[9], C[3]; };
+struct FltView { const float* depth; const float* conf; double K[9], R[9], C[3]; int w, h; };
 int ref_filter_depth_map(const FltView* ref, const FltView* nb, int N, int w, int h, float dMin, float dMax, int bAdjust,
 		unsigned nMinViewsFilter, unsigned nMinViewsFilterAdjust, unsigned nCalibratedImages, float fDepthDiffThreshold, float* newDepth, float* newConf) {
 	DepthMapsData dm;
@@ -261,16 +261,16 @@ int ref_filter_depth_map(const FltView* ref, const FltView* nb, int N, int w, in
 	images.resize((IIndex)(N + 1));
 	for (int i = 0; i <= N; ++i) images[(IIndex)i].ID = (uint32_t)i;
 	dm.arrDepthData.resize((IIndex)(N + 1));
-	const cv::Size size(w, h);
 	for (int i = 0; i <= N; ++i) {
 		const FltView& s = i == 0 ? *ref : nb[i - 1];
+		const cv::Size size(i && s.w ? s.w : w, i && s.h ? s.h : h);   // every depth map of its own size, as DepthMapsData::InitViews leaves them
 		DepthData& dd = dm.arrDepthData[(IIndex)i];
 		dd.images.resize(1);
 		DepthData::ViewData& v = dd.images[0];
 		setCamera(v.camera, s.K, s.R, s.C);
 		v.pImageData = &images[(IIndex)i];
-		dd.depthMap.create(size); memcpy(dd.depthMap.data(), s.depth, sizeof(float) * (size_t)w * h);
-		dd.confMap.create(size); memcpy(dd.confMap.data(), s.conf, sizeof(float) * (size_t)w * h);
+		dd.depthMap.create(size); memcpy(dd.depthMap.data(), s.depth, sizeof(float) * (size_t)size.width * size.height);
+		dd.confMap.create(size); memcpy(dd.confMap.data(), s.conf, sizeof(float) * (size_t)size.width * size.height);
 		dd.dMin = dMin; dd.dMax = dMax;
 	}
 	DepthData& dref = dm.arrDepthData[0];

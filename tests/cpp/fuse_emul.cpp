@@ -11,7 +11,7 @@
 #include "../../openmvs_amd/csrc/pm_fuse.h"
 
 extern "C" {
-struct EmuFuseView { const float* depth; const float* normal; const float* conf; const uint8_t* bgr; double K[9], R[9], C[3]; const uint32_t* neighbors; uint32_t nNeighbors; };
+struct EmuFuseView { const float* depth; const float* normal; const float* conf; const uint8_t* bgr; double K[9], R[9], C[3]; const uint32_t* neighbors; uint32_t nNeighbors; int w, h; };   // (w, h: carried by the oracle's layout; this harness runs the uniform-size case)
 struct EmuFuseCloud { uint64_t nPoints, nDepths, nViews; float* points; uint32_t* viewStart; uint32_t* views; float* weights; uint16_t* projs; uint8_t* colors; float* normals; };
 
 static uint64_t g_rounds = 0, g_seeds = 0;

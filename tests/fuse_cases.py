@@ -48,3 +48,17 @@ def same_cloud(a, b, what=""):
         assert a["colors"] is None and b["colors"] is None
     else:
         assert np.array_equal(a["colors"], b["colors"]), f"{what}: colors differ"
+
+
+def make_mixed(seed=0, W=160, H=120, n_views=5, n_src=4):
+    """The same cameras and surface rendered at three sizes (1x, 0.8x, 1.25x), every view taking its maps, image and K from one of them: a scene whose depth maps have
+    different sizes, as DepthMapsData::InitViews leaves them when the images do (SceneDensify.cpp:306-459).  -> deps, nrms, cnfs, bgrs, K, R, C, neighbour lists."""
+    from openmvs_amd import synth
+    scs = [synth.make_scene(n_views, W, H, n_src=n_src), synth.make_scene(n_views, W * 4 // 5, H * 4 // 5, n_src=n_src), synth.make_scene(n_views, W * 5 // 4, H * 5 // 4, n_src=n_src)]
+    maps = [make_maps(s, seed + k) for k, s in enumerate(scs)]
+    pick = [(v * 2 + seed) % 3 if v else 0 for v in range(n_views)]
+    deps = [maps[pick[v]][0][v] for v in range(n_views)]; nrms = [maps[pick[v]][1][v] for v in range(n_views)]; cnfs = [maps[pick[v]][2][v] for v in range(n_views)]
+    bgrs = [scs[pick[v]].bgr[v] for v in range(n_views)]; K = [scs[pick[v]].K[v] for v in range(n_views)]
+    base = scs[0]
+    assert len({d.shape for d in deps}) == 3
+    return deps, nrms, cnfs, bgrs, K, base.R, base.C, [list(base.neighbors[v]) for v in range(n_views)]

@@ -101,6 +101,11 @@ def test_estimator_mixed_resolution_neighbours_wide_kernel(pm_emulated):
     g.test_mixed_resolution_neighbours_parity_both_kernels("16", 80, 60)     # (quarter of the pixels of the device case: the regular-kernel run below has the full size)
 
 
+def test_estimator_reference_views_of_different_sizes(pm_emulated):
+    from tests import test_gpu_patchmatch as g
+    g.test_reference_views_of_different_sizes(96, 72)          # three size classes in one call, geometric round, per-map filters, cross-view filter
+
+
 def test_estimator_mixed_resolution_neighbours(engine):
     from tests import test_gpu_patchmatch as g
     g.test_mixed_resolution_neighbours_parity(engine)                        # sources at 0.8x / 1.25x, cameraDepthMap of another size
@@ -128,6 +133,7 @@ def test_fusion(pm_emulated, small_scene, nine_scene):
     g.test_device_merge_mode(small_scene)
     g.test_device_fuse_custom_order_and_errors(small_scene)
     g.test_fuse_option_sweep(small_scene)
+    g.test_device_fuse_of_depth_maps_of_different_sizes(96, 72)
 
 
 # ---- SGM: cost volume, 8-path aggregation, winner-take-all, the tSGM steps ------------------------------------------------------------------------

@@ -137,3 +137,31 @@ def test_device_fuse_full_size_is_exact_and_timed():
     print(f"\nfuse 9x1080p: {r['nPoints']} points from {r['nDepths']} depths; device {dt*1e3:.0f} ms incl. download ({r['rounds']} rounds), "
           f"sequential oracle {dt_ref*1e3:.0f} ms")
     e.close()
+
+
+def test_device_fuse_of_depth_maps_of_different_sizes(W=160, H=120):
+    """A scene whose views -- and therefore their depth, normal, confidence maps and colour images -- have different sizes (DepthMapsData::InitViews sizes every DepthData
+    on its own image, SceneDensify.cpp:306-459): the device fusion, the merge (nMinViewsFuse < 2) and a second call equal the sequential oracle, which equals the
+    reference's own FuseDepthMaps on such scenes (tests/test_ref_fuse.py)."""
+    from openmvs_amd import synth
+    deps, nrms, cnfs, bgrs, K, R, Cc, nbs = fc.make_mixed(0, W, H)
+    n = len(deps)
+    base = synth.make_scene(n, W, H, n_src=4)
+    e = PatchMatchHIP(0)
+    e.scene_load(base, n_levels=0)
+    for v in range(n):
+        if deps[v].shape != (H, W):
+            gray = np.zeros(deps[v].shape, np.float32)        # (fusion does not read the gray image)
+            e.scene_set_view_sized(v, gray, K[v], R[v], Cc[v], float(base.dmin[v]), float(base.dmax[v]), nbs[v])
+        e.scene_set_maps(v, deps[v], nrms[v]); e.scene_set_conf(v, cnfs[v]); e.scene_set_color(v, bgrs[v])
+    order = po.fuse_order([len(x) for x in nbs])
+    for kw in (dict(), dict(nMinViewsFuse=3, fDepthDiffThreshold=0.02), dict(bEstimateColor=False, bEstimateNormal=False), dict(nMinViewsFuse=1)):
+        got = e.scene_fuse(order if kw.get("nMinViewsFuse", 2) >= 2 else list(range(n)), **kw)
+        ref = po.fuse_depth_maps(deps, nrms, cnfs, bgrs, K, R, Cc, nbs, **kw)
+        if kw.get("nMinViewsFuse", 2) < 2:
+            got = dict(got); ref = dict(ref); got["weights"] = None; ref["weights"] = None
+        fc.same_cloud(got, ref, "mixed sizes %s" % kw)
+        assert got["nPoints"] > 1000
+    d2, _, _ = e.scene_get_maps(2)
+    assert d2.shape == deps[2].shape and np.array_equal(d2, deps[2])
+    e.close()

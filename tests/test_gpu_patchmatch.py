@@ -780,13 +780,78 @@ def test_mixed_resolution_neighbours_parity(engine, W=160, H=120):
     e.scene_estimate([ref], -1, p)
     sd, sn, scf = e.scene_get_maps(ref)
     _same(sd, od, "scene interface, sized sources, depth"); _same(sn, on, "normal"); _same(scf, oc, "conf")
-    with pytest.raises(Exception):
-        e.scene_estimate([s1], -1, p)                       # a sized view cannot be a reference view (PMHIP_E_SIZE)
     e.Init(True)
     for i in ids[1:]:
         e.scene_set_source_depth(i, src[i], *cams[i])
     e.scene_estimate([ref], 0, p)
     _same(e.scene_get_maps(ref)[0], gd, "scene interface, geometric round with installed source depth maps")
+    e.close()
+
+
+def test_reference_views_of_different_sizes(W=160, H=120, quick=False):
+    """Reference views of different sizes in one scene: the reference sizes every DepthData on its own image (DepthMapsData::InitViews, SceneDensify.cpp:306-459).
+    Five views, three sizes (1x, 0.8x, 1.25x), estimated by ONE call (one sweep per size class), then the geometric round (every view reads its neighbours'
+    previous-round maps at the neighbours' sizes), the two per-map filters and the cross-view filter (neighbour maps of other sizes: :1085, :1181): every map
+    equals the oracle run on that view alone."""
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    base = synth.make_scene(5, W, H, n_src=4)
+    small = synth.make_scene(5, W * 4 // 5, H * 4 // 5, n_src=4)
+    big = synth.make_scene(5, W * 5 // 4, H * 5 // 4, n_src=4)
+    src_of = {0: base, 1: base, 2: small, 3: big, 4: base}
+    gray = {i: src_of[i].gray[i] for i in range(5)}; K = {i: src_of[i].K[i] for i in range(5)}
+    seed = 31
+    p = default_params(seed=seed, nEstimationGeometricIters=1)
+    e = PatchMatchHIP(0); e.Init(False)
+    e.scene_load(base, n_levels=2)
+    for i in (2, 3):
+        e.scene_set_view_sized(i, gray[i], K[i], base.R[i], base.C[i], float(base.dmin[i]), float(base.dmax[i]), base.neighbors[i])
+    allv = list(range(5)) if not quick else [0, 2, 3]
+    e.scene_estimate(allv, -1, p)
+    maps = {}
+    for v in allv:
+        ids = [v] + [int(i) for i in base.neighbors[v]]
+        views, keep = po.make_views(gray, K, base.R, base.C, ids)
+        od, on, oc = po.estimate_depth_map(views, len(ids), float(base.dmin[v]), float(base.dmax[v]), po.default_opt(seed=seed, viewID=v, nEstimationGeometricIters=1))
+        d, n, c = e.scene_get_maps(v)
+        assert d.shape == gray[v].shape
+        _same(d, od, "view %d (%dx%d), photometric depth" % (v, d.shape[1], d.shape[0])); _same(n, on, "normal"); _same(c, oc, "conf")
+        assert (d > 0).mean() > 0.4
+        maps[v] = (od, on, oc)
+    if quick:
+        e.close(); return
+    # geometric round: the neighbours' previous-round maps at their own sizes with their own cameras
+    e.scene_commit_round(); e.Init(True)
+    e.scene_estimate(allv, 0, p)
+    geo = {}
+    for v in allv:
+        ids = [v] + [int(i) for i in base.neighbors[v]]
+        src = {i: maps[i][0] for i in ids[1:]}; cams = {i: (K[i], base.R[i], base.C[i]) for i in ids[1:]}
+        views, keep = po.make_views(gray, K, base.R, base.C, ids, depth_maps=src, depth_cams=cams)
+        gd, gn, gc = po.estimate_depth_map(views, len(ids), float(base.dmin[v]), float(base.dmax[v]), po.default_opt(seed=seed, viewID=v, nEstimationGeometricIters=1),
+                                           geo_iter=0, depth=maps[v][0], normal=maps[v][1])
+        d, n, c = e.scene_get_maps(v)
+        _same(d, gd, "view %d, geometric depth" % v); _same(n, gn, "normal"); _same(c, gc, "conf")
+        geo[v] = (gd, gn, gc)
+    # per-map filters at each view's own size
+    e.scene_remove_small_segments(allv, 30, 0.01); e.scene_gap_interpolation(allv, 7, 0.01)
+    flt = {}
+    for v in allv:
+        a = po.remove_small_segments(*geo[v], nSpeckleSize=30, fDepthDiffThreshold=0.01)
+        a = po.gap_interpolation(*a, nIpolGapSize=7, fDepthDiffThreshold=0.01)
+        d, n, c = e.scene_get_maps(v)
+        _same(d, a[0], "view %d, speckle + gap filter depth" % v); _same(n, a[1], "normal"); _same(c, a[2], "conf")
+        flt[v] = a
+    # cross-view filter: every view against neighbours whose maps have other sizes
+    D = {v: flt[v][0] for v in allv}; Cf = {v: flt[v][2] for v in allv}
+    for bAdjust in (True, False):
+        e.scene_filter(allv, bAdjust=bAdjust, commit=True)
+        for v in allv:
+            rc, nd, nc = po.filter_depth_map(D, Cf, K, base.R, base.C, v, [int(i) for i in base.neighbors[v]], float(base.dmin[v]), float(base.dmax[v]), bAdjust=bAdjust)
+            assert rc == 0
+            d, n, c = e.scene_get_maps(v)
+            _same(d, nd, "view %d, FilterDepthMap(bAdjust=%s) depth" % (v, bAdjust)); _same(c, nc, "conf")
+        for v in allv:                                          # back to the unfiltered maps for the second variant
+            e.scene_set_maps(v, D[v], None); e.scene_set_conf(v, Cf[v])
     e.close()
 
 

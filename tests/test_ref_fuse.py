@@ -70,3 +70,16 @@ def test_merge_is_the_reference_function(scenes):
         orc = po.fuse_depth_maps(deps, nrms, cnfs, sc.bgr, sc.K, sc.R, sc.C, nbs, nMinViewsFuse=1, **kw)
         ref = dict(ref); orc = dict(orc); ref["weights"] = None; orc["weights"] = None      # MergeDepthMaps stores no weights
         _same(ref, orc, "merge %s" % kw)
+
+
+@pytest.mark.parametrize("seed,opts", [(0, dict()), (1, dict(nMinViewsFuse=3, fDepthDiffThreshold=0.02)), (0, dict(nMinViewsFuse=1))])
+def test_fuse_of_depth_maps_of_different_sizes_is_the_reference_function(seed, opts):
+    """Every depth map of its own size (DepthMapsData::InitViews sizes each DepthData on its image): projections are tested against the neighbour's own map (:1548) and
+    pixel indices run over the view's own width."""
+    deps, nrms, cnfs, bgrs, K, R, Cc, nbs = fc.make_mixed(seed)
+    ref, order = pr.ref_fuse_depth_maps(deps, nrms, cnfs, bgrs, K, R, Cc, nbs, **opts)
+    orc = po.fuse_depth_maps(deps, nrms, cnfs, bgrs, K, R, Cc, nbs, order=order, **opts)
+    if opts.get("nMinViewsFuse", 2) < 2:
+        ref = dict(ref); orc = dict(orc); ref["weights"] = None; orc["weights"] = None
+    _same(ref, orc, "mixed sizes %s" % opts)
+    assert ref["nPoints"] > 1000

@@ -338,6 +338,40 @@ def test_filter_depth_map_is_the_reference_function(scene, estimated, bAdjust, v
         assert kept < had                                              # it discarded something
 
 
+def _resized_view(depth, conf, K, fx, fy):
+    """A depth / confidence map at another size (nearest resampling: depths stay depths) with the camera scaled like Camera::ScaleK does."""
+    h, w = depth.shape
+    nw, nh = int(round(w * fx)), int(round(h * fy))
+    xs = np.minimum((np.arange(nw) * (w / nw)).astype(int), w - 1); ys = np.minimum((np.arange(nh) * (h / nh)).astype(int), h - 1)
+    Kn = np.array(K, np.float64).copy()
+    sx, sy = nw / w, nh / h
+    Kn[0, 0] *= sx; Kn[1, 1] *= sy; Kn[0, 2] = (Kn[0, 2] + 0.5) * sx - 0.5; Kn[1, 2] = (Kn[1, 2] + 0.5) * sy - 0.5
+    return np.ascontiguousarray(depth[ys][:, xs]), np.ascontiguousarray(conf[ys][:, xs]), Kn
+
+
+@pytest.mark.parametrize("bAdjust", [True, False])
+@pytest.mark.parametrize("ref", [0, 4])
+def test_filter_depth_map_with_neighbours_of_other_sizes_is_the_reference_function(scene, estimated, bAdjust, ref):
+    """The reference sizes every depth map on its own image (DepthMapsData::InitViews, SceneDensify.cpp:306-459); FilterDepthMap walks each neighbour's map at the
+    neighbour's size (:1085) and tests free-space violations inside the neighbour's confidence map (:1181)."""
+    sc = scene
+    depths, confs, nd, nc = estimated
+    nbs = [int(i) for i in sc.neighbors[ref]]
+    D, Cf, K = dict(nd), dict(nc), [np.array(k, np.float64) for k in sc.K]
+    for k, j in enumerate(nbs):
+        fx, fy = [(0.75, 0.75), (1.25, 1.25), (1.0, 0.5), (1.4, 0.8)][k % 4]
+        if k % 5 != 4:
+            D[j], Cf[j], K[j] = _resized_view(nd[j], nc[j], sc.K[j], fx, fy)
+    assert len({D[j].shape for j in nbs}) >= 3
+    kw = dict(bAdjust=bAdjust, nMinViewsFilter=2, nMinViewsFilterAdjust=1, fDepthDiffThreshold=0.01)
+    a = po.filter_depth_map(D, Cf, K, sc.R, sc.C, ref, nbs, float(sc.dmin[ref]), float(sc.dmax[ref]), **kw)
+    b = pr.ref_filter_depth_map(D, Cf, K, sc.R, sc.C, ref, nbs, float(sc.dmin[ref]), float(sc.dmax[ref]), **kw)
+    assert a[0] == b[0] == 0
+    for x, y, nm in zip(a[1:], b[1:], ("depth", "conf")):
+        assert np.array_equal(x, y), "FilterDepthMap %s: %d of %d differ" % (nm, int((x != y).sum()), x.size)
+    assert 0 < (a[1] > 0).sum() < (D[ref] > 0).sum()
+
+
 def test_filter_depth_map_refuses_too_few_neighbours(scene, estimated):
     sc = scene; depths, confs, nd, nc = estimated
     a = po.filter_depth_map(depths, confs, sc.K, sc.R, sc.C, 0, [1], 1.0, 10.0, nMinViewsFilter=2)

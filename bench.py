@@ -304,7 +304,8 @@ def valu_issue_fields(sweep_pixels, sweep_wall_s, px_per_wave=16, simds=1024, cl
         return {"valu_issue": {"valu_busy_cycles_per_wave_visit": round(busy), "valu_insts_per_wave_visit": sq["valu_insts_per_wave"], "wave_visits": int(visits),
                                "valu_busy_frac": round(busy * visits / (simds * clock_hz * max(sweep_wall_s, 1e-12)), 4),
                                "note": "share of all SIMD cycles of the sweep phases in which a VALU instruction executes (offline SQ counters x this run's wave-visits, 2.4 GHz): "
-                                       "the bound this kernel actually approaches at this batch size is the issue of the reference's un-fusable fp32 arithmetic, not HBM"}}
+                                       "the bound this kernel actually approaches at this batch size is the issue of the reference's un-fusable fp32 arithmetic, not HBM.  Every pixel visit is "
+                                       "counted as pm_sweep2_kernel<4,2>'s (16 pixels per wave); the short diagonals that run the two-wide speculative kernel make the true share larger"}}
     except Exception:
         return {}
 

@@ -113,12 +113,23 @@ int sgmhip_set_problem(sgmhip_engine* e, const uint8_t* leftBGR, const float* le
 	return 0;
 }
 
-static void launchPath(sgmhip_engine* e, hipStream_t st, int NK, int lines, int P1, const SGMDirs& dirs) {
+static void launchPath(sgmhip_engine* e, hipStream_t st, int NK, int lines, int P1, const SGMDirs& dirs, bool delta) {
+#define SGM_LAUNCH_PATH(NK_, DL_) hipLaunchKernelGGL((sgm_path_kernel<NK_, DL_>), dim3(lines), dim3(64), 0, st, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, P1, dirs, e->d_deltas, (unsigned long long)e->numCosts)
 	switch (NK) {
-	case 1: hipLaunchKernelGGL((sgm_path_kernel<1>), dim3(lines), dim3(64), 0, st, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, P1, dirs); break;
-	case 2: hipLaunchKernelGGL((sgm_path_kernel<2>), dim3(lines), dim3(64), 0, st, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, P1, dirs); break;
-	default: hipLaunchKernelGGL((sgm_path_kernel<4>), dim3(lines), dim3(64), 0, st, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, P1, dirs); break;
+	case 1: if (delta) SGM_LAUNCH_PATH(1, true); else SGM_LAUNCH_PATH(1, false); break;
+	case 2: if (delta) SGM_LAUNCH_PATH(2, true); else SGM_LAUNCH_PATH(2, false); break;
+	default: if (delta) SGM_LAUNCH_PATH(4, true); else SGM_LAUNCH_PATH(4, false); break;
 	}
+#undef SGM_LAUNCH_PATH
+}
+// the 8 byte volumes of the DELTA aggregation (kept between calls, grown on demand); false: no room, the caller takes the atomic path
+static bool ensureDeltas(sgmhip_engine* e) {
+	if (e->capDeltas >= e->numCosts * 8) return true;
+	if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+	if (e->d_deltas) { hipFree(e->d_deltas); e->d_deltas = nullptr; e->capDeltas = 0; }
+	if (hipMalloc(&e->d_deltas, e->numCosts * 8 + 16) == hipSuccess) { e->capDeltas = e->numCosts * 8; return true; }
+	(void)hipGetLastError();
+	return false;
 }
 
 static int sgmMatch(sgmhip_engine* e, uint16_t P1);
@@ -151,7 +162,10 @@ static int sgmMatchSubT(sgmhip_engine* e, uint16_t P1) {
 		hipLaunchKernelGGL((sgm_cost_sub_kernel<LP>), dim3((unsigned)((nPairs + 4 * PW - 1) / (4 * PW))), dim3(256), 0, e->stream, e->d_color, e->d_grayL, e->d_grayR, e->w, e->h, W, H, e->d_pixels, e->d_setup, e->d_costs);
 	}
 	evE(e);
-	SGMCHK(e, hipMemsetAsync(e->d_accums, 0, (e->numCosts + 1) / 2 * 4, e->stream));
+	static const int allowDeltaSub = [] { const char* v = getenv("SGMHIP_DELTA"); return v ? atoi(v) : 3; }();
+	bool delta = e->maxP2 <= 255 && (allowDeltaSub & 2) != 0;
+	if (delta && !ensureDeltas(e)) delta = false;
+	if (!delta) SGMCHK(e, hipMemsetAsync(e->d_accums, 0, (e->numCosts + 1) / 2 * 4, e->stream));
 	struct Dir { int dx, dy; SGMLines ln; } dirs[8] = {
 		{0, 1,   {W, 0, 0, 1, 0,      0, 0, 0, 0, 0}},
 		{1, 0,   {H, 0, 0, 0, 1,      0, 0, 0, 0, 0}},
@@ -174,13 +188,16 @@ static int sgmMatchSubT(sgmhip_engine* e, uint16_t P1) {
 	sd.first[8] = total;
 	evB(e, 1);
 	if (total > 0) {
-		if (e->maxNumDisp <= 64) hipLaunchKernelGGL((sgm_path_sub_kernel<LP, 64>), dim3(total), dim3(64), 0, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, (int)P1, sd);
-		else hipLaunchKernelGGL((sgm_path_sub_kernel<LP, 256>), dim3(total), dim3(64), 0, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, (int)P1, sd);
+#define SGM_LAUNCH_SUB(MD_, DL_) hipLaunchKernelGGL((sgm_path_sub_kernel<LP, MD_, DL_>), dim3(total), dim3(64), 0, e->stream, e->d_grayL, e->w, e->vw, e->vh, e->d_pixels, e->d_costs, (unsigned*)e->d_accums, e->d_P2s, (int)P1, sd, e->d_deltas, (unsigned long long)e->numCosts)
+		if (e->maxNumDisp <= 64) { if (delta) SGM_LAUNCH_SUB(64, true); else SGM_LAUNCH_SUB(64, false); }
+		else { if (delta) SGM_LAUNCH_SUB(256, true); else SGM_LAUNCH_SUB(256, false); }
+#undef SGM_LAUNCH_SUB
 	}
 	if (e->statsOn) e->stats.aggrLaunches += 1;
 	evE(e);
 	evB(e, 2);
-	hipLaunchKernelGGL((sgm_wta_sub_kernel<LP>), dim3((unsigned)((nPix + 4 * PW - 1) / (4 * PW))), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, e->d_cost);
+	if (delta) hipLaunchKernelGGL(sgm_sum_wta_kernel, dim3((unsigned)((nPix + 15) / 16)), dim3(256), 0, e->stream, e->d_pixels, e->d_costs, e->d_deltas, (unsigned long long)e->numCosts, e->d_accums, nPix, e->d_disp, e->d_cost);
+	else hipLaunchKernelGGL((sgm_wta_sub_kernel<LP>), dim3((unsigned)((nPix + 4 * PW - 1) / (4 * PW))), dim3(256), 0, e->stream, e->d_pixels, e->d_accums, nPix, e->d_disp, e->d_cost);
 	evE(e);
 	SGMCHK(e, hipGetLastError());
 	if (e->statsOn) e->stats.calls += 1;
@@ -220,14 +237,11 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 	}
 	evE(e);
 	const int NK = e->maxNumDisp <= 64 ? 1 : (e->maxNumDisp <= 128 ? 2 : 4);
-	// DELTA aggregation: uniform ranges and penalties that fit a byte; 8 scratch bytes per entry (kept between calls, grown on demand)
-	static const bool allowDelta = [] { const char* v = getenv("SGMHIP_DELTA"); return !v || atoi(v) != 0; }();   // 0: atomic u16 sums
-	bool delta = allowDelta && e->uniform && NK <= 2 && e->maxP2 <= 255;
-	if (delta && e->capDeltas < e->numCosts * 8) {
-		SGMCHK(e, hipStreamSynchronize(e->stream));
-		if (e->d_deltas) { hipFree(e->d_deltas); e->d_deltas = nullptr; e->capDeltas = 0; }
-		if (hipMalloc(&e->d_deltas, e->numCosts * 8 + 16) == hipSuccess) e->capDeltas = e->numCosts * 8; else { (void)hipGetLastError(); delta = false; }   // no room: the atomic path
-	}
+	// DELTA aggregation: penalties that fit a byte (L - C <= P2); 8 scratch bytes per entry.  Uniform ranges: the register-resident kernel (NK <= 2); ragged ranges
+	// (round 4): sgm_path_kernel<NK, true> -- one coalesced byte store per lane and step instead of an atomic add into the shared u16 sums
+	static const int allowDelta = [] { const char* v = getenv("SGMHIP_DELTA"); return v ? atoi(v) : 3; }();   // bit 0: uniform ranges, bit 1: ragged ranges; 0: atomic u16 sums
+	bool delta = e->maxP2 <= 255 && ((e->uniform && NK <= 2) ? (allowDelta & 1) != 0 : (allowDelta & 2) != 0);
+	if (delta && !ensureDeltas(e)) delta = false;   // no room: the atomic path
 	if (!delta) SGMCHK(e, hipMemsetAsync(e->d_accums, 0, (e->numCosts + 1) / 2 * 4, e->stream)); // imageAccumCosts.Memset(0), :990
 	// the eight paths with the threaded variant's start sets, SemiGlobalMatcher.cpp:1083-1200
 	struct Dir { int dx, dy; SGMLines ln; } dirs[8] = {
@@ -270,7 +284,7 @@ static int sgmMatch(sgmhip_engine* e, uint16_t P1) {
 			}
 #undef SGM_LAUNCH_UNIFORM
 		}
-		else launchPath(e, e->stream, NK, total, (int)P1, sd);
+		else launchPath(e, e->stream, NK, total, (int)P1, sd, delta);
 	}
 	if (e->statsOn) e->stats.aggrLaunches += 1;
 	evE(e);

@@ -412,9 +412,11 @@ __device__ __forceinline__ void sgm_accumulate(unsigned* wordsBase, unsigned par
 #endif
 struct SGMStep { int rpMin, rpMax, cur; float Ip; };
 
-template <int NK>
+// DELTA: instead of adding L into the shared u16 sums with atomics, the direction writes L - C -- at most P2, a byte -- into its own byte volume (dvol); sgm_sum_wta_kernel
+// forms 8 C + the eight deltas afterwards.  Every entry of every valid pixel lies on exactly one line of each direction, so each byte is written exactly once.
+template <int NK, bool DELTA>
 __device__ __forceinline__ void sgm_step(int* sL, const unsigned short* sP2, const SGMPixel& px, float g, const unsigned char* c8,
-		unsigned* accumWords, int P1, int lane, SGMStep& st) {
+		unsigned* accumWords, unsigned char* dvol, int P1, int lane, SGMStep& st) {
 	constexpr int MD = 64 * NK, SL = 3 * MD;
 	const int rsMin = px.minDisp, rsMax = px.maxDisp, nD = rsMax - rsMin;
 	if (nD <= 0) return;                                            // invalid pixels do not reset Lp / Ip (:1071-1072)
@@ -432,7 +434,8 @@ __device__ __forceinline__ void sgm_step(int* sL, const unsigned short* sP2, con
 			const int k = lane + 64 * q;
 			const int L = (int)c8[q] + P2;
 			Ls[k] = k < nD ? L : SGM_INF;
-			sgm_accumulate(wordsBase, par, k, nD, L, lane);
+			if (DELTA) { if (k < nD) dvol[px.idx + (unsigned)k] = (unsigned char)P2; }
+			else sgm_accumulate(wordsBase, par, k, nD, L, lane);
 		}
 	} else {
 		int a0[NK], am[NK], ap[NK];
@@ -451,7 +454,8 @@ __device__ __forceinline__ void sgm_step(int* sL, const unsigned short* sP2, con
 			const int best = min(min(m + P2, a0[q]), side);
 			const int L = (int)c8[q] + best - m;
 			Ls[k] = k < nD ? L : SGM_INF;
-			sgm_accumulate(wordsBase, par, k, nD, L, lane);
+			if (DELTA) { if (k < nD) dvol[px.idx + (unsigned)k] = (unsigned char)(best - m); }
+			else sgm_accumulate(wordsBase, par, k, nD, L, lane);
 		}
 	}
 	st.rpMin = rsMin; st.rpMax = rsMax; st.Ip = g; st.cur ^= 1;
@@ -463,10 +467,10 @@ __device__ __forceinline__ void sgm_step(int* sL, const unsigned short* sP2, con
 // streams shared four hardware queues and overlapped only ~2.4x.)  The host lists the directions longest lines first.
 struct SGMDirs { int dx[8], dy[8]; SGMLines ln[8]; int first[9]; };
 
-template <int NK>
+template <int NK, bool DELTA = false>
 __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ grayL, int w, int vw, int vh,
 		const SGMPixel* __restrict__ pixels, const unsigned char* __restrict__ costs, unsigned* __restrict__ accumWords,
-		const unsigned short* __restrict__ P2s, int P1, SGMDirs dirs) {
+		const unsigned short* __restrict__ P2s, int P1, SGMDirs dirs, unsigned char* __restrict__ deltas = nullptr, unsigned long long numCosts = 0) {
 	constexpr int MD = 64 * NK, SL = 3 * MD;
 	__shared__ int s_L[2 * SL];
 	__shared__ unsigned short s_P2[256];
@@ -479,6 +483,7 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 	const int line = (int)blockIdx.x - dirs.first[dir];
 	const int dx = dirs.dx[dir], dy = dirs.dy[dir];
 	const SGMLines ln = dirs.ln[dir];
+	unsigned char* dvol = DELTA ? deltas + (unsigned long long)dir * numCosts : nullptr;   // this direction's byte volume
 	int x, y;
 	if (line < ln.nA) { x = ln.ax + line * ln.adx; y = ln.ay + line * ln.ady; }
 	else { const int i = line - ln.nA; x = ln.bx + i * ln.bdx; y = ln.by + i * ln.bdy; }
@@ -529,11 +534,11 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const float* __restrict__ 
 			__builtin_amdgcn_s_waitcnt(0x0F70);
 			costLoad(slot, t0 + SGM_T, cB);
 #pragma unroll
-			for (int t = 0; t < SGM_T; ++t) sgm_step<NK>(s_L, s_P2, s_px[slot][t0 + t], s_g[slot][t0 + t], cA[t], accumWords, P1, lane, st);
+			for (int t = 0; t < SGM_T; ++t) sgm_step<NK, DELTA>(s_L, s_P2, s_px[slot][t0 + t], s_g[slot][t0 + t], cA[t], accumWords, dvol, P1, lane, st);
 			__builtin_amdgcn_s_waitcnt(0x0F70);
 			if (t0 + 2 * SGM_T < SGM_TT) costLoad(slot, t0 + 2 * SGM_T, cA); else costLoad(slot ^ 1, 0, cA);
 #pragma unroll
-			for (int t = 0; t < SGM_T; ++t) sgm_step<NK>(s_L, s_P2, s_px[slot][t0 + SGM_T + t], s_g[slot][t0 + SGM_T + t], cB[t], accumWords, P1, lane, st);
+			for (int t = 0; t < SGM_T; ++t) sgm_step<NK, DELTA>(s_L, s_P2, s_px[slot][t0 + SGM_T + t], s_g[slot][t0 + SGM_T + t], cB[t], accumWords, dvol, P1, lane, st);
 		}
 		x += SGM_TT * dx; y += SGM_TT * dy; slot ^= 1;
 	}
@@ -736,7 +741,8 @@ __global__ __launch_bounds__(64) void sgm_path_uniform_kernel(const float* __res
 }
 
 // ---- sums and winner of the DELTA aggregation: accums(d) = 8 C(d) + sum over the 8 directions of delta_r(d); first minimum (:1272-1301) -----------------
-// 16 lanes per pixel, four entries per lane and trip (one dword of the cost volume and of each delta volume where the pixel's run is dword-aligned), four pixels per wave.
+// 16 lanes per pixel, four pixels per wave.  A lane takes whole dwords of the byte volumes: the pixel's run [idx, idx + nD) is covered by the dwords from idx & ~3 on, so
+// every load is aligned whatever idx is (ragged ranges start anywhere); bytes of the first and last dword that belong to the neighbouring pixels are masked out.
 __global__ __launch_bounds__(256) void sgm_sum_wta_kernel(const SGMPixel* __restrict__ pixels, const unsigned char* __restrict__ costs, const unsigned char* __restrict__ deltas,
 		unsigned long long numCosts, unsigned short* __restrict__ accums, long nPix, short* __restrict__ disp, unsigned short* __restrict__ cost) {
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane >> 4, kk = lane & 15;
@@ -746,30 +752,41 @@ __global__ __launch_bounds__(256) void sgm_sum_wta_kernel(const SGMPixel* __rest
 	if (have) px = pixels[pix];
 	const int nD = px.maxDisp - px.minDisp;
 	unsigned key = 0xFFFFFFFFu;
-	const bool aligned = (px.idx & 3ull) == 0ull && (numCosts & 3ull) == 0ull;   // the per-direction delta volumes start numCosts apart: dword loads only when that keeps them aligned
-	for (int k = kk * 4; k < nD; k += 64) {
-		unsigned s[4];
-		const int n = min(4, nD - k);
-		if (aligned && n == 4) {
-			const unsigned c = *reinterpret_cast<const unsigned*>(costs + px.idx + k);
+	if ((numCosts & 3ull) == 0ull) {             // the per-direction volumes start numCosts apart: dword loads keep their alignment in every one of them
+		const int head = (int)(px.idx & 3ull);       // bytes of the first dword that precede the run
+		const unsigned long long base = px.idx - (unsigned long long)head;
+		for (int j = kk * 4; j < head + nD; j += 64) {   // j = byte offset of this lane's dword from `base`
+			const unsigned c = *reinterpret_cast<const unsigned*>(costs + base + j);
+			unsigned s[4];
 #pragma unroll
 			for (int b = 0; b < 4; ++b) s[b] = ((c >> (8 * b)) & 255u) * 8u;
 #pragma unroll
 			for (int r = 0; r < 8; ++r) {
-				const unsigned dv = *reinterpret_cast<const unsigned*>(deltas + (unsigned long long)r * numCosts + px.idx + k);
+				const unsigned dv = *reinterpret_cast<const unsigned*>(deltas + (unsigned long long)r * numCosts + base + j);
 #pragma unroll
 				for (int b = 0; b < 4; ++b) s[b] += (dv >> (8 * b)) & 255u;
 			}
-			uint2 o; o.x = s[0] | (s[1] << 16); o.y = s[2] | (s[3] << 16);
-			*reinterpret_cast<uint2*>(accums + px.idx + k) = o;          // (idx + k) % 4 == 0: 8-byte aligned
-		} else {
-			for (int b = 0; b < n; ++b) {
-				unsigned v = (unsigned)costs[px.idx + k + b] * 8u;
-				for (int r = 0; r < 8; ++r) v += deltas[(unsigned long long)r * numCosts + px.idx + k + b];
-				s[b] = v; accums[px.idx + k + b] = (unsigned short)v;
+			const int k0 = j - head;                     // entry of byte 0 of the dword
+			if (k0 >= 0 && k0 + 4 <= nD) {
+				uint2 o; o.x = s[0] | (s[1] << 16); o.y = s[2] | (s[3] << 16);
+				*reinterpret_cast<uint2*>(accums + base + j) = o;          // (base + j) % 4 == 0: 8-byte aligned
+#pragma unroll
+				for (int b = 0; b < 4; ++b) key = min(key, (s[b] << 16) | (unsigned)(k0 + b));
+			} else {
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					const int k = k0 + b;
+					if (k >= 0 && k < nD) { accums[px.idx + (unsigned)k] = (unsigned short)s[b]; key = min(key, (s[b] << 16) | (unsigned)k); }
+				}
 			}
 		}
-		for (int b = 0; b < n; ++b) key = min(key, (s[b] << 16) | (unsigned)(k + b));
+	} else {
+		for (int k = kk; k < nD; k += 16) {
+			unsigned v = (unsigned)costs[px.idx + k] * 8u;
+			for (int r = 0; r < 8; ++r) v += deltas[(unsigned long long)r * numCosts + px.idx + k];
+			accums[px.idx + k] = (unsigned short)v;
+			key = min(key, (v << 16) | (unsigned)k);
+		}
 	}
 	key = (unsigned)sgm_sub_min16((int)(key ^ 0x80000000u)) ^ 0x80000000u;
 	if (have && kk == 0) {

@@ -128,10 +128,10 @@ __device__ __forceinline__ void sgm_accumulate_sub(unsigned* wordsBase, unsigned
 
 // The grid holds, per direction, ceil(lines / PW) workgroups (first[] counts workgroups); sub-group s of workgroup g owns line g * PW + s.
 // MD = capacity of a line buffer in disparities (>= maxNumDisp).
-template <int LP, int MD>
+template <int LP, int MD, bool DELTA = false>   // DELTA: L - C into this direction's byte volume instead of atomic u16 sums (see sgm_step)
 __global__ __launch_bounds__(64) void sgm_path_sub_kernel(const float* __restrict__ grayL, int w, int vw, int vh,
 		const SGMPixel* __restrict__ pixels, const unsigned char* __restrict__ costs, unsigned* __restrict__ accumWords,
-		const unsigned short* __restrict__ P2s, int P1, SGMDirs dirs) {
+		const unsigned short* __restrict__ P2s, int P1, SGMDirs dirs, unsigned char* __restrict__ deltas = nullptr, unsigned long long numCosts = 0) {
 	constexpr int PW = 64 / LP;
 	__shared__ int s_L[PW][2][MD];                                     // previous / current L of each line, entries [0, nD)
 	__shared__ unsigned short s_P2[256];
@@ -145,6 +145,7 @@ __global__ __launch_bounds__(64) void sgm_path_sub_kernel(const float* __restric
 	const int line = ((int)blockIdx.x - dirs.first[dir]) * PW + sub;
 	const int dx = dirs.dx[dir], dy = dirs.dy[dir];
 	const SGMLines ln = dirs.ln[dir];
+	unsigned char* dvol = DELTA ? deltas + (unsigned long long)dir * numCosts : nullptr;
 	const bool haveLine = line < ln.nA + ln.nB;
 	int x = -1, y = -1;                                                // a line that does not exist starts (and stays) outside
 	if (haveLine) {
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(64) void sgm_path_sub_kernel(const float* __restric
 			for (int k = kk; __any(on && k - kk < nD); k += LP) {
 				const bool mine = on && k < nD;
 				const int c = !mine ? 0 : (k < LP ? (int)s_c[sub][slot][t][kk] : (int)costs[px.idx + (unsigned)k]);
-				int L;
+				int L, dl = P2;                                          // dl = L - c
 				if (fresh) L = c + P2;
 				else {
 					const int ipx = k + off;
@@ -231,10 +232,11 @@ __global__ __launch_bounds__(64) void sgm_path_sub_kernel(const float* __restric
 					const int ap = (mine && k < nD - 1 && (unsigned)(ipx + 1) < (unsigned)nDp) ? Lp[ipx + 1] : SGM_INF;
 					const int side = min(am, ap) + P1;
 					const int best = min(min(m + P2, a0), side);
-					L = c + best - m;
+					dl = best - m; L = c + dl;
 				}
 				if (mine) Ls[k] = L;
-				sgm_accumulate_sub<LP>(wordsBase, par, k, kk, mine ? nD : 0, L);
+				if (DELTA) { if (mine) dvol[px.idx + (unsigned)k] = (unsigned char)dl; }
+				else sgm_accumulate_sub<LP>(wordsBase, par, k, kk, mine ? nD : 0, L);
 			}
 			if (on) { rpMin = rsMin; rpMax = rsMax; Ip = g; cur ^= 1; }
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -122,8 +122,7 @@ int pmhip_scene_set_view_id(pmhip_engine* e, int idx, uint32_t viewID);
  * libs/MVS/SceneDensify.cpp:306-459; also a neighbour rescaled by ViewData::ScaleImage): it keeps its own pyramid and its own depth / normal /
  * confidence maps of that size, and is a view like any other -- source view, reference view (a batch is swept one size class after the other),
  * per-map filters, cross-view filter and fusion against neighbours of other sizes.  pmhip_scene_get_maps / set_maps / set_conf / set_color of such
- * a view move w*h entries; pmhip_scene_device_ptr returns its own buffers; ignore masks are kept for views of the scene's size only
- * (PMHIP_E_SIZE).  gray is required. */
+ * a view (and its ignore mask, pmhip_scene_set_mask) have w*h entries; pmhip_scene_device_ptr returns its own buffers.  gray is required. */
 int pmhip_scene_set_view_sized(pmhip_engine* e, int idx, const float* gray, int w, int h, int onDevice,
                                const double K[9], const double R[9], const double C[3],
                                float dMin, float dMax, const int32_t* neighbors, int nNeighbors);

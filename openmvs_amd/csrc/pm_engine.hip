@@ -67,6 +67,7 @@ struct SceneView {
 	float *oDepth = nullptr, *oNormal = nullptr, *oConf = nullptr, *oSnap = nullptr;   // sw x sh (x 3): depth, normal, confidence (cost), previous round's depth
 	float *oFDepth = nullptr, *oFConf = nullptr;                                       // staged results of the cross-view filter (pmhip_scene_filter / _commit)
 	uint8_t* oBgr = nullptr;                                                           // its 8-bit BGR image (pmhip_scene_set_color), sw x sh x 3
+	unsigned char* oMask[4] = {nullptr, nullptr, nullptr, nullptr};                    // its ignore mask per pyramid level (pmhip_scene_set_mask)
 	float* sImg[4] = {nullptr, nullptr, nullptr, nullptr};
 	float* sImgS[4] = {nullptr, nullptr, nullptr, nullptr};
 	float4* sImgQ[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -81,6 +82,7 @@ static void freeSide(SceneView& v) {
 	if (v.sDepth) hipFree(v.sDepth);
 	if (v.oDepth) hipFree(v.oDepth); if (v.oNormal) hipFree(v.oNormal); if (v.oConf) hipFree(v.oConf); if (v.oSnap) hipFree(v.oSnap);
 	if (v.oFDepth) hipFree(v.oFDepth); if (v.oFConf) hipFree(v.oFConf); if (v.oBgr) hipFree(v.oBgr);
+	for (int l = 0; l < 4; ++l) { if (v.oMask[l]) hipFree(v.oMask[l]); v.oMask[l] = nullptr; }
 	v.oDepth = v.oNormal = v.oConf = v.oSnap = v.oFDepth = v.oFConf = nullptr; v.oBgr = nullptr;
 	v.sDepth = nullptr; v.sw = v.sh = v.dw = v.dh = 0; v.sideDirty = false;
 }
@@ -423,9 +425,16 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 	if (anyMask && e->maskDirty) {
 		for (int l = 1; l <= e->nLevels; ++l) {
 			const size_t Pm = (size_t)e->lw(l) * e->lh(l);
-			for (int i = 0; i < e->nImages; ++i) if (e->hasMask[i])
-				hipLaunchKernelGGL(pm_mask_level_kernel, dim3((unsigned)std::min<size_t>((Pm + 255) / 256, 4096)), dim3(256), 0, e->stream,
-					e->d_mask[0] + (size_t)e->w * e->h * i, e->d_mask[l] + Pm * i, e->w, e->h, e->lw(l), e->lh(l));
+			for (int i = 0; i < e->nImages; ++i) if (e->hasMask[i]) {
+				const SceneView& mv = e->views[i];
+				if (mv.sw) {   // a view with its own size: its own level masks
+					const int mlw = lvlSize(mv.sw, l), mlh = lvlSize(mv.sh, l);
+					if (mlw < 1 || mlh < 1 || !mv.oMask[l]) continue;
+					hipLaunchKernelGGL(pm_mask_level_kernel, dim3((unsigned)std::min<size_t>(((size_t)mlw * mlh + 255) / 256, 4096)), dim3(256), 0, e->stream, mv.oMask[0], mv.oMask[l], mv.sw, mv.sh, mlw, mlh);
+				} else
+					hipLaunchKernelGGL(pm_mask_level_kernel, dim3((unsigned)std::min<size_t>((Pm + 255) / 256, 4096)), dim3(256), 0, e->stream,
+						e->d_mask[0] + (size_t)e->w * e->h * i, e->d_mask[l] + Pm * i, e->w, e->h, e->lw(l), e->lh(l));
+			}
 		}
 		HIPCHK(e, hipGetLastError());
 		e->maskDirty = false;
@@ -473,7 +482,7 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 			if (v.sw) { t.ref = v.sImg[l]; t.refS = v.sImgS[l]; }
 			else { t.ref = e->d_img[l] + Pls * id; t.refS = e->d_imgS[l] + e->skewPitch(l) * id; }
 			t.qArr = e->d_imgQ[l]; t.sArr = e->d_imgS[l]; t.qCount = (unsigned)(e->skewPitch(l) * (size_t)e->nImages);
-			t.mask = (anyMask && e->hasMask[id] && !v.sw) ? e->d_mask[l] + Pls * id : nullptr;
+			t.mask = (anyMask && e->hasMask[id]) ? (v.sw ? v.oMask[l] : e->d_mask[l] + Pls * id) : nullptr;
 			t.w = lw; t.h = lh; t.nSrc = v.nNb;
 			double K0[9];
 			if (l == 0) memcpy(K0, v.K, sizeof(K0)); else scaleK(v.K, cw, ch, lw, lh, K0);
@@ -783,6 +792,8 @@ int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevi
 			for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgS[l]) hipFree(v.sImgS[l]); if (v.sImgQ[l]) hipFree(v.sImgQ[l]); v.sImg[l] = v.sImgS[l] = nullptr; v.sImgQ[l] = nullptr; }
 			if (v.oDepth) hipFree(v.oDepth); if (v.oNormal) hipFree(v.oNormal); if (v.oConf) hipFree(v.oConf); if (v.oSnap) hipFree(v.oSnap);
 			if (v.oFDepth) hipFree(v.oFDepth); if (v.oFConf) hipFree(v.oFConf); if (v.oBgr) hipFree(v.oBgr);
+			for (int l = 0; l < 4; ++l) { if (v.oMask[l]) hipFree(v.oMask[l]); v.oMask[l] = nullptr; }
+			if (!e->hasMask.empty()) e->hasMask[idx] = 0;
 			v.oDepth = v.oNormal = v.oConf = v.oSnap = v.oFDepth = v.oFConf = nullptr; v.oBgr = nullptr;
 			v.sw = v.sh = 0; v.sideDirty = false; v.hasMaps = false;
 		}
@@ -863,6 +874,7 @@ int pmhip_scene_set_view_sized(pmhip_engine* e, int idx, const float* gray, int 
 		HIPCHK(e, hipMemsetAsync(v.oDepth, 0, sizeof(float) * P, e->stream)); HIPCHK(e, hipMemsetAsync(v.oNormal, 0, sizeof(float) * P * 3, e->stream));
 		HIPCHK(e, hipMemsetAsync(v.oConf, 0, sizeof(float) * P, e->stream)); HIPCHK(e, hipMemsetAsync(v.oSnap, 0, sizeof(float) * P, e->stream));
 		v.sw = w; v.sh = h; v.hasMaps = false;
+		if (!e->hasMask.empty()) e->hasMask[idx] = 0;     // (a mask of the previous size went with the side storage)
 	}
 	HIPCHK(e, hipMemcpyAsync(v.sImg[0], gray, sizeof(float) * (size_t)w * h, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
 	if (!onDevice) HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -938,7 +950,18 @@ int pmhip_scene_set_mask(pmhip_engine* e, int idx, const unsigned char* mask) {
 	const size_t P0 = (size_t)e->w * e->h;
 	if (e->hasMask.empty()) e->hasMask.assign(e->nImages, 0);
 	if (!mask) { e->hasMask[idx] = 0; return 0; }
-	if (e->views[idx].sw) { e->err = "ignore masks are kept for views of the scene's size only"; return PMHIP_E_SIZE; }
+	if (e->views[idx].sw) {                       // a view with its own size keeps its own masks
+		SceneView& v = e->views[idx];
+		for (int l = 0; l <= e->nLevels; ++l) {
+			const int mlw = lvlSize(v.sw, l), mlh = lvlSize(v.sh, l);
+			if (mlw < 1 || mlh < 1) break;
+			if (!v.oMask[l]) HIPCHK(e, hipMalloc(&v.oMask[l], (size_t)mlw * mlh));
+		}
+		HIPCHK(e, hipMemcpyAsync(v.oMask[0], mask, (size_t)v.sw * v.sh, hipMemcpyHostToDevice, e->stream));
+		HIPCHK(e, hipStreamSynchronize(e->stream));
+		e->hasMask[idx] = 1; e->maskDirty = true;
+		return 0;
+	}
 	if (!e->d_mask[0]) for (int l = 0; l <= e->nLevels; ++l) HIPCHK(e, hipMalloc(&e->d_mask[l], (size_t)e->lw(l) * e->lh(l) * e->nImages));
 	HIPCHK(e, hipMemcpyAsync(e->d_mask[0] + P0 * idx, mask, P0, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(e, hipStreamSynchronize(e->stream));

@@ -249,7 +249,7 @@ class PatchMatchHIP:
         if mask is None:
             self._chk(self._lib.pmhip_scene_set_mask(self._h, idx, None)); return
         m = np.ascontiguousarray(np.asarray(mask) != 0, np.uint8)
-        _, w, h = self._scene
+        w, h = self.view_size(idx)
         if m.shape != (h, w):
             raise ValueError("mask must be (h, w)")
         self._chk(self._lib.pmhip_scene_set_mask(self._h, idx, m.ctypes.data_as(C.POINTER(C.c_uint8))))

@@ -104,6 +104,7 @@ def test_estimator_mixed_resolution_neighbours_wide_kernel(pm_emulated):
 def test_estimator_reference_views_of_different_sizes(pm_emulated):
     from tests import test_gpu_patchmatch as g
     g.test_reference_views_of_different_sizes(96, 72)          # three size classes in one call, geometric round, per-map filters, cross-view filter
+    g.test_ignore_mask_on_a_view_with_its_own_size(96, 72)
 
 
 def test_estimator_mixed_resolution_neighbours(engine):

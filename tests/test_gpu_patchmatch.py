@@ -855,6 +855,32 @@ def test_reference_views_of_different_sizes(W=160, H=120, quick=False):
     e.close()
 
 
+def test_ignore_mask_on_a_view_with_its_own_size(W=128, H=96):
+    """pmhip_scene_set_mask on a view that carries its own size: its level masks are its own; photometric pass over the pyramid against the oracle."""
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    base = synth.make_scene(5, W, H, n_src=4)
+    big = synth.make_scene(5, W * 5 // 4, H * 5 // 4, n_src=4)
+    gray = {i: base.gray[i] for i in range(5)}; K = {i: base.K[i] for i in range(5)}
+    gray[1] = big.gray[1]; K[1] = big.K[1]
+    h1, w1 = gray[1].shape
+    mask = np.ones((h1, w1), np.uint8); mask[10:50, 20:80] = 0; mask[::6, ::5] = 0
+    seed = 17
+    p = default_params(seed=seed)
+    e = PatchMatchHIP(0); e.Init(False)
+    e.scene_load(base, n_levels=2)
+    e.scene_set_view_sized(1, gray[1], K[1], base.R[1], base.C[1], float(base.dmin[1]), float(base.dmax[1]), base.neighbors[1])
+    e.scene_set_mask(1, mask)
+    e.scene_estimate([0, 1], -1, p)
+    for v in (1, 0):
+        ids = [v] + [int(i) for i in base.neighbors[v]]
+        views, keep = po.make_views(gray, K, base.R, base.C, ids)
+        od, on, oc = po.estimate_depth_map_masked(views, len(ids), float(base.dmin[v]), float(base.dmax[v]), po.default_opt(seed=seed, viewID=v), mask if v == 1 else None, mask_mode=True)
+        d, n, c = e.scene_get_maps(v)
+        _same(d, od, "view %d depth" % v); _same(n, on, "normal"); _same(c, oc, "conf")
+    assert not e.scene_get_maps(1)[0][mask == 0].any()
+    e.close()
+
+
 def test_config2_full_size_matches_golden():
     """BASELINE config 2 at its own size: 9-view 1920x1080 scene, every view 1 ref x 8 src, photometric pass + 2 geometric rounds, against the digests the
     SEQUENTIAL oracle produced on the CPU (tests/golden/make_fullsize_golden.py, ~10 CPU-minutes; SceneDensify.cpp:616-805).  Bit-exact, all 27 maps;

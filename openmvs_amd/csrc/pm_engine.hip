@@ -557,7 +557,9 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 			hipLaunchKernelGGL(pm_upsample_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, lvlSize(cw, l + 1), lvlSize(ch, l + 1), lw, lh, nearestDepth);
 		// pass A: ScoreDepthMapTmp.  (Row-major pixels, guarded tap rows: 9.5 % of a 100-view step.  The same evaluation on anti-diagonals with the sweep's optimistic
 		// quad rows was measured 9 % SLOWER -- the maps are row-major, and a wave that walks a diagonal reads and writes them one cache line per lane:
-		// profiles/r04_call14_diagonal_init_kernel_stats.csv, 143.4 against 125.9 ms per geometric round.)
+		// profiles/r04_call14_diagonal_init_kernel_stats.csv, 143.4 against 125.9 ms per geometric round.  Its tap rows are 73 % of the kernel (r04_call15_*), yet
+		// optimistic rows from the row-major images (two dwordx2 buffer loads per sample, a third fewer instructions) and 128- / 256-thread workgroups changed nothing:
+		// 397.8 / 395.6 / 405.0 against 399.5 ms per step, r04_call16_*, r04_call17_* -- neither instruction issue nor L1 locality bounds it.)
 		const int PPB = PM_BLOCK / G;
 		const uint32_t passInit = (uint32_t)l * 64u + 32u + (geo ? 16u + (uint32_t)nGeometricIter : 0u);
 		evBegin(e, 1);

@@ -40,6 +40,15 @@ for name, env in configs:
             tq = time.perf_counter() - t                      # the host has enqueued everything (no sync inside the calls): host-bound if this is the whole step
             e.sync(); dt = time.perf_counter() - t
             if rep and dt < best: best = dt; enq = tq
+        init_ms = None
+        if os.environ.get("PROBE_STATS"):                      # one more step with the engine's event timing: milliseconds of the init kernels (ScoreDepthMapTmp) per step
+            e.stats_reset(True)
+            for v in allv: e.scene_reset_view(v)
+            e.scene_estimate(allv, -1, p, sync=False)
+            for g in range(2):
+                e.scene_commit_round(); e.scene_estimate(allv, g, p, sync=False)
+            e.sync(); st = e.stats_get(); init_ms = st.initMs
+            print("   init kernels %.1f ms per step (%d launches), sweeps wall %.1f ms" % (st.initMs, st.initLaunches, st.sweepWallMs), flush=True)
         d = e.scene_get_maps(0)[0]
         if ref is None: ref = d
         print("%-28s %-60s %.3f s/step (host enqueue %.3f s)  %.2f Mpix/s  same-as-first %s" % (name, env, best, enq, V * W * H / best / 1e6, bool(np.array_equal(d, ref))), flush=True)

@@ -68,6 +68,11 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (a.gpus, a.gpus))
     import torch.distributed as dist
+    # OPENMVS_AMD_DIST_BACKEND=gloo (+ more ranks than GPUs): the N-rank path on a box with fewer GPUs -- ranks share devices, collectives go through the host.  A functional
+    # check of the sharded schedule on real hardware (tools/r04/two_ranks_one_gpu.sh); the driver's scaling runs use the default, RCCL with one rank per GPU.
+    backend = os.environ.get("OPENMVS_AMD_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # OPENMVS_AMD_FORCE_COLLECTIVES=1: run the collective plumbing (RCCL process group, broadcasts, all-gathers, barrier, all-reduce) with one rank too, so
@@ -77,7 +82,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from openmvs_amd import synth
     from openmvs_amd.distributed import ShardedDensifier, shard_range
@@ -203,6 +211,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     mpix = V * W * H * a.steps / dt / 1e6
+    digests = None
+    if os.environ.get("OPENMVS_AMD_BENCH_DIGESTS") == "1":   # sha-1 of every view's final depth map, gathered: equal between a 1-rank and an N-rank run of the same scene
+        import hashlib
+        own = {int(g): hashlib.sha1(eng.scene_get_maps(slot[g])[0].tobytes()).hexdigest()[:12] for g in mine}
+        if dist_on:
+            box = [None] * world
+            dist.all_gather_object(box, own)
+            own = {k: v for d in box for k, v in d.items()}
+        digests = {str(k): own[k] for k in sorted(own)}
     mine_info = {"rank": rank, "views_per_gpu": len(mine), "foreign_views_held": len(foreign), "kernel": sweep_kernel_name(len(mine) if not a.batch else min(a.batch, len(mine)), N),
                  "exchange_ms_per_step": round(1e3 * drv.exchange_seconds / max(1, a.steps + a.warmup), 2), "seconds": round(own_dt, 3)}
     ranks_info = [mine_info]
@@ -233,7 +250,8 @@ def main():
                                    "(3-level pyramid x 3 sweeps) + %d geometric rounds%s, all depth maps"
                                    % (V, W, H, N, a.geo_iters, " + cross-view filter" if a.with_filter else ""),
                        "views_total": V, "views_per_gpu": len(mine), "batch": B, "parallelism": "reference views sharded over %d GPU(s)" % world,
-                       "exchange": "neighbour-only point-to-point (a rank holds its block and the %d foreign views it reads)" % len(foreign), "ranks": ranks_info},
+                       "exchange": "neighbour-only point-to-point (a rank holds its block and the %d foreign views it reads)" % len(foreign), "ranks": ranks_info,
+                       **({"backend": backend} if dist_on else {}), **({"depth_digests": digests} if digests else {})},
             "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), **tf, **issue,
                          "launches": int(st.sweepLaunches), "avg_launch_us": round(1e3 * st.sweepMs / max(1, st.sweepLaunches), 2),

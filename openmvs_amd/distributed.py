@@ -75,7 +75,10 @@ def exchange_neighbour_views(mine_maps: torch.Tensor, neighbors, n_views: int, w
     if not _collectives_on(world):
         return foreign, mine_maps[:0]
     lo = mine[0] if mine else 0
-    recv = torch.empty((len(foreign),) + tuple(mine_maps.shape[1:]), dtype=mine_maps.dtype, device=mine_maps.device)
+    # gloo has no point-to-point for device tensors: stage through the host then (the functional check of the N-rank path on a box with fewer GPUs; RCCL sends device memory)
+    staged = mine_maps.device.type != "cpu" and dist.get_backend() == "gloo"
+    src = mine_maps.cpu() if staged else mine_maps
+    recv = torch.empty((len(foreign),) + tuple(mine_maps.shape[1:]), dtype=mine_maps.dtype, device=src.device)
     ops, keep = [], []
     for peer in range(world):
         if peer == rank:
@@ -83,7 +86,7 @@ def exchange_neighbour_views(mine_maps: torch.Tensor, neighbors, n_views: int, w
         _, their_foreign = needed_views(neighbors, n_views, world, peer)
         to_send = [v for v in their_foreign if owner_of(v, n_views, world) == rank]          # ascending: the receiver's order
         if to_send:
-            buf = mine_maps[[v - lo for v in to_send]].contiguous(); keep.append(buf)
+            buf = src[[v - lo for v in to_send]].contiguous(); keep.append(buf)
             ops.append(dist.P2POp(dist.isend, buf, peer))
         idx = [k for k, v in enumerate(foreign) if owner_of(v, n_views, world) == peer]
         if idx:
@@ -92,7 +95,7 @@ def exchange_neighbour_views(mine_maps: torch.Tensor, neighbors, n_views: int, w
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-    return foreign, recv
+    return foreign, (recv.to(mine_maps.device) if staged else recv)
 
 
 class ShardedDensifier:

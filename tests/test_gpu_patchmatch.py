@@ -163,7 +163,7 @@ def test_sweep_kernel_variants_parity(nine_scene, small_scene, variant, quick=Fa
                 os.environ[k] = v
 
 
-def test_tuning_through_the_abi(nine_scene, threads=True):
+def test_tuning_through_the_abi(nine_scene, threads=True, views=None):
     """pmhip_set_tuning (include/pmhip.h): the mapping of a batch onto the GPU is chosen through the C ABI, not through the environment; every setting gives the
     oracle's bits."""
     from openmvs_amd.patchmatch import PatchMatchHIP
@@ -182,7 +182,7 @@ def test_tuning_through_the_abi(nine_scene, threads=True):
         for k, v in kw.items():
             assert got[k] == v, (k, got)
         e.Init(False); e.scene_load(sc, n_levels=2)
-        e.scene_estimate(list(range(sc.n_views)), -1, default_params(seed=5))
+        e.scene_estimate(list(range(sc.n_views)) if views is None else list(views), -1, default_params(seed=5))   # (the CPU emulator's run estimates a batch of four)
         d, n, c = e.scene_get_maps(4)
         _same(d, od, "tuning %s: depth" % kw); _same(n, on, "normal"); _same(c, oc, "conf")
     with pytest.raises(Exception):

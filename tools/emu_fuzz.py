@@ -4,7 +4,7 @@
         python tools/emu_fuzz.py --minutes 30 --seed 1
 
 Each trial draws a size, a number of source views, options, masks and ranges at random and checks bit-exact equality for: the estimator (photometric pass,
-sometimes a geometric round, sometimes masked), the post-filters, the fusion, SGM Match with both kernel mappings, and the resident tSGM loop.  A failure prints
+sometimes a geometric round, sometimes masked), the post-filters, the fusion, whole scenes whose views differ in size, SGM Match with both kernel mappings, and the resident tSGM loop.  A failure prints
 the trial's seed (re-run with --only <seed>) and the harness goes on."""
 import argparse, os, sys, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -98,6 +98,77 @@ def trial_filters_and_fusion(r):
     e.close()
 
 
+def trial_mixed_sizes(r):
+    """A scene whose views differ in size (each rendered at its own scale with its own K): estimation of all views in one call (one sweep per size class), geometric round,
+    per-map filters, cross-view filter and fusion -- every result against the oracle run with each map at its own size."""
+    nv = int(r.randint(3, 6)); W, H = int(r.randint(48, 90)) // 4 * 4, int(r.randint(40, 72)) // 4 * 4
+    nsrc = min(int(r.randint(2, 5)), nv - 1)
+    scales = [(1, 1), (3, 4), (5, 4), (3, 2)]
+    seed_sc = int(r.randint(1 << 30))
+    scs = {}
+
+    def scene(k):
+        if k not in scs:
+            a, b = scales[k]
+            scs[k] = synth.make_scene(nv, W * a // b, H * a // b, n_src=nsrc, seed=seed_sc)
+        return scs[k]
+    pick = [0 if v == 0 else int(r.randint(len(scales))) for v in range(nv)]
+    base = scene(0)
+    gray = {v: scene(pick[v]).gray[v] for v in range(nv)}; K = {v: scene(pick[v]).K[v] for v in range(nv)}; bgr = [scene(pick[v]).bgr[v] for v in range(nv)]
+    nbs = [[int(x) for x in base.neighbors[v]] for v in range(nv)]
+    seed = int(r.randint(1 << 20)); lv = int(r.randint(0, 2))
+    kw = dict(nSubResolutionLevels=lv, nEstimationIters=int(r.randint(1, 3)), nEstimationGeometricIters=1)
+    p = default_params(seed=seed, **kw)
+    e = PatchMatchHIP(0); e.Init(False)
+    e.scene_load(base, n_levels=2)
+    for v in range(nv):
+        if pick[v]:
+            e.scene_set_view_sized(v, gray[v], K[v], base.R[v], base.C[v], float(base.dmin[v]), float(base.dmax[v]), nbs[v])
+    allv = list(range(nv))
+    e.scene_estimate(allv, -1, p)
+    cur = {}
+    for v in allv:
+        ids = [v] + nbs[v]
+        views, keep = po.make_views(gray, K, base.R, base.C, ids)
+        cur[v] = po.estimate_depth_map(views, len(ids), float(base.dmin[v]), float(base.dmax[v]), po.default_opt(seed=seed, viewID=v, **kw))
+        for a, b, t in zip(e.scene_get_maps(v), cur[v], "dnc"):
+            same(a, b, "mixed sizes %s, photometric %s v%d (%s)" % ([scales[k] for k in pick], t, v, kw))
+    e.scene_commit_round(); e.Init(True); e.scene_estimate(allv, 0, p)
+    geo = {}
+    for v in allv:
+        ids = [v] + nbs[v]
+        src = {i: cur[i][0] for i in ids[1:]}; cams = {i: (K[i], base.R[i], base.C[i]) for i in ids[1:]}
+        views, keep = po.make_views(gray, K, base.R, base.C, ids, depth_maps=src, depth_cams=cams)
+        geo[v] = po.estimate_depth_map(views, len(ids), float(base.dmin[v]), float(base.dmax[v]), po.default_opt(seed=seed, viewID=v, **kw), geo_iter=0, depth=cur[v][0], normal=cur[v][1])
+        for a, b, t in zip(e.scene_get_maps(v), geo[v], "dnc"):
+            same(a, b, "mixed sizes, geometric %s v%d" % (t, v))
+    size, th = int(r.choice([3, 20, 60])), float(r.choice([0.004, 0.01, 0.03]))
+    e.scene_remove_small_segments(allv, size, th); e.scene_gap_interpolation(allv, 7, th)
+    flt = {}
+    for v in allv:
+        flt[v] = po.gap_interpolation(*po.remove_small_segments(*geo[v], nSpeckleSize=size, fDepthDiffThreshold=th), nIpolGapSize=7, fDepthDiffThreshold=th)
+        for a, b, t in zip(e.scene_get_maps(v), flt[v], "dnc"):
+            same(a, b, "mixed sizes, speckle + gap %s v%d" % (t, v))
+    for v in allv:
+        e.scene_set_color(v, bgr[v])
+    fkw = dict(nMinViewsFuse=int(r.randint(1, 4)), fDepthDiffThreshold=float(r.choice([0.01, 0.05])), bEstimateColor=bool(r.rand() < 0.5), bEstimateNormal=bool(r.rand() < 0.5))
+    deps = [flt[v][0] for v in allv]; nrms = [flt[v][1] for v in allv]; cnfs = [flt[v][2] for v in allv]
+    got = e.scene_fuse(po.fuse_order([len(x) for x in nbs]) if fkw["nMinViewsFuse"] >= 2 else allv, **fkw)
+    ref = po.fuse_depth_maps(deps, nrms, cnfs, bgr, [K[v] for v in allv], base.R, base.C, nbs, **fkw)
+    if fkw["nMinViewsFuse"] < 2:
+        got = dict(got); ref = dict(ref); got["weights"] = None; ref["weights"] = None
+    fc.same_cloud(got, ref, "mixed sizes, fuse %s" % fkw)
+    adj = bool(r.rand() < 0.5)
+    e.scene_filter(allv, bAdjust=adj, fDepthDiffThreshold=th)
+    D = {v: flt[v][0] for v in allv}; Cf = {v: flt[v][2] for v in allv}
+    for v in allv:
+        rc, od, oc = po.filter_depth_map(D, Cf, K, base.R, base.C, v, nbs[v], float(base.dmin[v]), float(base.dmax[v]), bAdjust=adj, fDepthDiffThreshold=th)
+        gd, gn, gc = e.scene_get_maps(v)
+        if rc == 0:
+            same(gd, od, "mixed sizes, filter depth v%d" % v); same(gc, oc, "mixed sizes, filter conf v%d" % v)
+    e.close()
+
+
 def trial_sgm(r, m):
     w, h = int(r.randint(12, 240)), int(r.randint(10, 120))
     kind = str(r.choice(["uniform", "ragged", "ragged", "holes"]))
@@ -155,12 +226,14 @@ def trial_sgm_steps(r, m):
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--minutes", type=float, default=10); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--only", type=int)
+    ap = argparse.ArgumentParser(); ap.add_argument("--minutes", type=float, default=10); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--only", type=int); ap.add_argument("--kind", type=str, default=None)
     a = ap.parse_args()
     eng = PatchMatchHIP(0); m = sgm.SemiGlobalMatcherHIP(0)
     t0 = time.time(); n = fails = 0
-    kinds = [("estimator", lambda r: trial_estimator(r, eng)), ("filters+fusion", trial_filters_and_fusion), ("sgm", lambda r: trial_sgm(r, m)), ("tsgm", lambda r: trial_tsgm(r, m)),
-             ("sgm steps", lambda r: trial_sgm_steps(r, m))]
+    kinds = [("estimator", lambda r: trial_estimator(r, eng)), ("filters+fusion", trial_filters_and_fusion), ("mixed sizes", trial_mixed_sizes), ("sgm", lambda r: trial_sgm(r, m)),
+             ("tsgm", lambda r: trial_tsgm(r, m)), ("sgm steps", lambda r: trial_sgm_steps(r, m))]
+    if a.kind:
+        kinds = [k for k in kinds if k[0] == a.kind]
     counts = {k: 0 for k, _ in kinds}
     s = a.seed * 1000003
     while time.time() - t0 < a.minutes * 60:

@@ -172,17 +172,18 @@ def test_tuning_through_the_abi(nine_scene, threads=True, views=None):
     e = PatchMatchHIP(0)
     t0 = e.tuning()
     assert t0["viewGroups"] >= 1 and t0["quadBuffer"] in (1, 2)
+    per = (sc.n_views if views is None else len(views)) / 2.0        # reference views per group in the two-group settings: a launch has (diagonal length x per) pixels
     for kw in (dict(wideMaxViews=-1, sweepLanes=4), dict(wideMaxViews=-1, sweepLanes=8, viewGroups=3), dict(wideMaxViews=64, wideHyps=2), dict(wideMaxViews=64, wideHyps=8, quadBuffer=2),
                dict(wideMaxViews=-1, sweepLanes=-1, quadBuffer=1, viewGroups=1),
                # per-launch choice: the short diagonals of a batch with the eight-wide speculative kernel, the middle ones with the two-wide one, the long ones with pm_sweep2
-               dict(wideMaxViews=-1, sweepLanes=4, viewGroups=2, widePixels=max(8, sc.height * 2), wide8Pixels=max(4, sc.height // 2)),
+               dict(wideMaxViews=-1, sweepLanes=4, viewGroups=2, widePixels=max(8, int(sc.height * per * 0.45)), wide8Pixels=max(4, int(sc.height * per * 0.12))),
                # one host thread per view group enqueueing its launches (the CPU emulator's launches are synchronous: device only)
                dict(wideMaxViews=64, wideHyps=-1, widePixels=-1, wide8Pixels=-1, viewGroups=3, launchThreads=3 if threads else 1)):
         got = e.tuning(**kw)
         for k, v in kw.items():
             assert got[k] == v, (k, got)
         e.Init(False); e.scene_load(sc, n_levels=2)
-        e.scene_estimate(list(range(sc.n_views)) if views is None else list(views), -1, default_params(seed=5))   # (the CPU emulator's run estimates a batch of four)
+        e.scene_estimate(list(range(sc.n_views)) if views is None else list(views), -1, default_params(seed=5))   # (the CPU emulator's run estimates a batch of two: one view per group)
         d, n, c = e.scene_get_maps(4)
         _same(d, od, "tuning %s: depth" % kw); _same(n, on, "normal"); _same(c, oc, "conf")
     with pytest.raises(Exception):

@@ -68,10 +68,14 @@ def all_gather_views(mine: torch.Tensor, n_views: int, world: int, rank: int) ->
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], 0)
 
 
-def exchange_neighbour_views(mine_maps: torch.Tensor, neighbors, n_views: int, world: int, rank: int):
+def exchange_neighbour_views(mine_maps, neighbors, n_views: int, world: int, rank: int, view_shapes=None):
     """Point-to-point exchange of exactly the maps each rank reads: returns (view ids, [len(ids), H, W] tensor) of the FOREIGN views this rank needs, in ascending id.
-    mine_maps: [len(block), H, W] maps of this rank's block, in block order.  Every rank derives the same send / receive lists from `neighbors`, so no metadata travels."""
+    mine_maps: [len(block), H, W] maps of this rank's block, in block order.  Every rank derives the same send / receive lists from `neighbors`, so no metadata travels.
+    Views of different sizes: mine_maps is a LIST of [h_v, w_v] tensors and view_shapes[v] = (h_v, w_v) for every view of the scene (known everywhere, like the cameras);
+    one message per view then, and the foreign maps come back as a list."""
     mine, foreign = needed_views(neighbors, n_views, world, rank)
+    if isinstance(mine_maps, (list, tuple)):
+        return foreign, _exchange_view_lists(list(mine_maps), mine, foreign, neighbors, n_views, world, rank, view_shapes)
     if not _collectives_on(world):
         return foreign, mine_maps[:0]
     lo = mine[0] if mine else 0
@@ -98,6 +102,33 @@ def exchange_neighbour_views(mine_maps: torch.Tensor, neighbors, n_views: int, w
     return foreign, (recv.to(mine_maps.device) if staged else recv)
 
 
+def _exchange_view_lists(mine_maps, mine, foreign, neighbors, n_views, world, rank, view_shapes):
+    if not _collectives_on(world) or not (mine_maps or foreign):
+        return []
+    like = mine_maps[0] if mine_maps else None
+    staged = like is not None and like.device.type != "cpu" and dist.get_backend() == "gloo"
+    dev = torch.device("cpu") if (staged or like is None) else like.device
+    dtype = like.dtype if like is not None else torch.float32
+    lo = mine[0] if mine else 0
+    recv = [torch.empty(tuple(view_shapes[v]), dtype=dtype, device=dev) for v in foreign]
+    ops, keep = [], []
+    for peer in range(world):
+        if peer == rank:
+            continue
+        _, their_foreign = needed_views(neighbors, n_views, world, peer)
+        for v in their_foreign:                                                     # ascending: messages between a pair of ranks are matched in order
+            if owner_of(v, n_views, world) == rank:
+                buf = (mine_maps[v - lo].cpu() if staged else mine_maps[v - lo]).contiguous(); keep.append(buf)
+                ops.append(dist.P2POp(dist.isend, buf, peer))
+        for k, v in enumerate(foreign):
+            if owner_of(v, n_views, world) == peer:
+                ops.append(dist.P2POp(dist.irecv, recv[k], peer))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return [r.to(like.device) for r in recv] if staged else recv
+
+
 class ShardedDensifier:
     """Photometric pass + `geo_iters` geometric rounds over this rank's block of views.
 
@@ -115,10 +146,11 @@ class ShardedDensifier:
       set_maps_views(what, foreign_ids, foreign: Tensor)                        -- the foreign neighbours' unfiltered maps for the filter (its own are in place)
     """
 
-    def __init__(self, estimator, n_views: int, world: int = 1, rank: int = 0, geo_iters: int = 2, neighbors=None):
+    def __init__(self, estimator, n_views: int, world: int = 1, rank: int = 0, geo_iters: int = 2, neighbors=None, view_shapes=None):
         self.est, self.n_views, self.world, self.rank, self.geo_iters = estimator, n_views, world, rank, geo_iters
         self.mine = list(shard_range(n_views, world, rank))
         self.neighbors = neighbors
+        self.view_shapes = view_shapes       # (h, w) of every view's maps when they differ (neighbour-only exchange; the estimator then hands lists of tensors)
         self.exchange_seconds = 0.0
 
     def exchange(self):
@@ -128,7 +160,7 @@ class ShardedDensifier:
         if self.neighbors is None:
             self.est.set_snapshot(all_gather_views(own, self.n_views, self.world, self.rank))
         else:
-            ids, maps = exchange_neighbour_views(own, self.neighbors, self.n_views, self.world, self.rank)
+            ids, maps = exchange_neighbour_views(own, self.neighbors, self.n_views, self.world, self.rank, self.view_shapes)
             self.est.set_snapshot_views(self.mine, own, ids, maps)
         self.exchange_seconds += time.perf_counter() - t
 
@@ -148,7 +180,7 @@ class ShardedDensifier:
             if self.neighbors is None:
                 self.est.set_maps(what, all_gather_views(own, self.n_views, self.world, self.rank))
             else:
-                ids, maps = exchange_neighbour_views(own, self.neighbors, self.n_views, self.world, self.rank)
+                ids, maps = exchange_neighbour_views(own, self.neighbors, self.n_views, self.world, self.rank, self.view_shapes)
                 self.est.set_maps_views(what, ids, maps)
         self.est.filter(self.mine)
 

@@ -157,3 +157,73 @@ def test_two_ranks_match_single_process(tmp_path):
     drv.filter()
     assert np.array_equal(np.load(tmp_path / "filtered_depth.npy"), est.depth) and np.array_equal(np.load(tmp_path / "filtered_conf.npy"), est.conf)
     assert (est.depth != sharded).any() and (est.depth > 0).mean() > 0.2
+
+
+# ---- views of different sizes: per-view messages (exchange_neighbour_views with lists) --------------------------------------------------------------
+class MixedSizeEstimator:
+    """Oracle stand-in for a scene whose views differ in size: every map a [h_v, w_v] array; what a rank was not sent stays None (a read of it fails)."""
+
+    def __init__(self):
+        from oracle import pyoracle as po
+        self.po = po
+        base = synth.make_scene(5, 48, 32, n_src=3); small = synth.make_scene(5, 36, 24, n_src=3); big = synth.make_scene(5, 60, 40, n_src=3)
+        src = {0: base, 1: small, 2: base, 3: big, 4: small}
+        self.base = base
+        self.gray = {v: src[v].gray[v] for v in range(5)}; self.K = {v: src[v].K[v] for v in range(5)}
+        self.shapes = [self.gray[v].shape for v in range(5)]
+        self.depth = [np.zeros(s, np.float32) for s in self.shapes]; self.normal = [np.zeros(s + (3,), np.float32) for s in self.shapes]
+        self.conf = [np.zeros(s, np.float32) for s in self.shapes]; self.snap = [None] * 5
+
+    def reset(self, ids):
+        for v in ids:
+            self.depth[v][:] = 0; self.normal[v][:] = 0; self.conf[v][:] = 0
+
+    def estimate(self, ids, geo):
+        po, b = self.po, self.base
+        for v in ids:
+            vid = [v] + [int(i) for i in b.neighbors[v]]
+            src = None if geo < 0 else {i: self.snap[i] for i in vid[1:]}
+            cams = None if geo < 0 else {i: (self.K[i], b.R[i], b.C[i]) for i in vid[1:]}
+            views, keep = po.make_views(self.gray, self.K, b.R, b.C, vid, depth_maps=src, depth_cams=cams)
+            self.depth[v], self.normal[v], self.conf[v] = po.estimate_depth_map(views, len(vid), float(b.dmin[v]), float(b.dmax[v]), po.default_opt(seed=SEED, viewID=v, nSubResolutionLevels=1),
+                                                                                  geo_iter=geo, depth=self.depth[v], normal=self.normal[v])
+
+    def local_depths(self, ids):
+        return [torch.from_numpy(self.depth[v].copy()) for v in ids]
+
+    def set_snapshot_views(self, own_ids, own, foreign_ids, foreign):
+        self.snap = [None] * 5
+        for v, m in zip(own_ids, own):
+            self.snap[v] = m.numpy()
+        for v, m in zip(foreign_ids, foreign):
+            assert tuple(m.shape) == self.shapes[v]
+            self.snap[v] = m.numpy()
+
+
+def _mixed_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    est = MixedSizeEstimator()
+    nbs = [[int(i) for i in est.base.neighbors[v]] for v in range(5)]
+    drv = ShardedDensifier(est, 5, world, rank, geo_iters=1, neighbors=nbs, view_shapes=est.shapes)
+    drv.run()
+    for v in drv.mine:
+        np.save(os.path.join(out_dir, "depth%d.npy" % v), est.depth[v])
+    dist.destroy_process_group()
+
+
+def test_neighbour_only_exchange_of_views_of_different_sizes(tmp_path):
+    """Views whose maps differ in size travel one message per view: 2 and 3 gloo ranks equal one process (photometric pass + one geometric round reading the neighbours'
+    maps at the neighbours' sizes)."""
+    est = MixedSizeEstimator()
+    nbs = [[int(i) for i in est.base.neighbors[v]] for v in range(5)]
+    ShardedDensifier(est, 5, 1, 0, geo_iters=1, neighbors=nbs, view_shapes=est.shapes).run()
+    assert len({d.shape for d in est.depth}) == 3
+    for world in (2, 3):
+        out = tmp_path / ("w%d" % world); out.mkdir()
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+        mp.spawn(_mixed_worker, args=(world, port, str(out)), nprocs=world, join=True)
+        for v in range(5):
+            assert np.array_equal(np.load(out / ("depth%d.npy" % v)), est.depth[v]), "world %d view %d" % (world, v)
+    assert (est.depth[3] > 0).mean() > 0.2

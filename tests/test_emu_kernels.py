@@ -105,6 +105,7 @@ def test_estimator_reference_views_of_different_sizes(pm_emulated):
     from tests import test_gpu_patchmatch as g
     g.test_reference_views_of_different_sizes(96, 72)          # three size classes in one call, geometric round, per-map filters, cross-view filter
     g.test_ignore_mask_on_a_view_with_its_own_size(96, 72)
+    g.test_sized_view_api_edges(64, 48)
 
 
 def test_estimator_mixed_resolution_neighbours(engine):

@@ -882,6 +882,37 @@ def test_ignore_mask_on_a_view_with_its_own_size(W=128, H=96):
     e.close()
 
 
+def test_sized_view_api_edges(W=96, H=72):
+    """Edges of the own-size views: a contiguous scene range that contains one is refused by pmhip_scene_copy (one by one it works); taking the view back to the scene's
+    size releases its own storage and the scene estimates as if it had never been sized; the cross-view filter declines a view with too few neighbour maps whatever its size."""
+    from openmvs_amd.patchmatch import PatchMatchError, PatchMatchHIP
+    base = synth.make_scene(5, W, H, n_src=4)
+    big = synth.make_scene(5, W * 5 // 4, H * 5 // 4, n_src=4)
+    seed = 13
+    p = default_params(seed=seed)
+    e = PatchMatchHIP(0); e.Init(False)
+    e.scene_load(base, n_levels=2)
+    e.scene_set_view_sized(2, big.gray[2], big.K[2], base.R[2], base.C[2], float(base.dmin[2]), float(base.dmax[2]), base.neighbors[2])
+    assert e.view_size(2) == (W * 5 // 4, H * 5 // 4) and e.view_size(1) == (W, H)
+    assert e.scene_device_ptr(1, 2) != 0 and e.scene_device_ptr(1, 2) != e.scene_device_ptr(1, 1) + 4 * W * H      # its maps are its own
+    with pytest.raises(PatchMatchError):
+        e.scene_copy(1, 1, 3, e.scene_device_ptr(4, 0), False)             # views 1..3 contain the sized view 2
+    e.scene_estimate([2], -1, default_params(seed=seed, nSubResolutionLevels=1))
+    d_big = e.scene_get_maps(2)[0]
+    assert d_big.shape == big.gray[2].shape and (d_big > 0).mean() > 0.3
+    e.scene_filter([2], nMinViewsFilter=2)                                # no neighbour has a depth map yet: not filterable, nothing staged, the maps stay
+    _same(e.scene_get_maps(2)[0], d_big, "filter declined")
+    # back to the scene's size
+    e.scene_set_view(2, base.gray[2], base.K[2], base.R[2], base.C[2], float(base.dmin[2]), float(base.dmax[2]), base.neighbors[2])
+    assert e.view_size(2) == (W, H)
+    e.scene_estimate([0, 2], -1, p)
+    for v in (0, 2):
+        od, on, oc = _oracle(base, v, seed)
+        d, n, c = e.scene_get_maps(v)
+        _same(d, od, "view %d after un-sizing" % v); _same(n, on, "normal"); _same(c, oc, "conf")
+    e.close()
+
+
 def test_config2_full_size_matches_golden():
     """BASELINE config 2 at its own size: 9-view 1920x1080 scene, every view 1 ref x 8 src, photometric pass + 2 geometric rounds, against the digests the
     SEQUENTIAL oracle produced on the CPU (tests/golden/make_fullsize_golden.py, ~10 CPU-minutes; SceneDensify.cpp:616-805).  Bit-exact, all 27 maps;

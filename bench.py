@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--with-filter", action="store_true", help="append the cross-view depth-map filter (config 5's exchange) to every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config2 / parity / sgm blocks")
+    ap.add_argument("--no-shard-rates", action="store_true", help="skip the shard-size legs (the blocks a rank owns at 2 / 4 / 8 GPUs, timed on this GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -221,7 +222,9 @@ def main():
             own = {k: v for d in box for k, v in d.items()}
         digests = {str(k): own[k] for k in sorted(own)}
     mine_info = {"rank": rank, "views_per_gpu": len(mine), "foreign_views_held": len(foreign), "kernel": sweep_kernel_name(len(mine) if not a.batch else min(a.batch, len(mine)), N),
-                 "exchange_ms_per_step": round(1e3 * drv.exchange_seconds / max(1, a.steps + a.warmup), 2), "seconds": round(own_dt, 3)}
+                 # exchange = sending / receiving / installing maps at the round boundaries; wait = blocked on this rank's own asynchronous estimate before its maps can be read
+                 "exchange_ms_per_step": round(1e3 * drv.exchange_seconds / max(1, a.steps + a.warmup), 2),
+                 "wait_for_own_estimate_ms_per_step": round(1e3 * drv.wait_seconds / max(1, a.steps + a.warmup), 2), "seconds": round(own_dt, 3)}
     ranks_info = [mine_info]
     if dist_on:
         box = [None] * world
@@ -265,6 +268,8 @@ def main():
             "accuracy": {"valid_frac_view0": round(float(m.mean()), 4), "median_rel_err_vs_ground_truth": float(np.median(rel))},
         }
     # ---- extra legs (rank 0, 1 GPU only; outside the timed region) ---------------------------
+    if rank == 0 and world == 1 and not weak and not a.no_shard_rates and V >= 16:
+        out.update(shard_rate_legs(eng, a, V, W, H, p, mpix))
     if rank == 0 and world == 1:
         eng.scene_create(2, 16, 16, 0)   # release the benchmark scene's HBM before the other legs
         if not a.no_extras:
@@ -277,6 +282,33 @@ def main():
     eng.close()
     if dist_on:
         dist.destroy_process_group()
+
+
+def shard_rate_legs(eng, a, V, W, H, p, rate_full):
+    """The one-GPU side of the scaling model, under the driver's clock: the block of reference views ONE rank owns when the same scene is split over 2 / 4 / 8 GPUs
+    (ceil(V / N) contiguous views; their foreign source views are resident here as they are on that rank), full schedule, 1 warm-up + 2 timed steps each.
+    scaling_model[N] = N x rate(ceil(V / N)) / rate(V): what N GPUs would deliver if the exchange at the round boundaries were free (it is two neighbour-only
+    point-to-point rounds per step; its cost is `exchange_ms_per_step` of an N-rank run)."""
+    rates, model = {}, {}
+    for n_gpus in (2, 4, 8):
+        n = -(-V // n_gpus)
+        lo = (V - n) // 2                                  # a block from the middle of the scene: neighbours on both sides, like most ranks' blocks
+        ids = list(range(lo, lo + n))
+        best = None
+        for rep in range(3):
+            for v in ids:
+                eng.scene_reset_view(v)
+            eng.sync(); t = time.perf_counter()
+            eng.scene_estimate(ids, -1, p, sync=False)
+            for g in range(a.geo_iters):
+                eng.scene_commit_round(); eng.scene_estimate(ids, g, p, sync=False)
+            eng.sync(); dt = time.perf_counter() - t
+            if rep and (best is None or dt < best):
+                best = dt
+        rates[str(n)] = round(n * W * H / best / 1e6, 3)
+        model[str(n_gpus)] = round(n_gpus * rates[str(n)] / rate_full, 3)
+    return {"shard_rates": {"unit": "Mpix/s on one GPU for a block of this many reference views of the same scene (best of 2 timed steps)", **rates},
+            "scaling_model": {"note": "N x rate(ceil(views / N)) / rate(views), exchange excluded; measured on ONE GPU, not a multi-GPU run", **model}}
 
 
 def sweep_kernel_name(n_batch, n_src):
@@ -389,31 +421,27 @@ def golden_and_config2(eng):
                 gc.check_maps(rounds[r][v], g["rounds"][r][str(v)], "round %d view %d" % (r, v))
             except AssertionError as ex:
                 mismatches.append(str(ex)[:300])
-    # the same 27 maps through the kernel instantiation the TIMED region uses for a 100-view batch -- pm_sweep2_kernel<4 lanes per pixel, 2 views per lane> -- which
-    # the engine would not pick for 9 views by itself (PMHIP_WIDE / PMHIP_LANES are read at pmhip_create): the throughput figure and the bit-identity claim are about
-    # one and the same kernel
-    timed_mismatches = []
-    saved = {k: os.environ.get(k) for k in ("PMHIP_WIDE", "PMHIP_LANES")}          # (PMHIP_WIDE=0 also switches the per-launch use of the speculative kernels off)
-    os.environ["PMHIP_WIDE"] = "0"; os.environ["PMHIP_LANES"] = "4"
-    try:
-        from openmvs_amd.patchmatch import PatchMatchHIP
-        e2 = PatchMatchHIP(0); e2.Init(True); e2.scene_load(sc, 2)
+    # the same 27 maps through what the TIMED region runs for a 100-view batch, which the engine would not pick for 9 views by itself (set through pmhip_set_tuning):
+    #  (1) pm_sweep2_kernel<4 lanes per pixel, 2 views per lane> alone; (2) the timed MIX: that kernel on the long diagonals and pm_sweep_widen_kernel<2> on the short ones
+    #  inside one sweep, in two view groups that run out of phase -- the per-launch threshold scaled so that the same diagonals (by length) switch kernels as at 50 views per group:
+    #  PMHIP_DEFAULT_WIDE_PIXELS 20000 / 50 = 400 pixels of diagonal, x 4.5 views per group here
+    timed_mismatches, mix_mismatches = [], []
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    for name, tun, sink in (("timed kernel", dict(wideMaxViews=-1, sweepLanes=4), timed_mismatches),
+                            ("timed mix", dict(wideMaxViews=-1, sweepLanes=4, widePixels=1800, viewGroups=2), mix_mismatches)):
+        e2 = PatchMatchHIP(0); e2.tuning(**tun); e2.Init(True); e2.scene_load(sc, 2)
         for r in range(1 + c["geo_iters"]):
             if r:
                 e2.scene_commit_round()
             e2.scene_estimate(allv, r - 1, p)
             for v in allv:
                 try:
-                    gc.check_maps(e2.scene_get_maps(v), g["rounds"][r][str(v)], "timed kernel, round %d view %d" % (r, v))
+                    gc.check_maps(e2.scene_get_maps(v), g["rounds"][r][str(v)], "%s, round %d view %d" % (name, r, v))
                 except AssertionError as ex:
-                    timed_mismatches.append(str(ex)[:300])
+                    sink.append(str(ex)[:300])
+        mix_tuning = e2.tuning()
         e2.close()
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    timed_mismatches = timed_mismatches + mix_mismatches
     ref = c["ref"]
     ids = [ref] + list(sc.neighbors[ref])
     times, cur = [], None
@@ -446,10 +474,10 @@ def golden_and_config2(eng):
                                "against the SHA-256 digests of the sequential CPU oracle (tests/golden/pm_config2_1920x1080.json), scene interface and one-call boundary"
                                % (c["geo_iters"], 3 * len(allv) * (1 + c["geo_iters"])),
                        "inputs_reproduced": bool(same_inputs), "bit_identical": bool(same_inputs and not mismatches and not timed_mismatches), "mismatches": (mismatches + timed_mismatches)[:4],
-                       "kernel": "pm_sweep2_kernel", "kernel_note": "all 27 maps also through pm_sweep2_kernel<4,2> alone (PMHIP_WIDE=0 PMHIP_LANES=4), the instantiation that sweeps the long diagonals of the timed 100-view "
-                                 "batch; its short diagonals go through pm_sweep_widen_kernel<2>, which is the engine's own choice for these 9 views (the first check); the one-call "
-                                 "boundary (pm_sweep_wide_kernel) is the third",
-                       "bit_identical_timed_kernel": bool(same_inputs and not timed_mismatches),
+                       "kernel": "pm_sweep2_kernel", "kernel_note": "all 27 maps four ways: the engine's own choice for 9 views (pm_sweep_widen_kernel<2>); pm_sweep2_kernel<4,2> alone; the TIMED MIX "
+                                 "(pm_sweep2_kernel<4,2> on the long diagonals, pm_sweep_widen_kernel<2> on the short ones of the same sweep, two view groups out of phase: tuning %s); "
+                                 "the one-call boundary (pm_sweep_wide_kernel)" % json.dumps(mix_tuning),
+                       "bit_identical_timed_kernel": bool(same_inputs and not timed_mismatches), "bit_identical_timed_mix": bool(same_inputs and not mix_mismatches),
                        "depth_rmse_over_diameter": rmse / sc.diameter, "tolerance": 1e-4,
                        "rmse_note": "over the golden file's strided depth sample of the reference view (exactly 0 when bit_identical)"}}
 
@@ -569,7 +597,9 @@ def cpu_legs(a, eng):
         def est_ref(views, n, ref, geo, d, nrm):
             opt = po.default_opt(seed=seed, viewID=ref, nThreads=cores, rngMode=2, nEstimationGeometricIters=a.geo_iters)
             return pr.ref_estimate_depth_map(views, n, float(sc.dmin[ref]), float(sc.dmax[ref]), opt, geo_iter=geo, depth=d, normal=nrm, kind="libm")
-        outs, t_ref = cpu_schedule(sc, rounds, refs, cores, est_ref, False)
+        # (chain = True: a view's geometric rounds start from the reference code's OWN maps of the round before -- the full schedule of that view as the reference runs it; the
+        # neighbours' previous-round maps it reads are the engine's.  Same work as the decoupled form, so the timing is unchanged, and the result is what `tolerance` compares.)
+        outs, t_ref = cpu_schedule(sc, rounds, refs, cores, est_ref, True)
         base = {"value": round(len(refs) * W * H / t_ref / 1e6, 5), "unit": "Mpix/s", "cores": cores, "kind": "reference",
                 "sample": "%d reference views x 8 sources at %dx%d, photometric pass (3-level pyramid x 3 sweeps) + %d geometric rounds each, through the reference's own "
                           "DepthMapsData::EstimateDepthMap / DepthEstimator code (oracle/_ref: verbatim line ranges of SceneDensify.cpp and DepthMap.cpp, g++ -O3 -march=x86-64-v3, "
@@ -578,8 +608,11 @@ def cpu_legs(a, eng):
         # ---- what the 1e-4 x diameter tolerance means against a reference binary (information; the gate is bit-identity with the oracle) --------------------
         def cmp(x, y):
             m = (x > 0) & (y > 0)
-            rm = float(np.sqrt(np.mean((x[m].astype(np.float64) - y[m]) ** 2))) / sc.diameter if m.any() else float("nan")
-            return {"depth_rmse_over_diameter": rm, "median_abs_over_diameter": float(np.median(np.abs(x[m].astype(np.float64) - y[m]))) / sc.diameter if m.any() else float("nan"),
+            ad = np.abs(x[m].astype(np.float64) - y[m]) / sc.diameter
+            if not m.any():
+                return {"depth_rmse_over_diameter": float("nan")}
+            return {"depth_rmse_over_diameter": float(np.sqrt(np.mean(ad ** 2))), "median_abs_over_diameter": float(np.median(ad)),
+                    "p95_abs_over_diameter": float(np.percentile(ad, 95)), "frac_within_1e-4": float((ad <= 1e-4).mean()),
                     "valid_in_only_one": int(((x > 0) != (y > 0)).sum()), "valid_in_both": int(m.sum())}
         v0 = refs[0]
         ids0 = [v0] + list(sc.neighbors[v0])
@@ -589,14 +622,28 @@ def cpu_legs(a, eng):
         ref_b = est_ref(views0, len(ids0), v0, -1, None, None)
         t_tol = time.perf_counter() - t
         hip = rounds[0][v0]
-        gt = sc.gt_depth[v0]
+
+        def vs_gt_of(x, v):
+            m = x > 0
+            g = sc.gt_depth[v]
+            return {"depth_rmse_over_diameter": float(np.sqrt(np.mean((x[m].astype(np.float64) - g[m]) ** 2))) / sc.diameter, "valid_frac": float(m.mean())}
 
         def vs_gt(x):
-            m = x > 0
-            return {"depth_rmse_over_diameter": float(np.sqrt(np.mean((x[m].astype(np.float64) - gt[m]) ** 2))) / sc.diameter, "valid_frac": float(m.mean())}
+            return vs_gt_of(x, v0)
+        # the FULL schedule (photometric pass + the geometric rounds, which damp outliers): the final maps of three views, HIP vs the reference's code, and the reference's
+        # code against a second full run of itself on the first of them
+        t = time.perf_counter()
+        again, _ = cpu_schedule(sc, rounds, refs[:1], cores, est_ref, True)
+        t_tol += time.perf_counter() - t
+        full = {"views": refs[:3],
+                "hip_vs_reference_code": {str(v): cmp(rounds[-1][v][0], outs[v][0]) for v in refs[:3]},
+                "reference_code_run_a_vs_run_b": {str(refs[0]): cmp(outs[refs[0]][0], again[refs[0]][0])},
+                "hip_vs_ground_truth": {str(v): vs_gt_of(rounds[-1][v][0], v) for v in refs[:3]},
+                "reference_code_vs_ground_truth": {str(v): vs_gt_of(outs[v][0], v) for v in refs[:3]}}
         out["tolerance"] = {"case": "view %d of the 9-view %dx%d scene, photometric pass (end-of-pass threshold x 1.333), depth maps" % (v0, W, H),
                             "hip_vs_reference_code": cmp(hip[0], ref_a[0]), "reference_code_run_a_vs_run_b": cmp(ref_a[0], ref_b[0]),
                             "hip_vs_ground_truth": vs_gt(hip[0]), "reference_code_vs_ground_truth": vs_gt(ref_a[0]),
+                            "full_schedule": full,
                             "north_star_tolerance": 1e-4, "seconds": round(t_tol, 1),
                             "note": "reference code = oracle/_ref (libm, std::mt19937, %d racy threads); HIP = this engine (pm_math.h, Philox).  The estimator is chaotic pixel by pixel: the "
                                     "reference does not reproduce ITSELF within 1e-4 x diameter from run to run, so the tolerance is met by construction against the sequential oracle "

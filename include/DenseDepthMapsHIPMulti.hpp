@@ -12,7 +12,7 @@
 //
 // The collectives are a policy:
 //   RcclCollective       (define PMHIP_WITH_RCCL, link -lrccl): ncclCommInitAll over the devices, grouped ncclBroadcast calls on the engines' streams --
-//                        the product path.  Unequal shards: each owner's block is one broadcast of the group (a ring all-gather needs equal counts).
+//                        the product path; the round-boundary exchanges are grouped ncclSend / ncclRecv pairs of exactly the maps a device reads.
 //   LocalCopyCollective  several engines on ONE device (debugging, and the single-GPU CI box): device-to-device copies between the engines' arrays.
 #pragma once
 #include <algorithm>
@@ -30,17 +30,11 @@
 
 namespace MVS {
 
-// blocks [off[r], off[r] + cnt[r]) (bytes) of a per-device array are owned by device r; after AllGatherV every device holds every block
 struct LocalCopyCollective {
 	explicit LocalCopyCollective(const std::vector<int>&) {}
 	void Broadcast(const std::vector<void*>& bufs, size_t bytes, int root, const std::vector<hipStream_t>& streams) {
 		sync(streams);
 		for (size_t d = 0; d < bufs.size(); ++d) if ((int)d != root && hipMemcpy(bufs[d], bufs[(size_t)root], bytes, hipMemcpyDeviceToDevice) != hipSuccess) throw std::runtime_error("LocalCopyCollective: copy failed");
-	}
-	void AllGatherV(const std::vector<void*>& bases, const std::vector<size_t>& off, const std::vector<size_t>& cnt, const std::vector<hipStream_t>& streams) {
-		sync(streams);
-		for (size_t r = 0; r < bases.size(); ++r) for (size_t d = 0; d < bases.size(); ++d) if (d != r && cnt[r])
-			if (hipMemcpy((char*)bases[d] + off[r], (const char*)bases[r] + off[r], cnt[r], hipMemcpyDeviceToDevice) != hipSuccess) throw std::runtime_error("LocalCopyCollective: copy failed");
 	}
 	// point-to-point copies: every transfer moves `bytes` from device src's buffer to device dst's
 	struct Xfer { int src, dst; const void* from; void* to; size_t bytes; };
@@ -65,12 +59,6 @@ public:
 	void Broadcast(const std::vector<void*>& bufs, size_t bytes, int root, const std::vector<hipStream_t>& streams) {
 		ok(ncclGroupStart());
 		for (size_t d = 0; d < devs_.size(); ++d) { hipSetDevice(devs_[d]); ok(ncclBroadcast(bufs[d], bufs[d], bytes, ncclChar, root, comms_[d], streams[d])); }
-		ok(ncclGroupEnd());
-	}
-	void AllGatherV(const std::vector<void*>& bases, const std::vector<size_t>& off, const std::vector<size_t>& cnt, const std::vector<hipStream_t>& streams) {
-		ok(ncclGroupStart());
-		for (size_t r = 0; r < devs_.size(); ++r) if (cnt[r])
-			for (size_t d = 0; d < devs_.size(); ++d) { hipSetDevice(devs_[d]); ok(ncclBroadcast((char*)bases[d] + off[r], (char*)bases[d] + off[r], cnt[r], ncclChar, (int)r, comms_[d], streams[d])); }
 		ok(ncclGroupEnd());
 	}
 	typedef LocalCopyCollective::Xfer Xfer;
@@ -131,8 +119,11 @@ public:
 			for (int i = 0; i < n; ++i) {
 				const View& v = views[(size_t)i];
 				if (!v.gray) throw std::runtime_error("DenseDepthMapsHIPMulti: view without an image");
-				// images go up once, to the first device; the others get cameras and neighbour lists now and the pixels by the broadcast below
-				check(d, pmhip_scene_set_view(e, i, d == 0 ? v.gray : nullptr, 0, v.K, v.R, v.C, v.dMin, v.dMax, v.neighbors.data(), (int)v.neighbors.size()));
+				// images go up once, to the first device; the others get cameras and neighbour lists now and the pixels by the broadcast below.  A view with its own
+				// size (DepthMapsData::InitViews sizes every depth map on its own image, SceneDensify.cpp:306-459) lives outside the scene's image array: every device
+				// gets it from the host (such views are the exception -- a neighbour rescaled by ViewData::ScaleImage)
+				if (sized(i)) check(d, pmhip_scene_set_view_sized(e, i, v.gray, v.w, v.h, 0, v.K, v.R, v.C, v.dMin, v.dMax, v.neighbors.data(), (int)v.neighbors.size()));
+				else check(d, pmhip_scene_set_view(e, i, d == 0 ? v.gray : nullptr, 0, v.K, v.R, v.C, v.dMin, v.dMax, v.neighbors.data(), (int)v.neighbors.size()));
 				if (v.mask) check(d, pmhip_scene_set_mask(e, i, v.mask));
 				if (v.bgr && d == 0) check(d, pmhip_scene_set_color(e, i, v.bgr));    // colours are only read by the fusing device
 			}
@@ -179,7 +170,9 @@ public:
 		for (int d = 0; d < NumDevices(); ++d) check(d, pmhip_sync(eng_[(size_t)d]));
 		DenseDepthMapsHIP::FuseOn(eng_[0], views_, opt_, pc);
 	}
-	// a view's maps from the device that owns it
+	// a view's maps from the device that owns it; ViewWidth(idx) x ViewHeight(idx) entries
+	int ViewWidth(int idx) const { return sized(idx) ? views_[(size_t)idx].w : w_; }
+	int ViewHeight(int idx) const { return sized(idx) ? views_[(size_t)idx].h : h_; }
 	void GetMaps(int idx, float* depth, float* normal, float* conf) {
 		for (int d = 0; d < NumDevices(); ++d) if (owns(d, idx)) { check(d, pmhip_scene_get_maps(eng_[(size_t)d], idx, depth, normal, conf)); return; }
 		throw std::runtime_error("DenseDepthMapsHIPMulti: no such view");
@@ -213,19 +206,31 @@ public:
 	size_t ExchangedBytes() const { return exchanged_; }
 	const std::vector<int>& ForeignViews(int d) const { return needs_[(size_t)d]; }
 private:
-	// one per-view array (what: 1 depth, 2 normal, 3 conf): every device receives the views it reads from their owners, runs of consecutive views as one transfer
+	// a view that carries its own image size keeps its own maps on every device (pmhip_scene_device_ptr(e, what, idx) finds them); the others sit side by side in the scene arrays
+	bool sized(int i) const { const View& v = views_[(size_t)i]; return v.w > 0 && v.h > 0 && (v.w != w_ || v.h != h_); }
+	size_t mapBytes(int what, int i) const { return sizeof(float) * (size_t)ViewWidth(i) * ViewHeight(i) * (what == 2 ? 3 : 1); }
+	// transfers of the ascending views `list` (all owned by device src) to device dst: runs of consecutive scene-size views as one transfer, a view of its own size on its own
+	void addTransfers(std::vector<typename Collective::Xfer>& xs, int what, int src, int dst, const std::vector<int>& list) {
+		for (size_t k = 0; k < list.size(); ) {
+			size_t e = k + 1;
+			if (!sized(list[k])) while (e < list.size() && list[e] == list[e - 1] + 1 && !sized(list[e])) ++e;
+			typename Collective::Xfer x; x.src = src; x.dst = dst; x.bytes = 0;
+			for (size_t q = k; q < e; ++q) x.bytes += mapBytes(what, list[q]);
+			x.from = pmhip_scene_device_ptr(eng_[(size_t)src], what, list[k]);
+			x.to = pmhip_scene_device_ptr(eng_[(size_t)dst], what, list[k]);
+			xs.push_back(x); exchanged_ += x.bytes; k = e;
+		}
+	}
+	// one per-view array (what: 1 depth, 2 normal, 3 conf): every device receives the views it reads from their owners
 	void gatherNeighbours(int what) {
-		const size_t per = sizeof(float) * (size_t)w_ * h_ * (what == 2 ? 3 : 1);
 		std::vector<typename Collective::Xfer> xs;
 		for (int d = 0; d < NumDevices(); ++d) {
 			const std::vector<int>& nd = needs_[(size_t)d];
 			for (size_t k = 0; k < nd.size(); ) {
 				const int r = ownerOf(nd[k]); size_t e = k + 1;
-				while (e < nd.size() && nd[e] == nd[e - 1] + 1 && ownerOf(nd[e]) == r) ++e;
-				typename Collective::Xfer x; x.src = r; x.dst = d; x.bytes = per * (e - k);
-				x.from = (const char*)pmhip_scene_device_ptr(eng_[(size_t)r], what, 0) + per * (size_t)nd[k];
-				x.to = (char*)pmhip_scene_device_ptr(eng_[(size_t)d], what, 0) + per * (size_t)nd[k];
-				xs.push_back(x); exchanged_ += x.bytes; k = e;
+				while (e < nd.size() && ownerOf(nd[e]) == r) ++e;
+				addTransfers(xs, what, r, d, std::vector<int>(nd.begin() + (long)k, nd.begin() + (long)e));
+				k = e;
 			}
 		}
 		coll_->Exchange(xs, streams());
@@ -233,26 +238,15 @@ private:
 	}
 	// every block of one per-view array to ONE device (the fusing one)
 	void gatherTo(int root, int what) {
-		const size_t per = sizeof(float) * (size_t)w_ * h_ * (what == 2 ? 3 : 1);
 		std::vector<typename Collective::Xfer> xs;
 		for (int r = 0; r < NumDevices(); ++r) if (r != root && count_[(size_t)r]) {
-			typename Collective::Xfer x; x.src = r; x.dst = root; x.bytes = per * (size_t)count_[(size_t)r];
-			x.from = (const char*)pmhip_scene_device_ptr(eng_[(size_t)r], what, 0) + per * (size_t)first_[(size_t)r];
-			x.to = (char*)pmhip_scene_device_ptr(eng_[(size_t)root], what, 0) + per * (size_t)first_[(size_t)r];
-			xs.push_back(x); exchanged_ += x.bytes;
+			std::vector<int> block; for (int32_t i : ids(r)) block.push_back(i);
+			addTransfers(xs, what, r, root, block);
 		}
 		coll_->Exchange(xs, streams());
 		if (what == 1) check(root, pmhip_scene_maps_updated(eng_[(size_t)root], 0, (int)views_.size()));
 	}
 	int ownerOf(int i) const { for (int d = 0; d < NumDevices(); ++d) if (owns(d, i)) return d; return 0; }
-	// all-gather of one per-view array over the owners' blocks (kept for callers that want every map everywhere)
-	void gather(int what) {
-		const size_t per = sizeof(float) * (size_t)w_ * h_ * (what == 2 ? 3 : 1);
-		std::vector<void*> bases; std::vector<size_t> off, cnt;
-		for (int d = 0; d < NumDevices(); ++d) { bases.push_back(pmhip_scene_device_ptr(eng_[(size_t)d], what, 0)); off.push_back(per * (size_t)first_[(size_t)d]); cnt.push_back(per * (size_t)count_[(size_t)d]); }
-		coll_->AllGatherV(bases, off, cnt, streams());
-		if (what == 1) for (int d = 0; d < NumDevices(); ++d) check(d, pmhip_scene_maps_updated(eng_[(size_t)d], 0, (int)views_.size()));
-	}
 	void check(int d, int rc) const { if (rc != PMHIP_OK) throw std::runtime_error("pmhip (device " + std::to_string(devs_[(size_t)d]) + "): " + pmhip_last_error(eng_[(size_t)d])); }
 	void release() { for (pmhip_engine* e : eng_) pmhip_destroy(e); eng_.clear(); }
 

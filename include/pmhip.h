@@ -212,6 +212,8 @@ int pmhip_scene_images_updated(pmhip_engine* e);
  * (DepthData::IsValid(), SceneDensify.cpp:2150-2163).  pmhip_scene_estimate, _set_maps and _copy(what == 1, toEngine) do this themselves; a raw
  * pointer write cannot, and such neighbours would be skipped without this call. */
 int pmhip_scene_maps_updated(pmhip_engine* e, int firstIdx, int count);
+/* Device memory the resident scene holds right now, in bytes (images with their layouts, maps, masks, filter staging, batch scratch; not the fusion's working buffers). */
+uint64_t pmhip_scene_bytes(pmhip_engine* e);
 int pmhip_sync(pmhip_engine* e);
 /* Engine stream (hipStream_t) so callers can bracket work with their own events. */
 void* pmhip_stream(pmhip_engine* e);
@@ -223,8 +225,8 @@ void* pmhip_stream(pmhip_engine* e);
 typedef struct PMHipKernelStats {
 	uint64_t sweepLaunches; double sweepMs; double sweepBytes; uint64_t sweepPixels;
 	uint64_t initLaunches; double initMs;
-	double sweepWallMs; /* wall time of the sweep phases; sweepMs sums the per-stream times of the concurrent view groups */
-	double sweepHostMs; /* host time spent enqueueing the sweep launches (close to sweepWallMs: the host's launch rate, not the GPU, bounds the sweeps) */
+	double sweepWallMs; /* wall time of the passes (hand-off, init, sweeps, finalize of all view groups, which overlap); sweepMs sums the per-stream times of the sweeps alone */
+	double sweepHostMs; /* host time spent enqueueing the passes (a few per cent of sweepWallMs: one thread enqueues a launch in ~3 us, profiles/r04_call9_launch_rate.log) */
 } PMHipKernelStats;
 int pmhip_stats_reset(pmhip_engine* e, int enableEvents);
 int pmhip_stats_get(pmhip_engine* e, PMHipKernelStats* out);
@@ -233,14 +235,15 @@ int pmhip_stats_get(pmhip_engine* e, PMHipKernelStats* out);
  * csrc/pm_engine.hip); 0 in a field of pmhip_set_tuning keeps the current value.  (The PMHIP_* environment variables of earlier rounds still seed the defaults at
  * pmhip_create, for experiments; a host program uses these two calls.) */
 typedef struct PMHipTuning {
-	int32_t viewGroups;      /* view groups of a batch that sweep on their own streams (2) */
+	int32_t viewGroups;      /* view groups of a batch; each runs its whole pass (every level's hand-off, init, sweeps, finalize) on its own stream, the groups meet at the end of the call (2) */
 	int32_t wideMaxViews;    /* batches of at most this many reference views use the speculative sweep kernels for every launch (32); -1 = no speculative kernels at all (also clears widePixels / wide8Pixels unless set in the same call) */
 	int32_t wideHyps;        /* hypotheses per round of the speculative kernel: 8, 4 or 2; -1 = by batch size (8 for one or two views, else 2) */
 	int32_t sweepLanes;      /* lanes per pixel of pm_sweep2_kernel: 4, 8 or 16; -1 = by batch size */
 	int32_t quadBuffer;      /* 1: tap rows address the level's quad images as one buffer, 2: through each view's pointer */
 	int32_t widePixels;      /* larger batches: a diagonal launch of at most this many pixels (diagonal length x views of the group) uses the two-wide speculative kernel (20000); -1 = none */
 	int32_t wide8Pixels;     /* ... and one of at most this many pixels the eight-wide speculative kernel; -1 = none */
-	int32_t launchThreads;   /* host threads enqueueing a sweep's launches: 1 = the caller feeds every group's stream, N = one thread per view group (at most N); -1 = default */
+	int32_t groupOffset;     /* per mille of a pass's steps (level hand-offs, init passes, diagonal launches, finalize) by which view group g + 1 starts behind group g, so that the
+	                            short diagonals, coarse levels and init pass of one group run under the long diagonals of another; -1 = none (the groups start together) */
 } PMHipTuning;
 int pmhip_get_tuning(pmhip_engine* e, PMHipTuning* out);
 int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t);

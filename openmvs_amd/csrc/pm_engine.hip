@@ -15,19 +15,14 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
-#include <atomic>
 #include <chrono>
-#include <condition_variable>
-#include <functional>
 #include <map>
-#include <mutex>
 #include <set>
 #include <string>
-#include <thread>
 #include <vector>
 
-#ifndef PMHIP_DEFAULT_LAUNCH_THREADS
-#define PMHIP_DEFAULT_LAUNCH_THREADS 1
+#ifndef PMHIP_DEFAULT_GROUP_OFFSET
+#define PMHIP_DEFAULT_GROUP_OFFSET 0
 #endif
 #ifndef PMHIP_DEFAULT_WIDE_PIXELS
 #define PMHIP_DEFAULT_WIDE_PIXELS 20000   // larger batches: diagonal launches of at most this many pixels (diagonal length x views of the group) use the two-wide speculative
@@ -69,7 +64,6 @@ struct SceneView {
 	uint8_t* oBgr = nullptr;                                                           // its 8-bit BGR image (pmhip_scene_set_color), sw x sh x 3
 	unsigned char* oMask[4] = {nullptr, nullptr, nullptr, nullptr};                    // its ignore mask per pyramid level (pmhip_scene_set_mask)
 	float* sImg[4] = {nullptr, nullptr, nullptr, nullptr};
-	float* sImgS[4] = {nullptr, nullptr, nullptr, nullptr};
 	float4* sImgQ[4] = {nullptr, nullptr, nullptr, nullptr};
 	bool sideDirty = false;
 	// A known depth-map of this view to be read by geometric rounds instead of the scene's snapshot, of its own size and with the camera it
@@ -78,7 +72,7 @@ struct SceneView {
 };
 static int lvlSize(int n, int l) { return (int)nearbyint((double)n / (double)(1 << l)); }   // cvRound(size / 2^l), ties to even
 static void freeSide(SceneView& v) {
-	for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgS[l]) hipFree(v.sImgS[l]); if (v.sImgQ[l]) hipFree(v.sImgQ[l]); v.sImg[l] = v.sImgS[l] = nullptr; v.sImgQ[l] = nullptr; }
+	for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgQ[l]) hipFree(v.sImgQ[l]); v.sImg[l] = nullptr; v.sImgQ[l] = nullptr; }
 	if (v.sDepth) hipFree(v.sDepth);
 	if (v.oDepth) hipFree(v.oDepth); if (v.oNormal) hipFree(v.oNormal); if (v.oConf) hipFree(v.oConf); if (v.oSnap) hipFree(v.oSnap);
 	if (v.oFDepth) hipFree(v.oFDepth); if (v.oFConf) hipFree(v.oFConf); if (v.oBgr) hipFree(v.oBgr);
@@ -118,40 +112,6 @@ void scaleK(const double* K, int w, int h, int nw, int nh, double* o) {
 
 } // namespace
 
-// Worker threads that enqueue the diagonal launches of view groups 1, 2, ... on their streams while the calling thread enqueues group 0's: a sweep of a small batch is
-// tens of thousands of short launches, and one host thread feeding several streams can be what limits it (tools/probes/launch_rate.hip).
-struct PMLaunchPool {
-	std::vector<std::thread> th;
-	std::mutex m; std::condition_variable cv, cvDone;
-	std::function<void(int)> job; uint64_t gen = 0; int pending = 0; bool stop = false;
-	void ensure(int n, int device) {
-		while ((int)th.size() < n) {
-			const int id = (int)th.size();
-			th.emplace_back([this, id, device] {
-				(void)hipSetDevice(device);
-				uint64_t seen = 0;
-				for (;;) {
-					std::function<void(int)> f;
-					{ std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return stop || (gen != seen && id < nActive); }); if (stop) return; seen = gen; f = job; }
-					f(id + 1);
-					{ std::lock_guard<std::mutex> lk(m); if (--pending == 0) cvDone.notify_all(); }
-				}
-			});
-		}
-	}
-	int nActive = 0;
-	// f(g) for g = 1 .. n-1 on the workers and f(0) on the caller; returns when all are done
-	void run(int n, int device, const std::function<void(int)>& f) {
-		if (n <= 1) { f(0); return; }
-		ensure(n - 1, device);
-		{ std::lock_guard<std::mutex> lk(m); job = f; pending = n - 1; nActive = n - 1; ++gen; }
-		cv.notify_all();
-		f(0);
-		std::unique_lock<std::mutex> lk(m); cvDone.wait(lk, [&] { return pending == 0; });
-	}
-	~PMLaunchPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
-};
-
 struct pmhip_engine {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -165,17 +125,15 @@ struct pmhip_engine {
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
 	int quadBuffer = 1;                     // tap rows address the level's quad images as one buffer (entry index); 0 = through each view's own pointer (PMHIP_QUADBUF; forced for
 	                                        // batches that read a source view with its own image size, which lives outside the level's buffer)
-	int launchThreads = PMHIP_DEFAULT_LAUNCH_THREADS;   // host threads that enqueue a sweep's launches: 1 = the caller alone, feeding the groups' streams in turn; N > 1 = one thread per view group (up to N)
-	PMLaunchPool pool;
+	int groupOffset = PMHIP_DEFAULT_GROUP_OFFSET;   // per mille of a pass's steps by which view group g + 1 starts behind group g (0 = the groups start together)
 	hipStream_t gstream[16] = {};
-	hipEvent_t forkEv = nullptr, joinEv[16] = {};
+	hipEvent_t forkEv = nullptr, joinEv[16] = {}, phaseEv[16] = {};
 	bool inited = false, geom = false;
 	std::string err;
 	// scene (HBM resident)
 	int nImages = 0, w = 0, h = 0, nLevels = 0; // nLevels = sub-resolution levels available (pyramid has nLevels+1 entries)
 	float* d_img[4] = {nullptr, nullptr, nullptr, nullptr};
-	float* d_imgS[4] = {nullptr, nullptr, nullptr, nullptr}; // anti-diagonal-major copies, (w_l+h_l-1)*h_l floats per image
-	float4* d_imgQ[4] = {nullptr, nullptr, nullptr, nullptr}; // anti-diagonal-major quad images (PMSrcView::imgQ), same indexing, 16 bytes per entry
+	float4* d_imgQ[4] = {nullptr, nullptr, nullptr, nullptr}; // anti-diagonal-major quad images (PMSrcView::imgQ): texel (u,v)'s entry at (u+v)*h_l + v, (w_l+h_l-1)*h_l entries of 16 bytes per image
 	size_t skewPitch(int l) const { return (size_t)(lw(l) + lh(l) - 1) * lh(l); }
 	float *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr, *d_snap = nullptr;
 	// ignore masks (nIgnoreMaskLabel): per level [nImages][P_l] bytes, allocated with the first mask; maskMode -1 = on iff a mask is set
@@ -244,7 +202,7 @@ static void freeFuse(pmhip_engine* e) {
 static void freeScene(pmhip_engine* e) {
 	hipSetDevice(e->device);
 	freeFuse(e);
-	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_imgS[l]) hipFree(e->d_imgS[l]); e->d_imgS[l] = nullptr; if (e->d_imgQ[l]) hipFree(e->d_imgQ[l]); e->d_imgQ[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
+	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_imgQ[l]) hipFree(e->d_imgQ[l]); e->d_imgQ[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
 	if (e->d_depth) hipFree(e->d_depth); if (e->d_normal) hipFree(e->d_normal); if (e->d_conf) hipFree(e->d_conf); if (e->d_snap) hipFree(e->d_snap);
 	e->d_depth = e->d_normal = e->d_conf = e->d_snap = nullptr;
 	for (int l = 0; l < 4; ++l) { if (e->d_mask[l]) hipFree(e->d_mask[l]); e->d_mask[l] = nullptr; }
@@ -290,7 +248,6 @@ static int buildPyramid(pmhip_engine* e) {
 	for (int l = 0; l <= e->nLevels; ++l) {
 		const size_t n = (size_t)e->lw(l) * e->lh(l) * e->nImages;
 		const int blocks = (int)std::min<size_t>((n + 255) / 256, 65535);
-		hipLaunchKernelGGL(pm_skew_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_img[l], e->d_imgS[l], e->lw(l), e->lh(l), e->nImages);
 		hipLaunchKernelGGL(pm_quad_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_img[l], e->d_imgQ[l], e->lw(l), e->lh(l), e->nImages);
 	}
 	HIPCHK(e, hipGetLastError());
@@ -311,7 +268,6 @@ static int buildSidePyramids(pmhip_engine* e) {
 			const int lw = lvlSize(v.sw, l), lh = lvlSize(v.sh, l);
 			if (lw < 1 || lh < 1 || !v.sImg[l]) break;
 			const size_t n = (size_t)lw * lh;
-			hipLaunchKernelGGL(pm_skew_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, e->stream, v.sImg[l], v.sImgS[l], lw, lh, 1);
 			hipLaunchKernelGGL(pm_quad_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, e->stream, v.sImg[l], v.sImgQ[l], lw, lh, 1);
 		}
 		HIPCHK(e, hipGetLastError());
@@ -450,6 +406,9 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 		maxSrc = std::max(maxSrc, v.nNb);
 		for (int k = 0; k < v.nNb; ++k) if (e->views[v.nb[k]].sw) buf = false;   // a source image of its own size is not in the level's quad buffer
 	}
+	// the buffer path addresses a sample by a 32-bit entry index into the level's quad buffer (PMTask::qCount, PMSrcView::qBase): a level-0 buffer of 2^32 entries or more
+	// (about 330 views of 3840x2160) goes through the views' own pointers instead
+	if (e->skewPitch(0) * (size_t)e->nImages > 0xFFFFFFFFull) buf = false;
 	int G = 1; while (G < maxSrc) G <<= 1;          // init kernel: one view per lane
 	int SG = G, VPL = 1;                             // sweep kernel: (lanes per pixel, views per lane)
 	sweepMapping(maxSrc, e->sweepLanes > 0 ? e->sweepLanes : (nB >= PMHIP_LANES4_FROM && maxSrc > 4 ? 4 : 16), SG, VPL);
@@ -479,9 +438,9 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 				t.depth = base; t.normal = base + Pl; t.conf = base + Pl * 4;
 				t.prior = (l < S) ? base + Pl * 5 : nullptr;
 			}
-			if (v.sw) { t.ref = v.sImg[l]; t.refS = v.sImgS[l]; }
-			else { t.ref = e->d_img[l] + Pls * id; t.refS = e->d_imgS[l] + e->skewPitch(l) * id; }
-			t.qArr = e->d_imgQ[l]; t.sArr = e->d_imgS[l]; t.qCount = (unsigned)(e->skewPitch(l) * (size_t)e->nImages);
+			if (v.sw) { t.ref = v.sImg[l]; t.refQ = v.sImgQ[l]; }
+			else { t.ref = e->d_img[l] + Pls * id; t.refQ = e->d_imgQ[l] + e->skewPitch(l) * id; }
+			t.qArr = e->d_imgQ[l]; t.qCount = (unsigned)(e->skewPitch(l) * (size_t)e->nImages);
 			t.mask = (anyMask && e->hasMask[id]) ? (v.sw ? v.oMask[l] : e->d_mask[l] + Pls * id) : nullptr;
 			t.w = lw; t.h = lh; t.nSrc = v.nNb;
 			double K0[9];
@@ -501,11 +460,10 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 					// a source image of its own size: its own pyramid, its camera scaled from its own size (ScaleDepthData, SceneDensify.cpp:586-588)
 					const int jw = lvlSize(sv.sw, l), jh = lvlSize(sv.sh, l);
 					if (jw < 3 || jh < 3) { e->err = "source image too small for this many sub-resolution levels"; return PMHIP_E_SIZE; }
-					s.img = sv.sImg[l]; s.imgS = sv.sImgS[l]; s.imgQ = sv.sImgQ[l]; s.w = jw; s.h = jh;
+					s.img = sv.sImg[l]; s.imgQ = sv.sImgQ[l]; s.w = jw; s.h = jh;
 					if (l == 0) memcpy(Kj, sv.K, sizeof(Kj)); else scaleK(sv.K, sv.sw, sv.sh, jw, jh, Kj);
 				} else {
 					s.img = e->d_img[l] + Pls * v.nb[k];
-					s.imgS = e->d_imgS[l] + e->skewPitch(l) * v.nb[k];
 					s.imgQ = e->d_imgQ[l] + e->skewPitch(l) * v.nb[k];
 					s.qBase = (unsigned)(e->skewPitch(l) * (size_t)v.nb[k]);
 					s.w = slw; s.h = slh;
@@ -546,98 +504,117 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 				u.sdepth = cb; u.snormal = cb + Pc; u.ddepth = t.depth; u.dnormal = t.normal; u.dprior = const_cast<float*>(t.prior);
 			}
 		}
-		PMTask* dt = e->d_tasks + (size_t)l * e->batchCap;
-		PMUpTask* du = e->d_ups + (size_t)l * e->batchCap;
-		HIPCHK(e, hipMemcpyAsync(dt, ht, sizeof(PMTask) * nB, hipMemcpyHostToDevice, e->stream));
-		HIPCHK(e, hipMemcpyAsync(du, hu, sizeof(PMUpTask) * nB, hipMemcpyHostToDevice, e->stream));
-		const int eb = (int)std::min<size_t>((Pl + 255) / 256, 4096);
-		if (l == S && S > 0)
-			hipLaunchKernelGGL(pm_nearest_down_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, cw, ch, lw, lh, 1 << S);
-		else if (l < S)
-			hipLaunchKernelGGL(pm_upsample_kernel, dim3(eb, nB), dim3(256), 0, e->stream, du, lvlSize(cw, l + 1), lvlSize(ch, l + 1), lw, lh, nearestDepth);
-		// pass A: ScoreDepthMapTmp.  (Row-major pixels, guarded tap rows: 9.5 % of a 100-view step.  The same evaluation on anti-diagonals with the sweep's optimistic
-		// quad rows was measured 9 % SLOWER -- the maps are row-major, and a wave that walks a diagonal reads and writes them one cache line per lane:
-		// profiles/r04_call14_diagonal_init_kernel_stats.csv, 143.4 against 125.9 ms per geometric round.  Its tap rows are 73 % of the kernel (r04_call15_*), yet
-		// optimistic rows from the row-major images (two dwordx2 buffer loads per sample, a third fewer instructions) and 128- / 256-thread workgroups changed nothing:
-		// 397.8 / 395.6 / 405.0 against 399.5 ms per step, r04_call16_*, r04_call17_* -- neither instruction issue nor L1 locality bounds it.)
-		const int PPB = PM_BLOCK / G;
-		const uint32_t passInit = (uint32_t)l * 64u + 32u + (geo ? 16u + (uint32_t)nGeometricIter : 0u);
-		evBegin(e, 1);
-		{
-			const dim3 grid((unsigned)((Pl + PPB - 1) / PPB), nB);
-			if (geo) launchInit<true>(G, grid, e->stream, dt, kp, passInit); else launchInit<false>(G, grid, e->stream, dt, kp, passInit);
-		}
-		evEnd(e);
-		if (e->statsOn) e->stats.initLaunches += 1;
-		// pass B: sweeps, one launch per anti-diagonal
-		for (unsigned iter = iterBegin; iter < iterEnd; ++iter) {
-			const int dir = (int)(iter % 2u);
-			const uint32_t pass = (uint32_t)l * 64u + iter;
-			const int dLo = 2 * PM_HW, dHi = (lw - 1 - PM_HW) + (lh - 1 - PM_HW);
-			const int NG = std::max(1, std::min(e->nGroups, nB));
-			const size_t evWall = evBeginOn(e, 2, e->stream);
-			size_t evG[16] = {};
-			// group g's stream: the engine's own for a single group.  (Letting group 0 of several sweep on the engine's stream, or more than three groups, falls off a cliff:
-			// 13 views 27 -> 15.6 Mpix/s, whatever GPU_MAX_HW_QUEUES says -- profiles/r04_call10_lanes_13.log.)
-			auto gs = [&](int g) { return NG > 1 ? e->gstream[g] : e->stream; };
-			if (NG > 1) {
-				HIPCHK(e, hipEventRecord(e->forkEv, e->stream));
-				for (int g = 0; g < NG; ++g) { if (gs(g) != e->stream) HIPCHK(e, hipStreamWaitEvent(gs(g), e->forkEv, 0)); evG[g] = evBeginOn(e, 0, gs(g)); }
-			} else evG[0] = evBeginOn(e, 0, e->stream);
-			// group g's launches of diagonal k; the kernels compute the same bits, so the choice is per launch: the speculative kernels (more lanes per pixel, shorter
-			// dependent chain) for batches and for diagonals too small to fill the GPU with 64 / G pixels per wave
-			std::atomic<bool> allOk{true};
-			auto launchOne = [&](int g, int k) {
-				const int d = dir == 0 ? dLo + k : dHi - k;
-				const int xlo = std::max(PM_HW, d - (lh - 1 - PM_HW));
-				const int xhi = std::min(lw - 1 - PM_HW, d - PM_HW);
-				const int count = xhi - xlo + 1;
-				if (count <= 0) return 0;
-				const int s0 = (int)((long)nB * g / NG), s1 = (int)((long)nB * (g + 1) / NG);
-				hipStream_t st = gs(g);
-				const long npx = (long)count * (s1 - s0);
-				const bool wide = wideBatch || (maxSrc <= 8 && npx <= e->widePixels);
-				const int hyps = (wideBatch && e->wideHyps > 0) ? e->wideHyps : ((nB <= 2 || npx <= e->wide8Pixels) ? 8 : 2);
-				const bool ok = geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass))
-				                    : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, s1 - s0, st, dt + s0, kp, dir, d, xlo, count, pass));
-				if (!ok) allOk = false;
-				return 1;
-			};
-			const auto hostT0 = std::chrono::steady_clock::now();
-			const int nThreads = std::min(NG, std::max(1, e->launchThreads));
-			size_t nLaunched = 0;
-			if (nThreads > 1) {
-				std::atomic<size_t> cnt{0};
-				e->pool.run(nThreads, e->device, [&](int tix) {   // thread tix enqueues groups tix, tix + nThreads, ...
-					size_t c = 0;
-					for (int k = 0; k <= dHi - dLo && allOk; ++k) for (int g = tix; g < NG; g += nThreads) c += launchOne(g, k);
-					cnt += c;
-				});
-				nLaunched = cnt;
-			} else {
-				for (int k = 0; k <= dHi - dLo && allOk; ++k) for (int g = 0; g < NG; ++g) nLaunched += launchOne(g, k);
-			}
-			if (!allOk) { e->err = "sweep kernel: (lanes per pixel, views per lane) mapping not instantiated"; return PMHIP_E_ARG; }
-			if (e->statsOn) { e->stats.sweepLaunches += nLaunched; e->stats.sweepHostMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hostT0).count(); }
-			if (NG > 1) {
-				for (int g = 0; g < NG; ++g) { evEndOn(e, evG[g], gs(g)); if (gs(g) != e->stream) { HIPCHK(e, hipEventRecord(e->joinEv[g], gs(g))); HIPCHK(e, hipStreamWaitEvent(e->stream, e->joinEv[g], 0)); } }
-			} else evEndOn(e, evG[0], e->stream);
-			evEndOn(e, evWall, e->stream);
-			if (e->statsOn) {
-				// algorithmic bytes of one sweep, SURVEY.md 8(d): P_l * [4(1+N) + 20 + 20 + 4[prior] + 4N[geo]] per view
-				double bytes = 0;
-				for (int b = 0; b < nB; ++b) { const int N = e->views[ids[b]].nNb; bytes += (double)Pl * (4.0 * (1 + N) + 40.0 + (l < S ? 4.0 : 0.0) + (geo ? 4.0 * N : 0.0)); }
-				e->stats.sweepBytes += bytes;
-				e->stats.sweepPixels += (uint64_t)Pl * nB;
-			}
-		}
-		HIPCHK(e, hipGetLastError());
+		HIPCHK(e, hipMemcpyAsync(e->d_tasks + (size_t)l * e->batchCap, ht, sizeof(PMTask) * nB, hipMemcpyHostToDevice, e->stream));
+		HIPCHK(e, hipMemcpyAsync(e->d_ups + (size_t)l * e->batchCap, hu, sizeof(PMUpTask) * nB, hipMemcpyHostToDevice, e->stream));
 	}
-	// pass C: EndDepthMapTmp (threshold x1.333 when geometric rounds will follow, SceneDensify.cpp:774-776)
-	float th = p.fNCCThresholdKeep;
-	if (nGeometricIter < 0 && p.nEstimationGeometricIters) th *= 1.333f;
-	hipLaunchKernelGGL(pm_finalize_kernel, dim3((unsigned)std::min<size_t>((P0 + 255) / 256, 4096), nB), dim3(256), 0, e->stream, e->d_tasks, th);
+	// ---- the pass as a sequence of steps that is the same for every view group: per level {hand-off, ScoreDepthMapTmp, sweeps of one launch per anti-diagonal}, EndDepthMapTmp.
+	// A view group runs ALL of them on its own stream (views are independent; the steps of one view are not) and the groups meet only at the end of the call; group g starts
+	// when group g - 1 has finished `groupOffset` per mille of its steps, so that one group's latency-bound phases (the short diagonals at both ends of a sweep, the coarse levels,
+	// the init pass) run under another group's long diagonals instead of coinciding with them.  Scheduling only: the maps cannot depend on it.
+	struct Step { int kind, l; unsigned iter; int k; };   // kind 0: level hand-off, 1: init pass, 2: diagonal k of sweep `iter`, 3: finalize
+	std::vector<Step> steps;
+	for (int l = S; l >= 0; --l) {
+		if (S > 0) steps.push_back({0, l, 0u, 0});
+		steps.push_back({1, l, 0u, 0});
+		const int lw = lvlSize(cw, l), lh = lvlSize(ch, l);
+		const int nDiag = (lw - 1 - PM_HW) + (lh - 1 - PM_HW) - 2 * PM_HW + 1;
+		for (unsigned iter = iterBegin; iter < iterEnd; ++iter) for (int k = 0; k < nDiag; ++k) steps.push_back({2, l, iter, k});
+	}
+	steps.push_back({3, 0, 0u, 0});
+	const long nSteps = (long)steps.size();
+	const int NG = std::max(1, std::min(e->nGroups, nB));
+	const long off = NG > 1 ? std::min(nSteps, (nSteps * (long)std::max(0, e->groupOffset) + 999) / 1000) : 0;
+	// group g's stream: the engine's own for a single group.  (Letting group 0 of several sweep on the engine's stream, or more than three groups, falls off a cliff:
+	// 13 views 27 -> 15.6 Mpix/s, whatever GPU_MAX_HW_QUEUES says -- profiles/r04_call10_lanes_13.log.)
+	auto gs = [&](int g) { return NG > 1 ? e->gstream[g] : e->stream; };
+	auto g0 = [&](int g) { return (int)((long)nB * g / NG); };
+	const size_t evWall = evBeginOn(e, 2, e->stream);
+	if (NG > 1) {
+		HIPCHK(e, hipEventRecord(e->forkEv, e->stream));
+		for (int g = 0; g < NG; ++g) HIPCHK(e, hipStreamWaitEvent(gs(g), e->forkEv, 0));
+	}
+	float thFinal = p.fNCCThresholdKeep;   // EndDepthMapTmp: threshold x1.333 when geometric rounds will follow, SceneDensify.cpp:774-776
+	if (nGeometricIter < 0 && p.nEstimationGeometricIters) thFinal *= 1.333f;
+	size_t evSweep[16] = {}; bool evOpen[16] = {};
+	size_t nLaunched = 0;
+	const auto hostT0 = std::chrono::steady_clock::now();
+	auto issue = [&](int g, const Step& sp) -> bool {
+		const int l = sp.l, s0 = g0(g), nT = g0(g + 1) - s0;
+		const int lw = lvlSize(cw, l), lh = lvlSize(ch, l);
+		const size_t Pl = (size_t)lw * lh;
+		const PMTask* dt = e->d_tasks + (size_t)l * e->batchCap + s0;
+		const PMUpTask* du = e->d_ups + (size_t)l * e->batchCap + s0;
+		hipStream_t st = gs(g);
+		if (sp.kind != 2 && evOpen[g]) { evEndOn(e, evSweep[g], st); evOpen[g] = false; }
+		switch (sp.kind) {
+		case 0: {
+			const int eb = (int)std::min<size_t>((Pl + 255) / 256, 4096);
+			if (l == S) hipLaunchKernelGGL(pm_nearest_down_kernel, dim3(eb, nT), dim3(256), 0, st, du, cw, ch, lw, lh, 1 << S);
+			else hipLaunchKernelGGL(pm_upsample_kernel, dim3(eb, nT), dim3(256), 0, st, du, lvlSize(cw, l + 1), lvlSize(ch, l + 1), lw, lh, nearestDepth);
+			return true;
+		}
+		case 1: {
+			// pass A: ScoreDepthMapTmp.  (Row-major pixels, guarded tap rows.  The same evaluation on anti-diagonals with the sweep's optimistic quad rows was measured 9 % SLOWER --
+			// the maps are row-major, and a wave that walks a diagonal reads and writes them one cache line per lane: profiles/r04_call14_diagonal_init_kernel_stats.csv; optimistic
+			// rows from the row-major images and 128- / 256-thread workgroups changed nothing, r04_call16_*, r04_call17_*: it is latency-bound, which is why it now runs beside
+			// another group's sweeps.)
+			const int PPB = PM_BLOCK / G;
+			const uint32_t passInit = (uint32_t)l * 64u + 32u + (geo ? 16u + (uint32_t)nGeometricIter : 0u);
+			const size_t ev = evBeginOn(e, 1, st);
+			const dim3 grid((unsigned)((Pl + PPB - 1) / PPB), nT);
+			if (geo) launchInit<true>(G, grid, st, dt, kp, passInit); else launchInit<false>(G, grid, st, dt, kp, passInit);
+			evEndOn(e, ev, st);
+			if (e->statsOn && g == 0) e->stats.initLaunches += 1;
+			return true;
+		}
+		case 2: {
+			// pass B: one launch per anti-diagonal.  The kernels compute the same bits, so the choice is per launch: the speculative kernels (more lanes per pixel, shorter
+			// dependent chain) for batches and for diagonals too small to fill the GPU with 64 / G pixels per wave
+			const int dir = (int)(sp.iter % 2u);
+			const uint32_t pass = (uint32_t)l * 64u + sp.iter;
+			const int dLo = 2 * PM_HW, dHi = (lw - 1 - PM_HW) + (lh - 1 - PM_HW);
+			const int d = dir == 0 ? dLo + sp.k : dHi - sp.k;
+			const int xlo = std::max(PM_HW, d - (lh - 1 - PM_HW));
+			const int xhi = std::min(lw - 1 - PM_HW, d - PM_HW);
+			const int count = xhi - xlo + 1;
+			if (count <= 0) return true;
+			if (!evOpen[g]) { evSweep[g] = evBeginOn(e, 0, st); evOpen[g] = e->statsOn; }
+			const long npx = (long)count * nT;
+			const bool wide = wideBatch || (maxSrc <= 8 && npx <= e->widePixels);
+			const int hyps = (wideBatch && e->wideHyps > 0) ? e->wideHyps : ((nB <= 2 || npx <= e->wide8Pixels) ? 8 : 2);
+			++nLaunched;
+			return geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass))
+			           : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass));
+		}
+		default:
+			hipLaunchKernelGGL(pm_finalize_kernel, dim3((unsigned)std::min<size_t>((P0 + 255) / 256, 4096), nT), dim3(256), 0, st, e->d_tasks + s0, thFinal);
+			return true;
+		}
+	};
+	// The host feeds the groups in turn, group g lagging g * off steps behind group g - 1: the event group g waits for is recorded (on the host's time line) before the wait is enqueued.
+	for (long i = 0; i < nSteps + off * (NG - 1); ++i)
+		for (int g = 0; g < NG; ++g) {
+			const long j = i - off * g;
+			if (j < 0 || j >= nSteps) continue;
+			if (j == 0 && g > 0 && off > 0) HIPCHK(e, hipStreamWaitEvent(gs(g), e->phaseEv[g - 1], 0));
+			if (!issue(g, steps[j])) { e->err = "sweep kernel: (lanes per pixel, views per lane) mapping not instantiated"; return PMHIP_E_ARG; }
+			if (j == off - 1 && g + 1 < NG) HIPCHK(e, hipEventRecord(e->phaseEv[g], gs(g)));
+		}
+	if (NG > 1) for (int g = 0; g < NG; ++g) { HIPCHK(e, hipEventRecord(e->joinEv[g], gs(g))); HIPCHK(e, hipStreamWaitEvent(e->stream, e->joinEv[g], 0)); }
+	evEndOn(e, evWall, e->stream);
 	HIPCHK(e, hipGetLastError());
+	if (e->statsOn) {
+		e->stats.sweepLaunches += nLaunched;
+		e->stats.sweepHostMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hostT0).count();
+		// algorithmic bytes of the sweeps, SURVEY.md 8(d): P_l * [4(1+N) + 20 + 20 + 4[prior] + 4N[geo]] per view and sweep
+		for (int l = S; l >= 0; --l) {
+			const size_t Pl = (size_t)lvlSize(cw, l) * lvlSize(ch, l);
+			double bytes = 0;
+			for (int b = 0; b < nB; ++b) { const int N = e->views[ids[b]].nNb; bytes += (double)Pl * (4.0 * (1 + N) + 40.0 + (l < S ? 4.0 : 0.0) + (geo ? 4.0 * N : 0.0)); }
+			e->stats.sweepBytes += bytes * (iterEnd - iterBegin);
+			e->stats.sweepPixels += (uint64_t)Pl * nB * (iterEnd - iterBegin);
+		}
+	}
 	for (int b = 0; b < nB; ++b) e->views[ids[b]].hasMaps = true;
 	return 0;
 }
@@ -709,7 +686,7 @@ int pmhip_create(int device, pmhip_engine** out) {
 	e->nGroups = ng ? std::max(1, std::min(16, atoi(ng))) : PMHIP_DEFAULT_GROUPS;
 	const char* nw = getenv("PMHIP_WIDE");
 	if (nw) { e->wideMaxViews = atoi(nw); if (e->wideMaxViews <= 0) e->widePixels = e->wide8Pixels = 0; }   // PMHIP_WIDE=0: no speculative kernels at all (PMHIP_WIDE_PIXELS below may bring the per-launch rule back)
-	const char* lt = getenv("PMHIP_LAUNCH_THREADS"); if (lt && atoi(lt) >= 1) e->launchThreads = std::min(16, atoi(lt));
+	const char* go = getenv("PMHIP_GROUP_OFFSET"); if (go && atoi(go) >= 0) e->groupOffset = std::min(1000, atoi(go));
 	const char* wp = getenv("PMHIP_WIDE_PIXELS"); if (wp) e->widePixels = atoi(wp);
 	const char* w8 = getenv("PMHIP_WIDE8_PIXELS"); if (w8) e->wide8Pixels = atoi(w8);
 	const char* wh = getenv("PMHIP_WIDE_HYPS"); if (wh && (atoi(wh) == 8 || atoi(wh) == 4 || atoi(wh) == 2)) e->wideHyps = atoi(wh);
@@ -717,7 +694,8 @@ int pmhip_create(int device, pmhip_engine** out) {
 	const char* nl = getenv("PMHIP_LANES");
 	if (nl && atoi(nl) >= 1) e->sweepLanes = atoi(nl);
 	for (int g = 0; g < e->nGroups; ++g)
-		if (hipStreamCreateWithFlags(&e->gstream[g], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->joinEv[g], hipEventDisableTiming) != hipSuccess) { delete e; return PMHIP_E_HIP; }
+		if (hipStreamCreateWithFlags(&e->gstream[g], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->joinEv[g], hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&e->phaseEv[g], hipEventDisableTiming) != hipSuccess) { delete e; return PMHIP_E_HIP; }
 	if (hipEventCreateWithFlags(&e->forkEv, hipEventDisableTiming) != hipSuccess) { delete e; return PMHIP_E_HIP; }
 	*out = e;
 	return 0;
@@ -729,7 +707,7 @@ void pmhip_destroy(pmhip_engine* e) {
 	if (e->stream) hipStreamSynchronize(e->stream);
 	for (auto& ev : e->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
 	freeScene(e);
-	for (int g = 0; g < 16; ++g) { if (e->gstream[g]) hipStreamDestroy(e->gstream[g]); if (e->joinEv[g]) hipEventDestroy(e->joinEv[g]); }
+	for (int g = 0; g < 16; ++g) { if (e->gstream[g]) hipStreamDestroy(e->gstream[g]); if (e->joinEv[g]) hipEventDestroy(e->joinEv[g]); if (e->phaseEv[g]) hipEventDestroy(e->phaseEv[g]); }
 	if (e->forkEv) hipEventDestroy(e->forkEv);
 	if (e->stream) hipStreamDestroy(e->stream);
 	delete e;
@@ -761,7 +739,6 @@ int pmhip_scene_create(pmhip_engine* e, int nImages, int w, int h, int nLevels) 
 	const size_t P0 = (size_t)w * h;
 	for (int l = 0; l <= nLevels; ++l) {
 		HIPCHK(e, hipMalloc(&e->d_img[l], sizeof(float) * (size_t)e->lw(l) * e->lh(l) * nImages));
-		HIPCHK(e, hipMalloc(&e->d_imgS[l], sizeof(float) * e->skewPitch(l) * nImages));
 		HIPCHK(e, hipMalloc(&e->d_imgQ[l], sizeof(float4) * e->skewPitch(l) * nImages));
 	}
 	HIPCHK(e, hipMalloc(&e->d_depth, sizeof(float) * P0 * nImages));
@@ -791,11 +768,12 @@ int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevi
 	if (gray) {
 		if (v.sw) {   // the view goes back to the scene's size: its own pyramid is not needed any more
 			HIPCHK(e, hipStreamSynchronize(e->stream));
-			for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgS[l]) hipFree(v.sImgS[l]); if (v.sImgQ[l]) hipFree(v.sImgQ[l]); v.sImg[l] = v.sImgS[l] = nullptr; v.sImgQ[l] = nullptr; }
+			for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgQ[l]) hipFree(v.sImgQ[l]); v.sImg[l] = nullptr; v.sImgQ[l] = nullptr; }
 			if (v.oDepth) hipFree(v.oDepth); if (v.oNormal) hipFree(v.oNormal); if (v.oConf) hipFree(v.oConf); if (v.oSnap) hipFree(v.oSnap);
 			if (v.oFDepth) hipFree(v.oFDepth); if (v.oFConf) hipFree(v.oFConf); if (v.oBgr) hipFree(v.oBgr);
 			for (int l = 0; l < 4; ++l) { if (v.oMask[l]) hipFree(v.oMask[l]); v.oMask[l] = nullptr; }
 			if (!e->hasMask.empty()) e->hasMask[idx] = 0;
+			if (!e->fu.hasBgr.empty()) e->fu.hasBgr[idx] = 0;      // (its colour image went with the side storage)
 			v.oDepth = v.oNormal = v.oConf = v.oSnap = v.oFDepth = v.oFConf = nullptr; v.oBgr = nullptr;
 			v.sw = v.sh = 0; v.sideDirty = false; v.hasMaps = false;
 		}
@@ -813,13 +791,13 @@ int pmhip_get_tuning(pmhip_engine* e, PMHipTuning* out) {
 	out->viewGroups = e->nGroups; out->wideMaxViews = e->wideMaxViews > 0 ? e->wideMaxViews : -1; out->wideHyps = e->wideHyps > 0 ? e->wideHyps : -1;
 	out->sweepLanes = e->sweepLanes > 0 ? e->sweepLanes : -1; out->quadBuffer = e->quadBuffer ? 1 : 2;
 	out->widePixels = e->widePixels > 0 ? e->widePixels : -1; out->wide8Pixels = e->wide8Pixels > 0 ? e->wide8Pixels : -1;
-	out->launchThreads = e->launchThreads;
+	out->groupOffset = e->groupOffset > 0 ? e->groupOffset : -1;
 	return 0;
 }
 int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t) {
 	if (!e || !t) return PMHIP_E_ARG;
 	if (t->viewGroups < 0 || t->viewGroups > 16 || (t->wideHyps > 0 && t->wideHyps != 8 && t->wideHyps != 4 && t->wideHyps != 2) ||
-	    (t->sweepLanes > 0 && t->sweepLanes != 4 && t->sweepLanes != 8 && t->sweepLanes != 16) || t->quadBuffer < 0 || t->quadBuffer > 2) { e->err = "pmhip_set_tuning: value out of range"; return PMHIP_E_ARG; }
+	    (t->sweepLanes > 0 && t->sweepLanes != 4 && t->sweepLanes != 8 && t->sweepLanes != 16) || t->quadBuffer < 0 || t->quadBuffer > 2 || t->groupOffset > 1000) { e->err = "pmhip_set_tuning: value out of range"; return PMHIP_E_ARG; }
 	HIPCHK(e, hipSetDevice(e->device));
 	if (t->viewGroups > 0) {
 		for (int g = e->nGroups; g < t->viewGroups; ++g) if (!e->gstream[g]) {   // streams of the additional view groups
@@ -833,7 +811,7 @@ int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t) {
 	if (t->quadBuffer != 0) e->quadBuffer = t->quadBuffer == 1;
 	if (t->widePixels != 0) e->widePixels = t->widePixels < 0 ? 0 : t->widePixels;
 	if (t->wide8Pixels != 0) e->wide8Pixels = t->wide8Pixels < 0 ? 0 : t->wide8Pixels;
-	if (t->launchThreads != 0) e->launchThreads = t->launchThreads < 0 ? PMHIP_DEFAULT_LAUNCH_THREADS : std::min(16, t->launchThreads);
+	if (t->groupOffset != 0) e->groupOffset = t->groupOffset < 0 ? 0 : t->groupOffset;
 	return 0;
 }
 int pmhip_scene_set_view_id(pmhip_engine* e, int idx, uint32_t viewID) {
@@ -866,7 +844,6 @@ int pmhip_scene_set_view_sized(pmhip_engine* e, int idx, const float* gray, int 
 			const int lw = lvlSize(w, l), lh = lvlSize(h, l);
 			if (lw < 1 || lh < 1) break;
 			HIPCHK(e, hipMalloc(&v.sImg[l], sizeof(float) * (size_t)lw * lh));
-			HIPCHK(e, hipMalloc(&v.sImgS[l], sizeof(float) * (size_t)(lw + lh - 1) * lh));
 			HIPCHK(e, hipMalloc(&v.sImgQ[l], sizeof(float4) * (size_t)(lw + lh - 1) * lh));
 		}
 		// its own maps (DepthData::depthMap / normalMap / confMap of its own size), "unset" like the scene's after pmhip_scene_create
@@ -1211,6 +1188,40 @@ int pmhip_scene_copy(pmhip_engine* e, int what, int firstIdx, int count, void* d
 	return 0;
 }
 
+// HBM the scene holds right now: image pyramids with their quad layouts, the four map arrays, masks, the filter's staging, the batch scratch of the largest batch estimated
+// so far, and the own storage of views that carry their own size.  Not the working buffers of pmhip_scene_fuse (they live only during fusion and its download).
+uint64_t pmhip_scene_bytes(pmhip_engine* e) {
+	if (!e || e->nImages <= 0) return 0;
+	const size_t N = (size_t)e->nImages, P0 = (size_t)e->w * e->h;
+	size_t b = 0;
+	for (int l = 0; l <= e->nLevels; ++l) {
+		if (e->d_img[l]) b += sizeof(float) * (size_t)e->lw(l) * e->lh(l) * N;
+		if (e->d_imgQ[l]) b += sizeof(float4) * e->skewPitch(l) * N;
+		if (e->d_mask[l]) b += (size_t)e->lw(l) * e->lh(l) * N;
+	}
+	if (e->d_depth) b += sizeof(float) * P0 * N * 6;                       // depth, normal (3), confidence, previous round's depth
+	if (e->d_fdepth) b += sizeof(float) * P0 * N * 2 + P0 * N;             // FilterDepthMap staging
+	if (e->d_splat) b += sizeof(unsigned long long) * e->splatPix * PMF_MAXN * (size_t)e->splatCap;
+	if (e->batchCap) {
+		b += sizeof(float) * (size_t)e->batchCap * e->batchW * e->batchH;
+		for (int l = 1; l <= e->nLevels; ++l) b += sizeof(float) * (size_t)e->batchCap * 6 * lvlSize(e->batchW, l) * lvlSize(e->batchH, l);
+		b += (sizeof(PMTask) + sizeof(PMUpTask)) * 4 * (size_t)e->batchCap;
+	}
+	for (const SceneView& v : e->views) {
+		if (v.sDepth) b += sizeof(float) * (size_t)v.dw * v.dh;
+		if (!v.sw) continue;
+		const size_t P = (size_t)v.sw * v.sh;
+		b += sizeof(float) * P * 6 + (v.oFDepth ? sizeof(float) * P * 2 : 0) + (v.oBgr ? 3 * P : 0);
+		for (int l = 0; l <= e->nLevels; ++l) {
+			const size_t lw = (size_t)lvlSize(v.sw, l), lh = (size_t)lvlSize(v.sh, l);
+			if (v.sImg[l]) b += sizeof(float) * lw * lh;
+			if (v.sImgQ[l]) b += sizeof(float4) * (lw + lh - 1) * lh;
+			if (v.oMask[l]) b += lw * lh;
+		}
+	}
+	return (uint64_t)b;
+}
+
 int pmhip_sync(pmhip_engine* e) { if (!e) return PMHIP_E_ARG; HIPCHK(e, hipSetDevice(e->device)); HIPCHK(e, hipStreamSynchronize(e->stream)); return 0; }
 void* pmhip_stream(pmhip_engine* e) { return e ? (void*)e->stream : nullptr; }
 
@@ -1410,7 +1421,8 @@ int pmhip_scene_fuse(pmhip_engine* e, const int32_t* order, int nOrder, const PM
 	auto& f = e->fu;
 	const size_t P = f.slab, N = (size_t)e->nImages, P0 = (size_t)e->w * e->h;
 	bool wantColor = prm->bEstimateColor != 0;
-	if (wantColor) for (int i = 0; i < e->nImages; ++i) if (e->views[i].set && (f.hasBgr.empty() || !f.hasBgr[i])) { e->err = "bEstimateColor needs pmhip_scene_set_color for every view"; return PMHIP_E_STATE; }
+	if (wantColor) for (int i = 0; i < e->nImages; ++i) if (e->views[i].set && (f.hasBgr.empty() || !f.hasBgr[i] || !(e->views[i].sw ? (const void*)e->views[i].oBgr : (const void*)f.bgr))) {
+		e->err = "bEstimateColor needs pmhip_scene_set_color for every view"; return PMHIP_E_STATE; }
 	const bool wantNormal = prm->bEstimateNormal != 0;
 	// cameras (P composed like Camera::ComposeP)
 	std::vector<PMFuseCam> hc(N);

@@ -62,7 +62,6 @@ struct PMSrcView {
 	const float* depth;
 	int dw, dh;
 	const float* img;     // source image at this pyramid level, row-major
-	const float* imgS;    // same image, anti-diagonal-major ("skewed"): texel (u,v) at (u+v)*h + v
 	const float4* imgQ;   // anti-diagonal-major "quad" image: entry (u,v) = {I(u,v), I(u+1,v), I(u,v+1), I(u+1,v+1)} -- the four texels of a bilinear
 	                      // sample in ONE 16-byte load (the window-less tap rows are bound by the number of vector-memory instructions, not by bytes:
 	                      // the stride-2 taps of a patch never share texels, so the quad image is read at the same byte rate as the plain one)
@@ -75,7 +74,7 @@ struct PMTask {           // one reference view at one pyramid level
 	float* depth; float* normal; float* conf;
 	const float* prior;   // nullable: low-resolution depth prior at this level
 	const float* ref;     // reference image at this level, row-major
-	const float* refS;    // reference image, anti-diagonal-major
+	const float4* refQ;   // reference image as an anti-diagonal-major quad image (PMSrcView::imgQ's layout: entry (u,v) at (u+v)*h + v, .x = the texel itself)
 	const unsigned char* mask; // nullable: ignore mask at this level, 0 = pixel is not estimated (DepthData::ApplyIgnoreMask + masked MapMatrix2ZigzagIdx)
 	int w, h, nSrc, pad0;
 	double Hr[9];         // K_0^-1
@@ -86,7 +85,6 @@ struct PMTask {           // one reference view at one pyramid level
 	uint32_t k0, k1base;  // Philox key: (seed, viewID*0x9E3779B1 + pass)
 	const float4* qArr;   // the quad images of ALL scene views at this level, one allocation (view i at qArr + i * (w + h - 1) * h): the buffer the sweep kernels' tap rows index
 	unsigned qCount, qPad; // its entries
-	const float* sArr;    // the anti-diagonal-major images of ALL scene views at this level, same indexing (4-byte entries): the buffer of the PM_TRILOAD build
 	PMSrcView src[PM_MAX_SRC];
 };
 struct PMKParams {        // DepthEstimator ctor constants, DepthMap.cpp:397-406
@@ -284,28 +282,6 @@ __device__ __forceinline__ void pm_bufwait5(pm_f4v& q0, pm_f4v& q1, pm_f4v& q2, 
 	asm volatile("s_waitcnt vmcnt(%5)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4) : "i"(LEFT));
 }
 __device__ __forceinline__ unsigned pm_mad24(int a, int b, unsigned c) { return (unsigned)__mul24(a, b) + c; }   // v_mad_u32_u24: full rate
-// PM_TRILOAD: the same four texels from the PLAIN anti-diagonal-major image (4-byte entries, a quarter of the quad image's footprint in every cache): texel (u,v)
-// sits at entry e = (u+v)*h + v, (u+1,v) and (u,v+1) are the ADJACENT entries e+h, e+h+1 and (u+1,v+1) is e+2h+1 -- one dword, one dwordx2 and one dword load off
-// the same index register, the row offsets in two scalar registers (soff1 = 4h, soff2 = 4(2h+1) bytes; every scene image of a level has the level's size).
-// Fifteen loads per row; the pieces stay in their own registers until the row is consumed (nothing may touch a destination before the wait that names it).
-typedef float pm_f2v __attribute__((ext_vector_type(2)));
-struct PMTriQ { float a0, a1, a2, a3, a4; pm_f2v m0, m1, m2, m3, m4; float d0, d1, d2, d3, d4; };
-__device__ __forceinline__ void pm_triload5(PMTriQ& q, unsigned i0, unsigned i1, unsigned i2, unsigned i3, unsigned i4, pm_rsrc r, int soff1, int soff2) {
-	asm volatile(
-		"buffer_load_dword %0, %15, %20, 0 idxen\n\tbuffer_load_dwordx2 %5, %15, %20, %21 idxen\n\tbuffer_load_dword %10, %15, %20, %22 idxen\n\t"
-		"buffer_load_dword %1, %16, %20, 0 idxen\n\tbuffer_load_dwordx2 %6, %16, %20, %21 idxen\n\tbuffer_load_dword %11, %16, %20, %22 idxen\n\t"
-		"buffer_load_dword %2, %17, %20, 0 idxen\n\tbuffer_load_dwordx2 %7, %17, %20, %21 idxen\n\tbuffer_load_dword %12, %17, %20, %22 idxen\n\t"
-		"buffer_load_dword %3, %18, %20, 0 idxen\n\tbuffer_load_dwordx2 %8, %18, %20, %21 idxen\n\tbuffer_load_dword %13, %18, %20, %22 idxen\n\t"
-		"buffer_load_dword %4, %19, %20, 0 idxen\n\tbuffer_load_dwordx2 %9, %19, %20, %21 idxen\n\tbuffer_load_dword %14, %19, %20, %22 idxen"
-		: "=&v"(q.a0), "=&v"(q.a1), "=&v"(q.a2), "=&v"(q.a3), "=&v"(q.a4), "=&v"(q.m0), "=&v"(q.m1), "=&v"(q.m2), "=&v"(q.m3), "=&v"(q.m4),
-		  "=&v"(q.d0), "=&v"(q.d1), "=&v"(q.d2), "=&v"(q.d3), "=&v"(q.d4)
-		: "v"(i0), "v"(i1), "v"(i2), "v"(i3), "v"(i4), "s"(r), "s"(soff1), "s"(soff2) : "memory");
-}
-template <int LEFT>
-__device__ __forceinline__ void pm_triwait5(PMTriQ& q) {
-	asm volatile("s_waitcnt vmcnt(%15)" : "+v"(q.a0), "+v"(q.a1), "+v"(q.a2), "+v"(q.a3), "+v"(q.a4), "+v"(q.m0), "+v"(q.m1), "+v"(q.m2), "+v"(q.m3), "+v"(q.m4),
-		"+v"(q.d0), "+v"(q.d1), "+v"(q.d2), "+v"(q.d3), "+v"(q.d4) : "i"(LEFT));
-}
 #else
 // host build (the CPU emulator of the tests): the same semantics -- entry index, zeros outside
 typedef float4 pm_f4v;
@@ -316,46 +292,25 @@ __device__ __forceinline__ void pm_bufload5(pm_f4v& q0, pm_f4v& q1, pm_f4v& q2, 
 	q0 = i0 < r.count ? r.base[i0] : z; q1 = i1 < r.count ? r.base[i1] : z; q2 = i2 < r.count ? r.base[i2] : z; q3 = i3 < r.count ? r.base[i3] : z; q4 = i4 < r.count ? r.base[i4] : z;
 }
 template <int LEFT> __device__ __forceinline__ void pm_bufwait5(pm_f4v&, pm_f4v&, pm_f4v&, pm_f4v&, pm_f4v&) {}
-struct pm_f2v { float x, y; };
-struct PMTriQ { float a0, a1, a2, a3, a4; pm_f2v m0, m1, m2, m3, m4; float d0, d1, d2, d3, d4; };
-__device__ __forceinline__ void pm_triload5(PMTriQ& q, unsigned i0, unsigned i1, unsigned i2, unsigned i3, unsigned i4, pm_rsrc r, int soff1, int soff2) {
-	const float* b = (const float*)r.base; const unsigned o1 = (unsigned)soff1 / 4u, o2 = (unsigned)soff2 / 4u;
-	auto ld = [&](unsigned i, unsigned o) { return i < r.count ? b[i + o] : 0.f; };   // (the range check is on the index alone, as the hardware's: the rows below an image's last entry belong to the next image or the guard band)
-	q.a0 = ld(i0, 0); q.m0 = pm_f2v{ld(i0, o1), ld(i0, o1 + 1)}; q.d0 = ld(i0, o2);
-	q.a1 = ld(i1, 0); q.m1 = pm_f2v{ld(i1, o1), ld(i1, o1 + 1)}; q.d1 = ld(i1, o2);
-	q.a2 = ld(i2, 0); q.m2 = pm_f2v{ld(i2, o1), ld(i2, o1 + 1)}; q.d2 = ld(i2, o2);
-	q.a3 = ld(i3, 0); q.m3 = pm_f2v{ld(i3, o1), ld(i3, o1 + 1)}; q.d3 = ld(i3, o2);
-	q.a4 = ld(i4, 0); q.m4 = pm_f2v{ld(i4, o1), ld(i4, o1 + 1)}; q.d4 = ld(i4, o2);
-}
-template <int LEFT> __device__ __forceinline__ void pm_triwait5(PMTriQ&) {}
 __device__ __forceinline__ unsigned pm_mad24(int a, int b, unsigned c) { return (unsigned)(((unsigned)a & 0xffffffu) * ((unsigned)b & 0xffffffu)) + c; }   // wraps as the hardware's low 32 bits do
 #endif
 
-#ifndef PM_TRILOAD
-#define PM_TRILOAD 0   // 1: the sweep kernels' buffer path reads the plain anti-diagonal-major images with three loads per sample instead of the quad images with one
-#endif
-// what the buffer path of the tap rows needs, wave-uniform: the descriptor and (PM_TRILOAD) the two row offsets
-struct PMImgBuf { pm_rsrc rs; int soff1, soff2; };
+// what the buffer path of the tap rows needs, wave-uniform: the descriptor of the level's quad buffer
+struct PMImgBuf { pm_rsrc rs; };
 __device__ __forceinline__ PMImgBuf pm_make_imgbuf(const PMTask& t) {
 	PMImgBuf b;
-#if defined(__HIP_DEVICE_COMPILE__)
-	if (PM_TRILOAD) { b.rs = pm_make_rsrc(t.sArr, t.qCount - (unsigned)(2 * t.h + 1), 4u);   // (an index whose last piece, e + 2h + 1, would leave the buffer is out of range as a whole)
-	 b.soff1 = __builtin_amdgcn_readfirstlane(4 * t.h); b.soff2 = __builtin_amdgcn_readfirstlane(4 * (2 * t.h + 1)); }
-	else { b.rs = pm_make_rsrc(t.qArr, t.qCount); b.soff1 = 0; b.soff2 = 0; }
-#else
-	if (PM_TRILOAD) { b.rs = pm_make_rsrc(t.sArr, t.qCount - (unsigned)(2 * t.h + 1)); b.soff1 = 4 * t.h; b.soff2 = 4 * (2 * t.h + 1); }
-	else { b.rs = pm_make_rsrc(t.qArr, t.qCount); b.soff1 = 0; b.soff2 = 0; }
-#endif
+	b.rs = pm_make_rsrc(t.qArr, t.qCount);
 	return b;
 }
 
-// One tap row (5 taps) of ScorePixelImage through global loads, with the reference's per-tap tests; row-major (SKEW = false) or anti-diagonal-major image.
+// One tap row (5 taps) of ScorePixelImage through global loads, with the reference's per-tap tests; from the row-major image (SKEW = false, Img = pm_gcf) or from the
+// anti-diagonal-major quad image (SKEW = true, Img = pm_gcf4: the clamped position's entry holds exactly the four texels of the sample).
 // X = position of the row's first tap.  The reference returns thRobust at the first tap that leaves the image (DepthMap.cpp:484-485).  Here a tap outside
 // only raises a flag and its address is clamped, so there is no branch between taps: the 20 loads of the row are issued back to back and the sums of a flagged
 // hypothesis are simply discarded -- identical result, no load ever depends on a previous load.  This is the GUARDED path: every position is the IEEE quotient
 // whatever the operands (pm_div2).  The init kernel scores with it (one evaluation per pixel), the sweep kernels only redo a patch with it.
-template <bool SKEW>
-__device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int sh, float h0, float h3, float h6, float X0, float X1, float X2,
+template <bool SKEW, class Img>
+__device__ __forceinline__ void pm_tap_row_global(const Img img, int sw, int sh, float h0, float h3, float h6, float X0, float X1, float X2,
 		const float2* wrow, float& sum, float& sumSq, float& num, bool& oob)
 {
 	const int lxMax = sw - 2, lyMax = sh - 2;
@@ -376,10 +331,8 @@ __device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int 
 	float v00[5], v01[5], v10[5], v11[5];
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
-		const pm_gcf p = img + offs[j];
-		// texels (lx,ly), (lx+1,ly), (lx,ly+1), (lx+1,ly+1) sit at skew (s,t), (s+1,t), (s+1,t+1), (s+2,t+1)
-		if (SKEW) { v00[j] = p[0]; v01[j] = p[sh]; v10[j] = p[sh + 1]; v11[j] = p[2 * sh + 1]; }
-		else { v00[j] = p[0]; v01[j] = p[1]; v10[j] = p[sw]; v11[j] = p[sw + 1]; }
+		if constexpr (SKEW) { const auto q = img[offs[j]]; v00[j] = q.x; v01[j] = q.y; v10[j] = q.z; v11[j] = q.w; }   // texels (lx,ly), (lx+1,ly), (lx,ly+1), (lx+1,ly+1)
+		else { const pm_gcf p = img + offs[j]; v00[j] = p[0]; v01[j] = p[1]; v10[j] = p[sw]; v11[j] = p[sw + 1]; }
 	}
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
@@ -403,7 +356,7 @@ __device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int 
 // BUF: the sample is addressed as entry index qbase + (lx + ly) * sh + ly of the level's buffer (no clamp: out of range reads zeros, see above); otherwise through the
 // view's own pointer with clamped coordinates (views that carry their own image size live outside the level's buffer).
 struct PMRowPos { float ptx[5], pty[5]; };
-struct PMRowQ { pm_f4v q0, q1, q2, q3, q4; PMTriQ t; };   // (the quad entries or, PM_TRILOAD, their pieces: the unused member is never materialised)
+struct PMRowQ { pm_f4v q0, q1, q2, q3, q4; };
 struct PMTapRange { int zlo, zhi, plo, pxhi, pyhi; };
 // positions of a row's five taps, their samples requested; nothing waits here
 template <bool BUF>
@@ -421,8 +374,7 @@ __device__ __forceinline__ void pm_row_issue(const PMImgBuf& rs, unsigned qbase,
 		if (j == 4) { const int zLast = pm_f2i(X2); rg.zlo = min(rg.zlo, min(zFirst, zLast)); rg.zhi = max(rg.zhi, max(zFirst, zLast)); }
 		X0 += h0; X1 += h3; X2 += h6;
 	}
-	if (BUF && PM_TRILOAD) pm_triload5(q.t, idx[0], idx[1], idx[2], idx[3], idx[4], rs.rs, rs.soff1, rs.soff2);
-	else if (BUF) pm_bufload5(q.q0, q.q1, q.q2, q.q3, q.q4, idx[0], idx[1], idx[2], idx[3], idx[4], rs.rs);
+	if (BUF) pm_bufload5(q.q0, q.q1, q.q2, q.q3, q.q4, idx[0], idx[1], idx[2], idx[3], idx[4], rs.rs);
 	else { q.q0 = pm_loadq(imgQ, idx[0]); q.q1 = pm_loadq(imgQ, idx[1]); q.q2 = pm_loadq(imgQ, idx[2]); q.q3 = pm_loadq(imgQ, idx[3]); q.q4 = pm_loadq(imgQ, idx[4]); }
 	// (independent of the loads) the extremes of the positions, on their bit patterns (see pm_f2i): plo = the smallest x or y, pxhi / pyhi = the largest x / y
 	rg.plo = min(rg.plo, min(min(min(pm_f2i(p.ptx[0]), pm_f2i(p.ptx[1])), min(pm_f2i(p.ptx[2]), pm_f2i(p.ptx[3]))), pm_f2i(p.ptx[4])));
@@ -435,18 +387,10 @@ template <bool BUF, int LEFT>
 __device__ __forceinline__ void pm_row_consume(const PMRowPos& p, PMRowQ& q, const float2* wrow, float& sum, float& sumSq, float& num)
 {
 	float t00[5], t01[5], t10[5], t11[5];
-	if (BUF && PM_TRILOAD) {
-		pm_triwait5<3 * LEFT>(q.t);
-		t00[0] = q.t.a0; t00[1] = q.t.a1; t00[2] = q.t.a2; t00[3] = q.t.a3; t00[4] = q.t.a4;
-		t01[0] = q.t.m0.x; t01[1] = q.t.m1.x; t01[2] = q.t.m2.x; t01[3] = q.t.m3.x; t01[4] = q.t.m4.x;
-		t10[0] = q.t.m0.y; t10[1] = q.t.m1.y; t10[2] = q.t.m2.y; t10[3] = q.t.m3.y; t10[4] = q.t.m4.y;
-		t11[0] = q.t.d0; t11[1] = q.t.d1; t11[2] = q.t.d2; t11[3] = q.t.d3; t11[4] = q.t.d4;
-	} else {
-		if (BUF) pm_bufwait5<LEFT>(q.q0, q.q1, q.q2, q.q3, q.q4);
-		const pm_f4v qq[5] = {q.q0, q.q1, q.q2, q.q3, q.q4};
+	if (BUF) pm_bufwait5<LEFT>(q.q0, q.q1, q.q2, q.q3, q.q4);
+	const pm_f4v qq[5] = {q.q0, q.q1, q.q2, q.q3, q.q4};
 #pragma unroll
-		for (int j = 0; j < 5; ++j) { t00[j] = qq[j].x; t01[j] = qq[j].y; t10[j] = qq[j].z; t11[j] = qq[j].w; }
-	}
+	for (int j = 0; j < 5; ++j) { t00[j] = qq[j].x; t01[j] = qq[j].y; t10[j] = qq[j].z; t11[j] = qq[j].w; }
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
 		const float fx = pm_fract_pos(p.ptx[j]), fx1 = 1.f - fx, fy = pm_fract_pos(p.pty[j]), fy1 = 1.f - fy;   // == ptx - (float)(int)ptx for the positions the row is accepted with (>= 1)
@@ -540,7 +484,7 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 			bX0 = rX0; bX1 = rX1; bX2 = rX2;
 #pragma unroll 1
 			for (int i = 0; i < 5; ++i) {
-				pm_tap_row_global<true>(pm_glob(s.imgS), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
+				pm_tap_row_global<true>(imgQ, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
 				bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
 			}
 		}
@@ -640,8 +584,8 @@ __device__ __forceinline__ void pm_fill_patch(const PMTask& t, bool inb, int x, 
 	const float sigmaColor = -1.f / (2.f * (0.1f * 0.1f));
 	const float sigmaSpatial = -1.f / (2.f * 9.f);
 	if (inb) {
-		const pm_gcf refS = pm_glob(t.refS), ref = pm_glob(t.ref);
-		const float colCenter = SKEW ? refS[(size_t)(x + y) * t.h + y] : ref[(size_t)y * t.w + x];
+		const pm_gcf4 refQ = pm_glob4(t.refQ); const pm_gcf ref = pm_glob(t.ref);
+		const float colCenter = SKEW ? refQ[(size_t)(x + y) * t.h + y].x : ref[(size_t)y * t.w + x];
 		// the texels of this lane's taps are requested together (one memory round trip at the head of the visit, not one per tap)
 		constexpr int NK = (PM_NT + G - 1) / G;
 		float Is[NK];
@@ -649,7 +593,7 @@ __device__ __forceinline__ void pm_fill_patch(const PMTask& t, bool inb, int x, 
 		for (int q = 0; q < NK; ++q) {
 			const int k = v + q * G, kk = k < PM_NT ? k : v % PM_NT;   // (a lane without a tap re-reads one that exists: no address outside the patch)
 			const int i = (kk / 5) * 2 - PM_HW, j = (kk % 5) * 2 - PM_HW;
-			Is[q] = SKEW ? refS[(size_t)(x + j + y + i) * t.h + (y + i)] : ref[(size_t)(y + i) * t.w + (x + j)];
+			Is[q] = SKEW ? refQ[(size_t)(x + j + y + i) * t.h + (y + i)].x : ref[(size_t)(y + i) * t.w + (x + j)];
 		}
 #pragma unroll
 		for (int q = 0; q < NK; ++q) {
@@ -1001,14 +945,6 @@ __global__ void pm_area_kernel(const float* __restrict__ src, float* __restrict_
 			o = sum / (float)count;
 		}
 		dst[i] = o;
-	}
-}
-// anti-diagonal-major copy of nImg row-major images: dst[img][(u+v)*h + v] = src[img][v*w + u]
-__global__ void pm_skew_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, int nImg) {
-	const size_t n = (size_t)w * h * nImg, sp = (size_t)(w + h - 1) * h;
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-		const int u = (int)(i % w), v = (int)((i / w) % h); const size_t im = i / ((size_t)w * h);
-		dst[im * sp + (size_t)(u + v) * h + v] = src[i];
 	}
 }
 // anti-diagonal-major quad image of nImg row-major images: dst[img][(u+v)*h + v] = {I(u,v), I(u+1,v), I(u,v+1), I(u+1,v+1)}, neighbours clamped at the

@@ -129,6 +129,42 @@ def _exchange_view_lists(mine_maps, mine, foreign, neighbors, n_views, world, ra
     return [r.to(like.device) for r in recv] if staged else recv
 
 
+def gather_views_to_root(mine_maps, n_views: int, world: int, rank: int, root: int = 0, view_shapes=None):
+    """Every rank's block of maps (a [len(block), H, W] tensor or a list of [h_v, w_v] tensors) -> a list of all n_views maps on `root`, None on the other ranks."""
+    maps = list(mine_maps) if isinstance(mine_maps, (list, tuple)) else [mine_maps[k] for k in range(mine_maps.shape[0])]
+    if not _collectives_on(world):
+        return maps
+    like = maps[0] if maps else None
+    staged = like is not None and like.device.type != "cpu" and dist.get_backend() == "gloo"
+    if rank != root:
+        ops, keep = [], []
+        for m in maps:
+            buf = (m.cpu() if staged else m).contiguous(); keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, root))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return None
+    if view_shapes is None:
+        if like is None:
+            raise ValueError("gather_views_to_root: the root holds no view and no view_shapes were given")
+        view_shapes = [tuple(like.shape)] * n_views
+    dev = torch.device("cpu") if (staged or like is None) else like.device
+    dtype = like.dtype if like is not None else torch.float32
+    out, ops = [None] * n_views, []
+    for peer in range(world):
+        for k, v in enumerate(shard_range(n_views, world, peer)):
+            if peer == rank:
+                out[v] = maps[k]
+            else:
+                out[v] = torch.empty(tuple(view_shapes[v]), dtype=dtype, device=dev)
+                ops.append(dist.P2POp(dist.irecv, out[v], peer))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return [m.to(like.device) if (staged and m.device != like.device) else m for m in out]
+
+
 class ShardedDensifier:
     """Photometric pass + `geo_iters` geometric rounds over this rank's block of views.
 
@@ -151,12 +187,15 @@ class ShardedDensifier:
         self.mine = list(shard_range(n_views, world, rank))
         self.neighbors = neighbors
         self.view_shapes = view_shapes       # (h, w) of every view's maps when they differ (neighbour-only exchange; the estimator then hands lists of tensors)
-        self.exchange_seconds = 0.0
+        self.exchange_seconds = 0.0          # communication + installing the received maps (the round boundary proper)
+        self.wait_seconds = 0.0              # waiting for this rank's own asynchronous estimate before its maps can be read (kernel time, not communication)
 
     def exchange(self):
         import time
+        t0 = time.perf_counter()
+        own = self.est.local_depths(self.mine)          # blocks until the round's estimate has finished
         t = time.perf_counter()
-        own = self.est.local_depths(self.mine)
+        self.wait_seconds += t - t0
         if self.neighbors is None:
             self.est.set_snapshot(all_gather_views(own, self.n_views, self.world, self.rank))
         else:
@@ -174,7 +213,7 @@ class ShardedDensifier:
     def filter(self):
         """Scene::DenseReconstructionFilter (SceneDensify.cpp:2136-2222) sharded by view: every rank filters its own depth maps against the UNFILTERED
         depth and confidence maps of their neighbours (the reference writes *.filtered.dmap files and renames them only when all are done), so one
-        exchange of depth and one of confidence precede the filter; the filtered maps stay with their owner (gather them with `gather("depth")`)."""
+        exchange of depth and one of confidence precede the filter; the filtered maps stay with their owner (collect them on the fusing rank with `gather("depth", root=0)`)."""
         for what in ("depth", "conf"):
             own = self.est.local_maps(self.mine, what)
             if self.neighbors is None:
@@ -184,7 +223,14 @@ class ShardedDensifier:
                 self.est.set_maps_views(what, ids, maps)
         self.est.filter(self.mine)
 
-    def gather(self, what):
-        """[n_views, H, W] maps of all views on every rank (e.g. the filtered maps before FuseDepthMaps, which is sequential over the scene and
-        therefore runs on one rank, SceneDensify.cpp:1372-1650)."""
-        return all_gather_views(self.est.local_maps(self.mine, what), self.n_views, self.world, self.rank)
+    def gather(self, what, root=None):
+        """Maps of all views for FuseDepthMaps, which is sequential over the scene and therefore runs on one rank (SceneDensify.cpp:1372-1650).
+        root=None, uniform sizes: [n_views, H, W] on every rank (one all-gather).  root=r: only rank r receives -- a list of n_views maps there, None elsewhere --
+        by one point-to-point message per view, which is also the only form for views of different sizes (`view_shapes`) and the one that keeps a
+        neighbour-only rank from holding the whole scene."""
+        own = self.est.local_maps(self.mine, what)
+        if root is None:
+            if isinstance(own, (list, tuple)):
+                raise ValueError("gather(%r): views of different sizes have no [n_views, H, W] tensor -- pass root= to collect them view by view on the fusing rank" % what)
+            return all_gather_views(own, self.n_views, self.world, self.rank)
+        return gather_views_to_root(own, self.n_views, self.world, self.rank, root, self.view_shapes)

@@ -52,13 +52,13 @@ class PMHipFuseParams(C.Structure):
 
 
 class PMHipTuning(C.Structure):
-    _fields_ = [("viewGroups", C.c_int32), ("wideMaxViews", C.c_int32), ("wideHyps", C.c_int32), ("sweepLanes", C.c_int32), ("quadBuffer", C.c_int32), ("widePixels", C.c_int32), ("wide8Pixels", C.c_int32), ("launchThreads", C.c_int32)]
+    _fields_ = [("viewGroups", C.c_int32), ("wideMaxViews", C.c_int32), ("wideHyps", C.c_int32), ("sweepLanes", C.c_int32), ("quadBuffer", C.c_int32), ("widePixels", C.c_int32), ("wide8Pixels", C.c_int32), ("groupOffset", C.c_int32)]
 
 
 EXPORTS = ["pmhip_get_tuning", "pmhip_set_tuning", "pmhip_scene_set_view_id", "pmhip_scene_set_view_sized", "pmhip_scene_set_source_depth", "pmhip_scene_set_mask", "pmhip_scene_set_mask_mode", "pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
            "pmhip_estimate_depth_map", "pmhip_estimate_depth_map_masked", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
            "pmhip_scene_estimate", "pmhip_scene_commit_round", "pmhip_scene_reset_view", "pmhip_scene_set_maps",
-           "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_remove_small_segments", "pmhip_scene_images_updated", "pmhip_scene_maps_updated", "pmhip_sync",
+           "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_remove_small_segments", "pmhip_scene_images_updated", "pmhip_scene_maps_updated", "pmhip_scene_bytes", "pmhip_sync",
            "pmhip_stream", "pmhip_stats_reset", "pmhip_stats_get", "pmhip_prof_get", "pmhip_math_eval", "pmhip_resize"]
 
 _LIB = None
@@ -192,11 +192,14 @@ class PatchMatchHIP:
                                                  nb.ctypes.data_as(C.POINTER(C.c_int32)), len(nb)))
 
     def tuning(self, **kw):
-        """pmhip_get_tuning / pmhip_set_tuning: how a batch is mapped onto the GPU (viewGroups, wideMaxViews, wideHyps, sweepLanes, quadBuffer, widePixels, wide8Pixels, launchThreads); returns the settings
+        """pmhip_get_tuning / pmhip_set_tuning: how a batch is mapped onto the GPU (viewGroups, wideMaxViews, wideHyps, sweepLanes, quadBuffer, widePixels, wide8Pixels, groupOffset); returns the settings
         in force as a dict.  The results never depend on them."""
         t = PMHipTuning()
         if kw:
+            names = {k for k, _ in PMHipTuning._fields_}
             for k, v in kw.items():
+                if k not in names:
+                    raise KeyError("PMHipTuning has no field %r" % k)
                 setattr(t, k, int(v))
             self._chk(self._lib.pmhip_set_tuning(self._h, C.byref(t)))
         self._chk(self._lib.pmhip_get_tuning(self._h, C.byref(t)))
@@ -329,6 +332,11 @@ class PatchMatchHIP:
 
     def sync(self):
         self._chk(self._lib.pmhip_sync(self._h))
+
+    def scene_bytes(self) -> int:
+        """Device memory the resident scene holds right now (pmhip_scene_bytes)."""
+        self._lib.pmhip_scene_bytes.restype = C.c_uint64
+        return int(self._lib.pmhip_scene_bytes(self._h))
 
     def stream(self) -> int:
         return int(self._lib.pmhip_stream(self._h) or 0)

@@ -17,6 +17,14 @@ os.environ.setdefault("PMHIP_WIDE", "0")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "pinning: the oracle against the reference's own code compiled into oracle/_ref (tests/test_ref_*.py; `pytest -m pinning`, needs /root/reference to build)")
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_itemcollected(item):
+    # every case of tests/test_ref_*.py pins an oracle function to the reference's text: one command runs them all (`python -m pytest tests -m pinning`)
+    if os.path.basename(str(item.fspath)).startswith("test_ref_"):
+        item.add_marker(pytest.mark.pinning)
 
 
 def _have_gpu():

@@ -11,13 +11,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _write_scene(path, sc):
+def _write_scene(path, sc, own=None):
+    """own: {view: scene} -- these views take image, colours and K from another rendering of the same scene at another size (a scene whose views differ in size)."""
     n, w, h, ns = sc.n_views, sc.width, sc.height, sc.neighbors.shape[1]
     with open(path, "wb") as f:
-        f.write(np.array([n, w, h, ns], np.int32).tobytes())
+        f.write(np.array([-n if own else n, w, h, ns], np.int32).tobytes())
         for i in range(n):
-            f.write(np.ascontiguousarray(sc.gray[i], np.float32).tobytes()); f.write(np.ascontiguousarray(sc.bgr[i], np.uint8).tobytes())
-            f.write(np.concatenate([sc.K[i].ravel(), sc.R[i].ravel(), sc.C[i].ravel()]).astype(np.float64).tobytes())
+            src = own.get(i, sc) if own else sc
+            if own:
+                f.write(np.array([src.width, src.height], np.int32).tobytes())
+            f.write(np.ascontiguousarray(src.gray[i], np.float32).tobytes()); f.write(np.ascontiguousarray(src.bgr[i], np.uint8).tobytes())
+            f.write(np.concatenate([src.K[i].ravel(), sc.R[i].ravel(), sc.C[i].ravel()]).astype(np.float64).tobytes())
             f.write(np.array([sc.dmin[i], sc.dmax[i]], np.float32).tobytes()); f.write(np.ascontiguousarray(sc.neighbors[i], np.int32).tobytes())
 
 
@@ -34,6 +38,13 @@ def test_multi_engine_host_equals_single_engine_under_the_emulator(tmp_path):
         r = subprocess.run([exe, inp, str(engines), "31", "serial"], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-400:]
         assert "engines == 1 engine" in r.stdout
+    # views of different sizes (DepthMapsData::InitViews, SceneDensify.cpp:306-459): two of the five views smaller, one larger; blocks of 3 + 2 views, so maps of
+    # their own size cross engines at the round boundaries, before the filter and on the way to the fusing engine
+    small = synth.make_scene(5, 48, 36, n_src=4); big = synth.make_scene(5, 80, 60, n_src=4)
+    inp2 = str(tmp_path / "scene_mixed.bin"); _write_scene(inp2, sc, own={1: small, 3: big, 4: small})
+    r = subprocess.run([exe, inp2, "2", "31", "serial"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-400:]
+    assert "2 engines == 1 engine: 5 views of different sizes" in r.stdout
 
 
 def test_rccl_policy_compiles_and_links(tmp_path):
@@ -59,6 +70,13 @@ def test_multi_engine_host_equals_single_engine_on_the_device(tmp_path, small_sc
     inp = str(tmp_path / "scene.bin"); _write_scene(inp, small_scene)
     r = subprocess.run([exe, inp, "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-400:]
+    from openmvs_amd import synth
+    sc = synth.make_scene(5, 128, 96, n_src=4); small = synth.make_scene(5, 96, 72, n_src=4); big = synth.make_scene(5, 160, 120, n_src=4)
+    inp2 = str(tmp_path / "scene_mixed.bin"); _write_scene(inp2, sc, own={1: small, 3: big, 4: small})
+    for engines in ("2", "3"):
+        r = subprocess.run([exe, inp2, engines], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-400:]
+        assert "views of different sizes" in r.stdout
 
 
 @pytest.mark.gpu

@@ -95,7 +95,10 @@ def _worker(rank, world, port, out_dir, neighbour_only=False):
         est.conf[v] = np.where(est.depth[v] > 0, np.float32(1) - np.minimum(est.conf[v], np.float32(0.9)), np.float32(0)).astype(np.float32)
     drv.filter()
     fd, fc = drv.gather("depth"), drv.gather("conf")
+    rooted = drv.gather("depth", root=0)          # one message per view to the fusing rank only
+    assert (rooted is None) == (rank != 0)
     if rank == 0:
+        assert len(rooted) == sc.n_views and all(torch.equal(rooted[v], fd[v]) for v in range(sc.n_views))
         np.save(os.path.join(out_dir, "sharded.npy"), final.numpy())
         np.save(os.path.join(out_dir, "filtered_depth.npy"), fd.numpy()); np.save(os.path.join(out_dir, "filtered_conf.npy"), fc.numpy())
     dist.destroy_process_group()
@@ -191,6 +194,9 @@ class MixedSizeEstimator:
     def local_depths(self, ids):
         return [torch.from_numpy(self.depth[v].copy()) for v in ids]
 
+    def local_maps(self, ids, what):
+        return [torch.from_numpy({"depth": self.depth, "conf": self.conf}[what][v].copy()) for v in ids]
+
     def set_snapshot_views(self, own_ids, own, foreign_ids, foreign):
         self.snap = [None] * 5
         for v, m in zip(own_ids, own):
@@ -209,6 +215,20 @@ def _mixed_worker(rank, world, port, out_dir):
     drv.run()
     for v in drv.mine:
         np.save(os.path.join(out_dir, "depth%d.npy" % v), est.depth[v])
+    # the fusing rank collects every view's map view by view (ShardedDensifier.gather(root=)); there is no [n, H, W] tensor of such a scene
+    try:
+        drv.gather("depth")
+        raise AssertionError("gather without a root must refuse views of different sizes")
+    except ValueError:
+        pass
+    root = world - 1
+    got = drv.gather("depth", root=root)
+    if rank == root:
+        assert [tuple(m.shape) for m in got] == [tuple(s) for s in est.shapes]
+        for v in range(5):
+            np.save(os.path.join(out_dir, "gathered%d.npy" % v), got[v].numpy())
+    else:
+        assert got is None
     dist.destroy_process_group()
 
 
@@ -226,4 +246,5 @@ def test_neighbour_only_exchange_of_views_of_different_sizes(tmp_path):
         mp.spawn(_mixed_worker, args=(world, port, str(out)), nprocs=world, join=True)
         for v in range(5):
             assert np.array_equal(np.load(out / ("depth%d.npy" % v)), est.depth[v]), "world %d view %d" % (world, v)
+            assert np.array_equal(np.load(out / ("gathered%d.npy" % v)), est.depth[v]), "world %d view %d gathered on the last rank" % (world, v)
     assert (est.depth[3] > 0).mean() > 0.2

@@ -81,7 +81,7 @@ def test_estimator_sweep_kernel_variants(pm_emulated, nine_scene, small_scene, v
 
 def test_estimator_tuning_through_the_abi(pm_emulated, nine_scene):
     from tests import test_gpu_patchmatch as g
-    g.test_tuning_through_the_abi(nine_scene, threads=False, views=[4, 6])
+    g.test_tuning_through_the_abi(nine_scene, views=[4, 6])
 
 
 def test_estimator_wide_latency_mode(pm_emulated, nine_scene, small_scene):

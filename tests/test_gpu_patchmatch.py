@@ -163,7 +163,7 @@ def test_sweep_kernel_variants_parity(nine_scene, small_scene, variant, quick=Fa
                 os.environ[k] = v
 
 
-def test_tuning_through_the_abi(nine_scene, threads=True, views=None):
+def test_tuning_through_the_abi(nine_scene, views=None):
     """pmhip_set_tuning (include/pmhip.h): the mapping of a batch onto the GPU is chosen through the C ABI, not through the environment; every setting gives the
     oracle's bits."""
     from openmvs_amd.patchmatch import PatchMatchHIP
@@ -177,8 +177,10 @@ def test_tuning_through_the_abi(nine_scene, threads=True, views=None):
                dict(wideMaxViews=-1, sweepLanes=-1, quadBuffer=1, viewGroups=1),
                # per-launch choice: the short diagonals of a batch with the eight-wide speculative kernel, the middle ones with the two-wide one, the long ones with pm_sweep2
                dict(wideMaxViews=-1, sweepLanes=4, viewGroups=2, widePixels=max(8, int(sc.height * per * 0.45)), wide8Pixels=max(4, int(sc.height * per * 0.12))),
-               # one host thread per view group enqueueing its launches (the CPU emulator's launches are synchronous: device only)
-               dict(wideMaxViews=64, wideHyps=-1, widePixels=-1, wide8Pixels=-1, viewGroups=3, launchThreads=3 if threads else 1)):
+               # view groups that start out of phase: group g + 1 begins when group g has done 15 % (and, with three groups, 40 %) of its pass
+               dict(wideMaxViews=64, wideHyps=-1, widePixels=-1, wide8Pixels=-1, viewGroups=2, groupOffset=150),
+               dict(wideMaxViews=-1, sweepLanes=4, widePixels=max(8, int(sc.height * per * 0.45)), wide8Pixels=-1, viewGroups=3, groupOffset=400),
+               dict(viewGroups=2, groupOffset=1000), dict(viewGroups=2, groupOffset=-1)):
         got = e.tuning(**kw)
         for k, v in kw.items():
             assert got[k] == v, (k, got)
@@ -910,6 +912,22 @@ def test_sized_view_api_edges(W=96, H=72):
         od, on, oc = _oracle(base, v, seed)
         d, n, c = e.scene_get_maps(v)
         _same(d, od, "view %d after un-sizing" % v); _same(n, on, "normal"); _same(c, oc, "conf")
+    # a colour image follows its view's size class: after a view changes class, fusion with colours is refused until the colour is set again (it must not read a freed or
+    # never-written image)
+    e.scene_estimate([1, 3, 4], -1, p)
+    for v in range(5):
+        e.scene_set_color(v, base.bgr[v])
+    order = po.fuse_order([len(base.neighbors[v]) for v in range(5)])
+    n0 = e.scene_fuse(order)["nPoints"]
+    e.scene_set_view_sized(2, big.gray[2], big.K[2], base.R[2], base.C[2], float(base.dmin[2]), float(base.dmax[2]), base.neighbors[2])
+    with pytest.raises(PatchMatchError):
+        e.scene_fuse(order)
+    e.scene_set_color(2, big.bgr[2])
+    e.scene_set_view(2, base.gray[2], base.K[2], base.R[2], base.C[2], float(base.dmin[2]), float(base.dmax[2]), base.neighbors[2])
+    with pytest.raises(PatchMatchError):
+        e.scene_fuse(order)
+    e.scene_set_color(2, base.bgr[2]); e.scene_estimate([2], -1, p)
+    assert e.scene_fuse(order)["nPoints"] == n0
     e.close()
 
 
@@ -927,89 +945,111 @@ def test_config2_full_size_matches_golden():
         assert gc.sha(getattr(sc, k)) == g["inputs"][k], "camera " + k
     assert gc.sha(sc.neighbors.astype(np.int32)) == g["inputs"]["neighbors"]
     assert [float(x) for x in sc.dmin] == g["inputs"]["dmin"] and [float(x) for x in sc.dmax] == g["inputs"]["dmax"]
-    import os
     p = default_params(seed=c["seed"], nEstimationGeometricIters=c["geo_iters"])
     allv = list(range(c["n_views"]))
-    # the scene interface with every sweep kernel a batch can get: pm_sweep2_kernel<4 lanes, 2 views per lane> (what bench.py's timed 100-view batch runs),
-    # pm_sweep2_kernel<8,1> (26-79 views), and the engine's own choice for nine views (the two-wide speculative kernel)
-    for what, env in (("pm_sweep2_kernel<4,2>", {"PMHIP_WIDE": "0", "PMHIP_LANES": "4"}), ("pm_sweep2_kernel<8,1>", {"PMHIP_WIDE": "0", "PMHIP_LANES": "8"}),
-                      ("engine default", {"PMHIP_WIDE": None, "PMHIP_LANES": None})):
-        saved_env = {k: os.environ.get(k) for k in env}
-        for k, v in env.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
-        try:
-            e = PatchMatchHIP(0); e.Init(True)
-            e.scene_load(sc, n_levels=2)
-            rounds = []
-            for r in range(1 + c["geo_iters"]):
-                if r:
-                    e.scene_commit_round()
-                e.scene_estimate(allv, r - 1, p)
-                rounds.append([e.scene_get_maps(v) for v in allv])
-                for v in allv:
-                    gc.check_maps(rounds[r][v], g["rounds"][r][str(v)], "scene interface (%s), round %d, view %d" % (what, r, v))
-            e.close()
-        finally:
-            for k, v in saved_env.items():
-                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    # the scene interface with every sweep kernel a batch can get, chosen through pmhip_set_tuning: pm_sweep2_kernel<4 lanes, 2 views per lane> alone; <8,1> (26-79 views);
+    # the engine's own choice for nine views (the two-wide speculative kernel); and the MIX bench.py's timed 100-view batch runs -- <4,2> on the long diagonals and the
+    # two-wide kernel on the short ones of the same sweep, the view groups out of phase (threshold scaled to this batch: 20000 pixels / 50 views per group = 400 pixels of
+    # diagonal, x 4.5 views per group here), with two and with three groups
+    for what, tun in (("pm_sweep2_kernel<4,2>", dict(wideMaxViews=-1, sweepLanes=4)), ("pm_sweep2_kernel<8,1>", dict(wideMaxViews=-1, sweepLanes=8)), ("engine default", {}),
+                      ("timed mix, 2 groups", dict(wideMaxViews=-1, sweepLanes=4, widePixels=1800, viewGroups=2, groupOffset=160)),
+                      ("timed mix, 3 groups", dict(wideMaxViews=-1, sweepLanes=4, widePixels=1200, viewGroups=3, groupOffset=330))):
+        e = PatchMatchHIP(0); e.Init(True)
+        if tun:
+            e.tuning(**tun)
+        e.scene_load(sc, n_levels=2)
+        rounds = []
+        for r in range(1 + c["geo_iters"]):
+            if r:
+                e.scene_commit_round()
+            e.scene_estimate(allv, r - 1, p)
+            rounds.append([e.scene_get_maps(v) for v in allv])
+            for v in allv:
+                gc.check_maps(rounds[r][v], g["rounds"][r][str(v)], "scene interface (%s), round %d, view %d" % (what, r, v))
+        e.close()
     # the per-view boundary (layer 1): host buffers in and out, one blocking call per pass -- with the regular sweep kernel and with the
-    # one-wave-per-pixel kernel the engine uses by default for a single depth map (PMHIP_WIDE)
+    # one-wave-per-pixel kernel the engine uses by default for a single depth map
     ref = c["ref"]
     ids = [ref] + list(sc.neighbors[ref])
-    saved = os.environ.get("PMHIP_WIDE")
-    try:
-        for wide in ("0", "8"):
-            os.environ["PMHIP_WIDE"] = wide
-            e = PatchMatchHIP(0); e.Init(True)
-            cur = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], params=p)
-            gc.check_maps(cur, g["rounds"][0][str(ref)], "one-call boundary (PMHIP_WIDE=%s), photometric" % wide)
-            for r in range(1, 1 + c["geo_iters"]):
-                cur = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], depth=cur[0], normal=cur[1],
-                                         src_depths={v: rounds[r - 1][v][0] for v in ids[1:]}, nGeometricIter=r - 1, params=p)
-                gc.check_maps(cur, g["rounds"][r][str(ref)], "one-call boundary (PMHIP_WIDE=%s), geometric round %d" % (wide, r - 1))
-            e.close()
-    finally:
-        if saved is None:
-            os.environ.pop("PMHIP_WIDE", None)
-        else:
-            os.environ["PMHIP_WIDE"] = saved
+    for what, tun in (("pm_sweep2_kernel", dict(wideMaxViews=-1)), ("pm_sweep_wide_kernel", dict(wideMaxViews=8))):
+        e = PatchMatchHIP(0); e.Init(True); e.tuning(**tun)
+        cur = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], params=p)
+        gc.check_maps(cur, g["rounds"][0][str(ref)], "one-call boundary (%s), photometric" % what)
+        for r in range(1, 1 + c["geo_iters"]):
+            cur = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], depth=cur[0], normal=cur[1],
+                                     src_depths={v: rounds[r - 1][v][0] for v in ids[1:]}, nGeometricIter=r - 1, params=p)
+            gc.check_maps(cur, g["rounds"][r][str(ref)], "one-call boundary (%s), geometric round %d" % (what, r - 1))
+        e.close()
 
 
 def test_config5_resolution_estimate_filter_fuse():
-    """BASELINE config 5's resolution (3840x2160), a 5-view slice of such a scene: photometric pass + one geometric round, speckle / gap filters, the
-    cross-view filter and the fusion, all resident.  The oracle would need hours here, so the checks are size-independent properties: run-to-run
-    determinism of the whole chain (schedule races would show), accuracy against the analytic ground truth, the filters only remove or smooth,
-    fused points lie on the surface; the sizes where 32-bit offsets or grid limits could bite (8.3 Mpix per map, 6 k diagonals) are exercised."""
+    """BASELINE config 5's resolution (3840x2160), a 5-view slice of such a scene: photometric pass + one geometric round, speckle / gap filters, the cross-view filter
+    and the fusion, all resident -- stage by stage against the digests the SEQUENTIAL oracle produced on the CPU (tests/golden/make_fullsize_golden.py c5, ~25 CPU-minutes;
+    SceneDensify.cpp:616-805, :1049-1299, :809-1047, :1303-1646), bit-exact: every map of every stage and the fused cloud.  The sizes where 32-bit offsets or grid limits
+    could bite (8.3 Mpix per map, 6 k diagonals) are exercised.  Then the same chain once more through densify.compute_depth_maps: the driver is the stage sequence, and
+    the run repeats itself (schedule races would show)."""
     import time
     from openmvs_amd import densify
     from openmvs_amd.patchmatch import PatchMatchHIP
-    W, H, V = 3840, 2160, 5
-    sc = synth.make_scene(V, W, H, n_src=4, device="cuda", exact=True)
+    from tests import golden_check as gc
+    g = gc.load("pm_config5_3840x2160.json")
+    c = g["case"]
+    W, H, V = c["width"], c["height"], c["n_views"]
+    sc = synth.make_scene(V, W, H, n_src=c["n_src"], device="cuda", exact=True)
+    assert gc.sha(sc.gray) == g["inputs"]["gray"], "the exact scene generator did not reproduce the golden inputs on this machine (images differ)"
+    assert gc.sha(np.stack([np.asarray(b) for b in sc.bgr])) == g["inputs"]["bgr"]
+    for k in ("K", "R", "C"):
+        assert gc.sha(getattr(sc, k)) == g["inputs"][k], "camera " + k
     allv = list(range(V))
-    p = default_params(seed=3, nEstimationGeometricIters=1)
-    runs = []
-    for rep in range(2):
-        e = PatchMatchHIP(0)
-        e.scene_load(sc, n_levels=2)
-        for v in allv:
-            e.scene_set_color(v, sc.bgr[v])
-        t0 = time.time()
-        densify.compute_depth_maps(e, allv, p)
-        e.sync(); t1 = time.time()
-        cloud = e.scene_fuse(po.fuse_order([len(sc.neighbors[v]) for v in allv]))
-        t2 = time.time()
-        runs.append(([e.scene_get_maps(v) for v in allv], cloud))
-        e.close()
-    print("config-5 resolution, %d views: estimate + filters %.2f s (%.1f Mpix/s), fuse %.2f s, %d points" % (V, t1 - t0, V * W * H / (t1 - t0) / 1e6, t2 - t1, runs[0][1]["nPoints"]))
+    p = default_params(seed=c["seed"], nEstimationGeometricIters=c["geo_iters"])
+    order = po.fuse_order([len(sc.neighbors[v]) for v in allv])
+    e = PatchMatchHIP(0)
+    e.scene_load(sc, n_levels=2)
     for v in allv:
-        for a, b, what in zip(runs[0][0][v], runs[1][0][v], ("depth", "normal", "conf")):
-            _same(a, b, f"determinism v{v} {what}")
-    assert runs[0][1]["nPoints"] == runs[1][1]["nPoints"] and np.array_equal(runs[0][1]["points"], runs[1][1]["points"])
-    d = runs[0][0][2][0]; m = d > 0
+        e.scene_set_color(v, sc.bgr[v])
+
+    def stage(k):
+        assert g["stages"][k]["name"]
+        for v in allv:
+            gc.check_maps(e.scene_get_maps(v), g["stages"][k][str(v)], "config-5 resolution, %s, view %d" % (g["stages"][k]["name"], v))
+    t0 = time.time()
+    e.Init(False)
+    for v in allv:
+        e.scene_reset_view(v)
+    e.scene_estimate(allv, -1, p); stage(0)
+    e.scene_commit_round(); e.Init(True)
+    e.scene_estimate(allv, 0, p); stage(1)
+    e.scene_remove_small_segments(allv, 100, 0.01); e.scene_gap_interpolation(allv, 7, 0.01); stage(2)
+    e.scene_filter(allv, True, 2, 1, 0.01, commit=True); stage(3)
+    first = [e.scene_get_maps(v) for v in allv]
+    cloud = e.scene_fuse(order)
+    gf = g["fuse"]
+    assert cloud["nPoints"] == gf["nPoints"] and cloud["nDepths"] == gf["nDepths"], (cloud["nPoints"], gf["nPoints"])
+    for k in ("points", "viewStart", "views", "weights", "projs", "colors", "normals"):
+        assert gc.sha(cloud[k]) == gf[k], "config-5 resolution, fused cloud: %s differs from the sequential oracle's" % k
+    print("config-5 resolution, %d views: whole chain incl. downloads %.1f s, %d points" % (V, time.time() - t0, cloud["nPoints"]))
+    # the driver (Scene::ComputeDepthMaps order of operations) on a fresh engine: same maps, same cloud
+    e.close()
+    e = PatchMatchHIP(0)
+    e.scene_load(sc, n_levels=2)
+    for v in allv:
+        e.scene_set_color(v, sc.bgr[v])
+    t0 = time.time()
+    densify.compute_depth_maps(e, allv, p)
+    e.sync(); t1 = time.time()
+    cloud2 = e.scene_fuse(order)
+    t2 = time.time()
+    print("config-5 resolution, %d views: estimate + filters %.2f s (%.1f Mpix/s), fuse %.2f s" % (V, t1 - t0, V * W * H / (t1 - t0) / 1e6, t2 - t1))
+    for v in allv:
+        for a, b, what in zip(first[v], e.scene_get_maps(v), ("depth", "normal", "conf")):
+            _same(a, b, f"driver vs stage sequence v{v} {what}")
+    assert cloud2["nPoints"] == cloud["nPoints"] and np.array_equal(cloud2["points"], cloud["points"]) and np.array_equal(cloud2["views"], cloud["views"])
+    e.close()
+    d = first[2][0]; m = d > 0
     gt = sc.gt_depth[2]
     rel = np.abs(d[m] - gt[m]) / gt[m]
     assert m.mean() > 0.8 and np.median(rel) < 1e-3 and (rel < 0.01).mean() > 0.95
-    pts = runs[0][1]["points"]
+    pts = cloud["points"]
     assert len(pts) > 1_000_000 and np.abs(pts[:, 2]).max() < 0.12     # the surface is a height field |z| <= 0.1 around z = 0
 
 

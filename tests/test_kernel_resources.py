@@ -26,3 +26,22 @@ def test_sweep_kernels_keep_their_residency_budget():
     for k, v in wide.items():
         assert v["occupancy"] >= 3 and v["vgpr"] <= 168 and v["scratch"] <= 96 and v["lds"] <= 4096, (k, v)
     assert not any("pm_band_kernel" in k or "pm_sweep_kernel" in k for k in r)     # round 3's resident band kernel and round 2's LDS-window kernel are gone
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="no hipcc")
+def test_no_instruction_touches_a_tap_row_register_before_its_wait():
+    """The tap rows' 16-byte buffer loads are issued from inline assembly (pm_bufload5), outside the compiler's s_waitcnt bookkeeping: a copy, spill or reuse of one of
+    their destination registers before the hand-written `s_waitcnt vmcnt(N)` would corrupt samples silently.  tools/isa_inflight_check.py models the vector-memory queue
+    over the gfx950 assembly of every kernel with such loads; first a positive control on a hand-made sequence, then the shipped kernels."""
+    import isa_inflight_check as ic
+    fake = ["_Z4fakev:", "\tbuffer_load_dwordx4 v[10:13], v1, s[0:3], 0 idxen", "\tbuffer_load_dwordx4 v[14:17], v2, s[0:3], 0 idxen", "\tv_add_f32_e32 v20, v21, v22",
+            "\ts_waitcnt vmcnt(1)", "\tv_mul_f32_e32 v30, v10, v11", "\tv_mov_b32_e32 v31, v15", "\ts_waitcnt vmcnt(0)", "\tv_mov_b32_e32 v32, v16", ".Lfunc_end0:"]
+    got = ic.check(fake)
+    assert got["_Z4fakev"][0] == 2 and got["_Z4fakev"][1] == ["v_mov_b32_e32 v31, v15"], got
+    fake[3] = "\tscratch_store_dwordx4 off, v[10:13], off offset:16"              # a spill of an in-flight destination
+    assert ic.check(fake)["_Z4fakev"][1] == [fake[3].strip()]                     # (the store is a queue entry itself: vmcnt(1) then covers both loads, the later v_mov is fine)
+    r = ic.check()
+    buf = [k for k in r if "pm_sweep" in k]
+    assert len(buf) == 18, sorted(r)                                              # 12 pm_sweep2 (quad buffer) + 2 eight-wide + 4 two- / four-wide instantiations
+    for k, (n, bad) in r.items():
+        assert n >= 15 and not bad, (k, bad[:3])

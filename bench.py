@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--with-filter", action="store_true", help="append the cross-view depth-map filter (config 5's exchange) to every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config2 / parity / sgm blocks")
+    ap.add_argument("--images", choices=("broadcast", "needed"), default="broadcast", help="N > 1: one broadcast of the image set (default), or rank 0 sends every rank only the views it holds")
     ap.add_argument("--no-shard-rates", action="store_true", help="skip the shard-size legs (the blocks a rank owns at 2 / 4 / 8 GPUs, timed on this GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -103,15 +104,12 @@ def main():
         meta = [sc["K"], sc["R"], sc["C"], sc["neighbors"], sc["dmin"], sc["dmax"], sc["diameter"]]
         gt0 = sc["gt_depth"][0].cpu().numpy()
     else:
-        gray = torch.empty((V, H, W), dtype=torch.float32, device=dev)
-        meta = None; gt0 = None
+        gray = None; meta = None; gt0 = None
     if dist_on:
-        dist.broadcast(gray, 0)                       # the single broadcast of the image set over xGMI
         box = [meta]
         dist.broadcast_object_list(box, 0)
         meta = box[0]
     K, R, Cc, nbr, dmin, dmax, diameter = meta
-    torch.cuda.synchronize()
 
     # ---- this rank's part of the scene: its block of reference views and the foreign views they read, in a compact scene of local slots (own block first) ----
     from openmvs_amd.distributed import needed_views
@@ -120,18 +118,45 @@ def main():
     assert mine_chk == mine
     held = mine + foreign                                   # global view ids in slot order
     slot = {g: i for i, g in enumerate(held)}
+    # images: ONE broadcast of the whole set over xGMI (north_star; the default), every rank then keeps its block + closure; or, `--images needed`, rank 0 sends every rank
+    # just the views it holds, point to point -- what a scene too large to pass through every GPU (or a closure much smaller than the scene, BASELINE config 5) wants
+    images_how = "one broadcast of the image set"
+    if dist_on and a.images == "needed" and world > 1:
+        images_how = "point to point from rank 0: each rank receives the %d views it holds" % len(held)
+        staged = backend != "nccl"                          # (gloo has no point-to-point for device tensors: through the host then)
+        if rank == 0:
+            reqs = []
+            for r in range(1, world):
+                m_r, f_r = needed_views(nbr_lists, V, world, r)
+                if m_r + f_r:
+                    buf = gray[m_r + f_r].contiguous()
+                    reqs.append((dist.isend(buf.cpu() if staged else buf, r), buf))
+            for w_, _ in reqs:
+                w_.wait()
+            local_gray = gray[held].contiguous()
+        else:
+            local_gray = torch.empty((len(held), H, W), dtype=torch.float32, device="cpu" if staged else dev)
+            if held:
+                dist.recv(local_gray, 0)
+            local_gray = local_gray.to(dev)
+    else:
+        if rank != 0:
+            gray = torch.empty((V, H, W), dtype=torch.float32, device=dev)
+        if dist_on:
+            dist.broadcast(gray, 0)                         # the single broadcast of the image set over xGMI
+        local_gray = gray[held].contiguous() if (foreign or not mine or len(mine) < V) else gray
+    torch.cuda.synchronize()
+    del gray
     eng = PatchMatchHIP(local)
     eng.Init(True)
     eng.scene_create(max(2, len(held)), W, H, 2)
     for i, g in enumerate(held):
         eng.scene_set_view(i, None, K[g], R[g], Cc[g], float(dmin[g]), float(dmax[g]), [slot[n] for n in nbr_lists[g]] if i < len(mine) else [])
         eng.scene_set_view_id(i, g)                         # random numbers by the view's index in the whole scene: the maps do not depend on the split
-    if mine:
-        eng.scene_copy(0, 0, len(mine), gray[mine[0]:mine[-1] + 1].data_ptr(), True)
-    for g in foreign:
-        eng.scene_copy(0, slot[g], 1, gray[g].data_ptr(), True)
+    if held:
+        eng.scene_copy(0, 0, len(held), local_gray.data_ptr(), True)
     eng.sync()
-    del gray
+    del local_gray
     torch.cuda.empty_cache()
     p = default_params(seed=1, nEstimationGeometricIters=a.geo_iters)
     B = a.batch if a.batch > 0 else max(1, len(mine))
@@ -224,7 +249,8 @@ def main():
     mine_info = {"rank": rank, "views_per_gpu": len(mine), "foreign_views_held": len(foreign), "kernel": sweep_kernel_name(len(mine) if not a.batch else min(a.batch, len(mine)), N),
                  # exchange = sending / receiving / installing maps at the round boundaries; wait = blocked on this rank's own asynchronous estimate before its maps can be read
                  "exchange_ms_per_step": round(1e3 * drv.exchange_seconds / max(1, a.steps + a.warmup), 2),
-                 "wait_for_own_estimate_ms_per_step": round(1e3 * drv.wait_seconds / max(1, a.steps + a.warmup), 2), "seconds": round(own_dt, 3)}
+                 "wait_for_own_estimate_ms_per_step": round(1e3 * drv.wait_seconds / max(1, a.steps + a.warmup), 2), "seconds": round(own_dt, 3),
+                 "scene_mb": round(eng.scene_bytes() / 1e6, 1), "scene_mb_per_view_held": round(eng.scene_bytes() / 1e6 / max(1, len(held)), 1)}
     ranks_info = [mine_info]
     if dist_on:
         box = [None] * world
@@ -253,7 +279,7 @@ def main():
                                    "(3-level pyramid x 3 sweeps) + %d geometric rounds%s, all depth maps"
                                    % (V, W, H, N, a.geo_iters, " + cross-view filter" if a.with_filter else ""),
                        "views_total": V, "views_per_gpu": len(mine), "batch": B, "parallelism": "reference views sharded over %d GPU(s)" % world,
-                       "exchange": "neighbour-only point-to-point (a rank holds its block and the %d foreign views it reads)" % len(foreign), "ranks": ranks_info,
+                       "exchange": "neighbour-only point-to-point (a rank holds its block and the %d foreign views it reads)" % len(foreign), "images": images_how, "ranks": ranks_info,
                        **({"backend": backend} if dist_on else {}), **({"depth_digests": digests} if digests else {})},
             "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), **tf, **issue,
@@ -423,7 +449,7 @@ def golden_and_config2(eng):
                 mismatches.append(str(ex)[:300])
     # the same 27 maps through what the TIMED region runs for a 100-view batch, which the engine would not pick for 9 views by itself (set through pmhip_set_tuning):
     #  (1) pm_sweep2_kernel<4 lanes per pixel, 2 views per lane> alone; (2) the timed MIX: that kernel on the long diagonals and pm_sweep_widen_kernel<2> on the short ones
-    #  inside one sweep, in two view groups that run out of phase -- the per-launch threshold scaled so that the same diagonals (by length) switch kernels as at 50 views per group:
+    #  inside one sweep, in two view groups -- the per-launch threshold scaled so that the same diagonals (by length) switch kernels as at 50 views per group:
     #  PMHIP_DEFAULT_WIDE_PIXELS 20000 / 50 = 400 pixels of diagonal, x 4.5 views per group here
     timed_mismatches, mix_mismatches = [], []
     from openmvs_amd.patchmatch import PatchMatchHIP
@@ -475,7 +501,7 @@ def golden_and_config2(eng):
                                % (c["geo_iters"], 3 * len(allv) * (1 + c["geo_iters"])),
                        "inputs_reproduced": bool(same_inputs), "bit_identical": bool(same_inputs and not mismatches and not timed_mismatches), "mismatches": (mismatches + timed_mismatches)[:4],
                        "kernel": "pm_sweep2_kernel", "kernel_note": "all 27 maps four ways: the engine's own choice for 9 views (pm_sweep_widen_kernel<2>); pm_sweep2_kernel<4,2> alone; the TIMED MIX "
-                                 "(pm_sweep2_kernel<4,2> on the long diagonals, pm_sweep_widen_kernel<2> on the short ones of the same sweep, two view groups out of phase: tuning %s); "
+                                 "(pm_sweep2_kernel<4,2> on the long diagonals, pm_sweep_widen_kernel<2> on the short ones of the same sweep, two view groups: tuning %s); "
                                  "the one-call boundary (pm_sweep_wide_kernel)" % json.dumps(mix_tuning),
                        "bit_identical_timed_kernel": bool(same_inputs and not timed_mismatches), "bit_identical_timed_mix": bool(same_inputs and not mix_mismatches),
                        "depth_rmse_over_diameter": rmse / sc.diameter, "tolerance": 1e-4,

@@ -242,8 +242,6 @@ typedef struct PMHipTuning {
 	int32_t quadBuffer;      /* 1: tap rows address the level's quad images as one buffer, 2: through each view's pointer */
 	int32_t widePixels;      /* larger batches: a diagonal launch of at most this many pixels (diagonal length x views of the group) uses the two-wide speculative kernel (20000); -1 = none */
 	int32_t wide8Pixels;     /* ... and one of at most this many pixels the eight-wide speculative kernel; -1 = none */
-	int32_t groupOffset;     /* per mille of a pass's steps (level hand-offs, init passes, diagonal launches, finalize) by which view group g + 1 starts behind group g, so that the
-	                            short diagonals, coarse levels and init pass of one group run under the long diagonals of another; -1 = none (the groups start together) */
 } PMHipTuning;
 int pmhip_get_tuning(pmhip_engine* e, PMHipTuning* out);
 int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t);

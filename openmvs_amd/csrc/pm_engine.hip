@@ -21,9 +21,6 @@
 #include <string>
 #include <vector>
 
-#ifndef PMHIP_DEFAULT_GROUP_OFFSET
-#define PMHIP_DEFAULT_GROUP_OFFSET 0
-#endif
 #ifndef PMHIP_DEFAULT_WIDE_PIXELS
 #define PMHIP_DEFAULT_WIDE_PIXELS 20000   // larger batches: diagonal launches of at most this many pixels (diagonal length x views of the group) use the two-wide speculative
                                          // kernel -- the ramps of the fine level and all of the coarse ones.  profiles/r04_call9_lanes_100.log (100 views, Mpix/s): none 46.4,
@@ -64,6 +61,7 @@ struct SceneView {
 	uint8_t* oBgr = nullptr;                                                           // its 8-bit BGR image (pmhip_scene_set_color), sw x sh x 3
 	unsigned char* oMask[4] = {nullptr, nullptr, nullptr, nullptr};                    // its ignore mask per pyramid level (pmhip_scene_set_mask)
 	float* sImg[4] = {nullptr, nullptr, nullptr, nullptr};
+	float* sImgS[4] = {nullptr, nullptr, nullptr, nullptr};
 	float4* sImgQ[4] = {nullptr, nullptr, nullptr, nullptr};
 	bool sideDirty = false;
 	// A known depth-map of this view to be read by geometric rounds instead of the scene's snapshot, of its own size and with the camera it
@@ -72,7 +70,7 @@ struct SceneView {
 };
 static int lvlSize(int n, int l) { return (int)nearbyint((double)n / (double)(1 << l)); }   // cvRound(size / 2^l), ties to even
 static void freeSide(SceneView& v) {
-	for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgQ[l]) hipFree(v.sImgQ[l]); v.sImg[l] = nullptr; v.sImgQ[l] = nullptr; }
+	for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgS[l]) hipFree(v.sImgS[l]); if (v.sImgQ[l]) hipFree(v.sImgQ[l]); v.sImg[l] = v.sImgS[l] = nullptr; v.sImgQ[l] = nullptr; }
 	if (v.sDepth) hipFree(v.sDepth);
 	if (v.oDepth) hipFree(v.oDepth); if (v.oNormal) hipFree(v.oNormal); if (v.oConf) hipFree(v.oConf); if (v.oSnap) hipFree(v.oSnap);
 	if (v.oFDepth) hipFree(v.oFDepth); if (v.oFConf) hipFree(v.oFConf); if (v.oBgr) hipFree(v.oBgr);
@@ -125,14 +123,14 @@ struct pmhip_engine {
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
 	int quadBuffer = 1;                     // tap rows address the level's quad images as one buffer (entry index); 0 = through each view's own pointer (PMHIP_QUADBUF; forced for
 	                                        // batches that read a source view with its own image size, which lives outside the level's buffer)
-	int groupOffset = PMHIP_DEFAULT_GROUP_OFFSET;   // per mille of a pass's steps by which view group g + 1 starts behind group g (0 = the groups start together)
 	hipStream_t gstream[16] = {};
-	hipEvent_t forkEv = nullptr, joinEv[16] = {}, phaseEv[16] = {};
+	hipEvent_t forkEv = nullptr, joinEv[16] = {};
 	bool inited = false, geom = false;
 	std::string err;
 	// scene (HBM resident)
 	int nImages = 0, w = 0, h = 0, nLevels = 0; // nLevels = sub-resolution levels available (pyramid has nLevels+1 entries)
 	float* d_img[4] = {nullptr, nullptr, nullptr, nullptr};
+	float* d_imgS[4] = {nullptr, nullptr, nullptr, nullptr}; // folded anti-diagonal-major copies (PMTask::refS: the reference patch of a sweep visit), w_l*h_l floats per image
 	float4* d_imgQ[4] = {nullptr, nullptr, nullptr, nullptr}; // anti-diagonal-major quad images (PMSrcView::imgQ): texel (u,v)'s entry at (u+v)*h_l + v, (w_l+h_l-1)*h_l entries of 16 bytes per image
 	size_t skewPitch(int l) const { return (size_t)(lw(l) + lh(l) - 1) * lh(l); }
 	float *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr, *d_snap = nullptr;
@@ -202,7 +200,7 @@ static void freeFuse(pmhip_engine* e) {
 static void freeScene(pmhip_engine* e) {
 	hipSetDevice(e->device);
 	freeFuse(e);
-	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_imgQ[l]) hipFree(e->d_imgQ[l]); e->d_imgQ[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
+	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_imgS[l]) hipFree(e->d_imgS[l]); e->d_imgS[l] = nullptr; if (e->d_imgQ[l]) hipFree(e->d_imgQ[l]); e->d_imgQ[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
 	if (e->d_depth) hipFree(e->d_depth); if (e->d_normal) hipFree(e->d_normal); if (e->d_conf) hipFree(e->d_conf); if (e->d_snap) hipFree(e->d_snap);
 	e->d_depth = e->d_normal = e->d_conf = e->d_snap = nullptr;
 	for (int l = 0; l < 4; ++l) { if (e->d_mask[l]) hipFree(e->d_mask[l]); e->d_mask[l] = nullptr; }
@@ -248,6 +246,7 @@ static int buildPyramid(pmhip_engine* e) {
 	for (int l = 0; l <= e->nLevels; ++l) {
 		const size_t n = (size_t)e->lw(l) * e->lh(l) * e->nImages;
 		const int blocks = (int)std::min<size_t>((n + 255) / 256, 65535);
+		hipLaunchKernelGGL(pm_skew_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_img[l], e->d_imgS[l], e->lw(l), e->lh(l), e->nImages);
 		hipLaunchKernelGGL(pm_quad_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_img[l], e->d_imgQ[l], e->lw(l), e->lh(l), e->nImages);
 	}
 	HIPCHK(e, hipGetLastError());
@@ -268,6 +267,7 @@ static int buildSidePyramids(pmhip_engine* e) {
 			const int lw = lvlSize(v.sw, l), lh = lvlSize(v.sh, l);
 			if (lw < 1 || lh < 1 || !v.sImg[l]) break;
 			const size_t n = (size_t)lw * lh;
+			hipLaunchKernelGGL(pm_skew_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, e->stream, v.sImg[l], v.sImgS[l], lw, lh, 1);
 			hipLaunchKernelGGL(pm_quad_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, e->stream, v.sImg[l], v.sImgQ[l], lw, lh, 1);
 		}
 		HIPCHK(e, hipGetLastError());
@@ -438,8 +438,8 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 				t.depth = base; t.normal = base + Pl; t.conf = base + Pl * 4;
 				t.prior = (l < S) ? base + Pl * 5 : nullptr;
 			}
-			if (v.sw) { t.ref = v.sImg[l]; t.refQ = v.sImgQ[l]; }
-			else { t.ref = e->d_img[l] + Pls * id; t.refQ = e->d_imgQ[l] + e->skewPitch(l) * id; }
+			if (v.sw) { t.ref = v.sImg[l]; t.refS = v.sImgS[l]; }
+			else { t.ref = e->d_img[l] + Pls * id; t.refS = e->d_imgS[l] + Pls * id; }
 			t.qArr = e->d_imgQ[l]; t.qCount = (unsigned)(e->skewPitch(l) * (size_t)e->nImages);
 			t.mask = (anyMask && e->hasMask[id]) ? (v.sw ? v.oMask[l] : e->d_mask[l] + Pls * id) : nullptr;
 			t.w = lw; t.h = lh; t.nSrc = v.nNb;
@@ -508,9 +508,16 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 		HIPCHK(e, hipMemcpyAsync(e->d_ups + (size_t)l * e->batchCap, hu, sizeof(PMUpTask) * nB, hipMemcpyHostToDevice, e->stream));
 	}
 	// ---- the pass as a sequence of steps that is the same for every view group: per level {hand-off, ScoreDepthMapTmp, sweeps of one launch per anti-diagonal}, EndDepthMapTmp.
-	// A view group runs ALL of them on its own stream (views are independent; the steps of one view are not) and the groups meet only at the end of the call; group g starts
-	// when group g - 1 has finished `groupOffset` per mille of its steps, so that one group's latency-bound phases (the short diagonals at both ends of a sweep, the coarse levels,
-	// the init pass) run under another group's long diagonals instead of coinciding with them.  Scheduling only: the maps cannot depend on it.
+	// A view group runs ALL of them on its own stream (views are independent; the steps of one view are not); the groups start together and meet again at the end of the
+	// call.  Scheduling only: the maps cannot depend on it.
+	// Measured and not kept (round 5, MI355X, full schedule at 1920x1080; all bit-identical):
+	//  * group g + 1 starting behind group g, so that one group's short diagonals, coarse levels and init pass run under another group's long diagonals (commit c352a63,
+	//    PMHipTuning::groupOffset): slower for every offset and batch size -- 100 views 47.8 -> 46.5 (5 % of the pass) -> 41.9 Mpix/s (40 %), 13 views 26.6 -> 25.4 -> 20.0
+	//    (profiles/r05_call1_groups_*.log).  The late group also finishes late, and a group's launch chain runs slower beside the other's long diagonals than beside its ramps.
+	//  * the groups waiting for each other before every sweep (round 4's fork / join per sweep): no difference (48.8 vs 48.8, profiles/r05_call4_ab_100.log).
+	//  * the views of a group staggered along the pass, so that every launch mixes anti-diagonals, sweeps and levels and carries about the mean number of pixels
+	//    (profiles/r05_view_stagger_experiment.diff): 100 views 46.2 -> 44.0 (5 steps per view) -> 37.7 (30) -> 35.0 Mpix/s (100), profiles/r05_call3_stagger_*.log.  A launch
+	//    lasts one wave-visit at whatever fill, so evening out the fill buys nothing, while every step of the longer chain then costs the heavy kernel's visit.
 	struct Step { int kind, l; unsigned iter; int k; };   // kind 0: level hand-off, 1: init pass, 2: diagonal k of sweep `iter`, 3: finalize
 	std::vector<Step> steps;
 	for (int l = S; l >= 0; --l) {
@@ -523,7 +530,6 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 	steps.push_back({3, 0, 0u, 0});
 	const long nSteps = (long)steps.size();
 	const int NG = std::max(1, std::min(e->nGroups, nB));
-	const long off = NG > 1 ? std::min(nSteps, (nSteps * (long)std::max(0, e->groupOffset) + 999) / 1000) : 0;
 	// group g's stream: the engine's own for a single group.  (Letting group 0 of several sweep on the engine's stream, or more than three groups, falls off a cliff:
 	// 13 views 27 -> 15.6 Mpix/s, whatever GPU_MAX_HW_QUEUES says -- profiles/r04_call10_lanes_13.log.)
 	auto gs = [&](int g) { return NG > 1 ? e->gstream[g] : e->stream; };
@@ -591,15 +597,10 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 			return true;
 		}
 	};
-	// The host feeds the groups in turn, group g lagging g * off steps behind group g - 1: the event group g waits for is recorded (on the host's time line) before the wait is enqueued.
-	for (long i = 0; i < nSteps + off * (NG - 1); ++i)
-		for (int g = 0; g < NG; ++g) {
-			const long j = i - off * g;
-			if (j < 0 || j >= nSteps) continue;
-			if (j == 0 && g > 0 && off > 0) HIPCHK(e, hipStreamWaitEvent(gs(g), e->phaseEv[g - 1], 0));
-			if (!issue(g, steps[j])) { e->err = "sweep kernel: (lanes per pixel, views per lane) mapping not instantiated"; return PMHIP_E_ARG; }
-			if (j == off - 1 && g + 1 < NG) HIPCHK(e, hipEventRecord(e->phaseEv[g], gs(g)));
-		}
+	// the host feeds the groups' streams in turn, step by step
+	for (long i = 0; i < nSteps; ++i)
+		for (int g = 0; g < NG; ++g)
+			if (!issue(g, steps[i])) { e->err = "sweep kernel: (lanes per pixel, views per lane) mapping not instantiated"; return PMHIP_E_ARG; }
 	if (NG > 1) for (int g = 0; g < NG; ++g) { HIPCHK(e, hipEventRecord(e->joinEv[g], gs(g))); HIPCHK(e, hipStreamWaitEvent(e->stream, e->joinEv[g], 0)); }
 	evEndOn(e, evWall, e->stream);
 	HIPCHK(e, hipGetLastError());
@@ -686,7 +687,6 @@ int pmhip_create(int device, pmhip_engine** out) {
 	e->nGroups = ng ? std::max(1, std::min(16, atoi(ng))) : PMHIP_DEFAULT_GROUPS;
 	const char* nw = getenv("PMHIP_WIDE");
 	if (nw) { e->wideMaxViews = atoi(nw); if (e->wideMaxViews <= 0) e->widePixels = e->wide8Pixels = 0; }   // PMHIP_WIDE=0: no speculative kernels at all (PMHIP_WIDE_PIXELS below may bring the per-launch rule back)
-	const char* go = getenv("PMHIP_GROUP_OFFSET"); if (go && atoi(go) >= 0) e->groupOffset = std::min(1000, atoi(go));
 	const char* wp = getenv("PMHIP_WIDE_PIXELS"); if (wp) e->widePixels = atoi(wp);
 	const char* w8 = getenv("PMHIP_WIDE8_PIXELS"); if (w8) e->wide8Pixels = atoi(w8);
 	const char* wh = getenv("PMHIP_WIDE_HYPS"); if (wh && (atoi(wh) == 8 || atoi(wh) == 4 || atoi(wh) == 2)) e->wideHyps = atoi(wh);
@@ -694,8 +694,7 @@ int pmhip_create(int device, pmhip_engine** out) {
 	const char* nl = getenv("PMHIP_LANES");
 	if (nl && atoi(nl) >= 1) e->sweepLanes = atoi(nl);
 	for (int g = 0; g < e->nGroups; ++g)
-		if (hipStreamCreateWithFlags(&e->gstream[g], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->joinEv[g], hipEventDisableTiming) != hipSuccess ||
-		    hipEventCreateWithFlags(&e->phaseEv[g], hipEventDisableTiming) != hipSuccess) { delete e; return PMHIP_E_HIP; }
+		if (hipStreamCreateWithFlags(&e->gstream[g], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->joinEv[g], hipEventDisableTiming) != hipSuccess) { delete e; return PMHIP_E_HIP; }
 	if (hipEventCreateWithFlags(&e->forkEv, hipEventDisableTiming) != hipSuccess) { delete e; return PMHIP_E_HIP; }
 	*out = e;
 	return 0;
@@ -707,7 +706,7 @@ void pmhip_destroy(pmhip_engine* e) {
 	if (e->stream) hipStreamSynchronize(e->stream);
 	for (auto& ev : e->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
 	freeScene(e);
-	for (int g = 0; g < 16; ++g) { if (e->gstream[g]) hipStreamDestroy(e->gstream[g]); if (e->joinEv[g]) hipEventDestroy(e->joinEv[g]); if (e->phaseEv[g]) hipEventDestroy(e->phaseEv[g]); }
+	for (int g = 0; g < 16; ++g) { if (e->gstream[g]) hipStreamDestroy(e->gstream[g]); if (e->joinEv[g]) hipEventDestroy(e->joinEv[g]); }
 	if (e->forkEv) hipEventDestroy(e->forkEv);
 	if (e->stream) hipStreamDestroy(e->stream);
 	delete e;
@@ -739,6 +738,7 @@ int pmhip_scene_create(pmhip_engine* e, int nImages, int w, int h, int nLevels) 
 	const size_t P0 = (size_t)w * h;
 	for (int l = 0; l <= nLevels; ++l) {
 		HIPCHK(e, hipMalloc(&e->d_img[l], sizeof(float) * (size_t)e->lw(l) * e->lh(l) * nImages));
+		HIPCHK(e, hipMalloc(&e->d_imgS[l], sizeof(float) * (size_t)e->lw(l) * e->lh(l) * nImages));
 		HIPCHK(e, hipMalloc(&e->d_imgQ[l], sizeof(float4) * e->skewPitch(l) * nImages));
 	}
 	HIPCHK(e, hipMalloc(&e->d_depth, sizeof(float) * P0 * nImages));
@@ -768,7 +768,7 @@ int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevi
 	if (gray) {
 		if (v.sw) {   // the view goes back to the scene's size: its own pyramid is not needed any more
 			HIPCHK(e, hipStreamSynchronize(e->stream));
-			for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgQ[l]) hipFree(v.sImgQ[l]); v.sImg[l] = nullptr; v.sImgQ[l] = nullptr; }
+			for (int l = 0; l < 4; ++l) { if (v.sImg[l]) hipFree(v.sImg[l]); if (v.sImgS[l]) hipFree(v.sImgS[l]); if (v.sImgQ[l]) hipFree(v.sImgQ[l]); v.sImg[l] = v.sImgS[l] = nullptr; v.sImgQ[l] = nullptr; }
 			if (v.oDepth) hipFree(v.oDepth); if (v.oNormal) hipFree(v.oNormal); if (v.oConf) hipFree(v.oConf); if (v.oSnap) hipFree(v.oSnap);
 			if (v.oFDepth) hipFree(v.oFDepth); if (v.oFConf) hipFree(v.oFConf); if (v.oBgr) hipFree(v.oBgr);
 			for (int l = 0; l < 4; ++l) { if (v.oMask[l]) hipFree(v.oMask[l]); v.oMask[l] = nullptr; }
@@ -776,6 +776,10 @@ int pmhip_scene_set_view(pmhip_engine* e, int idx, const float* gray, int onDevi
 			if (!e->fu.hasBgr.empty()) e->fu.hasBgr[idx] = 0;      // (its colour image went with the side storage)
 			v.oDepth = v.oNormal = v.oConf = v.oSnap = v.oFDepth = v.oFConf = nullptr; v.oBgr = nullptr;
 			v.sw = v.sh = 0; v.sideDirty = false; v.hasMaps = false;
+			// its maps in the scene arrays: "unset", like after pmhip_scene_create (whatever the slot held before the view carried its own size is not an estimate of this image)
+			const size_t Ps = (size_t)e->w * e->h;
+			HIPCHK(e, hipMemsetAsync(e->d_depth + Ps * idx, 0, sizeof(float) * Ps, e->stream)); HIPCHK(e, hipMemsetAsync(e->d_normal + Ps * 3 * idx, 0, sizeof(float) * Ps * 3, e->stream));
+			HIPCHK(e, hipMemsetAsync(e->d_conf + Ps * idx, 0, sizeof(float) * Ps, e->stream)); HIPCHK(e, hipMemsetAsync(e->d_snap + Ps * idx, 0, sizeof(float) * Ps, e->stream));
 		}
 		const size_t P0 = (size_t)e->w * e->h;
 		HIPCHK(e, hipMemcpyAsync(e->d_img[0] + P0 * idx, gray, sizeof(float) * P0, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
@@ -791,13 +795,12 @@ int pmhip_get_tuning(pmhip_engine* e, PMHipTuning* out) {
 	out->viewGroups = e->nGroups; out->wideMaxViews = e->wideMaxViews > 0 ? e->wideMaxViews : -1; out->wideHyps = e->wideHyps > 0 ? e->wideHyps : -1;
 	out->sweepLanes = e->sweepLanes > 0 ? e->sweepLanes : -1; out->quadBuffer = e->quadBuffer ? 1 : 2;
 	out->widePixels = e->widePixels > 0 ? e->widePixels : -1; out->wide8Pixels = e->wide8Pixels > 0 ? e->wide8Pixels : -1;
-	out->groupOffset = e->groupOffset > 0 ? e->groupOffset : -1;
 	return 0;
 }
 int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t) {
 	if (!e || !t) return PMHIP_E_ARG;
 	if (t->viewGroups < 0 || t->viewGroups > 16 || (t->wideHyps > 0 && t->wideHyps != 8 && t->wideHyps != 4 && t->wideHyps != 2) ||
-	    (t->sweepLanes > 0 && t->sweepLanes != 4 && t->sweepLanes != 8 && t->sweepLanes != 16) || t->quadBuffer < 0 || t->quadBuffer > 2 || t->groupOffset > 1000) { e->err = "pmhip_set_tuning: value out of range"; return PMHIP_E_ARG; }
+	    (t->sweepLanes > 0 && t->sweepLanes != 4 && t->sweepLanes != 8 && t->sweepLanes != 16) || t->quadBuffer < 0 || t->quadBuffer > 2) { e->err = "pmhip_set_tuning: value out of range"; return PMHIP_E_ARG; }
 	HIPCHK(e, hipSetDevice(e->device));
 	if (t->viewGroups > 0) {
 		for (int g = e->nGroups; g < t->viewGroups; ++g) if (!e->gstream[g]) {   // streams of the additional view groups
@@ -811,7 +814,6 @@ int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t) {
 	if (t->quadBuffer != 0) e->quadBuffer = t->quadBuffer == 1;
 	if (t->widePixels != 0) e->widePixels = t->widePixels < 0 ? 0 : t->widePixels;
 	if (t->wide8Pixels != 0) e->wide8Pixels = t->wide8Pixels < 0 ? 0 : t->wide8Pixels;
-	if (t->groupOffset != 0) e->groupOffset = t->groupOffset < 0 ? 0 : t->groupOffset;
 	return 0;
 }
 int pmhip_scene_set_view_id(pmhip_engine* e, int idx, uint32_t viewID) {
@@ -844,6 +846,7 @@ int pmhip_scene_set_view_sized(pmhip_engine* e, int idx, const float* gray, int 
 			const int lw = lvlSize(w, l), lh = lvlSize(h, l);
 			if (lw < 1 || lh < 1) break;
 			HIPCHK(e, hipMalloc(&v.sImg[l], sizeof(float) * (size_t)lw * lh));
+			HIPCHK(e, hipMalloc(&v.sImgS[l], sizeof(float) * (size_t)lw * lh));
 			HIPCHK(e, hipMalloc(&v.sImgQ[l], sizeof(float4) * (size_t)(lw + lh - 1) * lh));
 		}
 		// its own maps (DepthData::depthMap / normalMap / confMap of its own size), "unset" like the scene's after pmhip_scene_create
@@ -1195,7 +1198,7 @@ uint64_t pmhip_scene_bytes(pmhip_engine* e) {
 	const size_t N = (size_t)e->nImages, P0 = (size_t)e->w * e->h;
 	size_t b = 0;
 	for (int l = 0; l <= e->nLevels; ++l) {
-		if (e->d_img[l]) b += sizeof(float) * (size_t)e->lw(l) * e->lh(l) * N;
+		if (e->d_img[l]) b += sizeof(float) * (size_t)e->lw(l) * e->lh(l) * N * 2;   // row-major + folded anti-diagonal-major
 		if (e->d_imgQ[l]) b += sizeof(float4) * e->skewPitch(l) * N;
 		if (e->d_mask[l]) b += (size_t)e->lw(l) * e->lh(l) * N;
 	}
@@ -1214,7 +1217,7 @@ uint64_t pmhip_scene_bytes(pmhip_engine* e) {
 		b += sizeof(float) * P * 6 + (v.oFDepth ? sizeof(float) * P * 2 : 0) + (v.oBgr ? 3 * P : 0);
 		for (int l = 0; l <= e->nLevels; ++l) {
 			const size_t lw = (size_t)lvlSize(v.sw, l), lh = (size_t)lvlSize(v.sh, l);
-			if (v.sImg[l]) b += sizeof(float) * lw * lh;
+			if (v.sImg[l]) b += sizeof(float) * lw * lh * 2;
 			if (v.sImgQ[l]) b += sizeof(float4) * (lw + lh - 1) * lh;
 			if (v.oMask[l]) b += lw * lh;
 		}

@@ -74,7 +74,8 @@ struct PMTask {           // one reference view at one pyramid level
 	float* depth; float* normal; float* conf;
 	const float* prior;   // nullable: low-resolution depth prior at this level
 	const float* ref;     // reference image at this level, row-major
-	const float4* refQ;   // reference image as an anti-diagonal-major quad image (PMSrcView::imgQ's layout: entry (u,v) at (u+v)*h + v, .x = the texel itself)
+	const float* refS;    // reference image, anti-diagonal-major and FOLDED: texel (u,v) at ((u+v) mod w)*h + v -- anti-diagonal d and d + w share row d mod w of the array
+	                      // without colliding (d holds v <= d, d + w holds v > d), so the copy is w*h floats; pixels of one anti-diagonal are adjacent (what a wave's lanes read)
 	const unsigned char* mask; // nullable: ignore mask at this level, 0 = pixel is not estimated (DepthData::ApplyIgnoreMask + masked MapMatrix2ZigzagIdx)
 	int w, h, nSrc, pad0;
 	double Hr[9];         // K_0^-1
@@ -303,19 +304,21 @@ __device__ __forceinline__ PMImgBuf pm_make_imgbuf(const PMTask& t) {
 	return b;
 }
 
-// One tap row (5 taps) of ScorePixelImage through global loads, with the reference's per-tap tests; from the row-major image (SKEW = false, Img = pm_gcf) or from the
-// anti-diagonal-major quad image (SKEW = true, Img = pm_gcf4: the clamped position's entry holds exactly the four texels of the sample).
+// One tap row (5 taps) of ScorePixelImage through global loads, with the reference's per-tap tests; from the row-major image (QUAD = false) or from the view's
+// anti-diagonal-major quad image read as plain floats (QUAD = true: the clamped position's entry (lx + ly) * sh + ly holds exactly the four texels of the sample).
 // X = position of the row's first tap.  The reference returns thRobust at the first tap that leaves the image (DepthMap.cpp:484-485).  Here a tap outside
 // only raises a flag and its address is clamped, so there is no branch between taps: the 20 loads of the row are issued back to back and the sums of a flagged
 // hypothesis are simply discarded -- identical result, no load ever depends on a previous load.  This is the GUARDED path: every position is the IEEE quotient
-// whatever the operands (pm_div2).  The init kernel scores with it (one evaluation per pixel), the sweep kernels only redo a patch with it.
-template <bool SKEW, class Img>
-__device__ __forceinline__ void pm_tap_row_global(const Img img, int sw, int sh, float h0, float h3, float h6, float X0, float X1, float X2,
+// whatever the operands (pm_div2).  The init kernel scores with it (one evaluation per pixel), the sweep kernels only redo a patch with it (0 of 5.9 M evaluations in
+// the emulator's census) -- as four 4-byte loads per sample also there: with 16-byte loads the redo path alone took pm_sweep2_kernel<4,2> from 127 to 136 VGPRs, i.e.
+// from four waves per SIMD to three (measured 1 % on the 100-view benchmark, profiles/r05_call4_ab_100.log).
+template <bool QUAD>
+__device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int sh, float h0, float h3, float h6, float X0, float X1, float X2,
 		const float2* wrow, float& sum, float& sumSq, float& num, bool& oob)
 {
 	const int lxMax = sw - 2, lyMax = sh - 2;
 	float fxs[5], fys[5];
-	unsigned offs[5];   // texel offsets fit 32 bits (an image or its skewed copy is < 2^32 floats)
+	unsigned offs[5];   // float offsets fit 32 bits (an image is < 2^32 floats, a quad image < 2^30 entries)
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
 		float ptx, pty;
@@ -325,14 +328,15 @@ __device__ __forceinline__ void pm_tap_row_global(const Img img, int sw, int sh,
 		int lx = (int)ptx, ly = (int)pty;
 		fxs[j] = ptx - (float)lx; fys[j] = pty - (float)ly;
 		lx = min(max(lx, 0), lxMax); ly = min(max(ly, 0), lyMax);
-		offs[j] = SKEW ? (unsigned)(lx + ly) * (unsigned)sh + (unsigned)ly : (unsigned)ly * (unsigned)sw + (unsigned)lx;
+		offs[j] = QUAD ? 4u * ((unsigned)(lx + ly) * (unsigned)sh + (unsigned)ly) : (unsigned)ly * (unsigned)sw + (unsigned)lx;
 		X0 += h0; X1 += h3; X2 += h6;
 	}
 	float v00[5], v01[5], v10[5], v11[5];
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
-		if constexpr (SKEW) { const auto q = img[offs[j]]; v00[j] = q.x; v01[j] = q.y; v10[j] = q.z; v11[j] = q.w; }   // texels (lx,ly), (lx+1,ly), (lx,ly+1), (lx+1,ly+1)
-		else { const pm_gcf p = img + offs[j]; v00[j] = p[0]; v01[j] = p[1]; v10[j] = p[sw]; v11[j] = p[sw + 1]; }
+		const pm_gcf p = img + offs[j];
+		if (QUAD) { v00[j] = p[0]; v01[j] = p[1]; v10[j] = p[2]; v11[j] = p[3]; }   // texels (lx,ly), (lx+1,ly), (lx,ly+1), (lx+1,ly+1)
+		else { v00[j] = p[0]; v01[j] = p[1]; v10[j] = p[sw]; v11[j] = p[sw + 1]; }
 	}
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
@@ -484,7 +488,7 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 			bX0 = rX0; bX1 = rX1; bX2 = rX2;
 #pragma unroll 1
 			for (int i = 0; i < 5; ++i) {
-				pm_tap_row_global<true>(imgQ, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
+				pm_tap_row_global<true>(pm_glob((const float*)s.imgQ), sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, wts + i * 5, sum, sumSq, num, oob);
 				bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
 			}
 		}
@@ -577,6 +581,8 @@ __device__ __forceinline__ float pm_aggregate(float viewScore, int nSrc, float t
 	return (m1 + m2) / 2.f;
 }
 
+// row of anti-diagonal d in the folded anti-diagonal-major image (PMTask::refS): d mod w, for 0 <= d <= w + h - 2
+__device__ __forceinline__ int pm_fold(int d, int w) { if (d >= w) { d -= w; if (d >= w) d %= w; } return d; }
 // FillPixelPatch, DepthMap.cpp:422-462: cooperative weights into LDS; returns normSq0, sumW.
 // Must be called by every thread of the workgroup (contains __syncthreads()).
 template <int G, bool SKEW>
@@ -584,8 +590,8 @@ __device__ __forceinline__ void pm_fill_patch(const PMTask& t, bool inb, int x, 
 	const float sigmaColor = -1.f / (2.f * (0.1f * 0.1f));
 	const float sigmaSpatial = -1.f / (2.f * 9.f);
 	if (inb) {
-		const pm_gcf4 refQ = pm_glob4(t.refQ); const pm_gcf ref = pm_glob(t.ref);
-		const float colCenter = SKEW ? refQ[(size_t)(x + y) * t.h + y].x : ref[(size_t)y * t.w + x];
+		const pm_gcf refS = pm_glob(t.refS), ref = pm_glob(t.ref);
+		const float colCenter = SKEW ? refS[(size_t)pm_fold(x + y, t.w) * t.h + y] : ref[(size_t)y * t.w + x];
 		// the texels of this lane's taps are requested together (one memory round trip at the head of the visit, not one per tap)
 		constexpr int NK = (PM_NT + G - 1) / G;
 		float Is[NK];
@@ -593,7 +599,7 @@ __device__ __forceinline__ void pm_fill_patch(const PMTask& t, bool inb, int x, 
 		for (int q = 0; q < NK; ++q) {
 			const int k = v + q * G, kk = k < PM_NT ? k : v % PM_NT;   // (a lane without a tap re-reads one that exists: no address outside the patch)
 			const int i = (kk / 5) * 2 - PM_HW, j = (kk % 5) * 2 - PM_HW;
-			Is[q] = SKEW ? refQ[(size_t)(x + j + y + i) * t.h + (y + i)].x : ref[(size_t)(y + i) * t.w + (x + j)];
+			Is[q] = SKEW ? refS[(size_t)pm_fold(x + j + y + i, t.w) * t.h + (y + i)] : ref[(size_t)(y + i) * t.w + (x + j)];
 		}
 #pragma unroll
 		for (int q = 0; q < NK; ++q) {
@@ -945,6 +951,14 @@ __global__ void pm_area_kernel(const float* __restrict__ src, float* __restrict_
 			o = sum / (float)count;
 		}
 		dst[i] = o;
+	}
+}
+// folded anti-diagonal-major copy of nImg row-major images (PMTask::refS): dst[img][((u+v) mod w)*h + v] = src[img][v*w + u]
+__global__ void pm_skew_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, int nImg) {
+	const size_t n = (size_t)w * h * nImg;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const int u = (int)(i % w), v = (int)((i / w) % h); const size_t im = i / ((size_t)w * h);
+		dst[im * (size_t)w * h + (size_t)((u + v) % w) * h + v] = src[i];
 	}
 }
 // anti-diagonal-major quad image of nImg row-major images: dst[img][(u+v)*h + v] = {I(u,v), I(u+1,v), I(u,v+1), I(u+1,v+1)}, neighbours clamped at the

@@ -44,6 +44,13 @@ __device__ __forceinline__ int sgm_round2int(float x) { return (int)pm_floorf(x 
 //    multiply-add pairs of a tap become v_pk_mul_f32 / v_pk_add_f32 (IEEE, unfused: -ffp-contract=off), and one ds_read_b128
 //    delivers the weights of both pixels.
 typedef float sgm_v2f __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+#define SGM_SCHED_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)   // no memory access is moved and nothing is scheduled across this point
+#define SGM_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#else
+#define SGM_SCHED_BARRIER() do {} while (0)
+#define SGM_PIN3(a, b, c) do {} while (0)
+#endif
 
 __device__ __forceinline__ float sgm_weight(const unsigned char* __restrict__ colorL, int w, int ux, int uy, int i, int j) {
 	const float sigmaColor = -1.f / (2.f * ((0.3f * 255) * (0.3f * 255)));
@@ -271,8 +278,11 @@ __global__ __launch_bounds__(256, SGM_PX_WAVES) void sgm_cost_px_kernel(const un
 // of sgm_cost_px_kernel -- 49 registers per lane and 7 global loads per cost -- becomes 49 conflict-free ds_read_b32 per cost (consecutive lanes, consecutive
 // addresses; ~20 % of the LDS rate next to 300 VALU instructions).  ~125 VGPRs: 3 waves per SIMD instead of 2, and no vector memory traffic in the walk but
 // the packed cost stores.  Same arithmetic, same order.
+#ifndef SGM_UNI_WAVES
+#define SGM_UNI_WAVES 3
+#endif
 template <int MD>   // nD <= MD: sizes the strip
-__global__ __launch_bounds__(256, 3) void sgm_cost_uni_kernel(const unsigned char* __restrict__ colorL, const float* __restrict__ grayL,
+__global__ __launch_bounds__(256, SGM_UNI_WAVES) void sgm_cost_uni_kernel(const unsigned char* __restrict__ colorL, const float* __restrict__ grayL,
 		const float* __restrict__ grayR, int w, int h, int vw, int vh, int minDisp, int nDall, unsigned char* __restrict__ costs) {
 	// column-major with 9 floats per column: every tap of a lane is within 60 dwords of one address register (ds_read2_b32 immediates; row-major needs a
 	// register per row), and consecutive lanes are 9 dwords apart -- coprime with the 64 banks, so a read is conflict-free
@@ -318,11 +328,30 @@ __global__ __launch_bounds__(256, 3) void sgm_cost_uni_kernel(const unsigned cha
 #pragma unroll 1
 	for (int k = 0; k < nDall; ++k) {
 		float sum = 0.f, sumSq = 0.f, nom = 0.f;
+		// the 49 taps row by row, the next row's seven strip values requested while this row's are consumed (two register sets of seven; with all 49 reads hoisted to the
+		// head of the iteration -- what the scheduler does with the flat loop -- the kernel needs 147 registers for weights and samples alone and spilled 41 of them into
+		// scratch inside this loop).  Same taps, same order: n = row * 7 + column.
+		const float* sk = strip + k * CS;
+		float fa[7], fb[7];
 #pragma unroll
-		for (int n = 0; n < SGM_NT; ++n) {
-			const float f = strip[(k + n % 7) * CS + n / 7];
-			const float fw = f * wk[n];
-			sum += fw; sumSq += f * fw; nom += f * tk[n];
+		for (int j = 0; j < 7; ++j) fa[j] = sk[j * CS];
+#pragma unroll
+		for (int r = 0; r < 7; ++r) {
+			float (&cur)[7] = (r & 1) ? fb : fa;
+			float (&nxt)[7] = (r & 1) ? fa : fb;
+			if (r < 6) {
+#pragma unroll
+				for (int j = 0; j < 7; ++j) nxt[j] = sk[j * CS + r + 1];
+			}
+			SGM_SCHED_BARRIER();
+#pragma unroll
+			for (int j = 0; j < 7; ++j) {
+				const float f = cur[j];
+				const float fw = f * wk[r * 7 + j];
+				sum += fw; sumSq += f * fw; nom += f * tk[r * 7 + j];
+			}
+			SGM_PIN3(sum, sumSq, nom);     // the row's sums exist HERE (the compiler otherwise sinks all 49 taps' arithmetic below the reads, into the block that uses the cost)
+			SGM_SCHED_BARRIER();
 		}
 		const int d = minDisp + k;
 		const bool in = !(ux - SGM_HW + d < 0 || ux + SGM_HW + d >= w);

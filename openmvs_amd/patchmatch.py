@@ -52,7 +52,7 @@ class PMHipFuseParams(C.Structure):
 
 
 class PMHipTuning(C.Structure):
-    _fields_ = [("viewGroups", C.c_int32), ("wideMaxViews", C.c_int32), ("wideHyps", C.c_int32), ("sweepLanes", C.c_int32), ("quadBuffer", C.c_int32), ("widePixels", C.c_int32), ("wide8Pixels", C.c_int32), ("groupOffset", C.c_int32)]
+    _fields_ = [("viewGroups", C.c_int32), ("wideMaxViews", C.c_int32), ("wideHyps", C.c_int32), ("sweepLanes", C.c_int32), ("quadBuffer", C.c_int32), ("widePixels", C.c_int32), ("wide8Pixels", C.c_int32)]
 
 
 EXPORTS = ["pmhip_get_tuning", "pmhip_set_tuning", "pmhip_scene_set_view_id", "pmhip_scene_set_view_sized", "pmhip_scene_set_source_depth", "pmhip_scene_set_mask", "pmhip_scene_set_mask_mode", "pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
@@ -192,7 +192,7 @@ class PatchMatchHIP:
                                                  nb.ctypes.data_as(C.POINTER(C.c_int32)), len(nb)))
 
     def tuning(self, **kw):
-        """pmhip_get_tuning / pmhip_set_tuning: how a batch is mapped onto the GPU (viewGroups, wideMaxViews, wideHyps, sweepLanes, quadBuffer, widePixels, wide8Pixels, groupOffset); returns the settings
+        """pmhip_get_tuning / pmhip_set_tuning: how a batch is mapped onto the GPU (viewGroups, wideMaxViews, wideHyps, sweepLanes, quadBuffer, widePixels, wide8Pixels); returns the settings
         in force as a dict.  The results never depend on them."""
         t = PMHipTuning()
         if kw:

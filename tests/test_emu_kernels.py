@@ -67,10 +67,10 @@ def test_estimator_group_sizes_and_geometric_pass(engine, nine_scene):
     g.test_many_source_views_parity(engine)                                   # G = 16 (9 .. 16 sources) and partial groups
 
 
-@pytest.mark.parametrize("lanes", [4])   # (2 lanes per pixel: device only)
+@pytest.mark.parametrize("lanes", [4])   # (8 lanes per pixel: device only)
 def test_estimator_views_per_lane(pm_emulated, nine_scene, small_scene, lanes):
     from tests import test_gpu_patchmatch as g
-    g.test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes)    # (4,2), (2,4), (2,2), (4,4): several source views per lane
+    g.test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes)    # (4,2), (4,1), (4,4): several source views per lane
 
 
 @pytest.mark.parametrize("variant", ["quad_pointer"])   # (the default addressing -- the level's quad buffer -- is what every other case of this module runs)
@@ -98,7 +98,7 @@ def test_estimator_narrower_speculation(pm_emulated, nine_scene, small_scene, hy
 
 def test_estimator_mixed_resolution_neighbours_wide_kernel(pm_emulated):
     from tests import test_gpu_patchmatch as g
-    g.test_mixed_resolution_neighbours_parity_both_kernels("16", 80, 60)     # (quarter of the pixels of the device case: the regular-kernel run below has the full size)
+    g.test_mixed_resolution_neighbours_parity_both_kernels(16, 80, 60)     # (quarter of the pixels of the device case: the regular-kernel run below has the full size)
 
 
 def test_estimator_reference_views_of_different_sizes(pm_emulated):

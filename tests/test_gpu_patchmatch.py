@@ -82,85 +82,65 @@ def test_single_view_parity_N8_and_N1(engine, nine_scene):
         _same(d, od, f"depth N={nsrc}"); _same(n, on, f"normal N={nsrc}"); _same(c, oc, f"conf N={nsrc}")
 
 
-@pytest.mark.parametrize("lanes", [4, 2])
+@pytest.mark.parametrize("lanes", [4, 8])
 def test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes):
-    """The sweep kernel's other work decompositions (PMHIP_LANES): 4 or 2 lanes per pixel with 2 or 4 source views per lane instead of one view per
-    lane (16 / 32 pixels per wavefront at 8 sources), and the mappings 8 and 3-4 and 9-16 sources fall to; MINMEAN is order-free, so the maps are
-    the same bits.  Photometric pass over the pyramid and a geometric round."""
-    import os
+    """The sweep kernel's work decompositions (PMHipTuning::sweepLanes): 4 lanes per pixel with 2 or 4 source views per lane (16 pixels per wavefront), or 8 lanes with 1 or 2,
+    instead of one view per lane, and the mappings 8, 3-4 and 9-16 sources fall to; MINMEAN is order-free, so the maps are the same bits.  Photometric pass over the
+    pyramid and a geometric round."""
     from openmvs_amd.patchmatch import PatchMatchHIP
-    saved = os.environ.get("PMHIP_LANES")
-    os.environ["PMHIP_LANES"] = str(lanes)
-    try:
-        e = PatchMatchHIP(0)
-        test_single_view_parity_N8_and_N1(e, nine_scene)                 # 8 sources: (4,2) / (2,4); 1-3 sources: one or two lanes
-        test_single_view_photometric_parity_N4(e, small_scene, 2)        # 4 sources: (4,1) / (2,2)
-        sc = nine_scene
-        p = default_params(seed=5, nEstimationGeometricIters=1)
-        e.Init(False); e.scene_load(sc, n_levels=2)
-        allv = list(range(sc.n_views))
-        e.scene_estimate(allv, -1, p)
-        photo = [e.scene_get_maps(v) for v in allv]
-        e.scene_commit_round(); e.Init(True)
-        e.scene_estimate([4, 0], 0, p)
-        for v in (4, 0):
-            od, on, oc = _oracle(sc, v, 5, nEstimationGeometricIters=1)
-            _same(photo[v][0], od, f"lanes {lanes}: photometric depth v{v}")
-            gd, gn, gc = _oracle(sc, v, 5, geo_iter=0, depth=od, normal=on, src={u: photo[u][0] for u in allv}, nEstimationGeometricIters=1)
-            d, n, c = e.scene_get_maps(v)
-            _same(d, gd, f"lanes {lanes}: geometric depth v{v}"); _same(n, gn, "normal"); _same(c, gc, "conf")
-        if lanes == 4:
-            test_many_source_views_parity(e)                            # 9 .. 16 sources: (4,4)
-        e.close()
-    finally:
-        if saved is None:
-            os.environ.pop("PMHIP_LANES", None)
-        else:
-            os.environ["PMHIP_LANES"] = saved
+    e = PatchMatchHIP(0)
+    e.tuning(wideMaxViews=-1, sweepLanes=lanes)
+    test_single_view_parity_N8_and_N1(e, nine_scene)                 # 8 sources: (4,2) / (8,1); 1-3 sources: a quad of lanes
+    test_single_view_photometric_parity_N4(e, small_scene, 2)        # 4 sources: (4,1)
+    sc = nine_scene
+    p = default_params(seed=5, nEstimationGeometricIters=1)
+    e.Init(False); e.scene_load(sc, n_levels=2)
+    allv = list(range(sc.n_views))
+    e.scene_estimate(allv, -1, p)
+    photo = [e.scene_get_maps(v) for v in allv]
+    e.scene_commit_round(); e.Init(True)
+    e.scene_estimate([4, 0], 0, p)
+    for v in (4, 0):
+        od, on, oc = _oracle(sc, v, 5, nEstimationGeometricIters=1)
+        _same(photo[v][0], od, f"lanes {lanes}: photometric depth v{v}")
+        gd, gn, gc = _oracle(sc, v, 5, geo_iter=0, depth=od, normal=on, src={u: photo[u][0] for u in allv}, nEstimationGeometricIters=1)
+        d, n, c = e.scene_get_maps(v)
+        _same(d, gd, f"lanes {lanes}: geometric depth v{v}"); _same(n, gn, "normal"); _same(c, gc, "conf")
+    test_many_source_views_parity(e)                                 # 9 .. 16 sources: (4,4) / (8,2)
+    e.close()
 
 
 SWEEP_VARIANTS = {
-    # how the sweep kernels' tap rows address the quad images; both must give the oracle's bits
-    "quad_buffer": {"PMHIP_QUADBUF": "1"},      # the default, named: 32-bit entry index into the level's buffer (buffer_load ... idxen, hardware range check)
-    "quad_pointer": {"PMHIP_QUADBUF": "0"},     # through each view's own pointer with clamped coordinates (what a batch with source views of their own image size falls to)
+    # how the sweep kernels' tap rows address the quad images (PMHipTuning::quadBuffer); both must give the oracle's bits
+    "quad_buffer": 1,       # the default, named: 32-bit entry index into the level's buffer (buffer_load ... idxen, hardware range check)
+    "quad_pointer": 2,      # through each view's own pointer with clamped coordinates (what a batch with source views of their own image size falls to)
 }
 
 
 @pytest.mark.parametrize("variant", sorted(SWEEP_VARIANTS))
 def test_sweep_kernel_variants_parity(nine_scene, small_scene, variant, quick=False):
-    """Both addressing modes of the sweep kernel (environment switch read at pmhip_create) against the oracle: 8 / 1 / 2 / 3 sources, the pyramid with 4 sources,
-    and a scene batch with a geometric round."""
-    import os
+    """Both addressing modes of the sweep kernel against the oracle: 8 / 1 / 2 / 3 sources, the pyramid with 4 sources, and a scene batch with a geometric round."""
     from openmvs_amd.patchmatch import PatchMatchHIP
-    env = SWEEP_VARIANTS[variant]
-    saved = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        e = PatchMatchHIP(0)
-        test_single_view_parity_N8_and_N1(e, nine_scene)
-        if not quick:
-            test_single_view_photometric_parity_N4(e, small_scene, 2)
-        sc = nine_scene
-        p = default_params(seed=5, nEstimationGeometricIters=1)
-        e.Init(False); e.scene_load(sc, n_levels=2)
-        allv = list(range(sc.n_views))
-        e.scene_estimate(allv, -1, p)
-        photo = [e.scene_get_maps(v) for v in allv]
-        e.scene_commit_round(); e.Init(True)
-        e.scene_estimate([4, 0], 0, p)
-        for v in (4, 0):
-            od, on, oc = _oracle(sc, v, 5, nEstimationGeometricIters=1)
-            _same(photo[v][0], od, f"{variant}: photometric depth v{v}")
-            gd, gn, gc = _oracle(sc, v, 5, geo_iter=0, depth=od, normal=on, src={u: photo[u][0] for u in allv}, nEstimationGeometricIters=1)
-            d, n, c = e.scene_get_maps(v)
-            _same(d, gd, f"{variant}: geometric depth v{v}"); _same(n, gn, "normal"); _same(c, gc, "conf")
-        e.close()
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    e = PatchMatchHIP(0)
+    e.tuning(wideMaxViews=-1, quadBuffer=SWEEP_VARIANTS[variant])
+    test_single_view_parity_N8_and_N1(e, nine_scene)
+    if not quick:
+        test_single_view_photometric_parity_N4(e, small_scene, 2)
+    sc = nine_scene
+    p = default_params(seed=5, nEstimationGeometricIters=1)
+    e.Init(False); e.scene_load(sc, n_levels=2)
+    allv = list(range(sc.n_views))
+    e.scene_estimate(allv, -1, p)
+    photo = [e.scene_get_maps(v) for v in allv]
+    e.scene_commit_round(); e.Init(True)
+    e.scene_estimate([4, 0], 0, p)
+    for v in (4, 0):
+        od, on, oc = _oracle(sc, v, 5, nEstimationGeometricIters=1)
+        _same(photo[v][0], od, f"{variant}: photometric depth v{v}")
+        gd, gn, gc = _oracle(sc, v, 5, geo_iter=0, depth=od, normal=on, src={u: photo[u][0] for u in allv}, nEstimationGeometricIters=1)
+        d, n, c = e.scene_get_maps(v)
+        _same(d, gd, f"{variant}: geometric depth v{v}"); _same(n, gn, "normal"); _same(c, gc, "conf")
+    e.close()
 
 
 def test_tuning_through_the_abi(nine_scene, views=None):
@@ -177,10 +157,8 @@ def test_tuning_through_the_abi(nine_scene, views=None):
                dict(wideMaxViews=-1, sweepLanes=-1, quadBuffer=1, viewGroups=1),
                # per-launch choice: the short diagonals of a batch with the eight-wide speculative kernel, the middle ones with the two-wide one, the long ones with pm_sweep2
                dict(wideMaxViews=-1, sweepLanes=4, viewGroups=2, widePixels=max(8, int(sc.height * per * 0.45)), wide8Pixels=max(4, int(sc.height * per * 0.12))),
-               # view groups that start out of phase: group g + 1 begins when group g has done 15 % (and, with three groups, 40 %) of its pass
-               dict(wideMaxViews=64, wideHyps=-1, widePixels=-1, wide8Pixels=-1, viewGroups=2, groupOffset=150),
-               dict(wideMaxViews=-1, sweepLanes=4, widePixels=max(8, int(sc.height * per * 0.45)), wide8Pixels=-1, viewGroups=3, groupOffset=400),
-               dict(viewGroups=2, groupOffset=1000), dict(viewGroups=2, groupOffset=-1)):
+               # three view groups, each running its whole pass on its own stream, with the two-wide speculative kernel
+               dict(wideMaxViews=64, wideHyps=-1, widePixels=-1, wide8Pixels=-1, viewGroups=3)):
         got = e.tuning(**kw)
         for k, v in kw.items():
             assert got[k] == v, (k, got)
@@ -194,58 +172,42 @@ def test_tuning_through_the_abi(nine_scene, views=None):
 
 
 def test_wide_latency_mode_parity(nine_scene, small_scene, quick=False, hyps="8"):
-    """The one-wave-per-pixel sweep kernel (PMHIP_WIDE: eight hypotheses of a pixel scored side by side, sequential accept rule replayed over them) gives
-    the bits of the sequential walk: 8 / 4 / 1-3 sources, pyramid, geometric round, ignore masks, option sets that change the iteration budget
-    (nRandomIters 8 and 2: more and fewer than one round holds), low-confidence pixels that take the random-restart stage."""
-    import os
+    """The one-wave-per-pixel sweep kernel (eight hypotheses of a pixel scored side by side, sequential accept rule replayed over them) gives the bits of the sequential walk:
+    8 / 4 / 1-3 sources, pyramid, geometric round, ignore masks, option sets that change the iteration budget (nRandomIters 8 and 2: more and fewer than one round holds),
+    low-confidence pixels that take the random-restart stage.  Chosen through pmhip_set_tuning: wideMaxViews = 16 makes every batch here speculative.
+    hyps: "8" = this test's subject, the eight-wide kernel, for every batch size; "4" / "2" = pm_sweep_widen_kernel; None = the engine's choice by batch size."""
     from openmvs_amd.patchmatch import PatchMatchHIP
-    saved = os.environ.get("PMHIP_WIDE"); saved_h = os.environ.get("PMHIP_WIDE_HYPS")
-    os.environ["PMHIP_WIDE"] = "16"
-    # hyps: "8" = this test's subject, the eight-wide kernel, for every batch size; "4" / "2" = pm_sweep_widen_kernel; None = the engine's choice by batch size
-    if hyps is None:
-        os.environ.pop("PMHIP_WIDE_HYPS", None)
-    else:
-        os.environ["PMHIP_WIDE_HYPS"] = str(hyps)
-    try:
-        e = PatchMatchHIP(0)
-        for k in ((0, 5) if quick else (0, 3, 5)):
-            test_non_default_options_parity(e, small_scene, k)
-        if quick:                                                          # the CPU emulator run: 8 sources with the pyramid, and the option sets above
-            sc = nine_scene
-            ids = [4] + list(sc.neighbors[4])
-            e.Init(False)
-            d, n, c = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[4], sc.dmax[4], params=default_params(seed=5))
-            od, on, oc = _oracle(sc, 4, 5)
-            _same(d, od, "wide: depth N=8"); _same(n, on, "wide: normal"); _same(c, oc, "wide: conf")
-            e.close(); return
-        test_single_view_parity_N8_and_N1(e, nine_scene)
-        test_single_call_with_ignore_mask(e, small_scene)
-        test_single_view_photometric_parity_N4(e, small_scene, 2)
-        test_initial_estimate_is_honoured(e, small_scene)
+    e = PatchMatchHIP(0)
+    e.tuning(wideMaxViews=16, wideHyps=-1 if hyps is None else int(hyps))
+    for k in ((0, 5) if quick else (0, 3, 5)):
+        test_non_default_options_parity(e, small_scene, k)
+    if quick:                                                          # the CPU emulator run: 8 sources with the pyramid, and the option sets above
         sc = nine_scene
-        p = default_params(seed=5, nEstimationGeometricIters=1)
-        e.Init(False); e.scene_load(sc, n_levels=2)
-        allv = list(range(sc.n_views))
-        e.scene_estimate(allv, -1, p)                                     # nine views in one batch, all in latency mode
-        photo = [e.scene_get_maps(v) for v in allv]
-        e.scene_commit_round(); e.Init(True)
-        e.scene_estimate([4, 0], 0, p)
-        for v in (4, 0):
-            od, on, oc = _oracle(sc, v, 5, nEstimationGeometricIters=1)
-            _same(photo[v][0], od, f"wide: photometric depth v{v}"); _same(photo[v][2], oc, f"wide: photometric conf v{v}")
-            gd, gn, gc = _oracle(sc, v, 5, geo_iter=0, depth=od, normal=on, src={u: photo[u][0] for u in allv}, nEstimationGeometricIters=1)
-            d, n, c = e.scene_get_maps(v)
-            _same(d, gd, f"wide: geometric depth v{v}"); _same(n, gn, "normal"); _same(c, gc, "conf")
-        e.close()
-    finally:
-        if saved is None:
-            os.environ.pop("PMHIP_WIDE", None)
-        else:
-            os.environ["PMHIP_WIDE"] = saved
-        if saved_h is None:
-            os.environ.pop("PMHIP_WIDE_HYPS", None)
-        else:
-            os.environ["PMHIP_WIDE_HYPS"] = saved_h
+        ids = [4] + list(sc.neighbors[4])
+        e.Init(False)
+        d, n, c = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[4], sc.dmax[4], params=default_params(seed=5))
+        od, on, oc = _oracle(sc, 4, 5)
+        _same(d, od, "wide: depth N=8"); _same(n, on, "wide: normal"); _same(c, oc, "wide: conf")
+        e.close(); return
+    test_single_view_parity_N8_and_N1(e, nine_scene)
+    test_single_call_with_ignore_mask(e, small_scene)
+    test_single_view_photometric_parity_N4(e, small_scene, 2)
+    test_initial_estimate_is_honoured(e, small_scene)
+    sc = nine_scene
+    p = default_params(seed=5, nEstimationGeometricIters=1)
+    e.Init(False); e.scene_load(sc, n_levels=2)
+    allv = list(range(sc.n_views))
+    e.scene_estimate(allv, -1, p)                                     # nine views in one batch, all in latency mode
+    photo = [e.scene_get_maps(v) for v in allv]
+    e.scene_commit_round(); e.Init(True)
+    e.scene_estimate([4, 0], 0, p)
+    for v in (4, 0):
+        od, on, oc = _oracle(sc, v, 5, nEstimationGeometricIters=1)
+        _same(photo[v][0], od, f"wide: photometric depth v{v}"); _same(photo[v][2], oc, f"wide: photometric conf v{v}")
+        gd, gn, gc = _oracle(sc, v, 5, geo_iter=0, depth=od, normal=on, src={u: photo[u][0] for u in allv}, nEstimationGeometricIters=1)
+        d, n, c = e.scene_get_maps(v)
+        _same(d, gd, f"wide: geometric depth v{v}"); _same(n, gn, "normal"); _same(c, gc, "conf")
+    e.close()
 
 
 def test_non_divisible_image_size_parity(engine):
@@ -711,23 +673,15 @@ def test_real_scene_from_mvs_archive_matches_oracle_and_sfm_points():
     e.close()
 
 
-@pytest.mark.parametrize("wide", ["0", "16"])
+@pytest.mark.parametrize("wide", [0, 16])
 def test_mixed_resolution_neighbours_parity_both_kernels(wide, W=160, H=120):
     """The shipped combination -- one-call boundary, one-wave-per-pixel kernel (the engine's choice for a single depth map), mixed-size sources, geometric
-    round with resized depth maps -- and the regular kernel, each on a fresh engine (PMHIP_WIDE is read at pmhip_create)."""
-    import os
+    round with resized depth maps -- and the regular kernel, each on a fresh engine (wide: PMHipTuning::wideMaxViews, 0 = no speculative kernels)."""
     from openmvs_amd.patchmatch import PatchMatchHIP
-    saved = os.environ.get("PMHIP_WIDE")
-    os.environ["PMHIP_WIDE"] = wide
-    try:
-        e = PatchMatchHIP(0)
-        test_mixed_resolution_neighbours_parity(e, W, H)
-        e.close()
-    finally:
-        if saved is None:
-            os.environ.pop("PMHIP_WIDE", None)
-        else:
-            os.environ["PMHIP_WIDE"] = saved
+    e = PatchMatchHIP(0)
+    e.tuning(wideMaxViews=wide if wide else -1)
+    test_mixed_resolution_neighbours_parity(e, W, H)
+    e.close()
 
 
 def test_mixed_resolution_neighbours_parity(engine, W=160, H=120):
@@ -949,11 +903,11 @@ def test_config2_full_size_matches_golden():
     allv = list(range(c["n_views"]))
     # the scene interface with every sweep kernel a batch can get, chosen through pmhip_set_tuning: pm_sweep2_kernel<4 lanes, 2 views per lane> alone; <8,1> (26-79 views);
     # the engine's own choice for nine views (the two-wide speculative kernel); and the MIX bench.py's timed 100-view batch runs -- <4,2> on the long diagonals and the
-    # two-wide kernel on the short ones of the same sweep, the view groups out of phase (threshold scaled to this batch: 20000 pixels / 50 views per group = 400 pixels of
-    # diagonal, x 4.5 views per group here), with two and with three groups
+    # two-wide kernel on the short ones of the same sweep (threshold scaled to this batch: 20000 pixels / 50 views per group = 400 pixels of diagonal, x 4.5 views per
+    # group here), with two and with three view groups
     for what, tun in (("pm_sweep2_kernel<4,2>", dict(wideMaxViews=-1, sweepLanes=4)), ("pm_sweep2_kernel<8,1>", dict(wideMaxViews=-1, sweepLanes=8)), ("engine default", {}),
-                      ("timed mix, 2 groups", dict(wideMaxViews=-1, sweepLanes=4, widePixels=1800, viewGroups=2, groupOffset=160)),
-                      ("timed mix, 3 groups", dict(wideMaxViews=-1, sweepLanes=4, widePixels=1200, viewGroups=3, groupOffset=330))):
+                      ("timed mix, 2 groups", dict(wideMaxViews=-1, sweepLanes=4, widePixels=1800, viewGroups=2)),
+                      ("timed mix, 3 groups", dict(wideMaxViews=-1, sweepLanes=4, widePixels=1200, viewGroups=3))):
         e = PatchMatchHIP(0); e.Init(True)
         if tun:
             e.tuning(**tun)

@@ -11,7 +11,8 @@ def resources(extra_flags=(), lib="libpmhip.so"):
     """{mangled kernel name: dict(vgpr, agpr, sgpr, scratch, occupancy, lds)} from -Rpass-analysis=kernel-resource-usage."""
     srcs, _ = _b.LIBS[lib]
     with tempfile.TemporaryDirectory() as td:
-        cmd = [_b.HIPCC] + _b.FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + list(extra_flags) + [os.path.join(_b._CSRC, s) for s in srcs] + ["-o", os.path.join(td, "x.so")]
+        # the product's flags, the per-library ones included (-fno-slp-vectorize changes the register allocation of every kernel here)
+        cmd = [_b.HIPCC] + _b.FLAGS + _b.LIB_FLAGS.get(lib, []) + ["-Rpass-analysis=kernel-resource-usage"] + list(extra_flags) + [os.path.join(_b._CSRC, s) for s in srcs] + ["-o", os.path.join(td, "x.so")]
         p = subprocess.run(cmd, cwd=_b._CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True)
     out = {}
     for blk in re.split(r"remark: [^\n]*Function Name: ", p.stderr)[1:]:

@@ -49,7 +49,14 @@ for name, env in configs:
                 e.scene_commit_round(); e.scene_estimate(allv, g, p, sync=False)
             e.sync(); st = e.stats_get(); init_ms = st.initMs
             print("   init kernels %.1f ms per step (%d launches), sweeps wall %.1f ms" % (st.initMs, st.initLaunches, st.sweepWallMs), flush=True)
-        d = e.scene_get_maps(0)[0]
+        if os.environ.get("PROBE_SPLIT"):                      # one more step with a sync after every call: seconds of the photometric pass and of each geometric round
+            for v in allv: e.scene_reset_view(v)
+            e.sync(); parts = []
+            t = time.perf_counter(); e.scene_estimate(allv, -1, p, sync=False); e.sync(); parts.append(time.perf_counter() - t)
+            for g in range(2):
+                e.scene_commit_round(); t = time.perf_counter(); e.scene_estimate(allv, g, p, sync=False); e.sync(); parts.append(time.perf_counter() - t)
+            print("   photometric %.3f s, geometric rounds %.3f / %.3f s" % tuple(parts), flush=True)
+        d = np.stack([e.scene_get_maps(0)[0], e.scene_get_maps(V - 1)[0]])      # the first and the last view of the batch
         if ref is None: ref = d
         print("%-28s %-60s %.3f s/step (host enqueue %.3f s)  %.2f Mpix/s  same-as-first %s" % (name, env, best, enq, V * W * H / best / 1e6, bool(np.array_equal(d, ref))), flush=True)
         e.close()

@@ -263,14 +263,15 @@ def main():
         m = d0 > 0
         rel = np.abs(d0[m] - gt0[m]) / gt0[m]
         sweep_s = st.sweepMs / 1e3          # summed over the streams the launches ran on (== sum of kernel durations)
-        wall_s = st.sweepWallMs / 1e3       # wall time of the sweep phases (view groups overlap)
+        wall_s = st.sweepWallMs / 1e3       # wall time of the passes: hand-offs, init passes, sweeps, finalize of all view groups (which overlap)
         achieved = st.sweepBytes / 1e9 / max(sweep_s, 1e-12)
         device = st.sweepBytes / 1e9 / max(wall_s, 1e-12)
         per_launch = st.sweepBytes / max(1, st.sweepLaunches)
         valu_tf = FLOP_PER_PIXEL * (len(mine) * W * H * a.steps / dt) / 1e12   # this rank's pixels per second x algorithmic flop per pixel
         kern = sweep_kernel_name(B if B else len(mine), N)
-        issue = valu_issue_fields(st.sweepPixels, wall_s) if kern == "pm_sweep2_kernel" else {}
-        tf = traffic_fields(per_launch) if kern == "pm_sweep2_kernel" else {"traffic": None, "traffic_note": "no counter passes of %s yet (the committed ones are of pm_sweep2_kernel)" % kern}
+        same_cfg = world == 1 and V == 100 and (W, H, N) == (1920, 1080, 8) and B == V and a.geo_iters == 2    # the configuration the counters were taken on
+        issue = valu_issue_fields(wall_s, a.steps, st.sweepPixels) if same_cfg else {}
+        tf = traffic_fields(per_launch) if same_cfg else {"traffic": None, "traffic_note": "counters exist for the 100-view 1920x1080 one-GPU configuration only"}
         out = {
             "metric": "Mpix/s depth-map output at 1920x1080 N-view", "value": round(mpix, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2),
@@ -286,7 +287,7 @@ def main():
                          "launches": int(st.sweepLaunches), "avg_launch_us": round(1e3 * st.sweepMs / max(1, st.sweepLaunches), 2),
                          "algorithmic_bytes_per_launch": round(per_launch, 1),
                          "concurrent_streams": round(sweep_s / max(wall_s, 1e-12), 2), "device_achieved": round(device, 2),
-                         "device_frac": round(device / HBM_PEAK_GBS, 6), "sweep_share_of_step": round(wall_s / dt, 4),
+                         "device_frac": round(device / HBM_PEAK_GBS, 6), "passes_share_of_step": round(wall_s / dt, 4),
                          "valu_achieved_tflops": round(valu_tf, 3), "valu_peak_tflops": VALU_PEAK_TFLOPS, "valu_frac": round(valu_tf / VALU_PEAK_TFLOPS, 5),
                          "note": "achieved = algorithmic bytes per launch (SURVEY 8(d) B_sweep / launches) / average launch duration from HIP events on the "
                                  "launching streams (rank 0); the view groups run on separate streams, so the device moves device_achieved; "
@@ -351,62 +352,75 @@ def sweep_kernel_name(n_batch, n_src):
     return "pm_sweep2_kernel"
 
 
-def traffic_fields(algorithmic_bytes_per_launch):
-    """`traffic`: fabric-side bytes (FETCH_SIZE + WRITE_SIZE) of one sweep launch of THIS run = the measured bytes per algorithmic byte of the counter passes x this run's
-    algorithmic bytes per launch (the counter passes use a smaller batch: the ratio is per pixel visit, the launch size is not); null without a valid measurement.
-    `traffic_measurement`: the counter figures as taken."""
-    t = measured_traffic(algorithmic_bytes_per_launch)
-    if t is None:
-        return {"traffic": None}
-    return {"traffic": round(t["over_algorithmic"] * algorithmic_bytes_per_launch), "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, offline counter passes, scaled by algorithmic bytes)",
-            "traffic_measurement": t}
-
-
-def valu_issue_fields(sweep_pixels, sweep_wall_s, px_per_wave=16, simds=1024, clock_hz=2.4e9):
-    """What the sweep kernel actually runs into at this batch size: the share of the SIMDs' cycles during which a VALU instruction of pm_sweep2_kernel<4,2> executes.
-    = (VALU-busy cycles of one wave-visit, SQ_ACTIVE_INST_VALU / SQ_WAVES of the offline counter passes) x (wave-visits of this run = pixel visits / 16 pixels per wave)
-    / (1024 SIMDs x sweep wall time x 2.4 GHz, the clock rocminfo reports; a lower clock under load makes the share larger).  Empty without counters of this tree's kernels."""
+def _counters():
+    """profiles/traffic.json (tools/r05/make_traffic.py): counters taken on the benchmark's own workload -- 100 views, two view groups, full schedule -- through the stand-alone
+    C++ program, because rocprofv3 --pmc cannot run next to this process's timing (separate passes, no trace domains; MI355X_MICROARCH.md).  None when the file is absent or
+    was measured on other kernel sources than this tree's."""
     try:
         import hashlib
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         h = hashlib.sha256()
-        for f in ("pm_kernels.hip", "pm_band.hip", "pm_math.h"):
+        for f in ("pm_kernels.hip", "pm_band.hip", "pm_wide_n.hip", "pm_math.h"):
             h.update(open(os.path.join(ROOT, "openmvs_amd", "csrc", f), "rb").read())
-        sq = t.get("sq", {})
-        if h.hexdigest()[:16] != t.get("kernel_digest") or "frac_active_valu" not in sq:
-            return {}
-        busy = 4.0 * sq["frac_active_valu"] * sq["wave_quadcycles_per_wave"]          # cycles per wave-visit
-        visits = sweep_pixels / float(px_per_wave)
-        return {"valu_issue": {"valu_busy_cycles_per_wave_visit": round(busy), "valu_insts_per_wave_visit": sq["valu_insts_per_wave"], "wave_visits": int(visits),
-                               "valu_busy_frac": round(busy * visits / (simds * clock_hz * max(sweep_wall_s, 1e-12)), 4),
-                               "note": "share of all SIMD cycles of the sweep phases in which a VALU instruction executes (offline SQ counters x this run's wave-visits, 2.4 GHz): "
-                                       "the bound this kernel actually approaches at this batch size is the issue of the reference's un-fusable fp32 arithmetic, not HBM.  Every pixel visit is "
-                                       "counted as pm_sweep2_kernel<4,2>'s (16 pixels per wave); the short diagonals that run the two-wide speculative kernel make the true share larger"}}
-    except Exception:
-        return {}
-
-
-def measured_traffic(algorithmic_bytes_per_launch):
-    """HBM-side bytes per sweep launch from rocprofv3's FETCH_SIZE + WRITE_SIZE counters (L2 <-> fabric requests).  They need their own profiler
-    passes (MI355X_MICROARCH.md: no trace domains next to --pmc), so bench.py cannot collect them live: the figure is an OFFLINE measurement, the
-    committed profiles/traffic.json written by tools/pmc/make_traffic.py from tools/pmc/run_pmc.sh's passes over the stand-alone C++ workload.  The file
-    names the kernel sources it was measured on (sha-256 prefix); when the tree's kernels differ, or the file is absent, the field is null."""
-    try:
-        import hashlib
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        h = hashlib.sha256()
-        for f in ("pm_kernels.hip", "pm_band.hip", "pm_math.h"):   # the measured kernel (pm_sweep2_kernel, pm_band.hip) and every device function it uses; not the host engine
-            h.update(open(os.path.join(ROOT, "openmvs_amd", "csrc", f), "rb").read())
-        if h.hexdigest()[:16] != t.get("kernel_digest"):
-            return None
-        # MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane loads -- this kernel's tap loads -- so the fetch figure is doubled
-        corrected = t.get("bytes_per_launch_fetch_doubled", 2 * t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"])
-        return {"bytes_per_launch": corrected, "fetch_bytes_per_launch_raw": t["fetch_bytes_per_launch"], "write_bytes_per_launch": t["write_bytes_per_launch"],
-                "correction": "FETCH_SIZE x 2 (16-byte-per-lane loads on gfx950, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
-                "over_algorithmic": round(corrected / max(1.0, t.get("algorithmic_bytes_per_launch", algorithmic_bytes_per_launch)), 2),
-                "measured": "offline", "kernel_digest": t["kernel_digest"], "source": t.get("source", "profiles/traffic.json")}
+        return t if h.hexdigest()[:16] == t.get("kernel_digest") and "sweeps" in t else None
     except Exception:
         return None
+
+
+def _counters_round4():
+    """The committed counter file of round 4 (24-view, one-stream C++ workload, round 4's kernels), when profiles/traffic.json still is that one: reported as what it is."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return t if "bytes_per_launch_fetch_doubled" in t and "sweeps" not in t else None
+    except Exception:
+        return None
+
+
+def traffic_fields(algorithmic_bytes_per_launch):
+    """`traffic`: fabric-side bytes (FETCH_SIZE x 2 + WRITE_SIZE) per sweep launch, measured OFFLINE on this benchmark's own configuration (same scene size, batch, groups,
+    kernels: the launches are the same ones); null without counters of this tree's kernels."""
+    t = _counters()
+    if t is None:
+        o = _counters_round4()
+        if o is None:
+            return {"traffic": None, "traffic_note": "no counter passes of this tree's kernels (profiles/traffic.json absent or measured on other sources)"}
+        ratio = o["bytes_per_launch_fetch_doubled"] / max(1.0, o["algorithmic_bytes_per_launch"])
+        return {"traffic": round(ratio * algorithmic_bytes_per_launch), "traffic_unit": "bytes per sweep launch (FETCH_SIZE x 2 + WRITE_SIZE per algorithmic byte of the counter passes x this run's algorithmic bytes per launch)",
+                "traffic_measurement": {"over_algorithmic": round(ratio, 2), "measured": "offline, ROUND 4: 24-view one-stream C++ workload on round 4's pm_sweep2_kernel<4,2> (kernel digest %s); this tree's sweep "
+                                        "kernels differ from those in the guarded redo path and the reference-patch indexing only.  The round-5 attempt to take the counters on the benchmark's own "
+                                        "100-view workload did not finish: every rocprofv3 --pmc pass ran into its 400 s limit (43 126 dispatches at ~9 ms each under counter collection; "
+                                        "profiles/r05_call5_pmc_fetch_timeout.err)" % o.get("kernel_digest"), "source": o.get("source")}}
+    sw = t["sweeps"]
+    return {"traffic": sw["fabric_bytes_per_launch"], "traffic_unit": "bytes per sweep launch (FETCH_SIZE x 2 + WRITE_SIZE; offline counter passes on this configuration)",
+            "traffic_measurement": {"over_algorithmic": sw["over_algorithmic"], "fetch_bytes_per_launch_raw": sw["fetch_bytes_per_launch_raw"], "write_bytes_per_launch": sw["write_bytes_per_launch"],
+                                    "fabric_rate_gbs_at_timed_config": sw["fabric_rate_gbs_at_timed_config"], "correction": sw["correction"], "dispatches": sw["dispatches"],
+                                    "per_kernel": {k: {q: v[q] for q in ("dispatches", "fabric_bytes_per_launch") if q in v} for k, v in t.get("families", {}).items()},
+                                    "measured": "offline", "kernel_digest": t["kernel_digest"], "source": t["source"]}}
+
+
+def valu_issue_fields(sweep_wall_s, steps, sweep_pixels=0, simds=1024, clock_hz=2.4e9):
+    """What the sweep kernels actually run into: the share of the SIMDs' cycles during THIS run's passes in which a VALU instruction of a sweep kernel executes
+    = SQ_ACTIVE_INST_VALU summed over every sweep launch of one step (offline counters on this configuration, all kernel families) / (1024 SIMDs x 2.4 GHz x this run's wall
+    time of the passes per step).  Empty without counters of this tree's kernels."""
+    t = _counters()
+    if t is None or "valu" not in t:
+        o = _counters_round4()
+        sq = (o or {}).get("sq", {})
+        if "frac_active_valu" not in sq or not sweep_pixels:
+            return {}
+        busy = 4.0 * sq["frac_active_valu"] * sq["wave_quadcycles_per_wave"]          # cycles per wave-visit of pm_sweep2_kernel<4,2>
+        visits = sweep_pixels / 16.0
+        return {"valu_issue": {"valu_busy_frac": round(busy * visits / (simds * clock_hz * max(sweep_wall_s, 1e-12)), 4), "valu_insts_per_wave_visit": sq["valu_insts_per_wave"],
+                               "note": "EXTRAPOLATION from round 4's counters (24-view one-stream workload, round 4's pm_sweep2_kernel<4,2>): VALU-busy cycles of one wave-visit x this run's "
+                                       "pixel visits / 16 pixels per wave / (1024 SIMDs x 2.4 GHz x wall time of the passes); every visit is priced as <4,2>'s although the short launches run the "
+                                       "two-wide kernel.  The counters on the benchmark's own workload that round 5 set out to take did not finish inside their time limits "
+                                       "(profiles/r05_call5_pmc_fetch_timeout.err)"}}
+    v = t["valu"]
+    return {"valu_issue": {"valu_active_cycles_per_step": v["valu_active_cycles_per_step"], "wave_visits_per_step": v["wave_visits_per_step"], "valu_insts_per_wave_visit": v["valu_insts_per_wave_visit"],
+                           "valu_busy_frac": round(v["valu_active_cycles_per_step"] * steps / (simds * clock_hz * max(sweep_wall_s, 1e-12)), 4),
+                           "per_kernel": {k: {q: f[q] for q in ("frac_active_valu", "frac_wait_inst_any", "valu_insts_per_wave", "waves_per_launch") if q in f} for k, f in t.get("families", {}).items()},
+                           "note": "share of all SIMD cycles of the passes in which a VALU instruction of a sweep kernel executes (SQ counters of every sweep launch of one step of this "
+                                   "configuration, offline; wall time of this run; 2.4 GHz): the bound the kernels approach is the issue of the reference's un-fusable fp32 arithmetic, not HBM"}}
 
 
 def usable_cores() -> int:

@@ -40,9 +40,9 @@ int main(int argc, char** argv) {
 	CK(pmhip_sync(e));
 	const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	PMHipKernelStats st; memset(&st, 0, sizeof(st)); CK(pmhip_stats_get(e, &st));
-	printf("{\"views\": %d, \"w\": %d, \"h\": %d, \"geo_iters\": %d, \"seconds\": %.3f, \"sweep_launches\": %llu, \"avg_launch_us\": %.2f, \"algorithmic_bytes_per_launch\": %.1f, \"mpix_s\": %.3f}\n",
+	printf("{\"views\": %d, \"w\": %d, \"h\": %d, \"geo_iters\": %d, \"seconds\": %.3f, \"sweep_launches\": %llu, \"avg_launch_us\": %.2f, \"algorithmic_bytes_per_launch\": %.1f, \"mpix_s\": %.3f, \"sweep_wall_s\": %.4f}\n",
 		n, w, h, geo, dt, (unsigned long long)st.sweepLaunches, 1e3 * st.sweepMs / (double)(st.sweepLaunches ? st.sweepLaunches : 1),
-		st.sweepBytes / (double)(st.sweepLaunches ? st.sweepLaunches : 1), (double)n * P / dt * 1e-6);
+		st.sweepBytes / (double)(st.sweepLaunches ? st.sweepLaunches : 1), (double)n * P / dt * 1e-6, st.sweepWallMs * 1e-3);
 	pmhip_destroy(e);
 	return 0;
 }

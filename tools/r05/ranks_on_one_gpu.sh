@@ -6,11 +6,11 @@ set -u
 OUT=gpurun_out/r05_ranks_on_one_gpu; mkdir -p "$OUT"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 OPENMVS_AMD_BENCH_DIGESTS=1
 ARGS="--views 12 --width 640 --height 360 --steps 1 --warmup 0 --no-extras --no-cpu-baseline"
-timeout 600 python bench.py --gpus 1 $ARGS > "$OUT/one_rank.json" 2> "$OUT/one_rank.err"; echo "1 rank rc $?"
+timeout 120 python bench.py --gpus 1 $ARGS > "$OUT/one_rank.json" 2> "$OUT/one_rank.err"; echo "1 rank rc $?"
 for n in 2 3; do
   # 2 ranks: one broadcast of the image set; 3 ranks: --images needed (rank 0 sends every rank only the views it holds)
   EXTRA=""; [ $n = 3 ] && EXTRA="--images needed"
-  OPENMVS_AMD_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29540 + n)) bench.py --gpus $n $ARGS $EXTRA > "$OUT/${n}_ranks.json" 2> "$OUT/${n}_ranks.err"; echo "$n ranks rc $?"
+  OPENMVS_AMD_DIST_BACKEND=gloo timeout 150 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29540 + n)) bench.py --gpus $n $ARGS $EXTRA > "$OUT/${n}_ranks.json" 2> "$OUT/${n}_ranks.err"; echo "$n ranks rc $?"
 done
 python - <<'PY'
 import json

@@ -272,6 +272,8 @@ def main():
         same_cfg = world == 1 and V == 100 and (W, H, N) == (1920, 1080, 8) and B == V and a.geo_iters == 2    # the configuration the counters were taken on
         issue = valu_issue_fields(wall_s, a.steps, st.sweepPixels) if same_cfg else {}
         tf = traffic_fields(per_launch) if same_cfg else {"traffic": None, "traffic_note": "counters exist for the 100-view 1920x1080 one-GPU configuration only"}
+        if "fabric_bytes_per_step" in tf.get("traffic_measurement", {}):   # the fabric-side rate of THIS run: counter bytes of a step / this run's wall time of the passes per step
+            tf["traffic_measurement"]["fabric_rate_gbs_this_run"] = round(tf["traffic_measurement"]["fabric_bytes_per_step"] * a.steps / 1e9 / max(wall_s, 1e-12), 1)
         out = {
             "metric": "Mpix/s depth-map output at 1920x1080 N-view", "value": round(mpix, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2),
@@ -393,9 +395,9 @@ def traffic_fields(algorithmic_bytes_per_launch):
     sw = t["sweeps"]
     return {"traffic": sw["fabric_bytes_per_launch"], "traffic_unit": "bytes per sweep launch (FETCH_SIZE x 2 + WRITE_SIZE; offline counter passes on this configuration)",
             "traffic_measurement": {"over_algorithmic": sw["over_algorithmic"], "fetch_bytes_per_launch_raw": sw["fetch_bytes_per_launch_raw"], "write_bytes_per_launch": sw["write_bytes_per_launch"],
-                                    "fabric_rate_gbs_at_timed_config": sw["fabric_rate_gbs_at_timed_config"], "correction": sw["correction"], "dispatches": sw["dispatches"],
+                                    "fabric_bytes_per_step": sw["fabric_bytes_per_step"], "correction": sw["correction"], "dispatches": sw["dispatches"],
                                     "per_kernel": {k: {q: v[q] for q in ("dispatches", "fabric_bytes_per_launch") if q in v} for k, v in t.get("families", {}).items()},
-                                    "measured": "offline", "kernel_digest": t["kernel_digest"], "source": t["source"]}}
+                                    "measured": "offline", "kernel_digest": t["kernel_digest"], "source": t["source"], **({"notes": t["notes"]} if "notes" in t else {})}}
 
 
 def valu_issue_fields(sweep_wall_s, steps, sweep_pixels=0, simds=1024, clock_hz=2.4e9):
@@ -405,7 +407,7 @@ def valu_issue_fields(sweep_wall_s, steps, sweep_pixels=0, simds=1024, clock_hz=
     t = _counters()
     if t is None or "valu" not in t:
         o = _counters_round4()
-        sq = (o or {}).get("sq", {})
+        sq = (t or {}).get("sq_round4") or (o or {}).get("sq", {})
         if "frac_active_valu" not in sq or not sweep_pixels:
             return {}
         busy = 4.0 * sq["frac_active_valu"] * sq["wave_quadcycles_per_wave"]          # cycles per wave-visit of pm_sweep2_kernel<4,2>
@@ -413,8 +415,8 @@ def valu_issue_fields(sweep_wall_s, steps, sweep_pixels=0, simds=1024, clock_hz=
         return {"valu_issue": {"valu_busy_frac": round(busy * visits / (simds * clock_hz * max(sweep_wall_s, 1e-12)), 4), "valu_insts_per_wave_visit": sq["valu_insts_per_wave"],
                                "note": "EXTRAPOLATION from round 4's counters (24-view one-stream workload, round 4's pm_sweep2_kernel<4,2>): VALU-busy cycles of one wave-visit x this run's "
                                        "pixel visits / 16 pixels per wave / (1024 SIMDs x 2.4 GHz x wall time of the passes); every visit is priced as <4,2>'s although the short launches run the "
-                                       "two-wide kernel.  The counters on the benchmark's own workload that round 5 set out to take did not finish inside their time limits "
-                                       "(profiles/r05_call5_pmc_fetch_timeout.err)"}}
+                                       "two-wide kernel.  Round 5 took FETCH_SIZE on the benchmark's own workload (roofline.traffic); its SQ passes hung "
+                                       "(rocprofv3 --pmc at start-up, profiles/r05_call6_pmc/run.log)"}}
     v = t["valu"]
     return {"valu_issue": {"valu_active_cycles_per_step": v["valu_active_cycles_per_step"], "wave_visits_per_step": v["wave_visits_per_step"], "valu_insts_per_wave_visit": v["valu_insts_per_wave_visit"],
                            "valu_busy_frac": round(v["valu_active_cycles_per_step"] * steps / (simds * clock_hz * max(sweep_wall_s, 1e-12)), 4),

@@ -77,16 +77,70 @@ class SceneViews:
         return len(self.gray)
 
 
+def _area_tab(ssize: int, dsize: int):
+    """OpenCV's computeResizeAreaTab (imgproc/src/resize.cpp) for one axis: for every destination cell the source cells it covers and their float weights, in order.
+    Returns (di, si, alpha) arrays; scale = ssize / dsize in double, the partial cells at both ends weighted by their covered fraction of the cell width."""
+    import math
+    import numpy as np
+    scale = ssize / dsize
+    di, si, al = [], [], []
+    for dx in range(dsize):
+        fsx1 = dx * scale
+        fsx2 = fsx1 + scale
+        cell = min(scale, ssize - fsx1)
+        sx1, sx2 = math.ceil(fsx1), math.floor(fsx2)
+        sx2 = min(sx2, ssize - 1)
+        sx1 = min(sx1, sx2)
+        if sx1 - fsx1 > 1e-3:
+            di.append(dx); si.append(sx1 - 1); al.append(np.float32((sx1 - fsx1) / cell))
+        for sx in range(sx1, sx2):
+            di.append(dx); si.append(sx); al.append(np.float32(1.0 / cell))
+        if fsx2 - sx2 > 1e-3:
+            di.append(dx); si.append(sx2); al.append(np.float32(min(min(fsx2 - sx2, 1.0), cell) / cell))
+    return np.asarray(di, np.int64), np.asarray(si, np.int64), np.asarray(al, np.float32)
+
+
+def _accumulate_in_order(dst_n, di, vals):
+    """out[di[k]] += vals[k] in k order, in float32 (entries of one destination cell are consecutive: the j-th entries of all cells are added together, j = 0, 1, ...)."""
+    import numpy as np
+    out = np.zeros((dst_n,) + vals.shape[1:], np.float32)
+    first = np.r_[True, di[1:] != di[:-1]]
+    start = np.maximum.accumulate(np.where(first, np.arange(len(di)), 0))
+    rank = np.arange(len(di)) - start
+    for j in range(int(rank.max()) + 1 if len(di) else 0):
+        m = rank == j
+        out[di[m]] = out[di[m]] + vals[m]
+    return out
+
+
 def _resize_area_u8(img, w: int, h: int):
-    """cv::resize(..., INTER_AREA) of an 8-bit image for an exact integer shrink factor (the only case implemented): the box mean,
-    rounded to nearest-even like OpenCV's `saturate_cast<uchar>(float)`."""
+    """cv::resize(img, Size(w, h), 0, 0, INTER_AREA) of an 8-bit image that shrinks on both axes (Image::ResizeImage, libs/MVS/Image.cpp:139-155, reached by
+    --max-resolution / nResolutionLevel).  Exact integer factors: OpenCV's integer path, the box mean rounded to nearest-even.  Any other factor: its general area path
+    (computeResizeAreaTab + ResizeArea_Invoker, imgproc/src/resize.cpp, restated here -- OpenCV is not vendored with the reference, so this is unpinned): per source
+    row the x cells weighted in float and accumulated in table order, the rows then weighted and accumulated in float per destination row, saturate_cast<uchar> = round to
+    nearest-even."""
     import numpy as np
     H, W = img.shape[:2]
-    if W % w or H % h or W // w != H // h:
-        raise NotImplementedError("image resize %dx%d -> %dx%d: only exact integer INTER_AREA factors are implemented" % (W, H, w, h))
-    f = W // w
-    s = img.reshape(h, f, w, f, -1).astype(np.float32).sum(axis=(1, 3))
-    return np.rint(s * np.float32(1.0 / (f * f))).astype(np.uint8)
+    if w > W or h > H:
+        raise NotImplementedError("image resize %dx%d -> %dx%d: INTER_AREA is implemented for shrinking only (OpenCV enlarges with the bilinear path)" % (W, H, w, h))
+    if W % w == 0 and H % h == 0 and W // w == H // h:
+        f = W // w
+        s = img.reshape(h, f, w, f, -1).astype(np.float32).sum(axis=(1, 3))
+        out = np.rint(s * np.float32(1.0 / (f * f))).astype(np.uint8)
+        return out if img.ndim == 3 else out[..., 0]
+    src = img.reshape(H, W, -1).astype(np.float32)
+    xdi, xsi, xal = _area_tab(W, w)
+    ydi, ysi, yal = _area_tab(H, h)
+    # every source row that takes part: buf[dx] = sum over its x cells, in table order
+    rows = np.unique(ysi)
+    buf = {}
+    for sy in rows:
+        buf[int(sy)] = _accumulate_in_order(w, xdi, src[sy][xsi] * xal[:, None])
+    # destination rows: sum[dx] = beta_0 * buf_0, then += beta_k * buf_k in table order
+    vals = np.stack([yal[k] * buf[int(ysi[k])] for k in range(len(ydi))])
+    out = _accumulate_in_order(h, ydi, vals)
+    out = np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    return out if img.ndim == 3 else out[..., 0]
 
 
 def load_scene(mvs_path: str, opt=None, image_loader=None):

@@ -147,7 +147,38 @@ def test_resolution_rules():
     half = densify._resize_area_u8(img, 6, 4)
     assert half.shape == (4, 6, 3) and half[0, 0, 0] == np.rint(img[:2, :2, 0].astype(np.float32).mean())
     with pytest.raises(NotImplementedError):
-        densify._resize_area_u8(img, 5, 4)
+        densify._resize_area_u8(img, 13, 4)                                          # enlarging is OpenCV's bilinear path: not restated
+
+
+def test_area_resize_by_a_non_integer_factor():
+    """cv::resize(INTER_AREA) for a factor that is not an integer (Image::ResizeImage under --max-resolution, libs/MVS/Image.cpp:139-155): densify's vectorised restatement of
+    OpenCV's general area path against a literal per-pixel walk of the same published algorithm (computeResizeAreaTab + ResizeArea_Invoker: x cells per source row in table
+    order, then the rows per destination row, everything in float), plus what any area resize must do.  OpenCV itself is not vendored with the reference: unpinned."""
+    r = np.random.RandomState(3)
+    img = r.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    w, h = 20, 14
+    out = densify._resize_area_u8(img, w, h)
+    xd, xs, xa = densify._area_tab(53, w); yd, ys, ya = densify._area_tab(37, h)
+    assert abs(float(xa[xd == 0].sum()) - 1) < 1e-6 and abs(float(ya[yd == h - 1].sum()) - 1) < 1e-6      # a cell's weights sum to one
+    ref = np.zeros((h, w, 3), np.uint8)
+    acc = np.zeros((w, 3), np.float32); prev = yd[0]
+    for j in range(len(yd)):
+        buf = np.zeros((w, 3), np.float32)
+        S = img[ys[j]].astype(np.float32)
+        for k in range(len(xd)):
+            buf[xd[k]] = buf[xd[k]] + S[xs[k]] * xa[k]
+        if yd[j] != prev:
+            ref[prev] = np.clip(np.rint(acc), 0, 255).astype(np.uint8); acc = ya[j] * buf; prev = yd[j]
+        else:
+            acc = acc + ya[j] * buf
+    ref[prev] = np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+    assert np.array_equal(out, ref)
+    assert np.unique(densify._resize_area_u8(np.full((40, 64, 3), 77, np.uint8), 25, 17)).tolist() == [77]   # a constant image stays constant
+    assert abs(float(out.mean()) - float(img.mean())) < 0.5                                                  # the mean survives
+    g = densify._resize_area_u8(img[..., 0].copy(), w, h)
+    assert g.shape == (h, w) and np.array_equal(g, out[..., 0])                                              # single-channel images too
+    # the size rule that leads here: a 4000x3000 image under --max-resolution 3200 becomes 3200x2400 (factor 1.25)
+    assert views.resized_size(4000, 3000, 3200) == (3200, 2400)
 
 
 def test_to_gray_is_the_bgr_weighted_sum():

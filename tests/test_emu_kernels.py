@@ -113,6 +113,25 @@ def test_estimator_mixed_resolution_neighbours(engine):
     g.test_mixed_resolution_neighbours_parity(engine)                        # sources at 0.8x / 1.25x, cameraDepthMap of another size
 
 
+def test_estimator_portrait_image(engine, W=30, H=76):
+    """An image more than twice as tall as wide: the folded anti-diagonal-major reference image (PMTask::refS, texel (u,v) at ((u+v) mod w)*h + v) wraps its rows more than
+    once there (anti-diagonals d, d + w and d + 2w share a row), and the sweeps' diagonals are long in y.  Photometric pass over two levels, through the one-call boundary.
+    (Written after the round's last device run: it lives here, in the emulator suite, and joins the gpu suite once it has been seen green on a device.)"""
+    import numpy as np
+    from openmvs_amd import synth
+    from openmvs_amd.patchmatch import default_params
+    from tests import test_gpu_patchmatch as g
+    sc = synth.make_scene(4, W, H, n_src=3)
+    engine.Init(False)
+    p = default_params(seed=6, nSubResolutionLevels=1)
+    for ref in (0, 2):
+        ids = [ref] + list(sc.neighbors[ref])
+        d, n, c = engine.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[ref], sc.dmax[ref], params=p)
+        od, on, oc = g._oracle(sc, ref, 6, nSubResolutionLevels=1)
+        g._same(d, od, "portrait depth v%d" % ref); g._same(n, on, "normal"); g._same(c, oc, "conf")
+    assert (d > 0).mean() > 0.3
+
+
 def test_estimator_odd_sizes(engine):
     from tests import test_gpu_patchmatch as g
     g.test_non_divisible_image_size_parity(engine)

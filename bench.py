@@ -274,6 +274,7 @@ def main():
         tf = traffic_fields(per_launch) if same_cfg else {"traffic": None, "traffic_note": "counters exist for the 100-view 1920x1080 one-GPU configuration only"}
         if "fabric_bytes_per_step" in tf.get("traffic_measurement", {}):   # the fabric-side rate of THIS run: counter bytes of a step / this run's wall time of the passes per step
             tf["traffic_measurement"]["fabric_rate_gbs_this_run"] = round(tf["traffic_measurement"]["fabric_bytes_per_step"] * a.steps / 1e9 / max(wall_s, 1e-12), 1)
+            tf["traffic_measurement"]["fabric_rate_frac_of_hbm_peak"] = round(tf["traffic_measurement"]["fabric_rate_gbs_this_run"] / HBM_PEAK_GBS, 4)   # (Infinity-Cache hits are in the counter: an upper bound on HBM traffic)
         out = {
             "metric": "Mpix/s depth-map output at 1920x1080 N-view", "value": round(mpix, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2),

@@ -48,6 +48,20 @@ int mvsf_select_views(const mvsf_scene* s, int idx, const int* sizes, const MVSF
 /* The unfiltered list of Scene::SelectNeighborViews (all candidates, sorted), for inspection / tests. */
 int mvsf_select_neighbor_views(const mvsf_scene* s, int idx, const int* sizes, uint32_t nMinViews, uint32_t nMinPointViews, float fOptimAngleDeg, uint32_t nInsideROI,
                                MVSFViewScore* neighbors, int cap, int* nNeighbors, uint32_t* points, int pointsCap, int* nPoints, float* avgDepth);
+/* Neighbour lists the scene already carries.  An archive of version > 6 stores every image's view scores (MVS::Interface::Image::viewScores, libs/MVS/Interface.h:527-577;
+ * Scene::LoadInterface copies them into Image::neighbors, libs/MVS/Scene.cpp:158), and `--view-neighbors-file` replaces them (Scene::LoadViewNeighbors, Scene.cpp:413-457:
+ * one line per image, "<id> <neighbour-0> <neighbour-1> ...", best first; every listed neighbour becomes ViewScore{ID, 0 points, scale 1, angle 15 deg, area 0.5, score 3}).
+ * DepthMapsData::SelectViews takes such a list as it is instead of scoring the views again (libs/MVS/SceneDensify.cpp:278-281) -- mvsf_select_views does the same; the image
+ * then has no seed points, so InitViews starts its depth map from random values in [0.1, 100] (:418-427; mvsf_init_depth_map with nPoints = 0).
+ * mvsf_load_view_neighbors: -2 = unreadable file or an image ID outside the scene (the reference asserts); lines starting with '#' and lines with fewer than two
+ * numbers are skipped as there.  mvsf_save_view_neighbors writes Scene::SaveViewNeighbors' format (Scene.cpp:458-480): every image, "<id> <n0> <n1> ...\n". */
+int mvsf_get_neighbors(const mvsf_scene* s, int idx, MVSFViewScore* neighbors, int cap, int* nNeighbors);
+int mvsf_set_neighbors(mvsf_scene* s, int idx, const MVSFViewScore* neighbors, int nNeighbors);
+int mvsf_load_view_neighbors(mvsf_scene* s, const char* path);
+int mvsf_save_view_neighbors(const mvsf_scene* s, const char* path);
+/* depth statistics an archive of version > 6 stores with the image (Interface.h:551-553; avgDepth is what the SGM path's corner support points use) */
+int mvsf_image_depths(const mvsf_scene* s, int idx, float* minDepth, float* avgDepth, float* maxDepth);
+
 /* Depth range [dMin, dMax] and seed maps (w*h depth, w*h*3 normal, zero where unknown) of image idx from `points`:
  * nMinViewsTrustPoint < 2: 5x5 splats with zero normals; else 2x2 splats with the area-weighted vertex normals of the Delaunay mesh of the
  * projections.  No points: dMin 0.1, dMax 100, empty maps. */

@@ -31,7 +31,7 @@ LIBS = {
 LIB_FLAGS = {"libsgmhip.so": ["-fno-slp-vectorize"], "libpmhip.so": ["-fno-slp-vectorize"]}
 
 HOST_LIBS = {"libdmapio.so": (["dmap_io.cpp"], ["../../include/dmapio.h"]),          # plain C++ (g++), no GPU code
-             "libmvsfront.so": (["mvs_front.cpp"], ["../../include/mvsfront.h"])}
+             "libmvsfront.so": (["mvs_front.cpp", "opt_dense.cpp"], ["sml_text.h", "../../include/mvsfront.h", "../../include/optdense.h", "../../include/pmhip.h"])}
 
 
 def build_host_lib(name: str, force: bool = False) -> str | None:

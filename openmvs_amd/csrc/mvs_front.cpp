@@ -2,6 +2,7 @@
 // written against the reference's sources (file:line in the header) so that a host without OpenMVS can drive the engine from a scene.mvs.
 // Mixed precision follows the reference term by term: cameras in double, the view scores in float with the reference's loop order.
 #include "../../include/mvsfront.h"
+#include "sml_text.h"
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -17,7 +18,10 @@ const uint32_t NO_ID = 0xFFFFFFFFu;
 
 struct Cam { std::string name, band; uint32_t w = 0, h = 0; double K[9], R[9], C[3]; };
 struct Platform { std::string name; std::vector<Cam> cams; std::vector<double> poses; /* 12 doubles each: R[9], C[3] */ };
-struct Image { std::string name, mask; uint32_t platform = NO_ID, camera = NO_ID, pose = NO_ID, id = NO_ID; };
+struct Image { std::string name, mask; uint32_t platform = NO_ID, camera = NO_ID, pose = NO_ID, id = NO_ID;
+	float minDepth = 0, avgDepth = 0, maxDepth = 0;   // stored by archives of version > 6 (Interface.h:551-553)
+	std::vector<MVSFViewScore> neighbors;             // Image::neighbors: the archive's view scores (Scene.cpp:158) or a view-neighbours file (Scene.cpp:413-457)
+};
 }
 
 struct mvsf_scene {
@@ -301,7 +305,13 @@ static int loadScene(const char* path, mvsf_scene** out) {
 		if (v > 4) im.mask = r.str();
 		im.platform = r.u32(); im.camera = r.u32(); im.pose = r.u32();
 		if (v > 2) im.id = r.u32();
-		if (v > 6) { r.skip(12); const uint64_t ns = r.u64(); r.skipn(ns, 24); }
+		if (v > 6) {
+			float d[3] = {0, 0, 0}; r.take(d, 12); im.minDepth = d[0]; im.avgDepth = d[1]; im.maxDepth = d[2];
+			const uint64_t ns = r.u64();
+			if (!r.ok || ns > (r.n - r.o) / sizeof(MVSFViewScore)) { r.ok = false; break; }
+			im.neighbors.resize((size_t)ns);
+			if (ns) r.take(im.neighbors.data(), (size_t)ns * sizeof(MVSFViewScore));
+		}
 		s->images.push_back(im);
 	}
 	const uint64_t nV = r.ok ? r.u64() : 0;
@@ -326,6 +336,7 @@ static int loadScene(const char* path, mvsf_scene** out) {
 		const uint64_t a = r.u64(); r.skipn(a, 12); const uint64_t b = r.u64(); r.skipn(b, 3);
 		if (v > 1) { r.skip(128); if (v > 5) { r.take(s->obbRot, 72); r.take(s->obbMin, 24); r.take(s->obbMax, 24); } }
 	}
+	for (const Image& im : s->images) for (const MVSFViewScore& n : im.neighbors) if (n.ID >= s->images.size()) r.ok = false;   // a view score names an image of this scene
 	// an image that names a platform / camera / pose the archive does not hold is uncalibrated (pixelCamera checks the ranges again); one
 	// whose platform index is not even NO_ID-or-valid is a corrupt file
 	for (const Image& im : s->images)
@@ -384,7 +395,9 @@ int mvsf_select_views(const mvsf_scene* s, int idx, const int* sizes, const MVSF
 	if (!camerasFor(*s, sizes, cams, nCal) || !cams[idx].valid) return -3;
 	std::vector<MVSFViewScore> nb; std::vector<uint32_t> pts; float avg = 0;
 	const float d2r = 3.14159265358979323846f / 180.f;
-	if (!selectNeighborViews(*s, cams, nCal, (uint32_t)idx, o->nMinViews, o->nMinViewsTrustPoint > 1 ? o->nMinViewsTrustPoint : 2, o->fOptimAngle * d2r, o->nPointInsideROI, nb, pts, avg)) return -3;
+	// DepthMapsData::SelectViews, SceneDensify.cpp:278-281: a list the scene already carries is taken as it is (no seed points then)
+	if (!s->images[idx].neighbors.empty()) { nb = s->images[idx].neighbors; avg = s->images[idx].avgDepth; }
+	else if (!selectNeighborViews(*s, cams, nCal, (uint32_t)idx, o->nMinViews, o->nMinViewsTrustPoint > 1 ? o->nMinViewsTrustPoint : 2, o->fOptimAngle * d2r, o->nPointInsideROI, nb, pts, avg)) return -3;
 	filterNeighborViews(nb, o->fMinArea, 0.2f, 3.2f, o->fMinAngle * d2r, o->fMaxAngle * d2r, o->nMaxViews);   // DepthMapsData::SelectViews, SceneDensify.cpp:283-292
 	if (nb.empty()) return -3;
 	const float fMinScore = std::max(nb[0].score * o->fViewMinScoreRatio, o->fViewMinScore);                   // InitViews, SceneDensify.cpp:333-340
@@ -601,6 +614,78 @@ int mvsf_triangulate_depth_map(const mvsf_scene* s, int idx, int w, int h, const
 int mvsf_init_depth_map_dense(const mvsf_scene* s, int idx, int w, int h, const uint32_t* points, int nPoints,
 		float* depthMap, float* normalMap, float* dMin, float* dMax) {
 	return initDepthMap(s, idx, w, h, points, nPoints, 2, true, depthMap, normalMap, dMin, dMax);
+}
+
+// ---- neighbour lists the scene carries (include/mvsfront.h) ------------------------------------------------------------------------------------------------
+int mvsf_get_neighbors(const mvsf_scene* s, int idx, MVSFViewScore* neighbors, int cap, int* nNeighbors) {
+	if (!s || idx < 0 || idx >= (int)s->images.size()) return -1;
+	const std::vector<MVSFViewScore>& nb = s->images[idx].neighbors;
+	if (nNeighbors) *nNeighbors = (int)nb.size();
+	if (neighbors) for (int i = 0; i < (int)nb.size() && i < cap; ++i) neighbors[i] = nb[i];
+	return 0;
+}
+int mvsf_set_neighbors(mvsf_scene* s, int idx, const MVSFViewScore* neighbors, int nNeighbors) {
+	if (!s || idx < 0 || idx >= (int)s->images.size() || nNeighbors < 0 || (nNeighbors && !neighbors)) return -1;
+	for (int i = 0; i < nNeighbors; ++i) if (neighbors[i].ID >= s->images.size()) return -1;
+	s->images[idx].neighbors.assign(neighbors, neighbors + nNeighbors);
+	return 0;
+}
+int mvsf_image_depths(const mvsf_scene* s, int idx, float* minDepth, float* avgDepth, float* maxDepth) {
+	if (!s || idx < 0 || idx >= (int)s->images.size()) return -1;
+	const Image& im = s->images[idx];
+	if (minDepth) *minDepth = im.minDepth; if (avgDepth) *avgDepth = im.avgDepth; if (maxDepth) *maxDepth = im.maxDepth;
+	return 0;
+}
+
+namespace {
+// an image index: decimal digits only (String::FromString<IIndex> reads through an istream; anything it would turn into NO_ID or garbage is an error here)
+bool parseIndex(const std::string& w, size_t nImages, uint32_t& out) {
+	if (w.empty() || w.size() > 10) return false;
+	unsigned long long v = 0;
+	for (const char c : w) { if (c < '0' || c > '9') return false; v = v * 10 + (unsigned)(c - '0'); }
+	if (v >= nImages) return false;
+	out = (uint32_t)v;
+	return true;
+}
+} // namespace
+
+// Scene::LoadViewNeighbors, libs/MVS/Scene.cpp:413-457
+int mvsf_load_view_neighbors(mvsf_scene* s, const char* path) {
+	if (!s || !path) return -1;
+	try {
+		std::vector<std::pair<std::string, std::string>> items;
+		if (smltext::rootValues(path, items) < 0) return -2;              // (the reference ignores what its reader returns: the entries in front of a malformed section count)
+		std::vector<std::pair<uint32_t, std::vector<MVSFViewScore>>> lists;   // nothing is installed unless the whole file is good
+		std::vector<std::string> words;
+		for (const auto& it : items) {
+			smltext::splitWords(it.second, words);
+			if (!words.empty() && words[0][0] == '#') continue;
+			if (words.size() < 2) continue;                                  // "Invalid image IDs list": skipped, as there
+			uint32_t id;
+			if (!parseIndex(words[0], s->images.size(), id)) return -2;
+			std::vector<MVSFViewScore> nb(words.size() - 1);
+			for (size_t i = 1; i < words.size(); ++i) {
+				uint32_t n;
+				if (!parseIndex(words[i], s->images.size(), n)) return -2;
+				nb[i - 1] = MVSFViewScore{n, 0u, 1.f, 15.f * (3.14159265358979323846f / 180.f), 0.5f, 3.f};   // Scene.cpp:451
+			}
+			lists.emplace_back(id, std::move(nb));
+		}
+		for (auto& l : lists) s->images[l.first].neighbors = std::move(l.second);
+		return 0;
+	} catch (...) { return -2; }
+}
+// Scene::SaveViewNeighbors, libs/MVS/Scene.cpp:458-480
+int mvsf_save_view_neighbors(const mvsf_scene* s, const char* path) {
+	if (!s || !path) return -1;
+	FILE* f = fopen(path, "wb");
+	if (!f) return -2;
+	for (size_t id = 0; id < s->images.size(); ++id) {
+		fprintf(f, "%u", (unsigned)id);
+		for (const MVSFViewScore& n : s->images[id].neighbors) fprintf(f, " %u", (unsigned)n.ID);
+		fprintf(f, "\n");
+	}
+	return fclose(f) == 0 ? 0 : -2;
 }
 
 } // extern "C"

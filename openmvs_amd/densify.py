@@ -143,14 +143,21 @@ def _resize_area_u8(img, w: int, h: int):
     return out if img.ndim == 3 else out[..., 0]
 
 
-def load_scene(mvs_path: str, opt=None, image_loader=None):
+def load_scene(mvs_path: str, opt=None, image_loader=None, view_neighbors_file=None):
     """Reads an MVSI scene and its images and runs view selection + depth initialisation for every valid image.
 
+    `opt`: a `views.DenseOptions` or the whole option table (`optdense.OptDense`, e.g. from `optdense.load(<--dense-config-file>)`).
+    `view_neighbors_file`: `DensifyPointCloud --view-neighbors-file` (Scene::LoadViewNeighbors, applied right after the scene is loaded,
+    apps/DensifyPointCloud/DensifyPointCloud.cpp:342-343): the listed neighbours replace view selection for those images.
     `image_loader(path) -> (h,w,3) uint8 RGB` defaults to PIL.  Returns a `SceneViews`."""
     import numpy as np
     from . import mvsi, views
     opt = opt or views.DenseOptions()
+    if hasattr(opt, "dense_options"):
+        opt = opt.dense_options()
     sc = mvsi.load(mvs_path)
+    if view_neighbors_file:
+        mvsi.load_view_neighbors(sc, view_neighbors_file)
     base = os.path.dirname(os.path.abspath(mvs_path))
     if image_loader is None:
         def image_loader(p):

@@ -10,7 +10,8 @@ from . import build as _build
 
 VIEW_SCORE_DTYPE = np.dtype([("ID", "<u4"), ("points", "<u4"), ("scale", "<f4"), ("angle", "<f4"), ("area", "<f4"), ("score", "<f4")])
 EXPORTS = ["mvsf_default_options", "mvsf_load", "mvsf_free", "mvsf_version", "mvsf_num_images", "mvsf_num_points", "mvsf_image_info", "mvsf_point",
-           "mvsf_camera", "mvsf_select_views", "mvsf_select_neighbor_views", "mvsf_init_depth_map", "mvsf_init_depth_map_dense", "mvsf_triangulate_depth_map"]
+           "mvsf_camera", "mvsf_select_views", "mvsf_select_neighbor_views", "mvsf_init_depth_map", "mvsf_init_depth_map_dense", "mvsf_triangulate_depth_map",
+           "mvsf_get_neighbors", "mvsf_set_neighbors", "mvsf_load_view_neighbors", "mvsf_save_view_neighbors", "mvsf_image_depths"]
 
 
 class MVSFOptions(C.Structure):
@@ -74,6 +75,34 @@ class SceneFront:
         if rc != 0:
             raise ValueError("mvsf_camera failed: %d" % rc)
         return K, R, Cc
+
+    def neighbors(self, i):
+        """The neighbour list image i carries (archive view scores or a view-neighbours file); empty = to be selected from the sparse points."""
+        n = C.c_int()
+        assert self._lib.mvsf_get_neighbors(self._h, i, None, 0, C.byref(n)) == 0
+        nb = np.zeros(n.value, VIEW_SCORE_DTYPE)
+        assert self._lib.mvsf_get_neighbors(self._h, i, nb.ctypes.data_as(C.c_void_p), len(nb), C.byref(n)) == 0
+        return nb
+
+    def set_neighbors(self, i, nb):
+        nb = np.ascontiguousarray(nb, VIEW_SCORE_DTYPE)
+        if self._lib.mvsf_set_neighbors(self._h, i, nb.ctypes.data_as(C.c_void_p), len(nb)) != 0:
+            raise ValueError("mvsf_set_neighbors(%d)" % i)
+
+    def load_view_neighbors(self, path: str):
+        """Scene::LoadViewNeighbors (`--view-neighbors-file`)."""
+        rc = self._lib.mvsf_load_view_neighbors(self._h, path.encode())
+        if rc != 0:
+            raise ValueError("mvsf_load_view_neighbors(%s) failed: %d" % (path, rc))
+
+    def save_view_neighbors(self, path: str):
+        if self._lib.mvsf_save_view_neighbors(self._h, path.encode()) != 0:
+            raise OSError("cannot write %s" % path)
+
+    def image_depths(self, i):
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        assert self._lib.mvsf_image_depths(self._h, i, C.byref(a), C.byref(b), C.byref(c)) == 0
+        return a.value, b.value, c.value
 
     def _sizes(self, sizes):
         if sizes is None:

@@ -325,3 +325,109 @@ def save(path: str, sc: Scene, version: int | None = None) -> None:
     with open(tmp, "wb") as f:
         f.write(b"".join(out))
     os.replace(tmp, path)
+
+
+def _sml_entries(chunk: str, out):
+    blank = "\n\r\t "
+    for line in chunk.split("\n"):
+        line = line.strip(blank)
+        if not line:
+            continue
+        name, eq, val = line.partition("=")
+        name = name.strip(blank) if eq else ""
+        out.append((name, val.strip(blank)) if name else ("", val.strip(blank) if eq else line))
+
+
+def _sml_section(text: str, pos: int, out, depth: int = 0):
+    """One section of an SML text from text[pos] (SML::ParseSection, libs/Common/SML.cpp:103-160) -> (ok, position behind it); same rule as csrc/sml_text.h."""
+    while True:
+        open_ = text.find("[", pos)
+        last = open_ < 0
+        if last:
+            open_ = len(text)
+        close = text.find("}", pos)
+        if 0 <= close < open_:
+            if out is not None:
+                _sml_entries(text[pos:close], out)
+            return True, close + 1
+        if out is not None:
+            _sml_entries(text[pos:open_], out)
+        if last:
+            return True, len(text)
+        name_end = text.find("]", open_ + 1)
+        if name_end < 0:                                               # a name that is never closed swallows the rest of the text
+            return True, len(text)
+        if name_end == open_ + 1:                                      # "[]": a parse error (blanks count as a name)
+            return False, len(text)
+        body = text.find("{", name_end + 1)
+        if body < 0:
+            return True, len(text)
+        ok, pos = _sml_section(text, body + 1, None, depth + 1) if depth <= 64 else (False, len(text))
+        if not ok:
+            return False, pos
+
+
+def _sml_root_values(text: str):
+    """(name, value) of the ROOT entries of an SML text (libs/Common/SML.cpp:94-227): the text outside child sections ("[name]" + "{ ... }"), one entry per line,
+    "name = value" or -- without a '=' or with nothing in front of it -- an unnamed entry whose value is the line (SML_AUTOVALUES).  A malformed section ends the reading;
+    what stood in front of it counts."""
+    out = []
+    _sml_section(text, 0, out)
+    return out
+
+
+def _split_words(line: str):
+    """Util::CommandLineToArgvA (libs/Common/Util.cpp:740-803): blanks separate, double quotes group."""
+    words, quoted, in_space = [], False, True
+    for a in line:
+        if quoted:
+            if a == '"':
+                quoted = False
+            else:
+                words[-1] += a
+        elif a == '"':
+            quoted = True
+            if in_space:
+                words.append("")
+            in_space = False
+        elif a in " \t\n\r":
+            in_space = True
+        else:
+            if in_space:
+                words.append("")
+            words[-1] += a
+            in_space = False
+    return words
+
+
+def load_view_neighbors(sc: Scene, path: str) -> None:
+    """`Scene::LoadViewNeighbors` (libs/MVS/Scene.cpp:413-457; `DensifyPointCloud --view-neighbors-file`): one line per image, "<id> <neighbour-0> <neighbour-1> ...",
+    best first; lines starting with '#' and lines with fewer than two words are skipped.  Every listed neighbour becomes ViewScore{ID, 0, 1, 15 deg, 0.5, 3} (`:451`) in
+    `images[id].view_scores`, which `views.select_views` then uses instead of scoring the views (SceneDensify.cpp:278-281).  An id outside the scene raises (the
+    reference asserts) and leaves the scene untouched."""
+    with open(path, "rb") as f:
+        text = f.read().decode("latin-1")
+
+    def index(w):
+        if not (0 < len(w) <= 10 and w.isascii() and w.isdigit() and int(w) < len(sc.images)):
+            raise ValueError("%s: %r is not an image of this scene" % (path, w))
+        return int(w)
+
+    lists = []
+    for _, val in _sml_root_values(text):
+        words = _split_words(val)
+        if (words and words[0][:1] == "#") or len(words) < 2:
+            continue
+        nb = np.zeros(len(words) - 1, VIEW_SCORE_DTYPE)
+        nb["ID"] = [index(w) for w in words[1:]]
+        nb["scale"], nb["angle"], nb["area"], nb["score"] = 1.0, np.float32(15.0) * (np.float32(3.14159265358979323846) / np.float32(180.0)), 0.5, 3.0
+        lists.append((index(words[0]), nb))
+    for i, nb in lists:
+        sc.images[i].view_scores = nb
+
+
+def save_view_neighbors(sc: Scene, path: str) -> None:
+    """`Scene::SaveViewNeighbors` (libs/MVS/Scene.cpp:458-480): every image, "<id> <n0> <n1> ...\\n"."""
+    with open(path, "wb") as f:
+        for i, im in enumerate(sc.images):
+            f.write((" ".join([str(i)] + [str(int(n)) for n in im.view_scores["ID"]]) + "\n").encode())

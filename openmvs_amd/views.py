@@ -215,11 +215,15 @@ def filter_neighbor_views(neighbors: np.ndarray, fMinArea=0.05, fMinScale=0.2, f
 def select_views(scene: mvsi.Scene, cams: Cameras, ID: int, opt: DenseOptions = DenseOptions()):
     """`DepthMapsData::SelectViews(DepthData&)` (libs/MVS/SceneDensify.cpp:273-293) followed by the score cut of `InitViews`
     (`:333-340`).  Returns (neighbors, points, avgDepth) or None when the image cannot be densified."""
-    ok, nb, points, avg = select_neighbor_views(scene, cams, ID, opt.nMinViews,
-                                                opt.nMinViewsTrustPoint if opt.nMinViewsTrustPoint > 1 else 2,
-                                                np.deg2rad(opt.fOptimAngle), opt.nPointInsideROI)
-    if not ok:
-        return None
+    stored = scene.images[ID].view_scores
+    if len(stored):            # a list the scene already carries -- the archive's view scores (Scene.cpp:158) or a view-neighbours file (mvsi.load_view_neighbors) -- is
+        nb, points, avg = stored.copy(), np.zeros(0, np.int64), float(scene.images[ID].avg_depth)   # taken as it is (SceneDensify.cpp:278-281); no seed points then
+    else:
+        ok, nb, points, avg = select_neighbor_views(scene, cams, ID, opt.nMinViews,
+                                                    opt.nMinViewsTrustPoint if opt.nMinViewsTrustPoint > 1 else 2,
+                                                    np.deg2rad(opt.fOptimAngle), opt.nPointInsideROI)
+        if not ok:
+            return None
     nb = filter_neighbor_views(nb, opt.fMinArea, 0.2, 3.2, np.deg2rad(opt.fMinAngle), np.deg2rad(opt.fMaxAngle), opt.nMaxViews)
     if len(nb) == 0:
         return None

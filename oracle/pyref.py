@@ -303,3 +303,55 @@ def ref_fuse_depth_maps(depths, normals, confs, bgrs, K, R, Cc, neighbors, nMinV
     rc = L.ref_fuse_depth_maps(arr, C.c_int(n), C.c_int(w), C.c_int(h), order.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(no), C.c_uint(nMinViewsFuse),
                                C.c_float(fDepthDiffThreshold), C.c_float(fNormalDiffThreshold), C.c_int(1 if bEstimateColor else 0), C.c_int(1 if bEstimateNormal else 0), C.byref(out))
     return po._cloud(out, rc, L.ref_fuse_free), [int(x) for x in order[:no.value]]
+
+
+# ---- the two text files in front of the path through the reference's own readers (oracle/ref/ref_text_harness.cpp: SML.cpp, ConfigTable.cpp, the OPTDENSE list of
+# DepthMap.cpp:50-115, Scene::LoadViewNeighbors / SaveViewNeighbors, Util::CommandLineToArgvA -- all verbatim) ----
+def text_available() -> bool:
+    available()
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_text.so"))
+
+
+def _text_lib():
+    if "text" not in _LIBS:
+        if not text_available():
+            raise RuntimeError("oracle/_ref/libref_text.so is not built and /root/reference is not here to build it from")
+        _LIBS["text"] = C.CDLL(os.path.join(_HERE, "_ref", "libref_text.so"))
+    return _LIBS["text"]
+
+
+def ref_optdense_load(path: str, save_path: str | None = None):
+    """OPTDENSE::init(); oConfig.Load(path); OPTDENSE::update() [; oConfig.Save(save_path)] -> (bValidConfig, the 46 variables in list order as float64)."""
+    v = np.zeros(64, np.float64)
+    n = _text_lib().ref_optdense_load(path.encode(), v.ctypes.data_as(C.POINTER(C.c_double)), 64, save_path.encode() if save_path else None)
+    return n > 0, v[:abs(n)].copy()
+
+
+def ref_load_view_neighbors(path: str, n_images: int, save_path: str | None = None):
+    """Scene::LoadViewNeighbors on a scene of n_images images -> (neighbour ID lists per image, (points, scale, angle, area, score) of the first ViewScore made)."""
+    counts = np.zeros(n_images, np.int32); ids = np.zeros(4096, np.uint32); first = np.zeros(5, np.float32)
+    n = _text_lib().ref_load_view_neighbors(path.encode(), n_images, counts.ctypes.data_as(C.POINTER(C.c_int)), ids.ctypes.data_as(C.POINTER(C.c_uint32)), len(ids),
+                                            first.ctypes.data_as(C.POINTER(C.c_float)), save_path.encode() if save_path else None)
+    if n < 0:
+        raise RuntimeError("ref_load_view_neighbors: %d" % n)
+    out, o = [], 0
+    for c in counts:
+        out.append([int(x) for x in ids[o:o + c]]); o += c
+    return out, first
+
+
+def ref_sml_root(path: str):
+    """(what SML::Load returned, {name: value} of the root entries as it files them -- unnamed entries are called Item<n>)."""
+    got = {}
+    CB = C.CFUNCTYPE(None, C.c_char_p, C.c_char_p, C.c_void_p)
+    cb = CB(lambda name, value, ctx: got.__setitem__(name.decode("latin-1"), value.decode("latin-1")))
+    n = _text_lib().ref_sml_root(path.encode(), cb, None)
+    return n >= 0, got
+
+
+def ref_split_words(line: str):
+    buf = C.create_string_buffer(len(line) + 8)
+    n = _text_lib().ref_split_words(line.encode("latin-1"), buf, len(buf))
+    assert n >= 0
+    words = buf.raw.split(b"\0")[:n]
+    return [w.decode("latin-1") for w in words]

@@ -96,10 +96,34 @@ SNIPPETS = {
     "scenedensify_estimate": ("libs/MVS/SceneDensify.cpp", 616, 805, "bool DepthMapsData::EstimateDepthMap(IIndex idxImage, int nGeometricIter)", "} // EstimateDepthMap"),
     "scenedensify_filters":  ("libs/MVS/SceneDensify.cpp", 809, 1045, "// filter out small depth segments from the given depth map", "} // GapInterpolation"),
     "scenedensify_filterdm": ("libs/MVS/SceneDensify.cpp", 1049, 1299, "// filter depth-map, one pixel at a time, using confidence based fusion or neighbor pixels", "} // FilterDepthMap"),
+    # the two text files in front of the path (ref_text_harness.cpp)
+    "util_h_flags":          ("libs/Common/Util.h", 55, 89, "template <typename TYPE>", "typedef class GENERAL_API TFlags<uint32_t> Flags;"),
+    "sml_cpp":               ("libs/Common/SML.cpp", 11, 419, "using namespace SEACAVE;", "/*----------------------------------------------------------------*/"),
+    "configtable_cpp":       ("libs/Common/ConfigTable.cpp", 11, 153, "using namespace SEACAVE;", "/*----------------------------------------------------------------*/"),
+    "util_cpp_argv":         ("libs/Common/Util.cpp", 740, 805, "LPSTR* Util::CommandLineToArgvA(LPCSTR CmdLine, size_t& _argc)", "/*----------------------------------------------------------------*/"),
+    "common_h_defvar":       ("libs/Common/Common.h", 101, 170, "// macros simplifying the task of managing options", "#define TDEFVAR_float(SPACE, name, title, desc, ...)"),
+    "scene_cpp_loadnb":      ("libs/MVS/Scene.cpp", 423, 457, "bool Scene::LoadViewNeighbors(const String& fileName)", "} // LoadViewNeighbors"),
+    "scene_cpp_savenb":      ("libs/MVS/Scene.cpp", 458, 479, "bool Scene::SaveViewNeighbors(const String& fileName) const", "} // SaveViewNeighbors"),
+    "depthmap_cpp_optdense": ("libs/MVS/DepthMap.cpp", 50, 115, "#define DEFVAR_OPTDENSE_string(name, title, desc, ...)", "}"),
+}
+
+# whole headers of libs/Common, cut under their own names into <scratch>/common/ so that their #includes of each other resolve there (ref_text_harness.cpp):
+# file: (number of lines, text the second line must contain, text the last line must contain)
+WHOLE = {
+    "libs/Common/AutoPtr.h":     (275, "// AutoPtr.h", "#endif // __SEACAVE_AUTOPTR_H__"),
+    "libs/Common/Streams.h":     (244, "// Streams.h", "#endif // __SEACAVE_STREAMS_H__"),
+    "libs/Common/Strings.h":     (239, "// Strings.h", "#endif // __SEACAVE_STRING_H__"),
+    "libs/Common/List.h":        (1704, "// List.h", "#endif // __SEACAVE_LIST_H__"),
+    "libs/Common/Hash.h":        (303, "// Hash.h", "#endif // __SEACAVE_HASH_H__"),
+    "libs/Common/File.h":        (686, "// File.h", "#endif // __SEACAVE_FILE_H__"),
+    "libs/Common/MemFile.h":     (182, "// MemFile.h", "#endif // __SEACAVE_MEMFILE_H__"),
+    "libs/Common/Filters.h":     (612, "// Filters.h", "#endif // __SEACAVE_FILTERS_H__"),
+    "libs/Common/SML.h":         (116, "// SML.h", "#endif // __SEACAVE_SML_H__"),
+    "libs/Common/ConfigTable.h": (82, "// ConfigTable.h", "#endif // __SEACAVE_CONFIGTABLE_H__"),
 }
 
 
-ALL = ("libref_pm.so", "libref_pm_libm.so", "libref_sgm.so", "libref_scene.so", "libref_fuse.so", "libref_driver.so", "libref_driver_libm.so")
+ALL = ("libref_pm.so", "libref_pm_libm.so", "libref_sgm.so", "libref_scene.so", "libref_fuse.so", "libref_driver.so", "libref_driver_libm.so", "libref_text.so")
 
 
 def cut(dst):
@@ -112,6 +136,16 @@ def cut(dst):
         with open(os.path.join(dst, "snip", name + ".inc"), "w") as f:
             f.write("#line %d \"%s\"\n" % (a, os.path.join(REF, rel)))
             f.write("\n".join(body) + "\n")
+    os.makedirs(os.path.join(dst, "common"), exist_ok=True)
+    for rel, (n, second, last) in WHOLE.items():
+        lines = open(os.path.join(REF, rel), encoding="utf-8", errors="replace").read().split("\n")
+        if lines and lines[-1] == "":
+            lines.pop()
+        if len(lines) != n or second not in lines[1] or last not in lines[-1]:
+            raise SystemExit("%s is not the file this recipe was written for (%d lines, %r ... %r)" % (rel, len(lines), lines[1], lines[-1]))
+        with open(os.path.join(dst, "common", os.path.basename(rel)), "w") as f:
+            f.write("#line 1 \"%s\"\n" % os.path.join(REF, rel))
+            f.write("\n".join(lines) + "\n")
 
 
 def build(verbose=False):
@@ -129,6 +163,7 @@ def build(verbose=False):
                                  ("libref_sgm.so", ["-DREF_MATH_PM"], "ref_sgm_harness.cpp"),
                                  ("libref_scene.so", [], "ref_scene_harness.cpp"),
                                  ("libref_fuse.so", [], "ref_fuse_harness.cpp"),
+                                 ("libref_text.so", [], "ref_text_harness.cpp"),
                                  ("libref_driver.so", ["-DREF_MATH_PM"] + link_orc, "ref_driver_harness.cpp"),
                                  ("libref_driver_libm.so", ["-O3", "-march=x86-64-v3"] + link_orc, "ref_driver_harness.cpp")):
             out = os.path.join(OUT, name)

@@ -1,0 +1,176 @@
+// ref_text_harness.cpp -- TEST INFRASTRUCTURE ONLY (oracle/_ref/libref_text.so).  The reference's own readers of the two text files in front of the path, compiled from its text:
+//   * the SML document reader (libs/Common/SML.h, SML.cpp with TokenInputStream / MemFile / File of libs/Common: whole files, cut by oracle/ref/build_ref.py into a scratch
+//     directory under their own names so that their mutual #includes resolve);
+//   * the option table: the DEFVAR machinery (libs/Common/Common.h:101-170), CConfigTable (ConfigTable.h / .cpp) and the OPTDENSE list itself (libs/MVS/DepthMap.cpp:50-115)
+//     -> OPTDENSE::init(), oConfig.Load(file), OPTDENSE::update(), oConfig.Save(file), exactly the calls of apps/DensifyPointCloud/DensifyPointCloud.cpp:236-255;
+//   * Scene::LoadViewNeighbors / SaveViewNeighbors (libs/MVS/Scene.cpp:423-480) with Util::CommandLineToArgvA (libs/Common/Util.cpp:740-805).
+// Pins openmvs_amd/csrc/opt_dense.cpp, sml_text.h, mvs_front.cpp (mvsf_load_view_neighbors / mvsf_save_view_neighbors) and their numpy mirrors (tests/test_ref_text.py).
+// What is written here is only what libs/Common/Types.h would have supplied (typedefs and C-library aliases for a non-Windows build, Types.h:239-335) and a Scene that
+// holds nothing but the neighbour lists.
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdarg.h>
+#include <string.h>
+#include <stdint.h>
+#include <assert.h>
+#include <sys/types.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/wait.h>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <sstream>
+#include <iomanip>
+#include <algorithm>
+#include <numeric>
+#include <limits>
+#include <unordered_map>
+#include <vector>
+#include <functional>
+#define GENERAL_API
+#define NOINITVTABLE
+#define ASSERT(exp)
+#define FORCEINLINE inline
+#define STCALL
+#define RESTRICT __restrict__
+typedef unsigned char BYTE; typedef unsigned short WORD; typedef unsigned int DWORD;
+typedef char CHAR; typedef CHAR* LPSTR; typedef const CHAR* LPCSTR; typedef CHAR TCHAR; typedef LPSTR LPTSTR; typedef LPCSTR LPCTSTR;
+#define _tcslen strlen
+#define _tcscpy strcpy
+#define _tcsncpy strncpy
+#define _tcschr strchr
+#define _tcsrchr strrchr
+#define _tcscmp strcmp
+#define _tcsncmp strncmp
+#define _tcsicmp strcasecmp
+#define _tcsnicmp strncasecmp
+#define _vsntprintf vsnprintf
+#define _vsctprintf _vscprintf
+inline int _vscprintf(LPCSTR format, va_list pargs) { va_list c; va_copy(c, pargs); const int r = vsnprintf(NULL, 0, format, c); va_end(c); return r; }
+#define _T(s) s
+#define DECLARE_NO_INDEX(...) std::numeric_limits<__VA_ARGS__>::max()
+#define RAND std::rand
+#define MINF std::min
+#define MAXF std::max
+namespace SEACAVE { typedef int64_t size_f_t; typedef double REAL; }
+using namespace SEACAVE;
+#include "common/Streams.h"      // (includes AutoPtr.h)
+#include "common/Strings.h"
+#include "common/List.h"
+#include "common/Hash.h"
+#include "common/File.h"
+#include "common/MemFile.h"
+namespace SEACAVE { typedef cList<String> StringArr; typedef cList<void*, void*, 0> VoidArr; }   // Types.h:416-418
+#include "common/Filters.h"
+namespace SEACAVE {
+#include "snip/util_h_flags.inc"            // Util.h:55-89: TFlags, Flags
+}
+#include "common/SML.h"
+#include "snip/sml_cpp.inc"                 // SML.cpp:11-419
+#include "common/ConfigTable.h"
+#include "snip/configtable_cpp.inc"         // ConfigTable.cpp:11-153
+namespace SEACAVE {
+struct Util { static LPSTR* CommandLineToArgvA(LPCSTR CmdLine, size_t& _argc); };
+#include "snip/util_cpp_argv.inc"           // Util.cpp:740-805
+}
+#include "snip/common_h_defvar.inc"         // Common.h:101-170
+#define FD2R(d) ((d)*(float)(3.14159265358979323846/180.0))   // Types.h: FD2R = float degrees to radians
+#define VERBOSE(...) ((void)0)
+#define DEBUG_EXTRA(...) ((void)0)
+#define TD_TIMER_STARTD()
+#define TD_TIMER_GET_FMT() String()
+namespace MVS {
+typedef uint32_t IIndex;
+constexpr uint32_t NO_ID = 0xFFFFFFFFu;
+struct ViewScore { uint32_t ID; uint32_t points; float scale, angle, area, score; };   // Image.h
+typedef SEACAVE::cList<ViewScore, const ViewScore&, 0> ViewScoreArr;
+struct Image { ViewScoreArr neighbors; };
+typedef SEACAVE::cList<Image> ImageArr;
+struct Scene {
+	ImageArr images;
+	bool LoadViewNeighbors(const String& fileName);
+	bool SaveViewNeighbors(const String& fileName) const;
+	bool ImagesHaveNeighbors() const { return true; }
+};
+#include "snip/scene_cpp_loadnb.inc"        // Scene.cpp:423-457
+#include "snip/scene_cpp_savenb.inc"        // Scene.cpp:458-479
+}
+#include "snip/depthmap_cpp_optdense.inc"   // DepthMap.cpp:50-115: the option list (opens and closes namespace MVS itself)
+
+extern "C" {
+// OPTDENSE::init(); bValid = oConfig.Load(path); OPTDENSE::update() -- then every variable, in the order of the list, as a double
+#define REF_OPT_LIST(X) X(nResolutionLevel) X(nMaxResolution) X(nMinResolution) X(nSubResolutionLevels) X(nMinViews) X(nMaxViews) X(nMinViewsFuse) X(nMinViewsFilter) \
+	X(nMinViewsFilterAdjust) X(nMinViewsTrustPoint) X(nNumViews) X(nPointInsideROI) X(bFilterAdjust) X(bAddCorners) X(bInitSparse) X(bRemoveDmaps) X(fViewMinScore) \
+	X(fViewMinScoreRatio) X(fMinArea) X(fMinAngle) X(fOptimAngle) X(fMaxAngle) X(fDescriptorMinMagnitudeThreshold) X(fDepthDiffThreshold) X(fNormalDiffThreshold) \
+	X(fPairwiseMul) X(fOptimizerEps) X(nOptimizerMaxIters) X(nSpeckleSize) X(nIpolGapSize) X(nIgnoreMaskLabel) X(nOptimize) X(nEstimateColors) X(nEstimateNormals) \
+	X(fNCCThresholdKeep) X(nEstimationIters) X(nEstimationGeometricIters) X(fEstimationGeometricWeight) X(nRandomIters) X(nRandomMaxScale) X(fRandomDepthRatio) \
+	X(fRandomAngle1Range) X(fRandomAngle2Range) X(fRandomSmoothDepth) X(fRandomSmoothNormal) X(fRandomSmoothBonus)
+// OPTDENSE::init() can run once per process (it replaces its own function table by the update functions, Common.h:127-139), as in the reference's main(); so every
+// call does its work in a forked child and hands the values back through a pipe
+static int optdenseLoadOnce(const char* path, double* values, int cap, const char* savePath) {
+	MVS::OPTDENSE::init();
+	const bool valid = MVS::OPTDENSE::oConfig.Load(String(path));
+	MVS::OPTDENSE::update();
+	int n = 0;
+#define X(name) if (n < cap) values[n] = (double)MVS::OPTDENSE::name; ++n;
+	REF_OPT_LIST(X)
+#undef X
+	if (savePath) MVS::OPTDENSE::oConfig.Save(String(savePath));
+	return valid ? n : -n;
+}
+int ref_optdense_load(const char* path, double* values, int cap, const char* savePath) {
+	int fd[2];
+	if (cap > 64 || pipe(fd) != 0) return 0;
+	const pid_t pid = fork();
+	if (pid < 0) return 0;
+	if (pid == 0) {
+		double v[64]; memset(v, 0, sizeof(v));
+		int n = optdenseLoadOnce(path, v, cap, savePath);
+		bool ok = write(fd[1], &n, sizeof(n)) == (ssize_t)sizeof(n) && write(fd[1], v, sizeof(v)) == (ssize_t)sizeof(v);
+		_exit(ok ? 0 : 1);
+	}
+	close(fd[1]);
+	int n = 0; double v[64];
+	const bool ok = read(fd[0], &n, sizeof(n)) == (ssize_t)sizeof(n) && read(fd[0], v, sizeof(v)) == (ssize_t)sizeof(v);
+	close(fd[0]);
+	int status = 0; waitpid(pid, &status, 0);
+	if (!ok) return 0;
+	memcpy(values, v, sizeof(double) * (size_t)(cap < 64 ? cap : 64));
+	return n;
+}
+// Scene::LoadViewNeighbors on a scene of nImages images: counts[i] neighbours of image i, their IDs flattened into ids (cap entries), the other ViewScore fields of the
+// first neighbour found into first[5] (points, scale, angle, area, score)
+int ref_load_view_neighbors(const char* path, int nImages, int* counts, uint32_t* ids, int cap, float* first, const char* savePath) {
+	MVS::Scene sc; sc.images.resize((unsigned)nImages);
+	if (!sc.LoadViewNeighbors(String(path))) return -1;
+	int n = 0; bool have = false;
+	for (int i = 0; i < nImages; ++i) {
+		counts[i] = (int)sc.images[i].neighbors.size();
+		for (const MVS::ViewScore& v : sc.images[i].neighbors) {
+			if (!have && first) { first[0] = (float)v.points; first[1] = v.scale; first[2] = v.angle; first[3] = v.area; first[4] = v.score; have = true; }
+			if (n < cap) ids[n] = v.ID;
+			++n;
+		}
+	}
+	if (savePath && !sc.SaveViewNeighbors(String(savePath))) return -2;
+	return n;
+}
+// The root entries of an SML file as the reference's reader sees them: calls back once per entry (hash-map order)
+int ref_sml_root(const char* path, void (*cb)(const char* name, const char* value, void* ctx), void* ctx) {
+	SML sml(_T("Root"));
+	const bool ok = sml.Load(String(path));      // false: the file cannot be opened, or a parse error (the entries read in front of it are in the table)
+	int n = 0;
+	for (SML::const_iterator it = sml.begin(); it != sml.end(); ++it, ++n) cb(it->first.c_str(), it->second.val.c_str(), ctx);
+	return ok ? n : -(n + 1);
+}
+// Util::CommandLineToArgvA: the words, NUL-separated, into out (cap bytes); returns their number
+int ref_split_words(const char* line, char* out, int cap) {
+	size_t argc = 0;
+	CAutoPtrArr<LPSTR> argv(Util::CommandLineToArgvA(line, argc));
+	int o = 0;
+	for (size_t i = 0; i < argc; ++i) { const int k = (int)strlen(argv[i]) + 1; if (o + k > cap) return -1; memcpy(out + o, argv[i], (size_t)k); o += k; }
+	return (int)argc;
+}
+}

@@ -71,6 +71,7 @@ class SceneViews:
         self.dmin = []; self.dmax = []; self.neighbors = []; self.view_scores = []
         self.init_depth = {}; self.init_normal = {}
         self.names = []; self.ids = []          # ids: images that passed view selection, in scene order
+        self.masks = {}; self.mask_option = False   # ignore masks by image index (1 = process, 0 = ignore); mask_option: OPTDENSE::nIgnoreMaskLabel >= 0
 
     @property
     def n_views(self):
@@ -143,16 +144,22 @@ def _resize_area_u8(img, w: int, h: int):
     return out if img.ndim == 3 else out[..., 0]
 
 
-def load_scene(mvs_path: str, opt=None, image_loader=None, view_neighbors_file=None):
+def load_scene(mvs_path: str, opt=None, image_loader=None, view_neighbors_file=None, ignore_mask_label=None, mask_path=None, mask_loader=None):
     """Reads an MVSI scene and its images and runs view selection + depth initialisation for every valid image.
 
     `opt`: a `views.DenseOptions` or the whole option table (`optdense.OptDense`, e.g. from `optdense.load(<--dense-config-file>)`).
     `view_neighbors_file`: `DensifyPointCloud --view-neighbors-file` (Scene::LoadViewNeighbors, applied right after the scene is loaded,
     apps/DensifyPointCloud/DensifyPointCloud.cpp:342-343): the listed neighbours replace view selection for those images.
+    `ignore_mask_label` (`--ignore-mask-label`; default: the option table's nIgnoreMaskLabel, else off) >= 0: every image's segmentation mask is looked up like
+    `DepthEstimator::ImportIgnoreMask` does (the scene's mask name, else <image>.mask.png; `mask_path` = `--mask-path`), read by `mask_loader(path) -> (h,w) labels`
+    (default PIL), brought to the working resolution with INTER_NEAREST, and lands in `SceneViews.masks[i]` (1 = process, 0 = ignore) for `scene_set_mask`; an image
+    whose mask cannot be read has none, as there (a warning in the reference), but `SceneViews.mask_option` tells the engine that the option is on (SceneDensify.cpp:661).
     `image_loader(path) -> (h,w,3) uint8 RGB` defaults to PIL.  Returns a `SceneViews`."""
     import numpy as np
     from . import mvsi, views
     opt = opt or views.DenseOptions()
+    if ignore_mask_label is None:
+        ignore_mask_label = int(getattr(opt, "nIgnoreMaskLabel", -1))
     if hasattr(opt, "dense_options"):
         opt = opt.dense_options()
     sc = mvsi.load(mvs_path)
@@ -178,6 +185,23 @@ def load_scene(mvs_path: str, opt=None, image_loader=None, view_neighbors_file=N
     if len(set(sizes)) != 1:
         raise NotImplementedError("the batch scene interface needs one image resolution; got %s" % sorted(set(sizes)))
     sv.width, sv.height = sizes[0]
+    if ignore_mask_label >= 0:
+        sv.mask_option = True
+        if mask_loader is None:
+            def mask_loader(p):
+                from PIL import Image
+                with Image.open(p) as im:
+                    return np.asarray(im)
+        for i, im in enumerate(sc.images):
+            name = views.mask_file_name(im.name, im.mask_name, mask_path)
+            p = name if os.path.isabs(name) else os.path.join(base, name)
+            if mask_path and not os.path.exists(p):
+                raise FileNotFoundError("Mask image %s not found" % p)          # DensifyPointCloud.cpp:315-318
+            try:
+                labels = mask_loader(p)
+            except (OSError, ValueError):
+                continue                                                         # "warning: can not load the segmentation mask": the image is estimated unmasked
+            sv.masks[i] = views.import_ignore_mask(labels, sizes[i], ignore_mask_label)
     cams = views.Cameras(sc, sizes)
     for i, im in enumerate(sc.images):
         sv.gray.append(views.to_gray(rgbs[i])); sv.names.append(im.name)

@@ -214,6 +214,12 @@ class PatchMatchHIP:
         self.scene_create(scene.n_views, scene.width, scene.height, n_levels)
         for i in range(scene.n_views):
             self.scene_set_view(i, scene.gray[i], scene.K[i], scene.R[i], scene.C[i], float(scene.dmin[i]), float(scene.dmax[i]), scene.neighbors[i])
+        # ignore masks of a scene loaded with --ignore-mask-label (densify.load_scene): per image where a mask file was found; the option alone already selects the
+        # nearest-neighbour level hand-off (SceneDensify.cpp:661)
+        for i, m in getattr(scene, "masks", {}).items():
+            self.scene_set_mask(i, m)
+        if getattr(scene, "mask_option", False):
+            self.scene_set_mask_mode(1)
 
     def scene_set_view_sized(self, idx, gray, K, R, Cc, dmin, dmax, neighbors):
         """A view whose image -- and therefore its depth, normal and confidence maps -- has its own size (pmhip_scene_set_view_sized): a source view or a reference view."""

@@ -421,3 +421,39 @@ def _raster_face(v, zs, ns, depthMap, normalMap):
             n = (n.astype(f32) + (ns[2] * pb[2]).astype(f32)).astype(f32)
             nn = np.sqrt(float(n[0]) * n[0] + float(n[1]) * n[1] + float(n[2]) * n[2])
             normalMap[y, x] = (n.astype(np.float64) * (1.0 / nn if nn else 0.0)).astype(f32)
+
+
+# ---- ignore masks (`--ignore-mask-label`, `--mask-path`) ------------------------------------------------------------------------------------------
+
+def mask_file_name(image_name: str, mask_name: str = "", mask_path: str | None = None) -> str:
+    """Where `DepthEstimator::ImportIgnoreMask` looks for an image's segmentation mask (libs/MVS/DepthMap.cpp:301): the name stored in the scene, else the image's path
+    with its extension replaced by ".mask.png" (`Util::getFileFullName`: everything before the LAST '.', libs/Common/Util.h:466-469).  `mask_path` is
+    `DensifyPointCloud --mask-path` (apps/DensifyPointCloud/DensifyPointCloud.cpp:307-320): <mask_path><file name without directory and extension>.mask.png for every
+    image; an image that already names a mask is an error there."""
+    if mask_path:
+        if mask_name:
+            raise ValueError("image %s has non-empty maskName %s" % (image_name, mask_name))
+        base = image_name[image_name.rfind("/") + 1:]                      # Util::getFileName, Util.h:476-482
+        j = image_name.rfind(".")
+        base = image_name[image_name.rfind("/") + 1:j] if j >= 0 else base
+        return (mask_path if mask_path.endswith("/") else mask_path + "/") + base + ".mask.png"      # (ensureValidFolderPath appends the separator)
+    if mask_name:
+        return mask_name
+    i = image_name.rfind(".")
+    return (image_name[:i] if i >= 0 else image_name) + ".mask.png"
+
+
+def import_ignore_mask(mask: np.ndarray, size, label: int) -> np.ndarray:
+    """`DepthEstimator::ImportIgnoreMask` after the file is read (libs/MVS/DepthMap.cpp:307-320): the 16-bit label image resized to the depth map's `size` = (w, h) with
+    INTER_NEAREST, then 1 where the label differs from `label` (pixels to process), 0 where it equals it (ignored) -- the array `PatchMatchHIP.scene_set_mask` takes.
+    cv::resize's nearest rule: sx = min(floor(dx * ifx), sw - 1) with ifx = 1 / (dw / sw) in double (resizeNN)."""
+    m = np.asarray(mask)
+    if m.ndim != 2:
+        raise ValueError("a label image is (h, w)")
+    m = m.astype(np.uint16)                                              # Image16U
+    w, h = int(size[0]), int(size[1])
+    sh, sw = m.shape
+    ifx, ify = 1.0 / (w / float(sw)), 1.0 / (h / float(sh))
+    sx = np.minimum(np.floor(np.arange(w) * ifx).astype(np.int64), sw - 1)
+    sy = np.minimum(np.floor(np.arange(h) * ify).astype(np.int64), sh - 1)
+    return (m[sy][:, sx] != np.uint16(label & 0xFFFF)).astype(np.uint8)

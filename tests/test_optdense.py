@@ -206,3 +206,58 @@ def test_archive_view_scores_are_the_neighbour_lists(tmp_path):
     bad = str(tmp_path / "bad.mvs"); open(bad, "wb").write(bytes(raw))
     with pytest.raises(ValueError):
         mvsfront.SceneFront(bad)
+
+
+# ---- ignore masks ---------------------------------------------------------------------------------------------------------------------------------
+
+def test_ignore_mask_lookup_and_import():
+    """DepthEstimator::ImportIgnoreMask (DepthMap.cpp:296-323) and --mask-path (DensifyPointCloud.cpp:307-320): where the mask is looked for, and label -> process / ignore at the
+    depth map's size through cv::resize(INTER_NEAREST)."""
+    assert views.mask_file_name("images/00001.jpg") == "images/00001.mask.png"
+    assert views.mask_file_name("images/a.b/00001") == "images/a.mask.png"               # Util::getFileFullName cuts at the LAST '.', wherever it is
+    assert views.mask_file_name("noext") == "noext.mask.png"
+    assert views.mask_file_name("images/00001.jpg", "masks/m1.png") == "masks/m1.png"
+    assert views.mask_file_name("images/00001.jpg", "", "/data/masks") == "/data/masks/00001.mask.png" == views.mask_file_name("images/00001.jpg", "", "/data/masks/")
+    with pytest.raises(ValueError):
+        views.mask_file_name("images/00001.jpg", "masks/m1.png", "/data/masks")
+    rng = np.random.default_rng(3)
+    for (sh, sw), (w, h) in (((48, 64), (64, 48)), ((48, 64), (32, 24)), ((37, 53), (64, 48)), ((100, 70), (33, 47)), ((5, 7), (3, 2))):
+        labels = rng.integers(0, 4, (sh, sw)).astype(np.uint16)
+        labels[0, 0] = 65535
+        got = views.import_ignore_mask(labels, (w, h), 2)
+        want = np.zeros((h, w), np.uint8)
+        ifx, ify = 1.0 / (w / sw), 1.0 / (h / sh)                                           # resizeNN, literally
+        for y in range(h):
+            for x in range(w):
+                want[y, x] = labels[min(int(np.floor(y * ify)), sh - 1), min(int(np.floor(x * ifx)), sw - 1)] != 2
+        assert got.dtype == np.uint8 and np.array_equal(got, want)
+        assert np.array_equal(views.import_ignore_mask(labels, (w, h), 65535) == 0, views.import_ignore_mask(labels, (w, h), -1) == 0)   # (uint16_t)nIgnoreMaskLabel
+    assert views.import_ignore_mask(np.full((4, 4), 7, np.uint8), (4, 4), 7).sum() == 0 and views.import_ignore_mask(np.full((4, 4), 7, np.uint8), (4, 4), 1).all()
+
+
+def test_load_scene_reads_the_option_table_the_neighbour_file_and_the_masks(tmp_path):
+    """densify.load_scene with what the command line hands the reference: --dense-config-file, --view-neighbors-file, --ignore-mask-label."""
+    from openmvs_amd import densify
+    ini = tmp_path / "dense.ini"; ini.write_text("Ignore Mask Label = 3\nMin Resolution = 320\nResolution Level = 1\n")
+    nbf = tmp_path / "nb.txt"; nbf.write_text("0 1 2\n")
+    opt = optdense.load(str(ini))
+    py = mvsi.load(SCENE)
+    seen = []
+
+    def masks(p):
+        seen.append(os.path.basename(p))
+        if p.endswith("00000.mask.png") or "0000" not in p:
+            raise OSError("no such mask")
+        m = np.zeros((479, 640), np.uint16); m[:100] = 3
+        return m
+
+    sv = densify.load_scene(SCENE, opt=opt, view_neighbors_file=str(nbf), mask_loader=masks)
+    assert (sv.width, sv.height) == (320, 240) and sv.mask_option and len(seen) == 4
+    got = sorted(sv.masks)
+    assert len(got) >= 1 and all(sv.masks[i].shape == (240, 320) for i in got)
+    m = sv.masks[got[0]]
+    assert not m[:50].any() and m[51:].all()                                   # rows 0..99 of 479 carry the label: rows 0..50 of 240 (nearest rule)
+    assert list(sv.neighbors[0]) == [1, 2] and not sv.init_depth[0].any() and abs(sv.dmin[0] - 0.1) < 1e-6 and sv.dmax[0] == 100.0     # the listed neighbours; no seed points
+    assert len(sv.neighbors[1]) >= 1 and sv.init_depth[1].any()               # the others are scored and seeded as before
+    sv2 = densify.load_scene(SCENE)                                            # option off: nothing is looked up
+    assert not sv2.mask_option and not sv2.masks

@@ -6,6 +6,8 @@ from __future__ import annotations
 
 import os
 
+import numpy as np
+
 from . import dmap as _dmap
 
 REMOVE_SPECKLES, FILL_GAPS, ADJUST_FILTER = 1, 2, 4   # OPTDENSE::DepthFlags, libs/MVS/DepthMap.h:87-92
@@ -13,12 +15,25 @@ REMOVE_SPECKLES, FILL_GAPS, ADJUST_FILTER = 1, 2, 4   # OPTDENSE::DepthFlags, li
 
 def compute_depth_maps(engine, view_ids, params, n_optimize: int = 7, b_filter_adjust: bool = True,
                        n_speckle_size: int = 100, n_ipol_gap_size: int = 7, f_depth_diff_threshold: float = 0.01,
-                       n_min_views_filter: int = 2, n_min_views_filter_adjust: int = 1, init_depth=None, init_normal=None):
+                       n_min_views_filter: int = 2, n_min_views_filter_adjust: int = 1, init_depth=None, init_normal=None, scene=None):
     """Runs the reference's dense schedule for `view_ids` on a loaded scene (engine.scene_load / scene_set_view).
     `init_depth` / `init_normal` (dicts view id -> map) seed the photometric pass like `InitViews(..., loadDepthMaps=0)` does
-    (SceneDensify.cpp:418-460); views without an entry start from random planes."""
+    (SceneDensify.cpp:418-460); views without an entry start from random planes.
+    `scene`: the `SceneViews` the engine was loaded from, needed when it holds resampled copies of neighbours (`alias_of`, ViewData::ScaleImage): at every round
+    boundary a copy is handed the depth map of the image it stands for, at that image's size and camera (the neighbour's saved .dmap, SceneDensify.cpp:378-393), and
+    before the cross-view filter the reference views get their image neighbours back (FilterDepthMap reads arrDepthData[ID], :1049-1299)."""
     ids = list(view_ids)
     G = int(params.nEstimationGeometricIters)
+    alias_of = dict(getattr(scene, "alias_of", None) or {})
+
+    def hand_depths_to_copies():
+        for a, j in alias_of.items():
+            engine.scene_set_source_depth(a, engine.scene_get_maps(j)[0], scene.K[j], scene.R[j], scene.C[j])
+
+    def image_neighbours():
+        for v in ids:
+            if alias_of and not np.array_equal(scene.estimate_neighbors[v], scene.neighbors[v]):
+                engine.scene_set_view(v, None, scene.K[v], scene.R[v], scene.C[v], float(scene.dmin[v]), float(scene.dmax[v]), scene.neighbors[v])
 
     def post():
         if n_optimize & REMOVE_SPECKLES:
@@ -36,10 +51,12 @@ def compute_depth_maps(engine, view_ids, params, n_optimize: int = 7, b_filter_a
         post()
     for g in range(G):
         engine.scene_commit_round()
+        hand_depths_to_copies()
         engine.Init(True)
         engine.scene_estimate(ids, g, params)
         if g + 1 == G:
             post()
+    image_neighbours()
     if n_optimize & ADJUST_FILTER:
         engine.scene_filter(ids, b_filter_adjust, n_min_views_filter, n_min_views_filter_adjust, f_depth_diff_threshold, commit=True)
 
@@ -53,7 +70,8 @@ def save_depth_maps(engine, scene, view_ids, out_dir: str, image_names=None):
         ids = [int(v)] + [int(i) for i in scene.neighbors[v]]
         name = image_names[v] if image_names else "images/%05d.jpg" % v
         p = os.path.join(out_dir, _dmap.depth_file_name(int(v)))
-        _dmap.save(p, name, ids, (scene.width, scene.height), scene.K[v], scene.R[v], scene.C[v], float(scene.dmin[v]), float(scene.dmax[v]), d, n, c)
+        size = tuple(scene.sizes[v]) if getattr(scene, "sizes", None) else (scene.width, scene.height)
+        _dmap.save(p, name, ids, size, scene.K[v], scene.R[v], scene.C[v], float(scene.dmin[v]), float(scene.dmax[v]), d, n, c)
         paths.append(p)
     return paths
 
@@ -61,8 +79,8 @@ def save_depth_maps(engine, scene, view_ids, out_dir: str, image_names=None):
 # ---- scene front end: *.mvs + images -> engine scene -----------------------------------------------------------------------------
 
 class SceneViews:
-    """What `Scene::ComputeDepthMaps` has in hand after its preparation steps (libs/MVS/SceneDensify.cpp:1772-1870) for a scene whose
-    images share one resolution: gray images, pixel cameras, neighbour lists, depth ranges and the sparse initial maps.  Same
+    """What `Scene::ComputeDepthMaps` has in hand after its preparation steps (libs/MVS/SceneDensify.cpp:1772-1870) for a scene:
+    gray images, pixel cameras, neighbour lists, depth ranges and the sparse initial maps.  Same
     attribute names as `synth.Scene`, so `PatchMatchHIP.scene_load` takes either."""
 
     def __init__(self):
@@ -72,18 +90,22 @@ class SceneViews:
         self.init_depth = {}; self.init_normal = {}
         self.names = []; self.ids = []          # ids: images that passed view selection, in scene order
         self.masks = {}; self.mask_option = False   # ignore masks by image index (1 = process, 0 = ignore); mask_option: OPTDENSE::nIgnoreMaskLabel >= 0
+        self.sizes = []                             # (w, h) of every slot: images of another size than the scene's carry their own (pmhip_scene_set_view_sized)
+        self.estimate_neighbors = None              # per slot: the slots the ESTIMATION reads (a resampled copy where ViewData::ScaleImage applies); None = `neighbors`
+        self.alias_of = {}                          # extra source-only slot -> the image it is a resampled copy of
 
     @property
     def n_views(self):
         return len(self.gray)
 
 
-def _area_tab(ssize: int, dsize: int):
+def _area_tab(ssize: int, dsize: int, scale: float | None = None):
     """OpenCV's computeResizeAreaTab (imgproc/src/resize.cpp) for one axis: for every destination cell the source cells it covers and their float weights, in order.
     Returns (di, si, alpha) arrays; scale = ssize / dsize in double, the partial cells at both ends weighted by their covered fraction of the cell width."""
     import math
     import numpy as np
-    scale = ssize / dsize
+    if scale is None:
+        scale = ssize / dsize
     di, si, al = [], [], []
     for dx in range(dsize):
         fsx1 = dx * scale
@@ -144,6 +166,104 @@ def _resize_area_u8(img, w: int, h: int):
     return out if img.ndim == 3 else out[..., 0]
 
 
+# ---- DepthData::ViewData::ScaleImage: a neighbour whose footprint differs by 15 % or more is resampled (libs/MVS/DepthMap.h:193-204) -----------------------------
+
+def need_scale_image(scale) -> bool:
+    """`NeedScaleImage`: ABS(scale - 1.f) >= 0.15f, in float."""
+    import numpy as np
+    return bool(np.abs(np.float32(scale) - np.float32(1)) >= np.float32(0.15))
+
+
+def _resize_area_f32(img, w: int, h: int, scale: float):
+    """cv::resize(img, Size(), 1/scale, 1/scale, INTER_AREA) of a float image that shrinks (`scale` = OpenCV's scale_x = scale_y > 1, (w, h) = the destination size it derived).
+    An integer `scale`: the "area fast" path -- full f x f blocks are ((a+b)+(c+d))*0.25 for f = 2, else the row-major running sum times 1/f^2; blocks cut by the right /
+    bottom border average what is there (the statement of oracle/pm_oracle.cpp's resizeArea, which the estimator's pyramid uses).  Any other factor: the general path
+    (computeResizeAreaTab + ResizeArea_Invoker) in float, as `_resize_area_u8` without the final rounding.  OpenCV is not vendored with the reference: unpinned."""
+    import numpy as np
+    H, W = img.shape
+    src = np.ascontiguousarray(img, np.float32)
+    f = int(np.rint(scale))
+    if abs(scale - f) < np.finfo(np.float64).eps:
+        out = np.zeros((h, w), np.float32)
+        fw, fh = min(w, W // f), min(h, H // f)                                # destination cells whose block is complete
+        if fw and fh:
+            blk = src[:fh * f, :fw * f].reshape(fh, f, fw, f)
+            if f == 2:
+                full = ((blk[:, 0, :, 0] + blk[:, 0, :, 1]) + (blk[:, 1, :, 0] + blk[:, 1, :, 1])) * np.float32(0.25)
+            else:
+                acc = np.zeros((fh, fw), np.float32)
+                for j in range(f):
+                    for i in range(f):
+                        acc = acc + blk[:, j, :, i]
+                full = acc * np.float32(1.0 / (f * f))
+            out[:fh, :fw] = full
+        for y in range(h):                                                     # cells cut by the border (sizes not divisible by f)
+            for x in range(w):
+                if y < fh and x < fw:
+                    continue
+                blk = src[y * f:min(y * f + f, H), x * f:min(x * f + f, W)]
+                if blk.size:
+                    acc = np.float32(0)
+                    for v in blk.reshape(-1):
+                        acc = np.float32(acc + v)
+                    out[y, x] = acc / np.float32(blk.size)
+        return out
+    xdi, xsi, xal = _area_tab(W, w, scale)
+    ydi, ysi, yal = _area_tab(H, h, scale)
+    buf = {int(sy): _accumulate_in_order(w, xdi, src[sy][xsi] * xal) for sy in np.unique(ysi)}
+    vals = np.stack([yal[k] * buf[int(ysi[k])] for k in range(len(ydi))])
+    return _accumulate_in_order(h, ydi, vals)
+
+
+def _cubic_coeffs(x):
+    """interpolateCubic (imgproc/src/resize.cpp), A = -0.75, in float."""
+    import numpy as np
+    f = np.float32
+    A = f(-0.75)
+    x = x.astype(np.float32)
+    c0 = ((A * (x + f(1)) - f(5) * A) * (x + f(1)) + f(8) * A) * (x + f(1)) - f(4) * A
+    c1 = ((A + f(2)) * x - (A + f(3))) * x * x + f(1)
+    c2 = ((A + f(2)) * (f(1) - x) - (A + f(3))) * (f(1) - x) * (f(1) - x) + f(1)
+    c3 = f(1) - c0 - c1 - c2
+    return c0, c1, c2, c3
+
+
+def _resize_cubic_f32(img, w: int, h: int, scale: float):
+    """cv::resize(img, Size(), 1/scale, 1/scale, INTER_CUBIC) of a float image (`scale` = OpenCV's scale_x = scale_y < 1 when enlarging): resizeGeneric_ with
+    HResizeCubic / VResizeCubic in their scalar form -- source position (d + 0.5) * scale - 0.5 in float, four taps around its floor with interpolateCubic's weights,
+    taps outside the image clamped to the border, rows first, then columns, each as ((t0*c0 + t1*c1) + t2*c2) + t3*c3 in float.  OpenCV's own SIMD column pass fuses and
+    reorders these products depending on how it was built, so the last bit of this resampling is not defined by the reference either: unpinned."""
+    import numpy as np
+    H, W = img.shape
+    src = np.ascontiguousarray(img, np.float32)
+
+    def taps(n_dst, n_src):
+        fx = ((np.arange(n_dst) + 0.5) * scale - 0.5).astype(np.float32)
+        sx = np.floor(fx).astype(np.int64)
+        fx = fx - sx.astype(np.float32)
+        idx = np.clip(sx[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
+        return idx, _cubic_coeffs(fx)
+
+    xi, (a0, a1, a2, a3) = taps(w, W)
+    rows = ((src[:, xi[:, 0]] * a0 + src[:, xi[:, 1]] * a1) + src[:, xi[:, 2]] * a2) + src[:, xi[:, 3]] * a3          # [H, w]
+    yi, (b0, b1, b2, b3) = taps(h, H)
+    return (((rows[yi[:, 0]] * b0[:, None] + rows[yi[:, 1]] * b1[:, None]) + rows[yi[:, 2]] * b2[:, None]) + rows[yi[:, 3]] * b3[:, None]).astype(np.float32)
+
+
+def scale_image(gray, scale):
+    """`DepthData::ViewData::ScaleImage` (libs/MVS/DepthMap.h:198-204): None if the scale is within 15 % of 1, else cv::resize(image, Size(), scale, scale,
+    scale > 1 ? INTER_CUBIC : INTER_AREA) -- destination size saturate_cast<int>(size * scale) (round half to even)."""
+    import numpy as np
+    if not need_scale_image(scale):
+        return None
+    s = float(np.float32(scale))
+    H, W = gray.shape
+    w, h = int(np.rint(W * s)), int(np.rint(H * s))
+    if w < 1 or h < 1:
+        raise ValueError("scale %g leaves no image" % s)
+    return _resize_cubic_f32(gray, w, h, 1.0 / s) if s > 1 else _resize_area_f32(gray, w, h, 1.0 / s)
+
+
 def load_scene(mvs_path: str, opt=None, image_loader=None, view_neighbors_file=None, ignore_mask_label=None, mask_path=None, mask_loader=None):
     """Reads an MVSI scene and its images and runs view selection + depth initialisation for every valid image.
 
@@ -182,9 +302,8 @@ def load_scene(mvs_path: str, opt=None, image_loader=None, view_neighbors_file=N
         if (w, h) != (W, H):
             rgb = _resize_area_u8(rgb, w, h)
         rgbs.append(rgb); sizes.append((w, h))
-    if len(set(sizes)) != 1:
-        raise NotImplementedError("the batch scene interface needs one image resolution; got %s" % sorted(set(sizes)))
-    sv.width, sv.height = sizes[0]
+    sv.width, sv.height = max(set(sizes), key=lambda wh: (sizes.count(wh), -sizes.index(wh)))     # the scene's size: the most frequent one; the other images carry their own
+    sv.sizes = list(sizes)
     if ignore_mask_label >= 0:
         sv.mask_option = True
         if mask_loader is None:
@@ -211,9 +330,30 @@ def load_scene(mvs_path: str, opt=None, image_loader=None, view_neighbors_file=N
             sv.neighbors.append(np.zeros(0, np.int32)); sv.view_scores.append(None); sv.dmin.append(0.1); sv.dmax.append(100.0)
             continue
         nb, points, _ = sel
-        if np.any(np.abs(nb["scale"] - 1) >= 0.15):          # DepthData::ViewData::NeedScaleImage, libs/MVS/DepthMap.h:194-197
-            raise NotImplementedError("image %d: a neighbour needs rescaling (scale %s)" % (i, nb["scale"]))
         d, n, dmin, dmax = views.init_depth_map(sc, cams, i, points, opt)
         sv.ids.append(i); sv.neighbors.append(nb["ID"].astype(np.int32)); sv.view_scores.append(nb)
         sv.dmin.append(dmin); sv.dmax.append(dmax); sv.init_depth[i] = d; sv.init_normal[i] = n
+    # InitViews, SceneDensify.cpp:333-352: a neighbour whose footprint differs by 15 % or more enters the estimation as a RESAMPLED image with the camera of that size
+    # (ViewData::ScaleImage).  Each (image, scale) pair becomes an extra source-only slot behind the images; the reference view's estimation list points at it, while
+    # `neighbors` keeps the image itself -- whose own depth map, at its own size and camera, is what the geometric rounds, the cross-view filter and the fusion read
+    # (cameraDepthMap, :378-393; FilterDepthMap / FuseDepthMaps go through arrDepthData[ID]).
+    n_img = len(sc.images)
+    sv.estimate_neighbors = [nb.copy() for nb in sv.neighbors]
+    made = {}
+    for i in sv.ids:
+        for k, v in enumerate(sv.view_scores[i]):
+            j, scale = int(v["ID"]), np.float32(v["scale"])
+            if not need_scale_image(scale):
+                continue
+            key = (j, float(scale))
+            if key not in made:
+                img = scale_image(sv.gray[j], scale)
+                Kj, Rj, Cj, w, h = sc.camera(j, (img.shape[1], img.shape[0]))          # Image::GetCamera(platforms, image.size())
+                made[key] = len(sv.gray)
+                sv.alias_of[made[key]] = j
+                sv.gray.append(img); sv.K.append(Kj); sv.R.append(Rj); sv.C.append(Cj); sv.sizes.append((w, h)); sv.names.append(sv.names[j])
+                sv.dmin.append(sv.dmin[j]); sv.dmax.append(sv.dmax[j]); sv.neighbors.append(np.zeros(0, np.int32)); sv.estimate_neighbors.append(np.zeros(0, np.int32))
+                sv.view_scores.append(None)
+            sv.estimate_neighbors[i][k] = made[key]
+    assert len(sv.gray) == n_img + len(sv.alias_of)
     return sv

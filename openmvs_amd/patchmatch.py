@@ -212,8 +212,11 @@ class PatchMatchHIP:
     def scene_load(self, scene, n_levels=2):
         """Upload a synth.Scene (or anything with the same attributes)."""
         self.scene_create(scene.n_views, scene.width, scene.height, n_levels)
+        sizes = getattr(scene, "sizes", None) or []
+        nbs = getattr(scene, "estimate_neighbors", None) or scene.neighbors       # (a densify.SceneViews lists resampled copies of neighbours here, ViewData::ScaleImage)
         for i in range(scene.n_views):
-            self.scene_set_view(i, scene.gray[i], scene.K[i], scene.R[i], scene.C[i], float(scene.dmin[i]), float(scene.dmax[i]), scene.neighbors[i])
+            own = i < len(sizes) and tuple(sizes[i]) != (scene.width, scene.height)
+            (self.scene_set_view_sized if own else self.scene_set_view)(i, scene.gray[i], scene.K[i], scene.R[i], scene.C[i], float(scene.dmin[i]), float(scene.dmax[i]), nbs[i])
         # ignore masks of a scene loaded with --ignore-mask-label (densify.load_scene): per image where a mask file was found; the option alone already selects the
         # nearest-neighbour level hand-off (SceneDensify.cpp:661)
         for i, m in getattr(scene, "masks", {}).items():

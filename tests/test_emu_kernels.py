@@ -108,6 +108,11 @@ def test_estimator_reference_views_of_different_sizes(pm_emulated):
     g.test_sized_view_api_edges(64, 48)
 
 
+def test_estimator_resampled_neighbour_copies_through_the_driver(pm_emulated):
+    from tests import test_gpu_patchmatch as g
+    g.test_resampled_neighbour_copies_through_the_driver(80, 60)           # ViewData::ScaleImage: copies in extra slots, handed their images' depth maps at the round boundary
+
+
 def test_estimator_mixed_resolution_neighbours(engine):
     from tests import test_gpu_patchmatch as g
     g.test_mixed_resolution_neighbours_parity(engine)                        # sources at 0.8x / 1.25x, cameraDepthMap of another size

@@ -745,6 +745,61 @@ def test_mixed_resolution_neighbours_parity(engine, W=160, H=120):
     e.close()
 
 
+def test_resampled_neighbour_copies_through_the_driver(W=160, H=120):
+    """ViewData::ScaleImage through the scene front end's bookkeeping (densify.SceneViews with `alias_of` / `estimate_neighbors`, as densify.load_scene builds them) and
+    densify.compute_depth_maps: reference view 0 reads two of its neighbours as RESAMPLED copies (0.8x: INTER_AREA, 1.25x: INTER_CUBIC, densify.scale_image) in extra
+    source-only slots; in the geometric round the copies stand for their images' previous-round depth maps at the images' own size and camera (the saved .dmap,
+    SceneDensify.cpp:378-393).  Every view's final map equals the oracle given exactly those inputs."""
+    from openmvs_amd import densify
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    base = synth.make_scene(5, W, H, n_src=4)
+    ref = 0
+    nb0 = [int(i) for i in base.neighbors[ref]]
+    s1, s2 = nb0[0], nb0[1]
+    sv = densify.SceneViews()
+    sv.width, sv.height = W, H
+    sv.gray = [g for g in base.gray]; sv.K = [k for k in base.K]; sv.R = [r for r in base.R]; sv.C = [c for c in base.C]
+    sv.dmin = [float(x) for x in base.dmin]; sv.dmax = [float(x) for x in base.dmax]
+    sv.neighbors = [np.asarray(n, np.int32) for n in base.neighbors]; sv.ids = list(range(5)); sv.sizes = [(W, H)] * 5
+    sv.estimate_neighbors = [n.copy() for n in sv.neighbors]
+    for j, scale in ((s1, 0.8), (s2, 1.25)):
+        img = densify.scale_image(base.gray[j], scale)
+        h, w = img.shape
+        f = max(w, h) / float(max(W, H))                                            # Image::GetCamera at the copy's size: K through the normalised form (Camera::ScaleK)
+        Kc = np.array(base.K[j], np.float64)
+        Kc = np.array([[Kc[0, 0] * f, 0, (Kc[0, 2] + 0.5) * f - 0.5], [0, Kc[1, 1] * f, (Kc[1, 2] + 0.5) * f - 0.5], [0, 0, 1]])
+        a = len(sv.gray)
+        sv.alias_of[a] = j
+        sv.gray.append(img); sv.K.append(Kc); sv.R.append(base.R[j]); sv.C.append(base.C[j]); sv.sizes.append((w, h))
+        sv.dmin.append(sv.dmin[j]); sv.dmax.append(sv.dmax[j]); sv.neighbors.append(np.zeros(0, np.int32)); sv.estimate_neighbors.append(np.zeros(0, np.int32))
+        sv.estimate_neighbors[ref][list(sv.neighbors[ref]).index(j)] = a
+    seed = 41
+    p = default_params(seed=seed, nEstimationGeometricIters=1)
+    e = PatchMatchHIP(0)
+    e.scene_load(sv, n_levels=2)
+    densify.compute_depth_maps(e, sv.ids, p, n_optimize=0, scene=sv)
+    # the oracle, view by view: photometric pass (view 0 with the copies' images and cameras), then the geometric round on the photometric maps of the images themselves
+    def views_of(i, depth_maps=None, depth_cams=None):
+        slots = [i] + [int(s) for s in sv.estimate_neighbors[i]]
+        gray = {s: sv.gray[s] for s in slots}; K = {s: sv.K[s] for s in slots}; R = {s: sv.R[s] for s in slots}; C = {s: sv.C[s] for s in slots}
+        dm = None if depth_maps is None else {s: depth_maps[sv.alias_of.get(s, s)] for s in slots[1:]}
+        dc = None if depth_cams is None else {s: depth_cams[sv.alias_of.get(s, s)] for s in slots[1:]}
+        return po.make_views(gray, K, R, C, slots, depth_maps=dm, depth_cams=dc), slots
+    photo = {}
+    for i in sv.ids:
+        (vw, keep), slots = views_of(i)
+        photo[i] = po.estimate_depth_map(vw, len(slots), sv.dmin[i], sv.dmax[i], po.default_opt(seed=seed, viewID=i, nEstimationGeometricIters=1))
+    cams = {i: (sv.K[i], sv.R[i], sv.C[i]) for i in sv.ids}
+    for i in sv.ids:
+        (vw, keep), slots = views_of(i, {j: photo[j][0] for j in sv.ids}, cams)
+        gd, gn, gc = po.estimate_depth_map(vw, len(slots), sv.dmin[i], sv.dmax[i], po.default_opt(seed=seed, viewID=i, nEstimationGeometricIters=1), geo_iter=0,
+                                           depth=photo[i][0], normal=photo[i][1])
+        d, n, c = e.scene_get_maps(i)
+        _same(d, gd, "view %d, depth after the geometric round" % i); _same(n, gn, "normal"); _same(c, gc, "conf")
+    assert (e.scene_get_maps(ref)[0] > 0).mean() > 0.5
+    e.close()
+
+
 def test_reference_views_of_different_sizes(W=160, H=120, quick=False):
     """Reference views of different sizes in one scene: the reference sizes every DepthData on its own image (DepthMapsData::InitViews, SceneDensify.cpp:306-459).
     Five views, three sizes (1x, 0.8x, 1.25x), estimated by ONE call (one sweep per size class), then the geometric round (every view reads its neighbours'

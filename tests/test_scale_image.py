@@ -1,0 +1,242 @@
+"""DepthData::ViewData::ScaleImage in the scene front end (openmvs_amd/densify.py): the float resamplers against literal per-pixel walks of OpenCV's published algorithms
+(OpenCV itself is not vendored with the reference: unpinned), resampled copies of neighbours as extra source-only slots, images of different sizes, and the
+driver's hand-offs at the round boundaries (recorded on a stand-in engine; the engine side of sized source views with their own stored depth maps is
+tests/test_gpu_patchmatch.py::test_mixed_resolution_neighbours_parity)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from openmvs_amd import densify, mvsi, views
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCENE = os.path.join(HERE, "data", "scene", "scene.mvs")
+f32 = np.float32
+
+
+def _area_literal(src, w, h, scale):
+    """computeResizeAreaTab + ResizeArea_Invoker for one float channel, statement by statement (imgproc/src/resize.cpp)."""
+    def tab(ssize, dsize):
+        t = []
+        for dx in range(dsize):
+            fsx1 = dx * scale; fsx2 = fsx1 + scale
+            cell = min(scale, ssize - fsx1)
+            sx1, sx2 = math.ceil(fsx1), math.floor(fsx2)
+            sx2 = min(sx2, ssize - 1); sx1 = min(sx1, sx2)
+            if sx1 - fsx1 > 1e-3:
+                t.append((dx, sx1 - 1, f32((sx1 - fsx1) / cell)))
+            for sx in range(sx1, sx2):
+                t.append((dx, sx, f32(1.0 / cell)))
+            if fsx2 - sx2 > 1e-3:
+                t.append((dx, sx2, f32(min(min(fsx2 - sx2, 1.0), cell) / cell)))
+        return t
+    H, W = src.shape
+    xtab, ytab = tab(W, w), tab(H, h)
+    dst = np.zeros((h, w), f32)
+    total = np.zeros(w, f32); prev = ytab[0][0]
+    for dy, sy, beta in ytab:
+        buf = np.zeros(w, f32)
+        for dx, sx, alpha in xtab:
+            buf[dx] = f32(buf[dx] + f32(src[sy, sx] * alpha))
+        if dy != prev:
+            dst[prev] = total
+            total = (beta * buf).astype(f32)
+            prev = dy
+        else:
+            total = (total + (beta * buf).astype(f32)).astype(f32)
+    dst[prev] = total
+    return dst
+
+
+def _cubic_literal(src, w, h, scale):
+    """resizeGeneric_ with HResizeCubic / VResizeCubic in scalar form."""
+    A = f32(-0.75)
+
+    def coeffs(x):
+        c0 = f32(f32(f32(f32(f32(A * f32(x + 1)) - f32(5 * A)) * f32(x + 1)) + f32(8 * A)) * f32(x + 1)) - f32(4 * A)
+        c1 = f32(f32(f32(f32(f32(A + 2) * x) - f32(A + 3)) * x) * x) + f32(1)
+        y = f32(1 - x)
+        c2 = f32(f32(f32(f32(f32(A + 2) * y) - f32(A + 3)) * y) * y) + f32(1)
+        return f32(c0), f32(c1), f32(c2), f32(f32(f32(f32(1) - f32(c0)) - f32(c1)) - f32(c2))
+    H, W = src.shape
+    rows = np.zeros((H, w), f32)
+    for dx in range(w):
+        fx = f32((dx + 0.5) * scale - 0.5); sx = math.floor(fx); fx = f32(fx - f32(sx))
+        c = coeffs(fx)
+        for y in range(H):
+            v = f32(0)
+            for j in range(4):
+                sxj = min(max(sx + j - 1, 0), W - 1)
+                v = f32(v + f32(src[y, sxj] * c[j]))
+            rows[y, dx] = v
+    dst = np.zeros((h, w), f32)
+    for dy in range(h):
+        fy = f32((dy + 0.5) * scale - 0.5); sy = math.floor(fy); fy = f32(fy - f32(sy))
+        b = coeffs(fy)
+        r = [rows[min(max(sy - 1 + k, 0), H - 1)] for k in range(4)]
+        dst[dy] = ((r[0] * b[0] + r[1] * b[1]) + r[2] * b[2]) + r[3] * b[3]
+    return dst
+
+
+@pytest.mark.parametrize("shape,scale", [((23, 31), 0.8), ((23, 31), 0.6), ((19, 17), 0.35), ((16, 24), 0.5), ((17, 25), 0.5), ((18, 21), 1 / 3), ((20, 20), 0.25)])
+def test_scale_image_shrinks_with_the_area_paths(shape, scale):
+    rng = np.random.default_rng(hash((shape, scale)) & 0xFFFF)
+    img = rng.random(shape).astype(f32)
+    out = densify.scale_image(img, scale)
+    s = float(f32(scale)); H, W = shape
+    w, h = int(np.rint(W * s)), int(np.rint(H * s))
+    assert out.shape == (h, w) and out.dtype == f32
+    sc = 1.0 / s
+    if abs(sc - round(sc)) < np.finfo(np.float64).eps:          # integer factor: the estimator pyramid's own rule (oracle/pm_oracle.cpp resizeArea), cut blocks averaged
+        f = int(round(sc))
+        for y in range(h):
+            for x in range(w):
+                blk = img[y * f:y * f + f, x * f:x * f + f]
+                if blk.shape == (f, f) and f == 2:
+                    want = ((blk[0, 0] + blk[0, 1]) + (blk[1, 0] + blk[1, 1])) * f32(0.25)
+                else:
+                    acc = f32(0)
+                    for v in blk.reshape(-1):
+                        acc = f32(acc + v)
+                    want = f32(acc * f32(1.0 / (f * f))) if blk.shape == (f, f) else f32(acc / f32(blk.size))
+                assert out[y, x] == want, (y, x)
+    else:
+        assert np.array_equal(out, _area_literal(img, w, h, sc))
+    assert abs(float(out.mean()) - float(img.mean())) < 0.05
+
+
+@pytest.mark.parametrize("shape,scale", [((13, 17), 1.25), ((11, 9), 1.5), ((8, 12), 2.0), ((10, 10), 1.2)])
+def test_scale_image_enlarges_with_the_cubic_path(shape, scale):
+    rng = np.random.default_rng(int(scale * 100))
+    img = rng.random(shape).astype(f32)
+    out = densify.scale_image(img, scale)
+    s = float(f32(scale)); H, W = shape
+    w, h = int(np.rint(W * s)), int(np.rint(H * s))
+    assert out.shape == (h, w) and np.array_equal(out, _cubic_literal(img, w, h, 1.0 / s))
+    ramp = np.tile(np.arange(W, dtype=f32), (H, 1))              # sanity: a ramp stays a ramp away from the clamped border (OpenCV's A = -0.75 kernel is not exact on it)
+    r = densify.scale_image(ramp, scale)
+    xs = (np.arange(w) + 0.5) / s - 0.5
+    inner = (xs > 1) & (xs < W - 2)
+    assert np.allclose(r[:, inner], np.tile(xs[inner], (h, 1)), atol=0.06)
+    assert np.allclose(densify.scale_image(np.full(shape, 0.37, f32), scale), 0.37, atol=1e-6)
+
+
+def test_need_scale_image_is_the_float_test():
+    assert not densify.need_scale_image(1.0) and not densify.need_scale_image(1.1499) and not densify.need_scale_image(0.8501)
+    assert densify.need_scale_image(1.15) == bool(abs(f32(1.15) - f32(1)) >= f32(0.15)) and densify.need_scale_image(0.85) == bool(abs(f32(0.85) - f32(1)) >= f32(0.15))
+    assert densify.need_scale_image(0.8) and densify.need_scale_image(1.3) and densify.scale_image(np.zeros((4, 4), f32), 1.05) is None
+
+
+class _Recorder:
+    """Stands in for PatchMatchHIP: records the scene calls of densify.compute_depth_maps / scene_load."""
+
+    def __init__(self, n, shapes):
+        self.calls, self.shapes = [], shapes
+        self.depth = {i: np.full(shapes[i], float(i + 1), f32) for i in range(n)}
+
+    def __getattr__(self, name):
+        def rec(*a, **k):
+            self.calls.append((name,) + tuple(a))
+            if name == "scene_get_maps":
+                return self.depth[a[0]], None, None
+        return rec
+
+
+@pytest.fixture(scope="module")
+def scaled_scene(tmp_path_factory):
+    """The pipeline-test scene with stored view scores (archive version 7) in which image 0 sees image 1 at 0.8x and image 2 at 1.25x, and image 3 sees image 1 at 0.8x too."""
+    py = mvsi.load(SCENE)
+    cams = views.Cameras(py)
+    for i, im in enumerate(py.images):
+        ok, nb, pts, avg = views.select_neighbor_views(py, cams, i)
+        assert ok
+        nb = nb.copy()
+        if i == 0:
+            nb["scale"][nb["ID"] == 1] = 0.8; nb["scale"][nb["ID"] == 2] = 1.25
+        if i == 3:
+            nb["scale"][nb["ID"] == 1] = 0.8
+        im.view_scores, im.avg_depth = nb, avg
+    d = tmp_path_factory.mktemp("scaled")
+    p = str(d / "scene7.mvs")
+    mvsi.save(p, py, version=7)
+    rng = np.random.default_rng(5)
+    imgs = {im.name: rng.integers(0, 255, (120, 160, 3)).astype(np.uint8) for im in py.images}
+    return p, (lambda path: imgs[os.path.relpath(path, str(d)).replace(os.sep, "/")] if os.path.relpath(path, str(d)).replace(os.sep, "/") in imgs else imgs[[k for k in imgs if path.endswith(k)][0]])
+
+
+def test_load_scene_makes_resampled_copies_of_neighbours(scaled_scene):
+    path, loader = scaled_scene
+    sv = densify.load_scene(path, opt=views.DenseOptions(nResolutionLevel=0, nMinResolution=64), image_loader=loader)
+    assert (sv.width, sv.height) == (160, 120) and sv.n_views == 4 + 2                      # image 1 at 0.8x is needed twice and made once
+    a08 = [a for a, j in sv.alias_of.items() if j == 1]; a125 = [a for a, j in sv.alias_of.items() if j == 2]
+    assert len(a08) == 1 and len(a125) == 1 and sorted(sv.alias_of) == [4, 5]
+    assert sv.sizes[a08[0]] == (128, 96) and sv.gray[a08[0]].shape == (96, 128) and sv.sizes[a125[0]] == (200, 150) and sv.gray[a125[0]].shape == (150, 200)
+    assert np.array_equal(sv.gray[a08[0]], densify.scale_image(sv.gray[1], 0.8)) and np.array_equal(sv.gray[a125[0]], densify.scale_image(sv.gray[2], 1.25))
+    sc = mvsi.load(path)
+    for a, (w, h) in ((a08[0], (128, 96)), (a125[0], (200, 150))):
+        K, R, C, _, _ = sc.camera(sv.alias_of[a], (w, h))                                  # Image::GetCamera(platforms, image.size())
+        assert np.array_equal(sv.K[a], K) and np.array_equal(sv.R[a], R) and np.array_equal(sv.C[a], C)
+        assert len(sv.neighbors[a]) == 0 and len(sv.estimate_neighbors[a]) == 0 and a not in sv.ids
+        assert abs(sv.K[a][0, 0] / sv.K[sv.alias_of[a]][0, 0] - w / 160) < 1e-12
+    e0 = list(sv.estimate_neighbors[0]); n0 = list(sv.neighbors[0])
+    assert [sv.alias_of.get(s, s) for s in e0] == n0 and a08[0] in e0 and a125[0] in e0 and 1 not in e0 and 2 not in e0
+    assert a08[0] in list(sv.estimate_neighbors[3]) and list(sv.estimate_neighbors[1]) == list(sv.neighbors[1]) and list(sv.estimate_neighbors[2]) == list(sv.neighbors[2])
+    # the engine is loaded with the estimation lists; the copies as sized source-only views
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    rec = _Recorder(6, {i: (sv.sizes[i][1], sv.sizes[i][0]) for i in range(6)})
+    PatchMatchHIP.scene_load(rec, sv, n_levels=2)
+    kinds = [c[0] for c in rec.calls]
+    assert kinds == ["scene_create"] + ["scene_set_view"] * 4 + ["scene_set_view_sized"] * 2 and rec.calls[0][1:] == (6, 160, 120, 2)
+    assert list(rec.calls[1][-1]) == e0 and rec.calls[5][1] == 4 and rec.calls[5][2].shape == sv.gray[4].shape
+    # the driver: after every commit the copies receive the depth map of their image with its own camera; the filter sees the images themselves
+    rec.calls.clear()
+    from openmvs_amd.patchmatch import PMHipParams
+    p = PMHipParams(); p.nEstimationGeometricIters = 2
+    densify.compute_depth_maps(rec, sv.ids, p, scene=sv)
+    seq = [(c[0], c[1] if len(c) > 1 and not isinstance(c[1], (list, np.ndarray)) else None) for c in rec.calls]
+    names = [s[0] for s in seq]
+    i_commit = [k for k, n in enumerate(names) if n == "scene_commit_round"]
+    assert len(i_commit) == 2
+    for k in i_commit:
+        after = rec.calls[k + 1:k + 1 + 2 * len(sv.alias_of)]
+        assert [c[0] for c in after] == ["scene_get_maps", "scene_set_source_depth"] * len(sv.alias_of)
+        for g, s_ in zip(after[0::2], after[1::2]):
+            a, j = s_[1], g[1]
+            assert sv.alias_of[a] == j and np.array_equal(s_[2], rec.depth[j]) and np.array_equal(s_[3], sv.K[j]) and np.array_equal(s_[4], sv.R[j]) and np.array_equal(s_[5], sv.C[j])
+        assert names[k + 1 + 2 * len(sv.alias_of)] == "Init"
+    i_filter = names.index("scene_filter")
+    back = [c for c in rec.calls[:i_filter] if c[0] == "scene_set_view"]
+    assert sorted(c[1] for c in back) == [0, 3] and all(c[2] is None for c in back)
+    assert list(back[0][-1]) == list(sv.neighbors[back[0][1]]) and names.index("scene_set_view") > i_commit[-1]
+    # without copies nothing changes for the driver
+    rec.calls.clear()
+    densify.compute_depth_maps(rec, sv.ids, p)
+    assert "scene_set_source_depth" not in [c[0] for c in rec.calls] and "scene_set_view" not in [c[0] for c in rec.calls]
+
+
+def test_load_scene_takes_images_of_different_sizes(scaled_scene):
+    path, loader = scaled_scene
+    py = mvsi.load(SCENE)
+    small = py.images[2].name
+
+    def mixed(p):
+        img = loader(p)
+        return img[:90, :120] if p.endswith(small) else img          # image 2 is 120x90, the others 160x120
+
+    sv = densify.load_scene(SCENE, opt=views.DenseOptions(nResolutionLevel=0, nMinResolution=64), image_loader=mixed)
+    assert (sv.width, sv.height) == (160, 120) and sv.sizes[2] == (120, 90) and sv.sizes[0] == (160, 120)
+    assert sv.gray[2].shape == (90, 120) and sv.init_depth[2].shape == (90, 120) and sv.init_depth[0].shape == (120, 160)
+    # the footprints now differ by the resolution ratio, so the reference's rule resamples across it: image 2 is seen enlarged by ~4/3 by the others, and sees them at ~3/4
+    assert sv.alias_of and set(sv.alias_of.values()) >= {2}
+    for a, j in sv.alias_of.items():
+        scales = [float(v["scale"]) for i in sv.ids for v in sv.view_scores[i] if int(v["ID"]) == j and densify.need_scale_image(v["scale"])]
+        W, H = sv.sizes[j]
+        assert sv.sizes[a] in [(int(np.rint(W * float(f32(s)))), int(np.rint(H * float(f32(s))))) for s in scales]
+        assert (j == 2) == (sv.sizes[a][0] > sv.sizes[j][0])                                  # image 2 only ever grows, the others only shrink
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    n = sv.n_views
+    rec = _Recorder(n, {i: (sv.sizes[i][1], sv.sizes[i][0]) for i in range(n)})
+    PatchMatchHIP.scene_load(rec, sv)
+    assert [c[0] for c in rec.calls][:5] == ["scene_create", "scene_set_view", "scene_set_view", "scene_set_view_sized", "scene_set_view"]
+    assert all((c[0] == "scene_set_view_sized") == (tuple(sv.sizes[c[1]]) != (160, 120)) for c in rec.calls[1:])

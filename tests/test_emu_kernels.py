@@ -110,7 +110,7 @@ def test_estimator_reference_views_of_different_sizes(pm_emulated):
 
 def test_estimator_resampled_neighbour_copies_through_the_driver(pm_emulated):
     from tests import test_gpu_patchmatch as g
-    g.test_resampled_neighbour_copies_through_the_driver(80, 60)           # ViewData::ScaleImage: copies in extra slots, handed their images' depth maps at the round boundary
+    g.resampled_neighbour_copies_through_the_driver(80, 60)           # ViewData::ScaleImage: copies in extra slots, handed their images' depth maps at the round boundary
 
 
 def test_estimator_mixed_resolution_neighbours(engine):

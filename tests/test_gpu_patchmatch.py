@@ -745,7 +745,7 @@ def test_mixed_resolution_neighbours_parity(engine, W=160, H=120):
     e.close()
 
 
-def test_resampled_neighbour_copies_through_the_driver(W=160, H=120):
+def resampled_neighbour_copies_through_the_driver(W=160, H=120):
     """ViewData::ScaleImage through the scene front end's bookkeeping (densify.SceneViews with `alias_of` / `estimate_neighbors`, as densify.load_scene builds them) and
     densify.compute_depth_maps: reference view 0 reads two of its neighbours as RESAMPLED copies (0.8x: INTER_AREA, 1.25x: INTER_CUBIC, densify.scale_image) in extra
     source-only slots; in the geometric round the copies stand for their images' previous-round depth maps at the images' own size and camera (the saved .dmap,

@@ -15,14 +15,20 @@ REMOVE_SPECKLES, FILL_GAPS, ADJUST_FILTER = 1, 2, 4   # OPTDENSE::DepthFlags, li
 
 def compute_depth_maps(engine, view_ids, params, n_optimize: int = 7, b_filter_adjust: bool = True,
                        n_speckle_size: int = 100, n_ipol_gap_size: int = 7, f_depth_diff_threshold: float = 0.01,
-                       n_min_views_filter: int = 2, n_min_views_filter_adjust: int = 1, init_depth=None, init_normal=None, scene=None):
+                       n_min_views_filter: int = 2, n_min_views_filter_adjust: int = 1, init_depth=None, init_normal=None, scene=None, dmap_dir=None, image_names=None):
     """Runs the reference's dense schedule for `view_ids` on a loaded scene (engine.scene_load / scene_set_view).
     `init_depth` / `init_normal` (dicts view id -> map) seed the photometric pass like `InitViews(..., loadDepthMaps=0)` does
     (SceneDensify.cpp:418-460); views without an entry start from random planes.
     `scene`: the `SceneViews` the engine was loaded from, needed when it holds resampled copies of neighbours (`alias_of`, ViewData::ScaleImage): at every round
     boundary a copy is handed the depth map of the image it stands for, at that image's size and camera (the neighbour's saved .dmap, SceneDensify.cpp:378-393), and
-    before the cross-view filter the reference views get their image neighbours back (FilterDepthMap reads arrDepthData[ID], :1049-1299)."""
+    before the cross-view filter the reference views get their image neighbours back (FilterDepthMap reads arrDepthData[ID], :1049-1299).
+    `dmap_dir` (needs `scene`): the reference's file-based checkpoint contract (SceneDensify.cpp:2010-2029,1943-1950).  A view whose `depthNNNN.dmap` is already there
+    is NOT estimated in the photometric pass: its depth, normal and confidence maps are read back and the schedule carries on from them (every view takes part in the geometric
+    rounds again, as there); every map is written when it has been estimated -- after the photometric pass, after each geometric round (the reference's .geo.dmap + rename)
+    and after the filters -- each file atomically (.tmp + rename, DepthData::Save).  Returns the views whose maps were resumed from files."""
     ids = list(view_ids)
+    if dmap_dir is not None and scene is None:
+        raise ValueError("dmap_dir needs the scene (cameras, neighbours and depth ranges go into the files)")
     G = int(params.nEstimationGeometricIters)
     alias_of = dict(getattr(scene, "alias_of", None) or {})
 
@@ -41,14 +47,31 @@ def compute_depth_maps(engine, view_ids, params, n_optimize: int = 7, b_filter_a
         if n_optimize & FILL_GAPS:
             engine.scene_gap_interpolation(ids, n_ipol_gap_size, f_depth_diff_threshold)
 
+    def save(which):
+        if dmap_dir is not None and which:
+            save_depth_maps(engine, scene, which, dmap_dir, image_names)
+
     engine.Init(False)
+    resumed = []
     for v in ids:
         engine.scene_reset_view(v)
-        if init_depth is not None and v in init_depth:
+        done = os.path.join(dmap_dir, _dmap.depth_file_name(int(v))) if dmap_dir is not None else None
+        if done is not None and os.path.exists(done):          # depthmapComputed (SceneDensify.cpp:2010): loaded instead of estimated
+            f = _dmap.load(done)
+            want = tuple(scene.sizes[v])[::-1] if getattr(scene, "sizes", None) else (scene.height, scene.width)
+            if f["depth_map"].shape != want or f.get("confidence_map") is None:
+                raise ValueError("%s does not hold the maps of view %d (%s, expected %s with a confidence map)" % (done, v, f["depth_map"].shape, want))
+            engine.scene_set_maps(v, f["depth_map"], f.get("normal_map"))
+            engine.scene_set_conf(v, f["confidence_map"])
+            resumed.append(v)
+        elif init_depth is not None and v in init_depth:
             engine.scene_set_maps(v, init_depth[v], None if init_normal is None else init_normal.get(v))
-    engine.scene_estimate(ids, -1, params)
+    todo = [v for v in ids if v not in resumed]
+    if todo:
+        engine.scene_estimate(todo, -1, params)
     if G == 0:
         post()
+    save(ids if (G == 0 and n_optimize & (REMOVE_SPECKLES | FILL_GAPS)) else todo)
     for g in range(G):
         engine.scene_commit_round()
         hand_depths_to_copies()
@@ -56,9 +79,12 @@ def compute_depth_maps(engine, view_ids, params, n_optimize: int = 7, b_filter_a
         engine.scene_estimate(ids, g, params)
         if g + 1 == G:
             post()
+        save(ids)
     image_neighbours()
     if n_optimize & ADJUST_FILTER:
         engine.scene_filter(ids, b_filter_adjust, n_min_views_filter, n_min_views_filter_adjust, f_depth_diff_threshold, commit=True)
+        save(ids)
+    return resumed
 
 
 def save_depth_maps(engine, scene, view_ids, out_dir: str, image_names=None):

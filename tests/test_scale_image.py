@@ -240,3 +240,39 @@ def test_load_scene_takes_images_of_different_sizes(scaled_scene):
     PatchMatchHIP.scene_load(rec, sv)
     assert [c[0] for c in rec.calls][:5] == ["scene_create", "scene_set_view", "scene_set_view", "scene_set_view_sized", "scene_set_view"]
     assert all((c[0] == "scene_set_view_sized") == (tuple(sv.sizes[c[1]]) != (160, 120)) for c in rec.calls[1:])
+
+
+def test_checkpoint_files_and_resume(tmp_path):
+    """The reference's file contract through densify.compute_depth_maps(dmap_dir=): a view whose depthNNNN.dmap exists is read back instead of estimated in the photometric
+    pass (SceneDensify.cpp:2010-2029), every estimated map is written (atomically) after the pass / each geometric round / the filters."""
+    from openmvs_amd import dmap, synth
+    from openmvs_amd.patchmatch import PMHipParams
+    sc = synth.make_scene(4, 32, 24, n_src=2)
+    sc.sizes = [(32, 24)] * 4
+    rec = _Recorder(4, {i: (24, 32) for i in range(4)})
+    full = rec.scene_get_maps                                         # depth from the recorder; give it normals and confidences too
+    rec.__dict__["scene_get_maps"] = lambda v: (rec.depth[v], np.zeros((24, 32, 3), f32), np.full((24, 32), 0.5, f32))
+    d = str(tmp_path / "dmaps")
+    p = PMHipParams(); p.nEstimationGeometricIters = 1
+    assert densify.compute_depth_maps(rec, [0, 1, 2, 3], p, scene=sc, dmap_dir=d) == []
+    assert sorted(os.listdir(d)) == ["depth%04d.dmap" % i for i in range(4)]              # no .tmp left behind
+    got = dmap.load(os.path.join(d, "depth0002.dmap"))
+    assert np.array_equal(got["depth_map"], rec.depth[2]) and got["reference_view_id"] == 2 and got["neighbor_view_ids"] == [int(i) for i in sc.neighbors[2]]
+    kinds = [c[0] for c in rec.calls]
+    assert kinds.count("scene_estimate") == 2 and list(rec.calls[kinds.index("scene_estimate")][1]) == [0, 1, 2, 3]
+    # second run: views 1 and 3 still have their files -> read back, only 0 and 2 go through the photometric pass; the geometric round takes all four
+    os.remove(os.path.join(d, "depth0000.dmap")); os.remove(os.path.join(d, "depth0002.dmap"))
+    rec.calls.clear()
+    assert densify.compute_depth_maps(rec, [0, 1, 2, 3], p, scene=sc, dmap_dir=d) == [1, 3]
+    est = [c for c in rec.calls if c[0] == "scene_estimate"]
+    assert list(est[0][1]) == [0, 2] and est[0][2] == -1 and list(est[1][1]) == [0, 1, 2, 3] and est[1][2] == 0
+    loaded = [c for c in rec.calls if c[0] in ("scene_set_maps", "scene_set_conf")]
+    assert [(c[0], c[1]) for c in loaded] == [("scene_set_maps", 1), ("scene_set_conf", 1), ("scene_set_maps", 3), ("scene_set_conf", 3)]
+    assert np.array_equal(loaded[0][2], rec.depth[1]) and np.array_equal(loaded[1][2], np.full((24, 32), 0.5, f32))
+    assert sorted(os.listdir(d)) == ["depth%04d.dmap" % i for i in range(4)]
+    # a file of another size is not this view's checkpoint
+    dmap.save(os.path.join(d, "depth0001.dmap"), "x.jpg", [1, 0], (16, 12), sc.K[1], sc.R[1], sc.C[1], 1.0, 2.0, np.ones((12, 16), f32), None, np.ones((12, 16), f32))
+    with pytest.raises(ValueError):
+        densify.compute_depth_maps(rec, [0, 1, 2, 3], p, scene=sc, dmap_dir=d)
+    with pytest.raises(ValueError):
+        densify.compute_depth_maps(rec, [0], p, dmap_dir=d)

@@ -119,6 +119,8 @@ class SceneViews:
         self.sizes = []                             # (w, h) of every slot: images of another size than the scene's carry their own (pmhip_scene_set_view_sized)
         self.estimate_neighbors = None              # per slot: the slots the ESTIMATION reads (a resampled copy where ViewData::ScaleImage applies); None = `neighbors`
         self.alias_of = {}                          # extra source-only slot -> the image it is a resampled copy of
+        self.all_view_scores = {}                   # image -> its WHOLE scored neighbour list (Image::neighbors: fusion order, and what a dense archive stores)
+        self.avg_depth = {}                         # image -> average depth of its sparse points (Image::avgDepth)
 
     @property
     def n_views(self):
@@ -351,11 +353,14 @@ def load_scene(mvs_path: str, opt=None, image_loader=None, view_neighbors_file=N
     for i, im in enumerate(sc.images):
         sv.gray.append(views.to_gray(rgbs[i])); sv.names.append(im.name)
         sv.K.append(cams.K[i]); sv.R.append(cams.R[i]); sv.C.append(cams.C[i])
-        sel = views.select_views(sc, cams, i, opt) if im.is_valid() else None
+        whole = []
+        sel = views.select_views(sc, cams, i, opt, all_neighbors=whole) if im.is_valid() else None
+        if whole:
+            sv.all_view_scores[i] = whole[0]
         if sel is None:
             sv.neighbors.append(np.zeros(0, np.int32)); sv.view_scores.append(None); sv.dmin.append(0.1); sv.dmax.append(100.0)
             continue
-        nb, points, _ = sel
+        nb, points, sv.avg_depth[i] = sel
         d, n, dmin, dmax = views.init_depth_map(sc, cams, i, points, opt)
         sv.ids.append(i); sv.neighbors.append(nb["ID"].astype(np.int32)); sv.view_scores.append(nb)
         sv.dmin.append(dmin); sv.dmax.append(dmax); sv.init_depth[i] = d; sv.init_normal[i] = n
@@ -383,3 +388,49 @@ def load_scene(mvs_path: str, opt=None, image_loader=None, view_neighbors_file=N
             sv.estimate_neighbors[i][k] = made[key]
     assert len(sv.gray) == n_img + len(sv.alias_of)
     return sv
+
+
+# ---- the consumer of the depth maps: fusion and the dense scene archive ---------------------------------------------------------------------------
+
+def fuse_order(scene) -> list:
+    """Processing order of `DepthMapsData::FuseDepthMaps` (libs/MVS/SceneDensify.cpp:1406-1452): the images that have a depth map, best connected first -- by the size
+    of the image's whole neighbour list (`Image::neighbors`), images without neighbours dropped; equal counts in index order (the reference's sort is not stable there)."""
+    n_all = {i: len(scene.all_view_scores[i]) if i in getattr(scene, "all_view_scores", {}) else len(scene.neighbors[i]) for i in scene.ids}
+    return sorted((i for i in scene.ids if n_all[i] > 0), key=lambda i: (-n_all[i], i))
+
+
+def fuse_depth_maps(engine, scene, opt=None, bgr=None) -> dict:
+    """`Scene::DenseReconstruction`'s last step (SceneDensify.cpp:1695-1712) on the resident maps: `FuseDepthMaps(pointcloud, nEstimateColors == 2, nEstimateNormals == 2)`
+    with `opt` = an `optdense.OptDense` (default: the table's defaults with the application's `--estimate-normals 2`).  `bgr`: {image: (h, w, 3) uint8 BGR} for the colours.
+    Returns the MVS::PointCloud fields of `PatchMatchHIP.scene_fuse`."""
+    n_min, f_depth, f_normal, colors, normals = 2, 0.01, 25.0, 2, 2
+    if opt is not None:
+        n_min, f_depth, f_normal, colors, normals = int(opt.nMinViewsFuse), float(opt.fDepthDiffThreshold), float(opt.fNormalDiffThreshold), int(opt.nEstimateColors), int(opt.nEstimateNormals)
+    want_color = colors == 2 and bgr is not None
+    if want_color:
+        for i in range(len(scene.gray) - len(scene.alias_of)):
+            engine.scene_set_color(i, bgr[i])
+    return engine.scene_fuse(fuse_order(scene), n_min, f_depth, f_normal, want_color, normals == 2)
+
+
+def save_dense_scene(mvs_in: str, mvs_out: str, cloud: dict, scene=None, version: int | None = None) -> None:
+    """What `DensifyPointCloud` leaves behind as `<scene>_dense.mvs` (`Scene::SaveInterface`, libs/MVS/Scene.cpp:218-300): the input archive with the fused cloud in place
+    of the sparse points -- position, the images that see the point with the fusion weight as `confidence`, normal, colour (Col3: B, G, R) -- and, when `scene`
+    (the `SceneViews`) is given and the archive version stores them (> 6), every image's whole scored neighbour list and average depth."""
+    import numpy as np
+    from . import mvsi
+    sc = mvsi.load(mvs_in)
+    P = int(cloud["nPoints"])
+    sc.vertices = np.ascontiguousarray(cloud["points"], np.float32).reshape(P, 3)
+    sc.vertex_view_start = np.asarray(cloud["viewStart"], np.int64)
+    vv = np.zeros(len(cloud["views"]), mvsi.VIEW_DTYPE)
+    vv["image_id"] = cloud["views"]; vv["confidence"] = cloud["weights"]
+    sc.vertex_views = vv
+    sc.vertices_normal = np.zeros((0, 3), np.float32) if cloud.get("normals") is None else np.ascontiguousarray(cloud["normals"], np.float32).reshape(P, 3)
+    sc.vertices_color = np.zeros((0, 3), np.uint8) if cloud.get("colors") is None else np.ascontiguousarray(cloud["colors"], np.uint8).reshape(P, 3)
+    if scene is not None:
+        for i, nb in getattr(scene, "all_view_scores", {}).items():
+            sc.images[i].view_scores = np.ascontiguousarray(nb, mvsi.VIEW_SCORE_DTYPE)
+        for i, a in getattr(scene, "avg_depth", {}).items():
+            sc.images[i].avg_depth = float(a)
+    mvsi.save(mvs_out, sc, version=version)

@@ -212,9 +212,10 @@ def filter_neighbor_views(neighbors: np.ndarray, fMinArea=0.05, fMinScale=0.2, f
     return neighbors[keep][:nMaxViews]
 
 
-def select_views(scene: mvsi.Scene, cams: Cameras, ID: int, opt: DenseOptions = DenseOptions()):
+def select_views(scene: mvsi.Scene, cams: Cameras, ID: int, opt: DenseOptions = DenseOptions(), all_neighbors: list | None = None):
     """`DepthMapsData::SelectViews(DepthData&)` (libs/MVS/SceneDensify.cpp:273-293) followed by the score cut of `InitViews`
-    (`:333-340`).  Returns (neighbors, points, avgDepth) or None when the image cannot be densified."""
+    (`:333-340`).  Returns (neighbors, points, avgDepth) or None when the image cannot be densified.  `all_neighbors` (a list) receives the image's WHOLE scored list --
+    `Image::neighbors`, which the reference keeps on the scene (it is what `scene_dense.mvs` stores as view scores and what orders the fusion, SceneDensify.cpp:1423)."""
     stored = scene.images[ID].view_scores
     if len(stored):            # a list the scene already carries -- the archive's view scores (Scene.cpp:158) or a view-neighbours file (mvsi.load_view_neighbors) -- is
         nb, points, avg = stored.copy(), np.zeros(0, np.int64), float(scene.images[ID].avg_depth)   # taken as it is (SceneDensify.cpp:278-281); no seed points then
@@ -224,6 +225,8 @@ def select_views(scene: mvsi.Scene, cams: Cameras, ID: int, opt: DenseOptions = 
                                                     np.deg2rad(opt.fOptimAngle), opt.nPointInsideROI)
         if not ok:
             return None
+    if all_neighbors is not None:
+        all_neighbors.append(nb.copy())
     nb = filter_neighbor_views(nb, opt.fMinArea, 0.2, 3.2, np.deg2rad(opt.fMinAngle), np.deg2rad(opt.fMaxAngle), opt.nMaxViews)
     if len(nb) == 0:
         return None

@@ -276,3 +276,37 @@ def test_checkpoint_files_and_resume(tmp_path):
         densify.compute_depth_maps(rec, [0, 1, 2, 3], p, scene=sc, dmap_dir=d)
     with pytest.raises(ValueError):
         densify.compute_depth_maps(rec, [0], p, dmap_dir=d)
+
+
+def test_fusion_order_and_the_dense_scene_archive(tmp_path):
+    """The output side: FuseDepthMaps' processing order, the option table's fusion values, and `<scene>_dense.mvs` (Scene::SaveInterface) read back by both archive readers."""
+    from openmvs_amd import mvsfront, optdense
+    sv = densify.load_scene(SCENE, opt=views.DenseOptions(nResolutionLevel=1, nMinResolution=64), image_loader=lambda p: np.zeros((479, 640, 3), np.uint8))
+    assert sorted(sv.all_view_scores) == [0, 1, 2, 3] and all(len(sv.all_view_scores[i]) >= len(sv.neighbors[i]) for i in range(4)) and all(sv.avg_depth[i] > 0 for i in range(4))
+    assert densify.fuse_order(sv) == sorted(range(4), key=lambda i: (-len(sv.all_view_scores[i]), i))
+    sv.all_view_scores[2] = sv.all_view_scores[2][:1]; sv.all_view_scores[1] = sv.all_view_scores[1][:0]
+    assert densify.fuse_order(sv) == [0, 3, 2]                                            # by the size of the whole list; an image without neighbours is dropped
+    rec = _Recorder(4, {i: (240, 320) for i in range(4)})
+    opt = optdense.defaults(); opt.nMinViewsFuse = 3; opt.nEstimateNormals = 2; opt.fNormalDiffThreshold = 20.0
+    densify.fuse_depth_maps(rec, sv, opt, bgr={i: np.zeros((240, 320, 3), np.uint8) for i in range(4)})
+    assert [c[0] for c in rec.calls] == ["scene_set_color"] * 4 + ["scene_fuse"] and rec.calls[-1][1:] == ([0, 3, 2], 3, float(f32(0.01)), 20.0, True, True)
+    rec.calls.clear(); opt.nEstimateColors = 1                                            # "final": colours are not estimated during the fusion (SceneDensify.cpp:1700,1733)
+    densify.fuse_depth_maps(rec, sv, opt, bgr={i: np.zeros((240, 320, 3), np.uint8) for i in range(4)})
+    assert [c[0] for c in rec.calls] == ["scene_fuse"] and rec.calls[-1][5:] == (False, True)
+    # a small cloud into the archive
+    cloud = dict(nPoints=3, points=np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]], f32), viewStart=np.array([0, 2, 5, 7], np.uint32), views=np.array([0, 1, 0, 2, 3, 1, 3], np.uint32),
+                 weights=np.array([.5, .25, 1, 2, 3, .125, 4], f32), normals=np.array([[0, 0, -1], [0, -1, 0], [-1, 0, 0]], f32), colors=np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]], np.uint8))
+    out = str(tmp_path / "scene_dense.mvs")
+    densify.save_dense_scene(SCENE, out, cloud, sv, version=7)
+    back = mvsi.load(out)
+    assert back.version == 7 and np.array_equal(back.vertices, cloud["points"]) and np.array_equal(back.vertices_normal, cloud["normals"]) and np.array_equal(back.vertices_color, cloud["colors"])
+    assert list(back.views_of(1)["image_id"]) == [0, 2, 3] and list(back.views_of(1)["confidence"]) == [1.0, 2.0, 3.0] and list(back.views_of(2)["image_id"]) == [1, 3]
+    src = mvsi.load(SCENE)
+    assert len(back.images) == 4 and [im.name for im in back.images] == [im.name for im in src.images] and np.array_equal(back.platforms[0].cameras[0].K, src.platforms[0].cameras[0].K)
+    assert back.images[0].view_scores.tobytes() == sv.all_view_scores[0].tobytes() and len(back.images[1].view_scores) == 0 and back.images[3].avg_depth == f32(sv.avg_depth[3])
+    cf = mvsfront.SceneFront(out)                                                         # the C++ reader: same points, and the stored lists are the images' neighbour lists now
+    assert cf.n_points == 3 and np.array_equal(cf.point(1)[0], cloud["points"][1]) and list(cf.point(1)[1]) == [0, 2, 3]
+    assert cf.neighbors(0).tobytes() == sv.all_view_scores[0].tobytes() and cf.image_depths(3)[1] == f32(sv.avg_depth[3])
+    densify.save_dense_scene(SCENE, out, dict(cloud, normals=None, colors=None))        # the archive's own version (6): no view scores, no normals / colours
+    b6 = mvsi.load(out)
+    assert b6.version == src.version and len(b6.vertices) == 3 and len(b6.vertices_normal) == 0 and len(b6.vertices_color) == 0

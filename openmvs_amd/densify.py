@@ -119,6 +119,7 @@ class SceneViews:
         self.sizes = []                             # (w, h) of every slot: images of another size than the scene's carry their own (pmhip_scene_set_view_sized)
         self.estimate_neighbors = None              # per slot: the slots the ESTIMATION reads (a resampled copy where ViewData::ScaleImage applies); None = `neighbors`
         self.alias_of = {}                          # extra source-only slot -> the image it is a resampled copy of
+        self.bgr = []                               # the colour images at the working resolution (B, G, R), for the fused cloud's colours
         self.all_view_scores = {}                   # image -> its WHOLE scored neighbour list (Image::neighbors: fusion order, and what a dense archive stores)
         self.avg_depth = {}                         # image -> average depth of its sparse points (Image::avgDepth)
 
@@ -352,6 +353,7 @@ def load_scene(mvs_path: str, opt=None, image_loader=None, view_neighbors_file=N
     cams = views.Cameras(sc, sizes)
     for i, im in enumerate(sc.images):
         sv.gray.append(views.to_gray(rgbs[i])); sv.names.append(im.name)
+        sv.bgr.append(np.ascontiguousarray(rgbs[i][..., ::-1]))
         sv.K.append(cams.K[i]); sv.R.append(cams.R[i]); sv.C.append(cams.C[i])
         whole = []
         sel = views.select_views(sc, cams, i, opt, all_neighbors=whole) if im.is_valid() else None
@@ -434,3 +436,28 @@ def save_dense_scene(mvs_in: str, mvs_out: str, cloud: dict, scene=None, version
         for i, a in getattr(scene, "avg_depth", {}).items():
             sc.images[i].avg_depth = float(a)
     mvsi.save(mvs_out, sc, version=version)
+
+
+def dense_reconstruction(engine, mvs_in: str, mvs_out: str | None = None, opt=None, seed: int = 0, fusion_mode: int = 0, dmap_dir: str | None = None, **load_args):
+    """`Scene::DenseReconstruction(nFusionMode)` (libs/MVS/SceneDensify.cpp:1655-1750) for the PatchMatch path on one engine: prepare the views (`load_scene`), estimate all
+    depth maps with the geometric rounds and the filters the option table asks for (`compute_depth_maps`; with `dmap_dir` under the reference's file contract), and -- unless
+    `fusion_mode` is 1, "export depth maps only" -- fuse them and write `<scene>_dense.mvs` to `mvs_out`.  `opt`: an `optdense.OptDense` (default: the table's defaults with the
+    application's own `--number-views 8`, `--estimate-normals 2`, `--number-views-fuse` left at the table's 2); `load_args` go to `load_scene` (image_loader,
+    view_neighbors_file, ignore_mask_label, mask_path, mask_loader).  The SGM modes (-1, -2) are openmvs_amd.sgm_pipeline's.  Returns (SceneViews, cloud or None)."""
+    from . import optdense
+    if fusion_mode not in (0, 1):
+        raise ValueError("fusion_mode %d: the PatchMatch path is modes 0 (estimate + fuse) and 1 (depth maps only)" % fusion_mode)
+    if opt is None:
+        opt = optdense.defaults(); opt.nNumViews = 8; opt.nEstimateNormals = 2
+    sv = load_scene(mvs_in, opt=opt, **load_args)
+    engine.scene_load(sv, n_levels=int(opt.nSubResolutionLevels))
+    compute_depth_maps(engine, sv.ids, opt.params(seed), n_optimize=int(opt.nOptimize), b_filter_adjust=bool(opt.bFilterAdjust), n_speckle_size=int(opt.nSpeckleSize),
+                       n_ipol_gap_size=int(opt.nIpolGapSize), f_depth_diff_threshold=float(opt.fDepthDiffThreshold), n_min_views_filter=int(opt.nMinViewsFilter),
+                       n_min_views_filter_adjust=int(opt.nMinViewsFilterAdjust), init_depth=sv.init_depth, init_normal=sv.init_normal, scene=sv, dmap_dir=dmap_dir,
+                       image_names=sv.names)
+    if fusion_mode == 1:
+        return sv, None
+    cloud = fuse_depth_maps(engine, sv, opt, bgr=sv.bgr)
+    if mvs_out:
+        save_dense_scene(mvs_in, mvs_out, cloud, sv)
+    return sv, cloud

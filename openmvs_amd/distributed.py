@@ -234,3 +234,79 @@ class ShardedDensifier:
                 raise ValueError("gather(%r): views of different sizes have no [n_views, H, W] tensor -- pass root= to collect them view by view on the fusing rank" % what)
             return all_gather_views(own, self.n_views, self.world, self.rank)
         return gather_views_to_root(own, self.n_views, self.world, self.rank, root, self.view_shapes)
+
+
+class EngineRank:
+    """One rank's HIP engine behind `ShardedDensifier` (neighbour-only exchange): a COMPACT scene of local slots -- this rank's block of reference views first, then the
+    foreign views its block reads -- so that a rank holds nothing else of the scene (BASELINE config 5).  Every slot draws its random numbers under the view's index in the
+    whole scene (`scene_set_view_id`), which makes the depth maps independent of the split.  Maps travel as tensors on `device`, handed to the engine by pointer
+    (`scene_copy`): device memory under RCCL, host memory when the engine is the CPU emulator of the tests.  bench.py's adapter is these same calls, inlined (and timed).
+
+    engine: a `PatchMatchHIP`; params: `PMHipParams`; neighbors: per view of the WHOLE scene, the global ids of its source views;
+    gray_of(g): the gray image of global view g (asked only for the views this rank holds); K, R, C, dmin, dmax: indexable by global id."""
+
+    def __init__(self, engine, params, n_views, world, rank, neighbors, gray_of, K, R, C, dmin, dmax, width, height, n_levels=2, device="cpu", batch=0,
+                 filter_args=(True, 2, 1, 0.01)):
+        self.eng, self.p, self.W, self.H, self.batch, self.filter_args = engine, params, int(width), int(height), int(batch), tuple(filter_args)
+        self.device = torch.device(device)
+        nbs = [[int(x) for x in neighbors[v]] for v in range(n_views)]
+        self.mine, self.foreign = needed_views(nbs, n_views, world, rank)
+        self.held = self.mine + self.foreign                    # global view ids in slot order
+        self.slot = {g: i for i, g in enumerate(self.held)}
+        engine.Init(True)
+        engine.scene_create(max(2, len(self.held)), self.W, self.H, n_levels)
+        for i, g in enumerate(self.held):
+            engine.scene_set_view(i, gray_of(g), K[g], R[g], C[g], float(dmin[g]), float(dmax[g]), [self.slot[n] for n in nbs[g]] if i < len(self.mine) else [])
+            engine.scene_set_view_id(i, g)
+        engine.sync()
+        self.buf = torch.empty((max(1, len(self.mine)), self.H, self.W), dtype=torch.float32, device=self.device)
+
+    def _fence(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()                            # a received tensor is complete before the engine's own stream copies out of it
+
+    def reset(self, ids):
+        for v in ids:
+            self.eng.scene_reset_view(self.slot[v])
+
+    def estimate(self, ids, geo):
+        s = [self.slot[v] for v in ids]
+        step = self.batch if self.batch > 0 else max(1, len(s))
+        for i in range(0, len(s), step):
+            self.eng.scene_estimate(s[i:i + step], geo, self.p, sync=False)
+
+    def local_maps(self, ids, what):
+        if list(ids) != self.mine:
+            raise ValueError("a rank hands out the maps of its own block")
+        buf = self.buf[:len(self.mine)]
+        if len(self.mine):
+            self.eng.scene_copy({"depth": 1, "conf": 3}[what], 0, len(self.mine), buf.data_ptr(), False)
+        self.eng.sync()                                         # (also the wait for this rank's asynchronous estimate)
+        return buf
+
+    def local_depths(self, ids):
+        return self.local_maps(ids, "depth")
+
+    def set_snapshot_views(self, own_ids, own, foreign_ids, foreign_maps):
+        # previous-round depth maps become visible to the next round (the reference writes depthNNNN.dmap and re-reads the neighbours' files, SceneDensify.cpp:378-393,
+        # 1943-1950): this rank's own maps by a device copy inside the engine, the foreign ones from the exchange
+        self.eng.scene_commit_round()
+        self._fence()
+        for k, g in enumerate(foreign_ids):
+            self.eng.scene_copy(4, self.slot[g], 1, foreign_maps[k].data_ptr(), True)
+        self.eng.sync()                                         # the received tensor may be released by the caller
+
+    def set_maps_views(self, what, foreign_ids, foreign_maps):
+        self._fence()
+        for k, g in enumerate(foreign_ids):
+            self.eng.scene_copy({"depth": 1, "conf": 3}[what], self.slot[g], 1, foreign_maps[k].data_ptr(), True)
+        self.eng.sync()
+
+    def filter(self, ids):
+        if len(ids):
+            b_adjust, n_min, n_min_adjust, f_depth = self.filter_args
+            self.eng.scene_filter([self.slot[v] for v in ids], b_adjust, n_min, n_min_adjust, f_depth, commit=True)
+
+    def maps_of(self, g):
+        """(depth, normal, conf) of global view g of this rank's block, on the host."""
+        return self.eng.scene_get_maps(self.slot[g])

@@ -248,3 +248,55 @@ def test_neighbour_only_exchange_of_views_of_different_sizes(tmp_path):
             assert np.array_equal(np.load(out / ("depth%d.npy" % v)), est.depth[v]), "world %d view %d" % (world, v)
             assert np.array_equal(np.load(out / ("gathered%d.npy" % v)), est.depth[v]), "world %d view %d gathered on the last rank" % (world, v)
     assert (est.depth[3] > 0).mean() > 0.2
+
+
+# ---- the real engine behind the driver: distributed.EngineRank on the CPU emulator, 2 and 3 gloo ranks --------------------------------------------------------
+def _engine_scene():
+    return synth.make_scene(6, 64, 48, n_src=3)
+
+
+def _engine_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    from openmvs_amd import patchmatch
+    from openmvs_amd.distributed import EngineRank, gather_views_to_root
+    from tests import emu
+    with emu.emulated(patchmatch, "PMHIP_LIB", "libpmhip_emu.so"):
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        sc = _engine_scene()
+        nbs = [[int(x) for x in sc.neighbors[v]] for v in range(sc.n_views)]
+        asked = []
+        eng = patchmatch.PatchMatchHIP(0)
+        p = patchmatch.default_params(seed=SEED, nEstimationGeometricIters=2)
+        est = EngineRank(eng, p, sc.n_views, world, rank, nbs, lambda g: (asked.append(g), sc.gray[g])[1], sc.K, sc.R, sc.C, sc.dmin, sc.dmax, sc.width, sc.height)
+        assert sorted(asked) == sorted(est.held) and len(est.held) <= sc.n_views            # a rank reads only the images it holds
+        drv = ShardedDensifier(est, sc.n_views, world, rank, geo_iters=2, neighbors=nbs)
+        drv.run()
+        final = [m.clone() for m in est.local_depths(drv.mine)]
+        drv.filter()
+        fd = gather_views_to_root(est.local_maps(drv.mine, "depth").clone(), sc.n_views, world, rank, 0)
+        fc = gather_views_to_root(est.local_maps(drv.mine, "conf").clone(), sc.n_views, world, rank, 0)
+        est_final = gather_views_to_root(torch.stack(final) if final else torch.zeros((0, sc.height, sc.width)), sc.n_views, world, rank, 0)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "final.npy"), torch.stack(est_final).numpy())
+            np.save(os.path.join(out_dir, "filtered_depth.npy"), torch.stack(fd).numpy()); np.save(os.path.join(out_dir, "filtered_conf.npy"), torch.stack(fc).numpy())
+        eng.close()
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_engine_ranks_match_single_process(tmp_path):
+    """distributed.EngineRank -- the compact per-rank scene, slots numbered locally, random numbers by the view's index in the whole scene, maps handed over by pointer --
+    with the product's kernels and host engine (under the wave64 emulator) behind ShardedDensifier: 2 and 3 gloo ranks give the bits of one process, through the
+    photometric pass, two geometric rounds with the neighbour-only exchange, and the cross-view filter."""
+    one = tmp_path / "w1"; one.mkdir()
+    _engine_worker(0, 1, 0, str(one))
+    want = [np.load(one / n) for n in ("final.npy", "filtered_depth.npy", "filtered_conf.npy")]
+    assert (want[0] > 0).mean() > 0.3 and (want[1] != want[0]).any()
+    for world in (2, 3):
+        out = tmp_path / ("w%d" % world); out.mkdir()
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+        mp.spawn(_engine_worker, args=(world, port, str(out)), nprocs=world, join=True)
+        for n, w in zip(("final.npy", "filtered_depth.npy", "filtered_conf.npy"), want):
+            assert np.array_equal(np.load(out / n), w), "world %d %s" % (world, n)

@@ -246,8 +246,9 @@ class EngineRank:
     gray_of(g): the gray image of global view g (asked only for the views this rank holds); K, R, C, dmin, dmax: indexable by global id."""
 
     def __init__(self, engine, params, n_views, world, rank, neighbors, gray_of, K, R, C, dmin, dmax, width, height, n_levels=2, device="cpu", batch=0,
-                 filter_args=(True, 2, 1, 0.01)):
+                 filter_args=(True, 2, 1, 0.01), init_depth=None, init_normal=None):
         self.eng, self.p, self.W, self.H, self.batch, self.filter_args = engine, params, int(width), int(height), int(batch), tuple(filter_args)
+        self.init_depth, self.init_normal = init_depth or {}, init_normal or {}       # seed maps by global view id (InitViews, SceneDensify.cpp:418-460), installed by reset()
         self.device = torch.device(device)
         nbs = [[int(x) for x in neighbors[v]] for v in range(n_views)]
         self.mine, self.foreign = needed_views(nbs, n_views, world, rank)
@@ -268,6 +269,16 @@ class EngineRank:
     def reset(self, ids):
         for v in ids:
             self.eng.scene_reset_view(self.slot[v])
+            if v in self.init_depth:
+                self.eng.scene_set_maps(self.slot[v], self.init_depth[v], self.init_normal.get(v))
+
+    def post_filters(self, ids, n_optimize=3, n_speckle_size=100, n_ipol_gap_size=7, f_depth_diff_threshold=0.01):
+        """The per-map filters of the last round (nOptimize bits REMOVE_SPECKLES = 1, FILL_GAPS = 2; SceneDensify.cpp:2069-2093) on this rank's own maps."""
+        s = [self.slot[v] for v in ids]
+        if s and n_optimize & 1:
+            self.eng.scene_remove_small_segments(s, n_speckle_size, f_depth_diff_threshold)
+        if s and n_optimize & 2:
+            self.eng.scene_gap_interpolation(s, n_ipol_gap_size, f_depth_diff_threshold)
 
     def estimate(self, ids, geo):
         s = [self.slot[v] for v in ids]
@@ -278,9 +289,12 @@ class EngineRank:
     def local_maps(self, ids, what):
         if list(ids) != self.mine:
             raise ValueError("a rank hands out the maps of its own block")
-        buf = self.buf[:len(self.mine)]
+        if what == "normal":                                    # (only the fusing rank ever asks: its own buffer)
+            buf = torch.empty((len(self.mine), self.H, self.W, 3), dtype=torch.float32, device=self.device)
+        else:
+            buf = self.buf[:len(self.mine)]
         if len(self.mine):
-            self.eng.scene_copy({"depth": 1, "conf": 3}[what], 0, len(self.mine), buf.data_ptr(), False)
+            self.eng.scene_copy({"depth": 1, "normal": 2, "conf": 3}[what], 0, len(self.mine), buf.data_ptr(), False)
         self.eng.sync()                                         # (also the wait for this rank's asynchronous estimate)
         return buf
 
@@ -310,3 +324,38 @@ class EngineRank:
     def maps_of(self, g):
         """(depth, normal, conf) of global view g of this rank's block, on the host."""
         return self.eng.scene_get_maps(self.slot[g])
+
+
+def dense_reconstruction(engine, scene, opt, world: int = 1, rank: int = 0, seed: int = 0, root: int = 0, device="cpu", fuse_engine=None):
+    """The PatchMatch path of `Scene::DenseReconstruction` (libs/MVS/SceneDensify.cpp:1655-1750) over `world` ranks, one engine each: every rank estimates its block of
+    reference views (photometric pass, geometric rounds with the neighbour-only exchange), runs the per-map filters on its own maps and the cross-view filter against its
+    neighbours' unfiltered maps; the fusing rank `root` then collects depth, normal and confidence maps view by view and fuses them (FuseDepthMaps is sequential over the
+    scene, :1372-1650).  Same maps and the same cloud as `densify.dense_reconstruction` on one engine, whatever the split.
+
+    scene: a `densify.SceneViews` (every rank runs `densify.load_scene` on the same archive; a rank's engine is handed only the images it holds) whose views share one size
+    and need no resampled copies; opt: an `optdense.OptDense`; fuse_engine: the engine `root` fuses on (default: `engine`, whose compact scene is replaced by the whole one).
+    Returns the cloud on `root`, None elsewhere."""
+    from . import densify
+    n = len(scene.gray)
+    if getattr(scene, "alias_of", None) or len(set(map(tuple, scene.sizes))) > 1 or list(scene.ids) != list(range(n)):
+        raise NotImplementedError("the sharded driver takes scenes whose views share one size, need no resampled neighbour copies and all passed view selection")
+    nbs = [[int(x) for x in scene.neighbors[v]] for v in range(n)]
+    G = int(opt.nEstimationGeometricIters)
+    est = EngineRank(engine, opt.params(seed), n, world, rank, nbs, lambda g: scene.gray[g], scene.K, scene.R, scene.C, scene.dmin, scene.dmax, scene.width, scene.height,
+                     n_levels=int(opt.nSubResolutionLevels), device=device,
+                     filter_args=(bool(opt.bFilterAdjust), int(opt.nMinViewsFilter), int(opt.nMinViewsFilterAdjust), float(opt.fDepthDiffThreshold)),
+                     init_depth=scene.init_depth, init_normal=scene.init_normal)
+    drv = ShardedDensifier(est, n, world, rank, geo_iters=G, neighbors=nbs)
+    drv.run()
+    est.post_filters(drv.mine, int(opt.nOptimize), int(opt.nSpeckleSize), int(opt.nIpolGapSize), float(opt.fDepthDiffThreshold))
+    if int(opt.nOptimize) & densify.ADJUST_FILTER:
+        drv.filter()
+    maps = {w: gather_views_to_root(est.local_maps(est.mine, w).clone(), n, world, rank, root) for w in ("depth", "normal", "conf")}
+    if rank != root:
+        return None
+    fe = fuse_engine or engine
+    fe.scene_load(scene, n_levels=int(opt.nSubResolutionLevels))
+    for v in range(n):
+        fe.scene_set_maps(v, maps["depth"][v].cpu().numpy(), maps["normal"][v].cpu().numpy())
+        fe.scene_set_conf(v, maps["conf"][v].cpu().numpy())
+    return densify.fuse_depth_maps(fe, scene, opt, bgr=scene.bgr)

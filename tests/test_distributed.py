@@ -300,3 +300,52 @@ def test_engine_ranks_match_single_process(tmp_path):
         mp.spawn(_engine_worker, args=(world, port, str(out)), nprocs=world, join=True)
         for n, w in zip(("final.npy", "filtered_depth.npy", "filtered_conf.npy"), want):
             assert np.array_equal(np.load(out / n), w), "world %d %s" % (world, n)
+
+
+# ---- the whole PatchMatch path of Scene::DenseReconstruction over ranks (distributed.dense_reconstruction) ------------------------------------------------------
+_REAL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "scene", "scene.mvs")
+
+
+def _recon_opt():
+    from openmvs_amd import optdense
+    opt = optdense.defaults()
+    opt.nResolutionLevel = 3; opt.nMinResolution = 40; opt.nNumViews = 8; opt.nEstimateNormals = 2; opt.nSpeckleSize = 20; opt.nEstimationGeometricIters = 1
+    return opt
+
+
+def _recon_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    from openmvs_amd import densify, patchmatch
+    from openmvs_amd import distributed as D
+    from tests import emu
+    with emu.emulated(patchmatch, "PMHIP_LIB", "libpmhip_emu.so"):
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        opt = _recon_opt()
+        sv = densify.load_scene(_REAL, opt=opt)
+        eng = patchmatch.PatchMatchHIP(0)
+        cloud = D.dense_reconstruction(eng, sv, opt, world, rank, seed=3)
+        assert (cloud is None) == (rank != 0)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "cloud.npz"), **{k: v for k, v in cloud.items() if isinstance(v, np.ndarray)})
+        eng.close()
+        dist.destroy_process_group()
+
+
+def test_dense_reconstruction_over_ranks_matches_one_engine(tmp_path):
+    """distributed.dense_reconstruction on the reference's pipeline-test scene (80x60), 2 and 3 gloo ranks of the emulated engine: the fused cloud -- points, views, weights,
+    normals, colours -- equals densify.dense_reconstruction on one engine."""
+    from openmvs_amd import densify, patchmatch
+    from tests import emu
+    with emu.emulated(patchmatch, "PMHIP_LIB", "libpmhip_emu.so"):
+        eng = patchmatch.PatchMatchHIP(0)
+        sv, want = densify.dense_reconstruction(eng, _REAL, None, _recon_opt(), seed=3)
+        eng.close()
+    assert want["nPoints"] > 100
+    for world in (2, 3):
+        out = tmp_path / ("w%d" % world); out.mkdir()
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+        mp.spawn(_recon_worker, args=(world, port, str(out)), nprocs=world, join=True)
+        got = np.load(out / "cloud.npz")
+        for k in ("points", "viewStart", "views", "weights", "projs", "colors", "normals"):
+            assert np.array_equal(got[k], want[k]), (world, k)

@@ -61,7 +61,11 @@ def compute_depth_maps(engine, view_ids, params, n_optimize: int = 7, b_filter_a
             want = tuple(scene.sizes[v])[::-1] if getattr(scene, "sizes", None) else (scene.height, scene.width)
             if f["depth_map"].shape != want or f.get("confidence_map") is None:
                 raise ValueError("%s does not hold the maps of view %d (%s, expected %s with a confidence map)" % (done, v, f["depth_map"].shape, want))
-            engine.scene_set_maps(v, f["depth_map"], f.get("normal_map"))
+            normal = f.get("normal_map")
+            if normal is None:                                     # a depth map stored without normals gets them from its depths (EstimateNormalMap, SceneDensify.cpp:411-414)
+                from . import views as _views
+                normal = _views.estimate_normal_map(scene.K[v], f["depth_map"])
+            engine.scene_set_maps(v, f["depth_map"], normal)
             engine.scene_set_conf(v, f["confidence_map"])
             resumed.append(v)
         elif init_depth is not None and v in init_depth:

@@ -460,3 +460,45 @@ def import_ignore_mask(mask: np.ndarray, size, label: int) -> np.ndarray:
     sx = np.minimum(np.floor(np.arange(w) * ifx).astype(np.int64), sw - 1)
     sy = np.minimum(np.floor(np.arange(h) * ify).astype(np.int64), sh - 1)
     return (m[sy][:, sx] != np.uint16(label & 0xFFFF)).astype(np.uint8)
+
+
+# ---- normals of a depth map that has none (a .dmap written without them, the SGM fuse mode) --------------------------------------------------------
+
+def estimate_normal_map(K, depth):
+    """`MVS::EstimateNormalMap(K, depthMap, normalMap)` (libs/MVS/DepthMap.cpp:1522-1613, the active least-squares branch): per pixel the depth gradient from the
+    8-neighbourhood -- neighbours inside the map, with a depth > 0 that differs by less than 3 % of the pixel's (IsDepthSimilar, libs/Common/Util.inl:797-809), at
+    least three of them, non-singular 2x2 system in integers -- then the normal normalized((K00*dx, K11*dy, (K02 - x)*dx + (K12 - y)*dy - d)); zero where that fails.
+    Float sums in the reference's order (rows of the neighbourhood top to bottom, left to right); cv::normalize = v * (1 / |v|) with the norm and the product in double."""
+    d = np.ascontiguousarray(depth, f32)
+    H, W = d.shape
+    Kf = np.asarray(K, np.float64).astype(f32)
+    whxx = np.zeros((H, W), np.int64); whxy = np.zeros((H, W), np.int64); whyy = np.zeros((H, W), np.int64); n = np.zeros((H, W), np.int64)
+    wgx = np.zeros((H, W), f32); wgy = np.zeros((H, W), f32)
+    pad = np.zeros((H + 2, W + 2), f32); pad[1:-1, 1:-1] = d
+    inside = np.zeros((H + 2, W + 2), bool); inside[1:-1, 1:-1] = True
+    pos = d > 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for y in (-1, 0, 1):
+            for x in (-1, 0, 1):
+                if x == 0 and y == 0:
+                    continue
+                wi = pad[1 + y:1 + y + H, 1 + x:1 + x + W]
+                ok = inside[1 + y:1 + y + H, 1 + x:1 + x + W] & pos & (wi > 0) & ((np.abs(d - wi) / d) < f32(0.03))
+                whxx += ok * (x * x); whxy += ok * (x * y); whyy += ok * (y * y); n += ok
+                diff = (wi - d).astype(f32)
+                wgx = np.where(ok, (wgx + diff * f32(x)).astype(f32), wgx)
+                wgy = np.where(ok, (wgy + diff * f32(y)).astype(f32), wgy)
+        det = whxx * whyy - whxy * whxy
+        good = pos & (n >= 3) & (det != 0)
+        inv = (f32(1) / np.where(good, det, 1).astype(f32)).astype(f32)
+        wx = ((whyy.astype(f32) * wgx - whxy.astype(f32) * wgy) * inv).astype(f32)
+        wy = (((-whxy).astype(f32) * wgx + whxx.astype(f32) * wgy) * inv).astype(f32)
+        xs = np.arange(W, dtype=f32)[None, :]; ys = np.arange(H, dtype=f32)[:, None]
+        nx = (Kf[0, 0] * wx).astype(f32); ny = (Kf[1, 1] * wy).astype(f32)
+        nz = ((((Kf[0, 2] - xs) * wx).astype(f32) + ((Kf[1, 2] - ys) * wy).astype(f32)).astype(f32) - d).astype(f32)
+        v = np.stack([nx, ny, nz], -1).astype(np.float64)
+        nv = np.sqrt((v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1]) + v[..., 2] * v[..., 2])
+        a = np.where(nv != 0, 1.0 / np.where(nv != 0, nv, 1.0), 0.0)
+        out = (v * a[..., None]).astype(f32)
+    out[~good] = 0
+    return out

@@ -305,6 +305,18 @@ def ref_fuse_depth_maps(depths, normals, confs, bgrs, K, R, Cc, neighbors, nMinV
     return po._cloud(out, rc, L.ref_fuse_free), [int(x) for x in order[:no.value]]
 
 
+def ref_estimate_normal_map(K, depth):
+    """MVS::EstimateNormalMap (libs/MVS/DepthMap.cpp:1522-1613, verbatim in oracle/_ref/libref_fuse.so) -> [h, w, 3] float32."""
+    d = np.ascontiguousarray(depth, np.float32); h, w = d.shape
+    Kf = np.ascontiguousarray(np.asarray(K, np.float64).astype(np.float32).ravel())
+    out = np.zeros((h, w, 3), np.float32)
+    lib = _fuse_lib()
+    rc = lib.ref_estimate_normal_map(Kf.ctypes.data_as(C.POINTER(C.c_float)), d.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(w), C.c_int(h), out.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc != 0:
+        raise RuntimeError("ref_estimate_normal_map: %d" % rc)
+    return out
+
+
 # ---- the two text files in front of the path through the reference's own readers (oracle/ref/ref_text_harness.cpp: SML.cpp, ConfigTable.cpp, the OPTDENSE list of
 # DepthMap.cpp:50-115, Scene::LoadViewNeighbors / SaveViewNeighbors, Util::CommandLineToArgvA -- all verbatim) ----
 def text_available() -> bool:

@@ -96,6 +96,7 @@ SNIPPETS = {
     "scenedensify_estimate": ("libs/MVS/SceneDensify.cpp", 616, 805, "bool DepthMapsData::EstimateDepthMap(IIndex idxImage, int nGeometricIter)", "} // EstimateDepthMap"),
     "scenedensify_filters":  ("libs/MVS/SceneDensify.cpp", 809, 1045, "// filter out small depth segments from the given depth map", "} // GapInterpolation"),
     "scenedensify_filterdm": ("libs/MVS/SceneDensify.cpp", 1049, 1299, "// filter depth-map, one pixel at a time, using confidence based fusion or neighbor pixels", "} // FilterDepthMap"),
+    "depthmap_cpp_estnormal": ("libs/MVS/DepthMap.cpp", 1522, 1613, "bool MVS::EstimateNormalMap(const Matrix3x3f& K, const DepthMap& depthMap, NormalMap& normalMap)", "} // EstimateNormalMap"),
     # the two text files in front of the path (ref_text_harness.cpp)
     "util_h_flags":          ("libs/Common/Util.h", 55, 89, "template <typename TYPE>", "typedef class GENERAL_API TFlags<uint32_t> Flags;"),
     "sml_cpp":               ("libs/Common/SML.cpp", 11, 419, "using namespace SEACAVE;", "/*----------------------------------------------------------------*/"),

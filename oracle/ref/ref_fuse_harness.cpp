@@ -36,7 +36,7 @@ struct PointCloud {
 	SEACAVE::cList<Point> points; SEACAVE::cList<ViewArr> pointViews; SEACAVE::cList<WeightArr> pointWeights; SEACAVE::cList<Normal> normals; SEACAVE::cList<Color> colors;
 	size_t GetSize() const { return points.size(); }
 };
-inline void EstimateNormalMap(const Matrix3x3f&, const DepthMap&, NormalMap&) { abort(); }   // (DepthMap.cpp; only for depth maps without normals: not part of this harness)
+bool EstimateNormalMap(const Matrix3x3f& K, const DepthMap&, NormalMap&);                       // DepthMap.h:494; the function itself is cut in below (DepthMap.cpp:1522-1613)
 typedef Image SceneImage;
 class Scene { public: ImageArr images; };
 class DepthMapsData {
@@ -75,6 +75,7 @@ void DepthData::GetNormal(const ImageRef& ir, Point3f& N, const TImage<Point3f>*
 	if (normalMap.empty()) abort();
 	N = camera.R.t()*Cast<REAL>(normalMap(ir));
 }
+#include "snip/depthmap_cpp_estnormal.inc"   // DepthMap.cpp:1522-1613: EstimateNormalMap (what FuseDepthMaps, the SGM fuse mode and a resumed .dmap without normals call)
 #include "snip/scenedensify_conf2weight.inc" // SceneDensify.cpp:119-122: Conf2Weight
 #include "snip/scenedensify_fuse.inc"       // SceneDensify.cpp:1303-1646: MergeDepthMaps, FuseDepthMaps
 
@@ -89,6 +90,15 @@ struct OrcFuseCloud {
 	uint64_t nPoints, nDepths, nViews;
 	float* points; uint32_t* viewStart; uint32_t* views; float* weights; uint16_t* projs; uint8_t* colors; float* normals;
 };
+// MVS::EstimateNormalMap: K 9 floats row-major, depth w*h -> normal w*h*3
+int ref_estimate_normal_map(const float* K, const float* depth, int w, int h, float* normal) {
+	Matrix3x3f Kf; for (int k = 0; k < 9; ++k) Kf.val[k] = K[k];
+	DepthMap d; d.create(cv::Size(w, h)); memcpy((void*)d.data(), depth, sizeof(float) * (size_t)w * h);
+	NormalMap n;
+	if (!EstimateNormalMap(Kf, d, n)) return -1;
+	memcpy(normal, (const void*)n.data(), sizeof(float) * 3 * (size_t)w * h);
+	return 0;
+}
 void ref_fuse_free(OrcFuseCloud* c) { free(c->points); free(c->viewStart); free(c->views); free(c->weights); free(c->projs); free(c->colors); free(c->normals); memset(c, 0, sizeof(*c)); }
 
 static void setup(Scene& scene, DepthMapsData& dm, const OrcFuseView* views, int nImages, int w, int h) {

@@ -83,3 +83,35 @@ def test_fuse_of_depth_maps_of_different_sizes_is_the_reference_function(seed, o
         ref = dict(ref); orc = dict(orc); ref["weights"] = None; orc["weights"] = None
     _same(ref, orc, "mixed sizes %s" % opts)
     assert ref["nPoints"] > 1000
+
+
+# ---- MVS::EstimateNormalMap (DepthMap.cpp:1522-1613, verbatim) against openmvs_amd.views.estimate_normal_map ---------------------------------------------------
+@pytest.mark.parametrize("case", ["plane", "surface", "holes", "steps", "tiny", "garbage"])
+def test_estimate_normal_map_is_the_reference_function(case):
+    """The normals the reference gives a depth map that has none (FuseDepthMaps :1427, InitViews :413, the SGM fuse mode :2055): bit for bit."""
+    from openmvs_amd import views
+    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    w, h = (67, 45) if case != "tiny" else (3, 2)
+    K = np.array([[80.5, 0, (w - 1) / 2 + 0.3], [0, 79.25, (h - 1) / 2 - 0.2], [0, 0, 1]])
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
+    if case == "plane":
+        d = (5 + 0.01 * xs + 0.02 * ys).astype(np.float32)
+    elif case == "steps":
+        d = (4 + (xs > w / 2) * 0.5 + 0.003 * ys).astype(np.float32)                        # a depth step of more than 3 %: neighbours across it do not count
+    elif case == "garbage":
+        d = rng.uniform(-1, 9, (h, w)).astype(np.float32)                                    # negative depths, nothing similar to anything
+    else:
+        d = (6 + 0.4 * np.sin(xs / 7) * np.cos(ys / 5) + rng.normal(0, 0.002, (h, w))).astype(np.float32)
+    if case == "holes":
+        d[rng.random((h, w)) < 0.35] = 0
+        d[10:14] = 0
+    got = views.estimate_normal_map(K, d)
+    want = pr.ref_estimate_normal_map(K, d)
+    assert got.dtype == np.float32 and got.shape == (h, w, 3)
+    bad = np.flatnonzero(got.view(np.uint32).ravel() != want.view(np.uint32).ravel())
+    assert bad.size == 0, (case, bad[:5], got.ravel()[bad[:5]], want.ravel()[bad[:5]])
+    if case in ("plane", "surface"):
+        nz = np.linalg.norm(got, axis=-1)
+        assert (nz[2:-2, 2:-2] > 0.999).all() and (got[..., 2][nz > 0] < 0).all()              # unit normals facing the camera
+    if case == "garbage":
+        assert (np.linalg.norm(got, axis=-1) == 0).mean() > 0.9

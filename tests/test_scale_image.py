@@ -270,6 +270,14 @@ def test_checkpoint_files_and_resume(tmp_path):
     assert [(c[0], c[1]) for c in loaded] == [("scene_set_maps", 1), ("scene_set_conf", 1), ("scene_set_maps", 3), ("scene_set_conf", 3)]
     assert np.array_equal(loaded[0][2], rec.depth[1]) and np.array_equal(loaded[1][2], np.full((24, 32), 0.5, f32))
     assert sorted(os.listdir(d)) == ["depth%04d.dmap" % i for i in range(4)]
+    # a checkpoint written without normals: they are estimated from its depths, as InitViews does (EstimateNormalMap)
+    ys, xs = np.mgrid[0:24, 0:32].astype(f32)
+    plane = (3 + 0.01 * xs + 0.02 * ys).astype(f32)
+    dmap.save(os.path.join(d, "depth0003.dmap"), "x.jpg", [3, 0], (32, 24), sc.K[3], sc.R[3], sc.C[3], 1.0, 9.0, plane, None, np.ones((24, 32), f32))
+    rec.calls.clear()
+    assert 3 in densify.compute_depth_maps(rec, [0, 1, 2, 3], p, scene=sc, dmap_dir=d)
+    got3 = [c for c in rec.calls if c[0] == "scene_set_maps" and c[1] == 3][0]
+    assert np.array_equal(got3[2], plane) and np.array_equal(got3[3], views.estimate_normal_map(sc.K[3], plane)) and (np.linalg.norm(got3[3][2:-2, 2:-2], axis=-1) > 0.999).all()
     # a file of another size is not this view's checkpoint
     dmap.save(os.path.join(d, "depth0001.dmap"), "x.jpg", [1, 0], (16, 12), sc.K[1], sc.R[1], sc.C[1], 1.0, 2.0, np.ones((12, 16), f32), None, np.ones((12, 16), f32))
     with pytest.raises(ValueError):

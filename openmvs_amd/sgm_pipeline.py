@@ -95,3 +95,118 @@ def fuse_pairs(be, pairs, min_views=2):
         w, h = pairs[0]["image_size"] if pairs else (0, 0)
         return np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
     return be.FusePairs(deps, rgs, cfs, min_views)
+
+
+# ---- scene level: `DensifyPointCloud --fusion-mode -1` (disparity maps of every pair) and `-2` (fuse them into depth maps) ------------------------------------------
+
+def _matx(a, b):
+    """cv::Matx product: c(i, j) = sum_k a(i, k) b(k, j), accumulated left to right from 0 in double."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    c = np.zeros((a.shape[0], b.shape[1]))
+    for i in range(a.shape[0]):
+        for j in range(b.shape[1]):
+            s = 0.0
+            for k in range(a.shape[1]):
+                s += a[i, k] * b[k, j]
+            c[i, j] = s
+    return c
+
+
+def swapped_pair_q(Q, cam_left, cam_right):
+    """`SemiGlobalMatcher::Fuse` when only the pair (right, left) is on disk (libs/MVS/SemiGlobalMatcher.cpp:767-777): that file's Q puts a disparity of the rectified RIGHT
+    image into the right camera's image space; `P * invK * Q` carries it on into the LEFT image -- P = K_left [R | -R C] with (R, C) the pose of the left camera relative to
+    the right one (ComputeRelativePose, libs/Common/Util.inl:39-42), invK = the right camera's inverse intrinsics (Camera::InvK)."""
+    (Kl, Rl, Cl), (Kr, Rr, Cr) = [tuple(np.asarray(x, np.float64) for x in cam) for cam in (cam_left, cam_right)]
+    poseR = _matx(Rl, Rr.T)
+    poseC = _matx(Rr, (Cl - Cr)[:, None])[:, 0]
+    M = _matx(Kl, poseR)
+    P = np.eye(4); P[:3, :3] = M; P[:3, 3] = _matx(M, (-poseC)[:, None])[:, 0]          # AssembleProjectionMatrix (libs/MVS/Camera.cpp:173-180)
+    invK = np.eye(4)
+    invK[0, 0] = 1.0 / Kr[0, 0]; invK[1, 1] = 1.0 / Kr[1, 1]; invK[0, 2] = -Kr[0, 2] * invK[0, 0]; invK[1, 2] = -Kr[1, 2] * invK[1, 1]   # Camera::InvK, libs/MVS/Camera.h:175-188
+    return _matx(_matx(P, invK), Q)
+
+
+def pair_file_name(a: int, b: int) -> str:
+    return "%04u_%04u.dimap" % (a, b)
+
+
+def _listed(neighbors, n_views, f_min_score_ratio, f_min_score):
+    """The neighbours `Match` / `Fuse` walk (:532-540, :742-759): best first, cut at numNeighbors and at the score threshold."""
+    if not len(neighbors):
+        return []
+    f_min = max(np.float32(neighbors[0]["score"]) * np.float32(f_min_score_ratio), np.float32(f_min_score))
+    out = []
+    for k, nb in enumerate(neighbors):
+        if (n_views and k >= n_views) or nb["score"] < f_min:
+            break
+        out.append(int(nb["ID"]))
+    return out
+
+
+def match_scene(be, sc, cams, bgr, neighbors, out_dir, n_views=0, f_min_score_ratio=0.03, f_min_score=2.0, min_resolution=320, subpixel_steps=4, avg_depth=None):
+    """`SemiGlobalMatcher::Match(scene, idxImage, numNeighbors, minResolution)` for every image (DenseReconstruction with nFusionMode == -1, SceneDensify.cpp:2046-2048):
+    each image against its listed neighbours -- a pair whose disparity file exists already, in either order, is skipped (:543-545) -- rectified, matched through the tSGM
+    loop seeded from the image's sparse points (`match_pair`), written as `<left>_<right>.dimap`.
+    sc: mvsi.Scene; cams: views.Cameras; bgr: the colour images; neighbors: {image: its whole scored list (Image::neighbors)}; avg_depth: {image: Image::avgDepth} for the
+    seed's corner points.  Returns the pairs written."""
+    import os
+    from . import dmap, views
+    os.makedirs(out_dir, exist_ok=True)
+    own = np.repeat(np.arange(len(sc.vertices)), np.diff(sc.vertex_view_start)); ids = sc.vertex_views["image_id"]
+    seen = {}
+
+    def sees(i):
+        if i not in seen:
+            s = np.zeros(len(sc.vertices), bool); s[own[ids == i]] = True; seen[i] = s
+        return seen[i]
+
+    cam = lambda i: (cams.K[i], cams.R[i], cams.C[i])
+    done = []
+    for i in sorted(neighbors):
+        for j in _listed(neighbors[i], n_views, f_min_score_ratio, f_min_score):
+            if os.path.exists(os.path.join(out_dir, pair_file_name(i, j))) or os.path.exists(os.path.join(out_dir, pair_file_name(j, i))):
+                continue
+            pts = np.nonzero(sees(i))[0]
+
+            def seed(w, h, i=i, pts=pts):
+                K, R, C, _, _ = sc.camera(i, (w, h))
+                P = K @ np.hstack([R, -(R @ C)[:, None]])
+                return views.triangulate_points_depth_map(K, P, sc.vertices[pts], w, h, avg_depth=None if avg_depth is None else avg_depth[i])[0]
+
+            p = match_pair(be, bgr[i], cam(i), bgr[j], cam(j), sc.vertices[sees(i) & sees(j)], min_resolution=min_resolution, subpixel_steps=subpixel_steps,
+                           seed_depth=seed if (avg_depth is not None and len(pts) >= 3) else None)
+            if p is None:
+                continue                                         # the pair cannot be rectified (:566-567)
+            dmap.save_dimap(os.path.join(out_dir, pair_file_name(i, j)), p["image_size"], p["H"], p["Q"], p["subpixel_steps"], p["disparity"], p["cost"])
+            done.append((i, j))
+    return done
+
+
+def fuse_scene(be, cams, sizes, neighbors, pair_dir, n_views=0, f_min_score_ratio=0.03, f_min_score=2.0, min_views=2, estimate_normals=True):
+    """`SemiGlobalMatcher::Fuse` for every image (DenseReconstruction with nFusionMode == -2, SceneDensify.cpp:2049-2057): the disparity files of the image's listed
+    neighbours -- stored as (image, neighbour), or as (neighbour, image) with Q carried over (`swapped_pair_q`) -- projected into the image and fused per pixel; normals from
+    the depths (`views.estimate_normal_map`) when `estimate_normals` (nEstimateNormals == 2).  sizes: {image: (w, h)}.
+    Returns {image: (depth, normal or None, conf)}; the depth range of such a map is (ZEROTOLERANCE, FLT_MAX), :2056."""
+    import os
+    from . import dmap, views
+    cam = lambda i: (cams.K[i], cams.R[i], cams.C[i])
+    out = {}
+    for i in sorted(neighbors):
+        pairs = []
+        for j in _listed(neighbors[i], n_views, f_min_score_ratio, f_min_score):
+            direct, swapped = os.path.join(pair_dir, pair_file_name(i, j)), os.path.join(pair_dir, pair_file_name(j, i))
+            if os.path.exists(direct):
+                g = dmap.load_dimap(direct)
+            elif os.path.exists(swapped):
+                g = dmap.load_dimap(swapped)
+                g["Q"] = swapped_pair_q(g["Q"], cam(i), cam(j))
+            else:
+                continue                                         # "no disparity-data file found for image pair"
+            pairs.append(dict(disparity=g["disparity"], cost=g["cost"], Q=g["Q"], subpixel_steps=g["subpixel_steps"], image_size=tuple(sizes[i])))
+        if not pairs:
+            w, h = sizes[i]
+            out[i] = (np.zeros((h, w), np.float32), None, np.zeros((h, w), np.float32))
+            continue
+        depth, conf = fuse_pairs(be, pairs, min_views)
+        out[i] = (depth, views.estimate_normal_map(cams.K[i], depth) if estimate_normals else None, conf)
+    return out

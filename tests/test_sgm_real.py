@@ -150,3 +150,40 @@ def test_seeded_first_level(scene):
         ok, dep, rg, cf_ = po.sgm_project_disparity2depth_map(m["disparity"], m["cost"], m["Q"], 4, m["image_size"])
         m["stats"] = _against_sfm(scene, 0, dep)
     assert p["stats"][0] >= q["stats"][0] - 0.02 and p["stats"][1] < 6e-3, (p["stats"], q["stats"])
+
+
+def test_scene_level_match_and_fuse(scene, tmp_path):
+    """`--fusion-mode -1` then `-2` over the scene (sgm_pipeline.match_scene / fuse_scene): each image matched against its best neighbour, a pair stored once whichever
+    image asked first, the other image fusing it through the swapped-pair Q (SemiGlobalMatcher.cpp:767-777); both land on the SfM points."""
+    from openmvs_amd import sgm_pipeline
+    sc, cams, bgr, seen = scene
+    be = OracleBackend()
+    nbs, avg = {}, {}
+    for i in (0, 2):
+        ok, nb, pts, a = views.select_neighbor_views(sc, cams, i)
+        assert ok
+        nbs[i] = nb; avg[i] = a
+    partner = int(nbs[0]["ID"][0])
+    nbs = {0: nbs[0], partner: views.select_neighbor_views(sc, cams, partner)[1]}
+    avg[partner] = views.select_neighbor_views(sc, cams, partner)[3]
+    # make the partner's best neighbour image 0, so that its only pair is the one image 0 writes
+    order = np.argsort([0 if int(v["ID"]) == 0 else 1 for v in nbs[partner]], kind="stable")
+    nbs[partner] = nbs[partner][order]
+    d = str(tmp_path / "pairs")
+    done = sgm_pipeline.match_scene(be, sc, cams, bgr, nbs, d, n_views=1, f_min_score=0.0, min_resolution=160, avg_depth=avg)
+    assert done == [(0, partner)] and sorted(os.listdir(d)) == [sgm_pipeline.pair_file_name(0, partner)]
+    assert sgm_pipeline.match_scene(be, sc, cams, bgr, nbs, d, n_views=1, f_min_score=0.0, min_resolution=160, avg_depth=avg) == []     # nothing left to do
+    sizes = {i: (bgr[i].shape[1], bgr[i].shape[0]) for i in nbs}
+    fused = sgm_pipeline.fuse_scene(be, cams, sizes, nbs, d, n_views=1, f_min_score=0.0, min_views=1)
+    for i in (0, partner):
+        depth, normal, conf = fused[i]
+        cover, med, p90 = _against_sfm(scene, i, depth)
+        assert (depth > 0).mean() > 0.3 and cover > 0.5 and med < 6e-3 and p90 < 3e-2, (i, cover, med, p90)
+        assert normal.shape == depth.shape + (3,) and (np.linalg.norm(normal[depth > 0], axis=-1) > 0.99).mean() > 0.8 and not normal[depth == 0].any()
+        assert conf[depth > 0].min() > 0
+    # the swapped Q really is another matrix, and without it the partner's map would be wrong
+    from openmvs_amd import dmap
+    g = dmap.load_dimap(os.path.join(d, sgm_pipeline.pair_file_name(0, partner)))
+    cam = lambda i: (cams.K[i], cams.R[i], cams.C[i])
+    Qs = sgm_pipeline.swapped_pair_q(g["Q"], cam(partner), cam(0))
+    assert not np.allclose(Qs, g["Q"]) and np.allclose(sgm_pipeline.swapped_pair_q(g["Q"], cam(0), cam(0)), g["Q"], rtol=1e-9, atol=1e-9)

@@ -210,3 +210,46 @@ def fuse_scene(be, cams, sizes, neighbors, pair_dir, n_views=0, f_min_score_rati
         depth, conf = fuse_pairs(be, pairs, min_views)
         out[i] = (depth, views.estimate_normal_map(cams.K[i], depth) if estimate_normals else None, conf)
     return out
+
+
+class DeviceBackend:
+    """The device behind `match_pair` / `fuse_pairs`: `sgm.SemiGlobalMatcherHIP` has every step of the interface (and the resident loop and fusion, `tsgm_match`,
+    `fuse_disparities`) except the float area resampler of the image pyramid, which the PatchMatch library provides (`PatchMatchHIP.resize`)."""
+
+    def __init__(self, matcher, engine):
+        self.m, self.e = matcher, engine
+
+    def resize_area_f32(self, img, f):
+        return self.e.resize(0, img, f)
+
+    def __getattr__(self, name):
+        return getattr(self.m, name)
+
+
+def dense_reconstruction(be, mvs_in, out_dir, fusion_mode, opt=None, image_loader=None, min_resolution=320):
+    """The SGM modes of `Scene::DenseReconstruction` (libs/MVS/SceneDensify.cpp:1655-1750, :2042-2058): `fusion_mode` -1 writes the disparity files of every image's
+    pairs into `out_dir`; -2 fuses the files found there into depth maps and writes `depthNNNN.dmap` (depth, normals when nEstimateNormals == 2, confidence; depth range
+    (ZEROTOLERANCE, FLT_MAX) as at :2056) -- what a later `--fusion-mode 0` run fuses into the cloud.  be: a backend (`DeviceBackend(SemiGlobalMatcherHIP(dev),
+    PatchMatchHIP(dev))`); opt: an `optdense.OptDense` (nNumViews, view-score cuts, resolution level); image_loader as in `densify.load_scene`.
+    Returns the pairs written (-1) or {image: (depth, normal, conf)} (-2)."""
+    import os
+    from . import densify, dmap, mvsi, optdense, views
+    if fusion_mode not in (-1, -2):
+        raise ValueError("the SGM path is fusion modes -1 and -2")
+    opt = opt or optdense.defaults()
+    sv = densify.load_scene(mvs_in, opt=opt, image_loader=image_loader)
+    if sv.alias_of or len(set(map(tuple, sv.sizes))) > 1:
+        raise NotImplementedError("the SGM driver takes scenes whose images share one size")
+    sc = mvsi.load(mvs_in)
+    cams = views.Cameras(sc, sv.sizes)
+    nbs = {i: sv.all_view_scores[i] for i in sv.ids if len(sv.all_view_scores.get(i, ()))}
+    args = dict(n_views=int(opt.nNumViews), f_min_score_ratio=float(opt.fViewMinScoreRatio), f_min_score=float(opt.fViewMinScore))
+    if fusion_mode == -1:
+        return match_scene(be, sc, cams, sv.bgr, nbs, out_dir, min_resolution=min_resolution, avg_depth=sv.avg_depth, **args)
+    sizes = {i: tuple(sv.sizes[i]) for i in nbs}
+    fused = fuse_scene(be, cams, sizes, nbs, out_dir, min_views=2, estimate_normals=int(opt.nEstimateNormals) == 2, **args)
+    for i, (depth, normal, conf) in fused.items():
+        ids = [i] + [int(v) for v in sv.neighbors[i]]
+        dmap.save(os.path.join(out_dir, dmap.depth_file_name(i)), sv.names[i], ids, sizes[i], sv.K[i], sv.R[i], sv.C[i], 1e-4, float(np.finfo(np.float32).max),      # ZEROTOLERANCE<float>() = FZERO_TOLERANCE (libs/Common/Types.h:579), FLT_MAX
+                  depth, normal, conf)
+    return fused

@@ -187,3 +187,34 @@ def test_scene_level_match_and_fuse(scene, tmp_path):
     cam = lambda i: (cams.K[i], cams.R[i], cams.C[i])
     Qs = sgm_pipeline.swapped_pair_q(g["Q"], cam(partner), cam(0))
     assert not np.allclose(Qs, g["Q"]) and np.allclose(sgm_pipeline.swapped_pair_q(g["Q"], cam(0), cam(0)), g["Q"], rtol=1e-9, atol=1e-9)
+
+
+def test_sgm_modes_of_dense_reconstruction(tmp_path):
+    """sgm_pipeline.dense_reconstruction: `--fusion-mode -1` then `-2` from the archive, at a quarter of the resolution: pair files once per pair, then depthNNNN.dmap with
+    depth, estimated normals and confidence that the .dmap reader takes back, on the SfM points."""
+    from openmvs_amd import dmap, optdense, sgm_pipeline
+    opt = optdense.defaults()
+    opt.nResolutionLevel = 2; opt.nMinResolution = 80; opt.nNumViews = 2; opt.nEstimateNormals = 2; opt.fViewMinScore = 0.0     # (Fuse wants two agreeing pairs per pixel, :2053)
+    mvs = os.path.join(SCENE, "scene.mvs")
+    d = str(tmp_path / "sgm")
+    be = OracleBackend()
+    done = sgm_pipeline.dense_reconstruction(be, mvs, d, -1, opt, min_resolution=40)
+    assert 4 <= len(done) <= 6 and sorted(os.listdir(d)) == sorted(sgm_pipeline.pair_file_name(a, b) for a, b in done)
+    assert not any((b, a) in done for a, b in done)                        # a pair is matched once
+    assert sgm_pipeline.dense_reconstruction(be, mvs, d, -1, opt, min_resolution=40) == []
+    fused = sgm_pipeline.dense_reconstruction(be, mvs, d, -2, opt)
+    assert sorted(fused) == [0, 1, 2, 3]
+    sc = mvsi.load(mvs)
+    for i in fused:
+        f = dmap.load(os.path.join(d, "depth%04d.dmap" % i))
+        depth, normal, conf = fused[i]
+        assert f["depth_map"].shape == (120, 160) and np.array_equal(f["depth_map"], depth) and np.array_equal(f["normal_map"], normal) and np.array_equal(f["confidence_map"], conf)
+        assert f["depth_min"] == np.float32(1e-4) and f["reference_view_id"] == i
+        K, R, C, _, _ = sc.camera(i, (160, 120))
+        X = sc.vertices.astype(np.float64)
+        cx = (X - C) @ R.T
+        u = np.rint(K[0, 2] + K[0, 0] * cx[:, 0] / cx[:, 2]).astype(int); v = np.rint(K[1, 2] + K[1, 1] * cx[:, 1] / cx[:, 2]).astype(int)
+        m = (cx[:, 2] > 0) & (u >= 0) & (v >= 0) & (u < 160) & (v < 120)
+        dm = depth[v[m], u[m]]; ok = dm > 0
+        rel = np.abs(dm[ok] - cx[m][ok, 2]) / cx[m][ok, 2]
+        assert (depth > 0).mean() > 0.2 and ok.mean() > 0.3 and np.median(rel) < 2e-2, (i, (depth > 0).mean(), ok.mean(), np.median(rel))

@@ -56,3 +56,33 @@ def test_out_of_range_view_index_is_rejected(tmp_path):
     struct.pack_into("<I", raw, o + 8, n_img + 7)
     p = tmp_path / "badview.mvs"; p.write_bytes(raw)
     assert _load(str(p)) == -2
+
+
+def test_stored_view_scores_with_huge_counts_or_foreign_ids(tmp_path):
+    """Archives of version 7 carry every image's view scores, which the reader now keeps as neighbour lists: a count that does not fit the file, or an ID that is not an
+    image of the scene, is a format error; truncations anywhere in the block are too.  (800 random text files and 600 randomly damaged version-7 archives went through an
+    AddressSanitizer / UBSan build of the two sources without a report: tools/README.md.)"""
+    import numpy as np
+    from openmvs_amd import mvsi, views
+    sc = mvsi.load(SCENE)
+    cams = views.Cameras(sc)
+    for i, im in enumerate(sc.images):
+        ok, nb, pts, avg = views.select_neighbor_views(sc, cams, i)
+        im.view_scores, im.avg_depth = nb, avg
+    p7 = tmp_path / "v7.mvs"
+    mvsi.save(str(p7), sc, version=7)
+    assert _load(str(p7)) == 0
+    raw = bytearray(p7.read_bytes())
+    first = sc.images[0].view_scores[:1].tobytes()
+    at = bytes(raw).find(first)
+    assert at > 8 and struct.unpack_from("<Q", raw, at - 8)[0] == len(sc.images[0].view_scores)
+    for val in (0xFFFFFFFFFFFFFFFF, 0x0AAAAAAAAAAAAAAB, 1 << 33, len(raw)):                      # the count of image 0's view scores
+        bad = bytearray(raw); struct.pack_into("<Q", bad, at - 8, val)
+        p = tmp_path / "count.mvs"; p.write_bytes(bad)
+        assert _load(str(p)) == -2, hex(val)
+    bad = bytearray(raw); struct.pack_into("<I", bad, at, len(sc.images))                       # a neighbour that is not an image of the scene
+    p = tmp_path / "id.mvs"; p.write_bytes(bad)
+    assert _load(str(p)) == -2
+    for cut in (at - 4, at + 3, at + 24 * len(sc.images[0].view_scores) - 1):
+        p = tmp_path / "cut.mvs"; p.write_bytes(raw[:cut])
+        assert _load(str(p)) == -2, cut

@@ -367,3 +367,10 @@ def ref_split_words(line: str):
     assert n >= 0
     words = buf.raw.split(b"\0")[:n]
     return [w.decode("latin-1") for w in words]
+
+
+def ref_image_size(width, height, level, min_size, max_size):
+    """TImage::computeMaxResolution then Image::ResizeImage (Types.inl:2457-2477, Image.cpp:139-155, verbatim in libref_text.so) -> (w, h, effective level, resolution, scale)."""
+    w, h, lv, res = C.c_uint(), C.c_uint(), C.c_uint(), C.c_uint(); sc = C.c_float()
+    _text_lib().ref_image_size(C.c_uint(width), C.c_uint(height), C.c_uint(level), C.c_uint(min_size), C.c_uint(max_size), C.byref(w), C.byref(h), C.byref(lv), C.byref(res), C.byref(sc))
+    return w.value, h.value, lv.value, res.value, sc.value

@@ -17,6 +17,7 @@
 #include <sys/stat.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <math.h>
 #include <sys/wait.h>
 #include <fstream>
 #include <iostream>
@@ -99,6 +100,37 @@ struct Scene {
 }
 #include "snip/depthmap_cpp_optdense.inc"   // DepthMap.cpp:50-115: the option list (opens and closes namespace MVS itself)
 
+// ---- the image size fed to the estimator: TImage::computeResize / computeMaxResolution (Types.inl:2437-2477) and Image::ResizeImage's size rule (Image.cpp:139-154) ----
+namespace cv {                                 // the two OpenCV names these lines use (types.hpp Size_, saturate_cast<int>(double) = cvRound: round half to even)
+struct Size { int width, height; Size() : width(0), height(0) {} Size(int w, int h) : width(w), height(h) {} };
+template <typename T> inline T saturate_cast(double v);
+template <> inline int saturate_cast<int>(double v) { return (int)lrint(v); }
+enum { INTER_AREA = 3 };
+}
+namespace SEACAVE {
+template <typename TYPE> struct TImage {
+	static cv::Size computeResize(const cv::Size& size, REAL scale);
+	static cv::Size computeResize(const cv::Size& size, REAL scale, unsigned resizes);
+	static unsigned computeMaxResolution(unsigned width, unsigned height, unsigned& level, unsigned minImageSize, unsigned maxImageSize);
+};
+typedef TImage<uint8_t> Image8U;
+#include "snip/types_inl_computeresize.inc"  // Types.inl:2437-2477
+}
+namespace MVS {
+struct ResizedImage {                          // the members of MVS::Image that ResizeImage touches; no pixels here (image.empty())
+	struct { bool empty() const { return true; } unsigned width() const { return 0; } unsigned height() const { return 0; } } image;
+	uint32_t width, height;
+	cv::Size GetSize() const { return cv::Size((int)width, (int)height); }
+	float ResizeImage(unsigned nMaxResolution);
+};
+namespace cvstub { template <typename A, typename B> inline void resize(A&, B&, cv::Size, int, int, int) {} }
+}
+#define Image ResizedImage
+namespace cv { using MVS::cvstub::resize; }
+using namespace MVS;
+#include "snip/image_cpp_resize.inc"         // Image.cpp:139-154: Image::ResizeImage
+#undef Image
+
 extern "C" {
 // OPTDENSE::init(); bValid = oConfig.Load(path); OPTDENSE::update() -- then every variable, in the order of the list, as a double
 #define REF_OPT_LIST(X) X(nResolutionLevel) X(nMaxResolution) X(nMinResolution) X(nSubResolutionLevels) X(nMinViews) X(nMaxViews) X(nMinViewsFuse) X(nMinViewsFilter) \
@@ -164,6 +196,14 @@ int ref_sml_root(const char* path, void (*cb)(const char* name, const char* valu
 	int n = 0;
 	for (SML::const_iterator it = sml.begin(); it != sml.end(); ++it, ++n) cb(it->first.c_str(), it->second.val.c_str(), ctx);
 	return ok ? n : -(n + 1);
+}
+// computeMaxResolution then ResizeImage, as Scene::ComputeDepthMaps prepares an image (SceneDensify.cpp:1806-1808): -> working size, effective level
+void ref_image_size(unsigned width, unsigned height, unsigned level, unsigned minSize, unsigned maxSize, unsigned* outW, unsigned* outH, unsigned* outLevel, unsigned* outRes, float* outScale) {
+	unsigned lv = level;
+	const unsigned res = Image8U::computeMaxResolution(width, height, lv, minSize, maxSize);
+	MVS::ResizedImage im; im.width = width; im.height = height;
+	const float sc = im.ResizeImage(res);
+	*outW = im.width; *outH = im.height; *outLevel = lv; *outRes = res; *outScale = sc;
 }
 // Util::CommandLineToArgvA: the words, NUL-separated, into out (cap bytes); returns their number
 int ref_split_words(const char* line, char* out, int cap) {

@@ -133,3 +133,19 @@ def test_view_neighbours_file_is_read_like_the_reference_reads_it(tmp_path, k):
     cf.save_view_neighbors(str(tmp_path / "c_out.txt")); mvsi.save_view_neighbors(py, str(tmp_path / "py_out.txt"))
     want = open(tmp_path / "ref_out.txt", "rb").read()
     assert want == open(tmp_path / "c_out.txt", "rb").read() == open(tmp_path / "py_out.txt", "rb").read()
+
+
+def test_working_resolution_is_the_reference_rule():
+    """--resolution-level / --min-resolution / --max-resolution -> the image size fed to the estimator: views.compute_max_resolution + views.resized_size against
+    TImage::computeMaxResolution + Image::ResizeImage, over sizes incl. odd ones and halves that round to even."""
+    from openmvs_amd import views
+    rng = np.random.default_rng(8)
+    cases = [(640, 479, 1, 640, 3200), (4000, 3000, 1, 640, 3200), (4000, 3000, 0, 640, 3200), (2000, 1000, 3, 640, 3200), (3840, 2160, 0, 640, 3840), (6000, 4000, 2, 640, 2560),
+             (1001, 667, 0, 100, 500), (667, 1001, 0, 100, 500), (1000, 1000, 0, 10, 333), (5, 3, 1, 640, 3200)]
+    for _ in range(400):
+        cases.append((int(rng.integers(1, 9000)), int(rng.integers(1, 9000)), int(rng.integers(0, 6)), int(rng.integers(1, 2000)), int(rng.integers(1, 5000))))
+    for W, H, level, mn, mx in cases:
+        rw, rh, rl, rres, rscale = pr.ref_image_size(W, H, level, mn, mx)
+        res, lv = views.compute_max_resolution(W, H, level, mn, mx)
+        assert (res, lv) == (rres, rl), (W, H, level, mn, mx)
+        assert views.resized_size(W, H, res) == (rw, rh), (W, H, level, mn, mx, res)

@@ -69,8 +69,9 @@ def resized_size(width: int, height: int, max_resolution: int):
 
 def to_gray(rgb: np.ndarray) -> np.ndarray:
     """`TImage::toGray(out, COLOR_BGR2GRAY, bNormalize=true)` (libs/Common/Types.inl:2377-2425) for an (h,w,3) uint8 RGB array:
-    float32 0.114*B + 0.587*G + 0.299*R of the channels divided by 255, summed in that (B, G, R) order."""
-    c = rgb.astype(f32) / f32(255)
+    float32 0.114*B + 0.587*G + 0.299*R of the channels times (1.f / 255.f) -- `CONVERT::NormRGB_t`, Types.inl:1610-1615: a product, which differs from a division
+    by 255 in the last bit for half of the byte values -- summed in that (B, G, R) order.  Pinned to the reference's helpers (tests/test_ref_text.py)."""
+    c = rgb.astype(f32) * (f32(1) / f32(255))
     return (f32(0.114) * c[..., 2] + f32(0.587) * c[..., 1]) + f32(0.299) * c[..., 0]
 
 

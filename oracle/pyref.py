@@ -374,3 +374,11 @@ def ref_image_size(width, height, level, min_size, max_size):
     w, h, lv, res = C.c_uint(), C.c_uint(), C.c_uint(), C.c_uint(); sc = C.c_float()
     _text_lib().ref_image_size(C.c_uint(width), C.c_uint(height), C.c_uint(level), C.c_uint(min_size), C.c_uint(max_size), C.byref(w), C.byref(h), C.byref(lv), C.byref(res), C.byref(sc))
     return w.value, h.value, lv.value, res.value, sc.value
+
+
+def ref_to_gray_bgr(bgr, srgb=False):
+    """TImage<Pixel8U>::toGray(COLOR_BGR2GRAY, bNormalize = true, bSRGB) with the reference's CONVERT helpers (Types.inl:1590-1659 verbatim) -> float32 image."""
+    a = np.ascontiguousarray(bgr, np.uint8)
+    out = np.zeros(a.shape[:-1], np.float32)
+    _text_lib().ref_to_gray_bgr(a.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(out.size), C.c_int(1 if srgb else 0), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out

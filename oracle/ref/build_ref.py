@@ -105,6 +105,7 @@ SNIPPETS = {
     "common_h_defvar":       ("libs/Common/Common.h", 101, 170, "// macros simplifying the task of managing options", "#define TDEFVAR_float(SPACE, name, title, desc, ...)"),
     "scene_cpp_loadnb":      ("libs/MVS/Scene.cpp", 423, 457, "bool Scene::LoadViewNeighbors(const String& fileName)", "} // LoadViewNeighbors"),
     "scene_cpp_savenb":      ("libs/MVS/Scene.cpp", 458, 479, "bool Scene::SaveViewNeighbors(const String& fileName) const", "} // SaveViewNeighbors"),
+    "types_inl_convert":     ("libs/Common/Types.inl", 1590, 1659, "namespace CONVERT {", "} // namespace CONVERT"),
     "types_inl_computeresize": ("libs/Common/Types.inl", 2437, 2477, "// compute scaled size such that the biggest dimension is scaled as desired", "}"),
     "image_cpp_resize":      ("libs/MVS/Image.cpp", 139, 154, "float Image::ResizeImage(unsigned nMaxResolution)", "} // ResizeImage"),
     "depthmap_cpp_optdense": ("libs/MVS/DepthMap.cpp", 50, 115, "#define DEFVAR_OPTDENSE_string(name, title, desc, ...)", "}"),

@@ -131,7 +131,28 @@ using namespace MVS;
 #include "snip/image_cpp_resize.inc"         // Image.cpp:139-154: Image::ResizeImage
 #undef Image
 
+// ---- colour to gray: the conversion helpers of libs/Common/Types.inl:1590-1659 (namespace CONVERT: NormRGB_t = value * (1 / 255), the sRGB -> linear table), which
+// TImage::toGray (Types.inl:2373-2421) applies per channel before the weighted sum ----
+#define POW std::pow                                   // Types.h:606
+namespace SEACAVE {
+template <typename TO, typename TI> inline TO ROUND2INT(TI v) { return (TO)lrint((double)v); }   // (only named by a helper that is not used here)
+#include "snip/types_inl_convert.inc"        // Types.inl:1590-1659
+}
+
 extern "C" {
+// TImage<Pixel8U>::toGray(out, COLOR_BGR2GRAY, bNormalize = true, bSRGB): the statement of Types.inl:2409 / :2419 over n pixels of B, G, R bytes
+void ref_to_gray_bgr(const uint8_t* src, size_t n, int bSRGB, float* dst) {
+	typedef float Real;
+	static const Real coeffsBGR[] = {Real(0.114), Real(0.587), Real(0.299)};
+	const Real &cb(coeffsBGR[0]), &cg(coeffsBGR[1]), &cr(coeffsBGR[2]);
+	if (bSRGB) {
+		typedef CONVERT::NormsRGB2RGB_t<uint8_t,Real> ColConv;
+		for (size_t i = 0; i < n; ++i, src += 3) dst[i] = float(cb*ColConv(src[0]) + cg*ColConv(src[1]) + cr*ColConv(src[2]));
+	} else {
+		typedef CONVERT::NormRGB_t<uint8_t,Real> ColConv;
+		for (size_t i = 0; i < n; ++i, src += 3) dst[i] = float(cb*ColConv(src[0]) + cg*ColConv(src[1]) + cr*ColConv(src[2]));
+	}
+}
 // OPTDENSE::init(); bValid = oConfig.Load(path); OPTDENSE::update() -- then every variable, in the order of the list, as a double
 #define REF_OPT_LIST(X) X(nResolutionLevel) X(nMaxResolution) X(nMinResolution) X(nSubResolutionLevels) X(nMinViews) X(nMaxViews) X(nMinViewsFuse) X(nMinViewsFilter) \
 	X(nMinViewsFilterAdjust) X(nMinViewsTrustPoint) X(nNumViews) X(nPointInsideROI) X(bFilterAdjust) X(bAddCorners) X(bInitSparse) X(bRemoveDmaps) X(fViewMinScore) \

@@ -186,7 +186,7 @@ def test_to_gray_is_the_bgr_weighted_sum():
     g = views.to_gray(rgb)[0]
     assert g.dtype == np.float32
     assert np.allclose(g[:4], [0.299, 0.587, 0.114, 1.0], atol=1e-6)
-    c = np.float32([77, 200, 12]) / np.float32(255)
+    c = np.float32([77, 200, 12]) * (np.float32(1) / np.float32(255))          # NormRGB_t: times the reciprocal, not a division
     assert g[4] == (np.float32(0.114) * c[0] + np.float32(0.587) * c[1]) + np.float32(0.299) * c[2]
 
 

@@ -149,3 +149,15 @@ def test_working_resolution_is_the_reference_rule():
         res, lv = views.compute_max_resolution(W, H, level, mn, mx)
         assert (res, lv) == (rres, rl), (W, H, level, mn, mx)
         assert views.resized_size(W, H, res) == (rw, rh), (W, H, level, mn, mx, res)
+
+
+def test_gray_conversion_is_the_reference_helpers():
+    """TImage::toGray as both paths call it: PatchMatch (normalised, views.to_gray) and SGM (normalised + sRGB -> linear, sgm_pipeline.to_gray_linear), against the
+    reference's CONVERT helpers compiled verbatim -- every byte value in every channel, and random pixels."""
+    from openmvs_amd import sgm_pipeline, views
+    rng = np.random.default_rng(0)
+    bgr = rng.integers(0, 256, (64, 256, 3)).astype(np.uint8)
+    for v in range(256):
+        bgr[0, v] = (v, v, v); bgr[1, v] = (v, 0, 0); bgr[2, v] = (0, v, 0); bgr[3, v] = (0, 0, v)
+    assert np.array_equal(views.to_gray(bgr[..., ::-1]), pr.ref_to_gray_bgr(bgr))
+    assert np.array_equal(sgm_pipeline.to_gray_linear(bgr), pr.ref_to_gray_bgr(bgr, srgb=True))

@@ -157,12 +157,29 @@ class Scene:
         else:                                   # ComposeK: principal point at the image centre
             Kp = np.array([[K[0, 0] * s, 0, 0.5 * (w - 1)], [0, K[1, 1] * s, 0.5 * (h - 1)], [0, 0, 1]], np.float64)
         Rp, Cp = pl.poses_R[im.pose_id], pl.poses_C[im.pose_id]
-        R = np.asarray(cam.R, np.float64) @ Rp
-        C = Rp.T @ np.asarray(cam.C, np.float64) + Cp
+        R = matx_mul(cam.R, Rp)                                           # Platform::GetCamera, libs/MVS/Platform.cpp:44-54
+        C = matx_mul(np.asarray(Rp).T, cam.C) + np.asarray(Cp, np.float64)
         return Kp, R, C, int(w), int(h)
 
     def views_of(self, v: int) -> np.ndarray:
         return self.vertex_views[self.vertex_view_start[v]:self.vertex_view_start[v + 1]]
+
+
+def matx_mul(a, b) -> np.ndarray:
+    """cv::Matx product as the reference's small matrices multiply: c(i, j) = sum_k a(i, k) b(k, j), accumulated left to right from 0 in double.  (numpy's `@` goes through
+    BLAS, whose blocked / fused summation differs from this in the last bit for almost every product.)"""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    vec = b.ndim == 1
+    if vec:
+        b = b[:, None]
+    c = np.zeros((a.shape[0], b.shape[1]))
+    for i in range(a.shape[0]):
+        for j in range(b.shape[1]):
+            s = 0.0
+            for k in range(a.shape[1]):
+                s += a[i, k] * b[k, j]
+            c[i, j] = s
+    return c[:, 0] if vec else c
 
 
 def _scale_k(K: np.ndarray, s: float) -> np.ndarray:

@@ -88,8 +88,9 @@ class Cameras:
                 continue
             K, R, C, w, h = scene.camera(i, None if sizes is None else sizes[i])
             self.K[i], self.R[i], self.C[i], self.size[i] = K, R, C, (w, h)
-            self.P[i, :, :3] = K @ R                    # Camera::ComposeP (libs/MVS/Camera.h)
-            self.P[i, :, 3] = -(K @ R) @ C
+            M = mvsi.matx_mul(K, R)                     # Camera::ComposeP -> AssembleProjectionMatrix (libs/MVS/Camera.cpp:173-180): P = [K R | K R (-C)]
+            self.P[i, :, :3] = M
+            self.P[i, :, 3] = mvsi.matx_mul(M, -np.asarray(C, np.float64))
 
     def point_depth(self, i: int, X: np.ndarray) -> np.ndarray:
         """`Camera::PointDepth` (libs/Common/Util.inl:462-464): R[2].(X-C) in double."""

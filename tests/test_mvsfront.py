@@ -139,3 +139,29 @@ def test_dense_initialisation_is_exact_on_a_plane():
     want = (n[2] * d0) / (r @ n)
     assert np.abs(d - want).max() < 2e-4 * d0
     assert np.abs(np.abs(nm @ n) - 1).max() < 1e-4                                       # every interpolated normal is the plane's
+
+
+def test_cameras_agree_when_the_platform_camera_is_not_the_identity(tmp_path):
+    """Platform::GetCamera composes the platform's own camera pose with the image's pose (R = Rc Rp, C = Rp^T Cc + Cp).  With a rotated, offset platform camera the
+    two front ends must still give the same bits: the numpy one multiplies like cv::Matx (sequential sums), not through BLAS."""
+    py = mvsi.load(SCENE)
+    a, b, c = 0.3, -0.2, 0.1
+    Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    Rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+    cam = py.platforms[0].cameras[0]
+    cam.R = Rz @ Ry @ Rx; cam.C = np.array([0.013, -0.027, 0.041])
+    p = str(tmp_path / "rig.mvs")
+    mvsi.save(p, py)
+    cf, py2 = mvsfront.SceneFront(p), mvsi.load(p)
+    pc = views.Cameras(py2)
+    for i in range(cf.n_images):
+        for size in ((0, 0), (321, 240)):
+            Kc, Rc, Cc = cf.camera(i, size)
+            Kp, Rp, Cp, _, _ = py2.camera(i, None if size == (0, 0) else size)
+            assert np.array_equal(Kc, Kp) and np.array_equal(Rc, Rp) and np.array_equal(Cc, Cp), (i, size)
+        assert not np.allclose(pc.R[i], py.platforms[0].poses_R[py.images[i].pose_id])          # the platform camera really takes part
+        # and view selection still agrees (integers exactly)
+    okc, nbc, ptc, avgc = cf.select_neighbor_views(0)
+    okp, nbp, ptp, avgp = views.select_neighbor_views(py2, pc, 0)
+    assert okc == okp and np.array_equal(nbc["ID"], nbp["ID"]) and np.array_equal(nbc["points"], nbp["points"]) and np.array_equal(ptc, ptp)

@@ -145,7 +145,12 @@ def test_resolution_rules():
     assert views.resized_size(640, 479, 640) == (640, 479)
     img = (np.arange(8 * 12 * 3) % 251).astype(np.uint8).reshape(8, 12, 3)
     half = densify._resize_area_u8(img, 6, 4)
-    assert half.shape == (4, 6, 3) and half[0, 0, 0] == np.rint(img[:2, :2, 0].astype(np.float32).mean())
+    blocks = img.reshape(4, 2, 6, 2, 3).astype(int).sum(axis=(1, 3))
+    assert half.shape == (4, 6, 3) and np.array_equal(half, (blocks + 2) >> 2)     # OpenCV's integer rule for a factor of 2: (a + b + c + d + 2) >> 2, halves round UP
+    ties = np.array([[1, 0], [1, 0]], np.uint8)                                     # mean 0.5: 1 under that rule (0 if it were rounded to even)
+    assert densify._resize_area_u8(np.tile(ties, (2, 2)), 2, 2).tolist() == [[1, 1], [1, 1]]
+    third = densify._resize_area_u8(np.tile(np.array([[1, 0, 0], [0, 0, 0], [0, 0, 0]], np.uint8) * 4 + np.uint8(0), (1, 1)), 1, 1)   # factor 3: sum * (1.f / 9) rounded to even: 4/9 -> 0
+    assert third.tolist() == [[0]]
     with pytest.raises(NotImplementedError):
         densify._resize_area_u8(img, 13, 4)                                          # enlarging is OpenCV's bilinear path: not restated
 

@@ -246,6 +246,19 @@ def ref_select_neighbor_views(cams, sizes, points, point_views, ID, nMinViews=2,
     return bool(ok), nb[:nn.value].copy(), keep[:npk.value].copy(), float(avg.value)
 
 
+def ref_pixel_camera(K, Rc, Cc, cam_size, Rp, Cp, size):
+    """The archive's platform camera (K, Rc, Cc, stored resolution cam_size or (0, 0) if already normalised) and an image's pose (Rp, Cp) -> that image's pixel camera
+    at `size`: Scene::LoadInterface's normalisation, Platform::GetCamera and Camera::GetK in the reference's own text (libref_scene.so)."""
+    lib = _scene_lib()
+    d = lambda a: np.ascontiguousarray(np.asarray(a, np.float64).ravel())
+    k, rc, cc, rp, cp = d(K), d(Rc), d(Cc), d(Rp), d(Cp)
+    oK, oR, oC = np.zeros(9), np.zeros(9), np.zeros(3)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    lib.ref_pixel_camera.restype = None
+    lib.ref_pixel_camera(p(k), p(rc), p(cc), C.c_uint32(int(cam_size[0])), C.c_uint32(int(cam_size[1])), p(rp), p(cp), C.c_uint32(int(size[0])), C.c_uint32(int(size[1])), p(oK), p(oR), p(oC))
+    return oK.reshape(3, 3), oR.reshape(3, 3), oC
+
+
 def ref_filter_neighbor_views(neighbors, fMinArea, fMinScale, fMaxScale, fMinAngle, fMaxAngle, nMaxViews):
     a = np.ascontiguousarray(neighbors, VIEW_SCORE).copy()
     n = _scene_lib().ref_filter_neighbor_views(a.ctypes.data_as(C.c_void_p), C.c_int(len(a)), C.c_float(fMinArea), C.c_float(fMinScale), C.c_float(fMaxScale), C.c_float(fMinAngle), C.c_float(fMaxAngle), C.c_uint(nMaxViews))

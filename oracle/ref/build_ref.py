@@ -74,6 +74,10 @@ SNIPPETS = {
     "camera_cpp_pointdepth": ("libs/MVS/Camera.cpp", 112, 115, "REAL Camera::PointDepth(const Point3& X) const", "} // PointDepth"),
     "scene_cpp_select":      ("libs/MVS/Scene.cpp", 801, 934, "bool Scene::SelectNeighborViews(uint32_t ID, IndexArr& points,", "} // SelectNeighborViews"),
     "scene_cpp_filter":      ("libs/MVS/Scene.cpp", 953, 968, "bool Scene::FilterNeighborViews(ViewScoreArr& neighbors,", "} // FilterNeighborViews"),
+    "camera_h_composek":     ("libs/MVS/Camera.h", 106, 122, "// returns the scale used to normalize the intrinsics", "}"),
+    "camera_h_scalek1":      ("libs/MVS/Camera.h", 144, 155, "// return scaled K (assuming standard K format)", "}"),
+    "camera_h_getk":         ("libs/MVS/Camera.h", 190, 201, "// returns full K and the inverse of K (assuming standard K format)", "}"),
+    "platform_cpp_getcamera": ("libs/MVS/Platform.cpp", 43, 54, "// return the normalized absolute camera pose", "} // GetCamera"),
     "camera_h_invk":         ("libs/MVS/Camera.h", 175, 188, "// return K.inv() (assuming standard K format and no shear)", "}"),
     "camera_h_i2c":          ("libs/MVS/Camera.h", 329, 344, "// un-project from image pixel coords to the camera space (z=1 plane by default)", "}"),
     "camera_h_c2w_i2w":      ("libs/MVS/Camera.h", 345, 356, "template <typename TYPE>", "}"),

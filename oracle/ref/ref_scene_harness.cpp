@@ -55,7 +55,36 @@ using namespace MVS;
 #include "snip/scene_cpp_select.inc"        // Scene.cpp:800-934: Scene::SelectNeighborViews(ID, ...)
 #include "snip/scene_cpp_filter.inc"        // Scene.cpp:952-968: Scene::FilterNeighborViews
 
+// ---- pixel cameras: Platform::GetCamera (Platform.cpp:43-54) and Camera::GetK (Camera.h:190-201) verbatim; what is written here is the Platform that holds one camera
+// and one pose, the normalisation statement of Scene::LoadInterface (Scene.cpp:100-104) and the two statements of Image::GetCamera (Image.cpp:196-199) ----
+namespace MVS {
+class Platform {
+public:
+	typedef MVS::Camera Camera;
+	struct Pose { RMatrix R; CMatrix C; };
+	SEACAVE::cList<Camera> cameras; SEACAVE::cList<Pose> poses;
+	Camera GetCamera(uint32_t cameraID, uint32_t poseID) const;
+};
+#include "snip/platform_cpp_getcamera.inc"
+}
+
 extern "C" {
+// K, Rc, Cc: the archive's platform camera (with its stored resolution camW x camH, 0 = already normalised); Rp, Cp: the image's pose; w x h: the working resolution
+void ref_pixel_camera(const double* K, const double* Rc, const double* Cc, uint32_t camW, uint32_t camH, const double* Rp, const double* Cp, uint32_t w, uint32_t h,
+		double* outK, double* outR, double* outC) {
+	Platform platform;
+	platform.cameras.resize(1); platform.poses.resize(1);
+	Platform::Camera& camera = platform.cameras[0];
+	for (int k = 0; k < 9; ++k) { camera.K.val[k] = K[k]; camera.R.val[k] = Rc[k]; platform.poses[0].R.val[k] = Rp[k]; }
+	camera.C.x = Cc[0]; camera.C.y = Cc[1]; camera.C.z = Cc[2];
+	platform.poses[0].C.x = Cp[0]; platform.poses[0].C.y = Cp[1]; platform.poses[0].C.z = Cp[2];
+	if (camW > 0 && camH > 0)                                                                  // !itCamera.IsNormalized(): Scene.cpp:100-104
+		camera.K = camera.GetScaledK(REAL(1)/Camera::GetNormalizationScale(camW, camH));
+	Camera cam(platform.GetCamera(0, 0));                                                     // Image::GetCamera, Image.cpp:196-199
+	cam.K = cam.GetK<REAL>(w, h);
+	for (int k = 0; k < 9; ++k) { outK[k] = cam.K.val[k]; outR[k] = cam.R.val[k]; }
+	outC[0] = cam.C.x; outC[1] = cam.C.y; outC[2] = cam.C.z;
+}
 struct RefViewScore { uint32_t ID, points; float scale, angle, area, score; };
 // cams: nImages x (K 9, R 9, C 3) doubles at each image's working resolution, sizes: nImages x (w, h); pts: nPoints x 3 floats; viewStart / views: CSR lists of the images
 // (ascending) that see each point.  Outputs: the candidate list of image ID in the reference's order, the indices of the points kept for it, its average depth.

@@ -347,6 +347,9 @@ public:
 #include "snip/camera_h_projectp.inc"    // Camera.h:307-320: ProjectPointP3, ProjectPointP
 #include "snip/camera_h_isinside.inc"    // Camera.h:402-405: IsInside(pt, size)
 #include "snip/camera_h_footprint.inc"   // Camera.h:437-446: GetFootprintImage
+#include "snip/camera_h_composek.inc"    // Camera.h:106-122: GetNormalizationScale, ComposeK
+#include "snip/camera_h_scalek1.inc"     // Camera.h:144-155: ScaleK(K, s), GetScaledK(s)
+#include "snip/camera_h_getk.inc"        // Camera.h:190-201: GetK(width, height)
 #endif
 };
 #ifdef REF_SCENE

@@ -93,3 +93,38 @@ def test_select_views_cut_matches_the_reference_pieces(scene):
                 cut = i; break
         got = cf.select_views(ID)
         assert got is not None and np.array_equal(got[0]["ID"], nb[:cut]["ID"]) and np.array_equal(got[0]["score"], nb[:cut]["score"]) and np.array_equal(got[1], keep)
+
+
+def test_pixel_cameras_are_the_reference_chain(scene, tmp_path):
+    """Scene::LoadInterface's normalisation of K, Platform::GetCamera (R = Rc Rp, C = Rp^T Cc + Cp) and Camera::GetK at a working resolution, in the reference's own
+    text, against mvsf_camera and mvsi.Scene.camera: the archive's scene, a rig whose platform camera is rotated and offset, a camera stored normalised, and one
+    without a principal point (ComposeK puts it at the image centre)."""
+    cf, py = scene
+    a, b, c = 0.31, -0.17, 0.09
+    Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    Rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+    import copy
+    variants = {}
+    variants["archive"] = py
+    rig = copy.deepcopy(py); rig.platforms[0].cameras[0].R = Rz @ Ry @ Rx; rig.platforms[0].cameras[0].C = np.array([0.013, -0.027, 0.041]); variants["rig"] = rig
+    nrm = copy.deepcopy(py); cam = nrm.platforms[0].cameras[0]
+    s = 1.0 / float(np.float32(max(cam.width, cam.height)))
+    cam.K = np.array([[cam.K[0][0] * s, 0, (cam.K[0][2] + 0.5) * s - 0.5], [0, cam.K[1][1] * s, (cam.K[1][2] + 0.5) * s - 0.5], [0, 0, 1]]); cam.width = cam.height = 0
+    variants["normalised"] = nrm
+    ctr = copy.deepcopy(nrm); k = ctr.platforms[0].cameras[0].K; k[0][2] = 0.0; k[1][2] = 0.0; variants["no principal point"] = ctr
+    for name, sc in variants.items():
+        p = str(tmp_path / (name.replace(" ", "_") + ".mvs"))
+        mvsi.save(p, sc)
+        c2, p2 = mvsfront.SceneFront(p), mvsi.load(p)
+        pcam = p2.platforms[0].cameras[0]
+        for i in range(c2.n_images):
+            im = p2.images[i]
+            Rp, Cp = p2.platforms[0].poses_R[im.pose_id], p2.platforms[0].poses_C[im.pose_id]
+            for size in ((640, 479), (321, 240), (1280, 958), (479, 640)):
+                want = pr.ref_pixel_camera(pcam.K, pcam.R, pcam.C, (pcam.width, pcam.height), Rp, Cp, size)
+                got_c = c2.camera(i, size)
+                got_p = p2.camera(i, size)[:3]
+                for w_, gc, gp, what in zip(want, got_c, got_p, "KRC"):
+                    assert np.array_equal(w_, gc), (name, i, size, what, "C++ front end")
+                    assert np.array_equal(w_, gp), (name, i, size, what, "numpy front end")

@@ -494,7 +494,11 @@ static void triangulatePoints(const mvsf_scene& s, const PixCam& cam, const uint
 
 // One face of the dense initialisation: TImage::RasterizeTriangleBary (libs/Common/Types.inl:2629-2669) driving the RasterDepth functor of
 // TriangulatePoints2DepthMap (libs/MVS/DepthMap.cpp:1159-1187): perspective-correct barycentric depth and normal at every covered pixel centre.
-static inline float edgeFn(const float* a, const float* b, const float* c) { return (c[0] - a[0]) * (b[1] - a[1]) - (c[1] - a[1]) * (b[0] - a[0]); }   // Util.inl:602-604
+// EdgeFunction, Util.inl:602-604: (x2 - x0).cross(x1 - x0) -- the differences in float, the cross product in double (cv::Point_::cross returns double), the result a float
+static inline float edgeFn(const float* a, const float* b, const float* c) {
+	const float dx2 = c[0] - a[0], dy2 = c[1] - a[1], dx1 = b[0] - a[0], dy1 = b[1] - a[1];
+	return (float)((double)dx2 * dy1 - (double)dy2 * dx1);
+}
 static void rasterFace(const float* v1, const float* v2, const float* v3, float z0, float z1, float z2, const float* n0, const float* n1, const float* n2,
 		int w, int h, float* depthMap, float* normalMap) {
 	const float mnx = std::min(v1[0], std::min(v2[0], v3[0])), mxx = std::max(v1[0], std::max(v2[0], v3[0]));

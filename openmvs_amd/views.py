@@ -398,7 +398,8 @@ def _raster_face(v, zs, ns, depthMap, normalMap):
         return
     x0, x1 = max(int(np.floor(mnx)), 0), min(int(np.ceil(mxx)), w - 1)
     y0, y1 = max(int(np.floor(mny)), 0), min(int(np.ceil(mxy)), h - 1)
-    edge = lambda a, b, c: f32(f32(f32(c[0] - a[0]) * f32(b[1] - a[1])) - f32(f32(c[1] - a[1]) * f32(b[0] - a[0])))     # (x2-x0).cross(x1-x0), Util.inl:602-604
+    # EdgeFunction, Util.inl:602-604: (x2 - x0).cross(x1 - x0) -- the differences in float, the cross product in DOUBLE (cv::Point_::cross returns double), then back to float
+    edge = lambda a, b, c: f32(float(f32(c[0] - a[0])) * float(f32(b[1] - a[1])) - float(f32(c[1] - a[1])) * float(f32(b[0] - a[0])))
     area = edge(v1, v2, v3)
     if area <= 0:
         return
@@ -424,8 +425,9 @@ def _raster_face(v, zs, ns, depthMap, normalMap):
                 continue
             n = (ns[0] * pb[0]).astype(f32) + (ns[1] * pb[1]).astype(f32)
             n = (n.astype(f32) + (ns[2] * pb[2]).astype(f32)).astype(f32)
-            nn = np.sqrt(float(n[0]) * n[0] + float(n[1]) * n[1] + float(n[2]) * n[2])
-            normalMap[y, x] = (n.astype(np.float64) * (1.0 / nn if nn else 0.0)).astype(f32)
+            nd = n.astype(np.float64)                                    # cv::normalize: the norm and the product in double (np.float64 operands: a Python float would
+            nn = np.sqrt((nd[0] * nd[0] + nd[1] * nd[1]) + nd[2] * nd[2])  # take the float32 operand's type under numpy 2's promotion rules)
+            normalMap[y, x] = (nd * (1.0 / nn if nn else 0.0)).astype(f32)
 
 
 # ---- ignore masks (`--ignore-mask-label`, `--mask-path`) ------------------------------------------------------------------------------------------

@@ -395,3 +395,15 @@ def ref_to_gray_bgr(bgr, srgb=False):
     out = np.zeros(a.shape[:-1], np.float32)
     _text_lib().ref_to_gray_bgr(a.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(out.size), C.c_int(1 if srgb else 0), out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
+
+
+def ref_raster_faces(w, h, projs, z, normals, faces):
+    """The face loop of TriangulatePoints2DepthMap with the reference's own rasteriser and functor (libref_fuse.so) -> (depth [h, w], normal [h, w, 3] or None)."""
+    lib = _fuse_lib()
+    pj = np.ascontiguousarray(projs, np.float32); zz = np.ascontiguousarray(z, np.float32); fc = np.ascontiguousarray(faces, np.uint32)
+    nr = None if normals is None else np.ascontiguousarray(normals, np.float32)
+    d = np.zeros((h, w), np.float32); n = np.zeros((h, w, 3), np.float32)
+    fp = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+    lib.ref_raster_faces.restype = None
+    lib.ref_raster_faces(C.c_int(w), C.c_int(h), C.c_int(len(zz)), fp(pj), fp(zz), fp(nr), C.c_int(len(fc)), fc.ctypes.data_as(C.POINTER(C.c_uint32)), fp(d), fp(n) if nr is not None else None)
+    return d, (n if nr is not None else None)

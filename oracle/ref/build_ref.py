@@ -100,6 +100,14 @@ SNIPPETS = {
     "scenedensify_estimate": ("libs/MVS/SceneDensify.cpp", 616, 805, "bool DepthMapsData::EstimateDepthMap(IIndex idxImage, int nGeometricIter)", "} // EstimateDepthMap"),
     "scenedensify_filters":  ("libs/MVS/SceneDensify.cpp", 809, 1045, "// filter out small depth segments from the given depth map", "} // GapInterpolation"),
     "scenedensify_filterdm": ("libs/MVS/SceneDensify.cpp", 1049, 1299, "// filter depth-map, one pixel at a time, using confidence based fusion or neighbor pixels", "} // FilterDepthMap"),
+    # the triangle rasteriser of the dense initialisation (ref_fuse_harness.cpp)
+    "types_h_minf3":         ("libs/Common/Types.h", 346, 353, "template<typename T>", "}"),
+    "types_h_clip":          ("libs/Common/Types.h", 1653, 1663, "template <typename T, int border=0>", "}"),
+    "types_inl_rasterbary":  ("libs/Common/Types.inl", 2625, 2669, "// same as above, but raster a triangle using barycentric coordinates:", "}"),
+    "util_inl_edge":         ("libs/Common/Util.inl", 600, 604, "// compute area for a triangle defined by three 2D points", "}"),
+    "util_inl_perspbary":    ("libs/Common/Util.inl", 745, 749, "template <typename TYPE>", "}"),
+    "mesh_h_rasterbase":     ("libs/MVS/Mesh.h", 283, 325, "// used to render a 3D triangle", "};"),
+    "depthmap_cpp_rasterdepth": ("libs/MVS/DepthMap.cpp", 1156, 1178, "struct RasterDepth : TRasterMeshBase<RasterDepth> {", "};"),
     "depthmap_cpp_estnormal": ("libs/MVS/DepthMap.cpp", 1522, 1613, "bool MVS::EstimateNormalMap(const Matrix3x3f& K, const DepthMap& depthMap, NormalMap& normalMap)", "} // EstimateNormalMap"),
     # the two text files in front of the path (ref_text_harness.cpp)
     "util_h_flags":          ("libs/Common/Util.h", 55, 89, "template <typename TYPE>", "typedef class GENERAL_API TFlags<uint32_t> Flags;"),

@@ -75,6 +75,19 @@ void DepthData::GetNormal(const ImageRef& ir, Point3f& N, const TImage<Point3f>*
 	if (normalMap.empty()) abort();
 	N = camera.R.t()*Cast<REAL>(normalMap(ir));
 }
+// ---- the triangle rasteriser of the dense initialisation: TImage::RasterizeTriangleBary (Types.inl:2625-2669) with EdgeFunction, the perspective-correct barycentric
+// coordinates, TRasterMeshBase (Mesh.h:283-325) and the RasterDepth functor of TriangulatePoints2DepthMap (DepthMap.cpp:1156-1178), all verbatim ----
+namespace SEACAVE {
+#include "snip/types_h_minf3.inc"            // Types.h:346-353: MINF3, MAXF3
+#include "snip/util_inl_edge.inc"            // Util.inl:600-604: EdgeFunction
+#include "snip/util_inl_perspbary.inc"       // Util.inl:745-749: PerspectiveCorrectBarycentricCoordinates
+#include "snip/types_inl_rasterbary.inc"     // Types.inl:2625-2669
+}
+namespace MVS {
+struct Mesh { typedef TPoint3<float> Normal; typedef SEACAVE::cList<Normal> NormalArr; typedef TPoint3<uint32_t> Face; };   // Mesh.h: the three names the functor uses
+#include "snip/mesh_h_rasterbase.inc"        // Mesh.h:283-325
+#include "snip/depthmap_cpp_rasterdepth.inc" // DepthMap.cpp:1156-1178 (a local struct of TriangulatePoints2DepthMap there)
+}
 #include "snip/depthmap_cpp_estnormal.inc"   // DepthMap.cpp:1522-1613: EstimateNormalMap (what FuseDepthMaps, the SGM fuse mode and a resumed .dmap without normals call)
 #include "snip/scenedensify_conf2weight.inc" // SceneDensify.cpp:119-122: Conf2Weight
 #include "snip/scenedensify_fuse.inc"       // SceneDensify.cpp:1303-1646: MergeDepthMaps, FuseDepthMaps
@@ -90,6 +103,29 @@ struct OrcFuseCloud {
 	uint64_t nPoints, nDepths, nViews;
 	float* points; uint32_t* viewStart; uint32_t* views; float* weights; uint16_t* projs; uint8_t* colors; float* normals;
 };
+// The face loop of TriangulatePoints2DepthMap (DepthMap.cpp:1178-1188) over nFaces triangles: projs = 2-D projections (floats), z = camera-space depths of the vertices,
+// normals = vertex normals (3 floats each, or NULL: the depth-only variant, :1229-1247, has the same functor without them); maps are zero where no face lands
+void ref_raster_faces(int w, int h, int nVerts, const float* projs, const float* z, const float* normals, int nFaces, const uint32_t* faces, float* depthOut, float* normalOut) {
+	Camera camera;
+	DepthMap depthMap(cv::Size(w, h)); NormalMap normalMap(cv::Size(w, h));
+	memset((void*)depthMap.data(), 0, sizeof(float) * (size_t)w * h); memset((void*)normalMap.data(), 0, sizeof(float) * 3 * (size_t)w * h);
+	Mesh::NormalArr vertexNormals; vertexNormals.resize((unsigned)nVerts);
+	for (int i = 0; i < nVerts; ++i) vertexNormals[i] = normals ? Mesh::Normal(normals[3*i], normals[3*i+1], normals[3*i+2]) : Mesh::Normal(0, 0, -1);
+	RasterDepth rasterer = {vertexNormals, camera, depthMap, normalMap};
+	for (int f = 0; f < nFaces; ++f) {
+		const Mesh::Face face(faces[3*f], faces[3*f+1], faces[3*f+2]);
+		rasterer.face = face;
+		rasterer.ptc[0].z = z[face[0]];
+		rasterer.ptc[1].z = z[face[1]];
+		rasterer.ptc[2].z = z[face[2]];
+		Image8U::RasterizeTriangleBary(
+			Point2f(projs[2*face[0]], projs[2*face[0]+1]),
+			Point2f(projs[2*face[1]], projs[2*face[1]+1]),
+			Point2f(projs[2*face[2]], projs[2*face[2]+1]), rasterer);
+	}
+	memcpy(depthOut, (const void*)depthMap.data(), sizeof(float) * (size_t)w * h);
+	if (normalOut) memcpy(normalOut, (const void*)normalMap.data(), sizeof(float) * 3 * (size_t)w * h);
+}
 // MVS::EstimateNormalMap: K 9 floats row-major, depth w*h -> normal w*h*3
 int ref_estimate_normal_map(const float* K, const float* depth, int w, int h, float* normal) {
 	Matrix3x3f Kf; for (int k = 0; k < 9; ++k) Kf.val[k] = K[k];

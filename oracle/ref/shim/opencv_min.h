@@ -50,6 +50,7 @@ public:
 	template<typename _Tp2> operator Point_<_Tp2>() const { return Point_<_Tp2>(saturate_cast<_Tp2>(x), saturate_cast<_Tp2>(y)); }
 	_Tp dot(const Point_& pt) const { return saturate_cast<_Tp>(x*pt.x + y*pt.y); }
 	double ddot(const Point_& pt) const { return (double)x*(double)pt.x + (double)y*(double)pt.y; }
+	double cross(const Point_& pt) const { return (double)x*pt.y - (double)y*pt.x; }   // types.hpp: the cross product is formed in double
 	_Tp x, y;
 };
 template<typename _Tp> static inline Point_<_Tp>& operator += (Point_<_Tp>& a, const Point_<_Tp>& b) { a.x += b.x; a.y += b.y; return a; }

@@ -201,6 +201,9 @@ public:
 	inline TYPE& operator()(int row, int col) { return d.get()[(size_t)row * (size_t)sz.width + (size_t)col]; }
 	inline Size size() const { return sz; }
 	Size sz; std::shared_ptr<TYPE> d;    // shallow copies share the pixels, as cv::Mat headers do
+#ifdef REF_FUSE
+#include "snip/types_h_clip.inc"         // Types.h:1653-1663: clip(ptMin, ptMax, size) (TDMatrix, the base of TImage)
+#endif
 	int rows = 0, cols = 0;              // cv::Mat's public fields (kept in step with sz by create / release)
 };
 template <typename TYPE> class TImage : public TImageStore<TYPE> {
@@ -211,6 +214,10 @@ public:
 	typedef cv::Size Size;
 	inline TImage() {}
 	inline TImage(const Size& s) { create(s); }
+#ifdef REF_FUSE
+	template <typename T, typename PARSER, bool CULL=true>
+	static void RasterizeTriangleBary(const TPoint2<T>& v1, const TPoint2<T>& v2, const TPoint2<T>& v3, PARSER& parser);   // Types.h:2192-2193
+#endif
 	inline TImage(const Size& s, const TYPE& v) { create(s); for (size_t i = 0, n = (size_t)s.width * s.height; i < n; ++i) Base::d.get()[i] = v; }   // cv::Mat_(Size, value)
 	inline void create(const Size& s) { Base::sz = s; Base::rows = s.height; Base::cols = s.width; Base::d = std::shared_ptr<TYPE>(new TYPE[(size_t)s.width * s.height](), std::default_delete<TYPE[]>()); }
 	inline void setTo(const TYPE& v) { for (size_t i = 0, n = (size_t)Base::sz.width * Base::sz.height; i < n; ++i) Base::d.get()[i] = v; }   // cv::Mat::setTo(scalar)

@@ -115,3 +115,34 @@ def test_estimate_normal_map_is_the_reference_function(case):
         assert (nz[2:-2, 2:-2] > 0.999).all() and (got[..., 2][nz > 0] < 0).all()              # unit normals facing the camera
     if case == "garbage":
         assert (np.linalg.norm(got, axis=-1) == 0).mean() > 0.9
+
+
+@pytest.mark.parametrize("seed", [2, 5, 11])
+def test_dense_initialisation_rasteriser_is_the_reference_code(seed):
+    """TImage::RasterizeTriangleBary + EdgeFunction + the perspective-correct barycentric coordinates + TRasterMeshBase + the RasterDepth functor of
+    TriangulatePoints2DepthMap (all verbatim in libref_fuse.so) against views._raster_face over a random Delaunay mesh that overhangs the image: depth and normal maps bit
+    for bit.  (mvs_front.cpp's rasterFace is compared with the numpy one on whole dense maps in tests/test_mvsfront.py.)"""
+    from scipy.spatial import Delaunay
+    from openmvs_amd import views
+    rng = np.random.default_rng(seed)
+    w, h, nv = 64, 48, 30
+    proj = (rng.random((nv, 2)) * [w + 10, h + 10] - 5).astype(np.float32)
+    z = (rng.random(nv) * 3 + 2).astype(np.float32)
+    nrm = rng.normal(size=(nv, 3)); nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    faces = []
+    for f in Delaunay(proj.astype(np.float64)).simplices.astype(np.uint32):
+        a, b, c = proj[f].astype(np.float64)
+        faces.append(f if (c[0] - a[0]) * (b[1] - a[1]) - (c[1] - a[1]) * (b[0] - a[0]) > 0 else f[[0, 2, 1]])      # front-facing for EdgeFunction (back faces are culled)
+    faces = np.array(faces, np.uint32)
+    rd, rn = pr.ref_raster_faces(w, h, proj, z, nrm, faces)
+    d = np.zeros((h, w), np.float32); n = np.zeros((h, w, 3), np.float32)
+    for fa in faces:
+        views._raster_face(proj[fa], z[fa], nrm[fa], d, n)
+    assert (rd > 0).mean() > 0.5
+    assert np.array_equal(rd.view(np.uint32), d.view(np.uint32)) and np.array_equal(rn.view(np.uint32), n.view(np.uint32))
+    d2 = np.zeros((h, w), np.float32)                                            # the depth-only variant (DepthMap.cpp:1229-1247): the same depths
+    for fa in faces:
+        views._raster_face(proj[fa], z[fa], None, d2, None)
+    assert np.array_equal(d2, pr.ref_raster_faces(w, h, proj, z, None, faces)[0]) and np.array_equal(d2, d)
+    rd_back = pr.ref_raster_faces(w, h, proj, z, nrm, faces[:, [0, 2, 1]])[0]    # back-facing triangles are culled
+    assert not rd_back.any()

@@ -79,6 +79,12 @@ int mvsf_init_depth_map_dense(const mvsf_scene* s, int idx, int w, int h, const 
 int mvsf_triangulate_depth_map(const mvsf_scene* s, int idx, int w, int h, const uint32_t* points, int nPoints, int addCorners, float avgDepth, int sparseOnly,
                                float* depthMap, float* dMin, float* dMax);
 
+/* Normals of a depth map that has none (MVS::EstimateNormalMap, libs/MVS/DepthMap.cpp:1522-1613: what InitViews does with a .dmap stored without normals,
+ * SceneDensify.cpp:411-414, FuseDepthMaps with such a map, :1427, and the SGM fuse mode, :2055): per pixel the least-squares depth gradient over the 8-neighbourhood
+ * (neighbours with a depth within 3 % of the pixel's, at least three), then normalize((K00 dx, K11 dy, (K02 - x) dx + (K12 - y) dy - d)); zero where that fails.
+ * K: 9 doubles row-major (used as floats, like the reference's Matrix3x3f); depth: w*h; normal: w*h*3. */
+int mvsf_estimate_normal_map(const double K[9], const float* depth, int w, int h, float* normal);
+
 #ifdef __cplusplus
 }
 #endif

@@ -692,4 +692,35 @@ int mvsf_save_view_neighbors(const mvsf_scene* s, const char* path) {
 	return fclose(f) == 0 ? 0 : -2;
 }
 
+// MVS::EstimateNormalMap, libs/MVS/DepthMap.cpp:1522-1613 (the active least-squares branch)
+int mvsf_estimate_normal_map(const double K[9], const float* depth, int w, int h, float* normal) {
+	if (!K || !depth || !normal || w <= 0 || h <= 0) return -1;
+	const float k00 = (float)K[0], k11 = (float)K[4], k02 = (float)K[2], k12 = (float)K[5];
+	for (int r = 0; r < h; ++r) for (int c = 0; c < w; ++c) {
+		float* n = normal + 3 * ((size_t)r * w + c);
+		n[0] = n[1] = n[2] = 0.f;
+		const float d = depth[(size_t)r * w + c];
+		if (d <= 0) continue;
+		int sxx = 0, sxy = 0, syy = 0, count = 0;
+		float gx = 0, gy = 0;
+		for (int y = -1; y <= 1; ++y) for (int x = -1; x <= 1; ++x) {
+			if ((x == 0 && y == 0) || c + x < 0 || r + y < 0 || c + x >= w || r + y >= h) continue;
+			const float di = depth[(size_t)(r + y) * w + (c + x)];
+			if (!(di > 0 && fabsf(d - di) / d < 0.03f)) continue;          // IsDepthSimilar(d, di, 0.03f), libs/Common/Util.inl:797-809
+			sxx += x * x; sxy += x * y; syy += y * y;
+			gx += (di - d) * (float)x; gy += (di - d) * (float)y;
+			++count;
+		}
+		const int det = sxx * syy - sxy * sxy;
+		if (count < 3 || det == 0) continue;
+		const float inv = 1.f / (float)det;
+		const float dx = ((float)syy * gx - (float)sxy * gy) * inv, dy = ((float)(-sxy) * gx + (float)sxx * gy) * inv;
+		const float v[3] = {k00 * dx, k11 * dy, (k02 - (float)c) * dx + (k12 - (float)r) * dy - d};
+		const double nv = sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]);      // cv::normalize: v * (1 / |v|), norm and product in double
+		const double a = nv ? 1. / nv : 0.;
+		n[0] = (float)(v[0] * a); n[1] = (float)(v[1] * a); n[2] = (float)(v[2] * a);
+	}
+	return 0;
+}
+
 } // extern "C"

@@ -11,7 +11,7 @@ from . import build as _build
 VIEW_SCORE_DTYPE = np.dtype([("ID", "<u4"), ("points", "<u4"), ("scale", "<f4"), ("angle", "<f4"), ("area", "<f4"), ("score", "<f4")])
 EXPORTS = ["mvsf_default_options", "mvsf_load", "mvsf_free", "mvsf_version", "mvsf_num_images", "mvsf_num_points", "mvsf_image_info", "mvsf_point",
            "mvsf_camera", "mvsf_select_views", "mvsf_select_neighbor_views", "mvsf_init_depth_map", "mvsf_init_depth_map_dense", "mvsf_triangulate_depth_map",
-           "mvsf_get_neighbors", "mvsf_set_neighbors", "mvsf_load_view_neighbors", "mvsf_save_view_neighbors", "mvsf_image_depths"]
+           "mvsf_get_neighbors", "mvsf_set_neighbors", "mvsf_load_view_neighbors", "mvsf_save_view_neighbors", "mvsf_image_depths", "mvsf_estimate_normal_map"]
 
 
 class MVSFOptions(C.Structure):
@@ -150,3 +150,14 @@ class SceneFront:
         if rc != 0:
             raise ValueError("mvsf_triangulate_depth_map failed: %d" % rc)
         return d, float(dmin.value), float(dmax.value)
+
+
+def estimate_normal_map(K, depth):
+    """mvsf_estimate_normal_map (MVS::EstimateNormalMap): K 3x3, depth [h, w] -> normals [h, w, 3] float32."""
+    d = np.ascontiguousarray(depth, np.float32); h, w = d.shape
+    k = np.ascontiguousarray(np.asarray(K, np.float64).ravel())
+    out = np.zeros((h, w, 3), np.float32)
+    rc = load_library().mvsf_estimate_normal_map(k.ctypes.data_as(C.POINTER(C.c_double)), d.ctypes.data_as(C.POINTER(C.c_float)), w, h, out.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc != 0:
+        raise ValueError("mvsf_estimate_normal_map: %d" % rc)
+    return out

@@ -105,8 +105,10 @@ def test_estimate_normal_map_is_the_reference_function(case):
     if case == "holes":
         d[rng.random((h, w)) < 0.35] = 0
         d[10:14] = 0
+    from openmvs_amd import mvsfront
     got = views.estimate_normal_map(K, d)
     want = pr.ref_estimate_normal_map(K, d)
+    assert np.array_equal(mvsfront.estimate_normal_map(K, d).view(np.uint32), want.view(np.uint32)), "C++ front end"
     assert got.dtype == np.float32 and got.shape == (h, w, 3)
     bad = np.flatnonzero(got.view(np.uint32).ravel() != want.view(np.uint32).ravel())
     assert bad.size == 0, (case, bad[:5], got.ravel()[bad[:5]], want.ravel()[bad[:5]])

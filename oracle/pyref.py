@@ -407,3 +407,17 @@ def ref_raster_faces(w, h, projs, z, normals, faces):
     lib.ref_raster_faces.restype = None
     lib.ref_raster_faces(C.c_int(w), C.c_int(h), C.c_int(len(zz)), fp(pj), fp(zz), fp(nr), C.c_int(len(fc)), fc.ctypes.data_as(C.POINTER(C.c_uint32)), fp(d), fp(n) if nr is not None else None)
     return d, (n if nr is not None else None)
+
+
+def ref_init_views_splat(K, R, Cc, size, X, pts):
+    """The nMinViewsTrustPoint < 2 branch of DepthMapsData::InitViews (SceneDensify.cpp:418-451 verbatim in libref_fuse.so) -> (depth, normal, dMin, dMax)."""
+    w, h = size
+    d = np.zeros((h, w), np.float32); n = np.ones((h, w, 3), np.float32); mn = C.c_float(); mx = C.c_float()
+    Xf = np.ascontiguousarray(X, np.float32); p = np.ascontiguousarray(pts, np.uint32)
+    dd = lambda a: np.ascontiguousarray(np.asarray(a, np.float64).ravel()).ctypes.data_as(C.POINTER(C.c_double))
+    k, r, c = (np.ascontiguousarray(np.asarray(a, np.float64).ravel()) for a in (K, R, Cc))
+    lib = _fuse_lib(); lib.ref_init_views_splat.restype = None
+    lib.ref_init_views_splat(k.ctypes.data_as(C.POINTER(C.c_double)), r.ctypes.data_as(C.POINTER(C.c_double)), c.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(w), C.c_int(h),
+                             Xf.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(len(Xf)), p.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int(len(p)),
+                             d.ctypes.data_as(C.POINTER(C.c_float)), n.ctypes.data_as(C.POINTER(C.c_float)), C.byref(mn), C.byref(mx))
+    return d, n, mn.value, mx.value

@@ -108,6 +108,7 @@ SNIPPETS = {
     "util_inl_perspbary":    ("libs/Common/Util.inl", 745, 749, "template <typename TYPE>", "}"),
     "mesh_h_rasterbase":     ("libs/MVS/Mesh.h", 283, 325, "// used to render a 3D triangle", "};"),
     "depthmap_cpp_rasterdepth": ("libs/MVS/DepthMap.cpp", 1156, 1178, "struct RasterDepth : TRasterMeshBase<RasterDepth> {", "};"),
+    "scenedensify_initsplat": ("libs/MVS/SceneDensify.cpp", 418, 451, "// compute depth range and initialize known depths, else random", "}"),
     "depthmap_cpp_estnormal": ("libs/MVS/DepthMap.cpp", 1522, 1613, "bool MVS::EstimateNormalMap(const Matrix3x3f& K, const DepthMap& depthMap, NormalMap& normalMap)", "} // EstimateNormalMap"),
     # the two text files in front of the path (ref_text_harness.cpp)
     "util_h_flags":          ("libs/Common/Util.h", 55, 89, "template <typename TYPE>", "typedef class GENERAL_API TFlags<uint32_t> Flags;"),

@@ -7,6 +7,7 @@
 // a depth map has no normal map) are stubs.
 #define REF_SCENE 1
 #define REF_FUSE 1
+#include <float.h>
 #include "seacave_min.h"
 #define DEBUG_EXTRA(...) ((void)0)
 #define _T(x) x
@@ -125,6 +126,27 @@ void ref_raster_faces(int w, int h, int nVerts, const float* projs, const float*
 	}
 	memcpy(depthOut, (const void*)depthMap.data(), sizeof(float) * (size_t)w * h);
 	if (normalOut) memcpy(normalOut, (const void*)normalMap.data(), sizeof(float) * 3 * (size_t)w * h);
+}
+// DepthMapsData::InitViews with OPTDENSE::nMinViewsTrustPoint < 2 (SceneDensify.cpp:418-451, the body of that branch verbatim): the depth range of the image's sparse
+// points and their depths splatted on 5x5 blocks.  X: all scene points (3 floats each); pts: the indices this image sees
+void ref_init_views_splat(const double* K, const double* R, const double* C, int w, int h, const float* X, int nX, const uint32_t* pts, int nPts, float* depthOut, float* normalOut,
+		float* dMin, float* dMax) {
+	struct { struct { SEACAVE::cList<TPoint3<float>> points; } pointcloud; } scene;
+	scene.pointcloud.points.resize((unsigned)nX);
+	for (int i = 0; i < nX; ++i) scene.pointcloud.points[i] = TPoint3<float>(X[3*i], X[3*i+1], X[3*i+2]);
+	DepthData depthData;
+	depthData.points.resize((unsigned)nPts);
+	for (int i = 0; i < nPts; ++i) depthData.points[i] = pts[i];
+	DepthData::ViewData viewRef;
+	for (int k = 0; k < 9; ++k) { viewRef.camera.K.val[k] = K[k]; viewRef.camera.R.val[k] = R[k]; }
+	viewRef.camera.C.x = C[0]; viewRef.camera.C.y = C[1]; viewRef.camera.C.z = C[2];
+	viewRef.image.create(cv::Size(w, h));
+	{
+#include "snip/scenedensify_initsplat.inc"
+	}
+	memcpy(depthOut, (const void*)depthData.depthMap.data(), sizeof(float) * (size_t)w * h);
+	memcpy(normalOut, (const void*)depthData.normalMap.data(), sizeof(float) * 3 * (size_t)w * h);
+	*dMin = depthData.dMin; *dMax = depthData.dMax;
 }
 // MVS::EstimateNormalMap: K 9 floats row-major, depth w*h -> normal w*h*3
 int ref_estimate_normal_map(const float* K, const float* depth, int w, int h, float* normal) {

@@ -148,3 +148,26 @@ def test_dense_initialisation_rasteriser_is_the_reference_code(seed):
     assert np.array_equal(d2, pr.ref_raster_faces(w, h, proj, z, None, faces)[0]) and np.array_equal(d2, d)
     rd_back = pr.ref_raster_faces(w, h, proj, z, nrm, faces[:, [0, 2, 1]])[0]    # back-facing triangles are culled
     assert not rd_back.any()
+
+
+def test_untrusted_point_initialisation_is_the_reference_code():
+    """`Min Views Trust Point = 1`: InitViews splats the sparse points' depths on 5x5 blocks with zero normals and takes the depth range from them (SceneDensify.cpp:418-451,
+    verbatim) -- against mvsf_init_depth_map and views.init_depth_map on the pipeline-test scene at two working resolutions, and with no points at all."""
+    import os
+    from openmvs_amd import mvsfront, mvsi, views
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "scene", "scene.mvs")
+    cf, py = mvsfront.SceneFront(path), mvsi.load(path)
+    opt = views.DenseOptions(nMinViewsTrustPoint=1)
+    for size in ((640, 479), (320, 240)):
+        cams = views.Cameras(py, [size] * 4)
+        for i in (0, 3):
+            ok, nb, pts, avg = views.select_neighbor_views(py, cams, i)
+            want = pr.ref_init_views_splat(cams.K[i], cams.R[i], cams.C[i], size, py.vertices, pts)
+            got_c = cf.init_depth_map(i, pts, size, nMinViewsTrustPoint=1)
+            got_p = views.init_depth_map(py, cams, i, pts, opt)
+            for name, got in (("C++", got_c), ("numpy", got_p)):
+                assert np.array_equal(got[0], want[0]) and not got[1].any() and not want[1].any(), (name, size, i)
+                assert np.float32(got[2]) == np.float32(want[2]) and np.float32(got[3]) == np.float32(want[3]), (name, size, i, got[2:], want[2:])
+            assert (want[0] > 0).mean() > 0.02
+    none = pr.ref_init_views_splat(cams.K[0], cams.R[0], cams.C[0], (320, 240), py.vertices, np.zeros(0, np.uint32))
+    assert not none[0].any() and np.float32(none[2]) == np.float32(0.1) and none[3] == 100.0

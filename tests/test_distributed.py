@@ -252,7 +252,7 @@ def test_neighbour_only_exchange_of_views_of_different_sizes(tmp_path):
 
 # ---- the real engine behind the driver: distributed.EngineRank on the CPU emulator, 2 and 3 gloo ranks --------------------------------------------------------
 def _engine_scene():
-    return synth.make_scene(6, 64, 48, n_src=3)
+    return synth.make_scene(6, 48, 36, n_src=3)        # (one sub-resolution level below: the emulator is ~1000x slower than the device)
 
 
 def _engine_worker(rank, world, port, out_dir):
@@ -267,8 +267,8 @@ def _engine_worker(rank, world, port, out_dir):
         nbs = [[int(x) for x in sc.neighbors[v]] for v in range(sc.n_views)]
         asked = []
         eng = patchmatch.PatchMatchHIP(0)
-        p = patchmatch.default_params(seed=SEED, nEstimationGeometricIters=2)
-        est = EngineRank(eng, p, sc.n_views, world, rank, nbs, lambda g: (asked.append(g), sc.gray[g])[1], sc.K, sc.R, sc.C, sc.dmin, sc.dmax, sc.width, sc.height)
+        p = patchmatch.default_params(seed=SEED, nEstimationGeometricIters=2, nSubResolutionLevels=1)
+        est = EngineRank(eng, p, sc.n_views, world, rank, nbs, lambda g: (asked.append(g), sc.gray[g])[1], sc.K, sc.R, sc.C, sc.dmin, sc.dmax, sc.width, sc.height, n_levels=1)
         assert sorted(asked) == sorted(est.held) and len(est.held) <= sc.n_views            # a rank reads only the images it holds
         drv = ShardedDensifier(est, sc.n_views, world, rank, geo_iters=2, neighbors=nbs)
         drv.run()

@@ -7,6 +7,9 @@
 #ifndef PM_BAND_MINWAVES
 #define PM_BAND_MINWAVES 3
 #endif
+#ifndef PM_BAND_MINWAVES_PHOTO
+#define PM_BAND_MINWAVES_PHOTO 4   // the photometric instantiations fit four waves per SIMD (128 VGPRs) without scratch
+#endif
 
 // Per-pixel state of a visit, in LDS.  The G lanes of a pixel all need it and all hold the same values, so one lane writes and all read: what lives in
 // registers while a hypothesis is scored (the long part of a visit) is then only what the scoring itself needs -- the register budget that decides how
@@ -173,7 +176,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 			}
 		}
 		if (!__any(need)) break;
-		PM_TICK(1); PM_COUNT(8, __popcll(__ballot(need)));
+		PM_TICK(1); PM_COUNT(8, __popcll(__ballot(need))); PM_HIST(__popcll(__ballot(need)) / G);
 		// -- smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533, one neighbour per lane
 		float sf0, sf1, sf2, sf3;
 		{
@@ -237,7 +240,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 // (Measured and dropped in round 4: "view-major" lanes -- lane = view * pixels-per-wave + pixel, so that the four lanes of a quad read adjacent entries of one quad
 // image -- 43.1 vs 42.6 Mpix/s at 100 views, 28.1 vs 28.3 at 25: the order in which a wave's addresses reach the vector L1 is not what bounds the kernel.)
 template <int G, int VPL, bool GEO, bool BUF>
-__global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_sweep2_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
+__global__ __launch_bounds__(64, (GEO ? PM_BAND_MINWAVES : PM_BAND_MINWAVES_PHOTO)) void pm_sweep2_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
 	constexpr int PPW = 64 / G;
 	constexpr int NV = G * VPL;
 	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
@@ -283,6 +286,16 @@ __global__ __launch_bounds__(64, PM_BAND_MINWAVES) void pm_sweep2_kernel(const P
 	}
 	__syncthreads();
 	float rD, rN0, rN1, rN2, rC; bool wr;
+#ifdef PM_PROBE_INNER
+	// (measurement builds only) the visit PM_PROBE_INNER times: every repetition after the first finds the lines of its own first pass in L1 / L2 -- an upper bound on what any
+	// scheme that keeps a view's footprint on-die across launches could save.  Same result (a visit reads nothing it writes).
+#pragma unroll 1
+	for (int probeRep = 1; probeRep < PM_PROBE_INNER; ++probeRep) {
+		pm_visit<G, VPL, GEO, BUF>(t, kp, rs, pass, sgn, s_w[g], &s_pix[g], s_src, g, v, slot, active, x, y, active ? y : PM_HW, active ? idx : (size_t)PM_HW * w + PM_HW, bok, qxs, qys, qis,
+			n0D, n0N0, n0N1, n0N2, n0C, n1D, n1N0, n1N1, n1N2, n1C, rD, rN0, rN1, rN2, rC, wr PM_PROF_PASS);
+		__syncthreads();
+	}
+#endif
 	pm_visit<G, VPL, GEO, BUF>(t, kp, rs, pass, sgn, s_w[g], &s_pix[g], s_src, g, v, slot, active, x, y, active ? y : PM_HW, active ? idx : (size_t)PM_HW * w + PM_HW, bok, qxs, qys, qis,
 		n0D, n0N0, n0N1, n0N2, n0C, n1D, n1N0, n1N1, n1N2, n1C, rD, rN0, rN1, rN2, rC, wr PM_PROF_PASS);
 	if (wr && v == 0) { gDepth[idx] = rD; gNormal[idx * 3] = rN0; gNormal[idx * 3 + 1] = rN1; gNormal[idx * 3 + 2] = rN2; gConf[idx] = rC; }

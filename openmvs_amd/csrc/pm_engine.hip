@@ -351,6 +351,11 @@ static bool launchDiagonal(bool wide, int hyps, int G2, int V2, int nTasks, hipS
 	return launchSweep2<GEO, BUF>(G2, V2, dim3((unsigned)((count + P2 - 1) / P2), (unsigned)nTasks), st, t, kp, dir, d, xlo, count, pass);
 }
 
+#ifdef PM_PROBES
+// measurement builds (-DPM_PROBES, tools/): never part of the product library
+static int g_probeRepeat = 1;
+extern "C" int pmhip_probe_set(int key, int val) { if (key == 0) g_probeRepeat = val < 1 ? 1 : val; return 0; }
+#endif
 static size_t evBeginOn(pmhip_engine* e, int kind, hipStream_t st) {
 	if (!e->statsOn) return 0;
 	pmhip_engine::Ev ev; ev.kind = kind;
@@ -589,6 +594,11 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 			const bool wide = wideBatch || (maxSrc <= 8 && npx <= e->widePixels);
 			const int hyps = (wideBatch && e->wideHyps > 0) ? e->wideHyps : ((nB <= 2 || npx <= e->wide8Pixels) ? 8 : 2);
 			++nLaunched;
+#ifdef PM_PROBES
+			for (int r = 1; r < g_probeRepeat; ++r)   // (measurement builds only) the same diagonal again, back to back: what does a launch find in the caches its predecessor filled?
+				geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass))
+				    : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass));
+#endif
 			return geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass))
 			           : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass));
 		}
@@ -1318,6 +1328,18 @@ int pmhip_prof_get(pmhip_engine* e, unsigned long long out16[16], int reset) {
 	return 0;
 #endif
 }
+
+#ifdef PM_PROFILE
+// (profile builds only, tools/phase_prof.py) histogram of pm_visit's trips by the number of pixels of the wave that take part
+int pmhip_prof_hist(pmhip_engine* e, unsigned long long out17[17], int reset) {
+	if (!e || !out17) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	HIPCHK(e, hipMemcpyFromSymbol(out17, HIP_SYMBOL(pm_hist), sizeof(unsigned long long) * 17));
+	if (reset) { unsigned long long z[17] = {0}; HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(pm_hist), z, sizeof(z))); }
+	return 0;
+}
+#endif
 
 int pmhip_math_eval(pmhip_engine* e, int kind, const float* a, const float* b, float* out, size_t n) {
 	if (!e || !a || !out || n == 0) return PMHIP_E_ARG;

@@ -114,12 +114,14 @@ enum { PM_STREAM_INIT = 0, PM_STREAM_RAND = 1, PM_STREAM_REFINE = 2 };
 // phase 0 further: 12 = head of the visit (own + neighbour estimates, patch texels, weights), 13 = neighbour set-up + window placement, 0 = window staging.
 #ifdef PM_PROFILE
 __device__ unsigned long long pm_prof[16];
+__device__ unsigned long long pm_hist[17];   // trips of pm_visit by the number of pixels of the wave that score a hypothesis in the trip (0..16)
 struct PmProfAcc { unsigned long long a[16]; unsigned long long t; };
 #define PM_PROF_ARG , PmProfAcc& _pa
 #define PM_PROF_PASS , _pa
 #define PM_PROF_DECL PmProfAcc _pa; for (int _i = 0; _i < 16; ++_i) _pa.a[_i] = 0; _pa.t = __builtin_readcyclecounter()
 #define PM_TICK(i) do { const unsigned long long _n = __builtin_readcyclecounter(); _pa.a[i] += _n - _pa.t; _pa.t = _n; } while (0)
 #define PM_COUNT(i, n) do { _pa.a[i] += (unsigned long long)(n); } while (0)
+#define PM_HIST(n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&pm_hist[(n) > 16 ? 16 : (n)], 1ull); } while (0)
 #define PM_PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int _i = 0; _i < 16; ++_i) atomicAdd(&pm_prof[_i], _pa.a[_i]); } while (0)
 #else
 #define PM_PROF_ARG
@@ -127,6 +129,7 @@ struct PmProfAcc { unsigned long long a[16]; unsigned long long t; };
 #define PM_PROF_DECL do {} while (0)
 #define PM_TICK(i) do {} while (0)
 #define PM_COUNT(i, n) do {} while (0)
+#define PM_HIST(n) do {} while (0)
 #define PM_PROF_FLUSH() do {} while (0)
 #endif
 #define PM_FD2R(d) ((d) * (PM_PI_F / 180.f))
@@ -282,7 +285,8 @@ template <int LEFT>
 __device__ __forceinline__ void pm_bufwait5(pm_f4v& q0, pm_f4v& q1, pm_f4v& q2, pm_f4v& q3, pm_f4v& q4) {
 	asm volatile("s_waitcnt vmcnt(%5)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4) : "i"(LEFT));
 }
-__device__ __forceinline__ unsigned pm_mad24(int a, int b, unsigned c) { return (unsigned)__mul24(a, b) + c; }   // v_mad_u32_u24: full rate
+// a * b + c on the low 24 bits of a and b, as ONE full-rate instruction (left to itself the compiler splits two chained ones into two multiplies and a three-operand add)
+__device__ __forceinline__ unsigned pm_mad24(int a, int b, unsigned c) { unsigned r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 #else
 // host build (the CPU emulator of the tests): the same semantics -- entry index, zeros outside
 typedef float4 pm_f4v;
@@ -351,40 +355,41 @@ __device__ __forceinline__ void pm_tap_row_global(const pm_gcf img, int sw, int 
 }
 
 // The same row, OPTIMISTIC and branch-free, from the anti-diagonal-major quad image (one 16-byte entry = the four texels of a bilinear sample): the divisions are
-// the unguarded reciprocal refinement (pm_div2_inrange), nothing is tested between the taps, the sums are committed unconditionally.  What the row records
-// instead, as running integer minima / maxima of bit patterns (pm_f2i): the extremes of the projected positions (plo, pxhi, pyhi) and the depth of its first and
-// last tap (zlo, zhi) -- z moves by the same float increment from tap to tap and from row to row, and x (+) h is monotone in x, so the extremes of z over the
-// patch are among those.  The caller decides afterwards (pm_score_view): with 2^-40 <= z <= 2^40 on the whole patch and `sane` start values every quotient was the
-// correctly rounded one, hence the sums are exactly pm_tap_row_global's and the image test (isInsideWithBorder<1> of every tap) on the extremes is exact;
-// otherwise the patch is redone through the guarded path.
+// the unguarded reciprocal refinement (pm_div2_inrange), nothing is tested between the taps, the sums are committed unconditionally.  What the patch records
+// instead (PMTapRange, below): position and depth of its four CORNER taps.  The caller decides afterwards (pm_score_view) whether the optimistic sums are the
+// guarded path's, whether the reference would have left the patch at a tap outside the image, or whether the patch has to be redone through the guarded path.
 // BUF: the sample is addressed as entry index qbase + (lx + ly) * sh + ly of the level's buffer (no clamp: out of range reads zeros, see above); otherwise through the
 // view's own pointer with clamped coordinates (views that carry their own image size live outside the level's buffer).
 struct PMRowPos { float ptx[5], pty[5]; };
 struct PMRowQ { pm_f4v q0, q1, q2, q3, q4; };
+// What a patch records for the decision afterwards, from its FOUR CORNER taps only (bit patterns, pm_f2i): zlo / zhi = extremes of the depth, plo = the smallest x or y,
+// pxhi / pyhi = the largest x / y.  z: a row's z moves by the same float increment from tap to tap, a row's first z by the same increment from row to row, and x (+) h is
+// monotone in x, so the extremes of z over the whole patch are exactly among the corners.  Positions: see pm_score_view.
 struct PMTapRange { int zlo, zhi, plo, pxhi, pyhi; };
-// positions of a row's five taps, their samples requested; nothing waits here
-template <bool BUF>
+__device__ __forceinline__ void pm_range_corner(PMTapRange& rg, float px, float py, float z) {
+	const int ix = pm_f2i(px), iy = pm_f2i(py), iz = pm_f2i(z);
+	rg.plo = min(rg.plo, min(ix, iy)); rg.pxhi = max(rg.pxhi, ix); rg.pyhi = max(rg.pyhi, iy);
+	rg.zlo = min(rg.zlo, iz); rg.zhi = max(rg.zhi, iz);
+}
+// positions of a row's five taps, their samples requested; nothing waits here.  CORNERS: the row is the patch's first one -- its taps 0 and 4 are recorded (the last row's
+// are recorded by pm_taps_fast from the positions the row leaves behind, so that the loop over the rows has one body).
+// Entry index of sample (lx, ly) of the view whose image starts at entry qbase: qbase + (lx + ly) * sh + ly == lx * sh + (ly * (sh + 1) + qbase): two v_mad_u32_u24.
+template <bool BUF, bool CORNERS>
 __device__ __forceinline__ void pm_row_issue(const PMImgBuf& rs, unsigned qbase, const pm_gcf4 imgQ, int sw, int sh, float h0, float h3, float h6, float X0, float X1, float X2,
 		PMRowPos& p, PMRowQ& q, PMTapRange& rg)
 {
 	unsigned idx[5];
-	const int zFirst = pm_f2i(X2);
 #pragma unroll
 	for (int j = 0; j < 5; ++j) {
 		pm_div2_inrange(X0, X1, X2, &p.ptx[j], &p.pty[j]);
 		const int lx = (int)p.ptx[j], ly = (int)p.pty[j];
-		if (BUF) idx[j] = pm_mad24(lx + ly, sh, (unsigned)ly + qbase);
+		if (BUF) idx[j] = pm_mad24(lx, sh, pm_mad24(ly, sh + 1, qbase));
 		else { const int lxc = min(max(lx, 0), sw - 2), lyc = min(max(ly, 0), sh - 2); idx[j] = (unsigned)(lxc + lyc) * (unsigned)sh + (unsigned)lyc; }
-		if (j == 4) { const int zLast = pm_f2i(X2); rg.zlo = min(rg.zlo, min(zFirst, zLast)); rg.zhi = max(rg.zhi, max(zFirst, zLast)); }
+		if (CORNERS && (j == 0 || j == 4)) pm_range_corner(rg, p.ptx[j], p.pty[j], X2);
 		X0 += h0; X1 += h3; X2 += h6;
 	}
 	if (BUF) pm_bufload5(q.q0, q.q1, q.q2, q.q3, q.q4, idx[0], idx[1], idx[2], idx[3], idx[4], rs.rs);
 	else { q.q0 = pm_loadq(imgQ, idx[0]); q.q1 = pm_loadq(imgQ, idx[1]); q.q2 = pm_loadq(imgQ, idx[2]); q.q3 = pm_loadq(imgQ, idx[3]); q.q4 = pm_loadq(imgQ, idx[4]); }
-	// (independent of the loads) the extremes of the positions, on their bit patterns (see pm_f2i): plo = the smallest x or y, pxhi / pyhi = the largest x / y
-	rg.plo = min(rg.plo, min(min(min(pm_f2i(p.ptx[0]), pm_f2i(p.ptx[1])), min(pm_f2i(p.ptx[2]), pm_f2i(p.ptx[3]))), pm_f2i(p.ptx[4])));
-	rg.plo = min(rg.plo, min(min(min(pm_f2i(p.pty[0]), pm_f2i(p.pty[1])), min(pm_f2i(p.pty[2]), pm_f2i(p.pty[3]))), pm_f2i(p.pty[4])));
-	rg.pxhi = max(rg.pxhi, max(max(max(pm_f2i(p.ptx[0]), pm_f2i(p.ptx[1])), max(pm_f2i(p.ptx[2]), pm_f2i(p.ptx[3]))), pm_f2i(p.ptx[4])));
-	rg.pyhi = max(rg.pyhi, max(max(max(pm_f2i(p.pty[0]), pm_f2i(p.pty[1])), max(pm_f2i(p.pty[2]), pm_f2i(p.pty[3]))), pm_f2i(p.pty[4])));
 }
 // the row's samples have arrived (LEFT younger loads may still be under way): bilinear values and the three running sums, in the reference's order
 template <bool BUF, int LEFT>
@@ -414,22 +419,25 @@ __device__ __forceinline__ void pm_taps_fast(const PMImgBuf& rs, unsigned qbase,
 		const float2* wts, float& sum, float& sumSq, float& num, PMTapRange& rg)
 {
 	PMRowPos pa, pb; PMRowQ qa, qb;
-	pm_row_issue<BUF>(rs, qbase, imgQ, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, pa, qa, rg);
+	pm_row_issue<BUF, true>(rs, qbase, imgQ, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, pa, qa, rg);
 	// rows (0,1), (2,3) as one loop body with the A / B sets swapping roles (no copies), then row 4.  The scheduling barriers keep the compiler from pulling the next
 	// row's divisions above the current row's arithmetic (which is what it does with the whole patch unrolled: every position of the patch live at once, 600 B of scratch)
 #pragma unroll 1
 	for (int i = 0; i < 4; i += 2) {
 		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
-		pm_row_issue<BUF>(rs, qbase, imgQ, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, pb, qb, rg);
+		pm_row_issue<BUF, false>(rs, qbase, imgQ, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, pb, qb, rg);
 		PM_SCHED_BARRIER();
 		pm_row_consume<BUF, 5>(pa, qa, wts + i * 5, sum, sumSq, num);
 		PM_SCHED_BARRIER();
 		bX0 += H[1]; bX1 += H[4]; bX2 += H[7];
-		pm_row_issue<BUF>(rs, qbase, imgQ, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, pa, qa, rg);
+		pm_row_issue<BUF, false>(rs, qbase, imgQ, sw, sh, H[0], H[3], H[6], bX0, bX1, bX2, pa, qa, rg);
 		PM_SCHED_BARRIER();
 		pm_row_consume<BUF, 5>(pb, qb, wts + (i + 1) * 5, sum, sumSq, num);
 		PM_SCHED_BARRIER();
 	}
+	// the last row's corners: its positions are still in `pa`, its z values are its first one (bX2) and that after the row's four increments (the same float additions)
+	pm_range_corner(rg, pa.ptx[0], pa.pty[0], bX2);
+	pm_range_corner(rg, pa.ptx[4], pa.pty[4], (((bX2 + H[6]) + H[6]) + H[6]) + H[6]);
 	pm_row_consume<BUF, 0>(pa, qa, wts + 20, sum, sumSq, num);
 }
 
@@ -477,13 +485,44 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		const float rX0 = bX0, rX1 = bX1, rX2 = bX2;
 		PMTapRange rg = {0x7fffffff, (int)0x80000000, 0x7fffffff, (int)0x80000000, (int)0x80000000};
 		pm_taps_fast<MODE == 2>(rs, qbase, imgQ, sw, sh, H, bX0, bX1, bX2, wts, sum, sumSq, num, rg);
-		const bool exact = sane && rg.zlo >= pm_f2i(9.094947e-13f) && rg.zhi <= pm_f2i(1.0995116e12f);   // 2^-40 <= z <= 2^40 on the whole patch
-		const bool outside = !(rg.plo >= pm_f2i(1.f) && rg.pxhi <= pm_f2i((float)(sw - 2)) && rg.pyhi <= pm_f2i((float)(sh - 2)));   // a tap with x < 1, y < 1, x > w - 2 or y > h - 2
+		// (1) exact: 2^-40 <= z <= 2^40 on the whole patch (the extremes of z are among the corners, PMTapRange) and `sane` start values: every quotient of the patch was
+		//     the correctly rounded one, so the sums are pm_tap_row_global's and a tap's position is the one the reference tests.  Otherwise (0 of 38 M evaluations in the
+		//     emulator's census) the whole patch is redone through the guarded path.
+		// (2) a corner fails isInsideWithBorder<1>: the reference returns thRobust at that tap at the latest -- outside.
+		// (3) every corner inside by at least delta = 2^-17 max(w, h) and zhi <= 2 zlo: every tap is inside.  In real arithmetic on the float start values and steps the taps
+		//     T(i,j) = b + i c + j r are affine in (i, j) with z > 0, so the positions T.xy / T.z lie in the convex hull of the four corner positions.  A float tap differs
+		//     from T by the roundings of its <= 8 additions, each <= 2^-24 of a value that is itself a tap: |dx| <= 8 2^-24 P zhi, |dz| <= 8 2^-24 zhi with P = max(w, h) >=
+		//     every position; the quotient adds one rounding: |position error| <= (16 zhi / zlo + 1) 2^-24 P <= 33 2^-24 P = eps.  A tap therefore lies within 2 eps =
+		//     66 2^-24 P < delta = 128 2^-24 P of the corners' range (0.015 px at 1920).
+		// (4) otherwise -- a corner within delta of the border band, or a plane that almost contains the viewing ray: the positions of all 25 taps again (the same float
+		//     operations, no loads), tested one by one as the reference does.
+		const bool exact = sane && rg.zlo >= pm_f2i(9.094947e-13f) && rg.zhi <= pm_f2i(1.0995116e12f);
+		const bool cornersIn = rg.plo >= pm_f2i(1.f) && rg.pxhi <= pm_f2i((float)(sw - 2)) && rg.pyhi <= pm_f2i((float)(sh - 2));
+		const float delta = (float)max(sw, sh) * 7.62939453125e-06f;   // 2^-17
+		const bool allIn = rg.plo >= pm_f2i(1.f + delta) && rg.pxhi <= pm_f2i((float)(sw - 2) - delta) && rg.pyhi <= pm_f2i((float)(sh - 2) - delta)
+			&& (unsigned)rg.zhi - (unsigned)rg.zlo <= 0x00800000u;   // zhi <= 2 zlo on the bit patterns of positive floats (one exponent step)
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(PM_DEBUG_REDO)
-		{ static unsigned long long c[2]; static bool reg = false; if (!reg) { reg = true; atexit([] { fprintf(stderr, "optimistic evaluations %llu, redone %llu\n", c[0], c[1]); }); } c[0]++; if (!exact) c[1]++; }
+		{ static unsigned long long c[3]; static bool reg = false; if (!reg) { reg = true; atexit([] { fprintf(stderr, "optimistic evaluations %llu, positions rechecked %llu, redone %llu\n", c[0], c[1], c[2]); }); }
+		  c[0]++; if (exact && cornersIn && !allIn) c[1]++; if (!exact) c[2]++; }
 #endif
-		if (exact) oob = outside;
-		else {   // (rare: a plane almost parallel to a viewing ray) the whole patch through the guarded path
+		if (exact) {
+			oob = !cornersIn;
+			if (cornersIn && !allIn) {
+				float cX0 = rX0, cX1 = rX1, cX2 = rX2;
+#pragma unroll 1
+				for (int i = 0; i < 5; ++i) {
+					float X0t = cX0, X1t = cX1, X2t = cX2;
+#pragma unroll 1
+					for (int j = 0; j < 5; ++j) {
+						float ptx, pty;
+						pm_div2_inrange(X0t, X1t, X2t, &ptx, &pty);
+						oob = oob || !pm_inside1(ptx, pty, sw, sh);
+						X0t += H[0]; X1t += H[3]; X2t += H[6];
+					}
+					cX0 += H[1]; cX1 += H[4]; cX2 += H[7];
+				}
+			}
+		} else {   // the whole patch through the guarded path
 			sum = 0.f; sumSq = 0.f; num = 0.f;
 			bX0 = rX0; bX1 = rX1; bX2 = rX2;
 #pragma unroll 1

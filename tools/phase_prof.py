@@ -15,6 +15,9 @@ for rep in range(2):
     for g in range(2): e.scene_commit_round(); e.scene_estimate(ids, g, p)
     e.sync(); dt = time.time() - t0
     c = e.prof_get(True)
+    import ctypes
+    hist = (ctypes.c_ulonglong * 17)()
+    if hasattr(e._lib, 'pmhip_prof_hist'): e._lib.pmhip_prof_hist(e._h, hist, 1)
 names = ["-", "hyp-gen", "smooth", "homography", "taps", "epilogue", "aggr+accept"]
 tot = (sum(c[1:7]) + c[12]) or 1
 print(os.environ.get("PMHIP_LIB", "default"), "views", len(ids), "of", views, "%.2f s -> %.2f Mpix/s" % (dt, len(ids) * 1920 * 1080 / dt / 1e6))
@@ -22,3 +25,7 @@ print("  wave-visits %d, cycles per wave-visit %.0f (s_memtime), hypotheses x ac
 print("  %-12s %5.1f %%   %8.0f cycles/wave-visit" % ("head", 100.0 * c[12] / tot, c[12] / max(1, c[9])))
 for i, n in enumerate(names):
     if i: print("  %-12s %5.1f %%   %8.0f cycles/wave-visit" % (n, 100.0 * c[i] / tot, c[i] / max(1, c[9])))
+if sum(hist):
+    tot_t = sum(hist)
+    print("  trips of a wave-visit by pixels taking part (of 16 with 4 lanes per pixel): " + " ".join("%d:%.1f%%" % (k, 100.0 * hist[k] / tot_t) for k in range(17) if hist[k]))
+    print("  trips with <= 8 pixels taking part: %.1f %%, <= 4: %.1f %%; mean pixels per trip %.2f" % (100.0 * sum(hist[:9]) / tot_t, 100.0 * sum(hist[:5]) / tot_t, sum(k * hist[k] for k in range(17)) / tot_t))

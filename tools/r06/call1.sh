@@ -5,14 +5,15 @@ set -u
 OUT=gpurun_out/r06_call1; mkdir -p "$OUT"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+START=$(date +%s)
 step() { echo "=== $1 ($(date +%T))" | tee -a "$OUT/steps.log"; }
 step "counter list"
 ( cd /tmp && timeout 60 rocprofv3 -L > "$R/$OUT/rocprofv3_counters.txt" 2>&1 )
 grep -c . "$OUT/rocprofv3_counters.txt"
 
 step "A/B of the instruction cuts (same box): round-5 library vs this tree, 100 / 13 views"
-timeout 500 python tools/tune.py 100 libpmhip_r05.so:2 libpmhip.so:2 libpmhip_r05.so:2 libpmhip.so:2 > "$OUT/ab_100.log" 2>&1; cat "$OUT/ab_100.log"
-timeout 300 python tools/tune.py 13 libpmhip_r05.so:2 libpmhip.so:2 > "$OUT/ab_13.log" 2>&1; cat "$OUT/ab_13.log"
+TUNE_STEPS='--steps 6 --warmup 2' timeout 500 python tools/tune.py 100 libpmhip_r05.so:2 libpmhip.so:2 libpmhip_r05.so:2 libpmhip.so:2 > "$OUT/ab_100.log" 2>&1; cat "$OUT/ab_100.log"
+TUNE_STEPS='--steps 10 --warmup 3' timeout 300 python tools/tune.py 13 libpmhip_r05.so:2 libpmhip.so:2 > "$OUT/ab_13.log" 2>&1; cat "$OUT/ab_13.log"
 
 step "golden parity of this tree (config 2 / config 5 golden maps, both kernel families)"
 timeout 600 python -m pytest tests -m gpu -q -x -k "golden or config5 or config2 or parity" > "$OUT/gpu_parity_subset.log" 2>&1; tail -5 "$OUT/gpu_parity_subset.log"
@@ -50,6 +51,7 @@ pass() {  # name, binary, scene tag, mode, extra args..., then -- counters
   local try
   for try in 1 2; do
     local t0=$(date +%s)
+    if [ $(( t0 - START )) -gt ${CALL_BUDGET:-3000} ]; then echo "pass $name skipped: call budget spent" | tee -a "$OUT/steps.log"; return; fi
     ( cd /tmp && timeout ${PMC_TIMEOUT:-150} rocprofv3 --pmc "$@" --output-format csv -d "/tmp/prof_$name" -o pmc -- $bin /tmp/scene$v.bin $mode /tmp/maps$v.bin "${extra[@]}" \
         > "$R/$OUT/pmc_${name}_run.json" 2> "$R/$OUT/pmc_$name.err" )
     local rc=$?

@@ -1446,8 +1446,19 @@ int pmhip_scene_fuse(pmhip_engine* e, const int32_t* order, int nOrder, const PM
 	auto& f = e->fu;
 	const size_t P = f.slab, N = (size_t)e->nImages, P0 = (size_t)e->w * e->h;
 	bool wantColor = prm->bEstimateColor != 0;
-	if (wantColor) for (int i = 0; i < e->nImages; ++i) if (e->views[i].set && (f.hasBgr.empty() || !f.hasBgr[i] || !(e->views[i].sw ? (const void*)e->views[i].oBgr : (const void*)f.bgr))) {
-		e->err = "bEstimateColor needs pmhip_scene_set_color for every view"; return PMHIP_E_STATE; }
+	if (wantColor) {
+		// colours are read of the fused views and of their neighbours only (SceneDensify.cpp:1455-1560): a source-only slot -- a resampled copy of a neighbour that the estimation
+		// read (ViewData::ScaleImage) -- has no depth map, is nobody's neighbour here and needs no colour
+		std::vector<unsigned char> need((size_t)e->nImages, 0);
+		for (int k = 0; k < nOrder; ++k) {
+			const int v = order[k];
+			if (v < 0 || v >= e->nImages) continue;
+			need[(size_t)v] = 1;
+			for (int j = 0; j < e->views[v].nNb; ++j) { const int b = e->views[v].nb[j]; if (b >= 0 && b < e->nImages) need[(size_t)b] = 1; }
+		}
+		for (int i = 0; i < e->nImages; ++i) if (need[(size_t)i] && e->views[i].set && (f.hasBgr.empty() || !f.hasBgr[i] || !(e->views[i].sw ? (const void*)e->views[i].oBgr : (const void*)f.bgr))) {
+			e->err = "bEstimateColor needs pmhip_scene_set_color for every fused view and its neighbours"; return PMHIP_E_STATE; }
+	}
 	const bool wantNormal = prm->bEstimateNormal != 0;
 	// cameras (P composed like Camera::ComposeP)
 	std::vector<PMFuseCam> hc(N);
@@ -1467,7 +1478,7 @@ int pmhip_scene_fuse(pmhip_engine* e, const int32_t* order, int nOrder, const PM
 			HIPCHK(e, hipMemcpyAsync(f.depth + P * i, e->depthOf((int)i), sizeof(float) * Pi, hipMemcpyDeviceToDevice, e->stream));
 			HIPCHK(e, hipMemcpyAsync(f.normalS + 3 * P * i, e->normalOf((int)i), sizeof(float) * 3 * Pi, hipMemcpyDeviceToDevice, e->stream));
 			HIPCHK(e, hipMemcpyAsync(f.confS + P * i, e->confOf((int)i), sizeof(float) * Pi, hipMemcpyDeviceToDevice, e->stream));
-			if (wantColor && e->views[i].set) HIPCHK(e, hipMemcpyAsync(f.bgrS + 3 * P * i, e->views[i].sw ? e->views[i].oBgr : f.bgr + 3 * P0 * i, 3 * Pi, hipMemcpyDeviceToDevice, e->stream));
+			if (wantColor && e->views[i].set && f.hasBgr[i]) HIPCHK(e, hipMemcpyAsync(f.bgrS + 3 * P * i, e->views[i].sw ? e->views[i].oBgr : f.bgr + 3 * P0 * i, 3 * Pi, hipMemcpyDeviceToDevice, e->stream));
 		}
 		HIPCHK(e, hipMemcpyAsync(f.dims, hw.data(), sizeof(int) * N, hipMemcpyHostToDevice, e->stream));          // iw = dims, ih = dims + N
 		HIPCHK(e, hipMemcpyAsync(f.dims + N, hh.data(), sizeof(int) * N, hipMemcpyHostToDevice, e->stream));

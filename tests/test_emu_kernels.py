@@ -113,6 +113,11 @@ def test_estimator_resampled_neighbour_copies_through_the_driver(pm_emulated):
     g.resampled_neighbour_copies_through_the_driver(80, 60)           # ViewData::ScaleImage: copies in extra slots, handed their images' depth maps at the round boundary
 
 
+def test_fusion_with_a_source_only_slot_without_colour(pm_emulated, small_scene):
+    from tests import test_gpu_fuse as g
+    g.test_fuse_with_a_source_only_slot_that_has_no_colour(small_scene)
+
+
 def test_dense_reconstruction_chain_on_the_pipeline_test_scene(pm_emulated, tmp_path):
     from tests import test_zz_gpu_scale_image as z
     z.dense_reconstruction_chain(tmp_path, level=3)             # 80x60: option table -> views -> depth maps (file contract) -> fusion -> scene_dense.mvs

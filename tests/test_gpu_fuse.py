@@ -165,3 +165,27 @@ def test_device_fuse_of_depth_maps_of_different_sizes(W=160, H=120):
     d2, _, _ = e.scene_get_maps(2)
     assert d2.shape == deps[2].shape and np.array_equal(d2, deps[2])
     e.close()
+
+
+def test_fuse_with_a_source_only_slot_that_has_no_colour(small_scene):
+    """A scene that also holds a source-only slot -- a resampled copy of a neighbour the estimation read (ViewData::ScaleImage; densify.load_scene puts them behind the images) --
+    fuses with colours on: the copy has its own size, no depth map and no colour image, is nobody's neighbour at fusion time and must neither be asked for a colour nor be read.
+    The cloud is the one the images alone give."""
+    sc = small_scene
+    maps = fc.make_maps(sc, seed=7)
+    ref = po.fuse_depth_maps(*maps, list(sc.bgr), sc.K, sc.R, sc.C, [list(x) for x in sc.neighbors])
+    e = PatchMatchHIP(0)
+    n = sc.n_views
+    e.scene_create(n + 1, sc.width, sc.height, 0)
+    for v in range(n):
+        e.scene_set_view(v, sc.gray[v], sc.K[v], sc.R[v], sc.C[v], float(sc.dmin[v]), float(sc.dmax[v]), sc.neighbors[v])
+    w2, h2 = sc.width * 3 // 4, sc.height * 3 // 4
+    K2 = np.array(sc.K[1], np.float64); K2[0] *= w2 / sc.width; K2[1] *= h2 / sc.height
+    e.scene_set_view_sized(n, np.ascontiguousarray(sc.gray[1][:h2, :w2]), K2, sc.R[1], sc.C[1], float(sc.dmin[1]), float(sc.dmax[1]), np.zeros(0, np.int32))
+    d, nm, c = maps
+    for v in range(n):
+        e.scene_set_maps(v, d[v], nm[v]); e.scene_set_conf(v, c[v]); e.scene_set_color(v, sc.bgr[v])
+    got = e.scene_fuse(_order(sc))
+    fc.same_cloud(got, ref, "source-only slot without colour")
+    assert got["nPoints"] > 1000 and got["colors"] is not None
+    e.close()

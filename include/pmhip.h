@@ -243,6 +243,12 @@ typedef struct PMHipTuning {
 	int32_t widePixels;      /* larger batches: a diagonal launch of at most this many pixels (diagonal length x views of the group) uses the two-wide speculative kernel (20000); -1 = none */
 	int32_t wide8Pixels;     /* ... and one of at most this many pixels the eight-wide speculative kernel; -1 = none */
 } PMHipTuning;
+/* OPT-IN, NOT the reference's estimator: tiled sweeps.  The pixels that take part in the estimation are cut into tileW x tileH tiles; a sweep (DepthMap.cpp:329-356 order)
+ * runs inside every tile, and a neighbour in another tile is read as the previous sweep left it.  The tiles of a sweep are independent, so a sweep is tileW + tileH - 1
+ * launches that each cover every tile of every view instead of w + h launches of one anti-diagonal: what a small batch (one depth map per call, a rank of an 8-GPU split)
+ * needs to fill the GPU.  The result is deterministic and equals oracle/pm_oracle.cpp with Opt::tileW / tileH bit for bit, but it is NOT the sequential sweep's: against
+ * that it differs like two runs of the reference differ from each other.  0, 0 = off (the default: the reference's sweep, bit for bit). */
+int pmhip_set_sweep_tiles(pmhip_engine* e, int tileW, int tileH);
 int pmhip_get_tuning(pmhip_engine* e, PMHipTuning* out);
 int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t);
 

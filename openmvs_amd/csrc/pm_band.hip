@@ -32,17 +32,80 @@ template <class T> __device__ __forceinline__ T* pm_launder(T* p) { asm volatile
 template <class T> __device__ __forceinline__ T* pm_launder(T* p) { return p; }
 #endif
 enum { PMF_SMOOTH = 1, PMF_CHANGED = 2, PMF_POK0 = 4, PMF_POK1 = 8 };
+enum { ST_PROP0 = 0, ST_PROP1 = 1, ST_DECIDE = 2, ST_RAND = 3, ST_REFINE = 4, ST_DONE = 5 };   // ProcessPixel's control flow as states (PMPix::st)
+
+// bit g * G of the result is set for every pixel slot g of a wave: the lanes with v == 0
+template <int G> __device__ __forceinline__ unsigned long long pm_lane0_mask() { unsigned long long m = 0; for (int i = 0; i < 64; i += G) m |= 1ull << i; return m; }
+
+// The scoring part of one trip of pm_visit for the G lanes [v = 0 .. G) of one pixel: the smoothness factors of the pixel's recorded hypothesis (PMPix::hd, hn*), its score
+// against the lane's VPL source views v, v + G, ..., ScorePixel's aggregation over the pixel's lanes, and the accept (DepthMap.cpp:794-799, :784-793, :843-851) by lane 0.
+// on: these lanes have a pixel in this trip.  s_wg / s_pixg: the pixel's weights and state in LDS.
+template <int G, int VPL, bool GEO, bool BUF>
+__device__ __forceinline__ void pm_trip_score(const PMTask& t, const PMKParams& kp, const PMImgBuf& rs, const float2* s_wg, PMPix* s_pixg, const double* hotBase, int v, bool on PM_PROF_ARG) {
+	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
+	const int slot = v & 3;
+	float hd, hnx, hny, hnz;
+	{ const PMPix* P = pm_launder(s_pixg); hd = P->hd; hnx = P->hnx; hny = P->hny; hnz = P->hnz; }
+	// -- smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533, one neighbour per lane
+	float sf0, sf1, sf2, sf3;
+	{
+		const PMPix* P = pm_launder(s_pixg);
+		const int flags = P->flags;
+		const bool sm = on && (flags & PMF_SMOOTH) && ((flags >> (8 + slot)) & 1);
+		float myF = 1.f;
+		if (sm) {
+			const float vx = P->vx, vy = P->vy;
+			const float q0 = P->qX[slot][0], q1 = P->qX[slot][1], q2 = P->qX[slot][2], m0 = P->qn[slot][0], m1 = P->qn[slot][1], m2 = P->qn[slot][2];
+			const float planeD = -hd * (hnx * vx + hny * vy + hnz * 1.f); // InitPlane, DepthMap.cpp:963-971
+			const float dist = (hnx * q0 + (hny * q1 + hnz * q2)) + planeD; // Planef::Distance, Eigen 3-dot order
+			const float r = dist / hd;
+			const float factorDepth = pm_expf((r * r) * kp.smoothSigmaDepth);
+			const float ca = pm_clampf((hnx * m0 + hny * m1 + hnz * m2) / pm_sqrtf((hnx * hnx + hny * hny + hnz * hnz) * (m0 * m0 + m1 * m1 + m2 * m2)), -1.f, 1.f);
+			const float ac = pm_acosf(ca);
+			const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
+			myF = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
+		}
+		sf0 = pm_quad_bcast<0>(myF); sf1 = pm_quad_bcast<1>(myF); sf2 = pm_quad_bcast<2>(myF); sf3 = pm_quad_bcast<3>(myF);
+	}
+	PM_TICK(2);
+	// -- score against my source view(s)
+	float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
+	{
+		const PMPix* P = pm_launder(s_pixg);
+#pragma unroll 1
+		for (int u = 0; u < VPL; ++u) {
+			const int vw = v + u * G;
+			if (on && vw < t.nSrc) {
+				const float s1 = pm_score_view<GEO, BUF ? 2 : 1, true>(t.src[vw], t, kp, P->x, P->y, P->X0x, P->X0y, P->normSq0, P->sumW, s_wg, hd, hnx, hny, hnz, sf0, sf1, sf2, sf3, 0.f,
+					hotBase + vw * NBD, hotBase + vw * NBD + PM_SRC_HOT, rs PM_PROF_PASS);
+				if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
+			}
+		}
+	}
+	const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
+	{	// -- accept (DepthMap.cpp:794-799, :784-793, :843-851)
+		PMPix* P = pm_launder(s_pixg);
+		if (on && v == 0 && P->conf > nconf) {
+			P->conf = nconf; P->depth = P->hd; P->nx = P->hnx; P->ny = P->hny; P->nz = P->hnz;
+			int flags = P->flags | PMF_CHANGED;
+			P->flags = flags;
+			const int hst = P->hst;
+			if (hst == ST_RAND) { if (nconf < kp.thConfRand) P->st = ST_DECIDE; }
+			else if (hst == ST_REFINE) { P->p0 = P->hp0; P->p1 = P->hp1; const int is = P->idxScale + 1; P->idxScale = is; P->scaleRange = pm_pow2neg((unsigned)is); }
+		}
+	}
+}
 
 // One ProcessPixel visit (DepthMap.cpp:630-852) of the G lanes of a pixel, shared by the band kernel and the per-diagonal kernel below.
 // n0* / n1*: the two neighbours the sweep has already updated (depth, normal, conf), however the caller obtained them; bok / qxs / qys / qis: the four
 // neighbour slots (bounds tests, coordinates, map indices).  afterPatch() runs once the visit's loads have been waited for (the band kernel publishes its
 // previous step there).  Result: r* = what the maps hold at this pixel after the visit, wr = it changed.
 template <int G, int VPL, bool GEO, bool BUF>
-__device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, const PMImgBuf& rs, uint32_t pass, int sgn, float2* s_wg, PMPix* s_pixg, const double* hotBase,
-		int g, int v, int slot, bool active, int x, int y, int ySafe, size_t idx, const bool* bok, const int* qxs, const int* qys, const size_t* qis,
+__device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, const PMImgBuf& rs, uint32_t pass, int sgn, float2* s_wBase, PMPix* s_pixBase, const double* hotBase,
+		int lane, int g, int v, int slot, bool active, int x, int y, int ySafe, size_t idx, const bool* bok, const int* qxs, const int* qys, const size_t* qis, unsigned oldMask,
 		float n0D, float n0N0, float n0N1, float n0N2, float n0C, float n1D, float n1N0, float n1N1, float n1N2, float n1C,
 		float& rD, float& rN0, float& rN1, float& rN2, float& rC, bool& wr PM_PROF_ARG) {
-	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
+	float2* const s_wg = s_wBase + (size_t)g * (PM_NT + 1); PMPix* const s_pixg = s_pixBase + g;   // my pixel's weights and state
 	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
 	const int yTop = ySafe;
 	// ---- what the visit reads from memory: its own estimate, the two not yet updated neighbours, prior, mask (none of it written earlier in this launch) ----
@@ -54,7 +117,12 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 		if (t.mask != nullptr) maskByte = t.mask[idx];
 		if (slot == 0) { myD = bok[0] ? n0D : 0.f; myN0 = n0N0; myN1 = n0N1; myN2 = n0N2; }
 		else if (slot == 1) { myD = bok[1] ? n1D : 0.f; myN0 = n1N0; myN1 = n1N1; myN2 = n1N2; }
-		else { const size_t qi = slot == 2 ? qis[2] : qis[3]; myD = gDepth[qi]; myN0 = gNormal[qi * 3]; myN1 = gNormal[qi * 3 + 1]; myN2 = gNormal[qi * 3 + 2]; }
+		else {   // the two neighbours the sweep has not reached yet: in this tile the maps hold what the sweep found; across a tile border that is the snapshot
+			const size_t qi = slot == 2 ? qis[2] : qis[3];
+			const bool old = (oldMask >> slot) & 1u;
+			const pm_gcf sD = pm_glob(old ? t.depthOld : t.depth), sN = pm_glob(old ? t.normalOld : t.normal);
+			myD = sD[qi]; myN0 = sN[qi * 3]; myN1 = sN[qi * 3 + 1]; myN2 = sN[qi * 3 + 2];
+		}
 		oDepth = gDepth[idx]; oNx = gNormal[idx * 3]; oNy = gNormal[idx * 3 + 1]; oNz = gNormal[idx * 3 + 2]; oConf = gConf[idx];
 	}
 	float normSq0, sumW;
@@ -84,7 +152,6 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 			P->X0x = X0x; P->X0y = X0y; P->vx = (float)X0x; P->vy = (float)X0y; P->normSq0 = normSq0; P->sumW = sumW; P->x = x; P->y = y;
 			P->depth = valid ? oDepth : 0.f; P->nx = valid ? oNx : 0.f; P->ny = valid ? oNy : 0.f; P->nz = valid ? oNz : 0.f; P->conf = valid ? oConf : 2.f;
 			P->p0 = 0.f; P->p1 = 0.f; P->scaleRange = 1.f; P->depthRange = 0.f;
-			enum { ST_PROP0 = 0, ST_DONE = 5 };
 			P->st = valid ? ST_PROP0 : ST_DONE; P->it = 0; P->idxScale = 0;
 			P->flags = PMF_SMOOTH | ((closeMask & 1u) ? PMF_POK0 : 0) | ((closeMask & 2u) ? PMF_POK1 : 0) | (int)(closeMask << 8);
 			P->nb[0][0] = n0D; P->nb[0][1] = n0N0; P->nb[0][2] = n0N1; P->nb[0][3] = n0N2; P->nb[0][4] = n0C;
@@ -94,8 +161,8 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 	__syncthreads();
 	PM_TICK(12); PM_COUNT(9, 1);
 	// ---- ProcessPixel's control flow as a per-pixel state machine: every outer trip scores at most one hypothesis per pixel (as pm_sweep_kernel) ----
-	enum { ST_PROP0 = 0, ST_PROP1 = 1, ST_DECIDE = 2, ST_RAND = 3, ST_REFINE = 4, ST_DONE = 5 };
 	const uint32_t k1 = t.k1base + pass;
+	PM_TRIPS_DECL;
 	for (;;) {
 		bool need = false;
 		float hd = 0.f, hnx = 0.f, hny = 0.f, hnz = 1.f;
@@ -175,59 +242,34 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 				P->hd = hd; P->hnx = hnx; P->hny = hny; P->hnz = hnz; P->hp0 = hp0; P->hp1 = hp1; P->hst = hst;
 			}
 		}
-		if (!__any(need)) break;
-		PM_TICK(1); PM_COUNT(8, __popcll(__ballot(need))); PM_HIST(__popcll(__ballot(need)) / G);
-		// -- smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533, one neighbour per lane
-		float sf0, sf1, sf2, sf3;
-		{
-			const PMPix* P = pm_launder(s_pixg);
-			const int flags = P->flags;
-			const bool on = need && (flags & PMF_SMOOTH) && ((flags >> (8 + slot)) & 1);
-			float myF = 1.f;
-			if (on) {
-				const float vx = P->vx, vy = P->vy;
-				const float q0 = P->qX[slot][0], q1 = P->qX[slot][1], q2 = P->qX[slot][2], m0 = P->qn[slot][0], m1 = P->qn[slot][1], m2 = P->qn[slot][2];
-				const float planeD = -hd * (hnx * vx + hny * vy + hnz * 1.f); // InitPlane, DepthMap.cpp:963-971
-				const float dist = (hnx * q0 + (hny * q1 + hnz * q2)) + planeD; // Planef::Distance, Eigen 3-dot order
-				const float r = dist / hd;
-				const float factorDepth = pm_expf((r * r) * kp.smoothSigmaDepth);
-				const float ca = pm_clampf((hnx * m0 + hny * m1 + hnz * m2) / pm_sqrtf((hnx * hnx + hny * hny + hnz * hnz) * (m0 * m0 + m1 * m1 + m2 * m2)), -1.f, 1.f);
-				const float ac = pm_acosf(ca);
-				const float factorNormal = pm_expf((ac * ac) * kp.smoothSigmaNormal);
-				myF = (1.f - kp.smoothBonusDepth * factorDepth) * (1.f - kp.smoothBonusNormal * factorNormal);
-			}
-			sf0 = pm_quad_bcast<0>(myF); sf1 = pm_quad_bcast<1>(myF); sf2 = pm_quad_bcast<2>(myF); sf3 = pm_quad_bcast<3>(myF);
-		}
-		PM_TICK(2);
-		// -- score against my source view(s)
-		float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
-		{
-			const PMPix* P = pm_launder(s_pixg);
-#pragma unroll 1
-			for (int u = 0; u < VPL; ++u) {
-				const int vw = v + u * G;
-				if (need && vw < t.nSrc) {
-					const float s1 = pm_score_view<GEO, BUF ? 2 : 1, true>(t.src[vw], t, kp, P->x, P->y, P->X0x, P->X0y, P->normSq0, P->sumW, s_wg, hd, hnx, hny, hnz, sf0, sf1, sf2, sf3, 0.f,
-						hotBase + vw * NBD, hotBase + vw * NBD + PM_SRC_HOT, rs PM_PROF_PASS);
-					if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
-				}
+		const unsigned long long needBal = __ballot(need);
+		if (needBal == 0ull) break;
+		PM_TRIPS_ADD(need);
+		PM_TICK(1); PM_COUNT(8, __popcll(needBal)); PM_HIST(__popcll(needBal) / G);
+		// -- the rest of the trip: smoothness factors, scores against the source views, accept.  Everything it needs of a pixel is in LDS (state, hypothesis, weights), so ANY
+		// lanes can do it for ANY pixel of the wave.  A visit ends with a tail of trips in which one or two pixels of the wave are still refining (a random restart that
+		// succeeded earns a second round of refinements: up to 14 trips against the usual 8; a wave of 16 pixels almost always holds such a pixel): when at most half of the
+		// pixels take part, each of them gets TWICE the lanes -- the k-th of them lanes [k 2G, (k+1) 2G), half the source views per lane -- and the trip takes about half the
+		// time.  Same hypotheses, same view scores, the same two smallest of them (an exact selection, whatever the pairing), same accept: the same bits.
+		bool wideTrip = false;
+		if constexpr (VPL >= 2) {
+			wideTrip = __popcll(needBal) <= (64 / G / 2) * G;        // (wave-uniform)
+			if (wideTrip) {
+				constexpr int G2 = G * 2, VPL2 = VPL / 2;
+				const int grp = lane / G2, v2 = lane % G2;
+				unsigned long long m = needBal & pm_lane0_mask<G>();     // one bit per pixel that takes part (its lane v == 0)
+				const bool on = grp < __popcll(m);
+				for (int i = 0; i < grp; ++i) m &= m - 1ull;
+				const int pid = on ? (int)(__ffsll((long long)m) - 1) / G : 0;
+				pm_trip_score<G2, VPL2, GEO, BUF>(t, kp, rs, s_wBase + (size_t)pid * (PM_NT + 1), s_pixBase + pid, hotBase, v2, on PM_PROF_PASS);
 			}
 		}
-		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
-		{	// -- accept (DepthMap.cpp:794-799, :784-793, :843-851)
-			PMPix* P = pm_launder(s_pixg);
-			if (need && v == 0 && P->conf > nconf) {
-				P->conf = nconf; P->depth = P->hd; P->nx = P->hnx; P->ny = P->hny; P->nz = P->hnz;
-				int flags = P->flags | PMF_CHANGED;
-				P->flags = flags;
-				const int hst = P->hst;
-				if (hst == ST_RAND) { if (nconf < kp.thConfRand) P->st = ST_DECIDE; }
-				else if (hst == ST_REFINE) { P->p0 = P->hp0; P->p1 = P->hp1; const int is = P->idxScale + 1; P->idxScale = is; P->scaleRange = pm_pow2neg((unsigned)is); }
-			}
-		}
+		if (!wideTrip)
+			pm_trip_score<G, VPL, GEO, BUF>(t, kp, rs, s_wg, s_pixg, hotBase, v, need PM_PROF_PASS);
 		__builtin_amdgcn_wave_barrier();
 		PM_TICK(6);
 	}
+	PM_HIST2(valid && v == 0, PM_TRIPS);
 	{
 		const PMPix* P = pm_launder(s_pixg);
 		wr = (P->flags & PMF_CHANGED) && valid;
@@ -240,7 +282,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 // (Measured and dropped in round 4: "view-major" lanes -- lane = view * pixels-per-wave + pixel, so that the four lanes of a quad read adjacent entries of one quad
 // image -- 43.1 vs 42.6 Mpix/s at 100 views, 28.1 vs 28.3 at 25: the order in which a wave's addresses reach the vector L1 is not what bounds the kernel.)
 template <int G, int VPL, bool GEO, bool BUF>
-__global__ __launch_bounds__(64, (GEO ? PM_BAND_MINWAVES : PM_BAND_MINWAVES_PHOTO)) void pm_sweep2_kernel(const PMTask* __restrict__ tasks, PMKParams kp, int dir, int d, int xlo, int count, uint32_t pass) {
+__global__ __launch_bounds__(64, (GEO ? PM_BAND_MINWAVES : PM_BAND_MINWAVES_PHOTO)) void pm_sweep2_kernel(const PMTask* __restrict__ tasks, PMKParams kp, PMStep st, uint32_t pass) {
 	constexpr int PPW = 64 / G;
 	constexpr int NV = G * VPL;
 	constexpr int NBD = PM_SRC_HOT + (GEO ? PM_SRC_GEO : 0);
@@ -263,11 +305,11 @@ __global__ __launch_bounds__(64, (GEO ? PM_BAND_MINWAVES : PM_BAND_MINWAVES_PHOT
 	for (int i = lane; i < NV * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];
 	const int g = lane / G, v = lane % G, slot = v & 3;
 	const int w = t.w, h = t.h;
-	const int pi = (int)vbx * PPW + g;
-	const bool active = pi < count;
-	const int x = xlo + (active ? pi : 0), y = d - x;
+	const PMStepPix sp = pm_step_pixel(st, w, h, (int)vbx / st.cpt, ((int)vbx % st.cpt) * PPW + g);
+	const bool active = sp.active;
+	const int x = sp.x, y = sp.y;
 	const size_t idx = (size_t)y * w + x;
-	const int sgn = dir == 0 ? -1 : 1;
+	const int sgn = st.dir == 0 ? -1 : 1;
 	bool bok[4]; int qxs[4], qys[4]; size_t qis[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
@@ -277,26 +319,29 @@ __global__ __launch_bounds__(64, (GEO ? PM_BAND_MINWAVES : PM_BAND_MINWAVES_PHOT
 		bok[k] = ok && active; qxs[k] = x + ox; qys[k] = y + oy;
 		qis[k] = bok[k] ? (size_t)(y + oy) * w + (x + ox) : idx;
 	}
-	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
+	// the two neighbours the sweep has already updated -- or, across a tile border, as the sweep found them
+	const pm_gcf nD0 = pm_glob((sp.oldMask & 1u) ? t.depthOld : t.depth), nN0 = pm_glob((sp.oldMask & 1u) ? t.normalOld : t.normal), nC0 = pm_glob((sp.oldMask & 1u) ? t.confOld : t.conf);
+	const pm_gcf nD1 = pm_glob((sp.oldMask & 2u) ? t.depthOld : t.depth), nN1 = pm_glob((sp.oldMask & 2u) ? t.normalOld : t.normal), nC1 = pm_glob((sp.oldMask & 2u) ? t.confOld : t.conf);
 	float n0D = 0.f, n0N0 = 0.f, n0N1 = 0.f, n0N2 = 0.f, n0C = 2.f, n1D = 0.f, n1N0 = 0.f, n1N1 = 0.f, n1N2 = 0.f, n1C = 2.f;
 	if (active) {
 		const size_t q0 = qis[0], q1 = qis[1];
-		n0D = gDepth[q0]; n0N0 = gNormal[q0 * 3]; n0N1 = gNormal[q0 * 3 + 1]; n0N2 = gNormal[q0 * 3 + 2]; n0C = gConf[q0];
-		n1D = gDepth[q1]; n1N0 = gNormal[q1 * 3]; n1N1 = gNormal[q1 * 3 + 1]; n1N2 = gNormal[q1 * 3 + 2]; n1C = gConf[q1];
+		n0D = nD0[q0]; n0N0 = nN0[q0 * 3]; n0N1 = nN0[q0 * 3 + 1]; n0N2 = nN0[q0 * 3 + 2]; n0C = nC0[q0];
+		n1D = nD1[q1]; n1N0 = nN1[q1 * 3]; n1N1 = nN1[q1 * 3 + 1]; n1N2 = nN1[q1 * 3 + 2]; n1C = nC1[q1];
 	}
 	__syncthreads();
+	const pm_gf gDepth = pm_globw(t.depth), gNormal = pm_globw(t.normal), gConf = pm_globw(t.conf);
 	float rD, rN0, rN1, rN2, rC; bool wr;
 #ifdef PM_PROBE_INNER
 	// (measurement builds only) the visit PM_PROBE_INNER times: every repetition after the first finds the lines of its own first pass in L1 / L2 -- an upper bound on what any
 	// scheme that keeps a view's footprint on-die across launches could save.  Same result (a visit reads nothing it writes).
 #pragma unroll 1
 	for (int probeRep = 1; probeRep < PM_PROBE_INNER; ++probeRep) {
-		pm_visit<G, VPL, GEO, BUF>(t, kp, rs, pass, sgn, s_w[g], &s_pix[g], s_src, g, v, slot, active, x, y, active ? y : PM_HW, active ? idx : (size_t)PM_HW * w + PM_HW, bok, qxs, qys, qis,
+		pm_visit<G, VPL, GEO, BUF>(t, kp, rs, pass, sgn, &s_w[0][0], &s_pix[0], s_src, lane, g, v, slot, active, x, y, active ? y : PM_HW, active ? idx : (size_t)PM_HW * w + PM_HW, bok, qxs, qys, qis, sp.oldMask,
 			n0D, n0N0, n0N1, n0N2, n0C, n1D, n1N0, n1N1, n1N2, n1C, rD, rN0, rN1, rN2, rC, wr PM_PROF_PASS);
 		__syncthreads();
 	}
 #endif
-	pm_visit<G, VPL, GEO, BUF>(t, kp, rs, pass, sgn, s_w[g], &s_pix[g], s_src, g, v, slot, active, x, y, active ? y : PM_HW, active ? idx : (size_t)PM_HW * w + PM_HW, bok, qxs, qys, qis,
+	pm_visit<G, VPL, GEO, BUF>(t, kp, rs, pass, sgn, &s_w[0][0], &s_pix[0], s_src, lane, g, v, slot, active, x, y, active ? y : PM_HW, active ? idx : (size_t)PM_HW * w + PM_HW, bok, qxs, qys, qis, sp.oldMask,
 		n0D, n0N0, n0N1, n0N2, n0C, n1D, n1N0, n1N1, n1N2, n1C, rD, rN0, rN1, rN2, rC, wr PM_PROF_PASS);
 	if (wr && v == 0) { gDepth[idx] = rD; gNormal[idx * 3] = rN0; gNormal[idx * 3 + 1] = rN1; gNormal[idx * 3 + 2] = rN2; gConf[idx] = rC; }
 	PM_PROF_FLUSH();

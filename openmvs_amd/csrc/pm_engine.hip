@@ -158,6 +158,9 @@ struct pmhip_engine {
 	// batch scratch (grow only)
 	int batchCap = 0;
 	float* d_lvl[4] = {nullptr, nullptr, nullptr, nullptr}; // level l>=1: [batch][6][h_l*w_l]; level 0: prior [batch][h*w]
+	float* d_old[4] = {nullptr, nullptr, nullptr, nullptr}; // tiled sweeps only: [batch][5][h_l*w_l] -- depth, normal, conf as the running sweep found them (PMTask::depthOld ...)
+	int oldCap = 0, oldW = 0, oldH = 0;
+	int tileW = 0, tileH = 0;                                // pmhip_set_sweep_tiles: 0 = the reference's sweep
 	PMTask* d_tasks = nullptr; PMTask* h_tasks = nullptr;     // [4 levels][batchCap]
 	PMUpTask* d_ups = nullptr; PMUpTask* h_ups = nullptr;     // [4][batchCap]
 	// single-view interface staging
@@ -200,7 +203,8 @@ static void freeFuse(pmhip_engine* e) {
 static void freeScene(pmhip_engine* e) {
 	hipSetDevice(e->device);
 	freeFuse(e);
-	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_imgS[l]) hipFree(e->d_imgS[l]); e->d_imgS[l] = nullptr; if (e->d_imgQ[l]) hipFree(e->d_imgQ[l]); e->d_imgQ[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; }
+	for (int l = 0; l < 4; ++l) { if (e->d_img[l]) hipFree(e->d_img[l]); e->d_img[l] = nullptr; if (e->d_imgS[l]) hipFree(e->d_imgS[l]); e->d_imgS[l] = nullptr; if (e->d_imgQ[l]) hipFree(e->d_imgQ[l]); e->d_imgQ[l] = nullptr; if (e->d_lvl[l]) hipFree(e->d_lvl[l]); e->d_lvl[l] = nullptr; if (e->d_old[l]) hipFree(e->d_old[l]); e->d_old[l] = nullptr; }
+	e->oldCap = 0;
 	if (e->d_depth) hipFree(e->d_depth); if (e->d_normal) hipFree(e->d_normal); if (e->d_conf) hipFree(e->d_conf); if (e->d_snap) hipFree(e->d_snap);
 	e->d_depth = e->d_normal = e->d_conf = e->d_snap = nullptr;
 	for (int l = 0; l < 4; ++l) { if (e->d_mask[l]) hipFree(e->d_mask[l]); e->d_mask[l] = nullptr; }
@@ -232,6 +236,18 @@ static int ensureBatch(pmhip_engine* e, int n, int bw, int bh) {
 	HIPCHK(e, hipMalloc(&e->d_ups, sizeof(PMUpTask) * 4 * cap));
 	HIPCHK(e, hipHostMalloc(&e->h_ups, sizeof(PMUpTask) * 4 * cap));
 	e->batchCap = cap; e->batchW = bw; e->batchH = bh;
+	return 0;
+}
+
+// tiled sweeps: snapshot storage for the batch (grow only)
+static int ensureOld(pmhip_engine* e) {
+	if (e->tileW <= 0 || e->tileH <= 0) return 0;
+	if (e->oldCap >= e->batchCap && e->oldW >= e->batchW && e->oldH >= e->batchH) return 0;
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	for (int l = 0; l < 4; ++l) { if (e->d_old[l]) hipFree(e->d_old[l]); e->d_old[l] = nullptr; }
+	for (int l = 0; l <= e->nLevels; ++l)
+		HIPCHK(e, hipMalloc(&e->d_old[l], sizeof(float) * (size_t)e->batchCap * 5 * lvlSize(e->batchW, l) * lvlSize(e->batchH, l)));
+	e->oldCap = e->batchCap; e->oldW = e->batchW; e->oldH = e->batchH;
 	return 0;
 }
 
@@ -318,9 +334,13 @@ static void sweepMapping(int maxSrc, int lanes, int& G, int& VPL) {
 	if (G == 8 && VPL > 2) { G <<= 1; VPL >>= 1; }   // (8,4) is not instantiated
 }
 
+// workgroups per tile of a sweep launch whose workgroups hold ppw pixels each (PMStep::cpt)
+static int chunksPerTile(const PMStep& st, int ppw) { return (std::min(st.tw, st.th) + ppw - 1) / ppw; }
 template <bool GEO, bool BUF>
-static bool launchSweep2(int G, int VPL, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
-#define PM_SWEEP2_CASE(g, vpl) case (g) * 16 + (vpl): hipLaunchKernelGGL((pm_sweep2_kernel<g, vpl, GEO, BUF>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass); return true
+static bool launchSweep2(int G, int VPL, int nTasks, hipStream_t s, const PMTask* t, const PMKParams& kp, PMStep st, uint32_t pass) {
+	st.cpt = chunksPerTile(st, 64 / G);
+	const dim3 grid((unsigned)(st.cpt * st.ntx * st.nty), (unsigned)nTasks);
+#define PM_SWEEP2_CASE(g, vpl) case (g) * 16 + (vpl): hipLaunchKernelGGL((pm_sweep2_kernel<g, vpl, GEO, BUF>), grid, dim3(64), 0, s, t, kp, st, pass); return true
 	switch (G * 16 + VPL) {
 	PM_SWEEP2_CASE(4, 1); PM_SWEEP2_CASE(8, 1); PM_SWEEP2_CASE(16, 1);
 	PM_SWEEP2_CASE(4, 2); PM_SWEEP2_CASE(8, 2);
@@ -330,25 +350,30 @@ static bool launchSweep2(int G, int VPL, dim3 grid, hipStream_t s, const PMTask*
 #undef PM_SWEEP2_CASE
 }
 
+// the eight-wide speculative kernel (one wave per pixel; batches of one or two views, never with tiles): launch k of the reference's one-tile sweep as an anti-diagonal
 template <bool GEO, bool BUF>
-static void launchSweepWide(dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
-	hipLaunchKernelGGL((pm_sweep_wide_kernel<GEO, BUF>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass);
+static void launchSweepWide(int nTasks, hipStream_t s, const PMTask* t, const PMKParams& kp, const PMStep& st, int lw, int lh, uint32_t pass) {
+	const int dLo = 2 * PM_HW, dHi = (lw - 1 - PM_HW) + (lh - 1 - PM_HW);
+	const int d = st.dir == 0 ? dLo + st.k : dHi - st.k;
+	const int xlo = std::max(PM_HW, d - (lh - 1 - PM_HW)), xhi = std::min(lw - 1 - PM_HW, d - PM_HW);
+	const int count = xhi - xlo + 1;
+	if (count <= 0) return;
+	hipLaunchKernelGGL((pm_sweep_wide_kernel<GEO, BUF>), dim3((unsigned)count, (unsigned)nTasks), dim3(64), 0, s, t, kp, st.dir, d, xlo, count, pass);
 }
 // the speculative kernel at 4 or 2 hypotheses per round (pm_wide_n.hip; PMHIP_WIDE_HYPS): 2 or 4 pixels per wave
 template <bool GEO, bool BUF>
-static void launchSweepWideN(int hyps, int nTasks, hipStream_t s, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
-	const int ppw = 8 / hyps;
-	const dim3 grid((unsigned)((count + ppw - 1) / ppw), (unsigned)nTasks);
-	if (hyps == 4) hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 4, BUF>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass);
-	else hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 2, BUF>), grid, dim3(64), 0, s, t, kp, dir, d, xlo, count, pass);
+static void launchSweepWideN(int hyps, int nTasks, hipStream_t s, const PMTask* t, const PMKParams& kp, PMStep st, uint32_t pass) {
+	st.cpt = chunksPerTile(st, 8 / hyps);
+	const dim3 grid((unsigned)(st.cpt * st.ntx * st.nty), (unsigned)nTasks);
+	if (hyps == 4) hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 4, BUF>), grid, dim3(64), 0, s, t, kp, st, pass);
+	else hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 2, BUF>), grid, dim3(64), 0, s, t, kp, st, pass);
 }
-// one diagonal of one view group with the kernel the batch calls for; false: the (lanes, views per lane) mapping is not instantiated
+// one launch of a sweep for one view group with the kernel the batch calls for; false: the (lanes, views per lane) mapping is not instantiated
 template <bool GEO, bool BUF>
-static bool launchDiagonal(bool wide, int hyps, int G2, int V2, int nTasks, hipStream_t st, const PMTask* t, const PMKParams& kp, int dir, int d, int xlo, int count, uint32_t pass) {
-	if (wide && hyps < 8) { launchSweepWideN<GEO, BUF>(hyps, nTasks, st, t, kp, dir, d, xlo, count, pass); return true; }
-	if (wide) { launchSweepWide<GEO, BUF>(dim3((unsigned)count, (unsigned)nTasks), st, t, kp, dir, d, xlo, count, pass); return true; }
-	const int P2 = 64 / G2;
-	return launchSweep2<GEO, BUF>(G2, V2, dim3((unsigned)((count + P2 - 1) / P2), (unsigned)nTasks), st, t, kp, dir, d, xlo, count, pass);
+static bool launchDiagonal(bool wide, int hyps, int G2, int V2, int nTasks, hipStream_t st, const PMTask* t, const PMKParams& kp, const PMStep& sp, int lw, int lh, uint32_t pass) {
+	if (wide && hyps < 8) { launchSweepWideN<GEO, BUF>(hyps, nTasks, st, t, kp, sp, pass); return true; }
+	if (wide) { launchSweepWide<GEO, BUF>(nTasks, st, t, kp, sp, lw, lh, pass); return true; }
+	return launchSweep2<GEO, BUF>(G2, V2, nTasks, st, t, kp, sp, pass);
 }
 
 #ifdef PM_PROBES
@@ -416,7 +441,7 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 	if (e->skewPitch(0) * (size_t)e->nImages > 0xFFFFFFFFull) buf = false;
 	int G = 1; while (G < maxSrc) G <<= 1;          // init kernel: one view per lane
 	int SG = G, VPL = 1;                             // sweep kernel: (lanes per pixel, views per lane)
-	sweepMapping(maxSrc, e->sweepLanes > 0 ? e->sweepLanes : (nB >= PMHIP_LANES4_FROM && maxSrc > 4 ? 4 : 16), SG, VPL);
+	sweepMapping(maxSrc, e->sweepLanes > 0 ? e->sweepLanes : ((nB >= PMHIP_LANES4_FROM || (e->tileW > 0 && e->tileH > 0)) && maxSrc > 4 ? 4 : 16), SG, VPL);
 	// latency mode (one wave per pixel, pm_sweep_wide_kernel) for batches too small to fill the GPU with one wave per 64 / G pixels
 	const bool wideBatch = nB <= e->wideMaxViews && maxSrc <= 8;
 	const size_t P0 = (size_t)cw * ch;                      // this class's pixels; the scene arrays are indexed with the scene's own
@@ -443,6 +468,7 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 				t.depth = base; t.normal = base + Pl; t.conf = base + Pl * 4;
 				t.prior = (l < S) ? base + Pl * 5 : nullptr;
 			}
+			if (e->tileW > 0 && e->tileH > 0) { float* ob = e->d_old[l] + Pl * 5 * b; t.depthOld = ob; t.normalOld = ob + Pl; t.confOld = ob + Pl * 4; }
 			if (v.sw) { t.ref = v.sImg[l]; t.refS = v.sImgS[l]; }
 			else { t.ref = e->d_img[l] + Pls * id; t.refS = e->d_imgS[l] + Pls * id; }
 			t.qArr = e->d_imgQ[l]; t.qCount = (unsigned)(e->skewPitch(l) * (size_t)e->nImages);
@@ -523,14 +549,25 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 	//  * the views of a group staggered along the pass, so that every launch mixes anti-diagonals, sweeps and levels and carries about the mean number of pixels
 	//    (profiles/r05_view_stagger_experiment.diff): 100 views 46.2 -> 44.0 (5 steps per view) -> 37.7 (30) -> 35.0 Mpix/s (100), profiles/r05_call3_stagger_*.log.  A launch
 	//    lasts one wave-visit at whatever fill, so evening out the fill buys nothing, while every step of the longer chain then costs the heavy kernel's visit.
-	struct Step { int kind, l; unsigned iter; int k; };   // kind 0: level hand-off, 1: init pass, 2: diagonal k of sweep `iter`, 3: finalize
+	struct Step { int kind, l; unsigned iter; int k; };   // kind 0: level hand-off, 1: init pass, 2: launch k of sweep `iter`, 3: finalize, 4: snapshot of the maps before a tiled sweep
 	std::vector<Step> steps;
+	// a level's sweep geometry (PMStep): the reference's sweep is one tile = all pixels that take part; pmhip_set_sweep_tiles cuts them into tiles
+	auto stepOf = [&](int l, int dir, int k) {
+		const int vw = lvlSize(cw, l) - 2 * PM_HW, vh = lvlSize(ch, l) - 2 * PM_HW;
+		PMStep sp; sp.dir = dir; sp.k = k; sp.cpt = 0;
+		sp.tw = e->tileW > 0 ? std::min(e->tileW, vw) : vw; sp.th = e->tileH > 0 ? std::min(e->tileH, vh) : vh;
+		sp.ntx = (vw + sp.tw - 1) / sp.tw; sp.nty = (vh + sp.th - 1) / sp.th;
+		return sp;
+	};
 	for (int l = S; l >= 0; --l) {
 		if (S > 0) steps.push_back({0, l, 0u, 0});
 		steps.push_back({1, l, 0u, 0});
-		const int lw = lvlSize(cw, l), lh = lvlSize(ch, l);
-		const int nDiag = (lw - 1 - PM_HW) + (lh - 1 - PM_HW) - 2 * PM_HW + 1;
-		for (unsigned iter = iterBegin; iter < iterEnd; ++iter) for (int k = 0; k < nDiag; ++k) steps.push_back({2, l, iter, k});
+		const PMStep g0s = stepOf(l, 0, 0);
+		const int nDiag = g0s.tw + g0s.th - 1;
+		for (unsigned iter = iterBegin; iter < iterEnd; ++iter) {
+			if (g0s.ntx * g0s.nty > 1) steps.push_back({4, l, iter, 0});
+			for (int k = 0; k < nDiag; ++k) steps.push_back({2, l, iter, k});
+		}
 	}
 	steps.push_back({3, 0, 0u, 0});
 	const long nSteps = (long)steps.size();
@@ -583,24 +620,28 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 			// dependent chain) for batches and for diagonals too small to fill the GPU with 64 / G pixels per wave
 			const int dir = (int)(sp.iter % 2u);
 			const uint32_t pass = (uint32_t)l * 64u + sp.iter;
-			const int dLo = 2 * PM_HW, dHi = (lw - 1 - PM_HW) + (lh - 1 - PM_HW);
-			const int d = dir == 0 ? dLo + sp.k : dHi - sp.k;
-			const int xlo = std::max(PM_HW, d - (lh - 1 - PM_HW));
-			const int xhi = std::min(lw - 1 - PM_HW, d - PM_HW);
-			const int count = xhi - xlo + 1;
-			if (count <= 0) return true;
+			const PMStep ps = stepOf(l, dir, sp.k);
+			// pixels of this launch: a full tile's k-th anti-diagonal holds min(k, tw - 1, th - 1, tw + th - 2 - k) + 1 of them (the tiles at the right and bottom border fewer)
+			const int perTile = std::min(std::min(sp.k, ps.tw + ps.th - 2 - sp.k), std::min(ps.tw, ps.th) - 1) + 1;
+			const bool tiled = ps.ntx * ps.nty > 1;
 			if (!evOpen[g]) { evSweep[g] = evBeginOn(e, 0, st); evOpen[g] = e->statsOn; }
-			const long npx = (long)count * nT;
-			const bool wide = wideBatch || (maxSrc <= 8 && npx <= e->widePixels);
-			const int hyps = (wideBatch && e->wideHyps > 0) ? e->wideHyps : ((nB <= 2 || npx <= e->wide8Pixels) ? 8 : 2);
+			const long npx = (long)perTile * ps.ntx * ps.nty * nT;
+			const bool wide = (wideBatch && !(tiled && npx > e->widePixels)) || (maxSrc <= 8 && npx <= e->widePixels);
+			int hyps = (wideBatch && e->wideHyps > 0) ? e->wideHyps : ((nB <= 2 || npx <= e->wide8Pixels) ? 8 : 2);
+			if (tiled && hyps == 8) hyps = 2;   // (the eight-wide kernel walks whole anti-diagonals of the map)
 			++nLaunched;
 #ifdef PM_PROBES
 			for (int r = 1; r < g_probeRepeat; ++r)   // (measurement builds only) the same diagonal again, back to back: what does a launch find in the caches its predecessor filled?
-				geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass))
-				    : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass));
+				geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass))
+				    : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass));
 #endif
-			return geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass))
-			           : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, nT, st, dt, kp, dir, d, xlo, count, pass));
+			return geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass))
+			           : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass));
+		}
+		case 4: {
+			// tiled sweeps: the maps as this sweep finds them, for the reads across tile borders
+			hipLaunchKernelGGL(pm_snapshot_kernel, dim3((unsigned)std::min<size_t>((Pl + 255) / 256, 2048), nT), dim3(256), 0, st, dt, Pl);
+			return true;
 		}
 		default:
 			hipLaunchKernelGGL(pm_finalize_kernel, dim3((unsigned)std::min<size_t>((P0 + 255) / 256, 4096), nT), dim3(256), 0, st, e->d_tasks + s0, thFinal);
@@ -652,6 +693,7 @@ static int estimateBatch(pmhip_engine* e, const int32_t* ids, int nB, const PMHi
 		maxN = std::max(maxN, (int)members[c].size()); maxW = std::max(maxW, sz.first); maxH = std::max(maxH, sz.second);
 	}
 	rc = ensureBatch(e, maxN, maxW, maxH); if (rc) return rc;
+	rc = ensureOld(e); if (rc) return rc;
 	for (size_t c = 0; c < sizes.size(); ++c) {
 		rc = estimateClass(e, members[c].data(), (int)members[c].size(), sizes[c].first, sizes[c].second, p, nGeometricIter);
 		if (rc) return rc;
@@ -824,6 +866,12 @@ int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t) {
 	if (t->quadBuffer != 0) e->quadBuffer = t->quadBuffer == 1;
 	if (t->widePixels != 0) e->widePixels = t->widePixels < 0 ? 0 : t->widePixels;
 	if (t->wide8Pixels != 0) e->wide8Pixels = t->wide8Pixels < 0 ? 0 : t->wide8Pixels;
+	return 0;
+}
+int pmhip_set_sweep_tiles(pmhip_engine* e, int tileW, int tileH) {
+	if (!e || tileW < 0 || tileH < 0 || (tileW > 0) != (tileH > 0) || (tileW > 0 && (tileW < 8 || tileH < 8))) { if (e) e->err = "pmhip_set_sweep_tiles: 0 x 0 (off) or at least 8 x 8"; return PMHIP_E_ARG; }
+	HIPCHK(e, hipSetDevice(e->device)); HIPCHK(e, hipStreamSynchronize(e->stream));
+	e->tileW = tileW; e->tileH = tileH;
 	return 0;
 }
 int pmhip_scene_set_view_id(pmhip_engine* e, int idx, uint32_t viewID) {
@@ -1337,6 +1385,14 @@ int pmhip_prof_hist(pmhip_engine* e, unsigned long long out17[17], int reset) {
 	HIPCHK(e, hipStreamSynchronize(e->stream));
 	HIPCHK(e, hipMemcpyFromSymbol(out17, HIP_SYMBOL(pm_hist), sizeof(unsigned long long) * 17));
 	if (reset) { unsigned long long z[17] = {0}; HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(pm_hist), z, sizeof(z))); }
+	return 0;
+}
+int pmhip_prof_hist2(pmhip_engine* e, unsigned long long out17[17], int reset) {
+	if (!e || !out17) return PMHIP_E_ARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	HIPCHK(e, hipMemcpyFromSymbol(out17, HIP_SYMBOL(pm_hist2), sizeof(unsigned long long) * 17));
+	if (reset) { unsigned long long z[17] = {0}; HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(pm_hist2), z, sizeof(z))); }
 	return 0;
 }
 #endif

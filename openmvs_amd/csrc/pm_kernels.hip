@@ -77,6 +77,8 @@ struct PMTask {           // one reference view at one pyramid level
 	const float* refS;    // reference image, anti-diagonal-major and FOLDED: texel (u,v) at ((u+v) mod w)*h + v -- anti-diagonal d and d + w share row d mod w of the array
 	                      // without colliding (d holds v <= d, d + w holds v > d), so the copy is w*h floats; pixels of one anti-diagonal are adjacent (what a wave's lanes read)
 	const unsigned char* mask; // nullable: ignore mask at this level, 0 = pixel is not estimated (DepthData::ApplyIgnoreMask + masked MapMatrix2ZigzagIdx)
+	// tiled sweeps only (pmhip_set_sweep_tiles; null otherwise): depth / normal / conf as the running sweep found them -- what a pixel reads of a neighbour in ANOTHER tile
+	const float* depthOld; const float* normalOld; const float* confOld;
 	int w, h, nSrc, pad0;
 	double Hr[9];         // K_0^-1
 	int hrUpper;          // 1 if Hr[1] == Hr[3] == Hr[6] == Hr[7] == 0 exactly (zero-skew K): products with those vanish exactly
@@ -97,6 +99,31 @@ struct PMKParams {        // DepthEstimator ctor constants, DepthMap.cpp:397-406
 
 enum { PM_STREAM_INIT = 0, PM_STREAM_RAND = 1, PM_STREAM_REFINE = 2 };
 
+// Which pixels one sweep launch visits.  The pixels that take part in the estimation, [HW, w - HW) x [HW, h - HW), are cut into ntx x nty tiles of tw x th pixels (the last
+// column / row of tiles is what is left); launch k visits, in every tile, the k-th anti-diagonal counted from the tile's corner the sweep starts at (dir 0: top left, 1: bottom
+// right).  The reference's sweep is ONE tile (ntx == nty == 1): launch k is anti-diagonal x + y == 2 HW + k of the map (or the last one minus k), pixels of one anti-diagonal
+// never read each other, so launches in stream order reproduce the sequential result.  With more tiles (opt-in, pmhip_set_sweep_tiles) a neighbour in another
+// tile is read from PMTask::depthOld / normalOld / confOld, the maps as this sweep found them -- see oracle/pm_oracle.cpp Opt::tileW for the definition both sides follow.
+struct PMStep { int dir, k, tw, th, ntx, nty, cpt; };   // cpt: workgroups per tile = ceil(min(tw, th) / pixels per workgroup)
+struct PMStepPix { bool active; int x, y; unsigned oldMask; };   // oldMask bit s: neighbour slot s lies in another tile
+// pixel `pi` of step-diagonal k in tile `tile`; slots: 0 (x+sgn,y), 1 (x,y+sgn), 2 (x-sgn,y), 3 (x,y-sgn) with sgn = dir == 0 ? -1 : 1
+__device__ __forceinline__ PMStepPix pm_step_pixel(const PMStep& st, int w, int h, int tile, int pi) {
+	PMStepPix r;
+	const int tx = tile % st.ntx, ty = tile / st.ntx;
+	const int ox = PM_HW + tx * st.tw, oy = PM_HW + ty * st.th;
+	const int twc = min(st.tw, w - PM_HW - ox), thc = min(st.th, h - PM_HW - oy);   // this tile's own size
+	const int lo = max(0, st.k - (thc - 1)), hi = min(twc - 1, st.k);
+	const int l = lo + pi;                                   // distance from the starting corner along x; st.k - l along y
+	r.active = ty < st.nty && pi >= 0 && l <= hi;
+	const int lx = st.dir == 0 ? l : twc - 1 - l, ly = st.dir == 0 ? st.k - l : thc - 1 - (st.k - l);
+	r.x = r.active ? ox + lx : PM_HW; r.y = r.active ? oy + ly : PM_HW;
+	const bool multi = st.ntx * st.nty > 1;
+	// dir 0 (sgn -1): slot 0 = left, 1 = top, 2 = right, 3 = bottom; dir 1: slot 0 = right, 1 = bottom, 2 = left, 3 = top
+	const bool oL = lx == 0, oT = ly == 0, oR = lx == twc - 1, oB = ly == thc - 1;
+	r.oldMask = !multi ? 0u : st.dir == 0 ? ((oL ? 1u : 0u) | (oT ? 2u : 0u) | (oR ? 4u : 0u) | (oB ? 8u : 0u)) : ((oR ? 1u : 0u) | (oB ? 2u : 0u) | (oL ? 4u : 0u) | (oT ? 8u : 0u));
+	return r;
+}
+
 #define PM_INF __builtin_huge_valf()
 // the value must exist in a register at this point (device only; nothing for the host build of the emulator)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -115,13 +142,18 @@ enum { PM_STREAM_INIT = 0, PM_STREAM_RAND = 1, PM_STREAM_REFINE = 2 };
 #ifdef PM_PROFILE
 __device__ unsigned long long pm_prof[16];
 __device__ unsigned long long pm_hist[17];   // trips of pm_visit by the number of pixels of the wave that score a hypothesis in the trip (0..16)
+__device__ unsigned long long pm_hist2[17];  // pixels by the number of hypotheses their visit scored
 struct PmProfAcc { unsigned long long a[16]; unsigned long long t; };
 #define PM_PROF_ARG , PmProfAcc& _pa
 #define PM_PROF_PASS , _pa
 #define PM_PROF_DECL PmProfAcc _pa; for (int _i = 0; _i < 16; ++_i) _pa.a[_i] = 0; _pa.t = __builtin_readcyclecounter()
 #define PM_TICK(i) do { const unsigned long long _n = __builtin_readcyclecounter(); _pa.a[i] += _n - _pa.t; _pa.t = _n; } while (0)
 #define PM_COUNT(i, n) do { _pa.a[i] += (unsigned long long)(n); } while (0)
-#define PM_HIST(n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&pm_hist[(n) > 16 ? 16 : (n)], 1ull); } while (0)
+#define PM_HIST(n) do { const int _n = (n); if ((threadIdx.x & 63) == 0) atomicAdd(&pm_hist[_n > 16 ? 16 : _n], 1ull); } while (0)
+#define PM_HIST2(on, n) do { const int _n = (n); if (on) atomicAdd(&pm_hist2[_n > 16 ? 16 : _n], 1ull); } while (0)
+#define PM_TRIPS_DECL int _trips = 0
+#define PM_TRIPS_ADD(c) do { _trips += (c) ? 1 : 0; } while (0)
+#define PM_TRIPS _trips
 #define PM_PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int _i = 0; _i < 16; ++_i) atomicAdd(&pm_prof[_i], _pa.a[_i]); } while (0)
 #else
 #define PM_PROF_ARG
@@ -130,6 +162,10 @@ struct PmProfAcc { unsigned long long a[16]; unsigned long long t; };
 #define PM_TICK(i) do {} while (0)
 #define PM_COUNT(i, n) do {} while (0)
 #define PM_HIST(n) do {} while (0)
+#define PM_HIST2(on, n) do {} while (0)
+#define PM_TRIPS_DECL do {} while (0)
+#define PM_TRIPS_ADD(c) do {} while (0)
+#define PM_TRIPS 0
 #define PM_PROF_FLUSH() do {} while (0)
 #endif
 #define PM_FD2R(d) ((d) * (PM_PI_F / 180.f))
@@ -948,6 +984,16 @@ __global__ __launch_bounds__(64, PM_WIDE_MINWAVES) void pm_sweep_wide_kernel(con
 	}
 	PM_PROF_FLUSH();
 	if (changed && lane == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
+}
+
+// tiled sweeps (PMStep): the maps of the group's views as the sweep that follows finds them
+__global__ void pm_snapshot_kernel(const PMTask* __restrict__ tasks, size_t n) {
+	const PMTask& t = tasks[blockIdx.y];
+	float* dO = const_cast<float*>(t.depthOld); float* nO = const_cast<float*>(t.normalOld); float* cO = const_cast<float*>(t.confOld);
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		dO[i] = t.depth[i]; cO[i] = t.conf[i];
+		nO[i * 3] = t.normal[i * 3]; nO[i * 3 + 1] = t.normal[i * 3 + 1]; nO[i * 3 + 2] = t.normal[i * 3 + 2];
+	}
 }
 
 // EndDepthMapTmp, SceneDensify.cpp:528-576

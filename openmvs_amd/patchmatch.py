@@ -59,7 +59,7 @@ EXPORTS = ["pmhip_get_tuning", "pmhip_set_tuning", "pmhip_scene_set_view_id", "p
            "pmhip_estimate_depth_map", "pmhip_estimate_depth_map_masked", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
            "pmhip_scene_estimate", "pmhip_scene_commit_round", "pmhip_scene_reset_view", "pmhip_scene_set_maps",
            "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_remove_small_segments", "pmhip_scene_images_updated", "pmhip_scene_maps_updated", "pmhip_scene_bytes", "pmhip_sync",
-           "pmhip_stream", "pmhip_stats_reset", "pmhip_stats_get", "pmhip_prof_get", "pmhip_math_eval", "pmhip_resize"]
+           "pmhip_stream", "pmhip_stats_reset", "pmhip_stats_get", "pmhip_prof_get", "pmhip_math_eval", "pmhip_resize", "pmhip_set_sweep_tiles"]
 
 _LIB = None
 
@@ -204,6 +204,11 @@ class PatchMatchHIP:
             self._chk(self._lib.pmhip_set_tuning(self._h, C.byref(t)))
         self._chk(self._lib.pmhip_get_tuning(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in PMHipTuning._fields_}
+
+    def set_sweep_tiles(self, tile_w: int = 0, tile_h: int = 0):
+        """OPT-IN, not the reference's estimator (pmhip_set_sweep_tiles): sweeps run inside tile_w x tile_h tiles, neighbours across a tile border are read as the previous
+        sweep left them.  0, 0 = off (the reference's sweep, bit for bit).  The result equals the oracle's with tileW / tileH set."""
+        self._chk(self._lib.pmhip_set_sweep_tiles(self._h, int(tile_w), int(tile_h)))
 
     def scene_set_view_id(self, idx, view_id):
         """The identity slot idx draws its random numbers under (pmhip_scene_set_view_id): the view's index in the whole scene when this engine holds a part of it."""

@@ -244,6 +244,11 @@ struct Opt {
 	int rngMode = 0;         // 0 = Philox per (pixel,attempt); 1 = mt19937 in traversal order (theta drawn before phi); 2 = the same with the two-draw
 	                         // expressions evaluated right to left, as GCC compiles the reference (DepthMap.h:441, DepthMap.cpp:836) -- what oracle/_ref is compared with
 	int nThreads = 1;        // 1 = sequential parity oracle; >1 = reference threading model (timing baseline)
+	// Tiled sweeps (the engine's opt-in PMHipParams::tileW / tileH; 0 = the reference's one sweep over the whole map): the pixels that take part in the estimation
+	// (x, y >= HW) are cut into tileW x tileH tiles; a sweep runs inside every tile in the reference's order, and a neighbour in ANOTHER tile is read as the previous sweep
+	// left it (depth, normal and confidence as they were when this sweep started).  The tiles of a sweep are then independent of each other -- which is all the engine
+	// gains from it -- and the result is a function of the inputs alone, so that this restatement and the device agree bit for bit.  NOT the reference's result.
+	int tileW = 0, tileH = 0;
 };
 
 // WeightedPatchFix<25>, DepthMap.h:145-155
@@ -280,6 +285,12 @@ struct DepthEstimator {
 	ImgF& depthMap0; ImgN& normalMap0; ImgF& confMap0;
 	std::vector<Weight>& weightMap0;
 	const ImgF* lowResDepthMap = nullptr;  // prior (nullptr == empty)
+	// tiled sweeps (Opt::tileW): the maps as the sweep found them, read for neighbours that lie in another tile
+	const ImgF* oldDepth = nullptr; const ImgN* oldNormal = nullptr; const ImgF* oldConf = nullptr;
+	bool otherTile(int nx, int ny) const { return opt.tileW > 0 && oldDepth && ((nx - HW) / opt.tileW != (x0x - HW) / opt.tileW || (ny - HW) / opt.tileH != (x0y - HW) / opt.tileH); }
+	float nbDepth(int nx, int ny) const { return otherTile(nx, ny) ? (*oldDepth)(ny, nx) : depthMap0(ny, nx); }
+	const float* nbNormal(int nx, int ny) const { return otherTile(nx, ny) ? oldNormal->at(ny, nx) : normalMap0.at(ny, nx); }
+	float nbConf(int nx, int ny) const { return otherTile(nx, ny) ? (*oldConf)(ny, nx) : confMap0(ny, nx); }
 	const unsigned nIteration;
 	const std::vector<ViewData>& views;    // images[0] = reference, images[1..] = sources
 	const ViewData& image0;
@@ -561,7 +572,7 @@ struct DepthEstimator {
 	void addClose(int nx, int ny, float ndepth) {
 		NeighborEstimate& ne = close[nClose++];
 		ne.depth = ndepth;
-		const float* nn = normalMap0.at(ny, nx);
+		const float* nn = nbNormal(nx, ny);
 		ne.normal[0] = nn[0]; ne.normal[1] = nn[1]; ne.normal[2] = nn[2];
 		// TransformPointI2C(Point3(nx, ndepth)) in double, then Cast<float>; Camera.h:338-344
 		const double* K = image0.camera.K;
@@ -578,15 +589,15 @@ struct DepthEstimator {
 		nNb = 0; nClose = 0;
 		const int x = x0x, y = x0y;
 		if (dir == LT2RB) {
-			if (x > HW)      { const float nd = depthMap0(y, x-1); if (nd > 0) { nbX[nNb] = x-1; nbY[nNb] = y; ++nNb; addClose(x-1, y, nd); } }
-			if (y > HW)      { const float nd = depthMap0(y-1, x); if (nd > 0) { nbX[nNb] = x; nbY[nNb] = y-1; ++nNb; addClose(x, y-1, nd); } }
-			if (x < W - HW)  { const float nd = depthMap0(y, x+1); if (nd > 0) addClose(x+1, y, nd); }
-			if (y < H - HW)  { const float nd = depthMap0(y+1, x); if (nd > 0) addClose(x, y+1, nd); }
+			if (x > HW)      { const float nd = nbDepth(x-1, y); if (nd > 0) { nbX[nNb] = x-1; nbY[nNb] = y; ++nNb; addClose(x-1, y, nd); } }
+			if (y > HW)      { const float nd = nbDepth(x, y-1); if (nd > 0) { nbX[nNb] = x; nbY[nNb] = y-1; ++nNb; addClose(x, y-1, nd); } }
+			if (x < W - HW)  { const float nd = nbDepth(x+1, y); if (nd > 0) addClose(x+1, y, nd); }
+			if (y < H - HW)  { const float nd = nbDepth(x, y+1); if (nd > 0) addClose(x, y+1, nd); }
 		} else {
-			if (x < W - HW)  { const float nd = depthMap0(y, x+1); if (nd > 0) { nbX[nNb] = x+1; nbY[nNb] = y; ++nNb; addClose(x+1, y, nd); } }
-			if (y < H - HW)  { const float nd = depthMap0(y+1, x); if (nd > 0) { nbX[nNb] = x; nbY[nNb] = y+1; ++nNb; addClose(x, y+1, nd); } }
-			if (x > HW)      { const float nd = depthMap0(y, x-1); if (nd > 0) addClose(x-1, y, nd); }
-			if (y > HW)      { const float nd = depthMap0(y-1, x); if (nd > 0) addClose(x, y-1, nd); }
+			if (x < W - HW)  { const float nd = nbDepth(x+1, y); if (nd > 0) { nbX[nNb] = x+1; nbY[nNb] = y; ++nNb; addClose(x+1, y, nd); } }
+			if (y < H - HW)  { const float nd = nbDepth(x, y+1); if (nd > 0) { nbX[nNb] = x; nbY[nNb] = y+1; ++nNb; addClose(x, y+1, nd); } }
+			if (x > HW)      { const float nd = nbDepth(x-1, y); if (nd > 0) addClose(x-1, y, nd); }
+			if (y > HW)      { const float nd = nbDepth(x, y-1); if (nd > 0) addClose(x, y-1, nd); }
 		}
 		float& conf = confMap0(y, x);
 		float& depth = depthMap0(y, x);
@@ -594,7 +605,7 @@ struct DepthEstimator {
 		const float viewDir[3] = {(float)X0[0], (float)X0[1], (float)X0[2]};
 		// propagate, :775-799
 		for (int n = 0; n < nNb; ++n) {
-			if (confMap0(nbY[n], nbX[n]) >= opt.fNCCThresholdKeep)
+			if (nbConf(nbX[n], nbY[n]) >= opt.fNCCThresholdKeep)
 				continue;
 			NeighborEstimate nb = close[n];
 			nb.depth = InterpolatePixel(nbX[n], nbY[n], nb.depth, nb.normal);
@@ -802,10 +813,15 @@ static int EstimateDepthMap(DepthData& full, const Opt& opt, int nGeometricIter,
 			runThreads(T, est, ScoreDepthMapTmp);
 		}
 		if (levelHook) levelHook(hookArg, (int)scaleNumber, -1, dd);
+		ImgF oldDepth, oldConf; ImgN oldNormal;
 		for (unsigned iter = iterBegin; iter < iterEnd; ++iter) { // pass B: sweeps
 			idxPixel = -1;
 			std::vector<std::unique_ptr<DepthEstimator>> own; std::vector<DepthEstimator*> est;
 			makeEstimators(iter, level * 64 + iter, own, est);
+			if (opt.tileW > 0 && opt.tileH > 0) {   // tiled sweeps: what the sweep finds, for the reads across tile borders
+				oldDepth = dd.depthMap; oldNormal = dd.normalMap; oldConf = dd.confMap;
+				for (DepthEstimator* e : est) { e->oldDepth = &oldDepth; e->oldNormal = &oldNormal; e->oldConf = &oldConf; }
+			}
 			runThreads(T, est, EstimateDepthMapTmp);
 			if (levelHook) levelHook(hookArg, (int)scaleNumber, (int)iter, dd);
 		}
@@ -837,6 +853,7 @@ struct OrcOpt {
 	float fEstimationGeometricWeight, fRandomDepthRatio, fRandomAngle1Range, fRandomAngle2Range;
 	float fRandomSmoothDepth, fRandomSmoothNormal, fRandomSmoothBonus, fNCCThresholdKeep, fDescriptorMinMagnitudeThreshold;
 	uint32_t seed, viewID; int32_t rngMode, nThreads;
+	int32_t tileW, tileH;        // tiled sweeps (orc::Opt::tileW); 0 = off
 };
 static orc::Opt toOpt(const OrcOpt* o) {
 	orc::Opt r;
@@ -848,6 +865,7 @@ static orc::Opt toOpt(const OrcOpt* o) {
 	r.fRandomSmoothBonus = o->fRandomSmoothBonus; r.fNCCThresholdKeep = o->fNCCThresholdKeep;
 	r.fDescriptorMinMagnitudeThreshold = o->fDescriptorMinMagnitudeThreshold;
 	r.seed = o->seed; r.viewID = o->viewID; r.rngMode = o->rngMode; r.nThreads = o->nThreads;
+	r.tileW = o->tileW; r.tileH = o->tileH;
 	return r;
 }
 void orc_default_opt(OrcOpt* o) {
@@ -859,7 +877,7 @@ void orc_default_opt(OrcOpt* o) {
 	o->fRandomSmoothDepth = d.fRandomSmoothDepth; o->fRandomSmoothNormal = d.fRandomSmoothNormal;
 	o->fRandomSmoothBonus = d.fRandomSmoothBonus; o->fNCCThresholdKeep = d.fNCCThresholdKeep;
 	o->fDescriptorMinMagnitudeThreshold = d.fDescriptorMinMagnitudeThreshold;
-	o->seed = 0; o->viewID = 0; o->rngMode = 0; o->nThreads = 1;
+	o->seed = 0; o->viewID = 0; o->rngMode = 0; o->nThreads = 1; o->tileW = 0; o->tileH = 0;
 }
 
 static void loadDepthData(const OrcView* views, int nViews, const float* depth, const float* normal, float dMin, float dMax, orc::DepthData& dd) {

@@ -30,7 +30,8 @@ class OrcOpt(C.Structure):
                 ("fRandomSmoothDepth", C.c_float), ("fRandomSmoothNormal", C.c_float),
                 ("fRandomSmoothBonus", C.c_float), ("fNCCThresholdKeep", C.c_float),
                 ("fDescriptorMinMagnitudeThreshold", C.c_float),
-                ("seed", C.c_uint32), ("viewID", C.c_uint32), ("rngMode", C.c_int32), ("nThreads", C.c_int32)]
+                ("seed", C.c_uint32), ("viewID", C.c_uint32), ("rngMode", C.c_int32), ("nThreads", C.c_int32),
+                ("tileW", C.c_int32), ("tileH", C.c_int32)]
 
 
 def build(force: bool = False) -> str:

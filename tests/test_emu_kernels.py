@@ -113,6 +113,12 @@ def test_estimator_resampled_neighbour_copies_through_the_driver(pm_emulated):
     g.resampled_neighbour_copies_through_the_driver(80, 60)           # ViewData::ScaleImage: copies in extra slots, handed their images' depth maps at the round boundary
 
 
+@pytest.mark.parametrize("kernel", ["sweep2", "speculative"])
+def test_estimator_tiled_sweeps(pm_emulated, nine_scene, small_scene, kernel):
+    from tests import test_gpu_patchmatch as g
+    g.test_tiled_sweeps_equal_the_tiled_oracle(nine_scene, small_scene, kernel, tiles=((24, 16),) if kernel == "sweep2" else ((9, 40),))
+
+
 def test_fusion_with_a_source_only_slot_without_colour(pm_emulated, small_scene):
     from tests import test_gpu_fuse as g
     g.test_fuse_with_a_source_only_slot_that_has_no_colour(small_scene)

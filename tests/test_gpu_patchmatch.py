@@ -1087,3 +1087,48 @@ def test_full_size_properties():
     assert (c[m] > 0).all() and (c <= 1).all() and (d[~m] == 0).all()
     assert (d[:4] == 0).all() and (d[:, :4] == 0).all()       # 4-px border never processed
     e.close()
+
+
+@pytest.mark.parametrize("kernel", ["sweep2", "speculative"])
+def test_tiled_sweeps_equal_the_tiled_oracle(nine_scene, small_scene, kernel, tiles=((24, 16), (9, 40))):
+    """The opt-in tiled sweeps (pmhip_set_sweep_tiles; NOT the reference's estimator): sweeps run inside tiles, a neighbour across a tile border is read as the previous sweep
+    left it.  Deterministic by construction, so the device must equal the oracle's restatement of the same definition (Opt::tileW / tileH) bit for bit: tiles that do not divide
+    the map, tiles larger than a coarse level, 8 and 4 sources, the pyramid, a geometric round of a scene batch -- and 0 x 0 switches back to the reference's sweep."""
+    from openmvs_amd.patchmatch import PatchMatchHIP
+    e = PatchMatchHIP(0)
+    e.tuning(wideMaxViews=-1 if kernel == "sweep2" else 64, wideHyps=-1)
+    for (tw, th) in tiles:
+        e.set_sweep_tiles(tw, th)
+        sc = nine_scene
+        e.Init(False)
+        p = default_params(seed=21)
+        ids = [4] + list(sc.neighbors[4])
+        d, n, c = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[4], sc.dmax[4], params=p)
+        od, on, oc = _oracle(sc, 4, 21, tileW=tw, tileH=th)
+        _same(d, od, f"tiles {tw}x{th}: depth"); _same(n, on, "normal"); _same(c, oc, "conf")
+        xd, _, _ = _oracle(sc, 4, 21)
+        assert not np.array_equal(od, xd) and (od > 0).mean() > 0.7          # it IS another estimator: the sequential sweep's maps differ
+        sc = small_scene                                                     # 4 sources, scene batch with a geometric round
+        p = default_params(seed=5, nEstimationGeometricIters=1)
+        e.Init(False); e.scene_load(sc, n_levels=2)
+        allv = list(range(sc.n_views))
+        e.scene_estimate(allv, -1, p)
+        photo = [e.scene_get_maps(v) for v in allv]
+        e.scene_commit_round(); e.Init(True)
+        e.scene_estimate([1, 3], 0, p)
+        for v in (1, 3):
+            od, on, oc = _oracle(sc, v, 5, nEstimationGeometricIters=1, tileW=tw, tileH=th)
+            _same(photo[v][0], od, f"tiles {tw}x{th}: photometric depth v{v}")
+            gd, gn, gc = _oracle(sc, v, 5, geo_iter=0, depth=od, normal=on, src={u: photo[u][0] for u in allv}, nEstimationGeometricIters=1, tileW=tw, tileH=th)
+            dd, nn, cc = e.scene_get_maps(v)
+            _same(dd, gd, f"tiles {tw}x{th}: geometric depth v{v}"); _same(nn, gn, "normal"); _same(cc, gc, "conf")
+    e.set_sweep_tiles(0, 0)
+    e.Init(False)
+    sc = nine_scene
+    ids = [4] + list(sc.neighbors[4])
+    d, n, c = e.EstimateDepthMap(sc.gray, sc.K, sc.R, sc.C, ids, sc.dmin[4], sc.dmax[4], params=default_params(seed=21))
+    od, on, oc = _oracle(sc, 4, 21)
+    _same(d, od, "tiles off: depth"); _same(n, on, "normal"); _same(c, oc, "conf")
+    with pytest.raises(Exception):
+        e.set_sweep_tiles(4, 4)
+    e.close()

@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--images", choices=("broadcast", "needed"), default="broadcast", help="N > 1: one broadcast of the image set (default), or rank 0 sends every rank only the views it holds")
     ap.add_argument("--no-shard-rates", action="store_true", help="skip the shard-size legs (the blocks a rank owns at 2 / 4 / 8 GPUs, timed on this GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--tiles", type=int, default=0, help="OPT-IN estimator mode, not the reference's sweep: tiled sweeps with tiles of this many pixels (pmhip_set_sweep_tiles); the line says so")
+    ap.add_argument("--no-tiled-leg", action="store_true", help="skip the tiled-sweeps leg (the opt-in mode's rates at the full batch and at the shard sizes)")
     return ap.parse_args()
 
 
@@ -149,6 +151,8 @@ def main():
     del gray
     eng = PatchMatchHIP(local)
     eng.Init(True)
+    if a.tiles:
+        eng.set_sweep_tiles(a.tiles, a.tiles)                # OPT-IN estimator mode (the line's config says so): not the reference's sweep order
     eng.scene_create(max(2, len(held)), W, H, 2)
     for i, g in enumerate(held):
         eng.scene_set_view(i, None, K[g], R[g], Cc[g], float(dmin[g]), float(dmax[g]), [slot[n] for n in nbr_lists[g]] if i < len(mine) else [])
@@ -282,6 +286,7 @@ def main():
             "config": {"workload": "%d-view %dx%d synthetic scene, %d source views per reference view, PatchMatch photometric pass "
                                    "(3-level pyramid x 3 sweeps) + %d geometric rounds%s, all depth maps"
                                    % (V, W, H, N, a.geo_iters, " + cross-view filter" if a.with_filter else ""),
+                       **({"estimator_mode": "OPT-IN tiled sweeps, %dx%d tiles (pmhip_set_sweep_tiles): NOT the reference's sweep order; see tiled_sweeps / tolerance" % (a.tiles, a.tiles)} if a.tiles else {}),
                        "views_total": V, "views_per_gpu": len(mine), "batch": B, "parallelism": "reference views sharded over %d GPU(s)" % world,
                        "exchange": "neighbour-only point-to-point (a rank holds its block and the %d foreign views it reads)" % len(foreign), "images": images_how, "ranks": ranks_info,
                        **({"backend": backend} if dist_on else {}), **({"depth_digests": digests} if digests else {})},
@@ -300,6 +305,8 @@ def main():
     # ---- extra legs (rank 0, 1 GPU only; outside the timed region) ---------------------------
     if rank == 0 and world == 1 and not weak and not a.no_shard_rates and V >= 16:
         out.update(shard_rate_legs(eng, a, V, W, H, p, mpix))
+    if rank == 0 and world == 1 and not weak and not a.no_tiled_leg and not a.tiles and V >= 16:
+        out.update(tiled_legs(eng, a, V, W, H, p, mpix))
     if rank == 0 and world == 1:
         eng.scene_create(2, 16, 16, 0)   # release the benchmark scene's HBM before the other legs
         if not a.no_extras:
@@ -339,6 +346,39 @@ def shard_rate_legs(eng, a, V, W, H, p, rate_full):
         model[str(n_gpus)] = round(n_gpus * rates[str(n)] / rate_full, 3)
     return {"shard_rates": {"unit": "Mpix/s on one GPU for a block of this many reference views of the same scene (best of 2 timed steps)", **rates},
             "scaling_model": {"note": "N x rate(ceil(views / N)) / rate(views), exchange excluded; measured on ONE GPU, not a multi-GPU run", **model}}
+
+
+def tiled_legs(eng, a, V, W, H, p, rate_full, tile=64):
+    """The OPT-IN tiled sweeps (pmhip_set_sweep_tiles: sweeps run inside tile x tile tiles, a neighbour across a tile border is read as the previous sweep left it -- another
+    estimator than the reference's sequential sweep, deterministic, bit-identical to its own oracle restatement; how far its maps are from the reference's: `tolerance`): the
+    same workload and the shard-size blocks of `shard_rates`, 1 warm-up + 2 timed steps each.  Never part of `value`."""
+    eng.set_sweep_tiles(tile, tile)
+    rates, model = {}, {}
+    try:
+        for n_gpus in (1, 2, 4, 8):
+            n = -(-V // n_gpus)
+            lo = (V - n) // 2
+            ids = list(range(lo, lo + n))
+            best = None
+            for rep in range(3):
+                for v in ids:
+                    eng.scene_reset_view(v)
+                eng.sync(); t = time.perf_counter()
+                eng.scene_estimate(ids, -1, p, sync=False)
+                for g in range(a.geo_iters):
+                    eng.scene_commit_round(); eng.scene_estimate(ids, g, p, sync=False)
+                eng.sync(); dt = time.perf_counter() - t
+                if rep and (best is None or dt < best):
+                    best = dt
+            rates[str(n)] = round(n * W * H / best / 1e6, 3)
+            if n_gpus > 1:
+                model[str(n_gpus)] = round(n_gpus * rates[str(n)] / rates[str(V)], 3)
+    finally:
+        eng.set_sweep_tiles(0, 0)
+    return {"tiled_sweeps": {"what": "OPT-IN, not the reference's sweep order: %dx%d tiles, neighbours across tile borders from the previous sweep; default off; `value` never uses it" % (tile, tile),
+                             "rates": {"unit": "Mpix/s on one GPU for a block of this many reference views, full schedule (best of 2 timed steps)", **rates},
+                             "vs_exact_sweep_at_%d_views" % V: round(rates[str(V)] / rate_full, 3),
+                             "scaling_model": {"note": "N x rate(ceil(views / N)) / rate(views) of the tiled mode, exchange excluded; measured on ONE GPU", **model}}}
 
 
 def sweep_kernel_name(n_batch, n_src):
@@ -592,15 +632,17 @@ def cpu_legs(a, eng):
     cores = usable_cores()
     seed = 1
 
-    def engine_rounds(sc):
+    def engine_rounds(sc, tiles=0):
         eng.Init(True)
         eng.scene_load(sc, 2)
+        eng.set_sweep_tiles(tiles, tiles)
         p = default_params(seed=seed, nEstimationGeometricIters=a.geo_iters)
         allv = list(range(sc.n_views))
         rounds = []
         eng.scene_estimate(allv, -1, p); rounds.append([eng.scene_get_maps(v) for v in allv])
         for g in range(a.geo_iters):
             eng.scene_commit_round(); eng.scene_estimate(allv, g, p); rounds.append([eng.scene_get_maps(v) for v in allv])
+        eng.set_sweep_tiles(0, 0)
         return rounds
 
     def cpu_schedule(sc, rounds, refs, threads, estimate, chain):
@@ -686,6 +728,11 @@ def cpu_legs(a, eng):
                 "reference_code_run_a_vs_run_b": {str(v): cmp(outs[v][0], again[v][0]) for v in refs[:3]},
                 "hip_vs_ground_truth": {str(v): vs_gt_of(rounds[-1][v][0], v) for v in refs[:3]},
                 "reference_code_vs_ground_truth": {str(v): vs_gt_of(outs[v][0], v) for v in refs[:3]}}
+        # the OPT-IN tiled sweeps (another estimator: tiled_sweeps) on the same scene, against the same reference runs
+        rounds_t = engine_rounds(sc, tiles=64)
+        full["hip_tiled64_vs_reference_code"] = {str(v): cmp(rounds_t[-1][v][0], outs[v][0]) for v in refs[:3]}
+        full["hip_tiled64_vs_hip"] = {str(v): cmp(rounds_t[-1][v][0], rounds[-1][v][0]) for v in refs[:3]}
+        full["hip_tiled64_vs_ground_truth"] = {str(v): vs_gt_of(rounds_t[-1][v][0], v) for v in refs[:3]}
         out["tolerance"] = {"case": "view %d of the 9-view %dx%d scene, photometric pass (end-of-pass threshold x 1.333), depth maps" % (v0, W, H),
                             "hip_vs_reference_code": cmp(hip[0], ref_a[0]), "reference_code_run_a_vs_run_b": cmp(ref_a[0], ref_b[0]),
                             "hip_vs_ground_truth": vs_gt(hip[0]), "reference_code_vs_ground_truth": vs_gt(ref_a[0]),

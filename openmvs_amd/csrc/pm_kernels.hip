@@ -151,9 +151,6 @@ struct PmProfAcc { unsigned long long a[16]; unsigned long long t; };
 #define PM_COUNT(i, n) do { _pa.a[i] += (unsigned long long)(n); } while (0)
 #define PM_HIST(n) do { const int _n = (n); if ((threadIdx.x & 63) == 0) atomicAdd(&pm_hist[_n > 16 ? 16 : _n], 1ull); } while (0)
 #define PM_HIST2(on, n) do { const int _n = (n); if (on) atomicAdd(&pm_hist2[_n > 16 ? 16 : _n], 1ull); } while (0)
-#define PM_TRIPS_DECL int _trips = 0
-#define PM_TRIPS_ADD(c) do { _trips += (c) ? 1 : 0; } while (0)
-#define PM_TRIPS _trips
 #define PM_PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int _i = 0; _i < 16; ++_i) atomicAdd(&pm_prof[_i], _pa.a[_i]); } while (0)
 #else
 #define PM_PROF_ARG
@@ -163,9 +160,6 @@ struct PmProfAcc { unsigned long long a[16]; unsigned long long t; };
 #define PM_COUNT(i, n) do {} while (0)
 #define PM_HIST(n) do {} while (0)
 #define PM_HIST2(on, n) do {} while (0)
-#define PM_TRIPS_DECL do {} while (0)
-#define PM_TRIPS_ADD(c) do {} while (0)
-#define PM_TRIPS 0
 #define PM_PROF_FLUSH() do {} while (0)
 #endif
 #define PM_FD2R(d) ((d) * (PM_PI_F / 180.f))
@@ -708,6 +702,11 @@ __device__ __forceinline__ float pm_pow2neg(unsigned i) { return pm_u2f((127u - 
 
 // -------------------------------------------------------------------------------------------
 // ScoreDepthMapTmp, SceneDensify.cpp:490-517: fully parallel, no neighbour dependency.
+// PM_INIT_MODE: how its one evaluation per pixel reads the source images -- 0: guarded tap rows from the row-major images (four 4-byte loads per sample, IEEE divisions and the
+// image test per tap); 2: the sweep kernels' optimistic rows from the level's quad buffer (one 16-byte load per sample, 34 VALU instructions per tap instead of ~60).
+#ifndef PM_INIT_MODE
+#define PM_INIT_MODE 0
+#endif
 template <int G, bool GEO>
 __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restrict__ tasks, PMKParams kp, uint32_t pass) {
 	constexpr int PPB = PM_BLOCK / G;
@@ -746,7 +745,8 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 	float sc = PM_INF;
 	PM_PROF_DECL;
 	if (v < t.nSrc)
-		sc = pm_score_view<GEO, 0>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, t.src[v].Hl, (const double*)t.src[v].Tl, PMImgBuf() PM_PROF_PASS);
+		sc = pm_score_view<GEO, PM_INIT_MODE>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, t.src[v].Hl, (const double*)t.src[v].Tl,
+			PM_INIT_MODE == 2 ? pm_make_imgbuf(t) : PMImgBuf() PM_PROF_PASS);
 	const float conf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 	if (v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
 }

@@ -51,15 +51,18 @@ class PMHipFuseParams(C.Structure):
                 ("bEstimateColor", C.c_int32), ("bEstimateNormal", C.c_int32)]
 
 
+PMHIP_ABI_VERSION = 6      # include/pmhip.h
+
+
 class PMHipTuning(C.Structure):
-    _fields_ = [("viewGroups", C.c_int32), ("wideMaxViews", C.c_int32), ("wideHyps", C.c_int32), ("sweepLanes", C.c_int32), ("quadBuffer", C.c_int32), ("widePixels", C.c_int32), ("wide8Pixels", C.c_int32)]
+    _fields_ = [("viewGroups", C.c_int32), ("wideMaxViews", C.c_int32), ("wideHyps", C.c_int32), ("sweepLanes", C.c_int32), ("quadBuffer", C.c_int32), ("widePixels", C.c_int32), ("wide8Pixels", C.c_int32), ("fatPixels", C.c_int32)]
 
 
 EXPORTS = ["pmhip_get_tuning", "pmhip_set_tuning", "pmhip_scene_set_view_id", "pmhip_scene_set_view_sized", "pmhip_scene_set_source_depth", "pmhip_scene_set_mask", "pmhip_scene_set_mask_mode", "pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",
            "pmhip_estimate_depth_map", "pmhip_estimate_depth_map_masked", "pmhip_last_error", "pmhip_scene_create", "pmhip_scene_set_view",
            "pmhip_scene_estimate", "pmhip_scene_commit_round", "pmhip_scene_reset_view", "pmhip_scene_set_maps",
            "pmhip_scene_get_maps", "pmhip_scene_device_ptr", "pmhip_scene_copy", "pmhip_scene_filter", "pmhip_scene_filter_commit", "pmhip_scene_gap_interpolation", "pmhip_scene_remove_small_segments", "pmhip_scene_images_updated", "pmhip_scene_maps_updated", "pmhip_scene_bytes", "pmhip_sync",
-           "pmhip_stream", "pmhip_stats_reset", "pmhip_stats_get", "pmhip_prof_get", "pmhip_math_eval", "pmhip_resize", "pmhip_set_sweep_tiles"]
+           "pmhip_stream", "pmhip_stats_reset", "pmhip_stats_get", "pmhip_prof_get", "pmhip_math_eval", "pmhip_resize", "pmhip_set_sweep_tiles", "pmhip_abi_version"]
 
 _LIB = None
 
@@ -80,8 +83,14 @@ def load_library() -> C.CDLL:
         lib.pmhip_stream.restype = C.c_void_p
         lib.pmhip_destroy.restype = None
         lib.pmhip_scene_fuse_rounds.restype = C.c_uint64
+        experiment = bool(os.environ.get("PMHIP_LIB"))        # (an older build of the library in an A/B run may lack the newest entry points)
         for n in EXPORTS:
-            getattr(lib, n)  # raises AttributeError if a declared symbol is missing
+            if not (experiment and n in ("pmhip_set_sweep_tiles", "pmhip_abi_version")):
+                getattr(lib, n)  # raises AttributeError if a declared symbol is missing
+        if hasattr(lib, "pmhip_abi_version"):
+            lib.pmhip_abi_version.restype = C.c_uint32
+        if hasattr(lib, "pmhip_abi_version") and lib.pmhip_abi_version() != PMHIP_ABI_VERSION and not experiment:
+            raise RuntimeError("%s has struct layout version %d, these bindings are written for %d (include/pmhip.h)" % (path, lib.pmhip_abi_version(), PMHIP_ABI_VERSION))
         _LIB = lib
     return _LIB
 

@@ -43,7 +43,7 @@ def test_struct_sizes_match_header():
     from openmvs_amd import patchmatch as pm
     assert C.sizeof(pm.PMHipParams) == 4 * 4 + 9 * 4 + 4
     assert C.sizeof(pm.PMHipView) == 8 + 8 + 21 * 8 + 8 + 21 * 8 + 16   # id, dw, dh + 4 bytes of tail padding
-    assert C.sizeof(pm.PMHipKernelStats) == 64 and C.sizeof(pm.PMHipTuning) == 7 * 4
+    assert C.sizeof(pm.PMHipKernelStats) == 64 and C.sizeof(pm.PMHipTuning) == 8 * 4
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

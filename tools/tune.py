@@ -10,7 +10,7 @@ for spec in variants:
     env = dict(os.environ, PMHIP_LIB=os.path.join(root, "openmvs_amd", lib), PMHIP_GROUPS=groups)
     if lanes:
         env["PMHIP_LANES"] = lanes
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-extras", "--views-per-gpu", views] + os.environ.get("TUNE_STEPS", "").split(), env=env, capture_output=True, text=True, timeout=400)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-extras", "--no-tiled-leg", "--no-shard-rates", "--views-per-gpu", views] + os.environ.get("TUNE_STEPS", "").split(), env=env, capture_output=True, text=True, timeout=400)
     try:
         j = json.loads(r.stdout.strip().splitlines()[-1])
         print("%-18s groups=%-2s lanes=%-2s views=%s  %.2f Mpix/s  step %.0f ms  avg_launch %.1f us" % (lib, groups, lanes or "-", views, j["value"], j["ms_per_step"], j["roofline"]["avg_launch_us"]), flush=True)

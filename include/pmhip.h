@@ -242,8 +242,7 @@ typedef struct PMHipTuning {
 	int32_t quadBuffer;      /* 1: tap rows address the level's quad images as one buffer, 2: through each view's pointer */
 	int32_t widePixels;      /* larger batches: a diagonal launch of at most this many pixels (diagonal length x views of the group) uses the two-wide speculative kernel (20000); -1 = none */
 	int32_t wide8Pixels;     /* ... and one of at most this many pixels the eight-wide speculative kernel; -1 = none */
-	int32_t fatPixels;       /* a sweep launch whose pixels x view groups reach this many keeps two pixels per lane group resident in a wave of pm_sweep2_kernel (57344); -1 = never.
-	                            (This slot was `launchThreads` until round 4 and absent in round 5: see PMHIP_ABI_VERSION.) */
+	int32_t reserved0;       /* ignored by pmhip_set_tuning, 0 from pmhip_get_tuning (`launchThreads` until round 4, absent in round 5: the struct is 32 bytes again -- PMHIP_ABI_VERSION) */
 } PMHipTuning;
 /* OPT-IN, NOT the reference's estimator: tiled sweeps.  The pixels that take part in the estimation are cut into tileW x tileH tiles; a sweep (DepthMap.cpp:329-356 order)
  * runs inside every tile, and a neighbour in another tile is read as the previous sweep left it.  The tiles of a sweep are independent, so a sweep is tileW + tileH - 1
@@ -252,7 +251,7 @@ typedef struct PMHipTuning {
  * that it differs like two runs of the reference differ from each other.  0, 0 = off (the default: the reference's sweep, bit for bit). */
 int pmhip_set_sweep_tiles(pmhip_engine* e, int tileW, int tileH);
 /* The layout of the structs of this header as a number: a host program compares pmhip_abi_version() with the PMHIP_ABI_VERSION it was compiled against before it hands the
- * library a struct (6: PMHipTuning has eight fields again -- fatPixels; pmhip_set_sweep_tiles). */
+ * library a struct (6: PMHipTuning is 32 bytes again -- reserved0; pmhip_set_sweep_tiles). */
 #define PMHIP_ABI_VERSION 6u
 uint32_t pmhip_abi_version(void);
 int pmhip_get_tuning(pmhip_engine* e, PMHipTuning* out);

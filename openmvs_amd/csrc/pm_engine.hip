@@ -21,10 +21,6 @@
 #include <string>
 #include <vector>
 
-#ifndef PMHIP_DEFAULT_FAT_PIXELS
-#define PMHIP_DEFAULT_FAT_PIXELS 57344    // = 3 584 waves (14 per CU: the LDS of a 16-pixel wave) x 16 pixels: a sweep launch whose pixels x view groups reach this many has more waves than the
-                                          // GPU holds at once; pm_sweep2_kernel then keeps 32 pixels resident per wave (two per lane group) -- see pm_band.hip
-#endif
 #ifndef PMHIP_DEFAULT_WIDE_PIXELS
 #define PMHIP_DEFAULT_WIDE_PIXELS 20000   // larger batches: diagonal launches of at most this many pixels (diagonal length x views of the group) use the two-wide speculative
                                          // kernel -- the ramps of the fine level and all of the coarse ones.  profiles/r04_call9_lanes_100.log (100 views, Mpix/s): none 46.4,
@@ -125,7 +121,6 @@ struct pmhip_engine {
 	int widePixels = PMHIP_DEFAULT_WIDE_PIXELS;     // in larger batches: a diagonal launch of at most this many pixels (diagonal length x views of the group) uses the two-wide speculative kernel (PMHIP_WIDE_PIXELS)
 	int wide8Pixels = PMHIP_DEFAULT_WIDE8_PIXELS;   // ... and one of at most this many pixels the eight-wide one (PMHIP_WIDE8_PIXELS)
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
-	int fatPixels = PMHIP_DEFAULT_FAT_PIXELS;   // a sweep launch whose pixels x view groups reach this many runs pm_sweep2_kernel with two pixels per lane group resident (0 = never)
 	int quadBuffer = 1;                     // tap rows address the level's quad images as one buffer (entry index); 0 = through each view's own pointer (PMHIP_QUADBUF; forced for
 	                                        // batches that read a source view with its own image size, which lives outside the level's buffer)
 	hipStream_t gstream[16] = {};
@@ -339,20 +334,20 @@ static void sweepMapping(int maxSrc, int lanes, int& G, int& VPL) {
 	if (G == 8 && VPL > 2) { G <<= 1; VPL >>= 1; }   // (8,4) is not instantiated
 }
 
-// workgroups per tile of a sweep launch whose workgroups hold ppw pixels each (PMStep::cpt)
-static int chunksPerTile(const PMStep& st, int ppw) { return (std::min(st.tw, st.th) + ppw - 1) / ppw; }
-// fat: two pixels per lane group resident in a wave (pm_sweep2_kernel's NP; instantiated for 4 lanes per pixel) -- for launches with more waves than the GPU holds
+// workgroups of a sweep launch whose workgroups hold ppw pixels each: the launch's pixels are numbered tile by tile, PMStep::len per tile
+static unsigned stepBlocks(const PMStep& st, int ppw) { return (unsigned)(((long)st.len * st.ntx * st.nty + ppw - 1) / ppw); }
+// (tiled sweeps are instantiated for the quad-buffer addressing only: a batch with source views of their own image size runs the reference's sweep)
 template <bool GEO, bool BUF>
-static bool launchSweep2(int G, int VPL, bool fat, int nTasks, hipStream_t s, const PMTask* t, const PMKParams& kp, PMStep st, uint32_t pass) {
-	const int np = (fat && G == 4) ? 32 : 64 / G;
-	st.cpt = chunksPerTile(st, np);
-	const dim3 grid((unsigned)(st.cpt * st.ntx * st.nty), (unsigned)nTasks);
-#define PM_SWEEP2_CASE(g, vpl, n) case ((g) * 16 + (vpl)) * 64 + (n): hipLaunchKernelGGL((pm_sweep2_kernel<g, vpl, GEO, BUF, n>), grid, dim3(64), 0, s, t, kp, st, pass); return true
-	switch ((G * 16 + VPL) * 64 + np) {
-	PM_SWEEP2_CASE(4, 1, 16); PM_SWEEP2_CASE(8, 1, 8); PM_SWEEP2_CASE(16, 1, 4);
-	PM_SWEEP2_CASE(4, 2, 16); PM_SWEEP2_CASE(8, 2, 8);
-	PM_SWEEP2_CASE(4, 4, 16);
-	PM_SWEEP2_CASE(4, 1, 32); PM_SWEEP2_CASE(4, 2, 32); PM_SWEEP2_CASE(4, 4, 32);
+static bool launchSweep2(int G, int VPL, int nTasks, hipStream_t s, const PMTask* t, const PMKParams& kp, const PMStep& st, uint32_t pass) {
+	const dim3 grid(stepBlocks(st, 64 / G), (unsigned)nTasks);
+	const bool tiled = st.ntx * st.nty > 1;
+#define PM_SWEEP2_CASE(g, vpl) case (g) * 16 + (vpl): \
+		if constexpr (BUF) { if (tiled) { hipLaunchKernelGGL((pm_sweep2_kernel<g, vpl, GEO, BUF, true>), grid, dim3(64), 0, s, t, kp, st, pass); return true; } } \
+		hipLaunchKernelGGL((pm_sweep2_kernel<g, vpl, GEO, BUF, false>), grid, dim3(64), 0, s, t, kp, st, pass); return true
+	switch (G * 16 + VPL) {
+	PM_SWEEP2_CASE(4, 1); PM_SWEEP2_CASE(8, 1); PM_SWEEP2_CASE(16, 1);
+	PM_SWEEP2_CASE(4, 2); PM_SWEEP2_CASE(8, 2);
+	PM_SWEEP2_CASE(4, 4);
 	default: return false;
 	}
 #undef PM_SWEEP2_CASE
@@ -371,17 +366,21 @@ static void launchSweepWide(int nTasks, hipStream_t s, const PMTask* t, const PM
 // the speculative kernel at 4 or 2 hypotheses per round (pm_wide_n.hip; PMHIP_WIDE_HYPS): 2 or 4 pixels per wave
 template <bool GEO, bool BUF>
 static void launchSweepWideN(int hyps, int nTasks, hipStream_t s, const PMTask* t, const PMKParams& kp, PMStep st, uint32_t pass) {
-	st.cpt = chunksPerTile(st, 8 / hyps);
-	const dim3 grid((unsigned)(st.cpt * st.ntx * st.nty), (unsigned)nTasks);
-	if (hyps == 4) hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 4, BUF>), grid, dim3(64), 0, s, t, kp, st, pass);
-	else hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 2, BUF>), grid, dim3(64), 0, s, t, kp, st, pass);
+	const dim3 grid(stepBlocks(st, 8 / hyps), (unsigned)nTasks);
+	if constexpr (BUF) if (st.ntx * st.nty > 1) {
+		if (hyps == 4) hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 4, BUF, true>), grid, dim3(64), 0, s, t, kp, st, pass);
+		else hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 2, BUF, true>), grid, dim3(64), 0, s, t, kp, st, pass);
+		return;
+	}
+	if (hyps == 4) hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 4, BUF, false>), grid, dim3(64), 0, s, t, kp, st, pass);
+	else hipLaunchKernelGGL((pm_sweep_widen_kernel<GEO, 2, BUF, false>), grid, dim3(64), 0, s, t, kp, st, pass);
 }
 // one launch of a sweep for one view group with the kernel the batch calls for; false: the (lanes, views per lane) mapping is not instantiated
 template <bool GEO, bool BUF>
-static bool launchDiagonal(bool wide, int hyps, int G2, int V2, bool fat, int nTasks, hipStream_t st, const PMTask* t, const PMKParams& kp, const PMStep& sp, int lw, int lh, uint32_t pass) {
+static bool launchDiagonal(bool wide, int hyps, int G2, int V2, int nTasks, hipStream_t st, const PMTask* t, const PMKParams& kp, const PMStep& sp, int lw, int lh, uint32_t pass) {
 	if (wide && hyps < 8) { launchSweepWideN<GEO, BUF>(hyps, nTasks, st, t, kp, sp, pass); return true; }
 	if (wide) { launchSweepWide<GEO, BUF>(nTasks, st, t, kp, sp, lw, lh, pass); return true; }
-	return launchSweep2<GEO, BUF>(G2, V2, fat, nTasks, st, t, kp, sp, pass);
+	return launchSweep2<GEO, BUF>(G2, V2, nTasks, st, t, kp, sp, pass);
 }
 
 #ifdef PM_PROBES
@@ -560,11 +559,14 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 	struct Step { int kind, l; unsigned iter; int k; };   // kind 0: level hand-off, 1: init pass, 2: launch k of sweep `iter`, 3: finalize, 4: snapshot of the maps before a tiled sweep
 	std::vector<Step> steps;
 	// a level's sweep geometry (PMStep): the reference's sweep is one tile = all pixels that take part; pmhip_set_sweep_tiles cuts them into tiles
+	const bool tilesOn = e->tileW > 0 && e->tileH > 0;
+	if (tilesOn && !buf) { e->err = "tiled sweeps (pmhip_set_sweep_tiles) address the level's quad buffer: not with source views of their own image size, PMHipTuning::quadBuffer = 2 or a level-0 buffer of 2^32 entries"; return PMHIP_E_ARG; }
 	auto stepOf = [&](int l, int dir, int k) {
 		const int vw = lvlSize(cw, l) - 2 * PM_HW, vh = lvlSize(ch, l) - 2 * PM_HW;
-		PMStep sp; sp.dir = dir; sp.k = k; sp.cpt = 0;
-		sp.tw = e->tileW > 0 ? std::min(e->tileW, vw) : vw; sp.th = e->tileH > 0 ? std::min(e->tileH, vh) : vh;
+		PMStep sp; sp.dir = dir; sp.k = k;
+		sp.tw = tilesOn ? std::min(e->tileW, vw) : vw; sp.th = tilesOn ? std::min(e->tileH, vh) : vh;
 		sp.ntx = (vw + sp.tw - 1) / sp.tw; sp.nty = (vh + sp.th - 1) / sp.th;
+		sp.len = std::max(0, std::min(std::min(k, sp.tw + sp.th - 2 - k), std::min(sp.tw, sp.th) - 1) + 1);
 		return sp;
 	};
 	for (int l = S; l >= 0; --l) {
@@ -630,23 +632,22 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 			const uint32_t pass = (uint32_t)l * 64u + sp.iter;
 			const PMStep ps = stepOf(l, dir, sp.k);
 			// pixels of this launch: a full tile's k-th anti-diagonal holds min(k, tw - 1, th - 1, tw + th - 2 - k) + 1 of them (the tiles at the right and bottom border fewer)
-			const int perTile = std::min(std::min(sp.k, ps.tw + ps.th - 2 - sp.k), std::min(ps.tw, ps.th) - 1) + 1;
+			const int perTile = ps.len;
+			if (perTile <= 0) return true;
 			const bool tiled = ps.ntx * ps.nty > 1;
 			if (!evOpen[g]) { evSweep[g] = evBeginOn(e, 0, st); evOpen[g] = e->statsOn; }
 			const long npx = (long)perTile * ps.ntx * ps.nty * nT;
 			const bool wide = (wideBatch && !(tiled && npx > e->widePixels)) || (maxSrc <= 8 && npx <= e->widePixels);
 			int hyps = (wideBatch && e->wideHyps > 0) ? e->wideHyps : ((nB <= 2 || npx <= e->wide8Pixels) ? 8 : 2);
 			if (tiled && hyps == 8) hyps = 2;   // (the eight-wide kernel walks whole anti-diagonals of the map)
-			// two pixels per lane group resident in a wave where the launches of all view groups together hold more waves than the GPU (PMHipTuning::fatPixels)
-			const bool fat = e->fatPixels > 0 && npx * NG >= e->fatPixels;
 			++nLaunched;
 #ifdef PM_PROBES
 			for (int r = 1; r < g_probeRepeat; ++r)   // (measurement builds only) the same diagonal again, back to back: what does a launch find in the caches its predecessor filled?
-				geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, fat, nT, st, dt, kp, ps, lw, lh, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, fat, nT, st, dt, kp, ps, lw, lh, pass))
-				    : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, fat, nT, st, dt, kp, ps, lw, lh, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, fat, nT, st, dt, kp, ps, lw, lh, pass));
+				geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass))
+				    : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass));
 #endif
-			return geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, fat, nT, st, dt, kp, ps, lw, lh, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, fat, nT, st, dt, kp, ps, lw, lh, pass))
-			           : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, fat, nT, st, dt, kp, ps, lw, lh, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, fat, nT, st, dt, kp, ps, lw, lh, pass));
+			return geo ? (buf ? launchDiagonal<true, true>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass) : launchDiagonal<true, false>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass))
+			           : (buf ? launchDiagonal<false, true>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass) : launchDiagonal<false, false>(wide, hyps, SG, VPL, nT, st, dt, kp, ps, lw, lh, pass));
 		}
 		case 4: {
 			// tiled sweeps: the maps as this sweep finds them, for the reads across tile borders
@@ -858,7 +859,7 @@ int pmhip_get_tuning(pmhip_engine* e, PMHipTuning* out) {
 	out->viewGroups = e->nGroups; out->wideMaxViews = e->wideMaxViews > 0 ? e->wideMaxViews : -1; out->wideHyps = e->wideHyps > 0 ? e->wideHyps : -1;
 	out->sweepLanes = e->sweepLanes > 0 ? e->sweepLanes : -1; out->quadBuffer = e->quadBuffer ? 1 : 2;
 	out->widePixels = e->widePixels > 0 ? e->widePixels : -1; out->wide8Pixels = e->wide8Pixels > 0 ? e->wide8Pixels : -1;
-	out->fatPixels = e->fatPixels > 0 ? e->fatPixels : -1;
+	out->reserved0 = 0;
 	return 0;
 }
 int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t) {
@@ -878,7 +879,6 @@ int pmhip_set_tuning(pmhip_engine* e, const PMHipTuning* t) {
 	if (t->quadBuffer != 0) e->quadBuffer = t->quadBuffer == 1;
 	if (t->widePixels != 0) e->widePixels = t->widePixels < 0 ? 0 : t->widePixels;
 	if (t->wide8Pixels != 0) e->wide8Pixels = t->wide8Pixels < 0 ? 0 : t->wide8Pixels;
-	if (t->fatPixels != 0) e->fatPixels = t->fatPixels < 0 ? 0 : t->fatPixels;
 	return 0;
 }
 int pmhip_set_sweep_tiles(pmhip_engine* e, int tileW, int tileH) {
@@ -1398,14 +1398,6 @@ int pmhip_prof_hist(pmhip_engine* e, unsigned long long out17[17], int reset) {
 	HIPCHK(e, hipStreamSynchronize(e->stream));
 	HIPCHK(e, hipMemcpyFromSymbol(out17, HIP_SYMBOL(pm_hist), sizeof(unsigned long long) * 17));
 	if (reset) { unsigned long long z[17] = {0}; HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(pm_hist), z, sizeof(z))); }
-	return 0;
-}
-int pmhip_prof_hist2(pmhip_engine* e, unsigned long long out17[17], int reset) {
-	if (!e || !out17) return PMHIP_E_ARG;
-	HIPCHK(e, hipSetDevice(e->device));
-	HIPCHK(e, hipStreamSynchronize(e->stream));
-	HIPCHK(e, hipMemcpyFromSymbol(out17, HIP_SYMBOL(pm_hist2), sizeof(unsigned long long) * 17));
-	if (reset) { unsigned long long z[17] = {0}; HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(pm_hist2), z, sizeof(z))); }
 	return 0;
 }
 #endif

@@ -104,23 +104,25 @@ enum { PM_STREAM_INIT = 0, PM_STREAM_RAND = 1, PM_STREAM_REFINE = 2 };
 // right).  The reference's sweep is ONE tile (ntx == nty == 1): launch k is anti-diagonal x + y == 2 HW + k of the map (or the last one minus k), pixels of one anti-diagonal
 // never read each other, so launches in stream order reproduce the sequential result.  With more tiles (opt-in, pmhip_set_sweep_tiles) a neighbour in another
 // tile is read from PMTask::depthOld / normalOld / confOld, the maps as this sweep found them -- see oracle/pm_oracle.cpp Opt::tileW for the definition both sides follow.
-struct PMStep { int dir, k, tw, th, ntx, nty, cpt; };   // cpt: workgroups per tile = ceil(min(tw, th) / pixels per workgroup)
+struct PMStep { int dir, k, tw, th, ntx, nty, len; };   // len: pixels of a full tile in this launch = min(k, tw - 1, th - 1, tw + th - 2 - k) + 1.  The launch's pixels are numbered
+                                                        // tile by tile, len per tile (a tile cut by the border has fewer: the rest of its numbers are idle), and waves take consecutive numbers
 struct PMStepPix { bool active; int x, y; unsigned oldMask; };   // oldMask bit s: neighbour slot s lies in another tile
-// pixel `pi` of step-diagonal k in tile `tile`; slots: 0 (x+sgn,y), 1 (x,y+sgn), 2 (x-sgn,y), 3 (x,y-sgn) with sgn = dir == 0 ? -1 : 1
-__device__ __forceinline__ PMStepPix pm_step_pixel(const PMStep& st, int w, int h, int tile, int pi) {
+// pixel number p of the launch; slots: 0 (x+sgn,y), 1 (x,y+sgn), 2 (x-sgn,y), 3 (x,y-sgn) with sgn = dir == 0 ? -1 : 1.  TILED = false: the reference's sweep, one tile.
+template <bool TILED>
+__device__ __forceinline__ PMStepPix pm_step_pixel(const PMStep& st, int w, int h, int p) {
 	PMStepPix r;
-	const int tx = tile % st.ntx, ty = tile / st.ntx;
+	int tile = 0, pi = p, tx = 0, ty = 0;
+	if (TILED) { tile = p / st.len; pi = p - tile * st.len; tx = tile % st.ntx; ty = tile / st.ntx; }
 	const int ox = PM_HW + tx * st.tw, oy = PM_HW + ty * st.th;
-	const int twc = min(st.tw, w - PM_HW - ox), thc = min(st.th, h - PM_HW - oy);   // this tile's own size
+	const int twc = TILED ? min(st.tw, w - PM_HW - ox) : st.tw, thc = TILED ? min(st.th, h - PM_HW - oy) : st.th;   // this tile's own size
 	const int lo = max(0, st.k - (thc - 1)), hi = min(twc - 1, st.k);
 	const int l = lo + pi;                                   // distance from the starting corner along x; st.k - l along y
-	r.active = ty < st.nty && pi >= 0 && l <= hi;
+	r.active = ty < st.nty && l <= hi;
 	const int lx = st.dir == 0 ? l : twc - 1 - l, ly = st.dir == 0 ? st.k - l : thc - 1 - (st.k - l);
 	r.x = r.active ? ox + lx : PM_HW; r.y = r.active ? oy + ly : PM_HW;
-	const bool multi = st.ntx * st.nty > 1;
 	// dir 0 (sgn -1): slot 0 = left, 1 = top, 2 = right, 3 = bottom; dir 1: slot 0 = right, 1 = bottom, 2 = left, 3 = top
 	const bool oL = lx == 0, oT = ly == 0, oR = lx == twc - 1, oB = ly == thc - 1;
-	r.oldMask = !multi ? 0u : st.dir == 0 ? ((oL ? 1u : 0u) | (oT ? 2u : 0u) | (oR ? 4u : 0u) | (oB ? 8u : 0u)) : ((oR ? 1u : 0u) | (oB ? 2u : 0u) | (oL ? 4u : 0u) | (oT ? 8u : 0u));
+	r.oldMask = !TILED ? 0u : st.dir == 0 ? ((oL ? 1u : 0u) | (oT ? 2u : 0u) | (oR ? 4u : 0u) | (oB ? 8u : 0u)) : ((oR ? 1u : 0u) | (oB ? 2u : 0u) | (oL ? 4u : 0u) | (oT ? 8u : 0u));
 	return r;
 }
 
@@ -142,7 +144,6 @@ __device__ __forceinline__ PMStepPix pm_step_pixel(const PMStep& st, int w, int 
 #ifdef PM_PROFILE
 __device__ unsigned long long pm_prof[16];
 __device__ unsigned long long pm_hist[17];   // trips of pm_visit by the number of pixels of the wave that score a hypothesis in the trip (0..16)
-__device__ unsigned long long pm_hist2[17];  // pixels by the number of hypotheses their visit scored
 struct PmProfAcc { unsigned long long a[16]; unsigned long long t; };
 #define PM_PROF_ARG , PmProfAcc& _pa
 #define PM_PROF_PASS , _pa
@@ -150,7 +151,6 @@ struct PmProfAcc { unsigned long long a[16]; unsigned long long t; };
 #define PM_TICK(i) do { const unsigned long long _n = __builtin_readcyclecounter(); _pa.a[i] += _n - _pa.t; _pa.t = _n; } while (0)
 #define PM_COUNT(i, n) do { _pa.a[i] += (unsigned long long)(n); } while (0)
 #define PM_HIST(n) do { const int _n = (n); if ((threadIdx.x & 63) == 0) atomicAdd(&pm_hist[_n > 16 ? 16 : _n], 1ull); } while (0)
-#define PM_HIST2(on, n) do { const int _n = (n); if (on) atomicAdd(&pm_hist2[_n > 16 ? 16 : _n], 1ull); } while (0)
 #define PM_PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int _i = 0; _i < 16; ++_i) atomicAdd(&pm_prof[_i], _pa.a[_i]); } while (0)
 #else
 #define PM_PROF_ARG
@@ -159,7 +159,6 @@ struct PmProfAcc { unsigned long long a[16]; unsigned long long t; };
 #define PM_TICK(i) do {} while (0)
 #define PM_COUNT(i, n) do {} while (0)
 #define PM_HIST(n) do {} while (0)
-#define PM_HIST2(on, n) do {} while (0)
 #define PM_PROF_FLUSH() do {} while (0)
 #endif
 #define PM_FD2R(d) ((d) * (PM_PI_F / 180.f))

@@ -23,7 +23,7 @@
 #ifndef PM_WIDEN_MINWAVES
 #define PM_WIDEN_MINWAVES 3   // waves per SIMD the kernel is compiled for (168 VGPRs, 12-44 B of scratch; 4 has not been tried on the device)
 #endif
-template <bool GEO, int NH, bool BUF>
+template <bool GEO, int NH, bool BUF, bool TILED>
 __global__ __launch_bounds__(64, PM_WIDEN_MINWAVES) void pm_sweep_widen_kernel(const PMTask* __restrict__ tasks, PMKParams kp, PMStep st, uint32_t pass) {
 	static_assert(NH == 2 || NH == 4, "two propagation candidates need two groups; eight groups are pm_sweep_wide_kernel");
 	constexpr int G = 8, LPP = G * NH, PPW = 64 / LPP;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64, PM_WIDEN_MINWAVES) void pm_sweep_widen_kernel(c
 	for (int i = lane; i < G * NBD; i += 64) s_src[i] = ((const double*)&t.src[i / NBD])[i % NBD];
 	const double* hot = s_src + v * NBD;
 	const int w = t.w, h = t.h;
-	const PMStepPix sp = pm_step_pixel(st, w, h, (int)blockIdx.x / st.cpt, ((int)blockIdx.x % st.cpt) * PPW + p);
+	const PMStepPix sp = pm_step_pixel<TILED>(st, w, h, (int)blockIdx.x * PPW + p);
 	const bool active = sp.active;
 	const int x = sp.x, y = sp.y;                                 // a segment without a pixel takes the map's first one and never writes
 	const size_t idx = (size_t)y * w + x;
@@ -59,10 +59,10 @@ __global__ __launch_bounds__(64, PM_WIDEN_MINWAVES) void pm_sweep_widen_kernel(c
 	if (t.prior) prior = pm_glob(t.prior)[idx];
 	if (t.mask != nullptr) maskByte = t.mask[idx];
 #pragma unroll
-	for (int k = 0; k < 4; ++k) nds[k] = ((sp.oldMask >> k) & 1u) ? oDepthM[qis[k]] : gDepth[qis[k]];
+	for (int k = 0; k < 4; ++k) nds[k] = (TILED && ((sp.oldMask >> k) & 1u)) ? oDepthM[qis[k]] : gDepth[qis[k]];
 	const int slot = v & 3;                                        // my smoothness slot (both quads of a group hold all four)
 	const size_t qv = (slot == 0) ? qis[0] : (slot == 1) ? qis[1] : (slot == 2) ? qis[2] : qis[3];
-	const bool oldV = (sp.oldMask >> slot) & 1u;
+	const bool oldV = TILED && ((sp.oldMask >> slot) & 1u);
 	const float on0 = oldV ? oNormalM[qv * 3] : gNormal[qv * 3], on1 = oldV ? oNormalM[qv * 3 + 1] : gNormal[qv * 3 + 1], on2 = oldV ? oNormalM[qv * 3 + 2] : gNormal[qv * 3 + 2];
 	const float oDepth = gDepth[idx], oNx = gNormal[idx * 3], oNy = gNormal[idx * 3 + 1], oNz = gNormal[idx * 3 + 2], oConf = gConf[idx];
 	// the two propagation sources' estimates (they were updated one diagonal earlier and are not touched again before this launch ends)
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64, PM_WIDEN_MINWAVES) void pm_sweep_widen_kernel(c
 #pragma unroll
 	for (int k = 0; k < 2; ++k) {
 		const size_t q = qis[k];
-		if ((sp.oldMask >> k) & 1u) { pcf[k] = oConfM[q]; pcd[k] = oDepthM[q]; pcn[k][0] = oNormalM[q * 3]; pcn[k][1] = oNormalM[q * 3 + 1]; pcn[k][2] = oNormalM[q * 3 + 2]; }
+		if (TILED && ((sp.oldMask >> k) & 1u)) { pcf[k] = oConfM[q]; pcd[k] = oDepthM[q]; pcn[k][0] = oNormalM[q * 3]; pcn[k][1] = oNormalM[q * 3 + 1]; pcn[k][2] = oNormalM[q * 3 + 2]; }
 		else { pcf[k] = gConf[q]; pcd[k] = gDepth[q]; pcn[k][0] = gNormal[q * 3]; pcn[k][1] = gNormal[q * 3 + 1]; pcn[k][2] = gNormal[q * 3 + 2]; }
 	}
 	float normSq0, sumW;

@@ -55,7 +55,7 @@ PMHIP_ABI_VERSION = 6      # include/pmhip.h
 
 
 class PMHipTuning(C.Structure):
-    _fields_ = [("viewGroups", C.c_int32), ("wideMaxViews", C.c_int32), ("wideHyps", C.c_int32), ("sweepLanes", C.c_int32), ("quadBuffer", C.c_int32), ("widePixels", C.c_int32), ("wide8Pixels", C.c_int32), ("fatPixels", C.c_int32)]
+    _fields_ = [("viewGroups", C.c_int32), ("wideMaxViews", C.c_int32), ("wideHyps", C.c_int32), ("sweepLanes", C.c_int32), ("quadBuffer", C.c_int32), ("widePixels", C.c_int32), ("wide8Pixels", C.c_int32), ("reserved0", C.c_int32)]
 
 
 EXPORTS = ["pmhip_get_tuning", "pmhip_set_tuning", "pmhip_scene_set_view_id", "pmhip_scene_set_view_sized", "pmhip_scene_set_source_depth", "pmhip_scene_set_mask", "pmhip_scene_set_mask_mode", "pmhip_scene_set_conf", "pmhip_scene_set_color", "pmhip_scene_fuse", "pmhip_scene_fuse_get", "pmhip_scene_fuse_rounds", "pmhip_default_params", "pmhip_create", "pmhip_destroy", "pmhip_init", "pmhip_release",

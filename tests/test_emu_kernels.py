@@ -67,7 +67,7 @@ def test_estimator_group_sizes_and_geometric_pass(engine, nine_scene):
     g.test_many_source_views_parity(engine)                                   # G = 16 (9 .. 16 sources) and partial groups
 
 
-@pytest.mark.parametrize("lanes", [4, "4fat"])   # (8 lanes per pixel: device only)
+@pytest.mark.parametrize("lanes", [4])   # (8 lanes per pixel: device only)
 def test_estimator_views_per_lane(pm_emulated, nine_scene, small_scene, lanes):
     from tests import test_gpu_patchmatch as g
     g.test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes)    # (4,2), (4,1), (4,4): several source views per lane

@@ -82,18 +82,14 @@ def test_single_view_parity_N8_and_N1(engine, nine_scene):
         _same(d, od, f"depth N={nsrc}"); _same(n, on, f"normal N={nsrc}"); _same(c, oc, f"conf N={nsrc}")
 
 
-@pytest.mark.parametrize("lanes", [4, 8, "4fat"])
+@pytest.mark.parametrize("lanes", [4, 8])
 def test_views_per_lane_mappings_parity(nine_scene, small_scene, lanes):
     """The sweep kernel's work decompositions (PMHipTuning::sweepLanes): 4 lanes per pixel with 2 or 4 source views per lane (16 pixels per wavefront), or 8 lanes with 1 or 2,
     instead of one view per lane, and the mappings 8, 3-4 and 9-16 sources fall to; MINMEAN is order-free, so the maps are the same bits.  Photometric pass over the
     pyramid and a geometric round."""
     from openmvs_amd.patchmatch import PatchMatchHIP
     e = PatchMatchHIP(0)
-    if lanes == "4fat":        # every launch with two pixels per lane group resident in a wave (PMHipTuning::fatPixels: the product only does that for launches that overfill the GPU)
-        e.tuning(wideMaxViews=-1, sweepLanes=4, fatPixels=1)
-        assert e.tuning()["fatPixels"] == 1
-    else:
-        e.tuning(wideMaxViews=-1, sweepLanes=lanes, fatPixels=-1)
+    e.tuning(wideMaxViews=-1, sweepLanes=lanes)
     test_single_view_parity_N8_and_N1(e, nine_scene)                 # 8 sources: (4,2) / (8,1); 1-3 sources: a quad of lanes
     test_single_view_photometric_parity_N4(e, small_scene, 2)        # 4 sources: (4,1)
     sc = nine_scene

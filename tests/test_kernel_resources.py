@@ -14,21 +14,19 @@ def test_sweep_kernels_keep_their_residency_budget():
     # lane) mappings x photometric / geometric x quad buffer / view pointer.  Three waves per SIMD (<= 168 VGPRs; the un-pipelined rows fitted four and were 7 % slower),
     # no scratch.
     sweep2 = {k: v for k, v in r.items() if "pm_sweep2_kernel" in k}
-    assert len(sweep2) == 24
-    # (the photometric instantiations are compiled for four waves per SIMD -- 128 VGPRs; with two instantiations of the scoring part inlined, the narrow trips and the wide tail
-    # trips of pm_visit, a few dwords spill in the head and the tail of the visit -- never inside a tap-row loop: test_no_scratch_access_inside_a_tap_row_loop)
+    assert len(sweep2) == 36      # + the tiled instantiations of the quad-buffer kernels (opt-in tiled sweeps)
     for k, v in sweep2.items():
-        assert v["occupancy"] >= 3 and v["vgpr"] <= 168 and v["scratch"] <= 64 and v["agpr"] == 0, (k, v)
+        assert v["occupancy"] >= 3 and v["vgpr"] <= 168 and v["scratch"] == 0 and v["agpr"] == 0, (k, v)
         assert v["lds"] <= 11264, (k, v)
     # the instantiation the 100-view benchmark times on its photometric sweeps -- 4 lanes per pixel, 2 views per lane, quad buffer -- fits FOUR waves per SIMD (<= 128 VGPRs).
     # It is a narrow fit: a guarded-redo path with 16-byte loads cost it 9 registers, the fourth wave and 1.6 % of the photometric pass (profiles/r05_call4_ab_100.log)
-    timed = [v for k, v in sweep2.items() if "ILi4ELi2ELb0ELb1E" in k]
+    timed = [v for k, v in sweep2.items() if "ILi4ELi2ELb0ELb1ELb0E" in k]
     assert len(timed) == 1 and timed[0]["occupancy"] >= 4 and timed[0]["vgpr"] <= 128, timed
     # the speculative kernels: eight-wide (one or two views) and the two- / four-wide template (3-64 views): three waves per SIMD; the two-deep tap-row pipeline costs them
     # a few spilled dwords (measured worth it: 25 views 33.9 -> 37.5 Mpix/s, 13 views 23.6 -> 27.0; the pointer-path instantiations, which only batches with own-size
     # source views use, spill the most)
     wide = {k: v for k, v in r.items() if "pm_sweep_wide_kernel" in k or "pm_sweep_widen_kernel" in k}
-    assert len(wide) == 12
+    assert len(wide) == 16
     for k, v in wide.items():
         assert v["occupancy"] >= 3 and v["vgpr"] <= 168 and v["scratch"] <= 96 and v["lds"] <= 4096, (k, v)
     assert not any("pm_band_kernel" in k or "pm_sweep_kernel" in k for k in r)     # round 3's resident band kernel and round 2's LDS-window kernel are gone
@@ -48,7 +46,7 @@ def test_no_instruction_touches_a_tap_row_register_before_its_wait():
     assert ic.check(fake)["_Z4fakev"][1] == [fake[3].strip()]                     # (the store is a queue entry itself: vmcnt(1) then covers both loads, the later v_mov is fine)
     r = ic.check()
     buf = [k for k in r if "pm_sweep" in k]
-    assert len(buf) == 18, sorted(r)                                              # 12 pm_sweep2 (quad buffer) + 2 eight-wide + 4 two- / four-wide instantiations
+    assert len(buf) == 34, sorted(r)                                              # 24 pm_sweep2 (quad buffer; reference / tiled sweeps) + 2 eight-wide + 8 two- / four-wide instantiations
     for k, (n, bad) in r.items():
         assert n >= 15 and not bad, (k, bad[:3])
 
@@ -69,4 +67,4 @@ def test_no_scratch_access_inside_a_tap_row_loop():
             seen += 1
             bad = [ln.strip() for ln in loop if ln.strip().startswith(("scratch_load", "scratch_store"))]
             assert not bad, (im.demangle(name), bad[:3])
-    assert seen >= 18
+    assert seen >= 34

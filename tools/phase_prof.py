@@ -18,8 +18,6 @@ for rep in range(2):
     import ctypes
     hist = (ctypes.c_ulonglong * 17)()
     if hasattr(e._lib, 'pmhip_prof_hist'): e._lib.pmhip_prof_hist(e._h, hist, 1)
-    hist2 = (ctypes.c_ulonglong * 17)()
-    if hasattr(e._lib, 'pmhip_prof_hist2'): e._lib.pmhip_prof_hist2(e._h, hist2, 1)
 names = ["-", "hyp-gen", "smooth", "homography", "taps", "epilogue", "aggr+accept"]
 tot = (sum(c[1:7]) + c[12]) or 1
 print(os.environ.get("PMHIP_LIB", "default"), "views", len(ids), "of", views, "%.2f s -> %.2f Mpix/s" % (dt, len(ids) * 1920 * 1080 / dt / 1e6))
@@ -31,6 +29,3 @@ if sum(hist):
     tot_t = sum(hist)
     print("  trips of a wave-visit by pixels taking part (of 16 with 4 lanes per pixel): " + " ".join("%d:%.1f%%" % (k, 100.0 * hist[k] / tot_t) for k in range(17) if hist[k]))
     print("  trips with <= 8 pixels taking part: %.1f %%, <= 4: %.1f %%; mean pixels per trip %.2f" % (100.0 * sum(hist[:9]) / tot_t, 100.0 * sum(hist[:5]) / tot_t, sum(k * hist[k] for k in range(17)) / tot_t))
-if sum(hist2):
-    tot_p = sum(hist2)
-    print("  pixels by hypotheses scored in their visit: " + " ".join("%d:%.1f%%" % (k, 100.0 * hist2[k] / tot_p) for k in range(17) if hist2[k]) + "; mean %.2f" % (sum(k * hist2[k] for k in range(17)) / tot_p))

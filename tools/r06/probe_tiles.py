@@ -32,7 +32,6 @@ for name, kv in configs:
         e.scene_set_view(i, None, sc["K"][i], sc["R"][i], sc["C"][i], float(sc["dmin"][i]), float(sc["dmax"][i]), sc["neighbors"][i])
     e.scene_copy(0, 0, V, gray.data_ptr(), True); e.sync()
     if "groups" in kv: e.tuning(viewGroups=int(kv["groups"]))
-    if "fat" in kv: e.tuning(fatPixels=int(kv["fat"]))
     if "widepx" in kv: e.tuning(widePixels=int(kv["widepx"]))
     tw, th = int(kv.get("tw", 0)), int(kv.get("th", 0))
     if tw: e.set_sweep_tiles(tw, th)

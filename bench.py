@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--images", choices=("broadcast", "needed"), default="broadcast", help="N > 1: one broadcast of the image set (default), or rank 0 sends every rank only the views it holds")
     ap.add_argument("--no-shard-rates", action="store_true", help="skip the shard-size legs (the blocks a rank owns at 2 / 4 / 8 GPUs, timed on this GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--groups", type=int, default=0, help="PMHipTuning::viewGroups (0 = the engine's default)")
+    ap.add_argument("--lanes", type=int, default=0, help="PMHipTuning::sweepLanes (0 = the engine's default)")
     ap.add_argument("--tiles", type=int, default=0, help="OPT-IN estimator mode, not the reference's sweep: tiled sweeps with tiles of this many pixels (pmhip_set_sweep_tiles); the line says so")
     ap.add_argument("--no-tiled-leg", action="store_true", help="skip the tiled-sweeps leg (the opt-in mode's rates at the full batch and at the shard sizes)")
     return ap.parse_args()
@@ -151,6 +153,8 @@ def main():
     del gray
     eng = PatchMatchHIP(local)
     eng.Init(True)
+    if a.groups or a.lanes:
+        eng.tuning(viewGroups=a.groups, sweepLanes=a.lanes)
     if a.tiles:
         eng.set_sweep_tiles(a.tiles, a.tiles)                # OPT-IN estimator mode (the line's config says so): not the reference's sweep order
     eng.scene_create(max(2, len(held)), W, H, 2)
@@ -384,14 +388,8 @@ def tiled_legs(eng, a, V, W, H, p, rate_full, tile=64):
 def sweep_kernel_name(n_batch, n_src):
     """The sweep kernel the engine picks for a batch of n_batch reference views (pm_engine.hip: PMHIP_DEFAULT_WIDE, PMHIP_DEFAULT_WIDE_PIXELS, PMHIP_LANES4_FROM).  Larger batches
     sweep their long diagonals (launches above PMHIP_DEFAULT_WIDE_PIXELS pixels: most of the time) with pm_sweep2_kernel and the short ones with the two-wide speculative kernel."""
-    try:
-        wide_max = int(os.environ.get("PMHIP_WIDE", "32"))
-        if n_batch <= wide_max and n_src <= 8:
-            hy = os.environ.get("PMHIP_WIDE_HYPS")
-            hyps = int(hy) if hy in ("8", "4", "2") else (8 if n_batch <= 2 else 2)
-            return "pm_sweep_wide_kernel" if hyps == 8 else "pm_sweep_widen_kernel<%d>" % hyps
-    except Exception:                                              # (naming only: never a reason for the line to fail)
-        pass
+    if n_batch <= 32 and n_src <= 8:
+        return "pm_sweep_wide_kernel" if n_batch <= 2 else "pm_sweep_widen_kernel<2>"
     return "pm_sweep2_kernel"
 
 

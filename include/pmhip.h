@@ -232,8 +232,7 @@ int pmhip_stats_reset(pmhip_engine* e, int enableEvents);
 int pmhip_stats_get(pmhip_engine* e, PMHipKernelStats* out);
 
 /* How the engine maps a batch onto the GPU -- never WHAT it computes: every setting gives the same bits.  pmhip_create fills the defaults (the measured choices of
- * csrc/pm_engine.hip); 0 in a field of pmhip_set_tuning keeps the current value.  (The PMHIP_* environment variables of earlier rounds still seed the defaults at
- * pmhip_create, for experiments; a host program uses these two calls.) */
+ * csrc/pm_engine.hip); 0 in a field of pmhip_set_tuning keeps the current value.  The library reads no environment variable. */
 typedef struct PMHipTuning {
 	int32_t viewGroups;      /* view groups of a batch; each runs its whole pass (every level's hand-off, init, sweeps, finalize) on its own stream, the groups meet at the end of the call (2) */
 	int32_t wideMaxViews;    /* batches of at most this many reference views use the speculative sweep kernels for every launch (32); -1 = no speculative kernels at all (also clears widePixels / wide8Pixels unless set in the same call) */

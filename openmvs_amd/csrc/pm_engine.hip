@@ -314,14 +314,14 @@ static PMKParams makeKParams(const PMHipParams& p) {
 	return k;
 }
 
-template <bool GEO>
+template <bool GEO, int MODE>
 static void launchInit(int G, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, uint32_t pass) {
 	switch (G) {
-	case 1: hipLaunchKernelGGL((pm_init_kernel<1, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
-	case 2: hipLaunchKernelGGL((pm_init_kernel<2, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
-	case 4: hipLaunchKernelGGL((pm_init_kernel<4, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
-	case 8: hipLaunchKernelGGL((pm_init_kernel<8, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
-	default: hipLaunchKernelGGL((pm_init_kernel<16, GEO>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
+	case 1: hipLaunchKernelGGL((pm_init_kernel<1, GEO, MODE>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
+	case 2: hipLaunchKernelGGL((pm_init_kernel<2, GEO, MODE>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
+	case 4: hipLaunchKernelGGL((pm_init_kernel<4, GEO, MODE>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
+	case 8: hipLaunchKernelGGL((pm_init_kernel<8, GEO, MODE>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
+	default: hipLaunchKernelGGL((pm_init_kernel<16, GEO, MODE>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
 	}
 }
 // Lanes per pixel for a batch whose views have at most maxSrc sources: G * VPL = next_pow2(maxSrc).  `lanes` (PMHIP_LANES or the built-in
@@ -612,15 +612,16 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 			return true;
 		}
 		case 1: {
-			// pass A: ScoreDepthMapTmp.  (Row-major pixels, guarded tap rows.  The same evaluation on anti-diagonals with the sweep's optimistic quad rows was measured 9 % SLOWER --
-			// the maps are row-major, and a wave that walks a diagonal reads and writes them one cache line per lane: profiles/r04_call14_diagonal_init_kernel_stats.csv; optimistic
-			// rows from the row-major images and 128- / 256-thread workgroups changed nothing, r04_call16_*, r04_call17_*: it is latency-bound, which is why it now runs beside
-			// another group's sweeps.)
+			// pass A: ScoreDepthMapTmp, row-major pixels.  (Round 4, 24 views resident: the pass was latency-bound, and the same evaluation on anti-diagonals with the sweep's optimistic
+			// quad rows was 9 % SLOWER -- the maps are row-major, and a wave that walks a diagonal reads and writes them one cache line per lane:
+			// profiles/r04_call14_diagonal_init_kernel_stats.csv.  Round 6, 100 views resident: bound by VALU issue; row-major pixels WITH the optimistic quad rows: +0.8 %.)
 			const int PPB = PM_BLOCK / G;
 			const uint32_t passInit = (uint32_t)l * 64u + 32u + (geo ? 16u + (uint32_t)nGeometricIter : 0u);
 			const size_t ev = evBeginOn(e, 1, st);
 			const dim3 grid((unsigned)((Pl + PPB - 1) / PPB), nT);
-			if (geo) launchInit<true>(G, grid, st, dt, kp, passInit); else launchInit<false>(G, grid, st, dt, kp, passInit);
+			// (optimistic rows from the level's quad buffer; the guarded rows from the row-major images for batches that read source views outside that buffer)
+			if (buf && PM_INIT_MODE == 2) { if (geo) launchInit<true, 2>(G, grid, st, dt, kp, passInit); else launchInit<false, 2>(G, grid, st, dt, kp, passInit); }
+			else { if (geo) launchInit<true, 0>(G, grid, st, dt, kp, passInit); else launchInit<false, 0>(G, grid, st, dt, kp, passInit); }
 			evEndOn(e, ev, st);
 			if (e->statsOn && g == 0) e->stats.initLaunches += 1;
 			return true;
@@ -746,16 +747,7 @@ int pmhip_create(int device, pmhip_engine** out) {
 	pmhip_engine* e = new pmhip_engine();
 	e->device = device;
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return PMHIP_E_HIP; }
-	const char* ng = getenv("PMHIP_GROUPS");
-	e->nGroups = ng ? std::max(1, std::min(16, atoi(ng))) : PMHIP_DEFAULT_GROUPS;
-	const char* nw = getenv("PMHIP_WIDE");
-	if (nw) { e->wideMaxViews = atoi(nw); if (e->wideMaxViews <= 0) e->widePixels = e->wide8Pixels = 0; }   // PMHIP_WIDE=0: no speculative kernels at all (PMHIP_WIDE_PIXELS below may bring the per-launch rule back)
-	const char* wp = getenv("PMHIP_WIDE_PIXELS"); if (wp) e->widePixels = atoi(wp);
-	const char* w8 = getenv("PMHIP_WIDE8_PIXELS"); if (w8) e->wide8Pixels = atoi(w8);
-	const char* wh = getenv("PMHIP_WIDE_HYPS"); if (wh && (atoi(wh) == 8 || atoi(wh) == 4 || atoi(wh) == 2)) e->wideHyps = atoi(wh);
-	const char* qb = getenv("PMHIP_QUADBUF"); if (qb) e->quadBuffer = atoi(qb) != 0;
-	const char* nl = getenv("PMHIP_LANES");
-	if (nl && atoi(nl) >= 1) e->sweepLanes = atoi(nl);
+	e->nGroups = PMHIP_DEFAULT_GROUPS;   // (every mapping choice is PMHipTuning's: the library reads no environment)
 	for (int g = 0; g < e->nGroups; ++g)
 		if (hipStreamCreateWithFlags(&e->gstream[g], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->joinEv[g], hipEventDisableTiming) != hipSuccess) { delete e; return PMHIP_E_HIP; }
 	if (hipEventCreateWithFlags(&e->forkEv, hipEventDisableTiming) != hipSuccess) { delete e; return PMHIP_E_HIP; }

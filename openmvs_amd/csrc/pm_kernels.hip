@@ -701,12 +701,14 @@ __device__ __forceinline__ float pm_pow2neg(unsigned i) { return pm_u2f((127u - 
 
 // -------------------------------------------------------------------------------------------
 // ScoreDepthMapTmp, SceneDensify.cpp:490-517: fully parallel, no neighbour dependency.
-// PM_INIT_MODE: how its one evaluation per pixel reads the source images -- 0: guarded tap rows from the row-major images (four 4-byte loads per sample, IEEE divisions and the
-// image test per tap); 2: the sweep kernels' optimistic rows from the level's quad buffer (one 16-byte load per sample, 34 VALU instructions per tap instead of ~60).
+// PM_INIT_MODE: how its one evaluation per pixel reads the source images -- 2 (default): the sweep kernels' optimistic rows from the level's quad buffer (one 16-byte load per
+// sample, 34 VALU instructions per tap); 0: guarded tap rows from the row-major images (four 4-byte loads per sample, IEEE divisions and the image test per tap, ~60 per tap).
+// With 100 views resident the pass is bound by VALU issue (85 % of the SIMD cycles, profiles/r06_call1): mode 2 is +0.8 % on the benchmark (profiles/r06_call4/ab_100.log).
+// Batches that read source views of their own image size (outside the level's quad buffer) use mode 0.
 #ifndef PM_INIT_MODE
-#define PM_INIT_MODE 0
+#define PM_INIT_MODE 2
 #endif
-template <int G, bool GEO>
+template <int G, bool GEO, int MODE>
 __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restrict__ tasks, PMKParams kp, uint32_t pass) {
 	constexpr int PPB = PM_BLOCK / G;
 	__shared__ float2 s_w[PPB][PM_NT + 1];
@@ -744,8 +746,8 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 	float sc = PM_INF;
 	PM_PROF_DECL;
 	if (v < t.nSrc)
-		sc = pm_score_view<GEO, PM_INIT_MODE>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, t.src[v].Hl, (const double*)t.src[v].Tl,
-			PM_INIT_MODE == 2 ? pm_make_imgbuf(t) : PMImgBuf() PM_PROF_PASS);
+		sc = pm_score_view<GEO, MODE>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, t.src[v].Hl, (const double*)t.src[v].Tl,
+			MODE == 2 ? pm_make_imgbuf(t) : PMImgBuf() PM_PROF_PASS);
 	const float conf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
 	if (v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
 }

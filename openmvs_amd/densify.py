@@ -172,7 +172,7 @@ def _accumulate_in_order(dst_n, di, vals):
 def _resize_area_u8(img, w: int, h: int):
     """cv::resize(img, Size(w, h), 0, 0, INTER_AREA) of an 8-bit image that shrinks on both axes (Image::ResizeImage, libs/MVS/Image.cpp:139-155, reached by
     --max-resolution / nResolutionLevel).  Factor 2 (the default halving, nResolutionLevel = 1): OpenCV's ResizeAreaFastVec for integer pixels, (a + b + c + d + 2) >> 2
-    -- round half UP, in integers.  Other exact integer factors: the integer box sum times the float 1 / f^2, saturate_cast = round to nearest-even.  Any other factor: its general area path
+    -- round half UP, in integers.  Other exact integer factors (the two axes may have different ones): the integer box sum times the float 1 / (fx fy), saturate_cast = round to nearest-even.  Any other factor: its general area path
     (computeResizeAreaTab + ResizeArea_Invoker, imgproc/src/resize.cpp, restated here -- OpenCV is not vendored with the reference, so this is unpinned): per source
     row the x cells weighted in float and accumulated in table order, the rows then weighted and accumulated in float per destination row, saturate_cast<uchar> = round to
     nearest-even."""
@@ -180,13 +180,13 @@ def _resize_area_u8(img, w: int, h: int):
     H, W = img.shape[:2]
     if w > W or h > H:
         raise NotImplementedError("image resize %dx%d -> %dx%d: INTER_AREA is implemented for shrinking only (OpenCV enlarges with the bilinear path)" % (W, H, w, h))
-    if W % w == 0 and H % h == 0 and W // w == H // h:
-        f = W // w
-        s = img.reshape(h, f, w, f, -1).astype(np.int64).sum(axis=(1, 3))
-        if f == 2:
+    if W % w == 0 and H % h == 0:          # OpenCV's `is_area_fast`: both factors are integers (they may differ)
+        fx, fy = W // w, H // h
+        s = img.reshape(h, fy, w, fx, -1).astype(np.int64).sum(axis=(1, 3))
+        if fx == 2 and fy == 2:
             out = ((s + 2) >> 2).astype(np.uint8)
         else:
-            out = np.rint(s.astype(np.float32) * np.float32(1.0 / (f * f))).astype(np.uint8)
+            out = np.rint(s.astype(np.float32) * np.float32(1.0 / (fx * fy))).astype(np.uint8)
         return out if img.ndim == 3 else out[..., 0]
     src = img.reshape(H, W, -1).astype(np.float32)
     xdi, xsi, xal = _area_tab(W, w)

@@ -246,7 +246,7 @@ class EngineRank:
     gray_of(g): the gray image of global view g (asked only for the views this rank holds); K, R, C, dmin, dmax: indexable by global id."""
 
     def __init__(self, engine, params, n_views, world, rank, neighbors, gray_of, K, R, C, dmin, dmax, width, height, n_levels=2, device="cpu", batch=0,
-                 filter_args=(True, 2, 1, 0.01), init_depth=None, init_normal=None):
+                 filter_args=(True, 2, 1, 0.01), init_depth=None, init_normal=None, masks=None, mask_option=False):
         self.eng, self.p, self.W, self.H, self.batch, self.filter_args = engine, params, int(width), int(height), int(batch), tuple(filter_args)
         self.init_depth, self.init_normal = init_depth or {}, init_normal or {}       # seed maps by global view id (InitViews, SceneDensify.cpp:418-460), installed by reset()
         self.device = torch.device(device)
@@ -259,6 +259,13 @@ class EngineRank:
         for i, g in enumerate(self.held):
             engine.scene_set_view(i, gray_of(g), K[g], R[g], C[g], float(dmin[g]), float(dmax[g]), [self.slot[n] for n in nbs[g]] if i < len(self.mine) else [])
             engine.scene_set_view_id(i, g)
+        # ignore masks of a scene loaded with --ignore-mask-label (densify.load_scene), by global view id: installed for the slots this rank holds; the option alone already selects
+        # the nearest-neighbour level hand-off (SceneDensify.cpp:661) -- as PatchMatchHIP.scene_load does on one engine
+        for g, m in (masks or {}).items():
+            if int(g) in self.slot:
+                engine.scene_set_mask(self.slot[int(g)], m)
+        if mask_option:
+            engine.scene_set_mask_mode(1)
         engine.sync()
         self.buf = torch.empty((max(1, len(self.mine)), self.H, self.W), dtype=torch.float32, device=self.device)
 
@@ -344,7 +351,7 @@ def dense_reconstruction(engine, scene, opt, world: int = 1, rank: int = 0, seed
     est = EngineRank(engine, opt.params(seed), n, world, rank, nbs, lambda g: scene.gray[g], scene.K, scene.R, scene.C, scene.dmin, scene.dmax, scene.width, scene.height,
                      n_levels=int(opt.nSubResolutionLevels), device=device,
                      filter_args=(bool(opt.bFilterAdjust), int(opt.nMinViewsFilter), int(opt.nMinViewsFilterAdjust), float(opt.fDepthDiffThreshold)),
-                     init_depth=scene.init_depth, init_normal=scene.init_normal)
+                     init_depth=scene.init_depth, init_normal=scene.init_normal, masks=getattr(scene, "masks", None), mask_option=bool(getattr(scene, "mask_option", False)))
     drv = ShardedDensifier(est, n, world, rank, geo_iters=G, neighbors=nbs)
     drv.run()
     est.post_filters(drv.mine, int(opt.nOptimize), int(opt.nSpeckleSize), int(opt.nIpolGapSize), float(opt.fDepthDiffThreshold))

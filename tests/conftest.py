@@ -8,11 +8,25 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# The engine picks a speculative sweep kernel for batches of <= 32 reference views and for the short diagonals of larger ones (PMHIP_WIDE, PMHIP_WIDE_PIXELS; eight-wide for one or two views, two-wide above); nearly every test case is that small, so
-# under the product default the regular sweep kernel -- the one that carries the benchmark -- would hardly be exercised.  The suite therefore pins the
-# regular kernel, runs every case of the `engine` fixture with both choices, and tests the speculative kernels by name (test_wide_latency_mode_parity, the one-call part of test_config2_full_size_matches_golden,
-# tests/test_zz_gpu_narrow_speculation.py).
-os.environ.setdefault("PMHIP_WIDE", "0")
+# The engine picks a speculative sweep kernel for batches of <= 32 reference views and for the short diagonals of larger ones (PMHipTuning::wideMaxViews / widePixels: eight-wide for one
+# or two views, two-wide above); nearly every test case is that small, so under the product default the regular sweep kernel -- the one that carries the benchmark -- would hardly be
+# exercised.  The suite therefore pins the regular kernel on every engine a test creates through the Python bindings (pmhip_set_tuning right after pmhip_create; the library
+# reads no environment), runs every case of the `engine` fixture with both choices, and tests the speculative kernels by name (test_wide_latency_mode_parity, the one-call part of
+# test_config2_full_size_matches_golden, tests/test_zz_gpu_narrow_speculation.py).  Programs that drive the C ABI themselves (tests/cpp) run the product's own choice.
+def _pin_the_regular_sweep_kernel():
+    from openmvs_amd import patchmatch as pm
+    if getattr(pm.PatchMatchHIP, "_suite_pinned", False):
+        return
+    created = pm.PatchMatchHIP.__init__
+
+    def init(self, device=0):
+        created(self, device)
+        self.tuning(wideMaxViews=-1)
+    pm.PatchMatchHIP.__init__ = init
+    pm.PatchMatchHIP._suite_pinned = True
+
+
+_pin_the_regular_sweep_kernel()
 
 
 def pytest_configure(config):

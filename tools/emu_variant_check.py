@@ -10,11 +10,11 @@ tag = "_".join(f.replace("-D", "").replace("=", "") for f in flags) or "default"
 out = "/tmp/libpm_emu_variant_%s.so" % tag
 subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value", "-Wno-unknown-attributes",
                        "-I", os.path.join(ROOT, "tests", "cpp", "hipemu")] + flags + ["pm_engine.hip", "-o", out], cwd=os.path.join(ROOT, "openmvs_amd", "csrc"))
-os.environ["OPENMVS_AMD_TEST_EMULATOR"] = "1"; os.environ["PMHIP_LIB"] = out; os.environ.setdefault("PMHIP_WIDE", "0")
+os.environ["OPENMVS_AMD_TEST_EMULATOR"] = "1"; os.environ["PMHIP_LIB"] = out
 from openmvs_amd import patchmatch, synth
 from tests import test_gpu_patchmatch as g
 small = synth.make_scene(5, 160, 120, n_src=4); nine = synth.make_scene(9, 128, 96, n_src=8)
-e = patchmatch.PatchMatchHIP(0); e.Init(False)
+e = patchmatch.PatchMatchHIP(0); e.tuning(wideMaxViews=-1); e.Init(False)      # the regular sweep kernel (the speculative ones: tests/test_emu_kernels.py)
 g.test_single_view_parity_N8_and_N1(e, nine); print("8 / 1 / 2 / 3 sources ok", flush=True)
 g.test_single_view_photometric_parity_N4(e, small, 2); print("4 sources, pyramid ok", flush=True)
 g.test_single_call_with_ignore_mask(e, small); print("mask ok", flush=True)

@@ -1,5 +1,5 @@
 """Full schedule (photometric pass over the pyramid + 2 geometric rounds) for small batches of reference views of a 13-view 1920x1080 scene, with the
-regular sweep kernel and with the one-wave-per-pixel kernel (PMHIP_WIDE): seconds per batch and Mpix/s.  Decides PMHIP_DEFAULT_WIDE.
+regular sweep kernel and with the speculative kernels (PMHipTuning::wideMaxViews): seconds per batch and Mpix/s.  Decides PMHIP_DEFAULT_WIDE.
     python tools/small_batch_probe.py [batch sizes ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,8 +12,7 @@ sc = synth.make_scene(V, W, H, n_src=8, device="cuda", gray_only=True)
 p = default_params(seed=1)
 ref = {}
 for band, wide in (("0", "0"), ("0", "64")):
-    os.environ["PMHIP_WIDE"] = wide
-    e = PatchMatchHIP(0); e.Init(True); e.scene_load(sc, 2)
+    e = PatchMatchHIP(0); e.tuning(wideMaxViews=-1 if wide == "0" else int(wide)); e.Init(True); e.scene_load(sc, 2)
     allv = list(range(V))
     for b in sizes:
         ids = [(4 + k) % V for k in range(b)]
@@ -29,5 +28,5 @@ for band, wide in (("0", "0"), ("0", "64")):
         same = ""
         if wide == "0": ref[b] = d
         else: same = "  identical to the regular kernel: %s" % bool(np.array_equal(d, ref[b]))
-        print("PMHIP_WIDE=%-2s batch %2d views: %.3f s  -> %.2f Mpix/s%s" % (wide, b, best, b * W * H / best / 1e6, same), flush=True)
+        print("wideMaxViews=%-2s batch %2d views: %.3f s  -> %.2f Mpix/s%s" % (wide, b, best, b * W * H / best / 1e6, same), flush=True)
     e.close()

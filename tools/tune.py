@@ -1,4 +1,4 @@
-"""Run bench.py for several (library variant, PMHIP_GROUPS[, PMHIP_LANES]) settings given as lib:groups[:lanes]; prints one line each.  (tools/r04/probe_lanes.py
+"""Run bench.py for several (library variant, view groups[, lanes per pixel]) settings given as lib:groups[:lanes]; prints one line each.  (tools/r04/probe_lanes.py
 does the same inside one process, without bench.py's extra legs.)"""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,10 +7,8 @@ variants = [a.split(":") for a in sys.argv[2:]] or [["libpmhip.so", "2"]]
 for spec in variants:
     lib, groups = spec[0], spec[1]
     lanes = spec[2] if len(spec) > 2 else ""
-    env = dict(os.environ, PMHIP_LIB=os.path.join(root, "openmvs_amd", lib), PMHIP_GROUPS=groups)
-    if lanes:
-        env["PMHIP_LANES"] = lanes
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-extras", "--no-tiled-leg", "--no-shard-rates", "--views-per-gpu", views] + os.environ.get("TUNE_STEPS", "").split(), env=env, capture_output=True, text=True, timeout=400)
+    env = dict(os.environ, PMHIP_LIB=os.path.join(root, "openmvs_amd", lib))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-extras", "--no-tiled-leg", "--no-shard-rates", "--views-per-gpu", views, "--groups", groups] + (["--lanes", lanes] if lanes else []) + os.environ.get("TUNE_STEPS", "").split(), env=env, capture_output=True, text=True, timeout=400)
     try:
         j = json.loads(r.stdout.strip().splitlines()[-1])
         print("%-18s groups=%-2s lanes=%-2s views=%s  %.2f Mpix/s  step %.0f ms  avg_launch %.1f us" % (lib, groups, lanes or "-", views, j["value"], j["ms_per_step"], j["roofline"]["avg_launch_us"]), flush=True)

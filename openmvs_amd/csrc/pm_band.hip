@@ -4,6 +4,9 @@
 // measured, profiles/README.md, and is gone.)
 #pragma once
 
+#ifndef PM_NDRAW
+#define PM_NDRAW 6     // refinement iterations whose draws a visit prepares up front (nRandomIters = 6 by default; later iterations draw on the spot)
+#endif
 #ifndef PM_BAND_MINWAVES
 #define PM_BAND_MINWAVES 3
 #endif
@@ -28,6 +31,10 @@ struct PMPix {
 	float vx, vy, normSq0, sumW;
 	double X0x, X0y;
 	int x, y;
+	float x1[2];                               // InterpolatePixel's ray coordinate of the already-updated neighbour: [0] same row (x + sgn), [1] same column (y + sgn)
+	double hr[3];                              // n / ((n . X0) depth) of the hypothesis being scored: the view-independent part of ComputeHomographyMatrix
+	float dr[PM_NDRAW][3];                     // the refinement stage's draws of iteration `it`, as 2 u - 1: they depend on (x, y, it, keys) only, so the G lanes of the
+	                                           // pixel each run Philox for ANOTHER iteration at the head of the visit instead of all of them for the same one, six times
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 template <class T> __device__ __forceinline__ T* pm_launder(T* p) { asm volatile("" : "+v"(p)); return p; }
@@ -98,6 +105,17 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 			P->nb[0][0] = n0D; P->nb[0][1] = n0N0; P->nb[0][2] = n0N1; P->nb[0][3] = n0N2; P->nb[0][4] = n0C;
 			P->nb[1][0] = n1D; P->nb[1][1] = n1N0; P->nb[1][2] = n1N1; P->nb[1][3] = n1N2; P->nb[1][4] = n1C;
 		}
+		if (v < 2)   // InterpolatePixel's x1 (DepthMap.cpp:915-959): lane 0 the same-row neighbour, lane 1 the same-column one
+			P->x1[v] = v == 0 ? (float)(((double)(x + sgn) - t.cx) / t.fx) : (float)(((double)(y + sgn) - t.cy) / t.fy);
+		// the refinement draws of iterations v, v + G, ...: one Philox per lane and round instead of one per hypothesis by every lane
+		const unsigned nd = min((unsigned)PM_NDRAW, kp.nRandomIters);
+		for (unsigned it0 = 0; it0 < nd; it0 += G) {
+			const unsigned itv = it0 + (unsigned)v;
+			const PmPhilox4 r = pm_philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)(PM_STREAM_REFINE * 256) + itv, 0u, t.k0, t.k1base + pass);
+			if (itv < (unsigned)PM_NDRAW) {
+				P->dr[itv][0] = 2.f * pm_u32_to_unit(r.v[0]) - 1.f; P->dr[itv][1] = 2.f * pm_u32_to_unit(r.v[1]) - 1.f; P->dr[itv][2] = 2.f * pm_u32_to_unit(r.v[2]) - 1.f;
+			}
+		}
 	}
 	__syncthreads();
 	PM_TICK(12); PM_COUNT(9, 1);
@@ -124,19 +142,13 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 					if (pok && pconf < kp.thKeep) {
 						// InterpolatePixel, DepthMap.cpp:915-959
 						float depthNew = cd; bool zero;
-						if (vert) { // same column
-							const float nx1 = (float)(((double)py - t.cy) / t.fy);
-							const float denom = cnz + nx1 * cny;
+						// (nx1 = (float)(((double)py - cy) / fy) is the pixel's own ray coordinate vy, x1 the neighbour's: both formed at the head of the visit)
+						{
+							const float nx1 = vert ? vy : vx, cn = vert ? cny : cnx;
+							const float denom = cnz + nx1 * cn;
 							zero = pm_fabsf(denom) < 0.0001f;
-							const float x1 = (float)(((double)(py + sgn) - t.cy) / t.fy);
-							const float nom = cd * (cnz + x1 * cny);
-							if (!zero) depthNew = nom / denom;
-						} else {
-							const float nx1 = (float)(((double)px - t.cx) / t.fx);
-							const float denom = cnz + nx1 * cnx;
-							zero = pm_fabsf(denom) < 0.0001f;
-							const float x1 = (float)(((double)(px + sgn) - t.cx) / t.fx);
-							const float nom = cd * (cnz + x1 * cnx);
+							const float x1 = P->x1[vert ? 1 : 0];
+							const float nom = cd * (cnz + x1 * cn);
 							if (!zero) depthNew = nom / denom;
 						}
 						hd = (!zero && pm_in_range(depthNew, t.dMin, t.dMax)) ? depthNew : cd;
@@ -164,20 +176,28 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 					need = true; hst = ST_RAND;
 				} else { // ST_REFINE, DepthMap.cpp:832-852
 					if (it >= kp.nRandomIters) { st = ST_DONE; break; }
-					const PmPhilox4 r = pm_philox4x32_10((uint32_t)px, (uint32_t)py, (uint32_t)(PM_STREAM_REFINE * 256) + it, 0u, t.k0, k1);
+					float e0, e1, e2;
+					if (it < (unsigned)PM_NDRAW) { e0 = P->dr[it][0]; e1 = P->dr[it][1]; e2 = P->dr[it][2]; }
+					else {
+						const PmPhilox4 r = pm_philox4x32_10((uint32_t)px, (uint32_t)py, (uint32_t)(PM_STREAM_REFINE * 256) + it, 0u, t.k0, k1);
+						e0 = 2.f * pm_u32_to_unit(r.v[0]) - 1.f; e1 = 2.f * pm_u32_to_unit(r.v[1]) - 1.f; e2 = 2.f * pm_u32_to_unit(r.v[2]) - 1.f;
+					}
 					++it;
-					const float ndepth = P->depth + (depthRange * scaleRange) * (2.f * pm_u32_to_unit(r.v[0]) - 1.f);
+					const float ndepth = P->depth + (depthRange * scaleRange) * e0;
 					if (!pm_in_range(ndepth, t.dMin, t.dMax)) continue;
-					hp0 = p0 + (kp.angle1Range * scaleRange) * (2.f * pm_u32_to_unit(r.v[1]) - 1.f);
-					hp1 = p1 + (kp.angle2Range * scaleRange) * (2.f * pm_u32_to_unit(r.v[2]) - 1.f);
-					pm_dir2normal(hp0, hp1, hnx, hny, hnz);
+					hp0 = p0 + (kp.angle1Range * scaleRange) * e1;
+					hp1 = p1 + (kp.angle2Range * scaleRange) * e2;
+					pm_dir2normal_quad(hp0, hp1, v, hnx, hny, hnz);
 					if (hnx * vx + hny * vy + hnz * vz >= 0) continue;
 					hd = ndepth;
 					need = true; hst = ST_REFINE;
 				}
 			}
+			double hr0 = 0.0, hr1 = 0.0, hr2 = 0.0;
+			if (need) pm_homography_plane(P->X0x, P->X0y, hd, hnx, hny, hnz, hr0, hr1, hr2);
 			__builtin_amdgcn_wave_barrier();                     // every lane of the group has read the state before lane 0 advances it
 			if (v == 0) {
+				P->hr[0] = hr0; P->hr[1] = hr1; P->hr[2] = hr2;
 				P->st = st; P->it = (int)it; P->idxScale = (int)idxScale; P->flags = flags;
 				P->scaleRange = scaleRange; P->depthRange = depthRange; P->p0 = p0; P->p1 = p1;
 				P->hd = hd; P->hnx = hnx; P->hny = hny; P->hnz = hnz; P->hp0 = hp0; P->hp1 = hp1; P->hst = hst;
@@ -217,7 +237,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 				const int vw = v + u * G;
 				if (need && vw < t.nSrc) {
 					const float s1 = pm_score_view<GEO, BUF ? 2 : 1, true>(t.src[vw], t, kp, P->x, P->y, P->X0x, P->X0y, P->normSq0, P->sumW, s_wg, hd, hnx, hny, hnz, sf0, sf1, sf2, sf3, 0.f,
-						hotBase + vw * NBD, hotBase + vw * NBD + PM_SRC_HOT, rs PM_PROF_PASS);
+						hotBase + vw * NBD, hotBase + vw * NBD + PM_SRC_HOT, rs PM_PROF_PASS, P->hr);
 					if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
 				}
 			}

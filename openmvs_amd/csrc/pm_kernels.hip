@@ -238,6 +238,15 @@ __device__ __forceinline__ void pm_group_min2(float s, float s2, float& m1, floa
 // value of lane k (k = 0..3) of the caller's quad
 template <int K> __device__ __forceinline__ float pm_quad_bcast(float v) { return PM_DPP_F(v, K * 0x55); }
 
+// Dir2Normal by the lanes of a pixel's quad: even lanes take p0, odd lanes p1 -- one sincos per lane instead of two, the four values travel through the quad's DPP
+// network.  Every lane of the quad must call it (they share the pixel's state, so they do).
+__device__ __forceinline__ void pm_dir2normal_quad(float p0, float p1, int v, float& nx, float& ny, float& nz) {
+	float s, c;
+	pm_sincosf((v & 1) ? p1 : p0, &s, &c);
+	const float sx = pm_quad_bcast<0>(s), cx = pm_quad_bcast<0>(c), sy = pm_quad_bcast<1>(s), cy = pm_quad_bcast<1>(c);
+	nx = cx * sy; ny = sx * sy; nz = cy;
+}
+
 // ScorePixelImage for this lane's source view, DepthMap.cpp:465-564.
 // sf[]: the (view-independent) smoothness factors of the up-to-4 close neighbours, in insertion
 // order; exactly 1.f for a neighbour that does not exist or does not take part (DepthMap.cpp:524-533).
@@ -247,19 +256,26 @@ template <int K> __device__ __forceinline__ float pm_quad_bcast(float v) { retur
 // line per pixel), which is what the vector L1 / texture-address unit is bound by here.  Same values.
 // ComputeHomographyMatrix, DepthMap.h:414-423: (Hl + Hm * (n^T / (n.X0 * depth))) * Hr in double, cast to float
 // hlm: the view's Hl (9) and Hm (3), contiguous as in PMSrcView's hot block -- in HBM (init kernel) or in the wave's LDS copy (sweep kernel)
+// its view-independent part: r = n / ((n . X0) depth)
+__device__ __forceinline__ void pm_homography_plane(double X0x, double X0y, float depth, float nx, float ny, float nz, double& r0, double& r1, double& r2) {
+	const double n0 = (double)nx, n1 = (double)ny, n2 = (double)nz;
+	const double ndx = (n0 * X0x + n1 * X0y) + n2;
+	const double den = ndx * (double)depth;
+	const double inv = (den == 0.0) ? 1e+14 : 1.0 / den; // INVERT, Types.h:1234
+	r0 = n0 * inv; r1 = n1 * inv; r2 = n2 * inv;
+}
+// rpre: the plane part already formed for this hypothesis (the sweep kernel: once per trip for all of the lane's views, in LDS), or null
 __device__ __forceinline__ void pm_homography(const double* hlm, const PMTask& t, double X0x, double X0y,
-		float depth, float nx, float ny, float nz, float* H) {
+		float depth, float nx, float ny, float nz, float* H, const double* rpre = nullptr) {
 	// the twelve matrix entries are requested first, together: one round trip (overlapping the division below) instead of one per row
 	double Hl[9], Hm[3];
 #pragma unroll
 	for (int i = 0; i < 9; ++i) Hl[i] = hlm[i];
 #pragma unroll
 	for (int i = 0; i < 3; ++i) Hm[i] = hlm[9 + i];
-	const double n0 = (double)nx, n1 = (double)ny, n2 = (double)nz;
-	const double ndx = (n0 * X0x + n1 * X0y) + n2;
-	const double den = ndx * (double)depth;
-	const double inv = (den == 0.0) ? 1e+14 : 1.0 / den; // INVERT, Types.h:1234
-	const double r0 = n0 * inv, r1 = n1 * inv, r2 = n2 * inv;
+	double r0, r1, r2;
+	if (rpre) { r0 = rpre[0]; r1 = rpre[1]; r2 = rpre[2]; }
+	else pm_homography_plane(X0x, X0y, depth, nx, ny, nz, r0, r1, r2);
 #pragma unroll
 	for (int i = 0; i < 3; ++i) {
 		const double hm = Hm[i];
@@ -484,11 +500,11 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		int x, int y, double X0x, double X0y, float normSq0, float sumW, const float2* wts,
 		float depth, float nx, float ny, float nz,
 		float sf0, float sf1, float sf2, float sf3, float prior,
-		const double* hot, const double* geoTab, const PMImgBuf& rs PM_PROF_ARG)
+		const double* hot, const double* geoTab, const PMImgBuf& rs PM_PROF_ARG, const double* rpre = nullptr)
 {
 	const int sw = ((const int*)(hot + 12))[0], sh = ((const int*)(hot + 12))[1];
 	float H[9];
-	pm_homography(hot, t, X0x, X0y, depth, nx, ny, nz, H);
+	pm_homography(hot, t, X0x, X0y, depth, nx, ny, nz, H, rpre);
 	PM_TICK(3);
 	const float px = (float)(x - PM_HW), py = (float)(y - PM_HW);
 	const float X0 = H[0] * px + H[1] * py + H[2];

@@ -314,14 +314,24 @@ static PMKParams makeKParams(const PMHipParams& p) {
 	return k;
 }
 
+// nv = next_pow2(source views of the batch); a pixel gets PM_INIT_LANES lanes (fewer if it has fewer views) and a lane scores nv / lanes views.  P: pixels of the level.
+#ifndef PM_INIT_LANES
+#define PM_INIT_LANES 2   // 100 views: 4 lanes 51.8, 2 lanes 52.1, 1 lane 51.8 Mpix/s (profiles/r06_call8); one view per lane (round 5): 51.1 (r06_call7)
+#endif
+template <bool GEO, int MODE, int G, int VPL>
+static void launchInitAs(size_t P, int nT, hipStream_t s, const PMTask* t, const PMKParams& kp, uint32_t pass) {
+	constexpr int PPB = PM_BLOCK / G;
+	hipLaunchKernelGGL((pm_init_kernel<G, GEO, MODE, VPL>), dim3((unsigned)((P + PPB - 1) / PPB), nT), dim3(PM_BLOCK), 0, s, t, kp, pass);
+}
 template <bool GEO, int MODE>
-static void launchInit(int G, dim3 grid, hipStream_t s, const PMTask* t, const PMKParams& kp, uint32_t pass) {
-	switch (G) {
-	case 1: hipLaunchKernelGGL((pm_init_kernel<1, GEO, MODE>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
-	case 2: hipLaunchKernelGGL((pm_init_kernel<2, GEO, MODE>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
-	case 4: hipLaunchKernelGGL((pm_init_kernel<4, GEO, MODE>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
-	case 8: hipLaunchKernelGGL((pm_init_kernel<8, GEO, MODE>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
-	default: hipLaunchKernelGGL((pm_init_kernel<16, GEO, MODE>), grid, dim3(PM_BLOCK), 0, s, t, kp, pass); break;
+static void launchInit(int nv, size_t P, int nT, hipStream_t s, const PMTask* t, const PMKParams& kp, uint32_t pass) {
+	constexpr int L = PM_INIT_LANES;
+	switch (nv) {
+	case 1: launchInitAs<GEO, MODE, 1, 1>(P, nT, s, t, kp, pass); break;
+	case 2: launchInitAs<GEO, MODE, 2, 1>(P, nT, s, t, kp, pass); break;
+	case 4: launchInitAs<GEO, MODE, (L < 4 ? L : 4), 4 / (L < 4 ? L : 4)>(P, nT, s, t, kp, pass); break;
+	case 8: launchInitAs<GEO, MODE, L, 8 / L>(P, nT, s, t, kp, pass); break;
+	default: launchInitAs<GEO, MODE, 2 * L, 16 / (2 * L)>(P, nT, s, t, kp, pass); break;
 	}
 }
 // Lanes per pixel for a batch whose views have at most maxSrc sources: G * VPL = next_pow2(maxSrc).  `lanes` (PMHIP_LANES or the built-in
@@ -615,13 +625,11 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 			// pass A: ScoreDepthMapTmp, row-major pixels.  (Round 4, 24 views resident: the pass was latency-bound, and the same evaluation on anti-diagonals with the sweep's optimistic
 			// quad rows was 9 % SLOWER -- the maps are row-major, and a wave that walks a diagonal reads and writes them one cache line per lane:
 			// profiles/r04_call14_diagonal_init_kernel_stats.csv.  Round 6, 100 views resident: bound by VALU issue; row-major pixels WITH the optimistic quad rows: +0.8 %.)
-			const int PPB = PM_BLOCK / G;
 			const uint32_t passInit = (uint32_t)l * 64u + 32u + (geo ? 16u + (uint32_t)nGeometricIter : 0u);
 			const size_t ev = evBeginOn(e, 1, st);
-			const dim3 grid((unsigned)((Pl + PPB - 1) / PPB), nT);
 			// (optimistic rows from the level's quad buffer; the guarded rows from the row-major images for batches that read source views outside that buffer)
-			if (buf && PM_INIT_MODE == 2) { if (geo) launchInit<true, 2>(G, grid, st, dt, kp, passInit); else launchInit<false, 2>(G, grid, st, dt, kp, passInit); }
-			else { if (geo) launchInit<true, 0>(G, grid, st, dt, kp, passInit); else launchInit<false, 0>(G, grid, st, dt, kp, passInit); }
+			if (buf && PM_INIT_MODE == 2) { if (geo) launchInit<true, 2>(G, Pl, nT, st, dt, kp, passInit); else launchInit<false, 2>(G, Pl, nT, st, dt, kp, passInit); }
+			else { if (geo) launchInit<true, 0>(G, Pl, nT, st, dt, kp, passInit); else launchInit<false, 0>(G, Pl, nT, st, dt, kp, passInit); }
 			evEndOn(e, ev, st);
 			if (e->statsOn && g == 0) e->stats.initLaunches += 1;
 			return true;

@@ -724,7 +724,10 @@ __device__ __forceinline__ float pm_pow2neg(unsigned i) { return pm_u2f((127u - 
 #ifndef PM_INIT_MODE
 #define PM_INIT_MODE 2
 #endif
-template <int G, bool GEO, int MODE>
+// G lanes per pixel, VPL source views per lane (lane v scores views v, v + G, ...): what a pixel's lanes compute redundantly -- the patch sums, the draw, the plane -- is
+// 40 % of a wave's instructions with one view per lane (profiles/r06_final_pmc: 1 710 VALU instructions per wave of 8 pixels x 8 lanes), so batches with more than four
+// source views give a pixel half the lanes and each lane two views.
+template <int G, bool GEO, int MODE, int VPL = 1>
 __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restrict__ tasks, PMKParams kp, uint32_t pass) {
 	constexpr int PPB = PM_BLOCK / G;
 	__shared__ float2 s_w[PPB][PM_NT + 1];
@@ -759,12 +762,19 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_init_kernel(const PMTask* __restr
 	} else if (nx * vx + ny * vy + nz * vz >= 0) {
 		pm_random_normal(pm_u32_to_unit(r.v[1]), pm_u32_to_unit(r.v[2]), vx, vy, vz, nx, ny, nz);
 	}
-	float sc = PM_INF;
+	float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
 	PM_PROF_DECL;
-	if (v < t.nSrc)
-		sc = pm_score_view<GEO, MODE>(t.src[v], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, t.src[v].Hl, (const double*)t.src[v].Tl,
-			MODE == 2 ? pm_make_imgbuf(t) : PMImgBuf() PM_PROF_PASS);
-	const float conf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust);
+	const PMImgBuf rs = MODE == 2 ? pm_make_imgbuf(t) : PMImgBuf();
+#pragma unroll 1
+	for (int u = 0; u < VPL; ++u) {
+		const int vw = v + u * G;
+		if (vw < t.nSrc) {
+			const float s1 = pm_score_view<GEO, MODE>(t.src[vw], t, kp, x, y, X0x, X0y, normSq0, sumW, s_w[g], depth, nx, ny, nz, 1.f, 1.f, 1.f, 1.f, prior, t.src[vw].Hl, (const double*)t.src[vw].Tl,
+				rs PM_PROF_PASS);
+			if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
+		}
+	}
+	const float conf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
 	if (v == 0) { gDepth[idx] = depth; gNormal[idx * 3] = nx; gNormal[idx * 3 + 1] = ny; gNormal[idx * 3 + 2] = nz; gConf[idx] = conf; }
 }
 

@@ -116,12 +116,12 @@ struct pmhip_engine {
 	// view groups of a batch sweep on their own streams so that the tail of one group's diagonal launch
 	// overlaps the next launch of another group (views are independent; diagonals of one view are not)
 	int nGroups = 1;
-	int wideHyps = 0;                        // hypotheses per round of the speculative kernel: 0 = by batch size (8 for one or two views, else 2); PMHIP_WIDE_HYPS = 8 / 4 / 2 fixes it
+	int wideHyps = 0;                        // hypotheses per round of the speculative kernel: 0 = by batch size (8 for one or two views, else 2); PMHipTuning::wideHyps = 8 / 4 / 2 fixes it
 	int wideMaxViews = PMHIP_DEFAULT_WIDE;   // batches of at most this many views use the one-wave-per-pixel sweep kernel (PMHIP_WIDE)
 	int widePixels = PMHIP_DEFAULT_WIDE_PIXELS;     // in larger batches: a diagonal launch of at most this many pixels (diagonal length x views of the group) uses the two-wide speculative kernel (PMHIP_WIDE_PIXELS)
 	int wide8Pixels = PMHIP_DEFAULT_WIDE8_PIXELS;   // ... and one of at most this many pixels the eight-wide one (PMHIP_WIDE8_PIXELS)
 	int sweepLanes = PMHIP_DEFAULT_LANES;   // lanes per pixel of the sweep kernel (PMHIP_LANES); the rest of a view's sources go to views-per-lane
-	int quadBuffer = 1;                     // tap rows address the level's quad images as one buffer (entry index); 0 = through each view's own pointer (PMHIP_QUADBUF; forced for
+	int quadBuffer = 1;                     // tap rows address the level's quad images as one buffer (entry index); 0 = through each view's own pointer (PMHipTuning::quadBuffer; forced for
 	                                        // batches that read a source view with its own image size, which lives outside the level's buffer)
 	hipStream_t gstream[16] = {};
 	hipEvent_t forkEv = nullptr, joinEv[16] = {};
@@ -334,7 +334,7 @@ static void launchInit(int nv, size_t P, int nT, hipStream_t s, const PMTask* t,
 	default: launchInitAs<GEO, MODE, 2 * L, 16 / (2 * L)>(P, nT, s, t, kp, pass); break;
 	}
 }
-// Lanes per pixel for a batch whose views have at most maxSrc sources: G * VPL = next_pow2(maxSrc).  `lanes` (PMHIP_LANES or the built-in
+// Lanes per pixel for a batch whose views have at most maxSrc sources: G * VPL = next_pow2(maxSrc).  `lanes` (PMHipTuning::sweepLanes or the built-in
 // default) caps G; VPL is what is left, limited to the instantiated mappings.
 static void sweepMapping(int maxSrc, int lanes, int& G, int& VPL) {
 	int NV = 1; while (NV < maxSrc) NV <<= 1;
@@ -373,7 +373,7 @@ static void launchSweepWide(int nTasks, hipStream_t s, const PMTask* t, const PM
 	if (count <= 0) return;
 	hipLaunchKernelGGL((pm_sweep_wide_kernel<GEO, BUF>), dim3((unsigned)count, (unsigned)nTasks), dim3(64), 0, s, t, kp, st.dir, d, xlo, count, pass);
 }
-// the speculative kernel at 4 or 2 hypotheses per round (pm_wide_n.hip; PMHIP_WIDE_HYPS): 2 or 4 pixels per wave
+// the speculative kernel at 4 or 2 hypotheses per round (pm_wide_n.hip; PMHipTuning::wideHyps): 2 or 4 pixels per wave
 template <bool GEO, bool BUF>
 static void launchSweepWideN(int hyps, int nTasks, hipStream_t s, const PMTask* t, const PMKParams& kp, PMStep st, uint32_t pass) {
 	const dim3 grid(stepBlocks(st, 8 / hyps), (unsigned)nTasks);

@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--with-filter", action="store_true", help="append the cross-view depth-map filter (config 5's exchange) to every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config2 / parity / sgm blocks")
-    ap.add_argument("--images", choices=("broadcast", "needed"), default="broadcast", help="N > 1: one broadcast of the image set (default), or rank 0 sends every rank only the views it holds")
+    ap.add_argument("--images", choices=("auto", "broadcast", "needed"), default="auto", help="N > 1: one broadcast of the image set, or rank 0 sends every rank only the views it holds (block + the foreign views it reads); auto = needed when every rank holds less than half of the scene")
     ap.add_argument("--no-shard-rates", action="store_true", help="skip the shard-size legs (the blocks a rank owns at 2 / 4 / 8 GPUs, timed on this GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
     ap.add_argument("--groups", type=int, default=0, help="PMHipTuning::viewGroups (0 = the engine's default)")
@@ -126,7 +126,11 @@ def main():
     # images: ONE broadcast of the whole set over xGMI (north_star; the default), every rank then keeps its block + closure; or, `--images needed`, rank 0 sends every rank
     # just the views it holds, point to point -- what a scene too large to pass through every GPU (or a closure much smaller than the scene, BASELINE config 5) wants
     images_how = "one broadcast of the image set"
-    if dist_on and a.images == "needed" and world > 1:
+    images = a.images
+    if images == "auto":                                    # every rank derives the same answer from the neighbour lists
+        most = max(len(set(needed_views(nbr_lists, V, world, r)[0]) | set(needed_views(nbr_lists, V, world, r)[1])) for r in range(world))
+        images = "needed" if 2 * most < V else "broadcast"
+    if dist_on and images == "needed" and world > 1:
         images_how = "point to point from rank 0: each rank receives the %d views it holds" % len(held)
         staged = backend != "nccl"                          # (gloo has no point-to-point for device tensors: through the host then)
         if rank == 0:

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -242,22 +243,37 @@ class EngineRank:
     whole scene (`scene_set_view_id`), which makes the depth maps independent of the split.  Maps travel as tensors on `device`, handed to the engine by pointer
     (`scene_copy`): device memory under RCCL, host memory when the engine is the CPU emulator of the tests.  bench.py's adapter is these same calls, inlined (and timed).
 
-    engine: a `PatchMatchHIP`; params: `PMHipParams`; neighbors: per view of the WHOLE scene, the global ids of its source views;
-    gray_of(g): the gray image of global view g (asked only for the views this rank holds); K, R, C, dmin, dmax: indexable by global id."""
+    engine: a `PatchMatchHIP`; params: `PMHipParams`; neighbors: per view of the WHOLE scene, the global ids of its source views (the images themselves);
+    gray_of(g): the gray image of global view g (asked only for the views this rank holds); K, R, C, dmin, dmax: indexable by global id.
+
+    Views of different sizes: sizes[g] = (w, h) of every slot id (a view whose size is not the scene's carries its own: pmhip_scene_set_view_sized); the maps of such a block
+    travel as lists of [h_v, w_v] tensors (`view_shapes`).  Resampled neighbour copies (ViewData::ScaleImage, densify.load_scene): alias_of = {copy id >= n_views: image id} and
+    estimate_neighbors = the lists the estimation reads (a copy in place of its image); a rank holds the copies its block reads as source-only slots behind the foreign
+    views, hands each one the depth map of the image it stands for at every round boundary (with that image's camera, the neighbour's saved .dmap of SceneDensify.cpp:378-393)
+    and gives its reference views their image neighbours back before the cross-view filter -- what densify.compute_depth_maps does on one engine."""
 
     def __init__(self, engine, params, n_views, world, rank, neighbors, gray_of, K, R, C, dmin, dmax, width, height, n_levels=2, device="cpu", batch=0,
-                 filter_args=(True, 2, 1, 0.01), init_depth=None, init_normal=None, masks=None, mask_option=False):
+                 filter_args=(True, 2, 1, 0.01), init_depth=None, init_normal=None, masks=None, mask_option=False, sizes=None, alias_of=None, estimate_neighbors=None):
         self.eng, self.p, self.W, self.H, self.batch, self.filter_args = engine, params, int(width), int(height), int(batch), tuple(filter_args)
         self.init_depth, self.init_normal = init_depth or {}, init_normal or {}       # seed maps by global view id (InitViews, SceneDensify.cpp:418-460), installed by reset()
         self.device = torch.device(device)
         nbs = [[int(x) for x in neighbors[v]] for v in range(n_views)]
+        self.alias_of = {int(a): int(j) for a, j in (alias_of or {}).items()}
+        est = [[int(x) for x in (estimate_neighbors[v] if estimate_neighbors is not None else nbs[v])] for v in range(n_views)]
         self.mine, self.foreign = needed_views(nbs, n_views, world, rank)
-        self.held = self.mine + self.foreign                    # global view ids in slot order
+        self.copies = sorted({a for v in self.mine for a in est[v] if a in self.alias_of})     # the resampled copies this block reads
+        self.held = self.mine + self.foreign + self.copies      # global ids in slot order
         self.slot = {g: i for i, g in enumerate(self.held)}
+        self.K, self.R, self.C, self.dmin, self.dmax, self.nbs, self.est = K, R, C, dmin, dmax, nbs, est
+        size_of = (lambda g: (int(sizes[g][0]), int(sizes[g][1]))) if sizes is not None else (lambda g: (self.W, self.H))
+        self.shape = {g: size_of(g)[::-1] for g in self.held}                                  # (h, w) of a held view's maps
+        self.mixed = any(size_of(g) != (self.W, self.H) for g in range(n_views))               # some image has its own size: every rank's maps travel view by view (one protocol for all ranks)
         engine.Init(True)
         engine.scene_create(max(2, len(self.held)), self.W, self.H, n_levels)
         for i, g in enumerate(self.held):
-            engine.scene_set_view(i, gray_of(g), K[g], R[g], C[g], float(dmin[g]), float(dmax[g]), [self.slot[n] for n in nbs[g]] if i < len(self.mine) else [])
+            own_size = self.shape[g] != (self.H, self.W)
+            (engine.scene_set_view_sized if own_size else engine.scene_set_view)(i, gray_of(g), K[g], R[g], C[g], float(dmin[g]), float(dmax[g]),
+                                                                                [self.slot[n] for n in est[g]] if i < len(self.mine) else [])
             engine.scene_set_view_id(i, g)
         # ignore masks of a scene loaded with --ignore-mask-label (densify.load_scene), by global view id: installed for the slots this rank holds; the option alone already selects
         # the nearest-neighbour level hand-off (SceneDensify.cpp:661) -- as PatchMatchHIP.scene_load does on one engine
@@ -296,6 +312,15 @@ class EngineRank:
     def local_maps(self, ids, what):
         if list(ids) != self.mine:
             raise ValueError("a rank hands out the maps of its own block")
+        if self.mixed:                                          # views of different sizes: one tensor per view
+            kind = {"depth": 1, "normal": 2, "conf": 3}[what]
+            out = []
+            for i, g in enumerate(self.mine):
+                t = torch.empty(self.shape[g] + ((3,) if what == "normal" else ()), dtype=torch.float32, device=self.device)
+                self.eng.scene_copy(kind, i, 1, t.data_ptr(), False)
+                out.append(t)
+            self.eng.sync()
+            return out
         if what == "normal":                                    # (only the fusing rank ever asks: its own buffer)
             buf = torch.empty((len(self.mine), self.H, self.W, 3), dtype=torch.float32, device=self.device)
         else:
@@ -315,6 +340,10 @@ class EngineRank:
         self._fence()
         for k, g in enumerate(foreign_ids):
             self.eng.scene_copy(4, self.slot[g], 1, foreign_maps[k].data_ptr(), True)
+        for a in self.copies:                                   # a resampled copy reads the depth map of the image it stands for, at that image's size and camera
+            j = self.alias_of[a]
+            d = own[list(own_ids).index(j)] if j in self.slot and self.slot[j] < len(self.mine) else foreign_maps[list(foreign_ids).index(j)]
+            self.eng.scene_set_source_depth(self.slot[a], d.cpu().numpy(), self.K[j], self.R[j], self.C[j])
         self.eng.sync()                                         # the received tensor may be released by the caller
 
     def set_maps_views(self, what, foreign_ids, foreign_maps):
@@ -324,6 +353,9 @@ class EngineRank:
         self.eng.sync()
 
     def filter(self, ids):
+        for v in ids:                                           # FilterDepthMap reads the images themselves (arrDepthData[ID], SceneDensify.cpp:1049-1299), not their resampled copies
+            if self.est[v] != self.nbs[v]:
+                self.eng.scene_set_view(self.slot[v], None, self.K[v], self.R[v], self.C[v], float(self.dmin[v]), float(self.dmax[v]), [self.slot[n] for n in self.nbs[v]])
         if len(ids):
             b_adjust, n_min, n_min_adjust, f_depth = self.filter_args
             self.eng.scene_filter([self.slot[v] for v in ids], b_adjust, n_min, n_min_adjust, f_depth, commit=True)
@@ -339,30 +371,41 @@ def dense_reconstruction(engine, scene, opt, world: int = 1, rank: int = 0, seed
     neighbours' unfiltered maps; the fusing rank `root` then collects depth, normal and confidence maps view by view and fuses them (FuseDepthMaps is sequential over the
     scene, :1372-1650).  Same maps and the same cloud as `densify.dense_reconstruction` on one engine, whatever the split.
 
-    scene: a `densify.SceneViews` (every rank runs `densify.load_scene` on the same archive; a rank's engine is handed only the images it holds) whose views share one size
-    and need no resampled copies; opt: an `optdense.OptDense`; fuse_engine: the engine `root` fuses on (default: `engine`, whose compact scene is replaced by the whole one).
-    Returns the cloud on `root`, None elsewhere."""
+    scene: a `densify.SceneViews` (every rank runs `densify.load_scene` on the same archive; a rank's engine is handed only the images it holds); its views may differ in size
+    and read resampled copies of their neighbours (`alias_of`, ViewData::ScaleImage); opt: an `optdense.OptDense`; fuse_engine: the engine `root` fuses on (default:
+    `engine`, whose compact scene is replaced by the whole one).  Returns the cloud on `root`, None elsewhere."""
     from . import densify
-    n = len(scene.gray)
-    if getattr(scene, "alias_of", None) or len(set(map(tuple, scene.sizes))) > 1 or list(scene.ids) != list(range(n)):
-        raise NotImplementedError("the sharded driver takes scenes whose views share one size, need no resampled neighbour copies and all passed view selection")
+    alias_of = dict(getattr(scene, "alias_of", None) or {})
+    n = len(scene.gray) - len(alias_of)                                         # the images; the resampled copies follow them as source-only slots
+    if list(scene.ids) != list(range(n)):
+        raise NotImplementedError("the sharded driver takes scenes all of whose views passed view selection")
     nbs = [[int(x) for x in scene.neighbors[v]] for v in range(n)]
+    sizes = [tuple(wh) for wh in scene.sizes] if getattr(scene, "sizes", None) else None
+    mixed = sizes is not None and len(set(sizes[:n])) > 1
     G = int(opt.nEstimationGeometricIters)
     est = EngineRank(engine, opt.params(seed), n, world, rank, nbs, lambda g: scene.gray[g], scene.K, scene.R, scene.C, scene.dmin, scene.dmax, scene.width, scene.height,
                      n_levels=int(opt.nSubResolutionLevels), device=device,
                      filter_args=(bool(opt.bFilterAdjust), int(opt.nMinViewsFilter), int(opt.nMinViewsFilterAdjust), float(opt.fDepthDiffThreshold)),
-                     init_depth=scene.init_depth, init_normal=scene.init_normal, masks=getattr(scene, "masks", None), mask_option=bool(getattr(scene, "mask_option", False)))
-    drv = ShardedDensifier(est, n, world, rank, geo_iters=G, neighbors=nbs)
+                     init_depth=scene.init_depth, init_normal=scene.init_normal, masks=getattr(scene, "masks", None), mask_option=bool(getattr(scene, "mask_option", False)),
+                     sizes=sizes, alias_of=alias_of, estimate_neighbors=getattr(scene, "estimate_neighbors", None) if alias_of else None)
+    shapes = [tuple(sizes[v])[::-1] for v in range(n)] if mixed else None         # (h, w) of every image's maps: known on every rank, like the cameras
+    drv = ShardedDensifier(est, n, world, rank, geo_iters=G, neighbors=nbs, view_shapes=shapes)
     drv.run()
     est.post_filters(drv.mine, int(opt.nOptimize), int(opt.nSpeckleSize), int(opt.nIpolGapSize), float(opt.fDepthDiffThreshold))
     if int(opt.nOptimize) & densify.ADJUST_FILTER:
         drv.filter()
-    maps = {w: gather_views_to_root(est.local_maps(est.mine, w).clone(), n, world, rank, root) for w in ("depth", "normal", "conf")}
+
+    def own(w):
+        m = est.local_maps(est.mine, w)
+        return [t.clone() for t in m] if isinstance(m, (list, tuple)) else m.clone()
+    maps = {w: gather_views_to_root(own(w), n, world, rank, root, [s + (3,) for s in shapes] if (shapes and w == "normal") else shapes) for w in ("depth", "normal", "conf")}
     if rank != root:
         return None
     fe = fuse_engine or engine
     fe.scene_load(scene, n_levels=int(opt.nSubResolutionLevels))
     for v in range(n):
+        if alias_of and not np.array_equal(scene.estimate_neighbors[v], scene.neighbors[v]):     # fusion reads the images themselves, as the filter did
+            fe.scene_set_view(v, None, scene.K[v], scene.R[v], scene.C[v], float(scene.dmin[v]), float(scene.dmax[v]), scene.neighbors[v])
         fe.scene_set_maps(v, maps["depth"][v].cpu().numpy(), maps["normal"][v].cpu().numpy())
         fe.scene_set_conf(v, maps["conf"][v].cpu().numpy())
     return densify.fuse_depth_maps(fe, scene, opt, bgr=scene.bgr)

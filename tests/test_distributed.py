@@ -349,3 +349,55 @@ def test_dense_reconstruction_over_ranks_matches_one_engine(tmp_path):
         got = np.load(out / "cloud.npz")
         for k in ("points", "viewStart", "views", "weights", "projs", "colors", "normals"):
             assert np.array_equal(got[k], want[k]), (world, k)
+
+
+# ---- the same over a scene whose images differ in size and read resampled copies of their neighbours (ViewData::ScaleImage) --------------------------------
+def _mixed_loader(p):
+    """The pipeline-test scene with its third image cut to 3/4 of the size of the others: the footprints then differ by the resolution ratio and the reference's rule
+    (SceneDensify.cpp:306-345) makes the other images read it enlarged and it read them reduced."""
+    from PIL import Image
+    with Image.open(p) as im:
+        rgb = np.asarray(im.convert("RGB"))
+    names = sorted(os.listdir(os.path.dirname(p)))
+    if os.path.basename(p) == [n for n in names if n.lower().endswith((".jpg", ".png"))][2]:
+        h, w = rgb.shape[:2]
+        return np.ascontiguousarray(rgb[:h * 3 // 4, :w * 3 // 4])
+    return rgb
+
+
+def _sized_recon_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    from openmvs_amd import densify, patchmatch
+    from openmvs_amd import distributed as D
+    from tests import emu
+    with emu.emulated(patchmatch, "PMHIP_LIB", "libpmhip_emu.so"):
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        opt = _recon_opt()
+        sv = densify.load_scene(_REAL, opt=opt, image_loader=_mixed_loader)
+        eng = patchmatch.PatchMatchHIP(0)
+        cloud = D.dense_reconstruction(eng, sv, opt, world, rank, seed=3)
+        assert (cloud is None) == (rank != 0)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "cloud.npz"), **{k: v for k, v in cloud.items() if isinstance(v, np.ndarray)})
+        eng.close()
+        dist.destroy_process_group()
+
+
+def test_dense_reconstruction_over_ranks_with_sizes_and_copies(tmp_path):
+    """distributed.dense_reconstruction on a scene with images of two sizes, whose views read resampled copies of their neighbours: 2 gloo ranks of the emulated engine --
+    maps exchanged view by view, a rank's copies fed the depth map of the image they stand for at every round boundary, image neighbours back for filter and fusion --
+    give the cloud of densify.dense_reconstruction on one engine."""
+    from openmvs_amd import densify, patchmatch
+    from tests import emu
+    with emu.emulated(patchmatch, "PMHIP_LIB", "libpmhip_emu.so"):
+        eng = patchmatch.PatchMatchHIP(0)
+        sv, want = densify.dense_reconstruction(eng, _REAL, None, _recon_opt(), seed=3, image_loader=_mixed_loader)
+        eng.close()
+    assert sv.alias_of and len(set(sv.sizes[:4])) == 2 and want["nPoints"] > 50
+    out = tmp_path / "w2"; out.mkdir()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mp.spawn(_sized_recon_worker, args=(2, port, str(out)), nprocs=2, join=True)
+    got = np.load(out / "cloud.npz")
+    for k in ("points", "viewStart", "views", "weights", "projs", "colors", "normals"):
+        assert np.array_equal(got[k], want[k]), k

@@ -37,8 +37,13 @@ struct PMPix {
 	                                           // pixel each run Philox for ANOTHER iteration at the head of the visit instead of all of them for the same one, six times
 };
 #if defined(__HIP_DEVICE_COMPILE__)
-template <class T> __device__ __forceinline__ T* pm_launder(T* p) { asm volatile("" : "+v"(p)); return p; }
+// The state lives in LDS and the pointer says so (address space 3): laundered as a GENERIC pointer -- what it was until round 6 -- every access became a flat_load / flat_store,
+// i.e. a vector-memory instruction that takes its turn in the texture-address unit next to the tap rows' gathers, which is the unit that bounds the kernel:
+// ~190 of a visit's 625 vector-memory reads were reads of this struct.
+#define PM_LDS __attribute__((address_space(3)))
+template <class T> __device__ __forceinline__ PM_LDS T* pm_launder(T* p) { PM_LDS T* q = (PM_LDS T*)p; asm volatile("" : "+v"(q)); return q; }
 #else
+#define PM_LDS
 template <class T> __device__ __forceinline__ T* pm_launder(T* p) { return p; }
 #endif
 enum { PMF_SMOOTH = 1, PMF_CHANGED = 2, PMF_POK0 = 4, PMF_POK1 = 8 };
@@ -79,7 +84,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 	if (v == 0) s_wg[PM_NT] = make_float2(prior, prior > 0 ? pm_expf(normSq0 * (-1.f / (1.f * 0.02f))) : 0.f);
 	// ---- the visit's state goes to LDS: current estimate, neighbours, close-neighbour slots (lane `slot` of the first quad writes slot `slot`) ----
 	{
-		PMPix* P = pm_launder(s_pixg);
+		PM_LDS PMPix* P = pm_launder(s_pixg);
 		const bool bk = slot == 0 ? bok[0] : slot == 1 ? bok[1] : slot == 2 ? bok[2] : bok[3];
 		const bool okS = valid && bk && myD > 0;
 		const unsigned long long bal = __ballot(okS);   // (ballot of the whole wave; my pixel's four bits -- its lanes v = 0..3 -- are picked here)
@@ -126,7 +131,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 		bool need = false;
 		float hd = 0.f, hnx = 0.f, hny = 0.f, hnz = 1.f;
 		{	// -- next hypothesis of my pixel (every lane of the group computes the same; lane 0 records it)
-			PMPix* P = pm_launder(s_pixg);
+			PM_LDS PMPix* P = pm_launder(s_pixg);
 			int st = P->st; unsigned it = (unsigned)P->it, idxScale = (unsigned)P->idxScale; int flags = P->flags;
 			const int px = P->x, py = P->y;
 			const float vx = P->vx, vy = P->vy, vz = 1.f;
@@ -136,7 +141,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 				if (st <= ST_PROP1) {
 					const bool vert = (st == ST_PROP1); ++st; // slot 0: same row, slot 1: same column
 					const bool pok = (flags & (vert ? PMF_POK1 : PMF_POK0)) != 0;
-					const float* nbp = P->nb[vert ? 1 : 0];
+					const PM_LDS float* nbp = P->nb[vert ? 1 : 0];
 					const float cd = nbp[0], cnx = nbp[1], cny = nbp[2], cnz = nbp[3], pconf = nbp[4];
 					hd = cd; hnx = cnx; hny = cny; hnz = cnz;
 					if (pok && pconf < kp.thKeep) {
@@ -209,7 +214,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 		// -- smoothness factors of the hypothesis plane w.r.t. the close neighbours, DepthMap.cpp:524-533, one neighbour per lane
 		float sf0, sf1, sf2, sf3;
 		{
-			const PMPix* P = pm_launder(s_pixg);
+			const PM_LDS PMPix* P = pm_launder(s_pixg);
 			const int flags = P->flags;
 			const bool on = need && (flags & PMF_SMOOTH) && ((flags >> (8 + slot)) & 1);
 			float myF = 1.f;
@@ -231,20 +236,20 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 		// -- score against my source view(s)
 		float sc = PM_INF, sc2 = PM_INF;   // the lane's two smallest view scores
 		{
-			const PMPix* P = pm_launder(s_pixg);
+			const PM_LDS PMPix* P = pm_launder(s_pixg);
 #pragma unroll 1
 			for (int u = 0; u < VPL; ++u) {
 				const int vw = v + u * G;
 				if (need && vw < t.nSrc) {
 					const float s1 = pm_score_view<GEO, BUF ? 2 : 1, true>(t.src[vw], t, kp, P->x, P->y, P->X0x, P->X0y, P->normSq0, P->sumW, s_wg, hd, hnx, hny, hnz, sf0, sf1, sf2, sf3, 0.f,
-						hotBase + vw * NBD, hotBase + vw * NBD + PM_SRC_HOT, rs PM_PROF_PASS, P->hr);
+						hotBase + vw * NBD, hotBase + vw * NBD + PM_SRC_HOT, rs PM_PROF_PASS, (const double*)P->hr);
 					if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
 				}
 			}
 		}
 		const float nconf = pm_aggregate<G>(sc, t.nSrc, kp.thRobust, sc2);
 		{	// -- accept (DepthMap.cpp:794-799, :784-793, :843-851)
-			PMPix* P = pm_launder(s_pixg);
+			PM_LDS PMPix* P = pm_launder(s_pixg);
 			if (need && v == 0 && P->conf > nconf) {
 				P->conf = nconf; P->depth = P->hd; P->nx = P->hnx; P->ny = P->hny; P->nz = P->hnz;
 				int flags = P->flags | PMF_CHANGED;
@@ -258,7 +263,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 		PM_TICK(6);
 	}
 	{
-		const PMPix* P = pm_launder(s_pixg);
+		const PM_LDS PMPix* P = pm_launder(s_pixg);
 		wr = (P->flags & PMF_CHANGED) && valid;
 		rD = wr ? P->depth : oDepth; rN0 = wr ? P->nx : oNx; rN1 = wr ? P->ny : oNy; rN2 = wr ? P->nz : oNz; rC = wr ? P->conf : oConf;
 	}

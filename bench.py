@@ -284,6 +284,8 @@ def main():
         kern = sweep_kernel_name(B if B else len(mine), N)
         same_cfg = world == 1 and V == 100 and (W, H, N) == (1920, 1080, 8) and B == V and a.geo_iters == 2    # the configuration the counters were taken on
         issue = valu_issue_fields(wall_s, a.steps, st.sweepPixels) if same_cfg else {}
+        if same_cfg:
+            issue.update(gather_issue_fields(wall_s, a.steps))
         tf = traffic_fields(per_launch) if same_cfg else {"traffic": None, "traffic_note": "counters exist for the 100-view 1920x1080 one-GPU configuration only"}
         if "fabric_bytes_per_step" in tf.get("traffic_measurement", {}):   # the fabric-side rate of THIS run: counter bytes of a step / this run's wall time of the passes per step
             tf["traffic_measurement"]["fabric_rate_gbs_this_run"] = round(tf["traffic_measurement"]["fabric_bytes_per_step"] * a.steps / 1e9 / max(wall_s, 1e-12), 1)
@@ -467,6 +469,22 @@ def valu_issue_fields(sweep_wall_s, steps, sweep_pixels=0, simds=1024, clock_hz=
                            "per_kernel": {k: {q: f[q] for q in ("frac_active_valu", "frac_wait_inst_any", "valu_insts_per_wave", "waves_per_launch") if q in f} for k, f in t.get("families", {}).items()},
                            "note": "share of all SIMD cycles of the passes in which a VALU instruction of a sweep kernel executes (SQ counters of every sweep launch of one step of this "
                                    "configuration, offline; wall time of this run; 2.4 GHz): the bound the kernels approach is the issue of the reference's un-fusable fp32 arithmetic, not HBM"}}
+
+
+def gather_issue_fields(sweep_wall_s, steps, cus=256, clock_hz=2.4e9):
+    """The unit the sweeps run into: a CU's texture-address unit takes one scattered wave-load per 64.5 cycles whatever its width (tools/probes/l1_gather.hip), and a
+    tap of the estimator is one such wave-load.  achieved = vector-memory wave-loads of one step (SQ_INSTS_VMEM_RD of every sweep launch, offline counters on this configuration)
+    per second of THIS run's passes; peak = 256 units x 2.4 GHz / 64.5.  Empty without counters of this tree's kernels."""
+    t = _counters()
+    if t is None or "gather" not in t or not t["gather"].get("vmem_rd_wave_loads_per_step"):
+        return {}
+    g = t["gather"]
+    peak = cus * clock_hz / g["cycles_per_scattered_wave_load"]
+    ach = g["vmem_rd_wave_loads_per_step"] * steps / max(sweep_wall_s, 1e-12)
+    return {"gather_issue": {"bound": "vector-L1 texture-address units: scattered wave-loads", "achieved": round(ach / 1e9, 3), "peak": round(peak / 1e9, 3), "unit": "G wave-loads/s",
+                             "frac": round(ach / peak, 4), "wave_loads_per_wave_visit": g["vmem_rd_wave_loads_per_wave_visit"], "ta_busy_frac_counters": g.get("ta_busy_frac_of_the_slice"),
+                             "note": "every vector-memory read of the sweep kernels priced as a scattered wave-load (the tap rows' 16-byte gathers are ~93 % of them; the rest "
+                                     "coalesce and cost less, so frac is an upper estimate of the unit's load); ta_busy_frac_counters = TA_TA_BUSY over the slice's cycles, all 256 units"}}
 
 
 def usable_cores() -> int:

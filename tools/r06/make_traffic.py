@@ -46,7 +46,7 @@ def fam(tab, family, counter=None):
     return sum(v.get(counter, 0.0) for v in rows)
 
 
-T = {m: {g: table("%s_%s" % (g, m)) for g in ("fetch", "write", "sq1", "sq2", "tcc", "tcp", "grbm")} for m in ("photo", "geo")}
+T = {m: {g: table("%s_%s" % (g, m)) for g in ("fetch", "write", "sq1", "sq2", "tcc", "tcp", "grbm", "ta1", "ta2")} for m in ("photo", "geo")}
 runs = [json.loads(l) for l in open(os.path.join(d, "slice_unprofiled.jsonl")) if l.strip().startswith("{")]
 res = {"source": "rocprofv3 --pmc, one counter group per pass, over a slice of the benchmark through tools/pmc/pmc_slice.cpp: 100 views 1920x1080 resident with the benchmark's maps, one "
                  "level-0 sweep of the photometric and one of the geometric kernels, one view group (tools/r06/final.sh); per-step figures = photo x 3 x (1 + 1/4 + 1/16) + geo x 2",
@@ -78,8 +78,24 @@ for f in FAMILIES:
         acc, l1miss = fam(t["tcp"], f, "TCP_TOTAL_CACHE_ACCESSES_sum"), fam(t["tcp"], f, "TCP_TCC_READ_REQ_sum")
         if acc:
             r["l1_hit_rate"] = round(1.0 - l1miss / acc, 4)
+        # the texture-address unit (one per CU): busy cycles of all 256 over the cycles the kernels ran, and what it was busy with.  A wave-load whose lanes are scattered
+        # costs it 64 cycles whatever the width (tools/probes/l1_gather.hip, profiles/r06_call10): the tap rows' 16-byte gathers are that case.
+        ta_busy, ta_waves = fam(t["ta1"], f, "TA_TA_BUSY_sum"), fam(t["ta1"], f, "TA_TOTAL_WAVEFRONTS_sum")
+        gui = fam(t["grbm"], f, "GRBM_GUI_ACTIVE")
+        if ta_busy and gui:
+            r.update({"ta_busy_frac": round(ta_busy / (256 * gui / 8), 4), "ta_wavefronts_per_wave": round(ta_waves / max(1.0, waves), 1),
+                      "ta_buffer_wavefronts_per_wave": round(fam(t["ta1"], f, "TA_BUFFER_WAVEFRONTS_sum") / max(1.0, waves), 1),
+                      "ta_flat_wavefronts_per_wave": round(fam(t["ta1"], f, "TA_FLAT_WAVEFRONTS_sum") / max(1.0, waves), 1),
+                      "ta_busy_cycles_per_wavefront": round(ta_busy / max(1.0, ta_waves), 1)})
+        if fam(t["ta2"], f, "TA_BUFFER_TOTAL_CYCLES_sum"):
+            r.update({"ta_buffer_cycles_per_wave": round(fam(t["ta2"], f, "TA_BUFFER_TOTAL_CYCLES_sum") / max(1.0, waves)),
+                      "ta_addr_stalled_by_tc_frac": round(fam(t["ta2"], f, "TA_ADDR_STALLED_BY_TC_CYCLES_sum") / max(1.0, 256 * gui / 8), 4) if gui else None,
+                      "ta_data_stalled_by_tc_frac": round(fam(t["ta2"], f, "TA_DATA_STALLED_BY_TC_CYCLES_sum") / max(1.0, 256 * gui / 8), 4) if gui else None,
+                      "td_busy_frac": round(fam(t["ta2"], f, "TD_TD_BUSY_sum") / max(1.0, 256 * gui / 8), 4) if gui else None})
         row[mode] = r
         if "sweep" in f:
+            step["vmem_rd"] = step.get("vmem_rd", 0.0) + weight * fam(t["sq2"], f, "SQ_INSTS_VMEM_RD")
+            step["ta_busy"] = step.get("ta_busy", 0.0) + weight * ta_busy; step["gui"] = step.get("gui", 0.0) + weight * gui
             step["fetch"] += weight * fb; step["write"] += weight * wb; step["profiled"] += n
             step["valu_active"] += weight * 4 * fam(t["sq1"], f, "SQ_ACTIVE_INST_VALU"); step["valu_insts"] += weight * fam(t["sq1"], f, "SQ_INSTS_VALU")
             step["waves"] += weight * waves; step["wave_cycles"] += weight * 4 * wc
@@ -103,5 +119,10 @@ res["valu"] = {"valu_active_cycles_per_step": round(step["valu_active"]), "wave_
                "cycles_per_valu_inst": round(step["valu_active"] / max(1.0, step["valu_insts"]), 2),
                "wave_cycle_shares": {"issuing": round(1.0 - (step["wait_inst"] + step["wait_any"]) / max(1.0, step["wave_cycles"]), 4), "issue_stall": round(step["wait_inst"] / max(1.0, step["wave_cycles"]), 4),
                                      "parked_on_waitcnt": round(step["wait_any"] / max(1.0, step["wave_cycles"]), 4)}}
+# the bound the sweeps run against: vector-memory wave-loads through the texture-address units, 64 cycles each when scattered (probe), one unit per CU
+res["gather"] = {"vmem_rd_wave_loads_per_step": round(step.get("vmem_rd", 0.0)), "vmem_rd_wave_loads_per_wave_visit": round(step.get("vmem_rd", 0.0) / max(1.0, step["waves"]), 1),
+                 "cycles_per_scattered_wave_load": 64.5, "texture_address_units": 256,
+                 "ta_busy_frac_of_the_slice": round(step.get("ta_busy", 0.0) / max(1.0, 256 * step.get("gui", 0.0) / 8), 4) if step.get("gui") else None,
+                 "note": "cycles_per_scattered_wave_load: tools/probes/l1_gather.hip (profiles/r06_call10/l1_gather.log): 64.5 cycles at 2.4 GHz for a wave-load whose quads of lanes touch four different 64-byte blocks, at 4, 8 or 16 bytes per lane; 17 when every quad stays inside one block"}
 json.dump(res, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-print(json.dumps({"sweeps": res["sweeps"], "valu": res["valu"], "families": {k: {q: v.get(q) for q in ("dispatches", "frac_active_valu", "valu_busy_of_simd_cycles", "l2_hit_rate", "l1_hit_rate", "valu_insts_per_wave")} for k, v in res["families"].items()}}, indent=1))
+print(json.dumps({"sweeps": res["sweeps"], "valu": res["valu"], "gather": res["gather"], "families": {k: {q: v.get(q) for q in ("dispatches", "frac_active_valu", "valu_busy_of_simd_cycles", "ta_busy_frac", "vmem_rd_insts_per_wave", "ta_busy_cycles_per_wavefront", "l2_hit_rate", "l1_hit_rate", "valu_insts_per_wave")} for k, v in res["families"].items()}}, indent=1))

@@ -624,7 +624,7 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 		case 1: {
 			// pass A: ScoreDepthMapTmp, row-major pixels.  (Round 4, 24 views resident: the pass was latency-bound, and the same evaluation on anti-diagonals with the sweep's optimistic
 			// quad rows was 9 % SLOWER -- the maps are row-major, and a wave that walks a diagonal reads and writes them one cache line per lane:
-			// profiles/r04_call14_diagonal_init_kernel_stats.csv.  Round 6, 100 views resident: bound by VALU issue; row-major pixels WITH the optimistic quad rows: +0.8 %.)
+			// profiles/r04_call14_diagonal_init_kernel_stats.csv.  Round 6, 100 views resident: bound by VALU issue (0.89 busy); row-major pixels WITH the optimistic quad rows: +0.8 %.)
 			const uint32_t passInit = (uint32_t)l * 64u + 32u + (geo ? 16u + (uint32_t)nGeometricIter : 0u);
 			const size_t ev = evBeginOn(e, 1, st);
 			// (optimistic rows from the level's quad buffer; the guarded rows from the row-major images for batches that read source views outside that buffer)

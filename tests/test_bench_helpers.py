@@ -49,5 +49,7 @@ def test_roofline_fields_from_the_counter_file():
     assert tf["traffic_measurement"]["dispatches"] == 43126                      # the benchmark's sweep launches per step (two view groups)
     v = b.valu_issue_fields(4.1, 1, 100 * 1920 * 1080 * 12)                      # live SQ sums of both kernel families of the slice, this run's wall time
     assert 0.4 < v["valu_issue"]["valu_busy_frac"] < 1.0 and "EXTRAPOLATION" not in v["valu_issue"]["note"]
+    g = b.gather_issue_fields(3.8, 1)["gather_issue"]                            # the unit the sweeps run into: vector-memory wave-loads of a step against 256 units x one scattered wave-load per 64.5 cycles
+    assert 0.5 < g["frac"] < 1.05 and 400 <= g["wave_loads_per_wave_visit"] < 520 and abs(g["peak"] - 256 * 2.4 / 64.5) < 0.01
     assert b.sweep_kernel_name(100, 8) == "pm_sweep2_kernel" and b.sweep_kernel_name(13, 8).startswith("pm_sweep_widen_kernel") and b.sweep_kernel_name(1, 8) == "pm_sweep_wide_kernel"
     assert b.usable_cores() >= 1

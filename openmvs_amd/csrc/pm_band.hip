@@ -241,7 +241,7 @@ __device__ __forceinline__ void pm_visit(const PMTask& t, const PMKParams& kp, c
 			for (int u = 0; u < VPL; ++u) {
 				const int vw = v + u * G;
 				if (need && vw < t.nSrc) {
-					const float s1 = pm_score_view<GEO, BUF ? 2 : 1, true>(t.src[vw], t, kp, P->x, P->y, P->X0x, P->X0y, P->normSq0, P->sumW, s_wg, hd, hnx, hny, hnz, sf0, sf1, sf2, sf3, 0.f,
+					const float s1 = pm_score_view<GEO, BUF ? 2 : 1, true, true>(t.src[vw], t, kp, P->x, P->y, P->X0x, P->X0y, P->normSq0, P->sumW, s_wg, hd, hnx, hny, hnz, sf0, sf1, sf2, sf3, 0.f,
 						hotBase + vw * NBD, hotBase + vw * NBD + PM_SRC_HOT, rs PM_PROF_PASS, (const double*)P->hr);
 					if (s1 < sc) { sc2 = sc; sc = s1; } else if (s1 < sc2) sc2 = s1;
 				}

@@ -495,7 +495,9 @@ __device__ __forceinline__ void pm_taps_fast(const PMImgBuf& rs, unsigned qbase,
 // visit by the sweep kernels) instead of in two registers that are live across the whole hypothesis loop.
 // hot / geoTab: the hot and geometric blocks of `s` (PMSrcView), in HBM (init kernel) or in the wave's LDS copy (sweep kernels); the image size and the view's
 // first entry in the level's quad buffer travel with the homography entries.
-template <bool GEO, int MODE, bool PF = false>
+// EARLY: test two opposite corner taps before any load (pm_sweep2_kernel, whose launches fill the GPU and run into the texture-address unit; the speculative kernels of the
+// short launches are bound by a visit's dependent chain, where the test's two extra divisions cost 3 %: profiles/r06_call13/ab_13.log)
+template <bool GEO, int MODE, bool PF = false, bool EARLY = false>
 __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask& t, const PMKParams& kp,
 		int x, int y, double X0x, double X0y, float normSq0, float sumW, const float2* wts,
 		float depth, float nx, float ny, float nz,
@@ -525,6 +527,23 @@ __device__ __forceinline__ float pm_score_view(const PMSrcView& s, const PMTask&
 		// |x|, |y| < 1e18 and |z| < 2^40 for every tap of the patch, from the first tap and the step sizes (8 steps along either axis at most)
 		const bool sane = pm_fabsf(X0) + 8.f * (pm_fabsf(H[0]) + pm_fabsf(H[1])) < 5e17f && pm_fabsf(X1) + 8.f * (pm_fabsf(H[3]) + pm_fabsf(H[4])) < 5e17f
 			&& pm_fabsf(X2) + 8.f * (pm_fabsf(H[6]) + pm_fabsf(H[7])) < 5e11f;
+		// Two opposite corner taps first, without loads: the texture-address unit, which bounds the sweep kernels, is paid by the active lane, and a source view
+		// that does not see the pixel at all -- a fifth of the (pixel, view) pairs of the benchmark's grid of cameras -- would otherwise gather all 25 samples for nothing.
+		// Tap (0,0) is the reference's first tap and tap (4,4) its last; their positions are formed by the very additions the rows below perform (four row steps, then four tap
+		// steps), and with z inside [2^-40, 2^40] and sane start values the quotient is the IEEE one (pm_div2_inrange): if either lies outside the image the reference has
+		// returned thRobust at that tap at the latest (DepthMap.cpp:484-485), whatever the other taps do.  A corner whose z is out of range decides nothing here.
+		if (EARLY && sane) {
+			bool outside = false;
+			float cx, cy;
+			if (bX2 >= 9.094947e-13f && bX2 <= 1.0995116e12f) { pm_div2_inrange(bX0, bX1, bX2, &cx, &cy); outside = !pm_inside1(cx, cy, sw, sh); }
+			float c0 = bX0, c1 = bX1, c2 = bX2;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) { c0 += H[1]; c1 += H[4]; c2 += H[7]; }
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { c0 += H[0]; c1 += H[3]; c2 += H[6]; }
+			if (c2 >= 9.094947e-13f && c2 <= 1.0995116e12f) { pm_div2_inrange(c0, c1, c2, &cx, &cy); outside = outside || !pm_inside1(cx, cy, sw, sh); }
+			if (outside) return kp.thRobust;
+		}
 		const unsigned qbase = ((const unsigned*)(hot + 13))[0];
 		const pm_gcf4 imgQ = pm_glob4(s.imgQ);
 		const float rX0 = bX0, rX1 = bX1, rX2 = bX2;

@@ -281,6 +281,9 @@ __global__ __launch_bounds__(256, SGM_PX_WAVES) void sgm_cost_px_kernel(const un
 #ifndef SGM_UNI_WAVES
 #define SGM_UNI_WAVES 3
 #endif
+#ifndef SGM_UNI_PAIR
+#define SGM_UNI_PAIR 1     // two disparities per trip of the cost loop (0: one)
+#endif
 template <int MD>   // nD <= MD: sizes the strip
 __global__ __launch_bounds__(256, SGM_UNI_WAVES) void sgm_cost_uni_kernel(const unsigned char* __restrict__ colorL, const float* __restrict__ grayL,
 		const float* __restrict__ grayR, int w, int h, int vw, int vh, int minDisp, int nDall, unsigned char* __restrict__ costs) {
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256, SGM_UNI_WAVES) void sgm_cost_uni_kernel(const 
 	const int ux = (have ? col : vw - 1) + SGM_HW, uy = row + SGM_HW;
 	// the strip: columns cb .. cb + 64 + nD + 5 of rows uy-3 .. uy+3 (clamped into the image; a clamped column only feeds costs that are 255 anyway)
 	const int cb = col0 + SGM_HW + minDisp - SGM_HW;
-	for (int c = lane; c < 64 + nDall + 6; c += 64) {
+	for (int c = lane; c < 64 + nDall + 7; c += 64) {                   // (+1: the pair loop reads one column past an odd range; that cost is never stored)
 		const int cc = cb + c < 0 ? 0 : (cb + c >= w ? w - 1 : cb + c);
 #pragma unroll
 		for (int i = 0; i < 7; ++i) s_r[wave][c * CS + i] = grayR[(size_t)(uy - SGM_HW + i) * w + cc];
@@ -325,6 +328,62 @@ __global__ __launch_bounds__(256, SGM_UNI_WAVES) void sgm_cost_uni_kernel(const 
 	__builtin_amdgcn_wave_barrier();
 	unsigned packed = 0u;
 	const float* strip = &s_r[wave][(have ? lane : vw - 1 - col0) * CS];   // a lane without a pixel repeats the row's last one
+	// one cost byte into the pixel's run of the volume: collected four to a dword
+	auto emit = [&](int k, unsigned c) {
+		if (k < nD) {
+			const unsigned pos = (idxLow + (unsigned)k) & 3u;               // byte of its dword in the volume
+			packed |= c << (8u * pos);
+			if (pos == 3u || k == nD - 1) {
+				unsigned char* at = costs + idx + (unsigned)k;              // address of this (the last collected) byte
+				const unsigned first = (unsigned)k < pos ? pos - (unsigned)k : 0u;   // first byte of the dword that belongs to this pixel
+				if (pos == 3u && first == 0u) *reinterpret_cast<unsigned*>(at - 3) = packed;
+				else for (unsigned bb = first; bb <= pos; ++bb) at[(int)bb - (int)pos] = (unsigned char)(packed >> (8u * bb));
+				packed = 0u;
+			}
+		}
+	};
+#if SGM_UNI_PAIR
+	// TWO disparities per trip: tap (i, j) of disparity k + 1 is tap (i, j + 1) of disparity k, so a row of the pair is eight strip values instead of fourteen -- 56 LDS
+	// reads for two costs instead of 98 (the reads' latency, with three waves per SIMD, is what kept the kernel at two thirds of its issue floor).  Each cost's own taps
+	// in its own order: n = row * 7 + column.
+#pragma unroll 1
+	for (int k = 0; k < nDall; k += 2) {
+		float sumA = 0.f, sumSqA = 0.f, nomA = 0.f, sumB = 0.f, sumSqB = 0.f, nomB = 0.f;
+		const float* sk = strip + k * CS;
+		float fa[8], fb[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) fa[j] = sk[j * CS];
+#pragma unroll
+		for (int r = 0; r < 7; ++r) {
+			float (&cur)[8] = (r & 1) ? fb : fa;
+			float (&nxt)[8] = (r & 1) ? fa : fb;
+			if (r < 6) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) nxt[j] = sk[j * CS + r + 1];
+			}
+			SGM_SCHED_BARRIER();
+#pragma unroll
+			for (int j = 0; j < 7; ++j) {
+				const float f = cur[j];
+				const float fw = f * wk[r * 7 + j];
+				sumA += fw; sumSqA += f * fw; nomA += f * tk[r * 7 + j];
+			}
+			SGM_PIN3(sumA, sumSqA, nomA);
+#pragma unroll
+			for (int j = 0; j < 7; ++j) {
+				const float f = cur[j + 1];
+				const float fw = f * wk[r * 7 + j];
+				sumB += fw; sumSqB += f * fw; nomB += f * tk[r * 7 + j];
+			}
+			SGM_PIN3(sumB, sumSqB, nomB);
+			SGM_SCHED_BARRIER();
+		}
+		const int d = minDisp + k;
+		const bool inA = !(ux - SGM_HW + d < 0 || ux + SGM_HW + d >= w), inB = !(ux - SGM_HW + d + 1 < 0 || ux + SGM_HW + d + 1 >= w);
+		emit(k, inA ? (unsigned)sgm_cost_of(sumA, sumSqA, nomA, sumW, normSq0) : 255u);
+		if (k + 1 < nDall) emit(k + 1, inB ? (unsigned)sgm_cost_of(sumB, sumSqB, nomB, sumW, normSq0) : 255u);
+	}
+#else
 #pragma unroll 1
 	for (int k = 0; k < nDall; ++k) {
 		float sum = 0.f, sumSq = 0.f, nom = 0.f;
@@ -355,19 +414,9 @@ __global__ __launch_bounds__(256, SGM_UNI_WAVES) void sgm_cost_uni_kernel(const 
 		}
 		const int d = minDisp + k;
 		const bool in = !(ux - SGM_HW + d < 0 || ux + SGM_HW + d >= w);
-		const unsigned c = in ? (unsigned)sgm_cost_of(sum, sumSq, nom, sumW, normSq0) : 255u;
-		if (k < nD) {
-			const unsigned pos = (idxLow + (unsigned)k) & 3u;               // byte of its dword in the volume
-			packed |= c << (8u * pos);
-			if (pos == 3u || k == nD - 1) {
-				unsigned char* at = costs + idx + (unsigned)k;              // address of this (the last collected) byte
-				const unsigned first = (unsigned)k < pos ? pos - (unsigned)k : 0u;   // first byte of the dword that belongs to this pixel
-				if (pos == 3u && first == 0u) *reinterpret_cast<unsigned*>(at - 3) = packed;
-				else for (unsigned bb = first; bb <= pos; ++bb) at[(int)bb - (int)pos] = (unsigned char)(packed >> (8u * bb));
-				packed = 0u;
-			}
-		}
+		emit(k, in ? (unsigned)sgm_cost_of(sum, sumSq, nom, sumW, normSq0) : 255u);
 	}
+#endif
 }
 
 // line start sets of one path direction: nA lines from (ax,ay) stepping (adx,ady), then the rest from (bx,by)

@@ -27,6 +27,9 @@
                                          // <= 8000: 48.1, <= 16000: 48.6, <= 24000: 48.6; 50 views: 43.4 against 42.7 with the two-wide kernel everywhere
 #define PMHIP_DEFAULT_WIDE8_PIXELS 0     // ... and of at most this many pixels the eight-wide one (no effect measured at 13 / 100 views: off)
 #endif
+#ifndef PMHIP_WIDE_DIAGONAL
+#define PMHIP_WIDE_DIAGONAL 400   // ... and of at most this many pixels per view of the group
+#endif
 #ifndef PMHIP_DEFAULT_WIDE
 #define PMHIP_DEFAULT_WIDE 32   // batches of at most this many reference views use the speculative kernels: eight hypotheses per round (one wave per pixel) for 1-2 views, two per round
                                 // (four pixels per wave, pm_wide_n.hip) from 3 views on.  Measured in round 4 (profiles/r04_call7_lanes_*.log, full schedule at 1920x1080, Mpix/s;
@@ -646,7 +649,10 @@ static int estimateClass(pmhip_engine* e, const int32_t* ids, int nB, int cw, in
 			const bool tiled = ps.ntx * ps.nty > 1;
 			if (!evOpen[g]) { evSweep[g] = evBeginOn(e, 0, st); evOpen[g] = e->statsOn; }
 			const long npx = (long)perTile * ps.ntx * ps.nty * nT;
-			const bool wide = (wideBatch && !(tiled && npx > e->widePixels)) || (maxSrc <= 8 && npx <= e->widePixels);
+			// larger batches: launches of at most widePixels pixels AND at most PMHIP_WIDE_DIAGONAL pixels per view go to the two-wide kernel (round 6: 100 views in two groups are
+			// best at 17-20 000 pixels, 50 views at <= 10 000 -- the same ~400 pixels of diagonal per view: profiles/r06_call18, r06_call19)
+			const long wpx = tiled ? (long)e->widePixels : std::min<long>(e->widePixels, (long)PMHIP_WIDE_DIAGONAL * nT);
+			const bool wide = (wideBatch && !(tiled && npx > e->widePixels)) || (maxSrc <= 8 && npx <= wpx);
 			int hyps = (wideBatch && e->wideHyps > 0) ? e->wideHyps : ((nB <= 2 || npx <= e->wide8Pixels) ? 8 : 2);
 			if (tiled && hyps == 8) hyps = 2;   // (the eight-wide kernel walks whole anti-diagonals of the map)
 			++nLaunched;

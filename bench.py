@@ -288,6 +288,9 @@ def main():
         issue = valu_issue_fields(wall_s, a.steps, st.sweepPixels) if same_cfg else {}
         if same_cfg:
             issue.update(gather_issue_fields(wall_s, a.steps))
+            if "gather_issue" in issue:     # (the contract's `bound` stays "hbm"; what the kernels actually run into is named beside it)
+                issue["bound_measured"] = "texture-address units in front of the vector L1 (scattered wave-loads): gather_issue.frac %.2f; VALU issue beside it: valu_issue.valu_busy_frac %.2f; HBM is not the bound (frac %.4f of its peak on algorithmic bytes)" % (
+                    issue["gather_issue"]["frac"], issue.get("valu_issue", {}).get("valu_busy_frac", float("nan")), achieved / HBM_PEAK_GBS)
         tf = traffic_fields(per_launch) if same_cfg else {"traffic": None, "traffic_note": "counters exist for the 100-view 1920x1080 one-GPU configuration only"}
         if "fabric_bytes_per_step" in tf.get("traffic_measurement", {}):   # the fabric-side rate of THIS run: counter bytes of a step / this run's wall time of the passes per step
             tf["traffic_measurement"]["fabric_rate_gbs_this_run"] = round(tf["traffic_measurement"]["fabric_bytes_per_step"] * a.steps / 1e9 / max(wall_s, 1e-12), 1)

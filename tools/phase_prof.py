@@ -19,10 +19,11 @@ for rep in range(2):
     hist = (ctypes.c_ulonglong * 17)()
     if hasattr(e._lib, 'pmhip_prof_hist'): e._lib.pmhip_prof_hist(e._h, hist, 1)
 names = ["-", "hyp-gen", "smooth", "homography", "taps", "epilogue", "aggr+accept"]
-tot = (sum(c[1:7]) + c[12]) or 1
+tot = (sum(c[0:7]) + c[12]) or 1
 print(os.environ.get("PMHIP_LIB", "default"), "views", len(ids), "of", views, "%.2f s -> %.2f Mpix/s" % (dt, len(ids) * 1920 * 1080 / dt / 1e6))
 print("  wave-visits %d, cycles per wave-visit %.0f (s_memtime), hypotheses x active lanes per wave-visit %.1f" % (c[9], tot / max(1, c[9]), c[8] / max(1, c[9])))
 print("  %-12s %5.1f %%   %8.0f cycles/wave-visit" % ("head", 100.0 * c[12] / tot, c[12] / max(1, c[9])))
+print("  %-12s %5.1f %%   %8.0f cycles/wave-visit   (the speculative kernels' whole head; pm_sweep2_kernel: window staging, unused)" % ("setup", 100.0 * c[0] / tot, c[0] / max(1, c[9])))
 for i, n in enumerate(names):
     if i: print("  %-12s %5.1f %%   %8.0f cycles/wave-visit" % (n, 100.0 * c[i] / tot, c[i] / max(1, c[9])))
 if sum(hist):

@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--wide-pixels", type=int, default=0, help="PMHipTuning::widePixels (0 = the engine's default)")
     ap.add_argument("--wide-max-views", type=int, default=0, help="PMHipTuning::wideMaxViews (0 = the engine's default)")
     ap.add_argument("--wide-hyps", type=int, default=0, help="PMHipTuning::wideHyps (0 = the engine's default)")
+    ap.add_argument("--wide8-pixels", type=int, default=0, help="PMHipTuning::wide8Pixels (0 = the engine's default)")
     ap.add_argument("--tiles", type=int, default=0, help="OPT-IN estimator mode, not the reference's sweep: tiled sweeps with tiles of this many pixels (pmhip_set_sweep_tiles); the line says so")
     ap.add_argument("--no-tiled-leg", action="store_true", help="skip the tiled-sweeps leg (the opt-in mode's rates at the full batch and at the shard sizes)")
     return ap.parse_args()
@@ -160,8 +161,8 @@ def main():
     del gray
     eng = PatchMatchHIP(local)
     eng.Init(True)
-    if a.groups or a.lanes or a.wide_pixels or a.wide_max_views or a.wide_hyps:
-        eng.tuning(viewGroups=a.groups, sweepLanes=a.lanes, wideMaxViews=a.wide_max_views, widePixels=a.wide_pixels, wideHyps=a.wide_hyps)
+    if a.groups or a.lanes or a.wide_pixels or a.wide_max_views or a.wide_hyps or a.wide8_pixels:
+        eng.tuning(viewGroups=a.groups, sweepLanes=a.lanes, wideMaxViews=a.wide_max_views, widePixels=a.wide_pixels, wideHyps=a.wide_hyps, wide8Pixels=a.wide8_pixels)
     if a.tiles:
         eng.set_sweep_tiles(a.tiles, a.tiles)                # OPT-IN estimator mode (the line's config says so): not the reference's sweep order
     eng.scene_create(max(2, len(held)), W, H, 2)
